@@ -1,0 +1,267 @@
+#!/usr/bin/env python
+"""bench.py -- fwd+bwd renders/sec of the rasterizer hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2|cfg3|cfg1] [--no-cpu-baseline]
+
+One "step" = one fused render of one camera: frustum cull + EWA projection + 16x16 tile
+binning with per-tile depth sort + SH(degree 3) front-to-back compositing, then the backward
+pass to mean[N,3], qvec[N,4], svec[N,3], alpha[N], sh[N,3,16] for a dense random grad_out
+(SURVEY.md 8d).  Workload at N=1: BASELINE.json configs[1] -- 100k Gaussians ("Point-E init"
+cloud), 800x800, SH degree 3.  Inputs are resident in HBM before the timed region.  With
+--gpus N each rank renders its own cameras (camera sharding, weak scaling) and the rendered
+images are all-gathered over RCCL each step (north_star: "RCCL only to gather rendered
+images").  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def make_workload(name):
+    import scenes
+    if name == "cfg2":
+        sc = scenes.pointe_scene(100_000, seed=0, svec=0.02, C=4)
+        W = H = 800
+    elif name == "cfg3":
+        sc = scenes.densified_scene(500_000, seed=0, C=4)
+        W = H = 1024
+    elif name == "cfg1":
+        sc = scenes.random_scene(1000, seed=0, C=1)
+        W = H = 256
+    else:
+        raise SystemExit(f"unknown config {name}")
+    return sc, W, H
+
+
+def camera_poses(n, rank, W, H):
+    import scenes
+    cams = []
+    for i in range(n):
+        az = 30.0 + 45.0 * i + 7.0 * rank
+        cams.append(scenes.Camera(W, H, fx=float(W), c2w=scenes.orbit(2.5, 15.0, az)))
+    return cams
+
+
+def b_alg_bytes(N, D, P, T, F):
+    """SURVEY.md 8(d) algorithmic bytes per fwd+bwd render, and the per-kernel split."""
+    parts = {
+        "project_fwd": 88 * N,
+        "bin_sort": 36 * D + 8 * T,
+        "composite_fwd": (4 + 4 * F) * D + 16 * P,
+        "composite_bwd": (4 + 4 * F) * D + 28 * P + 4 * F * D,
+        "project_bwd": 108 * N,
+    }
+    return sum(parts.values()), parts
+
+
+def cpu_baseline(sc, cams, C, budget_s=20.0):
+    """The CPU oracle (a port: the reference has no CPU rasteriser) timed on this box's cores
+    on a bounded sample of the same workload: whole renders of the bench cameras until
+    ~budget_s is spent (at least one)."""
+    import scenes
+    from oracle import oracle as O
+    go = None
+    n, t0 = 0, time.perf_counter()
+    while True:
+        cam = cams[n % len(cams)]
+        g = scenes.oracle_geometry(sc, cam)
+        m = g["mask"]
+        rot = cam.c2w[:3, :3].reshape(-1)
+        bg = np.array([0.1, 0.2, 0.3], np.float32)
+        out = O.render_sh_fwd(g["mean2d"], g["cov2d"], sc["sh"][m], sc["alpha"][m], g["start"], g["end"],
+                              g["ids"], cam.topleft, rot, C, 1 / cam.fx, 1 / cam.fy, cam.h, cam.w, bg=bg)
+        if go is None:
+            go = np.random.default_rng(0).normal(size=out.shape).astype(np.float32)
+        gm2, gc2, _, _ = O.render_sh_bwd(g["mean2d"], g["cov2d"], sc["sh"][m], sc["alpha"][m], g["start"],
+                                         g["end"], g["ids"], out, go, cam.topleft, rot, C, 1 / cam.fx,
+                                         1 / cam.fy, cam.h, cam.w)
+        O.project_bwd(sc["mean"][m], sc["qvec"][m], sc["svec"][m], cam.c2w, gm2, gc2, None, True)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s * 0.6 or n >= 8:
+            break
+    return {"value": n / el, "unit": "renders/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{n} whole fwd+bwd renders of the bench workload through oracle/gs_oracle.c "
+                      f"(OpenMP, {os.cpu_count()} threads) in {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="cfg2")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="also time every stage separately")
+    args = ap.parse_args()
+
+    import torch
+    from gsgen_amd import _capi, renderer as R
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    lib = _capi.load()
+    sc, W, H = make_workload(args.config)
+    C = sc["C"]
+    N = sc["mean"].shape[0]
+    cams = camera_poses(8, rank, W, H)
+    ci = R.CameraInfo(*cams[0].intr)
+    nth, ntw = R.n_tiles(H, W)
+    t = {k: torch.tensor(sc[k], device=dev) for k in ("mean", "qvec", "svec", "alpha", "sh")}
+    cam_dev = [torch.from_numpy(ci.pack(c.c2w)).to(dev) for c in cams]
+    rot_dev = [torch.from_numpy(np.ascontiguousarray(c.c2w[:3, :3]).reshape(-1).copy()).to(dev) for c in cams]
+    topleft = torch.from_numpy(cams[0].topleft).to(dev)
+    bg = torch.tensor([0.1, 0.2, 0.3], device=dev)
+    grad_out = torch.randn(H, W, 3, device=dev)
+    buf = R.FrameBuffers(N, W, H, dev)
+    out = torch.empty(H, W, 3, device=dev)
+    CC3 = 3 * C * C
+    gflat = torch.empty(N * (7 + CC3), device=dev)  # mean2d(2) | cov2d(4) | alpha(1) | sh(3*C*C)
+    g_mean2d, g_cov2d = gflat[:2 * N], gflat[2 * N:6 * N]
+    g_alpha, g_sh = gflat[6 * N:7 * N], gflat[7 * N:]
+    g_mean, g_qvec, g_svec = torch.empty(N, 3, device=dev), torch.empty(N, 4, device=dev), torch.empty(N, 3, device=dev)
+    gathered = torch.empty(world, H, W, 3, device=dev) if world > 1 else None
+    p = lambda x: x.data_ptr()  # noqa: E731
+    stream = torch.cuda.current_stream(dev)
+    s = stream.cuda_stream
+    psx, psy = 1.0 / ci.fx, 1.0 / ci.fy
+
+    ev = {}
+
+    def step(i, timed=None):
+        k = i % len(cams)
+        lib.frame_geometry(N, p(t["mean"]), p(t["qvec"]), p(t["svec"]), p(cam_dev[k]), W, H, buf.D_cap,
+                           p(buf.mean2d), p(buf.cov2d), p(buf.depth), p(buf.mask), p(buf.ids), p(buf.start),
+                           p(buf.end), p(buf.total), p(buf.ws), buf.ws.numel(), s)
+        if timed is not None:
+            timed[0].record(stream)
+        lib.vol_render_sh(N, buf.D_cap, p(buf.mean2d), p(buf.cov2d), p(t["sh"]), p(t["alpha"]), p(buf.start),
+                          p(buf.end), p(buf.ids), p(out), p(topleft), p(rot_dev[k]), 16, nth, ntw, psx, psy,
+                          H, W, C, 1e-4, p(bg), None, s)
+        if timed is not None:
+            timed[1].record(stream)
+        gflat.zero_()
+        if timed is not None:
+            timed[2].record(stream)
+        lib.vol_render_backward_sh(N, buf.D_cap, p(buf.mean2d), p(buf.cov2d), p(t["sh"]), p(t["alpha"]),
+                                   p(buf.start), p(buf.end), p(buf.ids), p(out), p(g_mean2d), p(g_cov2d),
+                                   p(g_sh), p(g_alpha), p(grad_out), p(topleft), p(rot_dev[k]), 16, nth, ntw,
+                                   psx, psy, H, W, C, 1e-4, p(bg), s)
+        if timed is not None:
+            timed[3].record(stream)
+        lib.project_gaussians_backward_masked(N, p(t["mean"]), p(t["qvec"]), p(t["svec"]), p(cam_dev[k]), 1,
+                                              p(buf.mask), p(g_mean2d), p(g_cov2d), None, p(g_mean), p(g_qvec),
+                                              p(g_svec), s)
+        if gathered is not None:
+            dist.all_gather_into_tensor(gathered, out)
+
+    # size the pair buffers once, outside the timed region (one sync)
+    for i in range(len(cams)):
+        step(i)
+        torch.cuda.synchronize()
+        buf.ensure_capacity()
+    Ds = []
+    for i in range(len(cams)):
+        step(i)
+        torch.cuda.synchronize()
+        assert buf.ensure_capacity()
+        Ds.append(int(buf.total.item()))
+    n_vis = int(buf.mask.sum().item())
+
+    for i in range(args.warmup):
+        step(i)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # HIP events around the dominant kernel (composite backward) and the forward, every step
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i, evs[i])
+    barrier()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+
+    fwd_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))
+    bwd_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in evs]))
+    D = float(np.mean([Ds[(args.warmup + i) % len(cams)] for i in range(args.steps)]))
+    P, T = W * H, nth * ntw
+    F = 7 + CC3
+    total_b, parts = b_alg_bytes(n_vis, D, P, T, F)
+    value = world * args.steps / el
+    # dominant kernel = composite backward
+    ach = parts["composite_bwd"] / (bwd_ms * 1e-3) / 1e9
+    res = {
+        "metric": "fwd+bwd renders/sec (800x800, 100k Gaussians)" if args.config == "cfg2" else f"fwd+bwd renders/sec ({args.config})",
+        "value": value, "unit": "renders/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": {"cfg2": "BASELINE configs[1]: 100k-Gaussian Point-E-init cloud, 800x800, SH degree 3, fwd+bwd",
+                                "cfg3": "BASELINE configs[2]: 500k post-densify Gaussians, 1024x1024, SH degree 3, fwd+bwd",
+                                "cfg1": "BASELINE configs[0]: 1k random Gaussians, 256x256, SH degree 0"}[args.config],
+                   "gaussians": N, "visible_after_cull": n_vis, "image": [H, W], "sh_degree": C - 1,
+                   "tile_pairs_D": D, "cameras_per_gpu_per_step": 1, "parallelism": f"camera-sharded x{world}",
+                   "gather": "rccl all_gather of rendered images" if world > 1 else "none"},
+        "roofline": {"bound": "hbm", "kernel": f"k_composite_bwd<SH,C={C}>", "achieved": ach, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                     "alg_bytes_per_launch": parts["composite_bwd"], "avg_launch_ms": bwd_ms,
+                     "fwd_kernel_ms": fwd_ms,
+                     "fwd_kernel_GBs": parts["composite_fwd"] / (fwd_ms * 1e-3) / 1e9,
+                     "whole_render_alg_bytes": total_b,
+                     "whole_render_hbm_frac": total_b * (value / world) / (HBM_PEAK_GBS * 1e9)},
+    }
+    if args.breakdown and rank == 0:
+        names = ["geometry+bin+sort", "composite_fwd", "zero_grads", "composite_bwd"]
+        stage_ev = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(20)]
+        for i in range(20):
+            e = stage_ev[i]
+            e[4].record(stream)
+            step(i, e)
+            e[5].record(stream)
+        torch.cuda.synchronize()
+        bd = {"geometry+bin+sort": np.mean([e[4].elapsed_time(e[0]) for e in stage_ev]),
+              "composite_fwd": np.mean([e[0].elapsed_time(e[1]) for e in stage_ev]),
+              "zero_grads": np.mean([e[1].elapsed_time(e[2]) for e in stage_ev]),
+              "composite_bwd": np.mean([e[2].elapsed_time(e[3]) for e in stage_ev]),
+              "project_bwd(+gather)": np.mean([e[3].elapsed_time(e[5]) for e in stage_ev])}
+        res["breakdown_ms"] = {k: float(v) for k, v in bd.items()}
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(sc, cams, C)
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,96 @@
+"""ctypes binding of the C ABI declared in include/gsgen_hip.h.
+
+`load()` opens gsgen_amd/lib/libgsgen_hip.so (built by gsgen_amd.build for gfx950) and fails
+loudly when it is missing -- there is no CPU fallback in this package.  Every wrapper takes
+raw device addresses (ints) so it can be driven from torch tensors (`.data_ptr()`), and
+returns nothing: a non-zero status raises RuntimeError with gsgen_error_string().
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "lib", "libgsgen_hip.so")
+
+u32, f32, vp, i32, sz = C.c_uint32, C.c_float, C.c_void_p, C.c_int, C.c_size_t
+
+# name -> argtypes, in the order of include/gsgen_hip.h
+SIGNATURES = {
+    "gsgen_culling_gaussian_bsphere": [u32, vp, vp, vp, vp, vp, vp, f32, vp],
+    "gsgen_tile_culling_aabb_start_end": [u32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, sz, vp],
+    "gsgen_vol_render_start_end_with_T": [u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, u32,
+                                          f32, f32, u32, u32, f32, vp, vp],
+    "gsgen_vol_render_backward_start_end": [u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                                            vp, vp, u32, u32, u32, f32, f32, u32, u32, f32, vp],
+    "gsgen_vol_render_scalar": [u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, u32, f32, f32,
+                                u32, u32, f32, vp, vp],
+    "gsgen_vol_render_scalar_backward": [u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                                         vp, u32, u32, u32, f32, f32, u32, u32, f32, vp],
+    "gsgen_vol_render_sh": [u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, u32, f32, f32,
+                            u32, u32, u32, f32, vp, vp, vp],
+    "gsgen_vol_render_backward_sh": [u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                                     vp, u32, u32, u32, f32, f32, u32, u32, u32, f32, vp, vp],
+    "gsgen_project_gaussians": [u32, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "gsgen_project_gaussians_backward": [u32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp],
+    "gsgen_project_gaussians_backward_masked": [u32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp],
+    "gsgen_tile_culling_aabb_count": [u32, vp, vp, u32, f32, f32, f32, f32, u32, u32, f32, vp, vp, vp, vp],
+    "gsgen_frame_geometry": [u32, vp, vp, vp, vp, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp],
+}
+SIZE_FUNCS = {
+    "gsgen_tile_culling_workspace_bytes": [u32, u32, u32],
+    "gsgen_frame_workspace_bytes": [u32, u32, u32],
+}
+EXPORTS = sorted(list(SIGNATURES) + list(SIZE_FUNCS) + ["gsgen_version", "gsgen_error_string"])
+
+
+class GsgenError(RuntimeError):
+    pass
+
+
+class Lib:
+    def __init__(self, path=None):
+        path = path or DEFAULT_LIB
+        if not os.path.exists(path):
+            raise ImportError(
+                f"{path} not found: build the HIP extension first (python -m gsgen_amd.build). "
+                "gsgen_amd has no CPU fallback.")
+        self.path = path
+        self.cdll = C.CDLL(path)
+        self.cdll.gsgen_version.restype = C.c_char_p
+        self.cdll.gsgen_error_string.restype = C.c_char_p
+        self.cdll.gsgen_error_string.argtypes = [i32]
+        for name, argt in SIGNATURES.items():
+            fn = getattr(self.cdll, name)
+            fn.argtypes = argt
+            fn.restype = i32
+            setattr(self, name[len("gsgen_"):], self._checked(name, fn))
+        for name, argt in SIZE_FUNCS.items():
+            fn = getattr(self.cdll, name)
+            fn.argtypes = argt
+            fn.restype = sz
+            setattr(self, name[len("gsgen_"):], fn)
+
+    def _checked(self, name, fn):
+        err = self.cdll.gsgen_error_string
+
+        def call(*args):
+            rc = fn(*args)
+            if rc != 0:
+                raise GsgenError(f"{name} failed: {err(rc).decode()} (code {rc})")
+        call.__name__ = name
+        return call
+
+    def version(self):
+        return self.cdll.gsgen_version().decode()
+
+
+_lib = None
+
+
+def load(path=None):
+    """The process-wide library handle (HIP build).  Raises ImportError when not built."""
+    global _lib
+    if path is not None:
+        return Lib(path)
+    if _lib is None:
+        _lib = Lib()
+    return _lib

@@ -1,0 +1,263 @@
+"""Host-side mirror of the reference's `_gs` extension module (gs/src/bindings.cpp:5-82).
+
+Same function names, argument orders, in-place output semantics and error behaviour
+(precondition failure -> RuntimeError, as TORCH_CHECK raises) as the pybind module the
+reference's Python imports (`import _gs as _backend`, gs/renderer.py:20-24), implemented on
+the C ABI of libgsgen_hip.so (include/gsgen_hip.h).  `gsgen_amd.install_as_gs()` registers
+this module as `_gs` in sys.modules so gs/renderer.py and gs/gaussian_splatting.py run
+unmodified.
+
+Differences from the reference, all deliberate:
+  * kernels go to torch's CURRENT stream of the tensors' device (the reference uses the legacy
+    default stream for most entry points) and nothing synchronises the device;
+  * temporaries come from torch's caching allocator instead of cudaMalloc/cudaFree per call;
+  * a HIP failure raises RuntimeError instead of exit().
+There is no CPU path: tensors must live on the GPU and the HIP library must be built.
+"""
+import torch
+
+from . import _capi
+
+__all__ = [
+    "culling_gaussian_bsphere", "tile_culling_aabb_start_end",
+    "tile_based_vol_rendering_start_end", "tile_based_vol_rendering_start_end_with_T",
+    "tile_based_vol_rendering_backward_start_end", "tile_based_vol_rendering_scalar",
+    "tile_based_vol_rendering_scalar_backward", "tile_based_vol_rendering_sh",
+    "tile_based_vol_rendering_backward_sh", "tile_based_vol_rendering_sh_with_bg",
+    "tile_based_vol_rendering_backward_sh_with_bg",
+]
+
+
+# ---- the reference's CHECK_* macros (gs/src/include/common.h:29-54) ---------------------------
+def _check_dc(x, name, dtype, what):
+    if not isinstance(x, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not x.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")
+    if not x.is_contiguous():
+        raise RuntimeError(f"{name} must be a contiguous tensor")
+    if x.dtype != dtype:
+        raise RuntimeError(f"{name} must be {what} tensor")
+
+
+def _f(x, name):
+    _check_dc(x, name, torch.float32, "a floating")
+
+
+def _i(x, name):
+    _check_dc(x, name, torch.int32, "an int")
+
+
+def _b(x, name):
+    _check_dc(x, name, torch.bool, "an bool")
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _p(t):
+    return t.data_ptr() if t is not None else None
+
+
+def culling_gaussian_bsphere(mean, qvec, svec, normal, pts, mask, thresh):
+    """render.h:3 / render.cu:16-44.  mask (bool[N]) is written in place."""
+    for t, n in ((mean, "mean"), (qvec, "qvec"), (svec, "svec"), (normal, "normal"), (pts, "pts")):
+        _f(t, n)
+    _b(mask, "mask")
+    with torch.cuda.device(mean.device):
+        _capi.load().culling_gaussian_bsphere(mean.size(0), _p(mean), _p(qvec), _p(svec), _p(normal),
+                                              _p(pts), _p(mask), float(thresh), _stream(mean))
+
+
+def tile_culling_aabb_start_end(aabb_topleft, aabb_bottomright, gaussian_ids, start, end, depth,
+                                n_tiles_h, n_tiles_w):
+    """render.h:61 / render.cu:381-398.  gaussian_ids [D], start/end [T] are written in place
+    (start/end = -1 for empty tiles)."""
+    _i(aabb_topleft, "aabb_topleft"); _i(aabb_bottomright, "aabb_bottomright")
+    _i(gaussian_ids, "gaussian_ids"); _i(start, "start"); _i(end, "end")
+    _f(depth, "depth")
+    N, D = aabb_topleft.size(0), gaussian_ids.size(0)
+    lib = _capi.load()
+    with torch.cuda.device(depth.device):
+        nbytes = lib.tile_culling_workspace_bytes(N, D, int(n_tiles_h) * int(n_tiles_w))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=depth.device)
+        lib.tile_culling_aabb_start_end(N, D, int(n_tiles_h), int(n_tiles_w), _p(aabb_topleft),
+                                        _p(aabb_bottomright), _p(depth), _p(gaussian_ids), _p(start),
+                                        _p(end), _p(ws), nbytes, _stream(depth))
+        ws.record_stream(torch.cuda.current_stream(depth.device))
+
+
+def _fwd_common(mean, cov, col, alpha, start, end, gaussian_ids, out, topleft, colname):
+    _f(mean, "mean"); _f(cov, "cov"); _f(col, colname); _f(alpha, "alpha")
+    _i(start, "start"); _i(end, "end"); _i(gaussian_ids, "gaussian_ids")
+    _f(out, "out"); _f(topleft, "topleft")
+
+
+def tile_based_vol_rendering_start_end_with_T(mean, cov, color, alpha, start, end, gaussian_ids, out,
+                                              topleft, tile_size, n_tiles_h, n_tiles_w, pixel_size_x,
+                                              pixel_size_y, H, W, thresh, T):
+    """render.h:149 / render.cu:989-1012.  out [H,W,3] (pre-zeroed) and T [H,W,1] (pre-set to 1)
+    are written in place."""
+    _fwd_common(mean, cov, color, alpha, start, end, gaussian_ids, out, topleft, "color")
+    _f(T, "T")
+    with torch.cuda.device(mean.device):
+        _capi.load().vol_render_start_end_with_T(
+            mean.size(0), gaussian_ids.size(0), _p(mean), _p(cov), _p(color), _p(alpha), _p(start),
+            _p(end), _p(gaussian_ids), _p(out), _p(topleft), int(tile_size), int(n_tiles_h),
+            int(n_tiles_w), float(pixel_size_x), float(pixel_size_y), int(H), int(W), float(thresh),
+            _p(T), _stream(mean))
+
+
+def tile_based_vol_rendering_start_end(mean, cov, color, alpha, start, end, gaussian_ids, out, topleft,
+                                       tile_size, n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H,
+                                       W, thresh):
+    """render.h:65 / render.cu:400-424 (no T output)."""
+    _fwd_common(mean, cov, color, alpha, start, end, gaussian_ids, out, topleft, "color")
+    with torch.cuda.device(mean.device):
+        _capi.load().vol_render_start_end_with_T(
+            mean.size(0), gaussian_ids.size(0), _p(mean), _p(cov), _p(color), _p(alpha), _p(start),
+            _p(end), _p(gaussian_ids), _p(out), _p(topleft), int(tile_size), int(n_tiles_h),
+            int(n_tiles_w), float(pixel_size_x), float(pixel_size_y), int(H), int(W), float(thresh),
+            None, _stream(mean))
+
+
+def tile_based_vol_rendering_backward_start_end(mean, cov, color, alpha, start, end, gaussian_ids, out,
+                                                grad_mean, grad_cov, grad_color, grad_alpha, grad_out,
+                                                topleft, tile_size, n_tiles_h, n_tiles_w, pixel_size_x,
+                                                pixel_size_y, H, W, thresh):
+    """render.h:73 / render.cu:426-482.  Accumulates into the (caller-zeroed) grad_* tensors."""
+    _fwd_common(mean, cov, color, alpha, start, end, gaussian_ids, out, topleft, "color")
+    for t, n in ((grad_mean, "grad_mean"), (grad_cov, "grad_cov"), (grad_color, "grad_color"),
+                 (grad_alpha, "grad_alpha"), (grad_out, "grad_out")):
+        _f(t, n)
+    with torch.cuda.device(mean.device):
+        _capi.load().vol_render_backward_start_end(
+            mean.size(0), gaussian_ids.size(0), _p(mean), _p(cov), _p(color), _p(alpha), _p(start),
+            _p(end), _p(gaussian_ids), _p(out), _p(grad_mean), _p(grad_cov), _p(grad_color),
+            _p(grad_alpha), _p(grad_out), _p(topleft), int(tile_size), int(n_tiles_h), int(n_tiles_w),
+            float(pixel_size_x), float(pixel_size_y), int(H), int(W), float(thresh), _stream(mean))
+
+
+def tile_based_vol_rendering_scalar(mean, cov, scalar, alpha, start, end, gaussian_ids, out, topleft,
+                                    tile_size, n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H, W,
+                                    thresh, T):
+    """render.h:131 / render.cu:928-954."""
+    _fwd_common(mean, cov, scalar, alpha, start, end, gaussian_ids, out, topleft, "scalar")
+    _f(T, "T")
+    with torch.cuda.device(mean.device):
+        _capi.load().vol_render_scalar(
+            mean.size(0), gaussian_ids.size(0), _p(mean), _p(cov), _p(scalar), _p(alpha), _p(start),
+            _p(end), _p(gaussian_ids), _p(out), _p(topleft), int(tile_size), int(n_tiles_h),
+            int(n_tiles_w), float(pixel_size_x), float(pixel_size_y), int(H), int(W), float(thresh),
+            _p(T), _stream(mean))
+
+
+def tile_based_vol_rendering_scalar_backward(mean, cov, scalar, alpha, start, end, gaussian_ids, out,
+                                             grad_mean, grad_cov, grad_scalar, grad_alpha, grad_out,
+                                             topleft, tile_size, n_tiles_h, n_tiles_w, pixel_size_x,
+                                             pixel_size_y, H, W, thresh):
+    """render.h:139 / render.cu:956-987."""
+    _fwd_common(mean, cov, scalar, alpha, start, end, gaussian_ids, out, topleft, "scalar")
+    for t, n in ((grad_mean, "grad_mean"), (grad_cov, "grad_cov"), (grad_scalar, "grad_scalar"),
+                 (grad_alpha, "grad_alpha"), (grad_out, "grad_out")):
+        _f(t, n)
+    with torch.cuda.device(mean.device):
+        _capi.load().vol_render_scalar_backward(
+            mean.size(0), gaussian_ids.size(0), _p(mean), _p(cov), _p(scalar), _p(alpha), _p(start),
+            _p(end), _p(gaussian_ids), _p(out), _p(grad_mean), _p(grad_cov), _p(grad_scalar),
+            _p(grad_alpha), _p(grad_out), _p(topleft), int(tile_size), int(n_tiles_h), int(n_tiles_w),
+            float(pixel_size_x), float(pixel_size_y), int(H), int(W), float(thresh), _stream(mean))
+
+
+def _sh_fwd(mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out, topleft, c2w, tile_size,
+            n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H, W, C, thresh, bg_rgb):
+    _fwd_common(mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out, topleft, "sh_coeffs")
+    _f(c2w, "c2w")
+    if bg_rgb is not None:
+        _f(bg_rgb, "bg_rgb")
+    if int(C) < 1 or int(C) > 4:
+        return  # the reference's switch silently does nothing (render.cu:507-544)
+    with torch.cuda.device(mean.device):
+        _capi.load().vol_render_sh(
+            mean.size(0), gaussian_ids.size(0), _p(mean), _p(cov), _p(sh_coeffs), _p(alpha), _p(start),
+            _p(end), _p(gaussian_ids), _p(out), _p(topleft), _p(c2w), int(tile_size), int(n_tiles_h),
+            int(n_tiles_w), float(pixel_size_x), float(pixel_size_y), int(H), int(W), int(C),
+            float(thresh), _p(bg_rgb), None, _stream(mean))
+
+
+def _sh_bwd(mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out, grad_mean, grad_cov,
+            grad_sh_coeffs, grad_alpha, grad_out, topleft, c2w, tile_size, n_tiles_h, n_tiles_w,
+            pixel_size_x, pixel_size_y, H, W, C, thresh, bg_rgb):
+    _fwd_common(mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out, topleft, "sh_coeffs")
+    _f(c2w, "c2w")
+    for t, n in ((grad_mean, "grad_mean"), (grad_cov, "grad_cov"), (grad_sh_coeffs, "grad_sh_coeffs"),
+                 (grad_alpha, "grad_alpha"), (grad_out, "grad_out")):
+        _f(t, n)
+    if bg_rgb is not None:
+        _f(bg_rgb, "bg_rgb")
+    if int(C) < 1 or int(C) > 4:
+        return
+    with torch.cuda.device(mean.device):
+        _capi.load().vol_render_backward_sh(
+            mean.size(0), gaussian_ids.size(0), _p(mean), _p(cov), _p(sh_coeffs), _p(alpha), _p(start),
+            _p(end), _p(gaussian_ids), _p(out), _p(grad_mean), _p(grad_cov), _p(grad_sh_coeffs),
+            _p(grad_alpha), _p(grad_out), _p(topleft), _p(c2w), int(tile_size), int(n_tiles_h),
+            int(n_tiles_w), float(pixel_size_x), float(pixel_size_y), int(H), int(W), int(C),
+            float(thresh), _p(bg_rgb), _stream(mean))
+
+
+def tile_based_vol_rendering_sh(mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out, topleft,
+                                c2w, tile_size, n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H,
+                                W, C, thresh):
+    """render.h:83 / render.cu:484-545.  out [H*W*3] pre-zeroed, written in place."""
+    _sh_fwd(mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out, topleft, c2w, tile_size,
+            n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H, W, C, thresh, None)
+
+
+def tile_based_vol_rendering_backward_sh(mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out,
+                                         grad_mean, grad_cov, grad_sh_coeffs, grad_alpha, grad_out,
+                                         topleft, c2w, tile_size, n_tiles_h, n_tiles_w, pixel_size_x,
+                                         pixel_size_y, H, W, C, thresh):
+    """render.h:91 / render.cu:547-625."""
+    _sh_bwd(mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out, grad_mean, grad_cov,
+            grad_sh_coeffs, grad_alpha, grad_out, topleft, c2w, tile_size, n_tiles_h, n_tiles_w,
+            pixel_size_x, pixel_size_y, H, W, C, thresh, None)
+
+
+def tile_based_vol_rendering_sh_with_bg(mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out,
+                                        topleft, c2w, tile_size, n_tiles_h, n_tiles_w, pixel_size_x,
+                                        pixel_size_y, H, W, C, thresh, bg_rgb):
+    """render.h:113 / render.cu:781-845."""
+    _sh_fwd(mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out, topleft, c2w, tile_size,
+            n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H, W, C, thresh, bg_rgb)
+
+
+def tile_based_vol_rendering_backward_sh_with_bg(mean, cov, sh_coeffs, alpha, start, end, gaussian_ids,
+                                                 out, grad_mean, grad_cov, grad_sh_coeffs, grad_alpha,
+                                                 grad_out, topleft, c2w, tile_size, n_tiles_h,
+                                                 n_tiles_w, pixel_size_x, pixel_size_y, H, W, C, thresh,
+                                                 bg_rgb):
+    """render.h:121 / render.cu:847-926."""
+    _sh_bwd(mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out, grad_mean, grad_cov,
+            grad_sh_coeffs, grad_alpha, grad_out, topleft, c2w, tile_size, n_tiles_h, n_tiles_w,
+            pixel_size_x, pixel_size_y, H, W, C, thresh, bg_rgb)
+
+
+# ---- legacy / benchmark-only entry points of the reference -------------
+def _legacy(name):
+    def fn(*a, **k):
+        raise NotImplementedError(
+            f"_gs.{name}: legacy entry point of the reference that no live caller uses "
+            "(SURVEY.md 2.2 rows 12-18); not part of the MI355X hot path.")
+    fn.__name__ = name
+    return fn
+
+
+for _n in ("count_num_gaussians_each_tile", "count_num_gaussians_each_tile_bcircle",
+           "prepare_image_sort", "image_sort", "tile_based_vol_rendering",
+           "tile_based_vol_rendering_v1", "tile_based_vol_rendering_v2",
+           "tile_based_vol_rendering_backward", "tile_culling_aabb",
+           "tile_based_vol_rendering_backward_sh_v1", "tile_based_vol_rendering_backward_sh_warp_reduce",
+           "debug_check_tiledepth"):
+    globals()[_n] = _legacy(_n)

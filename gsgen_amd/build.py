@@ -1,0 +1,62 @@
+"""Builds libgsgen_hip.so (the C-ABI HIP library) for gfx950 with hipcc, in-tree.
+
+    python -m gsgen_amd.build            # incremental
+    python -m gsgen_amd.build --force
+
+hipcc cross-compiles without a GPU.  geometry.hip is compiled with -ffp-contract=off (its
+fp32 results must be bit-identical to the reference's torch ops, see the file header); the
+compositing kernels are allowed to contract.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libgsgen_hip.so")
+OBJDIR = os.path.join(HERE, "build")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+
+SOURCES = {
+    "composite.hip": [],
+    "geometry.hip": ["-ffp-contract=off"],
+    "binning.hip": [],
+}
+COMMON = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _newer(src, dst, extra=()):
+    if not os.path.exists(dst):
+        return True
+    t = os.path.getmtime(dst)
+    deps = [src, os.path.join(CSRC, "common.hpp"),
+            os.path.join(HERE, "..", "include", "gsgen_hip.h"), __file__, *extra]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False, extra_flags=()):
+    os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(OBJDIR, exist_ok=True)
+    objs, rebuilt = [], False
+    for name, flags in SOURCES.items():
+        src = os.path.join(CSRC, name)
+        obj = os.path.join(OBJDIR, name.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _newer(src, obj):
+            cmd = [HIPCC, *COMMON, *flags, *extra_flags, "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+            rebuilt = True
+    if rebuilt or not os.path.exists(LIB):
+        cmd = [HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

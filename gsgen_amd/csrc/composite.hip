@@ -1,0 +1,722 @@
+// composite.hip -- front-to-back alpha compositing, forward and backward, for gfx950.
+//
+// Replaces (reference paths relative to /root/reference/gs/src/include):
+//   RGB     fwd vol_render.h:994-1062 (+ body :169-265), bwd :866-973 (+ body :318-418)
+//   scalar  fwd vol_render_scalar.h:14-102, bwd :104-234
+//   SH      fwd vol_render_sh.h:97-248 / vol_render_bg.h:12-110,
+//           bwd vol_render_sh.h:268-455 / vol_render_bg.h:131-242, basis shencoder.h:13-62
+//
+// Design (see common.hpp): one workgroup per 16x16 tile, 256/PPL threads, PPL pixels per
+// lane; the tile's depth-sorted Gaussian list is staged 64 records at a time into LDS with
+// coalesced loads (one record's coefficients are contiguous), then every lane walks the
+// staged records with broadcast LDS reads.  Early termination (T < thresh) and the
+// "nobody contributes" skip are wave ballots.  The backward re-walks the list front to back
+// exactly as the reference does (suffix = final - prefix), reduces the per-pixel gradient
+// contributions of a Gaussian across the wave with a register reduce-scatter, and issues
+// ONE vector atomic (<= 55 consecutive floats) per (tile, Gaussian) instead of the
+// reference's one LDS atomic per (pixel, Gaussian, component).
+//
+// Numerics: the per-(pixel, Gaussian) Gaussian is evaluated in fp32 on the fast path (the
+// reference uses fp64 for RGB/scalar, fp32 for SH).  For RGB/scalar the quadratic form is
+// evaluated through a Cholesky factor computed once per staged record in fp64, which keeps
+// the fp32 error at eps*sqrt(cond) instead of eps*cond.  Whenever a*G lands within kGuardTol
+// of the 1/255 skip threshold the value is recomputed with the reference's own arithmetic
+// (fp64 / uncontracted fp32), so the discontinuous decision is the reference's.  Forward and
+// backward share eval code, so the backward's recomputed prefix equals the forward bit for
+// bit (the invariant the reference asserts at vol_render_sh.h:452-454).
+#include "common.hpp"
+#include "../../include/gsgen_hip.h"
+
+namespace gs {
+
+enum : int { MODE_RGB = 0, MODE_SCALAR = 1, MODE_SH = 2 };
+constexpr int kBatch = 64;  // Gaussian records staged per LDS round
+
+struct CompParams {
+  const float *mean, *cov, *col, *alpha;
+  const int *start, *end, *ids;
+  const float *topleft, *rot, *bg;
+  float *out, *T;
+  const float *final_img, *grad_out;
+  float *g_mean, *g_cov, *g_col, *g_alpha;
+  int ntw, nth, H, W;
+  float psx, psy, thresh;
+};
+
+// ---- reference-arithmetic Gaussian evaluations (rare path) ------------------------------
+// kernels.h:195-224
+__device__ __noinline__ float gauss_ref_f64(float mx, float my, float c0f, float c1f, float c2f,
+                                            float c3f, float px, float py) {
+  const double c0 = c0f, c1 = c1f, c2 = c2f, c3 = c3f;
+  const double det = c0 * c3 - c1 * c2;
+  const double x = (double)(px - mx);
+  const double y = (double)(py - my);
+  const double tx = x * c3 - y * c2;
+  const double ty = -x * c1 + y * c0;
+  double radial = tx * x + ty * y;
+  radial /= det;
+  if (radial < 0.0) radial = 1000.0;
+  return (float)exp(-0.5 * radial);
+}
+// kernels.h:172-193, fp32 with every product rounded (the oracle's order)
+__device__ __noinline__ float gauss_ref_f32(float mx, float my, float c0, float c1, float c2,
+                                            float c3, float px, float py) {
+#pragma clang fp contract(off)
+  const float det = c0 * c3 - c1 * c2;
+  const float x = px - mx;
+  const float y = py - my;
+  const float tx = x * c3 - y * c2;
+  const float ty = -x * c1 + y * c0;
+  float radial = tx * x + ty * y;
+  radial = radial / det;
+  if (radial < 0.0f) radial = 1000.0f;
+  return expf(-0.5f * radial);
+}
+
+// real SH basis, bands CB = 1..4 (shencoder.h:13-62)
+template <int CB>
+__device__ __forceinline__ void sh_basis(float x, float y, float z, float (&Y)[CB * CB]) {
+  Y[0] = 0.28209479177387814f;
+  if constexpr (CB >= 2) {
+    Y[1] = -0.48860251190291987f * y;
+    Y[2] = 0.48860251190291987f * z;
+    Y[3] = -0.48860251190291987f * x;
+  }
+  if constexpr (CB >= 3) {
+    const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+    Y[4] = 1.0925484305920792f * xy;
+    Y[5] = -1.0925484305920792f * yz;
+    Y[6] = 0.94617469575755997f * z2 - 0.31539156525251999f;
+    Y[7] = -1.0925484305920792f * xz;
+    Y[8] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2;
+    if constexpr (CB >= 4) {
+      Y[9] = 0.59004358992664352f * y * (-3.0f * x2 + y2);
+      Y[10] = 2.8906114426405538f * xy * z;
+      Y[11] = 0.45704579946446572f * y * (1.0f - 5.0f * z2);
+      Y[12] = 0.3731763325901154f * z * (5.0f * z2 - 3.0f);
+      Y[13] = 0.45704579946446572f * x * (1.0f - 5.0f * z2);
+      Y[14] = 1.4453057213202769f * z * (x2 - y2);
+      Y[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
+    }
+  }
+}
+
+__device__ __forceinline__ float sigmoid_fast(float s) {
+  // 1/(1+exp(-s)) (shencoder.h:4) on v_exp_f32 / v_rcp_f32
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-kLog2e * s));
+}
+
+template <int MODE, int CB>
+struct Traits {
+  static constexpr int CC = CB * CB;
+  static constexpr int NCOL = (MODE == MODE_SH) ? 3 * CC : (MODE == MODE_RGB ? 3 : 1);
+  static constexpr int NCH = (MODE == MODE_SCALAR) ? 1 : 3;
+  // gradient components per Gaussian: mean(2) cov(4, the two off-diagonals carry the same
+  // value) alpha(1) colour/scalar/sh(NCOL)
+  static constexpr int NCOMP = 7 + NCOL;
+  static constexpr int P = NCOMP <= 8 ? 8 : (NCOMP <= 16 ? 16 : (NCOMP <= 32 ? 32 : 64));
+};
+
+// ---- LDS staging ---------------------------------------------------------------------------
+template <int MODE, int CB>
+struct Stage {
+  using TR = Traits<MODE, CB>;
+  float mx[kBatch], my[kBatch], a[kBatch];
+  float c0[kBatch], c1[kBatch], c2[kBatch], c3[kBatch];
+  float p0[kBatch], p1[kBatch], p2[kBatch];  // RGB/scalar: scaled Cholesky factor; SH: p0 = kk, p1 = 1/det
+  int id[kBatch];
+  alignas(16) float col[kBatch * TR::NCOL];
+};
+
+template <int MODE, int CB, int NT>
+__device__ __forceinline__ void stage_batch(Stage<MODE, CB> &S, const CompParams &p, int list_base,
+                                            int nb) {
+  using TR = Traits<MODE, CB>;
+  const int t = (int)threadIdx.x;
+  if (t < kBatch) {
+    int id = 0;
+    float mx = 0.f, my = 0.f, a = 0.f, c0 = 1.f, c1 = 0.f, c2 = 0.f, c3 = 1.f, p0 = 0.f, p1 = 0.f,
+          p2 = 0.f;
+    if (t < nb) {
+      id = p.ids[list_base + t];
+      const float2 m = *reinterpret_cast<const float2 *>(p.mean + 2 * (size_t)id);
+      const float4 c = *reinterpret_cast<const float4 *>(p.cov + 4 * (size_t)id);
+      mx = m.x; my = m.y; c0 = c.x; c1 = c.y; c2 = c.z; c3 = c.w;
+      a = fminf(p.alpha[id], kAlphaClamp);
+      bool ok = finite_f(mx) && finite_f(my) && finite_f(c0) && finite_f(c1) && finite_f(c2) &&
+                finite_f(c3) && finite_f(a);
+      if constexpr (MODE == MODE_SH) {
+        float det;
+        {
+#pragma clang fp contract(off)
+          det = c0 * c3 - c1 * c2;  // fp32 determinant, as kernels.h:179
+        }
+        ok = ok && (det > 0.0f) && finite_f(det);
+        const float inv = 1.0f / (ok ? det : 1.0f);
+        p0 = -0.5f * kLog2e * inv;  // G = exp2(p0 * q), q = d^T adj(S) d
+        p1 = inv;
+      } else {
+        const double d0 = c0, d1 = c1, d2 = c2, d3 = c3;
+        const double det = d0 * d3 - d1 * d2;
+        ok = ok && (det > 0.0) && (d3 > 0.0);
+        const double sdet = ok ? det : 1.0, s3 = ok ? d3 : 1.0;
+        // r = [c3 x^2 - (c1+c2) x y + c0 y^2]/det = u^2 + v^2,
+        // u = l11 x + l21 y, v = l22 y   (Cholesky of the quadratic form)
+        const double qa = s3 / sdet, qb = -0.5 * (d1 + d2) / sdet, qc = d0 / sdet;
+        const double l11 = sqrt(qa), l21 = qb / l11;
+        const double l22s = qc - l21 * l21;
+        ok = ok && (l22s > 0.0);
+        const double l22 = sqrt(ok ? l22s : 1.0);
+        const double sc = 0.84932180028801904;  // sqrt(0.5*log2(e)): G = exp2(-(u^2+v^2))
+        p0 = (float)(l11 * sc); p1 = (float)(l21 * sc); p2 = (float)(l22 * sc);
+        if (!ok) { p0 = 0.f; p1 = 0.f; p2 = 0.f; }
+      }
+      if (!ok) a = 0.0f;  // a degenerate / non-finite record never contributes
+    }
+    S.id[t] = id; S.mx[t] = mx; S.my[t] = my; S.a[t] = a;
+    S.c0[t] = c0; S.c1[t] = c1; S.c2[t] = c2; S.c3[t] = c3;
+    S.p0[t] = p0; S.p1[t] = p1; S.p2[t] = p2;
+  }
+  if constexpr (MODE == MODE_SH) __syncthreads();  // S.id is consumed below by other lanes
+  // colour / scalar / SH coefficients: NCOL contiguous floats per record
+  if constexpr (TR::NCOL % 4 == 0) {
+    constexpr int Q = TR::NCOL / 4;
+    for (int e = t; e < nb * Q; e += NT) {
+      const int g = e / Q, k = e - g * Q;
+      const float4 v = *reinterpret_cast<const float4 *>(p.col + (size_t)S.id[g] * TR::NCOL + 4 * k);
+      *reinterpret_cast<float4 *>(&S.col[g * TR::NCOL + 4 * k]) = v;
+    }
+  } else if constexpr (MODE == MODE_SH) {
+    for (int e = t; e < nb * TR::NCOL; e += NT) {
+      const int g = e / TR::NCOL, k = e - g * TR::NCOL;
+      S.col[e] = p.col[(size_t)S.id[g] * TR::NCOL + k];
+    }
+  } else {
+    if (t < nb) {
+      const int id = S.id[t];  // own record: written by this same thread above
+#pragma unroll
+      for (int k = 0; k < TR::NCOL; ++k) S.col[t * TR::NCOL + k] = p.col[(size_t)id * TR::NCOL + k];
+    }
+  }
+}
+
+// per-Gaussian values broadcast from LDS into registers
+struct GRec {
+  float mx, my, a, c0, c1, c2, c3, p0, p1, p2;
+};
+template <int MODE, int CB>
+__device__ __forceinline__ GRec load_rec(const Stage<MODE, CB> &S, int g) {
+  GRec r;
+  r.mx = S.mx[g]; r.my = S.my[g]; r.a = S.a[g];
+  r.c0 = S.c0[g]; r.c1 = S.c1[g]; r.c2 = S.c2[g]; r.c3 = S.c3[g];
+  r.p0 = S.p0[g]; r.p1 = S.p1[g]; r.p2 = S.p2[g];
+  return r;
+}
+
+// Gaussian value for one pixel.  x = px - mx (shared by the lane's pixels), y = py - my.
+template <int MODE>
+__device__ __forceinline__ float gauss_eval(const GRec &r, float x, float y, float px, float py,
+                                            bool alive) {
+  float G;
+  if constexpr (MODE == MODE_SH) {
+    const float tx = x * r.c3 - y * r.c2;
+    const float ty = y * r.c0 - x * r.c1;
+    const float q = tx * x + ty * y;
+    G = __builtin_amdgcn_exp2f(r.p0 * q);
+    G = (q < 0.0f) ? 0.0f : G;  // kernels.h:186-188: radial < 0 -> exp(-500) == 0
+  } else {
+    const float u = r.p0 * x + r.p1 * y;
+    const float v = r.p2 * y;
+    G = __builtin_amdgcn_exp2f(-(u * u + v * v));
+  }
+  const float ag = r.a * G;
+  if (alive && fabsf(ag - kMinAlpha) <= kMinAlpha * kGuardTol) {
+    // within rounding of the skip threshold: take the reference's arithmetic
+    if constexpr (MODE == MODE_SH)
+      G = gauss_ref_f32(r.mx, r.my, r.c0, r.c1, r.c2, r.c3, px, py);
+    else
+      G = gauss_ref_f64(r.mx, r.my, r.c0, r.c1, r.c2, r.c3, px, py);
+  }
+  return G;
+}
+
+// ============================================================================================
+// forward
+// ============================================================================================
+template <int MODE, int CB, int PPL>
+__global__ void __launch_bounds__(256 / PPL) k_composite_fwd(CompParams p) {
+  using TR = Traits<MODE, CB>;
+  constexpr int NT = 256 / PPL;
+  constexpr int ROWS = NT / 16;
+  constexpr int NCH = TR::NCH;
+  __shared__ Stage<MODE, CB> S;
+
+  const uint32_t tile = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int tx = (int)(tile % (uint32_t)p.ntw), ty = (int)(tile / (uint32_t)p.ntw);
+  const int st = p.start[tile];
+  const int n = (st < 0) ? 0 : (p.end[tile] - st);
+  const int t = (int)threadIdx.x;
+  const int lx = t & 15, ly0 = t >> 4;
+  const int gx = tx * kTile + lx;
+
+  bool valid[PPL];
+  int gy[PPL];
+#pragma unroll
+  for (int j = 0; j < PPL; ++j) {
+    gy[j] = ty * kTile + ly0 + j * ROWS;
+    valid[j] = (gx < p.W) && (gy[j] < p.H);
+  }
+
+  if (n == 0) {  // uniform over the workgroup
+    if (p.bg != nullptr) {  // vol_render_bg.h:34-53: empty tiles show the background
+#pragma unroll
+      for (int j = 0; j < PPL; ++j)
+        if (valid[j]) {
+          float *o = p.out + 3 * ((size_t)gy[j] * p.W + gx);
+          o[0] = p.bg[0]; o[1] = p.bg[1]; o[2] = p.bg[2];
+        }
+    }
+    return;  // otherwise the caller's pre-initialised out / T stand (vol_render.h:1006-1013)
+  }
+
+  const float px = pixel_coord(p.topleft[0], gx, p.psx);
+  float py[PPL];
+#pragma unroll
+  for (int j = 0; j < PPL; ++j) py[j] = pixel_coord(p.topleft[1], gy[j], p.psy);
+
+  // per-pixel SH basis (vol_render_sh.h:48-65, 210-216)
+  float Y[MODE == MODE_SH ? PPL : 1][MODE == MODE_SH ? TR::CC : 1];
+  if constexpr (MODE == MODE_SH) {
+    float R[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = p.rot[i];
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) {
+      float dx = R[0] * px + R[1] * py[j] + R[2];
+      float dy = R[3] * px + R[4] * py[j] + R[5];
+      float dz = R[6] * px + R[7] * py[j] + R[8];
+      const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+      dx /= len; dy /= len; dz /= len;
+      sh_basis<CB>(dx, dy, dz, Y[j]);
+    }
+  }
+
+  float acc[PPL][NCH];
+  float Tr[PPL];
+  bool alive[PPL];
+#pragma unroll
+  for (int j = 0; j < PPL; ++j) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) acc[j][c] = 0.0f;
+    Tr[j] = 1.0f;
+    alive[j] = valid[j];
+  }
+
+  for (int base = 0; base < n; base += kBatch) {
+    const int nb = min(kBatch, n - base);
+    if (base > 0) __syncthreads();  // everyone is done with the previous batch
+    stage_batch<MODE, CB, NT>(S, p, st + base, nb);
+    __syncthreads();
+
+    for (int g = 0; g < nb; ++g) {
+      bool any_alive = false;
+#pragma unroll
+      for (int j = 0; j < PPL; ++j) any_alive |= alive[j];
+      if (__ballot(any_alive) == 0ull) break;  // this wave's 64*PPL pixels are saturated
+
+      const GRec r = load_rec<MODE, CB>(S, g);
+      const float x = px - r.mx;
+      float G[PPL];
+      bool con[PPL];
+      bool any_con = false;
+#pragma unroll
+      for (int j = 0; j < PPL; ++j) {
+        G[j] = gauss_eval<MODE>(r, x, py[j] - r.my, px, py[j], alive[j]);
+        con[j] = alive[j] && !(r.a * G[j] < kMinAlpha);
+        any_con |= con[j];
+      }
+      if (__ballot(any_con) == 0ull) continue;  // nobody in the wave sees this Gaussian
+
+      const float *cg = &S.col[g * TR::NCOL];
+#pragma unroll
+      for (int j = 0; j < PPL; ++j) {
+        if (con[j]) {
+          const float ag = r.a * G[j];
+          const float coeff = (r.a * Tr[j]) * G[j];
+          if constexpr (MODE == MODE_SH) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              float s = 0.0f;
+#pragma unroll
+              for (int k = 0; k < TR::CC; ++k) s += cg[c * TR::CC + k] * Y[j][k];
+              acc[j][c] += coeff * sigmoid_fast(s);
+            }
+          } else {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) acc[j][c] += cg[c] * coeff;
+          }
+          Tr[j] *= (1.0f - ag);
+          alive[j] = !(Tr[j] < p.thresh);
+        }
+      }
+    }
+    bool any_alive = false;
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) any_alive |= alive[j];
+    if (__syncthreads_or((int)any_alive) == 0) break;  // whole tile saturated: stop staging
+  }
+
+#pragma unroll
+  for (int j = 0; j < PPL; ++j) {
+    if (!valid[j]) continue;
+    const size_t pix = (size_t)gy[j] * p.W + gx;
+    if constexpr (MODE == MODE_SCALAR) {
+      p.out[pix] = acc[j][0];
+    } else {
+      float *o = p.out + 3 * pix;
+      if (p.bg != nullptr) {  // vol_render_bg.h:95-100
+        o[0] = acc[j][0] + p.bg[0] * Tr[j];
+        o[1] = acc[j][1] + p.bg[1] * Tr[j];
+        o[2] = acc[j][2] + p.bg[2] * Tr[j];
+      } else {
+        o[0] = acc[j][0]; o[1] = acc[j][1]; o[2] = acc[j][2];
+      }
+    }
+    if (p.T != nullptr) p.T[pix] = Tr[j];
+  }
+}
+
+// ============================================================================================
+// backward
+// ============================================================================================
+template <int MODE, int CB, int PPL>
+__global__ void __launch_bounds__(256 / PPL) k_composite_bwd(CompParams p) {
+  using TR = Traits<MODE, CB>;
+  constexpr int NT = 256 / PPL;
+  constexpr int ROWS = NT / 16;
+  constexpr int NCH = TR::NCH;
+  constexpr int P = TR::P;
+  __shared__ Stage<MODE, CB> S;
+
+  const uint32_t tile = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int tx = (int)(tile % (uint32_t)p.ntw), ty = (int)(tile / (uint32_t)p.ntw);
+  const int st = p.start[tile];
+  const int n = (st < 0) ? 0 : (p.end[tile] - st);
+  if (n == 0) return;
+  const int t = (int)threadIdx.x;
+  const int lane = t & 63;
+  const int lx = t & 15, ly0 = t >> 4;
+  const int gx = tx * kTile + lx;
+
+  bool valid[PPL];
+  int gy[PPL];
+  float py[PPL];
+  const float px = pixel_coord(p.topleft[0], gx, p.psx);
+#pragma unroll
+  for (int j = 0; j < PPL; ++j) {
+    gy[j] = ty * kTile + ly0 + j * ROWS;
+    valid[j] = (gx < p.W) && (gy[j] < p.H);
+    py[j] = pixel_coord(p.topleft[1], gy[j], p.psy);
+  }
+
+  float Y[MODE == MODE_SH ? PPL : 1][MODE == MODE_SH ? TR::CC : 1];
+  if constexpr (MODE == MODE_SH) {
+    float R[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = p.rot[i];
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) {
+      float dx = R[0] * px + R[1] * py[j] + R[2];
+      float dy = R[3] * px + R[4] * py[j] + R[5];
+      float dz = R[6] * px + R[7] * py[j] + R[8];
+      const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+      dx /= len; dy /= len; dz /= len;
+      sh_basis<CB>(dx, dy, dz, Y[j]);
+    }
+  }
+
+  float go[PPL][NCH], fin[PPL][NCH], pre[PPL][NCH], Tr[PPL];
+  bool alive[PPL];
+#pragma unroll
+  for (int j = 0; j < PPL; ++j) {
+    const size_t pix = valid[j] ? ((size_t)gy[j] * p.W + gx) : 0;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      go[j][c] = valid[j] ? p.grad_out[NCH * pix + c] : 0.0f;
+      fin[j][c] = valid[j] ? p.final_img[NCH * pix + c] : 0.0f;
+      pre[j][c] = 0.0f;
+    }
+    Tr[j] = 1.0f;
+    alive[j] = valid[j];
+  }
+
+  for (int base = 0; base < n; base += kBatch) {
+    const int nb = min(kBatch, n - base);
+    if (base > 0) __syncthreads();
+    stage_batch<MODE, CB, NT>(S, p, st + base, nb);
+    __syncthreads();
+
+    for (int g = 0; g < nb; ++g) {
+      bool any_alive = false;
+#pragma unroll
+      for (int j = 0; j < PPL; ++j) any_alive |= alive[j];
+      if (__ballot(any_alive) == 0ull) break;
+
+      const GRec r = load_rec<MODE, CB>(S, g);
+      const float x = px - r.mx;
+      float G[PPL];
+      bool con[PPL];
+      bool any_con = false;
+#pragma unroll
+      for (int j = 0; j < PPL; ++j) {
+        G[j] = gauss_eval<MODE>(r, x, py[j] - r.my, px, py[j], alive[j]);
+        con[j] = alive[j] && !(r.a * G[j] < kMinAlpha);
+        any_con |= con[j];
+      }
+      if (__ballot(any_con) == 0ull) continue;
+
+      // per-lane partial gradient of this Gaussian over the lane's pixels
+      // layout: 0,1 mean | 2 c00 3 c01 4 c10 5 c11 | 6 alpha | 7.. colour/scalar/sh
+      float gr[P];
+#pragma unroll
+      for (int i = 0; i < P; ++i) gr[i] = 0.0f;
+
+      float inv_det;
+      if constexpr (MODE == MODE_SH) {
+        inv_det = r.p1;
+      } else {
+        inv_det = 1.0f / (r.c0 * r.c3 - r.c1 * r.c2);
+      }
+      const float *cg = &S.col[g * TR::NCOL];
+#pragma unroll
+      for (int j = 0; j < PPL; ++j) {
+        if (con[j]) {
+          const float y = py[j] - r.my;
+          const float ag = r.a * G[j];
+          const float coeff = (r.a * Tr[j]) * G[j];
+          const float inv1m = __builtin_amdgcn_rcpf(1.0f - ag);
+          float pAG = 0.0f;
+          if constexpr (MODE == MODE_SH) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              float s = 0.0f;
+#pragma unroll
+              for (int k = 0; k < TR::CC; ++k) s += cg[c * TR::CC + k] * Y[j][k];
+              const float yv = sigmoid_fast(s);
+              pre[j][c] += coeff * yv;
+              const float gs = coeff * (yv * (1.0f - yv)) * go[j][c];
+#pragma unroll
+              for (int k = 0; k < TR::CC; ++k) gr[7 + c * TR::CC + k] += gs * Y[j][k];
+              pAG += go[j][c] * (yv * Tr[j] - (fin[j][c] - pre[j][c]) * inv1m);
+            }
+          } else {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+              pre[j][c] += cg[c] * coeff;
+              gr[7 + c] += coeff * go[j][c];
+              pAG += (cg[c] * Tr[j] - (fin[j][c] - pre[j][c]) * inv1m) * go[j][c];
+            }
+          }
+          // kernel_gaussian_2d_backward (kernels.h:394-418): v = Sigma^-T d
+          const float gg = pAG * ag;
+          const float vx = (x * r.c3 - y * r.c2) * inv_det;
+          const float vy = (y * r.c0 - x * r.c1) * inv_det;
+          gr[0] += gg * vx;
+          gr[1] += gg * vy;
+          const float h = 0.5f * gg;
+          gr[2] += h * vx * vx;
+          gr[3] += h * vx * vy;
+          gr[5] += h * vy * vy;
+          gr[6] += pAG * G[j];
+          Tr[j] *= (1.0f - ag);
+          alive[j] = !(Tr[j] < p.thresh);
+        }
+      }
+      gr[4] = gr[3];  // grad_cov[1] and grad_cov[2] receive the same value (kernels.h:414-415)
+
+      wave_reduce_scatter<P>(gr);
+      const int comp = lane & (P - 1);
+      if (lane < P && comp < TR::NCOMP) {
+        const size_t id = (size_t)S.id[g];
+        float *dst;
+        if (comp < 2) dst = p.g_mean + 2 * id + comp;
+        else if (comp < 6) dst = p.g_cov + 4 * id + (comp - 2);
+        else if (comp == 6) dst = p.g_alpha + id;
+        else dst = p.g_col + (size_t)TR::NCOL * id + (comp - 7);
+        atomicAdd(dst, gr[0]);
+      }
+    }
+    bool any_alive = false;
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) any_alive |= alive[j];
+    if (__syncthreads_or((int)any_alive) == 0) break;
+  }
+}
+
+// ---- launch helpers ---------------------------------------------------------------------------
+#ifndef GSGEN_PPL
+#define GSGEN_PPL 4
+#endif
+
+static int check_common(uint32_t tile_size, const void *a, const void *b, const void *c) {
+  if (tile_size != (uint32_t)kTile) return GSGEN_EUNSUPPORTED;
+  if (!a || !b || !c) return GSGEN_EINVAL;
+  return 0;
+}
+
+template <int MODE, int CB>
+static int launch_fwd(const CompParams &p, hipStream_t s) {
+  constexpr int PPL = GSGEN_PPL;
+  const uint32_t nblk = (uint32_t)(p.ntw * p.nth);
+  if (nblk == 0) return 0;
+  hipLaunchKernelGGL((k_composite_fwd<MODE, CB, PPL>), dim3(nblk), dim3(256 / PPL), 0, s, p);
+  return (int)hipGetLastError();
+}
+template <int MODE, int CB>
+static int launch_bwd(const CompParams &p, hipStream_t s) {
+  constexpr int PPL = GSGEN_PPL;
+  const uint32_t nblk = (uint32_t)(p.ntw * p.nth);
+  if (nblk == 0) return 0;
+  hipLaunchKernelGGL((k_composite_bwd<MODE, CB, PPL>), dim3(nblk), dim3(256 / PPL), 0, s, p);
+  return (int)hipGetLastError();
+}
+
+}  // namespace gs
+
+using namespace gs;
+
+extern "C" {
+
+int gsgen_vol_render_start_end_with_T(uint32_t N, uint32_t D, const float *mean, const float *cov,
+                                      const float *color, const float *alpha, const int *start,
+                                      const int *end, const int *gaussian_ids, float *out,
+                                      const float *topleft, uint32_t tile_size, uint32_t n_tiles_h,
+                                      uint32_t n_tiles_w, float pixel_size_x, float pixel_size_y,
+                                      uint32_t H, uint32_t W, float thresh, float *T,
+                                      gsgen_stream_t stream) {
+  if (int e = check_common(tile_size, start, end, out)) return e;
+  if (N == 0 || D == 0) return 0;  // reference: zero-sized launch; out/T keep their init values
+  CompParams p{};
+  p.mean = mean; p.cov = cov; p.col = color; p.alpha = alpha;
+  p.start = start; p.end = end; p.ids = gaussian_ids; p.topleft = topleft;
+  p.out = out; p.T = T;
+  p.ntw = (int)n_tiles_w; p.nth = (int)n_tiles_h; p.H = (int)H; p.W = (int)W;
+  p.psx = pixel_size_x; p.psy = pixel_size_y; p.thresh = thresh;
+  return launch_fwd<MODE_RGB, 1>(p, (hipStream_t)stream);
+}
+
+int gsgen_vol_render_backward_start_end(uint32_t N, uint32_t D, const float *mean, const float *cov,
+                                        const float *color, const float *alpha, const int *start,
+                                        const int *end, const int *gaussian_ids, const float *out,
+                                        float *grad_mean, float *grad_cov, float *grad_color,
+                                        float *grad_alpha, const float *grad_out,
+                                        const float *topleft, uint32_t tile_size,
+                                        uint32_t n_tiles_h, uint32_t n_tiles_w, float pixel_size_x,
+                                        float pixel_size_y, uint32_t H, uint32_t W, float thresh,
+                                        gsgen_stream_t stream) {
+  if (int e = check_common(tile_size, start, end, out)) return e;
+  if (N == 0 || D == 0) return 0;
+  CompParams p{};
+  p.mean = mean; p.cov = cov; p.col = color; p.alpha = alpha;
+  p.start = start; p.end = end; p.ids = gaussian_ids; p.topleft = topleft;
+  p.final_img = out; p.grad_out = grad_out;
+  p.g_mean = grad_mean; p.g_cov = grad_cov; p.g_col = grad_color; p.g_alpha = grad_alpha;
+  p.ntw = (int)n_tiles_w; p.nth = (int)n_tiles_h; p.H = (int)H; p.W = (int)W;
+  p.psx = pixel_size_x; p.psy = pixel_size_y; p.thresh = thresh;
+  return launch_bwd<MODE_RGB, 1>(p, (hipStream_t)stream);
+}
+
+int gsgen_vol_render_scalar(uint32_t N, uint32_t D, const float *mean, const float *cov,
+                            const float *scalar, const float *alpha, const int *start,
+                            const int *end, const int *gaussian_ids, float *out,
+                            const float *topleft, uint32_t tile_size, uint32_t n_tiles_h,
+                            uint32_t n_tiles_w, float pixel_size_x, float pixel_size_y, uint32_t H,
+                            uint32_t W, float thresh, float *T, gsgen_stream_t stream) {
+  if (int e = check_common(tile_size, start, end, out)) return e;
+  if (N == 0 || D == 0) return 0;
+  CompParams p{};
+  p.mean = mean; p.cov = cov; p.col = scalar; p.alpha = alpha;
+  p.start = start; p.end = end; p.ids = gaussian_ids; p.topleft = topleft;
+  p.out = out; p.T = T;
+  p.ntw = (int)n_tiles_w; p.nth = (int)n_tiles_h; p.H = (int)H; p.W = (int)W;
+  p.psx = pixel_size_x; p.psy = pixel_size_y; p.thresh = thresh;
+  return launch_fwd<MODE_SCALAR, 1>(p, (hipStream_t)stream);
+}
+
+int gsgen_vol_render_scalar_backward(uint32_t N, uint32_t D, const float *mean, const float *cov,
+                                     const float *scalar, const float *alpha, const int *start,
+                                     const int *end, const int *gaussian_ids, const float *out,
+                                     float *grad_mean, float *grad_cov, float *grad_scalar,
+                                     float *grad_alpha, const float *grad_out, const float *topleft,
+                                     uint32_t tile_size, uint32_t n_tiles_h, uint32_t n_tiles_w,
+                                     float pixel_size_x, float pixel_size_y, uint32_t H, uint32_t W,
+                                     float thresh, gsgen_stream_t stream) {
+  if (int e = check_common(tile_size, start, end, out)) return e;
+  if (N == 0 || D == 0) return 0;
+  CompParams p{};
+  p.mean = mean; p.cov = cov; p.col = scalar; p.alpha = alpha;
+  p.start = start; p.end = end; p.ids = gaussian_ids; p.topleft = topleft;
+  p.final_img = out; p.grad_out = grad_out;
+  p.g_mean = grad_mean; p.g_cov = grad_cov; p.g_col = grad_scalar; p.g_alpha = grad_alpha;
+  p.ntw = (int)n_tiles_w; p.nth = (int)n_tiles_h; p.H = (int)H; p.W = (int)W;
+  p.psx = pixel_size_x; p.psy = pixel_size_y; p.thresh = thresh;
+  return launch_bwd<MODE_SCALAR, 1>(p, (hipStream_t)stream);
+}
+
+int gsgen_vol_render_sh(uint32_t N, uint32_t D, const float *mean, const float *cov,
+                        const float *sh_coeffs, const float *alpha, const int *start,
+                        const int *end, const int *gaussian_ids, float *out, const float *topleft,
+                        const float *c2w, uint32_t tile_size, uint32_t n_tiles_h,
+                        uint32_t n_tiles_w, float pixel_size_x, float pixel_size_y, uint32_t H,
+                        uint32_t W, uint32_t C, float thresh, const float *bg_rgb, float *T,
+                        gsgen_stream_t stream) {
+  if (int e = check_common(tile_size, start, end, out)) return e;
+  if (C < 1 || C > 4) return GSGEN_EUNSUPPORTED;  // reference dispatches C = 1..4 only (render.cu:507-544)
+  if (!c2w) return GSGEN_EINVAL;
+  if ((N == 0 || D == 0) && bg_rgb == nullptr) return 0;
+  CompParams p{};
+  p.mean = mean; p.cov = cov; p.col = sh_coeffs; p.alpha = alpha;
+  p.start = start; p.end = end; p.ids = gaussian_ids; p.topleft = topleft; p.rot = c2w;
+  p.bg = bg_rgb; p.out = out; p.T = T;
+  p.ntw = (int)n_tiles_w; p.nth = (int)n_tiles_h; p.H = (int)H; p.W = (int)W;
+  p.psx = pixel_size_x; p.psy = pixel_size_y; p.thresh = thresh;
+  hipStream_t s = (hipStream_t)stream;
+  switch (C) {
+    case 1: return launch_fwd<MODE_SH, 1>(p, s);
+    case 2: return launch_fwd<MODE_SH, 2>(p, s);
+    case 3: return launch_fwd<MODE_SH, 3>(p, s);
+    default: return launch_fwd<MODE_SH, 4>(p, s);
+  }
+}
+
+int gsgen_vol_render_backward_sh(uint32_t N, uint32_t D, const float *mean, const float *cov,
+                                 const float *sh_coeffs, const float *alpha, const int *start,
+                                 const int *end, const int *gaussian_ids, const float *out,
+                                 float *grad_mean, float *grad_cov, float *grad_sh_coeffs,
+                                 float *grad_alpha, const float *grad_out, const float *topleft,
+                                 const float *c2w, uint32_t tile_size, uint32_t n_tiles_h,
+                                 uint32_t n_tiles_w, float pixel_size_x, float pixel_size_y,
+                                 uint32_t H, uint32_t W, uint32_t C, float thresh,
+                                 const float *bg_rgb, gsgen_stream_t stream) {
+  (void)bg_rgb;  // the background only enters through `out` (= final incl. bg*T)
+  if (int e = check_common(tile_size, start, end, out)) return e;
+  if (C < 1 || C > 4) return GSGEN_EUNSUPPORTED;
+  if (!c2w) return GSGEN_EINVAL;
+  if (N == 0 || D == 0) return 0;
+  CompParams p{};
+  p.mean = mean; p.cov = cov; p.col = sh_coeffs; p.alpha = alpha;
+  p.start = start; p.end = end; p.ids = gaussian_ids; p.topleft = topleft; p.rot = c2w;
+  p.final_img = out; p.grad_out = grad_out;
+  p.g_mean = grad_mean; p.g_cov = grad_cov; p.g_col = grad_sh_coeffs; p.g_alpha = grad_alpha;
+  p.ntw = (int)n_tiles_w; p.nth = (int)n_tiles_h; p.H = (int)H; p.W = (int)W;
+  p.psx = pixel_size_x; p.psy = pixel_size_y; p.thresh = thresh;
+  hipStream_t s = (hipStream_t)stream;
+  switch (C) {
+    case 1: return launch_bwd<MODE_SH, 1>(p, s);
+    case 2: return launch_bwd<MODE_SH, 2>(p, s);
+    case 3: return launch_bwd<MODE_SH, 3>(p, s);
+    default: return launch_bwd<MODE_SH, 4>(p, s);
+  }
+}
+
+}  // extern "C"

@@ -1,0 +1,402 @@
+// geometry.hip -- per-Gaussian stages: frustum cull, EWA projection (fwd/bwd), AABB -> tile
+// rectangle.  One thread per Gaussian, ~100 B of HBM traffic each: purely bandwidth-bound.
+//
+// THIS FILE IS COMPILED WITH -ffp-contract=off.  Every fp32 expression below is written in
+// the order the oracle (oracle/gs_oracle.c) and the reference's PyTorch ops execute it and
+// uses only correctly-rounded IEEE operations (+ - * / sqrt), so mean2d / cov2d / depth and
+// therefore the integer tile rectangles, the pair count D and the per-tile lists are
+// BIT-IDENTICAL to the reference's torch path (tile membership is part of the image:
+// SURVEY.md 8a trap 1).
+//
+// Replaces (paths relative to /root/reference):
+//   cull        gs/src/include/culling.h:10-33, kernels.h:156-170
+//   projection  gs/renderer.py:366-421, utils/transforms.py:34-46 (kornia 0.6.0 quaternion)
+//   AABB count  gs/culling.py:8-37, utils/camera.py:301-314
+#include "common.hpp"
+#include "../../include/gsgen_hip.h"
+
+namespace gs {
+
+constexpr int kThreads = 256;
+
+// ---- frustum cull -------------------------------------------------------------------------
+__device__ __forceinline__ bool sphere_in_frustum(float mx, float my, float mz, float r,
+                                                  const float *__restrict__ normal,
+                                                  const float *__restrict__ pts) {
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const float d = (mx - pts[3 * k]) * normal[3 * k] + (my - pts[3 * k + 1]) * normal[3 * k + 1] +
+                    (mz - pts[3 * k + 2]) * normal[3 * k + 2];
+    ok = ok && (d > -r);
+  }
+  return ok;
+}
+
+__global__ void __launch_bounds__(kThreads)
+k_cull_bsphere(uint32_t N, const float *__restrict__ mean, const float *__restrict__ svec,
+               const float *__restrict__ normal, const float *__restrict__ pts,
+               uint8_t *__restrict__ mask, float thresh) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const float r = fmaxf(fmaxf(svec[3 * i], svec[3 * i + 1]), svec[3 * i + 2]) * thresh;
+  mask[i] = sphere_in_frustum(mean[3 * i], mean[3 * i + 1], mean[3 * i + 2], r, normal, pts) ? 1 : 0;
+}
+
+// ---- projection ----------------------------------------------------------------------------
+struct Proj {
+  float m2x, m2y, c00, c01, c10, c11, depth;
+  float A[9];  // JW
+};
+
+__device__ __forceinline__ void quat_to_rot(const float *__restrict__ q, float *R) {
+  float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  n = fmaxf(n, 1e-12f);  // F.normalize(p=2, eps=1e-12)
+  const float w = q[0] / n, x = q[1] / n, y = q[2] / n, z = q[3] / n;
+  const float tx = 2.0f * x, ty = 2.0f * y, tz = 2.0f * z;
+  const float twx = tx * w, twy = ty * w, twz = tz * w;
+  const float txx = tx * x, txy = ty * x, txz = tz * x;
+  const float tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  R[0] = 1.0f - (tyy + tzz); R[1] = txy - twz;          R[2] = txz + twy;
+  R[3] = txy + twz;          R[4] = 1.0f - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy;          R[7] = tyz + twx;          R[8] = 1.0f - (txx + tyy);
+}
+
+__device__ __forceinline__ Proj project_one(const float *__restrict__ p, const float *__restrict__ q,
+                                            const float *__restrict__ s, const float *Rc,
+                                            const float *t) {
+  Proj o;
+  const float d0 = p[0] - t[0], d1 = p[1] - t[1], d2 = p[2] - t[2];
+  float u[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) u[i] = Rc[i] * d0 + Rc[3 + i] * d1 + Rc[6 + i] * d2;
+  float Rq[9];
+  quat_to_rot(q, Rq);
+  float M[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) M[i * 3 + j] = s[j] * Rq[i * 3 + j];
+  float S[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      S[i * 3 + k] = M[i * 3] * M[k * 3] + M[i * 3 + 1] * M[k * 3 + 1] + M[i * 3 + 2] * M[k * 3 + 2];
+  const float x = u[0], y = u[1], z = u[2];
+  const float l = sqrtf(x * x + y * y + z * z);
+  const float J[9] = {1.0f / z, 0.0f, -x / z / z, 0.0f, 1.0f / z, -y / z / z, x / l, y / l, z / l};
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      o.A[i * 3 + k] = J[i * 3] * Rc[k * 3] + J[i * 3 + 1] * Rc[k * 3 + 1] + J[i * 3 + 2] * Rc[k * 3 + 2];
+  float T1[6];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      T1[a * 3 + k] = o.A[a * 3] * S[k] + o.A[a * 3 + 1] * S[3 + k] + o.A[a * 3 + 2] * S[6 + k];
+  o.c00 = T1[0] * o.A[0] + T1[1] * o.A[1] + T1[2] * o.A[2];
+  o.c01 = T1[0] * o.A[3] + T1[1] * o.A[4] + T1[2] * o.A[5];
+  o.c10 = T1[3] * o.A[0] + T1[4] * o.A[1] + T1[5] * o.A[2];
+  o.c11 = T1[3] * o.A[3] + T1[4] * o.A[4] + T1[5] * o.A[5];
+  o.depth = z;
+  o.m2x = x / z;
+  o.m2y = y / z;
+  return o;
+}
+
+__device__ __forceinline__ void load_pose(const float *__restrict__ c2w, float *Rc, float *t) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) Rc[i * 3 + j] = c2w[i * 4 + j];
+    t[i] = c2w[i * 4 + 3];
+  }
+}
+
+__global__ void __launch_bounds__(kThreads)
+k_project(uint32_t N, const float *__restrict__ mean, const float *__restrict__ qvec,
+          const float *__restrict__ svec, const float *__restrict__ c2w, float *__restrict__ mean2d,
+          float *__restrict__ cov2d, float *__restrict__ JW, float *__restrict__ depth) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  float Rc[9], t[3];
+  load_pose(c2w, Rc, t);
+  const Proj o = project_one(mean + 3 * (size_t)i, qvec + 4 * (size_t)i, svec + 3 * (size_t)i, Rc, t);
+  *reinterpret_cast<float2 *>(mean2d + 2 * (size_t)i) = make_float2(o.m2x, o.m2y);
+  *reinterpret_cast<float4 *>(cov2d + 4 * (size_t)i) = make_float4(o.c00, o.c01, o.c10, o.c11);
+  depth[i] = o.depth;
+  if (JW != nullptr) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) JW[9 * (size_t)i + k] = o.A[k];
+  }
+}
+
+// Backward of the projection as autograd differentiates gs/renderer.py:391-421: J is a
+// constant (@torch.no_grad), the depth in the perspective divide is detached iff
+// detach_depth.  Gradients are overwritten.
+__global__ void __launch_bounds__(kThreads)
+k_project_bwd(uint32_t N, const float *__restrict__ mean, const float *__restrict__ qvec,
+              const float *__restrict__ svec, const float *__restrict__ c2w, int detach_depth,
+              const uint8_t *__restrict__ mask, const float *__restrict__ g_mean2d,
+              const float *__restrict__ g_cov2d, const float *__restrict__ g_depth,
+              float *__restrict__ g_mean, float *__restrict__ g_qvec, float *__restrict__ g_svec) {
+  const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float *gm = g_mean + 3 * (size_t)n, *gq = g_qvec + 4 * (size_t)n, *gs_ = g_svec + 3 * (size_t)n;
+  if (mask != nullptr && mask[n] == 0) {
+    gm[0] = gm[1] = gm[2] = 0.f;
+    gq[0] = gq[1] = gq[2] = gq[3] = 0.f;
+    gs_[0] = gs_[1] = gs_[2] = 0.f;
+    return;
+  }
+  float Rc[9], t[3];
+  load_pose(c2w, Rc, t);
+  const float *p = mean + 3 * (size_t)n, *q = qvec + 4 * (size_t)n, *s = svec + 3 * (size_t)n;
+  const float d0 = p[0] - t[0], d1 = p[1] - t[1], d2 = p[2] - t[2];
+  float u[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) u[i] = Rc[i] * d0 + Rc[3 + i] * d1 + Rc[6 + i] * d2;
+  float nq = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  nq = fmaxf(nq, 1e-12f);
+  const float w = q[0] / nq, x = q[1] / nq, y = q[2] / nq, z = q[3] / nq;
+  const float Rq[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                       2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                       2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)};
+  float M[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) M[i * 3 + j] = s[j] * Rq[i * 3 + j];
+  const float ux = u[0], uy = u[1], uz = u[2];
+  const float iz = 1.0f / uz;
+  const float J[6] = {iz, 0.0f, -ux * iz * iz, 0.0f, iz, -uy * iz * iz};
+  float A[6];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      A[a * 3 + k] = J[a * 3] * Rc[k * 3] + J[a * 3 + 1] * Rc[k * 3 + 1] + J[a * 3 + 2] * Rc[k * 3 + 2];
+  const float4 g = *reinterpret_cast<const float4 *>(g_cov2d + 4 * (size_t)n);
+  const float gc[4] = {g.x, g.y, g.z, g.w};
+  // dSigma = A^T G A ; only the symmetrised form enters dM
+  float dS[9];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      float acc = 0.f;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc += A[a * 3 + j] * gc[a * 2 + b] * A[b * 3 + k];
+      dS[j * 3 + k] = acc;
+    }
+  float dM[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) acc += (dS[i * 3 + k] + dS[k * 3 + i]) * M[k * 3 + j];
+      dM[i * 3 + j] = acc;
+    }
+  float dR[9];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      acc += dM[i * 3 + j] * Rq[i * 3 + j];
+      dR[i * 3 + j] = dM[i * 3 + j] * s[j];
+    }
+    gs_[j] = acc;
+  }
+  float dq[4];
+  dq[0] = 2 * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]);
+  dq[1] = 2 * (y * dR[1] + z * dR[2] + y * dR[3] - 2 * x * dR[4] - w * dR[5] + z * dR[6] + w * dR[7] - 2 * x * dR[8]);
+  dq[2] = 2 * (-2 * y * dR[0] + x * dR[1] + w * dR[2] + x * dR[3] + z * dR[5] - w * dR[6] + z * dR[7] - 2 * y * dR[8]);
+  dq[3] = 2 * (-2 * z * dR[0] - w * dR[1] + x * dR[2] + w * dR[3] - 2 * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
+  const float qh[4] = {w, x, y, z};
+  const float dot = qh[0] * dq[0] + qh[1] * dq[1] + qh[2] * dq[2] + qh[3] * dq[3];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) gq[k] = (dq[k] - qh[k] * dot) / nq;
+  const float gm0 = g_mean2d[2 * (size_t)n], gm1 = g_mean2d[2 * (size_t)n + 1];
+  float du[3] = {gm0 * iz, gm1 * iz, g_depth != nullptr ? g_depth[n] : 0.0f};
+  if (!detach_depth) du[2] += -(ux * gm0 + uy * gm1) * iz * iz;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) gm[j] = Rc[j * 3] * du[0] + Rc[j * 3 + 1] * du[1] + Rc[j * 3 + 2] * du[2];
+}
+
+// ---- AABB -> tile rectangle -------------------------------------------------------------------
+__device__ __forceinline__ int to_i32_trunc(float v) {
+  // torch .to(int32) truncates toward zero; out-of-range / NaN -> INT_MIN like cvttss2si.
+  if (!(v == v) || v >= 2147483648.0f || v <= -2147483904.0f) return (int)0x80000000;
+  return (int)v;
+}
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+struct Rect { int x0, y0, x1, y1; };
+__device__ __forceinline__ Rect tile_rect(float m2x, float m2y, float c00, float c11, float Dr,
+                                          float fx, float fy, float cx, float cy, int w, int h) {
+  const float ax = sqrtf(Dr * c00), ay = sqrtf(Dr * c11);
+  const float tlx = m2x - ax, tly = m2y - ay, brx = m2x + ax, bry = m2y + ay;
+  float m;
+  m = tlx * fx; int px0 = to_i32_trunc(m + cx);
+  m = tly * fy; int py0 = to_i32_trunc(m + cy);
+  m = brx * fx; int px1 = to_i32_trunc(m + cx);
+  m = bry * fy; int py1 = to_i32_trunc(m + cy);
+  px0 = clampi(px0, 0, w - 1); px1 = clampi(px1, 0, w - 1);
+  py0 = clampi(py0, 0, h - 1); py1 = clampi(py1, 0, h - 1);
+  Rect r;  // clamped pixels are >= 0, so floor division == shift
+  r.x0 = px0 >> 4; r.y0 = py0 >> 4; r.x1 = px1 >> 4; r.y1 = py1 >> 4;
+  return r;
+}
+
+__global__ void __launch_bounds__(kThreads)
+k_aabb_count(uint32_t N, const float *__restrict__ mean2d, const float *__restrict__ cov2d,
+             float fx, float fy, float cx, float cy, int w, int h, float Dr,
+             int *__restrict__ tl, int *__restrict__ br, uint32_t *__restrict__ total) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t cnt = 0;
+  if (i < N) {
+    const float2 m = *reinterpret_cast<const float2 *>(mean2d + 2 * (size_t)i);
+    const float4 c = *reinterpret_cast<const float4 *>(cov2d + 4 * (size_t)i);
+    const Rect r = tile_rect(m.x, m.y, c.x, c.w, Dr, fx, fy, cx, cy, w, h);
+    *reinterpret_cast<int2 *>(tl + 2 * (size_t)i) = make_int2(r.x0, r.y0);
+    *reinterpret_cast<int2 *>(br + 2 * (size_t)i) = make_int2(r.x1, r.y1);
+    cnt = (uint32_t)((r.x1 - r.x0 + 1) * (r.y1 - r.y0 + 1));
+  }
+  // one atomic per wave
+  float dummy = 0.f; (void)dummy;
+  uint32_t s = cnt;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) s += (uint32_t)__shfl_xor((int)s, m, 64);
+  if ((threadIdx.x & 63u) == 0 && s != 0) atomicAdd(total, s);
+}
+
+// ---- fused per-frame geometry: cull + project + rectangle + per-tile histogram ---------------
+// cam layout documented in include/gsgen_hip.h (gsgen_frame_geometry).
+__global__ void __launch_bounds__(kThreads)
+k_frame_project(uint32_t N, const float *__restrict__ mean, const float *__restrict__ qvec,
+                const float *__restrict__ svec, const float *__restrict__ cam, int w, int h, int ntw,
+                float *__restrict__ mean2d, float *__restrict__ cov2d, float *__restrict__ depth,
+                uint8_t *__restrict__ mask, int *__restrict__ tl, int *__restrict__ br,
+                uint32_t *__restrict__ tile_count) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  float Rc[9], t[3];
+  load_pose(cam, Rc, t);
+  const float fx = cam[12], fy = cam[13], cx = cam[14], cy = cam[15];
+  const float frustum_r = cam[16], Dr = cam[17];
+  const float *p = mean + 3 * (size_t)i, *s = svec + 3 * (size_t)i;
+  bool in = true;
+  if (frustum_r > 0.0f) {
+    const float r = fmaxf(fmaxf(s[0], s[1]), s[2]) * frustum_r;
+    in = sphere_in_frustum(p[0], p[1], p[2], r, cam + 20, cam + 38);
+  }
+  Rect rc{0, 0, -1, -1};  // empty
+  float2 m2 = make_float2(0.f, 0.f);
+  float4 c2 = make_float4(1.f, 0.f, 0.f, 1.f);
+  float z = 0.f;
+  if (in) {
+    const Proj o = project_one(p, qvec + 4 * (size_t)i, s, Rc, t);
+    m2 = make_float2(o.m2x, o.m2y);
+    c2 = make_float4(o.c00, o.c01, o.c10, o.c11);
+    z = o.depth;
+    rc = tile_rect(o.m2x, o.m2y, o.c00, o.c11, Dr, fx, fy, cx, cy, w, h);
+  }
+  *reinterpret_cast<float2 *>(mean2d + 2 * (size_t)i) = m2;
+  *reinterpret_cast<float4 *>(cov2d + 4 * (size_t)i) = c2;
+  depth[i] = z;
+  mask[i] = in ? 1 : 0;
+  *reinterpret_cast<int2 *>(tl + 2 * (size_t)i) = make_int2(rc.x0, rc.y0);
+  *reinterpret_cast<int2 *>(br + 2 * (size_t)i) = make_int2(rc.x1, rc.y1);
+  for (int ty = rc.y0; ty <= rc.y1; ++ty)
+    for (int tx = rc.x0; tx <= rc.x1; ++tx) atomicAdd(&tile_count[ty * ntw + tx], 1u);
+}
+
+static inline dim3 grid_for(uint32_t n) { return dim3((n + kThreads - 1) / kThreads); }
+
+}  // namespace gs
+
+using namespace gs;
+
+extern "C" {
+
+int gsgen_culling_gaussian_bsphere(uint32_t N, const float *mean, const float *qvec,
+                                   const float *svec, const float *normal, const float *pts,
+                                   uint8_t *mask, float thresh, gsgen_stream_t stream) {
+  (void)qvec;  // unused by the reference too (culling.h:10-19)
+  if (N == 0) return 0;
+  if (!mean || !svec || !normal || !pts || !mask) return GSGEN_EINVAL;
+  hipLaunchKernelGGL(k_cull_bsphere, grid_for(N), dim3(kThreads), 0, (hipStream_t)stream, N, mean,
+                     svec, normal, pts, mask, thresh);
+  return (int)hipGetLastError();
+}
+
+int gsgen_project_gaussians(uint32_t N, const float *mean, const float *qvec, const float *svec,
+                            const float *c2w, float *mean2d, float *cov2d, float *JW, float *depth,
+                            gsgen_stream_t stream) {
+  if (N == 0) return 0;
+  if (!mean || !qvec || !svec || !c2w || !mean2d || !cov2d || !depth) return GSGEN_EINVAL;
+  hipLaunchKernelGGL(k_project, grid_for(N), dim3(kThreads), 0, (hipStream_t)stream, N, mean, qvec,
+                     svec, c2w, mean2d, cov2d, JW, depth);
+  return (int)hipGetLastError();
+}
+
+int gsgen_project_gaussians_backward_masked(uint32_t N, const float *mean, const float *qvec,
+                                            const float *svec, const float *c2w, int detach_depth,
+                                            const uint8_t *mask, const float *g_mean2d,
+                                            const float *g_cov2d, const float *g_depth,
+                                            float *g_mean, float *g_qvec, float *g_svec,
+                                            gsgen_stream_t stream) {
+  if (N == 0) return 0;
+  if (!mean || !qvec || !svec || !c2w || !g_mean2d || !g_cov2d || !g_mean || !g_qvec || !g_svec)
+    return GSGEN_EINVAL;
+  hipLaunchKernelGGL(k_project_bwd, grid_for(N), dim3(kThreads), 0, (hipStream_t)stream, N, mean,
+                     qvec, svec, c2w, detach_depth, mask, g_mean2d, g_cov2d, g_depth, g_mean, g_qvec,
+                     g_svec);
+  return (int)hipGetLastError();
+}
+
+int gsgen_project_gaussians_backward(uint32_t N, const float *mean, const float *qvec,
+                                     const float *svec, const float *c2w, int detach_depth,
+                                     const float *g_mean2d, const float *g_cov2d,
+                                     const float *g_depth, float *g_mean, float *g_qvec,
+                                     float *g_svec, gsgen_stream_t stream) {
+  return gsgen_project_gaussians_backward_masked(N, mean, qvec, svec, c2w, detach_depth, nullptr,
+                                                 g_mean2d, g_cov2d, g_depth, g_mean, g_qvec, g_svec,
+                                                 stream);
+}
+
+int gsgen_tile_culling_aabb_count(uint32_t N, const float *mean2d, const float *cov2d,
+                                  uint32_t tile_size, float fx, float fy, float cx, float cy,
+                                  uint32_t w, uint32_t h, float D, int *aabb_topleft,
+                                  int *aabb_bottomright, uint32_t *total, gsgen_stream_t stream) {
+  if (tile_size != (uint32_t)kTile) return GSGEN_EUNSUPPORTED;
+  if (!total) return GSGEN_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipError_t e = hipMemsetAsync(total, 0, sizeof(uint32_t), s)) return (int)e;
+  if (N == 0) return 0;
+  if (!mean2d || !cov2d || !aabb_topleft || !aabb_bottomright) return GSGEN_EINVAL;
+  hipLaunchKernelGGL(k_aabb_count, grid_for(N), dim3(kThreads), 0, s, N, mean2d, cov2d, fx, fy, cx, cy,
+                     (int)w, (int)h, D, aabb_topleft, aabb_bottomright, total);
+  return (int)hipGetLastError();
+}
+
+// used by binning.hip (gsgen_frame_geometry)
+int gsgen_internal_frame_project(uint32_t N, const float *mean, const float *qvec, const float *svec,
+                                 const float *cam, int w, int h, int ntw, float *mean2d, float *cov2d,
+                                 float *depth, uint8_t *mask, int *tl, int *br, uint32_t *tile_count,
+                                 gsgen_stream_t stream) {
+  if (N == 0) return 0;
+  hipLaunchKernelGGL(k_frame_project, grid_for(N), dim3(kThreads), 0, (hipStream_t)stream, N, mean,
+                     qvec, svec, cam, w, h, ntw, mean2d, cov2d, depth, mask, tl, br, tile_count);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,433 @@
+"""autograd surface of the rasterizer, mirroring gs/renderer.py of the reference.
+
+`render_with_T`, `render_scalar`, `render_sh`, `render_sh_bg`, `render_start_end` have the
+argument lists, return shapes, saved tensors and backward outputs of the reference's
+torch.autograd.Functions (gs/renderer.py:424-1291); `project_gaussians` and
+`tile_culling_aabb_count` replace the reference's PyTorch implementations
+(gs/renderer.py:391-421, gs/culling.py:8-37) with the HIP kernels and keep their signatures.
+`render_frame` is the additive fused path (cull -> project -> bin/sort -> composite, no host
+sync) used by bench.py and FrameRenderer.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import _capi
+from . import _gs as _backend
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _p(t):
+    return t.data_ptr() if t is not None else None
+
+
+# ---------------------------------------------------------------------------------------------
+# projection (gs/renderer.py:391-421)
+# ---------------------------------------------------------------------------------------------
+class _project_gaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mean, qvec, svec, c2w, detach_depth):
+        mean, qvec, svec = mean.contiguous(), qvec.contiguous(), svec.contiguous()
+        c2w = c2w.contiguous().float()
+        N = mean.size(0)
+        dev = mean.device
+        mean2d = torch.empty(N, 2, device=dev, dtype=torch.float32)
+        cov2d = torch.empty(N, 2, 2, device=dev, dtype=torch.float32)
+        JW = torch.empty(N, 3, 3, device=dev, dtype=torch.float32)
+        depth = torch.empty(N, 1, device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            _capi.load().project_gaussians(N, _p(mean), _p(qvec), _p(svec), _p(c2w), _p(mean2d),
+                                           _p(cov2d), _p(JW), _p(depth), _stream(mean))
+        ctx.save_for_backward(mean, qvec, svec, c2w)
+        ctx.detach_depth = bool(detach_depth)
+        ctx.mark_non_differentiable(JW)  # "JW should not be updated" (gs/renderer.py:405)
+        return mean2d, cov2d, JW, depth
+
+    @staticmethod
+    def backward(ctx, g_mean2d, g_cov2d, g_JW, g_depth):
+        mean, qvec, svec, c2w = ctx.saved_tensors
+        N = mean.size(0)
+        dev = mean.device
+        g_mean2d = (g_mean2d if g_mean2d is not None else torch.zeros(N, 2, device=dev)).contiguous()
+        g_cov2d = (g_cov2d if g_cov2d is not None else torch.zeros(N, 2, 2, device=dev)).contiguous()
+        g_depth = g_depth.contiguous() if g_depth is not None else None
+        g_mean = torch.empty_like(mean)
+        g_qvec = torch.empty_like(qvec)
+        g_svec = torch.empty_like(svec)
+        with torch.cuda.device(dev):
+            _capi.load().project_gaussians_backward(
+                N, _p(mean), _p(qvec), _p(svec), _p(c2w), int(ctx.detach_depth), _p(g_mean2d),
+                _p(g_cov2d), _p(g_depth), _p(g_mean), _p(g_qvec), _p(g_svec), _stream(mean))
+        return g_mean, g_qvec, g_svec, None, None
+
+
+def project_gaussians(mean, qvec, svec, c2w, detach_depth=False):
+    """Same contract as gs/renderer.py:391-421: -> (mean2d [N,2], cov2d [N,2,2], JW [N,3,3],
+    depth [N,1]); gradients flow to mean, qvec, svec (J is a constant; the depth of the
+    perspective divide is detached iff detach_depth)."""
+    return _project_gaussians.apply(mean, qvec, svec, c2w, detach_depth)
+
+
+@torch.no_grad()
+def tile_culling_aabb_count(mean, cov, tile_size, camera_info, D, sync=True):
+    """gs/culling.py:8-37 on the device.  Returns (N_with_dub, aabb_topleft, aabb_bottomright);
+    with sync=False N_with_dub is a device uint32 tensor instead of a python int (the
+    reference's `.item()` host sync is the only reason for a sync here)."""
+    N = mean.size(0)
+    dev = mean.device
+    tl = torch.empty(N, 2, device=dev, dtype=torch.int32)
+    br = torch.empty(N, 2, device=dev, dtype=torch.int32)
+    total = torch.empty(1, device=dev, dtype=torch.int32)
+    mean, cov = mean.contiguous(), cov.contiguous()
+    with torch.cuda.device(dev):
+        _capi.load().tile_culling_aabb_count(
+            N, _p(mean), _p(cov), int(tile_size), float(camera_info.fx), float(camera_info.fy),
+            float(camera_info.cx), float(camera_info.cy), int(camera_info.w), int(camera_info.h),
+            float(D), _p(tl), _p(br), _p(total), _stream(mean))
+    return (int(total.item()) if sync else total), tl, br
+
+
+# ---------------------------------------------------------------------------------------------
+# compositing autograd Functions (gs/renderer.py:517-1283)
+# ---------------------------------------------------------------------------------------------
+class _render_with_T(torch.autograd.Function):
+    """gs/renderer.py:1135-1283"""
+
+    @staticmethod
+    def forward(ctx, mean, cov, scalar, alpha, start, end, gaussian_ids, topleft, tile_size, n_tiles_h,
+                n_tiles_w, pixel_size_x, pixel_size_y, H, W, thresh, bg):
+        out = torch.zeros([H, W, 3], dtype=torch.float32, device=mean.device)
+        T = torch.ones_like(out[..., :1])
+        _backend.tile_based_vol_rendering_start_end_with_T(
+            mean, cov, scalar, alpha, start, end, gaussian_ids, out, topleft, tile_size, n_tiles_h,
+            n_tiles_w, pixel_size_x, pixel_size_y, H, W, thresh, T)
+        out = out + T * bg
+        ctx.save_for_backward(mean, cov, scalar, alpha, start, end, gaussian_ids, out, topleft, T)
+        ctx.const = [tile_size, n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H, W, thresh]
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        mean, cov, color, alpha, start, end, gaussian_ids, out, topleft, T = ctx.saved_tensors
+        grad = grad.contiguous()
+        grad_mean = torch.zeros_like(mean)
+        grad_cov = torch.zeros_like(cov)
+        grad_color = torch.zeros_like(color)
+        grad_alpha = torch.zeros_like(alpha)
+        tile_size, n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H, W, thresh = ctx.const
+        _backend.tile_based_vol_rendering_backward_start_end(
+            mean, cov, color, alpha, start, end, gaussian_ids, out, grad_mean, grad_cov, grad_color,
+            grad_alpha, grad, topleft, tile_size, n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H,
+            W, thresh)
+        return (grad_mean, grad_cov, grad_color, grad_alpha) + (None,) * 12 + (
+            torch.nan_to_num(grad * T),)
+
+
+class _render_start_end(torch.autograd.Function):
+    """gs/renderer.py:517-672 (`render_start_end`): flat [H*W*3] output, no background."""
+
+    @staticmethod
+    def forward(ctx, mean, cov, color, alpha, start, end, gaussian_ids, topleft, tile_size, n_tiles_h,
+                n_tiles_w, pixel_size_x, pixel_size_y, H, W, thresh):
+        out = torch.zeros([H * W * 3], dtype=torch.float32, device=mean.device)
+        _backend.tile_based_vol_rendering_start_end(
+            mean, cov, color, alpha, start, end, gaussian_ids, out, topleft, tile_size, n_tiles_h,
+            n_tiles_w, pixel_size_x, pixel_size_y, H, W, thresh)
+        ctx.save_for_backward(mean, cov, color, alpha, start, end, gaussian_ids, out, topleft)
+        ctx.const = [tile_size, n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H, W, thresh]
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        mean, cov, color, alpha, start, end, gaussian_ids, out, topleft = ctx.saved_tensors
+        grad = grad.contiguous()
+        grad_mean = torch.zeros_like(mean)
+        grad_cov = torch.zeros_like(cov)
+        grad_color = torch.zeros_like(color)
+        grad_alpha = torch.zeros_like(alpha)
+        tile_size, n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H, W, thresh = ctx.const
+        _backend.tile_based_vol_rendering_backward_start_end(
+            mean, cov, color, alpha, start, end, gaussian_ids, out, grad_mean, grad_cov, grad_color,
+            grad_alpha, grad, topleft, tile_size, n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H,
+            W, thresh)
+        return (grad_mean, grad_cov, grad_color, grad_alpha) + (None,) * 12
+
+
+class _render_scalar(torch.autograd.Function):
+    """gs/renderer.py:999-1132.  T is the caller's [H,W,1] tensor, overwritten in place."""
+
+    @staticmethod
+    def forward(ctx, mean, cov, scalar, alpha, start, end, gaussian_ids, topleft, tile_size, n_tiles_h,
+                n_tiles_w, pixel_size_x, pixel_size_y, H, W, thresh, T):
+        out = torch.zeros([H * W], dtype=torch.float32, device=mean.device)
+        scalar = scalar.contiguous()
+        _backend.tile_based_vol_rendering_scalar(
+            mean, cov, scalar, alpha, start, end, gaussian_ids, out, topleft, tile_size, n_tiles_h,
+            n_tiles_w, pixel_size_x, pixel_size_y, H, W, thresh, T)
+        ctx.save_for_backward(mean, cov, scalar, alpha, start, end, gaussian_ids, out, topleft)
+        ctx.const = [tile_size, n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H, W, thresh]
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        mean, cov, scalar, alpha, start, end, gaussian_ids, out, topleft = ctx.saved_tensors
+        grad = grad.contiguous()
+        grad_mean = torch.zeros_like(mean)
+        grad_cov = torch.zeros_like(cov)
+        grad_scalar = torch.zeros_like(scalar)
+        grad_alpha = torch.zeros_like(alpha)
+        tile_size, n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H, W, thresh = ctx.const
+        _backend.tile_based_vol_rendering_scalar_backward(
+            mean, cov, scalar, alpha, start, end, gaussian_ids, out, grad_mean, grad_cov, grad_scalar,
+            grad_alpha, grad, topleft, tile_size, n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H,
+            W, thresh)
+        return (grad_mean, grad_cov, grad_scalar, grad_alpha) + (None,) * 13
+
+
+class _render_sh(torch.autograd.Function):
+    """gs/renderer.py:674-830"""
+
+    @staticmethod
+    def forward(ctx, mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, topleft, c2w, tile_size,
+                n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H, W, C, thresh):
+        out = torch.zeros([H * W * 3], dtype=torch.float32, device=mean.device)
+        _backend.tile_based_vol_rendering_sh(
+            mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out, topleft, c2w, tile_size,
+            n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H, W, C, thresh)
+        ctx.save_for_backward(mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out, topleft, c2w)
+        ctx.const = [tile_size, n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H, W, C, thresh]
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out, topleft, c2w = ctx.saved_tensors
+        grad = grad.contiguous()
+        grad_mean = torch.zeros_like(mean)
+        grad_cov = torch.zeros_like(cov)
+        grad_sh = torch.zeros_like(sh_coeffs)
+        grad_alpha = torch.zeros_like(alpha)
+        tile_size, n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H, W, C, thresh = ctx.const
+        _backend.tile_based_vol_rendering_backward_sh(
+            mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out, grad_mean, grad_cov, grad_sh,
+            grad_alpha, grad, topleft, c2w, tile_size, n_tiles_h, n_tiles_w, pixel_size_x,
+            pixel_size_y, H, W, C, thresh)
+        return (grad_mean, grad_cov, grad_sh, grad_alpha) + (None,) * 14
+
+
+class _render_sh_bg(torch.autograd.Function):
+    """gs/renderer.py:833-996"""
+
+    @staticmethod
+    def forward(ctx, mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, topleft, c2w, tile_size,
+                n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H, W, C, thresh, bg_rgb):
+        out = torch.zeros([H * W * 3], dtype=torch.float32, device=mean.device)
+        _backend.tile_based_vol_rendering_sh_with_bg(
+            mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out, topleft, c2w, tile_size,
+            n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H, W, C, thresh, bg_rgb)
+        ctx.save_for_backward(mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out, topleft, c2w,
+                              bg_rgb)
+        ctx.const = [tile_size, n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H, W, C, thresh]
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        (mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out, topleft, c2w,
+         bg_rgb) = ctx.saved_tensors
+        grad = grad.contiguous()
+        grad_mean = torch.zeros_like(mean)
+        grad_cov = torch.zeros_like(cov)
+        grad_sh = torch.zeros_like(sh_coeffs)
+        grad_alpha = torch.zeros_like(alpha)
+        tile_size, n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H, W, C, thresh = ctx.const
+        _backend.tile_based_vol_rendering_backward_sh_with_bg(
+            mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out, grad_mean, grad_cov, grad_sh,
+            grad_alpha, grad, topleft, c2w, tile_size, n_tiles_h, n_tiles_w, pixel_size_x,
+            pixel_size_y, H, W, C, thresh, bg_rgb)
+        return (grad_mean, grad_cov, grad_sh, grad_alpha) + (None,) * 15
+
+
+render_start_end = _render_start_end.apply
+render_sh = _render_sh.apply
+render_sh_bg = _render_sh_bg.apply
+render_scalar = _render_scalar.apply
+render_with_T = _render_with_T.apply
+
+
+# ---------------------------------------------------------------------------------------------
+# camera packing for the fused path
+# ---------------------------------------------------------------------------------------------
+class CameraInfo:
+    """Field-compatible with utils/camera.py:219-259 (fx, fy, cx, cy, w, h, near/far planes,
+    yfov, aspect)."""
+
+    def __init__(self, fx, fy, cx, cy, w, h, near_plane=0.01, far_plane=100.0):
+        self.fx, self.fy, self.cx, self.cy = float(fx), float(fy), float(cx), float(cy)
+        self.w, self.h = int(w), int(h)
+        self.yfov = 2 * np.arctan(self.h / (2 * self.fy))
+        self.aspect = self.w / self.h
+        self.near_plane, self.far_plane = float(near_plane), float(far_plane)
+
+    def get_frustum(self, c2w):
+        """utils/camera.py:260-294 in fp32 numpy, operation for operation (python-double scalars
+        are rounded to fp32 before they meet an fp32 array, as torch does)."""
+        c2w = np.asarray(c2w, np.float32)
+        f32 = np.float32
+        up, right, lookat, t = -c2w[:, 1], c2w[:, 0], c2w[:, 2], c2w[:, 3]
+        half_v = self.far_plane * np.tan(self.yfov * 0.5)
+        half_h = half_v * self.aspect
+        near_point = f32(self.near_plane) * lookat
+        far_point = f32(self.far_plane) * lookat
+        cr = lambda a, b: np.array([a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2],  # noqa: E731
+                                    a[0] * b[1] - a[1] * b[0]], np.float32)
+        normals = np.stack([
+            lookat, -lookat,
+            cr(far_point - f32(half_h) * right, up), cr(up, far_point + f32(half_h) * right),
+            cr(far_point + f32(half_v) * up, right), cr(right, far_point - f32(half_v) * up)])
+        nrm = np.sqrt((normals * normals)[:, 0] + (normals * normals)[:, 1] + (normals * normals)[:, 2])
+        normals = (normals / np.maximum(nrm, f32(1e-12))[:, None]).astype(np.float32)
+        pts = np.stack([near_point + t, far_point + t, t, t, t, t]).astype(np.float32)
+        return normals, pts
+
+    def pack(self, c2w, frustum_radius=6.0, tile_radius=6.0):
+        """-> float32[56], the `cam` block of gsgen_frame_geometry (include/gsgen_hip.h)."""
+        c2w = np.asarray(c2w, np.float32).reshape(3, 4)
+        normals, pts = self.get_frustum(c2w)
+        cam = np.zeros(56, np.float32)
+        cam[:12] = c2w.reshape(-1)
+        cam[12:16] = (self.fx, self.fy, self.cx, self.cy)
+        cam[16], cam[17] = frustum_radius, tile_radius
+        cam[20:38] = normals.reshape(-1)
+        cam[38:56] = pts.reshape(-1)
+        return cam
+
+
+def n_tiles(H, W, tile_size=16):
+    return (H + tile_size - 1) // tile_size, (W + tile_size - 1) // tile_size
+
+
+class FrameBuffers:
+    """Device buffers of the fused path for one (N, W, H) shape.  D_cap is the capacity of the
+    (tile, Gaussian) pair list; `ensure_capacity()` grows it after an overflow."""
+
+    def __init__(self, N, W, H, device, D_cap=None):
+        self.N, self.W, self.H, self.device = N, W, H, device
+        self.nth, self.ntw = n_tiles(H, W)
+        f = dict(device=device, dtype=torch.float32)
+        self.mean2d = torch.empty(N, 2, **f)
+        self.cov2d = torch.empty(N, 2, 2, **f)
+        self.depth = torch.empty(N, 1, **f)
+        self.mask = torch.empty(N, device=device, dtype=torch.bool)
+        self.start = torch.empty(self.nth * self.ntw, device=device, dtype=torch.int32)
+        self.end = torch.empty_like(self.start)
+        self.total = torch.zeros(1, device=device, dtype=torch.int32)
+        self.D_cap = 0
+        self._alloc_pairs(D_cap if D_cap else max(16 * N, 1 << 16))
+
+    def _alloc_pairs(self, D_cap):
+        self.D_cap = int(D_cap)
+        self.ids = torch.empty(self.D_cap, device=self.device, dtype=torch.int32)
+        nbytes = _capi.load().frame_workspace_bytes(self.N, self.D_cap, self.nth * self.ntw)
+        self.ws = torch.empty(nbytes, device=self.device, dtype=torch.uint8)
+
+    def ensure_capacity(self):
+        """Host-side check (one sync): did the last frame fit?  Grows the pair buffers if not."""
+        need = int(self.total.item())
+        if need > self.D_cap:
+            self._alloc_pairs(int(need * 1.25) + 1024)
+            return False
+        return True
+
+
+def frame_geometry(mean, qvec, svec, cam_dev, buf):
+    """cull + project + AABB + bin + per-tile sort in one enqueue (no host sync)."""
+    with torch.cuda.device(mean.device):
+        _capi.load().frame_geometry(
+            buf.N, _p(mean), _p(qvec), _p(svec), _p(cam_dev), buf.W, buf.H, buf.D_cap, _p(buf.mean2d),
+            _p(buf.cov2d), _p(buf.depth), _p(buf.mask), _p(buf.ids), _p(buf.start), _p(buf.end),
+            _p(buf.total), _p(buf.ws), buf.ws.numel(), _stream(mean))
+
+
+class _render_frame(torch.autograd.Function):
+    """Fused differentiable frame: (mean, qvec, svec, alpha, sh|color) -> rgb [H,W,3] (+T)."""
+
+    @staticmethod
+    def forward(ctx, mean, qvec, svec, alpha, col, cam_dev, topleft, rot, bg_rgb, buf, cam_info, C,
+                thresh, detach_depth):
+        mean, qvec, svec = mean.contiguous(), qvec.contiguous(), svec.contiguous()
+        alpha, col = alpha.contiguous(), col.contiguous()
+        lib = _capi.load()
+        H, W = buf.H, buf.W
+        dev = mean.device
+        frame_geometry(mean, qvec, svec, cam_dev, buf)
+        out = torch.zeros(H, W, 3, device=dev, dtype=torch.float32)
+        T = torch.ones(H, W, 1, device=dev, dtype=torch.float32)
+        psx, psy = 1.0 / cam_info.fx, 1.0 / cam_info.fy
+        s = _stream(mean)
+        with torch.cuda.device(dev):
+            if C > 0:
+                lib.vol_render_sh(buf.N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col), _p(alpha),
+                                  _p(buf.start), _p(buf.end), _p(buf.ids), _p(out), _p(topleft), _p(rot),
+                                  16, buf.nth, buf.ntw, psx, psy, H, W, C, thresh, _p(bg_rgb), _p(T), s)
+            else:
+                lib.vol_render_start_end_with_T(buf.N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col),
+                                                _p(alpha), _p(buf.start), _p(buf.end), _p(buf.ids),
+                                                _p(out), _p(topleft), 16, buf.nth, buf.ntw, psx, psy, H,
+                                                W, thresh, _p(T), s)
+                if bg_rgb is not None:
+                    out = out + T * bg_rgb
+        ctx.save_for_backward(mean, qvec, svec, alpha, col, cam_dev, topleft, rot, out)
+        ctx.buf, ctx.cam_info, ctx.C, ctx.thresh, ctx.detach = buf, cam_info, C, thresh, detach_depth
+        ctx.has_bg = bg_rgb is not None
+        ctx.mark_non_differentiable(T)
+        return out, T
+
+    @staticmethod
+    def backward(ctx, grad, _gT):
+        mean, qvec, svec, alpha, col, cam_dev, topleft, rot, out = ctx.saved_tensors
+        buf, ci, C, thresh = ctx.buf, ctx.cam_info, ctx.C, ctx.thresh
+        lib = _capi.load()
+        dev = mean.device
+        H, W, N = buf.H, buf.W, buf.N
+        grad = grad.contiguous()
+        g2 = torch.zeros(7 * N, device=dev, dtype=torch.float32)  # one memset: mean2d | cov2d | alpha
+        g_mean2d, g_cov2d, g_alpha = g2[:2 * N].view(N, 2), g2[2 * N:6 * N].view(N, 4), g2[6 * N:]
+        g_col = torch.zeros_like(col)
+        psx, psy = 1.0 / ci.fx, 1.0 / ci.fy
+        s = _stream(mean)
+        with torch.cuda.device(dev):
+            if C > 0:
+                lib.vol_render_backward_sh(N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col), _p(alpha),
+                                           _p(buf.start), _p(buf.end), _p(buf.ids), _p(out), _p(g_mean2d),
+                                           _p(g_cov2d), _p(g_col), _p(g_alpha), _p(grad), _p(topleft),
+                                           _p(rot), 16, buf.nth, buf.ntw, psx, psy, H, W, C, thresh, None, s)
+            else:
+                lib.vol_render_backward_start_end(N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col),
+                                                  _p(alpha), _p(buf.start), _p(buf.end), _p(buf.ids),
+                                                  _p(out), _p(g_mean2d), _p(g_cov2d), _p(g_col),
+                                                  _p(g_alpha), _p(grad), _p(topleft), 16, buf.nth,
+                                                  buf.ntw, psx, psy, H, W, thresh, s)
+            g_mean = torch.empty_like(mean); g_qvec = torch.empty_like(qvec); g_svec = torch.empty_like(svec)
+            lib.project_gaussians_backward_masked(N, _p(mean), _p(qvec), _p(svec), _p(cam_dev),
+                                                  int(ctx.detach), _p(buf.mask), _p(g_mean2d), _p(g_cov2d),
+                                                  None, _p(g_mean), _p(g_qvec), _p(g_svec), s)
+        return (g_mean, g_qvec, g_svec, g_alpha, g_col) + (None,) * 9
+
+
+def render_frame(mean, qvec, svec, alpha, col, cam_info, c2w, buf, C=0, bg_rgb=None, thresh=1e-4,
+                 frustum_radius=6.0, tile_radius=6.0, detach_depth=True):
+    """One differentiable render of `cam_info` at pose `c2w` ([3,4], host array or tensor).
+
+    col is sh_coeffs [N,3,C*C] when C in 1..4, or post-activation rgb [N,3] when C == 0.
+    Culled Gaussians keep their index (no mask gathers); gradients come back for every input.
+    Returns (rgb [H,W,3], T [H,W,1])."""
+    c2w_np = c2w.detach().cpu().numpy() if isinstance(c2w, torch.Tensor) else np.asarray(c2w)
+    dev = mean.device
+    cam_dev = torch.from_numpy(cam_info.pack(c2w_np, frustum_radius, tile_radius)).to(dev, non_blocking=True)
+    topleft = torch.tensor([-cam_info.cx / cam_info.fx, -cam_info.cy / cam_info.fy], dtype=torch.float32).to(dev)
+    rot = torch.from_numpy(np.ascontiguousarray(c2w_np[:3, :3], np.float32).reshape(-1)).to(dev)
+    return _render_frame.apply(mean, qvec, svec, alpha, col, cam_dev, topleft, rot, bg_rgb, buf, cam_info,
+                               int(C), float(thresh), bool(detach_depth))

@@ -1,0 +1,168 @@
+/*
+ * gsgen_hip.h -- C ABI of libgsgen_hip.so, the MI355X (gfx950) rasterizer behind GSGEN's
+ * `_gs` extension.
+ *
+ * The reference binds this path through a pybind11/torch module (`gs/src/bindings.cpp:5-82`,
+ * prototypes `gs/src/render.h:3-155`) whose wrappers (`gs/src/render.cu`) unpack tensors to
+ * raw pointers and call `*_cuda(...)` launchers.  The entry points below are those launchers'
+ * replacement: plain pointers + sizes + a hipStream_t, no torch types.  All pointers are DEVICE
+ * pointers unless stated.  Every function returns 0 on success, a positive hipError_t value
+ * when a HIP call failed, or a negative GSGEN_E* code for a violated precondition; nothing
+ * calls exit() (the reference's cudaCheck does: gs/src/include/common.h:56-72).
+ *
+ * Ownership follows the reference: the caller allocates every array, outputs
+ * included, and pre-initialises them as the reference's Python does (out = 0, T = 1,
+ * start/end = -1, grad_* = 0 -- the backward entry points ACCUMULATE into grad_*).
+ * All work is enqueued on `stream`; no entry point synchronises the device or allocates.
+ *
+ * Layouts (row-major, fp32 unless noted): mean2d [N,2]; cov2d [N,2,2]; color [N,3];
+ * alpha [N]; scalar [N]; sh_coeffs [N,3,C*C]; start/end int32 [n_tiles_h*n_tiles_w];
+ * gaussian_ids int32 [D]; out [H,W,3] (or [H,W] scalar); T [H,W]; topleft [2]; bg_rgb [3].
+ * Only tile_size == 16 is implemented (the reference's only configured value,
+ * conf/base.yaml:131); anything else returns GSGEN_EUNSUPPORTED.
+ */
+#ifndef GSGEN_HIP_H
+#define GSGEN_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *gsgen_stream_t; /* hipStream_t; NULL = the legacy default stream */
+
+#define GSGEN_EUNSUPPORTED (-2) /* tile_size != 16, C not in 1..4 */
+#define GSGEN_EINVAL (-3)       /* null pointer / inconsistent sizes */
+#define GSGEN_EWORKSPACE (-4)   /* workspace too small */
+
+const char *gsgen_version(void);
+/* HIP error string for positive return codes, own text for negative ones. */
+const char *gsgen_error_string(int code);
+
+/* ---- frustum cull ------------------------------------------------------------------
+ * replaces culling_gaussian_bsphere, gs/src/render.h:3 -> render.cu:16-44 ->
+ * culling_gaussian_bsphere_cuda culling.h:21-33.  mask is bool[N] (1 byte each). */
+int gsgen_culling_gaussian_bsphere(uint32_t N, const float *mean, const float *qvec,
+                                   const float *svec, const float *normal /*[6,3]*/,
+                                   const float *pts /*[6,3]*/, uint8_t *mask, float thresh,
+                                   gsgen_stream_t stream);
+
+/* ---- tile binning + per-tile depth sort ---------------------------------------------
+ * replaces tile_culling_aabb_start_end, render.h:61 -> render.cu:381-398 ->
+ * tile_culling_aabb_start_end_cuda aabb_culling.h:192-260.  D = gaussian_ids length =
+ * sum over Gaussians of (br-tl+1) products (the caller's N_with_dub).  Unlike the reference
+ * there is no cudaMalloc/cudaFree/blocking memcpy: temporaries live in `workspace`. */
+size_t gsgen_tile_culling_workspace_bytes(uint32_t N, uint32_t D, uint32_t n_tiles);
+int gsgen_tile_culling_aabb_start_end(uint32_t N, uint32_t D, uint32_t n_tiles_h,
+                                      uint32_t n_tiles_w, const int *aabb_topleft,
+                                      const int *aabb_bottomright, const float *depth,
+                                      int *gaussian_ids, int *start, int *end, void *workspace,
+                                      size_t workspace_bytes, gsgen_stream_t stream);
+
+/* ---- RGB compositing -----------------------------------------------------------------
+ * forward with T: tile_based_vol_rendering_start_end_with_T render.h:149 -> render.cu:989-1012
+ *   -> ..._cuda_with_T vol_render.h:1064-1078.  T may be NULL (= tile_based_vol_rendering_start_end,
+ *   render.h:65 -> vol_render.h:849-864).
+ * backward: tile_based_vol_rendering_backward_start_end render.h:73 -> render.cu:426-482 ->
+ *   vol_render.h:975-992.  `out` is the saved forward image INCLUDING T*bg. */
+int gsgen_vol_render_start_end_with_T(uint32_t N, uint32_t D, const float *mean, const float *cov,
+                                      const float *color, const float *alpha, const int *start,
+                                      const int *end, const int *gaussian_ids, float *out,
+                                      const float *topleft, uint32_t tile_size, uint32_t n_tiles_h,
+                                      uint32_t n_tiles_w, float pixel_size_x, float pixel_size_y,
+                                      uint32_t H, uint32_t W, float thresh, float *T,
+                                      gsgen_stream_t stream);
+int gsgen_vol_render_backward_start_end(uint32_t N, uint32_t D, const float *mean, const float *cov,
+                                        const float *color, const float *alpha, const int *start,
+                                        const int *end, const int *gaussian_ids, const float *out,
+                                        float *grad_mean, float *grad_cov, float *grad_color,
+                                        float *grad_alpha, const float *grad_out,
+                                        const float *topleft, uint32_t tile_size,
+                                        uint32_t n_tiles_h, uint32_t n_tiles_w, float pixel_size_x,
+                                        float pixel_size_y, uint32_t H, uint32_t W, float thresh,
+                                        gsgen_stream_t stream);
+
+/* ---- scalar compositing (depth / opacity / z^2 heads) ---------------------------------
+ * tile_based_vol_rendering_scalar render.h:131 -> vol_render_scalar.h:47-102;
+ * tile_based_vol_rendering_scalar_backward render.h:139 -> vol_render_scalar.h:148-234. */
+int gsgen_vol_render_scalar(uint32_t N, uint32_t D, const float *mean, const float *cov,
+                            const float *scalar, const float *alpha, const int *start,
+                            const int *end, const int *gaussian_ids, float *out,
+                            const float *topleft, uint32_t tile_size, uint32_t n_tiles_h,
+                            uint32_t n_tiles_w, float pixel_size_x, float pixel_size_y, uint32_t H,
+                            uint32_t W, float thresh, float *T, gsgen_stream_t stream);
+int gsgen_vol_render_scalar_backward(uint32_t N, uint32_t D, const float *mean, const float *cov,
+                                     const float *scalar, const float *alpha, const int *start,
+                                     const int *end, const int *gaussian_ids, const float *out,
+                                     float *grad_mean, float *grad_cov, float *grad_scalar,
+                                     float *grad_alpha, const float *grad_out, const float *topleft,
+                                     uint32_t tile_size, uint32_t n_tiles_h, uint32_t n_tiles_w,
+                                     float pixel_size_x, float pixel_size_y, uint32_t H, uint32_t W,
+                                     float thresh, gsgen_stream_t stream);
+
+/* ---- spherical-harmonic compositing ---------------------------------------------------
+ * tile_based_vol_rendering_sh render.h:83 / _sh_with_bg render.h:113 -> vol_render_sh.h:171-265,
+ * vol_render_bg.h:12-127;  backward render.h:91 / :121 -> vol_render_sh.h:353-480,
+ * vol_render_bg.h:131-265.  `c2w` is read as the reference reads it: 9 consecutive floats =
+ * three packed rows (vol_render_sh.h:48-55).  bg_rgb == NULL selects the no-background
+ * variant; with bg_rgb the forward adds bg*T and writes bg to empty tiles, and `out` handed to
+ * the backward includes it.  T (optional, may be NULL) additionally receives the final
+ * transmittance -- an output the reference does not have. */
+int gsgen_vol_render_sh(uint32_t N, uint32_t D, const float *mean, const float *cov,
+                        const float *sh_coeffs, const float *alpha, const int *start,
+                        const int *end, const int *gaussian_ids, float *out, const float *topleft,
+                        const float *c2w, uint32_t tile_size, uint32_t n_tiles_h,
+                        uint32_t n_tiles_w, float pixel_size_x, float pixel_size_y, uint32_t H,
+                        uint32_t W, uint32_t C, float thresh, const float *bg_rgb, float *T,
+                        gsgen_stream_t stream);
+int gsgen_vol_render_backward_sh(uint32_t N, uint32_t D, const float *mean, const float *cov,
+                                 const float *sh_coeffs, const float *alpha, const int *start,
+                                 const int *end, const int *gaussian_ids, const float *out,
+                                 float *grad_mean, float *grad_cov, float *grad_sh_coeffs,
+                                 float *grad_alpha, const float *grad_out, const float *topleft,
+                                 const float *c2w, uint32_t tile_size, uint32_t n_tiles_h,
+                                 uint32_t n_tiles_w, float pixel_size_x, float pixel_size_y,
+                                 uint32_t H, uint32_t W, uint32_t C, float thresh,
+                                 const float *bg_rgb, gsgen_stream_t stream);
+
+/* ---- additive entry points (no native counterpart in the reference) -------------------
+ * EWA projection: the reference does this in PyTorch (gs/renderer.py:366-421); same outputs.
+ * c2w is a device pointer to the row-major [3,4] pose.  JW may be NULL.  The backward
+ * OVERWRITES g_mean [N,3], g_qvec [N,4], g_svec [N,3]; g_depth may be NULL. */
+int gsgen_project_gaussians(uint32_t N, const float *mean, const float *qvec, const float *svec,
+                            const float *c2w, float *mean2d, float *cov2d, float *JW, float *depth,
+                            gsgen_stream_t stream);
+int gsgen_project_gaussians_backward(uint32_t N, const float *mean, const float *qvec,
+                                     const float *svec, const float *c2w, int detach_depth,
+                                     const float *g_mean2d, const float *g_cov2d,
+                                     const float *g_depth, float *g_mean, float *g_qvec,
+                                     float *g_svec, gsgen_stream_t stream);
+/* AABB tile rectangles + pair count on the device (gs/culling.py:8-37 without the .item()
+ * host sync): writes aabb_topleft/bottomright int32 [N,2] and *total (device uint32, zeroed
+ * inside the call) = N_with_dub. */
+int gsgen_tile_culling_aabb_count(uint32_t N, const float *mean2d, const float *cov2d,
+                                  uint32_t tile_size, float fx, float fy, float cx, float cy,
+                                  uint32_t w, uint32_t h, float D, int *aabb_topleft,
+                                  int *aabb_bottomright, uint32_t *total, gsgen_stream_t stream);
+
+/* Fused frame: frustum cull + projection + AABB + binning + per-tile sort in one enqueue with
+ * no host round trip (gs/gaussian_splatting.py:1208-1295 without the mask gathers and syncs).
+ * `cam` (DEVICE, 56 floats): [0..11] c2w row-major 3x4; [12..15] fx, fy, cx, cy;
+ * [16] frustum_culling_radius (<= 0: skip the cull); [17] tile_culling_radius (the reference's
+ * D = 6.0); [18..19] spare; [20..37] frustum plane normals [6,3]; [38..55] plane points [6,3]
+ * (both as utils/camera.py:260-294 computes them; gsgen_amd.camera packs this on the host).
+ * Culled Gaussians keep their index and emit no pairs.  gaussian_ids has capacity D_cap; the
+ * true pair count is written to *total (device); if it exceeds D_cap nothing is binned,
+ * start/end are all -1 and *total still holds the required size. */
+size_t gsgen_frame_workspace_bytes(uint32_t N, uint32_t D_cap, uint32_t n_tiles);
+int gsgen_frame_geometry(uint32_t N, const float *mean, const float *qvec, const float *svec,
+                         const float *cam, uint32_t W, uint32_t H, uint32_t D_cap, float *mean2d,
+                         float *cov2d, float *depth, uint8_t *mask, int *gaussian_ids, int *start,
+                         int *end, uint32_t *total, void *workspace, size_t workspace_bytes,
+                         gsgen_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSGEN_HIP_H */
