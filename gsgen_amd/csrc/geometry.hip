@@ -284,8 +284,7 @@ __global__ void __launch_bounds__(kThreads)
 k_frame_project(uint32_t N, const float *__restrict__ mean, const float *__restrict__ qvec,
                 const float *__restrict__ svec, const float *__restrict__ cam, int w, int h, int ntw,
                 float *__restrict__ mean2d, float *__restrict__ cov2d, float *__restrict__ depth,
-                uint8_t *__restrict__ mask, int *__restrict__ tl, int *__restrict__ br,
-                uint32_t *__restrict__ tile_count) {
+                uint8_t *__restrict__ mask, int *__restrict__ tl, int *__restrict__ br) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   float Rc[9], t[3];
@@ -315,8 +314,7 @@ k_frame_project(uint32_t N, const float *__restrict__ mean, const float *__restr
   mask[i] = in ? 1 : 0;
   *reinterpret_cast<int2 *>(tl + 2 * (size_t)i) = make_int2(rc.x0, rc.y0);
   *reinterpret_cast<int2 *>(br + 2 * (size_t)i) = make_int2(rc.x1, rc.y1);
-  for (int ty = rc.y0; ty <= rc.y1; ++ty)
-    for (int tx = rc.x0; tx <= rc.x1; ++tx) atomicAdd(&tile_count[ty * ntw + tx], 1u);
+  (void)ntw;
 }
 
 static inline dim3 grid_for(uint32_t n) { return dim3((n + kThreads - 1) / kThreads); }
@@ -391,11 +389,10 @@ int gsgen_tile_culling_aabb_count(uint32_t N, const float *mean2d, const float *
 // used by binning.hip (gsgen_frame_geometry)
 int gsgen_internal_frame_project(uint32_t N, const float *mean, const float *qvec, const float *svec,
                                  const float *cam, int w, int h, int ntw, float *mean2d, float *cov2d,
-                                 float *depth, uint8_t *mask, int *tl, int *br, uint32_t *tile_count,
-                                 gsgen_stream_t stream) {
+                                 float *depth, uint8_t *mask, int *tl, int *br, gsgen_stream_t stream) {
   if (N == 0) return 0;
   hipLaunchKernelGGL(k_frame_project, grid_for(N), dim3(kThreads), 0, (hipStream_t)stream, N, mean,
-                     qvec, svec, cam, w, h, ntw, mean2d, cov2d, depth, mask, tl, br, tile_count);
+                     qvec, svec, cam, w, h, ntw, mean2d, cov2d, depth, mask, tl, br);
   return (int)hipGetLastError();
 }
 

@@ -50,6 +50,7 @@ inline unsigned long long __ballot(int p) { return simt::ballot(p); }
 template <typename T> inline T __shfl_xor(T v, int m, int = 64) { return simt::shfl_xor(v, m); }
 template <typename T> inline T __shfl(T v, int l, int = 64) { return simt::shfl_idx(v, l); }
 template <typename T> inline T __shfl_down(T v, int d, int = 64) { return simt::shfl_down(v, d); }
+inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 
 inline unsigned __float_as_uint(float f) { unsigned u; std::memcpy(&u, &f, 4); return u; }

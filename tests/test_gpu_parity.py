@@ -24,9 +24,17 @@ def dev():
     return torch.device("cuda:0")
 
 
+_KEEP = []  # p(T_(x)) hands a raw address to the C ABI: keep the tensor alive past the call
+
+
 def T_(a, dtype=None):
     t = torch.from_numpy(np.ascontiguousarray(a)).to(dev())
-    return t.to(dtype) if dtype is not None else t
+    t = t.to(dtype) if dtype is not None else t
+    _KEEP.append(t)
+    if len(_KEEP) > 256:
+        torch.cuda.synchronize()
+        del _KEEP[:128]
+    return t
 
 
 def lib():
