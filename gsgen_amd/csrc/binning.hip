@@ -209,6 +209,17 @@ k_sort_tiles(uint32_t T, const uint32_t *__restrict__ tile_off, const uint32_t *
   }
 }
 
+// ---- self test of the cross-lane primitives (tests/ only; exported for the parity suite) ----
+template <int P>
+__global__ void __launch_bounds__(64) k_selftest_reduce_scatter(const float *__restrict__ in, float *__restrict__ out) {
+  float v[P];
+  const int lane = lane_id();
+#pragma unroll
+  for (int i = 0; i < P; ++i) v[i] = in[lane * P + i];
+  wave_reduce_scatter<P>(v);
+  out[lane] = v[0];
+}
+
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct BinWs {
@@ -272,6 +283,19 @@ int gsgen_internal_frame_project(uint32_t N, const float *mean, const float *qve
                                  float *depth, uint8_t *mask, int *tl, int *br, gsgen_stream_t stream);
 
 const char *gsgen_version(void) { return "gsgen_hip 0.1 (gfx950)"; }
+
+int gsgen_selftest_reduce_scatter(uint32_t P, const float *in /*[64,P]*/, float *out /*[64]*/,
+                                  gsgen_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  switch (P) {
+    case 8: hipLaunchKernelGGL((k_selftest_reduce_scatter<8>), dim3(1), dim3(64), 0, s, in, out); break;
+    case 16: hipLaunchKernelGGL((k_selftest_reduce_scatter<16>), dim3(1), dim3(64), 0, s, in, out); break;
+    case 32: hipLaunchKernelGGL((k_selftest_reduce_scatter<32>), dim3(1), dim3(64), 0, s, in, out); break;
+    case 64: hipLaunchKernelGGL((k_selftest_reduce_scatter<64>), dim3(1), dim3(64), 0, s, in, out); break;
+    default: return GSGEN_EUNSUPPORTED;
+  }
+  return (int)hipGetLastError();
+}
 
 const char *gsgen_error_string(int code) {
   if (code == 0) return "success";

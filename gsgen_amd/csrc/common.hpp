@@ -28,29 +28,110 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// ---- cross-lane exchange on the VALU (no LDS traffic) ---------------------------------------
+// xchg_add<H>(lo, hi): with partner = lane ^ H, lanes with (lane & H) == 0 return
+// lo + partner.lo, the others return hi + partner.hi.  One reduce-scatter step for a pair of
+// components.  H = 32 / 16 use the gfx950 v_permlane{32,16}_swap instructions (one swap + one
+// add), H = 8 / 4 two DPP row shifts restricted by bank masks (+ one add), H = 2 / 1 quad
+// permutes and a select.  (The generic __shfl_xor path lowers to ds_bpermute_b32 through the
+// LDS crossbar; the backward spent half of its time there.)
+__device__ __forceinline__ float as_f(unsigned u) { return __uint_as_float(u); }
+__device__ __forceinline__ unsigned as_u(float f) { return __float_as_uint(f); }
+
+template <int CTRL, int BANK_MASK>
+__device__ __forceinline__ float dpp_mov(float old, float src) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, 0xf,
+                                                    BANK_MASK, false));
+}
+constexpr int kDppQuadXor1 = 0xB1;  // quad_perm:[1,0,3,2]
+constexpr int kDppQuadXor2 = 0x4E;  // quad_perm:[2,3,0,1]
+constexpr int kDppRowShl = 0x100;   // row_shl:n -> lane i reads lane i+n of its 16-lane row
+constexpr int kDppRowShr = 0x110;   // row_shr:n -> lane i reads lane i-n
+
+template <int H>
+__device__ __forceinline__ float xchg_add(float lo, float hi) {
+  if constexpr (H == 32) {
+    const auto r = __builtin_amdgcn_permlane32_swap(as_u(lo), as_u(hi), false, false);
+    return as_f(r[0]) + as_f(r[1]);
+  } else if constexpr (H == 16) {
+    const auto r = __builtin_amdgcn_permlane16_swap(as_u(lo), as_u(hi), false, false);
+    return as_f(r[0]) + as_f(r[1]);
+  } else if constexpr (H == 8) {
+    // banks (4-lane groups of a row) 0,1 are class 0, banks 2,3 class 1
+    const float t = dpp_mov<kDppRowShl + 8, 0x3>(hi, lo);  // class 0: partner.lo ; class 1: own hi
+    const float u = dpp_mov<kDppRowShr + 8, 0xC>(lo, hi);  // class 1: partner.hi ; class 0: own lo
+    return t + u;
+  } else if constexpr (H == 4) {
+    const float t = dpp_mov<kDppRowShl + 4, 0x5>(hi, lo);
+    const float u = dpp_mov<kDppRowShr + 4, 0xA>(lo, hi);
+    return t + u;
+  } else {
+    static_assert(H == 2 || H == 1, "H must be a power of two <= 32");
+    constexpr int ctrl = (H == 2) ? kDppQuadXor2 : kDppQuadXor1;
+    const float a = lo + dpp_mov<ctrl, 0xf>(lo, lo);
+    const float b = hi + dpp_mov<ctrl, 0xf>(hi, hi);
+    return (lane_id() & H) ? b : a;
+  }
+}
+
+// all-lanes xor-butterfly step on a single value: v + v[lane ^ H]
+template <int H>
+__device__ __forceinline__ float xor_add(float v) { return xchg_add<H>(v, v); }
+
 // Reduce-scatter over the 64 lanes of a wave.  v[0..P) are per-lane partial sums of P
 // components (P a power of two <= 64).  On return v[0] in lane l holds the wave-wide total of
-// component (l & (P-1)).  Costs P-1 exchanges for the scatter phase instead of 6*P for P
+// component (l & (P-1)).  P-1 exchanges for the scatter phase instead of 6*P for P
 // independent butterflies.
+template <int P, int H>
+__device__ __forceinline__ void reduce_scatter_step(float (&v)[P]) {
+  if constexpr (H >= 1) {
+#pragma unroll
+    for (int i = 0; i < H; ++i) v[i] = xchg_add<H>(v[i], v[i + H]);
+    reduce_scatter_step<P, H / 2>(v);
+  }
+}
+template <int P, int M>
+__device__ __forceinline__ float reduce_rest(float x) {
+  if constexpr (M >= P) {
+    return reduce_rest<P, M / 2>(xor_add<M>(x));
+  } else {
+    return x;
+  }
+}
 template <int P>
 __device__ __forceinline__ void wave_reduce_scatter(float (&v)[P]) {
   static_assert(P >= 1 && P <= 64 && (P & (P - 1)) == 0, "P must be a power of two <= 64");
-  const int lane = lane_id();
-  // scatter phase: masks P/2, P/4, ... 1
-#pragma unroll
-  for (int h = P / 2; h >= 1; h >>= 1) {
-    const bool up = (lane & h) != 0;
-#pragma unroll
-    for (int i = 0; i < h; ++i) {
-      const float lo = v[i], hi = v[i + h];
-      const float send = up ? lo : hi;
-      const float keep = up ? hi : lo;
-      v[i] = keep + __shfl_xor(send, h, 64);
-    }
-  }
-  // remaining lanes-with-equal-(l & (P-1)) hold partials of the same component
-#pragma unroll
-  for (int m = 32; m >= P; m >>= 1) v[0] += __shfl_xor(v[0], m, 64);
+  reduce_scatter_step<P, P / 2>(v);
+  // lanes with equal (l & (P-1)) hold partials of the same component
+  v[0] = reduce_rest<P, 32>(v[0]);
+}
+
+// two packed fp32 values: arithmetic on v2f lowers to v_pk_mul/add/fma_f32 (one VALU issue for
+// two lanes' worth of work per thread)
+typedef float v2f __attribute__((vector_size(8)));
+__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return a * b + c; }
+__device__ __forceinline__ v2f splat2(float a) { return v2f{a, a}; }
+
+// Workgroup -> tile map that is both XCD-local and XCD-balanced.  Workgroup b runs on XCD
+// b % 8 (observed dispatch, speed only).  The tile grid is cut into 4x4-tile super-tiles;
+// super-tile s belongs to XCD s % 8, so every XCD owns small clusters spread over the whole
+// image (the image centre carries lists several times longer than the border -- handing each
+// XCD a contiguous band of rows leaves the XCDs with the border rows idle), while the 16
+// neighbouring tiles of a cluster share most of their Gaussians in that XCD's private L2.
+// Launch tile_map_blocks() workgroups; some map outside the grid and simply exit.
+__host__ __device__ __forceinline__ uint32_t tile_map_blocks(int ntw, int nth) {
+  const uint32_t S = (uint32_t)(((ntw + 3) >> 2) * ((nth + 3) >> 2));
+  return ((S + 7u) >> 3) * 8u * 16u;
+}
+__device__ __forceinline__ bool tile_of_block(uint32_t b, int ntw, int nth, int &tx, int &ty) {
+  const uint32_t xcd = b & 7u, idx = b >> 3;
+  const uint32_t j = idx >> 4, k = idx & 15u;
+  const uint32_t sw = (uint32_t)((ntw + 3) >> 2), sh = (uint32_t)((nth + 3) >> 2);
+  const uint32_t sidx = xcd + 8u * j;
+  if (sidx >= sw * sh) return false;
+  tx = (int)((sidx % sw) * 4u + (k & 3u));
+  ty = (int)((sidx / sw) * 4u + (k >> 2));
+  return tx < ntw && ty < nth;
 }
 
 // Bijective remap of the linear workgroup index so that each XCD (workgroup b lands on XCD

@@ -24,6 +24,8 @@
 // (fp64 / uncontracted fp32), so the discontinuous decision is the reference's.  Forward and
 // backward share eval code, so the backward's recomputed prefix equals the forward bit for
 // bit (the invariant the reference asserts at vol_render_sh.h:452-454).
+#include <stdlib.h>
+
 #include "common.hpp"
 #include "../../include/gsgen_hip.h"
 
@@ -41,6 +43,7 @@ struct CompParams {
   float *g_mean, *g_cov, *g_col, *g_alpha;
   int ntw, nth, H, W;
   float psx, psy, thresh;
+  int dbg;  // experiment switches (GSGEN_DBG), 0 in production
 };
 
 // ---- reference-arithmetic Gaussian evaluations (rare path) ------------------------------
@@ -115,6 +118,11 @@ struct Traits {
   // value) alpha(1) colour/scalar/sh(NCOL)
   static constexpr int NCOMP = 7 + NCOL;
   static constexpr int P = NCOMP <= 8 ? 8 : (NCOMP <= 16 ? 16 : (NCOMP <= 32 ? 32 : 64));
+  // LDS layout of the SH coefficients: each channel padded to a multiple of 4 floats so that
+  // a channel is read as aligned float4s and multiplied as (k, k+1) pairs by v_pk_fma_f32
+  static constexpr int CCP = (MODE == MODE_SH) ? ((CC + 3) & ~3) : CC;
+  static constexpr int NCOLP = (MODE == MODE_SH) ? 3 * CCP : NCOL;
+  static constexpr int NPAIR = CCP / 2;
 };
 
 // ---- LDS staging ---------------------------------------------------------------------------
@@ -125,7 +133,7 @@ struct Stage {
   float c0[kBatch], c1[kBatch], c2[kBatch], c3[kBatch];
   float p0[kBatch], p1[kBatch], p2[kBatch];  // RGB/scalar: scaled Cholesky factor; SH: p0 = kk, p1 = 1/det
   int id[kBatch];
-  alignas(16) float col[kBatch * TR::NCOL];
+  alignas(16) float col[kBatch * TR::NCOLP];
 };
 
 template <int MODE, int CB, int NT>
@@ -178,18 +186,20 @@ __device__ __forceinline__ void stage_batch(Stage<MODE, CB> &S, const CompParams
     S.p0[t] = p0; S.p1[t] = p1; S.p2[t] = p2;
   }
   if constexpr (MODE == MODE_SH) __syncthreads();  // S.id is consumed below by other lanes
-  // colour / scalar / SH coefficients: NCOL contiguous floats per record
-  if constexpr (TR::NCOL % 4 == 0) {
+  // colour / scalar / SH coefficients: NCOL contiguous floats per record in HBM
+  if constexpr (MODE == MODE_SH && TR::CCP == TR::CC) {
     constexpr int Q = TR::NCOL / 4;
     for (int e = t; e < nb * Q; e += NT) {
       const int g = e / Q, k = e - g * Q;
       const float4 v = *reinterpret_cast<const float4 *>(p.col + (size_t)S.id[g] * TR::NCOL + 4 * k);
-      *reinterpret_cast<float4 *>(&S.col[g * TR::NCOL + 4 * k]) = v;
+      *reinterpret_cast<float4 *>(&S.col[g * TR::NCOLP + 4 * k]) = v;
     }
   } else if constexpr (MODE == MODE_SH) {
+    // channel stride CC in HBM -> CCP in LDS; the pad lanes were zeroed once at kernel start
     for (int e = t; e < nb * TR::NCOL; e += NT) {
       const int g = e / TR::NCOL, k = e - g * TR::NCOL;
-      S.col[e] = p.col[(size_t)S.id[g] * TR::NCOL + k];
+      const int c = k / TR::CC, kk = k - c * TR::CC;
+      S.col[g * TR::NCOLP + c * TR::CCP + kk] = p.col[(size_t)S.id[g] * TR::NCOL + k];
     }
   } else {
     if (t < nb) {
@@ -251,8 +261,9 @@ __global__ void __launch_bounds__(256 / PPL) k_composite_fwd(CompParams p) {
   constexpr int NCH = TR::NCH;
   __shared__ Stage<MODE, CB> S;
 
-  const uint32_t tile = xcd_swizzle(blockIdx.x, gridDim.x);
-  const int tx = (int)(tile % (uint32_t)p.ntw), ty = (int)(tile / (uint32_t)p.ntw);
+  int tx, ty;
+  if (!tile_of_block(blockIdx.x, p.ntw, p.nth, tx, ty)) return;  // uniform over the workgroup
+  const int tile = ty * p.ntw + tx;
   const int st = p.start[tile];
   const int n = (st < 0) ? 0 : (p.end[tile] - st);
   const int t = (int)threadIdx.x;
@@ -284,9 +295,13 @@ __global__ void __launch_bounds__(256 / PPL) k_composite_fwd(CompParams p) {
 #pragma unroll
   for (int j = 0; j < PPL; ++j) py[j] = pixel_coord(p.topleft[1], gy[j], p.psy);
 
-  // per-pixel SH basis (vol_render_sh.h:48-65, 210-216)
-  float Y[MODE == MODE_SH ? PPL : 1][MODE == MODE_SH ? TR::CC : 1];
+  // per-pixel SH basis (vol_render_sh.h:48-65, 210-216), kept as (k, k+1) pairs
+  v2f Yp[MODE == MODE_SH ? PPL : 1][MODE == MODE_SH ? TR::NPAIR : 1];
   if constexpr (MODE == MODE_SH) {
+    if constexpr (TR::CCP != TR::CC) {  // zero the pad lanes of the staged coefficients once
+      for (int e = t; e < kBatch * TR::NCOLP; e += NT) S.col[e] = 0.0f;
+      __syncthreads();
+    }
     float R[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) R[i] = p.rot[i];
@@ -297,7 +312,12 @@ __global__ void __launch_bounds__(256 / PPL) k_composite_fwd(CompParams p) {
       float dz = R[6] * px + R[7] * py[j] + R[8];
       const float len = sqrtf(dx * dx + dy * dy + dz * dz);
       dx /= len; dy /= len; dz /= len;
-      sh_basis<CB>(dx, dy, dz, Y[j]);
+      float Yf[TR::CCP];
+#pragma unroll
+      for (int k = 0; k < TR::CCP; ++k) Yf[k] = 0.0f;
+      sh_basis<CB>(dx, dy, dz, *reinterpret_cast<float (*)[TR::CC]>(&Yf[0]));
+#pragma unroll
+      for (int k = 0; k < TR::NPAIR; ++k) Yp[j][k] = v2f{Yf[2 * k], Yf[2 * k + 1]};
     }
   }
 
@@ -337,26 +357,44 @@ __global__ void __launch_bounds__(256 / PPL) k_composite_fwd(CompParams p) {
       }
       if (__ballot(any_con) == 0ull) continue;  // nobody in the wave sees this Gaussian
 
-      const float *cg = &S.col[g * TR::NCOL];
+      const float *cg = &S.col[g * TR::NCOLP];
+      if constexpr (MODE == MODE_SH) {
+        // Every lane evaluates all of its pixels; a pixel that does not contribute carries
+        // weight 0.  76 % of the evaluated pairs contribute on the headline workload, so the
+        // branch-free form wastes little and lets the 3 x CC dot products run as packed FMAs.
+        float w[PPL];
 #pragma unroll
-      for (int j = 0; j < PPL; ++j) {
-        if (con[j]) {
-          const float ag = r.a * G[j];
-          const float coeff = (r.a * Tr[j]) * G[j];
-          if constexpr (MODE == MODE_SH) {
+        for (int j = 0; j < PPL; ++j) w[j] = con[j] ? (r.a * Tr[j]) * G[j] : 0.0f;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-              float s = 0.0f;
+        for (int c = 0; c < 3; ++c) {
+          v2f q[TR::NPAIR];
 #pragma unroll
-              for (int k = 0; k < TR::CC; ++k) s += cg[c * TR::CC + k] * Y[j][k];
-              acc[j][c] += coeff * sigmoid_fast(s);
-            }
-          } else {
+          for (int k = 0; k < TR::NPAIR; ++k) q[k] = *reinterpret_cast<const v2f *>(cg + c * TR::CCP + 2 * k);
+#pragma unroll
+          for (int j = 0; j < PPL; ++j) {
+            v2f s2 = q[0] * Yp[j][0];
+#pragma unroll
+            for (int k = 1; k < TR::NPAIR; ++k) s2 = fma2(q[k], Yp[j][k], s2);
+            acc[j][c] += w[j] * sigmoid_fast(s2[0] + s2[1]);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < PPL; ++j) {
+          const float om = con[j] ? (1.0f - r.a * G[j]) : 1.0f;
+          Tr[j] *= om;
+          alive[j] = alive[j] && !(Tr[j] < p.thresh);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < PPL; ++j) {
+          if (con[j]) {
+            const float ag = r.a * G[j];
+            const float coeff = (r.a * Tr[j]) * G[j];
 #pragma unroll
             for (int c = 0; c < NCH; ++c) acc[j][c] += cg[c] * coeff;
+            Tr[j] *= (1.0f - ag);
+            alive[j] = !(Tr[j] < p.thresh);
           }
-          Tr[j] *= (1.0f - ag);
-          alive[j] = !(Tr[j] < p.thresh);
         }
       }
     }
@@ -398,8 +436,9 @@ __global__ void __launch_bounds__(256 / PPL) k_composite_bwd(CompParams p) {
   constexpr int P = TR::P;
   __shared__ Stage<MODE, CB> S;
 
-  const uint32_t tile = xcd_swizzle(blockIdx.x, gridDim.x);
-  const int tx = (int)(tile % (uint32_t)p.ntw), ty = (int)(tile / (uint32_t)p.ntw);
+  int tx, ty;
+  if (!tile_of_block(blockIdx.x, p.ntw, p.nth, tx, ty)) return;  // uniform over the workgroup
+  const int tile = ty * p.ntw + tx;
   const int st = p.start[tile];
   const int n = (st < 0) ? 0 : (p.end[tile] - st);
   if (n == 0) return;
@@ -419,8 +458,12 @@ __global__ void __launch_bounds__(256 / PPL) k_composite_bwd(CompParams p) {
     py[j] = pixel_coord(p.topleft[1], gy[j], p.psy);
   }
 
-  float Y[MODE == MODE_SH ? PPL : 1][MODE == MODE_SH ? TR::CC : 1];
+  v2f Yp[MODE == MODE_SH ? PPL : 1][MODE == MODE_SH ? TR::NPAIR : 1];
   if constexpr (MODE == MODE_SH) {
+    if constexpr (TR::CCP != TR::CC) {
+      for (int e = t; e < kBatch * TR::NCOLP; e += NT) S.col[e] = 0.0f;
+      __syncthreads();
+    }
     float R[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) R[i] = p.rot[i];
@@ -431,7 +474,12 @@ __global__ void __launch_bounds__(256 / PPL) k_composite_bwd(CompParams p) {
       float dz = R[6] * px + R[7] * py[j] + R[8];
       const float len = sqrtf(dx * dx + dy * dy + dz * dz);
       dx /= len; dy /= len; dz /= len;
-      sh_basis<CB>(dx, dy, dz, Y[j]);
+      float Yf[TR::CCP];
+#pragma unroll
+      for (int k = 0; k < TR::CCP; ++k) Yf[k] = 0.0f;
+      sh_basis<CB>(dx, dy, dz, *reinterpret_cast<float (*)[TR::CC]>(&Yf[0]));
+#pragma unroll
+      for (int k = 0; k < TR::NPAIR; ++k) Yp[j][k] = v2f{Yf[2 * k], Yf[2 * k + 1]};
     }
   }
 
@@ -487,56 +535,84 @@ __global__ void __launch_bounds__(256 / PPL) k_composite_bwd(CompParams p) {
       } else {
         inv_det = 1.0f / (r.c0 * r.c3 - r.c1 * r.c2);
       }
-      const float *cg = &S.col[g * TR::NCOL];
+      const float *cg = &S.col[g * TR::NCOLP];
+      float pAG[PPL], ag[PPL];
+      if constexpr (MODE == MODE_SH) {
+        // branch-free over the lane's pixels (weight 0 when a pixel does not contribute);
+        // the colour dot products and the d/d(sh) accumulation are (k, k+1)-packed FMAs
+        float w[PPL], inv1m[PPL];
 #pragma unroll
-      for (int j = 0; j < PPL; ++j) {
-        if (con[j]) {
-          const float y = py[j] - r.my;
-          const float ag = r.a * G[j];
+        for (int j = 0; j < PPL; ++j) {
+          ag[j] = r.a * G[j];
+          w[j] = con[j] ? (r.a * Tr[j]) * G[j] : 0.0f;
+          inv1m[j] = __builtin_amdgcn_rcpf(1.0f - ag[j]);
+          pAG[j] = 0.0f;
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          v2f q[TR::NPAIR], gq[TR::NPAIR];
+#pragma unroll
+          for (int k = 0; k < TR::NPAIR; ++k) {
+            q[k] = *reinterpret_cast<const v2f *>(cg + c * TR::CCP + 2 * k);
+            gq[k] = v2f{0.0f, 0.0f};
+          }
+#pragma unroll
+          for (int j = 0; j < PPL; ++j) {
+            v2f s2 = q[0] * Yp[j][0];
+#pragma unroll
+            for (int k = 1; k < TR::NPAIR; ++k) s2 = fma2(q[k], Yp[j][k], s2);
+            const float yv = sigmoid_fast(s2[0] + s2[1]);
+            pre[j][c] += w[j] * yv;
+            const float gs = w[j] * (yv * (1.0f - yv)) * go[j][c];
+            const v2f gs2 = splat2(gs);
+#pragma unroll
+            for (int k = 0; k < TR::NPAIR; ++k) gq[k] = fma2(gs2, Yp[j][k], gq[k]);
+            pAG[j] += go[j][c] * (yv * Tr[j] - (fin[j][c] - pre[j][c]) * inv1m[j]);
+          }
+#pragma unroll
+          for (int k = 0; k < TR::CC; ++k) gr[7 + c * TR::CC + k] = gq[k >> 1][k & 1];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < PPL; ++j) {
+          ag[j] = r.a * G[j];
           const float coeff = (r.a * Tr[j]) * G[j];
-          const float inv1m = __builtin_amdgcn_rcpf(1.0f - ag);
-          float pAG = 0.0f;
-          if constexpr (MODE == MODE_SH) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-              float s = 0.0f;
-#pragma unroll
-              for (int k = 0; k < TR::CC; ++k) s += cg[c * TR::CC + k] * Y[j][k];
-              const float yv = sigmoid_fast(s);
-              pre[j][c] += coeff * yv;
-              const float gs = coeff * (yv * (1.0f - yv)) * go[j][c];
-#pragma unroll
-              for (int k = 0; k < TR::CC; ++k) gr[7 + c * TR::CC + k] += gs * Y[j][k];
-              pAG += go[j][c] * (yv * Tr[j] - (fin[j][c] - pre[j][c]) * inv1m);
-            }
-          } else {
+          const float inv1m = __builtin_amdgcn_rcpf(1.0f - ag[j]);
+          pAG[j] = 0.0f;
+          if (con[j]) {
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
               pre[j][c] += cg[c] * coeff;
               gr[7 + c] += coeff * go[j][c];
-              pAG += (cg[c] * Tr[j] - (fin[j][c] - pre[j][c]) * inv1m) * go[j][c];
+              pAG[j] += (cg[c] * Tr[j] - (fin[j][c] - pre[j][c]) * inv1m) * go[j][c];
             }
           }
-          // kernel_gaussian_2d_backward (kernels.h:394-418): v = Sigma^-T d
-          const float gg = pAG * ag;
-          const float vx = (x * r.c3 - y * r.c2) * inv_det;
-          const float vy = (y * r.c0 - x * r.c1) * inv_det;
-          gr[0] += gg * vx;
-          gr[1] += gg * vy;
-          const float h = 0.5f * gg;
-          gr[2] += h * vx * vx;
-          gr[3] += h * vx * vy;
-          gr[5] += h * vy * vy;
-          gr[6] += pAG * G[j];
-          Tr[j] *= (1.0f - ag);
-          alive[j] = !(Tr[j] < p.thresh);
         }
+      }
+#pragma unroll
+      for (int j = 0; j < PPL; ++j) {
+        // kernel_gaussian_2d_backward (kernels.h:394-418): v = Sigma^-T d
+        const float pa = con[j] ? pAG[j] : 0.0f;
+        const float y = py[j] - r.my;
+        const float gg = pa * ag[j];
+        const float vx = (x * r.c3 - y * r.c2) * inv_det;
+        const float vy = (y * r.c0 - x * r.c1) * inv_det;
+        gr[0] += gg * vx;
+        gr[1] += gg * vy;
+        const float h = 0.5f * gg;
+        gr[2] += h * vx * vx;
+        gr[3] += h * vx * vy;
+        gr[5] += h * vy * vy;
+        gr[6] += pa * G[j];
+        const float om = con[j] ? (1.0f - ag[j]) : 1.0f;
+        Tr[j] *= om;
+        alive[j] = alive[j] && !(Tr[j] < p.thresh);
       }
       gr[4] = gr[3];  // grad_cov[1] and grad_cov[2] receive the same value (kernels.h:414-415)
 
-      wave_reduce_scatter<P>(gr);
+      if (!(p.dbg & 2)) wave_reduce_scatter<P>(gr);
       const int comp = lane & (P - 1);
-      if (lane < P && comp < TR::NCOMP) {
+      if (!(p.dbg & 1) && lane < P && comp < TR::NCOMP) {
         const size_t id = (size_t)S.id[g];
         float *dst;
         if (comp < 2) dst = p.g_mean + 2 * id + comp;
@@ -554,9 +630,15 @@ __global__ void __launch_bounds__(256 / PPL) k_composite_bwd(CompParams p) {
 }
 
 // ---- launch helpers ---------------------------------------------------------------------------
-#ifndef GSGEN_PPL
-#define GSGEN_PPL 4
-#endif
+// Pixels per lane: 4 = one wavefront per tile (north_star design), 2 / 1 = two / four
+// wavefronts per tile sharing the staged records.  Defaults chosen by measurement on MI355X
+// (profiles/); GSGEN_PPL_FWD / GSGEN_PPL_BWD override them for A/B runs.
+static int env_ppl(const char *name, int dflt) {
+  const char *v = getenv(name);
+  if (!v) return dflt;
+  const int x = atoi(v);
+  return (x == 1 || x == 2 || x == 4) ? x : dflt;
+}
 
 static int check_common(uint32_t tile_size, const void *a, const void *b, const void *c) {
   if (tile_size != (uint32_t)kTile) return GSGEN_EUNSUPPORTED;
@@ -566,18 +648,25 @@ static int check_common(uint32_t tile_size, const void *a, const void *b, const 
 
 template <int MODE, int CB>
 static int launch_fwd(const CompParams &p, hipStream_t s) {
-  constexpr int PPL = GSGEN_PPL;
-  const uint32_t nblk = (uint32_t)(p.ntw * p.nth);
-  if (nblk == 0) return 0;
-  hipLaunchKernelGGL((k_composite_fwd<MODE, CB, PPL>), dim3(nblk), dim3(256 / PPL), 0, s, p);
+  static const int ppl = env_ppl("GSGEN_PPL_FWD", 4);
+  const uint32_t nblk = tile_map_blocks(p.ntw, p.nth);
+  if (p.ntw * p.nth == 0) return 0;
+  if (ppl == 1) hipLaunchKernelGGL((k_composite_fwd<MODE, CB, 1>), dim3(nblk), dim3(256), 0, s, p);
+  else if (ppl == 2) hipLaunchKernelGGL((k_composite_fwd<MODE, CB, 2>), dim3(nblk), dim3(128), 0, s, p);
+  else hipLaunchKernelGGL((k_composite_fwd<MODE, CB, 4>), dim3(nblk), dim3(64), 0, s, p);
   return (int)hipGetLastError();
 }
 template <int MODE, int CB>
-static int launch_bwd(const CompParams &p, hipStream_t s) {
-  constexpr int PPL = GSGEN_PPL;
-  const uint32_t nblk = (uint32_t)(p.ntw * p.nth);
-  if (nblk == 0) return 0;
-  hipLaunchKernelGGL((k_composite_bwd<MODE, CB, PPL>), dim3(nblk), dim3(256 / PPL), 0, s, p);
+static int launch_bwd(const CompParams &p_, hipStream_t s) {
+  static const int ppl = env_ppl("GSGEN_PPL_BWD", 4);
+  static const int dbg = getenv("GSGEN_DBG") ? atoi(getenv("GSGEN_DBG")) : 0;
+  CompParams p = p_;
+  p.dbg = dbg;
+  const uint32_t nblk = tile_map_blocks(p.ntw, p.nth);
+  if (p.ntw * p.nth == 0) return 0;
+  if (ppl == 1) hipLaunchKernelGGL((k_composite_bwd<MODE, CB, 1>), dim3(nblk), dim3(256), 0, s, p);
+  else if (ppl == 2) hipLaunchKernelGGL((k_composite_bwd<MODE, CB, 2>), dim3(nblk), dim3(128), 0, s, p);
+  else hipLaunchKernelGGL((k_composite_bwd<MODE, CB, 4>), dim3(nblk), dim3(64), 0, s, p);
   return (int)hipGetLastError();
 }
 

@@ -162,6 +162,10 @@ int gsgen_frame_geometry(uint32_t N, const float *mean, const float *qvec, const
                          int *end, uint32_t *total, void *workspace, size_t workspace_bytes,
                          gsgen_stream_t stream);
 
+/* Self test of the wave64 cross-lane reduce-scatter used by the backward (tests only):
+ * in [64 lanes, P components], out[lane] = sum over lanes of component (lane mod P); P in {8,16,32,64}. */
+int gsgen_selftest_reduce_scatter(uint32_t P, const float *in, float *out, gsgen_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -58,6 +58,48 @@ inline int __float_as_int(float f) { int u; std::memcpy(&u, &f, 4); return u; }
 inline float __uint_as_float(unsigned u) { float f; std::memcpy(&f, &u, 4); return f; }
 inline float __int_as_float(int u) { float f; std::memcpy(&f, &u, 4); return f; }
 
+// gfx950 cross-lane builtins used by common.hpp (semantics per the CDNA4 ISA: DPP row = 16
+// lanes, bank = 4 lanes; v_permlane32_swap exchanges vdst's upper 32 lanes with vsrc's lower
+// 32; v_permlane16_swap exchanges vdst's odd rows with vsrc's even rows).
+struct emu_u2 { unsigned v[2]; unsigned operator[](int i) const { return v[i]; } };
+inline emu_u2 emu_permlane_swap(unsigned d, unsigned s, int width) {
+  const int lane = simt::lane_of_current();
+  emu_u2 r;
+  if (width == 32) {
+    // new vdst[l>=32] = vsrc[l-32]; new vsrc[l<32] = vdst[l+32]
+    const unsigned s_from = simt::shfl_idx(s, lane - 32 >= 0 ? lane - 32 : lane);
+    const unsigned d_from = simt::shfl_idx(d, lane + 32 < 64 ? lane + 32 : lane);
+    r.v[0] = (lane >= 32) ? s_from : d;
+    r.v[1] = (lane < 32) ? d_from : s;
+  } else {
+    const int row = lane >> 4;
+    const unsigned s_from = simt::shfl_idx(s, (row & 1) ? lane - 16 : lane);  // odd row of vdst <- even row of vsrc
+    const unsigned d_from = simt::shfl_idx(d, (row & 1) ? lane : lane + 16);  // even row of vsrc <- odd row of vdst
+    r.v[0] = (row & 1) ? s_from : d;
+    r.v[1] = (row & 1) ? s : d_from;
+  }
+  return r;
+}
+#define __builtin_amdgcn_permlane32_swap(d, s, fi, bc) emu_permlane_swap((d), (s), 32)
+#define __builtin_amdgcn_permlane16_swap(d, s, fi, bc) emu_permlane_swap((d), (s), 16)
+inline int emu_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+  const int lane = simt::lane_of_current();
+  const int row = lane >> 4, in_row = lane & 15, bank = in_row >> 2;
+  int from = -1;
+  if (ctrl < 0x100) from = (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3);
+  else if (ctrl > 0x100 && ctrl <= 0x10F) { int n = ctrl - 0x100; from = (in_row + n < 16) ? lane + n : -1; }
+  else if (ctrl > 0x110 && ctrl <= 0x11F) { int n = ctrl - 0x110; from = (in_row - n >= 0) ? lane - n : -1; }
+  else if (ctrl > 0x120 && ctrl <= 0x12F) { int n = ctrl - 0x120; from = (row << 4) | ((in_row - n) & 15); }
+  else if (ctrl == 0x140) from = (row << 4) | (15 - in_row);
+  else if (ctrl == 0x141) from = (lane & ~7) | (7 - (lane & 7));
+  const int got = simt::shfl_idx(src, from >= 0 ? from : lane);
+  const bool enabled = ((row_mask >> row) & 1) && ((bank_mask >> bank) & 1);
+  if (!enabled) return old;
+  if (from < 0) return bound_ctrl ? 0 : old;
+  return got;
+}
+#define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) emu_update_dpp((old), (src), (ctrl), (rm), (bm), (bc))
+
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 

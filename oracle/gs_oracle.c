@@ -720,3 +720,42 @@ void gso_render_sh_bwd(int N, const float *mean, const float *cov, const float *
   }
   free(acc);
 }
+
+/* ------------------------------------------------------------------------------------ */
+/* Work statistics of the SH forward (not part of the reference): per pixel, the list     */
+/* index at which it stopped (n if it never saturated) and how many entries contributed.  */
+/* Used by tools/workstats.py to size the GPU kernels' work; never by the product.        */
+/* ------------------------------------------------------------------------------------ */
+void gso_sh_workstats(const float *mean, const float *cov, const float *alpha, const int *start,
+                      const int *end, const int *ids, const float *topleft, int tile_size,
+                      int n_tiles_h, int n_tiles_w, float psx, float psy, int H, int W, float thresh,
+                      int *stop_idx /*[H,W]*/, int *n_contrib /*[H,W]*/, int *last_contrib /*[H,W]*/) {
+#pragma omp parallel for schedule(dynamic, 1) collapse(2)
+  for (int ty = 0; ty < n_tiles_h; ++ty)
+    for (int tx = 0; tx < n_tiles_w; ++tx) {
+      int tile = ty * n_tiles_w + tx;
+      int n = (start[tile] == -1) ? 0 : end[tile] - start[tile];
+      const int *lst = ids + (n ? start[tile] : 0);
+      for (int ly = 0; ly < tile_size; ++ly)
+        for (int lx = 0; lx < tile_size; ++lx) {
+          int gy = ty * tile_size + ly, gx = tx * tile_size + lx;
+          if (gy >= H || gx >= W) continue;
+          float pos[2];
+          pixel_pos(topleft, gx, gy, psx, psy, pos);
+          float cum = 1.0f;
+          int k, nc = 0, last = -1;
+          for (k = 0; k < n; ++k) {
+            if (cum < thresh) break;
+            int g = lst[k];
+            float a = fminf(alpha[g], 0.99f);
+            float val = gauss2d_f32(mean + 2 * g, cov + 4 * g, pos);
+            if (a * val < MIN_RENDER_ALPHA) continue;
+            ++nc; last = k;
+            cum *= (1 - a * val);
+          }
+          stop_idx[gy * W + gx] = k;
+          n_contrib[gy * W + gx] = nc;
+          last_contrib[gy * W + gx] = last;
+        }
+    }
+}

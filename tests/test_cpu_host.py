@@ -151,3 +151,12 @@ def test_emulated_fused_frame_geometry(emu):
             assert np.array_equal(m2[g["mask"]], g["mean2d"])
         else:  # overflow: nothing binned, required size reported
             assert (st == -1).all() and (en == -1).all()
+
+
+@pytest.mark.parametrize("Pc", [8, 16, 32, 64])
+def test_emulated_reduce_scatter(emu, Pc):
+    x = np.random.default_rng(Pc).normal(size=(64, Pc)).astype(np.float32)
+    out = np.zeros(64, np.float32)
+    emu.selftest_reduce_scatter(Pc, P(x), P(out), None)
+    want = x.astype(np.float64).sum(0)[np.arange(64) % Pc]
+    assert np.abs(out - want).max() < 1e-4

@@ -308,3 +308,14 @@ def test_run_to_run_determinism_forward(case):
     name, sc, cam, g, h = case
     g2 = hip_geometry(sc, cam, g)
     assert torch.equal(g2["ids"], h["ids"])
+
+
+@pytest.mark.parametrize("Pc", [8, 16, 32, 64])
+def test_wave_reduce_scatter_primitive(Pc):
+    """v_permlane32/16_swap + DPP reduce-scatter of the backward against a plain sum."""
+    x = np.random.default_rng(Pc).normal(size=(64, Pc)).astype(np.float32)
+    xin = T_(x)
+    out = torch.zeros(64, device=dev())
+    lib().selftest_reduce_scatter(Pc, p(xin), p(out), stream())
+    want = x.astype(np.float64).sum(0)[np.arange(64) % Pc]
+    assert np.abs(out.cpu().numpy() - want).max() < 1e-4
