@@ -21,6 +21,7 @@ ARCH = "gfx950"
 
 SOURCES = {
     "composite.hip": [],
+    "composite_bwd.hip": [],
     "geometry.hip": ["-ffp-contract=off"],
     "binning.hip": [],
 }
@@ -31,7 +32,7 @@ def _newer(src, dst, extra=()):
     if not os.path.exists(dst):
         return True
     t = os.path.getmtime(dst)
-    deps = [src, os.path.join(CSRC, "common.hpp"),
+    deps = [src, os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "composite_common.hpp"),
             os.path.join(HERE, "..", "include", "gsgen_hip.h"), __file__, *extra]
     return any(os.path.getmtime(d) > t for d in deps)
 

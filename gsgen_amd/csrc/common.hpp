@@ -106,6 +106,47 @@ __device__ __forceinline__ void wave_reduce_scatter(float (&v)[P]) {
   v[0] = reduce_rest<P, 32>(v[0]);
 }
 
+// ---- wave64 prefix scans on DPP (GCN/CDNA row_shr + row_bcast idiom, 7 fused steps) --------
+constexpr int kDppRowBcast15 = 0x142;  // lane 15 of each row -> every lane of the next row
+constexpr int kDppRowBcast31 = 0x143;  // lane 31 -> rows 2 and 3
+constexpr int kDppWaveShr1 = 0x138;    // lane i reads lane i-1 across the whole wave
+
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ float dpp_get(float identity, float src) {
+  // lanes masked off, or whose source lane does not exist, receive `identity`
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(src), CTRL,
+                                                    ROW_MASK, BANK_MASK, false));
+}
+// inclusive prefix sum over the 64 lanes
+__device__ __forceinline__ float wave_scan_add(float x) {
+  float v = x + dpp_get<kDppRowShr + 1, 0xf, 0xf>(0.0f, x);
+  v += dpp_get<kDppRowShr + 2, 0xf, 0xf>(0.0f, x);
+  v += dpp_get<kDppRowShr + 3, 0xf, 0xf>(0.0f, x);
+  v += dpp_get<kDppRowShr + 4, 0xf, 0xe>(0.0f, v);
+  v += dpp_get<kDppRowShr + 8, 0xf, 0xc>(0.0f, v);
+  v += dpp_get<kDppRowBcast15, 0xa, 0xf>(0.0f, v);
+  v += dpp_get<kDppRowBcast31, 0xc, 0xf>(0.0f, v);
+  return v;
+}
+// inclusive prefix product over the 64 lanes
+__device__ __forceinline__ float wave_scan_mul(float x) {
+  float v = x * dpp_get<kDppRowShr + 1, 0xf, 0xf>(1.0f, x);
+  v *= dpp_get<kDppRowShr + 2, 0xf, 0xf>(1.0f, x);
+  v *= dpp_get<kDppRowShr + 3, 0xf, 0xf>(1.0f, x);
+  v *= dpp_get<kDppRowShr + 4, 0xf, 0xe>(1.0f, v);
+  v *= dpp_get<kDppRowShr + 8, 0xf, 0xc>(1.0f, v);
+  v *= dpp_get<kDppRowBcast15, 0xa, 0xf>(1.0f, v);
+  v *= dpp_get<kDppRowBcast31, 0xc, 0xf>(1.0f, v);
+  return v;
+}
+// value of the previous lane (lane 0 receives `identity`)
+__device__ __forceinline__ float wave_shift_up(float identity, float x) {
+  return dpp_get<kDppWaveShr1, 0xf, 0xf>(identity, x);
+}
+__device__ __forceinline__ float read_lane(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
 // two packed fp32 values: arithmetic on v2f lowers to v_pk_mul/add/fma_f32 (one VALU issue for
 // two lanes' worth of work per thread)
 typedef float v2f __attribute__((vector_size(8)));

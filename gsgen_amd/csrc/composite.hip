@@ -24,106 +24,9 @@
 // (fp64 / uncontracted fp32), so the discontinuous decision is the reference's.  Forward and
 // backward share eval code, so the backward's recomputed prefix equals the forward bit for
 // bit (the invariant the reference asserts at vol_render_sh.h:452-454).
-#include <stdlib.h>
-
-#include "common.hpp"
-#include "../../include/gsgen_hip.h"
+#include "composite_common.hpp"
 
 namespace gs {
-
-enum : int { MODE_RGB = 0, MODE_SCALAR = 1, MODE_SH = 2 };
-constexpr int kBatch = 64;  // Gaussian records staged per LDS round
-
-struct CompParams {
-  const float *mean, *cov, *col, *alpha;
-  const int *start, *end, *ids;
-  const float *topleft, *rot, *bg;
-  float *out, *T;
-  const float *final_img, *grad_out;
-  float *g_mean, *g_cov, *g_col, *g_alpha;
-  int ntw, nth, H, W;
-  float psx, psy, thresh;
-  int dbg;  // experiment switches (GSGEN_DBG), 0 in production
-};
-
-// ---- reference-arithmetic Gaussian evaluations (rare path) ------------------------------
-// kernels.h:195-224
-__device__ __noinline__ float gauss_ref_f64(float mx, float my, float c0f, float c1f, float c2f,
-                                            float c3f, float px, float py) {
-  const double c0 = c0f, c1 = c1f, c2 = c2f, c3 = c3f;
-  const double det = c0 * c3 - c1 * c2;
-  const double x = (double)(px - mx);
-  const double y = (double)(py - my);
-  const double tx = x * c3 - y * c2;
-  const double ty = -x * c1 + y * c0;
-  double radial = tx * x + ty * y;
-  radial /= det;
-  if (radial < 0.0) radial = 1000.0;
-  return (float)exp(-0.5 * radial);
-}
-// kernels.h:172-193, fp32 with every product rounded (the oracle's order)
-__device__ __noinline__ float gauss_ref_f32(float mx, float my, float c0, float c1, float c2,
-                                            float c3, float px, float py) {
-#pragma clang fp contract(off)
-  const float det = c0 * c3 - c1 * c2;
-  const float x = px - mx;
-  const float y = py - my;
-  const float tx = x * c3 - y * c2;
-  const float ty = -x * c1 + y * c0;
-  float radial = tx * x + ty * y;
-  radial = radial / det;
-  if (radial < 0.0f) radial = 1000.0f;
-  return expf(-0.5f * radial);
-}
-
-// real SH basis, bands CB = 1..4 (shencoder.h:13-62)
-template <int CB>
-__device__ __forceinline__ void sh_basis(float x, float y, float z, float (&Y)[CB * CB]) {
-  Y[0] = 0.28209479177387814f;
-  if constexpr (CB >= 2) {
-    Y[1] = -0.48860251190291987f * y;
-    Y[2] = 0.48860251190291987f * z;
-    Y[3] = -0.48860251190291987f * x;
-  }
-  if constexpr (CB >= 3) {
-    const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
-    Y[4] = 1.0925484305920792f * xy;
-    Y[5] = -1.0925484305920792f * yz;
-    Y[6] = 0.94617469575755997f * z2 - 0.31539156525251999f;
-    Y[7] = -1.0925484305920792f * xz;
-    Y[8] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2;
-    if constexpr (CB >= 4) {
-      Y[9] = 0.59004358992664352f * y * (-3.0f * x2 + y2);
-      Y[10] = 2.8906114426405538f * xy * z;
-      Y[11] = 0.45704579946446572f * y * (1.0f - 5.0f * z2);
-      Y[12] = 0.3731763325901154f * z * (5.0f * z2 - 3.0f);
-      Y[13] = 0.45704579946446572f * x * (1.0f - 5.0f * z2);
-      Y[14] = 1.4453057213202769f * z * (x2 - y2);
-      Y[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
-    }
-  }
-}
-
-__device__ __forceinline__ float sigmoid_fast(float s) {
-  // 1/(1+exp(-s)) (shencoder.h:4) on v_exp_f32 / v_rcp_f32
-  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-kLog2e * s));
-}
-
-template <int MODE, int CB>
-struct Traits {
-  static constexpr int CC = CB * CB;
-  static constexpr int NCOL = (MODE == MODE_SH) ? 3 * CC : (MODE == MODE_RGB ? 3 : 1);
-  static constexpr int NCH = (MODE == MODE_SCALAR) ? 1 : 3;
-  // gradient components per Gaussian: mean(2) cov(4, the two off-diagonals carry the same
-  // value) alpha(1) colour/scalar/sh(NCOL)
-  static constexpr int NCOMP = 7 + NCOL;
-  static constexpr int P = NCOMP <= 8 ? 8 : (NCOMP <= 16 ? 16 : (NCOMP <= 32 ? 32 : 64));
-  // LDS layout of the SH coefficients: each channel padded to a multiple of 4 floats so that
-  // a channel is read as aligned float4s and multiplied as (k, k+1) pairs by v_pk_fma_f32
-  static constexpr int CCP = (MODE == MODE_SH) ? ((CC + 3) & ~3) : CC;
-  static constexpr int NCOLP = (MODE == MODE_SH) ? 3 * CCP : NCOL;
-  static constexpr int NPAIR = CCP / 2;
-};
 
 // ---- LDS staging ---------------------------------------------------------------------------
 template <int MODE, int CB>
@@ -150,36 +53,8 @@ __device__ __forceinline__ void stage_batch(Stage<MODE, CB> &S, const CompParams
       const float2 m = *reinterpret_cast<const float2 *>(p.mean + 2 * (size_t)id);
       const float4 c = *reinterpret_cast<const float4 *>(p.cov + 4 * (size_t)id);
       mx = m.x; my = m.y; c0 = c.x; c1 = c.y; c2 = c.z; c3 = c.w;
-      a = fminf(p.alpha[id], kAlphaClamp);
-      bool ok = finite_f(mx) && finite_f(my) && finite_f(c0) && finite_f(c1) && finite_f(c2) &&
-                finite_f(c3) && finite_f(a);
-      if constexpr (MODE == MODE_SH) {
-        float det;
-        {
-#pragma clang fp contract(off)
-          det = c0 * c3 - c1 * c2;  // fp32 determinant, as kernels.h:179
-        }
-        ok = ok && (det > 0.0f) && finite_f(det);
-        const float inv = 1.0f / (ok ? det : 1.0f);
-        p0 = -0.5f * kLog2e * inv;  // G = exp2(p0 * q), q = d^T adj(S) d
-        p1 = inv;
-      } else {
-        const double d0 = c0, d1 = c1, d2 = c2, d3 = c3;
-        const double det = d0 * d3 - d1 * d2;
-        ok = ok && (det > 0.0) && (d3 > 0.0);
-        const double sdet = ok ? det : 1.0, s3 = ok ? d3 : 1.0;
-        // r = [c3 x^2 - (c1+c2) x y + c0 y^2]/det = u^2 + v^2,
-        // u = l11 x + l21 y, v = l22 y   (Cholesky of the quadratic form)
-        const double qa = s3 / sdet, qb = -0.5 * (d1 + d2) / sdet, qc = d0 / sdet;
-        const double l11 = sqrt(qa), l21 = qb / l11;
-        const double l22s = qc - l21 * l21;
-        ok = ok && (l22s > 0.0);
-        const double l22 = sqrt(ok ? l22s : 1.0);
-        const double sc = 0.84932180028801904;  // sqrt(0.5*log2(e)): G = exp2(-(u^2+v^2))
-        p0 = (float)(l11 * sc); p1 = (float)(l21 * sc); p2 = (float)(l22 * sc);
-        if (!ok) { p0 = 0.f; p1 = 0.f; p2 = 0.f; }
-      }
-      if (!ok) a = 0.0f;  // a degenerate / non-finite record never contributes
+      const GRec r = prep_record<MODE>(mx, my, c0, c1, c2, c3, p.alpha[id]);
+      a = r.a; p0 = r.p0; p1 = r.p1; p2 = r.p2;
     }
     S.id[t] = id; S.mx[t] = mx; S.my[t] = my; S.a[t] = a;
     S.c0[t] = c0; S.c1[t] = c1; S.c2[t] = c2; S.c3[t] = c3;
@@ -211,9 +86,6 @@ __device__ __forceinline__ void stage_batch(Stage<MODE, CB> &S, const CompParams
 }
 
 // per-Gaussian values broadcast from LDS into registers
-struct GRec {
-  float mx, my, a, c0, c1, c2, c3, p0, p1, p2;
-};
 template <int MODE, int CB>
 __device__ __forceinline__ GRec load_rec(const Stage<MODE, CB> &S, int g) {
   GRec r;
@@ -221,33 +93,6 @@ __device__ __forceinline__ GRec load_rec(const Stage<MODE, CB> &S, int g) {
   r.c0 = S.c0[g]; r.c1 = S.c1[g]; r.c2 = S.c2[g]; r.c3 = S.c3[g];
   r.p0 = S.p0[g]; r.p1 = S.p1[g]; r.p2 = S.p2[g];
   return r;
-}
-
-// Gaussian value for one pixel.  x = px - mx (shared by the lane's pixels), y = py - my.
-template <int MODE>
-__device__ __forceinline__ float gauss_eval(const GRec &r, float x, float y, float px, float py,
-                                            bool alive) {
-  float G;
-  if constexpr (MODE == MODE_SH) {
-    const float tx = x * r.c3 - y * r.c2;
-    const float ty = y * r.c0 - x * r.c1;
-    const float q = tx * x + ty * y;
-    G = __builtin_amdgcn_exp2f(r.p0 * q);
-    G = (q < 0.0f) ? 0.0f : G;  // kernels.h:186-188: radial < 0 -> exp(-500) == 0
-  } else {
-    const float u = r.p0 * x + r.p1 * y;
-    const float v = r.p2 * y;
-    G = __builtin_amdgcn_exp2f(-(u * u + v * v));
-  }
-  const float ag = r.a * G;
-  if (alive && fabsf(ag - kMinAlpha) <= kMinAlpha * kGuardTol) {
-    // within rounding of the skip threshold: take the reference's arithmetic
-    if constexpr (MODE == MODE_SH)
-      G = gauss_ref_f32(r.mx, r.my, r.c0, r.c1, r.c2, r.c3, px, py);
-    else
-      G = gauss_ref_f64(r.mx, r.my, r.c0, r.c1, r.c2, r.c3, px, py);
-  }
-  return G;
 }
 
 // ============================================================================================
@@ -428,7 +273,7 @@ __global__ void __launch_bounds__(256 / PPL) k_composite_fwd(CompParams p) {
 // backward
 // ============================================================================================
 template <int MODE, int CB, int PPL>
-__global__ void __launch_bounds__(256 / PPL) k_composite_bwd(CompParams p) {
+__global__ void __launch_bounds__(256 / PPL) k_composite_bwd_pixel(CompParams p) {
   using TR = Traits<MODE, CB>;
   constexpr int NT = 256 / PPL;
   constexpr int ROWS = NT / 16;
@@ -633,19 +478,6 @@ __global__ void __launch_bounds__(256 / PPL) k_composite_bwd(CompParams p) {
 // Pixels per lane: 4 = one wavefront per tile (north_star design), 2 / 1 = two / four
 // wavefronts per tile sharing the staged records.  Defaults chosen by measurement on MI355X
 // (profiles/); GSGEN_PPL_FWD / GSGEN_PPL_BWD override them for A/B runs.
-static int env_ppl(const char *name, int dflt) {
-  const char *v = getenv(name);
-  if (!v) return dflt;
-  const int x = atoi(v);
-  return (x == 1 || x == 2 || x == 4) ? x : dflt;
-}
-
-static int check_common(uint32_t tile_size, const void *a, const void *b, const void *c) {
-  if (tile_size != (uint32_t)kTile) return GSGEN_EUNSUPPORTED;
-  if (!a || !b || !c) return GSGEN_EINVAL;
-  return 0;
-}
-
 template <int MODE, int CB>
 static int launch_fwd(const CompParams &p, hipStream_t s) {
   static const int ppl = env_ppl("GSGEN_PPL_FWD", 4);
@@ -664,10 +496,21 @@ static int launch_bwd(const CompParams &p_, hipStream_t s) {
   p.dbg = dbg;
   const uint32_t nblk = tile_map_blocks(p.ntw, p.nth);
   if (p.ntw * p.nth == 0) return 0;
-  if (ppl == 1) hipLaunchKernelGGL((k_composite_bwd<MODE, CB, 1>), dim3(nblk), dim3(256), 0, s, p);
-  else if (ppl == 2) hipLaunchKernelGGL((k_composite_bwd<MODE, CB, 2>), dim3(nblk), dim3(128), 0, s, p);
-  else hipLaunchKernelGGL((k_composite_bwd<MODE, CB, 4>), dim3(nblk), dim3(64), 0, s, p);
+  if (ppl == 1) hipLaunchKernelGGL((k_composite_bwd_pixel<MODE, CB, 1>), dim3(nblk), dim3(256), 0, s, p);
+  else if (ppl == 2) hipLaunchKernelGGL((k_composite_bwd_pixel<MODE, CB, 2>), dim3(nblk), dim3(128), 0, s, p);
+  else hipLaunchKernelGGL((k_composite_bwd_pixel<MODE, CB, 4>), dim3(nblk), dim3(64), 0, s, p);
   return (int)hipGetLastError();
+}
+
+int launch_bwd_pixel_dispatch(int mode, int C, const CompParams &p, hipStream_t s) {
+  if (mode == MODE_RGB) return launch_bwd<MODE_RGB, 1>(p, s);
+  if (mode == MODE_SCALAR) return launch_bwd<MODE_SCALAR, 1>(p, s);
+  switch (C) {
+    case 1: return launch_bwd<MODE_SH, 1>(p, s);
+    case 2: return launch_bwd<MODE_SH, 2>(p, s);
+    case 3: return launch_bwd<MODE_SH, 3>(p, s);
+    default: return launch_bwd<MODE_SH, 4>(p, s);
+  }
 }
 
 }  // namespace gs
@@ -694,26 +537,6 @@ int gsgen_vol_render_start_end_with_T(uint32_t N, uint32_t D, const float *mean,
   return launch_fwd<MODE_RGB, 1>(p, (hipStream_t)stream);
 }
 
-int gsgen_vol_render_backward_start_end(uint32_t N, uint32_t D, const float *mean, const float *cov,
-                                        const float *color, const float *alpha, const int *start,
-                                        const int *end, const int *gaussian_ids, const float *out,
-                                        float *grad_mean, float *grad_cov, float *grad_color,
-                                        float *grad_alpha, const float *grad_out,
-                                        const float *topleft, uint32_t tile_size,
-                                        uint32_t n_tiles_h, uint32_t n_tiles_w, float pixel_size_x,
-                                        float pixel_size_y, uint32_t H, uint32_t W, float thresh,
-                                        gsgen_stream_t stream) {
-  if (int e = check_common(tile_size, start, end, out)) return e;
-  if (N == 0 || D == 0) return 0;
-  CompParams p{};
-  p.mean = mean; p.cov = cov; p.col = color; p.alpha = alpha;
-  p.start = start; p.end = end; p.ids = gaussian_ids; p.topleft = topleft;
-  p.final_img = out; p.grad_out = grad_out;
-  p.g_mean = grad_mean; p.g_cov = grad_cov; p.g_col = grad_color; p.g_alpha = grad_alpha;
-  p.ntw = (int)n_tiles_w; p.nth = (int)n_tiles_h; p.H = (int)H; p.W = (int)W;
-  p.psx = pixel_size_x; p.psy = pixel_size_y; p.thresh = thresh;
-  return launch_bwd<MODE_RGB, 1>(p, (hipStream_t)stream);
-}
 
 int gsgen_vol_render_scalar(uint32_t N, uint32_t D, const float *mean, const float *cov,
                             const float *scalar, const float *alpha, const int *start,
@@ -732,25 +555,6 @@ int gsgen_vol_render_scalar(uint32_t N, uint32_t D, const float *mean, const flo
   return launch_fwd<MODE_SCALAR, 1>(p, (hipStream_t)stream);
 }
 
-int gsgen_vol_render_scalar_backward(uint32_t N, uint32_t D, const float *mean, const float *cov,
-                                     const float *scalar, const float *alpha, const int *start,
-                                     const int *end, const int *gaussian_ids, const float *out,
-                                     float *grad_mean, float *grad_cov, float *grad_scalar,
-                                     float *grad_alpha, const float *grad_out, const float *topleft,
-                                     uint32_t tile_size, uint32_t n_tiles_h, uint32_t n_tiles_w,
-                                     float pixel_size_x, float pixel_size_y, uint32_t H, uint32_t W,
-                                     float thresh, gsgen_stream_t stream) {
-  if (int e = check_common(tile_size, start, end, out)) return e;
-  if (N == 0 || D == 0) return 0;
-  CompParams p{};
-  p.mean = mean; p.cov = cov; p.col = scalar; p.alpha = alpha;
-  p.start = start; p.end = end; p.ids = gaussian_ids; p.topleft = topleft;
-  p.final_img = out; p.grad_out = grad_out;
-  p.g_mean = grad_mean; p.g_cov = grad_cov; p.g_col = grad_scalar; p.g_alpha = grad_alpha;
-  p.ntw = (int)n_tiles_w; p.nth = (int)n_tiles_h; p.H = (int)H; p.W = (int)W;
-  p.psx = pixel_size_x; p.psy = pixel_size_y; p.thresh = thresh;
-  return launch_bwd<MODE_SCALAR, 1>(p, (hipStream_t)stream);
-}
 
 int gsgen_vol_render_sh(uint32_t N, uint32_t D, const float *mean, const float *cov,
                         const float *sh_coeffs, const float *alpha, const int *start,
@@ -778,34 +582,5 @@ int gsgen_vol_render_sh(uint32_t N, uint32_t D, const float *mean, const float *
   }
 }
 
-int gsgen_vol_render_backward_sh(uint32_t N, uint32_t D, const float *mean, const float *cov,
-                                 const float *sh_coeffs, const float *alpha, const int *start,
-                                 const int *end, const int *gaussian_ids, const float *out,
-                                 float *grad_mean, float *grad_cov, float *grad_sh_coeffs,
-                                 float *grad_alpha, const float *grad_out, const float *topleft,
-                                 const float *c2w, uint32_t tile_size, uint32_t n_tiles_h,
-                                 uint32_t n_tiles_w, float pixel_size_x, float pixel_size_y,
-                                 uint32_t H, uint32_t W, uint32_t C, float thresh,
-                                 const float *bg_rgb, gsgen_stream_t stream) {
-  (void)bg_rgb;  // the background only enters through `out` (= final incl. bg*T)
-  if (int e = check_common(tile_size, start, end, out)) return e;
-  if (C < 1 || C > 4) return GSGEN_EUNSUPPORTED;
-  if (!c2w) return GSGEN_EINVAL;
-  if (N == 0 || D == 0) return 0;
-  CompParams p{};
-  p.mean = mean; p.cov = cov; p.col = sh_coeffs; p.alpha = alpha;
-  p.start = start; p.end = end; p.ids = gaussian_ids; p.topleft = topleft; p.rot = c2w;
-  p.final_img = out; p.grad_out = grad_out;
-  p.g_mean = grad_mean; p.g_cov = grad_cov; p.g_col = grad_sh_coeffs; p.g_alpha = grad_alpha;
-  p.ntw = (int)n_tiles_w; p.nth = (int)n_tiles_h; p.H = (int)H; p.W = (int)W;
-  p.psx = pixel_size_x; p.psy = pixel_size_y; p.thresh = thresh;
-  hipStream_t s = (hipStream_t)stream;
-  switch (C) {
-    case 1: return launch_bwd<MODE_SH, 1>(p, s);
-    case 2: return launch_bwd<MODE_SH, 2>(p, s);
-    case 3: return launch_bwd<MODE_SH, 3>(p, s);
-    default: return launch_bwd<MODE_SH, 4>(p, s);
-  }
-}
 
 }  // extern "C"

@@ -1,0 +1,193 @@
+// composite_common.hpp -- pieces shared by the compositing forward (composite.hip) and the
+// splat-parallel backward (composite_bwd.hip): parameter block, the reference-arithmetic
+// Gaussian evaluations of the guard path, the SH basis, per-record preparation.
+#pragma once
+#include <stdlib.h>
+
+#include "common.hpp"
+#include "../../include/gsgen_hip.h"
+
+namespace gs {
+
+enum : int { MODE_RGB = 0, MODE_SCALAR = 1, MODE_SH = 2 };
+constexpr int kBatch = 64;  // Gaussian records staged per LDS round
+
+struct CompParams {
+  const float *mean, *cov, *col, *alpha;
+  const int *start, *end, *ids;
+  const float *topleft, *rot, *bg;
+  float *out, *T;
+  const float *final_img, *grad_out;
+  float *g_mean, *g_cov, *g_col, *g_alpha;
+  int ntw, nth, H, W;
+  float psx, psy, thresh;
+  int dbg;  // experiment switches (GSGEN_DBG), 0 in production
+};
+
+// ---- reference-arithmetic Gaussian evaluations (rare path) ------------------------------
+// kernels.h:195-224
+static __device__ __noinline__ float gauss_ref_f64(float mx, float my, float c0f, float c1f, float c2f,
+                                            float c3f, float px, float py) {
+  const double c0 = c0f, c1 = c1f, c2 = c2f, c3 = c3f;
+  const double det = c0 * c3 - c1 * c2;
+  const double x = (double)(px - mx);
+  const double y = (double)(py - my);
+  const double tx = x * c3 - y * c2;
+  const double ty = -x * c1 + y * c0;
+  double radial = tx * x + ty * y;
+  radial /= det;
+  if (radial < 0.0) radial = 1000.0;
+  return (float)exp(-0.5 * radial);
+}
+// kernels.h:172-193, fp32 with every product rounded (the oracle's order)
+static __device__ __noinline__ float gauss_ref_f32(float mx, float my, float c0, float c1, float c2,
+                                            float c3, float px, float py) {
+#pragma clang fp contract(off)
+  const float det = c0 * c3 - c1 * c2;
+  const float x = px - mx;
+  const float y = py - my;
+  const float tx = x * c3 - y * c2;
+  const float ty = -x * c1 + y * c0;
+  float radial = tx * x + ty * y;
+  radial = radial / det;
+  if (radial < 0.0f) radial = 1000.0f;
+  return expf(-0.5f * radial);
+}
+
+// real SH basis, bands CB = 1..4 (shencoder.h:13-62)
+template <int CB>
+__device__ __forceinline__ void sh_basis(float x, float y, float z, float (&Y)[CB * CB]) {
+  Y[0] = 0.28209479177387814f;
+  if constexpr (CB >= 2) {
+    Y[1] = -0.48860251190291987f * y;
+    Y[2] = 0.48860251190291987f * z;
+    Y[3] = -0.48860251190291987f * x;
+  }
+  if constexpr (CB >= 3) {
+    const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+    Y[4] = 1.0925484305920792f * xy;
+    Y[5] = -1.0925484305920792f * yz;
+    Y[6] = 0.94617469575755997f * z2 - 0.31539156525251999f;
+    Y[7] = -1.0925484305920792f * xz;
+    Y[8] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2;
+    if constexpr (CB >= 4) {
+      Y[9] = 0.59004358992664352f * y * (-3.0f * x2 + y2);
+      Y[10] = 2.8906114426405538f * xy * z;
+      Y[11] = 0.45704579946446572f * y * (1.0f - 5.0f * z2);
+      Y[12] = 0.3731763325901154f * z * (5.0f * z2 - 3.0f);
+      Y[13] = 0.45704579946446572f * x * (1.0f - 5.0f * z2);
+      Y[14] = 1.4453057213202769f * z * (x2 - y2);
+      Y[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
+    }
+  }
+}
+
+__device__ __forceinline__ float sigmoid_fast(float s) {
+  // 1/(1+exp(-s)) (shencoder.h:4) on v_exp_f32 / v_rcp_f32
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-kLog2e * s));
+}
+
+template <int MODE, int CB>
+struct Traits {
+  static constexpr int CC = CB * CB;
+  static constexpr int NCOL = (MODE == MODE_SH) ? 3 * CC : (MODE == MODE_RGB ? 3 : 1);
+  static constexpr int NCH = (MODE == MODE_SCALAR) ? 1 : 3;
+  // gradient components per Gaussian: mean(2) cov(4, the two off-diagonals carry the same
+  // value) alpha(1) colour/scalar/sh(NCOL)
+  static constexpr int NCOMP = 7 + NCOL;
+  static constexpr int P = NCOMP <= 8 ? 8 : (NCOMP <= 16 ? 16 : (NCOMP <= 32 ? 32 : 64));
+  // LDS layout of the SH coefficients: each channel padded to a multiple of 4 floats so that
+  // a channel is read as aligned float4s and multiplied as (k, k+1) pairs by v_pk_fma_f32
+  static constexpr int CCP = (MODE == MODE_SH) ? ((CC + 3) & ~3) : CC;
+  static constexpr int NCOLP = (MODE == MODE_SH) ? 3 * CCP : NCOL;
+  static constexpr int NPAIR = CCP / 2;
+};
+
+
+// per-Gaussian values used by every (pixel, Gaussian) evaluation
+struct GRec {
+  float mx, my, a, c0, c1, c2, c3, p0, p1, p2;
+};
+
+// Builds the evaluation record of one Gaussian from its raw 2-D mean / covariance / opacity.
+// RGB/scalar: p0..p2 = Cholesky factor of the quadratic form scaled so that
+// G = exp2(-(u^2+v^2)), u = p0 x + p1 y, v = p2 y (computed in fp64 once per record).
+// SH: p0 = -0.5 log2(e)/det, p1 = 1/det with the fp32 determinant of kernels.h:179.
+// A degenerate / non-finite record gets a = 0 and never contributes.
+template <int MODE>
+__device__ __forceinline__ GRec prep_record(float mx, float my, float c0, float c1, float c2, float c3,
+                                            float alpha) {
+  GRec r;
+  r.mx = mx; r.my = my; r.c0 = c0; r.c1 = c1; r.c2 = c2; r.c3 = c3;
+  r.p0 = 0.f; r.p1 = 0.f; r.p2 = 0.f;
+  float a = fminf(alpha, kAlphaClamp);
+  bool ok = finite_f(mx) && finite_f(my) && finite_f(c0) && finite_f(c1) && finite_f(c2) && finite_f(c3) &&
+            finite_f(a);
+  if constexpr (MODE == MODE_SH) {
+    float det;
+    {
+#pragma clang fp contract(off)
+      det = c0 * c3 - c1 * c2;
+    }
+    ok = ok && (det > 0.0f) && finite_f(det);
+    const float inv = 1.0f / (ok ? det : 1.0f);
+    r.p0 = -0.5f * kLog2e * inv;
+    r.p1 = inv;
+  } else {
+    const double d0 = c0, d1 = c1, d2 = c2, d3 = c3;
+    const double det = d0 * d3 - d1 * d2;
+    ok = ok && (det > 0.0) && (d3 > 0.0);
+    const double sdet = ok ? det : 1.0, s3 = ok ? d3 : 1.0;
+    const double qa = s3 / sdet, qb = -0.5 * (d1 + d2) / sdet, qc = d0 / sdet;
+    const double l11 = sqrt(qa), l21 = qb / l11;
+    const double l22s = qc - l21 * l21;
+    ok = ok && (l22s > 0.0);
+    const double l22 = sqrt(ok ? l22s : 1.0);
+    const double sc = 0.84932180028801904;  // sqrt(0.5*log2(e))
+    if (ok) { r.p0 = (float)(l11 * sc); r.p1 = (float)(l21 * sc); r.p2 = (float)(l22 * sc); }
+  }
+  r.a = ok ? a : 0.0f;
+  return r;
+}
+
+// Gaussian value for one pixel.  x = px - mx, y = py - my.
+template <int MODE>
+__device__ __forceinline__ float gauss_eval(const GRec &r, float x, float y, float px, float py,
+                                            bool alive) {
+  float G;
+  if constexpr (MODE == MODE_SH) {
+    const float tx = x * r.c3 - y * r.c2;
+    const float ty = y * r.c0 - x * r.c1;
+    const float q = tx * x + ty * y;
+    G = __builtin_amdgcn_exp2f(r.p0 * q);
+    G = (q < 0.0f) ? 0.0f : G;  // kernels.h:186-188: radial < 0 -> exp(-500) == 0
+  } else {
+    const float u = r.p0 * x + r.p1 * y;
+    const float v = r.p2 * y;
+    G = __builtin_amdgcn_exp2f(-(u * u + v * v));
+  }
+  const float ag = r.a * G;
+  if (alive && fabsf(ag - kMinAlpha) <= kMinAlpha * kGuardTol) {
+    // within rounding of the skip threshold: take the reference's arithmetic
+    if constexpr (MODE == MODE_SH)
+      G = gauss_ref_f32(r.mx, r.my, r.c0, r.c1, r.c2, r.c3, px, py);
+    else
+      G = gauss_ref_f64(r.mx, r.my, r.c0, r.c1, r.c2, r.c3, px, py);
+  }
+  return G;
+}
+
+static inline int env_ppl(const char *name, int dflt) {
+  const char *v = getenv(name);
+  if (!v) return dflt;
+  const int x = atoi(v);
+  return (x == 1 || x == 2 || x == 4) ? x : dflt;
+}
+
+static inline int check_common(uint32_t tile_size, const void *a, const void *b, const void *c) {
+  if (tile_size != (uint32_t)kTile) return GSGEN_EUNSUPPORTED;
+  if (!a || !b || !c) return GSGEN_EINVAL;
+  return 0;
+}
+
+}  // namespace gs

@@ -90,6 +90,9 @@ inline int emu_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mas
   else if (ctrl > 0x100 && ctrl <= 0x10F) { int n = ctrl - 0x100; from = (in_row + n < 16) ? lane + n : -1; }
   else if (ctrl > 0x110 && ctrl <= 0x11F) { int n = ctrl - 0x110; from = (in_row - n >= 0) ? lane - n : -1; }
   else if (ctrl > 0x120 && ctrl <= 0x12F) { int n = ctrl - 0x120; from = (row << 4) | ((in_row - n) & 15); }
+  else if (ctrl == 0x138) from = lane - 1;  // wave_shr:1 (lane 0 has no source)
+  else if (ctrl == 0x142) from = (row >= 1) ? ((row - 1) << 4) | 15 : -1;  // row_bcast:15
+  else if (ctrl == 0x143) from = (row >= 2) ? 31 : -1;                       // row_bcast:31
   else if (ctrl == 0x140) from = (row << 4) | (15 - in_row);
   else if (ctrl == 0x141) from = (lane & ~7) | (7 - (lane & 7));
   const int got = simt::shfl_idx(src, from >= 0 ? from : lane);
@@ -100,6 +103,8 @@ inline int emu_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mas
 }
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) emu_update_dpp((old), (src), (ctrl), (rm), (bm), (bc))
 
+#define __builtin_amdgcn_readfirstlane(v) (v)
+#define __builtin_amdgcn_readlane(v, l) simt::shfl_idx((int)(v), (l))
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 

@@ -108,6 +108,34 @@ def test_emulated_kernels_match_oracle(emu, C, W, H):
     ref, refT = O.render_rgb_fwd(g["mean2d"], g["cov2d"], col, al, st, en, ids, tlp, 1 / cam.fx, 1 / cam.fy, H, W)
     assert np.abs(out - ref).max() < 1e-5
     go = np.random.default_rng(3).normal(size=(H, W, 3)).astype(np.float32)
+    # RGB backward (final includes a background, as gs/renderer.py:1182 folds it in)
+    bgimg = np.random.default_rng(4).uniform(size=(H, W, 3)).astype(np.float32)
+    final = (ref + refT * bgimg).astype(np.float32)
+    gm = np.zeros((N, 2), np.float32); gc = np.zeros((N, 4), np.float32)
+    gcol = np.zeros((N, 3), np.float32); ga = np.zeros(N, np.float32)
+    emu.vol_render_backward_start_end(N, D, P(m2), P(c2), P(col), P(al), P(st), P(en), P(ids), P(final), P(gm), P(gc),
+                                      P(gcol), P(ga), P(go), P(tlp), 16, nth, ntw, 1 / cam.fx, 1 / cam.fy, H, W, 1e-4,
+                                      None)
+    om, oc, ocol, oa = O.render_rgb_bwd(g["mean2d"], g["cov2d"], col, al, st, en, ids, final, go, tlp, 1 / cam.fx,
+                                        1 / cam.fy, H, W)
+    for a, b in ((gm, om), (gc, oc.reshape(-1, 4)), (gcol, ocol), (ga, oa)):
+        assert np.abs(a - b).max() <= 1e-4 * (np.abs(b).max() + 1e-12)
+    # scalar head backward
+    sval = np.ascontiguousarray(dep)
+    sout = np.zeros(H * W, np.float32); sT = np.ones((H, W), np.float32)
+    emu.vol_render_scalar(N, D, P(m2), P(c2), P(sval), P(al), P(st), P(en), P(ids), P(sout), P(tlp), 16, nth, ntw,
+                          1 / cam.fx, 1 / cam.fy, H, W, 1e-4, P(sT), None)
+    sref, _ = O.render_scalar_fwd(g["mean2d"], g["cov2d"], sval, al, st, en, ids, tlp, 1 / cam.fx, 1 / cam.fy, H, W)
+    assert np.abs(sout.reshape(H, W) - sref).max() < 1e-5 * max(1.0, np.abs(sref).max())
+    sgo = np.ascontiguousarray(go[..., 0])
+    gm = np.zeros((N, 2), np.float32); gc = np.zeros((N, 4), np.float32)
+    gs_ = np.zeros(N, np.float32); ga = np.zeros(N, np.float32)
+    emu.vol_render_scalar_backward(N, D, P(m2), P(c2), P(sval), P(al), P(st), P(en), P(ids), P(sref), P(gm), P(gc),
+                                   P(gs_), P(ga), P(sgo), P(tlp), 16, nth, ntw, 1 / cam.fx, 1 / cam.fy, H, W, 1e-4, None)
+    om, oc, os_, oa = O.render_scalar_bwd(g["mean2d"], g["cov2d"], sval, al, st, en, ids, sref, sgo, tlp, 1 / cam.fx,
+                                          1 / cam.fy, H, W)
+    for a, b in ((gm, om), (gc, oc.reshape(-1, 4)), (gs_, os_), (ga, oa)):
+        assert np.abs(a - b).max() <= 1e-4 * (np.abs(b).max() + 1e-12)
     sh = np.ascontiguousarray(sc["sh"][m]); rot = np.ascontiguousarray(cam.c2w[:3, :3]).reshape(-1).copy()
     bg = np.array([0.2, 0.5, 0.7], np.float32)
     out = np.zeros((H, W, 3), np.float32)
