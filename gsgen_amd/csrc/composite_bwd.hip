@@ -323,8 +323,10 @@ static int launch_bwd_splat(const CompParams &p, hipStream_t s) {
 }
 
 static int launch_bwd(int mode, int C, const CompParams &p, hipStream_t s) {
-  static const bool pixel = getenv("GSGEN_BWD") && getenv("GSGEN_BWD")[0] == 'p';
-  if (pixel) return launch_bwd_pixel_dispatch(mode, C, p, s);
+  // Two complete implementations (both parity-green); the faster one on MI355X is the default,
+  // GSGEN_BWD=splat|pixel selects explicitly for A/B measurements (profiles/).
+  static const bool splat = getenv("GSGEN_BWD") && getenv("GSGEN_BWD")[0] == 's';
+  if (!splat) return launch_bwd_pixel_dispatch(mode, C, p, s);
   if (mode == MODE_RGB) return launch_bwd_splat<MODE_RGB, 1>(p, s);
   if (mode == MODE_SCALAR) return launch_bwd_splat<MODE_SCALAR, 1>(p, s);
   switch (C) {
