@@ -28,7 +28,7 @@
 namespace gs {
 
 constexpr int kThreads = 256;
-constexpr int kSortThreads = 256;
+constexpr int kSortThreads = 64;  // one wavefront per tile: the 45+ bitonic stages need no workgroup barrier
 constexpr int kSortLds = 4096;  // keys sorted in LDS per tile (32 KiB); longer segments sort in global memory
 
 constexpr int kGroup = 8;      // tiles per group side: 8x8 tiles <-> 64 lanes
@@ -54,64 +54,130 @@ __device__ __forceinline__ GroupGeom group_geom(int ntw, int nth) {
 
 // EMIT = false: cnt[chunk][tile] = number of rectangles of the chunk covering the tile.
 // EMIT = true : write the keys at tile_off[tile] + cnt[chunk][tile] (now a prefix) + running.
+// Workgroup = 4 waves on one (group, chunk): wave w walks sub-chunk w (kChunk/4 Gaussians),
+// with all of its kIter rectangle loads in flight at once (the walk is latency-bound: one
+// dependent L2 round trip per 64 Gaussians otherwise).  The EMIT pass counts first, swaps the
+// four counts through LDS to get each wave's base, then replays the rectangles from registers.
+constexpr int kPullWaves = 4;
+constexpr int kIter = kChunk / (64 * kPullWaves);  // 64-Gaussian slices per wave
+
+struct RectRegs {
+  int x0[kIter], y0[kIter], x1[kIter], y1[kIter];
+};
+
+__device__ __forceinline__ int rd_lane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+
 template <bool EMIT>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64 * kPullWaves)
 k_bin_pull(uint32_t N, const int *__restrict__ tl, const int *__restrict__ br,
            const float *__restrict__ depth, int ntw, int nth, uint32_t T,
            uint32_t *__restrict__ cnt, const uint32_t *__restrict__ tile_off,
            const uint32_t *__restrict__ ctrl, unsigned long long *__restrict__ keys) {
+  __shared__ uint32_t s_cnt[kPullWaves][64];
   if (EMIT && ctrl[1] != 0u) return;  // capacity exceeded: bin nothing
   const GroupGeom q = group_geom(ntw, nth);
   const uint32_t chunk = blockIdx.y;
-  const uint32_t begin = chunk * (uint32_t)kChunk;
-  const uint32_t stop = min(N, begin + (uint32_t)kChunk);
   const int lane = lane_id();
-  uint32_t running = 0;
-  uint32_t base_pos = 0;
-  if (EMIT && q.in_grid) base_pos = tile_off[q.tile] + cnt[(size_t)chunk * T + q.tile];
-  for (uint32_t b0 = begin; b0 < stop; b0 += 64u) {
-    const uint32_t i = b0 + (uint32_t)lane;
+  const int wave = (int)(threadIdx.x >> 6);
+  const uint32_t begin = chunk * (uint32_t)kChunk + (uint32_t)wave * (uint32_t)(64 * kIter);
+  const uint32_t stop = min(N, chunk * (uint32_t)kChunk + (uint32_t)kChunk);
+
+  RectRegs R;
+  unsigned dbits[EMIT ? kIter : 1];
+  unsigned long long touch[kIter];
+#pragma unroll
+  for (int it = 0; it < kIter; ++it) {
+    const uint32_t i = begin + (uint32_t)(it * 64 + lane);
     int x0 = 0, y0 = 0, x1 = -1, y1 = -1;
-    unsigned long long key = 0ull;
     if (i < stop) {
       const int2 a = *reinterpret_cast<const int2 *>(tl + 2 * (size_t)i);
       const int2 c = *reinterpret_cast<const int2 *>(br + 2 * (size_t)i);
       // rectangles handed in through the C ABI are clamped to the grid (an out-of-grid tile
       // index would be an out-of-bounds write in the reference)
       x0 = max(a.x, 0); y0 = max(a.y, 0); x1 = min(c.x, ntw - 1); y1 = min(c.y, nth - 1);
-      if (EMIT) key = ((unsigned long long)__float_as_uint(depth[i]) << 32) | (unsigned long long)i;
+      if (EMIT) dbits[it] = __float_as_uint(depth[i]);
+    } else if (EMIT) {
+      dbits[it] = 0u;
     }
-    const bool touches = (x1 >= x0) && (y1 >= y0) && (x1 >= q.gx0) && (x0 <= q.gx0 + kGroup - 1) &&
-                         (y1 >= q.gy0) && (y0 <= q.gy0 + kGroup - 1);
+    R.x0[it] = x0; R.y0[it] = y0; R.x1[it] = x1; R.y1[it] = y1;
+  }
+  uint32_t running = 0;
+#pragma unroll
+  for (int it = 0; it < kIter; ++it) {
+    const bool touches = (R.x1[it] >= R.x0[it]) && (R.y1[it] >= R.y0[it]) && (R.x1[it] >= q.gx0) &&
+                         (R.x0[it] <= q.gx0 + kGroup - 1) && (R.y1[it] >= q.gy0) &&
+                         (R.y0[it] <= q.gy0 + kGroup - 1);
     unsigned long long m = __ballot(touches);
+    touch[it] = m;
     while (m != 0ull) {
       const int src = __ffsll((long long)m) - 1;
       m &= (m - 1ull);
-      const int rx0 = __shfl(x0, src, 64), ry0 = __shfl(y0, src, 64);
-      const int rx1 = __shfl(x1, src, 64), ry1 = __shfl(y1, src, 64);
+      const int rx0 = rd_lane(R.x0[it], src), rx1 = rd_lane(R.x1[it], src);
+      const int ry0 = rd_lane(R.y0[it], src), ry1 = rd_lane(R.y1[it], src);
       const bool hit = (q.tx >= rx0) && (q.tx <= rx1) && (q.ty >= ry0) && (q.ty <= ry1);
-      if (EMIT) {
-        const unsigned long long k = __shfl(key, src, 64);
-        if (hit) keys[base_pos + running] = k;
-      }
       running += hit ? 1u : 0u;
     }
   }
-  if (!EMIT && q.in_grid) cnt[(size_t)chunk * T + q.tile] = running;
+  s_cnt[wave][lane] = running;
+  __syncthreads();
+  if (!EMIT) {
+    if (wave == 0 && q.in_grid)
+      cnt[(size_t)chunk * T + q.tile] = s_cnt[0][lane] + s_cnt[1][lane] + s_cnt[2][lane] + s_cnt[3][lane];
+    return;
+  }
+  uint32_t pos = 0;
+  if (q.in_grid) {
+    pos = tile_off[q.tile] + cnt[(size_t)chunk * T + q.tile];
+    for (int w = 0; w < wave; ++w) pos += s_cnt[w][lane];
+  }
+#pragma unroll
+  for (int it = 0; it < kIter; ++it) {
+    unsigned long long m = touch[it];
+    const uint32_t i0 = begin + (uint32_t)(it * 64);
+    while (m != 0ull) {
+      const int src = __ffsll((long long)m) - 1;
+      m &= (m - 1ull);
+      const int rx0 = rd_lane(R.x0[it], src), rx1 = rd_lane(R.x1[it], src);
+      const int ry0 = rd_lane(R.y0[it], src), ry1 = rd_lane(R.y1[it], src);
+      const bool hit = (q.tx >= rx0) && (q.tx <= rx1) && (q.ty >= ry0) && (q.ty <= ry1);
+      const unsigned db = (unsigned)rd_lane((int)dbits[EMIT ? it : 0], src);
+      if (hit) {
+        keys[pos] = ((unsigned long long)db << 32) | (unsigned long long)(i0 + (uint32_t)src);
+        ++pos;
+      }
+    }
+  }
 }
 
-// per tile: exclusive scan of cnt[.][tile] over the chunks (in place), total -> tile_count
-__global__ void __launch_bounds__(kThreads)
+// per tile: exclusive scan of cnt[.][tile] over the chunks (in place), total -> tile_count.
+// One wave per tile, lanes <-> chunks, DPP prefix scan.
+__device__ __forceinline__ uint32_t wave_scan_add_u32(uint32_t x) {
+  int v = (int)x;
+  const int s1 = __builtin_amdgcn_update_dpp(0, v, kDppRowShr + 1, 0xf, 0xf, false);
+  const int s2 = __builtin_amdgcn_update_dpp(0, v, kDppRowShr + 2, 0xf, 0xf, false);
+  const int s3 = __builtin_amdgcn_update_dpp(0, v, kDppRowShr + 3, 0xf, 0xf, false);
+  v = v + s1 + s2 + s3;
+  v += __builtin_amdgcn_update_dpp(0, v, kDppRowShr + 4, 0xf, 0xe, false);
+  v += __builtin_amdgcn_update_dpp(0, v, kDppRowShr + 8, 0xf, 0xc, false);
+  v += __builtin_amdgcn_update_dpp(0, v, kDppRowBcast15, 0xa, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, kDppRowBcast31, 0xc, 0xf, false);
+  return (uint32_t)v;
+}
+
+__global__ void __launch_bounds__(256)
 k_scan_chunks(uint32_t T, uint32_t nchunks, uint32_t *__restrict__ cnt, uint32_t *__restrict__ tile_count) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t t = blockIdx.x * 4u + (threadIdx.x >> 6);  // one wave per tile
   if (t >= T) return;
-  uint32_t run = 0;
-  for (uint32_t c = 0; c < nchunks; ++c) {
-    const uint32_t v = cnt[(size_t)c * T + t];
-    cnt[(size_t)c * T + t] = run;
-    run += v;
+  const uint32_t lane = (uint32_t)lane_id();
+  uint32_t carry = 0;
+  for (uint32_t c0 = 0; c0 < nchunks; c0 += 64u) {
+    const uint32_t c = c0 + lane;
+    const uint32_t v = (c < nchunks) ? cnt[(size_t)c * T + t] : 0u;
+    const uint32_t inc = wave_scan_add_u32(v);
+    if (c < nchunks) cnt[(size_t)c * T + t] = carry + inc - v;
+    carry += (uint32_t)rd_lane((int)inc, 63);
   }
-  tile_count[t] = run;
+  if (lane == 0) tile_count[t] = carry;
 }
 
 // exclusive scan of tile_count[T] -> tile_off[T+1]; ctrl[0] = total, ctrl[1] = overflow flag
@@ -255,18 +321,19 @@ static int bin_and_sort(uint32_t N, uint32_t cap, uint32_t nth, uint32_t ntw, co
   const uint32_t T = nth * ntw;
   const uint32_t ngroups = ((ntw + kGroup - 1) / kGroup) * ((nth + kGroup - 1) / kGroup);
   const dim3 gpull(ngroups, w.nchunks);
+  const dim3 bpull(64 * kPullWaves);
   if (N == 0) {
     if (hipError_t e = hipMemsetAsync(w.cnt, 0, sizeof(uint32_t) * (size_t)w.nchunks * T, s)) return (int)e;
   } else {
-    hipLaunchKernelGGL((k_bin_pull<false>), gpull, dim3(64), 0, s, N, tl, br, depth, (int)ntw, (int)nth, T,
+    hipLaunchKernelGGL((k_bin_pull<false>), gpull, bpull, 0, s, N, tl, br, depth, (int)ntw, (int)nth, T,
                        w.cnt, (const uint32_t *)nullptr, (const uint32_t *)nullptr,
                        (unsigned long long *)nullptr);
   }
-  hipLaunchKernelGGL(k_scan_chunks, dim3((T + kThreads - 1) / kThreads), dim3(kThreads), 0, s, T, w.nchunks,
+  hipLaunchKernelGGL(k_scan_chunks, dim3((T + 3) / 4), dim3(256), 0, s, T, w.nchunks,
                      w.cnt, w.tile_count);
   hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, T, w.tile_count, w.tile_off, w.ctrl, cap, total_out);
   if (N)
-    hipLaunchKernelGGL((k_bin_pull<true>), gpull, dim3(64), 0, s, N, tl, br, depth, (int)ntw, (int)nth, T,
+    hipLaunchKernelGGL((k_bin_pull<true>), gpull, bpull, 0, s, N, tl, br, depth, (int)ntw, (int)nth, T,
                        w.cnt, w.tile_off, w.ctrl, w.keys);
   hipLaunchKernelGGL(k_sort_tiles, dim3(T), dim3(kSortThreads), 0, s, T, w.tile_off, w.ctrl, w.keys, ids, start, end);
   return (int)hipGetLastError();
