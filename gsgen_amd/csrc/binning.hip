@@ -28,7 +28,7 @@
 namespace gs {
 
 constexpr int kThreads = 256;
-constexpr int kSortThreads = 64;  // one wavefront per tile: the 45+ bitonic stages need no workgroup barrier
+constexpr int kSortThreads = 256;  // waves 1-3 only work on segments too long for the register sort
 constexpr int kSortLds = 4096;  // keys sorted in LDS per tile (32 KiB); longer segments sort in global memory
 
 constexpr int kGroup = 8;      // tiles per group side: 8x8 tiles <-> 64 lanes
@@ -215,6 +215,7 @@ k_scan_tiles(uint32_t T, const uint32_t *__restrict__ tile_count, uint32_t *__re
 
 // normalised bitonic network (every comparator puts the smaller key at the lower index), so
 // a segment of arbitrary length n behaves as if padded with +inf up to the next power of two.
+// LDS / global-memory form, one workgroup: only used for segments longer than 64*kSortMaxK.
 template <typename KeyPtr>
 __device__ __forceinline__ void bitonic_sort(KeyPtr k, uint32_t n, uint32_t tid, uint32_t nthreads) {
   uint32_t p2 = 1;
@@ -242,6 +243,80 @@ __device__ __forceinline__ void bitonic_sort(KeyPtr k, uint32_t n, uint32_t tid,
   }
 }
 
+// Register form: ONE wavefront sorts 64*K keys, K per lane (element e = lane*K + r), with no
+// memory traffic and no barrier: comparators whose partner lies in the same lane are plain
+// register compare-exchanges, the others trade registers with lane ^ m.
+typedef unsigned long long u64;
+__device__ __forceinline__ void cmpx(u64 &lo, u64 &hi) {
+  const u64 a = lo, b = hi;
+  const bool sw = a > b;
+  lo = sw ? b : a;
+  hi = sw ? a : b;
+}
+template <int K>
+__device__ __forceinline__ void cross_step(u64 (&k)[K], int m, bool flip) {
+  // partner lane = lane ^ m; in a flip step the partner register is K-1-r, else r
+  const int lane = lane_id();
+  int top = m;  // highest set bit of m decides who is the lower index
+  top |= top >> 1; top |= top >> 2; top |= top >> 4;
+  top = (top + 1) >> 1;
+  const bool keep_min = (lane & top) == 0;
+  u64 other[K];
+#pragma unroll
+  for (int r = 0; r < K; ++r) other[r] = __shfl_xor(k[flip ? (K - 1 - r) : r], m, 64);
+#pragma unroll
+  for (int r = 0; r < K; ++r) {
+    const u64 a = k[r], b = other[r];
+    const bool take = keep_min ? (b < a) : (b > a);
+    k[r] = take ? b : a;
+  }
+}
+template <int K>
+__device__ __forceinline__ void sort_regs(u64 (&k)[K]) {
+  constexpr int P2 = 64 * K;
+#pragma unroll
+  for (int size = 2; size <= P2; size <<= 1) {
+    if (size <= K) {
+#pragma unroll
+      for (int r = 0; r < K; ++r) {
+        const int l = r ^ (size - 1);
+        if (l > r) cmpx(k[r], k[l]);
+      }
+    } else {
+      cross_step<K>(k, size / K - 1, true);
+    }
+#pragma unroll
+    for (int j = size >> 2; j >= 1; j >>= 1) {
+      if (j >= K) {
+        cross_step<K>(k, j / K, false);
+      } else {
+#pragma unroll
+        for (int r = 0; r < K; ++r) {
+          const int l = r ^ j;
+          if (l > r) cmpx(k[r], k[l]);
+        }
+      }
+    }
+  }
+}
+template <int K>
+__device__ __forceinline__ void sort_segment_regs(const u64 *__restrict__ keys, int *__restrict__ ids, uint32_t n) {
+  const uint32_t lane = (uint32_t)lane_id();
+  u64 k[K];
+#pragma unroll
+  for (int r = 0; r < K; ++r) {
+    const uint32_t e = lane * K + r;
+    k[r] = (e < n) ? keys[e] : ~0ull;  // +inf padding
+  }
+  sort_regs<K>(k);
+#pragma unroll
+  for (int r = 0; r < K; ++r) {
+    const uint32_t e = lane * K + r;
+    if (e < n) ids[e] = (int)(uint32_t)(k[r] & 0xffffffffull);
+  }
+}
+constexpr int kSortMaxK = 32;  // 2048 keys in registers; longer segments take the workgroup path
+
 __global__ void __launch_bounds__(kSortThreads)
 k_sort_tiles(uint32_t T, const uint32_t *__restrict__ tile_off, const uint32_t *__restrict__ ctrl,
              unsigned long long *__restrict__ keys, int *__restrict__ ids, int *__restrict__ start,
@@ -260,7 +335,15 @@ k_sort_tiles(uint32_t T, const uint32_t *__restrict__ tile_off, const uint32_t *
     end[tile] = n ? (int)e : -1;
   }
   if (n == 0) return;
-  if (n <= (uint32_t)kSortLds) {
+  if (n <= 64u * kSortMaxK) {
+    if (tid >= 64u) return;  // one wavefront does it, in registers
+    if (n <= 64u) sort_segment_regs<1>(keys + b, ids + b, n);
+    else if (n <= 128u) sort_segment_regs<2>(keys + b, ids + b, n);
+    else if (n <= 256u) sort_segment_regs<4>(keys + b, ids + b, n);
+    else if (n <= 512u) sort_segment_regs<8>(keys + b, ids + b, n);
+    else if (n <= 1024u) sort_segment_regs<16>(keys + b, ids + b, n);
+    else sort_segment_regs<32>(keys + b, ids + b, n);
+  } else if (n <= (uint32_t)kSortLds) {
     for (uint32_t i = tid; i < n; i += kSortThreads) s_keys[i] = keys[b + i];
     __syncthreads();
     bitonic_sort(s_keys, n, tid, kSortThreads);

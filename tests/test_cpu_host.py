@@ -188,3 +188,26 @@ def test_emulated_reduce_scatter(emu, Pc):
     emu.selftest_reduce_scatter(Pc, P(x), P(out), None)
     want = x.astype(np.float64).sum(0)[np.arange(64) % Pc]
     assert np.abs(out - want).max() < 1e-4
+
+
+def test_emulated_sort_register_widths(emu):
+    """register sort K = 1..32 and the workgroup path under emulation"""
+    sizes = (1, 64, 65, 130, 300, 600, 1100, 2049)
+    ntw, nth = len(sizes), 1
+    rng = np.random.default_rng(12)
+    tl_l, dep_l = [], []
+    for t_, n in enumerate(sizes):
+        tl_l.append(np.tile(np.array([[t_, 0]], np.int32), (n, 1)))
+        d = rng.uniform(0.1, 5.0, n).astype(np.float32)
+        d[rng.integers(0, n, n // 3)] = 1.25
+        dep_l.append(d)
+    tl = np.concatenate(tl_l); depth = np.concatenate(dep_l)
+    perm = rng.permutation(len(depth))
+    tl, depth = np.ascontiguousarray(tl[perm]), np.ascontiguousarray(depth[perm])
+    br = tl.copy()
+    N = D = len(depth)
+    oi, os_, oe = O.bin_sort(tl, br, depth, nth, ntw, D)
+    ids = np.zeros(D, np.int32); st = -np.ones(ntw, np.int32); en = -np.ones(ntw, np.int32)
+    ws = np.zeros(emu.tile_culling_workspace_bytes(N, D, ntw), np.uint8)
+    emu.tile_culling_aabb_start_end(N, D, nth, ntw, P(tl), P(br), P(depth), P(ids), P(st), P(en), P(ws), ws.size, None)
+    assert np.array_equal(st, os_) and np.array_equal(en, oe) and np.array_equal(ids, oi)

@@ -302,6 +302,35 @@ def test_long_tile_list_and_ties():
     assert np.array_equal(ids.cpu().numpy(), oi)
 
 
+@pytest.mark.parametrize("sizes", [(1, 40, 64, 65, 100, 128, 129, 200, 256, 300, 511, 513, 700, 1024, 1500, 2047, 2049, 3000)])
+def test_sort_every_register_width(sizes):
+    """Per-tile segments of every size class of the register sort (K = 1..32 keys per lane),
+    the LDS path and their boundaries, with duplicate depths."""
+    L = lib()
+    ntw, nth = len(sizes), 1
+    rng = np.random.default_rng(12)
+    tl_l, br_l, dep_l = [], [], []
+    for t_, n in enumerate(sizes):
+        tl_l.append(np.tile(np.array([[t_, 0]], np.int32), (n, 1))); br_l.append(tl_l[-1].copy())
+        d = rng.uniform(0.1, 5.0, n).astype(np.float32)
+        d[rng.integers(0, n, n // 3)] = 1.25  # ties
+        dep_l.append(d)
+    tl = np.concatenate(tl_l); br = np.concatenate(br_l); depth = np.concatenate(dep_l)
+    perm = rng.permutation(len(depth))
+    tl, br, depth = tl[perm], br[perm], depth[perm]
+    N = D = len(depth)
+    oi, os_, oe = O.bin_sort(tl, br, depth, nth, ntw, D)
+    ids = torch.zeros(D, dtype=torch.int32, device=dev())
+    st = -torch.ones(ntw, dtype=torch.int32, device=dev()); en = -torch.ones_like(st)
+    nb = L.tile_culling_workspace_bytes(N, D, ntw)
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev())
+    L.tile_culling_aabb_start_end(N, D, nth, ntw, p(T_(tl)), p(T_(br)), p(T_(depth)), p(ids), p(st), p(en), p(ws), nb,
+                                  stream())
+    torch.cuda.synchronize()
+    assert np.array_equal(st.cpu().numpy(), os_) and np.array_equal(en.cpu().numpy(), oe)
+    assert np.array_equal(ids.cpu().numpy(), oi)
+
+
 def test_run_to_run_determinism_forward(case):
     """The forward has no atomics on the image path and the per-tile order is unique:
     two runs are bit-identical."""
