@@ -152,23 +152,24 @@ def main():
 
     def step(i, timed=None):
         k = i % len(cams)
+        order = None if os.environ.get("GSGEN_NO_ORDER") else buf.tile_order()
         lib.frame_geometry(N, p(t["mean"]), p(t["qvec"]), p(t["svec"]), p(cam_dev[k]), W, H, buf.D_cap,
                            p(buf.mean2d), p(buf.cov2d), p(buf.depth), p(buf.mask), p(buf.ids), p(buf.start),
                            p(buf.end), p(buf.total), p(buf.ws), buf.ws.numel(), s)
         if timed is not None:
             timed[0].record(stream)
-        lib.vol_render_sh(N, buf.D_cap, p(buf.mean2d), p(buf.cov2d), p(t["sh"]), p(t["alpha"]), p(buf.start),
-                          p(buf.end), p(buf.ids), p(out), p(topleft), p(rot_dev[k]), 16, nth, ntw, psx, psy,
-                          H, W, C, 1e-4, p(bg), None, s)
+        lib.vol_render_sh_ordered(N, buf.D_cap, p(buf.mean2d), p(buf.cov2d), p(t["sh"]), p(t["alpha"]), p(buf.start),
+                                  p(buf.end), p(buf.ids), p(out), p(topleft), p(rot_dev[k]), 16, nth, ntw, psx, psy,
+                                  H, W, C, 1e-4, p(bg), None, order, s)
         if timed is not None:
             timed[1].record(stream)
         gflat.zero_()
         if timed is not None:
             timed[2].record(stream)
-        lib.vol_render_backward_sh(N, buf.D_cap, p(buf.mean2d), p(buf.cov2d), p(t["sh"]), p(t["alpha"]),
-                                   p(buf.start), p(buf.end), p(buf.ids), p(out), p(g_mean2d), p(g_cov2d),
-                                   p(g_sh), p(g_alpha), p(grad_out), p(topleft), p(rot_dev[k]), 16, nth, ntw,
-                                   psx, psy, H, W, C, 1e-4, p(bg), s)
+        lib.vol_render_backward_sh_ordered(N, buf.D_cap, p(buf.mean2d), p(buf.cov2d), p(t["sh"]), p(t["alpha"]),
+                                           p(buf.start), p(buf.end), p(buf.ids), p(out), p(g_mean2d), p(g_cov2d),
+                                           p(g_sh), p(g_alpha), p(grad_out), p(topleft), p(rot_dev[k]), 16, nth, ntw,
+                                           psx, psy, H, W, C, 1e-4, p(bg), order, s)
         if timed is not None:
             timed[3].record(stream)
         lib.project_gaussians_backward_masked(N, p(t["mean"]), p(t["qvec"]), p(t["svec"]), p(cam_dev[k]), 1,

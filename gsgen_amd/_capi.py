@@ -34,13 +34,20 @@ SIGNATURES = {
     "gsgen_project_gaussians_backward_masked": [u32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp],
     "gsgen_tile_culling_aabb_count": [u32, vp, vp, u32, f32, f32, f32, f32, u32, u32, f32, vp, vp, vp, vp],
     "gsgen_selftest_reduce_scatter": [u32, vp, vp, vp],
+    "gsgen_vol_render_sh_ordered": [u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, u32, f32, f32,
+                                    u32, u32, u32, f32, vp, vp, vp, vp],
+    "gsgen_vol_render_backward_sh_ordered": [u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                                             vp, u32, u32, u32, f32, f32, u32, u32, u32, f32, vp, vp, vp],
     "gsgen_frame_geometry": [u32, vp, vp, vp, vp, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp],
+}
+PTR_FUNCS = {
+    "gsgen_frame_tile_order": [vp, u32, u32, u32],
 }
 SIZE_FUNCS = {
     "gsgen_tile_culling_workspace_bytes": [u32, u32, u32],
     "gsgen_frame_workspace_bytes": [u32, u32, u32],
 }
-EXPORTS = sorted(list(SIGNATURES) + list(SIZE_FUNCS) + ["gsgen_version", "gsgen_error_string"])
+EXPORTS = sorted(list(SIGNATURES) + list(SIZE_FUNCS) + list(PTR_FUNCS) + ["gsgen_version", "gsgen_error_string"])
 
 
 class GsgenError(RuntimeError):
@@ -64,6 +71,11 @@ class Lib:
             fn.argtypes = argt
             fn.restype = i32
             setattr(self, name[len("gsgen_"):], self._checked(name, fn))
+        for name, argt in PTR_FUNCS.items():
+            fn = getattr(self.cdll, name)
+            fn.argtypes = argt
+            fn.restype = vp
+            setattr(self, name[len("gsgen_"):], fn)
         for name, argt in SIZE_FUNCS.items():
             fn = getattr(self.cdll, name)
             fn.argtypes = argt

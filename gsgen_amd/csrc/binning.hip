@@ -213,6 +213,31 @@ k_scan_tiles(uint32_t T, const uint32_t *__restrict__ tile_count, uint32_t *__re
   }
 }
 
+// Longest-list-first launch order for the compositing kernels (LPT scheduling): a tile's
+// cost grows with its list length, the image centre carries lists several times longer than
+// the border, and a compositing launch does not fit the chip all at once -- started in spatial
+// order the long tiles begin late and the launch ends on a few stragglers.  Counting sort of
+// the tiles by (list length / 8) descending, one workgroup, LDS atomics only.
+__global__ void __launch_bounds__(1024)
+k_order_tiles(uint32_t T, const uint32_t *__restrict__ tile_count, uint32_t *__restrict__ tile_order) {
+  __shared__ uint32_t s_hist[256];
+  __shared__ uint32_t s_base[256];
+  const uint32_t t = threadIdx.x;
+  if (t < 256u) s_hist[t] = 0u;
+  __syncthreads();
+  for (uint32_t i = t; i < T; i += 1024u) atomicAdd(&s_hist[255u - min(tile_count[i] >> 3, 255u)], 1u);
+  __syncthreads();
+  if (t == 0) {
+    uint32_t run = 0;
+    for (int b = 0; b < 256; ++b) { s_base[b] = run; run += s_hist[b]; }
+  }
+  __syncthreads();
+  for (uint32_t i = t; i < T; i += 1024u) {
+    const uint32_t b = 255u - min(tile_count[i] >> 3, 255u);
+    tile_order[atomicAdd(&s_base[b], 1u)] = i;
+  }
+}
+
 // normalised bitonic network (every comparator puts the smaller key at the lower index), so
 // a segment of arbitrary length n behaves as if padded with +inf up to the next power of two.
 // LDS / global-memory form, one workgroup: only used for segments longer than 64*kSortMaxK.
@@ -372,7 +397,7 @@ __global__ void __launch_bounds__(64) k_selftest_reduce_scatter(const float *__r
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct BinWs {
-  uint32_t *tile_count, *tile_off, *ctrl, *cnt;
+  uint32_t *tile_count, *tile_off, *ctrl, *cnt, *tile_order;
   unsigned long long *keys;
   int *tl, *br;  // only in the frame workspace
   uint32_t nchunks;
@@ -388,6 +413,7 @@ static BinWs carve(void *base, uint32_t N, uint32_t D, uint32_t T, bool with_rec
   w.tile_count = (uint32_t *)take(sizeof(uint32_t) * ((size_t)T + 4));
   w.ctrl = w.tile_count ? w.tile_count + T : nullptr;
   w.tile_off = (uint32_t *)take(sizeof(uint32_t) * ((size_t)T + 1));
+  w.tile_order = (uint32_t *)take(sizeof(uint32_t) * (size_t)(T ? T : 1));
   w.cnt = (uint32_t *)take(sizeof(uint32_t) * (size_t)w.nchunks * T);
   w.keys = (unsigned long long *)take(sizeof(unsigned long long) * (size_t)(D ? D : 1));
   if (with_rects) {
@@ -415,6 +441,7 @@ static int bin_and_sort(uint32_t N, uint32_t cap, uint32_t nth, uint32_t ntw, co
   hipLaunchKernelGGL(k_scan_chunks, dim3((T + 3) / 4), dim3(256), 0, s, T, w.nchunks,
                      w.cnt, w.tile_count);
   hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, T, w.tile_count, w.tile_off, w.ctrl, cap, total_out);
+  hipLaunchKernelGGL(k_order_tiles, dim3(1), dim3(1024), 0, s, T, w.tile_count, w.tile_order);
   if (N)
     hipLaunchKernelGGL((k_bin_pull<true>), gpull, bpull, 0, s, N, tl, br, depth, (int)ntw, (int)nth, T,
                        w.cnt, w.tile_off, w.ctrl, w.keys);
@@ -474,6 +501,10 @@ int gsgen_tile_culling_aabb_start_end(uint32_t N, uint32_t D, uint32_t n_tiles_h
   if (w.bytes > workspace_bytes) return GSGEN_EWORKSPACE;
   return bin_and_sort(N, D, n_tiles_h, n_tiles_w, aabb_topleft, aabb_bottomright, depth, gaussian_ids,
                       start, end, w, nullptr, (hipStream_t)stream);
+}
+
+const uint32_t *gsgen_frame_tile_order(void *workspace, uint32_t N, uint32_t D_cap, uint32_t n_tiles) {
+  return carve(workspace, N, D_cap, n_tiles, true).tile_order;
 }
 
 size_t gsgen_frame_workspace_bytes(uint32_t N, uint32_t D_cap, uint32_t n_tiles) {

@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(256 / PPL) k_composite_fwd(CompParams p) {
   __shared__ Stage<MODE, CB> S;
 
   int tx, ty;
-  if (!tile_of_block(blockIdx.x, p.ntw, p.nth, tx, ty)) return;  // uniform over the workgroup
+  if (!block_tile(p, tx, ty)) return;  // uniform over the workgroup
   const int tile = ty * p.ntw + tx;
   const int st = p.start[tile];
   const int n = (st < 0) ? 0 : (p.end[tile] - st);
@@ -282,7 +282,7 @@ __global__ void __launch_bounds__(256 / PPL) k_composite_bwd_pixel(CompParams p)
   __shared__ Stage<MODE, CB> S;
 
   int tx, ty;
-  if (!tile_of_block(blockIdx.x, p.ntw, p.nth, tx, ty)) return;  // uniform over the workgroup
+  if (!block_tile(p, tx, ty)) return;  // uniform over the workgroup
   const int tile = ty * p.ntw + tx;
   const int st = p.start[tile];
   const int n = (st < 0) ? 0 : (p.end[tile] - st);
@@ -481,7 +481,7 @@ __global__ void __launch_bounds__(256 / PPL) k_composite_bwd_pixel(CompParams p)
 template <int MODE, int CB>
 static int launch_fwd(const CompParams &p, hipStream_t s) {
   static const int ppl = env_ppl("GSGEN_PPL_FWD", 4);
-  const uint32_t nblk = tile_map_blocks(p.ntw, p.nth);
+  const uint32_t nblk = comp_grid(p);
   if (p.ntw * p.nth == 0) return 0;
   if (ppl == 1) hipLaunchKernelGGL((k_composite_fwd<MODE, CB, 1>), dim3(nblk), dim3(256), 0, s, p);
   else if (ppl == 2) hipLaunchKernelGGL((k_composite_fwd<MODE, CB, 2>), dim3(nblk), dim3(128), 0, s, p);
@@ -494,7 +494,7 @@ static int launch_bwd(const CompParams &p_, hipStream_t s) {
   static const int dbg = getenv("GSGEN_DBG") ? atoi(getenv("GSGEN_DBG")) : 0;
   CompParams p = p_;
   p.dbg = dbg;
-  const uint32_t nblk = tile_map_blocks(p.ntw, p.nth);
+  const uint32_t nblk = comp_grid(p);
   if (p.ntw * p.nth == 0) return 0;
   if (ppl == 1) hipLaunchKernelGGL((k_composite_bwd_pixel<MODE, CB, 1>), dim3(nblk), dim3(256), 0, s, p);
   else if (ppl == 2) hipLaunchKernelGGL((k_composite_bwd_pixel<MODE, CB, 2>), dim3(nblk), dim3(128), 0, s, p);
@@ -556,13 +556,13 @@ int gsgen_vol_render_scalar(uint32_t N, uint32_t D, const float *mean, const flo
 }
 
 
-int gsgen_vol_render_sh(uint32_t N, uint32_t D, const float *mean, const float *cov,
-                        const float *sh_coeffs, const float *alpha, const int *start,
-                        const int *end, const int *gaussian_ids, float *out, const float *topleft,
-                        const float *c2w, uint32_t tile_size, uint32_t n_tiles_h,
-                        uint32_t n_tiles_w, float pixel_size_x, float pixel_size_y, uint32_t H,
-                        uint32_t W, uint32_t C, float thresh, const float *bg_rgb, float *T,
-                        gsgen_stream_t stream) {
+int gsgen_vol_render_sh_ordered(uint32_t N, uint32_t D, const float *mean, const float *cov,
+                                const float *sh_coeffs, const float *alpha, const int *start,
+                                const int *end, const int *gaussian_ids, float *out, const float *topleft,
+                                const float *c2w, uint32_t tile_size, uint32_t n_tiles_h,
+                                uint32_t n_tiles_w, float pixel_size_x, float pixel_size_y, uint32_t H,
+                                uint32_t W, uint32_t C, float thresh, const float *bg_rgb, float *T,
+                                const uint32_t *tile_order, gsgen_stream_t stream) {
   if (int e = check_common(tile_size, start, end, out)) return e;
   if (C < 1 || C > 4) return GSGEN_EUNSUPPORTED;  // reference dispatches C = 1..4 only (render.cu:507-544)
   if (!c2w) return GSGEN_EINVAL;
@@ -573,6 +573,7 @@ int gsgen_vol_render_sh(uint32_t N, uint32_t D, const float *mean, const float *
   p.bg = bg_rgb; p.out = out; p.T = T;
   p.ntw = (int)n_tiles_w; p.nth = (int)n_tiles_h; p.H = (int)H; p.W = (int)W;
   p.psx = pixel_size_x; p.psy = pixel_size_y; p.thresh = thresh;
+  p.tile_order = tile_order;
   hipStream_t s = (hipStream_t)stream;
   switch (C) {
     case 1: return launch_fwd<MODE_SH, 1>(p, s);
@@ -582,5 +583,16 @@ int gsgen_vol_render_sh(uint32_t N, uint32_t D, const float *mean, const float *
   }
 }
 
+int gsgen_vol_render_sh(uint32_t N, uint32_t D, const float *mean, const float *cov,
+                        const float *sh_coeffs, const float *alpha, const int *start,
+                        const int *end, const int *gaussian_ids, float *out, const float *topleft,
+                        const float *c2w, uint32_t tile_size, uint32_t n_tiles_h,
+                        uint32_t n_tiles_w, float pixel_size_x, float pixel_size_y, uint32_t H,
+                        uint32_t W, uint32_t C, float thresh, const float *bg_rgb, float *T,
+                        gsgen_stream_t stream) {
+  return gsgen_vol_render_sh_ordered(N, D, mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out, topleft,
+                                     c2w, tile_size, n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H, W, C,
+                                     thresh, bg_rgb, T, nullptr, stream);
+}
 
 }  // extern "C"

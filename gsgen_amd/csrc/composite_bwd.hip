@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(256) k_composite_bwd_splat(CompParams p) {
   __shared__ int s_any[kBatch];
 
   int tx, ty;
-  if (!tile_of_block(blockIdx.x, p.ntw, p.nth, tx, ty)) return;  // uniform over the workgroup
+  if (!block_tile(p, tx, ty)) return;  // uniform over the workgroup
   const int tile = ty * p.ntw + tx;
   const int st = p.start[tile];
   const int n = (st < 0) ? 0 : (p.end[tile] - st);
@@ -316,7 +316,7 @@ __global__ void __launch_bounds__(256) k_composite_bwd_splat(CompParams p) {
 
 template <int MODE, int CB>
 static int launch_bwd_splat(const CompParams &p, hipStream_t s) {
-  const uint32_t nblk = tile_map_blocks(p.ntw, p.nth);
+  const uint32_t nblk = comp_grid(p);
   if (p.ntw * p.nth == 0) return 0;
   hipLaunchKernelGGL((k_composite_bwd_splat<MODE, CB>), dim3(nblk), dim3(256), 0, s, p);
   return (int)hipGetLastError();
@@ -384,15 +384,16 @@ int gsgen_vol_render_scalar_backward(uint32_t N, uint32_t D, const float *mean, 
   return launch_bwd(MODE_SCALAR, 1, p, (hipStream_t)stream);
 }
 
-int gsgen_vol_render_backward_sh(uint32_t N, uint32_t D, const float *mean, const float *cov,
-                                 const float *sh_coeffs, const float *alpha, const int *start,
-                                 const int *end, const int *gaussian_ids, const float *out,
-                                 float *grad_mean, float *grad_cov, float *grad_sh_coeffs,
-                                 float *grad_alpha, const float *grad_out, const float *topleft,
-                                 const float *c2w, uint32_t tile_size, uint32_t n_tiles_h,
-                                 uint32_t n_tiles_w, float pixel_size_x, float pixel_size_y,
-                                 uint32_t H, uint32_t W, uint32_t C, float thresh,
-                                 const float *bg_rgb, gsgen_stream_t stream) {
+int gsgen_vol_render_backward_sh_ordered(uint32_t N, uint32_t D, const float *mean, const float *cov,
+                                         const float *sh_coeffs, const float *alpha, const int *start,
+                                         const int *end, const int *gaussian_ids, const float *out,
+                                         float *grad_mean, float *grad_cov, float *grad_sh_coeffs,
+                                         float *grad_alpha, const float *grad_out, const float *topleft,
+                                         const float *c2w, uint32_t tile_size, uint32_t n_tiles_h,
+                                         uint32_t n_tiles_w, float pixel_size_x, float pixel_size_y,
+                                         uint32_t H, uint32_t W, uint32_t C, float thresh,
+                                         const float *bg_rgb, const uint32_t *tile_order,
+                                         gsgen_stream_t stream) {
   (void)bg_rgb;  // the background only enters through `out` (= final incl. bg*T)
   if (int e = check_common(tile_size, start, end, out)) return e;
   if (C < 1 || C > 4) return GSGEN_EUNSUPPORTED;
@@ -405,7 +406,23 @@ int gsgen_vol_render_backward_sh(uint32_t N, uint32_t D, const float *mean, cons
   p.g_mean = grad_mean; p.g_cov = grad_cov; p.g_col = grad_sh_coeffs; p.g_alpha = grad_alpha;
   p.ntw = (int)n_tiles_w; p.nth = (int)n_tiles_h; p.H = (int)H; p.W = (int)W;
   p.psx = pixel_size_x; p.psy = pixel_size_y; p.thresh = thresh;
+  p.tile_order = tile_order;
   return launch_bwd(MODE_SH, (int)C, p, (hipStream_t)stream);
+}
+
+int gsgen_vol_render_backward_sh(uint32_t N, uint32_t D, const float *mean, const float *cov,
+                                 const float *sh_coeffs, const float *alpha, const int *start,
+                                 const int *end, const int *gaussian_ids, const float *out,
+                                 float *grad_mean, float *grad_cov, float *grad_sh_coeffs,
+                                 float *grad_alpha, const float *grad_out, const float *topleft,
+                                 const float *c2w, uint32_t tile_size, uint32_t n_tiles_h,
+                                 uint32_t n_tiles_w, float pixel_size_x, float pixel_size_y,
+                                 uint32_t H, uint32_t W, uint32_t C, float thresh,
+                                 const float *bg_rgb, gsgen_stream_t stream) {
+  return gsgen_vol_render_backward_sh_ordered(N, D, mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out,
+                                              grad_mean, grad_cov, grad_sh_coeffs, grad_alpha, grad_out, topleft,
+                                              c2w, tile_size, n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y,
+                                              H, W, C, thresh, bg_rgb, nullptr, stream);
 }
 
 }  // extern "C"

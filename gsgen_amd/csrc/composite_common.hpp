@@ -22,7 +22,22 @@ struct CompParams {
   int ntw, nth, H, W;
   float psx, psy, thresh;
   int dbg;  // experiment switches (GSGEN_DBG), 0 in production
+  const uint32_t *tile_order;  // optional launch order (longest list first); NULL = spatial map
 };
+
+// workgroup -> tile: explicit order if given, else the XCD-balanced spatial map
+__device__ __forceinline__ bool block_tile(const CompParams &p, int &tx, int &ty) {
+  if (p.tile_order != nullptr) {
+    const uint32_t t = p.tile_order[blockIdx.x];
+    tx = (int)(t % (uint32_t)p.ntw);
+    ty = (int)(t / (uint32_t)p.ntw);
+    return true;
+  }
+  return tile_of_block(blockIdx.x, p.ntw, p.nth, tx, ty);
+}
+__host__ __forceinline__ uint32_t comp_grid(const CompParams &p) {
+  return p.tile_order != nullptr ? (uint32_t)(p.ntw * p.nth) : tile_map_blocks(p.ntw, p.nth);
+}
 
 // ---- reference-arithmetic Gaussian evaluations (rare path) ------------------------------
 // kernels.h:195-224

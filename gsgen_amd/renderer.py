@@ -333,6 +333,10 @@ class FrameBuffers:
         nbytes = _capi.load().frame_workspace_bytes(self.N, self.D_cap, self.nth * self.ntw)
         self.ws = torch.empty(nbytes, device=self.device, dtype=torch.uint8)
 
+    def tile_order(self):
+        """device address of the longest-list-first launch order written by frame_geometry"""
+        return _capi.load().frame_tile_order(self.ws.data_ptr(), self.N, self.D_cap, self.nth * self.ntw)
+
     def ensure_capacity(self):
         """Host-side check (one sync): did the last frame fit?  Grows the pair buffers if not."""
         need = int(self.total.item())
@@ -369,9 +373,10 @@ class _render_frame(torch.autograd.Function):
         s = _stream(mean)
         with torch.cuda.device(dev):
             if C > 0:
-                lib.vol_render_sh(buf.N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col), _p(alpha),
-                                  _p(buf.start), _p(buf.end), _p(buf.ids), _p(out), _p(topleft), _p(rot),
-                                  16, buf.nth, buf.ntw, psx, psy, H, W, C, thresh, _p(bg_rgb), _p(T), s)
+                lib.vol_render_sh_ordered(buf.N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col), _p(alpha),
+                                          _p(buf.start), _p(buf.end), _p(buf.ids), _p(out), _p(topleft), _p(rot),
+                                          16, buf.nth, buf.ntw, psx, psy, H, W, C, thresh, _p(bg_rgb), _p(T),
+                                          buf.tile_order(), s)
             else:
                 lib.vol_render_start_end_with_T(buf.N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col),
                                                 _p(alpha), _p(buf.start), _p(buf.end), _p(buf.ids),
@@ -400,10 +405,11 @@ class _render_frame(torch.autograd.Function):
         s = _stream(mean)
         with torch.cuda.device(dev):
             if C > 0:
-                lib.vol_render_backward_sh(N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col), _p(alpha),
-                                           _p(buf.start), _p(buf.end), _p(buf.ids), _p(out), _p(g_mean2d),
-                                           _p(g_cov2d), _p(g_col), _p(g_alpha), _p(grad), _p(topleft),
-                                           _p(rot), 16, buf.nth, buf.ntw, psx, psy, H, W, C, thresh, None, s)
+                lib.vol_render_backward_sh_ordered(N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col), _p(alpha),
+                                                   _p(buf.start), _p(buf.end), _p(buf.ids), _p(out), _p(g_mean2d),
+                                                   _p(g_cov2d), _p(g_col), _p(g_alpha), _p(grad), _p(topleft),
+                                                   _p(rot), 16, buf.nth, buf.ntw, psx, psy, H, W, C, thresh, None,
+                                                   buf.tile_order(), s)
             else:
                 lib.vol_render_backward_start_end(N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col),
                                                   _p(alpha), _p(buf.start), _p(buf.end), _p(buf.ids),

@@ -162,6 +162,29 @@ int gsgen_frame_geometry(uint32_t N, const float *mean, const float *qvec, const
                          int *end, uint32_t *total, void *workspace, size_t workspace_bytes,
                          gsgen_stream_t stream);
 
+/* Launch order for the compositing kernels produced by gsgen_frame_geometry: a device array
+ * of n_tiles tile indices, longest list first (pointer into `workspace`; pure host arithmetic).
+ * The *_ordered variants of the SH compositing entry points take it (NULL = spatial order);
+ * they are otherwise identical to gsgen_vol_render_sh / gsgen_vol_render_backward_sh. */
+const uint32_t *gsgen_frame_tile_order(void *workspace, uint32_t N, uint32_t D_cap, uint32_t n_tiles);
+int gsgen_vol_render_sh_ordered(uint32_t N, uint32_t D, const float *mean, const float *cov,
+                                const float *sh_coeffs, const float *alpha, const int *start,
+                                const int *end, const int *gaussian_ids, float *out, const float *topleft,
+                                const float *c2w, uint32_t tile_size, uint32_t n_tiles_h,
+                                uint32_t n_tiles_w, float pixel_size_x, float pixel_size_y, uint32_t H,
+                                uint32_t W, uint32_t C, float thresh, const float *bg_rgb, float *T,
+                                const uint32_t *tile_order, gsgen_stream_t stream);
+int gsgen_vol_render_backward_sh_ordered(uint32_t N, uint32_t D, const float *mean, const float *cov,
+                                         const float *sh_coeffs, const float *alpha, const int *start,
+                                         const int *end, const int *gaussian_ids, const float *out,
+                                         float *grad_mean, float *grad_cov, float *grad_sh_coeffs,
+                                         float *grad_alpha, const float *grad_out, const float *topleft,
+                                         const float *c2w, uint32_t tile_size, uint32_t n_tiles_h,
+                                         uint32_t n_tiles_w, float pixel_size_x, float pixel_size_y,
+                                         uint32_t H, uint32_t W, uint32_t C, float thresh,
+                                         const float *bg_rgb, const uint32_t *tile_order,
+                                         gsgen_stream_t stream);
+
 /* Self test of the wave64 cross-lane reduce-scatter used by the backward (tests only):
  * in [64 lanes, P components], out[lane] = sum over lanes of component (lane mod P); P in {8,16,32,64}. */
 int gsgen_selftest_reduce_scatter(uint32_t P, const float *in, float *out, gsgen_stream_t stream);
