@@ -147,18 +147,12 @@ __device__ __forceinline__ float read_lane(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
-// A (k, k+1) pair of fp32 values.  Deliberately NOT a clang vector type: on gfx950 one
-// v_pk_fma_f32 costs 2.9x a v_fmac_f32 (tools/mb_inst.hip: 7.5 vs 2.6 SIMD-clk per wave64
-// instruction), i.e. packing the SH dot products is ~45 % slower than two scalar FMAs, so the
-// pair is kept as two scalars and every multiply-add is an explicit fmaf.
-struct alignas(8) v2f {
-  float x, y;
-  __device__ __forceinline__ float operator[](int i) const { return i ? y : x; }
-};
-__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) {
-  return v2f{__builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.y, b.y, c.y)};
-}
-__device__ __forceinline__ v2f operator*(v2f a, v2f b) { return v2f{a.x * b.x, a.y * b.y}; }
+// two packed fp32 values: arithmetic on v2f lowers to v_pk_mul/add/fma_f32.  Kernel-level A/B
+// on MI355X (profiles/r01_notes.md): packed SH dot products beat scalar FMA pairs by ~11 % on
+// the compositing backward (fewer issue slots), although an isolated dependent-chain
+// microbenchmark of v_pk_fma_f32 suggests otherwise.
+typedef float v2f __attribute__((vector_size(8)));
+__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return a * b + c; }
 __device__ __forceinline__ v2f splat2(float a) { return v2f{a, a}; }
 
 // Workgroup -> tile map that is both XCD-local and XCD-balanced.  Workgroup b runs on XCD
