@@ -103,6 +103,8 @@ def main():
     ap.add_argument("--config", default="cfg2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="also time every stage separately")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("GSGEN_STREAMS", "1")),
+                    help="independent renders in flight (HIP streams, own buffers each)")
     args = ap.parse_args()
 
     import torch
@@ -135,60 +137,78 @@ def main():
     topleft = torch.from_numpy(cams[0].topleft).to(dev)
     bg = torch.tensor([0.1, 0.2, 0.3], device=dev)
     grad_out = torch.randn(H, W, 3, device=dev)
-    buf = R.FrameBuffers(N, W, H, dev)
-    out = torch.empty(H, W, 3, device=dev)
     CC3 = 3 * C * C
-    gflat = torch.empty(N * (7 + CC3), device=dev)  # mean2d(2) | cov2d(4) | alpha(1) | sh(3*C*C)
-    g_mean2d, g_cov2d = gflat[:2 * N], gflat[2 * N:6 * N]
-    g_alpha, g_sh = gflat[6 * N:7 * N], gflat[7 * N:]
-    g_mean, g_qvec, g_svec = torch.empty(N, 3, device=dev), torch.empty(N, 4, device=dev), torch.empty(N, 3, device=dev)
-    gathered = torch.empty(world, H, W, 3, device=dev) if world > 1 else None
     p = lambda x: x.data_ptr()  # noqa: E731
-    stream = torch.cuda.current_stream(dev)
-    s = stream.cuda_stream
     psx, psy = 1.0 / ci.fx, 1.0 / ci.fy
+    gathered = torch.empty(world, H, W, 3, device=dev) if world > 1 else None
 
-    ev = {}
+    # Independent renders (different cameras of a batch) are issued round-robin on `--streams`
+    # HIP streams, each with its own frame buffers, so that the tail of one render's
+    # compositing launch (the image-centre tiles) overlaps the next render's kernels.  Every
+    # render still runs its complete cull->...->backward chain in order on its stream.
+    class Slot:
+        def __init__(self, stream):
+            self.stream = stream
+            self.s = stream.cuda_stream
+            with torch.cuda.stream(stream):
+                self.buf = R.FrameBuffers(N, W, H, dev)
+                self.out = torch.empty(H, W, 3, device=dev)
+                self.gflat = torch.empty(N * (7 + CC3), device=dev)  # mean2d(2) | cov2d(4) | alpha(1) | sh
+                self.g_mean = torch.empty(N, 3, device=dev)
+                self.g_qvec = torch.empty(N, 4, device=dev)
+                self.g_svec = torch.empty(N, 3, device=dev)
+            g = self.gflat
+            self.g_mean2d, self.g_cov2d, self.g_alpha, self.g_sh = g[:2 * N], g[2 * N:6 * N], g[6 * N:7 * N], g[7 * N:]
 
-    def step(i, timed=None):
+    n_streams = max(1, args.streams)
+    slots = [Slot(torch.cuda.current_stream(dev) if n_streams == 1 else torch.cuda.Stream(dev)) for _ in range(n_streams)]
+    torch.cuda.synchronize()
+    buf = slots[0].buf
+
+    def step(i, timed=None, slot=None):
         k = i % len(cams)
-        order = None if os.environ.get("GSGEN_NO_ORDER") else buf.tile_order()
-        lib.frame_geometry(N, p(t["mean"]), p(t["qvec"]), p(t["svec"]), p(cam_dev[k]), W, H, buf.D_cap,
-                           p(buf.mean2d), p(buf.cov2d), p(buf.depth), p(buf.mask), p(buf.ids), p(buf.start),
-                           p(buf.end), p(buf.total), p(buf.ws), buf.ws.numel(), s)
+        sl = slots[(i % n_streams) if slot is None else slot]
+        b_, s, stream = sl.buf, sl.s, sl.stream
+        order = None if os.environ.get("GSGEN_NO_ORDER") else b_.tile_order()
+        lib.frame_geometry(N, p(t["mean"]), p(t["qvec"]), p(t["svec"]), p(cam_dev[k]), W, H, b_.D_cap,
+                           p(b_.mean2d), p(b_.cov2d), p(b_.depth), p(b_.mask), p(b_.ids), p(b_.start),
+                           p(b_.end), p(b_.total), p(b_.ws), b_.ws.numel(), s)
         if timed is not None:
             timed[0].record(stream)
-        lib.vol_render_sh_ordered(N, buf.D_cap, p(buf.mean2d), p(buf.cov2d), p(t["sh"]), p(t["alpha"]), p(buf.start),
-                                  p(buf.end), p(buf.ids), p(out), p(topleft), p(rot_dev[k]), 16, nth, ntw, psx, psy,
+        lib.vol_render_sh_ordered(N, b_.D_cap, p(b_.mean2d), p(b_.cov2d), p(t["sh"]), p(t["alpha"]), p(b_.start),
+                                  p(b_.end), p(b_.ids), p(sl.out), p(topleft), p(rot_dev[k]), 16, nth, ntw, psx, psy,
                                   H, W, C, 1e-4, p(bg), None, order, s)
         if timed is not None:
             timed[1].record(stream)
-        gflat.zero_()
+        with torch.cuda.stream(stream):
+            sl.gflat.zero_()
         if timed is not None:
             timed[2].record(stream)
-        lib.vol_render_backward_sh_ordered(N, buf.D_cap, p(buf.mean2d), p(buf.cov2d), p(t["sh"]), p(t["alpha"]),
-                                           p(buf.start), p(buf.end), p(buf.ids), p(out), p(g_mean2d), p(g_cov2d),
-                                           p(g_sh), p(g_alpha), p(grad_out), p(topleft), p(rot_dev[k]), 16, nth, ntw,
-                                           psx, psy, H, W, C, 1e-4, p(bg), order, s)
+        lib.vol_render_backward_sh_ordered(N, b_.D_cap, p(b_.mean2d), p(b_.cov2d), p(t["sh"]), p(t["alpha"]),
+                                           p(b_.start), p(b_.end), p(b_.ids), p(sl.out), p(sl.g_mean2d), p(sl.g_cov2d),
+                                           p(sl.g_sh), p(sl.g_alpha), p(grad_out), p(topleft), p(rot_dev[k]), 16, nth,
+                                           ntw, psx, psy, H, W, C, 1e-4, p(bg), order, s)
         if timed is not None:
             timed[3].record(stream)
         lib.project_gaussians_backward_masked(N, p(t["mean"]), p(t["qvec"]), p(t["svec"]), p(cam_dev[k]), 1,
-                                              p(buf.mask), p(g_mean2d), p(g_cov2d), None, p(g_mean), p(g_qvec),
-                                              p(g_svec), s)
+                                              p(b_.mask), p(sl.g_mean2d), p(sl.g_cov2d), None, p(sl.g_mean),
+                                              p(sl.g_qvec), p(sl.g_svec), s)
         if gathered is not None:
-            dist.all_gather_into_tensor(gathered, out)
+            with torch.cuda.stream(stream):
+                dist.all_gather_into_tensor(gathered, sl.out)
 
     # size the pair buffers once, outside the timed region (one sync)
-    for i in range(len(cams)):
-        step(i)
-        torch.cuda.synchronize()
-        buf.ensure_capacity()
     Ds = []
-    for i in range(len(cams)):
-        step(i)
-        torch.cuda.synchronize()
-        assert buf.ensure_capacity()
-        Ds.append(int(buf.total.item()))
+    for sidx in range(n_streams):
+        for k in range(len(cams)):
+            step(k, slot=sidx)
+            torch.cuda.synchronize()
+            if not slots[sidx].buf.ensure_capacity():
+                step(k, slot=sidx)
+                torch.cuda.synchronize()
+                assert slots[sidx].buf.ensure_capacity()
+            if sidx == 0:
+                Ds.append(int(slots[0].buf.total.item()))
     n_vis = int(buf.mask.sum().item())
 
     for i in range(args.warmup):
@@ -236,7 +256,7 @@ def main():
                                 "cfg3": "BASELINE configs[2]: 500k post-densify Gaussians, 1024x1024, SH degree 3, fwd+bwd",
                                 "cfg1": "BASELINE configs[0]: 1k random Gaussians, 256x256, SH degree 0"}[args.config],
                    "gaussians": N, "visible_after_cull": n_vis, "image": [H, W], "sh_degree": C - 1,
-                   "tile_pairs_D": D, "cameras_per_gpu_per_step": 1, "parallelism": f"camera-sharded x{world}",
+                   "tile_pairs_D": D, "cameras_per_gpu_per_step": 1, "renders_in_flight": n_streams, "parallelism": f"camera-sharded x{world}",
                    "gather": "rccl all_gather of rendered images" if world > 1 else "none"},
         "roofline": {"bound": "hbm", "kernel": f"k_composite_bwd_pixel<SH,C={C}> (compositing backward)", "achieved": ach, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
@@ -251,9 +271,9 @@ def main():
         stage_ev = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(20)]
         for i in range(20):
             e = stage_ev[i]
-            e[4].record(stream)
-            step(i, e)
-            e[5].record(stream)
+            e[4].record(slots[0].stream)
+            step(i, e, slot=0)
+            e[5].record(slots[0].stream)
         torch.cuda.synchronize()
         bd = {"geometry+bin+sort": np.mean([e[4].elapsed_time(e[0]) for e in stage_ev]),
               "composite_fwd": np.mean([e[0].elapsed_time(e[1]) for e in stage_ev]),

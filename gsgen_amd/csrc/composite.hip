@@ -286,7 +286,7 @@ __global__ void __launch_bounds__(256 / PPL) k_composite_bwd_pixel(CompParams p)
   const int tile = ty * p.ntw + tx;
   const int st = p.start[tile];
   const int n = (st < 0) ? 0 : (p.end[tile] - st);
-  if (n == 0) return;
+  if (n == 0 || n < p.n_lo || n >= p.n_hi) return;
   const int t = (int)threadIdx.x;
   const int lane = t & 63;
   const int lx = t & 15, ly0 = t >> 4;
@@ -477,10 +477,13 @@ __global__ void __launch_bounds__(256 / PPL) k_composite_bwd_pixel(CompParams p)
 // ---- launch helpers ---------------------------------------------------------------------------
 // Pixels per lane: 4 = one wavefront per tile (north_star design), 2 / 1 = two / four
 // wavefronts per tile sharing the staged records.  Defaults chosen by measurement on MI355X
-// (profiles/); GSGEN_PPL_FWD / GSGEN_PPL_BWD override them for A/B runs.
+// (profiles/r01_notes.md): forward 1 (127 us vs 195 us at 4: one wave per tile leaves 2.4 waves
+// per SIMD and the launch ends on the centre tiles' serial chains), backward 4 (the per-Gaussian
+// gradient reduction costs the same per wave whatever the number of pixels behind it).
+// GSGEN_PPL_FWD / GSGEN_PPL_BWD override them for A/B runs.
 template <int MODE, int CB>
 static int launch_fwd(const CompParams &p, hipStream_t s) {
-  static const int ppl = env_ppl("GSGEN_PPL_FWD", 4);
+  static const int ppl = env_ppl("GSGEN_PPL_FWD", 1);
   const uint32_t nblk = comp_grid(p);
   if (p.ntw * p.nth == 0) return 0;
   if (ppl == 1) hipLaunchKernelGGL((k_composite_fwd<MODE, CB, 1>), dim3(nblk), dim3(256), 0, s, p);
@@ -494,6 +497,7 @@ static int launch_bwd(const CompParams &p_, hipStream_t s) {
   static const int dbg = getenv("GSGEN_DBG") ? atoi(getenv("GSGEN_DBG")) : 0;
   CompParams p = p_;
   p.dbg = dbg;
+  if (p.n_hi == 0) p.n_hi = 0x7fffffff;
   const uint32_t nblk = comp_grid(p);
   if (p.ntw * p.nth == 0) return 0;
   if (ppl == 1) hipLaunchKernelGGL((k_composite_bwd_pixel<MODE, CB, 1>), dim3(nblk), dim3(256), 0, s, p);

@@ -74,7 +74,7 @@ __global__ void __launch_bounds__(256) k_composite_bwd_splat(CompParams p) {
   const int tile = ty * p.ntw + tx;
   const int st = p.start[tile];
   const int n = (st < 0) ? 0 : (p.end[tile] - st);
-  if (n == 0) return;
+  if (n == 0 || n < p.n_lo || n >= p.n_hi) return;
   const int t = (int)threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
 
@@ -322,11 +322,7 @@ static int launch_bwd_splat(const CompParams &p, hipStream_t s) {
   return (int)hipGetLastError();
 }
 
-static int launch_bwd(int mode, int C, const CompParams &p, hipStream_t s) {
-  // Two complete implementations (both parity-green); the faster one on MI355X is the default,
-  // GSGEN_BWD=splat|pixel selects explicitly for A/B measurements (profiles/).
-  static const bool splat = getenv("GSGEN_BWD") && getenv("GSGEN_BWD")[0] == 's';
-  if (!splat) return launch_bwd_pixel_dispatch(mode, C, p, s);
+static int launch_bwd_splat_dispatch(int mode, int C, const CompParams &p, hipStream_t s) {
   if (mode == MODE_RGB) return launch_bwd_splat<MODE_RGB, 1>(p, s);
   if (mode == MODE_SCALAR) return launch_bwd_splat<MODE_SCALAR, 1>(p, s);
   switch (C) {
@@ -335,6 +331,25 @@ static int launch_bwd(int mode, int C, const CompParams &p, hipStream_t s) {
     case 3: return launch_bwd_splat<MODE_SH, 3>(p, s);
     default: return launch_bwd_splat<MODE_SH, 4>(p, s);
   }
+}
+
+static int launch_bwd(int mode, int C, const CompParams &p_, hipStream_t s) {
+  // Two complete implementations (both parity-green).  GSGEN_BWD=pixel|splat forces one;
+  // GSGEN_BWD_SPLIT=n sends tiles whose list is >= n entries long to the splat-parallel kernel
+  // (four waves per tile, no serial chain per wave) and the rest to the pixel-parallel one.
+  static const char *force = getenv("GSGEN_BWD");
+  static const int split = getenv("GSGEN_BWD_SPLIT") ? atoi(getenv("GSGEN_BWD_SPLIT")) : 0;
+  CompParams p = p_;
+  p.n_lo = 0; p.n_hi = 0x7fffffff;
+  if (force && force[0] == 's') return launch_bwd_splat_dispatch(mode, C, p, s);
+  if (force && force[0] == 'p') return launch_bwd_pixel_dispatch(mode, C, p, s);
+  if (split > 0) {
+    p.n_lo = split;
+    if (int e = launch_bwd_splat_dispatch(mode, C, p, s)) return e;
+    p.n_lo = 0; p.n_hi = split;
+    return launch_bwd_pixel_dispatch(mode, C, p, s);
+  }
+  return launch_bwd_pixel_dispatch(mode, C, p, s);
 }
 
 }  // namespace gs

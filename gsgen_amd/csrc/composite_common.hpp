@@ -23,6 +23,7 @@ struct CompParams {
   float psx, psy, thresh;
   int dbg;  // experiment switches (GSGEN_DBG), 0 in production
   const uint32_t *tile_order;  // optional launch order (longest list first); NULL = spatial map
+  int n_lo, n_hi;  // this launch only handles tiles with n_lo <= list length < n_hi (0, INT_MAX = all)
 };
 
 // workgroup -> tile: explicit order if given, else the XCD-balanced spatial map

@@ -2,7 +2,7 @@
 mkdir -p gpurun_out; : > gpurun_out/ab.log
 for v in "$@"; do
   echo "== $v" >> gpurun_out/ab.log
-  env $v timeout 120 python bench.py --steps 40 --warmup 10 --no-cpu-baseline 2>/dev/null | python -c "
+  env $v timeout 120 python bench.py --steps 64 --warmup 16 --no-cpu-baseline 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
