@@ -103,7 +103,7 @@ def main():
     ap.add_argument("--config", default="cfg2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="also time every stage separately")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("GSGEN_STREAMS", "1")),
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("GSGEN_STREAMS", "3")),
                     help="independent renders in flight (HIP streams, own buffers each)")
     args = ap.parse_args()
 
@@ -232,6 +232,20 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
 
+    # the same K steps again, strictly one render at a time on one stream (latency view)
+    one = None
+    if n_streams > 1:
+        ev1 = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            step(args.warmup + i, ev1[i], slot=0)
+        barrier()
+        el1 = time.perf_counter() - t1
+        one = {"value": world * args.steps / el1, "ms_per_step": el1 / args.steps * 1e3,
+               "fwd_kernel_ms": float(np.mean([e[0].elapsed_time(e[1]) for e in ev1])),
+               "bwd_kernel_ms": float(np.mean([e[2].elapsed_time(e[3]) for e in ev1]))}
+
     fwd_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))
     bwd_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in evs]))
     D = float(np.mean([Ds[(args.warmup + i) % len(cams)] for i in range(args.steps)]))
@@ -266,6 +280,10 @@ def main():
                      "whole_render_alg_bytes": total_b,
                      "whole_render_hbm_frac": total_b * (value / world) / (HBM_PEAK_GBS * 1e9)},
     }
+    if one is not None:
+        res["one_render_in_flight"] = one
+        res["roofline"]["isolated_launch_ms"] = one["bwd_kernel_ms"]
+        res["roofline"]["isolated_achieved"] = parts["composite_bwd"] / (one["bwd_kernel_ms"] * 1e-3) / 1e9
     if args.breakdown and rank == 0:
         names = ["geometry+bin+sort", "composite_fwd", "zero_grads", "composite_bwd"]
         stage_ev = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(20)]
