@@ -342,11 +342,11 @@ __device__ __forceinline__ void sort_segment_regs(const u64 *__restrict__ keys, 
 }
 constexpr int kSortMaxK = 32;  // 2048 keys in registers; longer segments take the workgroup path
 
-__global__ void __launch_bounds__(kSortThreads)
+// One wavefront per tile, keys in registers, no LDS: the common case (n <= 64 * kSortMaxK).
+__global__ void __launch_bounds__(64)
 k_sort_tiles(uint32_t T, const uint32_t *__restrict__ tile_off, const uint32_t *__restrict__ ctrl,
-             unsigned long long *__restrict__ keys, int *__restrict__ ids, int *__restrict__ start,
+             const unsigned long long *__restrict__ keys, int *__restrict__ ids, int *__restrict__ start,
              int *__restrict__ end) {
-  __shared__ unsigned long long s_keys[kSortLds];
   const uint32_t tile = xcd_swizzle(blockIdx.x, gridDim.x);
   const uint32_t tid = threadIdx.x;
   if (ctrl[1] != 0u) {
@@ -359,23 +359,36 @@ k_sort_tiles(uint32_t T, const uint32_t *__restrict__ tile_off, const uint32_t *
     start[tile] = n ? (int)b : -1;
     end[tile] = n ? (int)e : -1;
   }
-  if (n == 0) return;
-  if (n <= 64u * kSortMaxK) {
-    if (tid >= 64u) return;  // one wavefront does it, in registers
-    if (n <= 64u) sort_segment_regs<1>(keys + b, ids + b, n);
-    else if (n <= 128u) sort_segment_regs<2>(keys + b, ids + b, n);
-    else if (n <= 256u) sort_segment_regs<4>(keys + b, ids + b, n);
-    else if (n <= 512u) sort_segment_regs<8>(keys + b, ids + b, n);
-    else if (n <= 1024u) sort_segment_regs<16>(keys + b, ids + b, n);
-    else sort_segment_regs<32>(keys + b, ids + b, n);
-  } else if (n <= (uint32_t)kSortLds) {
+  if (n == 0 || n > 64u * kSortMaxK) return;  // oversized segments: k_sort_tiles_big
+  if (n <= 64u) sort_segment_regs<1>(keys + b, ids + b, n);
+  else if (n <= 128u) sort_segment_regs<2>(keys + b, ids + b, n);
+  else if (n <= 256u) sort_segment_regs<4>(keys + b, ids + b, n);
+  else if (n <= 512u) sort_segment_regs<8>(keys + b, ids + b, n);
+  else if (n <= 1024u) sort_segment_regs<16>(keys + b, ids + b, n);
+  else sort_segment_regs<32>(keys + b, ids + b, n);
+}
+
+// Segments longer than the register sort can hold: one workgroup, LDS (<= kSortLds keys) or the
+// global segment itself.  A separate launch so that the common kernel carries no LDS (32 KiB
+// of static LDS per workgroup would throttle the compositing kernels of other renders in flight).
+__global__ void __launch_bounds__(kSortThreads)
+k_sort_tiles_big(uint32_t T, const uint32_t *__restrict__ tile_off, const uint32_t *__restrict__ ctrl,
+                 unsigned long long *__restrict__ keys, int *__restrict__ ids) {
+  __shared__ unsigned long long s_keys[kSortLds];
+  const uint32_t tile = blockIdx.x;
+  const uint32_t tid = threadIdx.x;
+  if (ctrl[1] != 0u) return;
+  const uint32_t b = tile_off[tile], e = tile_off[tile + 1];
+  const uint32_t n = e - b;
+  if (n <= 64u * kSortMaxK) return;
+  if (n <= (uint32_t)kSortLds) {
     for (uint32_t i = tid; i < n; i += kSortThreads) s_keys[i] = keys[b + i];
     __syncthreads();
     bitonic_sort(s_keys, n, tid, kSortThreads);
     for (uint32_t i = tid; i < n; i += kSortThreads) ids[b + i] = (int)(uint32_t)(s_keys[i] & 0xffffffffull);
   } else {
-    // oversized segment: same network directly on the global segment (one workgroup, so
-    // __syncthreads + L2-coherent stores of this CU order the passes)
+    // same network directly on the global segment (one workgroup, so __syncthreads + the
+    // L2-coherent stores of this CU order the passes)
     unsigned long long *k = keys + b;
     __syncthreads();
     bitonic_sort(k, n, tid, kSortThreads);
@@ -445,7 +458,8 @@ static int bin_and_sort(uint32_t N, uint32_t cap, uint32_t nth, uint32_t ntw, co
   if (N)
     hipLaunchKernelGGL((k_bin_pull<true>), gpull, bpull, 0, s, N, tl, br, depth, (int)ntw, (int)nth, T,
                        w.cnt, w.tile_off, w.ctrl, w.keys);
-  hipLaunchKernelGGL(k_sort_tiles, dim3(T), dim3(kSortThreads), 0, s, T, w.tile_off, w.ctrl, w.keys, ids, start, end);
+  hipLaunchKernelGGL(k_sort_tiles, dim3(T), dim3(64), 0, s, T, w.tile_off, w.ctrl, w.keys, ids, start, end);
+  hipLaunchKernelGGL(k_sort_tiles_big, dim3(T), dim3(kSortThreads), 0, s, T, w.tile_off, w.ctrl, w.keys, ids);
   return (int)hipGetLastError();
 }
 
