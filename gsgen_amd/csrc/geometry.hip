@@ -2,11 +2,13 @@
 // rectangle.  One thread per Gaussian, ~100 B of HBM traffic each: purely bandwidth-bound.
 //
 // THIS FILE IS COMPILED WITH -ffp-contract=off.  Every fp32 expression below is written in
-// the order the oracle (oracle/gs_oracle.c) and the reference's PyTorch ops execute it and
-// uses only correctly-rounded IEEE operations (+ - * / sqrt), so mean2d / cov2d / depth and
-// therefore the integer tile rectangles, the pair count D and the per-tile lists are
-// BIT-IDENTICAL to the reference's torch path (tile membership is part of the image:
-// SURVEY.md 8a trap 1).
+// the order the oracle (oracle/gs_oracle.c) executes it and uses only correctly-rounded IEEE
+// operations (+ - * / sqrt), so mean2d / cov2d / depth and therefore the integer tile
+// rectangles, the pair count D and the per-tile lists are BIT-IDENTICAL to the oracle (tile
+// membership is part of the image: SURVEY.md 8a trap 1).  Against the reference's torch ops
+// the projection agrees to a few ulp (its einsum/bmm sum the 3-term dot products in BLAS
+// order; bit-exact for axis-aligned poses), the AABB -> tile arithmetic given the same
+// mean2d/cov2d is exact (tests/test_oracle_golden.py, tests/test_gpu_golden.py).
 //
 // Replaces (paths relative to /root/reference):
 //   cull        gs/src/include/culling.h:10-33, kernels.h:156-170

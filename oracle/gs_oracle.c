@@ -11,12 +11,13 @@
  * backward), fp32 elsewhere.  Build with -ffp-contract=off so the fp32 expression
  * order written here is the order executed.
  *
- * Pinning status (see oracle/README.md): the compositing / binning functions are pinned
- * against the reference's own CUDA sources executed on the CPU through the SIMT shim in
- * oracle/emu (oracle/_ref/libgs_ref.so, tests/test_oracle_vs_ref.py, container only) and
- * against golden vectors generated from it (tests/golden).  The projection functions are
- * pinned against the reference's Python (gs/renderer.py project_gaussians, imported in
- * this container by tests/golden/make_golden.py).
+ * Pinning status: PINNED (see oracle/README.md).  The cull / binning / compositing functions
+ * are bit-exact on every forward output (and <= 5e-7 on gradients) against the reference's own
+ * CUDA sources executed on the CPU through the SIMT shim in oracle/emu (oracle/_ref/libgs_ref.so)
+ * and against golden vectors generated from it (tests/golden, tests/test_oracle_golden.py).
+ * The projection / tile-count / frustum functions are checked against the reference's Python
+ * (gs/renderer.py project_gaussians etc., imported by tests/golden/make_golden.py): exact for
+ * the integer tile arithmetic, a few ulp for the projection (torch's BLAS summation order).
  *
  * Gradients: the reference accumulates fp32 atomics in a hardware-dependent order.  The
  * oracle computes every per-(pixel,Gaussian) contribution with the reference's own
