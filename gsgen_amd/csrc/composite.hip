@@ -79,8 +79,7 @@ __device__ __forceinline__ void stage_batch(Stage<MODE, CB> &S, const CompParams
   } else {
     if (t < nb) {
       const int id = S.id[t];  // own record: written by this same thread above
-#pragma unroll
-      for (int k = 0; k < TR::NCOL; ++k) S.col[t * TR::NCOL + k] = p.col[(size_t)id * TR::NCOL + k];
+      load_channels<MODE, TR::NCOL>(p, id, &S.col[t * TR::NCOL]);
     }
   }
 }
@@ -255,6 +254,9 @@ __global__ void __launch_bounds__(256 / PPL) k_composite_fwd(CompParams p) {
     const size_t pix = (size_t)gy[j] * p.W + gx;
     if constexpr (MODE == MODE_SCALAR) {
       p.out[pix] = acc[j][0];
+    } else if constexpr (MODE == MODE_RGBD) {
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) p.out[NCH * pix + c] = acc[j][c];
     } else {
       float *o = p.out + 3 * pix;
       if (p.bg != nullptr) {  // vol_render_bg.h:95-100
@@ -509,6 +511,7 @@ static int launch_bwd(const CompParams &p_, hipStream_t s) {
 int launch_bwd_pixel_dispatch(int mode, int C, const CompParams &p, hipStream_t s) {
   if (mode == MODE_RGB) return launch_bwd<MODE_RGB, 1>(p, s);
   if (mode == MODE_SCALAR) return launch_bwd<MODE_SCALAR, 1>(p, s);
+  if (mode == MODE_RGBD) return launch_bwd<MODE_RGBD, 1>(p, s);
   switch (C) {
     case 1: return launch_bwd<MODE_SH, 1>(p, s);
     case 2: return launch_bwd<MODE_SH, 2>(p, s);
@@ -559,6 +562,25 @@ int gsgen_vol_render_scalar(uint32_t N, uint32_t D, const float *mean, const flo
   return launch_fwd<MODE_SCALAR, 1>(p, (hipStream_t)stream);
 }
 
+
+int gsgen_vol_render_rgbd(uint32_t N, uint32_t D, const float *mean, const float *cov, const float *color,
+                          const float *depth, const float *alpha, const int *start, const int *end,
+                          const int *gaussian_ids, float *out6, const float *topleft, uint32_t tile_size,
+                          uint32_t n_tiles_h, uint32_t n_tiles_w, float pixel_size_x, float pixel_size_y,
+                          uint32_t H, uint32_t W, float thresh, float *T, const uint32_t *tile_order,
+                          gsgen_stream_t stream) {
+  if (int e = check_common(tile_size, start, end, out6)) return e;
+  if (N == 0 || D == 0) return 0;
+  if (!depth) return GSGEN_EINVAL;
+  CompParams p{};
+  p.mean = mean; p.cov = cov; p.col = color; p.depth = depth; p.alpha = alpha;
+  p.start = start; p.end = end; p.ids = gaussian_ids; p.topleft = topleft;
+  p.out = out6; p.T = T;
+  p.ntw = (int)n_tiles_w; p.nth = (int)n_tiles_h; p.H = (int)H; p.W = (int)W;
+  p.psx = pixel_size_x; p.psy = pixel_size_y; p.thresh = thresh;
+  p.tile_order = tile_order;
+  return launch_fwd<MODE_RGBD, 1>(p, (hipStream_t)stream);
+}
 
 int gsgen_vol_render_sh_ordered(uint32_t N, uint32_t D, const float *mean, const float *cov,
                                 const float *sh_coeffs, const float *alpha, const int *start,

@@ -167,7 +167,8 @@ __global__ void __launch_bounds__(256) k_composite_bwd_splat(CompParams p) {
           q[c][k] = *reinterpret_cast<const v2f *>(&s_rec[lane * CF::RSTRIDE + c * TR::CCP + 2 * k]);
     } else {
 #pragma unroll
-      for (int c = 0; c < NCH; ++c) colv[c] = have ? p.col[(size_t)id * NCOL + c] : 0.0f;
+      for (int c = 0; c < NCH; ++c) colv[c] = 0.0f;
+      if (have) load_channels<MODE, NCOL>(p, id, colv);
     }
 
     // gradient accumulators of this lane's Gaussian over this wave's pixels
@@ -325,6 +326,7 @@ static int launch_bwd_splat(const CompParams &p, hipStream_t s) {
 static int launch_bwd_splat_dispatch(int mode, int C, const CompParams &p, hipStream_t s) {
   if (mode == MODE_RGB) return launch_bwd_splat<MODE_RGB, 1>(p, s);
   if (mode == MODE_SCALAR) return launch_bwd_splat<MODE_SCALAR, 1>(p, s);
+  if (mode == MODE_RGBD) return launch_bwd_splat<MODE_RGBD, 1>(p, s);
   switch (C) {
     case 1: return launch_bwd_splat<MODE_SH, 1>(p, s);
     case 2: return launch_bwd_splat<MODE_SH, 2>(p, s);
@@ -377,6 +379,27 @@ int gsgen_vol_render_backward_start_end(uint32_t N, uint32_t D, const float *mea
   p.ntw = (int)n_tiles_w; p.nth = (int)n_tiles_h; p.H = (int)H; p.W = (int)W;
   p.psx = pixel_size_x; p.psy = pixel_size_y; p.thresh = thresh;
   return launch_bwd(MODE_RGB, 1, p, (hipStream_t)stream);
+}
+
+int gsgen_vol_render_rgbd_backward(uint32_t N, uint32_t D, const float *mean, const float *cov, const float *color,
+                                   const float *depth, const float *alpha, const int *start, const int *end,
+                                   const int *gaussian_ids, const float *out6, float *grad_mean, float *grad_cov,
+                                   float *grad_chan6, float *grad_alpha, const float *grad_out6,
+                                   const float *topleft, uint32_t tile_size, uint32_t n_tiles_h,
+                                   uint32_t n_tiles_w, float pixel_size_x, float pixel_size_y, uint32_t H,
+                                   uint32_t W, float thresh, const uint32_t *tile_order, gsgen_stream_t stream) {
+  if (int e = check_common(tile_size, start, end, out6)) return e;
+  if (N == 0 || D == 0) return 0;
+  if (!depth) return GSGEN_EINVAL;
+  CompParams p{};
+  p.mean = mean; p.cov = cov; p.col = color; p.depth = depth; p.alpha = alpha;
+  p.start = start; p.end = end; p.ids = gaussian_ids; p.topleft = topleft;
+  p.final_img = out6; p.grad_out = grad_out6;
+  p.g_mean = grad_mean; p.g_cov = grad_cov; p.g_col = grad_chan6; p.g_alpha = grad_alpha;
+  p.ntw = (int)n_tiles_w; p.nth = (int)n_tiles_h; p.H = (int)H; p.W = (int)W;
+  p.psx = pixel_size_x; p.psy = pixel_size_y; p.thresh = thresh;
+  p.tile_order = tile_order;
+  return launch_bwd(MODE_RGBD, 1, p, (hipStream_t)stream);
 }
 
 int gsgen_vol_render_scalar_backward(uint32_t N, uint32_t D, const float *mean, const float *cov,

@@ -9,11 +9,14 @@
 
 namespace gs {
 
-enum : int { MODE_RGB = 0, MODE_SCALAR = 1, MODE_SH = 2 };
+// MODE_RGBD: RGB and the three scalar heads of render_one (depth, opacity, depth^2) composited in
+// one pass: 6 channels whose per-Gaussian values are (r, g, b, d, 1, d*d).
+enum : int { MODE_RGB = 0, MODE_SCALAR = 1, MODE_SH = 2, MODE_RGBD = 3 };
 constexpr int kBatch = 64;  // Gaussian records staged per LDS round
 
 struct CompParams {
   const float *mean, *cov, *col, *alpha;
+  const float *depth;  // MODE_RGBD only: per-Gaussian depth feeding the (d, 1, d*d) channels
   const int *start, *end, *ids;
   const float *topleft, *rot, *bg;
   float *out, *T;
@@ -106,8 +109,8 @@ __device__ __forceinline__ float sigmoid_fast(float s) {
 template <int MODE, int CB>
 struct Traits {
   static constexpr int CC = CB * CB;
-  static constexpr int NCOL = (MODE == MODE_SH) ? 3 * CC : (MODE == MODE_RGB ? 3 : 1);
-  static constexpr int NCH = (MODE == MODE_SCALAR) ? 1 : 3;
+  static constexpr int NCOL = (MODE == MODE_SH) ? 3 * CC : (MODE == MODE_RGB ? 3 : (MODE == MODE_RGBD ? 6 : 1));
+  static constexpr int NCH = (MODE == MODE_SCALAR) ? 1 : (MODE == MODE_RGBD ? 6 : 3);
   // gradient components per Gaussian: mean(2) cov(4, the two off-diagonals carry the same
   // value) alpha(1) colour/scalar/sh(NCOL)
   static constexpr int NCOMP = 7 + NCOL;
@@ -119,6 +122,19 @@ struct Traits {
   static constexpr int NPAIR = CCP / 2;
 };
 
+
+// the NCOL per-Gaussian channel values of the non-SH modes
+template <int MODE, int NCOL>
+__device__ __forceinline__ void load_channels(const CompParams &p, int id, float *dst) {
+  if constexpr (MODE == MODE_RGBD) {
+    const float d = p.depth[id];
+    dst[0] = p.col[3 * (size_t)id]; dst[1] = p.col[3 * (size_t)id + 1]; dst[2] = p.col[3 * (size_t)id + 2];
+    dst[3] = d; dst[4] = 1.0f; dst[5] = d * d;
+  } else {
+#pragma unroll
+    for (int k = 0; k < NCOL; ++k) dst[k] = p.col[(size_t)id * NCOL + k];
+  }
+}
 
 // per-Gaussian values used by every (pixel, Gaussian) evaluation
 struct GRec {

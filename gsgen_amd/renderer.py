@@ -250,6 +250,57 @@ class _render_sh_bg(torch.autograd.Function):
         return (grad_mean, grad_cov, grad_sh, grad_alpha) + (None,) * 15
 
 
+class _render_rgb_heads(torch.autograd.Function):
+    """RGB + depth + opacity + depth^2 in ONE compositing pass: replaces the
+    render_with_T + 3x render_scalar sequence of gs/gaussian_splatting.py:1304-1403.  Returns
+    (rgb [H,W,3] incl. T*bg, depth [H,W,1], opacity [H,W,1], z2 [H,W,1], T [H,W,1]); gradients flow
+    to mean2d, cov2d, color, depth, alpha and bg exactly as the four reference Functions' sum."""
+
+    @staticmethod
+    def forward(ctx, mean, cov, color, depth, alpha, start, end, gaussian_ids, topleft, n_tiles_h, n_tiles_w,
+                pixel_size_x, pixel_size_y, H, W, thresh, bg, tile_order):
+        dev = mean.device
+        depth_c = depth.contiguous()
+        out6 = torch.zeros(H, W, 6, dtype=torch.float32, device=dev)
+        T = torch.ones(H, W, 1, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _capi.load().vol_render_rgbd(mean.size(0), gaussian_ids.size(0), _p(mean), _p(cov), _p(color), _p(depth_c),
+                                         _p(alpha), _p(start), _p(end), _p(gaussian_ids), _p(out6), _p(topleft), 16,
+                                         n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H, W, thresh, _p(T),
+                                         tile_order, _stream(mean))
+        if bg is not None:
+            out6[..., :3] += T * bg
+        ctx.save_for_backward(mean, cov, color, depth_c, alpha, start, end, gaussian_ids, topleft, out6, T)
+        ctx.const = [n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H, W, thresh, tile_order, bg is not None]
+        return out6[..., :3], out6[..., 3:4], out6[..., 4:5], out6[..., 5:6], T
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_depth, g_opac, g_z2, g_T):
+        mean, cov, color, depth, alpha, start, end, gaussian_ids, topleft, out6, T = ctx.saved_tensors
+        n_tiles_h, n_tiles_w, psx, psy, H, W, thresh, tile_order, has_bg = ctx.const
+        dev = mean.device
+        N = mean.size(0)
+        z = lambda g, c: g if g is not None else torch.zeros(H, W, c, device=dev)  # noqa: E731
+        go6 = torch.cat([z(g_rgb, 3), z(g_depth, 1), z(g_opac, 1), z(g_z2, 1)], dim=-1).contiguous()
+        g_mean, g_cov = torch.zeros_like(mean), torch.zeros_like(cov)
+        g_chan, g_alpha = torch.zeros(N, 6, device=dev), torch.zeros_like(alpha)
+        with torch.cuda.device(dev):
+            _capi.load().vol_render_rgbd_backward(N, gaussian_ids.size(0), _p(mean), _p(cov), _p(color), _p(depth),
+                                                  _p(alpha), _p(start), _p(end), _p(gaussian_ids), _p(out6), _p(g_mean),
+                                                  _p(g_cov), _p(g_chan), _p(g_alpha), _p(go6), _p(topleft), 16,
+                                                  n_tiles_h, n_tiles_w, psx, psy, H, W, thresh, tile_order, _stream(mean))
+        d = depth.reshape(N)
+        g_d = (g_chan[:, 3] + 2.0 * d * g_chan[:, 5]).reshape(depth.shape)
+        g_bg = torch.nan_to_num(g_rgb * T) if (has_bg and g_rgb is not None) else None
+        return (g_mean, g_cov, g_chan[:, :3].contiguous(), g_d, g_alpha) + (None,) * 11 + (g_bg, None)
+
+
+def render_rgb_heads(mean, cov, color, depth, alpha, start, end, gaussian_ids, topleft, n_tiles_h, n_tiles_w,
+                     pixel_size_x, pixel_size_y, H, W, thresh, bg=None, tile_order=None):
+    return _render_rgb_heads.apply(mean, cov, color, depth, alpha, start, end, gaussian_ids, topleft, n_tiles_h,
+                                   n_tiles_w, pixel_size_x, pixel_size_y, H, W, thresh, bg, tile_order)
+
+
 render_start_end = _render_start_end.apply
 render_sh = _render_sh.apply
 render_sh_bg = _render_sh_bg.apply

@@ -185,6 +185,26 @@ int gsgen_vol_render_backward_sh_ordered(uint32_t N, uint32_t D, const float *me
                                          const float *bg_rgb, const uint32_t *tile_order,
                                          gsgen_stream_t stream);
 
+/* Fused RGB + auxiliary heads: what render_one does in four compositing passes
+ * (gs/gaussian_splatting.py:1304-1403: rgb, depth, opacity = scalar 1, depth^2) in one.
+ * out6 / grad_out6 are [H,W,6] = (r, g, b, depth, opacity, depth^2); grad_chan6 [N,6] receives the
+ * gradients of the per-Gaussian channel values (r, g, b, d, 1, d*d) -- the caller folds columns
+ * 3 and 5 into d/d depth (g3 + 2 d g5).  Semantics per channel are those of the single-head
+ * entry points above; T as in gsgen_vol_render_start_end_with_T. */
+int gsgen_vol_render_rgbd(uint32_t N, uint32_t D, const float *mean, const float *cov, const float *color,
+                          const float *depth, const float *alpha, const int *start, const int *end,
+                          const int *gaussian_ids, float *out6, const float *topleft, uint32_t tile_size,
+                          uint32_t n_tiles_h, uint32_t n_tiles_w, float pixel_size_x, float pixel_size_y,
+                          uint32_t H, uint32_t W, float thresh, float *T, const uint32_t *tile_order,
+                          gsgen_stream_t stream);
+int gsgen_vol_render_rgbd_backward(uint32_t N, uint32_t D, const float *mean, const float *cov, const float *color,
+                                   const float *depth, const float *alpha, const int *start, const int *end,
+                                   const int *gaussian_ids, const float *out6, float *grad_mean, float *grad_cov,
+                                   float *grad_chan6, float *grad_alpha, const float *grad_out6,
+                                   const float *topleft, uint32_t tile_size, uint32_t n_tiles_h,
+                                   uint32_t n_tiles_w, float pixel_size_x, float pixel_size_y, uint32_t H,
+                                   uint32_t W, float thresh, const uint32_t *tile_order, gsgen_stream_t stream);
+
 /* Self test of the wave64 cross-lane reduce-scatter used by the backward (tests only):
  * in [64 lanes, P components], out[lane] = sum over lanes of component (lane mod P); P in {8,16,32,64}. */
 int gsgen_selftest_reduce_scatter(uint32_t P, const float *in, float *out, gsgen_stream_t stream);

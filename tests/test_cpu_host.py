@@ -211,3 +211,35 @@ def test_emulated_sort_register_widths(emu):
     ws = np.zeros(emu.tile_culling_workspace_bytes(N, D, ntw), np.uint8)
     emu.tile_culling_aabb_start_end(N, D, nth, ntw, P(tl), P(br), P(depth), P(ids), P(st), P(en), P(ws), ws.size, None)
     assert np.array_equal(st, os_) and np.array_equal(en, oe) and np.array_equal(ids, oi)
+
+
+def test_emulated_fused_rgb_heads(emu):
+    cam = scenes.Camera(48, 40, fx=44.0)
+    sc = scenes.random_scene(250, seed=6, svec=0.07)
+    g = scenes.oracle_geometry(sc, cam)
+    m = g["mask"]; N = int(m.sum()); D = g["D"]; nth, ntw = cam.tiles; H, W = cam.h, cam.w
+    m2 = np.ascontiguousarray(g["mean2d"]); c2 = np.ascontiguousarray(g["cov2d"]); dv = np.ascontiguousarray(g["depth"].ravel())
+    col = np.ascontiguousarray(sc["color"][m]); al = np.ascontiguousarray(sc["alpha"][m])
+    st, en, ids, tlp = g["start"], g["end"], g["ids"], cam.topleft
+    out6 = np.zeros((H, W, 6), np.float32); T = np.ones((H, W), np.float32)
+    emu.vol_render_rgbd(N, D, P(m2), P(c2), P(col), P(dv), P(al), P(st), P(en), P(ids), P(out6), P(tlp), 16, nth, ntw,
+                        1 / cam.fx, 1 / cam.fy, H, W, 1e-4, P(T), None, None)
+    geo = (st, en, ids, tlp, 1 / cam.fx, 1 / cam.fy, H, W)
+    o_rgb, _ = O.render_rgb_fwd(m2, c2, col, al, *geo)
+    o_d, _ = O.render_scalar_fwd(m2, c2, dv, al, *geo)
+    o_o, _ = O.render_scalar_fwd(m2, c2, np.ones_like(dv), al, *geo)
+    o_z, _ = O.render_scalar_fwd(m2, c2, dv * dv, al, *geo)
+    ref6 = np.ascontiguousarray(np.concatenate([o_rgb, o_d[..., None], o_o[..., None], o_z[..., None]], -1), np.float32)
+    assert np.abs(out6 - ref6).max() < 1e-5 * max(1.0, np.abs(ref6).max())
+    go6 = np.random.default_rng(2).normal(size=(H, W, 6)).astype(np.float32)
+    gm = np.zeros((N, 2), np.float32); gc = np.zeros((N, 4), np.float32); gch = np.zeros((N, 6), np.float32); ga = np.zeros(N, np.float32)
+    emu.vol_render_rgbd_backward(N, D, P(m2), P(c2), P(col), P(dv), P(al), P(st), P(en), P(ids), P(ref6),
+                                 P(gm), P(gc), P(gch), P(ga), P(go6), P(tlp), 16, nth, ntw, 1 / cam.fx, 1 / cam.fy, H, W,
+                                 1e-4, None, None)
+    r = O.render_rgb_bwd(m2, c2, col, al, st, en, ids, o_rgb, np.ascontiguousarray(go6[..., :3]), tlp, 1 / cam.fx, 1 / cam.fy, H, W)
+    ss = [O.render_scalar_bwd(m2, c2, v, al, st, en, ids, f, np.ascontiguousarray(go6[..., 3 + k]), tlp, 1 / cam.fx, 1 / cam.fy, H, W)
+          for k, (v, f) in enumerate(((dv, o_d), (np.ones_like(dv), o_o), (dv * dv, o_z)))]
+    want_m = r[0] + sum(s[0] for s in ss); want_c = r[1] + sum(s[1] for s in ss); want_a = r[3] + sum(s[3] for s in ss)
+    for a_, b_ in ((gm, want_m), (gc, want_c.reshape(-1, 4)), (ga, want_a), (gch[:, :3], r[2]), (gch[:, 3], ss[0][2]),
+                   (gch[:, 4], ss[1][2]), (gch[:, 5], ss[2][2])):
+        assert np.abs(a_ - b_).max() <= 1e-4 * (np.abs(b_).max() + 1e-12)

@@ -191,3 +191,50 @@ def test_full_size_cfg2():
                                         g["ids"], ref, go.cpu().numpy(), cam.topleft, rot, 4, 1 / 800, 1 / 800, 800, 800)
     assert rel_err(g1["sh"].cpu().numpy()[m], gsh) < 2e-3
     assert rel_err(g1["alpha"].cpu().numpy()[m], ga) < 2e-3
+
+
+def test_fused_rgb_heads_match_four_reference_passes():
+    """render_rgb_heads == render_with_T + render_scalar x3 of render_one, forward and backward."""
+    from gsgen_amd import renderer as R
+    sc = scenes.random_scene(1500, seed=8, svec=0.04, C=1)
+    cam = scenes.Camera(176, 120, fx=150.0, c2w=scenes.orbit(2.4, 12, 200))
+    g = scenes.oracle_geometry(sc, cam)
+    m = g["mask"]
+    H, W = cam.h, cam.w
+    nth, ntw = cam.tiles
+    leaf = lambda a: T_(a).requires_grad_(True)  # noqa: E731
+    mean2d, cov2d, color, depth, alpha = leaf(g["mean2d"]), leaf(g["cov2d"]), leaf(sc["color"][m]), leaf(g["depth"]), leaf(sc["alpha"][m])
+    bg = torch.rand(H, W, 3, device=dev(), requires_grad=True)
+    rgb, dimg, opac, z2, T = R.render_rgb_heads(mean2d, cov2d, color, depth, alpha, T_(g["start"]), T_(g["end"]),
+                                                T_(g["ids"]), T_(cam.topleft), nth, ntw, 1 / cam.fx, 1 / cam.fy, H, W,
+                                                1e-4, bg)
+    geo = (g["start"], g["end"], g["ids"], cam.topleft, 1 / cam.fx, 1 / cam.fy, H, W)
+    a = (g["mean2d"], g["cov2d"])
+    al = sc["alpha"][m]
+    o_rgb, o_T = O.render_rgb_fwd(*a, sc["color"][m], al, *geo)
+    dv = g["depth"].ravel()
+    o_d, _ = O.render_scalar_fwd(*a, dv, al, *geo)
+    o_o, _ = O.render_scalar_fwd(*a, np.ones_like(dv), al, *geo)
+    o_z, _ = O.render_scalar_fwd(*a, dv * dv, al, *geo)
+    final = o_rgb + o_T * bg.detach().cpu().numpy()
+    assert np.abs(rgb.detach().cpu().numpy() - final).max() <= 1e-4
+    for x, y in ((dimg, o_d), (opac, o_o), (z2, o_z)):
+        assert np.abs(x.detach().cpu().numpy()[..., 0] - y).max() <= 1e-4 * max(1.0, np.abs(y).max())
+    rng = np.random.default_rng(4)
+    go = [rng.normal(size=s).astype(np.float32) for s in ((H, W, 3), (H, W), (H, W), (H, W))]
+    loss = (rgb * T_(go[0])).sum() + (dimg[..., 0] * T_(go[1])).sum() + (opac[..., 0] * T_(go[2])).sum() + (z2[..., 0] * T_(go[3])).sum()
+    loss.backward()
+    r = O.render_rgb_bwd(*a, sc["color"][m], al, g["start"], g["end"], g["ids"], final, go[0], cam.topleft, 1 / cam.fx, 1 / cam.fy, H, W)
+    s1 = O.render_scalar_bwd(*a, dv, al, g["start"], g["end"], g["ids"], o_d, go[1], cam.topleft, 1 / cam.fx, 1 / cam.fy, H, W)
+    s2 = O.render_scalar_bwd(*a, np.ones_like(dv), al, g["start"], g["end"], g["ids"], o_o, go[2], cam.topleft, 1 / cam.fx, 1 / cam.fy, H, W)
+    s3 = O.render_scalar_bwd(*a, dv * dv, al, g["start"], g["end"], g["ids"], o_z, go[3], cam.topleft, 1 / cam.fx, 1 / cam.fy, H, W)
+    want_mean = r[0] + s1[0] + s2[0] + s3[0]
+    want_cov = r[1] + s1[1] + s2[1] + s3[1]
+    want_alpha = r[3] + s1[3] + s2[3] + s3[3]
+    want_depth = s1[2] + 2.0 * dv * s3[2]
+    assert rel_err(mean2d.grad.cpu().numpy(), want_mean) < 1e-3
+    assert rel_err(cov2d.grad.cpu().numpy(), want_cov) < 1e-3
+    assert rel_err(alpha.grad.cpu().numpy(), want_alpha) < 1e-3
+    assert rel_err(color.grad.cpu().numpy(), r[2]) < 1e-3
+    assert rel_err(depth.grad.cpu().numpy().ravel(), want_depth) < 1e-3
+    assert np.abs(bg.grad.cpu().numpy() - go[0] * o_T).max() <= 1e-4
