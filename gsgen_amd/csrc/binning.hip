@@ -405,6 +405,7 @@ __global__ void __launch_bounds__(64) k_selftest_reduce_scatter(const float *__r
   for (int i = 0; i < P; ++i) v[i] = in[lane * P + i];
   wave_reduce_scatter<P>(v);
   out[lane] = v[0];
+  out[64 + lane] = (float)(scatter_owner<P>(lane) ? scatter_comp<P>(lane) : -1);
 }
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

@@ -78,32 +78,79 @@ __device__ __forceinline__ float xchg_add(float lo, float hi) {
 template <int H>
 __device__ __forceinline__ float xor_add(float v) { return xchg_add<H>(v, v); }
 
-// Reduce-scatter over the 64 lanes of a wave.  v[0..P) are per-lane partial sums of P
-// components (P a power of two <= 64).  On return v[0] in lane l holds the wave-wide total of
-// component (l & (P-1)).  P-1 exchanges for the scatter phase instead of 6*P for P
-// independent butterflies.
-template <int P, int H>
-__device__ __forceinline__ void reduce_scatter_step(float (&v)[P]) {
-  if constexpr (H >= 1) {
-#pragma unroll
-    for (int i = 0; i < H; ++i) v[i] = xchg_add<H>(v[i], v[i + H]);
-    reduce_scatter_step<P, H / 2>(v);
-  }
-}
-template <int P, int M>
-__device__ __forceinline__ float reduce_rest(float x) {
-  if constexpr (M >= P) {
-    return reduce_rest<P, M / 2>(xor_add<M>(x));
+// In-row exchange with the add fused into the DPP instruction and the two classes selected by
+// bank masks: 2 instructions per exchange instead of 2 movs + add (device pass only: the host
+// pass and the CPU emulator take the builtin form above).
+template <int H>
+__device__ __forceinline__ float xchg_add_row(float lo, float hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  float d;
+  if constexpr (H == 8) {
+    asm volatile("s_nop 1\n v_add_f32_dpp %0, %1, %1 row_shl:8 row_mask:0xf bank_mask:0x3\n"
+                 " v_add_f32_dpp %0, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xc" : "=&v"(d) : "v"(lo), "v"(hi));
+    return d;
+  } else if constexpr (H == 4) {
+    asm volatile("s_nop 1\n v_add_f32_dpp %0, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n"
+                 " v_add_f32_dpp %0, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xa" : "=&v"(d) : "v"(lo), "v"(hi));
+    return d;
   } else {
-    return x;
+    return xchg_add<H>(lo, hi);
+  }
+#else
+  return xchg_add<H>(lo, hi);
+#endif
+}
+
+// Reduce-scatter over the 64 lanes of a wave.  v[0..P) are per-lane partial sums of P
+// components (P a power of two <= 64).  The exchange levels run over lane distances
+// 8, 4, 2, 1 (inside a 16-lane row: DPP), then 16, 32 (v_permlane swaps); the first log2(P)
+// levels halve the live components, the remaining ones are plain all-reduce steps on the one
+// surviving value.  On return v[0] in lane l holds the wave-wide total of component
+// scatter_comp<P>(l); lanes with scatter_owner<P>(l) hold each component exactly once.
+// Cost: P-1 exchanges instead of 6*P for P independent butterflies; doing the in-row levels
+// first keeps the expensive cross-row swaps for the last <= 3 values (tools/mb_xlane.hip:
+// -24 % vs swaps first).
+constexpr int kLaneDist[6] = {8, 4, 2, 1, 16, 32};
+constexpr int ilog2c(int v) { return v <= 1 ? 0 : 1 + ilog2c(v >> 1); }
+
+template <int P>
+__device__ __forceinline__ int scatter_comp(int lane) {
+  int comp = 0;
+#pragma unroll
+  for (int k = 0; k < ilog2c(P); ++k) comp |= ((lane & kLaneDist[k]) ? (P >> (k + 1)) : 0);
+  return comp;
+}
+template <int P>
+__device__ __forceinline__ bool scatter_owner(int lane) {
+  int rest = 0;
+#pragma unroll
+  for (int k = ilog2c(P); k < 6; ++k) rest |= kLaneDist[k];
+  return (lane & rest) == 0;
+}
+
+template <int L>
+__device__ __forceinline__ float xchg_any(float lo, float hi) {
+  if constexpr (L == 8 || L == 4) return xchg_add_row<L>(lo, hi);
+  else return xchg_add<L>(lo, hi);
+}
+template <int P, int K>
+__device__ __forceinline__ void reduce_scatter_level(float (&v)[P]) {
+  if constexpr (K < 6) {
+    constexpr int L = kLaneDist[K];
+    if constexpr (K < ilog2c(P)) {
+      constexpr int S = P >> (K + 1);
+#pragma unroll
+      for (int i = 0; i < S; ++i) v[i] = xchg_any<L>(v[i], v[i + S]);
+    } else {
+      v[0] = xchg_any<L>(v[0], v[0]);
+    }
+    reduce_scatter_level<P, K + 1>(v);
   }
 }
 template <int P>
 __device__ __forceinline__ void wave_reduce_scatter(float (&v)[P]) {
   static_assert(P >= 1 && P <= 64 && (P & (P - 1)) == 0, "P must be a power of two <= 64");
-  reduce_scatter_step<P, P / 2>(v);
-  // lanes with equal (l & (P-1)) hold partials of the same component
-  v[0] = reduce_rest<P, 32>(v[0]);
+  reduce_scatter_level<P, 0>(v);
 }
 
 // ---- wave64 prefix scans on DPP (GCN/CDNA row_shr + row_bcast idiom, 7 fused steps) --------

@@ -458,8 +458,8 @@ __global__ void __launch_bounds__(256 / PPL) k_composite_bwd_pixel(CompParams p)
       gr[4] = gr[3];  // grad_cov[1] and grad_cov[2] receive the same value (kernels.h:414-415)
 
       if (!(p.dbg & 2)) wave_reduce_scatter<P>(gr);
-      const int comp = lane & (P - 1);
-      if (!(p.dbg & 1) && lane < P && comp < TR::NCOMP) {
+      const int comp = scatter_comp<P>(lane);
+      if (!(p.dbg & 1) && scatter_owner<P>(lane) && comp < TR::NCOMP) {
         const size_t id = (size_t)S.id[g];
         float *dst;
         if (comp < 2) dst = p.g_mean + 2 * id + comp;

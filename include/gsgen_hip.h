@@ -206,7 +206,8 @@ int gsgen_vol_render_rgbd_backward(uint32_t N, uint32_t D, const float *mean, co
                                    uint32_t W, float thresh, const uint32_t *tile_order, gsgen_stream_t stream);
 
 /* Self test of the wave64 cross-lane reduce-scatter used by the backward (tests only):
- * in [64 lanes, P components], out[lane] = sum over lanes of component (lane mod P); P in {8,16,32,64}. */
+ * in [64 lanes, P components]; out[0..64) = per-lane result, out[64..128) = the component index that
+ * lane owns (-1: duplicate holder); P in {8,16,32,64}. */
 int gsgen_selftest_reduce_scatter(uint32_t P, const float *in, float *out, gsgen_stream_t stream);
 
 #ifdef __cplusplus

@@ -184,10 +184,14 @@ def test_emulated_fused_frame_geometry(emu):
 @pytest.mark.parametrize("Pc", [8, 16, 32, 64])
 def test_emulated_reduce_scatter(emu, Pc):
     x = np.random.default_rng(Pc).normal(size=(64, Pc)).astype(np.float32)
-    out = np.zeros(64, np.float32)
+    out = np.zeros(128, np.float32)
     emu.selftest_reduce_scatter(Pc, P(x), P(out), None)
-    want = x.astype(np.float64).sum(0)[np.arange(64) % Pc]
-    assert np.abs(out - want).max() < 1e-4
+    tot = x.astype(np.float64).sum(0)
+    owner = out[64:].astype(int)
+    assert sorted(owner[owner >= 0].tolist()) == list(range(Pc))  # every component owned exactly once
+    for lane in range(64):
+        if owner[lane] >= 0:
+            assert abs(out[lane] - tot[owner[lane]]) < 1e-4
 
 
 def test_emulated_sort_register_widths(emu):

@@ -344,7 +344,12 @@ def test_wave_reduce_scatter_primitive(Pc):
     """v_permlane32/16_swap + DPP reduce-scatter of the backward against a plain sum."""
     x = np.random.default_rng(Pc).normal(size=(64, Pc)).astype(np.float32)
     xin = T_(x)
-    out = torch.zeros(64, device=dev())
+    out = torch.zeros(128, device=dev())
     lib().selftest_reduce_scatter(Pc, p(xin), p(out), stream())
-    want = x.astype(np.float64).sum(0)[np.arange(64) % Pc]
-    assert np.abs(out.cpu().numpy() - want).max() < 1e-4
+    o = out.cpu().numpy()
+    tot = x.astype(np.float64).sum(0)
+    owner = o[64:].astype(int)
+    assert sorted(owner[owner >= 0].tolist()) == list(range(Pc))  # every component owned exactly once
+    for lane in range(64):
+        if owner[lane] >= 0:
+            assert abs(o[lane] - tot[owner[lane]]) < 1e-4
