@@ -102,15 +102,15 @@ __device__ __forceinline__ float xchg_add_row(float lo, float hi) {
 }
 
 // Reduce-scatter over the 64 lanes of a wave.  v[0..P) are per-lane partial sums of P
-// components (P a power of two <= 64).  The exchange levels run over lane distances
-// 8, 4, 2, 1 (inside a 16-lane row: DPP), then 16, 32 (v_permlane swaps); the first log2(P)
+// components (P a power of two <= 64).  The exchange levels run over the lane distances of
+// kLaneDist (32, 16: v_permlane swaps; 8, 4, 2, 1: DPP inside a 16-lane row); the first log2(P)
 // levels halve the live components, the remaining ones are plain all-reduce steps on the one
 // surviving value.  On return v[0] in lane l holds the wave-wide total of component
 // scatter_comp<P>(l); lanes with scatter_owner<P>(l) hold each component exactly once.
-// Cost: P-1 exchanges instead of 6*P for P independent butterflies; doing the in-row levels
-// first keeps the expensive cross-row swaps for the last <= 3 values (tools/mb_xlane.hip:
-// -24 % vs swaps first).
-constexpr int kLaneDist[6] = {8, 4, 2, 1, 16, 32};
+// Cost: P-1 exchanges instead of 6*P for P independent butterflies.
+// Order chosen by kernel-level A/B on MI355X (profiles/r01_notes.md): cross-row swaps first
+// (413 us backward) vs in-row first (437 us builtin, 419 us with the fused-DPP asm).
+constexpr int kLaneDist[6] = {32, 16, 8, 4, 2, 1};
 constexpr int ilog2c(int v) { return v <= 1 ? 0 : 1 + ilog2c(v >> 1); }
 
 template <int P>
@@ -130,8 +130,10 @@ __device__ __forceinline__ bool scatter_owner(int lane) {
 
 template <int L>
 __device__ __forceinline__ float xchg_any(float lo, float hi) {
+#if defined(GSGEN_ASM_DPP)
   if constexpr (L == 8 || L == 4) return xchg_add_row<L>(lo, hi);
-  else return xchg_add<L>(lo, hi);
+#endif
+  return xchg_add<L>(lo, hi);
 }
 template <int P, int K>
 __device__ __forceinline__ void reduce_scatter_level(float (&v)[P]) {
