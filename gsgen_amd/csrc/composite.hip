@@ -457,9 +457,9 @@ __global__ void __launch_bounds__(256 / PPL) k_composite_bwd_pixel(CompParams p)
       }
       gr[4] = gr[3];  // grad_cov[1] and grad_cov[2] receive the same value (kernels.h:414-415)
 
-      if (!(p.dbg & 2)) wave_reduce_scatter<P>(gr);
+      wave_reduce_scatter<P>(gr);
       const int comp = scatter_comp<P>(lane);
-      if (!(p.dbg & 1) && scatter_owner<P>(lane) && comp < TR::NCOMP) {
+      if (scatter_owner<P>(lane) && comp < TR::NCOMP) {
         const size_t id = (size_t)S.id[g];
         float *dst;
         if (comp < 2) dst = p.g_mean + 2 * id + comp;
@@ -496,9 +496,7 @@ static int launch_fwd(const CompParams &p, hipStream_t s) {
 template <int MODE, int CB>
 static int launch_bwd(const CompParams &p_, hipStream_t s) {
   static const int ppl = env_ppl("GSGEN_PPL_BWD", 4);
-  static const int dbg = getenv("GSGEN_DBG") ? atoi(getenv("GSGEN_DBG")) : 0;
   CompParams p = p_;
-  p.dbg = dbg;
   if (p.n_hi == 0) p.n_hi = 0x7fffffff;
   const uint32_t nblk = comp_grid(p);
   if (p.ntw * p.nth == 0) return 0;

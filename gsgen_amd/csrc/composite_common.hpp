@@ -24,7 +24,6 @@ struct CompParams {
   float *g_mean, *g_cov, *g_col, *g_alpha;
   int ntw, nth, H, W;
   float psx, psy, thresh;
-  int dbg;  // experiment switches (GSGEN_DBG), 0 in production
   const uint32_t *tile_order;  // optional launch order (longest list first); NULL = spatial map
   int n_lo, n_hi;  // this launch only handles tiles with n_lo <= list length < n_hi (0, INT_MAX = all)
 };
