@@ -245,19 +245,86 @@ def tile_based_vol_rendering_backward_sh_with_bg(mean, cov, sh_coeffs, alpha, st
 
 
 # ---- legacy / benchmark-only entry points of the reference -------------
+def _offset_to_start_end(offset):
+    _i(offset, "offset")
+    return offset[:-1].contiguous(), offset[1:].contiguous()
+
+
+def tile_based_vol_rendering(mean, cov, color, alpha, offset, gaussian_ids, out, topleft, tile_size, n_tiles_h,
+                             n_tiles_w, pixel_size_x, pixel_size_y, H, W, thresh):
+    """render.h:24 / render.cu:179-218: the CSR (`offset[T+1]`) form of the RGB forward
+    (vol_render.h:420-478); same compositing as the start/end form."""
+    start, end = _offset_to_start_end(offset)
+    tile_based_vol_rendering_start_end(mean, cov, color, alpha, start, end, gaussian_ids, out, topleft, tile_size,
+                                       n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H, W, thresh)
+
+
+# v1 keeps out/T in registers, v2 also stages the ids in LDS (vol_render.h:480-603): same results
+tile_based_vol_rendering_v1 = tile_based_vol_rendering
+tile_based_vol_rendering_v2 = tile_based_vol_rendering
+
+
+def tile_based_vol_rendering_backward(mean, cov, color, alpha, offset, gaussian_ids, out, grad_mean, grad_cov,
+                                      grad_color, grad_alpha, grad_out, topleft, tile_size, n_tiles_h, n_tiles_w,
+                                      pixel_size_x, pixel_size_y, H, W, thresh):
+    """render.h:42 / render.cu:304-361 (CSR form of the RGB backward, vol_render.h:605-703)."""
+    start, end = _offset_to_start_end(offset)
+    tile_based_vol_rendering_backward_start_end(mean, cov, color, alpha, start, end, gaussian_ids, out, grad_mean,
+                                                grad_cov, grad_color, grad_alpha, grad_out, topleft, tile_size,
+                                                n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H, W, thresh)
+
+
+def tile_culling_aabb(aabb_topleft, aabb_bottomright, gaussian_ids, offset, depth, n_tiles_h, n_tiles_w):
+    """render.h:56 / render.cu:363-379 -> aabb_culling.h:116-190: as tile_culling_aabb_start_end with a
+    CSR `offset[T+1]`.  The reference leaves the entries of empty tiles at -1 (its fixer kernel is
+    commented out, aabb_culling.h:180-184), which its own CSR consumers cannot digest; here empty
+    tiles get the next tile's offset, i.e. a valid CSR."""
+    _i(offset, "offset")
+    T = int(n_tiles_h) * int(n_tiles_w)
+    if offset.numel() != T + 1:
+        raise RuntimeError("offset must have n_tiles_h * n_tiles_w + 1 entries")
+    start = torch.empty(T, dtype=torch.int32, device=offset.device)
+    end = torch.empty_like(start)
+    tile_culling_aabb_start_end(aabb_topleft, aabb_bottomright, gaussian_ids, start, end, depth, n_tiles_h, n_tiles_w)
+    counts = torch.where(start >= 0, end - start, torch.zeros_like(start))
+    offset[0] = 0
+    offset[1:] = torch.cumsum(counts, 0).to(torch.int32)
+
+
+def tile_based_vol_rendering_backward_sh_v1(*args):
+    """render.h:99: experimental variant of the SH backward (ids staged in LDS); same result."""
+    tile_based_vol_rendering_backward_sh(*args)
+
+
+def tile_based_vol_rendering_backward_sh_warp_reduce(*args):
+    """render.h:106: the reference's warp-reduce experiment is unused and wrong;
+    this computes the correct SH backward."""
+    tile_based_vol_rendering_backward_sh(*args)
+
+
+def debug_check_tiledepth(offset, tiledepth):
+    """render.h / debug.h:3-32: host-side check that the (tile, depth) keys of a CSR are sorted.
+    offset int32 [T+1] and tiledepth float64 [D] (each double = {float depth, int32 tile}) on the CPU."""
+    import numpy as np
+    off = offset.cpu().numpy()
+    raw = tiledepth.cpu().numpy().view(np.int32).reshape(-1, 2)
+    tiles, depth = raw[:, 1], raw[:, 0].copy().view(np.float32)
+    for t in range(len(off) - 1):
+        s, e = int(off[t]), int(off[t + 1])
+        if e - s > 0:
+            assert (tiles[s:e] == t).all(), f"tile id mismatch in tile {t}"
+            assert (np.diff(depth[s:e]) >= 0).all(), f"depth not sorted in tile {t}"
+
+
 def _legacy(name):
     def fn(*a, **k):
         raise NotImplementedError(
-            f"_gs.{name}: legacy entry point of the reference that no live caller uses "
-            "(SURVEY.md 2.2 rows 12-18); not part of the MI355X hot path.")
+            f"_gs.{name}: legacy binning of the reference (probability / bounding-circle tile tests, "
+            "SURVEY.md 2.2 rows 14-15) that no live caller uses; not part of the MI355X hot path.")
     fn.__name__ = name
     return fn
 
 
-for _n in ("count_num_gaussians_each_tile", "count_num_gaussians_each_tile_bcircle",
-           "prepare_image_sort", "image_sort", "tile_based_vol_rendering",
-           "tile_based_vol_rendering_v1", "tile_based_vol_rendering_v2",
-           "tile_based_vol_rendering_backward", "tile_culling_aabb",
-           "tile_based_vol_rendering_backward_sh_v1", "tile_based_vol_rendering_backward_sh_warp_reduce",
-           "debug_check_tiledepth"):
+for _n in ("count_num_gaussians_each_tile", "count_num_gaussians_each_tile_bcircle", "prepare_image_sort",
+           "image_sort"):
     globals()[_n] = _legacy(_n)

@@ -55,6 +55,11 @@ def test_gs_mirror_rejects_cpu_tensors_like_torch_check():
         _gs.culling_gaussian_bsphere(a, a, a, a, a, torch.zeros(4, dtype=torch.bool), 6.0)
     with pytest.raises(NotImplementedError):
         _gs.image_sort()
+    # debug_check_tiledepth is host code (debug.h:3-32)
+    key = np.zeros(3, np.float64).view(np.int32).reshape(3, 2)
+    key[:, 1] = [0, 0, 1]
+    key[:, 0] = np.array([1.0, 2.0, 0.5], np.float32).view(np.int32)
+    _gs.debug_check_tiledepth(torch.tensor([0, 2, 3], dtype=torch.int32), torch.from_numpy(key.reshape(-1).view(np.float64).copy()))
 
 
 def test_camera_pack_matches_oracle_frustum():

@@ -238,3 +238,41 @@ def test_fused_rgb_heads_match_four_reference_passes():
     assert rel_err(color.grad.cpu().numpy(), r[2]) < 1e-3
     assert rel_err(depth.grad.cpu().numpy().ravel(), want_depth) < 1e-3
     assert np.abs(bg.grad.cpu().numpy() - go[0] * o_T).max() <= 1e-4
+
+
+def test_legacy_csr_entry_points():
+    """tile_culling_aabb + the offset (CSR) forms of the RGB forward/backward give the same image
+    and gradients as the start/end forms."""
+    from gsgen_amd import _gs
+    sc = scenes.random_scene(800, seed=3, svec=0.05)
+    cam = scenes.Camera(96, 80, fx=90.0)
+    g = scenes.oracle_geometry(sc, cam)
+    m = g["mask"]
+    nth, ntw = cam.tiles
+    H, W = cam.h, cam.w
+    tl, br, depth = T_(g["tl"]), T_(g["br"]), T_(g["depth"])
+    ids = torch.zeros(g["D"], dtype=torch.int32, device=dev())
+    offset = torch.zeros(nth * ntw + 1, dtype=torch.int32, device=dev())
+    _gs.tile_culling_aabb(tl, br, ids, offset, depth, nth, ntw)
+    assert np.array_equal(ids.cpu().numpy(), g["ids"])
+    cnt = np.where(g["start"] >= 0, g["end"] - g["start"], 0)
+    assert np.array_equal(offset.cpu().numpy(), np.concatenate([[0], np.cumsum(cnt)]))
+    mean2d, cov2d, col, al = T_(g["mean2d"]), T_(g["cov2d"]), T_(sc["color"][m]), T_(sc["alpha"][m])
+    out = torch.zeros(H * W * 3, device=dev())
+    topleft = T_(cam.topleft)
+    for fn in (_gs.tile_based_vol_rendering, _gs.tile_based_vol_rendering_v1, _gs.tile_based_vol_rendering_v2):
+        out.zero_()
+        fn(mean2d, cov2d, col, al, offset, ids, out, topleft, 16, nth, ntw, 1 / cam.fx, 1 / cam.fy, H, W, 1e-4)
+        ref, _ = O.render_rgb_fwd(g["mean2d"], g["cov2d"], sc["color"][m], sc["alpha"][m], g["start"], g["end"], g["ids"],
+                                  cam.topleft, 1 / cam.fx, 1 / cam.fy, H, W)
+        assert np.abs(out.cpu().numpy().reshape(H, W, 3) - ref).max() <= 1e-4
+    go = torch.randn(H, W, 3, device=dev())
+    gm, gc = torch.zeros_like(mean2d), torch.zeros_like(cov2d)
+    gcol, ga = torch.zeros_like(col), torch.zeros_like(al)
+    _gs.tile_based_vol_rendering_backward(mean2d, cov2d, col, al, offset, ids, out, gm, gc, gcol, ga, go, topleft, 16, nth,
+                                          ntw, 1 / cam.fx, 1 / cam.fy, H, W, 1e-4)
+    r = O.render_rgb_bwd(g["mean2d"], g["cov2d"], sc["color"][m], sc["alpha"][m], g["start"], g["end"], g["ids"], ref,
+                         go.cpu().numpy(), cam.topleft, 1 / cam.fx, 1 / cam.fy, H, W)
+    assert rel_err(gm.cpu().numpy(), r[0]) < 1e-3 and rel_err(gcol.cpu().numpy(), r[2]) < 1e-3
+    with pytest.raises(NotImplementedError):
+        _gs.image_sort()
