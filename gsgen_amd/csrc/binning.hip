@@ -286,42 +286,64 @@ __device__ __forceinline__ void cross_step(u64 (&k)[K], int m, bool flip) {
   top |= top >> 1; top |= top >> 2; top |= top >> 4;
   top = (top + 1) >> 1;
   const bool keep_min = (lane & top) == 0;
-  u64 other[K];
+  auto pick = [&](u64 mine, u64 theirs) { return (keep_min ? (theirs < mine) : (theirs > mine)) ? theirs : mine; };
+  if (flip) {
+    // my register r meets the partner's register K-1-r: handle (r, K-1-r) together so that no
+    // copy of the whole key array is needed (K = 32 would spill otherwise)
+    if constexpr (K == 1) {
+      k[0] = pick(k[0], __shfl_xor(k[0], m, 64));
+    } else {
 #pragma unroll
-  for (int r = 0; r < K; ++r) other[r] = __shfl_xor(k[flip ? (K - 1 - r) : r], m, 64);
+      for (int r = 0; r < K / 2; ++r) {
+        const u64 a = k[r], b = k[K - 1 - r];
+        const u64 oa = __shfl_xor(b, m, 64), ob = __shfl_xor(a, m, 64);
+        k[r] = pick(a, oa);
+        k[K - 1 - r] = pick(b, ob);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < K; ++r) k[r] = pick(k[r], __shfl_xor(k[r], m, 64));
+  }
+}
+// all comparators at distance J inside a lane (compile-time register indices)
+template <int K, int J>
+__device__ __forceinline__ void local_step(u64 (&k)[K]) {
 #pragma unroll
   for (int r = 0; r < K; ++r) {
-    const u64 a = k[r], b = other[r];
-    const bool take = keep_min ? (b < a) : (b > a);
-    k[r] = take ? b : a;
+    if ((r & J) == 0) cmpx(k[r], k[r | J]);
+  }
+}
+template <int K, int J>
+__device__ __forceinline__ void local_tail(u64 (&k)[K]) {  // distances J, J/2, ..., 1
+  if constexpr (J >= 1) {
+    local_step<K, J>(k);
+    local_tail<K, J / 2>(k);
+  }
+}
+// merge stages whose blocks fit in a lane: size = 2 .. K (compile time)
+template <int K, int SIZE>
+__device__ __forceinline__ void local_sizes(u64 (&k)[K]) {
+  if constexpr (SIZE <= K) {
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+      const int l = r ^ (SIZE - 1);
+      if (l > r) cmpx(k[r], k[l]);
+    }
+    local_tail<K, SIZE / 4>(k);
+    local_sizes<K, SIZE * 2>(k);
   }
 }
 template <int K>
 __device__ __forceinline__ void sort_regs(u64 (&k)[K]) {
-  constexpr int P2 = 64 * K;
-#pragma unroll
-  for (int size = 2; size <= P2; size <<= 1) {
-    if (size <= K) {
-#pragma unroll
-      for (int r = 0; r < K; ++r) {
-        const int l = r ^ (size - 1);
-        if (l > r) cmpx(k[r], k[l]);
-      }
-    } else {
-      cross_step<K>(k, size / K - 1, true);
-    }
-#pragma unroll
-    for (int j = size >> 2; j >= 1; j >>= 1) {
-      if (j >= K) {
-        cross_step<K>(k, j / K, false);
-      } else {
-#pragma unroll
-        for (int r = 0; r < K; ++r) {
-          const int l = r ^ j;
-          if (l > r) cmpx(k[r], k[l]);
-        }
-      }
-    }
+  local_sizes<K, 2>(k);
+  // merge stages spanning lanes: the bodies below are the same code for every size (only the
+  // xor mask changes), so this is a RUNTIME loop -- fully unrolling 66 stages of 32 registers
+  // made the compiler put the key array into scratch.
+  for (int size = 2 * K; size <= 64 * K; size <<= 1) {
+    cross_step<K>(k, size / K - 1, true);
+    for (int j = size >> 2; j >= K; j >>= 1) cross_step<K>(k, j / K, false);
+    local_tail<K, K / 2>(k);
   }
 }
 template <int K>
