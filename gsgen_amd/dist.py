@@ -67,3 +67,26 @@ def render_batch_sharded(render_one, cameras, group=None):
         probe = render_one(cameras[0])
         local = probe.new_zeros((0,) + tuple(probe.shape))
     return gather_images(local, len(cameras), group)
+
+
+def allreduce_gradients(tensors, group=None, average=True):
+    """Data-parallel training on top of camera sharding: every rank has rendered
+    and back-propagated its own cameras, the replicated parameters' gradients are summed (or
+    averaged) with ONE bucketed all_reduce -- all gradient tensors are packed into a single flat
+    buffer (24 MB for 100 k Gaussians at SH degree 3; on MI355X a reduce-scatter + all-gather over
+    the 7 direct xGMI links moves that in tens of microseconds) and unpacked in place."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return tensors
+    grads = [t for t in tensors if t is not None]
+    if not grads:
+        return tensors
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    if average:
+        flat /= dist.get_world_size(group)
+    off = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[off:off + n].view_as(g))
+        off += n
+    return tensors

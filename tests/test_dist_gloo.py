@@ -71,3 +71,39 @@ def test_shard_bounds_cover_everything():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(100 + rank)
+    grads = [torch.randn(50, 3, generator=g), torch.randn(50, generator=g), None, torch.randn(50, 3, 16, generator=g)]
+    D.allreduce_gradients(grads)
+    if rank == 0:
+        q.put([x.numpy() if x is not None else None for x in grads])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_gradient_allreduce():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = None
+    for r in range(world):
+        g = torch.Generator().manual_seed(100 + r)
+        cur = [torch.randn(50, 3, generator=g), torch.randn(50, generator=g), None, torch.randn(50, 3, 16, generator=g)]
+        want = cur if want is None else [a + b if a is not None else None for a, b in zip(want, cur)]
+    for a, b in zip(got, want):
+        if b is None:
+            assert a is None
+        else:
+            assert np.allclose(a, (b / world).numpy(), atol=1e-6)
