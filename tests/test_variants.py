@@ -1,0 +1,39 @@
+"""The compositing kernels exist in several compiled variants selected by environment variables
+read once per process (pixels per lane of the forward / backward, pixel-parallel vs splat-parallel
+backward).  Only one combination is the default; these tests run the parity suite in a
+subprocess for the others so that none of them rots.  CPU: on the SIMT emulator; GPU: on the
+real library."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+VARIANTS = [
+    {"GSGEN_BWD": "splat"},
+    {"GSGEN_PPL_FWD": "4", "GSGEN_PPL_BWD": "2"},
+    {"GSGEN_PPL_FWD": "2", "GSGEN_PPL_BWD": "1"},
+    {"GSGEN_BWD_SPLIT": "40"},
+]
+
+
+def _run(env_extra, args):
+    env = dict(os.environ)
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider"] + args, cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("variant", VARIANTS, ids=lambda v: ",".join(f"{k}={x}" for k, x in v.items()))
+def test_variant_on_emulator(variant):
+    _run(variant, ["tests/test_cpu_host.py", "-k", "emulated_kernels_match_oracle or emulated_fused_rgb_heads"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", VARIANTS, ids=lambda v: ",".join(f"{k}={x}" for k, x in v.items()))
+def test_variant_on_gpu(variant):
+    _run(variant, ["tests/test_gpu_parity.py", "tests/test_gpu_golden.py", "-m", "gpu", "-k",
+                   "forward_backward or golden"])
