@@ -32,6 +32,7 @@ SIGNATURES = {
     "gsgen_project_gaussians": [u32, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "gsgen_project_gaussians_backward": [u32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp],
     "gsgen_project_gaussians_backward_masked": [u32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp],
+    "gsgen_densify_update": [u32, vp, vp, vp, vp, vp, vp, vp],
     "gsgen_tile_culling_aabb_count": [u32, vp, vp, u32, f32, f32, f32, f32, u32, u32, f32, vp, vp, vp, vp],
     "gsgen_selftest_reduce_scatter": [u32, vp, vp, vp],
     "gsgen_vol_render_rgbd": [u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, u32, f32, f32, u32, u32,

@@ -136,6 +136,31 @@ k_project(uint32_t N, const float *__restrict__ mean, const float *__restrict__ 
   }
 }
 
+// Densification statistics of one rendered camera, rows aligned with the frustum mask
+// (gs/gaussian_splatting.py:1240-1245 and :464-469): the running maximum of the screen-space
+// "radius" m + sqrt(max(m^2 - det, 0)) (no outer sqrt on this path), the running sum of
+// |d L / d mean2d| and the visit count.  One pass, 29 B read + 12 B written per Gaussian.
+__global__ void __launch_bounds__(kThreads)
+k_densify_update(uint32_t N, const float *__restrict__ cov2d, const float *__restrict__ g_mean2d,
+                 const uint8_t *__restrict__ mask, float *__restrict__ max_radii2d,
+                 float *__restrict__ grad_accum, float *__restrict__ cnt) {
+  const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  if (mask != nullptr && mask[n] == 0) return;
+  if (max_radii2d != nullptr) {
+    const float4 c = *reinterpret_cast<const float4 *>(cov2d + 4 * (size_t)n);
+    const float m = (c.x + c.w) / 2.0f;
+    const float det = c.x * c.w - c.y * c.z;
+    const float r = m + sqrtf(fmaxf(m * m - det, 0.0f));
+    max_radii2d[n] = fmaxf(max_radii2d[n], r);
+  }
+  if (grad_accum != nullptr) {
+    const float2 g = *reinterpret_cast<const float2 *>(g_mean2d + 2 * (size_t)n);
+    grad_accum[n] += sqrtf(g.x * g.x + g.y * g.y);
+    if (cnt != nullptr) cnt[n] += 1.0f;
+  }
+}
+
 // Backward of the projection as autograd differentiates gs/renderer.py:391-421: J is a
 // constant (@torch.no_grad), the depth in the perspective divide is detached iff
 // detach_depth.  Gradients are overwritten.
@@ -385,6 +410,18 @@ int gsgen_tile_culling_aabb_count(uint32_t N, const float *mean2d, const float *
   if (!mean2d || !cov2d || !aabb_topleft || !aabb_bottomright) return GSGEN_EINVAL;
   hipLaunchKernelGGL(k_aabb_count, grid_for(N), dim3(kThreads), 0, s, N, mean2d, cov2d, fx, fy, cx, cy,
                      (int)w, (int)h, D, aabb_topleft, aabb_bottomright, total);
+  return (int)hipGetLastError();
+}
+
+int gsgen_densify_update(uint32_t N, const float *cov2d, const float *grad_mean2d,
+                         const uint8_t *mask, float *max_radii2d, float *grad_accum, float *cnt,
+                         gsgen_stream_t stream) {
+  if (N == 0) return 0;
+  if ((cov2d == nullptr) != (max_radii2d == nullptr)) return GSGEN_EINVAL;
+  if ((grad_mean2d == nullptr) != (grad_accum == nullptr)) return GSGEN_EINVAL;
+  if (cnt != nullptr && grad_accum == nullptr) return GSGEN_EINVAL;
+  hipLaunchKernelGGL(k_densify_update, grid_for(N), dim3(kThreads), 0, (hipStream_t)stream, N, cov2d,
+                     grad_mean2d, mask, max_radii2d, grad_accum, cnt);
   return (int)hipGetLastError();
 }
 

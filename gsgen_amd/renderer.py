@@ -406,18 +406,44 @@ def frame_geometry(mean, qvec, svec, cam_dev, buf):
             _p(buf.total), _p(buf.ws), buf.ws.numel(), _stream(mean))
 
 
+class DensifyStats:
+    """The three per-Gaussian running statistics the trainer's densify/prune step reads
+    (gs/gaussian_splatting.py:477-479): max_radii2d, mean_2d_grad_accum, cnt (all f32 [N]).
+
+    `render_frame(..., stats=s)` updates max_radii2d in the forward and grad_accum/cnt in the
+    backward (the reference does the latter in update_densify_info(), :464-469), each as one
+    masked pass on the render's stream."""
+
+    def __init__(self, N, device):
+        self.max_radii2d = torch.zeros(N, device=device, dtype=torch.float32)
+        self.grad_accum = torch.zeros(N, device=device, dtype=torch.float32)
+        self.cnt = torch.zeros(N, device=device, dtype=torch.float32)
+
+    def update_radii(self, cov2d, mask):
+        with torch.cuda.device(cov2d.device):
+            _capi.load().densify_update(cov2d.shape[0], _p(cov2d), None, _p(mask), _p(self.max_radii2d), None,
+                                        None, _stream(cov2d))
+
+    def update_grad(self, grad_mean2d, mask):
+        with torch.cuda.device(grad_mean2d.device):
+            _capi.load().densify_update(grad_mean2d.shape[0], None, _p(grad_mean2d), _p(mask), None,
+                                        _p(self.grad_accum), _p(self.cnt), _stream(grad_mean2d))
+
+
 class _render_frame(torch.autograd.Function):
     """Fused differentiable frame: (mean, qvec, svec, alpha, sh|color) -> rgb [H,W,3] (+T)."""
 
     @staticmethod
     def forward(ctx, mean, qvec, svec, alpha, col, cam_dev, topleft, rot, bg_rgb, buf, cam_info, C,
-                thresh, detach_depth):
+                thresh, detach_depth, stats):
         mean, qvec, svec = mean.contiguous(), qvec.contiguous(), svec.contiguous()
         alpha, col = alpha.contiguous(), col.contiguous()
         lib = _capi.load()
         H, W = buf.H, buf.W
         dev = mean.device
         frame_geometry(mean, qvec, svec, cam_dev, buf)
+        if stats is not None:
+            stats.update_radii(buf.cov2d, buf.mask)
         out = torch.zeros(H, W, 3, device=dev, dtype=torch.float32)
         T = torch.ones(H, W, 1, device=dev, dtype=torch.float32)
         psx, psy = 1.0 / cam_info.fx, 1.0 / cam_info.fy
@@ -438,6 +464,7 @@ class _render_frame(torch.autograd.Function):
         ctx.save_for_backward(mean, qvec, svec, alpha, col, cam_dev, topleft, rot, out)
         ctx.buf, ctx.cam_info, ctx.C, ctx.thresh, ctx.detach = buf, cam_info, C, thresh, detach_depth
         ctx.has_bg = bg_rgb is not None
+        ctx.stats = stats
         ctx.mark_non_differentiable(T)
         return out, T
 
@@ -471,11 +498,13 @@ class _render_frame(torch.autograd.Function):
             lib.project_gaussians_backward_masked(N, _p(mean), _p(qvec), _p(svec), _p(cam_dev),
                                                   int(ctx.detach), _p(buf.mask), _p(g_mean2d), _p(g_cov2d),
                                                   None, _p(g_mean), _p(g_qvec), _p(g_svec), s)
-        return (g_mean, g_qvec, g_svec, g_alpha, g_col) + (None,) * 9
+        if ctx.stats is not None:
+            ctx.stats.update_grad(g_mean2d, buf.mask)
+        return (g_mean, g_qvec, g_svec, g_alpha, g_col) + (None,) * 10
 
 
 def render_frame(mean, qvec, svec, alpha, col, cam_info, c2w, buf, C=0, bg_rgb=None, thresh=1e-4,
-                 frustum_radius=6.0, tile_radius=6.0, detach_depth=True):
+                 frustum_radius=6.0, tile_radius=6.0, detach_depth=True, stats=None):
     """One differentiable render of `cam_info` at pose `c2w` ([3,4], host array or tensor).
 
     col is sh_coeffs [N,3,C*C] when C in 1..4, or post-activation rgb [N,3] when C == 0.
@@ -487,4 +516,4 @@ def render_frame(mean, qvec, svec, alpha, col, cam_info, c2w, buf, C=0, bg_rgb=N
     topleft = torch.tensor([-cam_info.cx / cam_info.fx, -cam_info.cy / cam_info.fy], dtype=torch.float32).to(dev)
     rot = torch.from_numpy(np.ascontiguousarray(c2w_np[:3, :3], np.float32).reshape(-1)).to(dev)
     return _render_frame.apply(mean, qvec, svec, alpha, col, cam_dev, topleft, rot, bg_rgb, buf, cam_info,
-                               int(C), float(thresh), bool(detach_depth))
+                               int(C), float(thresh), bool(detach_depth), stats)

@@ -138,6 +138,23 @@ int gsgen_project_gaussians_backward(uint32_t N, const float *mean, const float 
                                      const float *g_mean2d, const float *g_cov2d,
                                      const float *g_depth, float *g_mean, float *g_qvec,
                                      float *g_svec, gsgen_stream_t stream);
+/* Same, rows with mask[i]==0 get zero gradients (mask may be NULL): the backward leg of
+ * gsgen_frame_geometry, which keeps every array full-N instead of compacting by the mask. */
+int gsgen_project_gaussians_backward_masked(uint32_t N, const float *mean, const float *qvec,
+                                            const float *svec, const float *c2w, int detach_depth,
+                                            const uint8_t *mask, const float *g_mean2d,
+                                            const float *g_cov2d, const float *g_depth,
+                                            float *g_mean, float *g_qvec, float *g_svec,
+                                            gsgen_stream_t stream);
+/* Densification statistics of one camera (gs/gaussian_splatting.py:1240-1245, :464-469), rows
+ * aligned with mask [N] (NULL = all rows):
+ *   max_radii2d[i] = max(max_radii2d[i], m + sqrt(max(m^2 - det(cov2d_i), 0))), m = tr/2
+ *   grad_accum[i] += |grad_mean2d_i|_2 ;  cnt[i] += 1
+ * Either pair (cov2d, max_radii2d) / (grad_mean2d, grad_accum[, cnt]) may be NULL together.
+ * torch.det's LU rounding is not reproduced: det = c00*c11 - c01*c10 in fp32. */
+int gsgen_densify_update(uint32_t N, const float *cov2d, const float *grad_mean2d,
+                         const uint8_t *mask, float *max_radii2d, float *grad_accum, float *cnt,
+                         gsgen_stream_t stream);
 /* AABB tile rectangles + pair count on the device (gs/culling.py:8-37 without the .item()
  * host sync): writes aabb_topleft/bottomright int32 [N,2] and *total (device uint32, zeroed
  * inside the call) = N_with_dub. */

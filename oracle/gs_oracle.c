@@ -273,6 +273,32 @@ long long gso_aabb_count(int N, const float *mean2d, const float *cov2d, int til
   return total;
 }
 
+/* Densification statistics (gs/gaussian_splatting.py:1240-1245 radii, :464-469 grad norm). */
+/* det restated as c00*c11 - c01*c10 (torch.det goes through an LU whose rounding is library  */
+/* specific; tests compare against torch with a tolerance).                                  */
+void gso_densify_update(int N, const float *cov2d, const float *g_mean2d, const unsigned char *mask,
+                        float *max_radii2d, float *grad_accum, float *cnt) {
+  for (int n = 0; n < N; ++n) {
+    if (mask && !mask[n]) continue;
+    if (max_radii2d) {
+      const float *c = cov2d + 4 * n;
+      float m = (c[0] + c[3]) / 2.0f;
+      float a = c[0] * c[3], b = c[1] * c[2];
+      float det = a - b;
+      float mm = m * m;
+      float d = mm - det;
+      float r = m + sqrtf(d > 0.0f ? d : 0.0f);
+      if (r > max_radii2d[n]) max_radii2d[n] = r;
+    }
+    if (grad_accum) {
+      float gx = g_mean2d[2 * n], gy = g_mean2d[2 * n + 1];
+      float xx = gx * gx, yy = gy * gy;
+      grad_accum[n] += sqrtf(xx + yy);
+      if (cnt) cnt[n] += 1.0f;
+    }
+  }
+}
+
 /* ------------------------------------------------------------------------------------ */
 /* Binning + sort (gs/src/include/aabb_culling.h:15-41, 70-103, 192-260)                  */
 /* key = int64{hi = tile id, lo = float bits of depth}, stable ascending sort on all 64   */

@@ -108,6 +108,16 @@ def aabb_count(mean2d, cov2d, tile_size, fx, fy, cx, cy, w, h, D=6.0):
     return int(n), tl, br
 
 
+def densify_update(cov2d, grad_mean2d, mask, max_radii2d, grad_accum, cnt):
+    """In place on the three float32 [N] statistics arrays (any pair may be None)."""
+    N = (cov2d if cov2d is not None else grad_mean2d).shape[0]
+    keep = [None if a is None else _f(a) for a in (cov2d, grad_mean2d)]
+    m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+    for a in (max_radii2d, grad_accum, cnt):
+        assert a is None or (a.dtype == np.float32 and a.flags.c_contiguous)
+    lib().gso_densify_update(N, _p(keep[0]), _p(keep[1]), _p(m), _p(max_radii2d), _p(grad_accum), _p(cnt))
+
+
 def bin_sort(tl, br, depth, n_tiles_h, n_tiles_w, D):
     tl, br, depth = _i(tl), _i(br), _f(depth).reshape(-1)
     N = tl.shape[0]

@@ -252,3 +252,49 @@ def test_emulated_fused_rgb_heads(emu):
     for a_, b_ in ((gm, want_m), (gc, want_c.reshape(-1, 4)), (ga, want_a), (gch[:, :3], r[2]), (gch[:, 3], ss[0][2]),
                    (gch[:, 4], ss[1][2]), (gch[:, 5], ss[2][2])):
         assert np.abs(a_ - b_).max() <= 1e-4 * (np.abs(b_).max() + 1e-12)
+
+
+def _torch_densify(cov2d, gmean2d, mask, max_r, acc, cnt):
+    """The reference's statements (gs/gaussian_splatting.py:1240-1245, :464-469) on full-N rows."""
+    cov = torch.from_numpy(cov2d).reshape(-1, 2, 2); mask = torch.from_numpy(mask.astype(bool))
+    max_r, acc, cnt = (torch.from_numpy(a.copy()) for a in (max_r, acc, cnt))
+    cov = cov[mask]
+    m = (cov[..., 0, 0] + cov[..., 1, 1]) / 2.0
+    p = torch.det(cov)
+    radii2d = m + torch.sqrt((m**2 - p).clamp(min=0))
+    max_r[mask] = torch.max(max_r[mask], radii2d)
+    acc[mask] += torch.from_numpy(gmean2d)[mask].norm(dim=-1)
+    cnt[mask] += 1
+    return max_r.numpy(), acc.numpy(), cnt.numpy()
+
+
+def test_densify_statistics_oracle_vs_torch_and_emulated_kernel(emu):
+    rng = np.random.default_rng(11)
+    N = 5000
+    A = rng.normal(size=(N, 2, 2)).astype(np.float32) * 0.02
+    cov = np.ascontiguousarray((A @ A.transpose(0, 2, 1)).reshape(N, 4), np.float32)
+    cov[:50] = np.array([4e-4, 0, 0, 4e-4], np.float32)  # isotropic: m^2 - det cancels to ~0
+    gm = rng.normal(size=(N, 2)).astype(np.float32) * 1e-3
+    mask = (rng.random(N) < 0.7).astype(np.uint8)
+    r0 = (rng.random(N) * 1e-3).astype(np.float32); a0 = rng.random(N).astype(np.float32)
+    c0 = rng.integers(0, 5, N).astype(np.float32)
+    want = _torch_densify(cov, gm, mask, r0, a0, c0)
+    o = [r0.copy(), a0.copy(), c0.copy()]
+    O.densify_update(cov, gm, mask, *o)
+    # torch.det is an LU: its rounding differs from c00*c11 - c01*c10 by ~1 ulp of det, which the
+    # sqrt of the cancelling m^2 - det turns into ~sqrt(eps)*m
+    assert np.abs(o[0] - want[0]).max() <= 1e-3 * np.abs(want[0]).max()
+    assert np.abs(o[1] - want[1]).max() <= 1e-6 and np.array_equal(o[2], want[2])
+    e = [r0.copy(), a0.copy(), c0.copy()]
+    emu.densify_update(N, P(cov), P(gm), P(mask), P(e[0]), P(e[1]), P(e[2]), None)
+    for a_, b_ in zip(e, o):
+        assert np.array_equal(a_, b_)
+    # halves of the update on their own, mask = NULL
+    e2 = [r0.copy(), a0.copy(), c0.copy()]
+    emu.densify_update(N, P(cov), None, None, P(e2[0]), None, None, None)
+    emu.densify_update(N, None, P(gm), None, None, P(e2[1]), None, None)
+    o2 = [r0.copy(), a0.copy(), c0.copy()]
+    O.densify_update(cov, gm, None, o2[0], o2[1], None)
+    assert np.array_equal(e2[0], o2[0]) and np.array_equal(e2[1], o2[1]) and np.array_equal(e2[2], c0)
+    with pytest.raises(Exception, match="invalid"):
+        emu.densify_update(N, P(cov), None, None, None, None, None, None)

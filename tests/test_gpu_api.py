@@ -141,6 +141,40 @@ def test_fused_frame_matches_oracle(C):
         assert float(P[k].grad[~buf.mask].abs().max()) == 0.0
 
 
+def test_densify_statistics_over_two_cameras():
+    """max_radii2d / mean2d-grad accumulation / cnt (gs/gaussian_splatting.py:1240-1245, :464-469)
+    updated inside render_frame, against the oracle's statements on the oracle's own geometry."""
+    from gsgen_amd import renderer as R
+    sc = scenes.random_scene(4000, seed=9, svec=0.03, C=2)
+    N = sc["mean"].shape[0]
+    Pm = {k: T_(sc[k]).requires_grad_(True) for k in ("mean", "qvec", "svec", "alpha", "sh")}
+    stats = R.DensifyStats(N, dev())
+    want = [np.zeros(N, np.float32) for _ in range(3)]
+    for az in (40.0, 200.0):
+        cam = scenes.Camera(160, 120, fx=150.0, c2w=scenes.orbit(2.4, 10, az))
+        ci = R.CameraInfo(*cam.intr)
+        buf = R.FrameBuffers(N, cam.w, cam.h, dev())
+        rgb, _ = R.render_frame(Pm["mean"], Pm["qvec"], Pm["svec"], Pm["alpha"], Pm["sh"], ci, cam.c2w, buf, C=2,
+                                stats=stats)
+        go = torch.randn_like(rgb)
+        (rgb * go).sum().backward()
+        g = scenes.oracle_geometry(sc, cam)
+        m = g["mask"]
+        assert np.array_equal(buf.mask.cpu().numpy(), m)
+        ref = O.render_sh_fwd(g["mean2d"], g["cov2d"], sc["sh"][m], sc["alpha"][m], g["start"], g["end"], g["ids"],
+                              cam.topleft, cam.c2w[:3, :3].reshape(-1), 2, 1 / cam.fx, 1 / cam.fy, cam.h, cam.w)
+        gm2 = O.render_sh_bwd(g["mean2d"], g["cov2d"], sc["sh"][m], sc["alpha"][m], g["start"], g["end"], g["ids"],
+                              ref, go.cpu().numpy(), cam.topleft, cam.c2w[:3, :3].reshape(-1), 2, 1 / cam.fx,
+                              1 / cam.fy, cam.h, cam.w)[0]
+        cov_full = np.zeros((N, 4), np.float32); cov_full[m] = g["cov2d"].reshape(-1, 4)
+        gm_full = np.zeros((N, 2), np.float32); gm_full[m] = gm2
+        O.densify_update(cov_full, gm_full, m, *want)
+    assert np.array_equal(stats.max_radii2d.cpu().numpy(), want[0])  # same fp32 expression, contraction off
+    assert np.array_equal(stats.cnt.cpu().numpy(), want[2])
+    assert rel_err(stats.grad_accum.cpu().numpy(), want[1]) < 2e-3
+    assert want[2].max() == 2.0 and want[2].min() == 0.0
+
+
 def test_full_size_cfg2():
     """BASELINE configs[1] (100k Gaussians, 800x800, SH degree 3) through the fused path:
     pair count and per-tile lists exact, image within 1e-4 of the oracle, per-tile lists
