@@ -1,0 +1,179 @@
+"""Batched-camera caller of the fused frame path.
+
+The reference renders the cameras of a batch strictly one after another in a Python loop and
+stacks the per-camera dicts (gs/gaussian_splatting.py:1423-1466).  One 800x800 frame of 100k
+Gaussians does not fill an MI355X (2.5k tiles on 256 CUs, each kernel ending on its longest
+tiles), so this caller keeps several cameras in flight instead: camera i is enqueued on HIP
+stream i % n_streams with its own FrameBuffers, all per-camera constants go up in ONE host to
+device copy, and nothing synchronises with the host.  The whole batch is ONE autograd node: its
+backward fans out over the same streams, and every camera adds atomically into one set of
+parameter gradients (compositing already accumulates; the projection backward runs in its
+accumulate form), so there is no per-camera zero-fill of the SH gradient (19 MB at 100k, C=4)
+and no B-way gradient sum afterwards.
+
+Every camera of the batch owns a FrameBuffers slot because its backward needs the lists and
+projected records of its forward (22 + 12 B x D_cap per slot; 64 cameras at cfg2 ~ 2 GB of the
+288 GB).
+"""
+import numpy as np
+import torch
+
+from . import _capi
+from . import renderer as R
+from .renderer import _p
+
+
+class _render_batch(torch.autograd.Function):
+    """(mean, qvec, svec, alpha, sh|color) -> rgb [B,H,W,3], T [B,H,W,1] for B cameras."""
+
+    @staticmethod
+    def forward(ctx, mean, qvec, svec, alpha, col, cams, br, B, C, bg_rgb, thresh, detach_depth, stats):
+        mean, qvec, svec = mean.contiguous(), qvec.contiguous(), svec.contiguous()
+        alpha, col = alpha.contiguous(), col.contiguous()
+        lib = _capi.load()
+        H, W, N, dev = br.H, br.W, br.N, mean.device
+        out = torch.zeros(B, H, W, 3, device=dev, dtype=torch.float32)
+        T = torch.ones(B, H, W, 1, device=dev, dtype=torch.float32)
+        cur = br._fork(B, (cams, out, T))
+        cams_p, out_p, T_p = cams.data_ptr(), out.data_ptr(), T.data_ptr()
+        with torch.cuda.device(dev):
+            for i in range(B):
+                buf, s, ci = br.slots[i], br.streams[i % len(br.streams)].cuda_stream, br._cis[i]
+                cam = cams_p + 272 * i  # row i: cam block | topleft at +56 floats | rotation at +58
+                psx, psy = 1.0 / ci.fx, 1.0 / ci.fy
+                lib.frame_geometry(N, _p(mean), _p(qvec), _p(svec), cam, W, H, buf.D_cap, _p(buf.mean2d),
+                                   _p(buf.cov2d), _p(buf.depth), _p(buf.mask), _p(buf.ids), _p(buf.start), _p(buf.end),
+                                   _p(buf.total), _p(buf.ws), buf.ws.numel(), s)
+                if stats is not None:
+                    lib.densify_update(N, _p(buf.cov2d), None, _p(buf.mask), _p(stats.max_radii2d), None, None, s)
+                if C > 0:
+                    lib.vol_render_sh_ordered(N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col), _p(alpha),
+                                              _p(buf.start), _p(buf.end), _p(buf.ids), out_p + 12 * H * W * i, cam + 224,
+                                              cam + 232, 16, buf.nth, buf.ntw, psx, psy, H, W, C, thresh,
+                                              _p(bg_rgb), T_p + 4 * H * W * i, buf.tile_order(), s)
+                else:
+                    lib.vol_render_start_end_with_T(N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col), _p(alpha),
+                                                    _p(buf.start), _p(buf.end), _p(buf.ids), out_p + 12 * H * W * i,
+                                                    cam + 224, 16, buf.nth, buf.ntw, psx, psy, H, W, thresh,
+                                                    T_p + 4 * H * W * i, s)
+        br._join(B, cur)
+        if C == 0 and bg_rgb is not None:
+            out = out + T * bg_rgb  # gs/renderer.py:1182
+        ctx.save_for_backward(mean, qvec, svec, alpha, col, cams, out)
+        ctx.br, ctx.B, ctx.C, ctx.thresh, ctx.detach, ctx.stats = br, B, C, thresh, detach_depth, stats
+        ctx.cis = list(br._cis[:B])
+        ctx.mark_non_differentiable(T)
+        return out, T
+
+    @staticmethod
+    def backward(ctx, grad, _gT):
+        mean, qvec, svec, alpha, col, cams, out = ctx.saved_tensors
+        br, B, C, thresh, stats = ctx.br, ctx.B, ctx.C, ctx.thresh, ctx.stats
+        lib = _capi.load()
+        H, W, N, dev = br.H, br.W, br.N, mean.device
+        grad = grad.contiguous()
+        g2d = torch.zeros(B, 6 * N, device=dev, dtype=torch.float32)  # per camera: mean2d | cov2d
+        g3d = torch.zeros(11 * N, device=dev, dtype=torch.float32)   # shared: mean | qvec | svec | alpha
+        g_mean, g_qvec = g3d[:3 * N].view(N, 3), g3d[3 * N:7 * N].view(N, 4)
+        g_svec, g_alpha = g3d[7 * N:10 * N].view(N, 3), g3d[10 * N:]
+        g_col = torch.zeros_like(col)
+        cur = br._fork(B, (grad, g2d, g3d, g_col))
+        cams_p, out_p, grad_p, g2d_p = cams.data_ptr(), out.data_ptr(), grad.data_ptr(), g2d.data_ptr()
+        with torch.cuda.device(dev):
+            for i in range(B):
+                buf, s, ci = br.slots[i], br.streams[i % len(br.streams)].cuda_stream, ctx.cis[i]
+                cam = cams_p + 272 * i
+                g_mean2d = g2d_p + 24 * N * i
+                g_cov2d = g_mean2d + 8 * N
+                psx, psy = 1.0 / ci.fx, 1.0 / ci.fy
+                if C > 0:
+                    lib.vol_render_backward_sh_ordered(N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col), _p(alpha),
+                                                       _p(buf.start), _p(buf.end), _p(buf.ids), out_p + 12 * H * W * i,
+                                                       g_mean2d, g_cov2d, _p(g_col), _p(g_alpha),
+                                                       grad_p + 12 * H * W * i, cam + 224, cam + 232, 16, buf.nth,
+                                                       buf.ntw, psx, psy, H, W, C, thresh, None, buf.tile_order(), s)
+                else:
+                    lib.vol_render_backward_start_end(N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col), _p(alpha),
+                                                      _p(buf.start), _p(buf.end), _p(buf.ids), out_p + 12 * H * W * i,
+                                                      g_mean2d, g_cov2d, _p(g_col), _p(g_alpha),
+                                                      grad_p + 12 * H * W * i, cam + 224, 16, buf.nth, buf.ntw, psx,
+                                                      psy, H, W, thresh, s)
+                lib.project_gaussians_backward_accum(N, _p(mean), _p(qvec), _p(svec), cam, int(ctx.detach),
+                                                     _p(buf.mask), g_mean2d, g_cov2d, None, _p(g_mean),
+                                                     _p(g_qvec), _p(g_svec), s)
+                if stats is not None:
+                    lib.densify_update(N, None, g_mean2d, _p(buf.mask), None, _p(stats.grad_accum),
+                                       _p(stats.cnt), s)
+        br._join(B, cur)
+        return (g_mean, g_qvec, g_svec, g_alpha, g_col) + (None,) * 8
+
+
+class BatchRenderer:
+    """Renders [B] cameras of one (W, H) shape for a fixed Gaussian count N."""
+
+    def __init__(self, N, W, H, device, max_batch, n_streams=3, D_cap=None):
+        self.N, self.W, self.H, self.device = N, W, H, torch.device(device)
+        self.slots = [R.FrameBuffers(N, W, H, device, D_cap=D_cap) for _ in range(max_batch)]
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(max(1, n_streams))]
+        # per camera: cam block (56) | topleft (2) | rotation rows (9) | pad -> 68 floats
+        self._host = torch.empty(max_batch, 68, dtype=torch.float32).pin_memory()
+        self._copied = None  # event: the last upload has left the pinned block
+        self._cis = []
+
+    def _upload(self, cam_infos, c2ws, frustum_radius, tile_radius):
+        B = len(cam_infos)
+        if self._copied is not None:
+            self._copied.synchronize()
+        h = self._host.numpy()
+        for i, (ci, c2w) in enumerate(zip(cam_infos, c2ws)):
+            c2w = np.asarray(c2w.detach().cpu() if isinstance(c2w, torch.Tensor) else c2w, np.float32).reshape(-1)[:12]
+            ci.pack_into(h[i], c2w, frustum_radius, tile_radius)
+            h[i, 56:58] = (-ci.cx / ci.fx, -ci.cy / ci.fy)
+            h[i, 58:67] = c2w.reshape(3, 4)[:, :3].reshape(-1)
+        # a fresh device block per batch: the rows are saved for the batch's backward
+        dev = self._host[:B].to(self.device, non_blocking=True)
+        self._copied = torch.cuda.Event()
+        self._copied.record(torch.cuda.current_stream(self.device))
+        return dev
+
+    def _fork(self, B, tensors):
+        """side streams wait for the current stream; `tensors` (allocated on the current stream)
+        are about to be used on them"""
+        cur = torch.cuda.current_stream(self.device)
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        for st in self.streams[:min(B, len(self.streams))]:
+            st.wait_event(ready)
+            for t in tensors:
+                t.record_stream(st)
+        return cur
+
+    def _join(self, B, cur):
+        for st in self.streams[:min(B, len(self.streams))]:
+            cur.wait_stream(st)
+
+    def render(self, mean, qvec, svec, alpha, col, cam_infos, c2ws, C=0, bg_rgb=None, thresh=1e-4,
+               frustum_radius=6.0, tile_radius=6.0, detach_depth=True, stats=None):
+        """-> (rgb [B,H,W,3], T [B,H,W,1]); differentiable wrt mean, qvec, svec, alpha, col.
+
+        cam_infos: B CameraInfo of this renderer's (W, H); c2ws: B poses [3,4] (arrays or tensors).
+        col is sh_coeffs [N,3,C*C] for C in 1..4, post-activation rgb [N,3] for C == 0.
+        """
+        B = len(cam_infos)
+        if B > len(self.slots):
+            raise ValueError(f"batch of {B} cameras, renderer was sized for {len(self.slots)}")
+        for ci in cam_infos:
+            if (ci.w, ci.h) != (self.W, self.H):
+                raise ValueError("every camera of a batch must have the renderer's (W, H)")
+        cams = self._upload(cam_infos, c2ws, frustum_radius, tile_radius)
+        self._cis = list(cam_infos)
+        return _render_batch.apply(mean, qvec, svec, alpha, col, cams, self, B, int(C), bg_rgb, float(thresh),
+                                   bool(detach_depth), stats)
+
+    def ensure_capacity(self, B=None):
+        """One host sync: grows any slot whose pair list overflowed in the last batch.  Returns
+        False if a slot had to grow (that camera's image was rendered empty: render again)."""
+        ok = True
+        for s in self.slots[:B]:
+            ok = s.ensure_capacity() and ok
+        return ok

@@ -139,7 +139,7 @@ k_project(uint32_t N, const float *__restrict__ mean, const float *__restrict__ 
 // Densification statistics of one rendered camera, rows aligned with the frustum mask
 // (gs/gaussian_splatting.py:1240-1245 and :464-469): the running maximum of the screen-space
 // "radius" m + sqrt(max(m^2 - det, 0)) (no outer sqrt on this path), the running sum of
-// |d L / d mean2d| and the visit count.  One pass, 29 B read + 12 B written per Gaussian.
+// |d L / d mean2d| and the visit count.  One pass, 25 B read + 3 atomics per visible Gaussian.
 __global__ void __launch_bounds__(kThreads)
 k_densify_update(uint32_t N, const float *__restrict__ cov2d, const float *__restrict__ g_mean2d,
                  const uint8_t *__restrict__ mask, float *__restrict__ max_radii2d,
@@ -152,18 +152,23 @@ k_densify_update(uint32_t N, const float *__restrict__ cov2d, const float *__res
     const float m = (c.x + c.w) / 2.0f;
     const float det = c.x * c.w - c.y * c.z;
     const float r = m + sqrtf(fmaxf(m * m - det, 0.0f));
-    max_radii2d[n] = fmaxf(max_radii2d[n], r);
+    // atomics: cameras of a batch run on concurrent streams and share the statistics arrays.
+    // Non-negative floats order like their bit patterns; a NaN radius sticks, as torch.max does.
+    if (!(r < 0.0f)) atomicMax(reinterpret_cast<unsigned int *>(max_radii2d) + n, __float_as_uint(r));
   }
   if (grad_accum != nullptr) {
     const float2 g = *reinterpret_cast<const float2 *>(g_mean2d + 2 * (size_t)n);
-    grad_accum[n] += sqrtf(g.x * g.x + g.y * g.y);
-    if (cnt != nullptr) cnt[n] += 1.0f;
+    atomicAdd(grad_accum + n, sqrtf(g.x * g.x + g.y * g.y));
+    if (cnt != nullptr) atomicAdd(cnt + n, 1.0f);
   }
 }
 
 // Backward of the projection as autograd differentiates gs/renderer.py:391-421: J is a
 // constant (@torch.no_grad), the depth in the perspective divide is detached iff
-// detach_depth.  Gradients are overwritten.
+// detach_depth.  ACC = false: gradients are overwritten (masked-out rows get zeros); ACC = true:
+// added atomically into caller-zeroed arrays shared by the cameras of a batch, which may run on
+// concurrent streams (masked-out rows are left alone).
+template <bool ACC>
 __global__ void __launch_bounds__(kThreads)
 k_project_bwd(uint32_t N, const float *__restrict__ mean, const float *__restrict__ qvec,
               const float *__restrict__ svec, const float *__restrict__ c2w, int detach_depth,
@@ -174,11 +179,17 @@ k_project_bwd(uint32_t N, const float *__restrict__ mean, const float *__restric
   if (n >= N) return;
   float *gm = g_mean + 3 * (size_t)n, *gq = g_qvec + 4 * (size_t)n, *gs_ = g_svec + 3 * (size_t)n;
   if (mask != nullptr && mask[n] == 0) {
-    gm[0] = gm[1] = gm[2] = 0.f;
-    gq[0] = gq[1] = gq[2] = gq[3] = 0.f;
-    gs_[0] = gs_[1] = gs_[2] = 0.f;
+    if constexpr (!ACC) {
+      gm[0] = gm[1] = gm[2] = 0.f;
+      gq[0] = gq[1] = gq[2] = gq[3] = 0.f;
+      gs_[0] = gs_[1] = gs_[2] = 0.f;
+    }
     return;
   }
+  auto put = [](float *dst, float v) {
+    if constexpr (ACC) atomicAdd(dst, v);
+    else *dst = v;
+  };
   float Rc[9], t[3];
   load_pose(c2w, Rc, t);
   const float *p = mean + 3 * (size_t)n, *q = qvec + 4 * (size_t)n, *s = svec + 3 * (size_t)n;
@@ -240,7 +251,7 @@ k_project_bwd(uint32_t N, const float *__restrict__ mean, const float *__restric
       acc += dM[i * 3 + j] * Rq[i * 3 + j];
       dR[i * 3 + j] = dM[i * 3 + j] * s[j];
     }
-    gs_[j] = acc;
+    put(gs_ + j, acc);
   }
   float dq[4];
   dq[0] = 2 * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]);
@@ -250,12 +261,12 @@ k_project_bwd(uint32_t N, const float *__restrict__ mean, const float *__restric
   const float qh[4] = {w, x, y, z};
   const float dot = qh[0] * dq[0] + qh[1] * dq[1] + qh[2] * dq[2] + qh[3] * dq[3];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) gq[k] = (dq[k] - qh[k] * dot) / nq;
+  for (int k = 0; k < 4; ++k) put(gq + k, (dq[k] - qh[k] * dot) / nq);
   const float gm0 = g_mean2d[2 * (size_t)n], gm1 = g_mean2d[2 * (size_t)n + 1];
   float du[3] = {gm0 * iz, gm1 * iz, g_depth != nullptr ? g_depth[n] : 0.0f};
   if (!detach_depth) du[2] += -(ux * gm0 + uy * gm1) * iz * iz;
 #pragma unroll
-  for (int j = 0; j < 3; ++j) gm[j] = Rc[j * 3] * du[0] + Rc[j * 3 + 1] * du[1] + Rc[j * 3 + 2] * du[2];
+  for (int j = 0; j < 3; ++j) put(gm + j, Rc[j * 3] * du[0] + Rc[j * 3 + 1] * du[1] + Rc[j * 3 + 2] * du[2]);
 }
 
 // ---- AABB -> tile rectangle -------------------------------------------------------------------
@@ -382,10 +393,76 @@ int gsgen_project_gaussians_backward_masked(uint32_t N, const float *mean, const
   if (N == 0) return 0;
   if (!mean || !qvec || !svec || !c2w || !g_mean2d || !g_cov2d || !g_mean || !g_qvec || !g_svec)
     return GSGEN_EINVAL;
-  hipLaunchKernelGGL(k_project_bwd, grid_for(N), dim3(kThreads), 0, (hipStream_t)stream, N, mean,
-                     qvec, svec, c2w, detach_depth, mask, g_mean2d, g_cov2d, g_depth, g_mean, g_qvec,
-                     g_svec);
+  hipLaunchKernelGGL(k_project_bwd<false>, grid_for(N), dim3(kThreads), 0, (hipStream_t)stream, N,
+                     mean, qvec, svec, c2w, detach_depth, mask, g_mean2d, g_cov2d, g_depth, g_mean,
+                     g_qvec, g_svec);
   return (int)hipGetLastError();
+}
+
+int gsgen_project_gaussians_backward_accum(uint32_t N, const float *mean, const float *qvec,
+                                           const float *svec, const float *c2w, int detach_depth,
+                                           const uint8_t *mask, const float *g_mean2d,
+                                           const float *g_cov2d, const float *g_depth,
+                                           float *g_mean, float *g_qvec, float *g_svec,
+                                           gsgen_stream_t stream) {
+  if (N == 0) return 0;
+  if (!mean || !qvec || !svec || !c2w || !g_mean2d || !g_cov2d || !g_mean || !g_qvec || !g_svec)
+    return GSGEN_EINVAL;
+  hipLaunchKernelGGL(k_project_bwd<true>, grid_for(N), dim3(kThreads), 0, (hipStream_t)stream, N,
+                     mean, qvec, svec, c2w, detach_depth, mask, g_mean2d, g_cov2d, g_depth, g_mean,
+                     g_qvec, g_svec);
+  return (int)hipGetLastError();
+}
+
+// Host side: the 56-float camera block of gsgen_frame_geometry.  Frustum planes as
+// utils/camera.py:225-226,260-294 builds them: scalars in double (python floats), rounded to
+// fp32 where they meet an fp32 tensor, every tensor op rounded to fp32 (this file is compiled
+// with -ffp-contract=off).
+int gsgen_pack_camera(const float *c2w, float fx, float fy, float cx, float cy, uint32_t w, uint32_t h,
+                      double near_plane, double far_plane, float frustum_radius, float tile_radius,
+                      float *cam) {
+  if (!c2w || !cam || w == 0 || h == 0) return GSGEN_EINVAL;
+  for (int i = 0; i < 56; ++i) cam[i] = 0.0f;
+  for (int i = 0; i < 12; ++i) cam[i] = c2w[i];
+  cam[12] = fx; cam[13] = fy; cam[14] = cx; cam[15] = cy;
+  cam[16] = frustum_radius; cam[17] = tile_radius;
+  const double yfov = 2.0 * atan((double)h / (2.0 * (double)fy));
+  const double aspect = (double)w / (double)h;
+  const double half_v_d = far_plane * tan(yfov * 0.5);
+  const float half_v = (float)half_v_d, half_h = (float)(half_v_d * aspect);
+  float up[3], right[3], look[3], t[3], nearp[3], farp[3];
+  for (int i = 0; i < 3; ++i) {
+    up[i] = -c2w[4 * i + 1]; right[i] = c2w[4 * i]; look[i] = c2w[4 * i + 2]; t[i] = c2w[4 * i + 3];
+    nearp[i] = (float)near_plane * look[i];
+    farp[i] = (float)far_plane * look[i];
+  }
+  auto cross = [](const float *a, const float *b, float *o) {
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+  };
+  float nrm[6][3], v[3];
+  for (int i = 0; i < 3; ++i) { nrm[0][i] = look[i]; nrm[1][i] = -look[i]; }
+  for (int i = 0; i < 3; ++i) v[i] = farp[i] - half_h * right[i];
+  cross(v, up, nrm[2]);
+  for (int i = 0; i < 3; ++i) v[i] = farp[i] + half_h * right[i];
+  cross(up, v, nrm[3]);
+  for (int i = 0; i < 3; ++i) v[i] = farp[i] + half_v * up[i];
+  cross(v, right, nrm[4]);
+  for (int i = 0; i < 3; ++i) v[i] = farp[i] - half_v * up[i];
+  cross(right, v, nrm[5]);
+  for (int k = 0; k < 6; ++k) {
+    const float xx = nrm[k][0] * nrm[k][0], yy = nrm[k][1] * nrm[k][1], zz = nrm[k][2] * nrm[k][2];
+    float len = sqrtf(xx + yy + zz);
+    len = len > 1e-12f ? len : 1e-12f;
+    for (int i = 0; i < 3; ++i) cam[20 + 3 * k + i] = nrm[k][i] / len;
+  }
+  for (int i = 0; i < 3; ++i) {
+    cam[38 + i] = nearp[i] + t[i];
+    cam[41 + i] = farp[i] + t[i];
+    for (int k = 2; k < 6; ++k) cam[38 + 3 * k + i] = t[i];
+  }
+  return 0;
 }
 
 int gsgen_project_gaussians_backward(uint32_t N, const float *mean, const float *qvec,

@@ -345,15 +345,16 @@ class CameraInfo:
 
     def pack(self, c2w, frustum_radius=6.0, tile_radius=6.0):
         """-> float32[56], the `cam` block of gsgen_frame_geometry (include/gsgen_hip.h)."""
-        c2w = np.asarray(c2w, np.float32).reshape(3, 4)
-        normals, pts = self.get_frustum(c2w)
-        cam = np.zeros(56, np.float32)
-        cam[:12] = c2w.reshape(-1)
-        cam[12:16] = (self.fx, self.fy, self.cx, self.cy)
-        cam[16], cam[17] = frustum_radius, tile_radius
-        cam[20:38] = normals.reshape(-1)
-        cam[38:56] = pts.reshape(-1)
+        cam = np.empty(56, np.float32)
+        self.pack_into(cam, c2w, frustum_radius, tile_radius)
         return cam
+
+    def pack_into(self, cam, c2w, frustum_radius=6.0, tile_radius=6.0):
+        """Fills a contiguous float32[>=56] host array in place (gsgen_pack_camera: the frustum of
+        get_frustum() computed by the library's host code, a few microseconds per camera)."""
+        c2w = np.ascontiguousarray(np.asarray(c2w, np.float32).reshape(-1)[:12])
+        _capi.load().pack_camera(c2w.ctypes.data, self.fx, self.fy, self.cx, self.cy, self.w, self.h,
+                                 self.near_plane, self.far_plane, frustum_radius, tile_radius, cam.ctypes.data)
 
 
 def n_tiles(H, W, tile_size=16):

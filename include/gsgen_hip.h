@@ -146,6 +146,15 @@ int gsgen_project_gaussians_backward_masked(uint32_t N, const float *mean, const
                                             const float *g_cov2d, const float *g_depth,
                                             float *g_mean, float *g_qvec, float *g_svec,
                                             gsgen_stream_t stream);
+/* Same, ADDED atomically into caller-zeroed g_mean/g_qvec/g_svec (masked-out rows untouched):
+ * the cameras of a batch accumulate into one set of parameter gradients, possibly from
+ * concurrent streams. */
+int gsgen_project_gaussians_backward_accum(uint32_t N, const float *mean, const float *qvec,
+                                           const float *svec, const float *c2w, int detach_depth,
+                                           const uint8_t *mask, const float *g_mean2d,
+                                           const float *g_cov2d, const float *g_depth,
+                                           float *g_mean, float *g_qvec, float *g_svec,
+                                           gsgen_stream_t stream);
 /* Densification statistics of one camera (gs/gaussian_splatting.py:1240-1245, :464-469), rows
  * aligned with mask [N] (NULL = all rows):
  *   max_radii2d[i] = max(max_radii2d[i], m + sqrt(max(m^2 - det(cov2d_i), 0))), m = tr/2
@@ -168,11 +177,16 @@ int gsgen_tile_culling_aabb_count(uint32_t N, const float *mean2d, const float *
  * `cam` (DEVICE, 56 floats): [0..11] c2w row-major 3x4; [12..15] fx, fy, cx, cy;
  * [16] frustum_culling_radius (<= 0: skip the cull); [17] tile_culling_radius (the reference's
  * D = 6.0); [18..19] spare; [20..37] frustum plane normals [6,3]; [38..55] plane points [6,3]
- * (both as utils/camera.py:260-294 computes them; gsgen_amd.camera packs this on the host).
+ * (both as utils/camera.py:260-294 computes them; gsgen_pack_camera fills the block on the host).
  * Culled Gaussians keep their index and emit no pairs.  gaussian_ids has capacity D_cap; the
  * true pair count is written to *total (device); if it exceeds D_cap nothing is binned,
  * start/end are all -1 and *total still holds the required size. */
 size_t gsgen_frame_workspace_bytes(uint32_t N, uint32_t D_cap, uint32_t n_tiles);
+/* HOST helper (no device work): fills cam[56] from a host c2w [3,4] and the CameraInfo fields
+ * (utils/camera.py:219-259; yfov = 2 atan(h / 2fy), aspect = w / h). */
+int gsgen_pack_camera(const float *c2w, float fx, float fy, float cx, float cy, uint32_t w, uint32_t h,
+                      double near_plane, double far_plane, float frustum_radius, float tile_radius,
+                      float *cam);
 int gsgen_frame_geometry(uint32_t N, const float *mean, const float *qvec, const float *svec,
                          const float *cam, uint32_t W, uint32_t H, uint32_t D_cap, float *mean2d,
                          float *cov2d, float *depth, uint8_t *mask, int *gaussian_ids, int *start,

@@ -72,6 +72,9 @@ def test_camera_pack_matches_oracle_frustum():
         assert np.array_equal(n, on) and np.array_equal(p, op)
         packed = ci.pack(cam.c2w)
         assert packed.shape == (56,) and np.array_equal(packed[20:38].reshape(6, 3), on)
+        assert np.array_equal(packed[38:56].reshape(6, 3), op)
+        assert np.array_equal(packed[:12], cam.c2w.reshape(-1)) and np.array_equal(packed[12:20], np.array(
+            [500.0, 510.0, 300.0, 250.0, 6.0, 6.0, 0, 0], np.float32))
 
 
 # ---- the HIP kernels on the CPU emulator ------------------------------------------------------
