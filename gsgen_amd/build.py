@@ -25,7 +25,7 @@ SOURCES = {
     "geometry.hip": ["-ffp-contract=off"],
     "binning.hip": [],
 }
-COMMON = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-Wall", "-Wno-unused-function"]
+COMMON = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-Wall", "-Wno-unused-function", f"-I{CSRC}"]
 
 
 def _newer(src, dst, extra=()):
@@ -33,6 +33,7 @@ def _newer(src, dst, extra=()):
         return True
     t = os.path.getmtime(dst)
     deps = [src, os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "composite_common.hpp"),
+            os.path.join(CSRC, "gsgen_mfma.hpp"),
             os.path.join(HERE, "..", "include", "gsgen_hip.h"), __file__, *extra]
     return any(os.path.getmtime(d) > t for d in deps)
 

@@ -25,26 +25,28 @@
 // backward share eval code, so the backward's recomputed prefix equals the forward bit for
 // bit (the invariant the reference asserts at vol_render_sh.h:452-454).
 #include "composite_common.hpp"
+#include <gsgen_mfma.hpp>
 
 namespace gs {
 
 // ---- LDS staging ---------------------------------------------------------------------------
-template <int MODE, int CB>
+template <int MODE, int CB, int KB = kBatch>
 struct Stage {
   using TR = Traits<MODE, CB>;
-  float mx[kBatch], my[kBatch], a[kBatch];
-  float c0[kBatch], c1[kBatch], c2[kBatch], c3[kBatch];
-  float p0[kBatch], p1[kBatch], p2[kBatch];  // RGB/scalar: scaled Cholesky factor; SH: p0 = kk, p1 = 1/det
-  int id[kBatch];
-  alignas(16) float col[kBatch * TR::NCOLP];
+  float mx[KB], my[KB], a[KB];
+  float c0[KB], c1[KB], c2[KB], c3[KB];
+  float p0[KB], p1[KB], p2[KB];  // RGB/scalar: scaled Cholesky factor; SH: p0 = kk, p1 = 1/det
+  int id[KB];
+  alignas(16) float col[KB * TR::NCOLP];
 };
 
-template <int MODE, int CB, int NT>
-__device__ __forceinline__ void stage_batch(Stage<MODE, CB> &S, const CompParams &p, int list_base,
+template <int MODE, int CB, int NT, int KB = kBatch>
+__device__ __forceinline__ void stage_batch(Stage<MODE, CB, KB> &S, const CompParams &p, int list_base,
                                             int nb) {
   using TR = Traits<MODE, CB>;
   const int t = (int)threadIdx.x;
-  if (t < kBatch) {
+  static_assert(KB <= NT, "one thread per staged record");
+  if (t < KB) {
     int id = 0;
     float mx = 0.f, my = 0.f, a = 0.f, c0 = 1.f, c1 = 0.f, c2 = 0.f, c3 = 1.f, p0 = 0.f, p1 = 0.f,
           p2 = 0.f;
@@ -85,8 +87,8 @@ __device__ __forceinline__ void stage_batch(Stage<MODE, CB> &S, const CompParams
 }
 
 // per-Gaussian values broadcast from LDS into registers
-template <int MODE, int CB>
-__device__ __forceinline__ GRec load_rec(const Stage<MODE, CB> &S, int g) {
+template <int MODE, int CB, int KB>
+__device__ __forceinline__ GRec load_rec(const Stage<MODE, CB, KB> &S, int g) {
   GRec r;
   r.mx = S.mx[g]; r.my = S.my[g]; r.a = S.a[g];
   r.c0 = S.c0[g]; r.c1 = S.c1[g]; r.c2 = S.c2[g]; r.c3 = S.c3[g];
@@ -162,6 +164,7 @@ __global__ void __launch_bounds__(256 / PPL) k_composite_fwd(CompParams p) {
       sh_basis<CB>(dx, dy, dz, *reinterpret_cast<float (*)[TR::CC]>(&Yf[0]));
 #pragma unroll
       for (int k = 0; k < TR::NPAIR; ++k) Yp[j][k] = v2f{Yf[2 * k], Yf[2 * k + 1]};
+      __builtin_amdgcn_sched_barrier(0);  // one pixel's temporaries at a time
     }
   }
 
@@ -188,7 +191,7 @@ __global__ void __launch_bounds__(256 / PPL) k_composite_fwd(CompParams p) {
       for (int j = 0; j < PPL; ++j) any_alive |= alive[j];
       if (__ballot(any_alive) == 0ull) break;  // this wave's 64*PPL pixels are saturated
 
-      const GRec r = load_rec<MODE, CB>(S, g);
+      const GRec r = load_rec(S, g);
       const float x = px - r.mx;
       float G[PPL];
       bool con[PPL];
@@ -357,7 +360,7 @@ __global__ void __launch_bounds__(256 / PPL) k_composite_bwd_pixel(CompParams p)
       for (int j = 0; j < PPL; ++j) any_alive |= alive[j];
       if (__ballot(any_alive) == 0ull) break;
 
-      const GRec r = load_rec<MODE, CB>(S, g);
+      const GRec r = load_rec(S, g);
       const float x = px - r.mx;
       float G[PPL];
       bool con[PPL];
@@ -476,6 +479,299 @@ __global__ void __launch_bounds__(256 / PPL) k_composite_bwd_pixel(CompParams p)
   }
 }
 
+
+// ============================================================================================
+// backward, SH, matrix-core form
+// ============================================================================================
+// d L / d sh[g][c][b] = sum over the tile's pixels of gs[pixel][g,c] * Y[pixel][b]: a contraction
+// over pixels of a per-(Gaussian, channel) scalar with the tile's FIXED per-pixel basis table,
+// i.e. a [rows = (g,c)] x [K = 256 pixels] x [16 basis] matrix product.  k_composite_bwd_pixel
+// does it as 48 FMAs per pixel plus a 48-component cross-lane reduction per Gaussian (~40 % of
+// that kernel's VALU time); here the lanes only produce the 3 scalars gs[.][g,c] per pixel, stage
+// them in LDS as split bf16 (x = hi + lo, both round-to-nearest: 2^-17 relative), and one
+// v_mfma_f32_16x16x32_bf16 chain per kNF Gaussians contracts them with Y (held in registers in
+// B-operand layout for the whole tile) with fp32 accumulation: hi*hi + hi*lo + lo*hi.  The
+// remaining 7 components (mean2d, cov2d, alpha) go through an 8-wide reduce-scatter.
+// One wavefront per tile, 4 pixels per lane; K index of pixel j of lane p is 4 p + j.
+constexpr int kNF = 3;                 // Gaussians per matrix flush (3 rows each, 16-row MFMA)
+constexpr int kKBm = 32;               // staged records per LDS round in this kernel
+constexpr int kRowDw = 132;            // dwords per staged row: 256 pixels x bf16 + one 16-byte pad
+
+// The pad staggers consecutive rows by one 16-byte bank group, so the 16 rows an MFMA operand read
+// touches at one k offset are conflict-free, the 64 8-byte writes of one row are contiguous, and
+// every address is (lane-dependent base) + (compile-time offset).
+__device__ __forceinline__ void stage_split4(uint32_t *hi, uint32_t *lo, int row, int lane, const float (&v)[4]) {
+  const uint32_t h0 = pack_bf16x2(v[0], v[1]), h1 = pack_bf16x2(v[2], v[3]);
+  const float r0 = v[0] - __uint_as_float(h0 << 16), r1 = v[1] - __uint_as_float(h0 & 0xffff0000u);
+  const float r2 = v[2] - __uint_as_float(h1 << 16), r3 = v[3] - __uint_as_float(h1 & 0xffff0000u);
+  const int dw = row * kRowDw + 2 * lane;
+  *reinterpret_cast<uint2 *>(hi + dw) = make_uint2(h0, h1);
+  *reinterpret_cast<uint2 *>(lo + dw) = make_uint2(pack_bf16x2(r0, r1), pack_bf16x2(r2, r3));
+}
+// operand fragment of lane `lane` for k-step s: row `row`, pixels 32 s + 8 (lane >> 4) .. + 8
+__device__ __forceinline__ int frag_dw(int row, int lane, int s) { return row * kRowDw + 4 * (lane >> 4) + 16 * s; }
+
+template <int CB>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
+k_composite_bwd_sh_mfma(CompParams p) {
+  constexpr int MODE = MODE_SH;
+  using TR = Traits<MODE, CB>;
+  constexpr int NT = 64, PPL = 4, ROWS = 4, NCH = 3;
+  constexpr int NROW = kNF * 3;
+  __shared__ Stage<MODE, CB, kKBm> S;
+  __shared__ alignas(16) uint32_t Ahi[NROW * kRowDw];
+  __shared__ alignas(16) uint32_t Alo[NROW * kRowDw];
+  __shared__ int fid[kNF];
+  __shared__ alignas(16) float Go[64 * 12];  // grad_out of the lane's 4 pixels x 3 channels
+  static_assert(NROW >= 8 && kNF <= 4, "basis table is transposed through the A buffers 8 rows at a time");
+
+  int tx, ty;
+  if (!block_tile(p, tx, ty)) return;
+  const int tile = ty * p.ntw + tx;
+  const int st = p.start[tile];
+  const int n = (st < 0) ? 0 : (p.end[tile] - st);
+  if (n <= 0 || n < p.n_lo || n >= p.n_hi) return;
+  const int t = (int)threadIdx.x;
+  const int lane = t;
+  const int lx = t & 15, ly0 = t >> 4;
+  const int gx = tx * kTile + lx;
+
+  bool valid[PPL];
+  int gy[PPL];
+  float py[PPL];
+  const float px = pixel_coord(p.topleft[0], gx, p.psx);
+#pragma unroll
+  for (int j = 0; j < PPL; ++j) {
+    gy[j] = ty * kTile + ly0 + j * ROWS;
+    valid[j] = (gx < p.W) && (gy[j] < p.H);
+    py[j] = pixel_coord(p.topleft[1], gy[j], p.psy);
+  }
+
+  const int gy0 = ty * kTile + ly0;
+  if constexpr (TR::CCP != TR::CC) {
+    for (int e = t; e < kKBm * TR::NCOLP; e += NT) S.col[e] = 0.0f;
+  }
+  // per-pixel SH basis, twice: Bh/Bl = the table in B-operand layout (lane l: basis l & 15, 8
+  // consecutive k per 32-pixel step), split in bf16, transposed through the A staging rows; Yp =
+  // the lane's own pixels in fp32 for the colour evaluation.  The two are built one after the
+  // other from separate evaluations so that their temporaries are never live together.
+  float R[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) R[i] = p.rot[i];
+  auto basis_of_pixel = [&](float qx, float qy, float (&Y)[16]) {
+    float dx = R[0] * qx + R[1] * qy + R[2];
+    float dy = R[3] * qx + R[4] * qy + R[5];
+    float dz = R[6] * qx + R[7] * qy + R[8];
+    const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+    dx /= len; dy /= len; dz /= len;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) Y[k] = 0.0f;
+    sh_basis<CB>(dx, dy, dz, *reinterpret_cast<float (*)[TR::CC]>(&Y[0]));
+  };
+  uint4 Bh[8], Bl[8];
+  {
+    float Yf[PPL][16];
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) basis_of_pixel(px, py[j], Yf[j]);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      if (half * 8 < TR::CC) {
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+          const float v[4] = {Yf[0][half * 8 + b], Yf[1][half * 8 + b], Yf[2][half * 8 + b], Yf[3][half * 8 + b]};
+          stage_split4(Ahi, Alo, b, lane, v);
+        }
+      }
+      __syncthreads();
+      if (((lane & 15) >> 3) == half) {
+        const int b = lane & 7;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          if (half * 8 + b < TR::CC) {
+            const int dw = frag_dw(b, lane, s);
+            Bh[s] = *reinterpret_cast<const uint4 *>(Ahi + dw);
+            Bl[s] = *reinterpret_cast<const uint4 *>(Alo + dw);
+          } else {
+            Bh[s] = uint4{0u, 0u, 0u, 0u};
+            Bl[s] = uint4{0u, 0u, 0u, 0u};
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  v2f Yp[PPL][TR::NPAIR];
+  {
+    float pxo = px;
+    pxo = opaque(pxo);  // a second evaluation, not a second live copy of the first
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) {
+      float Yf[16];
+      basis_of_pixel(pxo, py[j], Yf);
+#pragma unroll
+      for (int k = 0; k < TR::NPAIR; ++k) Yp[j][k] = v2f{Yf[2 * k], Yf[2 * k + 1]};
+    }
+  }
+
+  // rem = final - (prefix colour including the current splat): the suffix the reference forms as
+  // final - Cpre_incl (vol_render_sh.h:328-333), carried as one running value per channel
+  float rem[PPL][NCH], Tr[PPL];
+  bool alive[PPL];
+#pragma unroll
+  for (int j = 0; j < PPL; ++j) {
+    const size_t pix = valid[j] ? ((size_t)gy[j] * p.W + gx) : 0;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      Go[lane * 12 + c * 4 + j] = valid[j] ? p.grad_out[NCH * pix + c] : 0.0f;
+      rem[j][c] = valid[j] ? p.final_img[NCH * pix + c] : 0.0f;
+    }
+    Tr[j] = 1.0f;
+    alive[j] = valid[j];
+  }
+
+  int nst = 0;  // Gaussians staged since the last flush (wave-uniform)
+  // contracts the staged rows with the basis table and adds the result to grad_sh
+  // MFMA row 4 * slot + c holds (staged Gaussian slot, channel c); it lives in LDS row 3 * slot + c.
+  // Lane l then receives slot l >> 4, channel r in accumulator element r, basis l & 15.
+  const int arow = 3 * ((lane & 15) >> 2) + (((lane & 3) < 3) ? (lane & 3) : 0);  // c == 3: unused row
+  const int a_dw = frag_dw(arow < NROW ? arow : 0, lane, 0);
+  auto flush = [&]() {
+    __syncthreads();
+    f32x4 acc0 = f32x4_zero(), acc1 = f32x4_zero(), acc2 = f32x4_zero();
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const uint4 ah = *reinterpret_cast<const uint4 *>(Ahi + a_dw + 16 * s);
+      const uint4 al = *reinterpret_cast<const uint4 *>(Alo + a_dw + 16 * s);
+      acc0 = mfma_16x16x32_bf16(ah, Bh[s], acc0);
+      acc1 = mfma_16x16x32_bf16(ah, Bl[s], acc1);
+      acc2 = mfma_16x16x32_bf16(al, Bh[s], acc2);
+      // Keep every k-step's "two LDS reads, wait, three in-place MFMAs" together.  Left free, the
+      // ROCm 7.2 scheduler renames the accumulators (SrcC != vDst) and lets the next step's
+      // ds_read_b128 land in a register a queued MFMA still reads as SrcC; with a second wave
+      // feeding the same matrix core that corrupted accumulators AND registers the allocator had
+      // already handed to loop state (profiles/r01_notes.md, "MFMA chain hazard").
+      mfma_step_fence(acc0, acc1, acc2);
+    }
+    const int slot = lane >> 4, b = lane & 15;
+    if (slot < nst && b < TR::CC) {
+      float *dst = p.g_col + (size_t)TR::NCOL * (size_t)fid[slot < kNF ? slot : 0] + b;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) atomicAdd(dst + c * TR::CC, (acc0[c] + acc1[c]) + acc2[c]);
+    }
+    __syncthreads();
+    nst = 0;
+  };
+
+  for (int base = 0; base < n; base += kKBm) {
+    const int nb = min(kKBm, n - base);
+    if (base > 0) __syncthreads();
+    stage_batch<MODE, CB, NT, kKBm>(S, p, st + base, nb);
+    __syncthreads();
+
+    for (int g = 0; g < nb; ++g) {
+      bool any_alive = false;
+#pragma unroll
+      for (int j = 0; j < PPL; ++j) any_alive |= alive[j];
+      if (__ballot(any_alive) == 0ull) break;
+
+      // wave-uniform record: keep it in scalar registers (the vector file is the tight resource)
+      GRec r = load_rec(S, g);
+      auto uni = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+      r.mx = uni(r.mx); r.my = uni(r.my); r.a = uni(r.a);
+      r.c0 = uni(r.c0); r.c1 = uni(r.c1); r.c2 = uni(r.c2); r.c3 = uni(r.c3);
+      r.p0 = uni(r.p0); r.p1 = uni(r.p1); r.p2 = uni(r.p2);
+      const float x = px - r.mx;
+      // registers are the tight resource here: the pixel rows are re-derived (3 ops) rather than
+      // kept, and a*G is carried instead of G (d/d alpha = sum(pAG * G) = sum(pAG * a*G) / a)
+      float ag[PPL], yq[PPL];
+      bool con[PPL];
+      bool any_con = false;
+#pragma unroll
+      for (int j = 0; j < PPL; ++j) {
+        const float pyj = pixel_coord(p.topleft[1], gy0 + j * ROWS, p.psy);
+        yq[j] = pyj - r.my;
+        const float G = gauss_eval<MODE>(r, x, yq[j], px, pyj, alive[j]);
+        ag[j] = r.a * G;
+        con[j] = alive[j] && !(ag[j] < kMinAlpha);
+        any_con |= con[j];
+      }
+      if (__ballot(any_con) == 0ull) continue;
+
+      const float inv_det = r.p1;
+      const float *cg = &S.col[g * TR::NCOLP];
+      float pAG[PPL], w[PPL], inv1m[PPL];
+#pragma unroll
+      for (int j = 0; j < PPL; ++j) {
+        w[j] = con[j] ? ag[j] * Tr[j] : 0.0f;
+        inv1m[j] = __builtin_amdgcn_rcpf(1.0f - ag[j]);
+        pAG[j] = 0.0f;
+      }
+      if (lane == 0) fid[nst] = S.id[g];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        v2f q[TR::NPAIR];
+#pragma unroll
+        for (int k = 0; k < TR::NPAIR; ++k) q[k] = *reinterpret_cast<const v2f *>(cg + c * TR::CCP + 2 * k);
+        float gsv[PPL];
+        const float4 go4 = *reinterpret_cast<const float4 *>(&Go[lane * 12 + c * 4]);  // lane-private
+        const float go[PPL] = {go4.x, go4.y, go4.z, go4.w};
+#pragma unroll
+        for (int j = 0; j < PPL; ++j) {
+          v2f s2 = q[0] * Yp[j][0];
+#pragma unroll
+          for (int k = 1; k < TR::NPAIR; ++k) s2 = fma2(q[k], Yp[j][k], s2);
+          const float yv = sigmoid_fast(s2[0] + s2[1]);
+          rem[j][c] -= w[j] * yv;
+          gsv[j] = w[j] * (yv * (1.0f - yv)) * go[j];
+          pAG[j] += go[j] * (yv * Tr[j] - rem[j][c] * inv1m[j]);
+        }
+        stage_split4(Ahi, Alo, 3 * nst + c, lane, gsv);
+        __builtin_amdgcn_sched_barrier(0);  // keep the next channel's coefficient loads out of this one
+      }
+      // mean2d (2) | cov2d (4) | alpha (1): kernel_gaussian_2d_backward (kernels.h:394-418)
+      float gr[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) gr[i] = 0.0f;
+#pragma unroll
+      for (int j = 0; j < PPL; ++j) {
+        const float pa = con[j] ? pAG[j] : 0.0f;
+        const float y = yq[j];
+        const float gg = pa * ag[j];
+        const float vx = (x * r.c3 - y * r.c2) * inv_det;
+        const float vy = (y * r.c0 - x * r.c1) * inv_det;
+        gr[0] += gg * vx;
+        gr[1] += gg * vy;
+        const float h = 0.5f * gg;
+        gr[2] += h * vx * vx;
+        gr[3] += h * vx * vy;
+        gr[5] += h * vy * vy;
+        gr[6] += gg;
+        const float om = con[j] ? (1.0f - ag[j]) : 1.0f;
+        Tr[j] *= om;
+        alive[j] = alive[j] && !(Tr[j] < p.thresh);
+      }
+      gr[4] = gr[3];
+      gr[6] = gr[6] / r.a;  // a contributing splat has a >= 1/255
+      wave_reduce_scatter<8>(gr);
+      const int comp = scatter_comp<8>(lane);
+      if (scatter_owner<8>(lane) && comp < 7) {
+        const size_t id = (size_t)S.id[g];
+        float *dst;
+        if (comp < 2) dst = p.g_mean + 2 * id + comp;
+        else if (comp < 6) dst = p.g_cov + 4 * id + (comp - 2);
+        else dst = p.g_alpha + id;
+        atomicAdd(dst, gr[0]);
+      }
+      if (++nst == kNF) flush();
+    }
+    bool any_alive = false;
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) any_alive |= alive[j];
+    if (__syncthreads_or((int)any_alive) == 0) break;
+  }
+  if (nst > 0) flush();
+}
+
 // ---- launch helpers ---------------------------------------------------------------------------
 // Pixels per lane: 4 = one wavefront per tile (north_star design), 2 / 1 = two / four
 // wavefronts per tile sharing the staged records.  Defaults chosen by measurement on MI355X
@@ -500,6 +796,14 @@ static int launch_bwd(const CompParams &p_, hipStream_t s) {
   if (p.n_hi == 0) p.n_hi = 0x7fffffff;
   const uint32_t nblk = comp_grid(p);
   if (p.ntw * p.nth == 0) return 0;
+  // GSGEN_BWD_MFMA=0 keeps the SH gradient contraction on the vector ALUs (A/B runs)
+  static const bool mfma = !(getenv("GSGEN_BWD_MFMA") && getenv("GSGEN_BWD_MFMA")[0] == '0');
+  if constexpr (MODE == MODE_SH) {
+    if (ppl == 4 && mfma) {
+      hipLaunchKernelGGL((k_composite_bwd_sh_mfma<CB>), dim3(nblk), dim3(64), 0, s, p);
+      return (int)hipGetLastError();
+    }
+  }
   if (ppl == 1) hipLaunchKernelGGL((k_composite_bwd_pixel<MODE, CB, 1>), dim3(nblk), dim3(256), 0, s, p);
   else if (ppl == 2) hipLaunchKernelGGL((k_composite_bwd_pixel<MODE, CB, 2>), dim3(nblk), dim3(128), 0, s, p);
   else hipLaunchKernelGGL((k_composite_bwd_pixel<MODE, CB, 4>), dim3(nblk), dim3(64), 0, s, p);

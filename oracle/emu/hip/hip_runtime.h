@@ -36,6 +36,9 @@ inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { std::m
 struct float2 { float x, y; };
 struct alignas(16) float4 { float x, y, z, w; };
 struct int2 { int x, y; };
+struct alignas(8) uint2 { unsigned x, y; };
+struct alignas(16) uint4 { unsigned x, y, z, w; };
+inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 inline float2 make_float2(float x, float y) { return float2{x, y}; }
 inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 inline int2 make_int2(int x, int y) { return int2{x, y}; }
@@ -104,6 +107,7 @@ inline int emu_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mas
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) emu_update_dpp((old), (src), (ctrl), (rm), (bm), (bc))
 
 #define __builtin_amdgcn_readfirstlane(v) (v)
+#define __builtin_amdgcn_sched_barrier(m) ((void)0)
 #define __builtin_amdgcn_readlane(v, l) simt::shfl_idx((int)(v), (l))
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))

@@ -301,3 +301,35 @@ def test_densify_statistics_oracle_vs_torch_and_emulated_kernel(emu):
     assert np.array_equal(e2[0], o2[0]) and np.array_equal(e2[1], o2[1]) and np.array_equal(e2[2], c0)
     with pytest.raises(Exception, match="invalid"):
         emu.densify_update(N, P(cov), None, None, None, None, None, None)
+
+
+def test_emulated_projection_backward_overwrite_masked_and_accumulate(emu):
+    """the three forms of the projection backward against the oracle: overwrite, masked (zeros on
+    culled rows) and atomic accumulate over two cameras into shared gradients"""
+    sc = scenes.random_scene(400, seed=21, svec=0.05)
+    N = sc["mean"].shape[0]
+    mean, q, s = (np.ascontiguousarray(sc[k]) for k in ("mean", "qvec", "svec"))
+    rng = np.random.default_rng(3)
+    tot = [np.zeros((N, 3), np.float32), np.zeros((N, 4), np.float32), np.zeros((N, 3), np.float32)]
+    want = [np.zeros((N, 3), np.float64), np.zeros((N, 4), np.float64), np.zeros((N, 3), np.float64)]
+    for az, detach in ((20.0, 1), (140.0, 0)):
+        c2w = np.ascontiguousarray(scenes.orbit(2.5, 10, az))
+        gm2 = rng.normal(size=(N, 2)).astype(np.float32); gc2 = rng.normal(size=(N, 4)).astype(np.float32)
+        mask = (rng.random(N) < 0.6).astype(np.uint8)
+        om, oq, os_ = O.project_bwd(mean, q, s, c2w, gm2, gc2.reshape(N, 2, 2), None, bool(detach))
+        a = [np.full((N, 3), 7, np.float32), np.full((N, 4), 7, np.float32), np.full((N, 3), 7, np.float32)]
+        emu.project_gaussians_backward(N, P(mean), P(q), P(s), P(c2w), detach, P(gm2), P(gc2), None, P(a[0]), P(a[1]),
+                                       P(a[2]), None)
+        for x, y in zip(a, (om, oq, os_)):  # the oracle accumulates the chain rule in another order
+            assert np.abs(x - y).max() <= 2e-6 * np.abs(y).max()
+        b = [np.full((N, 3), 7, np.float32), np.full((N, 4), 7, np.float32), np.full((N, 3), 7, np.float32)]
+        emu.project_gaussians_backward_masked(N, P(mean), P(q), P(s), P(c2w), detach, P(mask), P(gm2), P(gc2), None,
+                                              P(b[0]), P(b[1]), P(b[2]), None)
+        for x, y in zip(b, a):
+            assert np.array_equal(x[mask == 1], y[mask == 1]) and not x[mask == 0].any()
+        emu.project_gaussians_backward_accum(N, P(mean), P(q), P(s), P(c2w), detach, P(mask), P(gm2), P(gc2), None,
+                                             P(tot[0]), P(tot[1]), P(tot[2]), None)
+        for w_, y in zip(want, a):
+            w_[mask == 1] += y[mask == 1]
+    for x, w_ in zip(tot, want):
+        assert np.abs(x - w_).max() <= 1e-6 * np.abs(w_).max()

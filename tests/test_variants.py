@@ -1,6 +1,6 @@
 """The compositing kernels exist in several compiled variants selected by environment variables
 read once per process (pixels per lane of the forward / backward, pixel-parallel vs splat-parallel
-backward).  Only one combination is the default; these tests run the parity suite in a
+backward, matrix-core vs vector SH gradient contraction).  Only one combination is the default; these tests run the parity suite in a
 subprocess for the others so that none of them rots.  CPU: on the SIMT emulator; GPU: on the
 real library."""
 import os
@@ -16,6 +16,7 @@ VARIANTS = [
     {"GSGEN_PPL_FWD": "4", "GSGEN_PPL_BWD": "2"},
     {"GSGEN_PPL_FWD": "2", "GSGEN_PPL_BWD": "1"},
     {"GSGEN_BWD_SPLIT": "40"},
+    {"GSGEN_BWD_MFMA": "0"},  # SH gradient contraction on the vector ALUs instead of the matrix cores
 ]
 
 
