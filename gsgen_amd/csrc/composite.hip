@@ -495,35 +495,65 @@ __global__ void __launch_bounds__(256 / PPL) k_composite_bwd_pixel(CompParams p)
 // One wavefront per tile, 4 pixels per lane; K index of pixel j of lane p is 4 p + j.
 constexpr int kNF = 3;                 // Gaussians per matrix flush (3 rows each, 16-row MFMA)
 constexpr int kKBm = 32;               // staged records per LDS round in this kernel
-constexpr int kRowDw = 132;            // dwords per staged row: 256 pixels x bf16 + one 16-byte pad
 
-// The pad staggers consecutive rows by one 16-byte bank group, so the 16 rows an MFMA operand read
-// touches at one k offset are conflict-free, the 64 8-byte writes of one row are contiguous, and
-// every address is (lane-dependent base) + (compile-time offset).
-__device__ __forceinline__ void stage_split4(uint32_t *hi, uint32_t *lo, int row, int lane, const float (&v)[4]) {
-  const uint32_t h0 = pack_bf16x2(v[0], v[1]), h1 = pack_bf16x2(v[2], v[3]);
-  const float r0 = v[0] - __uint_as_float(h0 << 16), r1 = v[1] - __uint_as_float(h0 & 0xffff0000u);
-  const float r2 = v[2] - __uint_as_float(h1 << 16), r3 = v[3] - __uint_as_float(h1 & 0xffff0000u);
-  const int dw = row * kRowDw + 2 * lane;
-  *reinterpret_cast<uint2 *>(hi + dw) = make_uint2(h0, h1);
-  *reinterpret_cast<uint2 *>(lo + dw) = make_uint2(pack_bf16x2(r0, r1), pack_bf16x2(r2, r3));
+// Staged rows: 64 * PPL pixels x bf16 plus one 16-byte pad.  The pad staggers consecutive rows by
+// one bank group, so the 16 rows an MFMA operand read touches at one k offset are conflict-free,
+// the 64 writes of one row are contiguous, and every address is (lane base) + (immediate).
+template <int PPL>
+struct MfmaCfg {
+  static constexpr int ROW_DW = 32 * PPL + 4;  // dwords per row
+  static constexpr int KSTEPS = 2 * PPL;       // 32 pixels per MFMA k-step
+  static constexpr int NW = 4 / PPL;           // wavefronts per tile
+};
+
+// lane `lane` owns pixels k = PPL * lane .. + PPL of its wavefront's K range
+template <int PPL>
+__device__ __forceinline__ void stage_split(uint32_t *hi, uint32_t *lo, int row, int lane, const float (&v)[PPL]) {
+  if constexpr (PPL == 1) {
+    const uint32_t h = pack_bf16x2(v[0], 0.0f);
+    const float r = v[0] - __uint_as_float(h << 16);
+    const int hw = 2 * row * MfmaCfg<PPL>::ROW_DW + lane;  // halfword index
+    reinterpret_cast<uint16_t *>(hi)[hw] = (uint16_t)h;
+    reinterpret_cast<uint16_t *>(lo)[hw] = (uint16_t)pack_bf16x2(r, 0.0f);
+    return;
+  }
+  constexpr int J1 = PPL > 1 ? 1 : 0;  // (keeps the PPL == 1 instantiation well-formed)
+  const int dw = row * MfmaCfg<PPL>::ROW_DW + (PPL / 2) * lane;
+  const uint32_t h0 = pack_bf16x2(v[0], v[J1]);
+  const float r0 = v[0] - __uint_as_float(h0 << 16), r1 = v[J1] - __uint_as_float(h0 & 0xffff0000u);
+  if constexpr (PPL == 4) {
+    const uint32_t h1 = pack_bf16x2(v[2], v[3]);
+    const float r2 = v[2] - __uint_as_float(h1 << 16), r3 = v[3] - __uint_as_float(h1 & 0xffff0000u);
+    *reinterpret_cast<uint2 *>(hi + dw) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2 *>(lo + dw) = make_uint2(pack_bf16x2(r0, r1), pack_bf16x2(r2, r3));
+  } else {
+    hi[dw] = h0;
+    lo[dw] = pack_bf16x2(r0, r1);
+  }
 }
 // operand fragment of lane `lane` for k-step s: row `row`, pixels 32 s + 8 (lane >> 4) .. + 8
-__device__ __forceinline__ int frag_dw(int row, int lane, int s) { return row * kRowDw + 4 * (lane >> 4) + 16 * s; }
+template <int PPL>
+__device__ __forceinline__ int frag_dw(int row, int lane, int s) {
+  return row * MfmaCfg<PPL>::ROW_DW + 4 * (lane >> 4) + 16 * s;
+}
 
-template <int CB>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
+// PPL = 4: one wavefront per tile.  PPL = 2: two wavefronts per tile, each contracting its own 128
+// pixels (the partial sums meet in the atomics); the records are staged once for both.
+template <int CB, int PPL>
+__global__ void __launch_bounds__(256 / PPL) __attribute__((amdgpu_waves_per_eu(2)))
 k_composite_bwd_sh_mfma(CompParams p) {
   constexpr int MODE = MODE_SH;
   using TR = Traits<MODE, CB>;
-  constexpr int NT = 64, PPL = 4, ROWS = 4, NCH = 3;
+  using MC = MfmaCfg<PPL>;
+  constexpr int NT = 256 / PPL, ROWS = NT / 16, NCH = 3, NW = MC::NW, KS = MC::KSTEPS;
   constexpr int NROW = kNF * 3;
-  __shared__ Stage<MODE, CB, kKBm> S;
-  __shared__ alignas(16) uint32_t Ahi[NROW * kRowDw];
-  __shared__ alignas(16) uint32_t Alo[NROW * kRowDw];
-  __shared__ int fid[kNF];
-  __shared__ alignas(16) float Go[64 * 12];  // grad_out of the lane's 4 pixels x 3 channels
+  static_assert(PPL == 4 || PPL == 2 || PPL == 1, "one, two or four wavefronts per tile");
   static_assert(NROW >= 8 && kNF <= 4, "basis table is transposed through the A buffers 8 rows at a time");
+  __shared__ Stage<MODE, CB, kKBm> S;
+  __shared__ alignas(16) uint32_t Ahi_[NW][NROW * MC::ROW_DW];
+  __shared__ alignas(16) uint32_t Alo_[NW][NROW * MC::ROW_DW];
+  __shared__ int fid_[NW][4];
+  __shared__ alignas(16) float Go[NT * 3 * PPL];  // grad_out of the lane's PPL pixels x 3 channels
 
   int tx, ty;
   if (!block_tile(p, tx, ty)) return;
@@ -532,7 +562,10 @@ k_composite_bwd_sh_mfma(CompParams p) {
   const int n = (st < 0) ? 0 : (p.end[tile] - st);
   if (n <= 0 || n < p.n_lo || n >= p.n_hi) return;
   const int t = (int)threadIdx.x;
-  const int lane = t;
+  const int lane = t & 63, wv = t >> 6;
+  uint32_t *const Ahi = Ahi_[wv];
+  uint32_t *const Alo = Alo_[wv];
+  int *const fid = fid_[wv];
   const int lx = t & 15, ly0 = t >> 4;
   const int gx = tx * kTile + lx;
 
@@ -568,7 +601,7 @@ k_composite_bwd_sh_mfma(CompParams p) {
     for (int k = 0; k < 16; ++k) Y[k] = 0.0f;
     sh_basis<CB>(dx, dy, dz, *reinterpret_cast<float (*)[TR::CC]>(&Y[0]));
   };
-  uint4 Bh[8], Bl[8];
+  uint4 Bh[KS], Bl[KS];
   {
     float Yf[PPL][16];
 #pragma unroll
@@ -578,17 +611,19 @@ k_composite_bwd_sh_mfma(CompParams p) {
       if (half * 8 < TR::CC) {
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
-          const float v[4] = {Yf[0][half * 8 + b], Yf[1][half * 8 + b], Yf[2][half * 8 + b], Yf[3][half * 8 + b]};
-          stage_split4(Ahi, Alo, b, lane, v);
+          float v[PPL];
+#pragma unroll
+          for (int j = 0; j < PPL; ++j) v[j] = Yf[j][half * 8 + b];
+          stage_split<PPL>(Ahi, Alo, b, lane, v);
         }
       }
-      __syncthreads();
+      wave_lds_sync();
       if (((lane & 15) >> 3) == half) {
         const int b = lane & 7;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
+        for (int s = 0; s < KS; ++s) {
           if (half * 8 + b < TR::CC) {
-            const int dw = frag_dw(b, lane, s);
+            const int dw = frag_dw<PPL>(b, lane, s);
             Bh[s] = *reinterpret_cast<const uint4 *>(Ahi + dw);
             Bl[s] = *reinterpret_cast<const uint4 *>(Alo + dw);
           } else {
@@ -597,7 +632,7 @@ k_composite_bwd_sh_mfma(CompParams p) {
           }
         }
       }
-      __syncthreads();
+      wave_lds_sync();
     }
   }
   v2f Yp[PPL][TR::NPAIR];
@@ -610,6 +645,7 @@ k_composite_bwd_sh_mfma(CompParams p) {
       basis_of_pixel(pxo, py[j], Yf);
 #pragma unroll
       for (int k = 0; k < TR::NPAIR; ++k) Yp[j][k] = v2f{Yf[2 * k], Yf[2 * k + 1]};
+      __builtin_amdgcn_sched_barrier(0);  // one pixel's temporaries at a time
     }
   }
 
@@ -622,7 +658,7 @@ k_composite_bwd_sh_mfma(CompParams p) {
     const size_t pix = valid[j] ? ((size_t)gy[j] * p.W + gx) : 0;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-      Go[lane * 12 + c * 4 + j] = valid[j] ? p.grad_out[NCH * pix + c] : 0.0f;
+      Go[t * 3 * PPL + c * PPL + j] = valid[j] ? p.grad_out[NCH * pix + c] : 0.0f;
       rem[j][c] = valid[j] ? p.final_img[NCH * pix + c] : 0.0f;
     }
     Tr[j] = 1.0f;
@@ -630,16 +666,16 @@ k_composite_bwd_sh_mfma(CompParams p) {
   }
 
   int nst = 0;  // Gaussians staged since the last flush (wave-uniform)
-  // contracts the staged rows with the basis table and adds the result to grad_sh
   // MFMA row 4 * slot + c holds (staged Gaussian slot, channel c); it lives in LDS row 3 * slot + c.
   // Lane l then receives slot l >> 4, channel r in accumulator element r, basis l & 15.
   const int arow = 3 * ((lane & 15) >> 2) + (((lane & 3) < 3) ? (lane & 3) : 0);  // c == 3: unused row
-  const int a_dw = frag_dw(arow < NROW ? arow : 0, lane, 0);
+  const int a_dw = frag_dw<PPL>(arow < NROW ? arow : 0, lane, 0);
+  // contracts the staged rows with the basis table and adds the result to grad_sh (per wavefront)
   auto flush = [&]() {
-    __syncthreads();
+    wave_lds_sync();
     f32x4 acc0 = f32x4_zero(), acc1 = f32x4_zero(), acc2 = f32x4_zero();
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
+    for (int s = 0; s < KS; ++s) {
       const uint4 ah = *reinterpret_cast<const uint4 *>(Ahi + a_dw + 16 * s);
       const uint4 al = *reinterpret_cast<const uint4 *>(Alo + a_dw + 16 * s);
       acc0 = mfma_16x16x32_bf16(ah, Bh[s], acc0);
@@ -654,11 +690,11 @@ k_composite_bwd_sh_mfma(CompParams p) {
     }
     const int slot = lane >> 4, b = lane & 15;
     if (slot < nst && b < TR::CC) {
-      float *dst = p.g_col + (size_t)TR::NCOL * (size_t)fid[slot < kNF ? slot : 0] + b;
+      float *dst = p.g_col + (size_t)TR::NCOL * (size_t)fid[slot] + b;
 #pragma unroll
       for (int c = 0; c < 3; ++c) atomicAdd(dst + c * TR::CC, (acc0[c] + acc1[c]) + acc2[c]);
     }
-    __syncthreads();
+    wave_lds_sync();
     nst = 0;
   };
 
@@ -712,9 +748,16 @@ k_composite_bwd_sh_mfma(CompParams p) {
         v2f q[TR::NPAIR];
 #pragma unroll
         for (int k = 0; k < TR::NPAIR; ++k) q[k] = *reinterpret_cast<const v2f *>(cg + c * TR::CCP + 2 * k);
-        float gsv[PPL];
-        const float4 go4 = *reinterpret_cast<const float4 *>(&Go[lane * 12 + c * 4]);  // lane-private
-        const float go[PPL] = {go4.x, go4.y, go4.z, go4.w};
+        float gsv[PPL], go[PPL];
+        if constexpr (PPL == 4) {
+          const float4 g4 = *reinterpret_cast<const float4 *>(&Go[t * 12 + c * 4]);  // lane-private
+          go[0] = g4.x; go[1] = g4.y; go[2] = g4.z; go[3] = g4.w;
+        } else if constexpr (PPL == 2) {
+          const float2 g2 = *reinterpret_cast<const float2 *>(&Go[t * 6 + c * 2]);
+          go[0] = g2.x; go[1] = g2.y;
+        } else {
+          go[0] = Go[t * 3 + c];
+        }
 #pragma unroll
         for (int j = 0; j < PPL; ++j) {
           v2f s2 = q[0] * Yp[j][0];
@@ -725,7 +768,7 @@ k_composite_bwd_sh_mfma(CompParams p) {
           gsv[j] = w[j] * (yv * (1.0f - yv)) * go[j];
           pAG[j] += go[j] * (yv * Tr[j] - rem[j][c] * inv1m[j]);
         }
-        stage_split4(Ahi, Alo, 3 * nst + c, lane, gsv);
+        stage_split<PPL>(Ahi, Alo, 3 * nst + c, lane, gsv);
         __builtin_amdgcn_sched_barrier(0);  // keep the next channel's coefficient loads out of this one
       }
       // mean2d (2) | cov2d (4) | alpha (1): kernel_gaussian_2d_backward (kernels.h:394-418)
@@ -796,11 +839,16 @@ static int launch_bwd(const CompParams &p_, hipStream_t s) {
   if (p.n_hi == 0) p.n_hi = 0x7fffffff;
   const uint32_t nblk = comp_grid(p);
   if (p.ntw * p.nth == 0) return 0;
-  // GSGEN_BWD_MFMA=0 keeps the SH gradient contraction on the vector ALUs (A/B runs)
-  static const bool mfma = !(getenv("GSGEN_BWD_MFMA") && getenv("GSGEN_BWD_MFMA")[0] == '0');
+  // GSGEN_BWD_MFMA=0 keeps the SH gradient contraction on the vector ALUs (A/B runs);
+  // GSGEN_BWD_MFMA=4 / 2 / 1 choose one / two / four wavefronts per tile for the matrix-core kernel.
+  // Measured on cfg2 (profiles/r01_notes.md): two wavefronts 2710-2770 renders/s, one 2600, four
+  // 2480, vector path 2445.
+  static const int mfma = getenv("GSGEN_BWD_MFMA") ? atoi(getenv("GSGEN_BWD_MFMA")) : 2;
   if constexpr (MODE == MODE_SH) {
-    if (ppl == 4 && mfma) {
-      hipLaunchKernelGGL((k_composite_bwd_sh_mfma<CB>), dim3(nblk), dim3(64), 0, s, p);
+    if (ppl == 4 && mfma != 0) {
+      if (mfma == 1) hipLaunchKernelGGL((k_composite_bwd_sh_mfma<CB, 1>), dim3(nblk), dim3(256), 0, s, p);
+      else if (mfma == 2) hipLaunchKernelGGL((k_composite_bwd_sh_mfma<CB, 2>), dim3(nblk), dim3(128), 0, s, p);
+      else hipLaunchKernelGGL((k_composite_bwd_sh_mfma<CB, 4>), dim3(nblk), dim3(64), 0, s, p);
       return (int)hipGetLastError();
     }
   }

@@ -37,6 +37,15 @@ __device__ __forceinline__ void mfma_step_fence(f32x4 &a, f32x4 &b, f32x4 &c) {
   asm volatile("s_nop 1" : "+v"(a), "+v"(b), "+v"(c) : : "memory");
 }
 
+// LDS written by some lanes of this wavefront is about to be read by others (or the reverse).  The
+// hardware executes one wavefront's LDS operations in order; this only stops the compiler from
+// moving them across.  (Not a workgroup barrier: wavefronts of a workgroup pass independently.)
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // the value, but opaque to common-subexpression elimination
 __device__ __forceinline__ float opaque(float v) {
   asm volatile("" : "+v"(v));

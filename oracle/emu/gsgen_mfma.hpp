@@ -53,6 +53,9 @@ inline f32x4 mfma_16x16x32_bf16(uint4 a, uint4 b, f32x4 c) {
   return d;
 }
 
+// lanes are fibers that only switch at collectives: make this one, so that every lane's LDS
+// writes are done before any lane reads
+inline void wave_lds_sync() { (void)simt::shfl_idx(0, 0); }
 inline void mfma_step_fence(f32x4 &, f32x4 &, f32x4 &) {}
 inline float opaque(float v) { return v; }
 

@@ -17,6 +17,8 @@ VARIANTS = [
     {"GSGEN_PPL_FWD": "2", "GSGEN_PPL_BWD": "1"},
     {"GSGEN_BWD_SPLIT": "40"},
     {"GSGEN_BWD_MFMA": "0"},  # SH gradient contraction on the vector ALUs instead of the matrix cores
+    {"GSGEN_BWD_MFMA": "4"},  # matrix-core kernel, one wavefront per tile (default: two)
+    {"GSGEN_BWD_MFMA": "1"},  # matrix-core kernel, four wavefronts per tile
 ]
 
 

@@ -1,7 +1,7 @@
 # usage: bash tools/pmc.sh <tag> "<counters>" [env...]   -> gpurun_out/pmc_<tag>/
 tag=$1; shift; ctrs=$1; shift
 cd /tmp && export TMPDIR=/tmp
-env "$@" timeout 300 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$tag -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/pmc_$tag.log 2>&1
+env "$@" timeout 300 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$tag -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline $BENCH_ARGS > $GRAFT_REPO_ROOT/gpurun_out/pmc_$tag.log 2>&1
 cd $GRAFT_REPO_ROOT
 python - <<PY
 import csv,glob,collections
