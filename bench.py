@@ -295,7 +295,7 @@ def main():
                    "gaussians": N, "visible_after_cull": n_vis, "image": [H, W], "sh_degree": C - 1,
                    "tile_pairs_D": D, "cameras_per_gpu_per_step": 1, "renders_in_flight": n_streams, "parallelism": f"camera-sharded x{world}",
                    "gather": "rccl all_gather of rendered images" if world > 1 else "none"},
-        "roofline": {"bound": "hbm", "kernel": f"k_composite_bwd_pixel<SH,C={C}> (compositing backward)", "achieved": ach, "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": f"k_composite_bwd_sh_mfma<C={C},2> (compositing backward, matrix-core grad_sh)", "achieved": ach, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                      "alg_bytes_per_launch": parts["composite_bwd"], "avg_launch_ms": bwd_ms,
                      "fwd_kernel_ms": fwd_ms,

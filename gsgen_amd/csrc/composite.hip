@@ -769,7 +769,7 @@ k_composite_bwd_sh_mfma(CompParams p) {
           pAG[j] += go[j] * (yv * Tr[j] - rem[j][c] * inv1m[j]);
         }
         stage_split<PPL>(Ahi, Alo, 3 * nst + c, lane, gsv);
-        __builtin_amdgcn_sched_barrier(0);  // keep the next channel's coefficient loads out of this one
+        if constexpr (PPL == 4) __builtin_amdgcn_sched_barrier(0);  // register diet: keep the next channel's coefficient loads out of this one
       }
       // mean2d (2) | cov2d (4) | alpha (1): kernel_gaussian_2d_backward (kernels.h:394-418)
       float gr[8];
