@@ -185,7 +185,7 @@ def main():
     torch.cuda.synchronize()
     buf = slots[0].buf
 
-    def step(i, timed=None, slot=None):
+    def step(i, timed=None, slot=None, gather=True):
         k = i % len(cams)
         sl = slots[(i % n_streams) if slot is None else slot]
         b_, s, stream = sl.buf, sl.s, sl.stream
@@ -214,7 +214,7 @@ def main():
         lib.project_gaussians_backward_masked(N, p(t["mean"]), p(t["qvec"]), p(t["svec"]), p(cam_dev[k]), 1,
                                               p(b_.mask), p(sl.g_mean2d), p(sl.g_cov2d), None, p(sl.g_mean),
                                               p(sl.g_qvec), p(sl.g_svec), s)
-        if gathered is not None:
+        if gathered is not None and gather:
             with torch.cuda.stream(stream):
                 dist.all_gather_into_tensor(gathered, sl.out)
 
@@ -222,10 +222,10 @@ def main():
     Ds = []
     for sidx in range(n_streams):
         for k in range(len(cams)):
-            step(k, slot=sidx)
+            step(k, slot=sidx, gather=False)  # (data-dependent retries: no collectives in here)
             torch.cuda.synchronize()
             if not slots[sidx].buf.ensure_capacity():
-                step(k, slot=sidx)
+                step(k, slot=sidx, gather=False)
                 torch.cuda.synchronize()
                 assert slots[sidx].buf.ensure_capacity()
             if sidx == 0:
