@@ -786,3 +786,47 @@ void gso_sh_workstats(const float *mean, const float *cov, const float *alpha, c
         }
     }
 }
+
+/* Per-wavefront work statistics of the compositing kernels' pixel partitions (tools only):
+ * rows_of_part[16] maps a tile row to its wavefront (4 strips of 4 rows for the forward; the
+ * backward's two interleaved halves).  Counts (wavefront, entry) pairs walked (some pixel of
+ * the part still alive) and contributing (some pixel alive and a*G >= 1/255). */
+void gso_part_workstats(const float *mean, const float *cov, const float *alpha, const int *start,
+                        const int *end, const int *ids, const float *topleft, int n_tiles_h,
+                        int n_tiles_w, float psx, float psy, int H, int W, float thresh,
+                        const int *rows_of_part, int n_parts, long long *walked, long long *contrib,
+                        long long *pix_pairs) {
+  long long w_tot = 0, c_tot = 0, p_tot = 0;
+#pragma omp parallel for schedule(dynamic, 1) collapse(2) reduction(+ : w_tot, c_tot, p_tot)
+  for (int ty = 0; ty < n_tiles_h; ++ty)
+    for (int tx = 0; tx < n_tiles_w; ++tx) {
+      int tile = ty * n_tiles_w + tx;
+      int n = (start[tile] == -1) ? 0 : end[tile] - start[tile];
+      const int *lst = ids + (n ? start[tile] : 0);
+      float cum[256];
+      for (int i = 0; i < 256; ++i) cum[i] = 1.0f;
+      for (int k = 0; k < n; ++k) {
+        int g = lst[k];
+        float a = fminf(alpha[g], 0.99f);
+        int part_alive[8] = {0}, part_con[8] = {0};
+        for (int ly = 0; ly < 16; ++ly)
+          for (int lx = 0; lx < 16; ++lx) {
+            int gy = ty * 16 + ly, gx = tx * 16 + lx;
+            if (gy >= H || gx >= W) continue;
+            float *c = &cum[ly * 16 + lx];
+            if (*c < thresh) continue;
+            int part = rows_of_part[ly];
+            part_alive[part] = 1;
+            float pos[2];
+            pixel_pos(topleft, gx, gy, psx, psy, pos);
+            float val = gauss2d_f32(mean + 2 * g, cov + 4 * g, pos);
+            if (a * val < MIN_RENDER_ALPHA) continue;
+            part_con[part] = 1;
+            ++p_tot;
+            *c *= (1 - a * val);
+          }
+        for (int q = 0; q < n_parts; ++q) { w_tot += part_alive[q]; c_tot += part_con[q]; }
+      }
+    }
+  *walked = w_tot; *contrib = c_tot; *pix_pairs = p_tot;
+}
