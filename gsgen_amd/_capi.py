@@ -34,6 +34,7 @@ SIGNATURES = {
     "gsgen_project_gaussians_backward_masked": [u32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp],
     "gsgen_project_gaussians_backward_accum": [u32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp],
     "gsgen_pack_camera": [vp, f32, f32, f32, f32, u32, u32, C.c_double, C.c_double, f32, f32, vp],
+    "gsgen_adam_step": [C.c_uint64, vp, vp, vp, vp, u32, vp, vp, f32, f32, f32, u32, vp],
     "gsgen_densify_update": [u32, vp, vp, vp, vp, vp, vp, vp],
     "gsgen_tile_culling_aabb_count": [u32, vp, vp, u32, f32, f32, f32, f32, u32, u32, f32, vp, vp, vp, vp],
     "gsgen_selftest_reduce_scatter": [u32, vp, vp, vp],

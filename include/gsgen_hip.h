@@ -155,6 +155,13 @@ int gsgen_project_gaussians_backward_accum(uint32_t N, const float *mean, const 
                                            const float *g_cov2d, const float *g_depth,
                                            float *g_mean, float *g_qvec, float *g_svec,
                                            gsgen_stream_t stream);
+/* torch.optim.Adam step (no weight decay, no amsgrad: gs/gaussian_splatting.py:398-419,
+ * conf/base.yaml:8-11) over one flat fp32 vector that holds every parameter field back to back,
+ * in place.  group_end[k] (HOST array, ascending, last == n) closes parameter group k, group_lr[k]
+ * (HOST) is its learning rate for this step; step counts from 1.  At most 8 groups. */
+int gsgen_adam_step(uint64_t n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
+                    uint32_t n_groups, const uint64_t *group_end, const float *group_lr, float beta1,
+                    float beta2, float eps, uint32_t step, gsgen_stream_t stream);
 /* Densification statistics of one camera (gs/gaussian_splatting.py:1240-1245, :464-469), rows
  * aligned with mask [N] (NULL = all rows):
  *   max_radii2d[i] = max(max_radii2d[i], m + sqrt(max(m^2 - det(cov2d_i), 0))), m = tr/2

@@ -333,3 +333,29 @@ def test_emulated_projection_backward_overwrite_masked_and_accumulate(emu):
             w_[mask == 1] += y[mask == 1]
     for x, w_ in zip(tot, want):
         assert np.abs(x - w_).max() <= 1e-6 * np.abs(w_).max()
+
+
+def test_emulated_adam_step_matches_torch_cpu(emu):
+    """gsgen_adam_step on the emulator vs torch.optim.Adam (CPU) with one param group per field and
+    learning rates that change every step (gs/gaussian_splatting.py:398-419, conf/base.yaml:8-11)"""
+    torch.manual_seed(0)
+    shapes = {"mean": (37, 3), "qvec": (37, 4), "svec": (37, 3), "color": (37, 3), "alpha": (37,)}
+    ref = {k: torch.randn(*sh).requires_grad_(True) for k, sh in shapes.items()}
+    opt = torch.optim.Adam([{"params": [v], "lr": 0.0, "name": k} for k, v in ref.items()], lr=0.0, eps=1e-15)
+    flat = np.concatenate([v.detach().numpy().reshape(-1) for v in ref.values()]).astype(np.float32)
+    m = np.zeros_like(flat); v2 = np.zeros_like(flat)
+    ends = np.cumsum([int(np.prod(sh)) for sh in shapes.values()]).astype(np.uint64)
+    for step in range(1, 6):
+        lrs = np.array([5e-3 / step, 1e-3, 5e-3, 1e-2 * step, 3e-2], np.float32)
+        grads = {k: torch.randn(*sh) * (10.0 ** (step - 3)) for k, sh in shapes.items()}
+        for (k, p_), grp in zip(ref.items(), opt.param_groups):
+            p_.grad = grads[k].clone()
+            grp["lr"] = float(lrs[list(shapes).index(k)])
+        opt.step()
+        g = np.concatenate([grads[k].numpy().reshape(-1) for k in shapes]).astype(np.float32)
+        emu.adam_step(flat.size, P(flat), P(g), P(m), P(v2), len(shapes), ends.ctypes.data, lrs.ctypes.data, 0.9, 0.999,
+                      1e-15, step, None)
+        want = np.concatenate([v.detach().numpy().reshape(-1) for v in ref.values()])
+        assert np.abs(flat - want).max() <= 2e-6 * np.abs(want).max(), step
+    with pytest.raises(Exception, match="invalid"):
+        emu.adam_step(flat.size, P(flat), P(g), P(m), P(v2), 1, ends.ctypes.data, lrs.ctypes.data, 0.9, 0.999, 1e-15, 1, None)

@@ -224,6 +224,38 @@ def test_batched_cameras_match_one_at_a_time(n_streams, C):
         br.render(Pb["mean"], Pb["qvec"], Pb["svec"], Pb["alpha"], Pb[ck], cis * 2, [c.c2w for c in cams] * 2, C=C)
 
 
+def test_fused_adam_tracks_torch_adam_through_a_render():
+    """optim.FusedAdam: parameters are views of one flat buffer, autograd accumulates straight into
+    the flat gradient, one kernel updates every field; against torch.optim.Adam on the same grads"""
+    from gsgen_amd import renderer as R
+    from gsgen_amd.optim import FusedAdam
+    sc = scenes.random_scene(2000, seed=3, svec=0.04, C=2)
+    cam = scenes.Camera(96, 80, fx=90.0, c2w=scenes.orbit(2.4, 10, 30))
+    ci = R.CameraInfo(*cam.intr)
+    keys = ("mean", "qvec", "svec", "alpha", "sh")
+    lrs = {"mean": 5e-3, "qvec": 1e-3, "svec": 5e-3, "alpha": 3e-2, "sh": 1e-2}
+    fa = FusedAdam({k: T_(sc[k]) for k in keys}, lrs)
+    ref = {k: T_(sc[k]).requires_grad_(True) for k in keys}
+    opt = torch.optim.Adam([{"params": [ref[k]], "lr": lrs[k]} for k in keys], lr=0.0, eps=1e-15)
+    buf = R.FrameBuffers(sc["mean"].shape[0], cam.w, cam.h, dev())
+    target = torch.rand(cam.h, cam.w, 3, device=dev())
+    for it in range(4):
+        fa.zero_grad(); opt.zero_grad()
+        for P_ in (fa.params, ref):
+            rgb, _ = R.render_frame(P_["mean"], P_["qvec"], P_["svec"], P_["alpha"], P_["sh"], ci, cam.c2w, buf, C=2)
+            ((rgb - target) ** 2).sum().backward()
+        assert fa.params["sh"].grad.data_ptr() == fa.grad[fa.n - fa.params["sh"].numel():].data_ptr()  # still the view
+        for k in keys:
+            assert rel_err(fa.params[k].grad.cpu().numpy(), ref[k].grad.cpu().numpy()) < 1e-5
+        new_lrs = {k: v / (it + 1) for k, v in lrs.items()}
+        for grp, k in zip(opt.param_groups, keys):
+            grp["lr"] = new_lrs[k]
+        fa.all_reduce_grad()  # no process group: a no-op
+        fa.step(new_lrs); opt.step()
+        for k in keys:
+            assert rel_err(fa.params[k].detach().cpu().numpy(), ref[k].detach().cpu().numpy()) < 2e-5, (it, k)
+
+
 def test_full_size_cfg2():
     """BASELINE configs[1] (100k Gaussians, 800x800, SH degree 3) through the fused path:
     pair count and per-tile lists exact, image within 1e-4 of the oracle, per-tile lists
