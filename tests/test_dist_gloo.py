@@ -107,3 +107,36 @@ def test_bucketed_gradient_allreduce():
             assert a is None
         else:
             assert np.allclose(a, (b / world).numpy(), atol=1e-6)
+
+
+def _flat_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gsgen_amd.optim import FusedAdam
+    fields = {"mean": torch.zeros(20, 3), "alpha": torch.zeros(20), "sh": torch.zeros(20, 3, 4)}
+    fa = FusedAdam(fields, {k: 1e-3 for k in fields})
+    # every rank back-propagates its own cameras' loss into the SAME flat gradient layout
+    loss = sum(((rank + 1) * (i + 1)) * p.sum() for i, p in enumerate(fa.params.values()))
+    loss.backward()
+    fa.all_reduce_grad()
+    if rank == 1:
+        q.put(fa.grad.numpy().copy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_parameter_buffer_one_allreduce():
+    """optim.FusedAdam: field gradients are views of one flat buffer, reduced with ONE collective"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_flat_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = np.concatenate([np.full(60, 1.5 * 1), np.full(20, 1.5 * 2), np.full(240, 1.5 * 3)]).astype(np.float32)
+    assert np.array_equal(got, want)
