@@ -123,6 +123,8 @@ def main():
     ap.add_argument("--config", default="cfg2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="also time every stage separately")
+    ap.add_argument("--segments", type=int, default=int(os.environ.get("GSGEN_SEGMENTS", "8")),
+                    help="backward workgroups per tile (segments of 32 list entries; 1 = one workgroup per tile)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("GSGEN_STREAMS", "3")),
                     help="independent renders in flight (HIP streams, own buffers each)")
     args = ap.parse_args()
@@ -174,6 +176,7 @@ def main():
                 self.buf = R.FrameBuffers(N, W, H, dev)
                 self.out = torch.empty(H, W, 3, device=dev)
                 self.gflat = torch.empty(N * (7 + CC3), device=dev)  # mean2d(2) | cov2d(4) | alpha(1) | sh
+                self.seg_ws = torch.empty(lib.segment_workspace_bytes(nth * ntw, args.segments), device=dev, dtype=torch.uint8)
                 self.g_mean = torch.empty(N, 3, device=dev)
                 self.g_qvec = torch.empty(N, 4, device=dev)
                 self.g_svec = torch.empty(N, 3, device=dev)
@@ -196,19 +199,19 @@ def main():
                            p(b_.end), p(b_.total), p(b_.ws), b_.ws.numel(), s)
         if timed is not None:
             timed[0].record(stream)
-        lib.vol_render_sh_ordered(N, b_.D_cap, p(b_.mean2d), p(b_.cov2d), p(t["sh"]), p(t["alpha"]), p(b_.start),
-                                  p(b_.end), p(b_.ids), p(sl.out), p(topleft), p(rot_dev[k]), 16, nth, ntw, psx, psy,
-                                  H, W, C, 1e-4, p(bg), None, order, s)
+        lib.vol_render_sh_segmented(N, b_.D_cap, p(b_.mean2d), p(b_.cov2d), p(t["sh"]), p(t["alpha"]), p(b_.start),
+                                    p(b_.end), p(b_.ids), p(sl.out), p(topleft), p(rot_dev[k]), 16, nth, ntw, psx, psy,
+                                    H, W, C, 1e-4, p(bg), None, order, p(sl.seg_ws), args.segments, s)
         if timed is not None:
             timed[1].record(stream)
         with torch.cuda.stream(stream):
             sl.gflat.zero_()
         if timed is not None:
             timed[2].record(stream)
-        lib.vol_render_backward_sh_ordered(N, b_.D_cap, p(b_.mean2d), p(b_.cov2d), p(t["sh"]), p(t["alpha"]),
-                                           p(b_.start), p(b_.end), p(b_.ids), p(sl.out), p(sl.g_mean2d), p(sl.g_cov2d),
-                                           p(sl.g_sh), p(sl.g_alpha), p(grad_out), p(topleft), p(rot_dev[k]), 16, nth,
-                                           ntw, psx, psy, H, W, C, 1e-4, p(bg), order, s)
+        lib.vol_render_backward_sh_segmented(N, b_.D_cap, p(b_.mean2d), p(b_.cov2d), p(t["sh"]), p(t["alpha"]),
+                                             p(b_.start), p(b_.end), p(b_.ids), p(sl.out), p(sl.g_mean2d), p(sl.g_cov2d),
+                                             p(sl.g_sh), p(sl.g_alpha), p(grad_out), p(topleft), p(rot_dev[k]), 16, nth,
+                                             ntw, psx, psy, H, W, C, 1e-4, p(bg), order, p(sl.seg_ws), args.segments, s)
         if timed is not None:
             timed[3].record(stream)
         lib.project_gaussians_backward_masked(N, p(t["mean"]), p(t["qvec"]), p(t["svec"]), p(cam_dev[k]), 1,

@@ -171,13 +171,16 @@ __global__ void __launch_bounds__(256 / PPL) k_composite_fwd(CompParams p) {
   float acc[PPL][NCH];
   float Tr[PPL];
   bool alive[PPL];
+  int stop[PPL];  // first list index the pixel does not process (segmented backward)
 #pragma unroll
   for (int j = 0; j < PPL; ++j) {
 #pragma unroll
     for (int c = 0; c < NCH; ++c) acc[j][c] = 0.0f;
     Tr[j] = 1.0f;
     alive[j] = valid[j];
+    stop[j] = valid[j] ? n : 0;
   }
+  const bool seg_out = (MODE == MODE_SH) && p.nseg > 1 && p.ckpt != nullptr;
 
   for (int base = 0; base < n; base += kBatch) {
     const int nb = min(kBatch, n - base);
@@ -190,6 +193,15 @@ __global__ void __launch_bounds__(256 / PPL) k_composite_fwd(CompParams p) {
 #pragma unroll
       for (int j = 0; j < PPL; ++j) any_alive |= alive[j];
       if (__ballot(any_alive) == 0ull) break;  // this wave's 64*PPL pixels are saturated
+      if constexpr (MODE == MODE_SH) {
+        const int e = base + g;
+        if (seg_out && (e % kSegLen) == 0 && e > 0 && e / kSegLen < p.nseg) {  // wave-uniform
+#pragma unroll
+          for (int j = 0; j < PPL; ++j)
+            p.ckpt[((size_t)tile * p.nseg + e / kSegLen) * 256 + (ly0 + j * ROWS) * 16 + lx] =
+                make_float4(Tr[j], acc[j][0], acc[j][1], acc[j][2]);
+        }
+      }
 
       const GRec r = load_rec(S, g);
       const float x = px - r.mx;
@@ -229,7 +241,9 @@ __global__ void __launch_bounds__(256 / PPL) k_composite_fwd(CompParams p) {
         for (int j = 0; j < PPL; ++j) {
           const float om = con[j] ? (1.0f - r.a * G[j]) : 1.0f;
           Tr[j] *= om;
-          alive[j] = alive[j] && !(Tr[j] < p.thresh);
+          const bool still = alive[j] && !(Tr[j] < p.thresh);
+          if (alive[j] && !still) stop[j] = base + g + 1;
+          alive[j] = still;
         }
       } else {
 #pragma unroll
@@ -271,6 +285,12 @@ __global__ void __launch_bounds__(256 / PPL) k_composite_fwd(CompParams p) {
       }
     }
     if (p.T != nullptr) p.T[pix] = Tr[j];
+  }
+  if constexpr (MODE == MODE_SH) {
+    if (p.stop != nullptr) {
+#pragma unroll
+      for (int j = 0; j < PPL; ++j) p.stop[(size_t)tile * 256 + (ly0 + j * ROWS) * 16 + lx] = stop[j];
+    }
   }
 }
 
@@ -555,12 +575,23 @@ k_composite_bwd_sh_mfma(CompParams p) {
   __shared__ int fid_[NW][4];
   __shared__ alignas(16) float Go[NT * 3 * PPL];  // grad_out of the lane's PPL pixels x 3 channels
 
+  // Segmented launch: workgroup = (tile, segment of kSegLen list entries); the forward left the
+  // state in front of every segment (CompParams::ckpt / stop), so segments are independent.
+  // Segment-major order (all tiles' segment 0, then all segment 1, ...): consecutive workgroup ids
+  // go round-robin over the 8 XCDs, so a tile-major order with 8 segments would park every tile's
+  // segment k on XCD k -- and only the first few segments have work.
+  const int nseg = p.nseg > 1 ? p.nseg : 1;
+  const uint32_t tiles_grid = gridDim.x / (uint32_t)nseg;
+  const int seg = (int)(blockIdx.x / tiles_grid);
   int tx, ty;
-  if (!block_tile(p, tx, ty)) return;
+  if (!block_tile(p, tx, ty, blockIdx.x % tiles_grid)) return;
   const int tile = ty * p.ntw + tx;
   const int st = p.start[tile];
   const int n = (st < 0) ? 0 : (p.end[tile] - st);
   if (n <= 0 || n < p.n_lo || n >= p.n_hi) return;
+  const int e_lo = seg * kSegLen;
+  const int e_hi = (seg == nseg - 1) ? n : min(n, e_lo + kSegLen);  // the last segment takes the rest
+  if (e_lo >= n) return;
   const int t = (int)threadIdx.x;
   const int lane = t & 63, wv = t >> 6;
   uint32_t *const Ahi = Ahi_[wv];
@@ -581,6 +612,17 @@ k_composite_bwd_sh_mfma(CompParams p) {
   }
 
   const int gy0 = ty * kTile + ly0;
+  bool alive[PPL];
+  {
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) {
+      alive[j] = valid[j];
+      if (nseg > 1) alive[j] = alive[j] && (p.stop[(size_t)tile * 256 + (ly0 + j * ROWS) * 16 + lx] > e_lo);
+      any |= alive[j];
+    }
+    if (__syncthreads_or((int)any) == 0) return;  // every pixel of the tile stopped before this segment
+  }
   if constexpr (TR::CCP != TR::CC) {
     for (int e = t; e < kKBm * TR::NCOLP; e += NT) S.col[e] = 0.0f;
   }
@@ -652,17 +694,18 @@ k_composite_bwd_sh_mfma(CompParams p) {
   // rem = final - (prefix colour including the current splat): the suffix the reference forms as
   // final - Cpre_incl (vol_render_sh.h:328-333), carried as one running value per channel
   float rem[PPL][NCH], Tr[PPL];
-  bool alive[PPL];
 #pragma unroll
   for (int j = 0; j < PPL; ++j) {
     const size_t pix = valid[j] ? ((size_t)gy[j] * p.W + gx) : 0;
+    float4 ck = make_float4(1.0f, 0.0f, 0.0f, 0.0f);  // state in front of entry e_lo: T, prefix rgb
+    if (seg > 0 && alive[j]) ck = p.ckpt[((size_t)tile * nseg + seg) * 256 + (ly0 + j * ROWS) * 16 + lx];
+    const float pre[3] = {ck.y, ck.z, ck.w};
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       Go[t * 3 * PPL + c * PPL + j] = valid[j] ? p.grad_out[NCH * pix + c] : 0.0f;
-      rem[j][c] = valid[j] ? p.final_img[NCH * pix + c] : 0.0f;
+      rem[j][c] = alive[j] ? p.final_img[NCH * pix + c] - pre[c] : 0.0f;
     }
-    Tr[j] = 1.0f;
-    alive[j] = valid[j];
+    Tr[j] = alive[j] ? ck.x : 0.0f;
   }
 
   int nst = 0;  // Gaussians staged since the last flush (wave-uniform)
@@ -698,9 +741,9 @@ k_composite_bwd_sh_mfma(CompParams p) {
     nst = 0;
   };
 
-  for (int base = 0; base < n; base += kKBm) {
-    const int nb = min(kKBm, n - base);
-    if (base > 0) __syncthreads();
+  for (int base = e_lo; base < e_hi; base += kKBm) {
+    const int nb = min(kKBm, e_hi - base);
+    if (base > e_lo) __syncthreads();
     stage_batch<MODE, CB, NT, kKBm>(S, p, st + base, nb);
     __syncthreads();
 
@@ -846,9 +889,10 @@ static int launch_bwd(const CompParams &p_, hipStream_t s) {
   static const int mfma = getenv("GSGEN_BWD_MFMA") ? atoi(getenv("GSGEN_BWD_MFMA")) : 2;
   if constexpr (MODE == MODE_SH) {
     if (ppl == 4 && mfma != 0) {
-      if (mfma == 1) hipLaunchKernelGGL((k_composite_bwd_sh_mfma<CB, 1>), dim3(nblk), dim3(256), 0, s, p);
-      else if (mfma == 2) hipLaunchKernelGGL((k_composite_bwd_sh_mfma<CB, 2>), dim3(nblk), dim3(128), 0, s, p);
-      else hipLaunchKernelGGL((k_composite_bwd_sh_mfma<CB, 4>), dim3(nblk), dim3(64), 0, s, p);
+      const uint32_t ng = nblk * (uint32_t)(p.nseg > 1 ? p.nseg : 1);
+      if (mfma == 1) hipLaunchKernelGGL((k_composite_bwd_sh_mfma<CB, 1>), dim3(ng), dim3(256), 0, s, p);
+      else if (mfma == 2) hipLaunchKernelGGL((k_composite_bwd_sh_mfma<CB, 2>), dim3(ng), dim3(128), 0, s, p);
+      else hipLaunchKernelGGL((k_composite_bwd_sh_mfma<CB, 4>), dim3(ng), dim3(64), 0, s, p);
       return (int)hipGetLastError();
     }
   }
@@ -932,6 +976,10 @@ int gsgen_vol_render_rgbd(uint32_t N, uint32_t D, const float *mean, const float
   return launch_fwd<MODE_RGBD, 1>(p, (hipStream_t)stream);
 }
 
+size_t gsgen_segment_workspace_bytes(uint32_t n_tiles, uint32_t n_segments) {
+  return (size_t)n_tiles * 256 * (sizeof(float4) * (size_t)(n_segments > 1 ? n_segments : 1) + sizeof(int));
+}
+
 int gsgen_vol_render_sh_ordered(uint32_t N, uint32_t D, const float *mean, const float *cov,
                                 const float *sh_coeffs, const float *alpha, const int *start,
                                 const int *end, const int *gaussian_ids, float *out, const float *topleft,
@@ -939,7 +987,21 @@ int gsgen_vol_render_sh_ordered(uint32_t N, uint32_t D, const float *mean, const
                                 uint32_t n_tiles_w, float pixel_size_x, float pixel_size_y, uint32_t H,
                                 uint32_t W, uint32_t C, float thresh, const float *bg_rgb, float *T,
                                 const uint32_t *tile_order, gsgen_stream_t stream) {
+  return gsgen_vol_render_sh_segmented(N, D, mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out, topleft,
+                                       c2w, tile_size, n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H, W, C,
+                                       thresh, bg_rgb, T, tile_order, nullptr, 0, stream);
+}
+
+int gsgen_vol_render_sh_segmented(uint32_t N, uint32_t D, const float *mean, const float *cov,
+                                  const float *sh_coeffs, const float *alpha, const int *start,
+                                  const int *end, const int *gaussian_ids, float *out, const float *topleft,
+                                  const float *c2w, uint32_t tile_size, uint32_t n_tiles_h,
+                                  uint32_t n_tiles_w, float pixel_size_x, float pixel_size_y, uint32_t H,
+                                  uint32_t W, uint32_t C, float thresh, const float *bg_rgb, float *T,
+                                  const uint32_t *tile_order, void *segment_workspace, uint32_t n_segments,
+                                  gsgen_stream_t stream) {
   if (int e = check_common(tile_size, start, end, out)) return e;
+  if (n_segments > 1 && segment_workspace == nullptr) return GSGEN_EINVAL;
   if (C < 1 || C > 4) return GSGEN_EUNSUPPORTED;  // reference dispatches C = 1..4 only (render.cu:507-544)
   if (!c2w) return GSGEN_EINVAL;
   if ((N == 0 || D == 0) && bg_rgb == nullptr) return 0;
@@ -950,6 +1012,11 @@ int gsgen_vol_render_sh_ordered(uint32_t N, uint32_t D, const float *mean, const
   p.ntw = (int)n_tiles_w; p.nth = (int)n_tiles_h; p.H = (int)H; p.W = (int)W;
   p.psx = pixel_size_x; p.psy = pixel_size_y; p.thresh = thresh;
   p.tile_order = tile_order;
+  if (n_segments > 1) {
+    p.nseg = (int)n_segments;
+    p.ckpt = reinterpret_cast<float4 *>(segment_workspace);
+    p.stop = reinterpret_cast<int *>(p.ckpt + (size_t)n_tiles_h * n_tiles_w * 256 * n_segments);
+  }
   hipStream_t s = (hipStream_t)stream;
   switch (C) {
     case 1: return launch_fwd<MODE_SH, 1>(p, s);

@@ -26,17 +26,27 @@ struct CompParams {
   float psx, psy, thresh;
   const uint32_t *tile_order;  // optional launch order (longest list first); NULL = spatial map
   int n_lo, n_hi;  // this launch only handles tiles with n_lo <= list length < n_hi (0, INT_MAX = all)
+  // Segmented backward (SH): the forward leaves, per tile, the state in front of list entry
+  // kSegLen * k (k = 1 .. nseg-1) and the entry at which each pixel stopped; the backward then runs
+  // one workgroup per (tile, segment) instead of one per tile.  nseg <= 1: unsegmented.
+  float4 *ckpt;  // [tile][nseg][256 pixels, row-major in the tile]: T, prefix rgb
+  int *stop;     // [tile][256]: first list index the pixel did not process (n if it never saturated)
+  int nseg;
 };
+constexpr int kSegLen = 32;
 
 // workgroup -> tile: explicit order if given, else the XCD-balanced spatial map
-__device__ __forceinline__ bool block_tile(const CompParams &p, int &tx, int &ty) {
+__device__ __forceinline__ bool block_tile(const CompParams &p, int &tx, int &ty, uint32_t bid) {
   if (p.tile_order != nullptr) {
-    const uint32_t t = p.tile_order[blockIdx.x];
+    const uint32_t t = p.tile_order[bid];
     tx = (int)(t % (uint32_t)p.ntw);
     ty = (int)(t / (uint32_t)p.ntw);
     return true;
   }
-  return tile_of_block(blockIdx.x, p.ntw, p.nth, tx, ty);
+  return tile_of_block(bid, p.ntw, p.nth, tx, ty);
+}
+__device__ __forceinline__ bool block_tile(const CompParams &p, int &tx, int &ty) {
+  return block_tile(p, tx, ty, blockIdx.x);
 }
 __host__ __forceinline__ uint32_t comp_grid(const CompParams &p) {
   return p.tile_order != nullptr ? (uint32_t)(p.ntw * p.nth) : tile_map_blocks(p.ntw, p.nth);

@@ -223,6 +223,35 @@ int gsgen_vol_render_backward_sh_ordered(uint32_t N, uint32_t D, const float *me
                                          const float *bg_rgb, const uint32_t *tile_order,
                                          gsgen_stream_t stream);
 
+/* Segmented backward.  The compositing backward normally runs one workgroup per tile, and the
+ * launch ends on the few heaviest tiles.  Given a segment workspace, the FORWARD additionally
+ * stores the per-pixel state (transmittance, prefix colour) in front of every 32nd list entry and
+ * the entry at which each pixel saturated; the BACKWARD then runs one workgroup per (tile,
+ * 32-entry segment) -- uniform work units, n_segments per tile (the last one takes whatever
+ * remains).  Same results up to the rounding of `final - prefix`.  n_segments <= 1 or a NULL
+ * workspace: exactly the *_ordered entry points.  The workspace written by the forward must be
+ * handed unchanged to the backward of the same frame. */
+size_t gsgen_segment_workspace_bytes(uint32_t n_tiles, uint32_t n_segments);
+int gsgen_vol_render_sh_segmented(uint32_t N, uint32_t D, const float *mean, const float *cov,
+                                  const float *sh_coeffs, const float *alpha, const int *start,
+                                  const int *end, const int *gaussian_ids, float *out, const float *topleft,
+                                  const float *c2w, uint32_t tile_size, uint32_t n_tiles_h,
+                                  uint32_t n_tiles_w, float pixel_size_x, float pixel_size_y, uint32_t H,
+                                  uint32_t W, uint32_t C, float thresh, const float *bg_rgb, float *T,
+                                  const uint32_t *tile_order, void *segment_workspace, uint32_t n_segments,
+                                  gsgen_stream_t stream);
+int gsgen_vol_render_backward_sh_segmented(uint32_t N, uint32_t D, const float *mean, const float *cov,
+                                           const float *sh_coeffs, const float *alpha, const int *start,
+                                           const int *end, const int *gaussian_ids, const float *out,
+                                           float *grad_mean, float *grad_cov, float *grad_sh_coeffs,
+                                           float *grad_alpha, const float *grad_out, const float *topleft,
+                                           const float *c2w, uint32_t tile_size, uint32_t n_tiles_h,
+                                           uint32_t n_tiles_w, float pixel_size_x, float pixel_size_y,
+                                           uint32_t H, uint32_t W, uint32_t C, float thresh,
+                                           const float *bg_rgb, const uint32_t *tile_order,
+                                           const void *segment_workspace, uint32_t n_segments,
+                                           gsgen_stream_t stream);
+
 /* Fused RGB + auxiliary heads: what render_one does in four compositing passes
  * (gs/gaussian_splatting.py:1304-1403: rgb, depth, opacity = scalar 1, depth^2) in one.
  * out6 / grad_out6 are [H,W,6] = (r, g, b, depth, opacity, depth^2); grad_chan6 [N,6] receives the

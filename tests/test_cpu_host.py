@@ -359,3 +359,42 @@ def test_emulated_adam_step_matches_torch_cpu(emu):
         assert np.abs(flat - want).max() <= 2e-6 * np.abs(want).max(), step
     with pytest.raises(Exception, match="invalid"):
         emu.adam_step(flat.size, P(flat), P(g), P(m), P(v2), 1, ends.ctypes.data, lrs.ctypes.data, 0.9, 0.999, 1e-15, 1, None)
+
+
+@pytest.mark.parametrize("C,nseg", [(4, 4), (2, 3)])
+def test_emulated_segmented_backward_matches_unsegmented(emu, C, nseg):
+    """forward with segment checkpoints + one backward workgroup per (tile, 32-entry segment) ==
+    the per-tile backward (lists of 60-150 entries, so several segments and a long last one)"""
+    cam = scenes.Camera(40, 30, fx=40.0)
+    sc = scenes.random_scene(900, seed=31, svec=0.09, C=C)
+    sc["alpha"] = (sc["alpha"] * 0.25).astype(np.float32)  # keep pixels alive deep into the lists
+    g = scenes.oracle_geometry(sc, cam)
+    m = g["mask"]; N = int(m.sum()); D = g["D"]; nth, ntw = cam.tiles; H, W = cam.h, cam.w
+    assert (g["end"] - g["start"]).max() > 32 * (nseg - 1) + 20
+    m2 = np.ascontiguousarray(g["mean2d"]); c2 = np.ascontiguousarray(g["cov2d"])
+    sh = np.ascontiguousarray(sc["sh"][m]); al = np.ascontiguousarray(sc["alpha"][m])
+    st, en, ids, tlp = g["start"], g["end"], g["ids"], cam.topleft
+    rot = np.ascontiguousarray(cam.c2w[:3, :3].reshape(-1))
+    bg = np.array([0.3, 0.1, 0.2], np.float32)
+    ws = np.zeros(emu.segment_workspace_bytes(nth * ntw, nseg), np.uint8)
+    out0 = np.zeros((H, W, 3), np.float32); out1 = np.zeros((H, W, 3), np.float32)
+    geo = (16, nth, ntw, 1 / cam.fx, 1 / cam.fy, H, W, C, 1e-4)
+    emu.vol_render_sh_ordered(N, D, P(m2), P(c2), P(sh), P(al), P(st), P(en), P(ids), P(out0), P(tlp), P(rot), *geo, P(bg),
+                              None, None, None)
+    emu.vol_render_sh_segmented(N, D, P(m2), P(c2), P(sh), P(al), P(st), P(en), P(ids), P(out1), P(tlp), P(rot), *geo, P(bg),
+                                None, None, P(ws), nseg, None)
+    assert np.array_equal(out0, out1)
+    stop = ws[nth * ntw * nseg * 256 * 16:].view(np.int32).reshape(nth * ntw, 256)
+    assert stop.max() <= (en - st).max() and (stop > 32).any()
+    go = np.random.default_rng(5).normal(size=(H, W, 3)).astype(np.float32)
+    res = []
+    for seg in (0, nseg):
+        gm = np.zeros((N, 2), np.float32); gc = np.zeros((N, 4), np.float32); gs_ = np.zeros_like(sh); ga = np.zeros(N, np.float32)
+        emu.vol_render_backward_sh_segmented(N, D, P(m2), P(c2), P(sh), P(al), P(st), P(en), P(ids), P(out0), P(gm), P(gc), P(gs_),
+                                             P(ga), P(go), P(tlp), P(rot), *geo, P(bg), None, P(ws) if seg else None, seg, None)
+        res.append((gm, gc, gs_, ga))
+    for a_, b_ in zip(*res):
+        assert np.abs(a_ - b_).max() <= 2e-5 * np.abs(a_).max()
+    with pytest.raises(Exception, match="invalid"):
+        emu.vol_render_sh_segmented(N, D, P(m2), P(c2), P(sh), P(al), P(st), P(en), P(ids), P(out1), P(tlp), P(rot), *geo,
+                                    P(bg), None, None, None, nseg, None)
