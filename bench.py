@@ -123,8 +123,11 @@ def main():
     ap.add_argument("--config", default="cfg2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="also time every stage separately")
-    ap.add_argument("--segments", type=int, default=int(os.environ.get("GSGEN_SEGMENTS", "8")),
-                    help="backward workgroups per tile (segments of 32 list entries; 1 = one workgroup per tile)")
+    ap.add_argument("--segments", type=int, default=int(os.environ.get("GSGEN_SEGMENTS", "1")),
+                    help="backward workgroups per tile in the timed (throughput) region: segments of 32 list entries; "
+                         "1 = one workgroup per tile (best with several renders in flight)")
+    ap.add_argument("--latency-segments", type=int, default=8,
+                    help="same for the one-render-in-flight pass (uniform work units shorten a lone launch's tail)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("GSGEN_STREAMS", "3")),
                     help="independent renders in flight (HIP streams, own buffers each)")
     args = ap.parse_args()
@@ -176,7 +179,7 @@ def main():
                 self.buf = R.FrameBuffers(N, W, H, dev)
                 self.out = torch.empty(H, W, 3, device=dev)
                 self.gflat = torch.empty(N * (7 + CC3), device=dev)  # mean2d(2) | cov2d(4) | alpha(1) | sh
-                self.seg_ws = torch.empty(lib.segment_workspace_bytes(nth * ntw, args.segments), device=dev, dtype=torch.uint8)
+                self.seg_ws = torch.empty(lib.segment_workspace_bytes(nth * ntw, max(args.segments, args.latency_segments)), device=dev, dtype=torch.uint8)
                 self.g_mean = torch.empty(N, 3, device=dev)
                 self.g_qvec = torch.empty(N, 4, device=dev)
                 self.g_svec = torch.empty(N, 3, device=dev)
@@ -188,7 +191,8 @@ def main():
     torch.cuda.synchronize()
     buf = slots[0].buf
 
-    def step(i, timed=None, slot=None, gather=True):
+    def step(i, timed=None, slot=None, gather=True, nseg=None):
+        nseg = args.segments if nseg is None else nseg
         k = i % len(cams)
         sl = slots[(i % n_streams) if slot is None else slot]
         b_, s, stream = sl.buf, sl.s, sl.stream
@@ -201,7 +205,7 @@ def main():
             timed[0].record(stream)
         lib.vol_render_sh_segmented(N, b_.D_cap, p(b_.mean2d), p(b_.cov2d), p(t["sh"]), p(t["alpha"]), p(b_.start),
                                     p(b_.end), p(b_.ids), p(sl.out), p(topleft), p(rot_dev[k]), 16, nth, ntw, psx, psy,
-                                    H, W, C, 1e-4, p(bg), None, order, p(sl.seg_ws), args.segments, s)
+                                    H, W, C, 1e-4, p(bg), None, order, p(sl.seg_ws), nseg, s)
         if timed is not None:
             timed[1].record(stream)
         with torch.cuda.stream(stream):
@@ -211,7 +215,7 @@ def main():
         lib.vol_render_backward_sh_segmented(N, b_.D_cap, p(b_.mean2d), p(b_.cov2d), p(t["sh"]), p(t["alpha"]),
                                              p(b_.start), p(b_.end), p(b_.ids), p(sl.out), p(sl.g_mean2d), p(sl.g_cov2d),
                                              p(sl.g_sh), p(sl.g_alpha), p(grad_out), p(topleft), p(rot_dev[k]), 16, nth,
-                                             ntw, psx, psy, H, W, C, 1e-4, p(bg), order, p(sl.seg_ws), args.segments, s)
+                                             ntw, psx, psy, H, W, C, 1e-4, p(bg), order, p(sl.seg_ws), nseg, s)
         if timed is not None:
             timed[3].record(stream)
         lib.project_gaussians_backward_masked(N, p(t["mean"]), p(t["qvec"]), p(t["svec"]), p(cam_dev[k]), 1,
@@ -264,10 +268,11 @@ def main():
         barrier()
         t1 = time.perf_counter()
         for i in range(args.steps):
-            step(args.warmup + i, ev1[i], slot=0)
+            step(args.warmup + i, ev1[i], slot=0, nseg=args.latency_segments)
         barrier()
         el1 = time.perf_counter() - t1
         one = {"value": world * args.steps / el1, "ms_per_step": el1 / args.steps * 1e3,
+               "backward_segments_per_tile": args.latency_segments,
                "fwd_kernel_ms": float(np.mean([e[0].elapsed_time(e[1]) for e in ev1])),
                "bwd_kernel_ms": float(np.mean([e[2].elapsed_time(e[3]) for e in ev1]))}
 
@@ -296,7 +301,7 @@ def main():
                                 "cfg4": "BASELINE configs[3]: 100k Gaussians, 64 random-pose cameras at 512x512, camera-sharded",
                                 "cfg1": "BASELINE configs[0]: 1k random Gaussians, 256x256, SH degree 0"}[args.config],
                    "gaussians": N, "visible_after_cull": n_vis, "image": [H, W], "sh_degree": C - 1,
-                   "tile_pairs_D": D, "cameras_per_gpu_per_step": 1, "renders_in_flight": n_streams, "parallelism": f"camera-sharded x{world}",
+                   "tile_pairs_D": D, "cameras_per_gpu_per_step": 1, "renders_in_flight": n_streams, "backward_segments_per_tile": args.segments, "parallelism": f"camera-sharded x{world}",
                    "gather": "rccl all_gather of rendered images" if world > 1 else "none"},
         "roofline": {"bound": "hbm", "kernel": f"k_composite_bwd_sh_mfma<C={C},2> (compositing backward, matrix-core grad_sh)", "achieved": ach, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,

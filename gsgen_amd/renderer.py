@@ -365,9 +365,18 @@ class FrameBuffers:
     """Device buffers of the fused path for one (N, W, H) shape.  D_cap is the capacity of the
     (tile, Gaussian) pair list; `ensure_capacity()` grows it after an overflow."""
 
-    def __init__(self, N, W, H, device, D_cap=None):
+    def __init__(self, N, W, H, device, D_cap=None, segments=1):
+        """segments > 1: the SH backward runs one workgroup per (tile, 32-entry list segment) from
+        checkpoints the forward leaves in `seg_ws` (gsgen_vol_render_sh_segmented) -- shorter tail for
+        a lone render, slightly more total work; 1 (one workgroup per tile) is best when several
+        renders are in flight."""
         self.N, self.W, self.H, self.device = N, W, H, device
         self.nth, self.ntw = n_tiles(H, W)
+        self.segments = int(segments)
+        self.seg_ws = None
+        if self.segments > 1:
+            self.seg_ws = torch.empty(_capi.load().segment_workspace_bytes(self.nth * self.ntw, self.segments),
+                                      device=device, dtype=torch.uint8)
         f = dict(device=device, dtype=torch.float32)
         self.mean2d = torch.empty(N, 2, **f)
         self.cov2d = torch.empty(N, 2, 2, **f)
@@ -451,10 +460,10 @@ class _render_frame(torch.autograd.Function):
         s = _stream(mean)
         with torch.cuda.device(dev):
             if C > 0:
-                lib.vol_render_sh_ordered(buf.N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col), _p(alpha),
-                                          _p(buf.start), _p(buf.end), _p(buf.ids), _p(out), _p(topleft), _p(rot),
-                                          16, buf.nth, buf.ntw, psx, psy, H, W, C, thresh, _p(bg_rgb), _p(T),
-                                          buf.tile_order(), s)
+                lib.vol_render_sh_segmented(buf.N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col), _p(alpha),
+                                            _p(buf.start), _p(buf.end), _p(buf.ids), _p(out), _p(topleft), _p(rot),
+                                            16, buf.nth, buf.ntw, psx, psy, H, W, C, thresh, _p(bg_rgb), _p(T),
+                                            buf.tile_order(), _p(buf.seg_ws), buf.segments, s)
             else:
                 lib.vol_render_start_end_with_T(buf.N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col),
                                                 _p(alpha), _p(buf.start), _p(buf.end), _p(buf.ids),
@@ -484,11 +493,11 @@ class _render_frame(torch.autograd.Function):
         s = _stream(mean)
         with torch.cuda.device(dev):
             if C > 0:
-                lib.vol_render_backward_sh_ordered(N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col), _p(alpha),
-                                                   _p(buf.start), _p(buf.end), _p(buf.ids), _p(out), _p(g_mean2d),
-                                                   _p(g_cov2d), _p(g_col), _p(g_alpha), _p(grad), _p(topleft),
-                                                   _p(rot), 16, buf.nth, buf.ntw, psx, psy, H, W, C, thresh, None,
-                                                   buf.tile_order(), s)
+                lib.vol_render_backward_sh_segmented(N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col), _p(alpha),
+                                                     _p(buf.start), _p(buf.end), _p(buf.ids), _p(out), _p(g_mean2d),
+                                                     _p(g_cov2d), _p(g_col), _p(g_alpha), _p(grad), _p(topleft),
+                                                     _p(rot), 16, buf.nth, buf.ntw, psx, psy, H, W, C, thresh, None,
+                                                     buf.tile_order(), _p(buf.seg_ws), buf.segments, s)
             else:
                 lib.vol_render_backward_start_end(N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col),
                                                   _p(alpha), _p(buf.start), _p(buf.end), _p(buf.ids),
