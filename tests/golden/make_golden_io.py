@@ -88,7 +88,7 @@ def main():
         to_splat(ck, d)
         ply = open(os.path.join(d, "ply", "a_golden.ply"), "rb").read()
         splat = open(os.path.join(d, "splat", "a_golden.splat"), "rb").read()
-    np.savez_compressed(os.path.join(HERE, "io_export.npz"), ply=np.frombuffer(ply, np.uint8), splat=np.frombuffer(splat, np.uint8),
+    np.savez_compressed(os.path.join(HERE, "io", "export.npz"), ply=np.frombuffer(ply, np.uint8), splat=np.frombuffer(splat, np.uint8),
                         **{k: v.numpy() for k, v in p.items()})
     print("ply", len(ply), "bytes; splat", len(splat), "bytes")
 

@@ -1,5 +1,5 @@
 """gsgen_amd/io.py against files written by the reference's own exporters
-(tests/golden/io_export.npz, made by tests/golden/make_golden_io.py) and round trips."""
+(tests/golden/io/export.npz, made by tests/golden/make_golden_io.py) and round trips."""
 import os
 
 import numpy as np
@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def _golden():
-    z = np.load(os.path.join(HERE, "golden", "io_export.npz"))
+    z = np.load(os.path.join(HERE, "golden", "io", "export.npz"))
     params = {k: z[k] for k in ("mean", "qvec", "svec", "color", "alpha")}
     return params, z["ply"].tobytes(), z["splat"].tobytes()
 
