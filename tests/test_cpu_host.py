@@ -365,7 +365,7 @@ def test_emulated_adam_step_matches_torch_cpu(emu):
 def test_emulated_segmented_backward_matches_unsegmented(emu, C, nseg):
     """forward with segment checkpoints + one backward workgroup per (tile, 32-entry segment) ==
     the per-tile backward (lists of 60-150 entries, so several segments and a long last one)"""
-    cam = scenes.Camera(40, 30, fx=40.0)
+    cam = scenes.Camera(32, 16, fx=40.0)
     sc = scenes.random_scene(900, seed=31, svec=0.09, C=C)
     sc["alpha"] = (sc["alpha"] * 0.25).astype(np.float32)  # keep pixels alive deep into the lists
     g = scenes.oracle_geometry(sc, cam)
