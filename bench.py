@@ -283,12 +283,13 @@ def main():
     F = 7 + CC3
     total_b, parts = b_alg_bytes(n_vis, D, P, T, F)
     value = world * args.steps / el
-    traffic = None
-    try:  # HBM bytes per launch of the dominant kernel from the committed PMC passes (cfg2 only)
+    traffic, valu_floor = None, None
+    try:  # per launch of the dominant kernel, from the committed PMC passes (cfg2 only)
         if args.config == "cfg2":
-            traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["k_composite_bwd"]["traffic_bytes"]
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["k_composite_bwd"]
+            traffic, valu_floor = pmc["traffic_bytes"], pmc.get("valu_floor_ms")
     except Exception:
-        traffic = None
+        traffic, valu_floor = None, None
     # dominant kernel = composite backward
     ach = parts["composite_bwd"] / (bwd_ms * 1e-3) / 1e9
     res = {
@@ -315,6 +316,11 @@ def main():
         res["one_render_in_flight"] = one
         res["roofline"]["isolated_launch_ms"] = one["bwd_kernel_ms"]
         res["roofline"]["isolated_achieved"] = parts["composite_bwd"] / (one["bwd_kernel_ms"] * 1e-3) / 1e9
+    if valu_floor is not None:
+        # the kernel is bound by vector-ALU issue, not HBM: time it would take if
+        # every SIMD issued its share of the measured vector instructions back to back
+        res["roofline"]["valu_floor_ms"] = valu_floor
+        res["roofline"]["valu_frac"] = valu_floor / bwd_ms
     if args.breakdown and rank == 0:
         names = ["geometry+bin+sort", "composite_fwd", "zero_grads", "composite_bwd"]
         stage_ev = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(20)]
