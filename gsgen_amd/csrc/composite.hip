@@ -14,7 +14,10 @@
 // exactly as the reference does (suffix = final - prefix), reduces the per-pixel gradient
 // contributions of a Gaussian across the wave with a register reduce-scatter, and issues
 // ONE vector atomic (<= 55 consecutive floats) per (tile, Gaussian) instead of the
-// reference's one LDS atomic per (pixel, Gaussian, component).
+// reference's one LDS atomic per (pixel, Gaussian, component).  The SH backward that runs by
+// default (k_composite_bwd_sh_mfma, further down) moves the 48 SH components of that reduction
+// onto the matrix cores and can be launched per (tile, list segment) from checkpoints the forward
+// leaves behind.
 //
 // Numerics: the per-(pixel, Gaussian) Gaussian is evaluated in fp32 on the fast path (the
 // reference uses fp64 for RGB/scalar, fp32 for SH).  For RGB/scalar the quadratic form is
