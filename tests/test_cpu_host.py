@@ -398,3 +398,40 @@ def test_emulated_segmented_backward_matches_unsegmented(emu, C, nseg):
     with pytest.raises(Exception, match="invalid"):
         emu.vol_render_sh_segmented(N, D, P(m2), P(c2), P(sh), P(al), P(st), P(en), P(ids), P(out1), P(tlp), P(rot), *geo,
                                     P(bg), None, None, None, nseg, None)
+
+
+def test_no_kernel_spills_and_hot_kernels_keep_their_occupancy(tmp_path):
+    """Reads the code-object metadata of the built library (cross-compiled, no GPU needed): no
+    kernel may use scratch memory, and the compositing kernels must keep the register budgets their
+    occupancy was tuned for (profiles/r01_notes.md)."""
+    import shutil
+    from gsgen_amd import _capi
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(os.path.join(llvm, "llvm-readelf")):
+        pytest.skip("no llvm-readelf")
+    so = shutil.copy(_capi.DEFAULT_LIB, tmp_path / "lib.so")
+    subprocess.run([os.path.join(llvm, "llvm-objdump"), "--offloading", so], cwd=tmp_path, capture_output=True, check=True)
+    kernels = {}
+    for f in sorted(os.listdir(tmp_path)):
+        if "amdgcn" not in f:
+            continue
+        txt = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", f], cwd=tmp_path, capture_output=True,
+                             text=True, check=True).stdout
+        for blk in txt.split("- .agpr_count:")[1:]:
+            name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+            kernels[name] = {k: int(re.search(rf"\.{k}:\s+(\d+)", blk).group(1))
+                             for k in ("private_segment_fixed_size", "vgpr_count", "group_segment_fixed_size")}
+    assert len(kernels) > 40
+    spilling = {k: v for k, v in kernels.items() if v["private_segment_fixed_size"] != 0}
+    assert not spilling, spilling
+
+    def find(*parts):
+        hits = [v for k, v in kernels.items() if all(p in k for p in parts)]
+        assert len(hits) == 1, (parts, hits)
+        return hits[0]
+    # default SH backward: 3 wavefronts per SIMD = 6 two-wavefront workgroups per CU (160 KB of LDS)
+    bwd = find("k_composite_bwd_sh_mfmaILi4ELi2E")
+    assert bwd["vgpr_count"] <= 168 and 6 * bwd["group_segment_fixed_size"] <= 160 * 1024
+    fwd = find("k_composite_fwdILi2ELi4ELi1E")      # default SH forward: 4 wavefronts per tile
+    assert fwd["vgpr_count"] <= 128
+    assert find("k_sort_tiles", "PKjS1_PKyPiS4_S4_")["group_segment_fixed_size"] == 0  # register sort: no LDS
