@@ -116,24 +116,29 @@ class BatchRenderer:
         self.slots = [R.FrameBuffers(N, W, H, device, D_cap=D_cap) for _ in range(max_batch)]
         self.streams = [torch.cuda.Stream(device=device) for _ in range(max(1, n_streams))]
         # per camera: cam block (56) | topleft (2) | rotation rows (9) | pad -> 68 floats
-        self._host = torch.empty(max_batch, 68, dtype=torch.float32).pin_memory()
-        self._copied = None  # event: the last upload has left the pinned block
+        # ring of pinned staging blocks: a block is only rewritten once its upload (queued behind
+        # whatever the stream was doing) has left it, so the host does not wait on the GPU per batch
+        self._host = [torch.empty(max_batch, 68, dtype=torch.float32).pin_memory() for _ in range(4)]
+        self._copied = [None] * len(self._host)
+        self._ring = 0
         self._cis = []
 
     def _upload(self, cam_infos, c2ws, frustum_radius, tile_radius):
         B = len(cam_infos)
-        if self._copied is not None:
-            self._copied.synchronize()
-        h = self._host.numpy()
+        slot = self._ring
+        self._ring = (self._ring + 1) % len(self._host)
+        if self._copied[slot] is not None:
+            self._copied[slot].synchronize()
+        h = self._host[slot].numpy()
         for i, (ci, c2w) in enumerate(zip(cam_infos, c2ws)):
             c2w = np.asarray(c2w.detach().cpu() if isinstance(c2w, torch.Tensor) else c2w, np.float32).reshape(-1)[:12]
             ci.pack_into(h[i], c2w, frustum_radius, tile_radius)
             h[i, 56:58] = (-ci.cx / ci.fx, -ci.cy / ci.fy)
             h[i, 58:67] = c2w.reshape(3, 4)[:, :3].reshape(-1)
         # a fresh device block per batch: the rows are saved for the batch's backward
-        dev = self._host[:B].to(self.device, non_blocking=True)
-        self._copied = torch.cuda.Event()
-        self._copied.record(torch.cuda.current_stream(self.device))
+        dev = self._host[slot][:B].to(self.device, non_blocking=True)
+        self._copied[slot] = torch.cuda.Event()
+        self._copied[slot].record(torch.cuda.current_stream(self.device))
         return dev
 
     def _fork(self, B, tensors):
