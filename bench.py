@@ -126,9 +126,6 @@ def main():
     ap.add_argument("--segments", type=int, default=int(os.environ.get("GSGEN_SEGMENTS", "1")),
                     help="backward workgroups per tile in the timed (throughput) region: segments of 32 list entries; "
                          "1 = one workgroup per tile (best with several renders in flight)")
-    ap.add_argument("--store-colours", type=int, default=int(os.environ.get("GSGEN_STORE_COLOURS", "0")),
-                    help="1: the forward keeps every evaluated colour in HBM (3 KB per list entry) and the backward "
-                         "reads them back instead of re-evaluating them")
     ap.add_argument("--latency-segments", type=int, default=8,
                     help="same for the one-render-in-flight pass (uniform work units shorten a lone launch's tail)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("GSGEN_STREAMS", "3")),
@@ -168,7 +165,6 @@ def main():
     grad_out = torch.randn(H, W, 3, device=dev)
     CC3 = 3 * C * C
     p = lambda x: x.data_ptr()  # noqa: E731
-    pc = lambda sl: sl.colours.data_ptr() if sl.colours is not None and sl.colours.numel() >= sl.buf.D_cap * 768 else None  # noqa: E731
     gathered = torch.empty(world, H, W, 3, device=dev) if world > 1 else None
 
     # Independent renders (different cameras of a batch) are issued round-robin on `--streams`
@@ -183,8 +179,6 @@ def main():
                 self.buf = R.FrameBuffers(N, W, H, dev)
                 self.out = torch.empty(H, W, 3, device=dev)
                 self.gflat = torch.empty(N * (7 + CC3), device=dev)  # mean2d(2) | cov2d(4) | alpha(1) | sh
-                self.colours = (torch.empty(lib.colour_store_bytes(self.buf.D_cap) // 4, device=dev)
-                                if args.store_colours else None)
                 self.seg_ws = torch.empty(lib.segment_workspace_bytes(nth * ntw, max(args.segments, args.latency_segments)), device=dev, dtype=torch.uint8)
                 self.g_mean = torch.empty(N, 3, device=dev)
                 self.g_qvec = torch.empty(N, 4, device=dev)
@@ -211,7 +205,7 @@ def main():
             timed[0].record(stream)
         lib.vol_render_sh_segmented(N, b_.D_cap, p(b_.mean2d), p(b_.cov2d), p(t["sh"]), p(t["alpha"]), p(b_.start),
                                     p(b_.end), p(b_.ids), p(sl.out), p(topleft), p(rot_dev[k]), 16, nth, ntw, psx, psy,
-                                    H, W, C, 1e-4, p(bg), None, order, p(sl.seg_ws), nseg, pc(sl), s)
+                                    H, W, C, 1e-4, p(bg), None, order, p(sl.seg_ws), nseg, s)
         if timed is not None:
             timed[1].record(stream)
         with torch.cuda.stream(stream):
@@ -221,7 +215,7 @@ def main():
         lib.vol_render_backward_sh_segmented(N, b_.D_cap, p(b_.mean2d), p(b_.cov2d), p(t["sh"]), p(t["alpha"]),
                                              p(b_.start), p(b_.end), p(b_.ids), p(sl.out), p(sl.g_mean2d), p(sl.g_cov2d),
                                              p(sl.g_sh), p(sl.g_alpha), p(grad_out), p(topleft), p(rot_dev[k]), 16, nth,
-                                             ntw, psx, psy, H, W, C, 1e-4, p(bg), order, p(sl.seg_ws), nseg, pc(sl), s)
+                                             ntw, psx, psy, H, W, C, 1e-4, p(bg), order, p(sl.seg_ws), nseg, s)
         if timed is not None:
             timed[3].record(stream)
         lib.project_gaussians_backward_masked(N, p(t["mean"]), p(t["qvec"]), p(t["svec"]), p(cam_dev[k]), 1,

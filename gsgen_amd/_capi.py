@@ -47,9 +47,9 @@ SIGNATURES = {
     "gsgen_vol_render_backward_sh_ordered": [u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                              vp, u32, u32, u32, f32, f32, u32, u32, u32, f32, vp, vp, vp],
     "gsgen_vol_render_sh_segmented": [u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, u32, f32, f32,
-                                      u32, u32, u32, f32, vp, vp, vp, vp, u32, vp, vp],
+                                      u32, u32, u32, f32, vp, vp, vp, vp, u32, vp],
     "gsgen_vol_render_backward_sh_segmented": [u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
-                                               vp, u32, u32, u32, f32, f32, u32, u32, u32, f32, vp, vp, vp, u32, vp, vp],
+                                               vp, u32, u32, u32, f32, f32, u32, u32, u32, f32, vp, vp, vp, u32, vp],
     "gsgen_frame_geometry": [u32, vp, vp, vp, vp, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp],
 }
 PTR_FUNCS = {
@@ -59,7 +59,6 @@ SIZE_FUNCS = {
     "gsgen_tile_culling_workspace_bytes": [u32, u32, u32],
     "gsgen_frame_workspace_bytes": [u32, u32, u32],
     "gsgen_segment_workspace_bytes": [u32, u32],
-    "gsgen_colour_store_bytes": [u32],
 }
 EXPORTS = sorted(list(SIGNATURES) + list(SIZE_FUNCS) + list(PTR_FUNCS) + ["gsgen_version", "gsgen_error_string"])
 

@@ -33,18 +33,18 @@
 namespace gs {
 
 // ---- LDS staging ---------------------------------------------------------------------------
-template <int MODE, int CB, int KB = kBatch, bool WITH_COL = true>
+template <int MODE, int CB, int KB = kBatch>
 struct Stage {
   using TR = Traits<MODE, CB>;
   float mx[KB], my[KB], a[KB];
   float c0[KB], c1[KB], c2[KB], c3[KB];
   float p0[KB], p1[KB], p2[KB];  // RGB/scalar: scaled Cholesky factor; SH: p0 = kk, p1 = 1/det
   int id[KB];
-  alignas(16) float col[WITH_COL ? KB * TR::NCOLP : 4];  // (no colour block: the stored-colour backward)
+  alignas(16) float col[KB * TR::NCOLP];
 };
 
-template <int MODE, int CB, int NT, int KB = kBatch, bool WITH_COL = true>
-__device__ __forceinline__ void stage_batch(Stage<MODE, CB, KB, WITH_COL> &S, const CompParams &p, int list_base,
+template <int MODE, int CB, int NT, int KB = kBatch>
+__device__ __forceinline__ void stage_batch(Stage<MODE, CB, KB> &S, const CompParams &p, int list_base,
                                             int nb) {
   using TR = Traits<MODE, CB>;
   const int t = (int)threadIdx.x;
@@ -65,7 +65,6 @@ __device__ __forceinline__ void stage_batch(Stage<MODE, CB, KB, WITH_COL> &S, co
     S.c0[t] = c0; S.c1[t] = c1; S.c2[t] = c2; S.c3[t] = c3;
     S.p0[t] = p0; S.p1[t] = p1; S.p2[t] = p2;
   }
-  if constexpr (!WITH_COL) return;
   if constexpr (MODE == MODE_SH) __syncthreads();  // S.id is consumed below by other lanes
   // colour / scalar / SH coefficients: NCOL contiguous floats per record in HBM
   if constexpr (MODE == MODE_SH && TR::CCP == TR::CC) {
@@ -91,8 +90,8 @@ __device__ __forceinline__ void stage_batch(Stage<MODE, CB, KB, WITH_COL> &S, co
 }
 
 // per-Gaussian values broadcast from LDS into registers
-template <int MODE, int CB, int KB, bool WITH_COL>
-__device__ __forceinline__ GRec load_rec(const Stage<MODE, CB, KB, WITH_COL> &S, int g) {
+template <int MODE, int CB, int KB>
+__device__ __forceinline__ GRec load_rec(const Stage<MODE, CB, KB> &S, int g) {
   GRec r;
   r.mx = S.mx[g]; r.my = S.my[g]; r.a = S.a[g];
   r.c0 = S.c0[g]; r.c1 = S.c1[g]; r.c2 = S.c2[g]; r.c3 = S.c3[g];
@@ -238,10 +237,7 @@ __global__ void __launch_bounds__(256 / PPL) k_composite_fwd(CompParams p) {
             v2f s2 = q[0] * Yp[j][0];
 #pragma unroll
             for (int k = 1; k < TR::NPAIR; ++k) s2 = fma2(q[k], Yp[j][k], s2);
-            const float yv = sigmoid_fast(s2[0] + s2[1]);
-            if (p.yv != nullptr)  // one coalesced 256-byte row per wavefront, channel and pixel row
-              p.yv[((size_t)(st + base + g) * 3 + c) * 256 + (ly0 + j * ROWS) * 16 + lx] = yv;
-            acc[j][c] += w[j] * yv;
+            acc[j][c] += w[j] * sigmoid_fast(s2[0] + s2[1]);
           }
         }
 #pragma unroll
@@ -566,9 +562,7 @@ __device__ __forceinline__ int frag_dw(int row, int lane, int s) {
 
 // PPL = 4: one wavefront per tile.  PPL = 2: two wavefronts per tile, each contracting its own 128
 // pixels (the partial sums meet in the atomics); the records are staged once for both.
-// STORED: the forward kept every evaluated colour (CompParams::yv); they are read back (one entry
-// ahead) instead of being re-evaluated, which also frees the 16 x PPL registers of the basis table.
-template <int CB, int PPL, bool STORED>
+template <int CB, int PPL>
 __global__ void __launch_bounds__(256 / PPL) __attribute__((amdgpu_waves_per_eu(2)))
 k_composite_bwd_sh_mfma(CompParams p) {
   constexpr int MODE = MODE_SH;
@@ -578,7 +572,7 @@ k_composite_bwd_sh_mfma(CompParams p) {
   constexpr int NROW = kNF * 3;
   static_assert(PPL == 4 || PPL == 2 || PPL == 1, "one, two or four wavefronts per tile");
   static_assert(NROW >= 8 && kNF <= 4, "basis table is transposed through the A buffers 8 rows at a time");
-  __shared__ Stage<MODE, CB, kKBm, !STORED> S;
+  __shared__ Stage<MODE, CB, kKBm> S;
   __shared__ alignas(16) uint32_t Ahi_[NW][NROW * MC::ROW_DW];
   __shared__ alignas(16) uint32_t Alo_[NW][NROW * MC::ROW_DW];
   __shared__ int fid_[NW][4];
@@ -632,7 +626,7 @@ k_composite_bwd_sh_mfma(CompParams p) {
     }
     if (__syncthreads_or((int)any) == 0) return;  // every pixel of the tile stopped before this segment
   }
-  if constexpr (TR::CCP != TR::CC && !STORED) {
+  if constexpr (TR::CCP != TR::CC) {
     for (int e = t; e < kKBm * TR::NCOLP; e += NT) S.col[e] = 0.0f;
   }
   // per-pixel SH basis, twice: Bh/Bl = the table in B-operand layout (lane l: basis l & 15, 8
@@ -686,8 +680,8 @@ k_composite_bwd_sh_mfma(CompParams p) {
       wave_lds_sync();
     }
   }
-  v2f Yp[STORED ? 1 : PPL][STORED ? 1 : TR::NPAIR];
-  if constexpr (!STORED) {
+  v2f Yp[PPL][TR::NPAIR];
+  {
     float pxo = px;
     pxo = opaque(pxo);  // a second evaluation, not a second live copy of the first
 #pragma unroll
@@ -699,16 +693,6 @@ k_composite_bwd_sh_mfma(CompParams p) {
       __builtin_amdgcn_sched_barrier(0);  // one pixel's temporaries at a time
     }
   }
-  // stored colours of list entry e at this lane's pixels
-  const float *yv_base = STORED ? p.yv + (size_t)st * 768 + (size_t)ly0 * 16 + lx : nullptr;
-  auto load_yv = [&](int e, float (&dst)[3][PPL]) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-      for (int j = 0; j < PPL; ++j) dst[c][j] = yv_base[(size_t)e * 768 + c * 256 + j * ROWS * 16];
-  };
-  float yv_next[3][PPL];
-  if constexpr (STORED) load_yv(e_lo, yv_next);
 
   // rem = final - (prefix colour including the current splat): the suffix the reference forms as
   // final - Cpre_incl (vol_render_sh.h:328-333), carried as one running value per channel
@@ -763,7 +747,7 @@ k_composite_bwd_sh_mfma(CompParams p) {
   for (int base = e_lo; base < e_hi; base += kKBm) {
     const int nb = min(kKBm, e_hi - base);
     if (base > e_lo) __syncthreads();
-    stage_batch<MODE, CB, NT, kKBm, !STORED>(S, p, st + base, nb);
+    stage_batch<MODE, CB, NT, kKBm>(S, p, st + base, nb);
     __syncthreads();
 
     for (int g = 0; g < nb; ++g) {
@@ -772,14 +756,6 @@ k_composite_bwd_sh_mfma(CompParams p) {
       for (int j = 0; j < PPL; ++j) any_alive |= alive[j];
       if (__ballot(any_alive) == 0ull) break;
 
-      float yv_cur[3][PPL];
-      if constexpr (STORED) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-#pragma unroll
-          for (int j = 0; j < PPL; ++j) yv_cur[c][j] = yv_next[c][j];
-        if (base + g + 1 < e_hi) load_yv(base + g + 1, yv_next);  // in flight during this entry
-      }
       // wave-uniform record: keep it in scalar registers (the vector file is the tight resource)
       GRec r = load_rec(S, g);
       auto uni = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
@@ -815,11 +791,9 @@ k_composite_bwd_sh_mfma(CompParams p) {
       if (lane == 0) fid[nst] = S.id[g];
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        v2f q[STORED ? 1 : TR::NPAIR];
-        if constexpr (!STORED) {
+        v2f q[TR::NPAIR];
 #pragma unroll
-          for (int k = 0; k < TR::NPAIR; ++k) q[k] = *reinterpret_cast<const v2f *>(cg + c * TR::CCP + 2 * k);
-        }
+        for (int k = 0; k < TR::NPAIR; ++k) q[k] = *reinterpret_cast<const v2f *>(cg + c * TR::CCP + 2 * k);
         float gsv[PPL], go[PPL];
         if constexpr (PPL == 4) {
           const float4 g4 = *reinterpret_cast<const float4 *>(&Go[t * 12 + c * 4]);  // lane-private
@@ -832,15 +806,10 @@ k_composite_bwd_sh_mfma(CompParams p) {
         }
 #pragma unroll
         for (int j = 0; j < PPL; ++j) {
-          float yv;
-          if constexpr (STORED) {
-            yv = con[j] ? yv_cur[c][j] : 0.0f;  // rows the forward skipped were never written
-          } else {
-            v2f s2 = q[0] * Yp[j][0];
+          v2f s2 = q[0] * Yp[j][0];
 #pragma unroll
-            for (int k = 1; k < TR::NPAIR; ++k) s2 = fma2(q[k], Yp[j][k], s2);
-            yv = sigmoid_fast(s2[0] + s2[1]);
-          }
+          for (int k = 1; k < TR::NPAIR; ++k) s2 = fma2(q[k], Yp[j][k], s2);
+          const float yv = sigmoid_fast(s2[0] + s2[1]);
           rem[j][c] -= w[j] * yv;
           gsv[j] = w[j] * (yv * (1.0f - yv)) * go[j];
           pAG[j] += go[j] * (yv * Tr[j] - rem[j][c] * inv1m[j]);
@@ -924,13 +893,9 @@ static int launch_bwd(const CompParams &p_, hipStream_t s) {
   if constexpr (MODE == MODE_SH) {
     if (ppl == 4 && mfma != 0) {
       const uint32_t ng = nblk * (uint32_t)(p.nseg > 1 ? p.nseg : 1);
-      if (p.yv != nullptr) {  // colours stored by the forward: only built for the default two-wavefront form
-        hipLaunchKernelGGL((k_composite_bwd_sh_mfma<CB, 2, true>), dim3(ng), dim3(128), 0, s, p);
-        return (int)hipGetLastError();
-      }
-      if (mfma == 1) hipLaunchKernelGGL((k_composite_bwd_sh_mfma<CB, 1, false>), dim3(ng), dim3(256), 0, s, p);
-      else if (mfma == 2) hipLaunchKernelGGL((k_composite_bwd_sh_mfma<CB, 2, false>), dim3(ng), dim3(128), 0, s, p);
-      else hipLaunchKernelGGL((k_composite_bwd_sh_mfma<CB, 4, false>), dim3(ng), dim3(64), 0, s, p);
+      if (mfma == 1) hipLaunchKernelGGL((k_composite_bwd_sh_mfma<CB, 1>), dim3(ng), dim3(256), 0, s, p);
+      else if (mfma == 2) hipLaunchKernelGGL((k_composite_bwd_sh_mfma<CB, 2>), dim3(ng), dim3(128), 0, s, p);
+      else hipLaunchKernelGGL((k_composite_bwd_sh_mfma<CB, 4>), dim3(ng), dim3(64), 0, s, p);
       return (int)hipGetLastError();
     }
   }
@@ -1014,8 +979,6 @@ int gsgen_vol_render_rgbd(uint32_t N, uint32_t D, const float *mean, const float
   return launch_fwd<MODE_RGBD, 1>(p, (hipStream_t)stream);
 }
 
-size_t gsgen_colour_store_bytes(uint32_t D_cap) { return (size_t)D_cap * 3 * 256 * sizeof(float); }
-
 size_t gsgen_segment_workspace_bytes(uint32_t n_tiles, uint32_t n_segments) {
   return (size_t)n_tiles * 256 * (sizeof(float4) * (size_t)(n_segments > 1 ? n_segments : 1) + sizeof(int));
 }
@@ -1029,7 +992,7 @@ int gsgen_vol_render_sh_ordered(uint32_t N, uint32_t D, const float *mean, const
                                 const uint32_t *tile_order, gsgen_stream_t stream) {
   return gsgen_vol_render_sh_segmented(N, D, mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out, topleft,
                                        c2w, tile_size, n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H, W, C,
-                                       thresh, bg_rgb, T, tile_order, nullptr, 0, nullptr, stream);
+                                       thresh, bg_rgb, T, tile_order, nullptr, 0, stream);
 }
 
 int gsgen_vol_render_sh_segmented(uint32_t N, uint32_t D, const float *mean, const float *cov,
@@ -1039,7 +1002,7 @@ int gsgen_vol_render_sh_segmented(uint32_t N, uint32_t D, const float *mean, con
                                   uint32_t n_tiles_w, float pixel_size_x, float pixel_size_y, uint32_t H,
                                   uint32_t W, uint32_t C, float thresh, const float *bg_rgb, float *T,
                                   const uint32_t *tile_order, void *segment_workspace, uint32_t n_segments,
-                                  float *colour_store, gsgen_stream_t stream) {
+                                  gsgen_stream_t stream) {
   if (int e = check_common(tile_size, start, end, out)) return e;
   if (n_segments > 1 && segment_workspace == nullptr) return GSGEN_EINVAL;
   if (C < 1 || C > 4) return GSGEN_EUNSUPPORTED;  // reference dispatches C = 1..4 only (render.cu:507-544)
@@ -1057,7 +1020,6 @@ int gsgen_vol_render_sh_segmented(uint32_t N, uint32_t D, const float *mean, con
     p.ckpt = reinterpret_cast<float4 *>(segment_workspace);
     p.stop = reinterpret_cast<int *>(p.ckpt + (size_t)n_tiles_h * n_tiles_w * 256 * n_segments);
   }
-  p.yv = colour_store;
   hipStream_t s = (hipStream_t)stream;
   switch (C) {
     case 1: return launch_fwd<MODE_SH, 1>(p, s);

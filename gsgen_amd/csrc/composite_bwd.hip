@@ -435,7 +435,7 @@ int gsgen_vol_render_backward_sh_ordered(uint32_t N, uint32_t D, const float *me
   return gsgen_vol_render_backward_sh_segmented(N, D, mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out,
                                                 grad_mean, grad_cov, grad_sh_coeffs, grad_alpha, grad_out, topleft,
                                                 c2w, tile_size, n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H,
-                                                W, C, thresh, bg_rgb, tile_order, nullptr, 0, nullptr, stream);
+                                                W, C, thresh, bg_rgb, tile_order, nullptr, 0, stream);
 }
 
 int gsgen_vol_render_backward_sh_segmented(uint32_t N, uint32_t D, const float *mean, const float *cov,
@@ -448,7 +448,7 @@ int gsgen_vol_render_backward_sh_segmented(uint32_t N, uint32_t D, const float *
                                            uint32_t H, uint32_t W, uint32_t C, float thresh,
                                            const float *bg_rgb, const uint32_t *tile_order,
                                            const void *segment_workspace, uint32_t n_segments,
-                                           const float *colour_store, gsgen_stream_t stream) {
+                                           gsgen_stream_t stream) {
   (void)bg_rgb;  // the background only enters through `out` (= final incl. bg*T)
   if (int e = check_common(tile_size, start, end, out)) return e;
   if (n_segments > 1 && segment_workspace == nullptr) return GSGEN_EINVAL;
@@ -468,7 +468,6 @@ int gsgen_vol_render_backward_sh_segmented(uint32_t N, uint32_t D, const float *
     p.ckpt = reinterpret_cast<float4 *>(const_cast<void *>(segment_workspace));
     p.stop = reinterpret_cast<int *>(p.ckpt + (size_t)n_tiles_h * n_tiles_w * 256 * n_segments);
   }
-  p.yv = const_cast<float *>(colour_store);
   return launch_bwd(MODE_SH, (int)C, p, (hipStream_t)stream);
 }
 

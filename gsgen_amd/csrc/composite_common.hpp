@@ -32,10 +32,6 @@ struct CompParams {
   float4 *ckpt;  // [tile][nseg][256 pixels, row-major in the tile]: T, prefix rgb
   int *stop;     // [tile][256]: first list index the pixel did not process (n if it never saturated)
   int nseg;
-  // Stored colours (SH): the forward writes the post-sigmoid colour of every (list entry, pixel) it
-  // evaluates, [list index][channel][256 pixels row-major in the tile]; the backward reads them back
-  // instead of re-evaluating 3 x 16 MACs + 3 sigmoids per pair (HBM traffic for VALU work).
-  float *yv;
 };
 constexpr int kSegLen = 32;
 

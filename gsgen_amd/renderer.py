@@ -365,7 +365,7 @@ class FrameBuffers:
     """Device buffers of the fused path for one (N, W, H) shape.  D_cap is the capacity of the
     (tile, Gaussian) pair list; `ensure_capacity()` grows it after an overflow."""
 
-    def __init__(self, N, W, H, device, D_cap=None, segments=1, store_colours=False):
+    def __init__(self, N, W, H, device, D_cap=None, segments=1):
         """segments > 1: the SH backward runs one workgroup per (tile, 32-entry list segment) from
         checkpoints the forward leaves in `seg_ws` (gsgen_vol_render_sh_segmented) -- shorter tail for
         a lone render, slightly more total work; 1 (one workgroup per tile) is best when several
@@ -373,10 +373,6 @@ class FrameBuffers:
         self.N, self.W, self.H, self.device = N, W, H, device
         self.nth, self.ntw = n_tiles(H, W)
         self.segments = int(segments)
-        # store_colours: the SH forward keeps every evaluated colour (3 KB per list entry, D_cap of
-        # them) and the backward reads them back instead of re-evaluating them
-        self.store_colours = bool(store_colours)
-        self.colours = None
         self.seg_ws = None
         if self.segments > 1:
             self.seg_ws = torch.empty(_capi.load().segment_workspace_bytes(self.nth * self.ntw, self.segments),
@@ -397,9 +393,6 @@ class FrameBuffers:
         self.ids = torch.empty(self.D_cap, device=self.device, dtype=torch.int32)
         nbytes = _capi.load().frame_workspace_bytes(self.N, self.D_cap, self.nth * self.ntw)
         self.ws = torch.empty(nbytes, device=self.device, dtype=torch.uint8)
-        if getattr(self, "store_colours", False):
-            self.colours = torch.empty(_capi.load().colour_store_bytes(self.D_cap) // 4, device=self.device,
-                                       dtype=torch.float32)
 
     def tile_order(self):
         """device address of the longest-list-first launch order written by frame_geometry"""
@@ -470,7 +463,7 @@ class _render_frame(torch.autograd.Function):
                 lib.vol_render_sh_segmented(buf.N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col), _p(alpha),
                                             _p(buf.start), _p(buf.end), _p(buf.ids), _p(out), _p(topleft), _p(rot),
                                             16, buf.nth, buf.ntw, psx, psy, H, W, C, thresh, _p(bg_rgb), _p(T),
-                                            buf.tile_order(), _p(buf.seg_ws), buf.segments, _p(buf.colours), s)
+                                            buf.tile_order(), _p(buf.seg_ws), buf.segments, s)
             else:
                 lib.vol_render_start_end_with_T(buf.N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col),
                                                 _p(alpha), _p(buf.start), _p(buf.end), _p(buf.ids),
@@ -504,7 +497,7 @@ class _render_frame(torch.autograd.Function):
                                                      _p(buf.start), _p(buf.end), _p(buf.ids), _p(out), _p(g_mean2d),
                                                      _p(g_cov2d), _p(g_col), _p(g_alpha), _p(grad), _p(topleft),
                                                      _p(rot), 16, buf.nth, buf.ntw, psx, psy, H, W, C, thresh, None,
-                                                     buf.tile_order(), _p(buf.seg_ws), buf.segments, _p(buf.colours), s)
+                                                     buf.tile_order(), _p(buf.seg_ws), buf.segments, s)
             else:
                 lib.vol_render_backward_start_end(N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col),
                                                   _p(alpha), _p(buf.start), _p(buf.end), _p(buf.ids),

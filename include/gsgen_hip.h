@@ -230,16 +230,8 @@ int gsgen_vol_render_backward_sh_ordered(uint32_t N, uint32_t D, const float *me
  * 32-entry segment) -- uniform work units, n_segments per tile (the last one takes whatever
  * remains).  Same results up to the rounding of `final - prefix`.  n_segments <= 1 or a NULL
  * workspace: exactly the *_ordered entry points.  The workspace written by the forward must be
- * handed unchanged to the backward of the same frame.
- *
- * Stored colours.  colour_store (gsgen_colour_store_bytes(D) = D * 3 * 256 floats, or NULL): the
- * forward writes the post-sigmoid colour of every (list entry, pixel) it evaluates, the backward
- * reads them back instead of re-evaluating 3 x 16 MACs + 3 sigmoids per pair -- the path is bound
- * by vector-ALU issue with HBM mostly idle, so this trades ~0.8 KB of traffic per evaluated (tile,
- * entry) each way for a third of the backward's arithmetic.  Needs the same list layout (start /
- * end / gaussian_ids) in both calls; only list entries the forward reached are touched. */
+ * handed unchanged to the backward of the same frame. */
 size_t gsgen_segment_workspace_bytes(uint32_t n_tiles, uint32_t n_segments);
-size_t gsgen_colour_store_bytes(uint32_t D);
 int gsgen_vol_render_sh_segmented(uint32_t N, uint32_t D, const float *mean, const float *cov,
                                   const float *sh_coeffs, const float *alpha, const int *start,
                                   const int *end, const int *gaussian_ids, float *out, const float *topleft,
@@ -247,7 +239,7 @@ int gsgen_vol_render_sh_segmented(uint32_t N, uint32_t D, const float *mean, con
                                   uint32_t n_tiles_w, float pixel_size_x, float pixel_size_y, uint32_t H,
                                   uint32_t W, uint32_t C, float thresh, const float *bg_rgb, float *T,
                                   const uint32_t *tile_order, void *segment_workspace, uint32_t n_segments,
-                                  float *colour_store, gsgen_stream_t stream);
+                                  gsgen_stream_t stream);
 int gsgen_vol_render_backward_sh_segmented(uint32_t N, uint32_t D, const float *mean, const float *cov,
                                            const float *sh_coeffs, const float *alpha, const int *start,
                                            const int *end, const int *gaussian_ids, const float *out,
@@ -258,7 +250,7 @@ int gsgen_vol_render_backward_sh_segmented(uint32_t N, uint32_t D, const float *
                                            uint32_t H, uint32_t W, uint32_t C, float thresh,
                                            const float *bg_rgb, const uint32_t *tile_order,
                                            const void *segment_workspace, uint32_t n_segments,
-                                           const float *colour_store, gsgen_stream_t stream);
+                                           gsgen_stream_t stream);
 
 /* Fused RGB + auxiliary heads: what render_one does in four compositing passes
  * (gs/gaussian_splatting.py:1304-1403: rgb, depth, opacity = scalar 1, depth^2) in one.

@@ -381,26 +381,23 @@ def test_emulated_segmented_backward_matches_unsegmented(emu, C, nseg):
     geo = (16, nth, ntw, 1 / cam.fx, 1 / cam.fy, H, W, C, 1e-4)
     emu.vol_render_sh_ordered(N, D, P(m2), P(c2), P(sh), P(al), P(st), P(en), P(ids), P(out0), P(tlp), P(rot), *geo, P(bg),
                               None, None, None)
-    store = np.full(emu.colour_store_bytes(D) // 4, np.nan, np.float32)  # rows the forward skips stay NaN
     emu.vol_render_sh_segmented(N, D, P(m2), P(c2), P(sh), P(al), P(st), P(en), P(ids), P(out1), P(tlp), P(rot), *geo, P(bg),
-                                None, None, P(ws), nseg, P(store), None)
+                                None, None, P(ws), nseg, None)
     assert np.array_equal(out0, out1)
     stop = ws[nth * ntw * nseg * 256 * 16:].view(np.int32).reshape(nth * ntw, 256)
     assert stop.max() <= (en - st).max() and (stop > 32).any()
     go = np.random.default_rng(5).normal(size=(H, W, 3)).astype(np.float32)
     res = []
-    for seg, col in ((0, None), (nseg, None), (nseg, store), (0, store)):
+    for seg in (0, nseg):
         gm = np.zeros((N, 2), np.float32); gc = np.zeros((N, 4), np.float32); gs_ = np.zeros_like(sh); ga = np.zeros(N, np.float32)
         emu.vol_render_backward_sh_segmented(N, D, P(m2), P(c2), P(sh), P(al), P(st), P(en), P(ids), P(out0), P(gm), P(gc), P(gs_),
-                                             P(ga), P(go), P(tlp), P(rot), *geo, P(bg), None, P(ws) if seg else None, seg,
-                                             P(col), None)
+                                             P(ga), P(go), P(tlp), P(rot), *geo, P(bg), None, P(ws) if seg else None, seg, None)
         res.append((gm, gc, gs_, ga))
-    for other in res[1:]:  # segmented, segmented + stored colours, stored colours alone: all == per-tile recompute
-        for a_, b_ in zip(res[0], other):
-            assert np.abs(a_ - b_).max() <= 2e-5 * np.abs(a_).max()
+    for a_, b_ in zip(*res):
+        assert np.abs(a_ - b_).max() <= 2e-5 * np.abs(a_).max()
     with pytest.raises(Exception, match="invalid"):
         emu.vol_render_sh_segmented(N, D, P(m2), P(c2), P(sh), P(al), P(st), P(en), P(ids), P(out1), P(tlp), P(rot), *geo,
-                                    P(bg), None, None, None, nseg, None, None)
+                                    P(bg), None, None, None, nseg, None)
 
 
 def test_no_kernel_spills_and_hot_kernels_keep_their_occupancy(tmp_path):
