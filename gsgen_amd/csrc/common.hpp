@@ -155,6 +155,24 @@ __device__ __forceinline__ void wave_reduce_scatter(float (&v)[P]) {
   reduce_scatter_level<P, 0>(v);
 }
 
+// Only the log2(P) halving levels: every lane ends with the partial sum of component
+// scatter_comp<P>(lane) over the lanes that agree with it on the remaining lane bits (64 / P
+// partials per component, to be combined by the caller -- e.g. by the atomics that follow anyway).
+template <int P, int K>
+__device__ __forceinline__ void reduce_scatter_halving_level(float (&v)[P]) {
+  if constexpr (K < ilog2c(P)) {
+    constexpr int L = kLaneDist[K];
+    constexpr int S = P >> (K + 1);
+#pragma unroll
+    for (int i = 0; i < S; ++i) v[i] = xchg_any<L>(v[i], v[i + S]);
+    reduce_scatter_halving_level<P, K + 1>(v);
+  }
+}
+template <int P>
+__device__ __forceinline__ void wave_reduce_scatter_partial(float (&v)[P]) {
+  reduce_scatter_halving_level<P, 0>(v);
+}
+
 // ---- wave64 prefix scans on DPP (GCN/CDNA row_shr + row_bcast idiom, 7 fused steps) --------
 constexpr int kDppRowBcast15 = 0x142;  // lane 15 of each row -> every lane of the next row
 constexpr int kDppRowBcast31 = 0x143;  // lane 31 -> rows 2 and 3
@@ -188,6 +206,16 @@ __device__ __forceinline__ float wave_scan_mul(float x) {
   v *= dpp_get<kDppRowBcast31, 0xc, 0xf>(1.0f, v);
   return v;
 }
+// Sum over each aligned group of 8 lanes, delivered to the group's last lane ((lane & 7) == 7):
+// three dependent row-shift adds (the xor-butterfly all-reduce costs nine instructions and gives
+// every lane a copy nobody needs).
+__device__ __forceinline__ float group8_sum_to_last(float v) {
+  v += dpp_get<kDppRowShr + 4, 0xf, 0xf>(0.0f, v);
+  v += dpp_get<kDppRowShr + 2, 0xf, 0xf>(0.0f, v);
+  v += dpp_get<kDppRowShr + 1, 0xf, 0xf>(0.0f, v);
+  return v;
+}
+
 // value of the previous lane (lane 0 receives `identity`)
 __device__ __forceinline__ float wave_shift_up(float identity, float x) {
   return dpp_get<kDppWaveShr1, 0xf, 0xf>(identity, x);

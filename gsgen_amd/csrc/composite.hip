@@ -841,9 +841,12 @@ k_composite_bwd_sh_mfma(CompParams p) {
       }
       gr[4] = gr[3];
       gr[6] = gr[6] / r.a;  // a contributing splat has a >= 1/255
-      wave_reduce_scatter<8>(gr);
+      // three halving levels (lane distances 32, 16, 8) leave 8 partials per component in 8
+      // consecutive lanes; three row-shift adds bring their sum to the last of them
+      wave_reduce_scatter_partial<8>(gr);
+      gr[0] = group8_sum_to_last(gr[0]);
       const int comp = scatter_comp<8>(lane);
-      if (scatter_owner<8>(lane) && comp < 7) {
+      if ((lane & 7) == 7 && comp < 7) {
         const size_t id = (size_t)S.id[g];
         float *dst;
         if (comp < 2) dst = p.g_mean + 2 * id + comp;
