@@ -646,7 +646,7 @@ k_composite_bwd_sh_mfma(CompParams p) {
     for (int k = 0; k < 16; ++k) Y[k] = 0.0f;
     sh_basis<CB>(dx, dy, dz, *reinterpret_cast<float (*)[TR::CC]>(&Y[0]));
   };
-  uint4 Bh[KS], Bl[KS];
+  u32x4 Bh[KS], Bl[KS];
   {
     float Yf[PPL][16];
 #pragma unroll
@@ -669,11 +669,11 @@ k_composite_bwd_sh_mfma(CompParams p) {
         for (int s = 0; s < KS; ++s) {
           if (half * 8 + b < TR::CC) {
             const int dw = frag_dw<PPL>(b, lane, s);
-            Bh[s] = *reinterpret_cast<const uint4 *>(Ahi + dw);
-            Bl[s] = *reinterpret_cast<const uint4 *>(Alo + dw);
+            Bh[s] = *reinterpret_cast<const u32x4 *>(Ahi + dw);
+            Bl[s] = *reinterpret_cast<const u32x4 *>(Alo + dw);
           } else {
-            Bh[s] = uint4{0u, 0u, 0u, 0u};
-            Bl[s] = uint4{0u, 0u, 0u, 0u};
+            Bh[s] = u32x4_zero();
+            Bl[s] = u32x4_zero();
           }
         }
       }
@@ -720,19 +720,33 @@ k_composite_bwd_sh_mfma(CompParams p) {
   auto flush = [&]() {
     wave_lds_sync();
     f32x4 acc0 = f32x4_zero(), acc1 = f32x4_zero(), acc2 = f32x4_zero();
+    // the chain, KG k-steps at a time, under the three rules of gsgen_mfma.hpp
+    constexpr int KG = KS < 4 ? KS : 4;
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const uint4 ah = *reinterpret_cast<const uint4 *>(Ahi + a_dw + 16 * s);
-      const uint4 al = *reinterpret_cast<const uint4 *>(Alo + a_dw + 16 * s);
-      acc0 = mfma_16x16x32_bf16(ah, Bh[s], acc0);
-      acc1 = mfma_16x16x32_bf16(ah, Bl[s], acc1);
-      acc2 = mfma_16x16x32_bf16(al, Bh[s], acc2);
-      // Keep every k-step's "two LDS reads, wait, three in-place MFMAs" together.  Left free, the
-      // ROCm 7.2 scheduler renames the accumulators (SrcC != vDst) and lets the next step's
-      // ds_read_b128 land in a register a queued MFMA still reads as SrcC; with a second wave
-      // feeding the same matrix core that corrupted accumulators AND registers the allocator had
-      // already handed to loop state (profiles/r01_notes.md, "MFMA chain hazard").
-      mfma_step_fence(acc0, acc1, acc2);
+    for (int s0 = 0; s0 < KS; s0 += KG) {
+      __builtin_amdgcn_sched_barrier(0);
+      u32x4 ah[KG], al[KG];
+#pragma unroll
+      for (int s = 0; s < KG; ++s) {
+        ah[s] = *reinterpret_cast<const u32x4 *>(Ahi + a_dw + 16 * (s0 + s));
+        al[s] = *reinterpret_cast<const u32x4 *>(Alo + a_dw + 16 * (s0 + s));
+      }
+      if constexpr (KG == 4) {
+        mfma_operands_ready(ah[0], ah[1], ah[2], ah[3]);
+        mfma_operands_ready(al[0], al[1], al[2], al[3]);
+      } else {
+        mfma_operands_ready(ah[0], ah[1]);
+        mfma_operands_ready(al[0], al[1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < KG; ++s) {
+        acc0 = mfma_16x16x32_bf16(ah[s], Bh[s0 + s], acc0);
+        acc1 = mfma_16x16x32_bf16(ah[s], Bl[s0 + s], acc1);
+        acc2 = mfma_16x16x32_bf16(al[s], Bh[s0 + s], acc2);
+      }
+      mfma_drain(acc0, acc1, acc2);
+      __builtin_amdgcn_sched_barrier(0);
     }
     const int slot = lane >> 4, b = lane & 15;
     if (slot < nst && b < TR::CC) {

@@ -10,6 +10,7 @@
 namespace gs {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // one 128-bit MFMA operand fragment (8 bf16)
 
 __device__ __forceinline__ f32x4 f32x4_zero() { return f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
 
@@ -25,16 +26,37 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
 // and column j = l & 15 of B, the 8 elements of its 128-bit operand are the SAME 8 k-indices
 // (a function of l >> 4 and the element number) in A and in B; lane l receives
 // D[4 * (l >> 4) + r][l & 15] in element r.
-__device__ __forceinline__ f32x4 mfma_16x16x32_bf16(uint4 a, uint4 b, f32x4 c) {
+__device__ __forceinline__ f32x4 mfma_16x16x32_bf16(u32x4 a, u32x4 b, f32x4 c) {
   typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
                                                  __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
+__device__ __forceinline__ u32x4 u32x4_zero() { return u32x4{0u, 0u, 0u, 0u}; }
 
-// Scheduling fence after one k-step of a multi-accumulator MFMA chain: the accumulators stay in
-// their registers and no memory operation moves across (see composite.hip, flush()).
-__device__ __forceinline__ void mfma_step_fence(f32x4 &a, f32x4 &b, f32x4 &c) {
-  asm volatile("s_nop 1" : "+v"(a), "+v"(b), "+v"(c) : : "memory");
+// ---- discipline around an MFMA chain ------------------------------------------------------------
+// Observed on MI355X / ROCm 7.2 (profiles/r01_notes.md, "MFMA chain hazard"): with two or more
+// wavefronts sharing a matrix core, a register that an already-issued v_mfma still has to read
+// (as A, B or C) can be overwritten by a later LDS return or vector write before the MFMA reads it
+// -- the compiler's wait-state counts assume the MFMA starts when it issues.  The chain in
+// composite.hip therefore follows three rules, enforced with these helpers:
+//   1. every operand fragment of the chain is loaded into its OWN registers before the first MFMA
+//      (mfma_operands_ready pins them all live at once and waits for the loads),
+//   2. between that point and the drain the instruction stream contains nothing but the MFMAs
+//      (scheduling barriers on both sides: no other write can land in a register an MFMA reads),
+//   3. the accumulators are consumed by real vector instructions (mfma_drain) before anything else
+//      runs: a vector read of an MFMA result waits for it, MFMAs complete in order, so after the
+//      drain every source register of the chain is free to be reused.
+__device__ __forceinline__ void mfma_operands_ready(u32x4 &a, u32x4 &b, u32x4 &c, u32x4 &d) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory");
+}
+__device__ __forceinline__ void mfma_operands_ready(u32x4 &a, u32x4 &b) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b) : : "memory");
+}
+__device__ __forceinline__ void mfma_drain(f32x4 &a, f32x4 &b, f32x4 &c) {
+  float a3 = a[3], b3 = b[3], c3 = c[3], sink;
+  asm volatile("s_nop 7\n\ts_nop 7\n\tv_or_b32 %0, %1, %2\n\tv_or_b32 %0, %0, %3"
+               : "=v"(sink) : "v"(a3), "v"(b3), "v"(c3) : "memory");
+  asm volatile("" : "+v"(a), "+v"(b), "+v"(c) : : "memory");
 }
 
 // LDS written by some lanes of this wavefront is about to be read by others (or the reverse).  The

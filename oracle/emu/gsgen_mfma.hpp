@@ -12,6 +12,8 @@ struct f32x4 {
   float operator[](int i) const { return v[i]; }
 };
 inline f32x4 f32x4_zero() { return f32x4{{0.0f, 0.0f, 0.0f, 0.0f}}; }
+typedef uint4 u32x4;
+inline u32x4 u32x4_zero() { return u32x4{0u, 0u, 0u, 0u}; }
 
 inline uint32_t emu_bf16_rne(float x) {
   uint32_t u;
@@ -56,7 +58,9 @@ inline f32x4 mfma_16x16x32_bf16(uint4 a, uint4 b, f32x4 c) {
 // lanes are fibers that only switch at collectives: make this one, so that every lane's LDS
 // writes are done before any lane reads
 inline void wave_lds_sync() { (void)simt::shfl_idx(0, 0); }
-inline void mfma_step_fence(f32x4 &, f32x4 &, f32x4 &) {}
+inline void mfma_operands_ready(uint4 &, uint4 &, uint4 &, uint4 &) {}
+inline void mfma_operands_ready(uint4 &, uint4 &) {}
+inline void mfma_drain(f32x4 &, f32x4 &, f32x4 &) {}
 inline float opaque(float v) { return v; }
 
 }  // namespace gs

@@ -64,11 +64,11 @@ def _worst(a, b):
 
 @pytest.mark.parametrize("C", [1, 2, 3, 4])
 def test_sh_backward_identical_launches_agree(C):
-    """one big launch (2500 tiles: every CU holds several wavefronts of the kernel) x 3"""
+    """one big launch (2500 tiles: every CU holds several wavefronts of the kernel), 25 times"""
     N, W, H = 60_000, 800, 800
     dev, lib, P, cams = _setup(C, N, W, H, 1)
     ref = _backward_all(dev, lib, P, cams, C, N, W, H, None)
-    for _ in range(2):
+    for _ in range(24):  # the hazard this guards against showed up about once in 15 launches
         again = _backward_all(dev, lib, P, cams, C, N, W, H, None)
         assert _worst(ref, again) < 5e-6
 
@@ -80,6 +80,6 @@ def test_sh_backward_unchanged_by_launches_in_flight(C):
     dev, lib, P, cams = _setup(C, N, W, H, 5)
     seq = _backward_all(dev, lib, P, cams, C, N, W, H, None)
     streams = [torch.cuda.Stream() for _ in range(3)]
-    for _ in range(4):
+    for _ in range(16):
         con = _backward_all(dev, lib, P, cams, C, N, W, H, streams)
         assert _worst(seq, con) < 5e-6

@@ -1,6 +1,6 @@
 """The compositing kernels exist in several compiled variants selected by environment variables
-read once per process (pixels per lane of the forward / backward, pixel-parallel vs splat-parallel
-backward, matrix-core vs vector SH gradient contraction).  Only one combination is the default; these tests run the parity suite in a
+read once per process (pixels per lane of the forward / backward, matrix-core vs vector SH gradient contraction and
+its wavefronts per tile).  Only one combination is the default; these tests run the parity suite in a
 subprocess for the others so that none of them rots.  CPU: on the SIMT emulator; GPU: on the
 real library."""
 import os
@@ -12,10 +12,8 @@ import pytest
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 VARIANTS = [
-    {"GSGEN_BWD": "splat"},
     {"GSGEN_PPL_FWD": "4", "GSGEN_PPL_BWD": "2"},
     {"GSGEN_PPL_FWD": "2", "GSGEN_PPL_BWD": "1"},
-    {"GSGEN_BWD_SPLIT": "40"},
     {"GSGEN_BWD_MFMA": "0"},  # SH gradient contraction on the vector ALUs instead of the matrix cores
     {"GSGEN_BWD_MFMA": "4"},  # matrix-core kernel, one wavefront per tile (default: two)
     {"GSGEN_BWD_MFMA": "1"},  # matrix-core kernel, four wavefronts per tile
