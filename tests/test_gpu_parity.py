@@ -268,6 +268,53 @@ def test_empty_inputs():
     assert torch.allclose(out, bg.expand(H, W, 3))
 
 
+def test_empty_inputs_of_the_additive_entry_points():
+    """N = 0 / D = 0 through the fused frame, the segmented SH pair, the densify statistics, the
+    accumulate-form projection backward and the Adam step: clean no-ops, bad arguments -> EINVAL"""
+    from gsgen_amd._capi import GsgenError
+    L = lib()
+    H = W = 32
+    z = torch.zeros(0, device=dev()); zi = torch.zeros(0, dtype=torch.int32, device=dev())
+    st = -torch.ones(4, dtype=torch.int32, device=dev()); en = -torch.ones_like(st)
+    out = torch.zeros(H, W, 3, device=dev())
+    tl = torch.tensor([-0.5, -0.5], device=dev()); rot = torch.eye(3, device=dev())
+    ws = torch.zeros(L.segment_workspace_bytes(4, 4), dtype=torch.uint8, device=dev())
+    bg = torch.tensor([0.1, 0.2, 0.3], device=dev())
+    L.vol_render_sh_segmented(0, 0, p(z), p(z), p(z), p(z), p(st), p(en), p(zi), p(out), p(tl), p(rot), 16, 2, 2, 1 / 32,
+                              1 / 32, H, W, 3, 1e-4, p(bg), None, None, p(ws), 4, stream())
+    torch.cuda.synchronize()
+    assert torch.allclose(out, bg.expand(H, W, 3))
+    L.vol_render_backward_sh_segmented(0, 0, p(z), p(z), p(z), p(z), p(st), p(en), p(zi), p(out), p(z), p(z), p(z), p(z),
+                                       p(out), p(tl), p(rot), 16, 2, 2, 1 / 32, 1 / 32, H, W, 3, 1e-4, None, None, p(ws), 4,
+                                       stream())
+    with pytest.raises(GsgenError, match="invalid"):
+        L.vol_render_backward_sh_segmented(0, 0, p(z), p(z), p(z), p(z), p(st), p(en), p(zi), p(out), p(z), p(z), p(z),
+                                           p(z), p(out), p(tl), p(rot), 16, 2, 2, 1 / 32, 1 / 32, H, W, 3, 1e-4, None, None,
+                                           None, 4, stream())
+    L.densify_update(0, None, None, None, None, None, None, stream())
+    L.project_gaussians_backward_accum(0, p(z), p(z), p(z), p(rot), 1, None, p(z), p(z), None, p(z), p(z), p(z), stream())
+    ends = np.array([0], np.uint64); lr = np.array([1e-3], np.float32)
+    L.adam_step(0, p(z), p(z), p(z), p(z), 1, ends.ctypes.data, lr.ctypes.data, 0.9, 0.999, 1e-15, 1, stream())
+    x = torch.ones(8, device=dev())
+    ends = np.array([8], np.uint64)
+    with pytest.raises(GsgenError, match="invalid"):  # steps count from 1
+        L.adam_step(8, p(x), p(x), p(x), p(x), 1, ends.ctypes.data, lr.ctypes.data, 0.9, 0.999, 1e-15, 0, stream())
+    with pytest.raises(GsgenError, match="invalid"):  # groups must end at n
+        L.adam_step(8, p(x), p(x), p(x), p(x), 1, np.array([7], np.uint64).ctypes.data, lr.ctypes.data, 0.9, 0.999,
+                    1e-15, 1, stream())
+    # a frame with nothing in view: all background, zero pairs, zero gradients
+    from gsgen_amd import renderer as R
+    sc = scenes.random_scene(50, seed=1, svec=0.02, C=2)
+    cam = scenes.Camera(48, 32, fx=40.0, c2w=scenes.look_at((50.0, 0.0, 0.0), at=(100.0, 0.0, 0.0)))
+    ci = R.CameraInfo(*cam.intr)
+    P_ = {k: T_(sc[k]).requires_grad_(True) for k in ("mean", "qvec", "svec", "alpha", "sh")}
+    buf = R.FrameBuffers(50, cam.w, cam.h, dev(), segments=4)
+    rgb, T = R.render_frame(P_["mean"], P_["qvec"], P_["svec"], P_["alpha"], P_["sh"], ci, cam.c2w, buf, C=2, bg_rgb=bg)
+    rgb.sum().backward()
+    assert int(buf.total.item()) == 0 and not bool(buf.mask.any())
+    assert torch.allclose(rgb, bg.expand(cam.h, cam.w, 3)) and float(P_["sh"].grad.abs().max()) == 0.0
+
+
 def test_unsupported_configs_raise():
     from gsgen_amd._capi import GsgenError
     L = lib()
