@@ -5,6 +5,7 @@ import ctypes
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -46,6 +47,16 @@ def test_gs_mirror_has_the_23_reference_names():
     assert len(names) == 23
     for n in names:
         assert callable(getattr(_gs, n)), n
+
+
+def test_import_gs_through_the_path_shim():
+    """`import _gs` with shim/ on PYTHONPATH yields gsgen_amd._gs itself (option 1b)"""
+    code = ("import _gs, gsgen_amd._gs as m, sys; assert _gs is m, (_gs, m); "
+            "assert callable(_gs.tile_based_vol_rendering_start_end_with_T); print('ok', len([n for n in dir(_gs) if not n.startswith('_')]))")
+    env = dict(os.environ)
+    env["PYTHONPATH"] = os.path.join(ROOT, "shim") + os.pathsep + env.get("PYTHONPATH", "")
+    r = subprocess.run([sys.executable, "-c", code], cwd="/", env=env, capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr
 
 
 def test_gs_mirror_rejects_cpu_tensors_like_torch_check():
