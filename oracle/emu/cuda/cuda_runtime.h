@@ -80,6 +80,13 @@ static inline cudaError_t cudaEventRecord(cudaEvent_t, cudaStream_t = nullptr) {
 static inline cudaError_t cudaEventSynchronize(cudaEvent_t) { return 0; }
 static inline cudaError_t cudaEventElapsedTime(float *ms, cudaEvent_t, cudaEvent_t) { *ms = 0.f; return 0; }
 
+// dynamic shared memory (`extern __shared__ T name[]`, rewritten by oracle/ref_build.py): the fibers
+// of a block run on one OS thread, so a thread_local buffer is per block, like the static ones
+inline void *simt_dyn_smem() {
+  alignas(16) static thread_local unsigned char buf[64 * 1024];
+  return buf;
+}
+
 // kernel<<<grid, block[, shmem[, stream]]>>>(args...) is rewritten by oracle/ref_build.py into
 // SIMT_LAUNCH((kernel), grid, block[, ...])(args...)
 namespace simt {

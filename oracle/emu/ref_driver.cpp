@@ -10,6 +10,7 @@
 #include "vol_render_scalar.h"
 #include "vol_render_sh.h"
 #include "vol_render_bg.h"
+#include "tile_ops.h"
 
 extern "C" {
 
@@ -98,4 +99,28 @@ void ref_vol_render_backward_sh(uint32_t N, uint32_t D, float *mean, float *cov,
   SH_SWITCH(BWD)
 }
 
+
+// legacy binning (render.cu:46-176)
+void ref_count_num_gaussians_each_tile(uint32_t N, float *mean, float *cov, float *topleft, uint32_t tile_size,
+                                       uint32_t nth, uint32_t ntw, float psx, float psy, int *num_gaussians,
+                                       float thresh) {
+  count_tiled_gaussians_cuda_sm(N, mean, cov, topleft, tile_size, nth, ntw, psx, psy, num_gaussians, thresh);
+}
+void ref_count_num_gaussians_each_tile_bcircle(uint32_t N, float *mean, float *radius, float *topleft,
+                                               uint32_t tile_size, uint32_t nth, uint32_t ntw, float psx, float psy,
+                                               int *num_gaussians) {
+  count_tiled_gaussians_bcircle_cuda_sm(N, mean, radius, topleft, tile_size, nth, ntw, psx, psy, num_gaussians);
+}
+void ref_prepare_image_sort(uint32_t N, uint32_t N_with_dub, int *gaussian_ids, double *tiledepth, float *depth,
+                            int *tile_n_gaussians, int *offset, float *mean, float *radius, float *topleft,
+                            uint32_t tile_size, uint32_t nth, uint32_t ntw, float psx, float psy) {
+  prepare_image_sort_cuda(N, N_with_dub, gaussian_ids, tiledepth, depth, tile_n_gaussians, offset, mean, radius,
+                          topleft, tile_size, nth, ntw, psx, psy);
+}
+void ref_image_sort(uint32_t N, uint32_t N_with_dub, int *gaussian_ids, double *tiledepth, float *depth,
+                    int *tile_n_gaussians, int *offset, float *mean, float *cov, float *topleft, uint32_t tile_size,
+                    uint32_t nth, uint32_t ntw, float psx, float psy, float thresh) {
+  image_sort_cuda(N, N_with_dub, gaussian_ids, tiledepth, depth, tile_n_gaussians, offset, mean, cov, topleft,
+                  tile_size, nth, ntw, psx, psy, thresh);
+}
 }  // extern "C"

@@ -830,3 +830,127 @@ void gso_part_workstats(const float *mean, const float *cov, const float *alpha,
     }
   *walked = w_tot; *contrib = c_tot; *pix_pairs = p_tot;
 }
+
+
+/* ------------------------------------------------------------------------------------ */
+/* Legacy binning (gs/src/include/tile_ops.h, culling.h:48-130, kernels.h:253-350): one   */
+/* membership test per (tile, Gaussian) -- the Gaussian's value at the four tile corners  */
+/* above `thresh` (mode 0), or the bounding circle reaching the tile (mode 1).  Used by   */
+/* the reference's older GaussianRenderer / gs/debug.py / gs/benchmarks.py only.         */
+/* ------------------------------------------------------------------------------------ */
+static int legacy_hit_corners(float tlx, float tly, unsigned tile_size, float psx, float psy,
+                              const float *mean, const float *cov, float thresh) {
+  /* kernels.h:253-272; corner coordinates in fp32, Gaussian in fp64 (kernels.h:226-251) */
+  float ex = (float)tile_size * psx, ey = (float)tile_size * psy;
+  float xr = tlx + ex, yb = tly + ey;
+  float q[2], m = 0.0f, v;
+  q[0] = tlx; q[1] = tly; v = gauss2d_f64(mean, cov, q); m = v > m ? v : m;
+  q[0] = xr; q[1] = tly; v = gauss2d_f64(mean, cov, q); m = v > m ? v : m;
+  q[0] = tlx; q[1] = yb; v = gauss2d_f64(mean, cov, q); m = v > m ? v : m;
+  q[0] = xr; q[1] = yb; v = gauss2d_f64(mean, cov, q); m = v > m ? v : m;
+  return m > thresh;
+}
+static float legacy_dist_seg(float x, float y, float x1, float x2, float y1, float y2) {
+  /* kernels.h:274-304 */
+  float A = x - x1, B = y - y1, C = x2 - x1, D = y2 - y1;
+  float ac = A * C, bd = B * D, dot = ac + bd;
+  float cc = C * C, dd = D * D, len_sq = cc + dd;
+  float param = -1.0f, xx, yy;
+  if (len_sq != 0) param = dot / len_sq;
+  if (param < 0) { xx = x1; yy = y1; }
+  else if (param > 1) { xx = x2; yy = y2; }
+  else { float pc = param * C, pd = param * D; xx = x1 + pc; yy = y1 + pd; }
+  float dx = x - xx, dy = y - yy;
+  float dx2 = dx * dx, dy2 = dy * dy;
+  return sqrtf(dx2 + dy2);
+}
+static int legacy_hit_bcircle(float tlx, float tly, unsigned tile_size, float psx, float psy,
+                              const float *mean, float radius) {
+  /* kernels.h:306-350 */
+  float rx = mean[0] - tlx, ry = mean[1] - tly;
+  float px = psx * (float)tile_size, py = psy * (float)tile_size;
+  if (rx >= 0 && rx <= px && ry >= 0 && ry <= py) return 1;
+  float d1 = legacy_dist_seg(rx, ry, 0.0f, px, 0.0f, 0.0f);
+  float d2 = legacy_dist_seg(rx, ry, 0.0f, px, py, py);
+  float d3 = legacy_dist_seg(rx, ry, 0.0f, 0.0f, 0.0f, py);
+  float d4 = legacy_dist_seg(rx, ry, px, px, 0.0f, py);
+  float d = fminf(fminf(d1, d2), fminf(d3, d4));
+  return d < radius;
+}
+static void legacy_tile_topleft(const float *topleft, int tx, int ty, unsigned tile_size, float psx, float psy,
+                                float *tlx, float *tly) {
+  /* topleft[0] + pixel_size_x * tile_x * tile_size, left to right in fp32 (tile_ops.h:51-53) */
+  float ax = psx * (float)tx, ay = psy * (float)ty;
+  ax = ax * (float)tile_size; ay = ay * (float)tile_size;
+  *tlx = topleft[0] + ax; *tly = topleft[1] + ay;
+}
+static int legacy_hit(int mode, const float *topleft, int tx, int ty, unsigned tile_size, float psx, float psy,
+                      const float *mean, const float *shape, int i, float thresh) {
+  float tlx, tly;
+  legacy_tile_topleft(topleft, tx, ty, tile_size, psx, psy, &tlx, &tly);
+  return mode == 0 ? legacy_hit_corners(tlx, tly, tile_size, psx, psy, mean + 2 * i, shape + 4 * i, thresh)
+                   : legacy_hit_bcircle(tlx, tly, tile_size, psx, psy, mean + 2 * i, shape[i]);
+}
+
+/* count_num_gaussians_each_tile{,_bcircle}: num_gaussians[tile] += hits (render.cu:46-97) */
+void gso_legacy_count(int mode, int N, const float *mean, const float *shape, const float *topleft,
+                      unsigned tile_size, int nth, int ntw, float psx, float psy, float thresh,
+                      int *num_gaussians) {
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int t = 0; t < nth * ntw; ++t) {
+    int cnt = 0;
+    for (int i = 0; i < N; ++i)
+      cnt += legacy_hit(mode, topleft, t % ntw, t / ntw, tile_size, psx, psy, mean, shape, i, thresh);
+    num_gaussians[t] += cnt;
+  }
+}
+
+/* image_sort (mode 0, tile_ops.h:457-506) / prepare_image_sort (mode 1, :365-455): offset =
+ * exclusive scan of the incoming tile_n_gaussians; keys {lo = depth bits, hi = tile} and ids
+ * filled per tile in Gaussian-index order (tiledepth keeps them UNSORTED); gaussian_ids = ids
+ * stably sorted by the signed 64-bit key; mode 0 also recounts tile_n_gaussians.  Returns the
+ * number of pairs written (== N_with_dub when the caller's counts were right). */
+long long gso_legacy_image_sort(int mode, int N, long long N_with_dub, int *gaussian_ids,
+                                unsigned long long *tiledepth, const float *depth, int *tile_n_gaussians,
+                                int *offset, const float *mean, const float *shape, const float *topleft,
+                                unsigned tile_size, int nth, int ntw, float psx, float psy, float thresh) {
+  int T = nth * ntw;
+  long long run = 0;
+  for (int t = 0; t < T; ++t) { offset[t] = (int)run; run += tile_n_gaussians[t]; }
+  int *uns = (int *)calloc((size_t)(N_with_dub > 0 ? N_with_dub : 1), sizeof(int));
+  long long total = 0;
+  for (int t = 0; t < T; ++t) {
+    long long off = offset[t];
+    int cnt = 0;
+    for (int i = 0; i < N; ++i)
+      if (legacy_hit(mode, topleft, t % ntw, t / ntw, tile_size, psx, psy, mean, shape, i, thresh)) {
+        if (off < N_with_dub) {
+          unsigned bits; memcpy(&bits, depth + i, 4);
+          tiledepth[off] = ((unsigned long long)(unsigned)t << 32) | bits;
+          uns[off] = i;
+        }
+        ++off; ++cnt;
+      }
+    if (mode == 0) tile_n_gaussians[t] = cnt;
+    total += cnt;
+  }
+  /* stable sort by the signed key: tiles ascending, then depth bits ascending as unsigned */
+  long long n = N_with_dub;
+  long long *order = (long long *)malloc(sizeof(long long) * (size_t)(n > 0 ? n : 1));
+  for (long long k = 0; k < n; ++k) order[k] = k;
+  /* insertion-free: per-tile segments are contiguous already, sort each by (depth bits, position) */
+  for (int t = 0; t < T; ++t) {
+    long long b = offset[t], e = (t + 1 < T) ? offset[t + 1] : n;
+    if (e > n) e = n;
+    for (long long a = b + 1; a < e; ++a) {  /* stable insertion sort (test sizes are small) */
+      long long cur = order[a];
+      unsigned long long key = tiledepth[cur];
+      long long j = a - 1;
+      while (j >= b && (long long)tiledepth[order[j]] > (long long)key) { order[j + 1] = order[j]; --j; }
+      order[j + 1] = cur;
+    }
+  }
+  for (long long k = 0; k < n; ++k) gaussian_ids[k] = uns[order[k]];
+  free(order); free(uns);
+  return total;
+}

@@ -216,3 +216,27 @@ def render_sh_bwd(mean2d, cov2d, sh, alpha, start, end, ids, final, grad_out, to
     lib().gso_render_sh_bwd(N, *[_p(x) for x in a], int(Cb), tile_size, nth, ntw, C.c_float(psx),
                             C.c_float(psy), H, W, C.c_float(thresh), _p(gm), _p(gc), _p(gsh), _p(ga))
     return gm, gc, gsh, ga
+
+
+# ---- legacy binning (tile_ops.h; used by the reference's older GaussianRenderer / debug / benchmarks) -----
+def legacy_count(mode, mean2d, shape, topleft, tile_size, nth, ntw, psx, psy, thresh=0.0, num=None):
+    mean2d, shape, topleft = _f(mean2d), _f(shape), _f(topleft)
+    num = np.zeros(nth * ntw, np.int32) if num is None else num
+    lib().gso_legacy_count(int(mode), mean2d.shape[0], _p(mean2d), _p(shape), _p(topleft), C.c_uint(tile_size), nth, ntw,
+                           C.c_float(psx), C.c_float(psy), C.c_float(thresh), _p(num))
+    return num
+
+
+def legacy_image_sort(mode, depth, tile_n, mean2d, shape, topleft, tile_size, nth, ntw, psx, psy, thresh=0.0):
+    mean2d, shape, topleft, depth = _f(mean2d), _f(shape), _f(topleft), _f(depth).reshape(-1)
+    tile_n = _i(tile_n).copy()
+    D = int(tile_n.sum())
+    ids = np.zeros(max(D, 1), np.int32)
+    td = np.zeros(max(D, 1), np.uint64)
+    offset = np.zeros(nth * ntw, np.int32)
+    lib().gso_legacy_image_sort.restype = C.c_longlong
+    tot = lib().gso_legacy_image_sort(int(mode), mean2d.shape[0], C.c_longlong(D), _p(ids), _p(td), _p(depth), _p(tile_n),
+                                      _p(offset), _p(mean2d), _p(shape), _p(topleft), C.c_uint(tile_size), nth, ntw,
+                                      C.c_float(psx), C.c_float(psy), C.c_float(thresh))
+    assert tot == D, (tot, D)
+    return ids[:D], td[:D], tile_n, offset

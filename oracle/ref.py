@@ -142,3 +142,37 @@ def render_sh_bwd(mean2d, cov2d, sh, alpha, start, end, ids, final, grad_out, to
                                      _p(go), _p(tl), _p(rot), u32(16), u32(nth), u32(ntw), f32(psx), f32(psy), u32(H),
                                      u32(W), u32(Cb), f32(thresh), _p(bg_))
     return gm, gc, gsh, ga
+
+
+# ---- legacy binning (render.cu:46-176) ---------------------------------------------------------
+def legacy_count(mode, mean2d, shape, topleft, tile_size, nth, ntw, psx, psy, thresh=0.0, num=None):
+    """mode 0: count_num_gaussians_each_tile (shape = cov2d, thresh); 1: ..._bcircle (shape = radius)"""
+    mean2d, shape, topleft = _f(mean2d), _f(shape), _f(topleft)
+    num = np.zeros(nth * ntw, np.int32) if num is None else num
+    N = mean2d.shape[0]
+    if mode == 0:
+        lib().ref_count_num_gaussians_each_tile(u32(N), _p(mean2d), _p(shape), _p(topleft), u32(tile_size), u32(nth),
+                                                u32(ntw), f32(psx), f32(psy), _p(num), f32(thresh))
+    else:
+        lib().ref_count_num_gaussians_each_tile_bcircle(u32(N), _p(mean2d), _p(shape), _p(topleft), u32(tile_size),
+                                                        u32(nth), u32(ntw), f32(psx), f32(psy), _p(num))
+    return num
+
+
+def legacy_image_sort(mode, depth, tile_n, mean2d, shape, topleft, tile_size, nth, ntw, psx, psy, thresh=0.0):
+    """-> gaussian_ids, tiledepth (u64 keys, unsorted), tile_n_gaussians, offset  (image_sort /
+    prepare_image_sort; the caller's zero-initialised outputs are allocated here)"""
+    mean2d, shape, topleft, depth = _f(mean2d), _f(shape), _f(topleft), _f(depth).reshape(-1)
+    tile_n = _i(tile_n).copy()
+    D = int(tile_n.sum())
+    ids = np.zeros(max(D, 1), np.int32)
+    td = np.zeros(max(D, 1), np.float64)
+    offset = np.zeros(nth * ntw, np.int32)
+    N = mean2d.shape[0]
+    if mode == 0:
+        lib().ref_image_sort(u32(N), u32(D), _p(ids), _p(td), _p(depth), _p(tile_n), _p(offset), _p(mean2d), _p(shape),
+                             _p(topleft), u32(tile_size), u32(nth), u32(ntw), f32(psx), f32(psy), f32(thresh))
+    else:
+        lib().ref_prepare_image_sort(u32(N), u32(D), _p(ids), _p(td), _p(depth), _p(tile_n), _p(offset), _p(mean2d),
+                                     _p(shape), _p(topleft), u32(tile_size), u32(nth), u32(ntw), f32(psx), f32(psy))
+    return ids[:D], td[:D].view(np.uint64), tile_n, offset

@@ -23,7 +23,9 @@ REF_INC = "/root/reference/gs/src/include"
 OUT_DIR = os.path.join(HERE, "_ref")
 LIB = os.path.join(OUT_DIR, "libgs_ref.so")
 HEADERS = ["common.h", "data_spec.h", "helper_math.h", "kernels.h", "culling.h", "aabb_culling.h", "vol_render.h",
-           "vol_render_scalar.h", "shencoder.h", "vol_render_sh.h", "vol_render_bg.h"]
+           "vol_render_scalar.h", "shencoder.h", "vol_render_sh.h", "vol_render_bg.h", "tile_ops.h"]
+# `extern __shared__ float name[];` (dynamic shared memory, tile_ops.h) -> a per-block buffer of the emulator
+_DYN_SMEM = re.compile(r"extern\s+__shared__\s+(\w+)\s+(\w+)\s*\[\s*\]\s*;")
 
 _LAUNCH = re.compile(r"([A-Za-z_]\w*(?:\s*<[^<>;(){}]*>)?)\s*<<<(.*?)>>>\s*\(", re.S)
 
@@ -48,6 +50,7 @@ def build(force=False):
         for h, src in zip(HEADERS, srcs):
             text = open(src).read()
             text = _LAUNCH.sub(lambda m: f"SIMT_LAUNCH(({m.group(1)}), {m.group(2)})(", text)
+            text = _DYN_SMEM.sub(lambda m: f"{m.group(1)} *{m.group(2)} = reinterpret_cast<{m.group(1)} *>(simt_dyn_smem());", text)
             open(os.path.join(gen, h), "w").write(text)
         cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-w",
                "-I", gen, "-I", os.path.join(HERE, "emu", "cuda"), os.path.join(HERE, "emu", "ref_driver.cpp"),
