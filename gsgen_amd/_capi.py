@@ -50,6 +50,8 @@ SIGNATURES = {
                                       u32, u32, u32, f32, vp, vp, vp, vp, u32, vp],
     "gsgen_vol_render_backward_sh_segmented": [u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                                vp, u32, u32, u32, f32, f32, u32, u32, u32, f32, vp, vp, vp, u32, vp],
+    "gsgen_legacy_count_tiles": [u32, u32, vp, vp, vp, u32, u32, u32, f32, f32, f32, vp, vp],
+    "gsgen_legacy_image_sort": [u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, u32, f32, f32, f32, vp, sz, vp],
     "gsgen_frame_geometry": [u32, vp, vp, vp, vp, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp],
 }
 PTR_FUNCS = {
@@ -59,6 +61,7 @@ SIZE_FUNCS = {
     "gsgen_tile_culling_workspace_bytes": [u32, u32, u32],
     "gsgen_frame_workspace_bytes": [u32, u32, u32],
     "gsgen_segment_workspace_bytes": [u32, u32],
+    "gsgen_legacy_sort_workspace_bytes": [u32, u32],
 }
 EXPORTS = sorted(list(SIGNATURES) + list(SIZE_FUNCS) + list(PTR_FUNCS) + ["gsgen_version", "gsgen_error_string"])
 

@@ -316,15 +316,58 @@ def debug_check_tiledepth(offset, tiledepth):
             assert (np.diff(depth[s:e]) >= 0).all(), f"depth not sorted in tile {t}"
 
 
-def _legacy(name):
-    def fn(*a, **k):
-        raise NotImplementedError(
-            f"_gs.{name}: legacy binning of the reference (probability / bounding-circle tile tests, "
-            "SURVEY.md 2.2 rows 14-15) that no live caller uses; not part of the MI355X hot path.")
-    fn.__name__ = name
-    return fn
+def _d(x, name):
+    _check_dc(x, name, torch.float64, "a double")
 
 
-for _n in ("count_num_gaussians_each_tile", "count_num_gaussians_each_tile_bcircle", "prepare_image_sort",
-           "image_sort"):
-    globals()[_n] = _legacy(_n)
+def count_num_gaussians_each_tile(mean, cov, topleft, tile_size, n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y,
+                                  num_gaussians, thresh):
+    """render.h:7 / render.cu:46-70: num_gaussians[tile] += #Gaussians whose value at a tile corner > thresh."""
+    _f(mean, "mean"); _f(cov, "cov"); _f(topleft, "topleft"); _i(num_gaussians, "num_gaussians")
+    with torch.cuda.device(mean.device):
+        _capi.load().legacy_count_tiles(0, mean.size(0), _p(mean), _p(cov), _p(topleft), int(tile_size), int(n_tiles_h),
+                                        int(n_tiles_w), float(pixel_size_x), float(pixel_size_y), float(thresh),
+                                        _p(num_gaussians), _stream(mean))
+
+
+def count_num_gaussians_each_tile_bcircle(mean, radius, topleft, tile_size, n_tiles_h, n_tiles_w, pixel_size_x,
+                                          pixel_size_y, num_gaussians):
+    """render.h:13 / render.cu:73-97: the bounding-circle membership test."""
+    _f(mean, "mean"); _f(radius, "radius"); _f(topleft, "topleft"); _i(num_gaussians, "num_gaussians")
+    with torch.cuda.device(mean.device):
+        _capi.load().legacy_count_tiles(1, mean.size(0), _p(mean), _p(radius), _p(topleft), int(tile_size),
+                                        int(n_tiles_h), int(n_tiles_w), float(pixel_size_x), float(pixel_size_y), 0.0,
+                                        _p(num_gaussians), _stream(mean))
+
+
+def _image_sort(mode, gaussian_ids, tiledepth, depth, tile_n_gaussians, offset, mean, shape, topleft, tile_size,
+                n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, thresh):
+    _i(gaussian_ids, "gaussian_ids"); _d(tiledepth, "tiledepth"); _f(depth, "depth")
+    _i(tile_n_gaussians, "tile_n_gaussians"); _i(offset, "offset"); _f(mean, "mean")
+    _f(shape, "cov" if mode == 0 else "radius"); _f(topleft, "topleft")
+    lib = _capi.load()
+    N, D, T = mean.size(0), tiledepth.size(0), int(n_tiles_h) * int(n_tiles_w)
+    with torch.cuda.device(mean.device):
+        nbytes = lib.legacy_sort_workspace_bytes(D, T)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=mean.device)
+        lib.legacy_image_sort(mode, N, D, _p(gaussian_ids), _p(tiledepth), _p(depth), _p(tile_n_gaussians), _p(offset),
+                              _p(mean), _p(shape), _p(topleft), int(tile_size), int(n_tiles_h), int(n_tiles_w),
+                              float(pixel_size_x), float(pixel_size_y), float(thresh), _p(ws), nbytes, _stream(mean))
+        ws.record_stream(torch.cuda.current_stream(mean.device))
+
+
+def prepare_image_sort(gaussian_ids, tiledepth, depth, tile_n_gaussians, offset, mean, radius, topleft, tile_size,
+                       n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y):
+    """render.h:18 / render.cu:99-137: offset = exclusive scan of tile_n_gaussians, {tile, depth} keys filled per
+    tile (bounding-circle test) into tiledepth (float64 [N_with_dub], left unsorted), ids sorted per tile by depth
+    into gaussian_ids."""
+    _image_sort(1, gaussian_ids, tiledepth, depth, tile_n_gaussians, offset, mean, radius, topleft, tile_size, n_tiles_h,
+                n_tiles_w, pixel_size_x, pixel_size_y, 0.0)
+
+
+def image_sort(gaussian_ids, tiledepth, depth, tile_n_gaussians, offset, mean, cov, topleft, tile_size, n_tiles_h,
+               n_tiles_w, pixel_size_x, pixel_size_y, thresh):
+    """render.h:24 / render.cu:139-176: as prepare_image_sort with the corner-value test; tile_n_gaussians is
+    recounted."""
+    _image_sort(0, gaussian_ids, tiledepth, depth, tile_n_gaussians, offset, mean, cov, topleft, tile_size, n_tiles_h,
+                n_tiles_w, pixel_size_x, pixel_size_y, thresh)

@@ -24,6 +24,7 @@ SOURCES = {
     "composite_bwd.hip": [],
     "geometry.hip": ["-ffp-contract=off"],
     "binning.hip": [],
+    "legacy.hip": ["-ffp-contract=off"],
 }
 COMMON = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-Wall", "-Wno-unused-function", f"-I{CSRC}"]
 

@@ -496,6 +496,16 @@ int gsgen_internal_frame_project(uint32_t N, const float *mean, const float *qve
                                  const float *cam, int w, int h, int ntw, float *mean2d, float *cov2d,
                                  float *depth, uint8_t *mask, int *tl, int *br, gsgen_stream_t stream);
 
+// used by legacy.hip: per-segment sort of (depth bits << 32 | id) keys, ids out (ctrl[1] must be 0)
+int gsgen_internal_sort_segments(uint32_t T, const uint32_t *tile_off, const uint32_t *ctrl,
+                                 unsigned long long *keys, int *ids, int *start, int *end, gsgen_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (T == 0) return 0;
+  hipLaunchKernelGGL(k_sort_tiles, dim3(T), dim3(64), 0, s, T, tile_off, ctrl, keys, ids, start, end);
+  hipLaunchKernelGGL(k_sort_tiles_big, dim3(T), dim3(kSortThreads), 0, s, T, tile_off, ctrl, keys, ids);
+  return (int)hipGetLastError();
+}
+
 const char *gsgen_version(void) { return "gsgen_hip 0.1 (gfx950)"; }
 
 int gsgen_selftest_reduce_scatter(uint32_t P, const float *in /*[64,P]*/, float *out /*[64]*/,

@@ -179,6 +179,28 @@ int gsgen_tile_culling_aabb_count(uint32_t N, const float *mean2d, const float *
                                   uint32_t w, uint32_t h, float D, int *aabb_topleft,
                                   int *aabb_bottomright, uint32_t *total, gsgen_stream_t stream);
 
+/* ---- the reference's older binning pipeline (compat: GaussianRenderer, gs/debug.py, gs/benchmarks.py) ----
+ * mode 0: a Gaussian belongs to a tile when its value at one of the four tile corners exceeds thresh
+ * (count_num_gaussians_each_tile / image_sort: render.cu:46-70,139-176, tile_ops.h, kernels.h:253-272;
+ * cov_or_radius = cov [N,2,2]); mode 1: when its bounding circle reaches the tile
+ * (count_num_gaussians_each_tile_bcircle / prepare_image_sort: render.cu:73-137, culling.h:48-130,
+ * kernels.h:306-350; cov_or_radius = radius [N]).
+ * count: num_gaussians[tile] += hits (int32 [T], caller-zeroed).
+ * image_sort: offset[T] = exclusive scan of the incoming tile_n_gaussians; tiledepth [N_with_dub] receives
+ * the {lo = float depth, hi = tile} keys in fill order (per tile, ascending Gaussian index) and is left
+ * unsorted, as in the reference; gaussian_ids [N_with_dub] receives the ids sorted per tile by depth;
+ * mode 0 rewrites tile_n_gaussians with its own count.  Workspace from the caller. */
+int gsgen_legacy_count_tiles(uint32_t mode, uint32_t N, const float *mean, const float *cov_or_radius,
+                             const float *topleft, uint32_t tile_size, uint32_t n_tiles_h, uint32_t n_tiles_w,
+                             float pixel_size_x, float pixel_size_y, float thresh, int *num_gaussians,
+                             gsgen_stream_t stream);
+size_t gsgen_legacy_sort_workspace_bytes(uint32_t N_with_dub, uint32_t n_tiles);
+int gsgen_legacy_image_sort(uint32_t mode, uint32_t N, uint32_t N_with_dub, int *gaussian_ids,
+                            unsigned long long *tiledepth, const float *depth, int *tile_n_gaussians, int *offset,
+                            const float *mean, const float *cov_or_radius, const float *topleft, uint32_t tile_size,
+                            uint32_t n_tiles_h, uint32_t n_tiles_w, float pixel_size_x, float pixel_size_y,
+                            float thresh, void *workspace, size_t workspace_bytes, gsgen_stream_t stream);
+
 /* Fused frame: frustum cull + projection + AABB + binning + per-tile sort in one enqueue with
  * no host round trip (gs/gaussian_splatting.py:1208-1295 without the mask gathers and syncs).
  * `cam` (DEVICE, 56 floats): [0..11] c2w row-major 3x4; [12..15] fx, fy, cx, cy;

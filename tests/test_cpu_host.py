@@ -64,8 +64,8 @@ def test_gs_mirror_rejects_cpu_tensors_like_torch_check():
     a = torch.zeros(4, 3)
     with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
         _gs.culling_gaussian_bsphere(a, a, a, a, a, torch.zeros(4, dtype=torch.bool), 6.0)
-    with pytest.raises(NotImplementedError):
-        _gs.image_sort()
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        _gs.count_num_gaussians_each_tile(a, a, a, 16, 1, 1, 0.1, 0.1, torch.zeros(1, dtype=torch.int32), 0.01)
     # debug_check_tiledepth is host code (debug.h:3-32)
     key = np.zeros(3, np.float64).view(np.int32).reshape(3, 2)
     key[:, 1] = [0, 0, 1]
@@ -446,3 +446,33 @@ def test_no_kernel_spills_and_hot_kernels_keep_their_occupancy(tmp_path):
     fwd = find("k_composite_fwdILi2ELi4ELi1E")      # default SH forward: 4 wavefronts per tile
     assert fwd["vgpr_count"] <= 128
     assert find("k_sort_tiles", "PKjS1_PKyPiS4_S4_")["group_segment_fixed_size"] == 0  # register sort: no LDS
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_emulated_legacy_binning_matches_oracle(emu, mode):
+    """count_num_gaussians_each_tile{,_bcircle} and image_sort / prepare_image_sort (the reference's older
+    pipeline) on the emulator against the oracle, which is pinned bit for bit against tile_ops.h itself
+    (tests/test_oracle_golden.py::test_legacy_binning_oracle_equals_reference)"""
+    sc = scenes.random_scene(500, seed=8, svec=0.06)
+    cam = scenes.Camera(80, 56, fx=70.0)
+    g = scenes.oracle_geometry(sc, cam)
+    m2 = np.ascontiguousarray(g["mean2d"]); c2 = np.ascontiguousarray(g["cov2d"].reshape(-1, 4))
+    dep = np.ascontiguousarray(g["depth"].ravel())
+    dep[5] = dep[6]  # equal depths: index order decides
+    N = m2.shape[0]; nth, ntw = cam.tiles; T = nth * ntw
+    shape = c2 if mode == 0 else np.sqrt(6.0 * np.maximum(c2[:, 0], c2[:, 3])).astype(np.float32)
+    tl = cam.topleft; th = 0.02
+    want_n = O.legacy_count(mode, m2, shape, tl, 16, nth, ntw, 1 / cam.fx, 1 / cam.fy, th)
+    num = np.zeros(T, np.int32)
+    emu.legacy_count_tiles(mode, N, P(m2), P(shape), P(tl), 16, nth, ntw, 1 / cam.fx, 1 / cam.fy, th, P(num), None)
+    assert np.array_equal(num, want_n) and num.sum() > 3 * T
+    emu.legacy_count_tiles(mode, N, P(m2), P(shape), P(tl), 16, nth, ntw, 1 / cam.fx, 1 / cam.fy, th, P(num), None)
+    assert np.array_equal(num, 2 * want_n)  # accumulates, as the reference does
+    D = int(want_n.sum())
+    w_ids, w_td, w_n, w_off = O.legacy_image_sort(mode, dep, want_n, m2, shape, tl, 16, nth, ntw, 1 / cam.fx, 1 / cam.fy, th)
+    ids = np.zeros(D, np.int32); td = np.zeros(D, np.uint64); tn = want_n.copy(); off = np.zeros(T, np.int32)
+    ws = np.zeros(emu.legacy_sort_workspace_bytes(D, T), np.uint8)
+    emu.legacy_image_sort(mode, N, D, P(ids), P(td), P(dep), P(tn), P(off), P(m2), P(shape), P(tl), 16, nth, ntw,
+                          1 / cam.fx, 1 / cam.fy, th, P(ws), ws.size, None)
+    assert np.array_equal(ids, w_ids) and np.array_equal(td, w_td)
+    assert np.array_equal(tn, w_n) and np.array_equal(off, w_off)

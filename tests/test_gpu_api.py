@@ -286,6 +286,56 @@ def test_segmented_backward_matches_per_tile_backward(C):
         assert rel_err(res[1][1][k].cpu().numpy(), res[0][1][k].cpu().numpy()) < 2e-5, k
 
 
+@pytest.mark.parametrize("kind", ["bcircle", "prob"])
+def test_legacy_renderer_call_sequence(kind):
+    """gs/renderer.py:1395-1520 (GaussianRenderer.render, tile_culling_type bcircle / prob) call for call through
+    the `_gs` mirror: count -> .sum().item() -> prepare_image_sort / image_sort -> offset[-1] = total ->
+    tile_based_vol_rendering (CSR form), against the oracle (itself pinned to tile_ops.h bit for bit)."""
+    from gsgen_amd import _gs
+    sc = scenes.random_scene(1500, seed=14, svec=0.05)
+    cam = scenes.Camera(112, 80, fx=100.0, c2w=scenes.orbit(2.4, 12, 200))
+    g = scenes.oracle_geometry(sc, cam)
+    m = g["mask"]
+    m2, c2, dep = g["mean2d"], g["cov2d"].reshape(-1, 4), g["depth"].ravel()
+    radius = np.sqrt(np.maximum(c2[:, 0], c2[:, 3])).astype(np.float32)
+    mean, cov, depth = T_(m2), T_(c2.reshape(-1, 2, 2)), T_(dep.reshape(-1, 1))
+    color, alpha = T_(sc["color"][m]), T_(sc["alpha"][m])
+    nth, ntw = cam.tiles; n_tiles = nth * ntw; H, W = cam.h, cam.w
+    topleft = T_(cam.topleft); psx, psy = 1 / cam.fx, 1 / cam.fy
+    num = torch.zeros(n_tiles, dtype=torch.int32, device=dev())
+    if kind == "bcircle":
+        shape_np = (radius * np.float32(2.5)).astype(np.float32)
+        _gs.count_num_gaussians_each_tile_bcircle(mean, T_(shape_np), topleft, 16, nth, ntw, psx, psy, num)
+        want_n = O.legacy_count(1, m2, shape_np, cam.topleft, 16, nth, ntw, psx, psy)
+    else:
+        shape_np = c2
+        _gs.count_num_gaussians_each_tile(mean, cov, topleft, 16, nth, ntw, psx, psy, num, 0.01)
+        want_n = O.legacy_count(0, m2, c2, cam.topleft, 16, nth, ntw, psx, psy, 0.01)
+    assert np.array_equal(num.cpu().numpy(), want_n)
+    total = int(num.sum().item())
+    tiledepth = torch.zeros(total, dtype=torch.float64, device=dev())
+    offset = torch.zeros(n_tiles + 1, dtype=torch.int32, device=dev())
+    ids = torch.zeros(total, dtype=torch.int32, device=dev())
+    if kind == "bcircle":
+        _gs.prepare_image_sort(ids, tiledepth, depth, num, offset, mean, T_(shape_np), topleft, 16, nth, ntw, psx, psy)
+    else:
+        _gs.image_sort(ids, tiledepth, depth, num, offset, mean, cov, topleft, 16, nth, ntw, psx, psy, 0.01)
+    offset[-1] = total
+    w_ids, w_td, w_n, w_off = O.legacy_image_sort(1 if kind == "bcircle" else 0, dep, want_n, m2, shape_np, cam.topleft, 16,
+                                                  nth, ntw, psx, psy, 0.01)
+    assert np.array_equal(ids.cpu().numpy(), w_ids)
+    assert np.array_equal(tiledepth.cpu().numpy().view(np.uint64), w_td)
+    assert np.array_equal(num.cpu().numpy(), w_n) and np.array_equal(offset.cpu().numpy()[:-1], w_off)
+    _gs.debug_check_tiledepth(offset.cpu(), torch.from_numpy(np.sort(w_td).view(np.float64)))  # sorted keys pass the reference's check
+    out = torch.zeros(H, W, 3, device=dev())
+    _gs.tile_based_vol_rendering(mean, cov, color, alpha, offset, ids, out, topleft, 16, nth, ntw, psx, psy, H, W, 1e-4)
+    off = offset.cpu().numpy()
+    st, en = off[:-1].copy(), off[1:].copy()
+    st[en == st] = -1; en[st == -1] = -1
+    ref, _ = O.render_rgb_fwd(m2, g["cov2d"], sc["color"][m], sc["alpha"][m], st, en, w_ids, cam.topleft, psx, psy, H, W)
+    assert np.abs(out.cpu().numpy() - ref).max() <= 1e-5
+
+
 def test_full_size_cfg2():
     """BASELINE configs[1] (100k Gaussians, 800x800, SH degree 3) through the fused path:
     pair count and per-tile lists exact, image within 1e-4 of the oracle, per-tile lists
@@ -419,8 +469,6 @@ def test_legacy_csr_entry_points():
     r = O.render_rgb_bwd(g["mean2d"], g["cov2d"], sc["color"][m], sc["alpha"][m], g["start"], g["end"], g["ids"], ref,
                          go.cpu().numpy(), cam.topleft, 1 / cam.fx, 1 / cam.fy, H, W)
     assert rel_err(gm.cpu().numpy(), r[0]) < 1e-3 and rel_err(gcol.cpu().numpy(), r[2]) < 1e-3
-    with pytest.raises(NotImplementedError):
-        _gs.image_sort()
 
 
 def test_frame_is_hip_graph_capturable():

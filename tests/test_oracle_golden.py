@@ -137,3 +137,27 @@ def test_reference_sort_semantics_negative_depth_and_ties():
     first = depth[o[0][: o[2][0]]]
     pos = first[first > 0]
     assert np.all(np.diff(pos) >= 0) and np.all(first[len(pos):] < 0)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_legacy_binning_oracle_equals_reference(mode):
+    """oracle gso_legacy_* == the reference's tile_ops.h / culling.h kernels compiled for the CPU
+    (oracle/_ref), bit for bit: counts, offsets, unsorted {tile, depth} keys, sorted ids"""
+    from oracle import ref as Rf
+    if not Rf.available():
+        pytest.skip("oracle/_ref/libgs_ref.so not built")
+    if not hasattr(Rf.lib(), "ref_image_sort"):
+        pytest.skip("oracle/_ref predates the legacy-binning entry points (rebuild needs /root/reference)")
+    import scenes
+    sc = scenes.random_scene(400, seed=7, svec=0.06)
+    cam = scenes.Camera(96, 64, fx=80.0)
+    g = scenes.oracle_geometry(sc, cam)
+    m2, c2, dep = g["mean2d"], g["cov2d"].reshape(-1, 4), g["depth"].ravel()
+    nth, ntw = cam.tiles
+    shape = c2 if mode == 0 else np.sqrt(6.0 * np.maximum(c2[:, 0], c2[:, 3])).astype(np.float32)
+    args = (cam.topleft, 16, nth, ntw, 1 / cam.fx, 1 / cam.fy, 0.01)
+    a = O.legacy_count(mode, m2, shape, *args)
+    b = Rf.legacy_count(mode, m2, shape, *args)
+    assert np.array_equal(a, b) and a.sum() > 0
+    for x, y in zip(O.legacy_image_sort(mode, dep, a, m2, shape, *args), Rf.legacy_image_sort(mode, dep, b, m2, shape, *args)):
+        assert np.array_equal(x, y)
