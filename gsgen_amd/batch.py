@@ -108,6 +108,83 @@ class _render_batch(torch.autograd.Function):
         return (g_mean, g_qvec, g_svec, g_alpha, g_col) + (None,) * 8
 
 
+class _render_batch_heads(torch.autograd.Function):
+    """(mean, qvec, svec, alpha, color) -> rgb [B,H,W,3], depth, opacity, depth^2, T [B,H,W,1]: the default
+    (rgb_only = False) output set of GaussianSplattingRenderer.forward (gs/gaussian_splatting.py:1304-1416,
+    :1423-1466), one fused compositing pass per camera (gsgen_vol_render_rgbd) instead of four."""
+
+    @staticmethod
+    def forward(ctx, mean, qvec, svec, alpha, col, cams, br, B, bg_rgb, thresh, detach_depth, stats):
+        mean, qvec, svec = mean.contiguous(), qvec.contiguous(), svec.contiguous()
+        alpha, col = alpha.contiguous(), col.contiguous()
+        lib = _capi.load()
+        H, W, N, dev = br.H, br.W, br.N, mean.device
+        out6 = torch.zeros(B, H, W, 6, device=dev, dtype=torch.float32)
+        T = torch.ones(B, H, W, 1, device=dev, dtype=torch.float32)
+        cur = br._fork(B, (cams, out6, T))
+        cams_p, out_p, T_p = cams.data_ptr(), out6.data_ptr(), T.data_ptr()
+        with torch.cuda.device(dev):
+            for i in range(B):
+                buf, s, ci = br.slots[i], br.streams[i % len(br.streams)].cuda_stream, br._cis[i]
+                cam = cams_p + 272 * i
+                lib.frame_geometry(N, _p(mean), _p(qvec), _p(svec), cam, W, H, buf.D_cap, _p(buf.mean2d),
+                                   _p(buf.cov2d), _p(buf.depth), _p(buf.mask), _p(buf.ids), _p(buf.start), _p(buf.end),
+                                   _p(buf.total), _p(buf.ws), buf.ws.numel(), s)
+                if stats is not None:
+                    lib.densify_update(N, _p(buf.cov2d), None, _p(buf.mask), _p(stats.max_radii2d), None, None, s)
+                lib.vol_render_rgbd(N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col), _p(buf.depth), _p(alpha),
+                                    _p(buf.start), _p(buf.end), _p(buf.ids), out_p + 24 * H * W * i, cam + 224, 16,
+                                    buf.nth, buf.ntw, 1.0 / ci.fx, 1.0 / ci.fy, H, W, thresh, T_p + 4 * H * W * i,
+                                    buf.tile_order(), s)
+        br._join(B, cur)
+        if bg_rgb is not None:
+            out6[..., :3] += T * bg_rgb  # gs/renderer.py:1182
+        ctx.save_for_backward(mean, qvec, svec, alpha, col, cams, out6)
+        ctx.br, ctx.B, ctx.thresh, ctx.detach, ctx.stats = br, B, thresh, detach_depth, stats
+        ctx.cis = list(br._cis[:B])
+        ctx.mark_non_differentiable(T)
+        return out6[..., :3], out6[..., 3:4], out6[..., 4:5], out6[..., 5:6], T
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_depth, g_opac, g_z2, _gT):
+        mean, qvec, svec, alpha, col, cams, out6 = ctx.saved_tensors
+        br, B, thresh, stats = ctx.br, ctx.B, ctx.thresh, ctx.stats
+        lib = _capi.load()
+        H, W, N, dev = br.H, br.W, br.N, mean.device
+        z = lambda g, c: g if g is not None else torch.zeros(B, H, W, c, device=dev)  # noqa: E731
+        go6 = torch.cat([z(g_rgb, 3), z(g_depth, 1), z(g_opac, 1), z(g_z2, 1)], dim=-1).contiguous()
+        g2d = torch.zeros(B, 6 * N, device=dev, dtype=torch.float32)   # per camera: mean2d | cov2d
+        gch = torch.zeros(B, N, 6, device=dev, dtype=torch.float32)    # per camera: rgb | depth | opacity | depth^2
+        gdp = torch.empty(B, N, device=dev, dtype=torch.float32)       # per camera: d L / d (view-space depth)
+        g3d = torch.zeros(11 * N, device=dev, dtype=torch.float32)     # shared: mean | qvec | svec | alpha
+        g_mean, g_qvec = g3d[:3 * N].view(N, 3), g3d[3 * N:7 * N].view(N, 4)
+        g_svec, g_alpha = g3d[7 * N:10 * N].view(N, 3), g3d[10 * N:]
+        cur = br._fork(B, (go6, g2d, gch, gdp, g3d))
+        cams_p, out_p, go_p, g2d_p = cams.data_ptr(), out6.data_ptr(), go6.data_ptr(), g2d.data_ptr()
+        with torch.cuda.device(dev):
+            for i in range(B):
+                buf, stream, ci = br.slots[i], br.streams[i % len(br.streams)], ctx.cis[i]
+                s = stream.cuda_stream
+                cam = cams_p + 272 * i
+                g_mean2d = g2d_p + 24 * N * i
+                g_cov2d = g_mean2d + 8 * N
+                lib.vol_render_rgbd_backward(N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col), _p(buf.depth), _p(alpha),
+                                             _p(buf.start), _p(buf.end), _p(buf.ids), out_p + 24 * H * W * i, g_mean2d,
+                                             g_cov2d, _p(gch[i]), _p(g_alpha), go_p + 24 * H * W * i, cam + 224, 16,
+                                             buf.nth, buf.ntw, 1.0 / ci.fx, 1.0 / ci.fy, H, W, thresh, buf.tile_order(), s)
+                with torch.cuda.stream(stream):  # the depth head and the depth^2 head both feed the depth
+                    torch.addcmul(gch[i, :, 3], buf.depth.view(-1), gch[i, :, 5], value=2.0, out=gdp[i])
+                lib.project_gaussians_backward_accum(N, _p(mean), _p(qvec), _p(svec), cam, int(ctx.detach),
+                                                     _p(buf.mask), g_mean2d, g_cov2d, _p(gdp[i]), _p(g_mean),
+                                                     _p(g_qvec), _p(g_svec), s)
+                if stats is not None:
+                    lib.densify_update(N, None, g_mean2d, _p(buf.mask), None, _p(stats.grad_accum),
+                                       _p(stats.cnt), s)
+        br._join(B, cur)
+        g_col = gch[:, :, :3].sum(0)
+        return (g_mean, g_qvec, g_svec, g_alpha, g_col) + (None,) * 7
+
+
 class BatchRenderer:
     """Renders [B] cameras of one (W, H) shape for a fixed Gaussian count N."""
 
@@ -174,6 +251,21 @@ class BatchRenderer:
         self._cis = list(cam_infos)
         return _render_batch.apply(mean, qvec, svec, alpha, col, cams, self, B, int(C), bg_rgb, float(thresh),
                                    bool(detach_depth), stats)
+
+    def render_heads(self, mean, qvec, svec, alpha, color, cam_infos, c2ws, bg_rgb=None, thresh=1e-4,
+                     frustum_radius=6.0, tile_radius=6.0, detach_depth=True, stats=None):
+        """-> (rgb [B,H,W,3], depth, opacity, depth2, T [B,H,W,1]) from post-activation colours [N,3]: what
+        GaussianSplattingRenderer.forward returns with rgb_only = False, one compositing pass per camera."""
+        B = len(cam_infos)
+        if B > len(self.slots):
+            raise ValueError(f"batch of {B} cameras, renderer was sized for {len(self.slots)}")
+        for ci in cam_infos:
+            if (ci.w, ci.h) != (self.W, self.H):
+                raise ValueError("every camera of a batch must have the renderer's (W, H)")
+        cams = self._upload(cam_infos, c2ws, frustum_radius, tile_radius)
+        self._cis = list(cam_infos)
+        return _render_batch_heads.apply(mean, qvec, svec, alpha, color, cams, self, B, bg_rgb, float(thresh),
+                                         bool(detach_depth), stats)
 
     def ensure_capacity(self, B=None):
         """One host sync: grows any slot whose pair list overflowed in the last batch.  Returns
