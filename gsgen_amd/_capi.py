@@ -13,6 +13,16 @@ DEFAULT_LIB = os.path.join(_HERE, "lib", "libgsgen_hip.so")
 
 u32, f32, vp, i32, sz = C.c_uint32, C.c_float, C.c_void_p, C.c_int, C.c_size_t
 
+
+
+class ShView(C.Structure):
+    """gsgen_sh_view (include/gsgen_hip.h): one camera of a batched SH launch; addresses as ints."""
+    _fields_ = [("mean", vp), ("cov", vp), ("start", vp), ("end", vp), ("gaussian_ids", vp),
+                ("tile_order", vp), ("topleft", vp), ("c2w", vp), ("bg_rgb", vp),
+                ("pixel_size_x", f32), ("pixel_size_y", f32), ("out", vp), ("T", vp),
+                ("segment_workspace", vp), ("grad_out", vp), ("grad_mean", vp), ("grad_cov", vp)]
+
+
 # name -> argtypes, in the order of include/gsgen_hip.h
 SIGNATURES = {
     "gsgen_culling_gaussian_bsphere": [u32, vp, vp, vp, vp, vp, vp, f32, vp],
@@ -50,6 +60,9 @@ SIGNATURES = {
                                       u32, u32, u32, f32, vp, vp, vp, vp, u32, vp],
     "gsgen_vol_render_backward_sh_segmented": [u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                                vp, u32, u32, u32, f32, f32, u32, u32, u32, f32, vp, vp, vp, u32, vp],
+    "gsgen_vol_render_sh_batch": [u32, C.POINTER(ShView), u32, vp, vp, u32, u32, u32, u32, u32, u32, f32, u32, vp, vp],
+    "gsgen_vol_render_backward_sh_batch": [u32, C.POINTER(ShView), u32, vp, vp, vp, vp, u32, u32, u32, u32, u32, u32,
+                                           f32, u32, vp, vp],
     "gsgen_legacy_count_tiles": [u32, u32, vp, vp, vp, u32, u32, u32, f32, f32, f32, vp, vp],
     "gsgen_legacy_image_sort": [u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, u32, f32, f32, f32, vp, sz, vp],
     "gsgen_frame_geometry": [u32, vp, vp, vp, vp, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp],
@@ -61,6 +74,7 @@ SIZE_FUNCS = {
     "gsgen_tile_culling_workspace_bytes": [u32, u32, u32],
     "gsgen_frame_workspace_bytes": [u32, u32, u32],
     "gsgen_segment_workspace_bytes": [u32, u32],
+    "gsgen_sh_batch_workspace_bytes": [u32],
     "gsgen_legacy_sort_workspace_bytes": [u32, u32],
 }
 EXPORTS = sorted(list(SIGNATURES) + list(SIZE_FUNCS) + list(PTR_FUNCS) + ["gsgen_version", "gsgen_error_string"])

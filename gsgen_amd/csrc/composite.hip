@@ -28,6 +28,7 @@
 // backward share eval code, so the backward's recomputed prefix equals the forward bit for
 // bit (the invariant the reference asserts at vol_render_sh.h:452-454).
 #include "composite_common.hpp"
+#include <vector>
 #include <gsgen_mfma.hpp>
 
 namespace gs {
@@ -102,8 +103,12 @@ __device__ __forceinline__ GRec load_rec(const Stage<MODE, CB, KB> &S, int g) {
 // ============================================================================================
 // forward
 // ============================================================================================
-template <int MODE, int CB, int PPL>
-__global__ void __launch_bounds__(256 / PPL) k_composite_fwd(CompParams p) {
+// BATCH: one launch renders gridDim.y cameras, camera blockIdx.y taking its parameters from
+// plist[blockIdx.y] (device memory) instead of the kernel argument -- a single launch's tail (the
+// never-saturating sparse tiles) is then paid once per batch instead of once per camera.
+template <int MODE, int CB, int PPL, bool BATCH = false>
+__global__ void __launch_bounds__(256 / PPL) k_composite_fwd(CompParams p_arg, const CompParams *plist) {
+  const CompParams &p = BATCH ? plist[blockIdx.y] : p_arg;
   using TR = Traits<MODE, CB>;
   constexpr int NT = 256 / PPL;
   constexpr int ROWS = NT / 16;
@@ -562,9 +567,10 @@ __device__ __forceinline__ int frag_dw(int row, int lane, int s) {
 
 // PPL = 4: one wavefront per tile.  PPL = 2: two wavefronts per tile, each contracting its own 128
 // pixels (the partial sums meet in the atomics); the records are staged once for both.
-template <int CB, int PPL>
+template <int CB, int PPL, bool BATCH = false>
 __global__ void __launch_bounds__(256 / PPL) __attribute__((amdgpu_waves_per_eu(2)))
-k_composite_bwd_sh_mfma(CompParams p) {
+k_composite_bwd_sh_mfma(CompParams p_arg, const CompParams *plist) {
+  const CompParams &p = BATCH ? plist[blockIdx.y] : p_arg;  // see k_composite_fwd
   constexpr int MODE = MODE_SH;
   using TR = Traits<MODE, CB>;
   using MC = MfmaCfg<PPL>;
@@ -890,9 +896,9 @@ static int launch_fwd(const CompParams &p, hipStream_t s) {
   static const int ppl = env_ppl("GSGEN_PPL_FWD", 1);
   const uint32_t nblk = comp_grid(p);
   if (p.ntw * p.nth == 0) return 0;
-  if (ppl == 1) hipLaunchKernelGGL((k_composite_fwd<MODE, CB, 1>), dim3(nblk), dim3(256), 0, s, p);
-  else if (ppl == 2) hipLaunchKernelGGL((k_composite_fwd<MODE, CB, 2>), dim3(nblk), dim3(128), 0, s, p);
-  else hipLaunchKernelGGL((k_composite_fwd<MODE, CB, 4>), dim3(nblk), dim3(64), 0, s, p);
+  if (ppl == 1) hipLaunchKernelGGL((k_composite_fwd<MODE, CB, 1>), dim3(nblk), dim3(256), 0, s, p, (const CompParams *)nullptr);
+  else if (ppl == 2) hipLaunchKernelGGL((k_composite_fwd<MODE, CB, 2>), dim3(nblk), dim3(128), 0, s, p, (const CompParams *)nullptr);
+  else hipLaunchKernelGGL((k_composite_fwd<MODE, CB, 4>), dim3(nblk), dim3(64), 0, s, p, (const CompParams *)nullptr);
   return (int)hipGetLastError();
 }
 template <int MODE, int CB>
@@ -910,15 +916,56 @@ static int launch_bwd(const CompParams &p_, hipStream_t s) {
   if constexpr (MODE == MODE_SH) {
     if (ppl == 4 && mfma != 0) {
       const uint32_t ng = nblk * (uint32_t)(p.nseg > 1 ? p.nseg : 1);
-      if (mfma == 1) hipLaunchKernelGGL((k_composite_bwd_sh_mfma<CB, 1>), dim3(ng), dim3(256), 0, s, p);
-      else if (mfma == 2) hipLaunchKernelGGL((k_composite_bwd_sh_mfma<CB, 2>), dim3(ng), dim3(128), 0, s, p);
-      else hipLaunchKernelGGL((k_composite_bwd_sh_mfma<CB, 4>), dim3(ng), dim3(64), 0, s, p);
+      if (mfma == 1) hipLaunchKernelGGL((k_composite_bwd_sh_mfma<CB, 1>), dim3(ng), dim3(256), 0, s, p, (const CompParams *)nullptr);
+      else if (mfma == 2) hipLaunchKernelGGL((k_composite_bwd_sh_mfma<CB, 2>), dim3(ng), dim3(128), 0, s, p, (const CompParams *)nullptr);
+      else hipLaunchKernelGGL((k_composite_bwd_sh_mfma<CB, 4>), dim3(ng), dim3(64), 0, s, p, (const CompParams *)nullptr);
       return (int)hipGetLastError();
     }
   }
   if (ppl == 1) hipLaunchKernelGGL((k_composite_bwd_pixel<MODE, CB, 1>), dim3(nblk), dim3(256), 0, s, p);
   else if (ppl == 2) hipLaunchKernelGGL((k_composite_bwd_pixel<MODE, CB, 2>), dim3(nblk), dim3(128), 0, s, p);
   else hipLaunchKernelGGL((k_composite_bwd_pixel<MODE, CB, 4>), dim3(nblk), dim3(64), 0, s, p);
+  return (int)hipGetLastError();
+}
+
+// ---- batched cameras: parameters through device memory ----------------------------------------
+constexpr int kPackMax = 8;
+struct CompParamsPack { CompParams v[kPackMax]; };
+__global__ void __launch_bounds__(64) k_write_params(CompParamsPack pack, CompParams *dst, int n) {
+  const int i = (int)threadIdx.x;
+  if (i < n) dst[i] = pack.v[i];
+}
+int write_params(const CompParams *host, uint32_t B, CompParams *dst, hipStream_t s) {
+  for (uint32_t b0 = 0; b0 < B; b0 += kPackMax) {
+    CompParamsPack pack{};
+    const int n = (int)((B - b0) < (uint32_t)kPackMax ? (B - b0) : (uint32_t)kPackMax);
+    for (int i = 0; i < n; ++i) pack.v[i] = host[b0 + i];
+    hipLaunchKernelGGL(k_write_params, dim3(1), dim3(64), 0, s, pack, dst + b0, n);
+  }
+  return (int)hipGetLastError();
+}
+int launch_fwd_sh_batch(int C, const CompParams &p0, const CompParams *plist, uint32_t B, hipStream_t s) {
+  const uint32_t nblk = comp_grid(p0);
+  if (p0.ntw * p0.nth == 0 || B == 0) return 0;
+  const dim3 g(nblk, B), b(256);
+  switch (C) {
+    case 1: hipLaunchKernelGGL((k_composite_fwd<MODE_SH, 1, 1, true>), g, b, 0, s, p0, plist); break;
+    case 2: hipLaunchKernelGGL((k_composite_fwd<MODE_SH, 2, 1, true>), g, b, 0, s, p0, plist); break;
+    case 3: hipLaunchKernelGGL((k_composite_fwd<MODE_SH, 3, 1, true>), g, b, 0, s, p0, plist); break;
+    default: hipLaunchKernelGGL((k_composite_fwd<MODE_SH, 4, 1, true>), g, b, 0, s, p0, plist); break;
+  }
+  return (int)hipGetLastError();
+}
+int launch_bwd_sh_batch(int C, const CompParams &p0, const CompParams *plist, uint32_t B, hipStream_t s) {
+  const uint32_t nblk = comp_grid(p0) * (uint32_t)(p0.nseg > 1 ? p0.nseg : 1);
+  if (p0.ntw * p0.nth == 0 || B == 0) return 0;
+  const dim3 g(nblk, B), b(128);
+  switch (C) {
+    case 1: hipLaunchKernelGGL((k_composite_bwd_sh_mfma<1, 2, true>), g, b, 0, s, p0, plist); break;
+    case 2: hipLaunchKernelGGL((k_composite_bwd_sh_mfma<2, 2, true>), g, b, 0, s, p0, plist); break;
+    case 3: hipLaunchKernelGGL((k_composite_bwd_sh_mfma<3, 2, true>), g, b, 0, s, p0, plist); break;
+    default: hipLaunchKernelGGL((k_composite_bwd_sh_mfma<4, 2, true>), g, b, 0, s, p0, plist); break;
+  }
   return (int)hipGetLastError();
 }
 
@@ -1044,6 +1091,83 @@ int gsgen_vol_render_sh_segmented(uint32_t N, uint32_t D, const float *mean, con
     case 3: return launch_fwd<MODE_SH, 3>(p, s);
     default: return launch_fwd<MODE_SH, 4>(p, s);
   }
+}
+
+// ---- batched cameras -----------------------------------------------------------------------------
+static int fill_view_params(uint32_t n_views, const gsgen_sh_view *views, const float *sh_coeffs,
+                            const float *alpha, float *g_sh, float *g_alpha, uint32_t ntw, uint32_t nth,
+                            uint32_t H, uint32_t W, float thresh, uint32_t n_segments, bool backward,
+                            std::vector<CompParams> &ps) {
+  ps.assign(n_views, CompParams{});
+  for (uint32_t b = 0; b < n_views; ++b) {
+    const gsgen_sh_view &v = views[b];
+    if (!v.start || !v.end || !v.out || !v.c2w) return GSGEN_EINVAL;
+    if ((v.tile_order == nullptr) != (views[0].tile_order == nullptr)) return GSGEN_EINVAL;
+    if (n_segments > 1 && v.segment_workspace == nullptr) return GSGEN_EINVAL;
+    if (backward && (!v.grad_out || !v.grad_mean || !v.grad_cov)) return GSGEN_EINVAL;
+    CompParams &p = ps[b];
+    p.mean = v.mean; p.cov = v.cov; p.col = sh_coeffs; p.alpha = alpha;
+    p.start = v.start; p.end = v.end; p.ids = v.gaussian_ids; p.topleft = v.topleft; p.rot = v.c2w;
+    p.ntw = (int)ntw; p.nth = (int)nth; p.H = (int)H; p.W = (int)W;
+    p.psx = v.pixel_size_x; p.psy = v.pixel_size_y; p.thresh = thresh;
+    p.tile_order = v.tile_order;
+    p.n_hi = 0x7fffffff;
+    if (backward) {
+      p.final_img = v.out; p.grad_out = v.grad_out;
+      p.g_mean = v.grad_mean; p.g_cov = v.grad_cov; p.g_col = g_sh; p.g_alpha = g_alpha;
+    } else {
+      p.bg = v.bg_rgb; p.out = v.out; p.T = v.T;
+    }
+    if (n_segments > 1) {
+      p.nseg = (int)n_segments;
+      p.ckpt = reinterpret_cast<float4 *>(v.segment_workspace);
+      p.stop = reinterpret_cast<int *>(p.ckpt + (size_t)nth * ntw * 256 * n_segments);
+    }
+  }
+  return 0;
+}
+
+size_t gsgen_sh_batch_workspace_bytes(uint32_t n_views) { return 2 * (size_t)n_views * sizeof(CompParams); }
+
+int gsgen_vol_render_sh_batch(uint32_t n_views, const gsgen_sh_view *views, uint32_t N,
+                              const float *sh_coeffs, const float *alpha, uint32_t tile_size,
+                              uint32_t n_tiles_h, uint32_t n_tiles_w, uint32_t H, uint32_t W, uint32_t C,
+                              float thresh, uint32_t n_segments, void *batch_workspace,
+                              gsgen_stream_t stream) {
+  if (tile_size != 16) return GSGEN_EUNSUPPORTED;
+  if (C < 1 || C > 4) return GSGEN_EUNSUPPORTED;
+  if (n_views == 0) return 0;
+  if (!views || !batch_workspace) return GSGEN_EINVAL;
+  if (n_views > 65535) return GSGEN_EINVAL;  // gridDim.y
+  (void)N;
+  std::vector<CompParams> ps;
+  if (int e = fill_view_params(n_views, views, sh_coeffs, alpha, nullptr, nullptr, n_tiles_w, n_tiles_h, H, W,
+                               thresh, n_segments, false, ps))
+    return e;
+  hipStream_t s = (hipStream_t)stream;
+  CompParams *dst = reinterpret_cast<CompParams *>(batch_workspace);
+  if (int e = write_params(ps.data(), n_views, dst, s)) return e;
+  return launch_fwd_sh_batch((int)C, ps[0], dst, n_views, s);
+}
+
+int gsgen_vol_render_backward_sh_batch(uint32_t n_views, const gsgen_sh_view *views, uint32_t N,
+                                       const float *sh_coeffs, const float *alpha, float *grad_sh_coeffs,
+                                       float *grad_alpha, uint32_t tile_size, uint32_t n_tiles_h,
+                                       uint32_t n_tiles_w, uint32_t H, uint32_t W, uint32_t C, float thresh,
+                                       uint32_t n_segments, void *batch_workspace, gsgen_stream_t stream) {
+  if (tile_size != 16) return GSGEN_EUNSUPPORTED;
+  if (C < 1 || C > 4) return GSGEN_EUNSUPPORTED;
+  if (n_views == 0 || N == 0) return 0;
+  if (!views || !batch_workspace || !grad_sh_coeffs || !grad_alpha) return GSGEN_EINVAL;
+  if (n_views > 65535) return GSGEN_EINVAL;
+  std::vector<CompParams> ps;
+  if (int e = fill_view_params(n_views, views, sh_coeffs, alpha, grad_sh_coeffs, grad_alpha, n_tiles_w,
+                               n_tiles_h, H, W, thresh, n_segments, true, ps))
+    return e;
+  hipStream_t s = (hipStream_t)stream;
+  CompParams *dst = reinterpret_cast<CompParams *>(batch_workspace) + n_views;
+  if (int e = write_params(ps.data(), n_views, dst, s)) return e;
+  return launch_bwd_sh_batch((int)C, ps[0], dst, n_views, s);
 }
 
 int gsgen_vol_render_sh(uint32_t N, uint32_t D, const float *mean, const float *cov,

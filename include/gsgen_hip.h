@@ -274,6 +274,40 @@ int gsgen_vol_render_backward_sh_segmented(uint32_t N, uint32_t D, const float *
                                            const void *segment_workspace, uint32_t n_segments,
                                            gsgen_stream_t stream);
 
+/* Batched cameras in ONE launch (the reference loops over the cameras of a batch in
+ * Python, gs/gaussian_splatting.py:1423-1466, calling render_sh / its backward once per camera).  A
+ * single 800x800 launch ends on a tail of long sparse tiles that leaves most of the chip idle;
+ * gridDim.y = n_views pays that tail once per batch.  Every view has its own projected records,
+ * lists and outputs; sh_coeffs / alpha and their gradients are shared, the gradients accumulating
+ * atomically over views exactly as they do over tiles.  Per view the result is bit-identical to
+ * gsgen_vol_render_sh_segmented / gsgen_vol_render_backward_sh_segmented on the same inputs
+ * (gradient sums up to fp32 atomic order).  `views` is HOST memory, read before the call returns.
+ * batch_workspace: device, gsgen_sh_batch_workspace_bytes(n_views) bytes, one per batch in flight
+ * (it carries the per-view kernel parameters from the forward launch to the end of the backward). */
+typedef struct gsgen_sh_view {
+  const float *mean, *cov;                 /* [N,2], [N,2,2] of this view */
+  const int *start, *end, *gaussian_ids;   /* [n_tiles], [n_tiles], [D] */
+  const uint32_t *tile_order;              /* [n_tiles] or NULL (then NULL in every view) */
+  const float *topleft, *c2w;              /* [2], [9] */
+  const float *bg_rgb;                     /* [3] or NULL */
+  float pixel_size_x, pixel_size_y;
+  float *out, *T;                          /* [H,W,3], [H,W]; out is read by the backward */
+  void *segment_workspace;                 /* gsgen_segment_workspace_bytes, or NULL if n_segments <= 1 */
+  const float *grad_out;                   /* backward: [H,W,3] */
+  float *grad_mean, *grad_cov;             /* backward: [N,2], [N,2,2] of this view, accumulated into */
+} gsgen_sh_view;
+size_t gsgen_sh_batch_workspace_bytes(uint32_t n_views);
+int gsgen_vol_render_sh_batch(uint32_t n_views, const gsgen_sh_view *views, uint32_t N,
+                              const float *sh_coeffs, const float *alpha, uint32_t tile_size,
+                              uint32_t n_tiles_h, uint32_t n_tiles_w, uint32_t H, uint32_t W, uint32_t C,
+                              float thresh, uint32_t n_segments, void *batch_workspace,
+                              gsgen_stream_t stream);
+int gsgen_vol_render_backward_sh_batch(uint32_t n_views, const gsgen_sh_view *views, uint32_t N,
+                                       const float *sh_coeffs, const float *alpha, float *grad_sh_coeffs,
+                                       float *grad_alpha, uint32_t tile_size, uint32_t n_tiles_h,
+                                       uint32_t n_tiles_w, uint32_t H, uint32_t W, uint32_t C, float thresh,
+                                       uint32_t n_segments, void *batch_workspace, gsgen_stream_t stream);
+
 /* Fused RGB + auxiliary heads: what render_one does in four compositing passes
  * (gs/gaussian_splatting.py:1304-1403: rgb, depth, opacity = scalar 1, depth^2) in one.
  * out6 / grad_out6 are [H,W,6] = (r, g, b, depth, opacity, depth^2); grad_chan6 [N,6] receives the

@@ -411,6 +411,80 @@ def test_emulated_segmented_backward_matches_unsegmented(emu, C, nseg):
                                     P(bg), None, None, None, nseg, None)
 
 
+@pytest.mark.parametrize("C,nseg", [(4, 0), (3, 3)])
+def test_emulated_batched_views_match_per_view_launches(emu, C, nseg):
+    """gsgen_vol_render_sh_batch / _backward_sh_batch (gridDim.y = views, parameters through device
+    memory) == one gsgen_vol_render_sh_segmented / _backward_sh_segmented call per view, shared SH and
+    opacity gradients accumulated over the views"""
+    from gsgen_amd._capi import ShView
+    W, H = 32, 32
+    sc = scenes.random_scene(700, seed=41, svec=0.08, C=C)
+    sc["alpha"] = (sc["alpha"] * 0.3).astype(np.float32)
+    Nall = sc["mean"].shape[0]
+    sh, al = np.ascontiguousarray(sc["sh"]), np.ascontiguousarray(sc["alpha"])
+    cams = [scenes.Camera(W, H, fx=40.0, c2w=scenes.look_at(e)) for e in ((2.5, 0, 0), (0, 2.4, 0.6), (-1.5, -1.5, 1.2))]
+    nth, ntw = cams[0].tiles
+    views, keep = [], []
+    for cam in cams:
+        g = scenes.oracle_geometry(sc, cam)
+        nz = np.nonzero(g["mask"])[0]
+        m2 = np.zeros((Nall, 2), np.float32); c2 = np.zeros((Nall, 2, 2), np.float32)
+        m2[nz] = g["mean2d"]; c2[nz] = g["cov2d"]
+        v = dict(m2=m2, c2=c2, st=g["start"], en=g["end"], ids=nz[g["ids"]].astype(np.int32), tlp=cam.topleft,
+                 rot=np.ascontiguousarray(cam.c2w[:3, :3].reshape(-1)), cam=cam, D=g["D"],
+                 bg=np.array([0.3, 0.1, 0.2], np.float32) * (len(views) + 1),
+                 go=np.random.default_rng(len(views)).normal(size=(H, W, 3)).astype(np.float32))
+        views.append(v)
+    assert max((v["en"] - v["st"]).max() for v in views) > 40
+    # per-view launches
+    ref_gsh = np.zeros_like(sh); ref_ga = np.zeros(Nall, np.float32)
+    for v in views:
+        cam = v["cam"]
+        geo = (16, nth, ntw, 1 / cam.fx, 1 / cam.fy, H, W, C, 1e-4)
+        v["ws"] = np.zeros(max(1, emu.segment_workspace_bytes(nth * ntw, nseg)), np.uint8)
+        v["out_ref"] = np.zeros((H, W, 3), np.float32); v["T_ref"] = np.ones((H, W), np.float32)
+        emu.vol_render_sh_segmented(Nall, v["D"], P(v["m2"]), P(v["c2"]), P(sh), P(al), P(v["st"]), P(v["en"]), P(v["ids"]),
+                                    P(v["out_ref"]), P(v["tlp"]), P(v["rot"]), *geo, P(v["bg"]), P(v["T_ref"]), None,
+                                    P(v["ws"]) if nseg else None, nseg, None)
+        v["gm_ref"] = np.zeros((Nall, 2), np.float32); v["gc_ref"] = np.zeros((Nall, 4), np.float32)
+        emu.vol_render_backward_sh_segmented(Nall, v["D"], P(v["m2"]), P(v["c2"]), P(sh), P(al), P(v["st"]), P(v["en"]),
+                                             P(v["ids"]), P(v["out_ref"]), P(v["gm_ref"]), P(v["gc_ref"]), P(ref_gsh),
+                                             P(ref_ga), P(v["go"]), P(v["tlp"]), P(v["rot"]), *geo, P(v["bg"]), None,
+                                             P(v["ws"]) if nseg else None, nseg, None)
+    # one batched launch each way
+    arr = (ShView * len(views))()
+    for a, v in zip(arr, views):
+        cam = v["cam"]
+        v["ws2"] = np.zeros_like(v["ws"])
+        v["out"] = np.zeros((H, W, 3), np.float32); v["T"] = np.ones((H, W), np.float32)
+        v["gm"] = np.zeros((Nall, 2), np.float32); v["gc"] = np.zeros((Nall, 4), np.float32)
+        a.mean, a.cov, a.start, a.end, a.gaussian_ids = P(v["m2"]), P(v["c2"]), P(v["st"]), P(v["en"]), P(v["ids"])
+        a.tile_order, a.topleft, a.c2w, a.bg_rgb = None, P(v["tlp"]), P(v["rot"]), P(v["bg"])
+        a.pixel_size_x, a.pixel_size_y = 1 / cam.fx, 1 / cam.fy
+        a.out, a.T, a.segment_workspace = P(v["out"]), P(v["T"]), (P(v["ws2"]) if nseg else None)
+        a.grad_out, a.grad_mean, a.grad_cov = P(v["go"]), P(v["gm"]), P(v["gc"])
+    bws = np.zeros(emu.sh_batch_workspace_bytes(len(views)), np.uint8)
+    emu.vol_render_sh_batch(len(views), arr, Nall, P(sh), P(al), 16, nth, ntw, H, W, C, 1e-4, nseg, P(bws), None)
+    gsh = np.zeros_like(sh); ga = np.zeros(Nall, np.float32)
+    emu.vol_render_backward_sh_batch(len(views), arr, Nall, P(sh), P(al), P(gsh), P(ga), 16, nth, ntw, H, W, C, 1e-4, nseg,
+                                     P(bws), None)
+    for v in views:
+        assert np.array_equal(v["out"], v["out_ref"]) and np.array_equal(v["T"], v["T_ref"])
+        assert np.abs(v["out"]).max() > 0.1
+        for a_, b_ in ((v["gm"], v["gm_ref"]), (v["gc"], v["gc_ref"])):
+            assert np.abs(a_ - b_).max() <= 2e-6 * np.abs(b_).max()
+    assert np.abs(gsh - ref_gsh).max() <= 2e-6 * np.abs(ref_gsh).max() and np.abs(ref_gsh).max() > 0
+    assert np.abs(ga - ref_ga).max() <= 2e-6 * np.abs(ref_ga).max()
+    # argument checks: a view without its segment workspace / without a batch workspace
+    with pytest.raises(Exception, match="invalid"):
+        emu.vol_render_sh_batch(len(views), arr, Nall, P(sh), P(al), 16, nth, ntw, H, W, C, 1e-4, nseg, None, None)
+    arr[1].grad_out = None
+    with pytest.raises(Exception, match="invalid"):
+        emu.vol_render_backward_sh_batch(len(views), arr, Nall, P(sh), P(al), P(gsh), P(ga), 16, nth, ntw, H, W, C, 1e-4,
+                                         nseg, P(bws), None)
+    emu.vol_render_sh_batch(0, arr, Nall, P(sh), P(al), 16, nth, ntw, H, W, C, 1e-4, nseg, None, None)  # empty batch
+
+
 def test_no_kernel_spills_and_hot_kernels_keep_their_occupancy(tmp_path):
     """Reads the code-object metadata of the built library (cross-compiled, no GPU needed): no
     kernel may use scratch memory, and the compositing kernels must keep the register budgets their
