@@ -130,6 +130,10 @@ def main():
                     help="same for the one-render-in-flight pass (uniform work units shorten a lone launch's tail)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("GSGEN_STREAMS", "3")),
                     help="independent renders in flight (HIP streams, own buffers each)")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("GSGEN_BATCH", "1")),
+                    help="cameras per compositing launch (gsgen_vol_render_sh_batch: gridDim.y = cameras); 1 = one "
+                         "launch per camera.  A step is still one render: K steps run as ceil(K / batch) launches")
+    ap.add_argument("--batch-slots", type=int, default=2, help="batches in flight (own stream and buffers each)")
     args = ap.parse_args()
 
     import torch
@@ -225,7 +229,113 @@ def main():
             with torch.cuda.stream(stream):
                 dist.all_gather_into_tensor(gathered, sl.out)
 
+    # --batch B > 1: the B cameras of a batch share ONE forward and ONE backward compositing launch
+    # (gridDim.y = B) and one set of parameter gradients -- what a training step over a camera batch
+    # needs (gs/gaussian_splatting.py:1423-1466 loops the cameras, autograd sums their gradients).
+    # Geometry / binning and the projection backward stay per camera.  Batches alternate over
+    # --batch-slots streams so one batch's geometry overlaps the other's compositing.
+    B = max(1, args.batch)
+
+    class BatchSlot:
+        def __init__(self, stream):
+            self.stream, self.s = stream, stream.cuda_stream
+            with torch.cuda.stream(stream):
+                self.bufs = [R.FrameBuffers(N, W, H, dev) for _ in range(B)]
+                self.out = torch.empty(B, H, W, 3, device=dev)
+                # per view: mean2d(2) | cov2d(4); shared: alpha(1) | sh | mean(3) | qvec(4) | svec(3)
+                self.gflat = torch.empty(B * 6 * N + N * (1 + CC3 + 10), device=dev)
+                self.seg_ws = [torch.empty(max(1, lib.segment_workspace_bytes(nth * ntw, args.segments)), device=dev,
+                                           dtype=torch.uint8) for _ in range(B)]
+                self.bws = torch.empty(lib.sh_batch_workspace_bytes(B), device=dev, dtype=torch.uint8)
+            o = B * 6 * N
+            g = self.gflat
+            self.g_alpha, self.g_sh = g[o:o + N], g[o + N:o + N * (1 + CC3)]
+            o += N * (1 + CC3)
+            self.g_mean, self.g_qvec, self.g_svec = g[o:o + 3 * N], g[o + 3 * N:o + 7 * N], g[o + 7 * N:o + 10 * N]
+            self.views = {}
+
+        def view_array(self, k0, nb):
+            key = (k0, nb)
+            if key not in self.views:
+                arr = (_capi.ShView * nb)()
+                for i in range(nb):
+                    k, b_, a = (k0 + i) % len(cams), self.bufs[i], arr[i]
+                    a.mean, a.cov, a.start, a.end, a.gaussian_ids = p(b_.mean2d), p(b_.cov2d), p(b_.start), p(b_.end), p(b_.ids)
+                    a.tile_order = None if os.environ.get("GSGEN_NO_ORDER") else b_.tile_order()
+                    a.topleft, a.c2w, a.bg_rgb = p(topleft_dev[k]), p(rot_dev[k]), p(bg)
+                    a.pixel_size_x, a.pixel_size_y = 1.0 / cis[k].fx, 1.0 / cis[k].fy
+                    a.out, a.T = p(self.out[i]), None
+                    a.segment_workspace = p(self.seg_ws[i]) if args.segments > 1 else None
+                    a.grad_out = p(grad_out)
+                    a.grad_mean = p(self.gflat) + 4 * 6 * N * i
+                    a.grad_cov = a.grad_mean + 4 * 2 * N
+                self.views[key] = arr
+            return self.views[key]
+
+    bslots = [BatchSlot(torch.cuda.Stream(dev)) for _ in range(max(1, args.batch_slots))] if B > 1 else []
+    gathered_b = torch.empty(world, B, H, W, 3, device=dev) if (world > 1 and B > 1) else None
+
+    def batch_step(j, k0, nb, timed=None, gather=True):
+        """renders cameras k0 .. k0+nb-1 (mod the camera set) as batch j"""
+        sl = bslots[j % len(bslots)]
+        s, stream = sl.s, sl.stream
+        for i in range(nb):
+            k, b_ = (k0 + i) % len(cams), sl.bufs[i]
+            lib.frame_geometry(N, p(t["mean"]), p(t["qvec"]), p(t["svec"]), p(cam_dev[k]), W, H, b_.D_cap,
+                               p(b_.mean2d), p(b_.cov2d), p(b_.depth), p(b_.mask), p(b_.ids), p(b_.start),
+                               p(b_.end), p(b_.total), p(b_.ws), b_.ws.numel(), s)
+        arr = sl.view_array(k0 % len(cams), nb)
+        if timed is not None:
+            timed[0].record(stream)
+        lib.vol_render_sh_batch(nb, arr, N, p(t["sh"]), p(t["alpha"]), 16, nth, ntw, H, W, C, 1e-4, args.segments,
+                                p(sl.bws), s)
+        if timed is not None:
+            timed[1].record(stream)
+        with torch.cuda.stream(stream):
+            sl.gflat.zero_()
+        if timed is not None:
+            timed[2].record(stream)
+        lib.vol_render_backward_sh_batch(nb, arr, N, p(t["sh"]), p(t["alpha"]), p(sl.g_sh), p(sl.g_alpha), 16, nth, ntw,
+                                         H, W, C, 1e-4, args.segments, p(sl.bws), s)
+        if timed is not None:
+            timed[3].record(stream)
+        for i in range(nb):
+            k, b_ = (k0 + i) % len(cams), sl.bufs[i]
+            lib.project_gaussians_backward_accum(N, p(t["mean"]), p(t["qvec"]), p(t["svec"]), p(cam_dev[k]), 1,
+                                                 p(b_.mask), arr[i].grad_mean, arr[i].grad_cov, None, p(sl.g_mean),
+                                                 p(sl.g_qvec), p(sl.g_svec), s)
+        if gathered_b is not None and gather:
+            with torch.cuda.stream(stream):
+                dist.all_gather_into_tensor(gathered_b, sl.out)
+
+    def run_steps(first, count, evs_):
+        """`count` renders starting at render index `first`: one launch chain per render (B == 1) or per
+        batch of B consecutive cameras"""
+        used = []
+        if B == 1:
+            for i in range(count):
+                step(first + i, evs_[i] if evs_ is not None else None)
+                used.append(i)
+            return used
+        done, j = 0, first // B
+        while done < count:
+            nb = min(B, count - done)
+            batch_step(j, first + done, nb, evs_[done] if evs_ is not None else None)
+            used.append(done)
+            done += nb
+            j += 1
+        return used
+
     # size the pair buffers once, outside the timed region (one sync)
+    for sl in bslots:
+        for k0 in range(len(cams)):  # every buffer meets every camera
+            for _ in range(2):
+                batch_step(bslots.index(sl), k0, B, gather=False)
+                torch.cuda.synchronize()
+                if all([b_.ensure_capacity() for b_ in sl.bufs]):
+                    break
+            else:
+                raise AssertionError("pair buffers still too small after growing")
     Ds = []
     for sidx in range(n_streams):
         for k in range(len(cams)):
@@ -239,8 +349,7 @@ def main():
                 Ds.append(int(slots[0].buf.total.item()))
     n_vis = int(buf.mask.sum().item())
 
-    for i in range(args.warmup):
-        step(i)
+    run_steps(0, args.warmup, None)
 
     def barrier():
         if dist is not None:
@@ -251,8 +360,7 @@ def main():
     evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i, evs[i])
+    launched = run_steps(args.warmup, args.steps, evs)
     host_el = time.perf_counter() - t0  # host time to enqueue everything (launch-bound if ~= el)
     barrier()
     el = time.perf_counter() - t0
@@ -301,8 +409,9 @@ def main():
                "fwd_kernel_ms": float(np.mean([e[0].elapsed_time(e[1]) for e in ev1])),
                "bwd_kernel_ms": float(np.mean([e[2].elapsed_time(e[3]) for e in ev1]))}
 
-    fwd_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))
-    bwd_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in evs]))
+    fwd_ms = float(np.mean([evs[i][0].elapsed_time(evs[i][1]) for i in launched]))
+    bwd_ms = float(np.mean([evs[i][2].elapsed_time(evs[i][3]) for i in launched]))
+    vpl = args.steps / len(launched)  # views per compositing launch
     D = float(np.mean([Ds[(args.warmup + i) % len(cams)] for i in range(args.steps)]))
     P, T = W * H, nth * ntw
     F = 7 + CC3
@@ -316,7 +425,7 @@ def main():
     except Exception:
         traffic, valu_floor = None, None
     # dominant kernel = composite backward
-    ach = parts["composite_bwd"] / (bwd_ms * 1e-3) / 1e9
+    ach = vpl * parts["composite_bwd"] / (bwd_ms * 1e-3) / 1e9
     res = {
         "metric": "fwd+bwd renders/sec (800x800, 100k Gaussians)" if args.config == "cfg2" else f"fwd+bwd renders/sec ({args.config})",
         "value": value, "unit": "renders/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -327,13 +436,13 @@ def main():
                                 "cfg4": "BASELINE configs[3]: 100k Gaussians, 64 random-pose cameras at 512x512, camera-sharded",
                                 "cfg1": "BASELINE configs[0]: 1k random Gaussians, 256x256, SH degree 0"}[args.config],
                    "gaussians": N, "visible_after_cull": n_vis, "image": [H, W], "sh_degree": C - 1,
-                   "tile_pairs_D": D, "cameras_per_gpu_per_step": 1, "renders_in_flight": n_streams, "backward_segments_per_tile": args.segments, "parallelism": f"camera-sharded x{world}",
+                   "tile_pairs_D": D, "cameras_per_gpu_per_step": 1, "cameras_per_launch": B, "renders_in_flight": n_streams if B == 1 else B * len(bslots), "backward_segments_per_tile": args.segments, "parallelism": f"camera-sharded x{world}",
                    "gather": "rccl all_gather of rendered images" if world > 1 else "none"},
         "roofline": {"bound": "hbm", "kernel": f"k_composite_bwd_sh_mfma<C={C},2> (compositing backward, matrix-core grad_sh)", "achieved": ach, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                     "alg_bytes_per_launch": parts["composite_bwd"], "avg_launch_ms": bwd_ms,
+                     "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None if traffic is None else traffic * vpl,
+                     "alg_bytes_per_launch": vpl * parts["composite_bwd"], "views_per_launch": vpl, "avg_launch_ms": bwd_ms,
                      "fwd_kernel_ms": fwd_ms,
-                     "fwd_kernel_GBs": parts["composite_fwd"] / (fwd_ms * 1e-3) / 1e9,
+                     "fwd_kernel_GBs": vpl * parts["composite_fwd"] / (fwd_ms * 1e-3) / 1e9,
                      "whole_render_alg_bytes": total_b,
                      "whole_render_hbm_frac": total_b * (value / world) / (HBM_PEAK_GBS * 1e9)},
     }
@@ -344,8 +453,8 @@ def main():
     if valu_floor is not None:
         # the kernel is bound by vector-ALU issue, not HBM: time it would take if
         # every SIMD issued its share of the measured vector instructions back to back
-        res["roofline"]["valu_floor_ms"] = valu_floor
-        res["roofline"]["valu_frac"] = valu_floor / bwd_ms
+        res["roofline"]["valu_floor_ms"] = valu_floor * vpl
+        res["roofline"]["valu_frac"] = valu_floor * vpl / bwd_ms
     if args.breakdown and rank == 0:
         names = ["geometry+bin+sort", "composite_fwd", "zero_grads", "composite_bwd"]
         stage_ev = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(20)]

@@ -34,6 +34,7 @@ class _render_batch(torch.autograd.Function):
         H, W, N, dev = br.H, br.W, br.N, mean.device
         out = torch.zeros(B, H, W, 3, device=dev, dtype=torch.float32)
         T = torch.ones(B, H, W, 1, device=dev, dtype=torch.float32)
+        fused = br.fused_launch and C > 0 and B > 0
         cur = br._fork(B, (cams, out, T))
         cams_p, out_p, T_p = cams.data_ptr(), out.data_ptr(), T.data_ptr()
         with torch.cuda.device(dev):
@@ -46,6 +47,8 @@ class _render_batch(torch.autograd.Function):
                                    _p(buf.total), _p(buf.ws), buf.ws.numel(), s)
                 if stats is not None:
                     lib.densify_update(N, _p(buf.cov2d), None, _p(buf.mask), _p(stats.max_radii2d), None, None, s)
+                if fused:
+                    continue
                 if C > 0:
                     lib.vol_render_sh_ordered(N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col), _p(alpha),
                                               _p(buf.start), _p(buf.end), _p(buf.ids), out_p + 12 * H * W * i, cam + 224,
@@ -57,6 +60,22 @@ class _render_batch(torch.autograd.Function):
                                                     cam + 224, 16, buf.nth, buf.ntw, psx, psy, H, W, thresh,
                                                     T_p + 4 * H * W * i, s)
         br._join(B, cur)
+        ctx.views = ctx.bws = None
+        if fused:  # every camera's lists are ready: ONE compositing launch for the batch (gridDim.y = B)
+            views = (_capi.ShView * B)()
+            for i in range(B):
+                buf, ci, v = br.slots[i], br._cis[i], views[i]
+                cam = cams_p + 272 * i
+                v.mean, v.cov, v.start, v.end, v.gaussian_ids = _p(buf.mean2d), _p(buf.cov2d), _p(buf.start), _p(buf.end), _p(buf.ids)
+                v.tile_order, v.topleft, v.c2w, v.bg_rgb = buf.tile_order(), cam + 224, cam + 232, _p(bg_rgb)
+                v.pixel_size_x, v.pixel_size_y = 1.0 / ci.fx, 1.0 / ci.fy
+                v.out, v.T = out_p + 12 * H * W * i, T_p + 4 * H * W * i
+                v.segment_workspace = _p(buf.seg_ws) if br.segments > 1 else None
+            bws = torch.empty(lib.sh_batch_workspace_bytes(B), device=dev, dtype=torch.uint8)
+            with torch.cuda.device(dev):
+                lib.vol_render_sh_batch(B, views, N, _p(col), _p(alpha), 16, br.slots[0].nth, br.slots[0].ntw, H, W, C,
+                                        thresh, br.segments, _p(bws), cur.cuda_stream)
+            ctx.views, ctx.bws = views, bws
         if C == 0 and bg_rgb is not None:
             out = out + T * bg_rgb  # gs/renderer.py:1182
         ctx.save_for_backward(mean, qvec, svec, alpha, col, cams, out)
@@ -77,8 +96,19 @@ class _render_batch(torch.autograd.Function):
         g_mean, g_qvec = g3d[:3 * N].view(N, 3), g3d[3 * N:7 * N].view(N, 4)
         g_svec, g_alpha = g3d[7 * N:10 * N].view(N, 3), g3d[10 * N:]
         g_col = torch.zeros_like(col)
-        cur = br._fork(B, (grad, g2d, g3d, g_col))
         cams_p, out_p, grad_p, g2d_p = cams.data_ptr(), out.data_ptr(), grad.data_ptr(), g2d.data_ptr()
+        fused = ctx.views is not None
+        if fused:  # one compositing-backward launch for the batch, then the per-camera projections fan out
+            for i in range(B):
+                v = ctx.views[i]
+                v.grad_out = grad_p + 12 * H * W * i
+                v.grad_mean = g2d_p + 24 * N * i
+                v.grad_cov = g2d_p + 24 * N * i + 8 * N
+            with torch.cuda.device(dev):
+                lib.vol_render_backward_sh_batch(B, ctx.views, N, _p(col), _p(alpha), _p(g_col), _p(g_alpha), 16,
+                                                 br.slots[0].nth, br.slots[0].ntw, H, W, C, thresh, br.segments,
+                                                 _p(ctx.bws), torch.cuda.current_stream(dev).cuda_stream)
+        cur = br._fork(B, (grad, g2d, g3d, g_col))
         with torch.cuda.device(dev):
             for i in range(B):
                 buf, s, ci = br.slots[i], br.streams[i % len(br.streams)].cuda_stream, ctx.cis[i]
@@ -86,7 +116,9 @@ class _render_batch(torch.autograd.Function):
                 g_mean2d = g2d_p + 24 * N * i
                 g_cov2d = g_mean2d + 8 * N
                 psx, psy = 1.0 / ci.fx, 1.0 / ci.fy
-                if C > 0:
+                if fused:
+                    pass
+                elif C > 0:
                     lib.vol_render_backward_sh_ordered(N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col), _p(alpha),
                                                        _p(buf.start), _p(buf.end), _p(buf.ids), out_p + 12 * H * W * i,
                                                        g_mean2d, g_cov2d, _p(g_col), _p(g_alpha),
@@ -188,9 +220,14 @@ class _render_batch_heads(torch.autograd.Function):
 class BatchRenderer:
     """Renders [B] cameras of one (W, H) shape for a fixed Gaussian count N."""
 
-    def __init__(self, N, W, H, device, max_batch, n_streams=3, D_cap=None):
+    def __init__(self, N, W, H, device, max_batch, n_streams=3, D_cap=None, fused_launch=False, segments=1):
+        """fused_launch: SH batches composite in ONE forward and ONE backward launch (gridDim.y = cameras,
+        gsgen_vol_render_sh_batch) instead of one launch per camera on the side streams; geometry /
+        binning and the projection backward still fan out over the streams.  segments: backward
+        workgroups per tile (FrameBuffers), fused launches only."""
         self.N, self.W, self.H, self.device = N, W, H, torch.device(device)
-        self.slots = [R.FrameBuffers(N, W, H, device, D_cap=D_cap) for _ in range(max_batch)]
+        self.fused_launch, self.segments = bool(fused_launch), int(segments) if fused_launch else 1
+        self.slots = [R.FrameBuffers(N, W, H, device, D_cap=D_cap, segments=self.segments) for _ in range(max_batch)]
         self.streams = [torch.cuda.Stream(device=device) for _ in range(max(1, n_streams))]
         # per camera: cam block (56) | topleft (2) | rotation rows (9) | pad -> 68 floats
         # ring of pinned staging blocks: a block is only rewritten once its upload (queued behind

@@ -107,8 +107,10 @@ __device__ __forceinline__ GRec load_rec(const Stage<MODE, CB, KB> &S, int g) {
 // plist[blockIdx.y] (device memory) instead of the kernel argument -- a single launch's tail (the
 // never-saturating sparse tiles) is then paid once per batch instead of once per camera.
 template <int MODE, int CB, int PPL, bool BATCH = false>
-__global__ void __launch_bounds__(256 / PPL) k_composite_fwd(CompParams p_arg, const CompParams *plist) {
-  const CompParams &p = BATCH ? plist[blockIdx.y] : p_arg;
+__global__ void __launch_bounds__(256 / PPL) k_composite_fwd(CompParams p_arg, const CompParams *__restrict__ plist) {
+  // by value: read once with scalar loads; through a reference every use in the entry loop would be
+  // re-read from memory (the kernel's own stores may alias it as far as the compiler knows)
+  const CompParams p = BATCH ? plist[blockIdx.y] : p_arg;
   using TR = Traits<MODE, CB>;
   constexpr int NT = 256 / PPL;
   constexpr int ROWS = NT / 16;
@@ -569,8 +571,8 @@ __device__ __forceinline__ int frag_dw(int row, int lane, int s) {
 // pixels (the partial sums meet in the atomics); the records are staged once for both.
 template <int CB, int PPL, bool BATCH = false>
 __global__ void __launch_bounds__(256 / PPL) __attribute__((amdgpu_waves_per_eu(2)))
-k_composite_bwd_sh_mfma(CompParams p_arg, const CompParams *plist) {
-  const CompParams &p = BATCH ? plist[blockIdx.y] : p_arg;  // see k_composite_fwd
+k_composite_bwd_sh_mfma(CompParams p_arg, const CompParams *__restrict__ plist) {
+  const CompParams p = BATCH ? plist[blockIdx.y] : p_arg;  // see k_composite_fwd
   constexpr int MODE = MODE_SH;
   using TR = Traits<MODE, CB>;
   using MC = MfmaCfg<PPL>;

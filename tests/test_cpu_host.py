@@ -510,16 +510,17 @@ def test_no_kernel_spills_and_hot_kernels_keep_their_occupancy(tmp_path):
     spilling = {k: v for k, v in kernels.items() if v["private_segment_fixed_size"] != 0}
     assert not spilling, spilling
 
-    def find(*parts):
+    def find(n, *parts):
         hits = [v for k, v in kernels.items() if all(p in k for p in parts)]
-        assert len(hits) == 1, (parts, hits)
-        return hits[0]
-    # default SH backward: 3 wavefronts per SIMD = 6 two-wavefront workgroups per CU (160 KB of LDS)
-    bwd = find("k_composite_bwd_sh_mfmaILi4ELi2E")
-    assert bwd["vgpr_count"] <= 168 and 6 * bwd["group_segment_fixed_size"] <= 160 * 1024
-    fwd = find("k_composite_fwdILi2ELi4ELi1E")      # default SH forward: 4 wavefronts per tile
-    assert fwd["vgpr_count"] <= 128
-    assert find("k_sort_tiles", "PKjS1_PKyPiS4_S4_")["group_segment_fixed_size"] == 0  # register sort: no LDS
+        assert len(hits) == n, (parts, hits)
+        return hits
+    # default SH backward: 3 wavefronts per SIMD = 6 two-wavefront workgroups per CU (160 KB of LDS);
+    # both the per-camera and the batched-cameras instantiation
+    for bwd in find(2, "k_composite_bwd_sh_mfmaILi4ELi2E"):
+        assert bwd["vgpr_count"] <= 168 and 6 * bwd["group_segment_fixed_size"] <= 160 * 1024
+    for fwd in find(2, "k_composite_fwdILi2ELi4ELi1E"):      # default SH forward: 4 wavefronts per tile
+        assert fwd["vgpr_count"] <= 128
+    assert find(1, "k_sort_tiles", "PKjS1_PKyPiS4_S4_")[0]["group_segment_fixed_size"] == 0  # register sort: no LDS
 
 
 @pytest.mark.parametrize("mode", [0, 1])

@@ -175,8 +175,8 @@ def test_densify_statistics_over_two_cameras():
     assert want[2].max() == 2.0 and want[2].min() == 0.0
 
 
-@pytest.mark.parametrize("n_streams,C", [(1, 3), (3, 3), (3, 0)])
-def test_batched_cameras_match_one_at_a_time(n_streams, C):
+@pytest.mark.parametrize("n_streams,C,fused", [(1, 3, 0), (3, 3, 0), (3, 0, 0), (3, 4, 1), (2, 2, 3)])
+def test_batched_cameras_match_one_at_a_time(n_streams, C, fused):
     """BatchRenderer (cameras in flight on several streams) == a loop of render_frame:
     identical images, the gradient of the summed loss, and the same densify statistics."""
     from gsgen_amd import renderer as R
@@ -203,7 +203,9 @@ def test_batched_cameras_match_one_at_a_time(n_streams, C):
 
     Pb = {k: T_(sc[k]).requires_grad_(True) for k in keys}
     sb = R.DensifyStats(N, dev())
-    br = BatchRenderer(N, W, H, dev(), max_batch=5, n_streams=n_streams)
+    # fused: one compositing launch per batch and direction (gridDim.y = cameras); fused > 1: that many
+    # backward segments per tile as well
+    br = BatchRenderer(N, W, H, dev(), max_batch=5, n_streams=n_streams, fused_launch=fused > 0, segments=max(fused, 1))
     for _ in range(2):  # second pass: the slots and the pinned camera block are reused
         for k in keys:
             Pb[k].grad = None
