@@ -242,20 +242,48 @@ def main():
             with torch.cuda.stream(stream):
                 self.bufs = [R.FrameBuffers(N, W, H, dev) for _ in range(B)]
                 self.out = torch.empty(B, H, W, 3, device=dev)
-                # per view: mean2d(2) | cov2d(4); shared: alpha(1) | sh | mean(3) | qvec(4) | svec(3)
-                self.gflat = torch.empty(B * 6 * N + N * (1 + CC3 + 10), device=dev)
+                # per view: mean2d(2) | cov2d(4); shared: alpha(1) | sh -- zeroed once per batch; the
+                # projection backward overwrites mean(3) | qvec(4) | svec(3)
+                self.gflat = torch.empty(B * 6 * N + N * (1 + CC3), device=dev)
+                self.g3d = torch.empty(N * 10, device=dev)
                 self.seg_ws = [torch.empty(max(1, lib.segment_workspace_bytes(nth * ntw, args.segments)), device=dev,
                                            dtype=torch.uint8) for _ in range(B)]
                 self.bws = torch.empty(lib.sh_batch_workspace_bytes(B), device=dev, dtype=torch.uint8)
+                self.gws = torch.empty(lib.frame_batch_workspace_bytes(B), device=dev, dtype=torch.uint8)
             o = B * 6 * N
             g = self.gflat
             self.g_alpha, self.g_sh = g[o:o + N], g[o + N:o + N * (1 + CC3)]
-            o += N * (1 + CC3)
-            self.g_mean, self.g_qvec, self.g_svec = g[o:o + 3 * N], g[o + 3 * N:o + 7 * N], g[o + 7 * N:o + 10 * N]
+            g = self.g3d
+            self.g_mean, self.g_qvec, self.g_svec = g[:3 * N], g[3 * N:7 * N], g[7 * N:]
             self.views = {}
 
+        def geometry_array(self, k0, nb):
+            key = ("geo", k0, nb, tuple(b_.D_cap for b_ in self.bufs[:nb]))
+            if key not in self.views:
+                arr = (_capi.GeometryView * nb)()
+                for i in range(nb):
+                    k, b_, a = (k0 + i) % len(cams), self.bufs[i], arr[i]
+                    a.cam, a.mean2d, a.cov2d, a.depth, a.mask = p(cam_dev[k]), p(b_.mean2d), p(b_.cov2d), p(b_.depth), p(b_.mask)
+                    a.gaussian_ids, a.start, a.end, a.total = p(b_.ids), p(b_.start), p(b_.end), p(b_.total)
+                    a.workspace, a.workspace_bytes, a.D_cap = p(b_.ws), b_.ws.numel(), b_.D_cap
+                self.views[key] = arr
+            return self.views[key]
+
+        def projection_tables(self, k0, nb):
+            """(c2w[], detach_depth, mask[], g_mean2d[], g_cov2d[], g_depth[]) of gsgen_project_gaussians_backward_batch"""
+            key = ("proj", k0, nb)
+            if key not in self.views:
+                import ctypes
+                tab = lambda vals: (ctypes.c_void_p * nb)(*vals)  # noqa: E731
+                g0 = p(self.gflat)
+                self.views[key] = (tab([p(cam_dev[(k0 + i) % len(cams)]) for i in range(nb)]), 1,
+                                   tab([p(self.bufs[i].mask) for i in range(nb)]),
+                                   tab([g0 + 4 * 6 * N * i for i in range(nb)]),
+                                   tab([g0 + 4 * 6 * N * i + 4 * 2 * N for i in range(nb)]), None)
+            return self.views[key]
+
         def view_array(self, k0, nb):
-            key = (k0, nb)
+            key = (k0, nb, tuple(b_.D_cap for b_ in self.bufs[:nb]))
             if key not in self.views:
                 arr = (_capi.ShView * nb)()
                 for i in range(nb):
@@ -279,11 +307,15 @@ def main():
         """renders cameras k0 .. k0+nb-1 (mod the camera set) as batch j"""
         sl = bslots[j % len(bslots)]
         s, stream = sl.s, sl.stream
-        for i in range(nb):
-            k, b_ = (k0 + i) % len(cams), sl.bufs[i]
-            lib.frame_geometry(N, p(t["mean"]), p(t["qvec"]), p(t["svec"]), p(cam_dev[k]), W, H, b_.D_cap,
-                               p(b_.mean2d), p(b_.cov2d), p(b_.depth), p(b_.mask), p(b_.ids), p(b_.start),
-                               p(b_.end), p(b_.total), p(b_.ws), b_.ws.numel(), s)
+        if os.environ.get("GSGEN_GEO_PER_VIEW"):
+            for i in range(nb):
+                k, b_ = (k0 + i) % len(cams), sl.bufs[i]
+                lib.frame_geometry(N, p(t["mean"]), p(t["qvec"]), p(t["svec"]), p(cam_dev[k]), W, H, b_.D_cap,
+                                   p(b_.mean2d), p(b_.cov2d), p(b_.depth), p(b_.mask), p(b_.ids), p(b_.start),
+                                   p(b_.end), p(b_.total), p(b_.ws), b_.ws.numel(), s)
+        else:
+            lib.frame_geometry_batch(nb, sl.geometry_array(k0 % len(cams), nb), N, p(t["mean"]), p(t["qvec"]),
+                                     p(t["svec"]), W, H, p(sl.gws), s)
         arr = sl.view_array(k0 % len(cams), nb)
         if timed is not None:
             timed[0].record(stream)
@@ -299,11 +331,9 @@ def main():
                                          H, W, C, 1e-4, args.segments, p(sl.bws), s)
         if timed is not None:
             timed[3].record(stream)
-        for i in range(nb):
-            k, b_ = (k0 + i) % len(cams), sl.bufs[i]
-            lib.project_gaussians_backward_accum(N, p(t["mean"]), p(t["qvec"]), p(t["svec"]), p(cam_dev[k]), 1,
-                                                 p(b_.mask), arr[i].grad_mean, arr[i].grad_cov, None, p(sl.g_mean),
-                                                 p(sl.g_qvec), p(sl.g_svec), s)
+        lib.project_gaussians_backward_batch(nb, N, p(t["mean"]), p(t["qvec"]), p(t["svec"]),
+                                             *sl.projection_tables(k0 % len(cams), nb), p(sl.g_mean), p(sl.g_qvec),
+                                             p(sl.g_svec), s)
         if gathered_b is not None and gather:
             with torch.cuda.stream(stream):
                 dist.all_gather_into_tensor(gathered_b, sl.out)

@@ -23,6 +23,12 @@ class ShView(C.Structure):
                 ("segment_workspace", vp), ("grad_out", vp), ("grad_mean", vp), ("grad_cov", vp)]
 
 
+class GeometryView(C.Structure):
+    """gsgen_geometry_view (include/gsgen_hip.h): one camera of a batched geometry enqueue."""
+    _fields_ = [("cam", vp), ("mean2d", vp), ("cov2d", vp), ("depth", vp), ("mask", vp), ("gaussian_ids", vp),
+                ("start", vp), ("end", vp), ("total", vp), ("workspace", vp), ("workspace_bytes", sz), ("D_cap", u32)]
+
+
 # name -> argtypes, in the order of include/gsgen_hip.h
 SIGNATURES = {
     "gsgen_culling_gaussian_bsphere": [u32, vp, vp, vp, vp, vp, vp, f32, vp],
@@ -43,6 +49,8 @@ SIGNATURES = {
     "gsgen_project_gaussians_backward": [u32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp],
     "gsgen_project_gaussians_backward_masked": [u32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp],
     "gsgen_project_gaussians_backward_accum": [u32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp],
+    "gsgen_project_gaussians_backward_batch": [u32, u32, vp, vp, vp, C.POINTER(vp), i32, C.POINTER(vp), C.POINTER(vp),
+                                               C.POINTER(vp), C.POINTER(vp), vp, vp, vp, vp],
     "gsgen_pack_camera": [vp, f32, f32, f32, f32, u32, u32, C.c_double, C.c_double, f32, f32, vp],
     "gsgen_adam_step": [C.c_uint64, vp, vp, vp, vp, u32, vp, vp, f32, f32, f32, u32, vp],
     "gsgen_densify_update": [u32, vp, vp, vp, vp, vp, vp, vp],
@@ -65,6 +73,7 @@ SIGNATURES = {
                                            f32, u32, vp, vp],
     "gsgen_legacy_count_tiles": [u32, u32, vp, vp, vp, u32, u32, u32, f32, f32, f32, vp, vp],
     "gsgen_legacy_image_sort": [u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, u32, f32, f32, f32, vp, sz, vp],
+    "gsgen_frame_geometry_batch": [u32, C.POINTER(GeometryView), u32, vp, vp, vp, u32, u32, vp, vp],
     "gsgen_frame_geometry": [u32, vp, vp, vp, vp, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp],
 }
 PTR_FUNCS = {
@@ -75,6 +84,7 @@ SIZE_FUNCS = {
     "gsgen_frame_workspace_bytes": [u32, u32, u32],
     "gsgen_segment_workspace_bytes": [u32, u32],
     "gsgen_sh_batch_workspace_bytes": [u32],
+    "gsgen_frame_batch_workspace_bytes": [u32],
     "gsgen_legacy_sort_workspace_bytes": [u32, u32],
 }
 EXPORTS = sorted(list(SIGNATURES) + list(SIZE_FUNCS) + list(PTR_FUNCS) + ["gsgen_version", "gsgen_error_string"])

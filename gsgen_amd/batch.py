@@ -35,8 +35,11 @@ class _render_batch(torch.autograd.Function):
         out = torch.zeros(B, H, W, 3, device=dev, dtype=torch.float32)
         T = torch.ones(B, H, W, 1, device=dev, dtype=torch.float32)
         fused = br.fused_launch and C > 0 and B > 0
-        cur = br._fork(B, (cams, out, T))
         cams_p, out_p, T_p = cams.data_ptr(), out.data_ptr(), T.data_ptr()
+        if fused:
+            return _render_batch._forward_fused(ctx, mean, qvec, svec, alpha, col, cams, br, B, C, bg_rgb, thresh,
+                                                detach_depth, stats, out, T)
+        cur = br._fork(B, (cams, out, T))
         with torch.cuda.device(dev):
             for i in range(B):
                 buf, s, ci = br.slots[i], br.streams[i % len(br.streams)].cuda_stream, br._cis[i]
@@ -47,8 +50,6 @@ class _render_batch(torch.autograd.Function):
                                    _p(buf.total), _p(buf.ws), buf.ws.numel(), s)
                 if stats is not None:
                     lib.densify_update(N, _p(buf.cov2d), None, _p(buf.mask), _p(stats.max_radii2d), None, None, s)
-                if fused:
-                    continue
                 if C > 0:
                     lib.vol_render_sh_ordered(N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col), _p(alpha),
                                               _p(buf.start), _p(buf.end), _p(buf.ids), out_p + 12 * H * W * i, cam + 224,
@@ -61,21 +62,6 @@ class _render_batch(torch.autograd.Function):
                                                     T_p + 4 * H * W * i, s)
         br._join(B, cur)
         ctx.views = ctx.bws = None
-        if fused:  # every camera's lists are ready: ONE compositing launch for the batch (gridDim.y = B)
-            views = (_capi.ShView * B)()
-            for i in range(B):
-                buf, ci, v = br.slots[i], br._cis[i], views[i]
-                cam = cams_p + 272 * i
-                v.mean, v.cov, v.start, v.end, v.gaussian_ids = _p(buf.mean2d), _p(buf.cov2d), _p(buf.start), _p(buf.end), _p(buf.ids)
-                v.tile_order, v.topleft, v.c2w, v.bg_rgb = buf.tile_order(), cam + 224, cam + 232, _p(bg_rgb)
-                v.pixel_size_x, v.pixel_size_y = 1.0 / ci.fx, 1.0 / ci.fy
-                v.out, v.T = out_p + 12 * H * W * i, T_p + 4 * H * W * i
-                v.segment_workspace = _p(buf.seg_ws) if br.segments > 1 else None
-            bws = torch.empty(lib.sh_batch_workspace_bytes(B), device=dev, dtype=torch.uint8)
-            with torch.cuda.device(dev):
-                lib.vol_render_sh_batch(B, views, N, _p(col), _p(alpha), 16, br.slots[0].nth, br.slots[0].ntw, H, W, C,
-                                        thresh, br.segments, _p(bws), cur.cuda_stream)
-            ctx.views, ctx.bws = views, bws
         if C == 0 and bg_rgb is not None:
             out = out + T * bg_rgb  # gs/renderer.py:1182
         ctx.save_for_backward(mean, qvec, svec, alpha, col, cams, out)
@@ -85,7 +71,84 @@ class _render_batch(torch.autograd.Function):
         return out, T
 
     @staticmethod
+    def _forward_fused(ctx, mean, qvec, svec, alpha, col, cams, br, B, C, bg_rgb, thresh, detach_depth, stats, out, T):
+        """the whole batch on the current stream: one enqueue of the geometry kernels (gridDim.y = cameras), one
+        compositing launch"""
+        lib = _capi.load()
+        H, W, N, dev = br.H, br.W, br.N, mean.device
+        cams_p, out_p, T_p = cams.data_ptr(), out.data_ptr(), T.data_ptr()
+        s = torch.cuda.current_stream(dev).cuda_stream
+        geo = (_capi.GeometryView * B)()
+        views = (_capi.ShView * B)()
+        for i in range(B):
+            buf, ci, g, v = br.slots[i], br._cis[i], geo[i], views[i]
+            cam = cams_p + 272 * i  # row i: cam block | topleft at +56 floats | rotation at +58
+            g.cam, g.mean2d, g.cov2d, g.depth, g.mask = cam, _p(buf.mean2d), _p(buf.cov2d), _p(buf.depth), _p(buf.mask)
+            g.gaussian_ids, g.start, g.end, g.total = _p(buf.ids), _p(buf.start), _p(buf.end), _p(buf.total)
+            g.workspace, g.workspace_bytes, g.D_cap = _p(buf.ws), buf.ws.numel(), buf.D_cap
+            v.mean, v.cov, v.start, v.end, v.gaussian_ids = _p(buf.mean2d), _p(buf.cov2d), _p(buf.start), _p(buf.end), _p(buf.ids)
+            v.tile_order, v.topleft, v.c2w, v.bg_rgb = buf.tile_order(), cam + 224, cam + 232, _p(bg_rgb)
+            v.pixel_size_x, v.pixel_size_y = 1.0 / ci.fx, 1.0 / ci.fy
+            v.out, v.T = out_p + 12 * H * W * i, T_p + 4 * H * W * i
+            v.segment_workspace = _p(buf.seg_ws) if br.segments > 1 else None
+        # parameter tables of the batch: compositing (forward | backward) | geometry
+        nb_sh = lib.sh_batch_workspace_bytes(B)
+        bws = torch.empty(nb_sh + lib.frame_batch_workspace_bytes(B), device=dev, dtype=torch.uint8)
+        with torch.cuda.device(dev):
+            lib.frame_geometry_batch(B, geo, N, _p(mean), _p(qvec), _p(svec), W, H, _p(bws) + nb_sh, s)
+            if stats is not None:
+                for i in range(B):
+                    buf = br.slots[i]
+                    lib.densify_update(N, _p(buf.cov2d), None, _p(buf.mask), _p(stats.max_radii2d), None, None, s)
+            lib.vol_render_sh_batch(B, views, N, _p(col), _p(alpha), 16, br.slots[0].nth, br.slots[0].ntw, H, W, C,
+                                    thresh, br.segments, _p(bws), s)
+        ctx.views, ctx.bws = views, bws
+        ctx.save_for_backward(mean, qvec, svec, alpha, col, cams, out)
+        ctx.br, ctx.B, ctx.C, ctx.thresh, ctx.detach, ctx.stats = br, B, C, thresh, detach_depth, stats
+        ctx.cis = list(br._cis[:B])
+        ctx.mark_non_differentiable(T)
+        return out, T
+
+    @staticmethod
+    def _backward_fused(ctx, grad):
+        import ctypes
+        mean, qvec, svec, alpha, col, cams, out = ctx.saved_tensors
+        br, B, C, thresh, stats = ctx.br, ctx.B, ctx.C, ctx.thresh, ctx.stats
+        lib = _capi.load()
+        H, W, N, dev = br.H, br.W, br.N, mean.device
+        grad = grad.contiguous()
+        g2d = torch.zeros(B, 6 * N, device=dev, dtype=torch.float32)  # per camera: mean2d | cov2d
+        g_alpha = torch.zeros(N, device=dev, dtype=torch.float32)
+        g_col = torch.zeros_like(col)
+        g3d = torch.empty(10 * N, device=dev, dtype=torch.float32)   # mean | qvec | svec: overwritten
+        g_mean, g_qvec, g_svec = g3d[:3 * N].view(N, 3), g3d[3 * N:7 * N].view(N, 4), g3d[7 * N:].view(N, 3)
+        cams_p, grad_p, g2d_p = cams.data_ptr(), grad.data_ptr(), g2d.data_ptr()
+        s = torch.cuda.current_stream(dev).cuda_stream
+        for i in range(B):
+            v = ctx.views[i]
+            v.grad_out = grad_p + 12 * H * W * i
+            v.grad_mean = g2d_p + 24 * N * i
+            v.grad_cov = g2d_p + 24 * N * i + 8 * N
+        tab = lambda vals: (ctypes.c_void_p * B)(*vals)  # noqa: E731
+        with torch.cuda.device(dev):
+            lib.vol_render_backward_sh_batch(B, ctx.views, N, _p(col), _p(alpha), _p(g_col), _p(g_alpha), 16,
+                                             br.slots[0].nth, br.slots[0].ntw, H, W, C, thresh, br.segments,
+                                             _p(ctx.bws), s)
+            lib.project_gaussians_backward_batch(B, N, _p(mean), _p(qvec), _p(svec), tab([cams_p + 272 * i for i in range(B)]),
+                                                 int(ctx.detach), tab([_p(br.slots[i].mask) for i in range(B)]),
+                                                 tab([g2d_p + 24 * N * i for i in range(B)]),
+                                                 tab([g2d_p + 24 * N * i + 8 * N for i in range(B)]), None,
+                                                 _p(g_mean), _p(g_qvec), _p(g_svec), s)
+            if stats is not None:
+                for i in range(B):
+                    lib.densify_update(N, None, g2d_p + 24 * N * i, _p(br.slots[i].mask), None, _p(stats.grad_accum),
+                                       _p(stats.cnt), s)
+        return (g_mean, g_qvec, g_svec, g_alpha, g_col) + (None,) * 8
+
+    @staticmethod
     def backward(ctx, grad, _gT):
+        if ctx.views is not None:
+            return _render_batch._backward_fused(ctx, grad)
         mean, qvec, svec, alpha, col, cams, out = ctx.saved_tensors
         br, B, C, thresh, stats = ctx.br, ctx.B, ctx.C, ctx.thresh, ctx.stats
         lib = _capi.load()
@@ -97,17 +160,6 @@ class _render_batch(torch.autograd.Function):
         g_svec, g_alpha = g3d[7 * N:10 * N].view(N, 3), g3d[10 * N:]
         g_col = torch.zeros_like(col)
         cams_p, out_p, grad_p, g2d_p = cams.data_ptr(), out.data_ptr(), grad.data_ptr(), g2d.data_ptr()
-        fused = ctx.views is not None
-        if fused:  # one compositing-backward launch for the batch, then the per-camera projections fan out
-            for i in range(B):
-                v = ctx.views[i]
-                v.grad_out = grad_p + 12 * H * W * i
-                v.grad_mean = g2d_p + 24 * N * i
-                v.grad_cov = g2d_p + 24 * N * i + 8 * N
-            with torch.cuda.device(dev):
-                lib.vol_render_backward_sh_batch(B, ctx.views, N, _p(col), _p(alpha), _p(g_col), _p(g_alpha), 16,
-                                                 br.slots[0].nth, br.slots[0].ntw, H, W, C, thresh, br.segments,
-                                                 _p(ctx.bws), torch.cuda.current_stream(dev).cuda_stream)
         cur = br._fork(B, (grad, g2d, g3d, g_col))
         with torch.cuda.device(dev):
             for i in range(B):
@@ -116,9 +168,7 @@ class _render_batch(torch.autograd.Function):
                 g_mean2d = g2d_p + 24 * N * i
                 g_cov2d = g_mean2d + 8 * N
                 psx, psy = 1.0 / ci.fx, 1.0 / ci.fy
-                if fused:
-                    pass
-                elif C > 0:
+                if C > 0:
                     lib.vol_render_backward_sh_ordered(N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col), _p(alpha),
                                                        _p(buf.start), _p(buf.end), _p(buf.ids), out_p + 12 * H * W * i,
                                                        g_mean2d, g_cov2d, _p(g_col), _p(g_alpha),
@@ -220,11 +270,14 @@ class _render_batch_heads(torch.autograd.Function):
 class BatchRenderer:
     """Renders [B] cameras of one (W, H) shape for a fixed Gaussian count N."""
 
-    def __init__(self, N, W, H, device, max_batch, n_streams=3, D_cap=None, fused_launch=False, segments=1):
-        """fused_launch: SH batches composite in ONE forward and ONE backward launch (gridDim.y = cameras,
-        gsgen_vol_render_sh_batch) instead of one launch per camera on the side streams; geometry /
-        binning and the projection backward still fan out over the streams.  segments: backward
-        workgroups per tile (FrameBuffers), fused launches only."""
+    def __init__(self, N, W, H, device, max_batch, n_streams=3, D_cap=None, fused_launch=True, segments=1):
+        """fused_launch: an SH batch is ONE enqueue per stage on the current stream -- geometry, compositing
+        forward, compositing backward and projection backward each launch once for all cameras
+        (gsgen_frame_geometry_batch, gsgen_vol_render_sh_batch, ..._backward_sh_batch,
+        gsgen_project_gaussians_backward_batch) -- instead of one chain per camera spread over
+        `n_streams` side streams (which post-activation colours and the fused heads still use).
+        cfg2: 2850 vs 2710 renders/s (profiles/r01_notes.md).  segments: backward workgroups per tile
+        (FrameBuffers), fused launches only."""
         self.N, self.W, self.H, self.device = N, W, H, torch.device(device)
         self.fused_launch, self.segments = bool(fused_launch), int(segments) if fused_launch else 1
         self.slots = [R.FrameBuffers(N, W, H, device, D_cap=D_cap, segments=self.segments) for _ in range(max_batch)]

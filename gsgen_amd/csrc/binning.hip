@@ -24,6 +24,7 @@
 // Everything is enqueued on the caller's stream with no host synchronisation.
 #include "common.hpp"
 #include "../../include/gsgen_hip.h"
+#include <vector>
 
 namespace gs {
 
@@ -68,8 +69,8 @@ struct RectRegs {
 __device__ __forceinline__ int rd_lane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 
 template <bool EMIT>
-__global__ void __launch_bounds__(64 * kPullWaves)
-k_bin_pull(uint32_t N, const int *__restrict__ tl, const int *__restrict__ br,
+__device__ __forceinline__ void
+bin_pull_body(uint32_t N, const int *__restrict__ tl, const int *__restrict__ br,
            const float *__restrict__ depth, int ntw, int nth, uint32_t T,
            uint32_t *__restrict__ cnt, const uint32_t *__restrict__ tile_off,
            const uint32_t *__restrict__ ctrl, unsigned long long *__restrict__ keys) {
@@ -164,8 +165,8 @@ __device__ __forceinline__ uint32_t wave_scan_add_u32(uint32_t x) {
   return (uint32_t)v;
 }
 
-__global__ void __launch_bounds__(256)
-k_scan_chunks(uint32_t T, uint32_t nchunks, uint32_t *__restrict__ cnt, uint32_t *__restrict__ tile_count) {
+__device__ __forceinline__ void
+scan_chunks_body(uint32_t T, uint32_t nchunks, uint32_t *__restrict__ cnt, uint32_t *__restrict__ tile_count) {
   const uint32_t t = blockIdx.x * 4u + (threadIdx.x >> 6);  // one wave per tile
   if (t >= T) return;
   const uint32_t lane = (uint32_t)lane_id();
@@ -181,8 +182,8 @@ k_scan_chunks(uint32_t T, uint32_t nchunks, uint32_t *__restrict__ cnt, uint32_t
 }
 
 // exclusive scan of tile_count[T] -> tile_off[T+1]; ctrl[0] = total, ctrl[1] = overflow flag
-__global__ void __launch_bounds__(1024)
-k_scan_tiles(uint32_t T, const uint32_t *__restrict__ tile_count, uint32_t *__restrict__ tile_off,
+__device__ __forceinline__ void
+scan_tiles_body(uint32_t T, const uint32_t *__restrict__ tile_count, uint32_t *__restrict__ tile_off,
              uint32_t *__restrict__ ctrl, uint32_t cap, uint32_t *__restrict__ total_out) {
   __shared__ uint32_t s_part[1024];
   const uint32_t t = threadIdx.x;
@@ -218,8 +219,8 @@ k_scan_tiles(uint32_t T, const uint32_t *__restrict__ tile_count, uint32_t *__re
 // the border, and a compositing launch does not fit the chip all at once -- started in spatial
 // order the long tiles begin late and the launch ends on a few stragglers.  Counting sort of
 // the tiles by (list length / 8) descending, one workgroup, LDS atomics only.
-__global__ void __launch_bounds__(1024)
-k_order_tiles(uint32_t T, const uint32_t *__restrict__ tile_count, uint32_t *__restrict__ tile_order) {
+__device__ __forceinline__ void
+order_tiles_body(uint32_t T, const uint32_t *__restrict__ tile_count, uint32_t *__restrict__ tile_order) {
   __shared__ uint32_t s_hist[256];
   __shared__ uint32_t s_base[256];
   const uint32_t t = threadIdx.x;
@@ -365,8 +366,8 @@ __device__ __forceinline__ void sort_segment_regs(const u64 *__restrict__ keys, 
 constexpr int kSortMaxK = 32;  // 2048 keys in registers; longer segments take the workgroup path
 
 // One wavefront per tile, keys in registers, no LDS: the common case (n <= 64 * kSortMaxK).
-__global__ void __launch_bounds__(64)
-k_sort_tiles(uint32_t T, const uint32_t *__restrict__ tile_off, const uint32_t *__restrict__ ctrl,
+__device__ __forceinline__ void
+sort_tiles_body(uint32_t T, const uint32_t *__restrict__ tile_off, const uint32_t *__restrict__ ctrl,
              const unsigned long long *__restrict__ keys, int *__restrict__ ids, int *__restrict__ start,
              int *__restrict__ end) {
   const uint32_t tile = xcd_swizzle(blockIdx.x, gridDim.x);
@@ -393,8 +394,8 @@ k_sort_tiles(uint32_t T, const uint32_t *__restrict__ tile_off, const uint32_t *
 // Segments longer than the register sort can hold: one workgroup, LDS (<= kSortLds keys) or the
 // global segment itself.  A separate launch so that the common kernel carries no LDS (32 KiB
 // of static LDS per workgroup would throttle the compositing kernels of other renders in flight).
-__global__ void __launch_bounds__(kSortThreads)
-k_sort_tiles_big(uint32_t T, const uint32_t *__restrict__ tile_off, const uint32_t *__restrict__ ctrl,
+__device__ __forceinline__ void
+sort_tiles_big_body(uint32_t T, const uint32_t *__restrict__ tile_off, const uint32_t *__restrict__ ctrl,
                  unsigned long long *__restrict__ keys, int *__restrict__ ids) {
   __shared__ unsigned long long s_keys[kSortLds];
   const uint32_t tile = blockIdx.x;
@@ -419,6 +420,72 @@ k_sort_tiles_big(uint32_t T, const uint32_t *__restrict__ tile_off, const uint32
 }
 
 // ---- self test of the cross-lane primitives (tests/ only; exported for the parity suite) ----
+// ---- kernels: one view per launch (arguments in the kernel arguments) and B views per launch
+// (gridDim.y or .z = view, the per-view pointers read from a GeoView table in device memory) --------
+template <bool EMIT>
+__global__ void __launch_bounds__(64 * kPullWaves)
+k_bin_pull(uint32_t N, const int *__restrict__ tl, const int *__restrict__ br,
+           const float *__restrict__ depth, int ntw, int nth, uint32_t T,
+           uint32_t *__restrict__ cnt, const uint32_t *__restrict__ tile_off,
+           const uint32_t *__restrict__ ctrl, unsigned long long *__restrict__ keys) {
+  bin_pull_body<EMIT>(N, tl, br, depth, ntw, nth, T, cnt, tile_off, ctrl, keys);
+}
+template <bool EMIT>
+__global__ void __launch_bounds__(64 * kPullWaves)
+k_bin_pull_views(uint32_t N, int ntw, int nth, uint32_t T, const GeoView *__restrict__ views) {
+  const GeoView v = views[blockIdx.z];
+  bin_pull_body<EMIT>(N, v.tl, v.br, v.depth, ntw, nth, T, v.cnt, v.tile_off, v.ctrl, v.keys);
+}
+__global__ void __launch_bounds__(256)
+k_scan_chunks(uint32_t T, uint32_t nchunks, uint32_t *__restrict__ cnt, uint32_t *__restrict__ tile_count) {
+  scan_chunks_body(T, nchunks, cnt, tile_count);
+}
+__global__ void __launch_bounds__(256)
+k_scan_chunks_views(uint32_t T, uint32_t nchunks, const GeoView *__restrict__ views) {
+  const GeoView v = views[blockIdx.y];
+  scan_chunks_body(T, nchunks, v.cnt, v.tile_count);
+}
+__global__ void __launch_bounds__(1024)
+k_scan_tiles(uint32_t T, const uint32_t *__restrict__ tile_count, uint32_t *__restrict__ tile_off,
+             uint32_t *__restrict__ ctrl, uint32_t cap, uint32_t *__restrict__ total_out) {
+  scan_tiles_body(T, tile_count, tile_off, ctrl, cap, total_out);
+}
+__global__ void __launch_bounds__(1024)
+k_scan_tiles_views(uint32_t T, const GeoView *__restrict__ views) {
+  const GeoView v = views[blockIdx.y];
+  scan_tiles_body(T, v.tile_count, v.tile_off, v.ctrl, v.cap, v.total);
+}
+__global__ void __launch_bounds__(1024)
+k_order_tiles(uint32_t T, const uint32_t *__restrict__ tile_count, uint32_t *__restrict__ tile_order) {
+  order_tiles_body(T, tile_count, tile_order);
+}
+__global__ void __launch_bounds__(1024)
+k_order_tiles_views(uint32_t T, const GeoView *__restrict__ views) {
+  const GeoView v = views[blockIdx.y];
+  order_tiles_body(T, v.tile_count, v.tile_order);
+}
+__global__ void __launch_bounds__(64)
+k_sort_tiles(uint32_t T, const uint32_t *__restrict__ tile_off, const uint32_t *__restrict__ ctrl,
+             const unsigned long long *__restrict__ keys, int *__restrict__ ids, int *__restrict__ start,
+             int *__restrict__ end) {
+  sort_tiles_body(T, tile_off, ctrl, keys, ids, start, end);
+}
+__global__ void __launch_bounds__(64)
+k_sort_tiles_views(uint32_t T, const GeoView *__restrict__ views) {
+  const GeoView v = views[blockIdx.y];
+  sort_tiles_body(T, v.tile_off, v.ctrl, v.keys, v.ids, v.start, v.end);
+}
+__global__ void __launch_bounds__(kSortThreads)
+k_sort_tiles_big(uint32_t T, const uint32_t *__restrict__ tile_off, const uint32_t *__restrict__ ctrl,
+                 unsigned long long *__restrict__ keys, int *__restrict__ ids) {
+  sort_tiles_big_body(T, tile_off, ctrl, keys, ids);
+}
+__global__ void __launch_bounds__(kSortThreads)
+k_sort_tiles_big_views(uint32_t T, const GeoView *__restrict__ views) {
+  const GeoView v = views[blockIdx.y];
+  sort_tiles_big_body(T, v.tile_off, v.ctrl, v.keys, v.ids);
+}
+
 template <int P>
 __global__ void __launch_bounds__(64) k_selftest_reduce_scatter(const float *__restrict__ in, float *__restrict__ out) {
   float v[P];
@@ -496,6 +563,10 @@ int gsgen_internal_frame_project(uint32_t N, const float *mean, const float *qve
                                  const float *cam, int w, int h, int ntw, float *mean2d, float *cov2d,
                                  float *depth, uint8_t *mask, int *tl, int *br, gsgen_stream_t stream);
 
+int gsgen_internal_frame_project_views(uint32_t N, const float *mean, const float *qvec, const float *svec,
+                                       int w, int h, int ntw, const GeoView *host_views, GeoView *dev_views,
+                                       uint32_t B, gsgen_stream_t stream);
+
 // used by legacy.hip: per-segment sort of (depth bits << 32 | id) keys, ids out (ctrl[1] must be 0)
 int gsgen_internal_sort_segments(uint32_t T, const uint32_t *tile_off, const uint32_t *ctrl,
                                  unsigned long long *keys, int *ids, int *start, int *end, gsgen_stream_t stream) {
@@ -548,6 +619,56 @@ int gsgen_tile_culling_aabb_start_end(uint32_t N, uint32_t D, uint32_t n_tiles_h
   if (w.bytes > workspace_bytes) return GSGEN_EWORKSPACE;
   return bin_and_sort(N, D, n_tiles_h, n_tiles_w, aabb_topleft, aabb_bottomright, depth, gaussian_ids,
                       start, end, w, nullptr, (hipStream_t)stream);
+}
+
+size_t gsgen_frame_batch_workspace_bytes(uint32_t n_views) { return (size_t)n_views * sizeof(GeoView); }
+
+int gsgen_frame_geometry_batch(uint32_t n_views, const gsgen_geometry_view *views, uint32_t N, const float *mean,
+                               const float *qvec, const float *svec, uint32_t W, uint32_t H,
+                               void *batch_workspace, gsgen_stream_t stream) {
+  const uint32_t ntw = (W + kTile - 1) / kTile, nth = (H + kTile - 1) / kTile;
+  const uint32_t T = ntw * nth;
+  if (T == 0 || n_views == 0) return 0;
+  if (!views || !batch_workspace) return GSGEN_EINVAL;
+  if (n_views > 65535) return GSGEN_EINVAL;  // gridDim.y / .z
+  if (N && (!mean || !qvec || !svec)) return GSGEN_EINVAL;
+  std::vector<GeoView> gv(n_views);
+  uint32_t nchunks = 1;
+  for (uint32_t b = 0; b < n_views; ++b) {
+    const gsgen_geometry_view &v = views[b];
+    if (!v.cam || !v.start || !v.end || !v.workspace || !v.total || !v.gaussian_ids) return GSGEN_EINVAL;
+    if (N && (!v.mean2d || !v.cov2d || !v.depth || !v.mask)) return GSGEN_EINVAL;
+    const BinWs w = carve(v.workspace, N, v.D_cap, T, true);
+    if (w.bytes > v.workspace_bytes) return GSGEN_EWORKSPACE;
+    nchunks = w.nchunks;
+    GeoView &g = gv[b];
+    g.cam = v.cam; g.mean2d = v.mean2d; g.cov2d = v.cov2d; g.depth = v.depth; g.mask = v.mask;
+    g.tl = w.tl; g.br = w.br; g.cnt = w.cnt; g.tile_count = w.tile_count; g.tile_off = w.tile_off;
+    g.ctrl = w.ctrl; g.tile_order = w.tile_order; g.keys = w.keys;
+    g.ids = v.gaussian_ids; g.start = v.start; g.end = v.end; g.total = v.total; g.cap = v.D_cap;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  GeoView *dv = reinterpret_cast<GeoView *>(batch_workspace);
+  if (int e = gsgen_internal_frame_project_views(N, mean, qvec, svec, (int)W, (int)H, (int)ntw, gv.data(), dv,
+                                                 n_views, stream))
+    return e;
+  const uint32_t B = n_views;
+  const uint32_t ngroups = ((ntw + kGroup - 1) / kGroup) * ((nth + kGroup - 1) / kGroup);
+  const dim3 gpull(ngroups, nchunks, B), bpull(64 * kPullWaves);
+  if (N == 0) {
+    for (uint32_t b = 0; b < B; ++b)
+      if (hipError_t e = hipMemsetAsync(gv[b].cnt, 0, sizeof(uint32_t) * (size_t)nchunks * T, s)) return (int)e;
+  } else {
+    hipLaunchKernelGGL((k_bin_pull_views<false>), gpull, bpull, 0, s, N, (int)ntw, (int)nth, T, (const GeoView *)dv);
+  }
+  hipLaunchKernelGGL(k_scan_chunks_views, dim3((T + 3) / 4, B), dim3(256), 0, s, T, nchunks, (const GeoView *)dv);
+  hipLaunchKernelGGL(k_scan_tiles_views, dim3(1, B), dim3(1024), 0, s, T, (const GeoView *)dv);
+  hipLaunchKernelGGL(k_order_tiles_views, dim3(1, B), dim3(1024), 0, s, T, (const GeoView *)dv);
+  if (N)
+    hipLaunchKernelGGL((k_bin_pull_views<true>), gpull, bpull, 0, s, N, (int)ntw, (int)nth, T, (const GeoView *)dv);
+  hipLaunchKernelGGL(k_sort_tiles_views, dim3(T, B), dim3(64), 0, s, T, (const GeoView *)dv);
+  hipLaunchKernelGGL(k_sort_tiles_big_views, dim3(T, B), dim3(kSortThreads), 0, s, T, (const GeoView *)dv);
+  return (int)hipGetLastError();
 }
 
 const uint32_t *gsgen_frame_tile_order(void *workspace, uint32_t N, uint32_t D_cap, uint32_t n_tiles) {

@@ -273,4 +273,18 @@ __device__ __forceinline__ float pixel_coord(float origin, int g, float pixel_si
 
 __device__ __forceinline__ bool finite_f(float v) { return fabsf(v) <= 3.402823466e+38f; }
 
+// One camera of a batched geometry enqueue (gsgen_frame_geometry_batch): everything that differs per
+// view; the kernels take the table in device memory and pick their view with blockIdx.y / .z.
+struct GeoView {
+  const float *cam;
+  float *mean2d, *cov2d, *depth;
+  uint8_t *mask;
+  int *tl, *br;
+  uint32_t *cnt, *tile_count, *tile_off, *ctrl, *tile_order;
+  unsigned long long *keys;
+  int *ids, *start, *end;
+  uint32_t *total;
+  uint32_t cap, pad_;
+};
+
 }  // namespace gs

@@ -207,28 +207,16 @@ k_densify_update(uint32_t N, const float *__restrict__ cov2d, const float *__res
 // detach_depth.  ACC = false: gradients are overwritten (masked-out rows get zeros); ACC = true:
 // added atomically into caller-zeroed arrays shared by the cameras of a batch, which may run on
 // concurrent streams (masked-out rows are left alone).
-template <bool ACC>
-__global__ void __launch_bounds__(kThreads)
-k_project_bwd(uint32_t N, const float *__restrict__ mean, const float *__restrict__ qvec,
-              const float *__restrict__ svec, const float *__restrict__ c2w, int detach_depth,
-              const uint8_t *__restrict__ mask, const float *__restrict__ g_mean2d,
-              const float *__restrict__ g_cov2d, const float *__restrict__ g_depth,
-              float *__restrict__ g_mean, float *__restrict__ g_qvec, float *__restrict__ g_svec) {
-  const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
-  float *gm = g_mean + 3 * (size_t)n, *gq = g_qvec + 4 * (size_t)n, *gs_ = g_svec + 3 * (size_t)n;
-  if (mask != nullptr && mask[n] == 0) {
-    if constexpr (!ACC) {
-      gm[0] = gm[1] = gm[2] = 0.f;
-      gq[0] = gq[1] = gq[2] = gq[3] = 0.f;
-      gs_[0] = gs_[1] = gs_[2] = 0.f;
-    }
-    return;
-  }
-  auto put = [](float *dst, float v) {
-    if constexpr (ACC) atomicAdd(dst, v);
-    else *dst = v;
-  };
+struct ProjGrad { float gm[3], gq[4], gs[3]; };
+// gradients of one Gaussian through one view's projection (rows of the reference's autograd graph,
+// gs/renderer.py:366-421)
+__device__ __forceinline__ ProjGrad project_bwd_one(uint32_t n, const float *__restrict__ mean,
+                                                    const float *__restrict__ qvec, const float *__restrict__ svec,
+                                                    const float *__restrict__ c2w, int detach_depth,
+                                                    const float *__restrict__ g_mean2d,
+                                                    const float *__restrict__ g_cov2d,
+                                                    const float *__restrict__ g_depth) {
+  ProjGrad o;
   float Rc[9], t[3];
   load_pose(c2w, Rc, t);
   const float *p = mean + 3 * (size_t)n, *q = qvec + 4 * (size_t)n, *s = svec + 3 * (size_t)n;
@@ -290,7 +278,7 @@ k_project_bwd(uint32_t N, const float *__restrict__ mean, const float *__restric
       acc += dM[i * 3 + j] * Rq[i * 3 + j];
       dR[i * 3 + j] = dM[i * 3 + j] * s[j];
     }
-    put(gs_ + j, acc);
+    o.gs[j] = acc;
   }
   float dq[4];
   dq[0] = 2 * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]);
@@ -300,12 +288,81 @@ k_project_bwd(uint32_t N, const float *__restrict__ mean, const float *__restric
   const float qh[4] = {w, x, y, z};
   const float dot = qh[0] * dq[0] + qh[1] * dq[1] + qh[2] * dq[2] + qh[3] * dq[3];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) put(gq + k, (dq[k] - qh[k] * dot) / nq);
+  for (int k = 0; k < 4; ++k) o.gq[k] = (dq[k] - qh[k] * dot) / nq;
   const float gm0 = g_mean2d[2 * (size_t)n], gm1 = g_mean2d[2 * (size_t)n + 1];
   float du[3] = {gm0 * iz, gm1 * iz, g_depth != nullptr ? g_depth[n] : 0.0f};
   if (!detach_depth) du[2] += -(ux * gm0 + uy * gm1) * iz * iz;
 #pragma unroll
-  for (int j = 0; j < 3; ++j) put(gm + j, Rc[j * 3] * du[0] + Rc[j * 3 + 1] * du[1] + Rc[j * 3 + 2] * du[2]);
+  for (int j = 0; j < 3; ++j) o.gm[j] = Rc[j * 3] * du[0] + Rc[j * 3 + 1] * du[1] + Rc[j * 3 + 2] * du[2];
+  return o;
+}
+
+template <bool ACC>
+__global__ void __launch_bounds__(kThreads)
+k_project_bwd(uint32_t N, const float *__restrict__ mean, const float *__restrict__ qvec,
+              const float *__restrict__ svec, const float *__restrict__ c2w, int detach_depth,
+              const uint8_t *__restrict__ mask, const float *__restrict__ g_mean2d,
+              const float *__restrict__ g_cov2d, const float *__restrict__ g_depth,
+              float *__restrict__ g_mean, float *__restrict__ g_qvec, float *__restrict__ g_svec) {
+  const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float *gm = g_mean + 3 * (size_t)n, *gq = g_qvec + 4 * (size_t)n, *gs_ = g_svec + 3 * (size_t)n;
+  if (mask != nullptr && mask[n] == 0) {
+    if constexpr (!ACC) {
+      gm[0] = gm[1] = gm[2] = 0.f;
+      gq[0] = gq[1] = gq[2] = gq[3] = 0.f;
+      gs_[0] = gs_[1] = gs_[2] = 0.f;
+    }
+    return;
+  }
+  auto put = [](float *dst, float v) {
+    if constexpr (ACC) atomicAdd(dst, v);
+    else *dst = v;
+  };
+  const ProjGrad o = project_bwd_one(n, mean, qvec, svec, c2w, detach_depth, g_mean2d, g_cov2d, g_depth);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) put(gs_ + j, o.gs[j]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) put(gq + k, o.gq[k]);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) put(gm + j, o.gm[j]);
+}
+
+// The cameras of a batch in one launch: thread n sums its Gaussian's gradients over the views in
+// registers (view order) and writes once -- no atomics, one pass over the parameters.  The per-view
+// pointers travel in the kernel arguments.
+constexpr int kProjViews = 16;
+struct ProjBwdViews {
+  const float *cam[kProjViews];
+  const uint8_t *mask[kProjViews];
+  const float *g_mean2d[kProjViews], *g_cov2d[kProjViews], *g_depth[kProjViews];
+};
+__global__ void __launch_bounds__(kThreads)
+k_project_bwd_views(uint32_t N, const float *__restrict__ mean, const float *__restrict__ qvec,
+                    const float *__restrict__ svec, ProjBwdViews pv, int n_views, int detach_depth, int accumulate,
+                    float *__restrict__ g_mean, float *__restrict__ g_qvec, float *__restrict__ g_svec) {
+  const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float *gm = g_mean + 3 * (size_t)n, *gq = g_qvec + 4 * (size_t)n, *gs_ = g_svec + 3 * (size_t)n;
+  ProjGrad a;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) { a.gm[j] = accumulate ? gm[j] : 0.f; a.gs[j] = accumulate ? gs_[j] : 0.f; }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) a.gq[k] = accumulate ? gq[k] : 0.f;
+  for (int v = 0; v < n_views; ++v) {
+    const uint8_t *m = pv.mask[v];
+    if (m != nullptr && m[n] == 0) continue;
+    const ProjGrad o = project_bwd_one(n, mean, qvec, svec, pv.cam[v], detach_depth, pv.g_mean2d[v], pv.g_cov2d[v],
+                                       pv.g_depth[v]);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { a.gm[j] += o.gm[j]; a.gs[j] += o.gs[j]; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a.gq[k] += o.gq[k];
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) { gm[j] = a.gm[j]; gs_[j] = a.gs[j]; }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) gq[k] = a.gq[k];
 }
 
 // ---- AABB -> tile rectangle -------------------------------------------------------------------
@@ -357,8 +414,8 @@ k_aabb_count(uint32_t N, const float *__restrict__ mean2d, const float *__restri
 
 // ---- fused per-frame geometry: cull + project + rectangle + per-tile histogram ---------------
 // cam layout documented in include/gsgen_hip.h (gsgen_frame_geometry).
-__global__ void __launch_bounds__(kThreads)
-k_frame_project(uint32_t N, const float *__restrict__ mean, const float *__restrict__ qvec,
+__device__ __forceinline__ void
+frame_project_body(uint32_t N, const float *__restrict__ mean, const float *__restrict__ qvec,
                 const float *__restrict__ svec, const float *__restrict__ cam, int w, int h, int ntw,
                 float *__restrict__ mean2d, float *__restrict__ cov2d, float *__restrict__ depth,
                 uint8_t *__restrict__ mask, int *__restrict__ tl, int *__restrict__ br) {
@@ -392,6 +449,27 @@ k_frame_project(uint32_t N, const float *__restrict__ mean, const float *__restr
   *reinterpret_cast<int2 *>(tl + 2 * (size_t)i) = make_int2(rc.x0, rc.y0);
   *reinterpret_cast<int2 *>(br + 2 * (size_t)i) = make_int2(rc.x1, rc.y1);
   (void)ntw;
+}
+
+__global__ void __launch_bounds__(kThreads)
+k_frame_project(uint32_t N, const float *__restrict__ mean, const float *__restrict__ qvec,
+                const float *__restrict__ svec, const float *__restrict__ cam, int w, int h, int ntw,
+                float *__restrict__ mean2d, float *__restrict__ cov2d, float *__restrict__ depth,
+                uint8_t *__restrict__ mask, int *__restrict__ tl, int *__restrict__ br) {
+  frame_project_body(N, mean, qvec, svec, cam, w, h, ntw, mean2d, cov2d, depth, mask, tl, br);
+}
+// B views per launch: gridDim.y = views (see GeoView)
+__global__ void __launch_bounds__(kThreads)
+k_frame_project_views(uint32_t N, const float *__restrict__ mean, const float *__restrict__ qvec,
+                      const float *__restrict__ svec, int w, int h, int ntw, const GeoView *__restrict__ views) {
+  const GeoView v = views[blockIdx.y];
+  frame_project_body(N, mean, qvec, svec, v.cam, w, h, ntw, v.mean2d, v.cov2d, v.depth, v.mask, v.tl, v.br);
+}
+constexpr int kViewPack = 8;
+struct GeoViewPack { GeoView v[kViewPack]; };
+__global__ void __launch_bounds__(64) k_write_views(GeoViewPack pack, GeoView *dst, int n) {
+  const int i = (int)threadIdx.x;
+  if (i < n) dst[i] = pack.v[i];
 }
 
 static inline dim3 grid_for(uint32_t n) { return dim3((n + kThreads - 1) / kThreads); }
@@ -450,6 +528,34 @@ int gsgen_project_gaussians_backward_accum(uint32_t N, const float *mean, const 
   hipLaunchKernelGGL(k_project_bwd<true>, grid_for(N), dim3(kThreads), 0, (hipStream_t)stream, N,
                      mean, qvec, svec, c2w, detach_depth, mask, g_mean2d, g_cov2d, g_depth, g_mean,
                      g_qvec, g_svec);
+  return (int)hipGetLastError();
+}
+
+int gsgen_project_gaussians_backward_batch(uint32_t n_views, uint32_t N, const float *mean, const float *qvec,
+                                           const float *svec, const float *const *c2w, int detach_depth,
+                                           const uint8_t *const *mask, const float *const *g_mean2d,
+                                           const float *const *g_cov2d, const float *const *g_depth,
+                                           float *g_mean, float *g_qvec, float *g_svec, gsgen_stream_t stream) {
+  if (N == 0) return 0;
+  if (!mean || !qvec || !svec || !g_mean || !g_qvec || !g_svec) return GSGEN_EINVAL;
+  if (n_views && (!c2w || !g_mean2d || !g_cov2d)) return GSGEN_EINVAL;
+  for (uint32_t v = 0; v < n_views; ++v)
+    if (!c2w[v] || !g_mean2d[v] || !g_cov2d[v]) return GSGEN_EINVAL;
+  uint32_t v0 = 0;
+  do {  // (an empty batch still zero-fills)
+    ProjBwdViews pv{};
+    const uint32_t nv = (n_views - v0) < (uint32_t)kProjViews ? (n_views - v0) : (uint32_t)kProjViews;
+    for (uint32_t i = 0; i < nv; ++i) {
+      pv.cam[i] = c2w[v0 + i];
+      pv.mask[i] = mask ? mask[v0 + i] : nullptr;
+      pv.g_mean2d[i] = g_mean2d[v0 + i];
+      pv.g_cov2d[i] = g_cov2d[v0 + i];
+      pv.g_depth[i] = g_depth ? g_depth[v0 + i] : nullptr;
+    }
+    hipLaunchKernelGGL(k_project_bwd_views, grid_for(N), dim3(kThreads), 0, (hipStream_t)stream, N, mean, qvec,
+                       svec, pv, (int)nv, detach_depth, v0 ? 1 : 0, g_mean, g_qvec, g_svec);
+    v0 += nv;
+  } while (v0 < n_views);
   return (int)hipGetLastError();
 }
 
@@ -567,6 +673,24 @@ int gsgen_densify_update(uint32_t N, const float *cov2d, const float *grad_mean2
 }
 
 // used by binning.hip (gsgen_frame_geometry)
+// host table -> device table through kernel arguments (no host-pinned staging, capture-safe), then
+// the projection of every view in one launch
+int gsgen_internal_frame_project_views(uint32_t N, const float *mean, const float *qvec, const float *svec,
+                                       int w, int h, int ntw, const GeoView *host_views, GeoView *dev_views,
+                                       uint32_t B, gsgen_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  for (uint32_t b0 = 0; b0 < B; b0 += kViewPack) {
+    GeoViewPack pack{};
+    const int n = (int)((B - b0) < (uint32_t)kViewPack ? (B - b0) : (uint32_t)kViewPack);
+    for (int i = 0; i < n; ++i) pack.v[i] = host_views[b0 + i];
+    hipLaunchKernelGGL(k_write_views, dim3(1), dim3(64), 0, s, pack, dev_views + b0, n);
+  }
+  if (N)
+    hipLaunchKernelGGL(k_frame_project_views, dim3(grid_for(N).x, B), dim3(kThreads), 0, s, N, mean, qvec, svec, w,
+                       h, ntw, (const GeoView *)dev_views);
+  return (int)hipGetLastError();
+}
+
 int gsgen_internal_frame_project(uint32_t N, const float *mean, const float *qvec, const float *svec,
                                  const float *cam, int w, int h, int ntw, float *mean2d, float *cov2d,
                                  float *depth, uint8_t *mask, int *tl, int *br, gsgen_stream_t stream) {

@@ -155,6 +155,16 @@ int gsgen_project_gaussians_backward_accum(uint32_t N, const float *mean, const 
                                            const float *g_cov2d, const float *g_depth,
                                            float *g_mean, float *g_qvec, float *g_svec,
                                            gsgen_stream_t stream);
+/* The cameras of a batch in ONE launch: g_* (OVERWRITTEN) = sum over the views of the masked backward
+ * above, each Gaussian summed in registers in view order (no atomics, no zero-fill, one pass over the
+ * parameters).  c2w / mask / g_mean2d / g_cov2d / g_depth are HOST arrays of n_views DEVICE pointers
+ * (read before the call returns); mask and g_depth may be NULL as arrays or per view.  c2w[v] is the
+ * row-major [3,4] pose (the first 12 floats of a gsgen_frame_geometry camera block). */
+int gsgen_project_gaussians_backward_batch(uint32_t n_views, uint32_t N, const float *mean, const float *qvec,
+                                           const float *svec, const float *const *c2w, int detach_depth,
+                                           const uint8_t *const *mask, const float *const *g_mean2d,
+                                           const float *const *g_cov2d, const float *const *g_depth,
+                                           float *g_mean, float *g_qvec, float *g_svec, gsgen_stream_t stream);
 /* torch.optim.Adam step (no weight decay, no amsgrad: gs/gaussian_splatting.py:398-419,
  * conf/base.yaml:8-11) over one flat fp32 vector that holds every parameter field back to back,
  * in place.  group_end[k] (HOST array, ascending, last == n) closes parameter group k, group_lr[k]
@@ -221,6 +231,29 @@ int gsgen_frame_geometry(uint32_t N, const float *mean, const float *qvec, const
                          float *cov2d, float *depth, uint8_t *mask, int *gaussian_ids, int *start,
                          int *end, uint32_t *total, void *workspace, size_t workspace_bytes,
                          gsgen_stream_t stream);
+
+/* gsgen_frame_geometry for the B cameras of a batch in ONE enqueue of the same eight kernels
+ * (gridDim.y / .z = view) instead of eight small launches per camera: a single view's launches are
+ * latency-bound (100k Gaussians, 2.5k tiles do not fill 256 CUs; 108 us end to end on cfg2, ~45 us per
+ * view however many streams overlap them), B views per launch fill the chip.  Per view the outputs are
+ * bit-identical to gsgen_frame_geometry.  `views` is HOST memory, read before the call returns; each
+ * view brings its own outputs, pair capacity and gsgen_frame_workspace_bytes(N, D_cap, n_tiles)
+ * workspace (gsgen_frame_tile_order applies to it unchanged).  batch_workspace: device,
+ * gsgen_frame_batch_workspace_bytes(n_views) bytes, not reused before the enqueued work has run. */
+typedef struct gsgen_geometry_view {
+  const float *cam;                        /* DEVICE, 56 floats as for gsgen_frame_geometry */
+  float *mean2d, *cov2d, *depth;           /* [N,2], [N,2,2], [N] */
+  uint8_t *mask;                           /* [N] */
+  int *gaussian_ids, *start, *end;         /* [D_cap], [n_tiles], [n_tiles] */
+  uint32_t *total;                         /* [1] */
+  void *workspace;
+  size_t workspace_bytes;
+  uint32_t D_cap;
+} gsgen_geometry_view;
+size_t gsgen_frame_batch_workspace_bytes(uint32_t n_views);
+int gsgen_frame_geometry_batch(uint32_t n_views, const gsgen_geometry_view *views, uint32_t N, const float *mean,
+                               const float *qvec, const float *svec, uint32_t W, uint32_t H,
+                               void *batch_workspace, gsgen_stream_t stream);
 
 /* Launch order for the compositing kernels produced by gsgen_frame_geometry: a device array
  * of n_tiles tile indices, longest list first (pointer into `workspace`; pure host arithmetic).

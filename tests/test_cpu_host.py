@@ -200,6 +200,54 @@ def test_emulated_fused_frame_geometry(emu):
             assert (st == -1).all() and (en == -1).all()
 
 
+def test_emulated_batched_frame_geometry_equals_per_view(emu):
+    """gsgen_frame_geometry_batch (gridDim.y / .z = view, per-view pointers through a device table) leaves
+    exactly what one gsgen_frame_geometry call per view leaves, including a view whose pair buffer is
+    too small (nothing binned, required size reported) next to views that fit"""
+    from gsgen_amd import renderer as R
+    from gsgen_amd._capi import GeometryView
+    W, H = 80, 64
+    sc = scenes.random_scene(2300, seed=19, svec=0.05, spread=1.5)   # > one 2048-Gaussian chunk
+    N = sc["mean"].shape[0]
+    cams = [scenes.Camera(W, H, fx=70.0 + 9 * i, c2w=scenes.orbit(2.0 + 0.2 * i, 25 - 10 * i, 200 + 70 * i)) for i in range(3)]
+    nth, ntw = cams[0].tiles
+    T = nth * ntw
+    Ds = [scenes.oracle_geometry(sc, c)["D"] for c in cams]
+    caps = [Ds[0] + 7, Ds[1] - 1, Ds[2]]
+
+    def fresh(cap):
+        return dict(m2=np.zeros((N, 2), np.float32), c2=np.zeros((N, 4), np.float32), dep=np.zeros(N, np.float32),
+                    mask=np.zeros(N, np.uint8), ids=np.full(max(cap, 1), -7, np.int32), st=np.zeros(T, np.int32),
+                    en=np.zeros(T, np.int32), tot=np.zeros(1, np.uint32),
+                    ws=np.zeros(emu.frame_workspace_bytes(N, cap, T), np.uint8))
+    ref, got = [fresh(c) for c in caps], [fresh(c) for c in caps]
+    camv = [np.ascontiguousarray(R.CameraInfo(*c.intr).pack(c.c2w)) for c in cams]
+    for c, cap, cv, r in zip(cams, caps, camv, ref):
+        emu.frame_geometry(N, P(sc["mean"]), P(sc["qvec"]), P(sc["svec"]), P(cv), W, H, cap, P(r["m2"]), P(r["c2"]),
+                           P(r["dep"]), P(r["mask"]), P(r["ids"]), P(r["st"]), P(r["en"]), P(r["tot"]), P(r["ws"]),
+                           r["ws"].size, None)
+    arr = (GeometryView * 3)()
+    for a, cap, cv, g in zip(arr, caps, camv, got):
+        a.cam, a.mean2d, a.cov2d, a.depth, a.mask = P(cv), P(g["m2"]), P(g["c2"]), P(g["dep"]), P(g["mask"])
+        a.gaussian_ids, a.start, a.end, a.total = P(g["ids"]), P(g["st"]), P(g["en"]), P(g["tot"])
+        a.workspace, a.workspace_bytes, a.D_cap = P(g["ws"]), g["ws"].size, cap
+    bws = np.zeros(emu.frame_batch_workspace_bytes(3), np.uint8)
+    emu.frame_geometry_batch(3, arr, N, P(sc["mean"]), P(sc["qvec"]), P(sc["svec"]), W, H, P(bws), None)
+    for i, (r, g) in enumerate(zip(ref, got)):
+        assert r["tot"][0] == Ds[i]
+        for k in ("m2", "c2", "dep", "mask", "ids", "st", "en", "tot"):
+            assert np.array_equal(r[k], g[k]), (i, k)
+        order_r = np.frombuffer(r["ws"], np.uint8)  # whole workspace incl. tile order and keys
+        assert np.array_equal(order_r, g["ws"]), i
+    assert (got[1]["st"] == -1).all() and (got[0]["st"] >= 0).any()
+    arr[2].workspace_bytes = 16
+    with pytest.raises(Exception, match="workspace"):
+        emu.frame_geometry_batch(3, arr, N, P(sc["mean"]), P(sc["qvec"]), P(sc["svec"]), W, H, P(bws), None)
+    with pytest.raises(Exception, match="invalid"):
+        emu.frame_geometry_batch(3, arr, N, P(sc["mean"]), P(sc["qvec"]), P(sc["svec"]), W, H, None, None)
+    emu.frame_geometry_batch(0, arr, N, P(sc["mean"]), P(sc["qvec"]), P(sc["svec"]), W, H, None, None)
+
+
 @pytest.mark.parametrize("Pc", [8, 16, 32, 64])
 def test_emulated_reduce_scatter(emu, Pc):
     x = np.random.default_rng(Pc).normal(size=(64, Pc)).astype(np.float32)
@@ -344,6 +392,45 @@ def test_emulated_projection_backward_overwrite_masked_and_accumulate(emu):
             w_[mask == 1] += y[mask == 1]
     for x, w_ in zip(tot, want):
         assert np.abs(x - w_).max() <= 1e-6 * np.abs(w_).max()
+
+
+@pytest.mark.parametrize("n_views", [3, 19])
+def test_emulated_projection_backward_over_a_batch_of_views(emu, n_views):
+    """gsgen_project_gaussians_backward_batch (views summed per Gaussian in registers, written once) == the sum
+    of the masked per-view backwards; 19 views take two launches (16 per launch), the second adding"""
+    import ctypes
+    sc = scenes.random_scene(300, seed=23, svec=0.05)
+    N = sc["mean"].shape[0]
+    mean, q, s = (np.ascontiguousarray(sc[k]) for k in ("mean", "qvec", "svec"))
+    rng = np.random.default_rng(5)
+    cams = [np.ascontiguousarray(scenes.orbit(2.5, 10, 19.0 * v)) for v in range(n_views)]
+    gm2 = [rng.normal(size=(N, 2)).astype(np.float32) for _ in range(n_views)]
+    gc2 = [rng.normal(size=(N, 4)).astype(np.float32) for _ in range(n_views)]
+    gdp = [rng.normal(size=N).astype(np.float32) if v % 2 else None for v in range(n_views)]
+    masks = [(rng.random(N) < 0.7).astype(np.uint8) if v != 1 else None for v in range(n_views)]
+    want = [np.zeros((N, 3), np.float64), np.zeros((N, 4), np.float64), np.zeros((N, 3), np.float64)]
+    for v in range(n_views):
+        b = [np.zeros((N, 3), np.float32), np.zeros((N, 4), np.float32), np.zeros((N, 3), np.float32)]
+        emu.project_gaussians_backward_masked(N, P(mean), P(q), P(s), P(cams[v]), 0, P(masks[v]), P(gm2[v]), P(gc2[v]),
+                                              P(gdp[v]), P(b[0]), P(b[1]), P(b[2]), None)
+        for w_, y in zip(want, b):
+            w_ += y
+    tab = lambda arrs: (ctypes.c_void_p * n_views)(*[P(a) for a in arrs])  # noqa: E731
+    got = [np.full((N, 3), 9, np.float32), np.full((N, 4), 9, np.float32), np.full((N, 3), 9, np.float32)]
+    emu.project_gaussians_backward_batch(n_views, N, P(mean), P(q), P(s), tab(cams), 0, tab(masks), tab(gm2), tab(gc2),
+                                         tab(gdp), P(got[0]), P(got[1]), P(got[2]), None)
+    for x, w_ in zip(got, want):
+        assert np.abs(x - w_).max() <= 2e-6 * np.abs(w_).max()
+    # no masks / no depth gradients at all; an empty batch zero-fills
+    emu.project_gaussians_backward_batch(n_views, N, P(mean), P(q), P(s), tab(cams), 1, None, tab(gm2), tab(gc2), None,
+                                         P(got[0]), P(got[1]), P(got[2]), None)
+    assert np.isfinite(got[0]).all() and np.abs(got[0]).max() > 0
+    emu.project_gaussians_backward_batch(0, N, P(mean), P(q), P(s), None, 1, None, None, None, None, P(got[0]), P(got[1]),
+                                         P(got[2]), None)
+    assert not got[0].any() and not got[1].any() and not got[2].any()
+    with pytest.raises(Exception, match="invalid"):
+        emu.project_gaussians_backward_batch(n_views, N, P(mean), P(q), P(s), None, 1, None, tab(gm2), tab(gc2), None,
+                                             P(got[0]), P(got[1]), P(got[2]), None)
 
 
 def test_emulated_adam_step_matches_torch_cpu(emu):
