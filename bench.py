@@ -130,7 +130,7 @@ def main():
                     help="same for the one-render-in-flight pass (uniform work units shorten a lone launch's tail)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("GSGEN_STREAMS", "3")),
                     help="independent renders in flight (HIP streams, own buffers each)")
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("GSGEN_BATCH", "1")),
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("GSGEN_BATCH", "8")),
                     help="cameras per compositing launch (gsgen_vol_render_sh_batch: gridDim.y = cameras); 1 = one "
                          "launch per camera.  A step is still one render: K steps run as ceil(K / batch) launches")
     ap.add_argument("--batch-slots", type=int, default=2, help="batches in flight (own stream and buffers each)")

@@ -103,14 +103,36 @@ __device__ __forceinline__ GRec load_rec(const Stage<MODE, CB, KB> &S, int g) {
 // ============================================================================================
 // forward
 // ============================================================================================
-// BATCH: one launch renders gridDim.y cameras, camera blockIdx.y taking its parameters from
-// plist[blockIdx.y] (device memory) instead of the kernel argument -- a single launch's tail (the
-// never-saturating sparse tiles) is then paid once per batch instead of once per camera.
+// BATCH: one launch renders B cameras, each workgroup taking its camera's parameters from plist[view]
+// (device memory) instead of the kernel argument -- a single launch's tail (the never-saturating
+// sparse tiles) is then paid once per batch instead of once per camera.  The grid is 1-D, B x the
+// per-camera grid; p_arg only carries B (n_lo) and the workgroup -> (view, per-camera block) map (n_hi):
+//   0  interleaved: view = id % B -- with longest-first tile order every camera's longest lists start at
+//      once and the launch ends on everyone's shortest; with B = 8, XCD k (ids = k mod 8) sees one camera
+//   1  interleaved, view rotated by the block index (no camera pinned to an XCD)
+//   2  camera-major: all blocks of camera 0, then camera 1, ... (the last camera's long lists start late)
+__device__ __forceinline__ uint32_t batch_view(const CompParams &p_arg, uint32_t &bid, uint32_t *grid = nullptr) {
+  const uint32_t B = (uint32_t)p_arg.n_lo, per = gridDim.x / B;
+  uint32_t view;
+  if (p_arg.n_hi == 2) {
+    view = bid / per;
+    bid -= view * per;
+  } else {
+    const uint32_t r = bid / B;
+    view = bid - r * B;
+    if (p_arg.n_hi == 1) view = (view + r) % B;
+    bid = r;
+  }
+  if (grid) *grid = per;
+  return view;
+}
+
 template <int MODE, int CB, int PPL, bool BATCH = false>
 __global__ void __launch_bounds__(256 / PPL) k_composite_fwd(CompParams p_arg, const CompParams *__restrict__ plist) {
   // by value: read once with scalar loads; through a reference every use in the entry loop would be
   // re-read from memory (the kernel's own stores may alias it as far as the compiler knows)
-  const CompParams p = BATCH ? plist[blockIdx.y] : p_arg;
+  uint32_t bid = blockIdx.x;
+  const CompParams p = BATCH ? plist[batch_view(p_arg, bid)] : p_arg;
   using TR = Traits<MODE, CB>;
   constexpr int NT = 256 / PPL;
   constexpr int ROWS = NT / 16;
@@ -118,7 +140,7 @@ __global__ void __launch_bounds__(256 / PPL) k_composite_fwd(CompParams p_arg, c
   __shared__ Stage<MODE, CB> S;
 
   int tx, ty;
-  if (!block_tile(p, tx, ty)) return;  // uniform over the workgroup
+  if (!block_tile(p, tx, ty, bid)) return;  // uniform over the workgroup
   const int tile = ty * p.ntw + tx;
   const int st = p.start[tile];
   const int n = (st < 0) ? 0 : (p.end[tile] - st);
@@ -572,7 +594,8 @@ __device__ __forceinline__ int frag_dw(int row, int lane, int s) {
 template <int CB, int PPL, bool BATCH = false>
 __global__ void __launch_bounds__(256 / PPL) __attribute__((amdgpu_waves_per_eu(2)))
 k_composite_bwd_sh_mfma(CompParams p_arg, const CompParams *__restrict__ plist) {
-  const CompParams p = BATCH ? plist[blockIdx.y] : p_arg;  // see k_composite_fwd
+  uint32_t bid = blockIdx.x, grid = gridDim.x;
+  const CompParams p = BATCH ? plist[batch_view(p_arg, bid, &grid)] : p_arg;  // see k_composite_fwd
   constexpr int MODE = MODE_SH;
   using TR = Traits<MODE, CB>;
   using MC = MfmaCfg<PPL>;
@@ -592,10 +615,10 @@ k_composite_bwd_sh_mfma(CompParams p_arg, const CompParams *__restrict__ plist) 
   // go round-robin over the 8 XCDs, so a tile-major order with 8 segments would park every tile's
   // segment k on XCD k -- and only the first few segments have work.
   const int nseg = p.nseg > 1 ? p.nseg : 1;
-  const uint32_t tiles_grid = gridDim.x / (uint32_t)nseg;
-  const int seg = (int)(blockIdx.x / tiles_grid);
+  const uint32_t tiles_grid = grid / (uint32_t)nseg;
+  const int seg = (int)(bid / tiles_grid);
   int tx, ty;
-  if (!block_tile(p, tx, ty, blockIdx.x % tiles_grid)) return;
+  if (!block_tile(p, tx, ty, bid % tiles_grid)) return;
   const int tile = ty * p.ntw + tx;
   const int st = p.start[tile];
   const int n = (st < 0) ? 0 : (p.end[tile] - st);
@@ -946,27 +969,51 @@ int write_params(const CompParams *host, uint32_t B, CompParams *dst, hipStream_
   }
   return (int)hipGetLastError();
 }
-int launch_fwd_sh_batch(int C, const CompParams &p0, const CompParams *plist, uint32_t B, hipStream_t s) {
-  const uint32_t nblk = comp_grid(p0);
-  if (p0.ntw * p0.nth == 0 || B == 0) return 0;
-  const dim3 g(nblk, B), b(256);
+template <int CB>
+static void launch_fwd_sh_batch_c(const CompParams &p0, const CompParams *plist, uint32_t B, uint32_t nblk, hipStream_t s) {
+  static const int ppl = env_ppl("GSGEN_PPL_FWD_BATCH", 1);  // wavefronts per tile = 4 / ppl
+  const dim3 g(nblk * B);
+  if (ppl == 1) hipLaunchKernelGGL((k_composite_fwd<MODE_SH, CB, 1, true>), g, dim3(256), 0, s, p0, plist);
+  else if (ppl == 2) hipLaunchKernelGGL((k_composite_fwd<MODE_SH, CB, 2, true>), g, dim3(128), 0, s, p0, plist);
+  else hipLaunchKernelGGL((k_composite_fwd<MODE_SH, CB, 4, true>), g, dim3(64), 0, s, p0, plist);
+}
+static CompParams batch_arg(const CompParams &p0, uint32_t B) {
+  static const int map = getenv("GSGEN_BATCH_MAP") ? atoi(getenv("GSGEN_BATCH_MAP")) : 0;
+  CompParams a = p0;
+  a.n_lo = (int)B;
+  a.n_hi = map;
+  return a;
+}
+int launch_fwd_sh_batch(int C, const CompParams &p0_, const CompParams *plist, uint32_t B, hipStream_t s) {
+  const uint32_t nblk = comp_grid(p0_);
+  if (p0_.ntw * p0_.nth == 0 || B == 0) return 0;
+  const CompParams p0 = batch_arg(p0_, B);
   switch (C) {
-    case 1: hipLaunchKernelGGL((k_composite_fwd<MODE_SH, 1, 1, true>), g, b, 0, s, p0, plist); break;
-    case 2: hipLaunchKernelGGL((k_composite_fwd<MODE_SH, 2, 1, true>), g, b, 0, s, p0, plist); break;
-    case 3: hipLaunchKernelGGL((k_composite_fwd<MODE_SH, 3, 1, true>), g, b, 0, s, p0, plist); break;
-    default: hipLaunchKernelGGL((k_composite_fwd<MODE_SH, 4, 1, true>), g, b, 0, s, p0, plist); break;
+    case 1: launch_fwd_sh_batch_c<1>(p0, plist, B, nblk, s); break;
+    case 2: launch_fwd_sh_batch_c<2>(p0, plist, B, nblk, s); break;
+    case 3: launch_fwd_sh_batch_c<3>(p0, plist, B, nblk, s); break;
+    default: launch_fwd_sh_batch_c<4>(p0, plist, B, nblk, s); break;
   }
   return (int)hipGetLastError();
 }
-int launch_bwd_sh_batch(int C, const CompParams &p0, const CompParams *plist, uint32_t B, hipStream_t s) {
-  const uint32_t nblk = comp_grid(p0) * (uint32_t)(p0.nseg > 1 ? p0.nseg : 1);
-  if (p0.ntw * p0.nth == 0 || B == 0) return 0;
-  const dim3 g(nblk, B), b(128);
+template <int CB>
+static void launch_bwd_sh_batch_c(const CompParams &p0, const CompParams *plist, uint32_t B, uint32_t nblk, hipStream_t s) {
+  // pixels per lane of the matrix-core kernel (wavefronts per tile = 4 / ppl), as GSGEN_BWD_MFMA = 4 | 2 | 1
+  static const int ppl = getenv("GSGEN_BWD_MFMA_BATCH") ? atoi(getenv("GSGEN_BWD_MFMA_BATCH")) : 2;
+  const dim3 g(nblk * B);
+  if (ppl == 4) hipLaunchKernelGGL((k_composite_bwd_sh_mfma<CB, 4, true>), g, dim3(64), 0, s, p0, plist);
+  else if (ppl == 1) hipLaunchKernelGGL((k_composite_bwd_sh_mfma<CB, 1, true>), g, dim3(256), 0, s, p0, plist);
+  else hipLaunchKernelGGL((k_composite_bwd_sh_mfma<CB, 2, true>), g, dim3(128), 0, s, p0, plist);
+}
+int launch_bwd_sh_batch(int C, const CompParams &p0_, const CompParams *plist, uint32_t B, hipStream_t s) {
+  const uint32_t nblk = comp_grid(p0_) * (uint32_t)(p0_.nseg > 1 ? p0_.nseg : 1);
+  if (p0_.ntw * p0_.nth == 0 || B == 0) return 0;
+  const CompParams p0 = batch_arg(p0_, B);
   switch (C) {
-    case 1: hipLaunchKernelGGL((k_composite_bwd_sh_mfma<1, 2, true>), g, b, 0, s, p0, plist); break;
-    case 2: hipLaunchKernelGGL((k_composite_bwd_sh_mfma<2, 2, true>), g, b, 0, s, p0, plist); break;
-    case 3: hipLaunchKernelGGL((k_composite_bwd_sh_mfma<3, 2, true>), g, b, 0, s, p0, plist); break;
-    default: hipLaunchKernelGGL((k_composite_bwd_sh_mfma<4, 2, true>), g, b, 0, s, p0, plist); break;
+    case 1: launch_bwd_sh_batch_c<1>(p0, plist, B, nblk, s); break;
+    case 2: launch_bwd_sh_batch_c<2>(p0, plist, B, nblk, s); break;
+    case 3: launch_bwd_sh_batch_c<3>(p0, plist, B, nblk, s); break;
+    default: launch_bwd_sh_batch_c<4>(p0, plist, B, nblk, s); break;
   }
   return (int)hipGetLastError();
 }
@@ -1140,7 +1187,7 @@ int gsgen_vol_render_sh_batch(uint32_t n_views, const gsgen_sh_view *views, uint
   if (C < 1 || C > 4) return GSGEN_EUNSUPPORTED;
   if (n_views == 0) return 0;
   if (!views || !batch_workspace) return GSGEN_EINVAL;
-  if (n_views > 65535) return GSGEN_EINVAL;  // gridDim.y
+  if (n_views > 65535) return GSGEN_EINVAL;
   (void)N;
   std::vector<CompParams> ps;
   if (int e = fill_view_params(n_views, views, sh_coeffs, alpha, nullptr, nullptr, n_tiles_w, n_tiles_h, H, W,
