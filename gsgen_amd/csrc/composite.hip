@@ -107,10 +107,10 @@ __device__ __forceinline__ GRec load_rec(const Stage<MODE, CB, KB> &S, int g) {
 // (device memory) instead of the kernel argument -- a single launch's tail (the never-saturating
 // sparse tiles) is then paid once per batch instead of once per camera.  The grid is 1-D, B x the
 // per-camera grid; p_arg only carries B (n_lo) and the workgroup -> (view, per-camera block) map (n_hi):
-//   0  interleaved: view = id % B -- with longest-first tile order every camera's longest lists start at
-//      once and the launch ends on everyone's shortest; with B = 8, XCD k (ids = k mod 8) sees one camera
+//   2  camera-major (default): all blocks of camera 0, then camera 1, ...
+//   0  interleaved: view = id % B -- every camera's longest lists start at once; with B = 8, XCD k
+//      (ids = k mod 8) sees one camera
 //   1  interleaved, view rotated by the block index (no camera pinned to an XCD)
-//   2  camera-major: all blocks of camera 0, then camera 1, ... (the last camera's long lists start late)
 __device__ __forceinline__ uint32_t batch_view(const CompParams &p_arg, uint32_t &bid, uint32_t *grid = nullptr) {
   const uint32_t B = (uint32_t)p_arg.n_lo, per = gridDim.x / B;
   uint32_t view;
@@ -978,7 +978,10 @@ static void launch_fwd_sh_batch_c(const CompParams &p0, const CompParams *plist,
   else hipLaunchKernelGGL((k_composite_fwd<MODE_SH, CB, 4, true>), g, dim3(64), 0, s, p0, plist);
 }
 static CompParams batch_arg(const CompParams &p0, uint32_t B) {
-  static const int map = getenv("GSGEN_BATCH_MAP") ? atoi(getenv("GSGEN_BATCH_MAP")) : 0;
+  // measured (profiles/r01_notes.md): camera-major is as fast as either interleaving on cfg2 (2820-2860 vs
+  // 2790-2850 renders/s) and faster on the 64 random cameras of cfg4 (5440-5590 vs 5030 / 5290-5360: an
+  // interleaved B = 8 pins each camera to one XCD, and random cameras differ in work)
+  static const int map = getenv("GSGEN_BATCH_MAP") ? atoi(getenv("GSGEN_BATCH_MAP")) : 2;
   CompParams a = p0;
   a.n_lo = (int)B;
   a.n_hi = map;
