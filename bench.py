@@ -439,6 +439,19 @@ def main():
                "fwd_kernel_ms": float(np.mean([e[0].elapsed_time(e[1]) for e in ev1])),
                "bwd_kernel_ms": float(np.mean([e[2].elapsed_time(e[3]) for e in ev1]))}
 
+    # batched launches once more with ONE batch in flight: the duration of a launch that has the chip to
+    # itself (in the timed region above two batches share it, so each launch there takes about twice as long)
+    alone = None
+    if B > 1:
+        nb_alone = max(2, min(8, args.steps // B))
+        eva = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(nb_alone)]
+        barrier()
+        for j in range(nb_alone):
+            batch_step(0, args.warmup + j * B, B, eva[j], gather=False)  # slot 0 every time: one stream
+        barrier()
+        alone = {"fwd_launch_ms": float(np.mean([e[0].elapsed_time(e[1]) for e in eva])),
+                 "bwd_launch_ms": float(np.mean([e[2].elapsed_time(e[3]) for e in eva])), "views_per_launch": B}
+
     fwd_ms = float(np.mean([evs[i][0].elapsed_time(evs[i][1]) for i in launched]))
     bwd_ms = float(np.mean([evs[i][2].elapsed_time(evs[i][3]) for i in launched]))
     vpl = args.steps / len(launched)  # views per compositing launch
@@ -450,8 +463,13 @@ def main():
     traffic, valu_floor = None, None
     try:  # per launch of the dominant kernel, from the committed PMC passes (cfg2 only)
         if args.config == "cfg2":
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["k_composite_bwd"]
-            traffic, valu_floor = pmc["traffic_bytes"], pmc.get("valu_floor_ms")
+            pmc_all = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            if B > 1 and vpl == 8 and "k_composite_bwd_batch8" in pmc_all:  # measured on the 8-camera launch itself
+                pmc = pmc_all["k_composite_bwd_batch8"]
+                traffic, valu_floor = pmc["traffic_bytes"] / vpl, pmc.get("valu_floor_ms") / vpl
+            else:
+                pmc = pmc_all["k_composite_bwd"]
+                traffic, valu_floor = pmc["traffic_bytes"], pmc.get("valu_floor_ms")
     except Exception:
         traffic, valu_floor = None, None
     # dominant kernel = composite backward
@@ -468,7 +486,8 @@ def main():
                    "gaussians": N, "visible_after_cull": n_vis, "image": [H, W], "sh_degree": C - 1,
                    "tile_pairs_D": D, "cameras_per_gpu_per_step": 1, "cameras_per_launch": B, "renders_in_flight": n_streams if B == 1 else B * len(bslots), "backward_segments_per_tile": args.segments, "parallelism": f"camera-sharded x{world}",
                    "gather": "rccl all_gather of rendered images" if world > 1 else "none"},
-        "roofline": {"bound": "hbm", "kernel": f"k_composite_bwd_sh_mfma<C={C},2> (compositing backward, matrix-core grad_sh)", "achieved": ach, "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": f"k_composite_bwd_sh_mfma<C={C},2{',batched' if B > 1 else ''}> (compositing backward, matrix-core grad_sh"
+                               + (f", {vpl:g} cameras per launch)" if B > 1 else ")"), "achieved": ach, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None if traffic is None else traffic * vpl,
                      "alg_bytes_per_launch": vpl * parts["composite_bwd"], "views_per_launch": vpl, "avg_launch_ms": bwd_ms,
                      "fwd_kernel_ms": fwd_ms,
@@ -480,6 +499,14 @@ def main():
         res["one_render_in_flight"] = one
         res["roofline"]["isolated_launch_ms"] = one["bwd_kernel_ms"]
         res["roofline"]["isolated_achieved"] = parts["composite_bwd"] / (one["bwd_kernel_ms"] * 1e-3) / 1e9
+    if alone is not None:
+        res["roofline"]["batches_in_flight"] = len(bslots)
+        res["roofline"]["alone_launch_ms"] = alone["bwd_launch_ms"]
+        res["roofline"]["alone_achieved"] = B * parts["composite_bwd"] / (alone["bwd_launch_ms"] * 1e-3) / 1e9
+        res["roofline"]["alone_frac"] = res["roofline"]["alone_achieved"] / HBM_PEAK_GBS
+        res["roofline"]["alone_fwd_launch_ms"] = alone["fwd_launch_ms"]
+        if valu_floor is not None:
+            res["roofline"]["alone_valu_frac"] = valu_floor * B / alone["bwd_launch_ms"]
     if valu_floor is not None:
         # the kernel is bound by vector-ALU issue, not HBM: time it would take if
         # every SIMD issued its share of the measured vector instructions back to back

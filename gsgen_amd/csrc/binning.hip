@@ -30,6 +30,7 @@ namespace gs {
 
 constexpr int kThreads = 256;
 constexpr int kSortThreads = 256;  // waves 1-3 only work on segments too long for the register sort
+constexpr uint32_t kBigGrid = 128;  // workgroups (per view) walking the long-list front of the launch order
 constexpr int kSortLds = 4096;  // keys sorted in LDS per tile (32 KiB); longer segments sort in global memory
 
 constexpr int kGroup = 8;      // tiles per group side: 8x8 tiles <-> 64 lanes
@@ -395,26 +396,35 @@ sort_tiles_body(uint32_t tile, const uint32_t *__restrict__ tile_off, const uint
 // of static LDS per workgroup would throttle the compositing kernels of other renders in flight).
 __device__ __forceinline__ void
 sort_tiles_big_body(uint32_t T, const uint32_t *__restrict__ tile_off, const uint32_t *__restrict__ ctrl,
-                 unsigned long long *__restrict__ keys, int *__restrict__ ids) {
+                 unsigned long long *__restrict__ keys, int *__restrict__ ids,
+                 const uint32_t *__restrict__ tile_order) {
   __shared__ unsigned long long s_keys[kSortLds];
-  const uint32_t tile = blockIdx.x;
   const uint32_t tid = threadIdx.x;
   if (ctrl[1] != 0u) return;
-  const uint32_t b = tile_off[tile], e = tile_off[tile + 1];
-  const uint32_t n = e - b;
-  if (n <= 64u * kSortMaxK) return;
-  if (n <= (uint32_t)kSortLds) {
-    for (uint32_t i = tid; i < n; i += kSortThreads) s_keys[i] = keys[b + i];
-    __syncthreads();
-    bitonic_sort(s_keys, n, tid, kSortThreads);
-    for (uint32_t i = tid; i < n; i += kSortThreads) ids[b + i] = (int)(uint32_t)(s_keys[i] & 0xffffffffull);
-  } else {
-    // same network directly on the global segment (one workgroup, so __syncthreads + the
-    // L2-coherent stores of this CU order the passes)
-    unsigned long long *k = keys + b;
-    __syncthreads();
-    bitonic_sort(k, n, tid, kSortThreads);
-    for (uint32_t i = tid; i < n; i += kSortThreads) ids[b + i] = (int)(uint32_t)(k[i] & 0xffffffffull);
+  // With a launch order (k_order_tiles: every list of >= 2040 entries sits in the first bucket) a few
+  // workgroups walk the front of it and stop at the first short list, instead of one workgroup per tile
+  // each finding it has nothing to do: 32 KiB of LDS per workgroup made 20k of those queue for 270 us
+  // behind the compositing kernels of another batch.
+  for (uint32_t r = blockIdx.x; r < T; r += gridDim.x) {
+    const uint32_t tile = tile_order != nullptr ? tile_order[r] : r;
+    const uint32_t b = tile_off[tile], e = tile_off[tile + 1];
+    const uint32_t n = e - b;
+    if (tile_order != nullptr && n < 2040u) break;
+    if (n <= 64u * kSortMaxK) continue;
+    if (n <= (uint32_t)kSortLds) {
+      for (uint32_t i = tid; i < n; i += kSortThreads) s_keys[i] = keys[b + i];
+      __syncthreads();
+      bitonic_sort(s_keys, n, tid, kSortThreads);
+      for (uint32_t i = tid; i < n; i += kSortThreads) ids[b + i] = (int)(uint32_t)(s_keys[i] & 0xffffffffull);
+    } else {
+      // same network directly on the global segment (one workgroup, so __syncthreads + the
+      // L2-coherent stores of this CU order the passes)
+      unsigned long long *k = keys + b;
+      __syncthreads();
+      bitonic_sort(k, n, tid, kSortThreads);
+      for (uint32_t i = tid; i < n; i += kSortThreads) ids[b + i] = (int)(uint32_t)(k[i] & 0xffffffffull);
+    }
+    __syncthreads();  // s_keys is reused by this workgroup's next tile
   }
 }
 
@@ -481,13 +491,14 @@ k_sort_tiles_views(uint32_t T, uint32_t B, const GeoView *__restrict__ views) {
 }
 __global__ void __launch_bounds__(kSortThreads)
 k_sort_tiles_big(uint32_t T, const uint32_t *__restrict__ tile_off, const uint32_t *__restrict__ ctrl,
-                 unsigned long long *__restrict__ keys, int *__restrict__ ids) {
-  sort_tiles_big_body(T, tile_off, ctrl, keys, ids);
+                 unsigned long long *__restrict__ keys, int *__restrict__ ids,
+                 const uint32_t *__restrict__ tile_order) {
+  sort_tiles_big_body(T, tile_off, ctrl, keys, ids, tile_order);
 }
 __global__ void __launch_bounds__(kSortThreads)
 k_sort_tiles_big_views(uint32_t T, const GeoView *__restrict__ views) {
   const GeoView v = views[blockIdx.y];
-  sort_tiles_big_body(T, v.tile_off, v.ctrl, v.keys, v.ids);
+  sort_tiles_big_body(T, v.tile_off, v.ctrl, v.keys, v.ids, v.tile_order);
 }
 
 template <int P>
@@ -553,7 +564,8 @@ static int bin_and_sort(uint32_t N, uint32_t cap, uint32_t nth, uint32_t ntw, co
     hipLaunchKernelGGL((k_bin_pull<true>), gpull, bpull, 0, s, N, tl, br, depth, (int)ntw, (int)nth, T,
                        w.cnt, w.tile_off, w.ctrl, w.keys);
   hipLaunchKernelGGL(k_sort_tiles, dim3(T), dim3(64), 0, s, T, w.tile_off, w.ctrl, w.keys, ids, start, end);
-  hipLaunchKernelGGL(k_sort_tiles_big, dim3(T), dim3(kSortThreads), 0, s, T, w.tile_off, w.ctrl, w.keys, ids);
+  hipLaunchKernelGGL(k_sort_tiles_big, dim3(T < kBigGrid ? T : kBigGrid), dim3(kSortThreads), 0, s, T, w.tile_off,
+                     w.ctrl, w.keys, ids, (const uint32_t *)w.tile_order);
   return (int)hipGetLastError();
 }
 
@@ -577,7 +589,8 @@ int gsgen_internal_sort_segments(uint32_t T, const uint32_t *tile_off, const uin
   hipStream_t s = (hipStream_t)stream;
   if (T == 0) return 0;
   hipLaunchKernelGGL(k_sort_tiles, dim3(T), dim3(64), 0, s, T, tile_off, ctrl, keys, ids, start, end);
-  hipLaunchKernelGGL(k_sort_tiles_big, dim3(T), dim3(kSortThreads), 0, s, T, tile_off, ctrl, keys, ids);
+  hipLaunchKernelGGL(k_sort_tiles_big, dim3(T), dim3(kSortThreads), 0, s, T, tile_off, ctrl, keys, ids,
+                     (const uint32_t *)nullptr);  // no launch order here: one workgroup per segment
   return (int)hipGetLastError();
 }
 
@@ -671,7 +684,8 @@ int gsgen_frame_geometry_batch(uint32_t n_views, const gsgen_geometry_view *view
   if (N)
     hipLaunchKernelGGL((k_bin_pull_views<true>), gpull, bpull, 0, s, N, (int)ntw, (int)nth, T, (const GeoView *)dv);
   hipLaunchKernelGGL(k_sort_tiles_views, dim3(T * B), dim3(64), 0, s, T, B, (const GeoView *)dv);
-  hipLaunchKernelGGL(k_sort_tiles_big_views, dim3(T, B), dim3(kSortThreads), 0, s, T, (const GeoView *)dv);
+  hipLaunchKernelGGL(k_sort_tiles_big_views, dim3(T < kBigGrid ? T : kBigGrid, B), dim3(kSortThreads), 0, s, T,
+                     (const GeoView *)dv);
   return (int)hipGetLastError();
 }
 

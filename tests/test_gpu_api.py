@@ -226,6 +226,86 @@ def test_batched_cameras_match_one_at_a_time(n_streams, C, fused):
         br.render(Pb["mean"], Pb["qvec"], Pb["svec"], Pb["alpha"], Pb[ck], cis * 2, [c.c2w for c in cams] * 2, C=C)
 
 
+def test_batched_geometry_and_projection_backward_c_abi():
+    """gsgen_frame_geometry_batch leaves bit for bit what one gsgen_frame_geometry call per view leaves (lists,
+    records, mask, pair count, launch order, one view overflowing its pair buffer), and
+    gsgen_project_gaussians_backward_batch equals the sum of the masked per-view backwards; both against
+    the oracle through the per-view entry points they are compared with (test_fused_frame_matches_oracle)."""
+    import ctypes
+    from gsgen_amd import _capi, renderer as R
+    lib = _capi.load()
+    W, H, B = 208, 144, 5
+    sc = scenes.random_scene(9000, seed=33, svec=0.03)
+    N = sc["mean"].shape[0]
+    cams = [scenes.Camera(W, H, fx=170.0 + 11 * i, c2w=scenes.orbit(2.2 + 0.1 * i, 30 - 12 * i, 50.0 + 67 * i)) for i in range(B)]
+    cam_dev = [T_(R.CameraInfo(*c.intr).pack(c.c2w)) for c in cams]
+    mean, qvec, svec = T_(sc["mean"]), T_(sc["qvec"]), T_(sc["svec"])
+    p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+    s = torch.cuda.current_stream().cuda_stream
+    Ds = [scenes.oracle_geometry(sc, c)["D"] for c in cams]
+    caps = [d + 64 for d in Ds]
+    caps[3] = Ds[3] - 1  # this view overflows: nothing binned, required size reported
+
+    def run(batched):
+        bufs = [R.FrameBuffers(N, W, H, dev(), D_cap=c) for c in caps]
+        for b_ in bufs:
+            b_.ids.fill_(-3); b_.ws.zero_()
+        if batched:
+            arr = (_capi.GeometryView * B)()
+            for a, b_, cd in zip(arr, bufs, cam_dev):
+                a.cam, a.mean2d, a.cov2d, a.depth, a.mask = p(cd), p(b_.mean2d), p(b_.cov2d), p(b_.depth), p(b_.mask)
+                a.gaussian_ids, a.start, a.end, a.total = p(b_.ids), p(b_.start), p(b_.end), p(b_.total)
+                a.workspace, a.workspace_bytes, a.D_cap = p(b_.ws), b_.ws.numel(), b_.D_cap
+            bws = torch.empty(lib.frame_batch_workspace_bytes(B), device=dev(), dtype=torch.uint8)
+            lib.frame_geometry_batch(B, arr, N, p(mean), p(qvec), p(svec), W, H, p(bws), s)
+        else:
+            for b_, cd in zip(bufs, cam_dev):
+                lib.frame_geometry(N, p(mean), p(qvec), p(svec), p(cd), W, H, b_.D_cap, p(b_.mean2d), p(b_.cov2d),
+                                   p(b_.depth), p(b_.mask), p(b_.ids), p(b_.start), p(b_.end), p(b_.total), p(b_.ws),
+                                   b_.ws.numel(), s)
+        torch.cuda.synchronize()
+        return bufs
+    ref, got = run(False), run(True)
+    T = ref[0].nth * ref[0].ntw
+    for i, (r, g) in enumerate(zip(ref, got)):
+        assert int(g.total.item()) == Ds[i]
+        for k in ("mean2d", "cov2d", "depth", "mask", "ids", "start", "end"):
+            assert torch.equal(getattr(r, k), getattr(g, k)), (i, k)
+        # the workspace too (counts, offsets, keys, rectangles), except the launch order: tiles of one
+        # length bucket are placed by LDS atomics, so only "same buckets, a permutation" is defined
+        wr, wg = r.ws.clone(), g.ws.clone()
+        o = r.tile_order() - r.ws.data_ptr()
+        orders = []
+        for w in (wr, wg):
+            orders.append(w[o:o + 4 * T].view(torch.int32).clone())
+            w[o:o + 4 * T] = 0
+        assert torch.equal(wr, wg), i
+        cnt = (r.end - r.start).clamp(min=0)
+        for od in orders:
+            assert torch.equal(od.sort().values, torch.arange(T, device=dev(), dtype=torch.int32))
+            b = cnt[od.long()] >> 3
+            assert bool((b[1:] <= b[:-1]).all())  # longest lists first, in buckets of 8 entries
+    assert bool((got[3].start == -1).all()) and bool((got[0].start >= 0).any())
+
+    gen = torch.Generator(device=dev()).manual_seed(1)
+    g2d = torch.randn(B, 6 * N, device=dev(), generator=gen)
+    gdp = torch.randn(B, N, device=dev(), generator=gen)
+    want = torch.zeros(10 * N, device=dev(), dtype=torch.float64)
+    for i in range(B):
+        o = torch.empty(10 * N, device=dev())
+        lib.project_gaussians_backward_masked(N, p(mean), p(qvec), p(svec), p(cam_dev[i]), 0, p(got[i].mask),
+                                              p(g2d[i]), p(g2d[i]) + 8 * N, p(gdp[i]), p(o), p(o) + 12 * N, p(o) + 28 * N, s)
+        want += o.double()
+    tab = lambda vals: (ctypes.c_void_p * B)(*vals)  # noqa: E731
+    o = torch.full((10 * N,), 5.0, device=dev())
+    lib.project_gaussians_backward_batch(B, N, p(mean), p(qvec), p(svec), tab([p(c) for c in cam_dev]), 0,
+                                         tab([p(b_.mask) for b_ in got]), tab([p(g2d[i]) for i in range(B)]),
+                                         tab([p(g2d[i]) + 8 * N for i in range(B)]), tab([p(gdp[i]) for i in range(B)]),
+                                         p(o), p(o) + 12 * N, p(o) + 28 * N, s)
+    torch.cuda.synchronize()
+    assert rel_err(o.cpu().numpy(), want.cpu().numpy()) < 2e-6
+
+
 def test_fused_adam_tracks_torch_adam_through_a_render():
     """optim.FusedAdam: parameters are views of one flat buffer, autograd accumulates straight into
     the flat gradient, one kernel updates every field; against torch.optim.Adam on the same grads"""
