@@ -23,6 +23,13 @@ class ShView(C.Structure):
                 ("segment_workspace", vp), ("grad_out", vp), ("grad_mean", vp), ("grad_cov", vp)]
 
 
+class RgbdView(C.Structure):
+    """gsgen_rgbd_view (include/gsgen_hip.h): one camera of a batched RGB + heads launch."""
+    _fields_ = [("mean", vp), ("cov", vp), ("depth", vp), ("start", vp), ("end", vp), ("gaussian_ids", vp),
+                ("tile_order", vp), ("topleft", vp), ("pixel_size_x", f32), ("pixel_size_y", f32), ("out6", vp),
+                ("T", vp), ("grad_out6", vp), ("grad_mean", vp), ("grad_cov", vp), ("grad_chan6", vp)]
+
+
 class GeometryView(C.Structure):
     """gsgen_geometry_view (include/gsgen_hip.h): one camera of a batched geometry enqueue."""
     _fields_ = [("cam", vp), ("mean2d", vp), ("cov2d", vp), ("depth", vp), ("mask", vp), ("gaussian_ids", vp),
@@ -71,6 +78,9 @@ SIGNATURES = {
     "gsgen_vol_render_sh_batch": [u32, C.POINTER(ShView), u32, vp, vp, u32, u32, u32, u32, u32, u32, f32, u32, vp, vp],
     "gsgen_vol_render_backward_sh_batch": [u32, C.POINTER(ShView), u32, vp, vp, vp, vp, u32, u32, u32, u32, u32, u32,
                                            f32, u32, vp, vp],
+    "gsgen_vol_render_rgbd_batch": [u32, C.POINTER(RgbdView), u32, vp, vp, u32, u32, u32, u32, u32, f32, vp, vp],
+    "gsgen_vol_render_rgbd_backward_batch": [u32, C.POINTER(RgbdView), u32, vp, vp, vp, u32, u32, u32, u32, u32, f32, vp,
+                                             vp],
     "gsgen_legacy_count_tiles": [u32, u32, vp, vp, vp, u32, u32, u32, f32, f32, f32, vp, vp],
     "gsgen_legacy_image_sort": [u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, u32, f32, f32, f32, vp, sz, vp],
     "gsgen_frame_geometry_batch": [u32, C.POINTER(GeometryView), u32, vp, vp, vp, u32, u32, vp, vp],

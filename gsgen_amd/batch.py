@@ -203,6 +203,48 @@ class _render_batch_heads(torch.autograd.Function):
         H, W, N, dev = br.H, br.W, br.N, mean.device
         out6 = torch.zeros(B, H, W, 6, device=dev, dtype=torch.float32)
         T = torch.ones(B, H, W, 1, device=dev, dtype=torch.float32)
+        cams_p, out_p, T_p = cams.data_ptr(), out6.data_ptr(), T.data_ptr()
+        ctx.views = ctx.bws = None
+        if br.fused_launch and B > 0:  # one enqueue per stage for the whole batch, on the current stream
+            s = torch.cuda.current_stream(dev).cuda_stream
+            geo = (_capi.GeometryView * B)()
+            views = (_capi.RgbdView * B)()
+            for i in range(B):
+                buf, ci, g, v = br.slots[i], br._cis[i], geo[i], views[i]
+                cam = cams_p + 272 * i
+                g.cam, g.mean2d, g.cov2d, g.depth, g.mask = cam, _p(buf.mean2d), _p(buf.cov2d), _p(buf.depth), _p(buf.mask)
+                g.gaussian_ids, g.start, g.end, g.total = _p(buf.ids), _p(buf.start), _p(buf.end), _p(buf.total)
+                g.workspace, g.workspace_bytes, g.D_cap = _p(buf.ws), buf.ws.numel(), buf.D_cap
+                v.mean, v.cov, v.depth = _p(buf.mean2d), _p(buf.cov2d), _p(buf.depth)
+                v.start, v.end, v.gaussian_ids = _p(buf.start), _p(buf.end), _p(buf.ids)
+                v.tile_order, v.topleft = buf.tile_order(), cam + 224
+                v.pixel_size_x, v.pixel_size_y = 1.0 / ci.fx, 1.0 / ci.fy
+                v.out6, v.T = out_p + 24 * H * W * i, T_p + 4 * H * W * i
+            nb_sh = lib.sh_batch_workspace_bytes(B)
+            bws = torch.empty(nb_sh + lib.frame_batch_workspace_bytes(B), device=dev, dtype=torch.uint8)
+            with torch.cuda.device(dev):
+                lib.frame_geometry_batch(B, geo, N, _p(mean), _p(qvec), _p(svec), W, H, _p(bws) + nb_sh, s)
+                if stats is not None:
+                    for i in range(B):
+                        buf = br.slots[i]
+                        lib.densify_update(N, _p(buf.cov2d), None, _p(buf.mask), _p(stats.max_radii2d), None, None, s)
+                lib.vol_render_rgbd_batch(B, views, N, _p(col), _p(alpha), 16, br.slots[0].nth, br.slots[0].ntw, H, W,
+                                          thresh, _p(bws), s)
+            ctx.views, ctx.bws = views, bws
+        else:
+            _render_batch_heads._forward_streams(br, B, lib, mean, qvec, svec, alpha, col, cams, out6, T, thresh, stats)
+        if bg_rgb is not None:
+            out6[..., :3] += T * bg_rgb  # gs/renderer.py:1182
+        ctx.save_for_backward(mean, qvec, svec, alpha, col, cams, out6)
+        ctx.br, ctx.B, ctx.thresh, ctx.detach, ctx.stats = br, B, thresh, detach_depth, stats
+        ctx.cis = list(br._cis[:B])
+        ctx.mark_non_differentiable(T)
+        return out6[..., :3], out6[..., 3:4], out6[..., 4:5], out6[..., 5:6], T
+
+    @staticmethod
+    def _forward_streams(br, B, lib, mean, qvec, svec, alpha, col, cams, out6, T, thresh, stats):
+        """one chain per camera on the side streams"""
+        H, W, N, dev = br.H, br.W, br.N, mean.device
         cur = br._fork(B, (cams, out6, T))
         cams_p, out_p, T_p = cams.data_ptr(), out6.data_ptr(), T.data_ptr()
         with torch.cuda.device(dev):
@@ -219,13 +261,6 @@ class _render_batch_heads(torch.autograd.Function):
                                     buf.nth, buf.ntw, 1.0 / ci.fx, 1.0 / ci.fy, H, W, thresh, T_p + 4 * H * W * i,
                                     buf.tile_order(), s)
         br._join(B, cur)
-        if bg_rgb is not None:
-            out6[..., :3] += T * bg_rgb  # gs/renderer.py:1182
-        ctx.save_for_backward(mean, qvec, svec, alpha, col, cams, out6)
-        ctx.br, ctx.B, ctx.thresh, ctx.detach, ctx.stats = br, B, thresh, detach_depth, stats
-        ctx.cis = list(br._cis[:B])
-        ctx.mark_non_differentiable(T)
-        return out6[..., :3], out6[..., 3:4], out6[..., 4:5], out6[..., 5:6], T
 
     @staticmethod
     def backward(ctx, g_rgb, g_depth, g_opac, g_z2, _gT):
@@ -241,8 +276,35 @@ class _render_batch_heads(torch.autograd.Function):
         g3d = torch.zeros(11 * N, device=dev, dtype=torch.float32)     # shared: mean | qvec | svec | alpha
         g_mean, g_qvec = g3d[:3 * N].view(N, 3), g3d[3 * N:7 * N].view(N, 4)
         g_svec, g_alpha = g3d[7 * N:10 * N].view(N, 3), g3d[10 * N:]
-        cur = br._fork(B, (go6, g2d, gch, gdp, g3d))
         cams_p, out_p, go_p, g2d_p = cams.data_ptr(), out6.data_ptr(), go6.data_ptr(), g2d.data_ptr()
+        if ctx.views is not None:
+            import ctypes
+            s = torch.cuda.current_stream(dev).cuda_stream
+            gch_p = gch.data_ptr()
+            for i in range(B):
+                v = ctx.views[i]
+                v.grad_out6 = go_p + 24 * H * W * i
+                v.grad_mean, v.grad_cov = g2d_p + 24 * N * i, g2d_p + 24 * N * i + 8 * N
+                v.grad_chan6 = gch_p + 24 * N * i
+            tab = lambda vals: (ctypes.c_void_p * B)(*vals)  # noqa: E731
+            with torch.cuda.device(dev):
+                lib.vol_render_rgbd_backward_batch(B, ctx.views, N, _p(col), _p(alpha), _p(g_alpha), 16, br.slots[0].nth,
+                                                   br.slots[0].ntw, H, W, thresh, _p(ctx.bws), s)
+                depths = torch.stack([br.slots[i].depth.view(-1) for i in range(B)], 0)
+                torch.addcmul(gch[:, :, 3], depths, gch[:, :, 5], value=2.0, out=gdp)  # depth and depth^2 heads
+                lib.project_gaussians_backward_batch(B, N, _p(mean), _p(qvec), _p(svec),
+                                                     tab([cams_p + 272 * i for i in range(B)]), int(ctx.detach),
+                                                     tab([_p(br.slots[i].mask) for i in range(B)]),
+                                                     tab([g2d_p + 24 * N * i for i in range(B)]),
+                                                     tab([g2d_p + 24 * N * i + 8 * N for i in range(B)]),
+                                                     tab([_p(gdp[i]) for i in range(B)]), _p(g_mean), _p(g_qvec),
+                                                     _p(g_svec), s)
+                if stats is not None:
+                    for i in range(B):
+                        lib.densify_update(N, None, g2d_p + 24 * N * i, _p(br.slots[i].mask), None, _p(stats.grad_accum),
+                                           _p(stats.cnt), s)
+            return (g_mean, g_qvec, g_svec, g_alpha, gch[:, :, :3].sum(0)) + (None,) * 7
+        cur = br._fork(B, (go6, g2d, gch, gdp, g3d))
         with torch.cuda.device(dev):
             for i in range(B):
                 buf, stream, ci = br.slots[i], br.streams[i % len(br.streams)], ctx.cis[i]
@@ -275,7 +337,8 @@ class BatchRenderer:
         forward, compositing backward and projection backward each launch once for all cameras
         (gsgen_frame_geometry_batch, gsgen_vol_render_sh_batch, ..._backward_sh_batch,
         gsgen_project_gaussians_backward_batch) -- instead of one chain per camera spread over
-        `n_streams` side streams (which post-activation colours and the fused heads still use).
+        `n_streams` side streams (post-activation colours, C = 0, still do); render_heads likewise
+        (gsgen_vol_render_rgbd_batch / _backward_batch).
         cfg2: 2850 vs 2710 renders/s (profiles/r01_notes.md).  segments: backward workgroups per tile
         (FrameBuffers), fused launches only."""
         self.N, self.W, self.H, self.device = N, W, H, torch.device(device)

@@ -329,8 +329,11 @@ __global__ void __launch_bounds__(256 / PPL) k_composite_fwd(CompParams p_arg, c
 // ============================================================================================
 // backward
 // ============================================================================================
-template <int MODE, int CB, int PPL>
-__global__ void __launch_bounds__(256 / PPL) k_composite_bwd_pixel(CompParams p) {
+template <int MODE, int CB, int PPL, bool BATCH = false>
+__global__ void __launch_bounds__(256 / PPL)
+k_composite_bwd_pixel(CompParams p_arg, const CompParams *__restrict__ plist) {
+  uint32_t bid = blockIdx.x;
+  const CompParams p = BATCH ? plist[batch_view(p_arg, bid)] : p_arg;  // see k_composite_fwd
   using TR = Traits<MODE, CB>;
   constexpr int NT = 256 / PPL;
   constexpr int ROWS = NT / 16;
@@ -339,7 +342,7 @@ __global__ void __launch_bounds__(256 / PPL) k_composite_bwd_pixel(CompParams p)
   __shared__ Stage<MODE, CB> S;
 
   int tx, ty;
-  if (!block_tile(p, tx, ty)) return;  // uniform over the workgroup
+  if (!block_tile(p, tx, ty, bid)) return;  // uniform over the workgroup
   const int tile = ty * p.ntw + tx;
   const int st = p.start[tile];
   const int n = (st < 0) ? 0 : (p.end[tile] - st);
@@ -947,9 +950,9 @@ static int launch_bwd(const CompParams &p_, hipStream_t s) {
       return (int)hipGetLastError();
     }
   }
-  if (ppl == 1) hipLaunchKernelGGL((k_composite_bwd_pixel<MODE, CB, 1>), dim3(nblk), dim3(256), 0, s, p);
-  else if (ppl == 2) hipLaunchKernelGGL((k_composite_bwd_pixel<MODE, CB, 2>), dim3(nblk), dim3(128), 0, s, p);
-  else hipLaunchKernelGGL((k_composite_bwd_pixel<MODE, CB, 4>), dim3(nblk), dim3(64), 0, s, p);
+  if (ppl == 1) hipLaunchKernelGGL((k_composite_bwd_pixel<MODE, CB, 1>), dim3(nblk), dim3(256), 0, s, p, (const CompParams *)nullptr);
+  else if (ppl == 2) hipLaunchKernelGGL((k_composite_bwd_pixel<MODE, CB, 2>), dim3(nblk), dim3(128), 0, s, p, (const CompParams *)nullptr);
+  else hipLaunchKernelGGL((k_composite_bwd_pixel<MODE, CB, 4>), dim3(nblk), dim3(64), 0, s, p, (const CompParams *)nullptr);
   return (int)hipGetLastError();
 }
 
@@ -1018,6 +1021,23 @@ int launch_bwd_sh_batch(int C, const CompParams &p0_, const CompParams *plist, u
     case 3: launch_bwd_sh_batch_c<3>(p0, plist, B, nblk, s); break;
     default: launch_bwd_sh_batch_c<4>(p0, plist, B, nblk, s); break;
   }
+  return (int)hipGetLastError();
+}
+
+// fused RGB + heads, B cameras per launch (same defaults as the per-camera launches: 4 wavefronts per tile
+// forward, 1 backward)
+int launch_fwd_rgbd_batch(const CompParams &p0_, const CompParams *plist, uint32_t B, hipStream_t s) {
+  const uint32_t nblk = comp_grid(p0_);
+  if (p0_.ntw * p0_.nth == 0 || B == 0) return 0;
+  const CompParams p0 = batch_arg(p0_, B);
+  hipLaunchKernelGGL((k_composite_fwd<MODE_RGBD, 1, 1, true>), dim3(nblk * B), dim3(256), 0, s, p0, plist);
+  return (int)hipGetLastError();
+}
+int launch_bwd_rgbd_batch(const CompParams &p0_, const CompParams *plist, uint32_t B, hipStream_t s) {
+  const uint32_t nblk = comp_grid(p0_);
+  if (p0_.ntw * p0_.nth == 0 || B == 0) return 0;
+  const CompParams p0 = batch_arg(p0_, B);
+  hipLaunchKernelGGL((k_composite_bwd_pixel<MODE_RGBD, 1, 4, true>), dim3(nblk * B), dim3(64), 0, s, p0, plist);
   return (int)hipGetLastError();
 }
 
@@ -1220,6 +1240,66 @@ int gsgen_vol_render_backward_sh_batch(uint32_t n_views, const gsgen_sh_view *vi
   CompParams *dst = reinterpret_cast<CompParams *>(batch_workspace) + n_views;
   if (int e = write_params(ps.data(), n_views, dst, s)) return e;
   return launch_bwd_sh_batch((int)C, ps[0], dst, n_views, s);
+}
+
+static int fill_rgbd_params(uint32_t n_views, const gsgen_rgbd_view *views, const float *color, const float *alpha,
+                            float *g_alpha, uint32_t ntw, uint32_t nth, uint32_t H, uint32_t W, float thresh,
+                            bool backward, std::vector<CompParams> &ps) {
+  ps.assign(n_views, CompParams{});
+  for (uint32_t b = 0; b < n_views; ++b) {
+    const gsgen_rgbd_view &v = views[b];
+    if (!v.start || !v.end || !v.out6 || !v.depth) return GSGEN_EINVAL;
+    if ((v.tile_order == nullptr) != (views[0].tile_order == nullptr)) return GSGEN_EINVAL;
+    if (backward && (!v.grad_out6 || !v.grad_mean || !v.grad_cov || !v.grad_chan6)) return GSGEN_EINVAL;
+    CompParams &p = ps[b];
+    p.mean = v.mean; p.cov = v.cov; p.col = color; p.depth = v.depth; p.alpha = alpha;
+    p.start = v.start; p.end = v.end; p.ids = v.gaussian_ids; p.topleft = v.topleft;
+    p.ntw = (int)ntw; p.nth = (int)nth; p.H = (int)H; p.W = (int)W;
+    p.psx = v.pixel_size_x; p.psy = v.pixel_size_y; p.thresh = thresh;
+    p.tile_order = v.tile_order;
+    p.n_hi = 0x7fffffff;
+    if (backward) {
+      p.final_img = v.out6; p.grad_out = v.grad_out6;
+      p.g_mean = v.grad_mean; p.g_cov = v.grad_cov; p.g_col = v.grad_chan6; p.g_alpha = g_alpha;
+    } else {
+      p.out = v.out6; p.T = v.T;
+    }
+  }
+  return 0;
+}
+
+int gsgen_vol_render_rgbd_batch(uint32_t n_views, const gsgen_rgbd_view *views, uint32_t N, const float *color,
+                                const float *alpha, uint32_t tile_size, uint32_t n_tiles_h, uint32_t n_tiles_w,
+                                uint32_t H, uint32_t W, float thresh, void *batch_workspace,
+                                gsgen_stream_t stream) {
+  if (tile_size != 16) return GSGEN_EUNSUPPORTED;
+  if (n_views == 0 || N == 0) return 0;
+  if (!views || !batch_workspace) return GSGEN_EINVAL;
+  if (n_views > 65535) return GSGEN_EINVAL;
+  std::vector<CompParams> ps;
+  if (int e = fill_rgbd_params(n_views, views, color, alpha, nullptr, n_tiles_w, n_tiles_h, H, W, thresh, false, ps))
+    return e;
+  hipStream_t s = (hipStream_t)stream;
+  CompParams *dst = reinterpret_cast<CompParams *>(batch_workspace);
+  if (int e = write_params(ps.data(), n_views, dst, s)) return e;
+  return launch_fwd_rgbd_batch(ps[0], dst, n_views, s);
+}
+
+int gsgen_vol_render_rgbd_backward_batch(uint32_t n_views, const gsgen_rgbd_view *views, uint32_t N,
+                                         const float *color, const float *alpha, float *grad_alpha,
+                                         uint32_t tile_size, uint32_t n_tiles_h, uint32_t n_tiles_w, uint32_t H,
+                                         uint32_t W, float thresh, void *batch_workspace, gsgen_stream_t stream) {
+  if (tile_size != 16) return GSGEN_EUNSUPPORTED;
+  if (n_views == 0 || N == 0) return 0;
+  if (!views || !batch_workspace || !grad_alpha) return GSGEN_EINVAL;
+  if (n_views > 65535) return GSGEN_EINVAL;
+  std::vector<CompParams> ps;
+  if (int e = fill_rgbd_params(n_views, views, color, alpha, grad_alpha, n_tiles_w, n_tiles_h, H, W, thresh, true, ps))
+    return e;
+  hipStream_t s = (hipStream_t)stream;
+  CompParams *dst = reinterpret_cast<CompParams *>(batch_workspace) + n_views;
+  if (int e = write_params(ps.data(), n_views, dst, s)) return e;
+  return launch_bwd_rgbd_batch(ps[0], dst, n_views, s);
 }
 
 int gsgen_vol_render_sh(uint32_t N, uint32_t D, const float *mean, const float *cov,

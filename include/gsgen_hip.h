@@ -361,6 +361,29 @@ int gsgen_vol_render_rgbd_backward(uint32_t N, uint32_t D, const float *mean, co
                                    uint32_t n_tiles_w, float pixel_size_x, float pixel_size_y, uint32_t H,
                                    uint32_t W, float thresh, const uint32_t *tile_order, gsgen_stream_t stream);
 
+/* The same for the B cameras of a batch in ONE launch each way (as gsgen_vol_render_sh_batch): per-view
+ * records, depths, lists, out6 / T and per-view gradients (grad_chan6 holds the view's own depth-head
+ * gradients, so it is not shared); color / alpha are shared and grad_alpha accumulates over the views.
+ * batch_workspace: gsgen_sh_batch_workspace_bytes(n_views), one per batch in flight. */
+typedef struct gsgen_rgbd_view {
+  const float *mean, *cov, *depth;         /* [N,2], [N,2,2], [N] of this view */
+  const int *start, *end, *gaussian_ids;
+  const uint32_t *tile_order;              /* or NULL (then NULL in every view) */
+  const float *topleft;                    /* [2] */
+  float pixel_size_x, pixel_size_y;
+  float *out6, *T;                         /* [H,W,6], [H,W]; out6 is read by the backward */
+  const float *grad_out6;                  /* backward: [H,W,6] */
+  float *grad_mean, *grad_cov, *grad_chan6; /* backward: [N,2], [N,2,2], [N,6] of this view, accumulated into */
+} gsgen_rgbd_view;
+int gsgen_vol_render_rgbd_batch(uint32_t n_views, const gsgen_rgbd_view *views, uint32_t N, const float *color,
+                                const float *alpha, uint32_t tile_size, uint32_t n_tiles_h, uint32_t n_tiles_w,
+                                uint32_t H, uint32_t W, float thresh, void *batch_workspace,
+                                gsgen_stream_t stream);
+int gsgen_vol_render_rgbd_backward_batch(uint32_t n_views, const gsgen_rgbd_view *views, uint32_t N,
+                                         const float *color, const float *alpha, float *grad_alpha,
+                                         uint32_t tile_size, uint32_t n_tiles_h, uint32_t n_tiles_w, uint32_t H,
+                                         uint32_t W, float thresh, void *batch_workspace, gsgen_stream_t stream);
+
 /* Self test of the wave64 cross-lane reduce-scatter used by the backward (tests only):
  * in [64 lanes, P components]; out[0..64) = per-lane result, out[64..128) = the component index that
  * lane owns (-1: duplicate holder); P in {8,16,32,64}. */

@@ -316,6 +316,60 @@ def test_emulated_fused_rgb_heads(emu):
         assert np.abs(a_ - b_).max() <= 1e-4 * (np.abs(b_).max() + 1e-12)
 
 
+def test_emulated_batched_rgb_heads_match_per_view_launches(emu):
+    """gsgen_vol_render_rgbd_batch / _backward_batch == one gsgen_vol_render_rgbd / _backward call per view
+    (per-view records, depths, lists and gradients; opacity gradient accumulated over the views)"""
+    from gsgen_amd._capi import RgbdView
+    W, H = 48, 32
+    sc = scenes.random_scene(400, seed=43, svec=0.07)
+    Nall = sc["mean"].shape[0]
+    col, al = np.ascontiguousarray(sc["color"]), np.ascontiguousarray(sc["alpha"])
+    cams = [scenes.Camera(W, H, fx=44.0, c2w=scenes.look_at(e)) for e in ((2.5, 0, 0), (0.3, 2.4, 0.6), (-1.5, -1.5, 1.2))]
+    nth, ntw = cams[0].tiles
+    views = []
+    for i, cam in enumerate(cams):
+        g = scenes.oracle_geometry(sc, cam)
+        nz = np.nonzero(g["mask"])[0]
+        m2 = np.zeros((Nall, 2), np.float32); c2 = np.zeros((Nall, 2, 2), np.float32); dv = np.zeros(Nall, np.float32)
+        m2[nz] = g["mean2d"]; c2[nz] = g["cov2d"]; dv[nz] = g["depth"].ravel()
+        views.append(dict(m2=m2, c2=c2, dv=dv, st=g["start"], en=g["end"], ids=nz[g["ids"]].astype(np.int32), tlp=cam.topleft,
+                          cam=cam, D=g["D"], go=np.random.default_rng(i).normal(size=(H, W, 6)).astype(np.float32)))
+    ref_ga = np.zeros(Nall, np.float32)
+    for v in views:
+        cam = v["cam"]
+        geo = (16, nth, ntw, 1 / cam.fx, 1 / cam.fy, H, W, 1e-4)
+        v["out_ref"] = np.zeros((H, W, 6), np.float32); v["T_ref"] = np.ones((H, W), np.float32)
+        emu.vol_render_rgbd(Nall, v["D"], P(v["m2"]), P(v["c2"]), P(col), P(v["dv"]), P(al), P(v["st"]), P(v["en"]),
+                            P(v["ids"]), P(v["out_ref"]), P(v["tlp"]), *geo, P(v["T_ref"]), None, None)
+        v["gm_ref"] = np.zeros((Nall, 2), np.float32); v["gc_ref"] = np.zeros((Nall, 4), np.float32)
+        v["gch_ref"] = np.zeros((Nall, 6), np.float32)
+        emu.vol_render_rgbd_backward(Nall, v["D"], P(v["m2"]), P(v["c2"]), P(col), P(v["dv"]), P(al), P(v["st"]), P(v["en"]),
+                                     P(v["ids"]), P(v["out_ref"]), P(v["gm_ref"]), P(v["gc_ref"]), P(v["gch_ref"]), P(ref_ga),
+                                     P(v["go"]), P(v["tlp"]), *geo, None, None)
+    arr = (RgbdView * len(views))()
+    for a, v in zip(arr, views):
+        cam = v["cam"]
+        v["out"] = np.zeros((H, W, 6), np.float32); v["T"] = np.ones((H, W), np.float32)
+        v["gm"] = np.zeros((Nall, 2), np.float32); v["gc"] = np.zeros((Nall, 4), np.float32); v["gch"] = np.zeros((Nall, 6), np.float32)
+        a.mean, a.cov, a.depth, a.start, a.end, a.gaussian_ids = P(v["m2"]), P(v["c2"]), P(v["dv"]), P(v["st"]), P(v["en"]), P(v["ids"])
+        a.tile_order, a.topleft, a.pixel_size_x, a.pixel_size_y = None, P(v["tlp"]), 1 / cam.fx, 1 / cam.fy
+        a.out6, a.T, a.grad_out6 = P(v["out"]), P(v["T"]), P(v["go"])
+        a.grad_mean, a.grad_cov, a.grad_chan6 = P(v["gm"]), P(v["gc"]), P(v["gch"])
+    bws = np.zeros(emu.sh_batch_workspace_bytes(len(views)), np.uint8)
+    emu.vol_render_rgbd_batch(len(views), arr, Nall, P(col), P(al), 16, nth, ntw, H, W, 1e-4, P(bws), None)
+    ga = np.zeros(Nall, np.float32)
+    emu.vol_render_rgbd_backward_batch(len(views), arr, Nall, P(col), P(al), P(ga), 16, nth, ntw, H, W, 1e-4, P(bws), None)
+    for v in views:
+        assert np.array_equal(v["out"], v["out_ref"]) and np.array_equal(v["T"], v["T_ref"])
+        assert np.abs(v["out"][..., 3]).max() > 0.1
+        for k in ("gm", "gc", "gch"):
+            assert np.abs(v[k] - v[k + "_ref"]).max() <= 2e-6 * np.abs(v[k + "_ref"]).max(), k
+    assert np.abs(ga - ref_ga).max() <= 2e-6 * np.abs(ref_ga).max() and np.abs(ref_ga).max() > 0
+    arr[2].depth = None
+    with pytest.raises(Exception, match="invalid"):
+        emu.vol_render_rgbd_batch(len(views), arr, Nall, P(col), P(al), 16, nth, ntw, H, W, 1e-4, P(bws), None)
+
+
 def _torch_densify(cov2d, gmean2d, mask, max_r, acc, cnt):
     """The reference's statements (gs/gaussian_splatting.py:1240-1245, :464-469) on full-N rows."""
     cov = torch.from_numpy(cov2d).reshape(-1, 2, 2); mask = torch.from_numpy(mask.astype(bool))

@@ -418,8 +418,8 @@ def test_legacy_renderer_call_sequence(kind):
     assert np.abs(out.cpu().numpy() - ref).max() <= 1e-5
 
 
-@pytest.mark.parametrize("detach", [True, False])
-def test_batched_fused_heads_match_oracle(detach):
+@pytest.mark.parametrize("detach,fused", [(True, True), (False, True), (False, False)])
+def test_batched_fused_heads_match_oracle(detach, fused):
     """BatchRenderer.render_heads: rgb + depth + opacity + depth^2 of 3 cameras in one autograd node against the
     oracle's four separate passes and its projection backward (with the depth gradient of the two depth heads)"""
     from gsgen_amd import renderer as R
@@ -431,7 +431,8 @@ def test_batched_fused_heads_match_oracle(detach):
     cis = [R.CameraInfo(*c.intr) for c in cams]
     keys = ("mean", "qvec", "svec", "alpha", "color")
     P_ = {k: T_(sc[k]).requires_grad_(True) for k in keys}
-    br = BatchRenderer(N, W, H, dev(), max_batch=3, n_streams=2)
+    # fused: one enqueue per stage for the batch (gsgen_vol_render_rgbd_batch ...); else one chain per camera
+    br = BatchRenderer(N, W, H, dev(), max_batch=3, n_streams=2, fused_launch=fused)
     rgb, dpt, opa, z2, T = br.render_heads(P_["mean"], P_["qvec"], P_["svec"], P_["alpha"], P_["color"], cis,
                                            [c.c2w for c in cams], detach_depth=detach)
     assert br.ensure_capacity(3)
