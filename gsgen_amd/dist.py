@@ -69,6 +69,24 @@ def render_batch_sharded(render_one, cameras, group=None):
     return gather_images(local, len(cameras), group)
 
 
+def render_cameras_sharded(render_many, cameras, group=None):
+    """As render_batch_sharded, with the rank's whole shard handed to `render_many(list of cameras) ->
+    [b, H, W, C]` in one call -- what BatchRenderer.render wants (one launch per stage for the shard),
+    e.g. `lambda cams: br.render(mean, qvec, svec, alpha, sh, [c.info for c in cams], [c.c2w for c in cams], C=4)[0]`.
+    A rank whose shard is empty renders camera 0 only to learn the image shape."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    lo, hi = shard_bounds(len(cameras), rank, world)
+    if hi > lo:
+        local = render_many(list(cameras[lo:hi]))
+        if local.shape[0] != hi - lo:
+            raise ValueError(f"render_many returned {local.shape[0]} images for {hi - lo} cameras")
+    else:
+        probe = render_many([cameras[0]])
+        local = probe.new_zeros((0,) + tuple(probe.shape[1:]))
+    return gather_images(local, len(cameras), group)
+
+
 def allreduce_gradients(tensors, group=None, average=True):
     """Data-parallel training on top of camera sharding: every rank has rendered
     and back-propagated its own cameras, the replicated parameters' gradients are summed (or

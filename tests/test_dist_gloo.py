@@ -41,6 +41,9 @@ def _worker(rank, world, port, n_cams, q):
     sc = scenes.random_scene(200, seed=5, svec=0.08)
     cams = _cams(n_cams)
     out = D.render_batch_sharded(lambda c: _render(sc, c), cams)
+    # the whole shard in one call (what BatchRenderer.render wants) must gather to the same batch
+    out2 = D.render_cameras_sharded(lambda cs: torch.stack([_render(sc, c) for c in cs], 0), cams)
+    assert torch.equal(out, out2)
     if rank == world - 1:
         q.put(out.numpy())
     dist.barrier()
