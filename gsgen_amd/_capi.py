@@ -112,6 +112,16 @@ class Lib:
                 f"{path} not found: build the HIP extension first (python -m gsgen_amd.build). "
                 "gsgen_amd has no CPU fallback.")
         self.path = path
+        if path == DEFAULT_LIB or "libgsgen_hip" in os.path.basename(path):
+            # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 and asks for it by FILE name
+            # (libamdhip64.so), this library asks for the SONAME (libamdhip64.so.7).  If torch's copy is loaded
+            # first ours resolves to it; the other way round the process ends up with two runtimes and the
+            # kernels of this library are launched on streams the other runtime made ("no ROCm-capable
+            # device").  The buffers and streams this binding is driven with are torch's, so torch goes first.
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         self.cdll = C.CDLL(path)
         self.cdll.gsgen_version.restype = C.c_char_p
         self.cdll.gsgen_error_string.restype = C.c_char_p

@@ -34,6 +34,21 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert ".hip_fatbin" in out
 
 
+def test_one_hip_runtime_per_process_whatever_the_import_order():
+    """the C-ABI library and PyTorch-ROCm must end up on ONE libamdhip64 (torch asks for its bundled copy by file
+    name, this library for the soname): loading this library before torch used to map two runtimes, and the
+    first kernel launch then failed with "no ROCm-capable device" (build() followed by smoke() in one process)"""
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from gsgen_amd import _capi\n"
+            "h = _capi.load()\n"
+            "import torch\n"
+            "maps = {l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l}\n"
+            "print(len(maps), sorted(maps))\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd="/")
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.split()[0] == "1", r.stdout
+
+
 def test_gs_mirror_has_the_23_reference_names():
     from gsgen_amd import _gs
     names = """culling_gaussian_bsphere count_num_gaussians_each_tile count_num_gaussians_each_tile_bcircle

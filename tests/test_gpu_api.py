@@ -517,6 +517,54 @@ def test_full_size_cfg2():
     assert rel_err(g1["alpha"].cpu().numpy()[m], ga) < 2e-3
 
 
+def test_full_size_cfg2_batched_launches():
+    """BASELINE configs[1] as the bench runs it by default: 8 cameras per launch and stage through BatchRenderer
+    against the same 8 cameras one at a time through render_frame (itself checked against the oracle at this
+    size in test_full_size_cfg2): images bit-identical, gradient of the summed loss within atomics reordering,
+    and the batch's backward linear in grad_out."""
+    from gsgen_amd import renderer as R
+    from gsgen_amd.batch import BatchRenderer
+    N, W, H, B = 100_000, 800, 800, 8
+    sc = scenes.pointe_scene(N, seed=0, C=4)
+    cams = [scenes.Camera(W, H, fx=800.0, c2w=scenes.orbit(2.5, 15.0, 30.0 + 45.0 * i)) for i in range(B)]
+    cis = [R.CameraInfo(*c.intr) for c in cams]
+    keys = ("mean", "qvec", "svec", "alpha", "sh")
+    bg = torch.tensor([0.1, 0.2, 0.3], device=dev())
+    go = torch.randn(B, H, W, 3, device=dev(), generator=torch.Generator(device=dev()).manual_seed(7))
+    Pa = {k: T_(sc[k]).requires_grad_(True) for k in keys}
+    buf = R.FrameBuffers(N, W, H, dev())
+    imgs = []
+    for i in range(B):
+        rgb, _ = R.render_frame(Pa["mean"], Pa["qvec"], Pa["svec"], Pa["alpha"], Pa["sh"], cis[i], cams[i].c2w, buf, C=4,
+                                bg_rgb=bg)
+        assert buf.ensure_capacity()
+        (rgb * go[i]).sum().backward()
+        imgs.append(rgb.detach())
+    Pb = {k: T_(sc[k]).requires_grad_(True) for k in keys}
+    br = BatchRenderer(N, W, H, dev(), max_batch=B)
+    assert br.fused_launch
+    rgb_b, T_b = br.render(Pb["mean"], Pb["qvec"], Pb["svec"], Pb["alpha"], Pb["sh"], cis, [c.c2w for c in cams], C=4,
+                           bg_rgb=bg)
+    assert br.ensure_capacity(B)
+    for i in range(B):
+        assert torch.equal(rgb_b[i].detach(), imgs[i]), i
+    (rgb_b * go).sum().backward()
+    g1 = {k: Pb[k].grad.clone() for k in keys}
+    for k in keys:
+        if k == "qvec":
+            continue  # isotropic svec: d/dq is rounding noise
+        assert rel_err(g1[k].cpu().numpy(), Pa[k].grad.cpu().numpy()) < 1e-4, k
+    for k in keys:
+        Pb[k].grad = None
+    rgb_c, _ = br.render(Pb["mean"], Pb["qvec"], Pb["svec"], Pb["alpha"], Pb["sh"], cis, [c.c2w for c in cams], C=4,
+                         bg_rgb=bg)
+    assert torch.equal(rgb_c, rgb_b)  # run-to-run bit-identical
+    (rgb_c * (2.0 * go)).sum().backward()
+    for k in keys:
+        if k != "qvec":
+            assert rel_err(Pb[k].grad.cpu().numpy(), 2.0 * g1[k].cpu().numpy()) < 1e-3, k
+
+
 def test_fused_rgb_heads_match_four_reference_passes():
     """render_rgb_heads == render_with_T + render_scalar x3 of render_one, forward and backward."""
     from gsgen_amd import renderer as R
