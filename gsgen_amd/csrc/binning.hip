@@ -54,26 +54,33 @@ __device__ __forceinline__ GroupGeom group_geom(int ntw, int nth) {
   return q;
 }
 
-// EMIT = false: cnt[chunk][tile] = number of rectangles of the chunk covering the tile.
-// EMIT = true : write the keys at tile_off[tile] + cnt[chunk][tile] (now a prefix) + running.
+// EMIT = false: cnt[chunk][tile] = number of rectangles of the chunk covering the tile, and
+//               wcnt[chunk][wave][tile] = the share of each of the workgroup's 4 wavefronts.
+// EMIT = true : write the keys at tile_off[tile] + cnt[chunk][tile] (now a prefix over chunks) + the
+//               counts of the lower wavefronts + running.
 // Workgroup = 4 waves on one (group, chunk): wave w walks sub-chunk w (kChunk/4 Gaussians),
 // with all of its kIter rectangle loads in flight at once (the walk is latency-bound: one
-// dependent L2 round trip per 64 Gaussians otherwise).  The EMIT pass counts first, swaps the
-// four counts through LDS to get each wave's base, then replays the rectangles from registers.
+// dependent L2 round trip per 64 Gaussians otherwise).
+// The walk over the ballot broadcasts the four rectangle words of a hit (readlane) and every lane tests its
+// tile.  (Tried: rectangle packed into 12 bits of group-relative coordinates, one readlane per hit and the
+// covered lanes as a 64-bit mask built with scalar instructions -- the ~15 scalar instructions per hit cost
+// more than the 3 readlanes + 4 compares they replace: count pass 78 -> 88 us per 8 cfg2 views.)  The count
+// pass leaves the per-wavefront counts in wcnt, so the emit pass walks once (it used to count again to find
+// each wavefront's base).
 constexpr int kPullWaves = 4;
 constexpr int kIter = kChunk / (64 * kPullWaves);  // 64-Gaussian slices per wave
+
+__device__ __forceinline__ int rd_lane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 
 struct RectRegs {
   int x0[kIter], y0[kIter], x1[kIter], y1[kIter];
 };
 
-__device__ __forceinline__ int rd_lane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
-
 template <bool EMIT>
 __device__ __forceinline__ void
 bin_pull_body(uint32_t N, const int *__restrict__ tl, const int *__restrict__ br,
            const float *__restrict__ depth, int ntw, int nth, uint32_t T,
-           uint32_t *__restrict__ cnt, const uint32_t *__restrict__ tile_off,
+           uint32_t *__restrict__ cnt, uint32_t *__restrict__ wcnt, const uint32_t *__restrict__ tile_off,
            const uint32_t *__restrict__ ctrl, unsigned long long *__restrict__ keys) {
   __shared__ uint32_t s_cnt[kPullWaves][64];
   if (EMIT && ctrl[1] != 0u) return;  // capacity exceeded: bin nothing
@@ -101,28 +108,28 @@ bin_pull_body(uint32_t N, const int *__restrict__ tl, const int *__restrict__ br
     } else if (EMIT) {
       dbits[it] = 0u;
     }
+    const bool touches = (x1 >= x0) && (y1 >= y0) && (x1 >= q.gx0) && (x0 <= q.gx0 + kGroup - 1) &&
+                         (y1 >= q.gy0) && (y0 <= q.gy0 + kGroup - 1);
+    touch[it] = __ballot(touches);
     R.x0[it] = x0; R.y0[it] = y0; R.x1[it] = x1; R.y1[it] = y1;
   }
-  uint32_t running = 0;
-#pragma unroll
-  for (int it = 0; it < kIter; ++it) {
-    const bool touches = (R.x1[it] >= R.x0[it]) && (R.y1[it] >= R.y0[it]) && (R.x1[it] >= q.gx0) &&
-                         (R.x0[it] <= q.gx0 + kGroup - 1) && (R.y1[it] >= q.gy0) &&
-                         (R.y0[it] <= q.gy0 + kGroup - 1);
-    unsigned long long m = __ballot(touches);
-    touch[it] = m;
-    while (m != 0ull) {
-      const int src = __ffsll((long long)m) - 1;
-      m &= (m - 1ull);
-      const int rx0 = rd_lane(R.x0[it], src), rx1 = rd_lane(R.x1[it], src);
-      const int ry0 = rd_lane(R.y0[it], src), ry1 = rd_lane(R.y1[it], src);
-      const bool hit = (q.tx >= rx0) && (q.tx <= rx1) && (q.ty >= ry0) && (q.ty <= ry1);
-      running += hit ? 1u : 0u;
-    }
-  }
-  s_cnt[wave][lane] = running;
-  __syncthreads();
   if (!EMIT) {
+    uint32_t running = 0;
+#pragma unroll
+    for (int it = 0; it < kIter; ++it) {
+      unsigned long long m = touch[it];
+      while (m != 0ull) {
+        const int src = __ffsll((long long)m) - 1;
+        m &= (m - 1ull);
+        const int rx0 = rd_lane(R.x0[it], src), rx1 = rd_lane(R.x1[it], src);
+        const int ry0 = rd_lane(R.y0[it], src), ry1 = rd_lane(R.y1[it], src);
+        const bool hit = (q.tx >= rx0) && (q.tx <= rx1) && (q.ty >= ry0) && (q.ty <= ry1);
+        running += hit ? 1u : 0u;
+      }
+    }
+    if (q.in_grid) wcnt[((size_t)chunk * kPullWaves + (size_t)wave) * T + q.tile] = running;
+    s_cnt[wave][lane] = running;
+    __syncthreads();
     if (wave == 0 && q.in_grid)
       cnt[(size_t)chunk * T + q.tile] = s_cnt[0][lane] + s_cnt[1][lane] + s_cnt[2][lane] + s_cnt[3][lane];
     return;
@@ -130,7 +137,7 @@ bin_pull_body(uint32_t N, const int *__restrict__ tl, const int *__restrict__ br
   uint32_t pos = 0;
   if (q.in_grid) {
     pos = tile_off[q.tile] + cnt[(size_t)chunk * T + q.tile];
-    for (int w = 0; w < wave; ++w) pos += s_cnt[w][lane];
+    for (int w = 0; w < wave; ++w) pos += wcnt[((size_t)chunk * kPullWaves + (size_t)w) * T + q.tile];
   }
 #pragma unroll
   for (int it = 0; it < kIter; ++it) {
@@ -435,15 +442,15 @@ template <bool EMIT>
 __global__ void __launch_bounds__(64 * kPullWaves)
 k_bin_pull(uint32_t N, const int *__restrict__ tl, const int *__restrict__ br,
            const float *__restrict__ depth, int ntw, int nth, uint32_t T,
-           uint32_t *__restrict__ cnt, const uint32_t *__restrict__ tile_off,
+           uint32_t *__restrict__ cnt, uint32_t *__restrict__ wcnt, const uint32_t *__restrict__ tile_off,
            const uint32_t *__restrict__ ctrl, unsigned long long *__restrict__ keys) {
-  bin_pull_body<EMIT>(N, tl, br, depth, ntw, nth, T, cnt, tile_off, ctrl, keys);
+  bin_pull_body<EMIT>(N, tl, br, depth, ntw, nth, T, cnt, wcnt, tile_off, ctrl, keys);
 }
 template <bool EMIT>
 __global__ void __launch_bounds__(64 * kPullWaves)
 k_bin_pull_views(uint32_t N, int ntw, int nth, uint32_t T, const GeoView *__restrict__ views) {
   const GeoView v = views[blockIdx.z];
-  bin_pull_body<EMIT>(N, v.tl, v.br, v.depth, ntw, nth, T, v.cnt, v.tile_off, v.ctrl, v.keys);
+  bin_pull_body<EMIT>(N, v.tl, v.br, v.depth, ntw, nth, T, v.cnt, v.wcnt, v.tile_off, v.ctrl, v.keys);
 }
 __global__ void __launch_bounds__(256)
 k_scan_chunks(uint32_t T, uint32_t nchunks, uint32_t *__restrict__ cnt, uint32_t *__restrict__ tile_count) {
@@ -515,7 +522,7 @@ __global__ void __launch_bounds__(64) k_selftest_reduce_scatter(const float *__r
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct BinWs {
-  uint32_t *tile_count, *tile_off, *ctrl, *cnt, *tile_order;
+  uint32_t *tile_count, *tile_off, *ctrl, *cnt, *wcnt, *tile_order;
   unsigned long long *keys;
   int *tl, *br;  // only in the frame workspace
   uint32_t nchunks;
@@ -533,6 +540,7 @@ static BinWs carve(void *base, uint32_t N, uint32_t D, uint32_t T, bool with_rec
   w.tile_off = (uint32_t *)take(sizeof(uint32_t) * ((size_t)T + 1));
   w.tile_order = (uint32_t *)take(sizeof(uint32_t) * (size_t)(T ? T : 1));
   w.cnt = (uint32_t *)take(sizeof(uint32_t) * (size_t)w.nchunks * T);
+  w.wcnt = (uint32_t *)take(sizeof(uint32_t) * (size_t)w.nchunks * kPullWaves * T);
   w.keys = (unsigned long long *)take(sizeof(unsigned long long) * (size_t)(D ? D : 1));
   if (with_rects) {
     w.tl = (int *)take(sizeof(int) * 2 * (size_t)(N ? N : 1));
@@ -553,7 +561,7 @@ static int bin_and_sort(uint32_t N, uint32_t cap, uint32_t nth, uint32_t ntw, co
     if (hipError_t e = hipMemsetAsync(w.cnt, 0, sizeof(uint32_t) * (size_t)w.nchunks * T, s)) return (int)e;
   } else {
     hipLaunchKernelGGL((k_bin_pull<false>), gpull, bpull, 0, s, N, tl, br, depth, (int)ntw, (int)nth, T,
-                       w.cnt, (const uint32_t *)nullptr, (const uint32_t *)nullptr,
+                       w.cnt, w.wcnt, (const uint32_t *)nullptr, (const uint32_t *)nullptr,
                        (unsigned long long *)nullptr);
   }
   hipLaunchKernelGGL(k_scan_chunks, dim3((T + 3) / 4), dim3(256), 0, s, T, w.nchunks,
@@ -562,7 +570,7 @@ static int bin_and_sort(uint32_t N, uint32_t cap, uint32_t nth, uint32_t ntw, co
   hipLaunchKernelGGL(k_order_tiles, dim3(1), dim3(1024), 0, s, T, w.tile_count, w.tile_order);
   if (N)
     hipLaunchKernelGGL((k_bin_pull<true>), gpull, bpull, 0, s, N, tl, br, depth, (int)ntw, (int)nth, T,
-                       w.cnt, w.tile_off, w.ctrl, w.keys);
+                       w.cnt, w.wcnt, w.tile_off, w.ctrl, w.keys);
   hipLaunchKernelGGL(k_sort_tiles, dim3(T), dim3(64), 0, s, T, w.tile_off, w.ctrl, w.keys, ids, start, end);
   hipLaunchKernelGGL(k_sort_tiles_big, dim3(T < kBigGrid ? T : kBigGrid), dim3(kSortThreads), 0, s, T, w.tile_off,
                      w.ctrl, w.keys, ids, (const uint32_t *)w.tile_order);
@@ -660,7 +668,7 @@ int gsgen_frame_geometry_batch(uint32_t n_views, const gsgen_geometry_view *view
     nchunks = w.nchunks;
     GeoView &g = gv[b];
     g.cam = v.cam; g.mean2d = v.mean2d; g.cov2d = v.cov2d; g.depth = v.depth; g.mask = v.mask;
-    g.tl = w.tl; g.br = w.br; g.cnt = w.cnt; g.tile_count = w.tile_count; g.tile_off = w.tile_off;
+    g.tl = w.tl; g.br = w.br; g.cnt = w.cnt; g.wcnt = w.wcnt; g.tile_count = w.tile_count; g.tile_off = w.tile_off;
     g.ctrl = w.ctrl; g.tile_order = w.tile_order; g.keys = w.keys;
     g.ids = v.gaussian_ids; g.start = v.start; g.end = v.end; g.total = v.total; g.cap = v.D_cap;
   }
