@@ -15,12 +15,19 @@ Every camera of the batch owns a FrameBuffers slot because its backward needs th
 projected records of its forward (22 + 12 B x D_cap per slot; 64 cameras at cfg2 ~ 2 GB of the
 288 GB).
 """
+import ctypes
+
 import numpy as np
 import torch
 
 from . import _capi
 from . import renderer as R
 from .renderer import _p
+
+
+def _tab(addresses):
+    """host array of device pointers for the *_batch entry points"""
+    return (ctypes.c_void_p * len(addresses))(*addresses)
 
 
 class _render_batch(torch.autograd.Function):
@@ -97,9 +104,9 @@ class _render_batch(torch.autograd.Function):
         with torch.cuda.device(dev):
             lib.frame_geometry_batch(B, geo, N, _p(mean), _p(qvec), _p(svec), W, H, _p(bws) + nb_sh, s)
             if stats is not None:
-                for i in range(B):
-                    buf = br.slots[i]
-                    lib.densify_update(N, _p(buf.cov2d), None, _p(buf.mask), _p(stats.max_radii2d), None, None, s)
+                lib.densify_update_batch(B, N, _tab([_p(br.slots[i].cov2d) for i in range(B)]), None,
+                                         _tab([_p(br.slots[i].mask) for i in range(B)]), _p(stats.max_radii2d), None,
+                                         None, s)
             lib.vol_render_sh_batch(B, views, N, _p(col), _p(alpha), 16, br.slots[0].nth, br.slots[0].ntw, H, W, C,
                                     thresh, br.segments, _p(bws), s)
         ctx.views, ctx.bws = views, bws
@@ -140,9 +147,9 @@ class _render_batch(torch.autograd.Function):
                                                  tab([g2d_p + 24 * N * i + 8 * N for i in range(B)]), None,
                                                  _p(g_mean), _p(g_qvec), _p(g_svec), s)
             if stats is not None:
-                for i in range(B):
-                    lib.densify_update(N, None, g2d_p + 24 * N * i, _p(br.slots[i].mask), None, _p(stats.grad_accum),
-                                       _p(stats.cnt), s)
+                lib.densify_update_batch(B, N, None, _tab([g2d_p + 24 * N * i for i in range(B)]),
+                                         _tab([_p(br.slots[i].mask) for i in range(B)]), None, _p(stats.grad_accum),
+                                         _p(stats.cnt), s)
         return (g_mean, g_qvec, g_svec, g_alpha, g_col) + (None,) * 8
 
     @staticmethod
@@ -225,9 +232,9 @@ class _render_batch_heads(torch.autograd.Function):
             with torch.cuda.device(dev):
                 lib.frame_geometry_batch(B, geo, N, _p(mean), _p(qvec), _p(svec), W, H, _p(bws) + nb_sh, s)
                 if stats is not None:
-                    for i in range(B):
-                        buf = br.slots[i]
-                        lib.densify_update(N, _p(buf.cov2d), None, _p(buf.mask), _p(stats.max_radii2d), None, None, s)
+                    lib.densify_update_batch(B, N, _tab([_p(br.slots[i].cov2d) for i in range(B)]), None,
+                                             _tab([_p(br.slots[i].mask) for i in range(B)]), _p(stats.max_radii2d),
+                                             None, None, s)
                 lib.vol_render_rgbd_batch(B, views, N, _p(col), _p(alpha), 16, br.slots[0].nth, br.slots[0].ntw, H, W,
                                           thresh, _p(bws), s)
             ctx.views, ctx.bws = views, bws
@@ -300,9 +307,9 @@ class _render_batch_heads(torch.autograd.Function):
                                                      tab([_p(gdp[i]) for i in range(B)]), _p(g_mean), _p(g_qvec),
                                                      _p(g_svec), s)
                 if stats is not None:
-                    for i in range(B):
-                        lib.densify_update(N, None, g2d_p + 24 * N * i, _p(br.slots[i].mask), None, _p(stats.grad_accum),
-                                           _p(stats.cnt), s)
+                    lib.densify_update_batch(B, N, None, _tab([g2d_p + 24 * N * i for i in range(B)]),
+                                             _tab([_p(br.slots[i].mask) for i in range(B)]), None,
+                                             _p(stats.grad_accum), _p(stats.cnt), s)
             return (g_mean, g_qvec, g_svec, g_alpha, gch[:, :, :3].sum(0)) + (None,) * 7
         cur = br._fork(B, (go6, g2d, gch, gdp, g3d))
         with torch.cuda.device(dev):

@@ -202,6 +202,49 @@ k_densify_update(uint32_t N, const float *__restrict__ cov2d, const float *__res
   }
 }
 
+// The same over the cameras of a batch in one launch: running maximum, gradient-norm sum and visit count of
+// a Gaussian are folded over the views in registers, then one atomic each (other batches may be updating the
+// same statistics from other streams).  Per-view pointers in the kernel arguments.
+constexpr int kStatViews = 16;
+struct DensifyViews {
+  const float *cov2d[kStatViews], *g_mean2d[kStatViews];
+  const uint8_t *mask[kStatViews];
+};
+__global__ void __launch_bounds__(kThreads)
+k_densify_update_views(uint32_t N, DensifyViews dv, int n_views, float *__restrict__ max_radii2d,
+                       float *__restrict__ grad_accum, float *__restrict__ cnt) {
+  const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float rmax = 0.0f, gsum = 0.0f, visits = 0.0f;
+  bool seen = false, rnan = false;
+  for (int v = 0; v < n_views; ++v) {
+    const uint8_t *m = dv.mask[v];
+    if (m != nullptr && m[n] == 0) continue;
+    seen = true;
+    if (max_radii2d != nullptr) {
+      const float4 c = *reinterpret_cast<const float4 *>(dv.cov2d[v] + 4 * (size_t)n);
+      const float mm = (c.x + c.w) / 2.0f;
+      const float det = c.x * c.w - c.y * c.z;
+      const float r = mm + sqrtf(fmaxf(mm * mm - det, 0.0f));
+      if (r != r) rnan = true;       // a NaN radius sticks, as torch.max does
+      else rmax = fmaxf(rmax, r);    // (negative radii never raise the maximum, as in the per-view kernel)
+    }
+    if (grad_accum != nullptr) {
+      const float2 g = *reinterpret_cast<const float2 *>(dv.g_mean2d[v] + 2 * (size_t)n);
+      gsum += sqrtf(g.x * g.x + g.y * g.y);
+      visits += 1.0f;
+    }
+  }
+  if (!seen) return;
+  if (max_radii2d != nullptr)
+    atomicMax(reinterpret_cast<unsigned int *>(max_radii2d) + n,
+              rnan ? 0x7fc00000u : __float_as_uint(rmax));
+  if (grad_accum != nullptr) {
+    atomicAdd(grad_accum + n, gsum);
+    if (cnt != nullptr) atomicAdd(cnt + n, visits);
+  }
+}
+
 // Backward of the projection as autograd differentiates gs/renderer.py:391-421: J is a
 // constant (@torch.no_grad), the depth in the perspective divide is detached iff
 // detach_depth.  ACC = false: gradients are overwritten (masked-out rows get zeros); ACC = true:
@@ -669,6 +712,29 @@ int gsgen_densify_update(uint32_t N, const float *cov2d, const float *grad_mean2
   if (cnt != nullptr && grad_accum == nullptr) return GSGEN_EINVAL;
   hipLaunchKernelGGL(k_densify_update, grid_for(N), dim3(kThreads), 0, (hipStream_t)stream, N, cov2d,
                      grad_mean2d, mask, max_radii2d, grad_accum, cnt);
+  return (int)hipGetLastError();
+}
+
+int gsgen_densify_update_batch(uint32_t n_views, uint32_t N, const float *const *cov2d,
+                               const float *const *grad_mean2d, const uint8_t *const *mask, float *max_radii2d,
+                               float *grad_accum, float *cnt, gsgen_stream_t stream) {
+  if (N == 0 || n_views == 0) return 0;
+  if ((cov2d == nullptr) != (max_radii2d == nullptr)) return GSGEN_EINVAL;
+  if ((grad_mean2d == nullptr) != (grad_accum == nullptr)) return GSGEN_EINVAL;
+  if (cnt != nullptr && grad_accum == nullptr) return GSGEN_EINVAL;
+  for (uint32_t v = 0; v < n_views; ++v)
+    if ((cov2d && !cov2d[v]) || (grad_mean2d && !grad_mean2d[v])) return GSGEN_EINVAL;
+  for (uint32_t v0 = 0; v0 < n_views; v0 += kStatViews) {
+    DensifyViews dv{};
+    const uint32_t nv = (n_views - v0) < (uint32_t)kStatViews ? (n_views - v0) : (uint32_t)kStatViews;
+    for (uint32_t i = 0; i < nv; ++i) {
+      dv.cov2d[i] = cov2d ? cov2d[v0 + i] : nullptr;
+      dv.g_mean2d[i] = grad_mean2d ? grad_mean2d[v0 + i] : nullptr;
+      dv.mask[i] = mask ? mask[v0 + i] : nullptr;
+    }
+    hipLaunchKernelGGL(k_densify_update_views, grid_for(N), dim3(kThreads), 0, (hipStream_t)stream, N, dv, (int)nv,
+                       max_radii2d, grad_accum, cnt);
+  }
   return (int)hipGetLastError();
 }
 

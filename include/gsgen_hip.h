@@ -181,6 +181,13 @@ int gsgen_adam_step(uint64_t n, float *param, const float *grad, float *exp_avg,
 int gsgen_densify_update(uint32_t N, const float *cov2d, const float *grad_mean2d,
                          const uint8_t *mask, float *max_radii2d, float *grad_accum, float *cnt,
                          gsgen_stream_t stream);
+/* The same for the cameras of a batch in ONE launch (maximum / sum / count folded over the views in
+ * registers, then one atomic each per Gaussian).  cov2d / grad_mean2d / mask: HOST arrays of n_views DEVICE
+ * pointers, read before the call returns; the NULL conventions of gsgen_densify_update apply to the arrays
+ * (mask may also be NULL per view). */
+int gsgen_densify_update_batch(uint32_t n_views, uint32_t N, const float *const *cov2d,
+                               const float *const *grad_mean2d, const uint8_t *const *mask, float *max_radii2d,
+                               float *grad_accum, float *cnt, gsgen_stream_t stream);
 /* AABB tile rectangles + pair count on the device (gs/culling.py:8-37 without the .item()
  * host sync): writes aabb_topleft/bottomright int32 [N,2] and *total (device uint32, zeroed
  * inside the call) = N_with_dub. */

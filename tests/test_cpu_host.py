@@ -429,6 +429,27 @@ def test_densify_statistics_oracle_vs_torch_and_emulated_kernel(emu):
     assert np.array_equal(e2[0], o2[0]) and np.array_equal(e2[1], o2[1]) and np.array_equal(e2[2], c0)
     with pytest.raises(Exception, match="invalid"):
         emu.densify_update(N, P(cov), None, None, None, None, None, None)
+    # the cameras of a batch in one launch == one oracle update per camera (19 views: two launches)
+    import ctypes
+    nv = 19
+    covs = [np.ascontiguousarray(cov * (0.5 + 0.1 * v), np.float32) for v in range(nv)]
+    gms = [np.ascontiguousarray(gm * (1 + v), np.float32) for v in range(nv)]
+    masks = [(rng.random(N) < 0.6).astype(np.uint8) if v != 2 else None for v in range(nv)]
+    ob = [r0.copy(), a0.copy(), c0.copy()]
+    for v in range(nv):
+        O.densify_update(covs[v], gms[v], masks[v], *ob)
+    tab = lambda arrs: (ctypes.c_void_p * nv)(*[P(a) for a in arrs])  # noqa: E731
+    eb = [r0.copy(), a0.copy(), c0.copy()]
+    emu.densify_update_batch(nv, N, tab(covs), tab(gms), tab(masks), P(eb[0]), P(eb[1]), P(eb[2]), None)
+    assert np.array_equal(eb[0], ob[0]) and np.array_equal(eb[2], ob[2])
+    assert np.abs(eb[1] - ob[1]).max() <= 2e-6 * np.abs(ob[1]).max()   # sum order
+    eb2 = [r0.copy(), a0.copy(), c0.copy()]
+    emu.densify_update_batch(nv, N, tab(covs), None, None, P(eb2[0]), None, None, None)   # radii only, no masks
+    emu.densify_update_batch(nv, N, None, tab(gms), tab(masks), None, P(eb2[1]), None, None)  # gradient sum without count
+    assert np.array_equal(eb2[2], c0) and np.abs(eb2[1] - ob[1]).max() <= 2e-6 * np.abs(ob[1]).max()
+    assert (eb2[0] >= eb[0]).all()
+    with pytest.raises(Exception, match="invalid"):
+        emu.densify_update_batch(nv, N, tab(covs), None, None, None, None, None, None)
 
 
 def test_emulated_projection_backward_overwrite_masked_and_accumulate(emu):

@@ -15,6 +15,7 @@ ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--streams", type=int, default=3)
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--warmup", type=int, default=5)
+ap.add_argument("--no-stats", action="store_true", help="without the densify statistics")
 ap.add_argument("--heads", action="store_true", help="RGB + depth + opacity + depth^2 (post-activation colours) instead of SH")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -28,7 +29,7 @@ cis = [R.CameraInfo(*c.intr) for c in cams]
 c2ws = [c.c2w for c in cams]
 br = BatchRenderer(a.n, a.res, a.res, dev, max_batch=a.batch, n_streams=a.streams)
 go = torch.randn(a.batch, a.res, a.res, 3, device=dev)
-stats = R.DensifyStats(a.n, dev)
+stats = None if a.no_stats else R.DensifyStats(a.n, dev)
 
 def step():
     for p in P.values():
