@@ -1024,20 +1024,27 @@ int launch_bwd_sh_batch(int C, const CompParams &p0_, const CompParams *plist, u
   return (int)hipGetLastError();
 }
 
-// fused RGB + heads, B cameras per launch (same defaults as the per-camera launches: 4 wavefronts per tile
-// forward, 1 backward)
+// fused RGB + heads, B cameras per launch (4 wavefronts per tile forward, 2 backward)
 int launch_fwd_rgbd_batch(const CompParams &p0_, const CompParams *plist, uint32_t B, hipStream_t s) {
   const uint32_t nblk = comp_grid(p0_);
   if (p0_.ntw * p0_.nth == 0 || B == 0) return 0;
   const CompParams p0 = batch_arg(p0_, B);
-  hipLaunchKernelGGL((k_composite_fwd<MODE_RGBD, 1, 1, true>), dim3(nblk * B), dim3(256), 0, s, p0, plist);
+  static const int ppl = env_ppl("GSGEN_PPL_FWD_BATCH", 1);
+  if (ppl == 1) hipLaunchKernelGGL((k_composite_fwd<MODE_RGBD, 1, 1, true>), dim3(nblk * B), dim3(256), 0, s, p0, plist);
+  else if (ppl == 2) hipLaunchKernelGGL((k_composite_fwd<MODE_RGBD, 1, 2, true>), dim3(nblk * B), dim3(128), 0, s, p0, plist);
+  else hipLaunchKernelGGL((k_composite_fwd<MODE_RGBD, 1, 4, true>), dim3(nblk * B), dim3(64), 0, s, p0, plist);
   return (int)hipGetLastError();
 }
 int launch_bwd_rgbd_batch(const CompParams &p0_, const CompParams *plist, uint32_t B, hipStream_t s) {
   const uint32_t nblk = comp_grid(p0_);
   if (p0_.ntw * p0_.nth == 0 || B == 0) return 0;
   const CompParams p0 = batch_arg(p0_, B);
-  hipLaunchKernelGGL((k_composite_bwd_pixel<MODE_RGBD, 1, 4, true>), dim3(nblk * B), dim3(64), 0, s, p0, plist);
+  // two wavefronts per tile: 6 087 / 3 588 views/s at 8 x 512^2 / 8 x 800^2 against 5 902 / 3 522 with one and
+  // 5 753 / 3 138 with four (tools/bench_batch.py --heads)
+  static const int ppl = env_ppl("GSGEN_PPL_BWD_BATCH", 2);
+  if (ppl == 1) hipLaunchKernelGGL((k_composite_bwd_pixel<MODE_RGBD, 1, 1, true>), dim3(nblk * B), dim3(256), 0, s, p0, plist);
+  else if (ppl == 2) hipLaunchKernelGGL((k_composite_bwd_pixel<MODE_RGBD, 1, 2, true>), dim3(nblk * B), dim3(128), 0, s, p0, plist);
+  else hipLaunchKernelGGL((k_composite_bwd_pixel<MODE_RGBD, 1, 4, true>), dim3(nblk * B), dim3(64), 0, s, p0, plist);
   return (int)hipGetLastError();
 }
 
