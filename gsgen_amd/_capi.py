@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-DEFAULT_LIB = os.path.join(_HERE, "lib", "libgsgen_hip.so")
+# GSGEN_HIP_LIB: another build of the same library (A/B experiments); default = the in-tree build
+DEFAULT_LIB = os.environ.get("GSGEN_HIP_LIB") or os.path.join(_HERE, "lib", "libgsgen_hip.so")
 
 u32, f32, vp, i32, sz = C.c_uint32, C.c_float, C.c_void_p, C.c_int, C.c_size_t
 

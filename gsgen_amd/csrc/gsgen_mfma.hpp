@@ -46,15 +46,30 @@ __device__ __forceinline__ u32x4 u32x4_zero() { return u32x4{0u, 0u, 0u, 0u}; }
 //   3. the accumulators are consumed by real vector instructions (mfma_drain) before anything else
 //      runs: a vector read of an MFMA result waits for it, MFMAs complete in order, so after the
 //      drain every source register of the chain is free to be reused.
+// The waits are software waits (s_nop: the hardware does not stall a vector read of a register an MFMA in flight
+// will still write, nor a write to one it still has to read).  Their length was first set for the steady
+// state (lgkmcnt(0) before, 16 wait states after): green for thousands of back-to-back launches, but the FIRST
+// launches of a process (and now and then the first after seconds of idling) came out wrong on some boxes --
+// all four gradient outputs off by 1e-5 .. 1e-2 of their maximum, only in the two-wavefronts-per-tile build,
+// SH degree 0 (tools/mfma_stress.py, profiles/r01_notes.md "first-launch hazard").  With the waits below
+// (everything outstanding retired + 32 wait states before the chain, 128 after it) 0 of the process starts
+// on the same box were affected; cost 3.8 % of cfg2 throughput.  GSGEN_MFMA_SHORT_WAITS builds the old lengths.
+#ifndef GSGEN_MFMA_SHORT_WAITS
+#define GSGEN_MFMA_PRE "s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15"
+#define GSGEN_MFMA_POST "s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\t"
+#else
+#define GSGEN_MFMA_PRE "s_waitcnt lgkmcnt(0)"
+#define GSGEN_MFMA_POST "s_nop 7\n\ts_nop 7\n\t"
+#endif
 __device__ __forceinline__ void mfma_operands_ready(u32x4 &a, u32x4 &b, u32x4 &c, u32x4 &d) {
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory");
+  asm volatile(GSGEN_MFMA_PRE : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory");
 }
 __device__ __forceinline__ void mfma_operands_ready(u32x4 &a, u32x4 &b) {
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b) : : "memory");
+  asm volatile(GSGEN_MFMA_PRE : "+v"(a), "+v"(b) : : "memory");
 }
 __device__ __forceinline__ void mfma_drain(f32x4 &a, f32x4 &b, f32x4 &c) {
   float a3 = a[3], b3 = b[3], c3 = c[3], sink;
-  asm volatile("s_nop 7\n\ts_nop 7\n\tv_or_b32 %0, %1, %2\n\tv_or_b32 %0, %0, %3"
+  asm volatile(GSGEN_MFMA_POST "v_or_b32 %0, %1, %2\n\tv_or_b32 %0, %0, %3"
                : "=v"(sink) : "v"(a3), "v"(b3), "v"(c3) : "memory");
   asm volatile("" : "+v"(a), "+v"(b), "+v"(c) : : "memory");
 }

@@ -175,8 +175,8 @@ def test_densify_statistics_over_two_cameras():
     assert want[2].max() == 2.0 and want[2].min() == 0.0
 
 
-@pytest.mark.parametrize("n_streams,C,fused", [(1, 3, 0), (3, 3, 0), (3, 0, 0), (3, 4, 1), (2, 2, 3)])
-def test_batched_cameras_match_one_at_a_time(n_streams, C, fused):
+@pytest.mark.parametrize("n_streams,C,fused,ncam", [(1, 3, 0, 5), (3, 3, 0, 5), (3, 0, 0, 5), (3, 4, 1, 5), (2, 2, 3, 5), (3, 4, 1, 11)])
+def test_batched_cameras_match_one_at_a_time(n_streams, C, fused, ncam):
     """BatchRenderer (cameras in flight on several streams) == a loop of render_frame:
     identical images, the gradient of the summed loss, and the same densify statistics."""
     from gsgen_amd import renderer as R
@@ -184,11 +184,11 @@ def test_batched_cameras_match_one_at_a_time(n_streams, C, fused):
     sc = scenes.random_scene(5000, seed=12, svec=0.03, C=max(C, 1))
     N = sc["mean"].shape[0]
     W, H = 176, 128
-    cams = [scenes.Camera(W, H, fx=150.0 + 10 * i, c2w=scenes.orbit(2.3 + 0.1 * i, 5 + 10 * i, 70.0 * i)) for i in range(5)]
+    cams = [scenes.Camera(W, H, fx=150.0 + 10 * i, c2w=scenes.orbit(2.3 + 0.1 * i, 5 + 10 * i, 70.0 * i)) for i in range(ncam)]
     cis = [R.CameraInfo(*c.intr) for c in cams]
     ck = "sh" if C > 0 else "color"
     keys = ("mean", "qvec", "svec", "alpha", ck)
-    gos = [torch.randn(H, W, 3, device=dev(), generator=torch.Generator(device=dev()).manual_seed(i)) for i in range(5)]
+    gos = [torch.randn(H, W, 3, device=dev(), generator=torch.Generator(device=dev()).manual_seed(i)) for i in range(ncam)]
     bg = torch.tensor([0.2, 0.4, 0.6], device=dev())
 
     Pa = {k: T_(sc[k]).requires_grad_(True) for k in keys}
@@ -205,18 +205,18 @@ def test_batched_cameras_match_one_at_a_time(n_streams, C, fused):
     sb = R.DensifyStats(N, dev())
     # fused: one compositing launch per batch and direction (gridDim.y = cameras); fused > 1: that many
     # backward segments per tile as well
-    br = BatchRenderer(N, W, H, dev(), max_batch=5, n_streams=n_streams, fused_launch=fused > 0, segments=max(fused, 1))
+    br = BatchRenderer(N, W, H, dev(), max_batch=ncam, n_streams=n_streams, fused_launch=fused > 0, segments=max(fused, 1))
     for _ in range(2):  # second pass: the slots and the pinned camera block are reused
         for k in keys:
             Pb[k].grad = None
         sb = R.DensifyStats(N, dev())
         rgb_b, T_b = br.render(Pb["mean"], Pb["qvec"], Pb["svec"], Pb["alpha"], Pb[ck], cis, [c.c2w for c in cams],
                                C=C, bg_rgb=bg, stats=sb)
-        assert br.ensure_capacity(5)
+        assert br.ensure_capacity(ncam)
         (rgb_b * torch.stack(gos, 0)).sum().backward()
         torch.cuda.synchronize()
-        assert rgb_b.shape == (5, H, W, 3) and T_b.shape == (5, H, W, 1)
-        for i in range(5):
+        assert rgb_b.shape == (ncam, H, W, 3) and T_b.shape == (ncam, H, W, 1)
+        for i in range(ncam):
             assert torch.equal(rgb_b[i].detach(), imgs[i])
         for k in keys:
             assert rel_err(Pb[k].grad.cpu().numpy(), Pa[k].grad.cpu().numpy()) < 1e-4, k

@@ -83,3 +83,22 @@ def test_sh_backward_unchanged_by_launches_in_flight(C):
     for _ in range(16):
         con = _backward_all(dev, lib, P, cams, C, N, W, H, streams)
         assert _worst(seq, con) < 5e-6
+
+
+def test_first_launches_of_a_fresh_process_agree():
+    """The residual form of the MFMA hazard (profiles/r01_notes.md, "first-launch hazard"): with the short software
+    waits the FIRST launches of a process came out wrong on some boxes while thousands of later ones agreed, so
+    a loop inside one process never saw it.  Three fresh processes, SH degree 0 (the build it showed on) and 3:
+    the first launch is the reference, the next 8 must agree with it."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    for _ in range(3):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "mfma_stress.py"), "8", "1", "4"], cwd=root,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("C=")]
+        assert len(lines) == 2, r.stdout
+        for ln in lines:
+            assert " bad 0/8 " in ln, ln

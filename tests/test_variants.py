@@ -35,6 +35,26 @@ def test_variant_on_emulator(variant):
                    "emulated_kernels_match_oracle and (4-33-20 or 3-48-32) or emulated_fused_rgb_heads"])
 
 
+# the batched launches (cameras of a batch in one launch) have their own switches: wavefronts per tile and the
+# order of the (camera, tile) blocks in the grid.  GPU only: the emulator runs the default of each in
+# tests/test_cpu_host.py, and one emulated batch costs ~30 s.
+BATCH_VARIANTS = [
+    {"GSGEN_BATCH_MAP": "0"},                                   # interleaved cameras
+    # interleaved + rotated; 2 wavefronts per tile forward (the per-camera launches the images are compared with bit
+    # for bit get the same split: different pixels-per-lane builds round a few pixels differently)
+    {"GSGEN_BATCH_MAP": "1", "GSGEN_PPL_FWD_BATCH": "2", "GSGEN_PPL_FWD": "2"},
+    {"GSGEN_BWD_MFMA_BATCH": "4", "GSGEN_PPL_BWD_BATCH": "4"},  # one wavefront per tile backward (SH / heads)
+    {"GSGEN_BWD_MFMA_BATCH": "1", "GSGEN_PPL_BWD_BATCH": "1", "GSGEN_PPL_FWD_BATCH": "4", "GSGEN_PPL_FWD": "4"},
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", BATCH_VARIANTS, ids=lambda v: ",".join(f"{k}={x}" for k, x in v.items()))
+def test_batch_variant_on_gpu(variant):
+    _run(variant, ["tests/test_gpu_api.py", "-m", "gpu", "-k",
+                   "batched_cameras_match_one_at_a_time and (3-4-1 or 2-2-3) or batched_fused_heads_match_oracle"])
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("variant", VARIANTS, ids=lambda v: ",".join(f"{k}={x}" for k, x in v.items()))
 def test_variant_on_gpu(variant):
