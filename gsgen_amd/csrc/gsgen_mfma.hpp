@@ -46,17 +46,18 @@ __device__ __forceinline__ u32x4 u32x4_zero() { return u32x4{0u, 0u, 0u, 0u}; }
 //   3. the accumulators are consumed by real vector instructions (mfma_drain) before anything else
 //      runs: a vector read of an MFMA result waits for it, MFMAs complete in order, so after the
 //      drain every source register of the chain is free to be reused.
-// The waits are software waits (s_nop: the hardware does not stall a vector read of a register an MFMA in flight
-// will still write, nor a write to one it still has to read).  Their length was first set for the steady
-// state (lgkmcnt(0) before, 16 wait states after): green for thousands of back-to-back launches, but the FIRST
-// launches of a process (and now and then the first after seconds of idling) came out wrong on some boxes --
-// all four gradient outputs off by 1e-5 .. 1e-2 of their maximum, only in the two-wavefronts-per-tile build,
-// SH degree 0 (tools/mfma_stress.py, profiles/r01_notes.md "first-launch hazard").  With the waits below
-// (everything outstanding retired + 32 wait states before the chain, 128 after it) 0 of the process starts
-// on the same box were affected; cost 3.8 % of cfg2 throughput.  GSGEN_MFMA_SHORT_WAITS builds the old lengths.
+// The waits are software waits (s_nop): nothing in the hardware stalls a vector read of a register an MFMA in
+// flight will still write, nor a write to one it still has to read.  Their length was first set for the steady
+// state (lgkmcnt(0) before the chain, 16 wait states after it): green for thousands of back-to-back launches, but
+// the FIRST launches of a process came out wrong on some boxes (20-100 % of process starts there; all four
+// gradient outputs off by 1e-5 .. 1e-2 of their maximum; only seen in the two-wavefronts-per-tile build at SH
+// degree 0) -- tools/mfma_stress.py, profiles/r01_notes.md "first-launch hazard".  Measured on such boxes, fresh
+// processes: short waits 3/8, 1/5, 3/3 starts wrong; 8 wait states before + 48 after 0/16; 32 + 128: 0/2.
+// Built with 16 before + 64 after (cfg2: -1 % against the short waits).  GSGEN_MFMA_SHORT_WAITS builds the old
+// lengths for such experiments.
 #ifndef GSGEN_MFMA_SHORT_WAITS
-#define GSGEN_MFMA_PRE "s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15"
-#define GSGEN_MFMA_POST "s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\t"
+#define GSGEN_MFMA_PRE "s_waitcnt lgkmcnt(0)\n\ts_nop 15"
+#define GSGEN_MFMA_POST "s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\t"
 #else
 #define GSGEN_MFMA_PRE "s_waitcnt lgkmcnt(0)"
 #define GSGEN_MFMA_POST "s_nop 7\n\ts_nop 7\n\t"
