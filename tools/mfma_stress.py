@@ -13,11 +13,32 @@ import test_gpu_stress as S
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 Cs = [int(c) for c in sys.argv[2:]] or [1, 2, 3, 4]
 N, W, H = 60_000, 800, 800
+NB = int(os.environ.get("STRESS_BATCH", "0"))  # > 0: that many cameras per launch through the batched entry point
 for C in Cs:
-    dev, lib, P, cams = S._setup(C, N, W, H, 1)
+    dev, lib, P, cams = S._setup(C, N, W, H, max(NB, 1))
     buf, out, topleft, rot, ci, go = cams[0]
+    if NB:
+        views = (_capi.ShView * NB)()
+        for v, (b_, o_, tl_, r_, ci_, go_) in zip(views, cams):
+            v.mean, v.cov, v.start, v.end, v.gaussian_ids = _p(b_.mean2d), _p(b_.cov2d), _p(b_.start), _p(b_.end), _p(b_.ids)
+            v.tile_order, v.topleft, v.c2w, v.bg_rgb = b_.tile_order(), _p(tl_), _p(r_), None
+            v.pixel_size_x, v.pixel_size_y, v.out, v.T, v.grad_out = 1 / ci_.fx, 1 / ci_.fy, _p(o_), None, _p(go_)
+        bws = torch.empty(lib.sh_batch_workspace_bytes(NB), device=dev, dtype=torch.uint8)
+
+    def run_batch():
+        per = 6 * N
+        g = torch.zeros(NB * per + N * (3 * C * C + 1), device=dev)
+        for i, v in enumerate(views):
+            v.grad_mean, v.grad_cov = _p(g) + 4 * per * i, _p(g) + 4 * per * i + 8 * N
+        gsh, ga = g[NB * per:NB * per + 3 * C * C * N], g[NB * per + 3 * C * C * N:]
+        lib.vol_render_backward_sh_batch(NB, views, N, _p(P["sh"]), _p(P["alpha"]), _p(gsh), _p(ga), 16, buf.nth, buf.ntw, H,
+                                         W, C, 1e-4, 0, _p(bws), None)
+        g2 = g[:NB * per].view(NB, per)
+        return [g2[:, :2 * N].contiguous(), g2[:, 2 * N:].contiguous(), gsh, ga]
 
     def run():
+        if NB:
+            return run_batch()
         g = torch.zeros(N * (2 + 4 + 3 * C * C + 1), device=dev)
         gm, gc, gsh, ga = g[:2 * N], g[2 * N:6 * N], g[6 * N:6 * N + 3 * C * C * N], g[6 * N + 3 * C * C * N:]
         lib.vol_render_backward_sh_ordered(N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(P["sh"]), _p(P["alpha"]),
