@@ -779,6 +779,7 @@ k_composite_bwd_sh_mfma(CompParams p_arg, const CompParams *__restrict__ plist) 
         acc1 = mfma_16x16x32_bf16(ah[s], Bl[s0 + s], acc1);
         acc2 = mfma_16x16x32_bf16(al[s], Bh[s0 + s], acc2);
       }
+      mfma_wait_chain<PPL>(ah[0], Bh[s0], acc0, acc1, acc2);  // no-op unless built with GSGEN_MFMA_POLL
       mfma_drain(acc0, acc1, acc2);
       __builtin_amdgcn_sched_barrier(0);
     }

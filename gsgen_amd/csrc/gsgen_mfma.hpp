@@ -46,21 +46,28 @@ __device__ __forceinline__ u32x4 u32x4_zero() { return u32x4{0u, 0u, 0u, 0u}; }
 //   3. the accumulators are consumed by real vector instructions (mfma_drain) before anything else
 //      runs: a vector read of an MFMA result waits for it, MFMAs complete in order, so after the
 //      drain every source register of the chain is free to be reused.
-// The waits are software waits (s_nop): nothing in the hardware stalls a vector read of a register an MFMA in
-// flight will still write, nor a write to one it still has to read.  Their length was first set for the steady
-// state (lgkmcnt(0) before the chain, 16 wait states after it): green for thousands of back-to-back launches, but
-// the FIRST launches of a process came out wrong on some boxes (20-100 % of process starts there; all four
-// gradient outputs off by 1e-5 .. 1e-2 of their maximum; only seen in the two-wavefronts-per-tile build at SH
-// degree 0) -- tools/mfma_stress.py, profiles/r01_notes.md "first-launch hazard".  Measured on such boxes, fresh
-// processes: short waits 3/8, 1/5, 3/3 starts wrong; 8 wait states before + 48 after 0/16; 32 + 128: 0/2.
-// Built with 16 before + 64 after (cfg2: -1 % against the short waits).  GSGEN_MFMA_SHORT_WAITS builds the old
-// lengths for such experiments.
-#ifndef GSGEN_MFMA_SHORT_WAITS
+// Rule 3 needs a wait for the chain, and nothing in the hardware provides one: a vector read of a register an MFMA
+// in flight will still write is not stalled, nor is a write to one it still has to read.  The first version
+// waited a fixed 16 wait states (s_nop), tuned in the steady state: green for thousands of back-to-back launches,
+// but the FIRST launches of a process came out wrong on some boxes (20-100 % of process starts there; all four
+// gradient outputs off by 1e-5 .. 1e-2 of their maximum; only caught in the two-wavefronts-per-tile build at SH
+// degree 0) -- tools/mfma_stress.py, profiles/r01_notes.md "first-launch hazard".  Fresh processes on such boxes,
+// wrong starts / starts: 16 wait states 3/3, 1/5, 3/8, 3/8; 8 before the chain + 48 after it 0/16; the
+// completion poll below 0/10.  Default build: the poll (mfma_wait_chain) -- it waits as long as the chain really
+// takes, whatever the clocks and the other wavefronts on the matrix core do -- at the cost of one extra MFMA per
+// chain and four registers (cfg2: same throughput as 16 + 64 fixed wait states, 1 % below the unsafe 16).
+// GSGEN_MFMA_FIXED_WAITS builds 16 + 64 fixed wait states instead, GSGEN_MFMA_SHORT_WAITS the original lengths
+// (the hazard detector of tools/mfma_stress.py experiments).
+#if defined(GSGEN_MFMA_SHORT_WAITS)
+#define GSGEN_MFMA_PRE "s_waitcnt lgkmcnt(0)"
+#define GSGEN_MFMA_POST "s_nop 7\n\ts_nop 7\n\t"
+#elif defined(GSGEN_MFMA_FIXED_WAITS)
 #define GSGEN_MFMA_PRE "s_waitcnt lgkmcnt(0)\n\ts_nop 15"
 #define GSGEN_MFMA_POST "s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\t"
 #else
-#define GSGEN_MFMA_PRE "s_waitcnt lgkmcnt(0)"
-#define GSGEN_MFMA_POST "s_nop 7\n\ts_nop 7\n\t"
+#define GSGEN_MFMA_POLL 1
+#define GSGEN_MFMA_PRE "s_waitcnt lgkmcnt(0)\n\ts_nop 15"
+#define GSGEN_MFMA_POST "s_nop 1\n\t"
 #endif
 __device__ __forceinline__ void mfma_operands_ready(u32x4 &a, u32x4 &b, u32x4 &c, u32x4 &d) {
   asm volatile(GSGEN_MFMA_PRE : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory");
@@ -68,6 +75,33 @@ __device__ __forceinline__ void mfma_operands_ready(u32x4 &a, u32x4 &b, u32x4 &c
 __device__ __forceinline__ void mfma_operands_ready(u32x4 &a, u32x4 &b) {
   asm volatile(GSGEN_MFMA_PRE : "+v"(a), "+v"(b) : : "memory");
 }
+#ifdef GSGEN_MFMA_POLL
+// The completion wait: one more MFMA is issued behind the chain into four registers this block owns, the last of
+// them preloaded with a pattern no product of bf16 values can produce (a NaN with a payload below bf16's
+// mantissa); MFMAs complete in order, so when that register changes the whole chain has read its operands and
+// written its results.  The four registers are chosen per kernel variant (pixels per lane) so that the kernel's
+// register count, hence its occupancy, stays what it was.
+#define GSGEN_MFMA_PROBE_ASM(R0, R1, R2, R3)                                                  \
+  asm volatile("v_mov_b32 v" R3 ", 0xffffdead\n\t"                                            \
+               "s_nop 4\n\t"                                                                  \
+               "v_mfma_f32_16x16x32_bf16 v[" R0 ":" R3 "], %3, %4, 0\n"                        \
+               ".Lgsgen_poll%=:\n\t"                                                          \
+               "s_nop 7\n\t"                                                                  \
+               "v_cmp_eq_u32_e32 vcc, 0xffffdead, v" R3 "\n\t"                                 \
+               "s_cbranch_vccnz .Lgsgen_poll%=\n\t"                                           \
+               "s_nop 1"                                                                       \
+               : "+v"(c0), "+v"(c1), "+v"(c2) : "v"(pa), "v"(pb) : "v" R0, "v" R1, "v" R2, "v" R3, "vcc", "memory")
+// c0..c2: the chain's accumulators -- only named so that the block is ordered behind the MFMAs producing them
+template <int PPL>
+__device__ __forceinline__ void mfma_wait_chain(const u32x4 &pa, const u32x4 &pb, f32x4 &c0, f32x4 &c1, f32x4 &c2) {
+  if constexpr (PPL == 4) GSGEN_MFMA_PROBE_ASM("252", "253", "254", "255");
+  else if constexpr (PPL == 2) GSGEN_MFMA_PROBE_ASM("160", "161", "162", "163");
+  else GSGEN_MFMA_PROBE_ASM("124", "125", "126", "127");
+}
+#else
+template <int PPL>
+__device__ __forceinline__ void mfma_wait_chain(const u32x4 &, const u32x4 &, f32x4 &, f32x4 &, f32x4 &) {}
+#endif
 __device__ __forceinline__ void mfma_drain(f32x4 &a, f32x4 &b, f32x4 &c) {
   float a3 = a[3], b3 = b[3], c3 = c[3], sink;
   asm volatile(GSGEN_MFMA_POST "v_or_b32 %0, %1, %2\n\tv_or_b32 %0, %0, %3"

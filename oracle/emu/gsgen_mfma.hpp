@@ -61,6 +61,8 @@ inline void wave_lds_sync() { (void)simt::shfl_idx(0, 0); }
 inline void mfma_operands_ready(uint4 &, uint4 &, uint4 &, uint4 &) {}
 inline void mfma_operands_ready(uint4 &, uint4 &) {}
 inline void mfma_drain(f32x4 &, f32x4 &, f32x4 &) {}
+template <int PPL>
+inline void mfma_wait_chain(const uint4 &, const uint4 &, f32x4 &, f32x4 &, f32x4 &) {}
 inline float opaque(float v) { return v; }
 
 }  // namespace gs
