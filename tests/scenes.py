@@ -6,7 +6,8 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-from oracle import oracle as O  # noqa: E402
+# The scene / camera generators are also used by bench.py and the tools for their workloads: the oracle is
+# imported only inside oracle_geometry (the checker), never by merely building a scene.
 
 
 def look_at(pos, at=(0.0, 0.0, 0.0), up=(0.0, 0.0, 1.0)):
@@ -107,6 +108,7 @@ def densified_scene(N, seed=0, C=4):
 def oracle_geometry(scene, cam, frustum_radius=6.0, tile_radius=6.0):
     """cull -> (gather) -> project -> aabb -> bin/sort through the oracle, on the COMPACTED
     (post-mask) Gaussians exactly as gs/gaussian_splatting.py:1208-1295 does."""
+    from oracle import oracle as O
     normals, pts = O.frustum(cam.c2w, *cam.intr)
     if frustum_radius > 0:
         mask = O.cull_bsphere(scene["mean"], scene["svec"], normals, pts, frustum_radius)

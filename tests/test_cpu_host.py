@@ -49,6 +49,21 @@ def test_one_hip_runtime_per_process_whatever_the_import_order():
     assert r.stdout.split()[0] == "1", r.stdout
 
 
+def test_product_and_bench_workloads_never_import_the_oracle():
+    """oracle/ is the checker: importing the whole package, the `_gs` shim and bench.py's workload builders must
+    not pull it in (bench.py only imports it inside its cpu_baseline leg)."""
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import gsgen_amd, gsgen_amd._capi, gsgen_amd._gs, gsgen_amd.renderer, gsgen_amd.batch, gsgen_amd.dist\n"
+            "import gsgen_amd.optim, gsgen_amd.io, gsgen_amd.build\n"
+            "import bench\n"
+            "sc, W, H = bench.make_workload('cfg1'); cams = bench.camera_poses(2, 0, W, H)\n"
+            "bad = sorted(m for m in sys.modules if m == 'oracle' or m.startswith('oracle.'))\n"
+            "print(bad)\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd="/")
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.strip() == "[]", r.stdout
+
+
 def test_gs_mirror_has_the_23_reference_names():
     from gsgen_amd import _gs
     names = """culling_gaussian_bsphere count_num_gaussians_each_tile count_num_gaussians_each_tile_bcircle
