@@ -118,8 +118,8 @@ def cpu_baseline(sc, cams, C, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=400)   # 50 batched launches: the pipeline's fill / drain is < 2 % of it
+    ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--config", default="cfg2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="also time every stage separately")
