@@ -48,6 +48,11 @@ BATCH_VARIANTS = [
 ]
 
 
+def test_batch_block_order_variant_on_emulator():
+    # the rotated interleaving exercises every branch of batch_view(); one emulated batch, ~25 s
+    _run({"GSGEN_BATCH_MAP": "1"}, ["tests/test_cpu_host.py", "-k", "emulated_batched_views_match_per_view_launches and 4-0"])
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("variant", BATCH_VARIANTS, ids=lambda v: ",".join(f"{k}={x}" for k, x in v.items()))
 def test_batch_variant_on_gpu(variant):
