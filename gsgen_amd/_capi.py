@@ -83,6 +83,9 @@ SIGNATURES = {
     "gsgen_vol_render_rgbd_batch": [u32, C.POINTER(RgbdView), u32, vp, vp, u32, u32, u32, u32, u32, f32, vp, vp],
     "gsgen_vol_render_rgbd_backward_batch": [u32, C.POINTER(RgbdView), u32, vp, vp, vp, u32, u32, u32, u32, u32, f32, vp,
                                              vp],
+    "gsgen_vol_render_rgb_batch": [u32, C.POINTER(RgbdView), u32, vp, vp, u32, u32, u32, u32, u32, f32, vp, vp],
+    "gsgen_vol_render_rgb_backward_batch": [u32, C.POINTER(RgbdView), u32, vp, vp, vp, vp, u32, u32, u32, u32, u32, f32,
+                                            vp, vp],
     "gsgen_legacy_count_tiles": [u32, u32, vp, vp, vp, u32, u32, u32, f32, f32, f32, vp, vp],
     "gsgen_legacy_image_sort": [u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, u32, f32, f32, f32, vp, sz, vp],
     "gsgen_frame_geometry_batch": [u32, C.POINTER(GeometryView), u32, vp, vp, vp, u32, u32, vp, vp],

@@ -41,7 +41,7 @@ class _render_batch(torch.autograd.Function):
         H, W, N, dev = br.H, br.W, br.N, mean.device
         out = torch.zeros(B, H, W, 3, device=dev, dtype=torch.float32)
         T = torch.ones(B, H, W, 1, device=dev, dtype=torch.float32)
-        fused = br.fused_launch and C > 0 and B > 0
+        fused = br.fused_launch and B > 0
         cams_p, out_p, T_p = cams.data_ptr(), out.data_ptr(), T.data_ptr()
         if fused:
             return _render_batch._forward_fused(ctx, mean, qvec, svec, alpha, col, cams, br, B, C, bg_rgb, thresh,
@@ -86,7 +86,7 @@ class _render_batch(torch.autograd.Function):
         cams_p, out_p, T_p = cams.data_ptr(), out.data_ptr(), T.data_ptr()
         s = torch.cuda.current_stream(dev).cuda_stream
         geo = (_capi.GeometryView * B)()
-        views = (_capi.ShView * B)()
+        views = ((_capi.ShView if C > 0 else _capi.RgbdView) * B)()  # C == 0: post-activation colours
         for i in range(B):
             buf, ci, g, v = br.slots[i], br._cis[i], geo[i], views[i]
             cam = cams_p + 272 * i  # row i: cam block | topleft at +56 floats | rotation at +58
@@ -94,10 +94,14 @@ class _render_batch(torch.autograd.Function):
             g.gaussian_ids, g.start, g.end, g.total = _p(buf.ids), _p(buf.start), _p(buf.end), _p(buf.total)
             g.workspace, g.workspace_bytes, g.D_cap = _p(buf.ws), buf.ws.numel(), buf.D_cap
             v.mean, v.cov, v.start, v.end, v.gaussian_ids = _p(buf.mean2d), _p(buf.cov2d), _p(buf.start), _p(buf.end), _p(buf.ids)
-            v.tile_order, v.topleft, v.c2w, v.bg_rgb = buf.tile_order(), cam + 224, cam + 232, _p(bg_rgb)
+            v.tile_order, v.topleft = buf.tile_order(), cam + 224
             v.pixel_size_x, v.pixel_size_y = 1.0 / ci.fx, 1.0 / ci.fy
-            v.out, v.T = out_p + 12 * H * W * i, T_p + 4 * H * W * i
-            v.segment_workspace = _p(buf.seg_ws) if br.segments > 1 else None
+            v.T = T_p + 4 * H * W * i
+            if C > 0:
+                v.c2w, v.bg_rgb, v.out = cam + 232, _p(bg_rgb), out_p + 12 * H * W * i
+                v.segment_workspace = _p(buf.seg_ws) if br.segments > 1 else None
+            else:
+                v.out6 = out_p + 12 * H * W * i  # read as [H,W,3] by the RGB entry points
         # parameter tables of the batch: compositing (forward | backward) | geometry
         nb_sh = lib.sh_batch_workspace_bytes(B)
         bws = torch.empty(nb_sh + lib.frame_batch_workspace_bytes(B), device=dev, dtype=torch.uint8)
@@ -107,8 +111,16 @@ class _render_batch(torch.autograd.Function):
                 lib.densify_update_batch(B, N, _tab([_p(br.slots[i].cov2d) for i in range(B)]), None,
                                          _tab([_p(br.slots[i].mask) for i in range(B)]), _p(stats.max_radii2d), None,
                                          None, s)
-            lib.vol_render_sh_batch(B, views, N, _p(col), _p(alpha), 16, br.slots[0].nth, br.slots[0].ntw, H, W, C,
-                                    thresh, br.segments, _p(bws), s)
+            if C > 0:
+                lib.vol_render_sh_batch(B, views, N, _p(col), _p(alpha), 16, br.slots[0].nth, br.slots[0].ntw, H, W, C,
+                                        thresh, br.segments, _p(bws), s)
+            else:
+                lib.vol_render_rgb_batch(B, views, N, _p(col), _p(alpha), 16, br.slots[0].nth, br.slots[0].ntw, H, W,
+                                         thresh, _p(bws), s)
+        if C == 0 and bg_rgb is not None:
+            out = out + T * bg_rgb  # gs/renderer.py:1182; `out` (saved below) is what the backward reads as final
+            for i in range(B):
+                views[i].out6 = out.data_ptr() + 12 * H * W * i
         ctx.views, ctx.bws = views, bws
         ctx.save_for_backward(mean, qvec, svec, alpha, col, cams, out)
         ctx.br, ctx.B, ctx.C, ctx.thresh, ctx.detach, ctx.stats = br, B, C, thresh, detach_depth, stats
@@ -133,14 +145,21 @@ class _render_batch(torch.autograd.Function):
         s = torch.cuda.current_stream(dev).cuda_stream
         for i in range(B):
             v = ctx.views[i]
-            v.grad_out = grad_p + 12 * H * W * i
+            if C > 0:
+                v.grad_out = grad_p + 12 * H * W * i
+            else:
+                v.grad_out6 = grad_p + 12 * H * W * i
             v.grad_mean = g2d_p + 24 * N * i
             v.grad_cov = g2d_p + 24 * N * i + 8 * N
         tab = lambda vals: (ctypes.c_void_p * B)(*vals)  # noqa: E731
         with torch.cuda.device(dev):
-            lib.vol_render_backward_sh_batch(B, ctx.views, N, _p(col), _p(alpha), _p(g_col), _p(g_alpha), 16,
-                                             br.slots[0].nth, br.slots[0].ntw, H, W, C, thresh, br.segments,
-                                             _p(ctx.bws), s)
+            if C > 0:
+                lib.vol_render_backward_sh_batch(B, ctx.views, N, _p(col), _p(alpha), _p(g_col), _p(g_alpha), 16,
+                                                 br.slots[0].nth, br.slots[0].ntw, H, W, C, thresh, br.segments,
+                                                 _p(ctx.bws), s)
+            else:
+                lib.vol_render_rgb_backward_batch(B, ctx.views, N, _p(col), _p(alpha), _p(g_col), _p(g_alpha), 16,
+                                                  br.slots[0].nth, br.slots[0].ntw, H, W, thresh, _p(ctx.bws), s)
             lib.project_gaussians_backward_batch(B, N, _p(mean), _p(qvec), _p(svec), tab([cams_p + 272 * i for i in range(B)]),
                                                  int(ctx.detach), tab([_p(br.slots[i].mask) for i in range(B)]),
                                                  tab([g2d_p + 24 * N * i for i in range(B)]),
@@ -344,8 +363,8 @@ class BatchRenderer:
         forward, compositing backward and projection backward each launch once for all cameras
         (gsgen_frame_geometry_batch, gsgen_vol_render_sh_batch, ..._backward_sh_batch,
         gsgen_project_gaussians_backward_batch) -- instead of one chain per camera spread over
-        `n_streams` side streams (post-activation colours, C = 0, still do); render_heads likewise
-        (gsgen_vol_render_rgbd_batch / _backward_batch).
+        `n_streams` side streams; post-activation colours (C = 0: gsgen_vol_render_rgb_batch) and render_heads
+        (gsgen_vol_render_rgbd_batch / _backward_batch) likewise.
         cfg2: 2850 vs 2710 renders/s (profiles/r01_notes.md).  segments: backward workgroups per tile
         (FrameBuffers), fused launches only."""
         self.N, self.W, self.H, self.device = N, W, H, torch.device(device)

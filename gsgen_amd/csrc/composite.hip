@@ -1049,6 +1049,24 @@ int launch_bwd_rgbd_batch(const CompParams &p0_, const CompParams *plist, uint32
   return (int)hipGetLastError();
 }
 
+// post-activation RGB (C = 0), B cameras per launch
+int launch_fwd_rgb_batch(const CompParams &p0_, const CompParams *plist, uint32_t B, hipStream_t s) {
+  const uint32_t nblk = comp_grid(p0_);
+  if (p0_.ntw * p0_.nth == 0 || B == 0) return 0;
+  const CompParams p0 = batch_arg(p0_, B);
+  hipLaunchKernelGGL((k_composite_fwd<MODE_RGB, 1, 1, true>), dim3(nblk * B), dim3(256), 0, s, p0, plist);
+  return (int)hipGetLastError();
+}
+int launch_bwd_rgb_batch(const CompParams &p0_, const CompParams *plist, uint32_t B, hipStream_t s) {
+  const uint32_t nblk = comp_grid(p0_);
+  if (p0_.ntw * p0_.nth == 0 || B == 0) return 0;
+  const CompParams p0 = batch_arg(p0_, B);
+  static const int ppl = env_ppl("GSGEN_PPL_BWD_BATCH", 2);
+  if (ppl == 4) hipLaunchKernelGGL((k_composite_bwd_pixel<MODE_RGB, 1, 4, true>), dim3(nblk * B), dim3(64), 0, s, p0, plist);
+  else hipLaunchKernelGGL((k_composite_bwd_pixel<MODE_RGB, 1, 2, true>), dim3(nblk * B), dim3(128), 0, s, p0, plist);
+  return (int)hipGetLastError();
+}
+
 int launch_bwd_pixel_dispatch(int mode, int C, const CompParams &p, hipStream_t s) {
   if (mode == MODE_RGB) return launch_bwd<MODE_RGB, 1>(p, s);
   if (mode == MODE_SCALAR) return launch_bwd<MODE_SCALAR, 1>(p, s);
@@ -1252,13 +1270,14 @@ int gsgen_vol_render_backward_sh_batch(uint32_t n_views, const gsgen_sh_view *vi
 
 static int fill_rgbd_params(uint32_t n_views, const gsgen_rgbd_view *views, const float *color, const float *alpha,
                             float *g_alpha, uint32_t ntw, uint32_t nth, uint32_t H, uint32_t W, float thresh,
-                            bool backward, std::vector<CompParams> &ps) {
+                            bool backward, std::vector<CompParams> &ps, bool heads = true,
+                            float *g_color = nullptr) {
   ps.assign(n_views, CompParams{});
   for (uint32_t b = 0; b < n_views; ++b) {
     const gsgen_rgbd_view &v = views[b];
-    if (!v.start || !v.end || !v.out6 || !v.depth) return GSGEN_EINVAL;
+    if (!v.start || !v.end || !v.out6 || (heads && !v.depth)) return GSGEN_EINVAL;
     if ((v.tile_order == nullptr) != (views[0].tile_order == nullptr)) return GSGEN_EINVAL;
-    if (backward && (!v.grad_out6 || !v.grad_mean || !v.grad_cov || !v.grad_chan6)) return GSGEN_EINVAL;
+    if (backward && (!v.grad_out6 || !v.grad_mean || !v.grad_cov || (heads && !v.grad_chan6))) return GSGEN_EINVAL;
     CompParams &p = ps[b];
     p.mean = v.mean; p.cov = v.cov; p.col = color; p.depth = v.depth; p.alpha = alpha;
     p.start = v.start; p.end = v.end; p.ids = v.gaussian_ids; p.topleft = v.topleft;
@@ -1268,7 +1287,7 @@ static int fill_rgbd_params(uint32_t n_views, const gsgen_rgbd_view *views, cons
     p.n_hi = 0x7fffffff;
     if (backward) {
       p.final_img = v.out6; p.grad_out = v.grad_out6;
-      p.g_mean = v.grad_mean; p.g_cov = v.grad_cov; p.g_col = v.grad_chan6; p.g_alpha = g_alpha;
+      p.g_mean = v.grad_mean; p.g_cov = v.grad_cov; p.g_col = heads ? v.grad_chan6 : g_color; p.g_alpha = g_alpha;
     } else {
       p.out = v.out6; p.T = v.T;
     }
@@ -1308,6 +1327,42 @@ int gsgen_vol_render_rgbd_backward_batch(uint32_t n_views, const gsgen_rgbd_view
   CompParams *dst = reinterpret_cast<CompParams *>(batch_workspace) + n_views;
   if (int e = write_params(ps.data(), n_views, dst, s)) return e;
   return launch_bwd_rgbd_batch(ps[0], dst, n_views, s);
+}
+
+int gsgen_vol_render_rgb_batch(uint32_t n_views, const gsgen_rgbd_view *views, uint32_t N, const float *color,
+                               const float *alpha, uint32_t tile_size, uint32_t n_tiles_h, uint32_t n_tiles_w,
+                               uint32_t H, uint32_t W, float thresh, void *batch_workspace, gsgen_stream_t stream) {
+  if (tile_size != 16) return GSGEN_EUNSUPPORTED;
+  if (n_views == 0 || N == 0) return 0;
+  if (!views || !batch_workspace) return GSGEN_EINVAL;
+  if (n_views > 65535) return GSGEN_EINVAL;
+  std::vector<CompParams> ps;
+  if (int e = fill_rgbd_params(n_views, views, color, alpha, nullptr, n_tiles_w, n_tiles_h, H, W, thresh, false, ps,
+                               false))
+    return e;
+  hipStream_t s = (hipStream_t)stream;
+  CompParams *dst = reinterpret_cast<CompParams *>(batch_workspace);
+  if (int e = write_params(ps.data(), n_views, dst, s)) return e;
+  return launch_fwd_rgb_batch(ps[0], dst, n_views, s);
+}
+
+int gsgen_vol_render_rgb_backward_batch(uint32_t n_views, const gsgen_rgbd_view *views, uint32_t N,
+                                        const float *color, const float *alpha, float *grad_color,
+                                        float *grad_alpha, uint32_t tile_size, uint32_t n_tiles_h,
+                                        uint32_t n_tiles_w, uint32_t H, uint32_t W, float thresh,
+                                        void *batch_workspace, gsgen_stream_t stream) {
+  if (tile_size != 16) return GSGEN_EUNSUPPORTED;
+  if (n_views == 0 || N == 0) return 0;
+  if (!views || !batch_workspace || !grad_alpha || !grad_color) return GSGEN_EINVAL;
+  if (n_views > 65535) return GSGEN_EINVAL;
+  std::vector<CompParams> ps;
+  if (int e = fill_rgbd_params(n_views, views, color, alpha, grad_alpha, n_tiles_w, n_tiles_h, H, W, thresh, true, ps,
+                               false, grad_color))
+    return e;
+  hipStream_t s = (hipStream_t)stream;
+  CompParams *dst = reinterpret_cast<CompParams *>(batch_workspace) + n_views;
+  if (int e = write_params(ps.data(), n_views, dst, s)) return e;
+  return launch_bwd_rgb_batch(ps[0], dst, n_views, s);
 }
 
 int gsgen_vol_render_sh(uint32_t N, uint32_t D, const float *mean, const float *cov,

@@ -390,6 +390,17 @@ int gsgen_vol_render_rgbd_backward_batch(uint32_t n_views, const gsgen_rgbd_view
                                          const float *color, const float *alpha, float *grad_alpha,
                                          uint32_t tile_size, uint32_t n_tiles_h, uint32_t n_tiles_w, uint32_t H,
                                          uint32_t W, float thresh, void *batch_workspace, gsgen_stream_t stream);
+/* Post-activation RGB only (gsgen_vol_render_start_end_with_T / gsgen_vol_render_backward_start_end for the
+ * cameras of a batch): the same view array with out6 / grad_out6 read as [H,W,3] images, depth and grad_chan6
+ * unused (may be NULL); the colour gradient [N,3] is shared and accumulates over the views like grad_alpha. */
+int gsgen_vol_render_rgb_batch(uint32_t n_views, const gsgen_rgbd_view *views, uint32_t N, const float *color,
+                               const float *alpha, uint32_t tile_size, uint32_t n_tiles_h, uint32_t n_tiles_w,
+                               uint32_t H, uint32_t W, float thresh, void *batch_workspace, gsgen_stream_t stream);
+int gsgen_vol_render_rgb_backward_batch(uint32_t n_views, const gsgen_rgbd_view *views, uint32_t N,
+                                        const float *color, const float *alpha, float *grad_color,
+                                        float *grad_alpha, uint32_t tile_size, uint32_t n_tiles_h,
+                                        uint32_t n_tiles_w, uint32_t H, uint32_t W, float thresh,
+                                        void *batch_workspace, gsgen_stream_t stream);
 
 /* Self test of the wave64 cross-lane reduce-scatter used by the backward (tests only):
  * in [64 lanes, P components]; out[0..64) = per-lane result, out[64..128) = the component index that

@@ -400,6 +400,62 @@ def test_emulated_batched_rgb_heads_match_per_view_launches(emu):
         emu.vol_render_rgbd_batch(len(views), arr, Nall, P(col), P(al), 16, nth, ntw, H, W, 1e-4, P(bws), None)
 
 
+def test_emulated_batched_rgb_matches_per_view_launches(emu):
+    """gsgen_vol_render_rgb_batch / _backward_batch (post-activation colours, no heads) == one
+    gsgen_vol_render_start_end_with_T / gsgen_vol_render_backward_start_end call per view, colour and opacity
+    gradients accumulated over the views"""
+    from gsgen_amd._capi import RgbdView
+    W, H = 48, 32
+    sc = scenes.random_scene(400, seed=47, svec=0.07)
+    Nall = sc["mean"].shape[0]
+    col, al = np.ascontiguousarray(sc["color"]), np.ascontiguousarray(sc["alpha"])
+    cams = [scenes.Camera(W, H, fx=44.0, c2w=scenes.look_at(e)) for e in ((2.5, 0, 0), (0.3, 2.4, 0.6))]
+    nth, ntw = cams[0].tiles
+    views = []
+    for i, cam in enumerate(cams):
+        g = scenes.oracle_geometry(sc, cam)
+        nz = np.nonzero(g["mask"])[0]
+        m2 = np.zeros((Nall, 2), np.float32); c2 = np.zeros((Nall, 2, 2), np.float32)
+        m2[nz] = g["mean2d"]; c2[nz] = g["cov2d"]
+        views.append(dict(m2=m2, c2=c2, st=g["start"], en=g["end"], ids=nz[g["ids"]].astype(np.int32), tlp=cam.topleft,
+                          cam=cam, D=g["D"], go=np.random.default_rng(i).normal(size=(H, W, 3)).astype(np.float32)))
+    ref_gcol = np.zeros((Nall, 3), np.float32); ref_ga = np.zeros(Nall, np.float32)
+    for v in views:
+        cam = v["cam"]
+        geo = (16, nth, ntw, 1 / cam.fx, 1 / cam.fy, H, W, 1e-4)
+        v["out_ref"] = np.zeros((H, W, 3), np.float32); v["T_ref"] = np.ones((H, W), np.float32)
+        emu.vol_render_start_end_with_T(Nall, v["D"], P(v["m2"]), P(v["c2"]), P(col), P(al), P(v["st"]), P(v["en"]), P(v["ids"]),
+                                        P(v["out_ref"]), P(v["tlp"]), *geo, P(v["T_ref"]), None)
+        v["gm_ref"] = np.zeros((Nall, 2), np.float32); v["gc_ref"] = np.zeros((Nall, 4), np.float32)
+        emu.vol_render_backward_start_end(Nall, v["D"], P(v["m2"]), P(v["c2"]), P(col), P(al), P(v["st"]), P(v["en"]),
+                                          P(v["ids"]), P(v["out_ref"]), P(v["gm_ref"]), P(v["gc_ref"]), P(ref_gcol), P(ref_ga),
+                                          P(v["go"]), P(v["tlp"]), *geo, None)
+    arr = (RgbdView * len(views))()
+    for a, v in zip(arr, views):
+        cam = v["cam"]
+        v["out"] = np.zeros((H, W, 3), np.float32); v["T"] = np.ones((H, W), np.float32)
+        v["gm"] = np.zeros((Nall, 2), np.float32); v["gc"] = np.zeros((Nall, 4), np.float32)
+        a.mean, a.cov, a.depth, a.start, a.end, a.gaussian_ids = P(v["m2"]), P(v["c2"]), None, P(v["st"]), P(v["en"]), P(v["ids"])
+        a.tile_order, a.topleft, a.pixel_size_x, a.pixel_size_y = None, P(v["tlp"]), 1 / cam.fx, 1 / cam.fy
+        a.out6, a.T, a.grad_out6 = P(v["out"]), P(v["T"]), P(v["go"])
+        a.grad_mean, a.grad_cov, a.grad_chan6 = P(v["gm"]), P(v["gc"]), None
+    bws = np.zeros(emu.sh_batch_workspace_bytes(len(views)), np.uint8)
+    emu.vol_render_rgb_batch(len(views), arr, Nall, P(col), P(al), 16, nth, ntw, H, W, 1e-4, P(bws), None)
+    gcol = np.zeros((Nall, 3), np.float32); ga = np.zeros(Nall, np.float32)
+    emu.vol_render_rgb_backward_batch(len(views), arr, Nall, P(col), P(al), P(gcol), P(ga), 16, nth, ntw, H, W, 1e-4,
+                                      P(bws), None)
+    for v in views:
+        assert np.array_equal(v["out"], v["out_ref"]) and np.array_equal(v["T"], v["T_ref"])
+        assert np.abs(v["out"]).max() > 0.1
+        for k in ("gm", "gc"):
+            assert np.abs(v[k] - v[k + "_ref"]).max() <= 2e-6 * np.abs(v[k + "_ref"]).max(), k
+    assert np.abs(gcol - ref_gcol).max() <= 2e-6 * np.abs(ref_gcol).max() and np.abs(ref_gcol).max() > 0
+    assert np.abs(ga - ref_ga).max() <= 2e-6 * np.abs(ref_ga).max()
+    with pytest.raises(Exception, match="invalid"):
+        emu.vol_render_rgb_backward_batch(len(views), arr, Nall, P(col), P(al), None, P(ga), 16, nth, ntw, H, W, 1e-4,
+                                          P(bws), None)
+
+
 def _torch_densify(cov2d, gmean2d, mask, max_r, acc, cnt):
     """The reference's statements (gs/gaussian_splatting.py:1240-1245, :464-469) on full-N rows."""
     cov = torch.from_numpy(cov2d).reshape(-1, 2, 2); mask = torch.from_numpy(mask.astype(bool))

@@ -175,7 +175,7 @@ def test_densify_statistics_over_two_cameras():
     assert want[2].max() == 2.0 and want[2].min() == 0.0
 
 
-@pytest.mark.parametrize("n_streams,C,fused,ncam", [(1, 3, 0, 5), (3, 3, 0, 5), (3, 0, 0, 5), (3, 4, 1, 5), (2, 2, 3, 5), (3, 4, 1, 11)])
+@pytest.mark.parametrize("n_streams,C,fused,ncam", [(1, 3, 0, 5), (3, 3, 0, 5), (3, 0, 0, 5), (3, 4, 1, 5), (2, 2, 3, 5), (3, 4, 1, 11), (2, 0, 1, 5)])
 def test_batched_cameras_match_one_at_a_time(n_streams, C, fused, ncam):
     """BatchRenderer (cameras in flight on several streams) == a loop of render_frame:
     identical images, the gradient of the summed loss, and the same densify statistics."""
