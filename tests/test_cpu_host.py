@@ -64,6 +64,29 @@ def test_product_and_bench_workloads_never_import_the_oracle():
     assert r.stdout.strip() == "[]", r.stdout
 
 
+def test_ctypes_view_structures_match_the_c_header(tmp_path):
+    """the per-view structs of the *_batch entry points: size and every field offset as gcc lays them out from
+    include/gsgen_hip.h == the ctypes Structures of gsgen_amd/_capi.py (a silent mismatch would hand the library
+    shifted pointers)"""
+    from gsgen_amd import _capi
+    structs = {"gsgen_sh_view": _capi.ShView, "gsgen_rgbd_view": _capi.RgbdView, "gsgen_geometry_view": _capi.GeometryView}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "gsgen_hip.h"', 'int main(void) {']
+    for cname, st in structs.items():
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in st._fields_:
+            lines.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = dict(ln.split() for ln in subprocess.check_output([str(exe)], text=True).splitlines())
+    for cname, st in structs.items():
+        assert int(got[cname]) == ctypes.sizeof(st), cname
+        for fname, _ in st._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(st, fname).offset, (cname, fname)
+
+
 def test_gs_mirror_has_the_23_reference_names():
     from gsgen_amd import _gs
     names = """culling_gaussian_bsphere count_num_gaussians_each_tile count_num_gaussians_each_tile_bcircle
