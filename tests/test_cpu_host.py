@@ -479,6 +479,48 @@ def test_emulated_batched_rgb_matches_per_view_launches(emu):
                                           P(bws), None)
 
 
+def test_emulated_batch_entry_points_on_empty_inputs(emu):
+    """N = 0 through the batched geometry (every tile empty, total 0), then the batched SH forward on those empty
+    lists (image = background, T = 1) and its backward (no-op), as the per-view entry points behave"""
+    from gsgen_amd import renderer as R
+    from gsgen_amd._capi import GeometryView, ShView
+    W, H, B = 48, 32, 2
+    cams = [scenes.Camera(W, H, fx=40.0 + i) for i in range(B)]
+    nth, ntw = cams[0].tiles
+    T = nth * ntw
+    camv = [np.ascontiguousarray(R.CameraInfo(*c.intr).pack(c.c2w)) for c in cams]
+    st = [np.zeros(T, np.int32) for _ in range(B)]; en = [np.zeros(T, np.int32) for _ in range(B)]
+    tot = [np.full(1, 9, np.uint32) for _ in range(B)]; ids = [np.zeros(8, np.int32) for _ in range(B)]
+    ws = [np.zeros(emu.frame_workspace_bytes(0, 8, T), np.uint8) for _ in range(B)]
+    geo = (GeometryView * B)()
+    for i, a in enumerate(geo):
+        a.cam, a.gaussian_ids, a.start, a.end, a.total = P(camv[i]), P(ids[i]), P(st[i]), P(en[i]), P(tot[i])
+        a.workspace, a.workspace_bytes, a.D_cap = P(ws[i]), ws[i].size, 8
+    gws = np.zeros(emu.frame_batch_workspace_bytes(B), np.uint8)
+    emu.frame_geometry_batch(B, geo, 0, None, None, None, W, H, P(gws), None)
+    for i in range(B):
+        assert tot[i][0] == 0 and (st[i] == -1).all() and (en[i] == -1).all()
+    bg = np.array([0.25, 0.5, 0.75], np.float32)
+    out = [np.zeros((H, W, 3), np.float32) for _ in range(B)]; Tt = [np.ones((H, W), np.float32) for _ in range(B)]  # caller-initialised, as for the per-view entry points
+    go = np.ones((H, W, 3), np.float32)
+    gm = np.zeros((1, 2), np.float32); gc = np.zeros((1, 4), np.float32)
+    sh = np.zeros((1, 3, 4), np.float32); al = np.zeros(1, np.float32)
+    views = (ShView * B)()
+    for i, v in enumerate(views):
+        rot = np.ascontiguousarray(cams[i].c2w[:3, :3].reshape(-1))
+        v.start, v.end, v.gaussian_ids, v.topleft, v.c2w, v.bg_rgb = P(st[i]), P(en[i]), P(ids[i]), P(cams[i].topleft), P(rot), P(bg)
+        v.pixel_size_x, v.pixel_size_y, v.out, v.T = 1 / cams[i].fx, 1 / cams[i].fy, P(out[i]), P(Tt[i])
+        v.grad_out, v.grad_mean, v.grad_cov = P(go), P(gm), P(gc)
+        v._keep = rot
+    bws = np.zeros(emu.sh_batch_workspace_bytes(B), np.uint8)
+    emu.vol_render_sh_batch(B, views, 1, P(sh), P(al), 16, nth, ntw, H, W, 2, 1e-4, 0, P(bws), None)
+    for i in range(B):
+        assert np.array_equal(out[i], np.broadcast_to(bg, (H, W, 3))) and (Tt[i] == 1).all()
+    gsh = np.zeros_like(sh); ga = np.zeros(1, np.float32)
+    emu.vol_render_backward_sh_batch(B, views, 1, P(sh), P(al), P(gsh), P(ga), 16, nth, ntw, H, W, 2, 1e-4, 0, P(bws), None)
+    assert not gsh.any() and not ga.any() and not gm.any() and not gc.any()
+
+
 def _torch_densify(cov2d, gmean2d, mask, max_r, acc, cnt):
     """The reference's statements (gs/gaussian_splatting.py:1240-1245, :464-469) on full-N rows."""
     cov = torch.from_numpy(cov2d).reshape(-1, 2, 2); mask = torch.from_numpy(mask.astype(bool))
