@@ -102,7 +102,8 @@ SIZE_FUNCS = {
     "gsgen_frame_batch_workspace_bytes": [u32],
     "gsgen_legacy_sort_workspace_bytes": [u32, u32],
 }
-EXPORTS = sorted(list(SIGNATURES) + list(SIZE_FUNCS) + list(PTR_FUNCS) + ["gsgen_version", "gsgen_error_string"])
+EXPORTS = sorted(list(SIGNATURES) + list(SIZE_FUNCS) + list(PTR_FUNCS)
+                 + ["gsgen_version", "gsgen_error_string", "gsgen_kernel_variant", "gsgen_debug_set_variant"])
 
 
 class GsgenError(RuntimeError):
@@ -159,6 +160,23 @@ class Lib:
 
     def version(self):
         return self.cdll.gsgen_version().decode()
+
+    def set_variant(self, name, value):
+        """debugging hook: override one entry of the kernel-variant table (see include/gsgen_hip.h)"""
+        fn = self.cdll.gsgen_debug_set_variant
+        fn.argtypes, fn.restype = [C.c_char_p, i32], i32
+        if fn(name.encode(), int(value)) != 0:
+            raise ValueError(f"bad kernel variant {name}={value}")
+
+    def kernel_variant(self, stage, bands=4, n_segments=1):
+        """name of the compiled compositing kernel a launch of `stage` runs in this process (bands = C)"""
+        fn = self.cdll.gsgen_kernel_variant
+        fn.argtypes, fn.restype = [C.c_char_p, u32, u32, C.c_char_p, sz], i32
+        buf = C.create_string_buffer(192)
+        n = fn(stage.encode(), bands, n_segments, buf, len(buf))
+        if n <= 0:
+            raise ValueError(f"unknown compositing stage {stage!r}")
+        return buf.value.decode()
 
 
 _lib = None

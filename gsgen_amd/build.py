@@ -61,5 +61,28 @@ def build(force=False, verbose=False, extra_flags=()):
     return LIB
 
 
+TOOLS_DIR = os.path.join(HERE, "..", "tools", "stress")
+
+
+def build_tools(force=False, verbose=False):
+    """tools/stress: the fresh-process stress harness of the SH backward variants (bwd_stress, a C++ program on the
+    C ABI, linked against the in-tree library with a relative rpath) and the stand-alone MFMA-chain reproducer
+    (mfma_first_launch).  Test tools, not product."""
+    lib = build()
+    out = []
+    for name, link in (("bwd_stress", [f"-L{LIBDIR}", "-lgsgen_hip", "-Wl,-rpath,$ORIGIN/../../gsgen_amd/lib"]),
+                       ("mfma_first_launch", [])):
+        src, exe = os.path.join(TOOLS_DIR, name + ".cpp"), os.path.join(TOOLS_DIR, name)
+        if force or _newer(src, exe, extra=(lib,)):
+            cmd = [HIPCC, "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-x", "hip", src, "-o", exe, *link]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        out.append(exe)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    if "--tools" in sys.argv:
+        print(build_tools(force="--force" in sys.argv, verbose=True))

@@ -28,6 +28,9 @@
 // backward share eval code, so the backward's recomputed prefix equals the forward bit for
 // bit (the invariant the reference asserts at vol_render_sh.h:452-454).
 #include "composite_common.hpp"
+#include <stdio.h>
+#include <string.h>
+#include <string>
 #include <vector>
 #include <gsgen_mfma.hpp>
 
@@ -332,8 +335,8 @@ __global__ void __launch_bounds__(256 / PPL) k_composite_fwd(CompParams p_arg, c
 template <int MODE, int CB, int PPL, bool BATCH = false>
 __global__ void __launch_bounds__(256 / PPL)
 k_composite_bwd_pixel(CompParams p_arg, const CompParams *__restrict__ plist) {
-  uint32_t bid = blockIdx.x;
-  const CompParams p = BATCH ? plist[batch_view(p_arg, bid)] : p_arg;  // see k_composite_fwd
+  uint32_t bid = blockIdx.x, grid = gridDim.x;
+  const CompParams p = BATCH ? plist[batch_view(p_arg, bid, &grid)] : p_arg;  // see k_composite_fwd
   using TR = Traits<MODE, CB>;
   constexpr int NT = 256 / PPL;
   constexpr int ROWS = NT / 16;
@@ -341,12 +344,21 @@ k_composite_bwd_pixel(CompParams p_arg, const CompParams *__restrict__ plist) {
   constexpr int P = TR::P;
   __shared__ Stage<MODE, CB> S;
 
+  // Segmented launch (SH only): workgroup = (tile, segment of kSegLen list entries) starting from the
+  // state the forward left in front of the segment (CompParams::ckpt / stop); segment-major order, see
+  // k_composite_bwd_sh_mfma.
+  const int nseg = (MODE == MODE_SH && p.nseg > 1) ? p.nseg : 1;
+  const uint32_t tiles_grid = grid / (uint32_t)nseg;
+  const int seg = (int)(bid / tiles_grid);
   int tx, ty;
-  if (!block_tile(p, tx, ty, bid)) return;  // uniform over the workgroup
+  if (!block_tile(p, tx, ty, bid % tiles_grid)) return;  // uniform over the workgroup
   const int tile = ty * p.ntw + tx;
   const int st = p.start[tile];
   const int n = (st < 0) ? 0 : (p.end[tile] - st);
   if (n == 0 || n < p.n_lo || n >= p.n_hi) return;
+  const int e_lo = seg * kSegLen;
+  const int e_hi = (seg == nseg - 1) ? n : min(n, e_lo + kSegLen);  // the last segment takes the rest
+  if (e_lo >= n) return;
   const int t = (int)threadIdx.x;
   const int lane = t & 63;
   const int lx = t & 15, ly0 = t >> 4;
@@ -392,20 +404,39 @@ k_composite_bwd_pixel(CompParams p_arg, const CompParams *__restrict__ plist) {
   bool alive[PPL];
 #pragma unroll
   for (int j = 0; j < PPL; ++j) {
+    alive[j] = valid[j];
+    if constexpr (MODE == MODE_SH) {
+      if (nseg > 1) alive[j] = alive[j] && (p.stop[(size_t)tile * 256 + (ly0 + j * ROWS) * 16 + lx] > e_lo);
+    }
+  }
+  if constexpr (MODE == MODE_SH) {
+    if (nseg > 1) {  // every pixel of the tile stopped before this segment?
+      bool any = false;
+#pragma unroll
+      for (int j = 0; j < PPL; ++j) any |= alive[j];
+      if (__syncthreads_or((int)any) == 0) return;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < PPL; ++j) {
     const size_t pix = valid[j] ? ((size_t)gy[j] * p.W + gx) : 0;
+    float4 ck = make_float4(1.0f, 0.0f, 0.0f, 0.0f);  // state in front of entry e_lo: T, prefix rgb
+    if constexpr (MODE == MODE_SH) {
+      if (seg > 0 && alive[j]) ck = p.ckpt[((size_t)tile * nseg + seg) * 256 + (ly0 + j * ROWS) * 16 + lx];
+    }
+    const float pre0[3] = {ck.y, ck.z, ck.w};
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       go[j][c] = valid[j] ? p.grad_out[NCH * pix + c] : 0.0f;
       fin[j][c] = valid[j] ? p.final_img[NCH * pix + c] : 0.0f;
-      pre[j][c] = 0.0f;
+      pre[j][c] = (MODE == MODE_SH) ? pre0[c < 3 ? c : 0] : 0.0f;
     }
-    Tr[j] = 1.0f;
-    alive[j] = valid[j];
+    Tr[j] = ck.x;
   }
 
-  for (int base = 0; base < n; base += kBatch) {
-    const int nb = min(kBatch, n - base);
-    if (base > 0) __syncthreads();
+  for (int base = e_lo; base < e_hi; base += kBatch) {
+    const int nb = min(kBatch, e_hi - base);
+    if (base > e_lo) __syncthreads();
     stage_batch<MODE, CB, NT>(S, p, st + base, nb);
     __syncthreads();
 
@@ -914,15 +945,43 @@ k_composite_bwd_sh_mfma(CompParams p_arg, const CompParams *__restrict__ plist) 
 }
 
 // ---- launch helpers ---------------------------------------------------------------------------
-// Pixels per lane: 4 = one wavefront per tile (north_star design), 2 / 1 = two / four
-// wavefronts per tile sharing the staged records.  Defaults chosen by measurement on MI355X
-// (profiles/r01_notes.md): forward 1 (127 us vs 195 us at 4: one wave per tile leaves 2.4 waves
-// per SIMD and the launch ends on the centre tiles' serial chains), backward 4 (the per-Gaussian
-// gradient reduction costs the same per wave whatever the number of pixels behind it).
-// GSGEN_PPL_FWD / GSGEN_PPL_BWD override them for A/B runs.
+// Kernel variants, read once per process from the environment (A/B runs and the variant tests):
+//   GSGEN_PPL_FWD / GSGEN_PPL_BWD          pixels per lane of the per-camera forward / backward (4 = one wavefront
+//                                          per tile, the north_star shape; 2 / 1 = two / four wavefronts per tile
+//                                          sharing the staged records)
+//   GSGEN_PPL_FWD_BATCH / GSGEN_PPL_BWD_BATCH / GSGEN_PPL_BWD_SH_BATCH   the same for the batched launches
+//                                          (RGB + heads backward / SH backward)
+//   GSGEN_BWD_MFMA / GSGEN_BWD_MFMA_BATCH  0 (default) = SH gradient contraction on the vector ALUs
+//                                          (k_composite_bwd_pixel); 4 | 2 | 1 = the matrix-core kernel
+//                                          (k_composite_bwd_sh_mfma) with that many pixels per lane.  OPT-IN: the
+//                                          matrix-core chain has shown timing- and box-dependent corruption that is
+//                                          not root-caused (profiles/r01_notes.md), the vector kernel
+//                                          never has -- and north_star asks for "no MFMA" on this path.
+//   GSGEN_BATCH_MAP                        block order of the batched grids (batch_view)
+// Defaults chosen by measurement on MI355X (profiles/r01_notes.md): forward 1 pixel per lane (127 us vs 195 us at 4:
+// one wave per tile leaves 2.4 waves per SIMD and the launch ends on the centre tiles' serial chains), vector
+// backward 4 (the per-Gaussian gradient reduction costs the same per wave whatever the number of pixels behind it).
+struct Variants {
+  int ppl_fwd, ppl_bwd, mfma, ppl_fwd_batch, ppl_bwd_batch, ppl_bwd_sh_batch, mfma_batch, batch_map;
+};
+static int env_mfma(const char *name) {
+  const char *v = getenv(name);
+  if (!v) return 0;
+  const int x = atoi(v);
+  return (x == 1 || x == 2 || x == 4) ? x : 0;
+}
+static Variants &variants() {
+  static Variants v = {env_ppl("GSGEN_PPL_FWD", 1),       env_ppl("GSGEN_PPL_BWD", 4),
+                             env_mfma("GSGEN_BWD_MFMA"),         env_ppl("GSGEN_PPL_FWD_BATCH", 1),
+                             env_ppl("GSGEN_PPL_BWD_BATCH", 2),  env_ppl("GSGEN_PPL_BWD_SH_BATCH", 4),
+                             env_mfma("GSGEN_BWD_MFMA_BATCH"),
+                             getenv("GSGEN_BATCH_MAP") ? atoi(getenv("GSGEN_BATCH_MAP")) : 2};
+  return v;
+}
+
 template <int MODE, int CB>
 static int launch_fwd(const CompParams &p, hipStream_t s) {
-  static const int ppl = env_ppl("GSGEN_PPL_FWD", 1);
+  const int ppl = variants().ppl_fwd;
   const uint32_t nblk = comp_grid(p);
   if (p.ntw * p.nth == 0) return 0;
   if (ppl == 1) hipLaunchKernelGGL((k_composite_fwd<MODE, CB, 1>), dim3(nblk), dim3(256), 0, s, p, (const CompParams *)nullptr);
@@ -932,28 +991,25 @@ static int launch_fwd(const CompParams &p, hipStream_t s) {
 }
 template <int MODE, int CB>
 static int launch_bwd(const CompParams &p_, hipStream_t s) {
-  static const int ppl = env_ppl("GSGEN_PPL_BWD", 4);
+  const int ppl = variants().ppl_bwd, mfma = variants().mfma;
   CompParams p = p_;
   if (p.n_hi == 0) p.n_hi = 0x7fffffff;
   const uint32_t nblk = comp_grid(p);
   if (p.ntw * p.nth == 0) return 0;
-  // GSGEN_BWD_MFMA=0 keeps the SH gradient contraction on the vector ALUs (A/B runs);
-  // GSGEN_BWD_MFMA=4 / 2 / 1 choose one / two / four wavefronts per tile for the matrix-core kernel.
-  // Measured on cfg2 (profiles/r01_notes.md): two wavefronts 2710-2770 renders/s, one 2600, four
-  // 2480, vector path 2445.
-  static const int mfma = getenv("GSGEN_BWD_MFMA") ? atoi(getenv("GSGEN_BWD_MFMA")) : 2;
   if constexpr (MODE == MODE_SH) {
-    if (ppl == 4 && mfma != 0) {
+    if (mfma != 0) {  // opt-in matrix-core kernel
       const uint32_t ng = nblk * (uint32_t)(p.nseg > 1 ? p.nseg : 1);
-      if (mfma == 1) hipLaunchKernelGGL((k_composite_bwd_sh_mfma<CB, 1>), dim3(ng), dim3(256), 0, s, p, (const CompParams *)nullptr);
-      else if (mfma == 2) hipLaunchKernelGGL((k_composite_bwd_sh_mfma<CB, 2>), dim3(ng), dim3(128), 0, s, p, (const CompParams *)nullptr);
+      const int w = mfma;
+      if (w == 1) hipLaunchKernelGGL((k_composite_bwd_sh_mfma<CB, 1>), dim3(ng), dim3(256), 0, s, p, (const CompParams *)nullptr);
+      else if (w == 2) hipLaunchKernelGGL((k_composite_bwd_sh_mfma<CB, 2>), dim3(ng), dim3(128), 0, s, p, (const CompParams *)nullptr);
       else hipLaunchKernelGGL((k_composite_bwd_sh_mfma<CB, 4>), dim3(ng), dim3(64), 0, s, p, (const CompParams *)nullptr);
       return (int)hipGetLastError();
     }
   }
-  if (ppl == 1) hipLaunchKernelGGL((k_composite_bwd_pixel<MODE, CB, 1>), dim3(nblk), dim3(256), 0, s, p, (const CompParams *)nullptr);
-  else if (ppl == 2) hipLaunchKernelGGL((k_composite_bwd_pixel<MODE, CB, 2>), dim3(nblk), dim3(128), 0, s, p, (const CompParams *)nullptr);
-  else hipLaunchKernelGGL((k_composite_bwd_pixel<MODE, CB, 4>), dim3(nblk), dim3(64), 0, s, p, (const CompParams *)nullptr);
+  const uint32_t ng = nblk * (uint32_t)((MODE == MODE_SH && p.nseg > 1) ? p.nseg : 1);
+  if (ppl == 1) hipLaunchKernelGGL((k_composite_bwd_pixel<MODE, CB, 1>), dim3(ng), dim3(256), 0, s, p, (const CompParams *)nullptr);
+  else if (ppl == 2) hipLaunchKernelGGL((k_composite_bwd_pixel<MODE, CB, 2>), dim3(ng), dim3(128), 0, s, p, (const CompParams *)nullptr);
+  else hipLaunchKernelGGL((k_composite_bwd_pixel<MODE, CB, 4>), dim3(ng), dim3(64), 0, s, p, (const CompParams *)nullptr);
   return (int)hipGetLastError();
 }
 
@@ -975,7 +1031,7 @@ int write_params(const CompParams *host, uint32_t B, CompParams *dst, hipStream_
 }
 template <int CB>
 static void launch_fwd_sh_batch_c(const CompParams &p0, const CompParams *plist, uint32_t B, uint32_t nblk, hipStream_t s) {
-  static const int ppl = env_ppl("GSGEN_PPL_FWD_BATCH", 1);  // wavefronts per tile = 4 / ppl
+  const int ppl = variants().ppl_fwd_batch;  // wavefronts per tile = 4 / ppl
   const dim3 g(nblk * B);
   if (ppl == 1) hipLaunchKernelGGL((k_composite_fwd<MODE_SH, CB, 1, true>), g, dim3(256), 0, s, p0, plist);
   else if (ppl == 2) hipLaunchKernelGGL((k_composite_fwd<MODE_SH, CB, 2, true>), g, dim3(128), 0, s, p0, plist);
@@ -985,10 +1041,9 @@ static CompParams batch_arg(const CompParams &p0, uint32_t B) {
   // measured (profiles/r01_notes.md): camera-major is as fast as either interleaving on cfg2 (2820-2860 vs
   // 2790-2850 renders/s) and faster on the 64 random cameras of cfg4 (5440-5590 vs 5030 / 5290-5360: an
   // interleaved B = 8 pins each camera to one XCD, and random cameras differ in work)
-  static const int map = getenv("GSGEN_BATCH_MAP") ? atoi(getenv("GSGEN_BATCH_MAP")) : 2;
   CompParams a = p0;
   a.n_lo = (int)B;
-  a.n_hi = map;
+  a.n_hi = variants().batch_map;
   return a;
 }
 int launch_fwd_sh_batch(int C, const CompParams &p0_, const CompParams *plist, uint32_t B, hipStream_t s) {
@@ -1005,12 +1060,19 @@ int launch_fwd_sh_batch(int C, const CompParams &p0_, const CompParams *plist, u
 }
 template <int CB>
 static void launch_bwd_sh_batch_c(const CompParams &p0, const CompParams *plist, uint32_t B, uint32_t nblk, hipStream_t s) {
-  // pixels per lane of the matrix-core kernel (wavefronts per tile = 4 / ppl), as GSGEN_BWD_MFMA = 4 | 2 | 1
-  static const int ppl = getenv("GSGEN_BWD_MFMA_BATCH") ? atoi(getenv("GSGEN_BWD_MFMA_BATCH")) : 2;
   const dim3 g(nblk * B);
-  if (ppl == 4) hipLaunchKernelGGL((k_composite_bwd_sh_mfma<CB, 4, true>), g, dim3(64), 0, s, p0, plist);
-  else if (ppl == 1) hipLaunchKernelGGL((k_composite_bwd_sh_mfma<CB, 1, true>), g, dim3(256), 0, s, p0, plist);
-  else hipLaunchKernelGGL((k_composite_bwd_sh_mfma<CB, 2, true>), g, dim3(128), 0, s, p0, plist);
+  const int mfma = variants().mfma_batch;
+  if (mfma != 0) {  // opt-in matrix-core kernel
+    const int w = mfma;
+    if (w == 4) hipLaunchKernelGGL((k_composite_bwd_sh_mfma<CB, 4, true>), g, dim3(64), 0, s, p0, plist);
+    else if (w == 1) hipLaunchKernelGGL((k_composite_bwd_sh_mfma<CB, 1, true>), g, dim3(256), 0, s, p0, plist);
+    else hipLaunchKernelGGL((k_composite_bwd_sh_mfma<CB, 2, true>), g, dim3(128), 0, s, p0, plist);
+    return;
+  }
+  const int ppl = variants().ppl_bwd_sh_batch;
+  if (ppl == 1) hipLaunchKernelGGL((k_composite_bwd_pixel<MODE_SH, CB, 1, true>), g, dim3(256), 0, s, p0, plist);
+  else if (ppl == 2) hipLaunchKernelGGL((k_composite_bwd_pixel<MODE_SH, CB, 2, true>), g, dim3(128), 0, s, p0, plist);
+  else hipLaunchKernelGGL((k_composite_bwd_pixel<MODE_SH, CB, 4, true>), g, dim3(64), 0, s, p0, plist);
 }
 int launch_bwd_sh_batch(int C, const CompParams &p0_, const CompParams *plist, uint32_t B, hipStream_t s) {
   const uint32_t nblk = comp_grid(p0_) * (uint32_t)(p0_.nseg > 1 ? p0_.nseg : 1);
@@ -1030,7 +1092,7 @@ int launch_fwd_rgbd_batch(const CompParams &p0_, const CompParams *plist, uint32
   const uint32_t nblk = comp_grid(p0_);
   if (p0_.ntw * p0_.nth == 0 || B == 0) return 0;
   const CompParams p0 = batch_arg(p0_, B);
-  static const int ppl = env_ppl("GSGEN_PPL_FWD_BATCH", 1);
+  const int ppl = variants().ppl_fwd_batch;
   if (ppl == 1) hipLaunchKernelGGL((k_composite_fwd<MODE_RGBD, 1, 1, true>), dim3(nblk * B), dim3(256), 0, s, p0, plist);
   else if (ppl == 2) hipLaunchKernelGGL((k_composite_fwd<MODE_RGBD, 1, 2, true>), dim3(nblk * B), dim3(128), 0, s, p0, plist);
   else hipLaunchKernelGGL((k_composite_fwd<MODE_RGBD, 1, 4, true>), dim3(nblk * B), dim3(64), 0, s, p0, plist);
@@ -1042,7 +1104,7 @@ int launch_bwd_rgbd_batch(const CompParams &p0_, const CompParams *plist, uint32
   const CompParams p0 = batch_arg(p0_, B);
   // two wavefronts per tile: 6 087 / 3 588 views/s at 8 x 512^2 / 8 x 800^2 against 5 902 / 3 522 with one and
   // 5 753 / 3 138 with four (tools/bench_batch.py --heads)
-  static const int ppl = env_ppl("GSGEN_PPL_BWD_BATCH", 2);
+  const int ppl = variants().ppl_bwd_batch;
   if (ppl == 1) hipLaunchKernelGGL((k_composite_bwd_pixel<MODE_RGBD, 1, 1, true>), dim3(nblk * B), dim3(256), 0, s, p0, plist);
   else if (ppl == 2) hipLaunchKernelGGL((k_composite_bwd_pixel<MODE_RGBD, 1, 2, true>), dim3(nblk * B), dim3(128), 0, s, p0, plist);
   else hipLaunchKernelGGL((k_composite_bwd_pixel<MODE_RGBD, 1, 4, true>), dim3(nblk * B), dim3(64), 0, s, p0, plist);
@@ -1061,7 +1123,7 @@ int launch_bwd_rgb_batch(const CompParams &p0_, const CompParams *plist, uint32_
   const uint32_t nblk = comp_grid(p0_);
   if (p0_.ntw * p0_.nth == 0 || B == 0) return 0;
   const CompParams p0 = batch_arg(p0_, B);
-  static const int ppl = env_ppl("GSGEN_PPL_BWD_BATCH", 2);
+  const int ppl = variants().ppl_bwd_batch;
   if (ppl == 4) hipLaunchKernelGGL((k_composite_bwd_pixel<MODE_RGB, 1, 4, true>), dim3(nblk * B), dim3(64), 0, s, p0, plist);
   else hipLaunchKernelGGL((k_composite_bwd_pixel<MODE_RGB, 1, 2, true>), dim3(nblk * B), dim3(128), 0, s, p0, plist);
   return (int)hipGetLastError();
@@ -1084,6 +1146,58 @@ int launch_bwd_pixel_dispatch(int mode, int C, const CompParams &p, hipStream_t 
 using namespace gs;
 
 extern "C" {
+
+/* Debugging hook (tools/stress, A/B measurements inside one process): overrides one entry of the variant table that
+ * the environment initialised.  Not thread-safe against concurrent launches.  name: "ppl_fwd", "ppl_bwd", "mfma",
+ * "ppl_fwd_batch", "ppl_bwd_batch", "ppl_bwd_sh_batch", "mfma_batch", "batch_map". */
+int gsgen_debug_set_variant(const char *name, int value) {
+  if (!name) return GSGEN_EINVAL;
+  Variants &v = variants();
+  const std::string n(name);
+  const bool ppl_ok = value == 1 || value == 2 || value == 4;
+  int *slot = nullptr;
+  bool ok = ppl_ok;
+  if (n == "ppl_fwd") slot = &v.ppl_fwd;
+  else if (n == "ppl_bwd") slot = &v.ppl_bwd;
+  else if (n == "ppl_fwd_batch") slot = &v.ppl_fwd_batch;
+  else if (n == "ppl_bwd_batch") slot = &v.ppl_bwd_batch;
+  else if (n == "ppl_bwd_sh_batch") slot = &v.ppl_bwd_sh_batch;
+  else if (n == "mfma") { slot = &v.mfma; ok = ppl_ok || value == 0; }
+  else if (n == "mfma_batch") { slot = &v.mfma_batch; ok = ppl_ok || value == 0; }
+  else if (n == "batch_map") { slot = &v.batch_map; ok = value >= 0 && value <= 2; }
+  if (!slot || !ok) return GSGEN_EINVAL;
+  *slot = value;
+  return 0;
+}
+
+/* Name of the compositing kernel a launch of `stage` would run in this process ("sh_fwd", "sh_bwd", "sh_fwd_batch",
+ * "sh_bwd_batch", "rgb_fwd", "rgb_bwd", "rgbd_fwd_batch", "rgbd_bwd_batch") at SH degree C-1, derived from the same
+ * variant table the launchers use.  Returns the length written (excluding the terminator), 0 for an unknown stage. */
+int gsgen_kernel_variant(const char *stage, uint32_t C, uint32_t n_segments, char *out, size_t out_bytes) {
+  if (!stage || !out || out_bytes == 0) return 0;
+  const Variants &v = variants();
+  const std::string st(stage);
+  char buf[160];
+  int n = 0;
+  auto sh_bwd = [&](int mfma, int ppl, const char *b) {
+    if (mfma) return snprintf(buf, sizeof buf, "k_composite_bwd_sh_mfma<C=%u,PPL=%d%s>%s", C, mfma, b, n_segments > 1 ? " segmented" : "");
+    return snprintf(buf, sizeof buf, "k_composite_bwd_pixel<SH,C=%u,PPL=%d%s>%s", C, ppl, b, n_segments > 1 ? " segmented" : "");
+  };
+  if (st == "sh_fwd") n = snprintf(buf, sizeof buf, "k_composite_fwd<SH,C=%u,PPL=%d>", C, v.ppl_fwd);
+  else if (st == "sh_fwd_batch") n = snprintf(buf, sizeof buf, "k_composite_fwd<SH,C=%u,PPL=%d,BATCH>", C, v.ppl_fwd_batch);
+  else if (st == "sh_bwd") n = sh_bwd(v.mfma, v.ppl_bwd, "");
+  else if (st == "sh_bwd_batch") n = sh_bwd(v.mfma_batch, v.ppl_bwd_sh_batch, ",BATCH");
+  else if (st == "rgb_fwd") n = snprintf(buf, sizeof buf, "k_composite_fwd<RGB,PPL=%d>", v.ppl_fwd);
+  else if (st == "rgb_bwd") n = snprintf(buf, sizeof buf, "k_composite_bwd_pixel<RGB,PPL=%d>", v.ppl_bwd);
+  else if (st == "rgbd_fwd_batch") n = snprintf(buf, sizeof buf, "k_composite_fwd<RGBD,PPL=%d,BATCH>", v.ppl_fwd_batch);
+  else if (st == "rgbd_bwd_batch") n = snprintf(buf, sizeof buf, "k_composite_bwd_pixel<RGBD,PPL=%d,BATCH>", v.ppl_bwd_batch);
+  else return 0;
+  if (n < 0) return 0;
+  if ((size_t)n >= out_bytes) n = (int)out_bytes - 1;
+  memcpy(out, buf, (size_t)n);
+  out[n] = 0;
+  return n;
+}
 
 int gsgen_vol_render_start_end_with_T(uint32_t N, uint32_t D, const float *mean, const float *cov,
                                       const float *color, const float *alpha, const int *start,

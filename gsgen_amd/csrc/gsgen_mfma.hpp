@@ -58,7 +58,11 @@ __device__ __forceinline__ u32x4 u32x4_zero() { return u32x4{0u, 0u, 0u, 0u}; }
 // chain and four registers (cfg2: same throughput as 16 + 64 fixed wait states, 1 % below the unsafe 16).
 // GSGEN_MFMA_FIXED_WAITS builds 16 + 64 fixed wait states instead, GSGEN_MFMA_SHORT_WAITS the original lengths
 // (the hazard detector of tools/mfma_stress.py experiments).
-#if defined(GSGEN_MFMA_SHORT_WAITS)
+#if defined(GSGEN_MFMA_PLAIN)
+// experiment build: no discipline at all -- the chain exactly as hipcc schedules and pads it (tools/stress)
+#define GSGEN_MFMA_PRE ""
+#define GSGEN_MFMA_POST ""
+#elif defined(GSGEN_MFMA_SHORT_WAITS)
 #define GSGEN_MFMA_PRE "s_waitcnt lgkmcnt(0)"
 #define GSGEN_MFMA_POST "s_nop 7\n\ts_nop 7\n\t"
 #elif defined(GSGEN_MFMA_FIXED_WAITS)
@@ -69,12 +73,17 @@ __device__ __forceinline__ u32x4 u32x4_zero() { return u32x4{0u, 0u, 0u, 0u}; }
 #define GSGEN_MFMA_PRE "s_waitcnt lgkmcnt(0)\n\ts_nop 15"
 #define GSGEN_MFMA_POST "s_nop 1\n\t"
 #endif
+#if defined(GSGEN_MFMA_PLAIN)
+__device__ __forceinline__ void mfma_operands_ready(u32x4 &, u32x4 &, u32x4 &, u32x4 &) {}
+__device__ __forceinline__ void mfma_operands_ready(u32x4 &, u32x4 &) {}
+#else
 __device__ __forceinline__ void mfma_operands_ready(u32x4 &a, u32x4 &b, u32x4 &c, u32x4 &d) {
   asm volatile(GSGEN_MFMA_PRE : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory");
 }
 __device__ __forceinline__ void mfma_operands_ready(u32x4 &a, u32x4 &b) {
   asm volatile(GSGEN_MFMA_PRE : "+v"(a), "+v"(b) : : "memory");
 }
+#endif
 #ifdef GSGEN_MFMA_POLL
 // The completion wait: one more MFMA is issued behind the chain into four registers this block owns, the last of
 // them preloaded with a pattern no product of bf16 values can produce (a NaN with a payload below bf16's
@@ -102,12 +111,16 @@ __device__ __forceinline__ void mfma_wait_chain(const u32x4 &pa, const u32x4 &pb
 template <int PPL>
 __device__ __forceinline__ void mfma_wait_chain(const u32x4 &, const u32x4 &, f32x4 &, f32x4 &, f32x4 &) {}
 #endif
+#if defined(GSGEN_MFMA_PLAIN)
+__device__ __forceinline__ void mfma_drain(f32x4 &, f32x4 &, f32x4 &) {}
+#else
 __device__ __forceinline__ void mfma_drain(f32x4 &a, f32x4 &b, f32x4 &c) {
   float a3 = a[3], b3 = b[3], c3 = c[3], sink;
   asm volatile(GSGEN_MFMA_POST "v_or_b32 %0, %1, %2\n\tv_or_b32 %0, %0, %3"
                : "=v"(sink) : "v"(a3), "v"(b3), "v"(c3) : "memory");
   asm volatile("" : "+v"(a), "+v"(b), "+v"(c) : : "memory");
 }
+#endif
 
 // LDS written by some lanes of this wavefront is about to be read by others (or the reverse).  The
 // hardware executes one wavefront's LDS operations in order; this only stops the compiler from

@@ -39,6 +39,17 @@ typedef void *gsgen_stream_t; /* hipStream_t; NULL = the legacy default stream *
 const char *gsgen_version(void);
 /* HIP error string for positive return codes, own text for negative ones. */
 const char *gsgen_error_string(int code);
+/* Which compiled kernel variant a compositing launch runs in this process (the variants are selected by
+ * environment variables read once: gsgen_amd/csrc/composite.hip "launch helpers").  stage: "sh_fwd", "sh_bwd",
+ * "sh_fwd_batch", "sh_bwd_batch", "rgb_fwd", "rgb_bwd", "rgbd_fwd_batch", "rgbd_bwd_batch".  Writes a
+ * NUL-terminated name into out[out_bytes] and returns its length, 0 for an unknown stage.  Host-only; no
+ * counterpart in the reference (bench.py reports it next to the measured kernel time). */
+int gsgen_kernel_variant(const char *stage, uint32_t C, uint32_t n_segments, char *out, size_t out_bytes);
+/* Debugging hook: override one entry of that variant table after the environment initialised it ("ppl_fwd",
+ * "ppl_bwd", "mfma", "ppl_fwd_batch", "ppl_bwd_batch", "ppl_bwd_sh_batch", "mfma_batch", "batch_map"; values as the
+ * GSGEN_* variables).  Not thread-safe against concurrent launches; used by tools/stress to compare kernel
+ * variants inside one process.  Returns 0 or GSGEN_EINVAL. */
+int gsgen_debug_set_variant(const char *name, int value);
 
 /* ---- frustum cull ------------------------------------------------------------------
  * replaces culling_gaussian_bsphere, gs/src/render.h:3 -> render.cu:16-44 ->

@@ -14,10 +14,17 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 VARIANTS = [
     {"GSGEN_PPL_FWD": "4", "GSGEN_PPL_BWD": "2"},
     {"GSGEN_PPL_FWD": "2", "GSGEN_PPL_BWD": "1"},
-    {"GSGEN_BWD_MFMA": "0"},  # SH gradient contraction on the vector ALUs instead of the matrix cores
-    {"GSGEN_BWD_MFMA": "4"},  # matrix-core kernel, one wavefront per tile (default: two)
-    {"GSGEN_BWD_MFMA": "1"},  # matrix-core kernel, four wavefronts per tile
 ]
+# The matrix-core SH backward is OPT-IN (GSGEN_BWD_MFMA = 4 | 2 | 1 pixels per lane; default 0 = vector ALUs): its
+# MFMA chain has shown box- and timing-dependent corruption on hardware that is not root-caused.
+# Its logic is still covered on the deterministic CPU emulator below; on the GPU the variants only run when
+# GSGEN_TEST_MFMA=1 asks for them (tools/stress is the tool that hunts the hazard).
+MFMA_VARIANTS = [
+    {"GSGEN_BWD_MFMA": "2"},  # two wavefronts per tile
+    {"GSGEN_BWD_MFMA": "4"},  # one wavefront per tile
+    {"GSGEN_BWD_MFMA": "1"},  # four wavefronts per tile
+]
+MFMA_ON_GPU = os.environ.get("GSGEN_TEST_MFMA") == "1"
 
 
 def _run(env_extra, args):
@@ -28,7 +35,7 @@ def _run(env_extra, args):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("variant", VARIANTS, ids=lambda v: ",".join(f"{k}={x}" for k, x in v.items()))
+@pytest.mark.parametrize("variant", VARIANTS + MFMA_VARIANTS, ids=lambda v: ",".join(f"{k}={x}" for k, x in v.items()))
 def test_variant_on_emulator(variant):
     # two SH degrees (padded and unpadded coefficient rows) + the fused RGB heads: ~20 s per variant
     _run(variant, ["tests/test_cpu_host.py", "-k",
@@ -43,8 +50,13 @@ BATCH_VARIANTS = [
     # interleaved + rotated; 2 wavefronts per tile forward (the per-camera launches the images are compared with bit
     # for bit get the same split: different pixels-per-lane builds round a few pixels differently)
     {"GSGEN_BATCH_MAP": "1", "GSGEN_PPL_FWD_BATCH": "2", "GSGEN_PPL_FWD": "2"},
-    {"GSGEN_BWD_MFMA_BATCH": "4", "GSGEN_PPL_BWD_BATCH": "4"},  # one wavefront per tile backward (SH / heads)
-    {"GSGEN_BWD_MFMA_BATCH": "1", "GSGEN_PPL_BWD_BATCH": "1", "GSGEN_PPL_FWD_BATCH": "4", "GSGEN_PPL_FWD": "4"},
+    {"GSGEN_PPL_BWD_SH_BATCH": "2", "GSGEN_PPL_BWD_BATCH": "4"},  # SH backward 2 wavefronts per tile, heads 1
+    {"GSGEN_PPL_BWD_SH_BATCH": "1", "GSGEN_PPL_BWD_BATCH": "1", "GSGEN_PPL_FWD_BATCH": "4", "GSGEN_PPL_FWD": "4"},
+]
+MFMA_BATCH_VARIANTS = [
+    {"GSGEN_BWD_MFMA_BATCH": "2"},
+    {"GSGEN_BWD_MFMA_BATCH": "4"},
+    {"GSGEN_BWD_MFMA_BATCH": "1"},
 ]
 
 
@@ -65,3 +77,15 @@ def test_batch_variant_on_gpu(variant):
 def test_variant_on_gpu(variant):
     _run(variant, ["tests/test_gpu_parity.py", "tests/test_gpu_golden.py", "-m", "gpu", "-k",
                    "forward_backward or golden"])
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not MFMA_ON_GPU, reason="matrix-core backward is opt-in: GSGEN_TEST_MFMA=1")
+@pytest.mark.parametrize("variant", MFMA_VARIANTS + MFMA_BATCH_VARIANTS, ids=lambda v: ",".join(f"{k}={x}" for k, x in v.items()))
+def test_mfma_variant_on_gpu(variant):
+    if "GSGEN_BWD_MFMA" in variant:
+        _run(variant, ["tests/test_gpu_parity.py", "tests/test_gpu_golden.py", "-m", "gpu", "-k",
+                       "forward_backward or golden"])
+    else:
+        _run(variant, ["tests/test_gpu_api.py", "-m", "gpu", "-k",
+                       "batched_cameras_match_one_at_a_time and (3-4-1 or 2-2-3)"])
