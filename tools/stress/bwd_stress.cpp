@@ -73,6 +73,13 @@ static T *dupload(const std::vector<T> &h) {
   return d;
 }
 
+#include "poison_regs.inc"
+// every SIMD, every vector / accumulator register: NaN patterns (a 512-register wavefront: one per SIMD at a time)
+__global__ void __launch_bounds__(64) k_poison_regs(int *sink) {
+  const uint32_t pat = 0x7fc0beef;
+  GSGEN_POISON_REGS_ASM(pat);
+  if (threadIdx.x == 1000) *sink = 2;
+}
 // every CU, all of its LDS: NaN patterns (quiet NaN with a recognisable payload)
 __global__ void __launch_bounds__(1024) k_poison_lds(int *sink) {
   extern __shared__ uint32_t lds[];
@@ -112,7 +119,8 @@ struct View {
 int main(int argc, char **argv) {
   std::string variant = "vec";
   int ppl = 0, B = 0, C = 4, N = 30000, size = 512, R = 8, seed = 1, nseg = 0;
-  bool poison = false, test_first = false, quiet = false;
+  bool poison = false, poison_regs = false, test_first = false, quiet = false;
+  int dump_bad = 0;
   double tol = 3e-5;
   for (int i = 1; i < argc; ++i) {
     const std::string a = argv[i];
@@ -128,6 +136,8 @@ int main(int argc, char **argv) {
     else if (a == "--segments") nseg = atoi(val());
     else if (a == "--tol") tol = atof(val());
     else if (a == "--poison") poison = true;
+    else if (a == "--poison-regs") poison_regs = true;
+    else if (a == "--dump-bad") dump_bad = atoi(val());
     else if (a == "--test-first") test_first = true;
     else if (a == "--quiet") quiet = true;
     else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
@@ -202,6 +212,10 @@ int main(int argc, char **argv) {
       hipLaunchKernelGGL(k_poison_lds, dim3(1024), dim3(1024), 160 * 1024, s, d_sink);
       HIPCHECK(hipGetLastError());
     }
+    if (poison_regs) {
+      hipLaunchKernelGGL(k_poison_regs, dim3(8192), dim3(64), 0, s, d_sink);
+      HIPCHECK(hipGetLastError());
+    }
     float *g_sh = g + nv * per_view, *g_alpha = g_sh + (size_t)N * CC3;
     if (B > 0) {
       std::vector<gsgen_sh_view> sv(nv);
@@ -257,6 +271,11 @@ int main(int argc, char **argv) {
     const double d = fabs((double)ref[i] - (double)ref2[i]) / (scale[grp_of(i)] + 1e-30);
     if (d > noise) noise = d;
   }
+  std::vector<float> h_m2;
+  if (dump_bad > 0) {
+    h_m2.resize(2 * (size_t)N);
+    HIPCHECK(hipMemcpy(h_m2.data(), views[0].mean2d, h_m2.size() * sizeof(float), hipMemcpyDeviceToHost));
+  }
   int bad_launches = 0;
   std::string detail;
   double worst = 0;
@@ -273,6 +292,21 @@ int main(int argc, char **argv) {
     }
     const double wl = fmax(fmax(w[0], w[1]), fmax(w[2], w[3]));
     if (wl > worst) worst = wl;
+    std::string dump;
+    if (nbad && dump_bad > 0) {  // Gaussians of view 0 whose mean2d gradient is off: id @ tile (x, y) : relative error
+      int shown = 0;
+      for (size_t gi = 0; gi < (size_t)N && shown < dump_bad; ++gi) {
+        double e = 0;
+        for (int k = 0; k < 2; ++k) e = fmax(e, fabs((double)x[2 * gi + k] - (double)ref[2 * gi + k]) / (scale[0] + 1e-30));
+        if (!(e > tol)) continue;
+        const float fx = views[0].fx;
+        const int tx = (int)floorf((h_m2[2 * gi] * fx + size / 2.0f) / 16.0f), ty = (int)floorf((h_m2[2 * gi + 1] * fx + size / 2.0f) / 16.0f);
+        char b2[96];
+        snprintf(b2, sizeof b2, "%s\"%zu@%d,%d:%.1e(%.3g vs %.3g)\"", shown ? "," : "", gi, tx, ty, e, x[2 * gi], ref[2 * gi]);
+        dump += b2;
+        ++shown;
+      }
+    }
     if (nbad) {
       ++bad_launches;
       char buf[256];
@@ -282,11 +316,12 @@ int main(int argc, char **argv) {
       snprintf(buf, sizeof buf, "%s{\"launch\":%d,\"bad\":%zu,\"nonfinite\":%zu,\"first\":\"%s[%zu]\",\"rel\":[%.2e,%.2e,%.2e,%.2e]}",
                detail.empty() ? "" : ",", r, nbad, nonfinite, grp[g].name, gi, w[0], w[1], w[2], w[3]);
       detail += buf;
+      if (!dump.empty()) { detail.pop_back(); detail += ",\"gaussians\":[" + dump + "]}"; }
     }
   }
-  printf("{\"kernel\":\"%s\",\"views\":%d,\"C\":%d,\"N\":%d,\"size\":%d,\"pairs\":%u,\"launches\":%d,\"test_first\":%s,\"poison\":%s,"
+  printf("{\"kernel\":\"%s\",\"views\":%d,\"C\":%d,\"N\":%d,\"size\":%d,\"pairs\":%u,\"launches\":%d,\"test_first\":%s,\"poison\":\"%s\","
          "\"ref_noise\":%.2e,\"ref_nonfinite\":%zu,\"worst\":%.2e,\"bad_launches\":%d,\"detail\":[%s]}\n",
-         kname, nv, C, N, size, total0, R, test_first ? "true" : "false", poison ? "true" : "false", noise, nonfinite_ref, worst,
+         kname, nv, C, N, size, total0, R, test_first ? "true" : "false", poison ? (poison_regs ? "lds+regs" : "lds") : (poison_regs ? "regs" : "none"), noise, nonfinite_ref, worst,
          bad_launches, quiet ? "" : detail.c_str());
   return (bad_launches || nonfinite_ref) ? 1 : 0;
 }
