@@ -29,10 +29,43 @@ __all__ = [
 
 
 # ---- the reference's CHECK_* macros (gs/src/include/common.h:29-54) ---------------------------
+# ---- which library the mirror drives ------------------------------------------------------------
+# The product binds the HIP library and accepts GPU tensors only (there is NO CPU path).  The tests additionally run
+# the reference's own autograd classes (gs/renderer.py, imported from /root/reference) on this mirror in the GPU-less
+# authoring container: they bind the SIMT-emulator build of the SAME kernels (oracle/_build/libgsgen_emu.so, test
+# infrastructure that is not part of the package) and hand it host tensors.  `_bind_library_for_tests` is that hook;
+# nothing in gsgen_amd calls it.
+_bound_lib = None
+_host_tensors_ok = False
+
+
+def _bind_library_for_tests(lib, host_tensors=False):
+    """lib: a gsgen_amd._capi.Lib (None restores the HIP library); host_tensors: accept CPU tensors"""
+    global _bound_lib, _host_tensors_ok
+    _bound_lib, _host_tensors_ok = lib, bool(host_tensors) and lib is not None
+
+
+def _load():
+    return _bound_lib if _bound_lib is not None else _capi.load()
+
+
+class _no_guard:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def _guard(t):
+    """device guard of the call (the reference installs none: SURVEY.md 8b)"""
+    return torch.cuda.device(t.device) if t.is_cuda else _no_guard()
+
+
 def _check_dc(x, name, dtype, what):
     if not isinstance(x, torch.Tensor):
         raise TypeError(f"{name} must be a torch.Tensor")
-    if not x.is_cuda:
+    if not x.is_cuda and not _host_tensors_ok:
         raise RuntimeError(f"{name} must be a CUDA tensor")
     if not x.is_contiguous():
         raise RuntimeError(f"{name} must be a contiguous tensor")
@@ -53,7 +86,7 @@ def _b(x, name):
 
 
 def _stream(t):
-    return torch.cuda.current_stream(t.device).cuda_stream
+    return torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else None
 
 
 def _p(t):
@@ -65,8 +98,8 @@ def culling_gaussian_bsphere(mean, qvec, svec, normal, pts, mask, thresh):
     for t, n in ((mean, "mean"), (qvec, "qvec"), (svec, "svec"), (normal, "normal"), (pts, "pts")):
         _f(t, n)
     _b(mask, "mask")
-    with torch.cuda.device(mean.device):
-        _capi.load().culling_gaussian_bsphere(mean.size(0), _p(mean), _p(qvec), _p(svec), _p(normal),
+    with _guard(mean):
+        _load().culling_gaussian_bsphere(mean.size(0), _p(mean), _p(qvec), _p(svec), _p(normal),
                                               _p(pts), _p(mask), float(thresh), _stream(mean))
 
 
@@ -78,14 +111,15 @@ def tile_culling_aabb_start_end(aabb_topleft, aabb_bottomright, gaussian_ids, st
     _i(gaussian_ids, "gaussian_ids"); _i(start, "start"); _i(end, "end")
     _f(depth, "depth")
     N, D = aabb_topleft.size(0), gaussian_ids.size(0)
-    lib = _capi.load()
-    with torch.cuda.device(depth.device):
+    lib = _load()
+    with _guard(depth):
         nbytes = lib.tile_culling_workspace_bytes(N, D, int(n_tiles_h) * int(n_tiles_w))
         ws = torch.empty(nbytes, dtype=torch.uint8, device=depth.device)
         lib.tile_culling_aabb_start_end(N, D, int(n_tiles_h), int(n_tiles_w), _p(aabb_topleft),
                                         _p(aabb_bottomright), _p(depth), _p(gaussian_ids), _p(start),
                                         _p(end), _p(ws), nbytes, _stream(depth))
-        ws.record_stream(torch.cuda.current_stream(depth.device))
+        if ws.is_cuda:
+            ws.record_stream(torch.cuda.current_stream(depth.device))
 
 
 def _fwd_common(mean, cov, col, alpha, start, end, gaussian_ids, out, topleft, colname):
@@ -101,8 +135,8 @@ def tile_based_vol_rendering_start_end_with_T(mean, cov, color, alpha, start, en
     are written in place."""
     _fwd_common(mean, cov, color, alpha, start, end, gaussian_ids, out, topleft, "color")
     _f(T, "T")
-    with torch.cuda.device(mean.device):
-        _capi.load().vol_render_start_end_with_T(
+    with _guard(mean):
+        _load().vol_render_start_end_with_T(
             mean.size(0), gaussian_ids.size(0), _p(mean), _p(cov), _p(color), _p(alpha), _p(start),
             _p(end), _p(gaussian_ids), _p(out), _p(topleft), int(tile_size), int(n_tiles_h),
             int(n_tiles_w), float(pixel_size_x), float(pixel_size_y), int(H), int(W), float(thresh),
@@ -114,8 +148,8 @@ def tile_based_vol_rendering_start_end(mean, cov, color, alpha, start, end, gaus
                                        W, thresh):
     """render.h:65 / render.cu:400-424 (no T output)."""
     _fwd_common(mean, cov, color, alpha, start, end, gaussian_ids, out, topleft, "color")
-    with torch.cuda.device(mean.device):
-        _capi.load().vol_render_start_end_with_T(
+    with _guard(mean):
+        _load().vol_render_start_end_with_T(
             mean.size(0), gaussian_ids.size(0), _p(mean), _p(cov), _p(color), _p(alpha), _p(start),
             _p(end), _p(gaussian_ids), _p(out), _p(topleft), int(tile_size), int(n_tiles_h),
             int(n_tiles_w), float(pixel_size_x), float(pixel_size_y), int(H), int(W), float(thresh),
@@ -131,8 +165,8 @@ def tile_based_vol_rendering_backward_start_end(mean, cov, color, alpha, start, 
     for t, n in ((grad_mean, "grad_mean"), (grad_cov, "grad_cov"), (grad_color, "grad_color"),
                  (grad_alpha, "grad_alpha"), (grad_out, "grad_out")):
         _f(t, n)
-    with torch.cuda.device(mean.device):
-        _capi.load().vol_render_backward_start_end(
+    with _guard(mean):
+        _load().vol_render_backward_start_end(
             mean.size(0), gaussian_ids.size(0), _p(mean), _p(cov), _p(color), _p(alpha), _p(start),
             _p(end), _p(gaussian_ids), _p(out), _p(grad_mean), _p(grad_cov), _p(grad_color),
             _p(grad_alpha), _p(grad_out), _p(topleft), int(tile_size), int(n_tiles_h), int(n_tiles_w),
@@ -145,8 +179,8 @@ def tile_based_vol_rendering_scalar(mean, cov, scalar, alpha, start, end, gaussi
     """render.h:131 / render.cu:928-954."""
     _fwd_common(mean, cov, scalar, alpha, start, end, gaussian_ids, out, topleft, "scalar")
     _f(T, "T")
-    with torch.cuda.device(mean.device):
-        _capi.load().vol_render_scalar(
+    with _guard(mean):
+        _load().vol_render_scalar(
             mean.size(0), gaussian_ids.size(0), _p(mean), _p(cov), _p(scalar), _p(alpha), _p(start),
             _p(end), _p(gaussian_ids), _p(out), _p(topleft), int(tile_size), int(n_tiles_h),
             int(n_tiles_w), float(pixel_size_x), float(pixel_size_y), int(H), int(W), float(thresh),
@@ -162,8 +196,8 @@ def tile_based_vol_rendering_scalar_backward(mean, cov, scalar, alpha, start, en
     for t, n in ((grad_mean, "grad_mean"), (grad_cov, "grad_cov"), (grad_scalar, "grad_scalar"),
                  (grad_alpha, "grad_alpha"), (grad_out, "grad_out")):
         _f(t, n)
-    with torch.cuda.device(mean.device):
-        _capi.load().vol_render_scalar_backward(
+    with _guard(mean):
+        _load().vol_render_scalar_backward(
             mean.size(0), gaussian_ids.size(0), _p(mean), _p(cov), _p(scalar), _p(alpha), _p(start),
             _p(end), _p(gaussian_ids), _p(out), _p(grad_mean), _p(grad_cov), _p(grad_scalar),
             _p(grad_alpha), _p(grad_out), _p(topleft), int(tile_size), int(n_tiles_h), int(n_tiles_w),
@@ -178,8 +212,8 @@ def _sh_fwd(mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out, topleft,
         _f(bg_rgb, "bg_rgb")
     if int(C) < 1 or int(C) > 4:
         return  # the reference's switch silently does nothing (render.cu:507-544)
-    with torch.cuda.device(mean.device):
-        _capi.load().vol_render_sh(
+    with _guard(mean):
+        _load().vol_render_sh(
             mean.size(0), gaussian_ids.size(0), _p(mean), _p(cov), _p(sh_coeffs), _p(alpha), _p(start),
             _p(end), _p(gaussian_ids), _p(out), _p(topleft), _p(c2w), int(tile_size), int(n_tiles_h),
             int(n_tiles_w), float(pixel_size_x), float(pixel_size_y), int(H), int(W), int(C),
@@ -198,8 +232,8 @@ def _sh_bwd(mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out, grad_mea
         _f(bg_rgb, "bg_rgb")
     if int(C) < 1 or int(C) > 4:
         return
-    with torch.cuda.device(mean.device):
-        _capi.load().vol_render_backward_sh(
+    with _guard(mean):
+        _load().vol_render_backward_sh(
             mean.size(0), gaussian_ids.size(0), _p(mean), _p(cov), _p(sh_coeffs), _p(alpha), _p(start),
             _p(end), _p(gaussian_ids), _p(out), _p(grad_mean), _p(grad_cov), _p(grad_sh_coeffs),
             _p(grad_alpha), _p(grad_out), _p(topleft), _p(c2w), int(tile_size), int(n_tiles_h),
@@ -324,8 +358,8 @@ def count_num_gaussians_each_tile(mean, cov, topleft, tile_size, n_tiles_h, n_ti
                                   num_gaussians, thresh):
     """render.h:7 / render.cu:46-70: num_gaussians[tile] += #Gaussians whose value at a tile corner > thresh."""
     _f(mean, "mean"); _f(cov, "cov"); _f(topleft, "topleft"); _i(num_gaussians, "num_gaussians")
-    with torch.cuda.device(mean.device):
-        _capi.load().legacy_count_tiles(0, mean.size(0), _p(mean), _p(cov), _p(topleft), int(tile_size), int(n_tiles_h),
+    with _guard(mean):
+        _load().legacy_count_tiles(0, mean.size(0), _p(mean), _p(cov), _p(topleft), int(tile_size), int(n_tiles_h),
                                         int(n_tiles_w), float(pixel_size_x), float(pixel_size_y), float(thresh),
                                         _p(num_gaussians), _stream(mean))
 
@@ -334,8 +368,8 @@ def count_num_gaussians_each_tile_bcircle(mean, radius, topleft, tile_size, n_ti
                                           pixel_size_y, num_gaussians):
     """render.h:13 / render.cu:73-97: the bounding-circle membership test."""
     _f(mean, "mean"); _f(radius, "radius"); _f(topleft, "topleft"); _i(num_gaussians, "num_gaussians")
-    with torch.cuda.device(mean.device):
-        _capi.load().legacy_count_tiles(1, mean.size(0), _p(mean), _p(radius), _p(topleft), int(tile_size),
+    with _guard(mean):
+        _load().legacy_count_tiles(1, mean.size(0), _p(mean), _p(radius), _p(topleft), int(tile_size),
                                         int(n_tiles_h), int(n_tiles_w), float(pixel_size_x), float(pixel_size_y), 0.0,
                                         _p(num_gaussians), _stream(mean))
 
@@ -345,15 +379,16 @@ def _image_sort(mode, gaussian_ids, tiledepth, depth, tile_n_gaussians, offset, 
     _i(gaussian_ids, "gaussian_ids"); _d(tiledepth, "tiledepth"); _f(depth, "depth")
     _i(tile_n_gaussians, "tile_n_gaussians"); _i(offset, "offset"); _f(mean, "mean")
     _f(shape, "cov" if mode == 0 else "radius"); _f(topleft, "topleft")
-    lib = _capi.load()
+    lib = _load()
     N, D, T = mean.size(0), tiledepth.size(0), int(n_tiles_h) * int(n_tiles_w)
-    with torch.cuda.device(mean.device):
+    with _guard(mean):
         nbytes = lib.legacy_sort_workspace_bytes(D, T)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=mean.device)
         lib.legacy_image_sort(mode, N, D, _p(gaussian_ids), _p(tiledepth), _p(depth), _p(tile_n_gaussians), _p(offset),
                               _p(mean), _p(shape), _p(topleft), int(tile_size), int(n_tiles_h), int(n_tiles_w),
                               float(pixel_size_x), float(pixel_size_y), float(thresh), _p(ws), nbytes, _stream(mean))
-        ws.record_stream(torch.cuda.current_stream(mean.device))
+        if ws.is_cuda:
+            ws.record_stream(torch.cuda.current_stream(mean.device))
 
 
 def prepare_image_sort(gaussian_ids, tiledepth, depth, tile_n_gaussians, offset, mean, radius, topleft, tile_size,

@@ -1,20 +1,17 @@
-"""autograd surface of the rasterizer, mirroring gs/renderer.py of the reference.
+"""Host side of the rasterizer above the `_gs` mirror.
 
-`render_with_T`, `render_scalar`, `render_sh`, `render_sh_bg`, `render_start_end` have the
-argument lists, return shapes, saved tensors and backward outputs of the reference's
-torch.autograd.Functions (gs/renderer.py:424-1291); `project_gaussians` and
-`tile_culling_aabb_count` replace the reference's PyTorch implementations
+`project_gaussians` and `tile_culling_aabb_count` replace the reference's PyTorch implementations
 (gs/renderer.py:391-421, gs/culling.py:8-37) with the HIP kernels and keep their signatures.
-`render_frame` is the additive fused path (cull -> project -> bin/sort -> composite, no host
-sync) used by bench.py and FrameRenderer.
+`render_rgb_heads` fuses render_one's four compositing passes; `render_frame` is the additive fused path
+(cull -> project -> bin/sort -> composite, no host sync) used by bench.py, BatchRenderer and the tests.
+The reference's compositing autograd.Functions (gs/renderer.py:424-1283) are deliberately not re-typed here: they
+are the reference's Python and run unmodified on gsgen_amd._gs (tests/test_reference_python_on_mirror.py).
 """
-import math
 
 import numpy as np
 import torch
 
 from . import _capi
-from . import _gs as _backend
 
 
 def _stream(t):
@@ -92,164 +89,10 @@ def tile_culling_aabb_count(mean, cov, tile_size, camera_info, D, sync=True):
 
 
 # ---------------------------------------------------------------------------------------------
-# compositing autograd Functions (gs/renderer.py:517-1283)
+# fused RGB + auxiliary heads (additive; the reference's own six autograd.Functions of gs/renderer.py:424-1283 are
+# NOT restated here: a user of the reference keeps them and only swaps `_gs` -- tests/test_reference_python_on_mirror.py
+# runs them, imported from the reference, on this package's mirror)
 # ---------------------------------------------------------------------------------------------
-class _render_with_T(torch.autograd.Function):
-    """gs/renderer.py:1135-1283"""
-
-    @staticmethod
-    def forward(ctx, mean, cov, scalar, alpha, start, end, gaussian_ids, topleft, tile_size, n_tiles_h,
-                n_tiles_w, pixel_size_x, pixel_size_y, H, W, thresh, bg):
-        out = torch.zeros([H, W, 3], dtype=torch.float32, device=mean.device)
-        T = torch.ones_like(out[..., :1])
-        _backend.tile_based_vol_rendering_start_end_with_T(
-            mean, cov, scalar, alpha, start, end, gaussian_ids, out, topleft, tile_size, n_tiles_h,
-            n_tiles_w, pixel_size_x, pixel_size_y, H, W, thresh, T)
-        out = out + T * bg
-        ctx.save_for_backward(mean, cov, scalar, alpha, start, end, gaussian_ids, out, topleft, T)
-        ctx.const = [tile_size, n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H, W, thresh]
-        return out
-
-    @staticmethod
-    def backward(ctx, grad):
-        mean, cov, color, alpha, start, end, gaussian_ids, out, topleft, T = ctx.saved_tensors
-        grad = grad.contiguous()
-        grad_mean = torch.zeros_like(mean)
-        grad_cov = torch.zeros_like(cov)
-        grad_color = torch.zeros_like(color)
-        grad_alpha = torch.zeros_like(alpha)
-        tile_size, n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H, W, thresh = ctx.const
-        _backend.tile_based_vol_rendering_backward_start_end(
-            mean, cov, color, alpha, start, end, gaussian_ids, out, grad_mean, grad_cov, grad_color,
-            grad_alpha, grad, topleft, tile_size, n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H,
-            W, thresh)
-        return (grad_mean, grad_cov, grad_color, grad_alpha) + (None,) * 12 + (
-            torch.nan_to_num(grad * T),)
-
-
-class _render_start_end(torch.autograd.Function):
-    """gs/renderer.py:517-672 (`render_start_end`): flat [H*W*3] output, no background."""
-
-    @staticmethod
-    def forward(ctx, mean, cov, color, alpha, start, end, gaussian_ids, topleft, tile_size, n_tiles_h,
-                n_tiles_w, pixel_size_x, pixel_size_y, H, W, thresh):
-        out = torch.zeros([H * W * 3], dtype=torch.float32, device=mean.device)
-        _backend.tile_based_vol_rendering_start_end(
-            mean, cov, color, alpha, start, end, gaussian_ids, out, topleft, tile_size, n_tiles_h,
-            n_tiles_w, pixel_size_x, pixel_size_y, H, W, thresh)
-        ctx.save_for_backward(mean, cov, color, alpha, start, end, gaussian_ids, out, topleft)
-        ctx.const = [tile_size, n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H, W, thresh]
-        return out
-
-    @staticmethod
-    def backward(ctx, grad):
-        mean, cov, color, alpha, start, end, gaussian_ids, out, topleft = ctx.saved_tensors
-        grad = grad.contiguous()
-        grad_mean = torch.zeros_like(mean)
-        grad_cov = torch.zeros_like(cov)
-        grad_color = torch.zeros_like(color)
-        grad_alpha = torch.zeros_like(alpha)
-        tile_size, n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H, W, thresh = ctx.const
-        _backend.tile_based_vol_rendering_backward_start_end(
-            mean, cov, color, alpha, start, end, gaussian_ids, out, grad_mean, grad_cov, grad_color,
-            grad_alpha, grad, topleft, tile_size, n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H,
-            W, thresh)
-        return (grad_mean, grad_cov, grad_color, grad_alpha) + (None,) * 12
-
-
-class _render_scalar(torch.autograd.Function):
-    """gs/renderer.py:999-1132.  T is the caller's [H,W,1] tensor, overwritten in place."""
-
-    @staticmethod
-    def forward(ctx, mean, cov, scalar, alpha, start, end, gaussian_ids, topleft, tile_size, n_tiles_h,
-                n_tiles_w, pixel_size_x, pixel_size_y, H, W, thresh, T):
-        out = torch.zeros([H * W], dtype=torch.float32, device=mean.device)
-        scalar = scalar.contiguous()
-        _backend.tile_based_vol_rendering_scalar(
-            mean, cov, scalar, alpha, start, end, gaussian_ids, out, topleft, tile_size, n_tiles_h,
-            n_tiles_w, pixel_size_x, pixel_size_y, H, W, thresh, T)
-        ctx.save_for_backward(mean, cov, scalar, alpha, start, end, gaussian_ids, out, topleft)
-        ctx.const = [tile_size, n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H, W, thresh]
-        return out
-
-    @staticmethod
-    def backward(ctx, grad):
-        mean, cov, scalar, alpha, start, end, gaussian_ids, out, topleft = ctx.saved_tensors
-        grad = grad.contiguous()
-        grad_mean = torch.zeros_like(mean)
-        grad_cov = torch.zeros_like(cov)
-        grad_scalar = torch.zeros_like(scalar)
-        grad_alpha = torch.zeros_like(alpha)
-        tile_size, n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H, W, thresh = ctx.const
-        _backend.tile_based_vol_rendering_scalar_backward(
-            mean, cov, scalar, alpha, start, end, gaussian_ids, out, grad_mean, grad_cov, grad_scalar,
-            grad_alpha, grad, topleft, tile_size, n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H,
-            W, thresh)
-        return (grad_mean, grad_cov, grad_scalar, grad_alpha) + (None,) * 13
-
-
-class _render_sh(torch.autograd.Function):
-    """gs/renderer.py:674-830"""
-
-    @staticmethod
-    def forward(ctx, mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, topleft, c2w, tile_size,
-                n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H, W, C, thresh):
-        out = torch.zeros([H * W * 3], dtype=torch.float32, device=mean.device)
-        _backend.tile_based_vol_rendering_sh(
-            mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out, topleft, c2w, tile_size,
-            n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H, W, C, thresh)
-        ctx.save_for_backward(mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out, topleft, c2w)
-        ctx.const = [tile_size, n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H, W, C, thresh]
-        return out
-
-    @staticmethod
-    def backward(ctx, grad):
-        mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out, topleft, c2w = ctx.saved_tensors
-        grad = grad.contiguous()
-        grad_mean = torch.zeros_like(mean)
-        grad_cov = torch.zeros_like(cov)
-        grad_sh = torch.zeros_like(sh_coeffs)
-        grad_alpha = torch.zeros_like(alpha)
-        tile_size, n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H, W, C, thresh = ctx.const
-        _backend.tile_based_vol_rendering_backward_sh(
-            mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out, grad_mean, grad_cov, grad_sh,
-            grad_alpha, grad, topleft, c2w, tile_size, n_tiles_h, n_tiles_w, pixel_size_x,
-            pixel_size_y, H, W, C, thresh)
-        return (grad_mean, grad_cov, grad_sh, grad_alpha) + (None,) * 14
-
-
-class _render_sh_bg(torch.autograd.Function):
-    """gs/renderer.py:833-996"""
-
-    @staticmethod
-    def forward(ctx, mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, topleft, c2w, tile_size,
-                n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H, W, C, thresh, bg_rgb):
-        out = torch.zeros([H * W * 3], dtype=torch.float32, device=mean.device)
-        _backend.tile_based_vol_rendering_sh_with_bg(
-            mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out, topleft, c2w, tile_size,
-            n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H, W, C, thresh, bg_rgb)
-        ctx.save_for_backward(mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out, topleft, c2w,
-                              bg_rgb)
-        ctx.const = [tile_size, n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H, W, C, thresh]
-        return out
-
-    @staticmethod
-    def backward(ctx, grad):
-        (mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out, topleft, c2w,
-         bg_rgb) = ctx.saved_tensors
-        grad = grad.contiguous()
-        grad_mean = torch.zeros_like(mean)
-        grad_cov = torch.zeros_like(cov)
-        grad_sh = torch.zeros_like(sh_coeffs)
-        grad_alpha = torch.zeros_like(alpha)
-        tile_size, n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H, W, C, thresh = ctx.const
-        _backend.tile_based_vol_rendering_backward_sh_with_bg(
-            mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out, grad_mean, grad_cov, grad_sh,
-            grad_alpha, grad, topleft, c2w, tile_size, n_tiles_h, n_tiles_w, pixel_size_x,
-            pixel_size_y, H, W, C, thresh, bg_rgb)
-        return (grad_mean, grad_cov, grad_sh, grad_alpha) + (None,) * 15
-
-
 class _render_rgb_heads(torch.autograd.Function):
     """RGB + depth + opacity + depth^2 in ONE compositing pass: replaces the
     render_with_T + 3x render_scalar sequence of gs/gaussian_splatting.py:1304-1403.  Returns
@@ -300,12 +143,6 @@ def render_rgb_heads(mean, cov, color, depth, alpha, start, end, gaussian_ids, t
     return _render_rgb_heads.apply(mean, cov, color, depth, alpha, start, end, gaussian_ids, topleft, n_tiles_h,
                                    n_tiles_w, pixel_size_x, pixel_size_y, H, W, thresh, bg, tile_order)
 
-
-render_start_end = _render_start_end.apply
-render_sh = _render_sh.apply
-render_sh_bg = _render_sh_bg.apply
-render_scalar = _render_scalar.apply
-render_with_T = _render_with_T.apply
 
 
 # ---------------------------------------------------------------------------------------------

@@ -51,7 +51,8 @@ def test_reference_call_sequence_render_one():
     assert np.array_equal(gaussian_ids.cpu().numpy(), g["ids"])
     img_topleft = torch.FloatTensor([-ci.cx / ci.fx, -ci.cy / ci.fy]).to(dev())
     bg = torch.rand(H, W, 3, device=dev(), requires_grad=True)
-    out = R.render_with_T(mean2d, cov, color, alpha, start, end, gaussian_ids, img_topleft, 16, nth, ntw,
+    import ref_autograd
+    out = ref_autograd.render_with_T(mean2d, cov, color, alpha, start, end, gaussian_ids, img_topleft, 16, nth, ntw,
                           1.0 / ci.fx, 1.0 / ci.fy, H, W, 1e-4, bg)
     m = g["mask"]
     ref, refT = O.render_rgb_fwd(g["mean2d"], g["cov2d"], sc["color"][m], sc["alpha"][m], g["start"], g["end"],
@@ -74,7 +75,7 @@ def test_reference_call_sequence_render_one():
     assert np.abs(bg.grad.cpu().numpy() - go.cpu().numpy() * refT).max() <= 1e-4
     # scalar heads exactly as render_one calls them (depth, opacity, z^2)
     T = torch.ones([H, W, 1], device=dev())
-    d_img = R.render_scalar(mean2d, cov, depth, alpha, start, end, gaussian_ids, img_topleft, 16, nth, ntw,
+    d_img = ref_autograd.render_scalar(mean2d, cov, depth, alpha, start, end, gaussian_ids, img_topleft, 16, nth, ntw,
                             1.0 / ci.fx, 1.0 / ci.fy, H, W, 1e-4, T).reshape(H, W)
     rd, _ = O.render_scalar_fwd(g["mean2d"], g["cov2d"], g["depth"].ravel(), sc["alpha"][m], g["start"], g["end"],
                                 g["ids"], cam.topleft, 1 / cam.fx, 1 / cam.fy, H, W)
@@ -119,7 +120,7 @@ def test_fused_frame_matches_oracle(C):
         ref, _ = O.render_rgb_fwd(g["mean2d"], g["cov2d"], sc["color"][m], sc["alpha"][m], g["start"], g["end"],
                                   g["ids"], cam.topleft, 1 / cam.fx, 1 / cam.fy, H, W)
     err = np.abs(rgb.detach().cpu().numpy() - ref)
-    assert (err.max(-1) > 1e-4).mean() <= (1e-4 if C > 0 else 0.0)
+    assert err.max() <= 1e-4  # every pixel
     go = torch.randn_like(rgb)
     (rgb * go).sum().backward()
     if C > 0:
@@ -497,7 +498,7 @@ def test_full_size_cfg2():
     ref = O.render_sh_fwd(g["mean2d"], g["cov2d"], sc["sh"][m], sc["alpha"][m], g["start"], g["end"], g["ids"],
                           cam.topleft, rot, 4, 1 / 800, 1 / 800, 800, 800, bg=bg.cpu().numpy())
     err = np.abs(rgb.detach().cpu().numpy() - ref).max(-1)
-    assert (err > 1e-4).mean() <= 1e-4, f"{(err > 1e-4).sum()} px off, max {err.max()}"
+    assert err.max() <= 1e-4, f"{(err > 1e-4).sum()} px off, max {err.max()}"  # every pixel (north_star)
     go = torch.randn_like(rgb)
     (rgb * go).sum().backward()
     g1 = {k: P[k].grad.clone() for k in P}

@@ -99,12 +99,12 @@ def test_hip_path_reproduces_reference_golden(path):
         L.vol_render_sh(N, D, p(m2), p(c2), p(sh), p(al), p(st), p(en), p(ids), p(img), p(topleft), p(rot), 16, nth, ntw,
                         1 / fx, 1 / fy, h, w, C, 1e-4, p(bg), None, s)
         err = np.abs(img.cpu().numpy() - g[tag + "_img"]).max(-1)
-        assert (err > 1e-4).mean() <= 1e-4 and err.max() <= 0.0045, tag
+        assert err.max() <= 1e-4, (tag, float(err.max()), int((err > 1e-4).sum()))  # every pixel (north_star)
         gm = torch.zeros(N, 2, device=dev()); gc = torch.zeros(N, 2, 2, device=dev())
         gsh = torch.zeros(N, 3, C * C, device=dev()); ga = torch.zeros(N, device=dev())
         L.vol_render_backward_sh(N, D, p(m2), p(c2), p(sh), p(al), p(st), p(en), p(ids), p(T_(g[tag + "_img"])), p(gm),
                                  p(gc), p(gsh), p(ga), p(go), p(topleft), p(rot), 16, nth, ntw, 1 / fx, 1 / fy, h, w, C,
                                  1e-4, p(bg), s)
-        tol = 1e-3 if err.max() <= 1e-4 else 5e-3
+        tol = 1e-3
         for a, k in ((gm, "_gmean"), (gc, "_gcov"), (gsh, "_gsh"), (ga, "_galpha")):
             assert rel(a.cpu().numpy(), g[tag + k]) < tol, tag + k

@@ -223,12 +223,12 @@ def test_sh_forward_backward(case, use_bg):
     ref = O.render_sh_fwd(g["mean2d"], g["cov2d"], sc["sh"][m], sc["alpha"][m], g["start"], g["end"], g["ids"],
                           cam.topleft, rot, C, 1 / cam.fx, 1 / cam.fy, H, W, bg=bg)
     err = np.abs(out.cpu().numpy() - ref)
-    # the reference evaluates this path in fp32: a pixel whose a*G sits within fp32 rounding of
-    # the 1/255 skip threshold may legitimately flip.  Allow at most 1e-4 of
-    # the pixels to exceed the tolerance, and none by more than one skipped splat (1/255 * 1.0).
+    # north_star: pixel for pixel within 1e-4.  The reference evaluates this path in fp32 and skips a splat when
+    # a*G < 1/255 -- a discontinuity of up to 1/255 in the image; the kernel re-evaluates any a*G within 2e-4
+    # (relative) of the threshold with the reference's own arithmetic, so the decision is the reference's: no
+    # pixel may exceed the tolerance.
     bad = (err.max(axis=-1) > IMG_TOL)
-    assert bad.mean() <= 1e-4, f"{bad.sum()} pixels off"
-    assert err.max() <= 0.0045
+    assert bad.sum() == 0, f"{bad.sum()} pixels off, max {err.max()} at {np.argwhere(bad)[:4].tolist()}"
     go = np.random.default_rng(10).normal(size=(H, W, 3)).astype(np.float32)
     N = h["N"]
     gm = torch.zeros(N, 2, device=dev()); gc = torch.zeros(N, 2, 2, device=dev())
