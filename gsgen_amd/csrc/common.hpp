@@ -22,6 +22,9 @@ constexpr float kGuardTol = 2.0e-4f;
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 
+// two packed fp32 values: arithmetic on v2f lowers to v_pk_mul / v_pk_add / v_pk_fma_f32
+typedef float v2f __attribute__((vector_size(8)));
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
@@ -155,6 +158,61 @@ __device__ __forceinline__ void wave_reduce_scatter(float (&v)[P]) {
   reduce_scatter_level<P, 0>(v);
 }
 
+// The same reduce-scatter on components held as (even, odd) pairs: v2[i] = (v[2i], v[2i+1]).  The exchanges are
+// per register as above, but the adds of a pair are one v_pk_add_f32 (packed fp32 adds issue at the rate of scalar
+// ones on gfx950), which halves the add count of the levels that still hold two or more components per lane.
+template <int H>
+__device__ __forceinline__ v2f xchg_add2(v2f lo, v2f hi) {
+  if constexpr (H == 32) {
+    const auto a = __builtin_amdgcn_permlane32_swap(as_u(lo[0]), as_u(hi[0]), false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(as_u(lo[1]), as_u(hi[1]), false, false);
+    return v2f{as_f(a[0]), as_f(b[0])} + v2f{as_f(a[1]), as_f(b[1])};
+  } else if constexpr (H == 16) {
+    const auto a = __builtin_amdgcn_permlane16_swap(as_u(lo[0]), as_u(hi[0]), false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(as_u(lo[1]), as_u(hi[1]), false, false);
+    return v2f{as_f(a[0]), as_f(b[0])} + v2f{as_f(a[1]), as_f(b[1])};
+  } else if constexpr (H == 8) {
+    const v2f t = {dpp_mov<kDppRowShl + 8, 0x3>(hi[0], lo[0]), dpp_mov<kDppRowShl + 8, 0x3>(hi[1], lo[1])};
+    const v2f u = {dpp_mov<kDppRowShr + 8, 0xC>(lo[0], hi[0]), dpp_mov<kDppRowShr + 8, 0xC>(lo[1], hi[1])};
+    return t + u;
+  } else if constexpr (H == 4) {
+    const v2f t = {dpp_mov<kDppRowShl + 4, 0x5>(hi[0], lo[0]), dpp_mov<kDppRowShl + 4, 0x5>(hi[1], lo[1])};
+    const v2f u = {dpp_mov<kDppRowShr + 4, 0xA>(lo[0], hi[0]), dpp_mov<kDppRowShr + 4, 0xA>(lo[1], hi[1])};
+    return t + u;
+  } else {
+    static_assert(H == 2 || H == 1, "H must be a power of two <= 32");
+    constexpr int ctrl = (H == 2) ? kDppQuadXor2 : kDppQuadXor1;
+    const v2f a = lo + v2f{dpp_mov<ctrl, 0xf>(lo[0], lo[0]), dpp_mov<ctrl, 0xf>(lo[1], lo[1])};
+    const v2f b = hi + v2f{dpp_mov<ctrl, 0xf>(hi[0], hi[0]), dpp_mov<ctrl, 0xf>(hi[1], hi[1])};
+    return (lane_id() & H) ? b : a;
+  }
+}
+// v2[0 .. P/2): on return v2[0][0] in lane l holds the wave-wide total of component scatter_comp<P>(l), exactly as
+// wave_reduce_scatter<P> leaves it in v[0] (same exchange order, same owners).
+template <int P, int K>
+__device__ __forceinline__ void reduce_scatter2_level(v2f (&v2)[P / 2]) {
+  if constexpr (K < 6) {
+    constexpr int L = kLaneDist[K];
+    if constexpr (K < ilog2c(P)) {
+      constexpr int S = P >> (K + 1);  // live components after this level
+      if constexpr (S >= 2) {
+#pragma unroll
+        for (int i = 0; i < S / 2; ++i) v2[i] = xchg_add2<L>(v2[i], v2[i + S / 2]);
+      } else {
+        v2[0][0] = xchg_add<L>(v2[0][0], v2[0][1]);
+      }
+    } else {
+      v2[0][0] = xchg_add<L>(v2[0][0], v2[0][0]);
+    }
+    reduce_scatter2_level<P, K + 1>(v2);
+  }
+}
+template <int P>
+__device__ __forceinline__ void wave_reduce_scatter2(v2f (&v2)[P / 2]) {
+  static_assert(P >= 2 && P <= 64 && (P & (P - 1)) == 0, "P must be a power of two, 2..64");
+  reduce_scatter2_level<P, 0>(v2);
+}
+
 // Only the log2(P) halving levels: every lane ends with the partial sum of component
 // scatter_comp<P>(lane) over the lanes that agree with it on the remaining lane bits (64 / P
 // partials per component, to be combined by the caller -- e.g. by the atomics that follow anyway).
@@ -228,9 +286,20 @@ __device__ __forceinline__ float read_lane(float v, int lane) {
 // on MI355X (profiles/r01_notes.md): packed SH dot products beat scalar FMA pairs by ~11 % on
 // the compositing backward (fewer issue slots), although an isolated dependent-chain
 // microbenchmark of v_pk_fma_f32 suggests otherwise.
-typedef float v2f __attribute__((vector_size(8)));
 __device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return a * b + c; }
 __device__ __forceinline__ v2f splat2(float a) { return v2f{a, a}; }
+// Explicitly fused multiply-adds (one rounding), scalar and packed: used where forward and backward kernels must
+// produce the same bits from the same inputs whatever the surrounding code looks like (the Gaussian evaluation
+// that decides "skip" and "saturated"), instead of leaving the choice of what to contract to the compiler.  The CPU
+// emulator build (g++, -ffp-contract=off) takes the fmaf form, which is the same arithmetic.
+__device__ __forceinline__ float ffma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ v2f ffma2(v2f a, v2f b, v2f c) {
+#if defined(__clang__)
+  return __builtin_elementwise_fma(a, b, c);
+#else
+  return v2f{__builtin_fmaf(a[0], b[0], c[0]), __builtin_fmaf(a[1], b[1], c[1])};
+#endif
+}
 
 // Workgroup -> tile map that is both XCD-local and XCD-balanced.  Workgroup b runs on XCD
 // b % 8 (observed dispatch, speed only).  The tile grid is cut into 4x4-tile super-tiles;

@@ -31,6 +31,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <string>
+#include <type_traits>
 #include <vector>
 #include <gsgen_mfma.hpp>
 
@@ -47,7 +48,9 @@ struct Stage {
   alignas(16) float col[KB * TR::NCOLP];
 };
 
-template <int MODE, int CB, int NT, int KB = kBatch>
+// SCALE: the staged SH coefficients are pre-multiplied by -log2(e), so that the colour evaluation's
+// sigmoid(s) = 1 / (1 + exp2(-log2(e) s)) needs no multiply per (pixel, channel)
+template <int MODE, int CB, int NT, int KB = kBatch, bool SCALE = false>
 __device__ __forceinline__ void stage_batch(Stage<MODE, CB, KB> &S, const CompParams &p, int list_base,
                                             int nb) {
   using TR = Traits<MODE, CB>;
@@ -75,7 +78,8 @@ __device__ __forceinline__ void stage_batch(Stage<MODE, CB, KB> &S, const CompPa
     constexpr int Q = TR::NCOL / 4;
     for (int e = t; e < nb * Q; e += NT) {
       const int g = e / Q, k = e - g * Q;
-      const float4 v = *reinterpret_cast<const float4 *>(p.col + (size_t)S.id[g] * TR::NCOL + 4 * k);
+      float4 v = *reinterpret_cast<const float4 *>(p.col + (size_t)S.id[g] * TR::NCOL + 4 * k);
+      if constexpr (SCALE) { v.x *= -kLog2e; v.y *= -kLog2e; v.z *= -kLog2e; v.w *= -kLog2e; }
       *reinterpret_cast<float4 *>(&S.col[g * TR::NCOLP + 4 * k]) = v;
     }
   } else if constexpr (MODE == MODE_SH) {
@@ -83,7 +87,8 @@ __device__ __forceinline__ void stage_batch(Stage<MODE, CB, KB> &S, const CompPa
     for (int e = t; e < nb * TR::NCOL; e += NT) {
       const int g = e / TR::NCOL, k = e - g * TR::NCOL;
       const int c = k / TR::CC, kk = k - c * TR::CC;
-      S.col[g * TR::NCOLP + c * TR::CCP + kk] = p.col[(size_t)S.id[g] * TR::NCOL + k];
+      const float v = p.col[(size_t)S.id[g] * TR::NCOL + k];
+      S.col[g * TR::NCOLP + c * TR::CCP + kk] = SCALE ? -kLog2e * v : v;
     }
   } else {
     if (t < nb) {
@@ -274,7 +279,9 @@ __global__ void __launch_bounds__(256 / PPL) k_composite_fwd(CompParams p_arg, c
         }
 #pragma unroll
         for (int j = 0; j < PPL; ++j) {
-          const float om = con[j] ? (1.0f - r.a * G[j]) : 1.0f;
+          // explicit: 1 - round(a G) in every kernel (left to the compiler, `1 - a*G` becomes a fused -a*G + 1 in
+          // some instantiations and not in others, and forward and backward would disagree on T in the last bit)
+          const float om = ffma(-(r.a * G[j]), con[j] ? 1.0f : 0.0f, 1.0f);
           Tr[j] *= om;
           const bool still = alive[j] && !(Tr[j] < p.thresh);
           if (alive[j] && !still) stop[j] = base + g + 1;
@@ -288,7 +295,7 @@ __global__ void __launch_bounds__(256 / PPL) k_composite_fwd(CompParams p_arg, c
             const float coeff = (r.a * Tr[j]) * G[j];
 #pragma unroll
             for (int c = 0; c < NCH; ++c) acc[j][c] += cg[c] * coeff;
-            Tr[j] *= (1.0f - ag);
+            Tr[j] *= ffma(-ag, 1.0f, 1.0f);  // 1 - round(a G), never a fused -a*G + 1 (see the SH branch)
             alive[j] = !(Tr[j] < p.thresh);
           }
         }
@@ -540,7 +547,7 @@ k_composite_bwd_pixel(CompParams p_arg, const CompParams *__restrict__ plist) {
         gr[3] += h * vx * vy;
         gr[5] += h * vy * vy;
         gr[6] += pa * G[j];
-        const float om = con[j] ? (1.0f - ag[j]) : 1.0f;
+        const float om = ffma(-ag[j], con[j] ? 1.0f : 0.0f, 1.0f);  // as the forward: 1 - round(a G), explicit
         Tr[j] *= om;
         alive[j] = alive[j] && !(Tr[j] < p.thresh);
       }
@@ -565,6 +572,275 @@ k_composite_bwd_pixel(CompParams p_arg, const CompParams *__restrict__ plist) {
   }
 }
 
+
+// ============================================================================================
+// backward, SH, vector ALUs, packed per-pixel arithmetic (the default SH backward)
+// ============================================================================================
+// k_composite_bwd_pixel<MODE_SH> spends 890 VALU quad-cycles per (wavefront, list entry) at 4 pixels per lane
+// (profiles/r02_*): ~310 of them are the per-pixel scalar arithmetic (Gaussian, weights, suffix colour,
+// d/d(alpha G), mean / covariance terms) which is identical for the lane's pixels, 32 are transcendental (4 quads
+// each).  On gfx950 a packed fp32 instruction (v_pk_mul / v_pk_add / v_pk_fma) issues at the rate of a scalar one
+// (SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.11 quads for a stream that is a quarter packed), so this kernel
+//   * carries every per-pixel quantity as a PAIR of pixels (v2f) and does that arithmetic packed;
+//   * replaces the three selects per pixel (weight, 1 - aG, d/d(aG)) by one 0/1 mask multiplied in (exact);
+//   * keeps the suffix colour as one running value per channel (final - prefix) instead of final and prefix;
+//   * reads the coefficients pre-scaled by -log2(e) (stage_batch<SCALE>): no multiply in front of the exp2;
+//   * lays the 3 x CCP SH components out FIRST in the reduction vector, so that the (k, k+1) accumulator pairs of
+//     the packed FMAs are the (even, odd) pairs of wave_reduce_scatter2 (packed adds, no register moves).
+// The Gaussian evaluation is gauss_sh_pair: bit for bit gauss_eval<MODE_SH>, so "skip" and "saturated" decisions
+// equal the forward's.  Same launch shapes as k_composite_bwd_pixel (one workgroup per tile or per (tile, segment),
+// 256 / PPL threads); PPL = 4 (one wavefront per tile) or 2.
+#if defined(GSGEN_BWD_WAVES3)  // experiment build: three wavefronts per SIMD (168 registers), whatever it takes
+#define GSGEN_BWD_VEC_ATTR __attribute__((amdgpu_waves_per_eu(3, 3)))
+#else
+#define GSGEN_BWD_VEC_ATTR
+#endif
+template <int CB, int PPL, bool BATCH = false>
+__global__ void __launch_bounds__(256 / PPL) GSGEN_BWD_VEC_ATTR
+k_composite_bwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
+  static_assert(PPL == 4 || PPL == 2, "pixel pairs: 2 or 4 pixels per lane");
+  uint32_t bid = blockIdx.x, grid = gridDim.x;
+  const CompParams p = BATCH ? plist[batch_view(p_arg, bid, &grid)] : p_arg;  // see k_composite_fwd
+  constexpr int MODE = MODE_SH;
+  using TR = Traits<MODE, CB>;
+  constexpr int NT = 256 / PPL, ROWS = NT / 16, NP = PPL / 2;
+  constexpr int CCP = TR::CCP, NPAIR = TR::NPAIR, NSH = 3 * CCP;  // SH components incl. padding
+  constexpr int P = (NSH + 7) <= 32 ? 32 : 64;                    // reduction width: SH | mean 2 | cov 4 | alpha 1
+  static_assert(NSH % 2 == 0 && NSH + 7 <= P, "component layout");
+  __shared__ Stage<MODE, CB> S;
+
+  const int nseg = p.nseg > 1 ? p.nseg : 1;
+  const uint32_t tiles_grid = grid / (uint32_t)nseg;
+  const int seg = (int)(bid / tiles_grid);
+  int tx, ty;
+  if (!block_tile(p, tx, ty, bid % tiles_grid)) return;  // uniform over the workgroup
+  const int tile = ty * p.ntw + tx;
+  const int st = p.start[tile];
+  const int n = (st < 0) ? 0 : (p.end[tile] - st);
+  if (n == 0 || n < p.n_lo || n >= p.n_hi) return;
+  const int e_lo = seg * kSegLen;
+  const int e_hi = (seg == nseg - 1) ? n : min(n, e_lo + kSegLen);  // the last segment takes the rest
+  if (e_lo >= n) return;
+  const int t = (int)threadIdx.x;
+  const int lane = t & 63;
+  const int lx = t & 15, ly0 = t >> 4;
+  const int gx = tx * kTile + lx;
+  const float px = pixel_coord(p.topleft[0], gx, p.psx);
+
+  bool valid[PPL], alive[PPL];
+  int gy[PPL];
+  v2f py2[NP];
+#pragma unroll
+  for (int j = 0; j < PPL; ++j) {
+    gy[j] = ty * kTile + ly0 + j * ROWS;
+    valid[j] = (gx < p.W) && (gy[j] < p.H);
+    py2[j >> 1][j & 1] = pixel_coord(p.topleft[1], gy[j], p.psy);
+    alive[j] = valid[j];
+    if (nseg > 1) alive[j] = alive[j] && (p.stop[(size_t)tile * 256 + (ly0 + j * ROWS) * 16 + lx] > e_lo);
+  }
+  if (nseg > 1) {  // every pixel of the tile stopped before this segment?
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) any |= alive[j];
+    if (__syncthreads_or((int)any) == 0) return;
+  }
+  if constexpr (CCP != TR::CC) {  // zero the pad lanes of the staged coefficients once
+    for (int e = t; e < kBatch * TR::NCOLP; e += NT) S.col[e] = 0.0f;
+    __syncthreads();
+  }
+
+  // per-pixel SH basis as (k, k+1) pairs
+  v2f Yp[PPL][NPAIR];
+  {
+    float R[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = p.rot[i];
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) {
+      const float pyj = py2[j >> 1][j & 1];
+      float dx = R[0] * px + R[1] * pyj + R[2];
+      float dy = R[3] * px + R[4] * pyj + R[5];
+      float dz = R[6] * px + R[7] * pyj + R[8];
+      const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+      dx /= len; dy /= len; dz /= len;
+      float Yf[CCP];
+#pragma unroll
+      for (int k = 0; k < CCP; ++k) Yf[k] = 0.0f;
+      sh_basis<CB>(dx, dy, dz, *reinterpret_cast<float (*)[TR::CC]>(&Yf[0]));
+#pragma unroll
+      for (int k = 0; k < NPAIR; ++k) Yp[j][k] = v2f{Yf[2 * k], Yf[2 * k + 1]};
+      __builtin_amdgcn_sched_barrier(0);  // one pixel's temporaries at a time
+    }
+  }
+
+  // pixel pairs: element e of pair jp is pixel j = 2 jp + e.  rem = final - (prefix colour incl. the current
+  // splat): the suffix the reference forms as final - Cpre_incl (vol_render_sh.h:328-333)
+  v2f go2[NP][3], rem2[NP][3], Tr2[NP];
+#pragma unroll
+  for (int j = 0; j < PPL; ++j) {
+    const size_t pix = valid[j] ? ((size_t)gy[j] * p.W + gx) : 0;
+    float4 ck = make_float4(1.0f, 0.0f, 0.0f, 0.0f);  // state in front of entry e_lo: T, prefix rgb
+    if (seg > 0 && alive[j]) ck = p.ckpt[((size_t)tile * nseg + seg) * 256 + (ly0 + j * ROWS) * 16 + lx];
+    const float pre0[3] = {ck.y, ck.z, ck.w};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      go2[j >> 1][c][j & 1] = valid[j] ? p.grad_out[3 * pix + c] : 0.0f;
+      rem2[j >> 1][c][j & 1] = valid[j] ? p.final_img[3 * pix + c] - pre0[c] : 0.0f;
+    }
+    Tr2[j >> 1][j & 1] = ck.x;
+  }
+
+  for (int base = e_lo; base < e_hi; base += kBatch) {
+    const int nb = min(kBatch, e_hi - base);
+    if (base > e_lo) __syncthreads();
+    stage_batch<MODE, CB, NT, kBatch, true>(S, p, st + base, nb);
+    __syncthreads();
+
+    for (int g = 0; g < nb; ++g) {
+      bool any_alive = false;
+#pragma unroll
+      for (int j = 0; j < PPL; ++j) any_alive |= alive[j];
+      if (__ballot(any_alive) == 0ull) break;
+
+      // the record as plain scalars (a struct handed around by reference makes the compiler build the packed
+      // operands through scratch memory)
+      const float r_mx = S.mx[g], r_my = S.my[g], r_a = S.a[g], r_c0 = S.c0[g], r_c1 = S.c1[g], r_c2 = S.c2[g],
+                  r_c3 = S.c3[g], r_p0 = S.p0[g], r_p1 = S.p1[g];
+      const float x = px - r_mx;
+      v2f y2[NP], G2[NP], ag2[NP], conf2[NP];
+      bool any_con = false;
+#pragma unroll
+      for (int jp = 0; jp < NP; ++jp) {
+        y2[jp] = py2[jp] - splat2(r_my);
+        G2[jp] = gauss_sh_pair(r_c0, r_c1, r_c2, r_c3, r_p0, x, y2[jp]);
+        ag2[jp] = splat2(r_a) * G2[jp];
+        bool pair_con = false;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int j = 2 * jp + e;
+          // within rounding of the skip threshold: the reference's arithmetic decides (as gauss_eval)
+          if (alive[j] && fabsf(ag2[jp][e] - kMinAlpha) <= kMinAlpha * kGuardTol) {
+            G2[jp][e] = gauss_ref_f32(r_mx, r_my, r_c0, r_c1, r_c2, r_c3, px, py2[jp][e]);
+            ag2[jp][e] = r_a * G2[jp][e];
+          }
+          const bool con = alive[j] && !(ag2[jp][e] < kMinAlpha);
+          conf2[jp][e] = con ? 1.0f : 0.0f;
+          pair_con |= con;
+        }
+        any_con |= pair_con;
+      }
+      if (__ballot(any_con) == 0ull) continue;  // nobody in the wave sees this Gaussian
+
+      // reduction vector as (even, odd) pairs: SH components [0, NSH) | mean | cov | alpha | zeros
+      v2f gr2[P / 2];
+#pragma unroll
+      for (int i = NSH / 2; i < P / 2; ++i) gr2[i] = v2f{0.0f, 0.0f};
+      const float *cg = &S.col[g * TR::NCOLP];
+      v2f w2[NP], inv1m2[NP], pAG2[NP];
+#pragma unroll
+      for (int jp = 0; jp < NP; ++jp) {
+        w2[jp] = ((splat2(r_a) * Tr2[jp]) * G2[jp]) * conf2[jp];  // the forward's (a T) G, or 0
+        const v2f om = splat2(1.0f) - ag2[jp];
+        inv1m2[jp] = v2f{__builtin_amdgcn_rcpf(om[0]), __builtin_amdgcn_rcpf(om[1])};
+        pAG2[jp] = v2f{0.0f, 0.0f};
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        v2f q[NPAIR], gq[NPAIR];
+#pragma unroll
+        for (int k = 0; k < NPAIR; ++k) q[k] = *reinterpret_cast<const v2f *>(cg + c * CCP + 2 * k);
+        // one pixel pair: colours, suffix, d/d(a G), and its share of d/d(sh) (FIRST: it initialises the accumulators)
+        auto pair_colour = [&](auto JP, auto FIRST) {
+          constexpr int jp = decltype(JP)::value;
+          constexpr bool first = decltype(FIRST)::value;
+          // -log2(e) * (sh . Y) of the pair's two pixels: the two dot products interleaved (a v_pk_fma that depends
+          // on the previous instruction costs a wait state)
+          v2f sa = q[0] * Yp[2 * jp][0], sb = q[0] * Yp[2 * jp + 1][0];
+#pragma unroll
+          for (int k = 1; k < NPAIR; ++k) {
+            sa = fma2(q[k], Yp[2 * jp][k], sa);
+            sb = fma2(q[k], Yp[2 * jp + 1][k], sb);
+          }
+          const v2f sp = v2f{sa[0], sb[0]} + v2f{sa[1], sb[1]};
+          const v2f den = splat2(1.0f) + v2f{__builtin_amdgcn_exp2f(sp[0]), __builtin_amdgcn_exp2f(sp[1])};
+          const v2f yv = v2f{__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+          rem2[jp][c] = fma2(-w2[jp], yv, rem2[jp][c]);
+          const v2f dy = fma2(-yv, yv, yv);  // y (1 - y)
+          const v2f gs = (w2[jp] * dy) * go2[jp][c];
+          const v2f sfx = rem2[jp][c] * inv1m2[jp];
+          pAG2[jp] = fma2(go2[jp][c], fma2(yv, Tr2[jp], -sfx), pAG2[jp]);
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const v2f gse = splat2(gs[e]);
+            if (first && e == 0) {
+#pragma unroll
+              for (int k = 0; k < NPAIR; ++k) gq[k] = gse * Yp[2 * jp + e][k];
+            } else {
+#pragma unroll
+              for (int k = 0; k < NPAIR; ++k) gq[k] = fma2(gse, Yp[2 * jp + e][k], gq[k]);
+            }
+          }
+        };
+        // (skipping a pair none of whose pixels contributes -- a wave-uniform branch per pair and channel, ~1 pair in 5
+        // on the headline workload -- was measured: -1.5 % on a lone launch, +1 % with two batches in flight, 32 more
+        // registers; not kept)
+        pair_colour(std::integral_constant<int, 0>{}, std::true_type{});
+        if constexpr (NP > 1) pair_colour(std::integral_constant<int, NP - 1>{}, std::false_type{});
+#pragma unroll
+        for (int k = 0; k < NPAIR; ++k) gr2[c * NPAIR + k] = gq[k];
+      }
+      // mean2d (2) | cov2d (4) | alpha (1): kernel_gaussian_2d_backward (kernels.h:394-418), packed over the pair
+      // and summed over the lane's pairs; the two halves are added at the end
+      const float inv_det = r_p1;
+      v2f gm0 = {0.f, 0.f}, gm1 = gm0, gc0 = gm0, gc1 = gm0, gc3 = gm0, gal = gm0;
+#pragma unroll
+      for (int jp = 0; jp < NP; ++jp) {
+        const v2f pa = pAG2[jp] * conf2[jp];
+        const v2f gg = pa * ag2[jp];
+        const v2f vx = (splat2(x * r_c3) - y2[jp] * splat2(r_c2)) * splat2(inv_det);
+        const v2f vy = (y2[jp] * splat2(r_c0) - splat2(x * r_c1)) * splat2(inv_det);
+        gm0 = fma2(gg, vx, gm0);
+        gm1 = fma2(gg, vy, gm1);
+        const v2f h = splat2(0.5f) * gg;
+        const v2f hvx = h * vx;
+        gc0 = fma2(hvx, vx, gc0);
+        gc1 = fma2(hvx, vy, gc1);
+        gc3 = fma2(h * vy, vy, gc3);
+        gal = fma2(pa, G2[jp], gal);
+        Tr2[jp] = Tr2[jp] * ffma2(-ag2[jp], conf2[jp], splat2(1.0f));  // T (1 - a G) if it contributed (explicit: as the forward)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) alive[2 * jp + e] = alive[2 * jp + e] && !(Tr2[jp][e] < p.thresh);
+      }
+      {
+        const float m0 = gm0[0] + gm0[1], m1 = gm1[0] + gm1[1];
+        const float c0 = gc0[0] + gc0[1], c1 = gc1[0] + gc1[1], c3 = gc3[0] + gc3[1];
+        const float ga = gal[0] + gal[1];
+        gr2[NSH / 2 + 0] = v2f{m0, m1};
+        gr2[NSH / 2 + 1] = v2f{c0, c1};
+        gr2[NSH / 2 + 2] = v2f{c1, c3};  // grad_cov[1] and grad_cov[2] receive the same value (kernels.h:414-415)
+        gr2[NSH / 2 + 3] = v2f{ga, 0.0f};
+      }
+
+      wave_reduce_scatter2<P>(gr2);
+      const int comp = scatter_comp<P>(lane);
+      if (scatter_owner<P>(lane) && comp < NSH + 7) {
+        const size_t id = (size_t)S.id[g];
+        float *dst = nullptr;
+        if (comp < NSH) {
+          const int c = comp / CCP, k = comp - c * CCP;
+          if (k < TR::CC) dst = p.g_col + (size_t)TR::NCOL * id + c * TR::CC + k;
+        } else if (comp < NSH + 2) dst = p.g_mean + 2 * id + (comp - NSH);
+        else if (comp < NSH + 6) dst = p.g_cov + 4 * id + (comp - NSH - 2);
+        else dst = p.g_alpha + id;
+        if (dst != nullptr) atomicAdd(dst, gr2[0][0]);
+      }
+    }
+    bool any_alive = false;
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) any_alive |= alive[j];
+    if (__syncthreads_or((int)any_alive) == 0) break;
+  }
+}
 
 // ============================================================================================
 // backward, SH, matrix-core form
@@ -915,7 +1191,7 @@ k_composite_bwd_sh_mfma(CompParams p_arg, const CompParams *__restrict__ plist) 
         gr[3] += h * vx * vy;
         gr[5] += h * vy * vy;
         gr[6] += gg;
-        const float om = con[j] ? (1.0f - ag[j]) : 1.0f;
+        const float om = ffma(-ag[j], con[j] ? 1.0f : 0.0f, 1.0f);  // as the forward: 1 - round(a G), explicit
         Tr[j] *= om;
         alive[j] = alive[j] && !(Tr[j] < p.thresh);
       }
@@ -963,6 +1239,7 @@ k_composite_bwd_sh_mfma(CompParams p_arg, const CompParams *__restrict__ plist) 
 // backward 4 (the per-Gaussian gradient reduction costs the same per wave whatever the number of pixels behind it).
 struct Variants {
   int ppl_fwd, ppl_bwd, mfma, ppl_fwd_batch, ppl_bwd_batch, ppl_bwd_sh_batch, mfma_batch, batch_map;
+  int sh_packed;  // GSGEN_BWD_SH_PACKED: 1 (default) = k_composite_bwd_sh_vec, 0 = k_composite_bwd_pixel<MODE_SH> (A/B)
 };
 static int env_mfma(const char *name) {
   const char *v = getenv(name);
@@ -975,7 +1252,8 @@ static Variants &variants() {
                              env_mfma("GSGEN_BWD_MFMA"),         env_ppl("GSGEN_PPL_FWD_BATCH", 1),
                              env_ppl("GSGEN_PPL_BWD_BATCH", 2),  env_ppl("GSGEN_PPL_BWD_SH_BATCH", 4),
                              env_mfma("GSGEN_BWD_MFMA_BATCH"),
-                             getenv("GSGEN_BATCH_MAP") ? atoi(getenv("GSGEN_BATCH_MAP")) : 2};
+                             getenv("GSGEN_BATCH_MAP") ? atoi(getenv("GSGEN_BATCH_MAP")) : 2,
+                             getenv("GSGEN_BWD_SH_PACKED") ? (atoi(getenv("GSGEN_BWD_SH_PACKED")) != 0) : 1};
   return v;
 }
 
@@ -1007,6 +1285,13 @@ static int launch_bwd(const CompParams &p_, hipStream_t s) {
     }
   }
   const uint32_t ng = nblk * (uint32_t)((MODE == MODE_SH && p.nseg > 1) ? p.nseg : 1);
+  if constexpr (MODE == MODE_SH) {
+    if (variants().sh_packed && ppl != 1) {  // default SH backward: packed per-pixel arithmetic
+      if (ppl == 2) hipLaunchKernelGGL((k_composite_bwd_sh_vec<CB, 2>), dim3(ng), dim3(128), 0, s, p, (const CompParams *)nullptr);
+      else hipLaunchKernelGGL((k_composite_bwd_sh_vec<CB, 4>), dim3(ng), dim3(64), 0, s, p, (const CompParams *)nullptr);
+      return (int)hipGetLastError();
+    }
+  }
   if (ppl == 1) hipLaunchKernelGGL((k_composite_bwd_pixel<MODE, CB, 1>), dim3(ng), dim3(256), 0, s, p, (const CompParams *)nullptr);
   else if (ppl == 2) hipLaunchKernelGGL((k_composite_bwd_pixel<MODE, CB, 2>), dim3(ng), dim3(128), 0, s, p, (const CompParams *)nullptr);
   else hipLaunchKernelGGL((k_composite_bwd_pixel<MODE, CB, 4>), dim3(ng), dim3(64), 0, s, p, (const CompParams *)nullptr);
@@ -1070,6 +1355,11 @@ static void launch_bwd_sh_batch_c(const CompParams &p0, const CompParams *plist,
     return;
   }
   const int ppl = variants().ppl_bwd_sh_batch;
+  if (variants().sh_packed && ppl != 1) {
+    if (ppl == 2) hipLaunchKernelGGL((k_composite_bwd_sh_vec<CB, 2, true>), g, dim3(128), 0, s, p0, plist);
+    else hipLaunchKernelGGL((k_composite_bwd_sh_vec<CB, 4, true>), g, dim3(64), 0, s, p0, plist);
+    return;
+  }
   if (ppl == 1) hipLaunchKernelGGL((k_composite_bwd_pixel<MODE_SH, CB, 1, true>), g, dim3(256), 0, s, p0, plist);
   else if (ppl == 2) hipLaunchKernelGGL((k_composite_bwd_pixel<MODE_SH, CB, 2, true>), g, dim3(128), 0, s, p0, plist);
   else hipLaunchKernelGGL((k_composite_bwd_pixel<MODE_SH, CB, 4, true>), g, dim3(64), 0, s, p0, plist);
@@ -1149,7 +1439,7 @@ extern "C" {
 
 /* Debugging hook (tools/stress, A/B measurements inside one process): overrides one entry of the variant table that
  * the environment initialised.  Not thread-safe against concurrent launches.  name: "ppl_fwd", "ppl_bwd", "mfma",
- * "ppl_fwd_batch", "ppl_bwd_batch", "ppl_bwd_sh_batch", "mfma_batch", "batch_map". */
+ * "ppl_fwd_batch", "ppl_bwd_batch", "ppl_bwd_sh_batch", "mfma_batch", "batch_map", "sh_packed". */
 int gsgen_debug_set_variant(const char *name, int value) {
   if (!name) return GSGEN_EINVAL;
   Variants &v = variants();
@@ -1165,6 +1455,7 @@ int gsgen_debug_set_variant(const char *name, int value) {
   else if (n == "mfma") { slot = &v.mfma; ok = ppl_ok || value == 0; }
   else if (n == "mfma_batch") { slot = &v.mfma_batch; ok = ppl_ok || value == 0; }
   else if (n == "batch_map") { slot = &v.batch_map; ok = value >= 0 && value <= 2; }
+  else if (n == "sh_packed") { slot = &v.sh_packed; ok = value == 0 || value == 1; }
   if (!slot || !ok) return GSGEN_EINVAL;
   *slot = value;
   return 0;
@@ -1181,7 +1472,8 @@ int gsgen_kernel_variant(const char *stage, uint32_t C, uint32_t n_segments, cha
   int n = 0;
   auto sh_bwd = [&](int mfma, int ppl, const char *b) {
     if (mfma) return snprintf(buf, sizeof buf, "k_composite_bwd_sh_mfma<C=%u,PPL=%d%s>%s", C, mfma, b, n_segments > 1 ? " segmented" : "");
-    return snprintf(buf, sizeof buf, "k_composite_bwd_pixel<SH,C=%u,PPL=%d%s>%s", C, ppl, b, n_segments > 1 ? " segmented" : "");
+    return snprintf(buf, sizeof buf, "%s<%sC=%u,PPL=%d%s>%s", (v.sh_packed && ppl != 1) ? "k_composite_bwd_sh_vec" : "k_composite_bwd_pixel",
+                    (v.sh_packed && ppl != 1) ? "" : "SH,", C, ppl, b, n_segments > 1 ? " segmented" : "");
   };
   if (st == "sh_fwd") n = snprintf(buf, sizeof buf, "k_composite_fwd<SH,C=%u,PPL=%d>", C, v.ppl_fwd);
   else if (st == "sh_fwd_batch") n = snprintf(buf, sizeof buf, "k_composite_fwd<SH,C=%u,PPL=%d,BATCH>", C, v.ppl_fwd_batch);

@@ -79,7 +79,10 @@ static __device__ __noinline__ float gauss_ref_f32(float mx, float my, float c0,
   float radial = tx * x + ty * y;
   radial = radial / det;
   if (radial < 0.0f) radial = 1000.0f;
-  return expf(-0.5f * radial);
+  // the correctly rounded fp32 exponential (through fp64): this value decides a discontinuity of the image, and a
+  // 1-ulp expf on one side of the comparison against a <0.51-ulp libm expf on the other flips ~0.3 pixels per
+  // 800x800 frame (measured); two correctly rounded values agree
+  return (float)exp((double)(-0.5f * radial));
 }
 
 // real SH basis, bands CB = 1..4 (shencoder.h:13-62)
@@ -197,10 +200,16 @@ __device__ __forceinline__ float gauss_eval(const GRec &r, float x, float y, flo
                                             bool alive) {
   float G;
   if constexpr (MODE == MODE_SH) {
-    const float tx = x * r.c3 - y * r.c2;
-    const float ty = y * r.c0 - x * r.c1;
-    const float q = tx * x + ty * y;
-    G = __builtin_amdgcn_exp2f(r.p0 * q);
+    // One fixed operation sequence (explicit fused multiply-adds, every other product rounded), shared with the
+    // packed two-pixel form gauss_sh_pair below: forward and backward kernels of any shape get the same bits.
+#pragma clang fp contract(off)
+    const float yc2 = y * r.c2, xc1 = x * r.c1;
+    const float tx = ffma(x, r.c3, -yc2);
+    const float ty = ffma(y, r.c0, -xc1);
+    const float tyy = ty * y;
+    const float q = ffma(tx, x, tyy);
+    const float e = r.p0 * q;
+    G = __builtin_amdgcn_exp2f(e);
     G = (q < 0.0f) ? 0.0f : G;  // kernels.h:186-188: radial < 0 -> exp(-500) == 0
   } else {
     const float u = r.p0 * x + r.p1 * y;
@@ -215,6 +224,24 @@ __device__ __forceinline__ float gauss_eval(const GRec &r, float x, float y, flo
     else
       G = gauss_ref_f64(r.mx, r.my, r.c0, r.c1, r.c2, r.c3, px, py);
   }
+  return G;
+}
+
+// MODE_SH Gaussian values of the two pixels (x, y2[0]) and (x, y2[1]) of one lane: the operation sequence of
+// gauss_eval<MODE_SH> element for element (v_pk_mul / v_pk_fma round exactly like their scalar forms), without the
+// threshold guard -- the caller applies it per pixel with gauss_ref_f32 as gauss_eval does.
+__device__ __forceinline__ v2f gauss_sh_pair(float c0, float c1, float c2, float c3, float p0, float x, v2f y2) {
+#pragma clang fp contract(off)
+  const float xc1 = x * c1;
+  const v2f yc2 = y2 * splat2(c2);
+  const v2f tx = ffma2(splat2(x), splat2(c3), -yc2);
+  const v2f ty = ffma2(y2, splat2(c0), -splat2(xc1));
+  const v2f tyy = ty * y2;
+  const v2f q2 = ffma2(tx, splat2(x), tyy);
+  const v2f e = splat2(p0) * q2;
+  v2f G = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+  G[0] = (q2[0] < 0.0f) ? 0.0f : G[0];
+  G[1] = (q2[1] < 0.0f) ? 0.0f : G[1];
   return G;
 }
 

@@ -680,6 +680,44 @@ void gso_render_sh_fwd(const float *mean, const float *cov, const float *sh /*[N
     }
 }
 
+/* Test aid (no counterpart in the reference): how close every pixel of the SH forward above came to its two
+ * discontinuous decisions -- margin[gy*W+gx][0] = min over the splats it evaluated of |a*G - 1/255| / (1/255) (the
+ * skip test of line "a * val < MIN_RENDER_ALPHA"), [1] = min over its stop tests of |T - thresh| / thresh.  A GPU
+ * pixel that differs from this oracle by more than the 1e-4 tolerance is only acceptable if its margin is a few
+ * ulps: two correct fp32 evaluations of G (different exp implementations) may then decide differently. */
+void gso_sh_decision_margin(const float *mean, const float *cov, const float *alpha, const int *start,
+                            const int *end, const int *ids, const float *topleft, int tile_size, int n_tiles_h,
+                            int n_tiles_w, float psx, float psy, int H, int W, float thresh, float *margin /*[H,W,2]*/) {
+#pragma omp parallel for schedule(dynamic, 1) collapse(2)
+  for (int ty = 0; ty < n_tiles_h; ++ty)
+    for (int tx = 0; tx < n_tiles_w; ++tx) {
+      int tile = ty * n_tiles_w + tx;
+      int n = (start[tile] == -1) ? 0 : end[tile] - start[tile];
+      const int *lst = ids + (n ? start[tile] : 0);
+      for (int ly = 0; ly < tile_size; ++ly)
+        for (int lx = 0; lx < tile_size; ++lx) {
+          int gy = ty * tile_size + ly, gx = tx * tile_size + lx;
+          if (gy >= H || gx >= W) continue;
+          float m_skip = 1e30f, m_stop = 1e30f;
+          float pos[3];
+          pixel_pos(topleft, gx, gy, psx, psy, pos);
+          float cum = 1.0f;
+          for (int k = 0; k < n; ++k) {
+            m_stop = fminf(m_stop, fabsf(cum - thresh) / thresh);
+            if (cum < thresh) break;
+            int g = lst[k];
+            float a = fminf(alpha[g], 0.99f);
+            float val = gauss2d_f32(mean + 2 * g, cov + 4 * g, pos);
+            m_skip = fminf(m_skip, fabsf(a * val - MIN_RENDER_ALPHA) / MIN_RENDER_ALPHA);
+            if (a * val < MIN_RENDER_ALPHA) continue;
+            cum *= (1 - a * val);
+          }
+          margin[2 * (gy * W + gx)] = m_skip;
+          margin[2 * (gy * W + gx) + 1] = m_stop;
+        }
+    }
+}
+
 /* SH compositing backward: vol_render_sh.h:268-455 / vol_render_bg.h:131-242.  `final` is
  * the saved forward output (including bg*T for the bg variant). */
 void gso_render_sh_bwd(int N, const float *mean, const float *cov, const float *sh,

@@ -204,6 +204,17 @@ def render_sh_fwd(mean2d, cov2d, sh, alpha, start, end, ids, topleft, rot9, Cb, 
     return (out, T) if want_T else out
 
 
+def sh_decision_margin(mean2d, cov2d, alpha, start, end, ids, topleft, psx, psy, H, W, thresh=1e-4, tile_size=16):
+    """[H,W,2]: per pixel, how close the SH forward came to flipping a skip test (|a G - 1/255| relative) and a stop
+    test (|T - thresh| relative).  Test aid: a pixel off by more than the tolerance must have a margin of a few ulps."""
+    nth, ntw = _tiles(H, W, tile_size)
+    margin = np.zeros((H, W, 2), np.float32)
+    a = [_f(mean2d), _f(cov2d), _f(alpha), _i(start), _i(end), _i(ids), _f(topleft)]
+    lib().gso_sh_decision_margin(*[_p(x) for x in a], tile_size, nth, ntw, C.c_float(psx), C.c_float(psy), H, W,
+                                 C.c_float(thresh), _p(margin))
+    return margin
+
+
 def render_sh_bwd(mean2d, cov2d, sh, alpha, start, end, ids, final, grad_out, topleft, rot9, Cb, psx,
                   psy, H, W, thresh=1e-4, tile_size=16):
     nth, ntw = _tiles(H, W, tile_size)

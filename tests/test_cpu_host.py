@@ -827,10 +827,15 @@ def test_no_kernel_spills_and_hot_kernels_keep_their_occupancy(tmp_path):
         hits = [v for k, v in kernels.items() if all(p in k for p in parts)]
         assert len(hits) == n, (parts, hits)
         return hits
-    # default SH backward (vector ALUs, one wavefront per tile, 4 pixels per lane): 2 wavefronts per SIMD;
-    # both the per-camera and the batched-cameras instantiation.  Two wavefronts per tile: 4 per SIMD.
-    for bwd in find(2, "k_composite_bwd_pixelILi2ELi4ELi4E"):
+    # default SH backward (k_composite_bwd_sh_vec: vector ALUs, packed per-pixel arithmetic, one wavefront per tile,
+    # 4 pixels per lane): 2 wavefronts per SIMD; both the per-camera and the batched-cameras instantiation.  Two
+    # wavefronts per tile: 3 per SIMD.  The unpacked A/B kernel (GSGEN_BWD_SH_PACKED=0) keeps its budgets too.
+    for bwd in find(2, "k_composite_bwd_sh_vecILi4ELi4E"):
         assert bwd["vgpr_count"] <= 256 and 8 * bwd["group_segment_fixed_size"] <= 160 * 1024
+    for bwd in find(2, "k_composite_bwd_sh_vecILi4ELi2E"):
+        assert bwd["vgpr_count"] <= 168
+    for bwd in find(2, "k_composite_bwd_pixelILi2ELi4ELi4E"):
+        assert bwd["vgpr_count"] <= 256
     for bwd in find(2, "k_composite_bwd_pixelILi2ELi4ELi2E"):
         assert bwd["vgpr_count"] <= 128
     # opt-in matrix-core SH backward: 3 wavefronts per SIMD = 6 two-wavefront workgroups per CU (160 KB of LDS)

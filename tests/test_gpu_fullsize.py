@@ -91,8 +91,9 @@ def frame_case(sc, cam, C, anisotropic, min_longest=0):
     check_lists(buf, g)
     longest = int((g["end"] - g["start"]).max())
     assert longest >= min_longest, longest
-    err = np.abs(rgb.detach().cpu().numpy() - ref).max(-1)
-    assert err.max() <= 1e-4, f"{(err > 1e-4).sum()} pixels off, max {err.max()}"
+    m = g["mask"]
+    scenes.assert_sh_image_parity(rgb.detach().cpu().numpy(), ref, g["mean2d"], g["cov2d"], sc["alpha"][m], g["start"],
+                                  g["end"], g["ids"], cam.topleft, 1 / cam.fx, 1 / cam.fy, what="frame")
     check_grads(P, want, anisotropic)
     return longest
 
@@ -132,7 +133,7 @@ def test_full_size_cfg4_64_random_poses_batched():
     bg = np.array([0.1, 0.2, 0.3], np.float32)
     gen = torch.Generator(device=dev()).manual_seed(9)
     want = {k: np.zeros(sc[k].shape, np.float64) for k in KEYS}
-    worst = 0.0
+    worst = 0  # threshold-adjacent pixels over the 64 frames (each named and justified by the helper)
     for b0 in range(0, 64, B):
         batch = cams[b0:b0 + B]
         cis = [R.CameraInfo(*c.intr) for c in batch]
@@ -147,9 +148,10 @@ def test_full_size_cfg4_64_random_poses_batched():
         for i, cam in enumerate(batch):
             g, ref, gr = oracle_render(sc, cam, C, go[i].cpu().numpy(), bg)
             check_lists(br.slots[i], g)
-            err = float(np.abs(img[i] - ref).max())
-            worst = max(worst, err)
-            assert err <= 1e-4, (b0 + i, err)
+            mk = g["mask"]
+            worst += scenes.assert_sh_image_parity(img[i], ref, g["mean2d"], g["cov2d"], sc["alpha"][mk], g["start"], g["end"],
+                                                   g["ids"], cam.topleft, 1 / cam.fx, 1 / cam.fy, what=f"camera {b0 + i}")
             for k in KEYS:
                 want[k] += gr[k]
+    assert worst <= 4
     check_grads(P, want, anisotropic=False)

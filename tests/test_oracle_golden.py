@@ -161,3 +161,31 @@ def test_legacy_binning_oracle_equals_reference(mode):
     assert np.array_equal(a, b) and a.sum() > 0
     for x, y in zip(O.legacy_image_sort(mode, dep, a, m2, shape, *args), Rf.legacy_image_sort(mode, dep, b, m2, shape, *args)):
         assert np.array_equal(x, y)
+
+
+def test_decision_margin_reports_threshold_adjacent_pixels():
+    """oracle.sh_decision_margin (the test aid behind scenes.assert_sh_image_parity): a splat whose opacity is tuned so
+    that a*G at one pixel sits exactly on the 1/255 skip threshold gives that pixel a zero margin and leaves the
+    others well away from it; empty tiles report 'no decision'."""
+    cam = scenes.Camera(32, 32, fx=32.0)
+    sc = scenes.random_scene(1, seed=0, svec=0.2, C=1)
+    sc["mean"][:] = 0.0
+    g = scenes.oracle_geometry(sc, cam)
+    assert g["mask"].all() and g["D"] >= 1
+    a = (g["mean2d"], g["cov2d"])
+    geo = (g["start"], g["end"], g["ids"], cam.topleft, 1 / cam.fx, 1 / cam.fy, cam.h, cam.w)
+    m0 = O.sh_decision_margin(*a, np.array([0.5], np.float32), *geo)
+    assert m0.shape == (32, 32, 2) and np.isfinite(m0[m0 < 1e29]).all() and (m0 >= 0).all()
+    # G at pixel (20, 13) from the margin at alpha = 0.5: |0.5 G - t| / t = m  =>  G = (1 +- m) t / 0.5
+    t = np.float32(1.0 / 255.0)
+    y, x = 20, 13
+    cands = [np.float32((1 + s * m0[y, x, 0]) * t / np.float32(0.5)) for s in (+1, -1)]
+    hit = False
+    for G in cands:
+        if not (0 < G <= 1):
+            continue
+        alpha = np.float32(t / G)
+        m1 = O.sh_decision_margin(*a, np.array([alpha], np.float32), *geo)
+        hit |= bool(m1[y, x, 0] <= 3e-7)
+    assert hit
+    assert np.median(m0[..., 0][m0[..., 0] < 1e29]) > 1e-3

@@ -7,6 +7,7 @@
     short   -DGSGEN_MFMA_SHORT_WAITS  operands up front + 16 wait states after the chain (the round-1 build that
                                       failed on the first launches of a process on some boxes)
     fixed   -DGSGEN_MFMA_FIXED_WAITS  16 before + 64 after
+    waves3  -DGSGEN_BWD_WAVES3        packed SH backward forced to three wavefronts per SIMD (A/B)
 Run a variant with LD_LIBRARY_PATH=gsgen_amd/lib_alt/<name> tools/stress/bwd_stress ... (the tool's RUNPATH comes after
 LD_LIBRARY_PATH) or GSGEN_HIP_LIB=... for the Python binding.  Only composite.hip is recompiled."""
 import os
@@ -17,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 from gsgen_amd import build as B  # noqa: E402
 
-ALT = {"plain": ["-DGSGEN_MFMA_PLAIN"], "short": ["-DGSGEN_MFMA_SHORT_WAITS"], "fixed": ["-DGSGEN_MFMA_FIXED_WAITS"]}
+ALT = {"waves3": ["-DGSGEN_BWD_WAVES3"], "plain": ["-DGSGEN_MFMA_PLAIN"], "short": ["-DGSGEN_MFMA_SHORT_WAITS"], "fixed": ["-DGSGEN_MFMA_FIXED_WAITS"]}
 
 
 def build(name):
