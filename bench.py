@@ -155,13 +155,16 @@ def main():
     ap.add_argument("--steps", type=int, default=50, help="timed steps; a step renders --batch cameras fwd+bwd")
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="cfg2")
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("GSGEN_BATCH", "8")),
-                    help="cameras per step = cameras per launch of every stage (gsgen_*_batch entry points)")
-    ap.add_argument("--slots", type=int, default=2,
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("GSGEN_BATCH", "0")),
+                    help="cameras per step = cameras per launch of every stage (gsgen_*_batch entry points); 0 = chosen "
+                         "from the workload: about 6 M (tile, Gaussian) pairs per launch, between 2 and 8 cameras")
+    ap.add_argument("--slots", type=int, default=0,
                     help="steps in flight: own HIP stream and buffers each, so one batch's geometry overlaps the "
-                         "other's compositing")
+                         "other's compositing; 0 = 2, or 3 when the batch is smaller than 4 cameras")
     ap.add_argument("--segments", type=int, default=int(os.environ.get("GSGEN_SEGMENTS", "1")),
                     help="backward workgroups per tile (segments of 32 list entries); 1 = one workgroup per tile")
+    ap.add_argument("--latency-segments", type=int, default=8,
+                    help="the same for the one-render-in-flight pass: uniform work units shorten a lone launch's tail")
     ap.add_argument("--repeats", type=int, default=0, help="repeats of the timed region (0: until 0.5 s are timed, <= 25)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the one-render-in-flight and hipGraph passes")
@@ -192,7 +195,24 @@ def main():
     sc, W, H = make_workload(args.config)
     C = sc["C"]
     N = sc["mean"].shape[0]
-    B, K, nseg = max(1, args.batch), max(1, args.steps), max(1, args.segments)
+    K, nseg = max(1, args.steps), max(1, args.segments)
+    B = args.batch
+    if B <= 0:
+        # batch size from the workload (one untimed probe render): a launch should carry enough tiles to fill the
+        # chip and hide its tail, but the cameras of a launch share the gradient accumulators -- with 500 k
+        # Gaussians and 2.5 M pairs per view (cfg3) two cameras per launch beat eight (profiles/r02_notes.md)
+        probe_cam = (random_pose_cameras(64, rank, world, W, H) if args.config == "cfg4" else camera_poses(1, rank, W, H))[0]
+        pb = R.FrameBuffers(N, W, H, dev)
+        tp = {k: torch.tensor(sc[k], device=dev) for k in ("mean", "qvec", "svec")}
+        R.frame_geometry(tp["mean"], tp["qvec"], tp["svec"], torch.from_numpy(R.CameraInfo(*probe_cam.intr).pack(probe_cam.c2w)).to(dev), pb)
+        d_probe = max(1, int(pb.total.item()))
+        B = int(min(8, max(2, round(6.0e6 / d_probe))))
+        del pb, tp
+        if dist is not None:  # one batch size for the job (the gathered tensor is [world, B, H, W, 3])
+            bt = torch.tensor([B], device=dev)
+            dist.broadcast(bt, 0)
+            B = int(bt.item())
+    auto_slots = args.slots if args.slots > 0 else (2 if B >= 4 else 3)
     cams = random_pose_cameras(64, rank, world, W, H) if args.config == "cfg4" else camera_poses(max(8, B), rank, W, H)
     ncam = len(cams)
     cis = [R.CameraInfo(*c.intr) for c in cams]
@@ -254,7 +274,7 @@ def main():
                 self.tables[key] = (geo, views, proj)
             return self.tables[key]
 
-    slots = [Slot(torch.cuda.Stream(dev)) for _ in range(max(1, args.slots))]
+    slots = [Slot(torch.cuda.Stream(dev)) for _ in range(max(1, auto_slots))]
     seg_arg = nseg if nseg > 1 else 0
 
     def run_step(j, ev=None, gather=True):
@@ -363,6 +383,9 @@ def main():
     if not args.no_latency:
         sl0 = slots[0]
         b0 = sl0.bufs[0]
+        lseg = max(1, args.latency_segments)
+        lseg_arg = lseg if lseg > 1 else 0
+        lseg_ws = torch.empty(max(1, lib.segment_workspace_bytes(nth * ntw, lseg)), device=dev, dtype=torch.uint8)
         g1 = torch.empty(N * (7 + CC3), device=dev)
         g1_mean2d, g1_cov2d, g1_alpha, g1_sh = g1[:2 * N], g1[2 * N:6 * N], g1[6 * N:7 * N], g1[7 * N:]
 
@@ -376,7 +399,7 @@ def main():
                 ev[0].record(stream)
             lib.vol_render_sh_segmented(N, b0.D_cap, p(b0.mean2d), p(b0.cov2d), p(t["sh"]), p(t["alpha"]), p(b0.start), p(b0.end),
                                         p(b0.ids), p(sl0.out[0]), p(topleft_dev[k]), p(rot_dev[k]), 16, nth, ntw, 1.0 / cis[k].fx,
-                                        1.0 / cis[k].fy, H, W, C, 1e-4, p(bg), None, order_, p(sl0.seg_ws[0]), seg_arg, s)
+                                        1.0 / cis[k].fy, H, W, C, 1e-4, p(bg), None, order_, p(lseg_ws), lseg_arg, s)
             if ev is not None:
                 ev[1].record(stream)
             with torch.cuda.stream(stream):
@@ -387,7 +410,7 @@ def main():
                                                  p(b0.end), p(b0.ids), p(sl0.out[0]), p(g1_mean2d), p(g1_cov2d), p(g1_sh),
                                                  p(g1_alpha), p(grad_out), p(topleft_dev[k]), p(rot_dev[k]), 16, nth, ntw,
                                                  1.0 / cis[k].fx, 1.0 / cis[k].fy, H, W, C, 1e-4, p(bg), order_,
-                                                 p(sl0.seg_ws[0]), seg_arg, s)
+                                                 p(lseg_ws), lseg_arg, s)
             if ev is not None:
                 ev[3].record(stream)
             lib.project_gaussians_backward_masked(N, p(t["mean"]), p(t["qvec"]), p(t["svec"]), p(cam_dev[k]), 1, p(b0.mask),
@@ -412,7 +435,8 @@ def main():
         barrier()
         el1 = time.perf_counter() - t1
         one = {"value": world * n1 / el1, "ms_per_render": el1 / n1 * 1e3, "renders": n1,
-               "fwd_kernel": lib.kernel_variant("sh_fwd", C, nseg), "bwd_kernel": lib.kernel_variant("sh_bwd", C, nseg),
+               "backward_segments_per_tile": lseg,
+               "fwd_kernel": lib.kernel_variant("sh_fwd", C, lseg), "bwd_kernel": lib.kernel_variant("sh_bwd", C, lseg),
                "fwd_kernel_ms": float(np.mean([e[0].elapsed_time(e[1]) for e in ev1])),
                "bwd_kernel_ms": float(np.mean([e[2].elapsed_time(e[3]) for e in ev1]))}
         try:  # ... and replayed from one captured hipGraph per camera: same kernels, no launch gaps

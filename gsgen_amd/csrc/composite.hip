@@ -337,6 +337,198 @@ __global__ void __launch_bounds__(256 / PPL) k_composite_fwd(CompParams p_arg, c
 }
 
 // ============================================================================================
+// forward, SH, packed per-pixel arithmetic (2 or 4 pixels per lane)
+// ============================================================================================
+// k_composite_fwd<MODE_SH> with the lane's pixels taken two at a time (v2f): Gaussian, weights, colour sums and the
+// transmittance update are packed fp32 instructions (full rate on gfx950, see k_composite_bwd_sh_vec), the
+// coefficients are staged pre-scaled by -log2(e), and the two pixels' dot products are interleaved.  Decisions (skip,
+// saturated) come from gauss_sh_pair / the explicit T update, bit for bit those of every other kernel.  Same launch
+// shape and outputs (image, T, segment checkpoints and stop indices) as k_composite_fwd.
+template <int CB, int PPL, bool BATCH = false>
+__global__ void __launch_bounds__(256 / PPL)
+k_composite_fwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
+  static_assert(PPL == 4 || PPL == 2, "pixel pairs: 2 or 4 pixels per lane");
+  uint32_t bid = blockIdx.x;
+  const CompParams p = BATCH ? plist[batch_view(p_arg, bid)] : p_arg;  // see k_composite_fwd
+  constexpr int MODE = MODE_SH;
+  using TR = Traits<MODE, CB>;
+  constexpr int NT = 256 / PPL, ROWS = NT / 16, NP = PPL / 2;
+  constexpr int CCP = TR::CCP, NPAIR = TR::NPAIR;
+  __shared__ Stage<MODE, CB> S;
+
+  int tx, ty;
+  if (!block_tile(p, tx, ty, bid)) return;  // uniform over the workgroup
+  const int tile = ty * p.ntw + tx;
+  const int st = p.start[tile];
+  const int n = (st < 0) ? 0 : (p.end[tile] - st);
+  const int t = (int)threadIdx.x;
+  const int lx = t & 15, ly0 = t >> 4;
+  const int gx = tx * kTile + lx;
+
+  bool valid[PPL], alive[PPL];
+  int gy[PPL], stop[PPL];
+#pragma unroll
+  for (int j = 0; j < PPL; ++j) {
+    gy[j] = ty * kTile + ly0 + j * ROWS;
+    valid[j] = (gx < p.W) && (gy[j] < p.H);
+    alive[j] = valid[j];
+    stop[j] = valid[j] ? n : 0;
+  }
+  if (n == 0) {  // uniform over the workgroup
+    if (p.bg != nullptr) {  // vol_render_bg.h:34-53: empty tiles show the background
+#pragma unroll
+      for (int j = 0; j < PPL; ++j)
+        if (valid[j]) {
+          float *o = p.out + 3 * ((size_t)gy[j] * p.W + gx);
+          o[0] = p.bg[0]; o[1] = p.bg[1]; o[2] = p.bg[2];
+        }
+    }
+    return;  // otherwise the caller's pre-initialised out / T stand (vol_render.h:1006-1013)
+  }
+  if constexpr (CCP != TR::CC) {  // zero the pad lanes of the staged coefficients once
+    for (int e = t; e < kBatch * TR::NCOLP; e += NT) S.col[e] = 0.0f;
+    __syncthreads();
+  }
+
+  const float px = pixel_coord(p.topleft[0], gx, p.psx);
+  v2f py2[NP];
+#pragma unroll
+  for (int j = 0; j < PPL; ++j) py2[j >> 1][j & 1] = pixel_coord(p.topleft[1], gy[j], p.psy);
+  v2f Yp[PPL][NPAIR];
+  {
+    float R[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = p.rot[i];
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) {
+      const float pyj = py2[j >> 1][j & 1];
+      float dx = R[0] * px + R[1] * pyj + R[2];
+      float dy = R[3] * px + R[4] * pyj + R[5];
+      float dz = R[6] * px + R[7] * pyj + R[8];
+      const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+      dx /= len; dy /= len; dz /= len;
+      float Yf[CCP];
+#pragma unroll
+      for (int k = 0; k < CCP; ++k) Yf[k] = 0.0f;
+      sh_basis<CB>(dx, dy, dz, *reinterpret_cast<float (*)[TR::CC]>(&Yf[0]));
+#pragma unroll
+      for (int k = 0; k < NPAIR; ++k) Yp[j][k] = v2f{Yf[2 * k], Yf[2 * k + 1]};
+      __builtin_amdgcn_sched_barrier(0);  // one pixel's temporaries at a time
+    }
+  }
+
+  v2f acc2[NP][3], Tr2[NP];
+#pragma unroll
+  for (int jp = 0; jp < NP; ++jp) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) acc2[jp][c] = v2f{0.0f, 0.0f};
+    Tr2[jp] = v2f{1.0f, 1.0f};
+  }
+  const bool seg_out = p.nseg > 1 && p.ckpt != nullptr;
+
+  for (int base = 0; base < n; base += kBatch) {
+    const int nb = min(kBatch, n - base);
+    if (base > 0) __syncthreads();  // everyone is done with the previous batch
+    stage_batch<MODE, CB, NT, kBatch, true>(S, p, st + base, nb);
+    __syncthreads();
+
+    for (int g = 0; g < nb; ++g) {
+      bool any_alive = false;
+#pragma unroll
+      for (int j = 0; j < PPL; ++j) any_alive |= alive[j];
+      if (__ballot(any_alive) == 0ull) break;  // this wave's 64*PPL pixels are saturated
+      const int e_idx = base + g;
+      if (seg_out && (e_idx % kSegLen) == 0 && e_idx > 0 && e_idx / kSegLen < p.nseg) {  // wave-uniform
+#pragma unroll
+        for (int j = 0; j < PPL; ++j)
+          p.ckpt[((size_t)tile * p.nseg + e_idx / kSegLen) * 256 + (ly0 + j * ROWS) * 16 + lx] =
+              make_float4(Tr2[j >> 1][j & 1], acc2[j >> 1][0][j & 1], acc2[j >> 1][1][j & 1], acc2[j >> 1][2][j & 1]);
+      }
+
+      const float r_mx = S.mx[g], r_my = S.my[g], r_a = S.a[g], r_c0 = S.c0[g], r_c1 = S.c1[g], r_c2 = S.c2[g],
+                  r_c3 = S.c3[g], r_p0 = S.p0[g];
+      const float x = px - r_mx;
+      v2f G2[NP], ag2[NP], conf2[NP];
+      bool any_con = false;
+#pragma unroll
+      for (int jp = 0; jp < NP; ++jp) {
+        G2[jp] = gauss_sh_pair(r_c0, r_c1, r_c2, r_c3, r_p0, x, py2[jp] - splat2(r_my));
+        ag2[jp] = splat2(r_a) * G2[jp];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int j = 2 * jp + e;
+          if (alive[j] && fabsf(ag2[jp][e] - kMinAlpha) <= kMinAlpha * kGuardTol) {  // as gauss_eval
+            G2[jp][e] = gauss_ref_f32(r_mx, r_my, r_c0, r_c1, r_c2, r_c3, px, py2[jp][e]);
+            ag2[jp][e] = r_a * G2[jp][e];
+          }
+          const bool con = alive[j] && !(ag2[jp][e] < kMinAlpha);
+          conf2[jp][e] = con ? 1.0f : 0.0f;
+          any_con |= con;
+        }
+      }
+      if (__ballot(any_con) == 0ull) continue;  // nobody in the wave sees this Gaussian
+
+      const float *cg = &S.col[g * TR::NCOLP];
+      v2f w2[NP];
+#pragma unroll
+      for (int jp = 0; jp < NP; ++jp) w2[jp] = ((splat2(r_a) * Tr2[jp]) * G2[jp]) * conf2[jp];  // (a T) G, or 0
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        v2f q[NPAIR];
+#pragma unroll
+        for (int k = 0; k < NPAIR; ++k) q[k] = *reinterpret_cast<const v2f *>(cg + c * CCP + 2 * k);
+#pragma unroll
+        for (int jp = 0; jp < NP; ++jp) {
+          v2f sa = q[0] * Yp[2 * jp][0], sb = q[0] * Yp[2 * jp + 1][0];
+#pragma unroll
+          for (int k = 1; k < NPAIR; ++k) {
+            sa = fma2(q[k], Yp[2 * jp][k], sa);
+            sb = fma2(q[k], Yp[2 * jp + 1][k], sb);
+          }
+          const v2f sp = v2f{sa[0], sb[0]} + v2f{sa[1], sb[1]};
+          const v2f den = splat2(1.0f) + v2f{__builtin_amdgcn_exp2f(sp[0]), __builtin_amdgcn_exp2f(sp[1])};
+          const v2f yv = v2f{__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+          acc2[jp][c] = fma2(w2[jp], yv, acc2[jp][c]);
+        }
+      }
+#pragma unroll
+      for (int jp = 0; jp < NP; ++jp) {
+        Tr2[jp] = Tr2[jp] * ffma2(-ag2[jp], conf2[jp], splat2(1.0f));  // T (1 - a G) if it contributed (explicit)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int j = 2 * jp + e;
+          const bool still = alive[j] && !(Tr2[jp][e] < p.thresh);
+          if (alive[j] && !still) stop[j] = base + g + 1;
+          alive[j] = still;
+        }
+      }
+    }
+    bool any_alive = false;
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) any_alive |= alive[j];
+    if (__syncthreads_or((int)any_alive) == 0) break;  // whole tile saturated: stop staging
+  }
+
+#pragma unroll
+  for (int j = 0; j < PPL; ++j) {
+    if (!valid[j]) continue;
+    const size_t pix = (size_t)gy[j] * p.W + gx;
+    const float Tj = Tr2[j >> 1][j & 1];
+    float *o = p.out + 3 * pix;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float a = acc2[j >> 1][c][j & 1];
+      o[c] = (p.bg != nullptr) ? a + p.bg[c] * Tj : a;  // vol_render_bg.h:95-100
+    }
+    if (p.T != nullptr) p.T[pix] = Tj;
+  }
+  if (p.stop != nullptr) {
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) p.stop[(size_t)tile * 256 + (ly0 + j * ROWS) * 16 + lx] = stop[j];
+  }
+}
+
+// ============================================================================================
 // backward
 // ============================================================================================
 template <int MODE, int CB, int PPL, bool BATCH = false>
@@ -1234,9 +1426,12 @@ k_composite_bwd_sh_mfma(CompParams p_arg, const CompParams *__restrict__ plist) 
 //                                          not root-caused (profiles/r01_notes.md), the vector kernel
 //                                          never has -- and north_star asks for "no MFMA" on this path.
 //   GSGEN_BATCH_MAP                        block order of the batched grids (batch_view)
-// Defaults chosen by measurement on MI355X (profiles/r01_notes.md): forward 1 pixel per lane (127 us vs 195 us at 4:
-// one wave per tile leaves 2.4 waves per SIMD and the launch ends on the centre tiles' serial chains), vector
-// backward 4 (the per-Gaussian gradient reduction costs the same per wave whatever the number of pixels behind it).
+// Defaults chosen by measurement on MI355X (profiles/r01_notes.md, profiles/r02_notes.md): per-camera forward 1 pixel per
+// lane (127 us vs 195 us at 4: one wave per tile leaves 2.4 waves per SIMD and the launch ends on the centre tiles' serial
+// chains; 129 vs 153 us against the packed 2-pixel kernel), batched forward 2 (packed k_composite_fwd_sh_vec: a lone
+// 8-view launch is 4 % slower than at 1 pixel per lane but issues fewer vector instructions, which is what counts with
+// another batch's backward in flight: 3 010 vs 2 885 renders/s), vector backward 4 (the per-Gaussian gradient
+// reduction costs the same per wave whatever the number of pixels behind it).
 struct Variants {
   int ppl_fwd, ppl_bwd, mfma, ppl_fwd_batch, ppl_bwd_batch, ppl_bwd_sh_batch, mfma_batch, batch_map;
   int sh_packed;  // GSGEN_BWD_SH_PACKED: 1 (default) = k_composite_bwd_sh_vec, 0 = k_composite_bwd_pixel<MODE_SH> (A/B)
@@ -1249,7 +1444,7 @@ static int env_mfma(const char *name) {
 }
 static Variants &variants() {
   static Variants v = {env_ppl("GSGEN_PPL_FWD", 1),       env_ppl("GSGEN_PPL_BWD", 4),
-                             env_mfma("GSGEN_BWD_MFMA"),         env_ppl("GSGEN_PPL_FWD_BATCH", 1),
+                             env_mfma("GSGEN_BWD_MFMA"),         env_ppl("GSGEN_PPL_FWD_BATCH", 2),
                              env_ppl("GSGEN_PPL_BWD_BATCH", 2),  env_ppl("GSGEN_PPL_BWD_SH_BATCH", 4),
                              env_mfma("GSGEN_BWD_MFMA_BATCH"),
                              getenv("GSGEN_BATCH_MAP") ? atoi(getenv("GSGEN_BATCH_MAP")) : 2,
@@ -1262,6 +1457,13 @@ static int launch_fwd(const CompParams &p, hipStream_t s) {
   const int ppl = variants().ppl_fwd;
   const uint32_t nblk = comp_grid(p);
   if (p.ntw * p.nth == 0) return 0;
+  if constexpr (MODE == MODE_SH) {
+    if (variants().sh_packed && ppl != 1) {  // packed per-pixel arithmetic needs pixel pairs
+      if (ppl == 2) hipLaunchKernelGGL((k_composite_fwd_sh_vec<CB, 2>), dim3(nblk), dim3(128), 0, s, p, (const CompParams *)nullptr);
+      else hipLaunchKernelGGL((k_composite_fwd_sh_vec<CB, 4>), dim3(nblk), dim3(64), 0, s, p, (const CompParams *)nullptr);
+      return (int)hipGetLastError();
+    }
+  }
   if (ppl == 1) hipLaunchKernelGGL((k_composite_fwd<MODE, CB, 1>), dim3(nblk), dim3(256), 0, s, p, (const CompParams *)nullptr);
   else if (ppl == 2) hipLaunchKernelGGL((k_composite_fwd<MODE, CB, 2>), dim3(nblk), dim3(128), 0, s, p, (const CompParams *)nullptr);
   else hipLaunchKernelGGL((k_composite_fwd<MODE, CB, 4>), dim3(nblk), dim3(64), 0, s, p, (const CompParams *)nullptr);
@@ -1318,6 +1520,11 @@ template <int CB>
 static void launch_fwd_sh_batch_c(const CompParams &p0, const CompParams *plist, uint32_t B, uint32_t nblk, hipStream_t s) {
   const int ppl = variants().ppl_fwd_batch;  // wavefronts per tile = 4 / ppl
   const dim3 g(nblk * B);
+  if (variants().sh_packed && ppl != 1) {
+    if (ppl == 2) hipLaunchKernelGGL((k_composite_fwd_sh_vec<CB, 2, true>), g, dim3(128), 0, s, p0, plist);
+    else hipLaunchKernelGGL((k_composite_fwd_sh_vec<CB, 4, true>), g, dim3(64), 0, s, p0, plist);
+    return;
+  }
   if (ppl == 1) hipLaunchKernelGGL((k_composite_fwd<MODE_SH, CB, 1, true>), g, dim3(256), 0, s, p0, plist);
   else if (ppl == 2) hipLaunchKernelGGL((k_composite_fwd<MODE_SH, CB, 2, true>), g, dim3(128), 0, s, p0, plist);
   else hipLaunchKernelGGL((k_composite_fwd<MODE_SH, CB, 4, true>), g, dim3(64), 0, s, p0, plist);
@@ -1475,8 +1682,12 @@ int gsgen_kernel_variant(const char *stage, uint32_t C, uint32_t n_segments, cha
     return snprintf(buf, sizeof buf, "%s<%sC=%u,PPL=%d%s>%s", (v.sh_packed && ppl != 1) ? "k_composite_bwd_sh_vec" : "k_composite_bwd_pixel",
                     (v.sh_packed && ppl != 1) ? "" : "SH,", C, ppl, b, n_segments > 1 ? " segmented" : "");
   };
-  if (st == "sh_fwd") n = snprintf(buf, sizeof buf, "k_composite_fwd<SH,C=%u,PPL=%d>", C, v.ppl_fwd);
-  else if (st == "sh_fwd_batch") n = snprintf(buf, sizeof buf, "k_composite_fwd<SH,C=%u,PPL=%d,BATCH>", C, v.ppl_fwd_batch);
+  auto sh_fwd = [&](int ppl, const char *b) {
+    if (v.sh_packed && ppl != 1) return snprintf(buf, sizeof buf, "k_composite_fwd_sh_vec<C=%u,PPL=%d%s>", C, ppl, b);
+    return snprintf(buf, sizeof buf, "k_composite_fwd<SH,C=%u,PPL=%d%s>", C, ppl, b);
+  };
+  if (st == "sh_fwd") n = sh_fwd(v.ppl_fwd, "");
+  else if (st == "sh_fwd_batch") n = sh_fwd(v.ppl_fwd_batch, ",BATCH");
   else if (st == "sh_bwd") n = sh_bwd(v.mfma, v.ppl_bwd, "");
   else if (st == "sh_bwd_batch") n = sh_bwd(v.mfma_batch, v.ppl_bwd_sh_batch, ",BATCH");
   else if (st == "rgb_fwd") n = snprintf(buf, sizeof buf, "k_composite_fwd<RGB,PPL=%d>", v.ppl_fwd);
