@@ -25,6 +25,14 @@ from . import renderer as R
 from .renderer import _p
 
 
+def _bg_grad(ctx, grad_rgb, T):
+    """d/d bg of rgb = ... + T * bg (gs/renderer.py:1283: nan_to_num(grad * T)), reduced to bg's shape; None unless
+    the background takes part in the graph (the reference's ConstBackground / MLPBackground are trainable)"""
+    if getattr(ctx, "bg_shape", None) is None or grad_rgb is None:
+        return None
+    return torch.nan_to_num(grad_rgb * T).sum_to_size(ctx.bg_shape)
+
+
 def _tab(addresses):
     """host array of device pointers for the *_batch entry points"""
     return (ctypes.c_void_p * len(addresses))(*addresses)
@@ -43,6 +51,7 @@ class _render_batch(torch.autograd.Function):
         T = torch.ones(B, H, W, 1, device=dev, dtype=torch.float32)
         fused = br.fused_launch and B > 0
         cams_p, out_p, T_p = cams.data_ptr(), out.data_ptr(), T.data_ptr()
+        ctx.gen = br._begin_batch(B)
         if fused:
             return _render_batch._forward_fused(ctx, mean, qvec, svec, alpha, col, cams, br, B, C, bg_rgb, thresh,
                                                 detach_depth, stats, out, T)
@@ -68,10 +77,12 @@ class _render_batch(torch.autograd.Function):
                                                     cam + 224, 16, buf.nth, buf.ntw, psx, psy, H, W, thresh,
                                                     T_p + 4 * H * W * i, s)
         br._join(B, cur)
+        br._end_batch(B)
         ctx.views = ctx.bws = None
         if C == 0 and bg_rgb is not None:
             out = out + T * bg_rgb  # gs/renderer.py:1182
-        ctx.save_for_backward(mean, qvec, svec, alpha, col, cams, out)
+        ctx.save_for_backward(mean, qvec, svec, alpha, col, cams, out, T)
+        ctx.bg_shape = tuple(bg_rgb.shape) if (bg_rgb is not None and ctx.needs_input_grad[9]) else None
         ctx.br, ctx.B, ctx.C, ctx.thresh, ctx.detach, ctx.stats = br, B, C, thresh, detach_depth, stats
         ctx.cis = list(br._cis[:B])
         ctx.mark_non_differentiable(T)
@@ -107,6 +118,7 @@ class _render_batch(torch.autograd.Function):
         bws = torch.empty(nb_sh + lib.frame_batch_workspace_bytes(B), device=dev, dtype=torch.uint8)
         with torch.cuda.device(dev):
             lib.frame_geometry_batch(B, geo, N, _p(mean), _p(qvec), _p(svec), W, H, _p(bws) + nb_sh, s)
+            br._end_batch(B)
             if stats is not None:
                 lib.densify_update_batch(B, N, _tab([_p(br.slots[i].cov2d) for i in range(B)]), None,
                                          _tab([_p(br.slots[i].mask) for i in range(B)]), _p(stats.max_radii2d), None,
@@ -122,7 +134,8 @@ class _render_batch(torch.autograd.Function):
             for i in range(B):
                 views[i].out6 = out.data_ptr() + 12 * H * W * i
         ctx.views, ctx.bws = views, bws
-        ctx.save_for_backward(mean, qvec, svec, alpha, col, cams, out)
+        ctx.save_for_backward(mean, qvec, svec, alpha, col, cams, out, T)
+        ctx.bg_shape = tuple(bg_rgb.shape) if (bg_rgb is not None and ctx.needs_input_grad[9]) else None
         ctx.br, ctx.B, ctx.C, ctx.thresh, ctx.detach, ctx.stats = br, B, C, thresh, detach_depth, stats
         ctx.cis = list(br._cis[:B])
         ctx.mark_non_differentiable(T)
@@ -131,7 +144,7 @@ class _render_batch(torch.autograd.Function):
     @staticmethod
     def _backward_fused(ctx, grad):
         import ctypes
-        mean, qvec, svec, alpha, col, cams, out = ctx.saved_tensors
+        mean, qvec, svec, alpha, col, cams, out, T = ctx.saved_tensors
         br, B, C, thresh, stats = ctx.br, ctx.B, ctx.C, ctx.thresh, ctx.stats
         lib = _capi.load()
         H, W, N, dev = br.H, br.W, br.N, mean.device
@@ -169,13 +182,14 @@ class _render_batch(torch.autograd.Function):
                 lib.densify_update_batch(B, N, None, _tab([g2d_p + 24 * N * i for i in range(B)]),
                                          _tab([_p(br.slots[i].mask) for i in range(B)]), None, _p(stats.grad_accum),
                                          _p(stats.cnt), s)
-        return (g_mean, g_qvec, g_svec, g_alpha, g_col) + (None,) * 8
+        return (g_mean, g_qvec, g_svec, g_alpha, g_col, None, None, None, None, _bg_grad(ctx, grad, T), None, None, None)
 
     @staticmethod
     def backward(ctx, grad, _gT):
+        ctx.br._check_generation(ctx.gen)
         if ctx.views is not None:
             return _render_batch._backward_fused(ctx, grad)
-        mean, qvec, svec, alpha, col, cams, out = ctx.saved_tensors
+        mean, qvec, svec, alpha, col, cams, out, T = ctx.saved_tensors
         br, B, C, thresh, stats = ctx.br, ctx.B, ctx.C, ctx.thresh, ctx.stats
         lib = _capi.load()
         H, W, N, dev = br.H, br.W, br.N, mean.device
@@ -213,7 +227,7 @@ class _render_batch(torch.autograd.Function):
                     lib.densify_update(N, None, g_mean2d, _p(buf.mask), None, _p(stats.grad_accum),
                                        _p(stats.cnt), s)
         br._join(B, cur)
-        return (g_mean, g_qvec, g_svec, g_alpha, g_col) + (None,) * 8
+        return (g_mean, g_qvec, g_svec, g_alpha, g_col, None, None, None, None, _bg_grad(ctx, grad, T), None, None, None)
 
 
 class _render_batch_heads(torch.autograd.Function):
@@ -231,6 +245,7 @@ class _render_batch_heads(torch.autograd.Function):
         T = torch.ones(B, H, W, 1, device=dev, dtype=torch.float32)
         cams_p, out_p, T_p = cams.data_ptr(), out6.data_ptr(), T.data_ptr()
         ctx.views = ctx.bws = None
+        ctx.gen = br._begin_batch(B)
         if br.fused_launch and B > 0:  # one enqueue per stage for the whole batch, on the current stream
             s = torch.cuda.current_stream(dev).cuda_stream
             geo = (_capi.GeometryView * B)()
@@ -250,6 +265,7 @@ class _render_batch_heads(torch.autograd.Function):
             bws = torch.empty(nb_sh + lib.frame_batch_workspace_bytes(B), device=dev, dtype=torch.uint8)
             with torch.cuda.device(dev):
                 lib.frame_geometry_batch(B, geo, N, _p(mean), _p(qvec), _p(svec), W, H, _p(bws) + nb_sh, s)
+                br._end_batch(B)
                 if stats is not None:
                     lib.densify_update_batch(B, N, _tab([_p(br.slots[i].cov2d) for i in range(B)]), None,
                                              _tab([_p(br.slots[i].mask) for i in range(B)]), _p(stats.max_radii2d),
@@ -261,7 +277,8 @@ class _render_batch_heads(torch.autograd.Function):
             _render_batch_heads._forward_streams(br, B, lib, mean, qvec, svec, alpha, col, cams, out6, T, thresh, stats)
         if bg_rgb is not None:
             out6[..., :3] += T * bg_rgb  # gs/renderer.py:1182
-        ctx.save_for_backward(mean, qvec, svec, alpha, col, cams, out6)
+        ctx.save_for_backward(mean, qvec, svec, alpha, col, cams, out6, T)
+        ctx.bg_shape = tuple(bg_rgb.shape) if (bg_rgb is not None and ctx.needs_input_grad[8]) else None
         ctx.br, ctx.B, ctx.thresh, ctx.detach, ctx.stats = br, B, thresh, detach_depth, stats
         ctx.cis = list(br._cis[:B])
         ctx.mark_non_differentiable(T)
@@ -287,10 +304,12 @@ class _render_batch_heads(torch.autograd.Function):
                                     buf.nth, buf.ntw, 1.0 / ci.fx, 1.0 / ci.fy, H, W, thresh, T_p + 4 * H * W * i,
                                     buf.tile_order(), s)
         br._join(B, cur)
+        br._end_batch(B)
 
     @staticmethod
     def backward(ctx, g_rgb, g_depth, g_opac, g_z2, _gT):
-        mean, qvec, svec, alpha, col, cams, out6 = ctx.saved_tensors
+        ctx.br._check_generation(ctx.gen)
+        mean, qvec, svec, alpha, col, cams, out6, T = ctx.saved_tensors
         br, B, thresh, stats = ctx.br, ctx.B, ctx.thresh, ctx.stats
         lib = _capi.load()
         H, W, N, dev = br.H, br.W, br.N, mean.device
@@ -329,7 +348,8 @@ class _render_batch_heads(torch.autograd.Function):
                     lib.densify_update_batch(B, N, None, _tab([g2d_p + 24 * N * i for i in range(B)]),
                                              _tab([_p(br.slots[i].mask) for i in range(B)]), None,
                                              _p(stats.grad_accum), _p(stats.cnt), s)
-            return (g_mean, g_qvec, g_svec, g_alpha, gch[:, :, :3].sum(0)) + (None,) * 7
+            return (g_mean, g_qvec, g_svec, g_alpha, gch[:, :, :3].sum(0), None, None, None, _bg_grad(ctx, g_rgb, T), None,
+                    None, None)
         cur = br._fork(B, (go6, g2d, gch, gdp, g3d))
         with torch.cuda.device(dev):
             for i in range(B):
@@ -352,7 +372,7 @@ class _render_batch_heads(torch.autograd.Function):
                                        _p(stats.cnt), s)
         br._join(B, cur)
         g_col = gch[:, :, :3].sum(0)
-        return (g_mean, g_qvec, g_svec, g_alpha, g_col) + (None,) * 7
+        return (g_mean, g_qvec, g_svec, g_alpha, g_col, None, None, None, _bg_grad(ctx, g_rgb, T), None, None, None)
 
 
 class BatchRenderer:
@@ -369,7 +389,14 @@ class BatchRenderer:
         (FrameBuffers), fused launches only."""
         self.N, self.W, self.H, self.device = N, W, H, torch.device(device)
         self.fused_launch, self.segments = bool(fused_launch), int(segments) if fused_launch else 1
-        self.slots = [R.FrameBuffers(N, W, H, device, D_cap=D_cap, segments=self.segments) for _ in range(max_batch)]
+        # the slots' pair counters live in one tensor: one copy brings a batch's counts to the host (overflow detection
+        # without a sync, see FrameBuffers.check_overflow)
+        self._totals = torch.zeros(max_batch, device=device, dtype=torch.int32)
+        self._totals_host = torch.zeros(max_batch, dtype=torch.int32).pin_memory()
+        self._totals_event, self._totals_B = None, 0
+        self._generation = 0
+        self.slots = [R.FrameBuffers(N, W, H, device, D_cap=D_cap, segments=self.segments, total=self._totals[i:i + 1])
+                      for i in range(max_batch)]
         self.streams = [torch.cuda.Stream(device=device) for _ in range(max(1, n_streams))]
         # per camera: cam block (56) | topleft (2) | rotation rows (9) | pad -> 68 floats
         # ring of pinned staging blocks: a block is only rewritten once its upload (queued behind
@@ -396,6 +423,50 @@ class BatchRenderer:
         self._copied[slot] = torch.cuda.Event()
         self._copied[slot].record(torch.cuda.current_stream(self.device))
         return dev
+
+    # ---- one-forward-one-backward contract and overflow detection ------------------------------------------------
+    def _begin_batch(self, B):
+        """Every forward starts here.  The batch's backward reads the lists its forward left in the slots, so a
+        later render (or a regrown slot) invalidates it: the generation it returns is checked in backward."""
+        self.check_overflow()
+        self._generation += 1
+        return self._generation
+
+    def _end_batch(self, B):
+        """behind the geometry enqueue: the batch's pair counts follow it to the host (one async copy, one event)"""
+        self._totals_host[:B].copy_(self._totals[:B], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self._totals_event, self._totals_B = ev, B
+
+    def _check_generation(self, gen):
+        if gen != self._generation:
+            raise RuntimeError("gsgen_amd.BatchRenderer: another render() / render_heads() (or a regrown slot) came "
+                               "between this batch's forward and its backward -- the lists the backward needs are gone. "
+                               "Call backward before the next render, or use one BatchRenderer per batch in flight "
+                               "(e.g. for gradient accumulation or an evaluation render in between).")
+
+    def check_overflow(self):
+        """No sync: if the previous batch's pair counts have reached the host and one exceeded its slot's capacity,
+        grow that slot and warn (that camera was rendered as background only, with zero gradients)."""
+        ev = self._totals_event
+        if ev is None or not ev.query():
+            return True
+        self._totals_event = None
+        ok = True
+        for i in range(self._totals_B):
+            need, s = int(self._totals_host[i]), self.slots[i]
+            if need > s.D_cap:
+                import warnings
+                old = s.D_cap
+                s._alloc_pairs(int(need * 1.25) + 1024)
+                self._generation += 1
+                warnings.warn(f"gsgen_amd: camera {i} of the previous batch needed {need} (tile, Gaussian) pairs, "
+                              f"capacity was {old}: it was rendered as BACKGROUND ONLY with zero gradients.  The slot has "
+                              f"been regrown to {s.D_cap}; call BatchRenderer.ensure_capacity() after a render to catch "
+                              f"this synchronously.", RuntimeWarning, stacklevel=3)
+                ok = False
+        return ok
 
     def _fork(self, B, tensors):
         """side streams wait for the current stream; `tensors` (allocated on the current stream)
@@ -449,7 +520,10 @@ class BatchRenderer:
     def ensure_capacity(self, B=None):
         """One host sync: grows any slot whose pair list overflowed in the last batch.  Returns
         False if a slot had to grow (that camera's image was rendered empty: render again)."""
+        self._totals_event = None
         ok = True
         for s in self.slots[:B]:
             ok = s.ensure_capacity() and ok
+        if not ok:
+            self._generation += 1  # a pending backward would read freed lists
         return ok

@@ -61,6 +61,34 @@ def build(force=False, verbose=False, extra_flags=()):
     return LIB
 
 
+EXT_DIR = os.path.join(HERE, "ext")
+
+
+def build_torch_ext(force=False, verbose=False):
+    """gsgen_amd/ext/_gs.<abi>.so: the `_gs` CPython module (torch::Tensor in, C ABI underneath, gsgen_amd/csrc/
+    torch_gs.cpp) -- what the reference builds from gs/src/bindings.cpp.  Plain host C++: compiled with g++ against
+    torch's headers and linked to the in-tree HIP library (relative rpath) and torch's own libraries."""
+    import sysconfig
+    import torch
+    lib = build()
+    os.makedirs(EXT_DIR, exist_ok=True)
+    src = os.path.join(CSRC, "torch_gs.cpp")
+    out = os.path.join(EXT_DIR, "_gs" + sysconfig.get_config_var("EXT_SUFFIX"))
+    if force or _newer(src, out, extra=(lib,)):
+        tdir = os.path.dirname(torch.__file__)
+        inc = [os.path.join(tdir, "include"), os.path.join(tdir, "include", "torch", "csrc", "api", "include"),
+               "/opt/rocm/include", sysconfig.get_paths()["include"]]
+        tlib = os.path.join(tdir, "lib")
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-deprecated-declarations", "-D__HIP_PLATFORM_AMD__=1",
+               "-DUSE_ROCM=1", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}",
+               *[f"-I{i}" for i in inc], src, "-o", out, f"-L{LIBDIR}", "-lgsgen_hip", f"-L{tlib}", "-ltorch", "-ltorch_cpu",
+               "-ltorch_python", "-lc10", "-lc10_hip", "-ltorch_hip", "-Wl,-rpath,$ORIGIN/../lib", f"-Wl,-rpath,{tlib}"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return out
+
+
 TOOLS_DIR = os.path.join(HERE, "..", "tools", "stress")
 
 
@@ -86,3 +114,5 @@ if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
     if "--tools" in sys.argv:
         print(build_tools(force="--force" in sys.argv, verbose=True))
+    if "--ext" in sys.argv:
+        print(build_torch_ext(force="--force" in sys.argv, verbose=True))

@@ -193,15 +193,8 @@ __global__ void __launch_bounds__(256 / PPL) k_composite_fwd(CompParams p_arg, c
     for (int i = 0; i < 9; ++i) R[i] = p.rot[i];
 #pragma unroll
     for (int j = 0; j < PPL; ++j) {
-      float dx = R[0] * px + R[1] * py[j] + R[2];
-      float dy = R[3] * px + R[4] * py[j] + R[5];
-      float dz = R[6] * px + R[7] * py[j] + R[8];
-      const float len = sqrtf(dx * dx + dy * dy + dz * dz);
-      dx /= len; dy /= len; dz /= len;
       float Yf[TR::CCP];
-#pragma unroll
-      for (int k = 0; k < TR::CCP; ++k) Yf[k] = 0.0f;
-      sh_basis<CB>(dx, dy, dz, *reinterpret_cast<float (*)[TR::CC]>(&Yf[0]));
+      sh_basis_of_pixel<CB>(R, px, py[j], Yf);
 #pragma unroll
       for (int k = 0; k < TR::NPAIR; ++k) Yp[j][k] = v2f{Yf[2 * k], Yf[2 * k + 1]};
       __builtin_amdgcn_sched_barrier(0);  // one pixel's temporaries at a time
@@ -225,7 +218,7 @@ __global__ void __launch_bounds__(256 / PPL) k_composite_fwd(CompParams p_arg, c
   for (int base = 0; base < n; base += kBatch) {
     const int nb = min(kBatch, n - base);
     if (base > 0) __syncthreads();  // everyone is done with the previous batch
-    stage_batch<MODE, CB, NT>(S, p, st + base, nb);
+    stage_batch<MODE, CB, NT, kBatch, MODE == MODE_SH>(S, p, st + base, nb);  // SH: coefficients x -log2(e)
     __syncthreads();
 
     for (int g = 0; g < nb; ++g) {
@@ -271,10 +264,13 @@ __global__ void __launch_bounds__(256 / PPL) k_composite_fwd(CompParams p_arg, c
           for (int k = 0; k < TR::NPAIR; ++k) q[k] = *reinterpret_cast<const v2f *>(cg + c * TR::CCP + 2 * k);
 #pragma unroll
           for (int j = 0; j < PPL; ++j) {
+            // the colour arithmetic of k_composite_fwd_sh_vec, operation for operation (pre-scaled coefficients,
+            // explicit fused accumulate): a camera renders to the same bits through either kernel
             v2f s2 = q[0] * Yp[j][0];
 #pragma unroll
-            for (int k = 1; k < TR::NPAIR; ++k) s2 = fma2(q[k], Yp[j][k], s2);
-            acc[j][c] += w[j] * sigmoid_fast(s2[0] + s2[1]);
+            for (int k = 1; k < TR::NPAIR; ++k) s2 = ffma2(q[k], Yp[j][k], s2);
+            const float yv = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(s2[0] + s2[1]));
+            acc[j][c] = ffma(w[j], yv, acc[j][c]);
           }
         }
 #pragma unroll
@@ -402,15 +398,8 @@ k_composite_fwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
 #pragma unroll
     for (int j = 0; j < PPL; ++j) {
       const float pyj = py2[j >> 1][j & 1];
-      float dx = R[0] * px + R[1] * pyj + R[2];
-      float dy = R[3] * px + R[4] * pyj + R[5];
-      float dz = R[6] * px + R[7] * pyj + R[8];
-      const float len = sqrtf(dx * dx + dy * dy + dz * dz);
-      dx /= len; dy /= len; dz /= len;
       float Yf[CCP];
-#pragma unroll
-      for (int k = 0; k < CCP; ++k) Yf[k] = 0.0f;
-      sh_basis<CB>(dx, dy, dz, *reinterpret_cast<float (*)[TR::CC]>(&Yf[0]));
+      sh_basis_of_pixel<CB>(R, px, pyj, Yf);
 #pragma unroll
       for (int k = 0; k < NPAIR; ++k) Yp[j][k] = v2f{Yf[2 * k], Yf[2 * k + 1]};
       __builtin_amdgcn_sched_barrier(0);  // one pixel's temporaries at a time
@@ -482,13 +471,13 @@ k_composite_fwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
           v2f sa = q[0] * Yp[2 * jp][0], sb = q[0] * Yp[2 * jp + 1][0];
 #pragma unroll
           for (int k = 1; k < NPAIR; ++k) {
-            sa = fma2(q[k], Yp[2 * jp][k], sa);
-            sb = fma2(q[k], Yp[2 * jp + 1][k], sb);
+            sa = ffma2(q[k], Yp[2 * jp][k], sa);
+            sb = ffma2(q[k], Yp[2 * jp + 1][k], sb);
           }
           const v2f sp = v2f{sa[0], sb[0]} + v2f{sa[1], sb[1]};
           const v2f den = splat2(1.0f) + v2f{__builtin_amdgcn_exp2f(sp[0]), __builtin_amdgcn_exp2f(sp[1])};
           const v2f yv = v2f{__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
-          acc2[jp][c] = fma2(w2[jp], yv, acc2[jp][c]);
+          acc2[jp][c] = ffma2(w2[jp], yv, acc2[jp][c]);
         }
       }
 #pragma unroll
@@ -585,15 +574,8 @@ k_composite_bwd_pixel(CompParams p_arg, const CompParams *__restrict__ plist) {
     for (int i = 0; i < 9; ++i) R[i] = p.rot[i];
 #pragma unroll
     for (int j = 0; j < PPL; ++j) {
-      float dx = R[0] * px + R[1] * py[j] + R[2];
-      float dy = R[3] * px + R[4] * py[j] + R[5];
-      float dz = R[6] * px + R[7] * py[j] + R[8];
-      const float len = sqrtf(dx * dx + dy * dy + dz * dz);
-      dx /= len; dy /= len; dz /= len;
       float Yf[TR::CCP];
-#pragma unroll
-      for (int k = 0; k < TR::CCP; ++k) Yf[k] = 0.0f;
-      sh_basis<CB>(dx, dy, dz, *reinterpret_cast<float (*)[TR::CC]>(&Yf[0]));
+      sh_basis_of_pixel<CB>(R, px, py[j], Yf);
 #pragma unroll
       for (int k = 0; k < TR::NPAIR; ++k) Yp[j][k] = v2f{Yf[2 * k], Yf[2 * k + 1]};
     }
@@ -850,15 +832,8 @@ k_composite_bwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
 #pragma unroll
     for (int j = 0; j < PPL; ++j) {
       const float pyj = py2[j >> 1][j & 1];
-      float dx = R[0] * px + R[1] * pyj + R[2];
-      float dy = R[3] * px + R[4] * pyj + R[5];
-      float dz = R[6] * px + R[7] * pyj + R[8];
-      const float len = sqrtf(dx * dx + dy * dy + dz * dz);
-      dx /= len; dy /= len; dz /= len;
       float Yf[CCP];
-#pragma unroll
-      for (int k = 0; k < CCP; ++k) Yf[k] = 0.0f;
-      sh_basis<CB>(dx, dy, dz, *reinterpret_cast<float (*)[TR::CC]>(&Yf[0]));
+      sh_basis_of_pixel<CB>(R, px, pyj, Yf);
 #pragma unroll
       for (int k = 0; k < NPAIR; ++k) Yp[j][k] = v2f{Yf[2 * k], Yf[2 * k + 1]};
       __builtin_amdgcn_sched_barrier(0);  // one pixel's temporaries at a time
@@ -1169,16 +1144,7 @@ k_composite_bwd_sh_mfma(CompParams p_arg, const CompParams *__restrict__ plist) 
   float R[9];
 #pragma unroll
   for (int i = 0; i < 9; ++i) R[i] = p.rot[i];
-  auto basis_of_pixel = [&](float qx, float qy, float (&Y)[16]) {
-    float dx = R[0] * qx + R[1] * qy + R[2];
-    float dy = R[3] * qx + R[4] * qy + R[5];
-    float dz = R[6] * qx + R[7] * qy + R[8];
-    const float len = sqrtf(dx * dx + dy * dy + dz * dz);
-    dx /= len; dy /= len; dz /= len;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) Y[k] = 0.0f;
-    sh_basis<CB>(dx, dy, dz, *reinterpret_cast<float (*)[TR::CC]>(&Y[0]));
-  };
+  auto basis_of_pixel = [&](float qx, float qy, float (&Y)[16]) { sh_basis_of_pixel<CB>(R, qx, qy, Y); };
   u32x4 Bh[KS], Bl[KS];
   {
     float Yf[PPL][16];

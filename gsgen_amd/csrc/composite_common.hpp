@@ -88,6 +88,9 @@ static __device__ __noinline__ float gauss_ref_f32(float mx, float my, float c0,
 // real SH basis, bands CB = 1..4 (shencoder.h:13-62)
 template <int CB>
 __device__ __forceinline__ void sh_basis(float x, float y, float z, float (&Y)[CB * CB]) {
+  // every product rounded (as the oracle evaluates shencoder.h): the table is the same in every kernel, whatever
+  // the compiler would have liked to contract in the code around it
+#pragma clang fp contract(off)
   Y[0] = 0.28209479177387814f;
   if constexpr (CB >= 2) {
     Y[1] = -0.48860251190291987f * y;
@@ -111,6 +114,24 @@ __device__ __forceinline__ void sh_basis(float x, float y, float z, float (&Y)[C
       Y[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
     }
   }
+}
+
+// The SH basis of the pixel whose normalised camera-space position is (qx, qy, 1): dir = normalize(R (qx, qy, 1))
+// (vol_render_sh.h:48-65; R = the 9 packed floats the reference reads from c2w), Y zero-padded to NY entries.
+// One function with contraction off: forward and backward kernels of every shape hold bit-identical tables, hence
+// render a camera to the same bits whether it goes through a per-camera or a batched launch.
+template <int CB, int NY>
+__device__ __forceinline__ void sh_basis_of_pixel(const float (&R)[9], float qx, float qy, float (&Y)[NY]) {
+#pragma clang fp contract(off)
+  static_assert(NY >= CB * CB, "room for the basis");
+  float dx = R[0] * qx + R[1] * qy + R[2];
+  float dy = R[3] * qx + R[4] * qy + R[5];
+  float dz = R[6] * qx + R[7] * qy + R[8];
+  const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+  dx /= len; dy /= len; dz /= len;
+#pragma unroll
+  for (int k = 0; k < NY; ++k) Y[k] = 0.0f;
+  sh_basis<CB>(dx, dy, dz, *reinterpret_cast<float (*)[CB * CB]>(&Y[0]));
 }
 
 __device__ __forceinline__ float sigmoid_fast(float s) {

@@ -27,11 +27,30 @@ def shard_sizes(n_items, world):
     return [shard_bounds(n_items, r, world)[1] - shard_bounds(n_items, r, world)[0] for r in range(world)]
 
 
+class _AllGatherImages(torch.autograd.Function):
+    """all_gather_into_tensor whose backward hands every rank the gradient of ITS OWN shard (each rank evaluates the
+    loss on the gathered batch; the other shards' gradients belong to the ranks that rendered them) -- so a loss on the
+    gathered batch trains exactly as it does at world size 1, where `local` itself is returned."""
+
+    @staticmethod
+    def forward(ctx, send, group):
+        world = dist.get_world_size(group)
+        recv = torch.empty((world * send.shape[0],) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+        dist.all_gather_into_tensor(recv, send.contiguous(), group=group)
+        ctx.rank, ctx.n = dist.get_rank(group), send.shape[0]
+        return recv
+
+    @staticmethod
+    def backward(ctx, grad):
+        return grad[ctx.rank * ctx.n:(ctx.rank + 1) * ctx.n].contiguous(), None
+
+
 def gather_images(local, n_total, group=None):
     """all_gather of per-rank image stacks.
 
     local: [b_local, H, W, C] tensor of this rank's rendered cameras (b_local from shard_bounds).
-    Returns [n_total, H, W, C] on every rank, in camera order.  Uneven shards are padded to the
+    Returns [n_total, H, W, C] on every rank, in camera order; gradients of a loss on the result flow back to this
+    rank's own `local` (as they do at world size 1).  Uneven shards are padded to the
     largest shard so that a single all_gather_into_tensor moves everything (one collective per
     batch; on MI355X a direct all-gather uses all 7 xGMI links of a GPU at once)."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
@@ -45,9 +64,7 @@ def gather_images(local, n_total, group=None):
     if local.shape[0] < bmax:
         pad = torch.zeros((bmax - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         send = torch.cat([local, pad], 0)
-    send = send.contiguous()
-    recv = torch.empty((world * bmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(recv, send, group=group)
+    recv = _AllGatherImages.apply(send, group)  # differentiable wrt this rank's own images
     if all(s == bmax for s in sizes):
         return recv
     parts = [recv[r * bmax:r * bmax + sizes[r]] for r in range(world)]

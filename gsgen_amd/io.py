@@ -21,7 +21,10 @@ def _np(params, key):
 
 
 def _sigmoid(x):
-    return (1.0 / (1.0 + np.exp(-x.astype(np.float32), dtype=np.float32))).astype(np.float32)
+    """torch.sigmoid, as utils/export.py uses it: the u8 truncation that follows is sensitive to the last bit, and
+    a numpy 1 / (1 + exp(-x)) differs from torch's kernel on rare values"""
+    import torch
+    return torch.sigmoid(torch.from_numpy(np.ascontiguousarray(x, np.float32))).numpy()
 
 
 # ---- checkpoint ---------------------------------------------------------------------------------

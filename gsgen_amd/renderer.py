@@ -202,8 +202,10 @@ class FrameBuffers:
     """Device buffers of the fused path for one (N, W, H) shape.  D_cap is the capacity of the
     (tile, Gaussian) pair list; `ensure_capacity()` grows it after an overflow."""
 
-    def __init__(self, N, W, H, device, D_cap=None, segments=1):
-        """segments > 1: the SH backward runs one workgroup per (tile, 32-entry list segment) from
+    def __init__(self, N, W, H, device, D_cap=None, segments=1, total=None):
+        """total: optional int32 [1] device tensor to use as this buffer set's pair counter (BatchRenderer keeps the
+        counters of its slots in one tensor so that one copy brings a whole batch's counts to the host).
+        segments > 1: the SH backward runs one workgroup per (tile, 32-entry list segment) from
         checkpoints the forward leaves in `seg_ws` (gsgen_vol_render_sh_segmented) -- shorter tail for
         a lone render, slightly more total work; 1 (one workgroup per tile) is best when several
         renders are in flight."""
@@ -221,11 +223,20 @@ class FrameBuffers:
         self.mask = torch.empty(N, device=device, dtype=torch.bool)
         self.start = torch.empty(self.nth * self.ntw, device=device, dtype=torch.int32)
         self.end = torch.empty_like(self.start)
-        self.total = torch.zeros(1, device=device, dtype=torch.int32)
+        self.total = total if total is not None else torch.zeros(1, device=device, dtype=torch.int32)
         self.D_cap = 0
+        # `generation` counts the forwards that rewrote these buffers (and regrowths): a backward whose forward is no
+        # longer the latest user raises instead of reading another frame's lists.  `_total_host` / `_total_event`: the
+        # pair count of the last frame travels to pinned host memory behind the frame (no sync); the next forward
+        # looks at it when it has arrived and regrows + warns after an overflow (a frame whose pair list overflowed
+        # is rendered as background only).
+        self.generation = 0
+        self._total_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._total_event = None
         self._alloc_pairs(D_cap if D_cap else max(16 * N, 1 << 16))
 
     def _alloc_pairs(self, D_cap):
+        self.generation += 1  # pending backwards hold pointers into the old lists
         self.D_cap = int(D_cap)
         self.ids = torch.empty(self.D_cap, device=self.device, dtype=torch.int32)
         nbytes = _capi.load().frame_workspace_bytes(self.N, self.D_cap, self.nth * self.ntw)
@@ -236,10 +247,46 @@ class FrameBuffers:
         return _capi.load().frame_tile_order(self.ws.data_ptr(), self.N, self.D_cap, self.nth * self.ntw)
 
     def ensure_capacity(self):
-        """Host-side check (one sync): did the last frame fit?  Grows the pair buffers if not."""
+        """Host-side check (one sync): did the last frame fit?  Grows the pair buffers if not (False: that frame was
+        rendered as background only -- render it again)."""
+        self._total_event = None
         need = int(self.total.item())
         if need > self.D_cap:
             self._alloc_pairs(int(need * 1.25) + 1024)
+            return False
+        return True
+
+    def begin_frame(self):
+        """Every forward through these buffers starts here: -> the generation its backward must still find."""
+        self.check_overflow()
+        self.generation += 1
+        return self.generation
+
+    def end_frame(self, stream=None):
+        """after the geometry enqueue: the frame's pair count follows it to the host, asynchronously"""
+        st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(st):
+            self._total_host.copy_(self.total, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(st)
+        self._total_event = ev
+
+    def check_overflow(self):
+        """No sync: if the previous frame's pair count has reached the host and exceeded the capacity, grow the
+        buffers and warn (that frame showed background only, with zero gradients).  Returns False in that case."""
+        ev = self._total_event
+        if ev is None or not ev.query():
+            return True
+        self._total_event = None
+        need = int(self._total_host.item())
+        if need > self.D_cap:
+            import warnings
+            old = self.D_cap
+            self._alloc_pairs(int(need * 1.25) + 1024)
+            warnings.warn(f"gsgen_amd: the previous frame through these buffers needed {need} (tile, Gaussian) pairs, "
+                          f"capacity was {old}: it was rendered as BACKGROUND ONLY with zero gradients.  The buffers "
+                          f"have been regrown to {self.D_cap}; call FrameBuffers.ensure_capacity() after a render to "
+                          f"catch this synchronously.", RuntimeWarning, stacklevel=3)
             return False
         return True
 
@@ -288,7 +335,9 @@ class _render_frame(torch.autograd.Function):
         lib = _capi.load()
         H, W = buf.H, buf.W
         dev = mean.device
+        ctx.gen = buf.begin_frame()
         frame_geometry(mean, qvec, svec, cam_dev, buf)
+        buf.end_frame()
         if stats is not None:
             stats.update_radii(buf.cov2d, buf.mask)
         out = torch.zeros(H, W, 3, device=dev, dtype=torch.float32)
@@ -308,17 +357,21 @@ class _render_frame(torch.autograd.Function):
                                                 W, thresh, _p(T), s)
                 if bg_rgb is not None:
                     out = out + T * bg_rgb
-        ctx.save_for_backward(mean, qvec, svec, alpha, col, cam_dev, topleft, rot, out)
+        ctx.save_for_backward(mean, qvec, svec, alpha, col, cam_dev, topleft, rot, out, T)
         ctx.buf, ctx.cam_info, ctx.C, ctx.thresh, ctx.detach = buf, cam_info, C, thresh, detach_depth
-        ctx.has_bg = bg_rgb is not None
+        ctx.bg_shape = tuple(bg_rgb.shape) if (bg_rgb is not None and ctx.needs_input_grad[8]) else None
         ctx.stats = stats
         ctx.mark_non_differentiable(T)
         return out, T
 
     @staticmethod
     def backward(ctx, grad, _gT):
-        mean, qvec, svec, alpha, col, cam_dev, topleft, rot, out = ctx.saved_tensors
+        mean, qvec, svec, alpha, col, cam_dev, topleft, rot, out, T = ctx.saved_tensors
         buf, ci, C, thresh = ctx.buf, ctx.cam_info, ctx.C, ctx.thresh
+        if ctx.gen != buf.generation:
+            raise RuntimeError("gsgen_amd.render_frame: these FrameBuffers were used by a later render (or regrown) "
+                               "before this frame's backward ran -- its lists are gone.  Run backward before the next "
+                               "render with the same buffers, or give every frame in flight its own FrameBuffers.")
         lib = _capi.load()
         dev = mean.device
         H, W, N = buf.H, buf.W, buf.N
@@ -347,7 +400,9 @@ class _render_frame(torch.autograd.Function):
                                                   None, _p(g_mean), _p(g_qvec), _p(g_svec), s)
         if ctx.stats is not None:
             ctx.stats.update_grad(g_mean2d, buf.mask)
-        return (g_mean, g_qvec, g_svec, g_alpha, g_col) + (None,) * 10
+        # d/d bg of out = ... + T * bg (gs/renderer.py:1283: nan_to_num(grad * T)), reduced to bg's shape
+        g_bg = torch.nan_to_num(grad * T).sum_to_size(ctx.bg_shape) if ctx.bg_shape is not None else None
+        return (g_mean, g_qvec, g_svec, g_alpha, g_col, None, None, None, g_bg) + (None,) * 6
 
 
 def render_frame(mean, qvec, svec, alpha, col, cam_info, c2w, buf, C=0, bg_rgb=None, thresh=1e-4,

@@ -4,8 +4,8 @@ put the MI355X rasterizer behind the reference's `try: import _gs as _backend`
 
     PYTHONPATH=/path/to/repo:/path/to/repo/shim python main.py ...
 
-The module object that ends up in sys.modules["_gs"] IS gsgen_amd._gs (same functions, same
-identity), exactly as gsgen_amd.install_as_gs() would have registered it."""
+The module object that ends up in sys.modules["_gs"] is what gsgen_amd.install_as_gs() registers: the compiled
+extension gsgen_amd/ext/_gs.*.so when it has been built, else the ctypes mirror gsgen_amd._gs (same functions)."""
 import os
 import sys
 

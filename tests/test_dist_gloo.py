@@ -143,3 +143,58 @@ def test_flat_parameter_buffer_one_allreduce():
         assert p.exitcode == 0
     want = np.concatenate([np.full(60, 1.5 * 1), np.full(20, 1.5 * 2), np.full(240, 1.5 * 3)]).astype(np.float32)
     assert np.array_equal(got, want)
+
+
+def _gather_grad_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_total = 5  # uneven shards at world 2: 3 + 2
+    lo, hi = D.shard_bounds(n_total, rank, world)
+    torch.manual_seed(0)
+    full = torch.randn(n_total, 4, 6, 3)
+    local = full[lo:hi].clone().requires_grad_(True)
+    gathered = D.gather_images(local, n_total)
+    assert torch.equal(gathered.detach(), full)
+    w = torch.arange(gathered.numel(), dtype=torch.float32).reshape(gathered.shape)
+    (gathered * w).sum().backward()  # every rank evaluates the loss on the whole batch
+    q.put((rank, local.grad.numpy(), w[lo:hi].numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gathered_batch_is_differentiable_wrt_the_local_shard():
+    """a loss on the gathered batch must send gradients back to the rank's own images (as it does at world
+    size 1), instead of silently dropping the local graph"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, grad, want in got:
+        assert np.array_equal(grad, want), rank
+
+
+def test_bench_camera_shards_partition_the_64_poses():
+    """bench.py --gpus N (BASELINE configs[3]): the ranks' camera lists are the contiguous shards of ONE seeded set of
+    64 poses -- disjoint, complete, in order; and the self-launch command starts N ranks on 127.0.0.1"""
+    import sys
+    sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+    import bench
+    allc = bench.random_pose_cameras(64, 0, 1, 512, 512)
+    for world in (2, 4, 8, 3):
+        parts = [bench.random_pose_cameras(64, r, world, 512, 512) for r in range(world)]
+        assert sum(len(p) for p in parts) == 64
+        flat = [c for p in parts for c in p]
+        for a, b in zip(flat, allc):
+            assert a.fx == b.fx and np.array_equal(a.c2w, b.c2w)
+    # elevation stays within [-20, 90] degrees and the focal within [0.7, 1.35] x resolution (data/__init__.py:151-205)
+    for c in allc:
+        pos = c.c2w[:, 3]
+        elev = np.rad2deg(np.arcsin(pos[2] / np.linalg.norm(pos)))
+        assert -20.5 <= elev <= 90.0 and 0.7 * 512 <= c.fx <= 1.35 * 512 and 1.99 <= np.linalg.norm(pos) <= 2.51

@@ -708,3 +708,66 @@ def test_frame_is_hip_graph_capturable():
     assert torch.equal(out, ref_out)
     for a, b in zip(g3, ref_g):
         assert float((a - b).abs().max() / (b.abs().max() + 1e-30)) < 1e-4
+
+
+def test_stale_backward_overflow_warning_and_background_gradient():
+    """(1) a backward whose forward state was overwritten by a later render raises instead of returning
+    another frame's gradients; (2) a frame whose pair list overflowed is reported at the next render (no sync, a
+    RuntimeWarning) and the buffers regrown; (3) a trainable background gets nan_to_num(grad * T) through the fused
+    paths (gs/renderer.py:1283), reduced to its shape."""
+    import warnings
+    from gsgen_amd import renderer as R
+    from gsgen_amd.batch import BatchRenderer
+    sc = scenes.random_scene(3000, seed=4, svec=0.03, C=2)
+    N = sc["mean"].shape[0]
+    W, H = 96, 64
+    cams = [scenes.Camera(W, H, fx=90.0, c2w=scenes.orbit(2.4, 10 + 5 * i, 60.0 * i)) for i in range(3)]
+    cis = [R.CameraInfo(*c.intr) for c in cams]
+    P = {k: T_(sc[k]).requires_grad_(True) for k in ("mean", "qvec", "svec", "alpha", "sh")}
+    # (1) FrameBuffers
+    buf = R.FrameBuffers(N, W, H, dev())
+    rgb1, _ = R.render_frame(P["mean"], P["qvec"], P["svec"], P["alpha"], P["sh"], cis[0], cams[0].c2w, buf, C=2)
+    rgb2, _ = R.render_frame(P["mean"], P["qvec"], P["svec"], P["alpha"], P["sh"], cis[1], cams[1].c2w, buf, C=2)
+    with pytest.raises(RuntimeError, match="later render"):
+        rgb1.sum().backward()
+    rgb2.sum().backward()  # the latest frame is fine
+    # (1) BatchRenderer
+    br = BatchRenderer(N, W, H, dev(), max_batch=3)
+    a, _ = br.render(P["mean"], P["qvec"], P["svec"], P["alpha"], P["sh"], cis, [c.c2w for c in cams], C=2)
+    b, _ = br.render(P["mean"], P["qvec"], P["svec"], P["alpha"], P["sh"], cis, [c.c2w for c in cams], C=2)
+    with pytest.raises(RuntimeError, match="between this batch's forward and its backward"):
+        a.sum().backward()
+    b.sum().backward()
+    # (2) overflow: capacity far too small -> the frame is background only; the NEXT render warns and regrows
+    small = R.FrameBuffers(N, W, H, dev(), D_cap=64)
+    with torch.no_grad():
+        img, _ = R.render_frame(P["mean"], P["qvec"], P["svec"], P["alpha"], P["sh"], cis[0], cams[0].c2w, small, C=2)
+        torch.cuda.synchronize()  # (the count has reached the host; without this the warning comes one render later)
+        assert float(img.abs().max()) == 0.0
+        with pytest.warns(RuntimeWarning, match="BACKGROUND ONLY"):
+            img2, _ = R.render_frame(P["mean"], P["qvec"], P["svec"], P["alpha"], P["sh"], cis[0], cams[0].c2w, small, C=2)
+        assert small.D_cap > 64 and float(img2.abs().max()) > 0.0
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            torch.cuda.synchronize()
+            R.render_frame(P["mean"], P["qvec"], P["svec"], P["alpha"], P["sh"], cis[0], cams[0].c2w, small, C=2)
+    # (3) background gradients: SH batch with an rgb triple, post-activation colours with a full background image, heads
+    go = torch.randn(3, H, W, 3, device=dev())
+    bg3 = torch.tensor([0.2, 0.4, 0.6], device=dev(), requires_grad=True)
+    out, T = br.render(P["mean"], P["qvec"], P["svec"], P["alpha"], P["sh"], cis, [c.c2w for c in cams], C=2, bg_rgb=bg3)
+    (out * go).sum().backward()
+    assert torch.allclose(bg3.grad, (go * T).sum((0, 1, 2)), rtol=1e-5, atol=1e-5)
+    col = torch.sigmoid(T_(sc["sh"][:, :, 0])).requires_grad_(True)
+    bgi = torch.rand(3, H, W, 3, device=dev(), requires_grad=True)
+    out, T = br.render(P["mean"], P["qvec"], P["svec"], P["alpha"], col, cis, [c.c2w for c in cams], C=0, bg_rgb=bgi)
+    (out * go).sum().backward()
+    assert torch.allclose(bgi.grad, go * T, rtol=1e-6, atol=1e-6)
+    bg3.grad = None
+    rgb, dpt, opa, z2, T = br.render_heads(P["mean"], P["qvec"], P["svec"], P["alpha"], col, cis, [c.c2w for c in cams], bg_rgb=bg3)
+    ((rgb * go).sum() + dpt.sum()).backward()
+    assert torch.allclose(bg3.grad, (go * T).sum((0, 1, 2)), rtol=1e-5, atol=1e-5)
+    bg1 = torch.tensor([0.1, 0.5, 0.9], device=dev(), requires_grad=True)
+    f = R.FrameBuffers(N, W, H, dev())
+    out, T = R.render_frame(P["mean"], P["qvec"], P["svec"], P["alpha"], P["sh"], cis[0], cams[0].c2w, f, C=2, bg_rgb=bg1)
+    (out * go[0]).sum().backward()
+    assert torch.allclose(bg1.grad, (go[0] * T).sum((0, 1)), rtol=1e-5, atol=1e-5)

@@ -1,0 +1,200 @@
+"""The compiled `_gs` module (gsgen_amd/csrc/torch_gs.cpp -> gsgen_amd/ext/_gs.*.so): the reference's pybind surface
+(gs/src/bindings.cpp:5-82) over the C ABI.
+
+CPU part: it is built, imports, exports exactly the names the reference's bindings.cpp defines (parsed from the
+reference when it is present, else the committed list), and raises the reference's precondition errors.
+GPU part (-m gpu): every live entry point against the reference-generated golden vectors THROUGH the compiled module
+(the same values tests/test_gpu_golden.py holds the C ABI to), agreement with the ctypes mirror, and the host cost
+of a call."""
+import glob
+import os
+import re
+import time
+
+import numpy as np
+import pytest
+import torch
+
+import gsgen_amd
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+GOLD = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "*.npz")))
+REFERENCE_NAMES = sorted("""culling_gaussian_bsphere count_num_gaussians_each_tile count_num_gaussians_each_tile_bcircle
+prepare_image_sort image_sort tile_based_vol_rendering tile_based_vol_rendering_backward debug_check_tiledepth
+tile_culling_aabb tile_based_vol_rendering_v1 tile_based_vol_rendering_v2 tile_culling_aabb_start_end
+tile_based_vol_rendering_start_end tile_based_vol_rendering_backward_start_end tile_based_vol_rendering_sh
+tile_based_vol_rendering_backward_sh tile_based_vol_rendering_backward_sh_v1
+tile_based_vol_rendering_backward_sh_warp_reduce tile_based_vol_rendering_sh_with_bg
+tile_based_vol_rendering_backward_sh_with_bg tile_based_vol_rendering_scalar tile_based_vol_rendering_scalar_backward
+tile_based_vol_rendering_start_end_with_T""".split())
+
+
+@pytest.fixture(scope="module")
+def ext():
+    from gsgen_amd import build
+    build.build_torch_ext()
+    mod = gsgen_amd.compiled_gs()
+    assert mod is not None
+    return mod
+
+
+def test_compiled_module_exports_the_reference_surface(ext):
+    names = sorted(n for n in dir(ext) if not n.startswith("_") and n != "gsgen_version")
+    assert names == REFERENCE_NAMES and len(names) == 23
+    ref = "/root/reference/gs/src/bindings.cpp"
+    if os.path.exists(ref):  # the list above is the reference's, not ours
+        assert sorted(re.findall(r'm\.def\(\s*"(\w+)"', open(ref).read())) == REFERENCE_NAMES
+    from gsgen_amd import _gs as mirror
+    for n in REFERENCE_NAMES:  # the ctypes mirror covers the same surface
+        assert callable(getattr(mirror, n)), n
+    assert ext.gsgen_version().startswith("gsgen_hip")
+    assert gsgen_amd.install_as_gs() is ext or gsgen_amd.install_as_gs().__file__ == ext.__file__
+
+
+def test_compiled_module_precondition_errors(ext):
+    a = torch.zeros(4, 3)
+    with pytest.raises(RuntimeError, match="mean must be a CUDA tensor"):  # CHECK_CUDA, gs/src/include/common.h:29-54
+        ext.culling_gaussian_bsphere(a, a, a, a, a, torch.zeros(4, dtype=torch.bool), 6.0)
+    with pytest.raises(TypeError):  # pybind11 argument conversion, as in the reference
+        ext.culling_gaussian_bsphere(a, a, a)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+gpu = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def T_(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+@gpu
+def test_compiled_module_rejects_bad_tensors_on_gpu(ext):
+    a = torch.zeros(4, 3, device=dev())
+    m = torch.zeros(4, dtype=torch.bool, device=dev())
+    with pytest.raises(RuntimeError, match="must be a contiguous tensor"):
+        ext.culling_gaussian_bsphere(a.t(), a, a, a, a, m, 6.0)
+    with pytest.raises(RuntimeError, match="must be an bool tensor"):
+        ext.culling_gaussian_bsphere(a, a, a, a, a, torch.zeros(4, device=dev()), 6.0)
+    with pytest.raises(RuntimeError, match="must be a floating tensor"):
+        ext.culling_gaussian_bsphere(a.double(), a, a, a, a, m, 6.0)
+
+
+@gpu
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[:-4] for p in GOLD])
+def test_golden_through_the_compiled_module(ext, path):
+    g = dict(np.load(path))
+    m = g["mask"].astype(bool)
+    fx, fy, cx, cy, w, h = g["cam_intr"][:6]
+    w, h = int(w), int(h)
+    nth, ntw = (h + 15) // 16, (w + 15) // 16
+    mean, q, sv = T_(g["in_mean"]), T_(g["in_qvec"]), T_(g["in_svec"])
+    mask = torch.zeros(mean.shape[0], dtype=torch.bool, device=dev())
+    ext.culling_gaussian_bsphere(mean, q, sv, T_(g["frustum_normals"]), T_(g["frustum_pts"]), mask, 6.0)
+    assert np.array_equal(mask.cpu().numpy(), m)
+    D = int(g["D"])
+    ids = torch.zeros(D, dtype=torch.int32, device=dev())
+    st = -torch.ones(nth * ntw, dtype=torch.int32, device=dev())
+    en = -torch.ones_like(st)
+    ext.tile_culling_aabb_start_end(T_(g["tl"]), T_(g["br"]), ids, st, en, T_(g["depth"]), nth, ntw)
+    assert np.array_equal(ids.cpu().numpy(), g["ids"])
+    assert np.array_equal(st.cpu().numpy(), g["start"]) and np.array_equal(en.cpu().numpy(), g["end"])
+    m2, c2 = T_(g["mean2d"]), T_(g["cov2d"])
+    col, al = T_(g["in_color"][m]), T_(g["in_alpha"][m])
+    topleft = T_(np.array([-cx / fx, -cy / fy], np.float32))
+    geo = (16, nth, ntw, float(1 / fx), float(1 / fy), h, w, 1e-4)
+    out = torch.zeros(h, w, 3, device=dev())
+    T = torch.ones(h, w, 1, device=dev())
+    ext.tile_based_vol_rendering_start_end_with_T(m2, c2, col, al, st, en, ids, out, topleft, *geo, T)
+    assert np.abs(out.cpu().numpy() - g["rgb"]).max() <= 1e-4 and np.abs(T.cpu().numpy() - g["T"]).max() <= 1e-4
+    final = T_((g["rgb"] + g["T"] * g["bg_img"]).astype(np.float32))
+    go = T_(g["grad_out"])
+    gm, gc = torch.zeros_like(m2), torch.zeros_like(c2)
+    gcol, ga = torch.zeros_like(col), torch.zeros_like(al)
+    ext.tile_based_vol_rendering_backward_start_end(m2, c2, col, al, st, en, ids, final, gm, gc, gcol, ga, go, topleft, *geo)
+    for a, k in ((gm, "rgb_gmean"), (gc, "rgb_gcov"), (gcol, "rgb_gcol"), (ga, "rgb_galpha")):
+        assert rel(a.cpu().numpy(), g[k]) < 1e-3, k
+    # scalar head (depth), T overwritten in place
+    dep = T_(g["depth"])
+    s_img = torch.zeros(h * w, device=dev())
+    sT = torch.ones(h, w, 1, device=dev())
+    ext.tile_based_vol_rendering_scalar(m2, c2, dep, al, st, en, ids, s_img, topleft, *geo, sT)
+    assert np.abs(s_img.cpu().numpy().reshape(h, w) - g["depth_img"]).max() <= 1e-4 * max(1.0, np.abs(g["depth_img"]).max())
+    gm, gc, gs_, ga = torch.zeros_like(m2), torch.zeros_like(c2), torch.zeros_like(dep), torch.zeros_like(al)
+    ext.tile_based_vol_rendering_scalar_backward(m2, c2, dep, al, st, en, ids, T_(g["depth_img"]).reshape(-1), gm, gc, gs_, ga,
+                                                 T_(np.ascontiguousarray(g["grad_out"][..., 0])), topleft, *geo)
+    for a, k in ((gm, "sc_gmean"), (gc, "sc_gcov"), (gs_, "sc_gscalar"), (ga, "sc_galpha")):
+        assert rel(a.cpu().numpy().reshape(g[k].shape), g[k]) < 1e-3, k
+    # spherical harmonics, without and with background
+    C = int(g["C"])
+    sh = T_(g["in_sh"][m])
+    rot = T_(np.ascontiguousarray(g["c2w"][:3, :3]))
+    for tag, bg in (("sh", None), ("shbg", T_(g["bg_rgb"]))):
+        img = torch.zeros(h * w * 3, device=dev())
+        a = (m2, c2, sh, al, st, en, ids, img, topleft, rot, 16, nth, ntw, float(1 / fx), float(1 / fy), h, w, C, 1e-4)
+        ext.tile_based_vol_rendering_sh(*a) if bg is None else ext.tile_based_vol_rendering_sh_with_bg(*a, bg)
+        assert np.abs(img.cpu().numpy().reshape(h, w, 3) - g[tag + "_img"]).max() <= 1e-4, tag
+        gm, gc, gsh, ga = torch.zeros_like(m2), torch.zeros_like(c2), torch.zeros_like(sh), torch.zeros_like(al)
+        b = (m2, c2, sh, al, st, en, ids, T_(g[tag + "_img"]).reshape(-1), gm, gc, gsh, ga, go, topleft, rot, 16, nth, ntw,
+             float(1 / fx), float(1 / fy), h, w, C, 1e-4)
+        (ext.tile_based_vol_rendering_backward_sh(*b) if bg is None
+         else ext.tile_based_vol_rendering_backward_sh_with_bg(*b, bg))
+        for x, k in ((gm, "_gmean"), (gc, "_gcov"), (gsh, "_gsh"), (ga, "_galpha")):
+            assert rel(x.cpu().numpy(), g[tag + k]) < 1e-3, tag + k
+    # CSR compat forms agree with the start/end forms
+    off = torch.zeros(nth * ntw + 1, dtype=torch.int32, device=dev())
+    ids2 = torch.zeros(D, dtype=torch.int32, device=dev())
+    ext.tile_culling_aabb(T_(g["tl"]), T_(g["br"]), ids2, off, T_(g["depth"]), nth, ntw)
+    assert torch.equal(ids2, ids) and int(off[-1]) == D
+    out2 = torch.zeros(h * w * 3, device=dev())
+    ext.tile_based_vol_rendering(m2, c2, col, al, off, ids2, out2, topleft, *geo)
+    assert torch.equal(out2.reshape(h, w, 3), out)
+
+
+@gpu
+def test_compiled_module_agrees_with_the_ctypes_mirror_and_is_cheap_to_call(ext):
+    """same kernels underneath: bit-identical outputs; and the host cost of one call (tensor unpacking, checks, one
+    launch) stays in the microseconds (< 15 us per render call)"""
+    from gsgen_amd import _gs as mirror
+    g = dict(np.load(GOLD[-1]))
+    m = g["mask"].astype(bool)
+    fx, fy, cx, cy, w, h = g["cam_intr"][:6]
+    w, h = int(w), int(h)
+    nth, ntw = (h + 15) // 16, (w + 15) // 16
+    m2, c2, sh, al = T_(g["mean2d"]), T_(g["cov2d"]), T_(g["in_sh"][m]), T_(g["in_alpha"][m])
+    st, en, ids = T_(g["start"]), T_(g["end"]), T_(g["ids"])
+    topleft = T_(np.array([-cx / fx, -cy / fy], np.float32))
+    rot = T_(np.ascontiguousarray(g["c2w"][:3, :3]))
+    C = int(g["C"])
+    outs = []
+    for mod in (ext, mirror):
+        img = torch.zeros(h * w * 3, device=dev())
+        mod.tile_based_vol_rendering_sh(m2, c2, sh, al, st, en, ids, img, topleft, rot, 16, nth, ntw, float(1 / fx),
+                                        float(1 / fy), h, w, C, 1e-4)
+        outs.append(img)
+    assert torch.equal(outs[0], outs[1])
+    cost = {}
+    for name, mod in (("compiled", ext), ("ctypes", mirror)):
+        img = torch.zeros(h * w * 3, device=dev())
+        args = (m2, c2, sh, al, st, en, ids, img, topleft, rot, 16, nth, ntw, float(1 / fx), float(1 / fy), h, w, C, 1e-4)
+        for _ in range(50):
+            mod.tile_based_vol_rendering_sh(*args)
+        torch.cuda.synchronize()
+        best = 1e9
+        for _ in range(5):
+            t0 = time.perf_counter()
+            for _ in range(200):
+                mod.tile_based_vol_rendering_sh(*args)
+            best = min(best, (time.perf_counter() - t0) / 200)
+            torch.cuda.synchronize()
+        cost[name] = best * 1e6
+    print(f"host cost per tile_based_vol_rendering_sh call: compiled {cost['compiled']:.1f} us, ctypes {cost['ctypes']:.1f} us")
+    assert cost["compiled"] < 15.0, cost
