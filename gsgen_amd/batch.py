@@ -96,21 +96,18 @@ class _render_batch(torch.autograd.Function):
         H, W, N, dev = br.H, br.W, br.N, mean.device
         cams_p, out_p, T_p = cams.data_ptr(), out.data_ptr(), T.data_ptr()
         s = torch.cuda.current_stream(dev).cuda_stream
-        geo = (_capi.GeometryView * B)()
-        views = ((_capi.ShView if C > 0 else _capi.RgbdView) * B)()  # C == 0: post-activation colours
+        # the slots' buffer addresses sit in cached tables (BatchRenderer._tables); only what changes per call is set
+        geo, views = br._tables("sh" if C > 0 else "rgb")  # C == 0: post-activation colours
+        bg_p = _p(bg_rgb)
         for i in range(B):
-            buf, ci, g, v = br.slots[i], br._cis[i], geo[i], views[i]
+            ci, g, v = br._cis[i], geo[i], views[i]
             cam = cams_p + 272 * i  # row i: cam block | topleft at +56 floats | rotation at +58
-            g.cam, g.mean2d, g.cov2d, g.depth, g.mask = cam, _p(buf.mean2d), _p(buf.cov2d), _p(buf.depth), _p(buf.mask)
-            g.gaussian_ids, g.start, g.end, g.total = _p(buf.ids), _p(buf.start), _p(buf.end), _p(buf.total)
-            g.workspace, g.workspace_bytes, g.D_cap = _p(buf.ws), buf.ws.numel(), buf.D_cap
-            v.mean, v.cov, v.start, v.end, v.gaussian_ids = _p(buf.mean2d), _p(buf.cov2d), _p(buf.start), _p(buf.end), _p(buf.ids)
-            v.tile_order, v.topleft = buf.tile_order(), cam + 224
+            g.cam = cam
+            v.topleft = cam + 224
             v.pixel_size_x, v.pixel_size_y = 1.0 / ci.fx, 1.0 / ci.fy
             v.T = T_p + 4 * H * W * i
             if C > 0:
-                v.c2w, v.bg_rgb, v.out = cam + 232, _p(bg_rgb), out_p + 12 * H * W * i
-                v.segment_workspace = _p(buf.seg_ws) if br.segments > 1 else None
+                v.c2w, v.bg_rgb, v.out = cam + 232, bg_p, out_p + 12 * H * W * i
             else:
                 v.out6 = out_p + 12 * H * W * i  # read as [H,W,3] by the RGB entry points
         # parameter tables of the batch: compositing (forward | backward) | geometry
@@ -248,17 +245,12 @@ class _render_batch_heads(torch.autograd.Function):
         ctx.gen = br._begin_batch(B)
         if br.fused_launch and B > 0:  # one enqueue per stage for the whole batch, on the current stream
             s = torch.cuda.current_stream(dev).cuda_stream
-            geo = (_capi.GeometryView * B)()
-            views = (_capi.RgbdView * B)()
+            geo, views = br._tables("rgbd")
             for i in range(B):
-                buf, ci, g, v = br.slots[i], br._cis[i], geo[i], views[i]
+                ci, g, v = br._cis[i], geo[i], views[i]
                 cam = cams_p + 272 * i
-                g.cam, g.mean2d, g.cov2d, g.depth, g.mask = cam, _p(buf.mean2d), _p(buf.cov2d), _p(buf.depth), _p(buf.mask)
-                g.gaussian_ids, g.start, g.end, g.total = _p(buf.ids), _p(buf.start), _p(buf.end), _p(buf.total)
-                g.workspace, g.workspace_bytes, g.D_cap = _p(buf.ws), buf.ws.numel(), buf.D_cap
-                v.mean, v.cov, v.depth = _p(buf.mean2d), _p(buf.cov2d), _p(buf.depth)
-                v.start, v.end, v.gaussian_ids = _p(buf.start), _p(buf.end), _p(buf.ids)
-                v.tile_order, v.topleft = buf.tile_order(), cam + 224
+                g.cam = cam
+                v.topleft = cam + 224
                 v.pixel_size_x, v.pixel_size_y = 1.0 / ci.fx, 1.0 / ci.fy
                 v.out6, v.T = out_p + 24 * H * W * i, T_p + 4 * H * W * i
             nb_sh = lib.sh_batch_workspace_bytes(B)
@@ -395,6 +387,7 @@ class BatchRenderer:
         self._totals_host = torch.zeros(max_batch, dtype=torch.int32).pin_memory()
         self._totals_event, self._totals_B = None, 0
         self._generation = 0
+        self._table_cache = {}
         self.slots = [R.FrameBuffers(N, W, H, device, D_cap=D_cap, segments=self.segments, total=self._totals[i:i + 1])
                       for i in range(max_batch)]
         self.streams = [torch.cuda.Stream(device=device) for _ in range(max(1, n_streams))]
@@ -423,6 +416,32 @@ class BatchRenderer:
         self._copied[slot] = torch.cuda.Event()
         self._copied[slot].record(torch.cuda.current_stream(self.device))
         return dev
+
+    def _tables(self, kind):
+        """(GeometryView[max_batch], ShView | RgbdView[max_batch]) with every per-slot buffer address filled in; rebuilt
+        when a slot's pair list is regrown.  One set per kind ("sh", "rgb", "rgbd"): a batch's backward reads the
+        view table its forward filled, and only one batch per BatchRenderer is between forward and backward
+        (_check_generation)."""
+        caps = tuple(s.D_cap for s in self.slots)
+        hit = self._table_cache.get(kind)
+        if hit is not None and hit[0] == caps:
+            return hit[1], hit[2]
+        n = len(self.slots)
+        geo = (_capi.GeometryView * n)()
+        views = ((_capi.ShView if kind == "sh" else _capi.RgbdView) * n)()
+        for i, buf in enumerate(self.slots):
+            g, v = geo[i], views[i]
+            g.mean2d, g.cov2d, g.depth, g.mask = _p(buf.mean2d), _p(buf.cov2d), _p(buf.depth), _p(buf.mask)
+            g.gaussian_ids, g.start, g.end, g.total = _p(buf.ids), _p(buf.start), _p(buf.end), _p(buf.total)
+            g.workspace, g.workspace_bytes, g.D_cap = _p(buf.ws), buf.ws.numel(), buf.D_cap
+            v.mean, v.cov, v.start, v.end, v.gaussian_ids = _p(buf.mean2d), _p(buf.cov2d), _p(buf.start), _p(buf.end), _p(buf.ids)
+            v.tile_order = buf.tile_order()
+            if kind == "sh":
+                v.segment_workspace = _p(buf.seg_ws) if self.segments > 1 else None
+            else:
+                v.depth = _p(buf.depth)
+        self._table_cache[kind] = (caps, geo, views)
+        return geo, views
 
     # ---- one-forward-one-backward contract and overflow detection ------------------------------------------------
     def _begin_batch(self, B):
