@@ -391,30 +391,22 @@ class BatchRenderer:
         self.slots = [R.FrameBuffers(N, W, H, device, D_cap=D_cap, segments=self.segments, total=self._totals[i:i + 1])
                       for i in range(max_batch)]
         self.streams = [torch.cuda.Stream(device=device) for _ in range(max(1, n_streams))]
-        # per camera: cam block (56) | topleft (2) | rotation rows (9) | pad -> 68 floats
-        # ring of pinned staging blocks: a block is only rewritten once its upload (queued behind
-        # whatever the stream was doing) has left it, so the host does not wait on the GPU per batch
-        self._host = [torch.empty(max_batch, 68, dtype=torch.float32).pin_memory() for _ in range(4)]
-        self._copied = [None] * len(self._host)
-        self._ring = 0
+        # per camera: cam block (56) | topleft (2) | rotation rows (9) | pad -> 68 floats, packed on the host and sent
+        # through kernel arguments (gsgen_upload_small): no pinned ring, no copy event, the host never waits
+        self._host = np.zeros((max_batch, 68), np.float32)
         self._cis = []
 
     def _upload(self, cam_infos, c2ws, frustum_radius, tile_radius):
         B = len(cam_infos)
-        slot = self._ring
-        self._ring = (self._ring + 1) % len(self._host)
-        if self._copied[slot] is not None:
-            self._copied[slot].synchronize()
-        h = self._host[slot].numpy()
+        h = self._host
         for i, (ci, c2w) in enumerate(zip(cam_infos, c2ws)):
             c2w = np.asarray(c2w.detach().cpu() if isinstance(c2w, torch.Tensor) else c2w, np.float32).reshape(-1)[:12]
             ci.pack_into(h[i], c2w, frustum_radius, tile_radius)
             h[i, 56:58] = (-ci.cx / ci.fx, -ci.cy / ci.fy)
             h[i, 58:67] = c2w.reshape(3, 4)[:, :3].reshape(-1)
         # a fresh device block per batch: the rows are saved for the batch's backward
-        dev = self._host[slot][:B].to(self.device, non_blocking=True)
-        self._copied[slot] = torch.cuda.Event()
-        self._copied[slot].record(torch.cuda.current_stream(self.device))
+        dev = torch.empty(B, 68, device=self.device, dtype=torch.float32)
+        _capi.load().upload_small(_p(dev), h.ctypes.data, B * 272, torch.cuda.current_stream(self.device).cuda_stream)
         return dev
 
     def _tables(self, kind):

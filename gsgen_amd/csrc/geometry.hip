@@ -14,6 +14,8 @@
 //   cull        gs/src/include/culling.h:10-33, kernels.h:156-170
 //   projection  gs/renderer.py:366-421, utils/transforms.py:34-46 (kornia 0.6.0 quaternion)
 //   AABB count  gs/culling.py:8-37, utils/camera.py:301-314
+#include <string.h>
+
 #include "common.hpp"
 #include "../../include/gsgen_hip.h"
 
@@ -520,6 +522,37 @@ static inline dim3 grid_for(uint32_t n) { return dim3((n + kThreads - 1) / kThre
 }  // namespace gs
 
 using namespace gs;
+
+// ---- small host -> device uploads through kernel arguments ------------------------------------------------------
+// Per-render constants (a camera block is 272 bytes) reach the device as the ARGUMENTS of a one-workgroup kernel
+// instead of a hipMemcpyAsync: the bytes are copied into the dispatch packet when the launch is enqueued, so the
+// host buffer may be reused at once, nothing is staged or pinned, the call never waits for the stream, and it can be
+// captured into a hipGraph.  (Measured on the public autograd path: torch's pinned `.to(device, non_blocking=True)`
+// of the same block cost 0.7 ms of host time per batch -- it waited for the stream -- and made BatchRenderer
+// host-bound below 4 x 512^2.)
+namespace gs {
+constexpr int kUploadWords = 896;  // 3 584 bytes per launch: below the 4 KB kernel-argument segment
+struct UploadPack { uint32_t w[kUploadWords]; };
+__global__ void __launch_bounds__(256) k_upload_words(UploadPack pack, uint32_t *dst, int n) {
+  for (int i = (int)threadIdx.x; i < n; i += (int)blockDim.x) dst[i] = pack.w[i];
+}
+}  // namespace gs
+
+extern "C" int gsgen_upload_small(void *dst, const void *host_src, size_t bytes, gsgen_stream_t stream) {
+  if (bytes == 0) return 0;
+  if (!dst || !host_src || (bytes & 3u) != 0 || (reinterpret_cast<uintptr_t>(dst) & 3u) != 0) return GSGEN_EINVAL;
+  const uint32_t *src = static_cast<const uint32_t *>(host_src);
+  uint32_t *d = static_cast<uint32_t *>(dst);
+  size_t words = bytes / 4;
+  while (words > 0) {
+    const int n = (int)(words < (size_t)gs::kUploadWords ? words : (size_t)gs::kUploadWords);
+    gs::UploadPack pack;
+    memcpy(pack.w, src, (size_t)n * 4);
+    hipLaunchKernelGGL(gs::k_upload_words, dim3(1), dim3(256), 0, (hipStream_t)stream, pack, d, n);
+    src += n; d += n; words -= (size_t)n;
+  }
+  return (int)hipGetLastError();
+}
 
 extern "C" {
 

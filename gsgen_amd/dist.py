@@ -125,3 +125,22 @@ def allreduce_gradients(tensors, group=None, average=True):
         g.copy_(flat[off:off + n].view_as(g))
         off += n
     return tensors
+
+
+def allreduce_densify_stats(stats, group=None):
+    """Camera sharding and the densify / prune policy (gs/gaussian_splatting.py:551-628, :1124-1132): every rank has
+    accumulated the statistics of ITS cameras only (renderer.DensifyStats: max_radii2d, mean-2d-gradient sum, visit
+    count).  The policy reads them and must take the same decisions on every rank -- the parameters are replicated
+    -- so before it runs the three arrays are combined exactly as one process rendering all cameras would have left
+    them: MAX for max_radii2d, SUM for the gradient sum and the count (fp32 sums in rank order: every rank receives
+    the same bits, RCCL reduces deterministically for a fixed algorithm).  Two collectives on 3 N floats; a no-op
+    without a process group.  With identical statistics, identical (seeded) RNG state and identical parameters the
+    reference's densify_by_split / densify_by_clone / prune produce identical clouds on every rank."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return stats
+    dist.all_reduce(stats.max_radii2d, op=dist.ReduceOp.MAX, group=group)
+    both = torch.stack([stats.grad_accum, stats.cnt], 0)
+    dist.all_reduce(both, op=dist.ReduceOp.SUM, group=group)
+    stats.grad_accum.copy_(both[0])
+    stats.cnt.copy_(both[1])
+    return stats

@@ -414,8 +414,15 @@ def render_frame(mean, qvec, svec, alpha, col, cam_info, c2w, buf, C=0, bg_rgb=N
     Returns (rgb [H,W,3], T [H,W,1])."""
     c2w_np = c2w.detach().cpu().numpy() if isinstance(c2w, torch.Tensor) else np.asarray(c2w)
     dev = mean.device
-    cam_dev = torch.from_numpy(cam_info.pack(c2w_np, frustum_radius, tile_radius)).to(dev, non_blocking=True)
-    topleft = torch.tensor([-cam_info.cx / cam_info.fx, -cam_info.cy / cam_info.fy], dtype=torch.float32).to(dev)
-    rot = torch.from_numpy(np.ascontiguousarray(c2w_np[:3, :3], np.float32).reshape(-1)).to(dev)
+    # cam block (56) | pixel origin (2) | rotation rows (9) | pad: packed on the host, sent through kernel arguments
+    # (gsgen_upload_small) -- three pageable `.to(device)` copies here each waited for the stream
+    h = np.zeros(68, np.float32)
+    c2w_f = np.ascontiguousarray(np.asarray(c2w_np, np.float32).reshape(-1)[:12])
+    cam_info.pack_into(h, c2w_f, frustum_radius, tile_radius)
+    h[56:58] = (-cam_info.cx / cam_info.fx, -cam_info.cy / cam_info.fy)
+    h[58:67] = c2w_f.reshape(3, 4)[:, :3].reshape(-1)
+    block = torch.empty(68, device=dev, dtype=torch.float32)
+    _capi.load().upload_small(_p(block), h.ctypes.data, 272, torch.cuda.current_stream(dev).cuda_stream)
+    cam_dev, topleft, rot = block[:56], block[56:58], block[58:67]
     return _render_frame.apply(mean, qvec, svec, alpha, col, cam_dev, topleft, rot, bg_rgb, buf, cam_info,
                                int(C), float(thresh), bool(detach_depth), stats)

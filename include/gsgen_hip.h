@@ -239,6 +239,12 @@ int gsgen_legacy_image_sort(uint32_t mode, uint32_t N, uint32_t N_with_dub, int 
  * true pair count is written to *total (device); if it exceeds D_cap nothing is binned,
  * start/end are all -1 and *total still holds the required size. */
 size_t gsgen_frame_workspace_bytes(uint32_t N, uint32_t D_cap, uint32_t n_tiles);
+/* Small host -> device upload THROUGH KERNEL ARGUMENTS (per-render constants: camera blocks, pixel origins): the bytes
+ * travel in the dispatch packets of one-workgroup kernels (3 584 bytes each), so the host buffer may be reused as soon
+ * as the call returns, nothing is staged or pinned, the call does not wait for the stream and can be captured into a
+ * hipGraph.  dst (device) and bytes must be multiples of 4.  No counterpart in the reference (it uploads with
+ * torch's `.to(device)` per camera). */
+int gsgen_upload_small(void *dst, const void *host_src, size_t bytes, gsgen_stream_t stream);
 /* HOST helper (no device work): fills cam[56] from a host c2w [3,4] and the CameraInfo fields
  * (utils/camera.py:219-259; yfov = 2 atan(h / 2fy), aspect = w / h). */
 int gsgen_pack_camera(const float *c2w, float fx, float fy, float cx, float cy, uint32_t w, uint32_t h,

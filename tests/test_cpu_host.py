@@ -301,6 +301,24 @@ def test_emulated_batched_frame_geometry_equals_per_view(emu):
     emu.frame_geometry_batch(0, arr, N, P(sc["mean"]), P(sc["qvec"]), P(sc["svec"]), W, H, None, None)
 
 
+def test_emulated_upload_small_chunks_and_argument_checks(emu):
+    """gsgen_upload_small: the bytes travel as kernel arguments, 3 584 per launch; any multiple of 4 arrives intact,
+    the source may be reused at once, misaligned sizes are refused."""
+    rng = np.random.default_rng(5)
+    for words in (1, 68, 8 * 68, 896, 897, 3000):
+        src = rng.integers(0, 2**32, words, dtype=np.uint32)
+        dst = np.zeros(words + 2, np.uint32)
+        keep = src.copy()
+        emu.upload_small(dst.ctypes.data, src.ctypes.data, words * 4, None)
+        src[:] = 0
+        assert np.array_equal(dst[:words], keep) and not dst[words:].any()
+    emu.upload_small(None, None, 0, None)  # nothing to do
+    with pytest.raises(RuntimeError, match="invalid"):
+        emu.upload_small(dst.ctypes.data, src.ctypes.data, 6, None)
+    with pytest.raises(RuntimeError, match="invalid"):
+        emu.upload_small(None, src.ctypes.data, 8, None)
+
+
 @pytest.mark.parametrize("Pc", [8, 16, 32, 64])
 def test_emulated_reduce_scatter(emu, Pc):
     x = np.random.default_rng(Pc).normal(size=(64, Pc)).astype(np.float32)

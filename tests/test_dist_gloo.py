@@ -198,3 +198,42 @@ def test_bench_camera_shards_partition_the_64_poses():
         pos = c.c2w[:, 3]
         elev = np.rad2deg(np.arcsin(pos[2] / np.linalg.norm(pos)))
         assert -20.5 <= elev <= 90.0 and 0.7 * 512 <= c.fx <= 1.35 * 512 and 1.99 <= np.linalg.norm(pos) <= 2.51
+
+
+def _densify_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import types
+    g = torch.Generator().manual_seed(7 + rank)
+    st = types.SimpleNamespace(max_radii2d=torch.rand(40, generator=g), grad_accum=torch.rand(40, generator=g),
+                               cnt=torch.randint(0, 3, (40,), generator=g).float())
+    D.allreduce_densify_stats(st)
+    q.put((rank, st.max_radii2d.numpy(), st.grad_accum.numpy(), st.cnt.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_densify_statistics_are_identical_on_every_rank():
+    """the densify / prune policy must decide identically on every rank -- the per-rank statistics are
+    combined as one process rendering all cameras would have left them (max / sum / sum), bit-identical everywhere"""
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_densify_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in range(world)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    per = []
+    for r in range(world):
+        g = torch.Generator().manual_seed(7 + r)
+        per.append((torch.rand(40, generator=g), torch.rand(40, generator=g), torch.randint(0, 3, (40,), generator=g).float()))
+    want_max = torch.stack([p_[0] for p_ in per]).max(0).values.numpy()
+    want_cnt = torch.stack([p_[2] for p_ in per]).sum(0).numpy()
+    for rank, mx, ga, cnt in got:
+        assert np.array_equal(mx, want_max) and np.array_equal(cnt, want_cnt)
+        assert np.array_equal(mx, got[0][1]) and np.array_equal(ga, got[0][2])  # the same bits on every rank
+        assert np.allclose(ga, torch.stack([p_[1] for p_ in per]).sum(0).numpy(), rtol=1e-6)

@@ -771,3 +771,51 @@ def test_stale_backward_overflow_warning_and_background_gradient():
     out, T = R.render_frame(P["mean"], P["qvec"], P["svec"], P["alpha"], P["sh"], cis[0], cams[0].c2w, f, C=2, bg_rgb=bg1)
     (out * go[0]).sum().backward()
     assert torch.allclose(bg1.grad, (go[0] * T).sum((0, 1)), rtol=1e-5, atol=1e-5)
+
+
+def test_upload_small_does_not_wait_for_the_stream_and_is_capturable():
+    """gsgen_upload_small: per-render constants travel as kernel arguments -- the call returns while the stream is
+    still busy (a pageable `.to(device)` would wait), the host buffer may be reused at once, any multiple of 4 bytes
+    arrives intact, and the launch can be captured into a hipGraph (a memcpy from pageable memory cannot)."""
+    import time
+    from gsgen_amd import _capi
+    lib = _capi.load()
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(11)
+    s = torch.cuda.current_stream(dev).cuda_stream
+    for words in (2, 68, 8 * 68, 896, 897, 2500):
+        src = rng.standard_normal(words).astype(np.float32)
+        keep = src.copy()
+        dst = torch.zeros(words + 4, device=dev)
+        lib.upload_small(dst.data_ptr(), src.ctypes.data, words * 4, s)
+        src[:] = -1.0
+        assert np.array_equal(dst[:words].cpu().numpy(), keep) and not dst[words:].any().item()
+    # the stream is kept busy for tens of milliseconds; the upload must be enqueued behind it without waiting
+    a = torch.randn(8192, 8192, device=dev)
+    torch.cuda.synchronize()
+    t_busy = time.perf_counter()
+    for _ in range(20):
+        a = a @ a
+        a = a / a.abs().max()
+    src = rng.standard_normal(8 * 68).astype(np.float32)
+    dst = torch.zeros(8 * 68, device=dev)
+    t0 = time.perf_counter()
+    lib.upload_small(dst.data_ptr(), src.ctypes.data, src.nbytes, s)
+    t_call = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    t_total = time.perf_counter() - t_busy
+    assert np.array_equal(dst.cpu().numpy(), src)
+    assert t_total > 5e-3, "the stream was not busy: the test proves nothing"
+    assert t_call < 0.2 * t_total and t_call < 2e-3, f"upload waited for the stream: {t_call * 1e3:.2f} ms of {t_total * 1e3:.1f}"
+    # graph capture
+    side = torch.cuda.Stream(device=dev)
+    g = torch.cuda.CUDAGraph()
+    dst2 = torch.zeros(68, device=dev)
+    src2 = np.arange(68, dtype=np.float32)
+    with torch.cuda.graph(g, stream=side):
+        lib.upload_small(dst2.data_ptr(), src2.ctypes.data, 272, torch.cuda.current_stream(dev).cuda_stream)
+    src2[:] = 0          # the graph carries the bytes, not the address
+    dst2.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(dst2.cpu().numpy(), np.arange(68, dtype=np.float32))
