@@ -31,6 +31,11 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// a value every lane of the wave holds identically (e.g. an LDS broadcast read), moved to a scalar register
+__device__ __forceinline__ float wave_uniform(float v) {
+  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
+
 // ---- cross-lane exchange on the VALU (no LDS traffic) ---------------------------------------
 // xchg_add<H>(lo, hi): with partner = lane ^ H, lanes with (lane & H) == 0 return
 // lo + partner.lo, the others return hi + partner.hi.  One reduce-scatter step for a pair of
@@ -50,6 +55,24 @@ constexpr int kDppQuadXor1 = 0xB1;  // quad_perm:[1,0,3,2]
 constexpr int kDppQuadXor2 = 0x4E;  // quad_perm:[2,3,0,1]
 constexpr int kDppRowShl = 0x100;   // row_shl:n -> lane i reads lane i+n of its 16-lane row
 constexpr int kDppRowShr = 0x110;   // row_shr:n -> lane i reads lane i-n
+
+// quad permute of a value every lane of which is read: no "old" operand, so the compiler folds the permute into the
+// instruction that consumes it (v_add_f32_dpp) instead of copy + v_mov_b32_dpp + add
+template <int CTRL>
+__device__ __forceinline__ float quad_perm(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+// a + b as ONE scalar add whatever the vectoriser thinks: horizontal sums of packed accumulators -- (a0 + a1, b0 + b1)
+// written as a vector expression costs three register moves and a packed add
+__device__ __forceinline__ float add_scalar(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  float r;
+  asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+#else
+  return a + b;
+#endif
+}
 
 template <int H>
 __device__ __forceinline__ float xchg_add(float lo, float hi) {
@@ -71,8 +94,8 @@ __device__ __forceinline__ float xchg_add(float lo, float hi) {
   } else {
     static_assert(H == 2 || H == 1, "H must be a power of two <= 32");
     constexpr int ctrl = (H == 2) ? kDppQuadXor2 : kDppQuadXor1;
-    const float a = lo + dpp_mov<ctrl, 0xf>(lo, lo);
-    const float b = hi + dpp_mov<ctrl, 0xf>(hi, hi);
+    const float a = lo + quad_perm<ctrl>(lo);
+    const float b = hi + quad_perm<ctrl>(hi);
     return (lane_id() & H) ? b : a;
   }
 }
@@ -189,9 +212,9 @@ __device__ __forceinline__ v2f xchg_add2(v2f lo, v2f hi) {
 }
 // v2[0 .. P/2): on return v2[0][0] in lane l holds the wave-wide total of component scatter_comp<P>(l), exactly as
 // wave_reduce_scatter<P> leaves it in v[0] (same exchange order, same owners).
-template <int P, int K>
+template <int P, int K, int KEND = 6>
 __device__ __forceinline__ void reduce_scatter2_level(v2f (&v2)[P / 2]) {
-  if constexpr (K < 6) {
+  if constexpr (K < KEND) {
     constexpr int L = kLaneDist[K];
     if constexpr (K < ilog2c(P)) {
       constexpr int S = P >> (K + 1);  // live components after this level
@@ -204,13 +227,37 @@ __device__ __forceinline__ void reduce_scatter2_level(v2f (&v2)[P / 2]) {
     } else {
       v2[0][0] = xchg_add<L>(v2[0][0], v2[0][0]);
     }
-    reduce_scatter2_level<P, K + 1>(v2);
+    reduce_scatter2_level<P, K + 1, KEND>(v2);
   }
 }
 template <int P>
 __device__ __forceinline__ void wave_reduce_scatter2(v2f (&v2)[P / 2]) {
   static_assert(P >= 2 && P <= 64 && (P & (P - 1)) == 0, "P must be a power of two, 2..64");
   reduce_scatter2_level<P, 0>(v2);
+}
+// The first four levels only (lane distances 32, 16, 8, 4; P <= 16): v2[0][0] in lane l is the total of component
+// scatter_comp<P>(l) over the 16 lanes that share l's two low bits.  Four such partial results (say of four
+// independent vectors) are then finished by ONE 4-component reduce-scatter over the distances 2 and 1
+// (quad_reduce_scatter4): the lane's low bits select the vector, so 4 x 16 components end up one per lane.
+template <int P>
+__device__ __forceinline__ float wave_reduce_scatter2_rows(v2f (&v2)[P / 2]) {
+  static_assert(P >= 2 && P <= 16 && (P & (P - 1)) == 0, "P must be a power of two, 2..16");
+  reduce_scatter2_level<P, 0, 4>(v2);
+  return v2[0][0];
+}
+// lane l returns the sum over its quad (lanes l ^ 1, l ^ 2, l ^ 3 and itself) of r[l & 3]
+__device__ __forceinline__ float quad_reduce_scatter4(float r0, float r1, float r2, float r3) {
+  r0 = xchg_add<2>(r0, r2);
+  r1 = xchg_add<2>(r1, r3);
+  return xchg_add<1>(r0, r1);
+}
+// lanes that hold a component of wave_reduce_scatter2_rows<P> exactly once within their 16-lane class
+template <int P>
+__device__ __forceinline__ bool scatter_rows_owner(int lane) {
+  int rest = 0;
+#pragma unroll
+  for (int k = ilog2c(P); k < 4; ++k) rest |= kLaneDist[k];
+  return (lane & rest) == 0;
 }
 
 // Only the log2(P) halving levels: every lane ends with the partial sum of component

@@ -474,7 +474,7 @@ k_composite_fwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
             sa = ffma2(q[k], Yp[2 * jp][k], sa);
             sb = ffma2(q[k], Yp[2 * jp + 1][k], sb);
           }
-          const v2f sp = v2f{sa[0], sb[0]} + v2f{sa[1], sb[1]};
+          const v2f sp = v2f{add_scalar(sa[0], sa[1]), add_scalar(sb[0], sb[1])};
           const v2f den = splat2(1.0f) + v2f{__builtin_amdgcn_exp2f(sp[0]), __builtin_amdgcn_exp2f(sp[1])};
           const v2f yv = v2f{__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
           acc2[jp][c] = ffma2(w2[jp], yv, acc2[jp][c]);
@@ -769,7 +769,11 @@ k_composite_bwd_pixel(CompParams p_arg, const CompParams *__restrict__ plist) {
 #else
 #define GSGEN_BWD_VEC_ATTR
 #endif
-template <int CB, int PPL, bool BATCH = false>
+// CHRED: the gradient vector is reduced channel by channel (wave_reduce_scatter2_rows on the 3 x CCP SH components as
+// soon as a channel's accumulators are complete, the 7 geometric components likewise, one quad_reduce_scatter4 at the
+// end) instead of as one 64-component vector after the third channel: the same number of exchanges, but the finished
+// channels no longer sit in 32 registers while the next one is computed.
+template <int CB, int PPL, bool BATCH = false, bool CHRED = false>
 __global__ void __launch_bounds__(256 / PPL) GSGEN_BWD_VEC_ATTR
 k_composite_bwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
   static_assert(PPL == 4 || PPL == 2, "pixel pairs: 2 or 4 pixels per lane");
@@ -781,7 +785,9 @@ k_composite_bwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
   constexpr int CCP = TR::CCP, NPAIR = TR::NPAIR, NSH = 3 * CCP;  // SH components incl. padding
   constexpr int P = (NSH + 7) <= 32 ? 32 : 64;                    // reduction width: SH | mean 2 | cov 4 | alpha 1
   static_assert(NSH % 2 == 0 && NSH + 7 <= P, "component layout");
-  __shared__ Stage<MODE, CB> S;
+  constexpr int KB = CHRED ? 32 : kBatch;  // CHRED: 10.6 KB of LDS per workgroup, 12+ workgroups per CU
+  __shared__ Stage<MODE, CB, KB> S;
+  __shared__ v2f go_s[CHRED ? 3 * NP * NT : 1];  // CHRED: grad_out of the lane's pixel pairs, [channel][pair][thread]
 
   const int nseg = p.nseg > 1 ? p.nseg : 1;
   const uint32_t tiles_grid = grid / (uint32_t)nseg;
@@ -801,7 +807,10 @@ k_composite_bwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
   const int gx = tx * kTile + lx;
   const float px = pixel_coord(p.topleft[0], gx, p.psx);
 
-  bool valid[PPL], alive[PPL];
+  // A pixel is "alive" while its transmittance has not dropped below the threshold: T only decreases, so the flag is
+  // T itself (pixels outside the image, or stopped before this segment, start at T = -1: never alive, and every
+  // product they enter is masked by the 0/1 contribution mask).
+  bool valid[PPL], alive0[PPL];
   int gy[PPL];
   v2f py2[NP];
 #pragma unroll
@@ -809,17 +818,17 @@ k_composite_bwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
     gy[j] = ty * kTile + ly0 + j * ROWS;
     valid[j] = (gx < p.W) && (gy[j] < p.H);
     py2[j >> 1][j & 1] = pixel_coord(p.topleft[1], gy[j], p.psy);
-    alive[j] = valid[j];
-    if (nseg > 1) alive[j] = alive[j] && (p.stop[(size_t)tile * 256 + (ly0 + j * ROWS) * 16 + lx] > e_lo);
+    alive0[j] = valid[j];
+    if (nseg > 1) alive0[j] = alive0[j] && (p.stop[(size_t)tile * 256 + (ly0 + j * ROWS) * 16 + lx] > e_lo);
   }
   if (nseg > 1) {  // every pixel of the tile stopped before this segment?
     bool any = false;
 #pragma unroll
-    for (int j = 0; j < PPL; ++j) any |= alive[j];
+    for (int j = 0; j < PPL; ++j) any |= alive0[j];
     if (__syncthreads_or((int)any) == 0) return;
   }
   if constexpr (CCP != TR::CC) {  // zero the pad lanes of the staged coefficients once
-    for (int e = t; e < kBatch * TR::NCOLP; e += NT) S.col[e] = 0.0f;
+    for (int e = t; e < KB * TR::NCOLP; e += NT) S.col[e] = 0.0f;
     __syncthreads();
   }
 
@@ -847,34 +856,44 @@ k_composite_bwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
   for (int j = 0; j < PPL; ++j) {
     const size_t pix = valid[j] ? ((size_t)gy[j] * p.W + gx) : 0;
     float4 ck = make_float4(1.0f, 0.0f, 0.0f, 0.0f);  // state in front of entry e_lo: T, prefix rgb
-    if (seg > 0 && alive[j]) ck = p.ckpt[((size_t)tile * nseg + seg) * 256 + (ly0 + j * ROWS) * 16 + lx];
+    if (seg > 0 && alive0[j]) ck = p.ckpt[((size_t)tile * nseg + seg) * 256 + (ly0 + j * ROWS) * 16 + lx];
     const float pre0[3] = {ck.y, ck.z, ck.w};
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       go2[j >> 1][c][j & 1] = valid[j] ? p.grad_out[3 * pix + c] : 0.0f;
       rem2[j >> 1][c][j & 1] = valid[j] ? p.final_img[3 * pix + c] - pre0[c] : 0.0f;
     }
-    Tr2[j >> 1][j & 1] = ck.x;
+    Tr2[j >> 1][j & 1] = (alive0[j] && !(ck.x < p.thresh)) ? ck.x : -1.0f;
   }
+  if constexpr (CHRED) {  // each thread reads back only what it wrote: no barrier
+#pragma unroll
+    for (int jp = 0; jp < NP; ++jp)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) go_s[(c * NP + jp) * NT + t] = go2[jp][c];
+  }
+  auto alive = [&](int j) { return !(Tr2[j >> 1][j & 1] < p.thresh); };
 
-  for (int base = e_lo; base < e_hi; base += kBatch) {
-    const int nb = min(kBatch, e_hi - base);
+  for (int base = e_lo; base < e_hi; base += KB) {
+    const int nb = min(KB, e_hi - base);
     if (base > e_lo) __syncthreads();
-    stage_batch<MODE, CB, NT, kBatch, true>(S, p, st + base, nb);
+    stage_batch<MODE, CB, NT, KB, true>(S, p, st + base, nb);
     __syncthreads();
 
     for (int g = 0; g < nb; ++g) {
       bool any_alive = false;
 #pragma unroll
-      for (int j = 0; j < PPL; ++j) any_alive |= alive[j];
+      for (int j = 0; j < PPL; ++j) any_alive |= alive(j);
       if (__ballot(any_alive) == 0ull) break;
 
       // the record as plain scalars (a struct handed around by reference makes the compiler build the packed
       // operands through scratch memory)
-      const float r_mx = S.mx[g], r_my = S.my[g], r_a = S.a[g], r_c0 = S.c0[g], r_c1 = S.c1[g], r_c2 = S.c2[g],
-                  r_c3 = S.c3[g], r_p0 = S.p0[g], r_p1 = S.p1[g];
+      // (CHRED: wave-uniform values moved to scalar registers -- nine vector registers less)
+      auto uni = [&](float v) { return CHRED ? wave_uniform(v) : v; };
+      const float r_mx = uni(S.mx[g]), r_my = uni(S.my[g]), r_a = uni(S.a[g]), r_c0 = uni(S.c0[g]), r_c1 = uni(S.c1[g]),
+                  r_c2 = uni(S.c2[g]), r_c3 = uni(S.c3[g]), r_p0 = uni(S.p0[g]), r_p1 = uni(S.p1[g]);
       const float x = px - r_mx;
-      v2f y2[NP], G2[NP], ag2[NP], conf2[NP];
+      // G2 / ag2: the Gaussian and a G, ZEROED where the pixel does not take part (skip threshold, or not alive)
+      v2f y2[NP], G2[NP], ag2[NP];
       bool any_con = false;
 #pragma unroll
       for (int jp = 0; jp < NP; ++jp) {
@@ -886,12 +905,14 @@ k_composite_bwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
         for (int e = 0; e < 2; ++e) {
           const int j = 2 * jp + e;
           // within rounding of the skip threshold: the reference's arithmetic decides (as gauss_eval)
-          if (alive[j] && fabsf(ag2[jp][e] - kMinAlpha) <= kMinAlpha * kGuardTol) {
+          const bool live = alive(j);
+          if (live && fabsf(ag2[jp][e] - kMinAlpha) <= kMinAlpha * kGuardTol) {
             G2[jp][e] = gauss_ref_f32(r_mx, r_my, r_c0, r_c1, r_c2, r_c3, px, py2[jp][e]);
             ag2[jp][e] = r_a * G2[jp][e];
           }
-          const bool con = alive[j] && !(ag2[jp][e] < kMinAlpha);
-          conf2[jp][e] = con ? 1.0f : 0.0f;
+          const bool con = live && !(ag2[jp][e] < kMinAlpha);
+          G2[jp][e] = con ? G2[jp][e] : 0.0f;
+          ag2[jp][e] = con ? ag2[jp][e] : 0.0f;
           pair_con |= con;
         }
         any_con |= pair_con;
@@ -899,14 +920,18 @@ k_composite_bwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
       if (__ballot(any_con) == 0ull) continue;  // nobody in the wave sees this Gaussian
 
       // reduction vector as (even, odd) pairs: SH components [0, NSH) | mean | cov | alpha | zeros
-      v2f gr2[P / 2];
+      constexpr int PCH = CCP <= 2 ? 2 : (CCP <= 4 ? 4 : (CCP <= 8 ? 8 : 16));  // CHRED: one channel's components
+      v2f gr2[CHRED ? 1 : P / 2];
+      float chsum[3] = {0.0f, 0.0f, 0.0f};
+      if constexpr (!CHRED) {
 #pragma unroll
-      for (int i = NSH / 2; i < P / 2; ++i) gr2[i] = v2f{0.0f, 0.0f};
+        for (int i = NSH / 2; i < P / 2; ++i) gr2[i] = v2f{0.0f, 0.0f};
+      }
       const float *cg = &S.col[g * TR::NCOLP];
       v2f w2[NP], inv1m2[NP], pAG2[NP];
 #pragma unroll
       for (int jp = 0; jp < NP; ++jp) {
-        w2[jp] = ((splat2(r_a) * Tr2[jp]) * G2[jp]) * conf2[jp];  // the forward's (a T) G, or 0
+        w2[jp] = (splat2(r_a) * Tr2[jp]) * G2[jp];  // the forward's (a T) G, or 0
         const v2f om = splat2(1.0f) - ag2[jp];
         inv1m2[jp] = v2f{__builtin_amdgcn_rcpf(om[0]), __builtin_amdgcn_rcpf(om[1])};
         pAG2[jp] = v2f{0.0f, 0.0f};
@@ -928,14 +953,17 @@ k_composite_bwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
             sa = fma2(q[k], Yp[2 * jp][k], sa);
             sb = fma2(q[k], Yp[2 * jp + 1][k], sb);
           }
-          const v2f sp = v2f{sa[0], sb[0]} + v2f{sa[1], sb[1]};
+          const v2f sp = v2f{add_scalar(sa[0], sa[1]), add_scalar(sb[0], sb[1])};
           const v2f den = splat2(1.0f) + v2f{__builtin_amdgcn_exp2f(sp[0]), __builtin_amdgcn_exp2f(sp[1])};
           const v2f yv = v2f{__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
           rem2[jp][c] = fma2(-w2[jp], yv, rem2[jp][c]);
           const v2f dy = fma2(-yv, yv, yv);  // y (1 - y)
-          const v2f gs = (w2[jp] * dy) * go2[jp][c];
+          v2f go;
+          if constexpr (CHRED) go = go_s[(c * NP + jp) * NT + t];
+          else go = go2[jp][c];
+          const v2f gs = (w2[jp] * dy) * go;
           const v2f sfx = rem2[jp][c] * inv1m2[jp];
-          pAG2[jp] = fma2(go2[jp][c], fma2(yv, Tr2[jp], -sfx), pAG2[jp]);
+          pAG2[jp] = fma2(go, fma2(yv, Tr2[jp], -sfx), pAG2[jp]);
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
             const v2f gse = splat2(gs[e]);
@@ -953,8 +981,15 @@ k_composite_bwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
         // registers; not kept)
         pair_colour(std::integral_constant<int, 0>{}, std::true_type{});
         if constexpr (NP > 1) pair_colour(std::integral_constant<int, NP - 1>{}, std::false_type{});
+        if constexpr (CHRED) {
+          v2f t[PCH / 2];
 #pragma unroll
-        for (int k = 0; k < NPAIR; ++k) gr2[c * NPAIR + k] = gq[k];
+          for (int k = 0; k < PCH / 2; ++k) t[k] = k < NPAIR ? gq[k < NPAIR ? k : 0] : v2f{0.0f, 0.0f};
+          chsum[c] = wave_reduce_scatter2_rows<PCH>(t);
+        } else {
+#pragma unroll
+          for (int k = 0; k < NPAIR; ++k) gr2[c * NPAIR + k] = gq[k];
+        }
       }
       // mean2d (2) | cov2d (4) | alpha (1): kernel_gaussian_2d_backward (kernels.h:394-418), packed over the pair
       // and summed over the lane's pairs; the two halves are added at the end
@@ -962,7 +997,7 @@ k_composite_bwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
       v2f gm0 = {0.f, 0.f}, gm1 = gm0, gc0 = gm0, gc1 = gm0, gc3 = gm0, gal = gm0;
 #pragma unroll
       for (int jp = 0; jp < NP; ++jp) {
-        const v2f pa = pAG2[jp] * conf2[jp];
+        const v2f pa = pAG2[jp];  // (its uses below are products with the masked G / a G)
         const v2f gg = pa * ag2[jp];
         const v2f vx = (splat2(x * r_c3) - y2[jp] * splat2(r_c2)) * splat2(inv_det);
         const v2f vy = (y2[jp] * splat2(r_c0) - splat2(x * r_c1)) * splat2(inv_det);
@@ -974,37 +1009,52 @@ k_composite_bwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
         gc1 = fma2(hvx, vy, gc1);
         gc3 = fma2(h * vy, vy, gc3);
         gal = fma2(pa, G2[jp], gal);
-        Tr2[jp] = Tr2[jp] * ffma2(-ag2[jp], conf2[jp], splat2(1.0f));  // T (1 - a G) if it contributed (explicit: as the forward)
-#pragma unroll
-        for (int e = 0; e < 2; ++e) alive[2 * jp + e] = alive[2 * jp + e] && !(Tr2[jp][e] < p.thresh);
+        Tr2[jp] = Tr2[jp] * ffma2(-ag2[jp], splat2(1.0f), splat2(1.0f));  // T (1 - a G) if it contributed (explicit: as the forward)
       }
-      {
-        const float m0 = gm0[0] + gm0[1], m1 = gm1[0] + gm1[1];
-        const float c0 = gc0[0] + gc0[1], c1 = gc1[0] + gc1[1], c3 = gc3[0] + gc3[1];
-        const float ga = gal[0] + gal[1];
+      const float m0 = gm0[0] + gm0[1], m1 = gm1[0] + gm1[1];
+      const float c0 = gc0[0] + gc0[1], c1 = gc1[0] + gc1[1], c3 = gc3[0] + gc3[1];
+      const float ga = gal[0] + gal[1];
+      if constexpr (CHRED) {
+        // grad_cov[1] and grad_cov[2] receive the same value (kernels.h:414-415)
+        v2f ex[4] = {v2f{m0, m1}, v2f{c0, c1}, v2f{c1, c3}, v2f{ga, 0.0f}};
+        const float exsum = wave_reduce_scatter2_rows<8>(ex);
+        const float tot = quad_reduce_scatter4(chsum[0], chsum[1], chsum[2], exsum);
+        const int m = lane & 3;  // the vector this lane ends up with: channel 0 / 1 / 2 / geometric
+        const size_t id = (size_t)S.id[g];
+        float *dst = nullptr;
+        if (m < 3) {
+          const int k = scatter_comp<PCH>(lane);
+          if (scatter_rows_owner<PCH>(lane) && k < TR::CC) dst = p.g_col + (size_t)TR::NCOL * id + m * TR::CC + k;
+        } else if (scatter_rows_owner<8>(lane)) {
+          const int e = scatter_comp<8>(lane);
+          if (e < 2) dst = p.g_mean + 2 * id + e;
+          else if (e < 6) dst = p.g_cov + 4 * id + (e - 2);
+          else if (e == 6) dst = p.g_alpha + id;
+        }
+        if (dst != nullptr) atomicAdd(dst, tot);
+      } else {
         gr2[NSH / 2 + 0] = v2f{m0, m1};
         gr2[NSH / 2 + 1] = v2f{c0, c1};
         gr2[NSH / 2 + 2] = v2f{c1, c3};  // grad_cov[1] and grad_cov[2] receive the same value (kernels.h:414-415)
         gr2[NSH / 2 + 3] = v2f{ga, 0.0f};
-      }
-
-      wave_reduce_scatter2<P>(gr2);
-      const int comp = scatter_comp<P>(lane);
-      if (scatter_owner<P>(lane) && comp < NSH + 7) {
-        const size_t id = (size_t)S.id[g];
-        float *dst = nullptr;
-        if (comp < NSH) {
-          const int c = comp / CCP, k = comp - c * CCP;
-          if (k < TR::CC) dst = p.g_col + (size_t)TR::NCOL * id + c * TR::CC + k;
-        } else if (comp < NSH + 2) dst = p.g_mean + 2 * id + (comp - NSH);
-        else if (comp < NSH + 6) dst = p.g_cov + 4 * id + (comp - NSH - 2);
-        else dst = p.g_alpha + id;
-        if (dst != nullptr) atomicAdd(dst, gr2[0][0]);
+        wave_reduce_scatter2<P>(gr2);
+        const int comp = scatter_comp<P>(lane);
+        if (scatter_owner<P>(lane) && comp < NSH + 7) {
+          const size_t id = (size_t)S.id[g];
+          float *dst = nullptr;
+          if (comp < NSH) {
+            const int c = comp / CCP, k = comp - c * CCP;
+            if (k < TR::CC) dst = p.g_col + (size_t)TR::NCOL * id + c * TR::CC + k;
+          } else if (comp < NSH + 2) dst = p.g_mean + 2 * id + (comp - NSH);
+          else if (comp < NSH + 6) dst = p.g_cov + 4 * id + (comp - NSH - 2);
+          else dst = p.g_alpha + id;
+          if (dst != nullptr) atomicAdd(dst, gr2[0][0]);
+        }
       }
     }
     bool any_alive = false;
 #pragma unroll
-    for (int j = 0; j < PPL; ++j) any_alive |= alive[j];
+    for (int j = 0; j < PPL; ++j) any_alive |= alive(j);
     if (__syncthreads_or((int)any_alive) == 0) break;
   }
 }
@@ -1401,6 +1451,7 @@ k_composite_bwd_sh_mfma(CompParams p_arg, const CompParams *__restrict__ plist) 
 struct Variants {
   int ppl_fwd, ppl_bwd, mfma, ppl_fwd_batch, ppl_bwd_batch, ppl_bwd_sh_batch, mfma_batch, batch_map;
   int sh_packed;  // GSGEN_BWD_SH_PACKED: 1 (default) = k_composite_bwd_sh_vec, 0 = k_composite_bwd_pixel<MODE_SH> (A/B)
+  int sh_chred;   // GSGEN_BWD_SH_CHRED: channel-wise gradient reduction in k_composite_bwd_sh_vec at 4 pixels per lane
 };
 static int env_mfma(const char *name) {
   const char *v = getenv(name);
@@ -1414,7 +1465,8 @@ static Variants &variants() {
                              env_ppl("GSGEN_PPL_BWD_BATCH", 2),  env_ppl("GSGEN_PPL_BWD_SH_BATCH", 4),
                              env_mfma("GSGEN_BWD_MFMA_BATCH"),
                              getenv("GSGEN_BATCH_MAP") ? atoi(getenv("GSGEN_BATCH_MAP")) : 2,
-                             getenv("GSGEN_BWD_SH_PACKED") ? (atoi(getenv("GSGEN_BWD_SH_PACKED")) != 0) : 1};
+                             getenv("GSGEN_BWD_SH_PACKED") ? (atoi(getenv("GSGEN_BWD_SH_PACKED")) != 0) : 1,
+                             getenv("GSGEN_BWD_SH_CHRED") ? (atoi(getenv("GSGEN_BWD_SH_CHRED")) != 0) : 1};
   return v;
 }
 
@@ -1456,6 +1508,7 @@ static int launch_bwd(const CompParams &p_, hipStream_t s) {
   if constexpr (MODE == MODE_SH) {
     if (variants().sh_packed && ppl != 1) {  // default SH backward: packed per-pixel arithmetic
       if (ppl == 2) hipLaunchKernelGGL((k_composite_bwd_sh_vec<CB, 2>), dim3(ng), dim3(128), 0, s, p, (const CompParams *)nullptr);
+      else if (variants().sh_chred) hipLaunchKernelGGL((k_composite_bwd_sh_vec<CB, 4, false, true>), dim3(ng), dim3(64), 0, s, p, (const CompParams *)nullptr);
       else hipLaunchKernelGGL((k_composite_bwd_sh_vec<CB, 4>), dim3(ng), dim3(64), 0, s, p, (const CompParams *)nullptr);
       return (int)hipGetLastError();
     }
@@ -1530,6 +1583,7 @@ static void launch_bwd_sh_batch_c(const CompParams &p0, const CompParams *plist,
   const int ppl = variants().ppl_bwd_sh_batch;
   if (variants().sh_packed && ppl != 1) {
     if (ppl == 2) hipLaunchKernelGGL((k_composite_bwd_sh_vec<CB, 2, true>), g, dim3(128), 0, s, p0, plist);
+    else if (variants().sh_chred) hipLaunchKernelGGL((k_composite_bwd_sh_vec<CB, 4, true, true>), g, dim3(64), 0, s, p0, plist);
     else hipLaunchKernelGGL((k_composite_bwd_sh_vec<CB, 4, true>), g, dim3(64), 0, s, p0, plist);
     return;
   }
@@ -1612,7 +1666,7 @@ extern "C" {
 
 /* Debugging hook (tools/stress, A/B measurements inside one process): overrides one entry of the variant table that
  * the environment initialised.  Not thread-safe against concurrent launches.  name: "ppl_fwd", "ppl_bwd", "mfma",
- * "ppl_fwd_batch", "ppl_bwd_batch", "ppl_bwd_sh_batch", "mfma_batch", "batch_map", "sh_packed". */
+ * "ppl_fwd_batch", "ppl_bwd_batch", "ppl_bwd_sh_batch", "mfma_batch", "batch_map", "sh_packed", "sh_chred". */
 int gsgen_debug_set_variant(const char *name, int value) {
   if (!name) return GSGEN_EINVAL;
   Variants &v = variants();
@@ -1629,6 +1683,7 @@ int gsgen_debug_set_variant(const char *name, int value) {
   else if (n == "mfma_batch") { slot = &v.mfma_batch; ok = ppl_ok || value == 0; }
   else if (n == "batch_map") { slot = &v.batch_map; ok = value >= 0 && value <= 2; }
   else if (n == "sh_packed") { slot = &v.sh_packed; ok = value == 0 || value == 1; }
+  else if (n == "sh_chred") { slot = &v.sh_chred; ok = value == 0 || value == 1; }
   if (!slot || !ok) return GSGEN_EINVAL;
   *slot = value;
   return 0;
@@ -1645,8 +1700,9 @@ int gsgen_kernel_variant(const char *stage, uint32_t C, uint32_t n_segments, cha
   int n = 0;
   auto sh_bwd = [&](int mfma, int ppl, const char *b) {
     if (mfma) return snprintf(buf, sizeof buf, "k_composite_bwd_sh_mfma<C=%u,PPL=%d%s>%s", C, mfma, b, n_segments > 1 ? " segmented" : "");
-    return snprintf(buf, sizeof buf, "%s<%sC=%u,PPL=%d%s>%s", (v.sh_packed && ppl != 1) ? "k_composite_bwd_sh_vec" : "k_composite_bwd_pixel",
-                    (v.sh_packed && ppl != 1) ? "" : "SH,", C, ppl, b, n_segments > 1 ? " segmented" : "");
+    return snprintf(buf, sizeof buf, "%s<%sC=%u,PPL=%d%s%s>%s", (v.sh_packed && ppl != 1) ? "k_composite_bwd_sh_vec" : "k_composite_bwd_pixel",
+                    (v.sh_packed && ppl != 1) ? "" : "SH,", C, ppl, b, (v.sh_packed && ppl == 4 && v.sh_chred) ? ",CHRED" : "",
+                    n_segments > 1 ? " segmented" : "");
   };
   auto sh_fwd = [&](int ppl, const char *b) {
     if (v.sh_packed && ppl != 1) return snprintf(buf, sizeof buf, "k_composite_fwd_sh_vec<C=%u,PPL=%d%s>", C, ppl, b);

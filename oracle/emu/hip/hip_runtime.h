@@ -106,6 +106,7 @@ inline int emu_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mas
 }
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) emu_update_dpp((old), (src), (ctrl), (rm), (bm), (bc))
 
+#define __builtin_amdgcn_mov_dpp(src, ctrl, rm, bm, bc) emu_update_dpp((src), (src), (ctrl), (rm), (bm), (bc))
 #define __builtin_amdgcn_readfirstlane(v) (v)
 #define __builtin_amdgcn_sched_barrier(m) ((void)0)
 #define __builtin_amdgcn_readlane(v, l) simt::shfl_idx((int)(v), (l))

@@ -103,9 +103,12 @@ def test_gs_mirror_has_the_23_reference_names():
 
 
 def test_import_gs_through_the_path_shim():
-    """`import _gs` with shim/ on PYTHONPATH yields gsgen_amd._gs itself (option 1b)"""
-    code = ("import _gs, gsgen_amd._gs as m, sys; assert _gs is m, (_gs, m); "
-            "assert callable(_gs.tile_based_vol_rendering_start_end_with_T); print('ok', len([n for n in dir(_gs) if not n.startswith('_')]))")
+    """`import _gs` with shim/ on PYTHONPATH yields what gsgen_amd.install_as_gs() registers: the compiled module
+    gsgen_amd/ext/_gs.*.so when it has been built, else the ctypes mirror gsgen_amd._gs (option 1)"""
+    code = ("import _gs, gsgen_amd, gsgen_amd._gs as m, sys; c = gsgen_amd.compiled_gs(); "
+            "assert (_gs.__file__ == c.__file__) if c is not None else (_gs is m), (_gs, c, m); assert sys.modules['_gs'] is _gs; "
+            "assert callable(_gs.tile_based_vol_rendering_start_end_with_T); "
+            "print('ok', 'compiled' if c is not None else 'mirror')")
     env = dict(os.environ)
     env["PYTHONPATH"] = os.path.join(ROOT, "shim") + os.pathsep + env.get("PYTHONPATH", "")
     r = subprocess.run([sys.executable, "-c", code], cwd="/", env=env, capture_output=True, text=True)
@@ -848,7 +851,11 @@ def test_no_kernel_spills_and_hot_kernels_keep_their_occupancy(tmp_path):
     # default SH backward (k_composite_bwd_sh_vec: vector ALUs, packed per-pixel arithmetic, one wavefront per tile,
     # 4 pixels per lane): 2 wavefronts per SIMD; both the per-camera and the batched-cameras instantiation.  Two
     # wavefronts per tile: 3 per SIMD.  The unpacked A/B kernel (GSGEN_BWD_SH_PACKED=0) keeps its budgets too.
-    for bwd in find(2, "k_composite_bwd_sh_vecILi4ELi4E"):
+    # CHRED (default since round 2, session r2n): channel-wise reduction, grad_out in LDS, record in scalar registers:
+    # THREE wavefronts per SIMD (<= 168 registers) and at least 12 workgroups per CU by LDS
+    for bwd in find(2, "k_composite_bwd_sh_vecILi4ELi4ELb", "ELb1EE"):
+        assert bwd["vgpr_count"] <= 168 and 12 * bwd["group_segment_fixed_size"] <= 160 * 1024, bwd
+    for bwd in find(2, "k_composite_bwd_sh_vecILi4ELi4ELb", "ELb0EE"):  # the 64-component reduction, A/B only
         assert bwd["vgpr_count"] <= 256 and 8 * bwd["group_segment_fixed_size"] <= 160 * 1024
     for bwd in find(2, "k_composite_bwd_sh_vecILi4ELi2E"):
         assert bwd["vgpr_count"] <= 168

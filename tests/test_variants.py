@@ -14,6 +14,7 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 VARIANTS = [
     {"GSGEN_PPL_FWD": "4", "GSGEN_PPL_BWD": "2"},
     {"GSGEN_PPL_FWD": "2", "GSGEN_PPL_BWD": "1"},
+    {"GSGEN_BWD_SH_CHRED": "0"},  # packed SH backward with ONE 64-component gradient reduction (2 wavefronts per SIMD)
 ]
 # The matrix-core SH backward is OPT-IN (GSGEN_BWD_MFMA = 4 | 2 | 1 pixels per lane; default 0 = vector ALUs): its
 # MFMA chain has shown box- and timing-dependent corruption on hardware that is not root-caused.
@@ -52,6 +53,7 @@ BATCH_VARIANTS = [
     {"GSGEN_BATCH_MAP": "1", "GSGEN_PPL_FWD_BATCH": "2", "GSGEN_PPL_FWD": "2"},
     {"GSGEN_PPL_BWD_SH_BATCH": "2", "GSGEN_PPL_BWD_BATCH": "4"},  # SH backward 2 wavefronts per tile, heads 1
     {"GSGEN_PPL_BWD_SH_BATCH": "1", "GSGEN_PPL_BWD_BATCH": "1", "GSGEN_PPL_FWD_BATCH": "4", "GSGEN_PPL_FWD": "4"},
+    {"GSGEN_BWD_SH_CHRED": "0"},
 ]
 MFMA_BATCH_VARIANTS = [
     {"GSGEN_BWD_MFMA_BATCH": "2"},
