@@ -361,13 +361,12 @@ k_composite_fwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
   const int lx = t & 15, ly0 = t >> 4;
   const int gx = tx * kTile + lx;
 
-  bool valid[PPL], alive[PPL];
+  bool valid[PPL];
   int gy[PPL], stop[PPL];
 #pragma unroll
   for (int j = 0; j < PPL; ++j) {
     gy[j] = ty * kTile + ly0 + j * ROWS;
     valid[j] = (gx < p.W) && (gy[j] < p.H);
-    alive[j] = valid[j];
     stop[j] = valid[j] ? n : 0;
   }
   if (n == 0) {  // uniform over the workgroup
@@ -411,8 +410,11 @@ k_composite_fwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
   for (int jp = 0; jp < NP; ++jp) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) acc2[jp][c] = v2f{0.0f, 0.0f};
-    Tr2[jp] = v2f{1.0f, 1.0f};
+    // a pixel is alive while T >= thresh (T only decreases); pixels outside the image start at -1: never alive,
+    // never written
+    Tr2[jp] = v2f{valid[2 * jp] ? 1.0f : -1.0f, valid[2 * jp + 1] ? 1.0f : -1.0f};
   }
+  auto alive = [&](int j) { return !(Tr2[j >> 1][j & 1] < p.thresh); };
   const bool seg_out = p.nseg > 1 && p.ckpt != nullptr;
 
   for (int base = 0; base < n; base += kBatch) {
@@ -424,7 +426,7 @@ k_composite_fwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
     for (int g = 0; g < nb; ++g) {
       bool any_alive = false;
 #pragma unroll
-      for (int j = 0; j < PPL; ++j) any_alive |= alive[j];
+      for (int j = 0; j < PPL; ++j) any_alive |= alive(j);
       if (__ballot(any_alive) == 0ull) break;  // this wave's 64*PPL pixels are saturated
       const int e_idx = base + g;
       if (seg_out && (e_idx % kSegLen) == 0 && e_idx > 0 && e_idx / kSegLen < p.nseg) {  // wave-uniform
@@ -437,30 +439,43 @@ k_composite_fwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
       const float r_mx = S.mx[g], r_my = S.my[g], r_a = S.a[g], r_c0 = S.c0[g], r_c1 = S.c1[g], r_c2 = S.c2[g],
                   r_c3 = S.c3[g], r_p0 = S.p0[g];
       const float x = px - r_mx;
-      v2f G2[NP], ag2[NP], conf2[NP];
-      bool any_con = false;
+      // G2 / ag2: the Gaussian and a G, ZEROED where the pixel does not take part (skip threshold, or not alive)
+      v2f G2[NP], ag2[NP];
+      bool any_con = false, any_guard = false;
 #pragma unroll
       for (int jp = 0; jp < NP; ++jp) {
         G2[jp] = gauss_sh_pair(r_c0, r_c1, r_c2, r_c3, r_p0, x, py2[jp] - splat2(r_my));
         ag2[jp] = splat2(r_a) * G2[jp];
 #pragma unroll
+        for (int e = 0; e < 2; ++e) any_guard |= alive(2 * jp + e) && fabsf(ag2[jp][e] - kMinAlpha) <= kMinAlpha * kGuardTol;
+      }
+      // within rounding of the skip threshold the reference's arithmetic decides (as gauss_eval); one wave-uniform
+      // test for all the lane's pixels, almost never taken
+      if (__ballot(any_guard) != 0ull) {
+#pragma unroll
+        for (int jp = 0; jp < NP; ++jp)
+#pragma unroll
+          for (int e = 0; e < 2; ++e)
+            if (alive(2 * jp + e) && fabsf(ag2[jp][e] - kMinAlpha) <= kMinAlpha * kGuardTol) {
+              G2[jp][e] = gauss_ref_f32(r_mx, r_my, r_c0, r_c1, r_c2, r_c3, px, py2[jp][e]);
+              ag2[jp][e] = r_a * G2[jp][e];
+            }
+      }
+#pragma unroll
+      for (int jp = 0; jp < NP; ++jp)
+#pragma unroll
         for (int e = 0; e < 2; ++e) {
-          const int j = 2 * jp + e;
-          if (alive[j] && fabsf(ag2[jp][e] - kMinAlpha) <= kMinAlpha * kGuardTol) {  // as gauss_eval
-            G2[jp][e] = gauss_ref_f32(r_mx, r_my, r_c0, r_c1, r_c2, r_c3, px, py2[jp][e]);
-            ag2[jp][e] = r_a * G2[jp][e];
-          }
-          const bool con = alive[j] && !(ag2[jp][e] < kMinAlpha);
-          conf2[jp][e] = con ? 1.0f : 0.0f;
+          const bool con = alive(2 * jp + e) && !(ag2[jp][e] < kMinAlpha);
+          G2[jp][e] = con ? G2[jp][e] : 0.0f;
+          ag2[jp][e] = con ? ag2[jp][e] : 0.0f;
           any_con |= con;
         }
-      }
       if (__ballot(any_con) == 0ull) continue;  // nobody in the wave sees this Gaussian
 
       const float *cg = &S.col[g * TR::NCOLP];
       v2f w2[NP];
 #pragma unroll
-      for (int jp = 0; jp < NP; ++jp) w2[jp] = ((splat2(r_a) * Tr2[jp]) * G2[jp]) * conf2[jp];  // (a T) G, or 0
+      for (int jp = 0; jp < NP; ++jp) w2[jp] = (splat2(r_a) * Tr2[jp]) * G2[jp];  // (a T) G, or 0
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         v2f q[NPAIR];
@@ -482,19 +497,16 @@ k_composite_fwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
       }
 #pragma unroll
       for (int jp = 0; jp < NP; ++jp) {
-        Tr2[jp] = Tr2[jp] * ffma2(-ag2[jp], conf2[jp], splat2(1.0f));  // T (1 - a G) if it contributed (explicit)
+        const bool was[2] = {alive(2 * jp), alive(2 * jp + 1)};
+        Tr2[jp] = Tr2[jp] * ffma2(-ag2[jp], splat2(1.0f), splat2(1.0f));  // T (1 - a G) if it contributed (explicit)
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const int j = 2 * jp + e;
-          const bool still = alive[j] && !(Tr2[jp][e] < p.thresh);
-          if (alive[j] && !still) stop[j] = base + g + 1;
-          alive[j] = still;
-        }
+        for (int e = 0; e < 2; ++e)
+          if (was[e] && !alive(2 * jp + e)) stop[2 * jp + e] = base + g + 1;
       }
     }
     bool any_alive = false;
 #pragma unroll
-    for (int j = 0; j < PPL; ++j) any_alive |= alive[j];
+    for (int j = 0; j < PPL; ++j) any_alive |= alive(j);
     if (__syncthreads_or((int)any_alive) == 0) break;  // whole tile saturated: stop staging
   }
 
@@ -894,29 +906,36 @@ k_composite_bwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
       const float x = px - r_mx;
       // G2 / ag2: the Gaussian and a G, ZEROED where the pixel does not take part (skip threshold, or not alive)
       v2f y2[NP], G2[NP], ag2[NP];
-      bool any_con = false;
+      bool any_con = false, any_guard = false;
 #pragma unroll
       for (int jp = 0; jp < NP; ++jp) {
         y2[jp] = py2[jp] - splat2(r_my);
         G2[jp] = gauss_sh_pair(r_c0, r_c1, r_c2, r_c3, r_p0, x, y2[jp]);
         ag2[jp] = splat2(r_a) * G2[jp];
-        bool pair_con = false;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) any_guard |= alive(2 * jp + e) && fabsf(ag2[jp][e] - kMinAlpha) <= kMinAlpha * kGuardTol;
+      }
+      // within rounding of the skip threshold: the reference's arithmetic decides (as gauss_eval).  One wave-uniform
+      // test for all the lane's pixels: the branch is almost never taken (a handful of pixels per frame)
+      if (__ballot(any_guard) != 0ull) {
+#pragma unroll
+        for (int jp = 0; jp < NP; ++jp)
+#pragma unroll
+          for (int e = 0; e < 2; ++e)
+            if (alive(2 * jp + e) && fabsf(ag2[jp][e] - kMinAlpha) <= kMinAlpha * kGuardTol) {
+              G2[jp][e] = gauss_ref_f32(r_mx, r_my, r_c0, r_c1, r_c2, r_c3, px, py2[jp][e]);
+              ag2[jp][e] = r_a * G2[jp][e];
+            }
+      }
+#pragma unroll
+      for (int jp = 0; jp < NP; ++jp)
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-          const int j = 2 * jp + e;
-          // within rounding of the skip threshold: the reference's arithmetic decides (as gauss_eval)
-          const bool live = alive(j);
-          if (live && fabsf(ag2[jp][e] - kMinAlpha) <= kMinAlpha * kGuardTol) {
-            G2[jp][e] = gauss_ref_f32(r_mx, r_my, r_c0, r_c1, r_c2, r_c3, px, py2[jp][e]);
-            ag2[jp][e] = r_a * G2[jp][e];
-          }
-          const bool con = live && !(ag2[jp][e] < kMinAlpha);
+          const bool con = alive(2 * jp + e) && !(ag2[jp][e] < kMinAlpha);
           G2[jp][e] = con ? G2[jp][e] : 0.0f;
           ag2[jp][e] = con ? ag2[jp][e] : 0.0f;
-          pair_con |= con;
+          any_con |= con;
         }
-        any_con |= pair_con;
-      }
       if (__ballot(any_con) == 0ull) continue;  // nobody in the wave sees this Gaussian
 
       // reduction vector as (even, odd) pairs: SH components [0, NSH) | mean | cov | alpha | zeros
