@@ -350,7 +350,8 @@ def test_long_tile_list_and_ties():
     assert np.array_equal(ids.cpu().numpy(), oi)
 
 
-@pytest.mark.parametrize("sizes", [(1, 40, 64, 65, 100, 128, 129, 200, 256, 300, 511, 513, 700, 1024, 1500, 2047, 2049, 3000)])
+@pytest.mark.parametrize("sizes", [(1, 40, 64, 65, 100, 128, 129, 200, 256, 300, 511, 512, 513, 700, 1024, 1025, 1500, 2039, 2040,
+                                    2047, 2048, 2049, 3000, 4096, 4100)])
 def test_sort_every_register_width(sizes):
     """Per-tile segments of every size class of the register sort (K = 1..32 keys per lane),
     the LDS path and their boundaries, with duplicate depths."""
