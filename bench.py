@@ -177,6 +177,10 @@ def main():
     import torch
     from gsgen_amd import _capi, renderer as R
 
+    # stdout carries the ONE JSON line and nothing else: whatever libraries print there (RCCL's version banner at
+    # process-group start-up, flushed at exit) is sent to stderr
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -186,9 +190,14 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # GSGEN_BENCH_FORCE_DIST=1: run the multi-rank code path (process group, broadcasts, the per-step all_gather on the
+    # communication stream) with ONE rank -- the only way to exercise it on a single-GPU box
+    if world > 1 or os.environ.get("GSGEN_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         dist.init_process_group("nccl", device_id=dev)
 
     lib = _capi.load()
@@ -243,7 +252,10 @@ def main():
                                for _ in range(B)]
                 self.bws = torch.empty(lib.sh_batch_workspace_bytes(B), device=dev, dtype=torch.uint8)
                 self.gws = torch.empty(lib.frame_batch_workspace_bytes(B), device=dev, dtype=torch.uint8)
-                self.gathered = torch.empty(world, B, H, W, 3, device=dev) if world > 1 else None
+                self.gathered = torch.empty(world, B, H, W, 3, device=dev) if dist is not None else None
+            # the images of a step are complete after its forward: they are gathered on the communication stream while
+            # the step's backward runs; the slot's next forward waits for that gather before it overwrites `out`
+            self.e_fwd, self.e_gathered, self.gather_pending = torch.cuda.Event(), torch.cuda.Event(), False
             o = B * 6 * N
             self.g_alpha, self.g_sh = self.gflat[o:o + N], self.gflat[o + N:o + N * (1 + CC3)]
             self.g_mean, self.g_qvec, self.g_svec = self.g3d[:3 * N], self.g3d[3 * N:7 * N], self.g3d[7 * N:]
@@ -275,6 +287,7 @@ def main():
             return self.tables[key]
 
     slots = [Slot(torch.cuda.Stream(dev)) for _ in range(max(1, auto_slots))]
+    comm_stream = torch.cuda.Stream(dev)
     seg_arg = nseg if nseg > 1 else 0
 
     def run_step(j, ev=None, gather=True):
@@ -282,6 +295,9 @@ def main():
         sl = slots[j % len(slots)]
         s, stream = sl.s, sl.stream
         geo, views, proj = sl.prepared((j * B) % ncam)
+        if sl.gather_pending:
+            stream.wait_event(sl.e_gathered)
+            sl.gather_pending = False
         clock.call("geometry", lib.frame_geometry_batch, B, geo, N, p(t["mean"]), p(t["qvec"]), p(t["svec"]), W, H, p(sl.gws), s)
         if ev is not None:
             clock.call("events", ev[0].record, stream)
@@ -289,6 +305,15 @@ def main():
                    1e-4, seg_arg, p(sl.bws), s)
         if ev is not None:
             clock.call("events", ev[1].record, stream)
+        if sl.gathered is not None and gather:
+            t0 = time.perf_counter()
+            sl.e_fwd.record(stream)
+            comm_stream.wait_event(sl.e_fwd)
+            with torch.cuda.stream(comm_stream):
+                dist.all_gather_into_tensor(sl.gathered, sl.out)
+                sl.e_gathered.record(comm_stream)
+            sl.gather_pending = True
+            clock.acc["gather"] = clock.acc.get("gather", 0.0) + time.perf_counter() - t0
         t0 = time.perf_counter()
         with torch.cuda.stream(stream):
             sl.gflat.zero_()
@@ -301,11 +326,6 @@ def main():
             clock.call("events", ev[3].record, stream)
         clock.call("project_bwd", lib.project_gaussians_backward_batch, B, N, p(t["mean"]), p(t["qvec"]), p(t["svec"]), *proj,
                    p(sl.g_mean), p(sl.g_qvec), p(sl.g_svec), s)
-        if sl.gathered is not None and gather:
-            t0 = time.perf_counter()
-            with torch.cuda.stream(stream):
-                dist.all_gather_into_tensor(sl.gathered, sl.out)
-            clock.acc["gather"] = clock.acc.get("gather", 0.0) + time.perf_counter() - t0
 
     def barrier():
         if dist is not None:
@@ -486,7 +506,8 @@ def main():
         "config": {"workload": WORKLOADS[args.config], "gaussians": N, "visible_after_cull": n_vis, "image": [H, W],
                    "sh_degree": C - 1, "tile_pairs_D": D, "cameras_per_step": B, "steps_in_flight": len(slots),
                    "backward_segments_per_tile": nseg, "parallelism": f"camera-sharded x{world}",
-                   "gather": "one rccl all_gather of the step's rendered images" if world > 1 else "none"},
+                   "gather": ("one rccl all_gather of the step's rendered images, on its own stream behind the step's forward"
+                              if dist is not None else "none")},
         "timing": {"repeats": len(regions), "reported": "median repeat", "renders_per_s_min": world * B * K / max(els),
                    "renders_per_s_max": world * B * K / min(els), "timed_region_s": el,
                    "host_enqueue_ms_per_step": med["host"] / K * 1e3,
@@ -513,7 +534,7 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(sc, cams, C)
-        print(json.dumps(res), flush=True)
+        print(json.dumps(res), file=json_out, flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
