@@ -819,3 +819,39 @@ def test_upload_small_does_not_wait_for_the_stream_and_is_capturable():
     g.replay()
     torch.cuda.synchronize()
     assert np.array_equal(dst2.cpu().numpy(), np.arange(68, dtype=np.float32))
+
+
+def test_rccl_process_group_of_one_runs_the_gather_and_its_backward():
+    """The multi-GPU code path cannot meet a second GPU here; what CAN be checked on one is that RCCL initialises under
+    this environment (HSA_ENABLE_IPC_MODE_LEGACY=0), that the differentiable image all_gather of gsgen_amd.dist runs on
+    the device through it and that its backward hands the rank its own slice.  In a subprocess: a process group is
+    process-wide state."""
+    import subprocess, sys, os, socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    code = f"""
+import os, torch, torch.distributed as dist
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="{port}")
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+from gsgen_amd import dist as D
+x = torch.randn(3, 16, 24, 3, device=dev, requires_grad=True)
+y = D._AllGatherImages.apply(x, None)
+assert y.shape == x.shape and torch.equal(y.detach(), x.detach())
+w = torch.randn_like(y)
+(y * w).sum().backward()
+assert torch.equal(x.grad, w)
+t = torch.ones(5, device=dev)
+dist.all_reduce(t)
+assert torch.equal(t, torch.ones(5, device=dev))
+dist.barrier()
+dist.destroy_process_group()
+print("ok")
+"""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
