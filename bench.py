@@ -208,7 +208,7 @@ def main():
     # batch size and launches in flight from the workload (one untimed probe render): a launch should carry enough tiles
     # to fill the chip and hide its tail, but the cameras of a launch share the gradient accumulators -- with 500 k
     # Gaussians and 2.5 M pairs per view (cfg3) two cameras per launch beat eight (profiles/r02_notes.md); light launches
-    # (< 4.5 M pairs: the 512^2 views of cfg4, cfg3's pairs of cameras) overlap better three deep than two
+    # (< 5.2 M pairs: the 512^2 views of cfg4, cfg3's pairs of cameras) overlap better three deep than two
     # (cfg4: 6 988 vs 6 661 renders/s; cfg2, 5.7 M pairs per launch: 3 372 vs 3 368)
     probe_cam = (random_pose_cameras(64, rank, world, W, H) if args.config == "cfg4" else camera_poses(1, rank, W, H))[0]
     pb = R.FrameBuffers(N, W, H, dev)
@@ -217,7 +217,7 @@ def main():
     d_probe = max(1, int(pb.total.item()))
     del pb, tp
     B = args.batch if args.batch > 0 else int(min(8, max(2, round(6.0e6 / d_probe))))
-    auto_slots = args.slots if args.slots > 0 else (3 if B * d_probe < 4.5e6 else 2)
+    auto_slots = args.slots if args.slots > 0 else (3 if B * d_probe < 5.2e6 else 2)
     if dist is not None:  # one shape for the job (the gathered tensor is [world, B, H, W, 3])
         bt = torch.tensor([B, auto_slots], device=dev)
         dist.broadcast(bt, 0)
