@@ -135,15 +135,21 @@ __device__ __forceinline__ uint32_t batch_view(const CompParams &p_arg, uint32_t
   return view;
 }
 
-template <int MODE, int CB, int PPL, bool BATCH = false>
-__global__ void __launch_bounds__(256 / PPL) k_composite_fwd(CompParams p_arg, const CompParams *__restrict__ plist) {
+// TS: tile side.  16 everywhere in this library's own pipeline; 8 and 32 exist for callers of the `_gs` entry points
+// that configure another `tile_size` (the reference takes it as a parameter, conf/base.yaml:132; its launch is
+// tile_size x tile_size threads, vol_render.h:1001-1004): TS = 8 runs one wavefront per tile (PPL = 1), TS = 32 four
+// wavefronts at 4 pixels per lane.  Per-pixel results do not depend on the tile size.
+template <int MODE, int CB, int PPL, bool BATCH = false, int TS = 16>
+__global__ void __launch_bounds__(TS * TS / PPL) k_composite_fwd(CompParams p_arg, const CompParams *__restrict__ plist) {
   // by value: read once with scalar loads; through a reference every use in the entry loop would be
   // re-read from memory (the kernel's own stores may alias it as far as the compiler knows)
   uint32_t bid = blockIdx.x;
   const CompParams p = BATCH ? plist[batch_view(p_arg, bid)] : p_arg;
   using TR = Traits<MODE, CB>;
-  constexpr int NT = 256 / PPL;
-  constexpr int ROWS = NT / 16;
+  constexpr int NT = TS * TS / PPL;
+  constexpr int ROWS = NT / TS;
+  static_assert(TS == 8 || TS == 16 || TS == 32, "tile side");
+  static_assert(NT >= kBatch && NT % 64 == 0, "a staging round needs one thread per record");
   constexpr int NCH = TR::NCH;
   __shared__ Stage<MODE, CB> S;
 
@@ -153,14 +159,14 @@ __global__ void __launch_bounds__(256 / PPL) k_composite_fwd(CompParams p_arg, c
   const int st = p.start[tile];
   const int n = (st < 0) ? 0 : (p.end[tile] - st);
   const int t = (int)threadIdx.x;
-  const int lx = t & 15, ly0 = t >> 4;
-  const int gx = tx * kTile + lx;
+  const int lx = t % TS, ly0 = t / TS;
+  const int gx = tx * TS + lx;
 
   bool valid[PPL];
   int gy[PPL];
 #pragma unroll
   for (int j = 0; j < PPL; ++j) {
-    gy[j] = ty * kTile + ly0 + j * ROWS;
+    gy[j] = ty * TS + ly0 + j * ROWS;
     valid[j] = (gx < p.W) && (gy[j] < p.H);
   }
 
@@ -231,7 +237,7 @@ __global__ void __launch_bounds__(256 / PPL) k_composite_fwd(CompParams p_arg, c
         if (seg_out && (e % kSegLen) == 0 && e > 0 && e / kSegLen < p.nseg) {  // wave-uniform
 #pragma unroll
           for (int j = 0; j < PPL; ++j)
-            p.ckpt[((size_t)tile * p.nseg + e / kSegLen) * 256 + (ly0 + j * ROWS) * 16 + lx] =
+            p.ckpt[((size_t)tile * p.nseg + e / kSegLen) * (TS * TS) + (ly0 + j * ROWS) * TS + lx] =
                 make_float4(Tr[j], acc[j][0], acc[j][1], acc[j][2]);
         }
       }
@@ -327,7 +333,7 @@ __global__ void __launch_bounds__(256 / PPL) k_composite_fwd(CompParams p_arg, c
   if constexpr (MODE == MODE_SH) {
     if (p.stop != nullptr) {
 #pragma unroll
-      for (int j = 0; j < PPL; ++j) p.stop[(size_t)tile * 256 + (ly0 + j * ROWS) * 16 + lx] = stop[j];
+      for (int j = 0; j < PPL; ++j) p.stop[(size_t)tile * (TS * TS) + (ly0 + j * ROWS) * TS + lx] = stop[j];
     }
   }
 }
@@ -532,14 +538,15 @@ k_composite_fwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
 // ============================================================================================
 // backward
 // ============================================================================================
-template <int MODE, int CB, int PPL, bool BATCH = false>
-__global__ void __launch_bounds__(256 / PPL)
+template <int MODE, int CB, int PPL, bool BATCH = false, int TS = 16>  // TS: tile side, see k_composite_fwd
+__global__ void __launch_bounds__(TS * TS / PPL)
 k_composite_bwd_pixel(CompParams p_arg, const CompParams *__restrict__ plist) {
   uint32_t bid = blockIdx.x, grid = gridDim.x;
   const CompParams p = BATCH ? plist[batch_view(p_arg, bid, &grid)] : p_arg;  // see k_composite_fwd
   using TR = Traits<MODE, CB>;
-  constexpr int NT = 256 / PPL;
-  constexpr int ROWS = NT / 16;
+  constexpr int NT = TS * TS / PPL;
+  static_assert(NT >= kBatch && NT % 64 == 0, "a staging round needs one thread per record");
+  constexpr int ROWS = NT / TS;
   constexpr int NCH = TR::NCH;
   constexpr int P = TR::P;
   __shared__ Stage<MODE, CB> S;
@@ -561,8 +568,8 @@ k_composite_bwd_pixel(CompParams p_arg, const CompParams *__restrict__ plist) {
   if (e_lo >= n) return;
   const int t = (int)threadIdx.x;
   const int lane = t & 63;
-  const int lx = t & 15, ly0 = t >> 4;
-  const int gx = tx * kTile + lx;
+  const int lx = t % TS, ly0 = t / TS;
+  const int gx = tx * TS + lx;
 
   bool valid[PPL];
   int gy[PPL];
@@ -570,7 +577,7 @@ k_composite_bwd_pixel(CompParams p_arg, const CompParams *__restrict__ plist) {
   const float px = pixel_coord(p.topleft[0], gx, p.psx);
 #pragma unroll
   for (int j = 0; j < PPL; ++j) {
-    gy[j] = ty * kTile + ly0 + j * ROWS;
+    gy[j] = ty * TS + ly0 + j * ROWS;
     valid[j] = (gx < p.W) && (gy[j] < p.H);
     py[j] = pixel_coord(p.topleft[1], gy[j], p.psy);
   }
@@ -599,7 +606,7 @@ k_composite_bwd_pixel(CompParams p_arg, const CompParams *__restrict__ plist) {
   for (int j = 0; j < PPL; ++j) {
     alive[j] = valid[j];
     if constexpr (MODE == MODE_SH) {
-      if (nseg > 1) alive[j] = alive[j] && (p.stop[(size_t)tile * 256 + (ly0 + j * ROWS) * 16 + lx] > e_lo);
+      if (nseg > 1) alive[j] = alive[j] && (p.stop[(size_t)tile * (TS * TS) + (ly0 + j * ROWS) * TS + lx] > e_lo);
     }
   }
   if constexpr (MODE == MODE_SH) {
@@ -615,7 +622,7 @@ k_composite_bwd_pixel(CompParams p_arg, const CompParams *__restrict__ plist) {
     const size_t pix = valid[j] ? ((size_t)gy[j] * p.W + gx) : 0;
     float4 ck = make_float4(1.0f, 0.0f, 0.0f, 0.0f);  // state in front of entry e_lo: T, prefix rgb
     if constexpr (MODE == MODE_SH) {
-      if (seg > 0 && alive[j]) ck = p.ckpt[((size_t)tile * nseg + seg) * 256 + (ly0 + j * ROWS) * 16 + lx];
+      if (seg > 0 && alive[j]) ck = p.ckpt[((size_t)tile * nseg + seg) * (TS * TS) + (ly0 + j * ROWS) * TS + lx];
     }
     const float pre0[3] = {ck.y, ck.z, ck.w};
 #pragma unroll
@@ -1494,6 +1501,15 @@ static int launch_fwd(const CompParams &p, hipStream_t s) {
   const int ppl = variants().ppl_fwd;
   const uint32_t nblk = comp_grid(p);
   if (p.ntw * p.nth == 0) return 0;
+  if (p.tile_side == 8 || p.tile_side == 32) {  // a caller's own tile size: one fixed shape of the unpacked kernel
+    if constexpr (MODE == MODE_RGBD) return GSGEN_EUNSUPPORTED;
+    else {
+      if (p.nseg > 1) return GSGEN_EUNSUPPORTED;
+      if (p.tile_side == 8) hipLaunchKernelGGL((k_composite_fwd<MODE, CB, 1, false, 8>), dim3(nblk), dim3(64), 0, s, p, (const CompParams *)nullptr);
+      else hipLaunchKernelGGL((k_composite_fwd<MODE, CB, 4, false, 32>), dim3(nblk), dim3(256), 0, s, p, (const CompParams *)nullptr);
+      return (int)hipGetLastError();
+    }
+  }
   if constexpr (MODE == MODE_SH) {
     if (variants().sh_packed && ppl != 1) {  // packed per-pixel arithmetic needs pixel pairs
       if (ppl == 2) hipLaunchKernelGGL((k_composite_fwd_sh_vec<CB, 2>), dim3(nblk), dim3(128), 0, s, p, (const CompParams *)nullptr);
@@ -1513,6 +1529,15 @@ static int launch_bwd(const CompParams &p_, hipStream_t s) {
   if (p.n_hi == 0) p.n_hi = 0x7fffffff;
   const uint32_t nblk = comp_grid(p);
   if (p.ntw * p.nth == 0) return 0;
+  if (p.tile_side == 8 || p.tile_side == 32) {  // a caller's own tile size: one fixed shape of the unpacked kernel
+    if constexpr (MODE == MODE_RGBD) return GSGEN_EUNSUPPORTED;
+    else {
+      if (p.nseg > 1) return GSGEN_EUNSUPPORTED;
+      if (p.tile_side == 8) hipLaunchKernelGGL((k_composite_bwd_pixel<MODE, CB, 1, false, 8>), dim3(nblk), dim3(64), 0, s, p, (const CompParams *)nullptr);
+      else hipLaunchKernelGGL((k_composite_bwd_pixel<MODE, CB, 4, false, 32>), dim3(nblk), dim3(256), 0, s, p, (const CompParams *)nullptr);
+      return (int)hipGetLastError();
+    }
+  }
   if constexpr (MODE == MODE_SH) {
     if (mfma != 0) {  // opt-in matrix-core kernel
       const uint32_t ng = nblk * (uint32_t)(p.nseg > 1 ? p.nseg : 1);
@@ -1757,7 +1782,7 @@ int gsgen_vol_render_start_end_with_T(uint32_t N, uint32_t D, const float *mean,
   p.start = start; p.end = end; p.ids = gaussian_ids; p.topleft = topleft;
   p.out = out; p.T = T;
   p.ntw = (int)n_tiles_w; p.nth = (int)n_tiles_h; p.H = (int)H; p.W = (int)W;
-  p.psx = pixel_size_x; p.psy = pixel_size_y; p.thresh = thresh;
+  p.psx = pixel_size_x; p.psy = pixel_size_y; p.thresh = thresh; p.tile_side = (int)tile_size;
   return launch_fwd<MODE_RGB, 1>(p, (hipStream_t)stream);
 }
 
@@ -1775,7 +1800,7 @@ int gsgen_vol_render_scalar(uint32_t N, uint32_t D, const float *mean, const flo
   p.start = start; p.end = end; p.ids = gaussian_ids; p.topleft = topleft;
   p.out = out; p.T = T;
   p.ntw = (int)n_tiles_w; p.nth = (int)n_tiles_h; p.H = (int)H; p.W = (int)W;
-  p.psx = pixel_size_x; p.psy = pixel_size_y; p.thresh = thresh;
+  p.psx = pixel_size_x; p.psy = pixel_size_y; p.thresh = thresh; p.tile_side = (int)tile_size;
   return launch_fwd<MODE_SCALAR, 1>(p, (hipStream_t)stream);
 }
 
@@ -1794,7 +1819,7 @@ int gsgen_vol_render_rgbd(uint32_t N, uint32_t D, const float *mean, const float
   p.start = start; p.end = end; p.ids = gaussian_ids; p.topleft = topleft;
   p.out = out6; p.T = T;
   p.ntw = (int)n_tiles_w; p.nth = (int)n_tiles_h; p.H = (int)H; p.W = (int)W;
-  p.psx = pixel_size_x; p.psy = pixel_size_y; p.thresh = thresh;
+  p.psx = pixel_size_x; p.psy = pixel_size_y; p.thresh = thresh; p.tile_side = (int)tile_size;
   p.tile_order = tile_order;
   return launch_fwd<MODE_RGBD, 1>(p, (hipStream_t)stream);
 }
@@ -1833,7 +1858,7 @@ int gsgen_vol_render_sh_segmented(uint32_t N, uint32_t D, const float *mean, con
   p.start = start; p.end = end; p.ids = gaussian_ids; p.topleft = topleft; p.rot = c2w;
   p.bg = bg_rgb; p.out = out; p.T = T;
   p.ntw = (int)n_tiles_w; p.nth = (int)n_tiles_h; p.H = (int)H; p.W = (int)W;
-  p.psx = pixel_size_x; p.psy = pixel_size_y; p.thresh = thresh;
+  p.psx = pixel_size_x; p.psy = pixel_size_y; p.thresh = thresh; p.tile_side = (int)tile_size;
   p.tile_order = tile_order;
   if (n_segments > 1) {
     p.nseg = (int)n_segments;

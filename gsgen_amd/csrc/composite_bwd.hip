@@ -53,7 +53,7 @@ int gsgen_vol_render_backward_start_end(uint32_t N, uint32_t D, const float *mea
   p.final_img = out; p.grad_out = grad_out;
   p.g_mean = grad_mean; p.g_cov = grad_cov; p.g_col = grad_color; p.g_alpha = grad_alpha;
   p.ntw = (int)n_tiles_w; p.nth = (int)n_tiles_h; p.H = (int)H; p.W = (int)W;
-  p.psx = pixel_size_x; p.psy = pixel_size_y; p.thresh = thresh;
+  p.psx = pixel_size_x; p.psy = pixel_size_y; p.thresh = thresh; p.tile_side = (int)tile_size;
   return launch_bwd(MODE_RGB, 1, p, (hipStream_t)stream);
 }
 
@@ -73,7 +73,7 @@ int gsgen_vol_render_rgbd_backward(uint32_t N, uint32_t D, const float *mean, co
   p.final_img = out6; p.grad_out = grad_out6;
   p.g_mean = grad_mean; p.g_cov = grad_cov; p.g_col = grad_chan6; p.g_alpha = grad_alpha;
   p.ntw = (int)n_tiles_w; p.nth = (int)n_tiles_h; p.H = (int)H; p.W = (int)W;
-  p.psx = pixel_size_x; p.psy = pixel_size_y; p.thresh = thresh;
+  p.psx = pixel_size_x; p.psy = pixel_size_y; p.thresh = thresh; p.tile_side = (int)tile_size;
   p.tile_order = tile_order;
   return launch_bwd(MODE_RGBD, 1, p, (hipStream_t)stream);
 }
@@ -94,7 +94,7 @@ int gsgen_vol_render_scalar_backward(uint32_t N, uint32_t D, const float *mean, 
   p.final_img = out; p.grad_out = grad_out;
   p.g_mean = grad_mean; p.g_cov = grad_cov; p.g_col = grad_scalar; p.g_alpha = grad_alpha;
   p.ntw = (int)n_tiles_w; p.nth = (int)n_tiles_h; p.H = (int)H; p.W = (int)W;
-  p.psx = pixel_size_x; p.psy = pixel_size_y; p.thresh = thresh;
+  p.psx = pixel_size_x; p.psy = pixel_size_y; p.thresh = thresh; p.tile_side = (int)tile_size;
   return launch_bwd(MODE_SCALAR, 1, p, (hipStream_t)stream);
 }
 
@@ -137,7 +137,7 @@ int gsgen_vol_render_backward_sh_segmented(uint32_t N, uint32_t D, const float *
   p.final_img = out; p.grad_out = grad_out;
   p.g_mean = grad_mean; p.g_cov = grad_cov; p.g_col = grad_sh_coeffs; p.g_alpha = grad_alpha;
   p.ntw = (int)n_tiles_w; p.nth = (int)n_tiles_h; p.H = (int)H; p.W = (int)W;
-  p.psx = pixel_size_x; p.psy = pixel_size_y; p.thresh = thresh;
+  p.psx = pixel_size_x; p.psy = pixel_size_y; p.thresh = thresh; p.tile_side = (int)tile_size;
   p.tile_order = tile_order;
   if (n_segments > 1) {
     p.nseg = (int)n_segments;

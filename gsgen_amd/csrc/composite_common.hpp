@@ -32,6 +32,7 @@ struct CompParams {
   float4 *ckpt;  // [tile][nseg][256 pixels, row-major in the tile]: T, prefix rgb
   int *stop;     // [tile][256]: first list index the pixel did not process (n if it never saturated)
   int nseg;
+  int tile_side;  // host side only (kernel selection): 0 / 16 = this library's tiles; 8, 32: see k_composite_fwd
 };
 constexpr int kSegLen = 32;
 
@@ -273,8 +274,9 @@ static inline int env_ppl(const char *name, int dflt) {
   return (x == 1 || x == 2 || x == 4) ? x : dflt;
 }
 
+// tile_size: 16 (every kernel variant) or 8 / 32 (the unpacked vector kernels at one fixed shape; no segments, no batch)
 static inline int check_common(uint32_t tile_size, const void *a, const void *b, const void *c) {
-  if (tile_size != (uint32_t)kTile) return GSGEN_EUNSUPPORTED;
+  if (tile_size != 8u && tile_size != 16u && tile_size != 32u) return GSGEN_EUNSUPPORTED;
   if (!a || !b || !c) return GSGEN_EINVAL;
   return 0;
 }

@@ -18,8 +18,12 @@
  * Layouts (row-major, fp32 unless noted): mean2d [N,2]; cov2d [N,2,2]; color [N,3];
  * alpha [N]; scalar [N]; sh_coeffs [N,3,C*C]; start/end int32 [n_tiles_h*n_tiles_w];
  * gaussian_ids int32 [D]; out [H,W,3] (or [H,W] scalar); T [H,W]; topleft [2]; bg_rgb [3].
- * Only tile_size == 16 is implemented (the reference's only configured value,
- * conf/base.yaml:131); anything else returns GSGEN_EUNSUPPORTED.
+ * tile_size: 16 is the reference's only configured value (conf/base.yaml:132) and the size every tuned kernel variant,
+ * the batched, segmented and fused entry points are built for.  The per-camera entry points of the `_gs` surface
+ * (gsgen_tile_culling_aabb_count, gsgen_vol_render_start_end_with_T / _backward_start_end, _scalar / _scalar_backward,
+ * _sh / _backward_sh) also take 8 and 32, as the reference's launch of tile_size x tile_size threads does
+ * (vol_render.h:1001-1004); binning works on tile-index rectangles and is size-agnostic.  Anything else returns
+ * GSGEN_EUNSUPPORTED.  Per-pixel results do not depend on the tile size.
  */
 #ifndef GSGEN_HIP_H
 #define GSGEN_HIP_H
@@ -32,7 +36,7 @@ extern "C" {
 
 typedef void *gsgen_stream_t; /* hipStream_t; NULL = the legacy default stream */
 
-#define GSGEN_EUNSUPPORTED (-2) /* tile_size != 16, C not in 1..4 */
+#define GSGEN_EUNSUPPORTED (-2) /* tile_size not in {8, 16, 32} (16 only: batched / segmented / fused), C not in 1..4 */
 #define GSGEN_EINVAL (-3)       /* null pointer / inconsistent sizes */
 #define GSGEN_EWORKSPACE (-4)   /* workspace too small */
 

@@ -229,6 +229,31 @@ def test_emulated_kernels_match_oracle(emu, C, W, H):
         assert np.abs(a - b).max() <= 1e-4 * (np.abs(b).max() + 1e-12)
 
 
+class _HostArrays:
+    """the emulator works on host memory: "device" arrays are numpy arrays"""
+
+    class Arr:
+        def __init__(self, a):
+            self.a = np.ascontiguousarray(a).copy(); self.p = self.a.ctypes.data; self.n = self.a.size
+
+        def get(self):
+            return self.a
+
+    def __init__(self, lib):
+        self.lib, self.stream = lib, None
+
+    def to_dev(self, a):
+        return self.Arr(a)
+
+
+@pytest.mark.parametrize("ts,C,W,H", [(8, 4, 33, 20), (32, 3, 70, 40), (8, 1, 24, 17), (32, 2, 40, 40)])
+def test_emulated_other_tile_sizes(emu, ts, C, W, H):
+    """tile_size 8 and 32 (the reference takes the tile size as a parameter, conf/base.yaml:132): the whole per-camera
+    chain of `_gs` entry points against the oracle at that tile size"""
+    from tile_chain import other_tile_size_chain
+    other_tile_size_chain(_HostArrays(emu), ts, C, W, H)
+
+
 def test_emulated_fused_frame_geometry(emu):
     from gsgen_amd import renderer as R
     cam = scenes.Camera(80, 64, fx=70.0, c2w=scenes.orbit(2.0, 25, 200))
@@ -859,14 +884,14 @@ def test_no_kernel_spills_and_hot_kernels_keep_their_occupancy(tmp_path):
         assert bwd["vgpr_count"] <= 256 and 8 * bwd["group_segment_fixed_size"] <= 160 * 1024
     for bwd in find(2, "k_composite_bwd_sh_vecILi4ELi2E"):
         assert bwd["vgpr_count"] <= 168
-    for bwd in find(2, "k_composite_bwd_pixelILi2ELi4ELi4E"):
+    for bwd in find(2, "k_composite_bwd_pixelILi2ELi4ELi4E", "ELi16EE"):
         assert bwd["vgpr_count"] <= 256
-    for bwd in find(2, "k_composite_bwd_pixelILi2ELi4ELi2E"):
+    for bwd in find(2, "k_composite_bwd_pixelILi2ELi4ELi2E", "ELi16EE"):
         assert bwd["vgpr_count"] <= 128
     # opt-in matrix-core SH backward: 3 wavefronts per SIMD = 6 two-wavefront workgroups per CU (160 KB of LDS)
     for bwd in find(2, "k_composite_bwd_sh_mfmaILi4ELi2E"):
         assert bwd["vgpr_count"] <= 168 and 6 * bwd["group_segment_fixed_size"] <= 160 * 1024
-    for fwd in find(2, "k_composite_fwdILi2ELi4ELi1E"):      # default SH forward: 4 wavefronts per tile
+    for fwd in find(2, "k_composite_fwdILi2ELi4ELi1E", "ELi16EE"):      # default SH forward: 4 wavefronts per tile
         assert fwd["vgpr_count"] <= 128
     assert find(1, "k_sort_tiles", "PKjS1_PKyPiS4_S4_")[0]["group_segment_fixed_size"] == 0  # register sort: no LDS
 

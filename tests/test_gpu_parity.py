@@ -402,3 +402,28 @@ def test_wave_reduce_scatter_primitive(Pc):
     for lane in range(64):
         if owner[lane] >= 0:
             assert abs(o[lane] - tot[owner[lane]]) < 1e-4
+
+
+class _DeviceArrays:
+    """tile_chain.other_tile_size_chain on the GPU: arrays are torch tensors on the device"""
+
+    class Arr:
+        def __init__(self, a):
+            self.t = torch.from_numpy(np.ascontiguousarray(a).copy()).to(dev()); self.p = self.t.data_ptr(); self.n = self.t.numel()
+
+        def get(self):
+            return self.t.cpu().numpy()
+
+    def __init__(self):
+        self.lib, self.stream = lib(), stream()
+
+    def to_dev(self, a):
+        return self.Arr(a)
+
+
+@pytest.mark.parametrize("ts,C,W,H", [(8, 4, 133, 90), (32, 4, 200, 120), (8, 1, 64, 48), (32, 2, 97, 65), (8, 3, 80, 80)])
+def test_other_tile_sizes(ts, C, W, H):
+    """tile_size 8 and 32 through the C ABI: count, bin / sort, RGB / scalar / SH forward and backward against the
+    oracle at that tile size (the reference takes the tile size as a parameter, conf/base.yaml:132)"""
+    from tile_chain import other_tile_size_chain
+    other_tile_size_chain(_DeviceArrays(), ts, C, W, H, sync=torch.cuda.synchronize)

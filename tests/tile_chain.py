@@ -1,0 +1,100 @@
+"""The per-camera chain of `_gs` entry points at a caller-chosen tile size (8 / 32), against the oracle at that tile size.
+Shared by the emulator test (tests/test_cpu_host.py) and the GPU test (tests/test_gpu_parity.py): `L` provides
+`lib` (the ctypes binding), `stream`, and `to_dev(array)` -> object with `.p` (address), `.n` (elements), `.get()`."""
+import numpy as np
+import pytest
+
+import scenes
+from oracle import oracle as O
+
+
+def other_tile_size_chain(L, ts, C, W, H, sync=lambda: None, rtol=1e-4):
+    """count -> bin / sort -> RGB, scalar and SH forward + backward at tile size `ts` through the library `L`
+    (P_: array -> address) against the oracle at the same tile size.  Shared by the emulator and the GPU test."""
+    cam = scenes.Camera(W, H, fx=float(W))
+    sc = scenes.random_scene(300, seed=C + ts, svec=0.07, C=C)
+    normals, pts = O.frustum(cam.c2w, *cam.intr)
+    m = O.cull_bsphere(sc["mean"], sc["svec"], normals, pts, 6.0)
+    N = int(m.sum())
+    m2, c2, _, dep = O.project(sc["mean"][m], sc["qvec"][m], sc["svec"][m], cam.c2w)
+    D, otl, obr = O.aabb_count(m2, c2, ts, cam.fx, cam.fy, cam.cx, cam.cy, cam.w, cam.h, 6.0)
+    nth, ntw = (H + ts - 1) // ts, (W + ts - 1) // ts
+    oids, ost, oen = O.bin_sort(otl, obr, dep, nth, ntw, D)
+    c2f = np.ascontiguousarray(c2.reshape(-1, 4))
+    tl = np.zeros((N, 2), np.int32); br = np.zeros((N, 2), np.int32); tot = np.zeros(1, np.uint32)
+    h = {k: v for k, v in dict(m2=m2, c2=c2f, dep=dep, tl=tl, br=br, tot=tot).items()}
+    h = {k: L.to_dev(v) for k, v in h.items()}
+    L.lib.tile_culling_aabb_count(N, h["m2"].p, h["c2"].p, ts, cam.fx, cam.fy, cam.cx, cam.cy, cam.w, cam.h, 6.0, h["tl"].p,
+                                  h["br"].p, h["tot"].p, L.stream)
+    sync()
+    assert int(h["tot"].get()[0]) == D and np.array_equal(h["tl"].get(), otl) and np.array_equal(h["br"].get(), obr)
+    ws = L.to_dev(np.zeros(L.lib.tile_culling_workspace_bytes(N, D, nth * ntw), np.uint8))
+    ids = L.to_dev(np.zeros(D, np.int32)); st = L.to_dev(-np.ones(nth * ntw, np.int32)); en = L.to_dev(-np.ones(nth * ntw, np.int32))
+    L.lib.tile_culling_aabb_start_end(N, D, nth, ntw, h["tl"].p, h["br"].p, h["dep"].p, ids.p, st.p, en.p, ws.p, ws.n, L.stream)
+    sync()
+    assert np.array_equal(st.get(), ost) and np.array_equal(en.get(), oen) and np.array_equal(ids.get(), oids)
+    col = np.ascontiguousarray(sc["color"][m]); al = np.ascontiguousarray(sc["alpha"][m])
+    tlp = cam.topleft; psx, psy = 1 / cam.fx, 1 / cam.fy
+    geo = (ost, oen, oids, tlp, psx, psy, H, W)
+    d = {k: L.to_dev(v) for k, v in dict(col=col, al=al, tlp=tlp).items()}
+    go = np.random.default_rng(3).normal(size=(H, W, 3)).astype(np.float32)
+
+    def close(a, b):
+        assert np.abs(a - b).max() <= rtol * (np.abs(b).max() + 1e-12)
+    # RGB
+    out = L.to_dev(np.zeros((H, W, 3), np.float32)); T = L.to_dev(np.ones((H, W), np.float32))
+    L.lib.vol_render_start_end_with_T(N, D, h["m2"].p, h["c2"].p, d["col"].p, d["al"].p, st.p, en.p, ids.p, out.p, d["tlp"].p, ts,
+                                      nth, ntw, psx, psy, H, W, 1e-4, T.p, L.stream)
+    sync()
+    ref, refT = O.render_rgb_fwd(m2, c2, col, al, *geo, tile_size=ts)
+    assert np.abs(out.get() - ref).max() < 1e-5 and np.abs(T.get() - refT.reshape(H, W)).max() < 1e-5
+    bgimg = np.random.default_rng(4).uniform(size=(H, W, 3)).astype(np.float32)
+    final = (ref + refT.reshape(H, W, 1) * bgimg).astype(np.float32)
+    g = {k: L.to_dev(np.zeros(s_, np.float32)) for k, s_ in dict(gm=(N, 2), gc=(N, 4), gcol=(N, 3), ga=(N,)).items()}
+    fin = L.to_dev(final); god = L.to_dev(go)
+    L.lib.vol_render_backward_start_end(N, D, h["m2"].p, h["c2"].p, d["col"].p, d["al"].p, st.p, en.p, ids.p, fin.p, g["gm"].p,
+                                        g["gc"].p, g["gcol"].p, g["ga"].p, god.p, d["tlp"].p, ts, nth, ntw, psx, psy, H, W,
+                                        1e-4, L.stream)
+    sync()
+    om, oc, ocol, oa = O.render_rgb_bwd(m2, c2, col, al, ost, oen, oids, final, go, tlp, psx, psy, H, W, tile_size=ts)
+    for a, b in ((g["gm"], om), (g["gc"], oc.reshape(-1, 4)), (g["gcol"], ocol), (g["ga"], oa)):
+        close(a.get(), b)
+    # scalar
+    sval = np.ascontiguousarray(dep); sv = L.to_dev(sval)
+    sout = L.to_dev(np.zeros((H, W), np.float32)); sT = L.to_dev(np.ones((H, W), np.float32))
+    L.lib.vol_render_scalar(N, D, h["m2"].p, h["c2"].p, sv.p, d["al"].p, st.p, en.p, ids.p, sout.p, d["tlp"].p, ts, nth, ntw,
+                            psx, psy, H, W, 1e-4, sT.p, L.stream)
+    sync()
+    sref, _ = O.render_scalar_fwd(m2, c2, sval, al, *geo, tile_size=ts)
+    assert np.abs(sout.get() - sref).max() < 1e-5 * max(1.0, np.abs(sref).max())
+    sgo = np.ascontiguousarray(go[..., 0]); sgod = L.to_dev(sgo); srefd = L.to_dev(sref)
+    g = {k: L.to_dev(np.zeros(s_, np.float32)) for k, s_ in dict(gm=(N, 2), gc=(N, 4), gs=(N,), ga=(N,)).items()}
+    L.lib.vol_render_scalar_backward(N, D, h["m2"].p, h["c2"].p, sv.p, d["al"].p, st.p, en.p, ids.p, srefd.p, g["gm"].p,
+                                     g["gc"].p, g["gs"].p, g["ga"].p, sgod.p, d["tlp"].p, ts, nth, ntw, psx, psy, H, W, 1e-4,
+                                     L.stream)
+    sync()
+    om, oc, os_, oa = O.render_scalar_bwd(m2, c2, sval, al, ost, oen, oids, sref, sgo, tlp, psx, psy, H, W, tile_size=ts)
+    for a, b in ((g["gm"], om), (g["gc"], oc.reshape(-1, 4)), (g["gs"], os_), (g["ga"], oa)):
+        close(a.get(), b)
+    # SH with a background
+    sh = np.ascontiguousarray(sc["sh"][m]); rot = np.ascontiguousarray(cam.c2w[:3, :3]).reshape(-1).copy()
+    bg = np.array([0.2, 0.5, 0.7], np.float32)
+    shd, rotd, bgd = L.to_dev(sh), L.to_dev(rot), L.to_dev(bg)
+    out = L.to_dev(np.zeros((H, W, 3), np.float32))
+    L.lib.vol_render_sh(N, D, h["m2"].p, h["c2"].p, shd.p, d["al"].p, st.p, en.p, ids.p, out.p, d["tlp"].p, rotd.p, ts, nth, ntw,
+                        psx, psy, H, W, C, 1e-4, bgd.p, None, L.stream)
+    sync()
+    ref = O.render_sh_fwd(m2, c2, sh, al, ost, oen, oids, tlp, rot, C, psx, psy, H, W, bg=bg, tile_size=ts)
+    scenes.assert_sh_image_parity(out.get(), ref, m2, c2, al, ost, oen, oids, tlp, psx, psy, tol=1e-5, what=f"tile {ts}")
+    g = {k: L.to_dev(np.zeros(s_, np.float32)) for k, s_ in dict(gm=(N, 2), gc=(N, 4), gsh=(N, 3, C * C), ga=(N,)).items()}
+    L.lib.vol_render_backward_sh(N, D, h["m2"].p, h["c2"].p, shd.p, d["al"].p, st.p, en.p, ids.p, out.p, g["gm"].p, g["gc"].p,
+                                 g["gsh"].p, g["ga"].p, god.p, d["tlp"].p, rotd.p, ts, nth, ntw, psx, psy, H, W, C, 1e-4, bgd.p,
+                                 L.stream)
+    sync()
+    om, oc, osh, oa = O.render_sh_bwd(m2, c2, sh, al, ost, oen, oids, ref, go, tlp, rot, C, psx, psy, H, W, tile_size=ts)
+    for a, b in ((g["gm"], om), (g["gc"], oc.reshape(-1, 4)), (g["gsh"], osh), (g["ga"], oa)):
+        close(a.get(), b)
+    # tile sizes the kernels do not exist for are refused, not misrendered
+    with pytest.raises(Exception, match="unsupported"):
+        L.lib.vol_render_sh(N, D, h["m2"].p, h["c2"].p, shd.p, d["al"].p, st.p, en.p, ids.p, out.p, d["tlp"].p, rotd.p, 12, nth,
+                            ntw, psx, psy, H, W, C, 1e-4, bgd.p, None, L.stream)
