@@ -321,8 +321,8 @@ def test_unsupported_configs_raise():
     L = lib()
     z = torch.zeros(4, device=dev()); zi = torch.zeros(4, dtype=torch.int32, device=dev())
     with pytest.raises(GsgenError):
-        L.vol_render_start_end_with_T(1, 1, p(z), p(z), p(z), p(z), p(zi), p(zi), p(zi), p(z), p(z), 8, 1, 1, 1.0, 1.0,
-                                      8, 8, 1e-4, p(z), stream())
+        L.vol_render_start_end_with_T(1, 1, p(z), p(z), p(z), p(z), p(zi), p(zi), p(zi), p(z), p(z), 12, 1, 1, 1.0, 1.0,
+                                      8, 8, 1e-4, p(z), stream())  # tile sizes: 8, 16, 32
 
 
 def test_long_tile_list_and_ties():
