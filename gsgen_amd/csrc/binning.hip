@@ -408,7 +408,7 @@ sort_tiles_big_body(uint32_t T, const uint32_t *__restrict__ tile_off, const uin
   __shared__ unsigned long long s_keys[kSortLds];
   const uint32_t tid = threadIdx.x;
   if (ctrl[1] != 0u) return;
-  // With a launch order (k_order_tiles: every list of >= 2040 entries sits in the first bucket) a few
+  // With a launch order (order_tiles_body: every list of >= 2040 entries sits in the first bucket) a few
   // workgroups walk the front of it and stop at the first short list, instead of one workgroup per tile
   // each finding it has nothing to do: 32 KiB of LDS per workgroup made 20k of those queue for 270 us
   // behind the compositing kernels of another batch.
@@ -461,23 +461,19 @@ k_scan_chunks_views(uint32_t T, uint32_t nchunks, const GeoView *__restrict__ vi
   const GeoView v = views[blockIdx.y];
   scan_chunks_body(T, nchunks, v.cnt, v.tile_count);
 }
+// tile offsets and the longest-first launch order in ONE launch: both read tile_count only, both are one workgroup --
+// as two kernels they were two ~5 us links in a lone render's chain of dependent launches
 __global__ void __launch_bounds__(1024)
-k_scan_tiles(uint32_t T, const uint32_t *__restrict__ tile_count, uint32_t *__restrict__ tile_off,
-             uint32_t *__restrict__ ctrl, uint32_t cap, uint32_t *__restrict__ total_out) {
+k_scan_order_tiles(uint32_t T, const uint32_t *__restrict__ tile_count, uint32_t *__restrict__ tile_off,
+                   uint32_t *__restrict__ ctrl, uint32_t cap, uint32_t *__restrict__ total_out,
+                   uint32_t *__restrict__ tile_order) {
   scan_tiles_body(T, tile_count, tile_off, ctrl, cap, total_out);
-}
-__global__ void __launch_bounds__(1024)
-k_scan_tiles_views(uint32_t T, const GeoView *__restrict__ views) {
-  const GeoView v = views[blockIdx.y];
-  scan_tiles_body(T, v.tile_count, v.tile_off, v.ctrl, v.cap, v.total);
-}
-__global__ void __launch_bounds__(1024)
-k_order_tiles(uint32_t T, const uint32_t *__restrict__ tile_count, uint32_t *__restrict__ tile_order) {
   order_tiles_body(T, tile_count, tile_order);
 }
 __global__ void __launch_bounds__(1024)
-k_order_tiles_views(uint32_t T, const GeoView *__restrict__ views) {
+k_scan_order_tiles_views(uint32_t T, const GeoView *__restrict__ views) {
   const GeoView v = views[blockIdx.y];
+  scan_tiles_body(T, v.tile_count, v.tile_off, v.ctrl, v.cap, v.total);
   order_tiles_body(T, v.tile_count, v.tile_order);
 }
 __global__ void __launch_bounds__(64)
@@ -486,7 +482,7 @@ k_sort_tiles(uint32_t T, const uint32_t *__restrict__ tile_off, const uint32_t *
              int *__restrict__ end) {
   sort_tiles_body(xcd_swizzle(blockIdx.x, gridDim.x), tile_off, ctrl, keys, ids, start, end);
 }
-// 1-D grid of T x B workgroups, view = id % B, tiles in k_order_tiles order (longest list first): every
+// 1-D grid of T x B workgroups, view = id % B, tiles in order_tiles_body order (longest list first): every
 // view's long sorts (one wavefront, up to ~30 us) start at once and the launch ends on the short ones.
 // View-major order measured 134 us for 8 cfg2 views: ~2.5 views resident at a time, each waiting on
 // its longest tile.
@@ -566,8 +562,8 @@ static int bin_and_sort(uint32_t N, uint32_t cap, uint32_t nth, uint32_t ntw, co
   }
   hipLaunchKernelGGL(k_scan_chunks, dim3((T + 3) / 4), dim3(256), 0, s, T, w.nchunks,
                      w.cnt, w.tile_count);
-  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, T, w.tile_count, w.tile_off, w.ctrl, cap, total_out);
-  hipLaunchKernelGGL(k_order_tiles, dim3(1), dim3(1024), 0, s, T, w.tile_count, w.tile_order);
+  hipLaunchKernelGGL(k_scan_order_tiles, dim3(1), dim3(1024), 0, s, T, w.tile_count, w.tile_off, w.ctrl, cap, total_out,
+                     w.tile_order);
   if (N)
     hipLaunchKernelGGL((k_bin_pull<true>), gpull, bpull, 0, s, N, tl, br, depth, (int)ntw, (int)nth, T,
                        w.cnt, w.wcnt, w.tile_off, w.ctrl, w.keys);
@@ -687,8 +683,7 @@ int gsgen_frame_geometry_batch(uint32_t n_views, const gsgen_geometry_view *view
     hipLaunchKernelGGL((k_bin_pull_views<false>), gpull, bpull, 0, s, N, (int)ntw, (int)nth, T, (const GeoView *)dv);
   }
   hipLaunchKernelGGL(k_scan_chunks_views, dim3((T + 3) / 4, B), dim3(256), 0, s, T, nchunks, (const GeoView *)dv);
-  hipLaunchKernelGGL(k_scan_tiles_views, dim3(1, B), dim3(1024), 0, s, T, (const GeoView *)dv);
-  hipLaunchKernelGGL(k_order_tiles_views, dim3(1, B), dim3(1024), 0, s, T, (const GeoView *)dv);
+  hipLaunchKernelGGL(k_scan_order_tiles_views, dim3(1, B), dim3(1024), 0, s, T, (const GeoView *)dv);
   if (N)
     hipLaunchKernelGGL((k_bin_pull_views<true>), gpull, bpull, 0, s, N, (int)ntw, (int)nth, T, (const GeoView *)dv);
   hipLaunchKernelGGL(k_sort_tiles_views, dim3(T * B), dim3(64), 0, s, T, B, (const GeoView *)dv);

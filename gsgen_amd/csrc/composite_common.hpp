@@ -239,12 +239,16 @@ __device__ __forceinline__ float gauss_eval(const GRec &r, float x, float y, flo
     G = __builtin_amdgcn_exp2f(-(u * u + v * v));
   }
   const float ag = r.a * G;
-  if (alive && fabsf(ag - kMinAlpha) <= kMinAlpha * kGuardTol) {
-    // within rounding of the skip threshold: take the reference's arithmetic
-    if constexpr (MODE == MODE_SH)
-      G = gauss_ref_f32(r.mx, r.my, r.c0, r.c1, r.c2, r.c3, px, py);
-    else
-      G = gauss_ref_f64(r.mx, r.my, r.c0, r.c1, r.c2, r.c3, px, py);
+  // within rounding of the skip threshold: take the reference's arithmetic.  The wave-uniform test in front keeps the
+  // common case (no lane anywhere near: all but a handful of pixels per frame) free of exec-mask juggling
+  const bool near = alive && fabsf(ag - kMinAlpha) <= kMinAlpha * kGuardTol;
+  if (__ballot(near) != 0ull) {
+    if (near) {
+      if constexpr (MODE == MODE_SH)
+        G = gauss_ref_f32(r.mx, r.my, r.c0, r.c1, r.c2, r.c3, px, py);
+      else
+        G = gauss_ref_f64(r.mx, r.my, r.c0, r.c1, r.c2, r.c3, px, py);
+    }
   }
   return G;
 }
