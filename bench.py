@@ -459,6 +459,19 @@ def main():
                "fwd_kernel": lib.kernel_variant("sh_fwd", C, lseg), "bwd_kernel": lib.kernel_variant("sh_bwd", C, lseg),
                "fwd_kernel_ms": float(np.mean([e[0].elapsed_time(e[1]) for e in ev1])),
                "bwd_kernel_ms": float(np.mean([e[2].elapsed_time(e[3]) for e in ev1]))}
+        if lseg > 1:
+            # list entries the compositing actually walks: the segmented forward leaves, per pixel, the first entry it did
+            # not process; a tile's workgroup walks up to the largest of its pixels' (early termination, T < thresh)
+            walked = []
+            off = nth * ntw * 256 * lseg * 16
+            for k in range(min(ncam, 8)):
+                one_render(k)
+                torch.cuda.synchronize()
+                stop_ = lseg_ws[off:off + nth * ntw * 256 * 4].view(torch.int32).view(nth * ntw, 256)
+                n_tile = (b0.end - b0.start).clamp(min=0).view(-1)
+                walked.append((float(stop_.max(dim=1).values.clamp(min=0).minimum(n_tile).sum().item()), float(n_tile.sum().item())))
+            one["walked_pairs_per_view"] = float(np.mean([w_[0] for w_ in walked]))
+            one["walked_fraction_of_D"] = float(np.sum([w_[0] for w_ in walked]) / max(1.0, np.sum([w_[1] for w_ in walked])))
         try:  # ... and replayed from one captured hipGraph per camera: same kernels, no launch gaps
             graphs = []
             with torch.cuda.stream(sl0.stream):
@@ -524,6 +537,13 @@ def main():
                      "whole_render_alg_bytes": total_b,
                      "whole_render_hbm_frac": total_b * (value / world) / (HBM_PEAK_GBS * 1e9)},
     }
+    if one is not None and "walked_fraction_of_D" in one:
+        # "honest bytes": the list entries the kernels really walk (early termination), not the D of the formula
+        wf = one["walked_fraction_of_D"]
+        wb = (4 + 4 * F) * D * wf + 28 * P + 4 * F * D * wf
+        res["roofline"]["walked_fraction_of_D"] = wf
+        res["roofline"]["walked_bytes_per_launch"] = B * wb
+        res["roofline"]["walked_achieved_GBs"] = B * wb / (bwd_ms * 1e-3) / 1e9
     if valu_floor is not None:
         # the kernel is bound by vector-ALU issue, not HBM: the time it would take if every
         # SIMD issued its share of the measured vector instructions back to back
