@@ -1086,6 +1086,180 @@ k_composite_bwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
 }
 
 // ============================================================================================
+// backward, post-activation channels (RGB, scalar, RGB + heads), packed per-pixel arithmetic
+// ============================================================================================
+// The trainer's default outputs (gs/gaussian_splatting.py:1304-1416: rgb + depth + opacity + depth^2 from
+// post-activation colours) go through MODE_RGBD.  k_composite_bwd_pixel spends ~300 vector instructions per
+// (wavefront, list entry) on it at 2 pixels per lane -- a third of them register moves around its per-pixel branches.
+// This is k_composite_bwd_sh_vec without the SH part: one wavefront per tile, 4 pixels per lane as two pixel PAIRS,
+// every per-pixel quantity packed, contribution mask folded into G and a G, `alive` = (T >= thresh), one wave-uniform
+// guard branch, the record in scalar registers, the NCH + 7 gradient components reduced as (even, odd) pairs.
+// Reduction vector: channels [0, NCH) | pad to even | mean 2 | cov 4 | alpha 1.
+template <int MODE, bool BATCH = false>
+__global__ void __launch_bounds__(64)
+k_composite_bwd_chan_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
+  static_assert(MODE == MODE_RGB || MODE == MODE_SCALAR || MODE == MODE_RGBD, "post-activation channel modes");
+  uint32_t bid = blockIdx.x, grid = gridDim.x;
+  const CompParams p = BATCH ? plist[batch_view(p_arg, bid, &grid)] : p_arg;
+  (void)grid;
+  using TR = Traits<MODE, 1>;
+  constexpr int PPL = 4, NT = 64, ROWS = NT / 16, NP = PPL / 2;
+  constexpr int NCH = TR::NCH;
+  constexpr int G0 = (NCH + 1) & ~1;  // first geometric component
+  constexpr int P = 16;
+  static_assert(G0 + 7 <= P, "component layout");
+  __shared__ Stage<MODE, 1> S;
+
+  int tx, ty;
+  if (!block_tile(p, tx, ty, bid)) return;  // uniform over the workgroup
+  const int tile = ty * p.ntw + tx;
+  const int st = p.start[tile];
+  const int n = (st < 0) ? 0 : (p.end[tile] - st);
+  if (n == 0 || n < p.n_lo || n >= p.n_hi) return;
+  const int t = (int)threadIdx.x;
+  const int lane = t & 63;
+  const int lx = t & 15, ly0 = t >> 4;
+  const int gx = tx * kTile + lx;
+  const float px = pixel_coord(p.topleft[0], gx, p.psx);
+
+  v2f py2[NP], go2[NP][NCH], rem2[NP][NCH], Tr2[NP];
+#pragma unroll
+  for (int j = 0; j < PPL; ++j) {
+    const int gy = ty * kTile + ly0 + j * ROWS;
+    const bool valid = (gx < p.W) && (gy < p.H);
+    py2[j >> 1][j & 1] = pixel_coord(p.topleft[1], gy, p.psy);
+    const size_t pix = valid ? ((size_t)gy * p.W + gx) : 0;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      go2[j >> 1][c][j & 1] = valid ? p.grad_out[NCH * pix + c] : 0.0f;
+      rem2[j >> 1][c][j & 1] = valid ? p.final_img[NCH * pix + c] : 0.0f;  // final - prefix, prefix = 0
+    }
+    Tr2[j >> 1][j & 1] = valid ? 1.0f : -1.0f;  // alive = (T >= thresh); pixels outside never are
+  }
+  auto alive = [&](int j) { return !(Tr2[j >> 1][j & 1] < p.thresh); };
+
+  for (int base = 0; base < n; base += kBatch) {
+    const int nb = min(kBatch, n - base);
+    if (base > 0) __syncthreads();
+    stage_batch<MODE, 1, NT>(S, p, st + base, nb);
+    __syncthreads();
+
+    for (int g = 0; g < nb; ++g) {
+      bool any_alive = false;
+#pragma unroll
+      for (int j = 0; j < PPL; ++j) any_alive |= alive(j);
+      if (__ballot(any_alive) == 0ull) break;
+
+      const float r_mx = wave_uniform(S.mx[g]), r_my = wave_uniform(S.my[g]), r_a = wave_uniform(S.a[g]),
+                  r_c0 = wave_uniform(S.c0[g]), r_c1 = wave_uniform(S.c1[g]), r_c2 = wave_uniform(S.c2[g]),
+                  r_c3 = wave_uniform(S.c3[g]), r_p0 = wave_uniform(S.p0[g]), r_p1 = wave_uniform(S.p1[g]),
+                  r_p2 = wave_uniform(S.p2[g]);
+      const float x = px - r_mx;
+      // G2 / ag2: the Gaussian (gauss_eval's Cholesky form) and a G, ZEROED where the pixel does not take part
+      v2f y2[NP], G2[NP], ag2[NP];
+      bool any_con = false, any_guard = false;
+      const float p0x = r_p0 * x;
+#pragma unroll
+      for (int jp = 0; jp < NP; ++jp) {
+        y2[jp] = py2[jp] - splat2(r_my);
+        const v2f u = fma2(splat2(r_p1), y2[jp], splat2(p0x));
+        const v2f v = splat2(r_p2) * y2[jp];
+        const v2f e = -(u * u + v * v);
+        G2[jp] = v2f{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+        ag2[jp] = splat2(r_a) * G2[jp];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) any_guard |= alive(2 * jp + k) && fabsf(ag2[jp][k] - kMinAlpha) <= kMinAlpha * kGuardTol;
+      }
+      if (__ballot(any_guard) != 0ull) {  // within rounding of the skip threshold: the reference's arithmetic decides
+#pragma unroll
+        for (int jp = 0; jp < NP; ++jp)
+#pragma unroll
+          for (int k = 0; k < 2; ++k)
+            if (alive(2 * jp + k) && fabsf(ag2[jp][k] - kMinAlpha) <= kMinAlpha * kGuardTol) {
+              G2[jp][k] = gauss_ref_f64(r_mx, r_my, r_c0, r_c1, r_c2, r_c3, px, py2[jp][k]);
+              ag2[jp][k] = r_a * G2[jp][k];
+            }
+      }
+#pragma unroll
+      for (int jp = 0; jp < NP; ++jp)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const bool con = alive(2 * jp + k) && !(ag2[jp][k] < kMinAlpha);
+          G2[jp][k] = con ? G2[jp][k] : 0.0f;
+          ag2[jp][k] = con ? ag2[jp][k] : 0.0f;
+          any_con |= con;
+        }
+      if (__ballot(any_con) == 0ull) continue;  // nobody in the wave sees this Gaussian
+
+      v2f gr2[P / 2];
+#pragma unroll
+      for (int i = 0; i < P / 2; ++i) gr2[i] = v2f{0.0f, 0.0f};
+      const float *cg = &S.col[g * TR::NCOLP];
+      v2f w2[NP], inv1m2[NP], pAG2[NP];
+#pragma unroll
+      for (int jp = 0; jp < NP; ++jp) {
+        w2[jp] = (splat2(r_a) * Tr2[jp]) * G2[jp];  // the forward's (a T) G, or 0
+        const v2f om = splat2(1.0f) - ag2[jp];
+        inv1m2[jp] = v2f{__builtin_amdgcn_rcpf(om[0]), __builtin_amdgcn_rcpf(om[1])};
+        pAG2[jp] = v2f{0.0f, 0.0f};
+      }
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const float val = wave_uniform(cg[c]);
+        v2f gacc = v2f{0.0f, 0.0f};
+#pragma unroll
+        for (int jp = 0; jp < NP; ++jp) {
+          rem2[jp][c] = fma2(-w2[jp], splat2(val), rem2[jp][c]);        // suffix colour behind this splat
+          gacc = fma2(w2[jp], go2[jp][c], gacc);                        // d/d(channel value)
+          const v2f sfx = rem2[jp][c] * inv1m2[jp];
+          pAG2[jp] = fma2(go2[jp][c], fma2(splat2(val), Tr2[jp], -sfx), pAG2[jp]);
+        }
+        gr2[c >> 1][c & 1] = add_scalar(gacc[0], gacc[1]);
+      }
+      // mean2d (2) | cov2d (4) | alpha (1): kernel_gaussian_2d_backward (kernels.h:394-418), packed over the pair
+      const float inv_det = __builtin_amdgcn_rcpf(r_c0 * r_c3 - r_c1 * r_c2);
+      v2f gm0 = {0.f, 0.f}, gm1 = gm0, gc0 = gm0, gc1 = gm0, gc3 = gm0, gal = gm0;
+#pragma unroll
+      for (int jp = 0; jp < NP; ++jp) {
+        const v2f gg = pAG2[jp] * ag2[jp];
+        const v2f vx = (splat2(x * r_c3) - y2[jp] * splat2(r_c2)) * splat2(inv_det);
+        const v2f vy = (y2[jp] * splat2(r_c0) - splat2(x * r_c1)) * splat2(inv_det);
+        gm0 = fma2(gg, vx, gm0);
+        gm1 = fma2(gg, vy, gm1);
+        const v2f h = splat2(0.5f) * gg;
+        const v2f hvx = h * vx;
+        gc0 = fma2(hvx, vx, gc0);
+        gc1 = fma2(hvx, vy, gc1);
+        gc3 = fma2(h * vy, vy, gc3);
+        gal = fma2(pAG2[jp], G2[jp], gal);
+        Tr2[jp] = Tr2[jp] * ffma2(-ag2[jp], splat2(1.0f), splat2(1.0f));  // T (1 - a G) if it contributed (as the forward)
+      }
+      const float c1s = add_scalar(gc1[0], gc1[1]);
+      gr2[G0 / 2 + 0] = v2f{add_scalar(gm0[0], gm0[1]), add_scalar(gm1[0], gm1[1])};
+      gr2[G0 / 2 + 1] = v2f{add_scalar(gc0[0], gc0[1]), c1s};
+      gr2[G0 / 2 + 2] = v2f{c1s, add_scalar(gc3[0], gc3[1])};  // grad_cov[1] and [2] receive the same value (kernels.h:414-415)
+      gr2[G0 / 2 + 3] = v2f{add_scalar(gal[0], gal[1]), 0.0f};
+
+      wave_reduce_scatter2<P>(gr2);
+      const int comp = scatter_comp<P>(lane);
+      if (scatter_owner<P>(lane)) {
+        const size_t id = (size_t)S.id[g];
+        float *dst = nullptr;
+        if (comp < NCH) dst = p.g_col + (size_t)TR::NCOL * id + comp;
+        else if (comp >= G0 && comp < G0 + 2) dst = p.g_mean + 2 * id + (comp - G0);
+        else if (comp >= G0 + 2 && comp < G0 + 6) dst = p.g_cov + 4 * id + (comp - G0 - 2);
+        else if (comp == G0 + 6) dst = p.g_alpha + id;
+        if (dst != nullptr) atomicAdd(dst, gr2[0][0]);
+      }
+    }
+    bool any_alive = false;
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) any_alive |= alive(j);
+    if (__syncthreads_or((int)any_alive) == 0) break;
+  }
+}
+
+// ============================================================================================
 // backward, SH, matrix-core form
 // ============================================================================================
 // d L / d sh[g][c][b] = sum over the tile's pixels of gs[pixel][g,c] * Y[pixel][b]: a contraction
@@ -1478,6 +1652,7 @@ struct Variants {
   int ppl_fwd, ppl_bwd, mfma, ppl_fwd_batch, ppl_bwd_batch, ppl_bwd_sh_batch, mfma_batch, batch_map;
   int sh_packed;  // GSGEN_BWD_SH_PACKED: 1 (default) = k_composite_bwd_sh_vec, 0 = k_composite_bwd_pixel<MODE_SH> (A/B)
   int sh_chred;   // GSGEN_BWD_SH_CHRED: channel-wise gradient reduction in k_composite_bwd_sh_vec at 4 pixels per lane
+  int chan_packed;  // GSGEN_BWD_CHAN_PACKED: 1 (default) = k_composite_bwd_chan_vec for RGB / scalar / RGB + heads, 0 = k_composite_bwd_pixel
 };
 static int env_mfma(const char *name) {
   const char *v = getenv(name);
@@ -1492,7 +1667,8 @@ static Variants &variants() {
                              env_mfma("GSGEN_BWD_MFMA_BATCH"),
                              getenv("GSGEN_BATCH_MAP") ? atoi(getenv("GSGEN_BATCH_MAP")) : 2,
                              getenv("GSGEN_BWD_SH_PACKED") ? (atoi(getenv("GSGEN_BWD_SH_PACKED")) != 0) : 1,
-                             getenv("GSGEN_BWD_SH_CHRED") ? (atoi(getenv("GSGEN_BWD_SH_CHRED")) != 0) : 1};
+                             getenv("GSGEN_BWD_SH_CHRED") ? (atoi(getenv("GSGEN_BWD_SH_CHRED")) != 0) : 1,
+                             getenv("GSGEN_BWD_CHAN_PACKED") ? (atoi(getenv("GSGEN_BWD_CHAN_PACKED")) != 0) : 1};
   return v;
 }
 
@@ -1549,6 +1725,12 @@ static int launch_bwd(const CompParams &p_, hipStream_t s) {
     }
   }
   const uint32_t ng = nblk * (uint32_t)((MODE == MODE_SH && p.nseg > 1) ? p.nseg : 1);
+  if constexpr (MODE != MODE_SH) {
+    if (variants().chan_packed && ppl == 4) {  // default: packed per-pixel arithmetic, one wavefront per tile
+      hipLaunchKernelGGL((k_composite_bwd_chan_vec<MODE>), dim3(nblk), dim3(64), 0, s, p, (const CompParams *)nullptr);
+      return (int)hipGetLastError();
+    }
+  }
   if constexpr (MODE == MODE_SH) {
     if (variants().sh_packed && ppl != 1) {  // default SH backward: packed per-pixel arithmetic
       if (ppl == 2) hipLaunchKernelGGL((k_composite_bwd_sh_vec<CB, 2>), dim3(ng), dim3(128), 0, s, p, (const CompParams *)nullptr);
@@ -1665,6 +1847,11 @@ int launch_bwd_rgbd_batch(const CompParams &p0_, const CompParams *plist, uint32
   const CompParams p0 = batch_arg(p0_, B);
   // two wavefronts per tile: 6 087 / 3 588 views/s at 8 x 512^2 / 8 x 800^2 against 5 902 / 3 522 with one and
   // 5 753 / 3 138 with four (tools/bench_batch.py --heads)
+  // ... all of them measured on the unpacked kernel; the packed one (default) runs one wavefront per tile
+  if (variants().chan_packed) {
+    hipLaunchKernelGGL((k_composite_bwd_chan_vec<MODE_RGBD, true>), dim3(nblk * B), dim3(64), 0, s, p0, plist);
+    return (int)hipGetLastError();
+  }
   const int ppl = variants().ppl_bwd_batch;
   if (ppl == 1) hipLaunchKernelGGL((k_composite_bwd_pixel<MODE_RGBD, 1, 1, true>), dim3(nblk * B), dim3(256), 0, s, p0, plist);
   else if (ppl == 2) hipLaunchKernelGGL((k_composite_bwd_pixel<MODE_RGBD, 1, 2, true>), dim3(nblk * B), dim3(128), 0, s, p0, plist);
@@ -1684,6 +1871,10 @@ int launch_bwd_rgb_batch(const CompParams &p0_, const CompParams *plist, uint32_
   const uint32_t nblk = comp_grid(p0_);
   if (p0_.ntw * p0_.nth == 0 || B == 0) return 0;
   const CompParams p0 = batch_arg(p0_, B);
+  if (variants().chan_packed) {
+    hipLaunchKernelGGL((k_composite_bwd_chan_vec<MODE_RGB, true>), dim3(nblk * B), dim3(64), 0, s, p0, plist);
+    return (int)hipGetLastError();
+  }
   const int ppl = variants().ppl_bwd_batch;
   if (ppl == 4) hipLaunchKernelGGL((k_composite_bwd_pixel<MODE_RGB, 1, 4, true>), dim3(nblk * B), dim3(64), 0, s, p0, plist);
   else hipLaunchKernelGGL((k_composite_bwd_pixel<MODE_RGB, 1, 2, true>), dim3(nblk * B), dim3(128), 0, s, p0, plist);
@@ -1710,7 +1901,7 @@ extern "C" {
 
 /* Debugging hook (tools/stress, A/B measurements inside one process): overrides one entry of the variant table that
  * the environment initialised.  Not thread-safe against concurrent launches.  name: "ppl_fwd", "ppl_bwd", "mfma",
- * "ppl_fwd_batch", "ppl_bwd_batch", "ppl_bwd_sh_batch", "mfma_batch", "batch_map", "sh_packed", "sh_chred". */
+ * "ppl_fwd_batch", "ppl_bwd_batch", "ppl_bwd_sh_batch", "mfma_batch", "batch_map", "sh_packed", "sh_chred", "chan_packed". */
 int gsgen_debug_set_variant(const char *name, int value) {
   if (!name) return GSGEN_EINVAL;
   Variants &v = variants();
@@ -1728,6 +1919,7 @@ int gsgen_debug_set_variant(const char *name, int value) {
   else if (n == "batch_map") { slot = &v.batch_map; ok = value >= 0 && value <= 2; }
   else if (n == "sh_packed") { slot = &v.sh_packed; ok = value == 0 || value == 1; }
   else if (n == "sh_chred") { slot = &v.sh_chred; ok = value == 0 || value == 1; }
+  else if (n == "chan_packed") { slot = &v.chan_packed; ok = value == 0 || value == 1; }
   if (!slot || !ok) return GSGEN_EINVAL;
   *slot = value;
   return 0;
@@ -1757,9 +1949,11 @@ int gsgen_kernel_variant(const char *stage, uint32_t C, uint32_t n_segments, cha
   else if (st == "sh_bwd") n = sh_bwd(v.mfma, v.ppl_bwd, "");
   else if (st == "sh_bwd_batch") n = sh_bwd(v.mfma_batch, v.ppl_bwd_sh_batch, ",BATCH");
   else if (st == "rgb_fwd") n = snprintf(buf, sizeof buf, "k_composite_fwd<RGB,PPL=%d>", v.ppl_fwd);
-  else if (st == "rgb_bwd") n = snprintf(buf, sizeof buf, "k_composite_bwd_pixel<RGB,PPL=%d>", v.ppl_bwd);
+  else if (st == "rgb_bwd") n = (v.chan_packed && v.ppl_bwd == 4) ? snprintf(buf, sizeof buf, "k_composite_bwd_chan_vec<RGB>")
+                                                                   : snprintf(buf, sizeof buf, "k_composite_bwd_pixel<RGB,PPL=%d>", v.ppl_bwd);
   else if (st == "rgbd_fwd_batch") n = snprintf(buf, sizeof buf, "k_composite_fwd<RGBD,PPL=%d,BATCH>", v.ppl_fwd_batch);
-  else if (st == "rgbd_bwd_batch") n = snprintf(buf, sizeof buf, "k_composite_bwd_pixel<RGBD,PPL=%d,BATCH>", v.ppl_bwd_batch);
+  else if (st == "rgbd_bwd_batch") n = v.chan_packed ? snprintf(buf, sizeof buf, "k_composite_bwd_chan_vec<RGBD,BATCH>")
+                                                     : snprintf(buf, sizeof buf, "k_composite_bwd_pixel<RGBD,PPL=%d,BATCH>", v.ppl_bwd_batch);
   else return 0;
   if (n < 0) return 0;
   if ((size_t)n >= out_bytes) n = (int)out_bytes - 1;

@@ -882,6 +882,9 @@ def test_no_kernel_spills_and_hot_kernels_keep_their_occupancy(tmp_path):
         assert bwd["vgpr_count"] <= 168 and 12 * bwd["group_segment_fixed_size"] <= 160 * 1024, bwd
     for bwd in find(2, "k_composite_bwd_sh_vecILi4ELi4ELb", "ELb0EE"):  # the 64-component reduction, A/B only
         assert bwd["vgpr_count"] <= 256 and 8 * bwd["group_segment_fixed_size"] <= 160 * 1024
+    # packed backward of the post-activation modes (RGB + heads is the trainer's default): 4 wavefronts per SIMD
+    for bwd in find(2, "k_composite_bwd_chan_vecILi3E"):
+        assert bwd["vgpr_count"] <= 128, bwd
     for bwd in find(2, "k_composite_bwd_sh_vecILi4ELi2E"):
         assert bwd["vgpr_count"] <= 168
     for bwd in find(2, "k_composite_bwd_pixelILi2ELi4ELi4E", "ELi16EE"):

@@ -15,6 +15,7 @@ VARIANTS = [
     {"GSGEN_PPL_FWD": "4", "GSGEN_PPL_BWD": "2"},
     {"GSGEN_PPL_FWD": "2", "GSGEN_PPL_BWD": "1"},
     {"GSGEN_BWD_SH_CHRED": "0"},  # packed SH backward with ONE 64-component gradient reduction (2 wavefronts per SIMD)
+    {"GSGEN_BWD_CHAN_PACKED": "0"},  # RGB / scalar / RGB + heads backward on the unpacked k_composite_bwd_pixel
 ]
 # The matrix-core SH backward is OPT-IN (GSGEN_BWD_MFMA = 4 | 2 | 1 pixels per lane; default 0 = vector ALUs): its
 # MFMA chain has shown box- and timing-dependent corruption on hardware that is not root-caused.
@@ -54,6 +55,7 @@ BATCH_VARIANTS = [
     {"GSGEN_PPL_BWD_SH_BATCH": "2", "GSGEN_PPL_BWD_BATCH": "4"},  # SH backward 2 wavefronts per tile, heads 1
     {"GSGEN_PPL_BWD_SH_BATCH": "1", "GSGEN_PPL_BWD_BATCH": "1", "GSGEN_PPL_FWD_BATCH": "4", "GSGEN_PPL_FWD": "4"},
     {"GSGEN_BWD_SH_CHRED": "0"},
+    {"GSGEN_BWD_CHAN_PACKED": "0"},
 ]
 MFMA_BATCH_VARIANTS = [
     {"GSGEN_BWD_MFMA_BATCH": "2"},
