@@ -296,7 +296,7 @@ __global__ void __launch_bounds__(TS * TS / PPL) k_composite_fwd(CompParams p_ar
             const float ag = r.a * G[j];
             const float coeff = (r.a * Tr[j]) * G[j];
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) acc[j][c] += cg[c] * coeff;
+            for (int c = 0; c < NCH; ++c) acc[j][c] = ffma(cg[c], coeff, acc[j][c]);  // explicit: as k_composite_fwd_chan_vec
             Tr[j] *= ffma(-ag, 1.0f, 1.0f);  // 1 - round(a G), never a fused -a*G + 1 (see the SH branch)
             alive[j] = !(Tr[j] < p.thresh);
           }
@@ -1086,6 +1086,121 @@ k_composite_bwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
 }
 
 // ============================================================================================
+// forward, post-activation channels, packed per-pixel arithmetic (batched RGB + heads)
+// ============================================================================================
+// k_composite_fwd<MODE_RGBD> at 2 pixels per lane issues ~100 vector instructions per (wavefront, list entry), two
+// wavefronts per tile; with the lane's 4 pixels as two packed pairs, one wavefront per tile, the record in scalar
+// registers and one wave-uniform guard branch it is ~70 per tile and entry.  Same structure as k_composite_fwd_sh_vec.
+template <int MODE, bool BATCH = false>
+__global__ void __launch_bounds__(64)
+k_composite_fwd_chan_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
+  static_assert(MODE == MODE_RGB || MODE == MODE_SCALAR || MODE == MODE_RGBD, "post-activation channel modes");
+  uint32_t bid = blockIdx.x;
+  const CompParams p = BATCH ? plist[batch_view(p_arg, bid)] : p_arg;
+  using TR = Traits<MODE, 1>;
+  constexpr int PPL = 4, NT = 64, ROWS = NT / 16, NP = PPL / 2;
+  constexpr int NCH = TR::NCH;
+  __shared__ Stage<MODE, 1> S;
+
+  int tx, ty;
+  if (!block_tile(p, tx, ty, bid)) return;  // uniform over the workgroup
+  const int tile = ty * p.ntw + tx;
+  const int st = p.start[tile];
+  const int n = (st < 0) ? 0 : (p.end[tile] - st);
+  if (n == 0) return;  // the caller's pre-initialised out / T stand (vol_render.h:1006-1013)
+  const int t = (int)threadIdx.x;
+  const int lx = t & 15, ly0 = t >> 4;
+  const int gx = tx * kTile + lx;
+  const float px = pixel_coord(p.topleft[0], gx, p.psx);
+
+  bool valid[PPL];
+  int gy[PPL];
+  v2f py2[NP], acc2[NP][NCH], Tr2[NP];
+#pragma unroll
+  for (int j = 0; j < PPL; ++j) {
+    gy[j] = ty * kTile + ly0 + j * ROWS;
+    valid[j] = (gx < p.W) && (gy[j] < p.H);
+    py2[j >> 1][j & 1] = pixel_coord(p.topleft[1], gy[j], p.psy);
+    Tr2[j >> 1][j & 1] = valid[j] ? 1.0f : -1.0f;  // alive = (T >= thresh); pixels outside never are, never written
+  }
+#pragma unroll
+  for (int jp = 0; jp < NP; ++jp)
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) acc2[jp][c] = v2f{0.0f, 0.0f};
+  auto alive = [&](int j) { return !(Tr2[j >> 1][j & 1] < p.thresh); };
+
+  for (int base = 0; base < n; base += kBatch) {
+    const int nb = min(kBatch, n - base);
+    if (base > 0) __syncthreads();
+    stage_batch<MODE, 1, NT>(S, p, st + base, nb);
+    __syncthreads();
+
+    for (int g = 0; g < nb; ++g) {
+      bool any_alive = false;
+#pragma unroll
+      for (int j = 0; j < PPL; ++j) any_alive |= alive(j);
+      if (__ballot(any_alive) == 0ull) break;  // the tile's 256 pixels are saturated
+
+      const float r_mx = wave_uniform(S.mx[g]), r_my = wave_uniform(S.my[g]), r_a = wave_uniform(S.a[g]),
+                  r_p0 = wave_uniform(S.p0[g]), r_p1 = wave_uniform(S.p1[g]), r_p2 = wave_uniform(S.p2[g]);
+      const float p0x = r_p0 * (px - r_mx);
+      v2f G2[NP], ag2[NP];
+      bool any_con = false, any_guard = false;
+#pragma unroll
+      for (int jp = 0; jp < NP; ++jp) {
+        G2[jp] = gauss_chol_pair(p0x, r_p1, r_p2, py2[jp] - splat2(r_my));
+        ag2[jp] = splat2(r_a) * G2[jp];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) any_guard |= alive(2 * jp + k) && fabsf(ag2[jp][k] - kMinAlpha) <= kMinAlpha * kGuardTol;
+      }
+      if (__ballot(any_guard) != 0ull) {  // within rounding of the skip threshold: the reference's arithmetic decides
+        const float r_c0 = S.c0[g], r_c1 = S.c1[g], r_c2 = S.c2[g], r_c3 = S.c3[g];
+#pragma unroll
+        for (int jp = 0; jp < NP; ++jp)
+#pragma unroll
+          for (int k = 0; k < 2; ++k)
+            if (alive(2 * jp + k) && fabsf(ag2[jp][k] - kMinAlpha) <= kMinAlpha * kGuardTol) {
+              G2[jp][k] = gauss_ref_f64(r_mx, r_my, r_c0, r_c1, r_c2, r_c3, px, py2[jp][k]);
+              ag2[jp][k] = r_a * G2[jp][k];
+            }
+      }
+#pragma unroll
+      for (int jp = 0; jp < NP; ++jp)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const bool con = alive(2 * jp + k) && !(ag2[jp][k] < kMinAlpha);
+          G2[jp][k] = con ? G2[jp][k] : 0.0f;
+          ag2[jp][k] = con ? ag2[jp][k] : 0.0f;
+          any_con |= con;
+        }
+      if (__ballot(any_con) == 0ull) continue;  // nobody in the wave sees this Gaussian
+
+      const float *cg = &S.col[g * TR::NCOLP];
+#pragma unroll
+      for (int jp = 0; jp < NP; ++jp) {
+        const v2f w2 = (splat2(r_a) * Tr2[jp]) * G2[jp];  // (a T) G, or 0
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) acc2[jp][c] = ffma2(splat2(wave_uniform(cg[c])), w2, acc2[jp][c]);
+        Tr2[jp] = Tr2[jp] * ffma2(-ag2[jp], splat2(1.0f), splat2(1.0f));  // T (1 - a G) if it contributed (explicit)
+      }
+    }
+    bool any_alive = false;
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) any_alive |= alive(j);
+    if (__syncthreads_or((int)any_alive) == 0) break;  // whole tile saturated: stop staging
+  }
+
+#pragma unroll
+  for (int j = 0; j < PPL; ++j) {
+    if (!valid[j]) continue;
+    const size_t pix = (size_t)gy[j] * p.W + gx;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) p.out[NCH * pix + c] = acc2[j >> 1][c][j & 1];
+    if (p.T != nullptr) p.T[pix] = Tr2[j >> 1][j & 1];
+  }
+}
+
+// ============================================================================================
 // backward, post-activation channels (RGB, scalar, RGB + heads), packed per-pixel arithmetic
 // ============================================================================================
 // The trainer's default outputs (gs/gaussian_splatting.py:1304-1416: rgb + depth + opacity + depth^2 from
@@ -1162,10 +1277,7 @@ k_composite_bwd_chan_vec(CompParams p_arg, const CompParams *__restrict__ plist)
 #pragma unroll
       for (int jp = 0; jp < NP; ++jp) {
         y2[jp] = py2[jp] - splat2(r_my);
-        const v2f u = fma2(splat2(r_p1), y2[jp], splat2(p0x));
-        const v2f v = splat2(r_p2) * y2[jp];
-        const v2f e = -(u * u + v * v);
-        G2[jp] = v2f{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+        G2[jp] = gauss_chol_pair(p0x, r_p1, r_p2, y2[jp]);
         ag2[jp] = splat2(r_a) * G2[jp];
 #pragma unroll
         for (int k = 0; k < 2; ++k) any_guard |= alive(2 * jp + k) && fabsf(ag2[jp][k] - kMinAlpha) <= kMinAlpha * kGuardTol;
@@ -1835,6 +1947,10 @@ int launch_fwd_rgbd_batch(const CompParams &p0_, const CompParams *plist, uint32
   const uint32_t nblk = comp_grid(p0_);
   if (p0_.ntw * p0_.nth == 0 || B == 0) return 0;
   const CompParams p0 = batch_arg(p0_, B);
+  if (variants().chan_packed) {  // default: packed per-pixel arithmetic, one wavefront per tile
+    hipLaunchKernelGGL((k_composite_fwd_chan_vec<MODE_RGBD, true>), dim3(nblk * B), dim3(64), 0, s, p0, plist);
+    return (int)hipGetLastError();
+  }
   const int ppl = variants().ppl_fwd_batch;
   if (ppl == 1) hipLaunchKernelGGL((k_composite_fwd<MODE_RGBD, 1, 1, true>), dim3(nblk * B), dim3(256), 0, s, p0, plist);
   else if (ppl == 2) hipLaunchKernelGGL((k_composite_fwd<MODE_RGBD, 1, 2, true>), dim3(nblk * B), dim3(128), 0, s, p0, plist);
@@ -1951,7 +2067,8 @@ int gsgen_kernel_variant(const char *stage, uint32_t C, uint32_t n_segments, cha
   else if (st == "rgb_fwd") n = snprintf(buf, sizeof buf, "k_composite_fwd<RGB,PPL=%d>", v.ppl_fwd);
   else if (st == "rgb_bwd") n = (v.chan_packed && v.ppl_bwd == 4) ? snprintf(buf, sizeof buf, "k_composite_bwd_chan_vec<RGB>")
                                                                    : snprintf(buf, sizeof buf, "k_composite_bwd_pixel<RGB,PPL=%d>", v.ppl_bwd);
-  else if (st == "rgbd_fwd_batch") n = snprintf(buf, sizeof buf, "k_composite_fwd<RGBD,PPL=%d,BATCH>", v.ppl_fwd_batch);
+  else if (st == "rgbd_fwd_batch") n = v.chan_packed ? snprintf(buf, sizeof buf, "k_composite_fwd_chan_vec<RGBD,BATCH>")
+                                                     : snprintf(buf, sizeof buf, "k_composite_fwd<RGBD,PPL=%d,BATCH>", v.ppl_fwd_batch);
   else if (st == "rgbd_bwd_batch") n = v.chan_packed ? snprintf(buf, sizeof buf, "k_composite_bwd_chan_vec<RGBD,BATCH>")
                                                      : snprintf(buf, sizeof buf, "k_composite_bwd_pixel<RGBD,PPL=%d,BATCH>", v.ppl_bwd_batch);
   else return 0;

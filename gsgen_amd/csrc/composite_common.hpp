@@ -234,9 +234,14 @@ __device__ __forceinline__ float gauss_eval(const GRec &r, float x, float y, flo
     G = __builtin_amdgcn_exp2f(e);
     G = (q < 0.0f) ? 0.0f : G;  // kernels.h:186-188: radial < 0 -> exp(-500) == 0
   } else {
-    const float u = r.p0 * x + r.p1 * y;
+    // one fixed operation sequence here too (shared with gauss_chol_pair): a camera renders to the same bits through
+    // the per-camera kernels and the packed batched ones
+#pragma clang fp contract(off)
+    const float p0x = r.p0 * x;
+    const float u = ffma(r.p1, y, p0x);
     const float v = r.p2 * y;
-    G = __builtin_amdgcn_exp2f(-(u * u + v * v));
+    const float vv = v * v;
+    G = __builtin_amdgcn_exp2f(-ffma(u, u, vv));
   }
   const float ag = r.a * G;
   // within rounding of the skip threshold: take the reference's arithmetic.  The wave-uniform test in front keeps the
@@ -269,6 +274,17 @@ __device__ __forceinline__ v2f gauss_sh_pair(float c0, float c1, float c2, float
   G[0] = (q2[0] < 0.0f) ? 0.0f : G[0];
   G[1] = (q2[1] < 0.0f) ? 0.0f : G[1];
   return G;
+}
+
+// The Cholesky-form Gaussian (RGB / scalar / RGB + heads) of the two pixels (x, y2[0]), (x, y2[1]) of one lane: the
+// operation sequence of gauss_eval's non-SH branch element for element, without the threshold guard.  p0x = p0 * x.
+__device__ __forceinline__ v2f gauss_chol_pair(float p0x, float p1, float p2, v2f y2) {
+#pragma clang fp contract(off)
+  const v2f u = ffma2(splat2(p1), y2, splat2(p0x));
+  const v2f v = splat2(p2) * y2;
+  const v2f vv = v * v;
+  const v2f e = -ffma2(u, u, vv);
+  return v2f{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
 }
 
 static inline int env_ppl(const char *name, int dflt) {
