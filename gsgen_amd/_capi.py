@@ -28,7 +28,8 @@ class RgbdView(C.Structure):
     """gsgen_rgbd_view (include/gsgen_hip.h): one camera of a batched RGB + heads launch."""
     _fields_ = [("mean", vp), ("cov", vp), ("depth", vp), ("start", vp), ("end", vp), ("gaussian_ids", vp),
                 ("tile_order", vp), ("topleft", vp), ("pixel_size_x", f32), ("pixel_size_y", f32), ("out6", vp),
-                ("T", vp), ("grad_out6", vp), ("grad_mean", vp), ("grad_cov", vp), ("grad_chan6", vp)]
+                ("T", vp), ("grad_out6", vp), ("grad_mean", vp), ("grad_cov", vp), ("grad_chan6", vp),
+                ("grad_rgb", vp), ("grad_depth", vp), ("grad_opacity", vp), ("grad_depth2", vp)]
 
 
 class GeometryView(C.Structure):

@@ -305,22 +305,32 @@ class _render_batch_heads(torch.autograd.Function):
         br, B, thresh, stats = ctx.br, ctx.B, ctx.thresh, ctx.stats
         lib = _capi.load()
         H, W, N, dev = br.H, br.W, br.N, mean.device
-        z = lambda g, c: g if g is not None else torch.zeros(B, H, W, c, device=dev)  # noqa: E731
-        go6 = torch.cat([z(g_rgb, 3), z(g_depth, 1), z(g_opac, 1), z(g_z2, 1)], dim=-1).contiguous()
+        # the four head gradients as autograd hands them over; the batched launch reads them in place (no [B,H,W,6]
+        # image is assembled: that concatenation was 8 % of a step at 8 x 800^2), the per-camera chains want one image
+        parts = [g.contiguous() if g is not None else None for g in (g_rgb, g_depth, g_opac, g_z2)]
+        go6 = None
+        if ctx.views is None:
+            z = lambda g, c: g if g is not None else torch.zeros(B, H, W, c, device=dev)  # noqa: E731
+            go6 = torch.cat([z(parts[0], 3), z(parts[1], 1), z(parts[2], 1), z(parts[3], 1)], dim=-1).contiguous()
         g2d = torch.zeros(B, 6 * N, device=dev, dtype=torch.float32)   # per camera: mean2d | cov2d
         gch = torch.zeros(B, N, 6, device=dev, dtype=torch.float32)    # per camera: rgb | depth | opacity | depth^2
         gdp = torch.empty(B, N, device=dev, dtype=torch.float32)       # per camera: d L / d (view-space depth)
         g3d = torch.zeros(11 * N, device=dev, dtype=torch.float32)     # shared: mean | qvec | svec | alpha
         g_mean, g_qvec = g3d[:3 * N].view(N, 3), g3d[3 * N:7 * N].view(N, 4)
         g_svec, g_alpha = g3d[7 * N:10 * N].view(N, 3), g3d[10 * N:]
-        cams_p, out_p, go_p, g2d_p = cams.data_ptr(), out6.data_ptr(), go6.data_ptr(), g2d.data_ptr()
+        cams_p, out_p, g2d_p = cams.data_ptr(), out6.data_ptr(), g2d.data_ptr()
+        go_p = go6.data_ptr() if go6 is not None else 0
         if ctx.views is not None:
             import ctypes
             s = torch.cuda.current_stream(dev).cuda_stream
             gch_p = gch.data_ptr()
             for i in range(B):
                 v = ctx.views[i]
-                v.grad_out6 = go_p + 24 * H * W * i
+                v.grad_out6 = None
+                v.grad_rgb = parts[0].data_ptr() + 12 * H * W * i if parts[0] is not None else None
+                v.grad_depth = parts[1].data_ptr() + 4 * H * W * i if parts[1] is not None else None
+                v.grad_opacity = parts[2].data_ptr() + 4 * H * W * i if parts[2] is not None else None
+                v.grad_depth2 = parts[3].data_ptr() + 4 * H * W * i if parts[3] is not None else None
                 v.grad_mean, v.grad_cov = g2d_p + 24 * N * i, g2d_p + 24 * N * i + 8 * N
                 v.grad_chan6 = gch_p + 24 * N * i
             tab = lambda vals: (ctypes.c_void_p * B)(*vals)  # noqa: E731

@@ -627,7 +627,7 @@ k_composite_bwd_pixel(CompParams p_arg, const CompParams *__restrict__ plist) {
     const float pre0[3] = {ck.y, ck.z, ck.w};
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-      go[j][c] = valid[j] ? p.grad_out[NCH * pix + c] : 0.0f;
+      go[j][c] = valid[j] ? load_grad_out<MODE, NCH>(p, pix, c) : 0.0f;
       fin[j][c] = valid[j] ? p.final_img[NCH * pix + c] : 0.0f;
       pre[j][c] = (MODE == MODE_SH) ? pre0[c < 3 ? c : 0] : 0.0f;
     }
@@ -1246,7 +1246,7 @@ k_composite_bwd_chan_vec(CompParams p_arg, const CompParams *__restrict__ plist)
     const size_t pix = valid ? ((size_t)gy * p.W + gx) : 0;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-      go2[j >> 1][c][j & 1] = valid ? p.grad_out[NCH * pix + c] : 0.0f;
+      go2[j >> 1][c][j & 1] = valid ? load_grad_out<MODE, NCH>(p, pix, c) : 0.0f;
       rem2[j >> 1][c][j & 1] = valid ? p.final_img[NCH * pix + c] : 0.0f;  // final - prefix, prefix = 0
     }
     Tr2[j >> 1][j & 1] = valid ? 1.0f : -1.0f;  // alive = (T >= thresh); pixels outside never are
@@ -2271,7 +2271,8 @@ static int fill_rgbd_params(uint32_t n_views, const gsgen_rgbd_view *views, cons
     const gsgen_rgbd_view &v = views[b];
     if (!v.start || !v.end || !v.out6 || (heads && !v.depth)) return GSGEN_EINVAL;
     if ((v.tile_order == nullptr) != (views[0].tile_order == nullptr)) return GSGEN_EINVAL;
-    if (backward && (!v.grad_out6 || !v.grad_mean || !v.grad_cov || (heads && !v.grad_chan6))) return GSGEN_EINVAL;
+    if (backward && (!v.grad_mean || !v.grad_cov || (heads && !v.grad_chan6))) return GSGEN_EINVAL;
+    if (backward && !v.grad_out6 && !heads) return GSGEN_EINVAL;  // the split form exists for the heads only
     CompParams &p = ps[b];
     p.mean = v.mean; p.cov = v.cov; p.col = color; p.depth = v.depth; p.alpha = alpha;
     p.start = v.start; p.end = v.end; p.ids = v.gaussian_ids; p.topleft = v.topleft;
@@ -2281,6 +2282,9 @@ static int fill_rgbd_params(uint32_t n_views, const gsgen_rgbd_view *views, cons
     p.n_hi = 0x7fffffff;
     if (backward) {
       p.final_img = v.out6; p.grad_out = v.grad_out6;
+      if (heads && v.grad_out6 == nullptr) {
+        p.go_rgb = v.grad_rgb; p.go_d = v.grad_depth; p.go_o = v.grad_opacity; p.go_z2 = v.grad_depth2;
+      }
       p.g_mean = v.grad_mean; p.g_cov = v.grad_cov; p.g_col = heads ? v.grad_chan6 : g_color; p.g_alpha = g_alpha;
     } else {
       p.out = v.out6; p.T = v.T;

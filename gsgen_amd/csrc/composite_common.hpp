@@ -33,6 +33,8 @@ struct CompParams {
   int *stop;     // [tile][256]: first list index the pixel did not process (n if it never saturated)
   int nseg;
   int tile_side;  // host side only (kernel selection): 0 / 16 = this library's tiles; 8, 32: see k_composite_fwd
+  // MODE_RGBD backward with grad_out == NULL: the four head gradients as autograd delivers them (any may be NULL = 0)
+  const float *go_rgb, *go_d, *go_o, *go_z2;  // [H,W,3], [H,W], [H,W], [H,W]
 };
 constexpr int kSegLen = 32;
 
@@ -156,6 +158,19 @@ struct Traits {
   static constexpr int NPAIR = CCP / 2;
 };
 
+
+// d L / d out[pix][c]: one [H,W,NCH] image, or (RGB + heads only, grad_out == NULL) the four images of the heads
+template <int MODE, int NCH>
+__device__ __forceinline__ float load_grad_out(const CompParams &p, size_t pix, int c) {
+  if constexpr (MODE == MODE_RGBD) {
+    if (p.grad_out == nullptr) {  // uniform over the launch
+      if (c < 3) return p.go_rgb != nullptr ? p.go_rgb[3 * pix + c] : 0.0f;
+      const float *q = (c == 3) ? p.go_d : (c == 4 ? p.go_o : p.go_z2);
+      return q != nullptr ? q[pix] : 0.0f;
+    }
+  }
+  return p.grad_out[NCH * pix + c];
+}
 
 // the NCOL per-Gaussian channel values of the non-SH modes
 template <int MODE, int NCOL>

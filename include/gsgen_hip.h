@@ -400,8 +400,11 @@ typedef struct gsgen_rgbd_view {
   const float *topleft;                    /* [2] */
   float pixel_size_x, pixel_size_y;
   float *out6, *T;                         /* [H,W,6], [H,W]; out6 is read by the backward */
-  const float *grad_out6;                  /* backward: [H,W,6] */
+  const float *grad_out6;                  /* backward: [H,W,6]; or NULL (heads only): the four images below */
   float *grad_mean, *grad_cov, *grad_chan6; /* backward: [N,2], [N,2,2], [N,6] of this view, accumulated into */
+  /* backward of the heads with grad_out6 == NULL: d L / d rgb [H,W,3], / d depth, / d opacity, / d depth^2 [H,W] as an
+   * autograd engine delivers them (one tensor per output; any may be NULL = zero) -- no [H,W,6] image to assemble */
+  const float *grad_rgb, *grad_depth, *grad_opacity, *grad_depth2;
 } gsgen_rgbd_view;
 int gsgen_vol_render_rgbd_batch(uint32_t n_views, const gsgen_rgbd_view *views, uint32_t N, const float *color,
                                 const float *alpha, uint32_t tile_size, uint32_t n_tiles_h, uint32_t n_tiles_w,

@@ -464,6 +464,29 @@ def test_emulated_batched_rgb_heads_match_per_view_launches(emu):
         for k in ("gm", "gc", "gch"):
             assert np.abs(v[k] - v[k + "_ref"]).max() <= 2e-6 * np.abs(v[k + "_ref"]).max(), k
     assert np.abs(ga - ref_ga).max() <= 2e-6 * np.abs(ref_ga).max() and np.abs(ref_ga).max() > 0
+    # the same backward with the head gradients as four images (what an autograd engine delivers): identical results;
+    # a missing image is a zero gradient
+    keep = {id(v): {k: v[k].copy() for k in ("gm", "gc", "gch")} for v in views}
+    ga_keep = ga.copy()
+    for a, v in zip(arr, views):
+        v["go_parts"] = [np.ascontiguousarray(v["go"][..., :3]), np.ascontiguousarray(v["go"][..., 3]),
+                         np.ascontiguousarray(v["go"][..., 4]), np.ascontiguousarray(v["go"][..., 5])]
+        for k in ("gm", "gc", "gch"):
+            v[k][:] = 0
+        a.grad_out6 = None
+        a.grad_rgb, a.grad_depth, a.grad_opacity, a.grad_depth2 = (P(x) for x in v["go_parts"])
+    ga[:] = 0
+    emu.vol_render_rgbd_backward_batch(len(views), arr, Nall, P(col), P(al), P(ga), 16, nth, ntw, H, W, 1e-4, P(bws), None)
+    for v in views:
+        for k in ("gm", "gc", "gch"):
+            assert np.array_equal(v[k], keep[id(v)][k]), k
+    assert np.array_equal(ga, ga_keep)
+    for a, v in zip(arr, views):  # depth^2 head without a gradient
+        a.grad_depth2 = None
+        v["gch"][:] = 0
+    emu.vol_render_rgbd_backward_batch(len(views), arr, Nall, P(col), P(al), P(ga), 16, nth, ntw, H, W, 1e-4, P(bws), None)
+    for v in views:
+        assert not v["gch"][:, 5].any() and np.abs(v["gch"][:, :5]).max() > 0
     arr[2].depth = None
     with pytest.raises(Exception, match="invalid"):
         emu.vol_render_rgbd_batch(len(views), arr, Nall, P(col), P(al), 16, nth, ntw, H, W, 1e-4, P(bws), None)
