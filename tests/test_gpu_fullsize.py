@@ -155,3 +155,73 @@ def test_full_size_cfg4_64_random_poses_batched():
                 want[k] += gr[k]
     assert worst <= 4
     check_grads(P, want, anisotropic=False)
+
+
+def test_full_size_rgb_heads_batched():
+    """The trainer's default outputs at the headline size: rgb + depth + opacity + depth^2 of a 100k-Gaussian cloud at
+    800x800, two cameras through BatchRenderer.render_heads (packed kernels k_composite_{fwd,bwd}_chan_vec, head
+    gradients read in place), against four oracle passes per camera: every pixel of every head, every gradient
+    (mean, qvec, svec, alpha, colour) including the depth heads' path through the projection."""
+    from gsgen_amd import renderer as R
+    from gsgen_amd.batch import BatchRenderer
+    sc = scenes.pointe_scene(100_000, seed=0, C=1)
+    rng = np.random.default_rng(3)
+    sc["svec"] = (sc["svec"] * np.exp(rng.normal(0, 0.3, sc["svec"].shape))).astype(np.float32)  # anisotropic: d/d qvec lives
+    N = sc["mean"].shape[0]
+    W = H = 800
+    cams = [scenes.Camera(W, H, fx=800.0, c2w=scenes.orbit(2.5, 15, 30)), scenes.Camera(W, H, fx=640.0, c2w=scenes.orbit(2.2, 40, -75))]
+    cis = [R.CameraInfo(*c.intr) for c in cams]
+    keys = ("mean", "qvec", "svec", "alpha", "color")
+    P = {k: T_(sc[k]).requires_grad_(True) for k in keys}
+    br = BatchRenderer(N, W, H, dev(), max_batch=2)
+    for _ in range(2):
+        rgb, dimg, opac, z2, T = br.render_heads(P["mean"], P["qvec"], P["svec"], P["alpha"], P["color"], cis,
+                                                 [c.c2w for c in cams], detach_depth=False)
+        if br.ensure_capacity(2):
+            break
+    gen = torch.Generator(device=dev()).manual_seed(9)
+    go = [torch.randn(2, H, W, c, device=dev(), generator=gen) for c in (3, 1, 1, 1)]
+    ((rgb * go[0]).sum() + (dimg * go[1]).sum() + (opac * go[2]).sum() + (z2 * go[3]).sum()).backward()
+    want = {k: np.zeros(sc[k].shape, np.float64) for k in keys}
+    for i, cam in enumerate(cams):
+        g = scenes.oracle_geometry(sc, cam)
+        m = g["mask"]
+        a = (g["mean2d"], g["cov2d"])
+        al, col, dv = sc["alpha"][m], sc["color"][m], g["depth"].ravel()
+        geo = (g["start"], g["end"], g["ids"], cam.topleft, 1 / cam.fx, 1 / cam.fy, H, W)
+        o_rgb, o_T = O.render_rgb_fwd(*a, col, al, *geo)
+        heads = [(dv, dimg), (np.ones_like(dv), opac), (dv * dv, z2)]
+        T_gpu, T_or = T[i, ..., 0].cpu().numpy(), o_T.reshape(H, W)
+
+        def check_image(got, ref, scale, what):
+            """every pixel within 1e-4 * scale -- except, named, a pixel whose transmittance came within rounding of
+            the stop threshold (T < 1e-4, tested before each splat) so that one side processed one splat more: that splat
+            weighs less than 1e-4 of its value"""
+            err = np.abs(got - ref)
+            err = err.max(-1) if err.ndim == 3 else err
+            bad = np.argwhere(err > 1e-4 * scale)
+            for y, x in bad:
+                t_hi = max(T_gpu[y, x], T_or[y, x])
+                assert 0.999e-4 <= t_hi < 1.0001e-4, (what, i, y, x, err[y, x], T_gpu[y, x], T_or[y, x])
+                assert err[y, x] <= 1.05e-4 * scale + 1e-4, (what, i, y, x, err[y, x])
+            assert len(bad) <= 2, (what, i, len(bad))
+        check_image(rgb[i].detach().cpu().numpy(), o_rgb, 1.0, "rgb")
+        assert np.abs(T_gpu - T_or).max() <= 1.0001e-4
+        gi = [x[i].cpu().numpy() for x in go]
+        r = O.render_rgb_bwd(*a, col, al, g["start"], g["end"], g["ids"], o_rgb, gi[0], cam.topleft, 1 / cam.fx, 1 / cam.fy, H, W)
+        gm2, gc2, galpha = r[0].astype(np.float64), r[1].astype(np.float64), r[3].astype(np.float64)
+        gval = []
+        for (val, img), gh in zip(heads, gi[1:]):
+            o_s, _ = O.render_scalar_fwd(*a, val, al, *geo)
+            check_image(img[i, ..., 0].detach().cpu().numpy(), o_s, max(1.0, float(np.abs(val).max())), "head")
+            s_ = O.render_scalar_bwd(*a, val, al, g["start"], g["end"], g["ids"], o_s, np.ascontiguousarray(gh[..., 0]),
+                                     cam.topleft, 1 / cam.fx, 1 / cam.fy, H, W)
+            gm2 += s_[0]; gc2 += s_[1]; galpha += s_[3]
+            gval.append(s_[2])
+        gdepth = gval[0] + 2.0 * dv * gval[2]
+        om, oq, os_ = O.project_bwd(sc["mean"][m], sc["qvec"][m], sc["svec"][m], cam.c2w, gm2.astype(np.float32),
+                                    gc2.astype(np.float32), gdepth.astype(np.float32), False)
+        want["mean"][m] += om; want["qvec"][m] += oq; want["svec"][m] += os_
+        want["alpha"][m] += galpha; want["color"][m] += r[2]
+    for k in keys:
+        assert rel_err(P[k].grad.cpu().numpy(), want[k]) < 1e-3, (k, rel_err(P[k].grad.cpu().numpy(), want[k]))
