@@ -62,6 +62,7 @@ SIGNATURES = {
                                                C.POINTER(vp), C.POINTER(vp), vp, vp, vp, vp],
     "gsgen_pack_camera": [vp, f32, f32, f32, f32, u32, u32, C.c_double, C.c_double, f32, f32, vp],
     "gsgen_upload_small": [vp, vp, sz, vp],
+    "gsgen_pack_camera_blocks": [u32, vp, u32, vp, f32, f32, vp],
     "gsgen_adam_step": [C.c_uint64, vp, vp, vp, vp, u32, vp, vp, f32, f32, f32, u32, vp],
     "gsgen_densify_update_batch": [u32, u32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp, vp, vp, vp],
     "gsgen_densify_update": [u32, vp, vp, vp, vp, vp, vp, vp],

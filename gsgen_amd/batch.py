@@ -118,7 +118,7 @@ class _render_batch(torch.autograd.Function):
             br._end_batch(B)
             if stats is not None:
                 lib.densify_update_batch(B, N, _tab([_p(br.slots[i].cov2d) for i in range(B)]), None,
-                                         _tab([_p(br.slots[i].mask) for i in range(B)]), _p(stats.max_radii2d), None,
+                                         br._mask_table(B), _p(stats.max_radii2d), None,
                                          None, s)
             if C > 0:
                 lib.vol_render_sh_batch(B, views, N, _p(col), _p(alpha), 16, br.slots[0].nth, br.slots[0].ntw, H, W, C,
@@ -171,13 +171,13 @@ class _render_batch(torch.autograd.Function):
                 lib.vol_render_rgb_backward_batch(B, ctx.views, N, _p(col), _p(alpha), _p(g_col), _p(g_alpha), 16,
                                                   br.slots[0].nth, br.slots[0].ntw, H, W, thresh, _p(ctx.bws), s)
             lib.project_gaussians_backward_batch(B, N, _p(mean), _p(qvec), _p(svec), tab([cams_p + 272 * i for i in range(B)]),
-                                                 int(ctx.detach), tab([_p(br.slots[i].mask) for i in range(B)]),
+                                                 int(ctx.detach), br._mask_table(B),
                                                  tab([g2d_p + 24 * N * i for i in range(B)]),
                                                  tab([g2d_p + 24 * N * i + 8 * N for i in range(B)]), None,
                                                  _p(g_mean), _p(g_qvec), _p(g_svec), s)
             if stats is not None:
                 lib.densify_update_batch(B, N, None, _tab([g2d_p + 24 * N * i for i in range(B)]),
-                                         _tab([_p(br.slots[i].mask) for i in range(B)]), None, _p(stats.grad_accum),
+                                         br._mask_table(B), None, _p(stats.grad_accum),
                                          _p(stats.cnt), s)
         return (g_mean, g_qvec, g_svec, g_alpha, g_col, None, None, None, None, _bg_grad(ctx, grad, T), None, None, None)
 
@@ -260,7 +260,7 @@ class _render_batch_heads(torch.autograd.Function):
                 br._end_batch(B)
                 if stats is not None:
                     lib.densify_update_batch(B, N, _tab([_p(br.slots[i].cov2d) for i in range(B)]), None,
-                                             _tab([_p(br.slots[i].mask) for i in range(B)]), _p(stats.max_radii2d),
+                                             br._mask_table(B), _p(stats.max_radii2d),
                                              None, None, s)
                 lib.vol_render_rgbd_batch(B, views, N, _p(col), _p(alpha), 16, br.slots[0].nth, br.slots[0].ntw, H, W,
                                           thresh, _p(bws), s)
@@ -312,8 +312,9 @@ class _render_batch_heads(torch.autograd.Function):
         if ctx.views is None:
             z = lambda g, c: g if g is not None else torch.zeros(B, H, W, c, device=dev)  # noqa: E731
             go6 = torch.cat([z(parts[0], 3), z(parts[1], 1), z(parts[2], 1), z(parts[3], 1)], dim=-1).contiguous()
-        g2d = torch.zeros(B, 6 * N, device=dev, dtype=torch.float32)   # per camera: mean2d | cov2d
-        gch = torch.zeros(B, N, 6, device=dev, dtype=torch.float32)    # per camera: rgb | depth | opacity | depth^2
+        gbuf = torch.zeros(2 * B * 6 * N, device=dev, dtype=torch.float32)  # one fill for both
+        g2d = gbuf[:B * 6 * N].view(B, 6 * N)      # per camera: mean2d | cov2d
+        gch = gbuf[B * 6 * N:].view(B, N, 6)       # per camera: rgb | depth | opacity | depth^2
         gdp = torch.empty(B, N, device=dev, dtype=torch.float32)       # per camera: d L / d (view-space depth)
         g3d = torch.zeros(11 * N, device=dev, dtype=torch.float32)     # shared: mean | qvec | svec | alpha
         g_mean, g_qvec = g3d[:3 * N].view(N, 3), g3d[3 * N:7 * N].view(N, 4)
@@ -337,18 +338,17 @@ class _render_batch_heads(torch.autograd.Function):
             with torch.cuda.device(dev):
                 lib.vol_render_rgbd_backward_batch(B, ctx.views, N, _p(col), _p(alpha), _p(g_alpha), 16, br.slots[0].nth,
                                                    br.slots[0].ntw, H, W, thresh, _p(ctx.bws), s)
-                depths = torch.stack([br.slots[i].depth.view(-1) for i in range(B)], 0)
-                torch.addcmul(gch[:, :, 3], depths, gch[:, :, 5], value=2.0, out=gdp)  # depth and depth^2 heads
+                torch.addcmul(gch[:, :, 3], br._depths[:B], gch[:, :, 5], value=2.0, out=gdp)  # depth and depth^2 heads
                 lib.project_gaussians_backward_batch(B, N, _p(mean), _p(qvec), _p(svec),
                                                      tab([cams_p + 272 * i for i in range(B)]), int(ctx.detach),
-                                                     tab([_p(br.slots[i].mask) for i in range(B)]),
+                                                     br._mask_table(B),
                                                      tab([g2d_p + 24 * N * i for i in range(B)]),
                                                      tab([g2d_p + 24 * N * i + 8 * N for i in range(B)]),
                                                      tab([_p(gdp[i]) for i in range(B)]), _p(g_mean), _p(g_qvec),
                                                      _p(g_svec), s)
                 if stats is not None:
                     lib.densify_update_batch(B, N, None, _tab([g2d_p + 24 * N * i for i in range(B)]),
-                                             _tab([_p(br.slots[i].mask) for i in range(B)]), None,
+                                             br._mask_table(B), None,
                                              _p(stats.grad_accum), _p(stats.cnt), s)
             return (g_mean, g_qvec, g_svec, g_alpha, gch[:, :, :3].sum(0), None, None, None, _bg_grad(ctx, g_rgb, T), None,
                     None, None)
@@ -398,26 +398,45 @@ class BatchRenderer:
         self._totals_event, self._totals_B = None, 0
         self._generation = 0
         self._table_cache = {}
-        self.slots = [R.FrameBuffers(N, W, H, device, D_cap=D_cap, segments=self.segments, total=self._totals[i:i + 1])
+        # the slots' depth buffers are the rows of one matrix (the heads' backward reads depths[:B] as one tensor)
+        self._depths = torch.empty(max_batch, N, device=device, dtype=torch.float32)
+        self.slots = [R.FrameBuffers(N, W, H, device, D_cap=D_cap, segments=self.segments, total=self._totals[i:i + 1],
+                                     depth=self._depths[i].view(N, 1))
                       for i in range(max_batch)]
+        self._ptr_tabs = {}
         self.streams = [torch.cuda.Stream(device=device) for _ in range(max(1, n_streams))]
         # per camera: cam block (56) | topleft (2) | rotation rows (9) | pad -> 68 floats, packed on the host and sent
         # through kernel arguments (gsgen_upload_small): no pinned ring, no copy event, the host never waits
         self._host = np.zeros((max_batch, 68), np.float32)
+        self._poses = np.zeros((max_batch, 12), np.float32)
+        self._intr = np.zeros((max_batch, 8), np.float64)
         self._cis = []
 
     def _upload(self, cam_infos, c2ws, frustum_radius, tile_radius):
+        """The batch's camera blocks, packed by ONE library call (gsgen_pack_camera_blocks) and sent through kernel
+        arguments (gsgen_upload_small).  (Per camera in Python -- numpy slices, one ctypes call each -- this was 15 us a
+        camera: a tenth of a 4 x 512^2 step.)"""
         B = len(cam_infos)
-        h = self._host
+        poses, intr, h = self._poses, self._intr, self._host
         for i, (ci, c2w) in enumerate(zip(cam_infos, c2ws)):
-            c2w = np.asarray(c2w.detach().cpu() if isinstance(c2w, torch.Tensor) else c2w, np.float32).reshape(-1)[:12]
-            ci.pack_into(h[i], c2w, frustum_radius, tile_radius)
-            h[i, 56:58] = (-ci.cx / ci.fx, -ci.cy / ci.fy)
-            h[i, 58:67] = c2w.reshape(3, 4)[:, :3].reshape(-1)
+            if isinstance(c2w, torch.Tensor):
+                c2w = c2w.detach().cpu().numpy()
+            poses[i] = np.asarray(c2w, np.float32).reshape(-1)[:12]
+            intr[i] = (ci.fx, ci.fy, ci.cx, ci.cy, ci.w, ci.h, ci.near_plane, ci.far_plane)
+        lib = _capi.load()
+        lib.pack_camera_blocks(B, poses.ctypes.data, 12, intr.ctypes.data, frustum_radius, tile_radius, h.ctypes.data)
         # a fresh device block per batch: the rows are saved for the batch's backward
         dev = torch.empty(B, 68, device=self.device, dtype=torch.float32)
-        _capi.load().upload_small(_p(dev), h.ctypes.data, B * 272, torch.cuda.current_stream(self.device).cuda_stream)
+        lib.upload_small(_p(dev), h.ctypes.data, B * 272, torch.cuda.current_stream(self.device).cuda_stream)
         return dev
+
+    def _mask_table(self, B):
+        """void*[B] of the slots' visibility masks (they never move): built once per batch size"""
+        t = self._ptr_tabs.get(B)
+        if t is None:
+            import ctypes
+            t = self._ptr_tabs[B] = (ctypes.c_void_p * B)(*[_p(self.slots[i].mask) for i in range(B)])
+        return t
 
     def _tables(self, kind):
         """(GeometryView[max_batch], ShView | RgbdView[max_batch]) with every per-slot buffer address filled in; rebuilt

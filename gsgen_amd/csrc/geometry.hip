@@ -697,6 +697,27 @@ int gsgen_project_gaussians_backward(uint32_t N, const float *mean, const float 
                                                  stream);
 }
 
+int gsgen_pack_camera_blocks(uint32_t n, const float *c2w, uint32_t c2w_stride, const double *intr,
+                             float frustum_radius, float tile_radius, float *blocks) {
+  if (n == 0) return 0;
+  if (!c2w || !intr || !blocks || c2w_stride < 12) return GSGEN_EINVAL;
+  for (uint32_t b = 0; b < n; ++b) {
+    const float *m = c2w + (size_t)b * c2w_stride;
+    const double *k = intr + 8 * (size_t)b;  // fx fy cx cy w h near far
+    float *o = blocks + 68 * (size_t)b;
+    if (int e = gsgen_pack_camera(m, (float)k[0], (float)k[1], (float)k[2], (float)k[3], (uint32_t)k[4], (uint32_t)k[5],
+                                  k[6], k[7], frustum_radius, tile_radius, o))
+      return e;
+    // pixel origin of the image plane (utils/camera.py: -cx/fx, -cy/fy in double, rounded once) and the rotation rows
+    o[56] = (float)(-k[2] / k[0]);
+    o[57] = (float)(-k[3] / k[1]);
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) o[58 + 3 * r + c] = m[4 * r + c];
+    o[67] = 0.0f;
+  }
+  return 0;
+}
+
 int gsgen_tile_culling_aabb_count(uint32_t N, const float *mean2d, const float *cov2d,
                                   uint32_t tile_size, float fx, float fy, float cx, float cy,
                                   uint32_t w, uint32_t h, float D, int *aabb_topleft,

@@ -202,9 +202,10 @@ class FrameBuffers:
     """Device buffers of the fused path for one (N, W, H) shape.  D_cap is the capacity of the
     (tile, Gaussian) pair list; `ensure_capacity()` grows it after an overflow."""
 
-    def __init__(self, N, W, H, device, D_cap=None, segments=1, total=None):
+    def __init__(self, N, W, H, device, D_cap=None, segments=1, total=None, depth=None):
         """total: optional int32 [1] device tensor to use as this buffer set's pair counter (BatchRenderer keeps the
         counters of its slots in one tensor so that one copy brings a whole batch's counts to the host).
+        depth: optional float32 [N, 1] device tensor to use as the depth buffer (BatchRenderer: the rows of one matrix).
         segments > 1: the SH backward runs one workgroup per (tile, 32-entry list segment) from
         checkpoints the forward leaves in `seg_ws` (gsgen_vol_render_sh_segmented) -- shorter tail for
         a lone render, slightly more total work; 1 (one workgroup per tile) is best when several
@@ -219,7 +220,7 @@ class FrameBuffers:
         f = dict(device=device, dtype=torch.float32)
         self.mean2d = torch.empty(N, 2, **f)
         self.cov2d = torch.empty(N, 2, 2, **f)
-        self.depth = torch.empty(N, 1, **f)
+        self.depth = depth if depth is not None else torch.empty(N, 1, **f)
         self.mask = torch.empty(N, device=device, dtype=torch.bool)
         self.start = torch.empty(self.nth * self.ntw, device=device, dtype=torch.int32)
         self.end = torch.empty_like(self.start)

@@ -249,6 +249,12 @@ size_t gsgen_frame_workspace_bytes(uint32_t N, uint32_t D_cap, uint32_t n_tiles)
  * hipGraph.  dst (device) and bytes must be multiples of 4.  No counterpart in the reference (it uploads with
  * torch's `.to(device)` per camera). */
 int gsgen_upload_small(void *dst, const void *host_src, size_t bytes, gsgen_stream_t stream);
+/* HOST helper: the 68-float per-camera blocks this library's fused paths upload (gsgen_upload_small) for n cameras in
+ * one call: cam[56] as gsgen_pack_camera | pixel origin (-cx/fx, -cy/fy) | the 9 rotation entries of c2w, row-major |
+ * pad.  c2w: n poses of >= 12 floats (rows of [R|t]), c2w_stride floats apart; intr: [n,8] doubles fx fy cx cy w h near
+ * far. */
+int gsgen_pack_camera_blocks(uint32_t n, const float *c2w, uint32_t c2w_stride, const double *intr,
+                             float frustum_radius, float tile_radius, float *blocks);
 /* HOST helper (no device work): fills cam[56] from a host c2w [3,4] and the CameraInfo fields
  * (utils/camera.py:219-259; yfov = 2 atan(h / 2fy), aspect = w / h). */
 int gsgen_pack_camera(const float *c2w, float fx, float fy, float cx, float cy, uint32_t w, uint32_t h,

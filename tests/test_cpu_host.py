@@ -144,6 +144,23 @@ def test_camera_pack_matches_oracle_frustum():
             [500.0, 510.0, 300.0, 250.0, 6.0, 6.0, 0, 0], np.float32))
 
 
+def test_camera_blocks_in_one_call_match_per_camera_packing():
+    """gsgen_pack_camera_blocks (what BatchRenderer uploads per batch): cam[56] == CameraInfo.pack, pixel origin, rotation"""
+    from gsgen_amd import _capi, renderer as R
+    cams = [scenes.Camera(640, 480, fx=500.0 + 7 * i, fy=510.0, cx=300.0, cy=250.0 - i, c2w=scenes.orbit(2.5, 15 + i, 40 * i)) for i in range(5)]
+    poses = np.zeros((5, 16), np.float32)  # a stride of 16 floats: [4,4] poses work too
+    poses[:, :12] = [c.c2w.reshape(-1)[:12] for c in cams]
+    intr = np.array([(c.fx, c.fy, c.cx, c.cy, c.w, c.h, 0.01, 100.0) for c in cams], np.float64)
+    out = np.full((5, 68), np.nan, np.float32)
+    _capi.load().pack_camera_blocks(5, poses.ctypes.data, 16, intr.ctypes.data, 6.0, 4.0, out.ctypes.data)
+    for i, c in enumerate(cams):
+        assert np.array_equal(out[i, :56], R.CameraInfo(*c.intr).pack(c.c2w, 6.0, 4.0))
+        assert np.array_equal(out[i, 56:58], c.topleft)
+        assert np.array_equal(out[i, 58:67], c.c2w[:3, :3].reshape(-1)) and out[i, 67] == 0.0
+    with pytest.raises(RuntimeError, match="invalid"):
+        _capi.load().pack_camera_blocks(5, poses.ctypes.data, 8, intr.ctypes.data, 6.0, 4.0, out.ctypes.data)
+
+
 # ---- the HIP kernels on the CPU emulator ------------------------------------------------------
 @pytest.fixture(scope="module")
 def emu():
