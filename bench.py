@@ -90,6 +90,15 @@ def b_alg_bytes(N, D, P, T, F):
     return sum(parts.values()), parts
 
 
+def choose_batch_and_slots(pairs_per_view, batch=0, slots=0):
+    """cameras per launch and launches in flight for a workload of `pairs_per_view` (tile, Gaussian) pairs per camera:
+    about 6 M pairs per launch (2 .. 8 cameras), three launches in flight when a launch is light (< 5.2 M pairs), else
+    two (measured: profiles/r02_notes.md).  Explicit --batch / --slots win."""
+    d = max(1, int(pairs_per_view))
+    B = batch if batch > 0 else int(min(8, max(2, round(6.0e6 / d))))
+    return B, (slots if slots > 0 else (3 if B * d < 5.2e6 else 2))
+
+
 def cpu_baseline(sc, cams, C, budget_s=20.0):
     """The CPU oracle (a port: the reference has no CPU rasteriser) timed on this box's cores
     on a bounded sample of the same workload: whole renders of the bench cameras until
@@ -216,8 +225,7 @@ def main():
     R.frame_geometry(tp["mean"], tp["qvec"], tp["svec"], torch.from_numpy(R.CameraInfo(*probe_cam.intr).pack(probe_cam.c2w)).to(dev), pb)
     d_probe = max(1, int(pb.total.item()))
     del pb, tp
-    B = args.batch if args.batch > 0 else int(min(8, max(2, round(6.0e6 / d_probe))))
-    auto_slots = args.slots if args.slots > 0 else (3 if B * d_probe < 5.2e6 else 2)
+    B, auto_slots = choose_batch_and_slots(d_probe, args.batch, args.slots)
     if dist is not None:  # one shape for the job (the gathered tensor is [world, B, H, W, 3])
         bt = torch.tensor([B, auto_slots], device=dev)
         dist.broadcast(bt, 0)

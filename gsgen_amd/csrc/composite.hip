@@ -1980,7 +1980,9 @@ int launch_fwd_rgb_batch(const CompParams &p0_, const CompParams *plist, uint32_
   const uint32_t nblk = comp_grid(p0_);
   if (p0_.ntw * p0_.nth == 0 || B == 0) return 0;
   const CompParams p0 = batch_arg(p0_, B);
-  hipLaunchKernelGGL((k_composite_fwd<MODE_RGB, 1, 1, true>), dim3(nblk * B), dim3(256), 0, s, p0, plist);
+  // packed, one wavefront per tile (default); same operation sequence as the per-camera kernel: identical bits
+  if (variants().chan_packed) hipLaunchKernelGGL((k_composite_fwd_chan_vec<MODE_RGB, true>), dim3(nblk * B), dim3(64), 0, s, p0, plist);
+  else hipLaunchKernelGGL((k_composite_fwd<MODE_RGB, 1, 1, true>), dim3(nblk * B), dim3(256), 0, s, p0, plist);
   return (int)hipGetLastError();
 }
 int launch_bwd_rgb_batch(const CompParams &p0_, const CompParams *plist, uint32_t B, hipStream_t s) {

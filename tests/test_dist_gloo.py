@@ -237,3 +237,18 @@ def test_densify_statistics_are_identical_on_every_rank():
         assert np.array_equal(mx, want_max) and np.array_equal(cnt, want_cnt)
         assert np.array_equal(mx, got[0][1]) and np.array_equal(ga, got[0][2])  # the same bits on every rank
         assert np.allclose(ga, torch.stack([p_[1] for p_ in per]).sum(0).numpy(), rtol=1e-6)
+
+
+def test_bench_accounting_and_launch_shape():
+    """bench.py's host-side arithmetic (no GPU): SURVEY 8(d)'s algorithmic bytes, and the cameras-per-launch /
+    launches-in-flight rule on the four BASELINE workloads' measured pair counts."""
+    import bench
+    total, parts = bench.b_alg_bytes(N=79_549, D=713_016, P=640_000, T=2_500, F=55)
+    assert parts["composite_bwd"] == (4 + 4 * 55) * 713_016 + 28 * 640_000 + 4 * 55 * 713_016
+    assert parts["composite_fwd"] == (4 + 4 * 55) * 713_016 + 16 * 640_000
+    assert total == sum(parts.values()) and abs(total / 0.5457e9 - 1) < 0.01  # 0.546 GB per render at cfg2
+    assert bench.choose_batch_and_slots(713_016) == (8, 2)      # cfg2: 5.7 M pairs per launch
+    assert bench.choose_batch_and_slots(2_470_000) == (2, 3)    # cfg3: two cameras per launch, three in flight
+    assert bench.choose_batch_and_slots(440_000) == (8, 3)      # cfg4: light launches
+    assert bench.choose_batch_and_slots(2_700) == (8, 3)        # cfg1
+    assert bench.choose_batch_and_slots(713_016, batch=4, slots=1) == (4, 1)
