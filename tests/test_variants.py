@@ -37,7 +37,11 @@ def _run(env_extra, args):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("variant", VARIANTS + MFMA_VARIANTS, ids=lambda v: ",".join(f"{k}={x}" for k, x in v.items()))
+# the opt-in matrix-core kernel: one shape in the default CPU run (19 s each), all three with GSGEN_TEST_MFMA=1
+EMU_VARIANTS = VARIANTS + (MFMA_VARIANTS if MFMA_ON_GPU else MFMA_VARIANTS[:1])
+
+
+@pytest.mark.parametrize("variant", EMU_VARIANTS, ids=lambda v: ",".join(f"{k}={x}" for k, x in v.items()))
 def test_variant_on_emulator(variant):
     # two SH degrees (padded and unpadded coefficient rows) + the fused RGB heads: ~20 s per variant
     _run(variant, ["tests/test_cpu_host.py", "-k",
