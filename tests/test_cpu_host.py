@@ -271,6 +271,24 @@ def test_emulated_other_tile_sizes(emu, ts, C, W, H):
     other_tile_size_chain(_HostArrays(emu), ts, C, W, H)
 
 
+def test_emulated_chain_fuzz(emu):
+    """hypothesis over the per-camera chain: image shapes from one pixel to several ragged tiles, 1 .. 400 Gaussians of
+    any size, every SH degree and tile size, opaque scenes (early termination on every pixel) -- each example checks
+    count, lists, RGB / scalar / SH images and all gradients against the oracle"""
+    from hypothesis import given, settings, strategies as st, HealthCheck
+    from tile_chain import other_tile_size_chain
+
+    n_ex = int(os.environ.get("GSGEN_FUZZ_EXAMPLES", "14"))  # a longer hunt: GSGEN_FUZZ_EXAMPLES=300 (random seeds)
+
+    @settings(max_examples=n_ex, deadline=None, derandomize=(n_ex == 14), suppress_health_check=list(HealthCheck))
+    @given(ts=st.sampled_from([8, 16, 32]), C=st.integers(1, 4), W=st.integers(1, 70), H=st.integers(1, 50),
+           n=st.integers(1, 400), seed=st.integers(0, 10_000), svec=st.sampled_from([0.01, 0.05, 0.2, 0.6]),
+           opaque=st.booleans())
+    def run(ts, C, W, H, n, seed, svec, opaque):
+        other_tile_size_chain(_HostArrays(emu), ts, C, W, H, n=n, seed=seed, svec=svec, opaque=opaque)
+    run()
+
+
 def test_emulated_fused_frame_geometry(emu):
     from gsgen_amd import renderer as R
     cam = scenes.Camera(80, 64, fx=70.0, c2w=scenes.orbit(2.0, 25, 200))

@@ -427,3 +427,22 @@ def test_other_tile_sizes(ts, C, W, H):
     oracle at that tile size (the reference takes the tile size as a parameter, conf/base.yaml:132)"""
     from tile_chain import other_tile_size_chain
     other_tile_size_chain(_DeviceArrays(), ts, C, W, H, sync=torch.cuda.synchronize)
+
+
+def test_chain_fuzz():
+    """hypothesis over the per-camera chain on the GPU (see tests/test_cpu_host.py::test_emulated_chain_fuzz): image
+    shapes from one pixel to several ragged tiles, 1 .. 3000 Gaussians of any size, every SH degree and tile size,
+    opaque scenes"""
+    import os
+    from hypothesis import given, settings, strategies as st, HealthCheck
+    from tile_chain import other_tile_size_chain
+    n_ex = int(os.environ.get("GSGEN_FUZZ_EXAMPLES", "40"))
+
+    @settings(max_examples=n_ex, deadline=None, derandomize=(n_ex == 40), suppress_health_check=list(HealthCheck))
+    @given(ts=st.sampled_from([8, 16, 32]), C=st.integers(1, 4), W=st.integers(1, 200), H=st.integers(1, 150),
+           n=st.integers(1, 3000), seed=st.integers(0, 10_000), svec=st.sampled_from([0.01, 0.05, 0.2, 0.6]),
+           opaque=st.booleans())
+    def run(ts, C, W, H, n, seed, svec, opaque):
+        other_tile_size_chain(_DeviceArrays(), ts, C, W, H, sync=torch.cuda.synchronize, n=n, seed=seed, svec=svec,
+                              opaque=opaque)
+    run()

@@ -8,14 +8,19 @@ import scenes
 from oracle import oracle as O
 
 
-def other_tile_size_chain(L, ts, C, W, H, sync=lambda: None, rtol=1e-4):
+def other_tile_size_chain(L, ts, C, W, H, sync=lambda: None, rtol=1e-4, n=300, seed=None, svec=0.07, opaque=False):
     """count -> bin / sort -> RGB, scalar and SH forward + backward at tile size `ts` through the library `L`
-    (P_: array -> address) against the oracle at the same tile size.  Shared by the emulator and the GPU test."""
-    cam = scenes.Camera(W, H, fx=float(W))
-    sc = scenes.random_scene(300, seed=C + ts, svec=0.07, C=C)
+    against the oracle at the same tile size.  Shared by the emulator and the GPU tests.  n / seed / svec: the random
+    scene; opaque: every opacity at 0.999 (above the 0.99 clamp: lists end early, T crosses the stop threshold)."""
+    cam = scenes.Camera(W, H, fx=float(max(W, 4)))
+    sc = scenes.random_scene(n, seed=C + ts if seed is None else seed, svec=svec, C=C)
+    if opaque:
+        sc["alpha"][:] = 0.999
     normals, pts = O.frustum(cam.c2w, *cam.intr)
     m = O.cull_bsphere(sc["mean"], sc["svec"], normals, pts, 6.0)
     N = int(m.sum())
+    if N == 0:
+        return
     m2, c2, _, dep = O.project(sc["mean"][m], sc["qvec"][m], sc["svec"][m], cam.c2w)
     D, otl, obr = O.aabb_count(m2, c2, ts, cam.fx, cam.fy, cam.cx, cam.cy, cam.w, cam.h, 6.0)
     nth, ntw = (H + ts - 1) // ts, (W + ts - 1) // ts
