@@ -19,6 +19,10 @@ constexpr float kLog2e = 1.4426950408889634f;
 // re-evaluated with the reference's own arithmetic, so that the skip decision (a discontinuity
 // of size ~1/255 in the image) is the reference's decision.
 constexpr float kGuardTol = 2.0e-4f;
+// The Cholesky-form record of the RGB / scalar modes holds p = L * sqrt(0.5 log2 e) with L L^T = Sigma^-1 (prepared in
+// fp64 per record), so Sigma^-1 d = (p0 u, p1 u + p2 v) * kInvSc2 with u = p0 x + p1 y, v = p2 y -- the backward's
+// v = Sigma^-1 d without the fp32 determinant (whose cancellation costs eps * cond on large, elongated splats).
+constexpr float kInvSc2 = 1.3862943611198906f;  // 1 / (0.5 log2 e) = 2 ln 2
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 

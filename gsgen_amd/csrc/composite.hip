@@ -665,12 +665,7 @@ k_composite_bwd_pixel(CompParams p_arg, const CompParams *__restrict__ plist) {
 #pragma unroll
       for (int i = 0; i < P; ++i) gr[i] = 0.0f;
 
-      float inv_det;
-      if constexpr (MODE == MODE_SH) {
-        inv_det = r.p1;
-      } else {
-        inv_det = 1.0f / (r.c0 * r.c3 - r.c1 * r.c2);
-      }
+      const float inv_det = r.p1;  // SH: 1 / det (fp32, as the reference); the other modes do not use it
       const float *cg = &S.col[g * TR::NCOLP];
       float pAG[PPL], ag[PPL];
       if constexpr (MODE == MODE_SH) {
@@ -731,8 +726,15 @@ k_composite_bwd_pixel(CompParams p_arg, const CompParams *__restrict__ plist) {
         const float pa = con[j] ? pAG[j] : 0.0f;
         const float y = py[j] - r.my;
         const float gg = pa * ag[j];
-        const float vx = (x * r.c3 - y * r.c2) * inv_det;
-        const float vy = (y * r.c0 - x * r.c1) * inv_det;
+        float vx, vy;
+        if constexpr (MODE == MODE_SH) {  // the reference's fp32 formula (kernels.h:394-418)
+          vx = (x * r.c3 - y * r.c2) * inv_det;
+          vy = (y * r.c0 - x * r.c1) * inv_det;
+        } else {  // from the Cholesky factor (see kInvSc2): no fp32 determinant
+          const float u = r.p0 * x + r.p1 * y, v = r.p2 * y;
+          vx = kInvSc2 * (r.p0 * u);
+          vy = kInvSc2 * (r.p1 * u + r.p2 * v);
+        }
         gr[0] += gg * vx;
         gr[1] += gg * vy;
         const float h = 0.5f * gg;
@@ -1266,9 +1268,7 @@ k_composite_bwd_chan_vec(CompParams p_arg, const CompParams *__restrict__ plist)
       if (__ballot(any_alive) == 0ull) break;
 
       const float r_mx = wave_uniform(S.mx[g]), r_my = wave_uniform(S.my[g]), r_a = wave_uniform(S.a[g]),
-                  r_c0 = wave_uniform(S.c0[g]), r_c1 = wave_uniform(S.c1[g]), r_c2 = wave_uniform(S.c2[g]),
-                  r_c3 = wave_uniform(S.c3[g]), r_p0 = wave_uniform(S.p0[g]), r_p1 = wave_uniform(S.p1[g]),
-                  r_p2 = wave_uniform(S.p2[g]);
+                  r_p0 = wave_uniform(S.p0[g]), r_p1 = wave_uniform(S.p1[g]), r_p2 = wave_uniform(S.p2[g]);
       const float x = px - r_mx;
       // G2 / ag2: the Gaussian (gauss_eval's Cholesky form) and a G, ZEROED where the pixel does not take part
       v2f y2[NP], G2[NP], ag2[NP];
@@ -1283,6 +1283,7 @@ k_composite_bwd_chan_vec(CompParams p_arg, const CompParams *__restrict__ plist)
         for (int k = 0; k < 2; ++k) any_guard |= alive(2 * jp + k) && fabsf(ag2[jp][k] - kMinAlpha) <= kMinAlpha * kGuardTol;
       }
       if (__ballot(any_guard) != 0ull) {  // within rounding of the skip threshold: the reference's arithmetic decides
+        const float r_c0 = S.c0[g], r_c1 = S.c1[g], r_c2 = S.c2[g], r_c3 = S.c3[g];
 #pragma unroll
         for (int jp = 0; jp < NP; ++jp)
 #pragma unroll
@@ -1329,13 +1330,15 @@ k_composite_bwd_chan_vec(CompParams p_arg, const CompParams *__restrict__ plist)
         gr2[c >> 1][c & 1] = add_scalar(gacc[0], gacc[1]);
       }
       // mean2d (2) | cov2d (4) | alpha (1): kernel_gaussian_2d_backward (kernels.h:394-418), packed over the pair
-      const float inv_det = __builtin_amdgcn_rcpf(r_c0 * r_c3 - r_c1 * r_c2);
+      // v = Sigma^-1 d from the Cholesky factor (see kInvSc2): no fp32 determinant
+      const float k0 = kInvSc2 * r_p0, k1 = kInvSc2 * r_p1, k2 = kInvSc2 * r_p2;
       v2f gm0 = {0.f, 0.f}, gm1 = gm0, gc0 = gm0, gc1 = gm0, gc3 = gm0, gal = gm0;
 #pragma unroll
       for (int jp = 0; jp < NP; ++jp) {
         const v2f gg = pAG2[jp] * ag2[jp];
-        const v2f vx = (splat2(x * r_c3) - y2[jp] * splat2(r_c2)) * splat2(inv_det);
-        const v2f vy = (y2[jp] * splat2(r_c0) - splat2(x * r_c1)) * splat2(inv_det);
+        const v2f u = fma2(splat2(r_p1), y2[jp], splat2(p0x));
+        const v2f vx = splat2(k0) * u;
+        const v2f vy = fma2(splat2(k1), u, (splat2(k2) * splat2(r_p2)) * y2[jp]);
         gm0 = fma2(gg, vx, gm0);
         gm1 = fma2(gg, vy, gm1);
         const v2f h = splat2(0.5f) * gg;
