@@ -8,12 +8,16 @@ import scenes
 from oracle import oracle as O
 
 
-def other_tile_size_chain(L, ts, C, W, H, sync=lambda: None, rtol=1e-4, n=300, seed=None, svec=0.07, opaque=False, atol=0.0):
+def other_tile_size_chain(L, ts, C, W, H, sync=lambda: None, rtol=1e-4, n=300, seed=None, svec=0.07, opaque=False, atol=0.0, ftol=1e-5):
     """count -> bin / sort -> RGB, scalar and SH forward + backward at tile size `ts` through the library `L`
     against the oracle at the same tile size.  Shared by the emulator and the GPU tests.  n / seed / svec: the random
     scene; opaque: every opacity at 0.999 (above the 0.99 clamp: lists end early, T crosses the stop threshold).
     Gradients: |got - want| <= rtol * max|want| + atol (atol for the fuzz: a one-pixel image of opaque, image-sized
-    splats has gradients of 1e-5 behind (final - prefix) / (1 - 0.99), i.e. rounding noise of 1e-7 amplified 100 x)."""
+    splats has gradients of 1e-5 behind (final - prefix) / (1 - 0.99), i.e. rounding noise of 1e-7 amplified 100 x).
+    ftol: forward tolerance (1e-5 on the fixed scenes; the fuzz takes north_star's 1e-4: a transmittance within rounding
+    of the stop threshold lets one side composite one splat more, which weighs up to 1e-4).  When the ORACLE's own
+    decision margins say that an SH pixel sits within a few ulps of a threshold (oracle.sh_decision_margin), the SH
+    gradients of that example are not compared: the flipped splat moves them by up to 1e-4 of an O(1) term."""
     cam = scenes.Camera(W, H, fx=float(max(W, 4)))
     sc = scenes.random_scene(n, seed=C + ts if seed is None else seed, svec=svec, C=C)
     if opaque:
@@ -54,7 +58,7 @@ def other_tile_size_chain(L, ts, C, W, H, sync=lambda: None, rtol=1e-4, n=300, s
                                       nth, ntw, psx, psy, H, W, 1e-4, T.p, L.stream)
     sync()
     ref, refT = O.render_rgb_fwd(m2, c2, col, al, *geo, tile_size=ts)
-    assert np.abs(out.get() - ref).max() < 1e-5 and np.abs(T.get() - refT.reshape(H, W)).max() < 1e-5
+    assert np.abs(out.get() - ref).max() < ftol and np.abs(T.get() - refT.reshape(H, W)).max() < max(ftol, 1.0001e-4 if ftol > 1e-5 else 0)
     bgimg = np.random.default_rng(4).uniform(size=(H, W, 3)).astype(np.float32)
     final = (ref + refT.reshape(H, W, 1) * bgimg).astype(np.float32)
     g = {k: L.to_dev(np.zeros(s_, np.float32)) for k, s_ in dict(gm=(N, 2), gc=(N, 4), gcol=(N, 3), ga=(N,)).items()}
@@ -73,7 +77,7 @@ def other_tile_size_chain(L, ts, C, W, H, sync=lambda: None, rtol=1e-4, n=300, s
                             psx, psy, H, W, 1e-4, sT.p, L.stream)
     sync()
     sref, _ = O.render_scalar_fwd(m2, c2, sval, al, *geo, tile_size=ts)
-    assert np.abs(sout.get() - sref).max() < 1e-5 * max(1.0, np.abs(sref).max())
+    assert np.abs(sout.get() - sref).max() < ftol * max(1.0, np.abs(sref).max())
     sgo = np.ascontiguousarray(go[..., 0]); sgod = L.to_dev(sgo); srefd = L.to_dev(sref)
     g = {k: L.to_dev(np.zeros(s_, np.float32)) for k, s_ in dict(gm=(N, 2), gc=(N, 4), gs=(N,), ga=(N,)).items()}
     L.lib.vol_render_scalar_backward(N, D, h["m2"].p, h["c2"].p, sv.p, d["al"].p, st.p, en.p, ids.p, srefd.p, g["gm"].p,
@@ -92,15 +96,17 @@ def other_tile_size_chain(L, ts, C, W, H, sync=lambda: None, rtol=1e-4, n=300, s
                         psx, psy, H, W, C, 1e-4, bgd.p, None, L.stream)
     sync()
     ref = O.render_sh_fwd(m2, c2, sh, al, ost, oen, oids, tlp, rot, C, psx, psy, H, W, bg=bg, tile_size=ts)
-    scenes.assert_sh_image_parity(out.get(), ref, m2, c2, al, ost, oen, oids, tlp, psx, psy, tol=1e-5, what=f"tile {ts}")
+    scenes.assert_sh_image_parity(out.get(), ref, m2, c2, al, ost, oen, oids, tlp, psx, psy, tol=ftol, what=f"tile {ts}")
     g = {k: L.to_dev(np.zeros(s_, np.float32)) for k, s_ in dict(gm=(N, 2), gc=(N, 4), gsh=(N, 3, C * C), ga=(N,)).items()}
     L.lib.vol_render_backward_sh(N, D, h["m2"].p, h["c2"].p, shd.p, d["al"].p, st.p, en.p, ids.p, out.p, g["gm"].p, g["gc"].p,
                                  g["gsh"].p, g["ga"].p, god.p, d["tlp"].p, rotd.p, ts, nth, ntw, psx, psy, H, W, C, 1e-4, bgd.p,
                                  L.stream)
     sync()
     om, oc, osh, oa = O.render_sh_bwd(m2, c2, sh, al, ost, oen, oids, ref, go, tlp, rot, C, psx, psy, H, W, tile_size=ts)
-    for a, b in ((g["gm"], om), (g["gc"], oc.reshape(-1, 4)), (g["gsh"], osh), (g["ga"], oa)):
-        close(a.get(), b)
+    margin = O.sh_decision_margin(m2, c2, al, ost, oen, oids, tlp, psx, psy, H, W, tile_size=ts)
+    if atol == 0.0 or margin.min() > 4e-7:
+        for a, b in ((g["gm"], om), (g["gc"], oc.reshape(-1, 4)), (g["gsh"], osh), (g["ga"], oa)):
+            close(a.get(), b)
     # tile sizes the kernels do not exist for are refused, not misrendered
     with pytest.raises(Exception, match="unsupported"):
         L.lib.vol_render_sh(N, D, h["m2"].p, h["c2"].p, shd.p, d["al"].p, st.p, en.p, ids.p, out.p, d["tlp"].p, rotd.p, 12, nth,
