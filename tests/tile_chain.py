@@ -17,7 +17,9 @@ def other_tile_size_chain(L, ts, C, W, H, sync=lambda: None, rtol=1e-4, n=300, s
     ftol: forward tolerance (1e-5 on the fixed scenes; the fuzz takes north_star's 1e-4: a transmittance within rounding
     of the stop threshold lets one side composite one splat more, which weighs up to 1e-4).  When the ORACLE's own
     decision margins say that an SH pixel sits within a few ulps of a threshold (oracle.sh_decision_margin), the SH
-    gradients of that example are not compared: the flipped splat moves them by up to 1e-4 of an O(1) term."""
+    gradients of that example are not compared: the flipped splat moves them by up to 1e-4 of an O(1) term.
+    (The fuzz keeps svec <= 0.2: with image-sized splats -- svec 0.6 -- the covariance gradient is a heavily cancelling sum
+    over every pixel and fp32 atomics against the oracle's fp64 sums reach 1.1e-3 of its largest entry.)"""
     cam = scenes.Camera(W, H, fx=float(max(W, 4)))
     sc = scenes.random_scene(n, seed=C + ts if seed is None else seed, svec=svec, C=C)
     if opaque:
