@@ -485,7 +485,7 @@ def main():
             with torch.cuda.stream(sl0.stream):
                 for k in range(min(ncam, 8)):
                     gk = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gk, stream=sl0.stream):
+                    with torch.cuda.graph(gk, stream=sl0.stream, capture_error_mode="thread_local"):  # RCCL's watchdog thread may query events meanwhile
                         one_render(k)
                     graphs.append(gk)
                 for i in range(8):
