@@ -9,6 +9,9 @@ _render_with_T (gs/renderer.py:1135-1283), _render_scalar (:999-1132), _render_s
 (:833-996) and _render_start_end (:541-672), plus the reference's PyTorch projection chained in front of
 _render_sh so that gradients flow to mean / qvec / svec through the reference's whole Python graph.
 
+The last test runs the reference's MODEL class (gs/gaussian_splatting.py GaussianSplattingRenderer: forward over a camera
+batch, backward, post_backward) unmodified on the mirror.
+
 Skipped where /root/reference does not exist (the GPU box); tests/test_gpu_golden.py holds the HIP library to
 the same golden vectors there."""
 import os
@@ -146,3 +149,124 @@ def test_reference_projection_chained_into_reference_render_sh(ref):
     ((a2 * t(g["sh_gmean"])).sum() + (b2 * t(g["sh_gcov"])).sum()).backward()
     for got, want, k in ((mean, m2, "mean"), (qvec, q2, "qvec"), (svec, s2, "svec")):
         assert rel(got.grad.numpy(), want.grad.numpy()) < 2e-3, k
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The reference's MODEL class on the mirror: gs/gaussian_splatting.py imported from /root/reference, its own
+# GaussianSplattingRenderer constructed from a config and run unmodified -- forward() over a camera batch (render_one
+# per camera: culling_gaussian_bsphere -> project_gaussians -> tile_culling_aabb_count -> tile_culling_aabb_start_end ->
+# render_with_T + three render_scalar passes, :1198-1466), backward of a loss on all four outputs, post_backward()
+# (update_densify_info, :464-469).  Every `_backend.*` call in that file lands in this repo's `_gs`.
+# ---------------------------------------------------------------------------------------------------------------
+class _Cfg(dict):
+    """what the reference reads its OmegaConf node through: attribute access, .get, hasattr"""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k) from None
+
+
+@pytest.fixture(scope="module")
+def refmodel(ref):
+    """-> (gs.gaussian_splatting module with _backend = the mirror, gs.renderer module)"""
+    from gsgen_amd import _gs
+    dm = types.ModuleType("kornia.geometry.depth")  # utils/ops.py:5 imports depth_to_3d (unused on this path)
+    dm.depth_to_3d = None
+    sys.modules["kornia.geometry.depth"] = dm
+    sys.modules["kornia"].__path__ = []
+    sys.modules["kornia.geometry"].__path__ = []
+    import gs.gaussian_splatting as M
+    M._backend = _gs
+    return M, ref
+
+
+def test_reference_model_forward_backward_and_densify_info_on_the_mirror(refmodel):
+    import scenes
+    from oracle import oracle as O
+    from utils.camera import CameraInfo
+    M, GR = refmodel
+    bg = [0.1, 0.2, 0.3]
+    cfg = _Cfg(device="cpu", svec_act="exp", alpha_act="sigmoid", color_act="sigmoid", tile_size=16,
+               frustum_culling_radius=6.0, tile_culling_type="aabb", tile_culling_thresh=0.01, tile_culling_radius=6.0,
+               T_thresh=1e-4, skip_frustum_culling=False, normal_as_rgb=False, debug=False, depth_detach=True,
+               background=_Cfg(type="fixed", device="cpu", color=bg, random_aug=False, random_aug_prob=0.0),
+               densify=_Cfg(enabled=True), prune=_Cfg(enabled=False))  # conf/base.yaml:129-160
+    sc = scenes.random_scene(600, seed=11, svec=0.05, spread=1.2, C=1)
+    t = lambda a, **k: torch.tensor(np.ascontiguousarray(a), **k)  # noqa: E731
+    model = M.GaussianSplattingRenderer(cfg, {k: t(sc[k]) for k in ("mean", "qvec", "svec", "color", "alpha")})
+    model.train()
+    cams = [scenes.Camera(72, 56, fx=66.0, c2w=scenes.orbit(2.4, 20, 40)),
+            scenes.Camera(72, 56, fx=80.0, c2w=scenes.orbit(1.6, -10, 200))]
+    N = sc["mean"].shape[0]
+    out = model({"c2w": torch.stack([t(c.c2w) for c in cams]), "camera_info": [CameraInfo(*c.intr) for c in cams]})
+    assert {k: tuple(v.shape) for k, v in out.items()} == {"rgb": (2, 56, 72, 3), "depth": (2, 56, 72, 1),
+                                                          "opacity": (2, 56, 72, 1), "z_var": (2, 56, 72, 1)}
+    rng = np.random.default_rng(5)
+    go = {k: rng.normal(size=tuple(v.shape)).astype(np.float32) for k, v in out.items()}
+    sum((out[k] * t(go[k])).sum() for k in out).backward()
+    masks = [m_.numpy().copy() for m_ in model.masks]
+    g_mean2d = [m_.grad.numpy().copy() for m_ in model.mean_2ds]  # retained by render_one for update_densify_info
+    model.post_backward()
+
+    # ---- the expectation: the reference's torch projection (same bits as inside the model) in front of the oracle's
+    # cull / count / bin / sort / four compositing passes and their backward, chained to the raw parameters by autograd
+    raw = {"mean": model.mean, "qvec": model.qvec, "svec": model.svec_before_activation,
+           "color": model.color_before_activation, "alpha": model.alpha_before_activation}
+    P = {k: v.detach().clone().requires_grad_(True) for k, v in raw.items()}
+    svec_a, color_a, alpha_a = torch.exp(P["svec"]), torch.sigmoid(P["color"]), torch.sigmoid(P["alpha"])
+    want_maxr, want_acc, want_cnt = np.zeros(N, np.float32), np.zeros(N, np.float32), np.zeros(N, np.float32)
+    some_culled = False
+    for b, cam in enumerate(cams):
+        H, W = cam.h, cam.w
+        normals, pts = O.frustum(cam.c2w, *cam.intr)
+        mask = O.cull_bsphere(sc["mean"], svec_a.detach().numpy(), normals, pts, 6.0)
+        assert np.array_equal(mask, masks[b])
+        some_culled |= bool(0 < mask.sum() < N)
+        mt = t(mask)
+        mean2d, cov2d, _, depth = GR.project_gaussians(P["mean"][mt].contiguous(), P["qvec"][mt].contiguous(),
+                                                       svec_a[mt].contiguous(), t(cam.c2w), True)
+        col, al = color_a[mt].contiguous(), alpha_a[mt].contiguous()
+        m2, c2, dv = mean2d.detach().numpy(), cov2d.detach().numpy(), depth.detach().numpy().ravel().copy()
+        D, tl, br = O.aabb_count(m2, c2, 16, cam.fx, cam.fy, cam.cx, cam.cy, W, H, 6.0)
+        ids, start, end = O.bin_sort(tl, br, dv, *cam.tiles, D)
+        geo = (start, end, ids, cam.topleft, 1 / cam.fx, 1 / cam.fy, H, W)
+        cn, an = col.detach().numpy(), al.detach().numpy()
+        o_rgb, T = O.render_rgb_fwd(m2, c2, cn, an, *geo)
+        o_d, _ = O.render_scalar_fwd(m2, c2, dv, an, *geo)
+        o_o, _ = O.render_scalar_fwd(m2, c2, np.ones_like(dv), an, *geo)
+        o_z, _ = O.render_scalar_fwd(m2, c2, dv * dv, an, *geo)
+        img = o_rgb + T.reshape(H, W, 1) * np.array(bg, np.float32)
+        zmax = max(1.0, float(np.abs(o_z).max()))
+        assert np.abs(out["rgb"][b].detach().numpy() - img).max() <= 1e-4
+        assert np.abs(out["depth"][b, ..., 0].detach().numpy() - o_d).max() <= 1e-4 * max(1.0, float(np.abs(o_d).max()))
+        assert np.abs(out["opacity"][b, ..., 0].detach().numpy() - o_o).max() <= 1e-4
+        assert np.abs(out["z_var"][b, ..., 0].detach().numpy() - (o_z - o_d * o_d)).max() <= 2e-4 * zmax
+        # backward: z_var = z2 - depth^2 (gs/gaussian_splatting.py:1397); the RGB backward is handed the image INCLUDING
+        # the background (gs/renderer.py:1182,1213: the suffix colour behind a splat contains T_final * bg)
+        g_rgb = np.ascontiguousarray(go["rgb"][b])
+        g_d = np.ascontiguousarray(go["depth"][b, ..., 0] - 2.0 * o_d * go["z_var"][b, ..., 0])
+        g_o, g_z = np.ascontiguousarray(go["opacity"][b, ..., 0]), np.ascontiguousarray(go["z_var"][b, ..., 0])
+        r = O.render_rgb_bwd(m2, c2, cn, an, start, end, ids, np.ascontiguousarray(img, np.float32), g_rgb, cam.topleft, 1 / cam.fx, 1 / cam.fy, H, W)
+        ss = [O.render_scalar_bwd(m2, c2, v, an, start, end, ids, f, g_, cam.topleft, 1 / cam.fx, 1 / cam.fy, H, W)
+              for v, f, g_ in ((dv, o_d, g_d), (np.ones_like(dv), o_o, g_o), (dv * dv, o_z, g_z))]
+        gm2 = r[0] + sum(s[0] for s in ss)
+        assert rel(g_mean2d[b], gm2) < 1e-3
+        gc2 = (r[1] + sum(s[1] for s in ss)).reshape(-1, 2, 2)
+        gal = r[3] + sum(s[3] for s in ss)
+        gdv = (ss[0][2] + 2.0 * dv * ss[2][2]).reshape(-1, 1)  # depth is a scalar channel twice: z and z^2
+        torch.autograd.backward([mean2d, cov2d, depth, col, al],
+                                [t(gm2), t(gc2), t(gdv.astype(np.float32)), t(r[2]), t(gal)], retain_graph=True)
+        # the densify statistics of this camera (:1240-1245, :464-469)
+        mm = (c2[:, 0, 0] + c2[:, 1, 1]) / 2
+        radii = mm + np.sqrt(np.clip(mm * mm - (c2[:, 0, 0] * c2[:, 1, 1] - c2[:, 0, 1] * c2[:, 1, 0]), 0, None))
+        want_maxr[mask] = np.maximum(want_maxr[mask], radii)
+        want_acc[mask] += np.linalg.norm(gm2, axis=-1)
+        want_cnt[mask] += 1
+    assert some_culled  # the cull does something on at least one camera
+    for k in raw:
+        assert rel(raw[k].grad.numpy(), P[k].grad.numpy()) < 1e-3, k
+    assert np.abs(model.max_radii2d.numpy() - want_maxr).max() <= 1e-6 * max(1.0, float(want_maxr.max()))
+    assert np.array_equal(model.cnt.numpy(), want_cnt)
+    assert rel(model.mean_2d_grad_accum.numpy(), want_acc) < 1e-3
