@@ -187,18 +187,14 @@ def test_reference_model_forward_backward_and_densify_info_on_the_mirror(refmode
     from oracle import oracle as O
     from utils.camera import CameraInfo
     M, GR = refmodel
-    bg = [0.1, 0.2, 0.3]
-    cfg = _Cfg(device="cpu", svec_act="exp", alpha_act="sigmoid", color_act="sigmoid", tile_size=16,
-               frustum_culling_radius=6.0, tile_culling_type="aabb", tile_culling_thresh=0.01, tile_culling_radius=6.0,
-               T_thresh=1e-4, skip_frustum_culling=False, normal_as_rgb=False, debug=False, depth_detach=True,
-               background=_Cfg(type="fixed", device="cpu", color=bg, random_aug=False, random_aug_prob=0.0),
-               densify=_Cfg(enabled=True), prune=_Cfg(enabled=False))  # conf/base.yaml:129-160
-    sc = scenes.random_scene(600, seed=11, svec=0.05, spread=1.2, C=1)
+    sys.path.insert(0, GOLD)
+    import make_golden_model as MG  # the scene, cameras and config the committed fixture was generated from
+    bg = MG.BG
+    sc, cams = MG.case()
+    gold = np.load(os.path.join(GOLD, "model", "model_batch.npz"))
     t = lambda a, **k: torch.tensor(np.ascontiguousarray(a), **k)  # noqa: E731
-    model = M.GaussianSplattingRenderer(cfg, {k: t(sc[k]) for k in ("mean", "qvec", "svec", "color", "alpha")})
+    model = M.GaussianSplattingRenderer(_Cfg(MG.model_cfg()), {k: t(sc[k]) for k in ("mean", "qvec", "svec", "color", "alpha")})
     model.train()
-    cams = [scenes.Camera(72, 56, fx=66.0, c2w=scenes.orbit(2.4, 20, 40)),
-            scenes.Camera(72, 56, fx=80.0, c2w=scenes.orbit(1.6, -10, 200))]
     N = sc["mean"].shape[0]
     out = model({"c2w": torch.stack([t(c.c2w) for c in cams]), "camera_info": [CameraInfo(*c.intr) for c in cams]})
     assert {k: tuple(v.shape) for k, v in out.items()} == {"rgb": (2, 56, 72, 3), "depth": (2, 56, 72, 1),
@@ -270,3 +266,14 @@ def test_reference_model_forward_backward_and_densify_info_on_the_mirror(refmode
     assert np.abs(model.max_radii2d.numpy() - want_maxr).max() <= 1e-6 * max(1.0, float(want_maxr.max()))
     assert np.array_equal(model.cnt.numpy(), want_cnt)
     assert rel(model.mean_2d_grad_accum.numpy(), want_acc) < 1e-3
+    # ... and against the fixture the reference's own kernels produced under the same model class
+    # (tests/golden/make_golden_model.py): images, raw-parameter gradients, densify statistics
+    assert np.array_equal(np.stack(masks), gold["masks"])
+    for k in out:
+        scale = max(1.0, float(np.abs(gold["out_" + k]).max()))
+        assert np.abs(out[k].detach().numpy() - gold["out_" + k]).max() <= 1e-4 * scale, k
+    for k in raw:
+        assert rel(raw[k].grad.numpy(), gold["grad_" + k]) < 1e-3, k
+    assert np.array_equal(model.cnt.numpy(), gold["cnt"])
+    assert rel(model.max_radii2d.numpy(), gold["max_radii2d"]) < 1e-6
+    assert rel(model.mean_2d_grad_accum.numpy(), gold["grad_accum"]) < 1e-3
