@@ -474,6 +474,9 @@ class BatchRenderer:
 
     def _end_batch(self, B):
         """behind the geometry enqueue: the batch's pair counts follow it to the host (one async copy, one event)"""
+        if torch.cuda.is_current_stream_capturing():  # a hipGraph of the step: an event recorded under capture cannot be
+            self._totals_event = None                 # queried afterwards; size the slots (ensure_capacity) before capturing
+            return
         self._totals_host[:B].copy_(self._totals[:B], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
@@ -490,7 +493,7 @@ class BatchRenderer:
         """No sync: if the previous batch's pair counts have reached the host and one exceeded its slot's capacity,
         grow that slot and warn (that camera was rendered as background only, with zero gradients)."""
         ev = self._totals_event
-        if ev is None or not ev.query():
+        if ev is None or torch.cuda.is_current_stream_capturing() or not ev.query():  # (no queries under capture)
             return True
         self._totals_event = None
         ok = True

@@ -266,6 +266,9 @@ class FrameBuffers:
     def end_frame(self, stream=None):
         """after the geometry enqueue: the frame's pair count follows it to the host, asynchronously"""
         st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        if torch.cuda.is_current_stream_capturing():  # see BatchRenderer._end_batch
+            self._total_event = None
+            return
         with torch.cuda.stream(st):
             self._total_host.copy_(self.total, non_blocking=True)
             ev = torch.cuda.Event()
@@ -276,7 +279,7 @@ class FrameBuffers:
         """No sync: if the previous frame's pair count has reached the host and exceeded the capacity, grow the
         buffers and warn (that frame showed background only, with zero gradients).  Returns False in that case."""
         ev = self._total_event
-        if ev is None or not ev.query():
+        if ev is None or torch.cuda.is_current_stream_capturing() or not ev.query():
             return True
         self._total_event = None
         need = int(self._total_host.item())

@@ -1,0 +1,101 @@
+"""The renderer's share of one GSGEN optimisation step (BASELINE configs[4], guidance stubbed): what
+trainer.py:291-421 does around the diffusion model, on this repo's public autograd path.
+
+    raw parameters --activations--> BatchRenderer.render_heads (4 views at 512x512: rgb + depth + opacity + depth^2,
+    one enqueue per stage) --> loss = <rgb, g_sds> + sparsity + z_var terms --> backward --> densify statistics
+    --> FusedAdam step on the five raw fields (one flat buffer, one kernel)
+
+The StableDiffusion guidance (diffusers + weights) is not available offline; its output as far as the renderer is
+concerned is a gradient on the rendered rgb batch (SDS: grad = w(t) (eps_hat - eps), back through the VAE encoder), so
+the stub is a fixed random image gradient of that shape.  Everything else is the real step.  Prints one JSON line:
+iterations per second and the host time per iteration.  A tool next to bench.py (which measures BASELINE's headline
+metric); not part of the driver's contract."""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import scenes  # noqa: E402
+from gsgen_amd import renderer as R  # noqa: E402
+from gsgen_amd.batch import BatchRenderer  # noqa: E402
+from gsgen_amd.optim import FusedAdam  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--n", type=int, default=100_000)
+ap.add_argument("--res", type=int, default=512)
+ap.add_argument("--batch", type=int, default=4, help="views per step (conf/base.yaml:2)")
+ap.add_argument("--steps", type=int, default=100)
+ap.add_argument("--warmup", type=int, default=20)
+ap.add_argument("--graph", action="store_true", help="replay the whole step from one hipGraph")
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+sc = scenes.pointe_scene(a.n, seed=0, C=1)
+logit = lambda x: np.log(x / (1 - x))  # noqa: E731
+raw0 = {"mean": sc["mean"], "qvec": sc["qvec"], "svec": np.log(sc["svec"]), "color": logit(np.clip(sc["color"], 1e-3, 1 - 1e-3)),
+        "alpha": logit(np.clip(sc["alpha"], 1e-3, 1 - 1e-3))}
+opt = FusedAdam({k: torch.from_numpy(np.ascontiguousarray(v, np.float32)).to(dev) for k, v in raw0.items()},
+                {"mean": 5e-3, "qvec": 3e-3, "svec": 3e-3, "color": 1e-2, "alpha": 3e-3}, eps=1e-15)  # conf/base.yaml:8-30
+P = opt.params
+rng = np.random.default_rng(0)
+cams = [scenes.Camera(a.res, a.res, fx=float(rng.uniform(0.7, 1.35) * a.res),
+                      c2w=scenes.orbit(float(rng.uniform(2, 2.5)), float(rng.uniform(-20, 60)), float(rng.uniform(-180, 180))))
+        for _ in range(a.batch)]
+cis, c2ws = [R.CameraInfo(*c.intr) for c in cams], [c.c2w for c in cams]
+br = BatchRenderer(a.n, a.res, a.res, dev, max_batch=a.batch)
+stats = R.DensifyStats(a.n, dev)
+g_sds = torch.randn(a.batch, a.res, a.res, 3, device=dev) * 1e-4  # the guidance's gradient on the rendered batch
+bg = torch.tensor([0.5, 0.5, 0.5], device=dev)
+
+
+def step():
+    opt.zero_grad()
+    rgb, dpt, opa, z2, _ = br.render_heads(P["mean"], P["qvec"], torch.exp(P["svec"]), torch.sigmoid(P["alpha"]),
+                                           torch.sigmoid(P["color"]), cis, c2ws, bg_rgb=bg, stats=stats)
+    z_var = z2 - dpt * dpt
+    loss = (rgb * g_sds).sum() + 1e-3 * (opa * opa + 0.01).sqrt().mean() + 1e-3 * z_var.mean()  # trainer.py:305-388
+    loss.backward()
+    opt.step()
+
+
+step()
+torch.cuda.synchronize()
+assert br.ensure_capacity(a.batch)
+for _ in range(a.warmup):
+    step()
+run, graph_error = step, None
+if a.graph:
+    # (the captured optimiser step carries its step count -- the bias correction -- as a constant: fine for a timing run)
+    try:
+        torch.cuda.synchronize()
+        assert br.ensure_capacity(a.batch)  # also drops the pending pair-count event: nothing is queried during capture
+        s = torch.cuda.Stream(dev)
+        s.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(s):
+            step()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=s):
+                step()
+            for _ in range(5):
+                gr.replay()
+        torch.cuda.current_stream(dev).wait_stream(s)
+        run = gr.replay
+    except Exception as e:  # report, and time the eager step instead
+        graph_error = f"{type(e).__name__}: {str(e)[:300]}"
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(a.steps):
+    run()
+t_host = time.perf_counter() - t0
+torch.cuda.synchronize()
+t1 = time.perf_counter() - t0
+print(json.dumps({"metric": "optimisation-step iters/sec, renderer + optimiser share (guidance stubbed)", "value": a.steps / t1,
+                  "unit": "iters/s", "ms_per_iter": 1e3 * t1 / a.steps, "host_ms_per_iter": 1e3 * t_host / a.steps,
+                  "views_per_s": a.batch * a.steps / t1, "hipgraph": bool(a.graph) and graph_error is None, "hipgraph_error": graph_error,
+                  "config": {"workload": "BASELINE configs[4] without the diffusion model: 100k Gaussians, "
+                                         f"{a.batch} views at {a.res}x{a.res}, rgb + depth + opacity + z_var, "
+                                         "densify statistics, Adam on the five raw fields", "gaussians": a.n}}))
