@@ -225,3 +225,57 @@ def test_full_size_rgb_heads_batched():
         want["alpha"][m] += galpha; want["color"][m] += r[2]
     for k in keys:
         assert rel_err(P[k].grad.cpu().numpy(), want[k]) < 1e-3, (k, rel_err(P[k].grad.cpu().numpy(), want[k]))
+
+
+def test_batched_launches_fuzz():
+    """hypothesis over the BATCHED launches -- the kernels bench.py times (k_composite_{fwd,bwd}_sh_vec<BATCH>, the
+    batched geometry and projection backward) -- through the public autograd path: 1 .. 4 cameras of ragged image shapes
+    (one pixel to several partial tiles), 1 .. 3000 Gaussians of any size, every SH degree, opaque scenes (early
+    termination everywhere), 1 or 4 backward segments per tile.  Each example: pair lists exact, every pixel of every
+    camera against the oracle (threshold-adjacent pixels named by the oracle's own decision margins), the summed
+    gradients of all five parameter fields against the oracle's."""
+    from hypothesis import given, settings, strategies as st, HealthCheck
+    from gsgen_amd import renderer as R
+    from gsgen_amd.batch import BatchRenderer
+    n_ex = int(os.environ.get("GSGEN_FUZZ_EXAMPLES", "25"))
+
+    @settings(max_examples=n_ex, deadline=None, derandomize=(n_ex == 25), suppress_health_check=list(HealthCheck))
+    @given(B=st.integers(1, 4), C=st.integers(1, 4), W=st.integers(1, 150), H=st.integers(1, 120), n=st.integers(1, 3000),
+           seed=st.integers(0, 10_000), svec=st.sampled_from([0.01, 0.05, 0.2]), opaque=st.booleans(),
+           nseg=st.sampled_from([1, 4]))
+    def run(B, C, W, H, n, seed, svec, opaque, nseg):
+        sc = scenes.random_scene(n, seed=seed, svec=svec, C=C)
+        if opaque:
+            sc["alpha"][:] = 0.999
+        cams = [scenes.Camera(W, H, fx=float(max(W, 4)) * (0.8 + 0.25 * i), c2w=scenes.orbit(2.4 + 0.1 * i, 12.0 * i, 35.0 + 95.0 * i))
+                for i in range(B)]
+        cis = [R.CameraInfo(*c.intr) for c in cams]
+        bg = np.array([0.1, 0.2, 0.3], np.float32)
+        P = {k: T_(sc[k]).requires_grad_(True) for k in KEYS}
+        br = BatchRenderer(n, W, H, dev(), max_batch=B, fused_launch=True, segments=nseg)
+        for _ in range(2):
+            rgb, _ = br.render(P["mean"], P["qvec"], P["svec"], P["alpha"], P["sh"], cis, [c.c2w for c in cams], C=C, bg_rgb=T_(bg))
+            if br.ensure_capacity(B):
+                break
+        gos = torch.randn(B, H, W, 3, device=dev(), generator=torch.Generator(device=dev()).manual_seed(seed))
+        (rgb * gos).sum().backward()
+        torch.cuda.synchronize()
+        want = {k: np.zeros(sc[k].shape, np.float64) for k in KEYS}
+        margin = np.inf
+        for i, cam in enumerate(cams):
+            g, ref, gr = oracle_render(sc, cam, C, gos[i].cpu().numpy(), bg)
+            check_lists(br.slots[i], g)
+            m = g["mask"]
+            if m.any():
+                geo = (g["mean2d"], g["cov2d"], sc["alpha"][m], g["start"], g["end"], g["ids"], cam.topleft, 1 / cam.fx, 1 / cam.fy)
+                scenes.assert_sh_image_parity(rgb[i].detach().cpu().numpy(), ref, *geo, what=f"camera {i}")
+                margin = min(margin, float(O.sh_decision_margin(*geo, H, W).min()))
+            else:
+                assert np.abs(rgb[i].detach().cpu().numpy() - bg).max() <= 1e-6
+            for k in KEYS:
+                want[k] += gr[k]
+        if margin > 4e-7:  # (a flipped threshold decision moves the gradients by up to 1e-4 of an O(1) term)
+            for k in KEYS:
+                got = P[k].grad.cpu().numpy()
+                assert np.abs(got - want[k]).max() <= 1e-3 * np.abs(want[k]).max() + 1e-6, (k, B, C, W, H, n, seed, svec, opaque, nseg)
+    run()
