@@ -279,3 +279,78 @@ def test_batched_launches_fuzz():
                 got = P[k].grad.cpu().numpy()
                 assert np.abs(got - want[k]).max() <= 1e-3 * np.abs(want[k]).max() + 1e-6, (k, B, C, W, H, n, seed, svec, opaque, nseg)
     run()
+
+
+def oracle_heads(sc, cam, go_rgb, go_d, go_o, go_z, bg):
+    """oracle: the reference's four passes of one camera (rgb with T, depth, opacity, depth^2) forward + backward ->
+    geometry, the four images, full-N gradients (mean, qvec, svec, alpha, color) incl. the depth heads' gradient
+    through the view-space depth (gs/gaussian_splatting.py:1304-1416)"""
+    g = scenes.oracle_geometry(sc, cam)
+    m = g["mask"]
+    H, W = cam.h, cam.w
+    m2, c2, dv = g["mean2d"], g["cov2d"], np.ascontiguousarray(g["depth"].ravel())
+    col, al = np.ascontiguousarray(sc["color"][m]), np.ascontiguousarray(sc["alpha"][m])
+    geo = (g["start"], g["end"], g["ids"], cam.topleft, 1 / cam.fx, 1 / cam.fy, H, W)
+    o_rgb, T = O.render_rgb_fwd(m2, c2, col, al, *geo)
+    img = np.ascontiguousarray(o_rgb + T.reshape(H, W, 1) * bg, np.float32)
+    heads = [(dv, go_d), (np.ones_like(dv), go_o), (dv * dv, go_z)]
+    outs = [O.render_scalar_fwd(m2, c2, v, al, *geo)[0] for v, _ in heads]
+    r = O.render_rgb_bwd(m2, c2, col, al, g["start"], g["end"], g["ids"], img, go_rgb, cam.topleft, 1 / cam.fx, 1 / cam.fy, H, W)
+    ss = [O.render_scalar_bwd(m2, c2, v, al, g["start"], g["end"], g["ids"], o_, np.ascontiguousarray(go_), cam.topleft,
+                              1 / cam.fx, 1 / cam.fy, H, W) for (v, go_), o_ in zip(heads, outs)]
+    gm2 = r[0] + sum(s[0] for s in ss)
+    gc2 = r[1] + sum(s[1] for s in ss)
+    gdv = ss[0][2] + 2.0 * dv * ss[2][2]
+    om, oq, os_ = O.project_bwd(sc["mean"][m], sc["qvec"][m], sc["svec"][m], cam.c2w, gm2, gc2, gdv.reshape(-1, 1).astype(np.float32), True)
+    grads = {k: np.zeros(sc[k].shape, np.float64) for k in ("mean", "qvec", "svec", "alpha", "color")}
+    grads["mean"][m], grads["qvec"][m], grads["svec"][m] = om, oq, os_
+    grads["alpha"][m] = r[3] + sum(s[3] for s in ss)
+    grads["color"][m] = r[2]
+    return g, (img, outs[0], outs[1], outs[2]), grads
+
+
+def test_batched_heads_fuzz():
+    """hypothesis over the trainer's default outputs through BatchRenderer.render_heads (rgb + depth + opacity + depth^2 in
+    one compositing pass per camera: k_composite_{fwd,bwd}_chan_vec<RGBD, BATCH>) against the reference's four passes in
+    the oracle: ragged shapes, 1 .. 4 cameras, 1 .. 3000 Gaussians, opaque scenes, with and without a detached depth"""
+    from hypothesis import given, settings, strategies as st, HealthCheck
+    from gsgen_amd import renderer as R
+    from gsgen_amd.batch import BatchRenderer
+    n_ex = int(os.environ.get("GSGEN_FUZZ_EXAMPLES", "25"))
+    keys = ("mean", "qvec", "svec", "alpha", "color")
+
+    @settings(max_examples=n_ex, deadline=None, derandomize=(n_ex == 25), suppress_health_check=list(HealthCheck))
+    @given(B=st.integers(1, 4), W=st.integers(1, 150), H=st.integers(1, 120), n=st.integers(1, 3000),
+           seed=st.integers(0, 10_000), svec=st.sampled_from([0.01, 0.05, 0.2]), opaque=st.booleans())
+    def run(B, W, H, n, seed, svec, opaque):
+        sc = scenes.random_scene(n, seed=seed, svec=svec, C=1)
+        if opaque:
+            sc["alpha"][:] = 0.999
+        cams = [scenes.Camera(W, H, fx=float(max(W, 4)) * (0.8 + 0.25 * i), c2w=scenes.orbit(2.4 + 0.1 * i, 12.0 * i, 35.0 + 95.0 * i))
+                for i in range(B)]
+        cis = [R.CameraInfo(*c.intr) for c in cams]
+        bg = np.array([0.1, 0.2, 0.3], np.float32)
+        P = {k: T_(sc[k]).requires_grad_(True) for k in keys}
+        br = BatchRenderer(n, W, H, dev(), max_batch=B)
+        for _ in range(2):
+            outs = br.render_heads(P["mean"], P["qvec"], P["svec"], P["alpha"], P["color"], cis, [c.c2w for c in cams], bg_rgb=T_(bg))[:4]
+            if br.ensure_capacity(B):
+                break
+        gen = torch.Generator(device=dev()).manual_seed(seed)
+        gos = [torch.randn(B, H, W, c, device=dev(), generator=gen) for c in (3, 1, 1, 1)]
+        sum((o * g_).sum() for o, g_ in zip(outs, gos)).backward()
+        torch.cuda.synchronize()
+        want = {k: np.zeros(sc[k].shape, np.float64) for k in keys}
+        for i, cam in enumerate(cams):
+            gnp = [g_[i].cpu().numpy() for g_ in gos]
+            g, imgs, gr = oracle_heads(sc, cam, np.ascontiguousarray(gnp[0]), gnp[1][..., 0], gnp[2][..., 0], gnp[3][..., 0], bg)
+            check_lists(br.slots[i], g)
+            for o, ref in zip(outs, imgs):
+                got = o[i].detach().cpu().numpy().reshape(ref.shape)
+                assert np.abs(got - ref).max() <= 1e-4 * max(1.0, float(np.abs(ref).max())), (i, B, W, H, n, seed, svec, opaque)
+            for k in keys:
+                want[k] += gr[k]
+        for k in keys:
+            got = P[k].grad.cpu().numpy()
+            assert np.abs(got - want[k]).max() <= 1e-3 * np.abs(want[k]).max() + 1e-6, (k, B, W, H, n, seed, svec, opaque)
+    run()
