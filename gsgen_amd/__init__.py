@@ -6,6 +6,9 @@
     gsgen_amd.renderer   HIP projection, fused RGB + heads, the fused `render_frame`
     gsgen_amd.batch      camera batches: one enqueue per stage for all cameras of a batch
     gsgen_amd.dist       camera sharding across GPUs (one process per GPU, RCCL all_gather)
+    gsgen_amd.optim      one flat Adam step over the replicated parameters
+    gsgen_amd.densify    the reference's densify / prune bookkeeping, identical on every rank (pure torch)
+    gsgen_amd.io         the reference's checkpoint / .ply / .splat formats
     gsgen_amd.build      hipcc build of gsgen_amd/lib/libgsgen_hip.so (C ABI: include/gsgen_hip.h)
 
 There is no CPU implementation in this package: every entry point needs the HIP library and

@@ -31,13 +31,14 @@ class FusedAdam:
         self.grad = torch.zeros_like(self.flat)
         self.exp_avg = torch.zeros_like(self.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat)
-        self.params = {}
+        self.params, self._span = {}, {}
         ends, off = [], 0
         for k, sz in zip(self.names, sizes):
             self.flat[off:off + sz].copy_(fields[k].detach().reshape(-1).to(torch.float32))
             p = self.flat[off:off + sz].view(fields[k].shape).requires_grad_(True)
             p.grad = self.grad[off:off + sz].view(fields[k].shape)
             self.params[k] = p
+            self._span[k] = (off, off + sz, tuple(fields[k].shape))
             off += sz
             ends.append(off)
         self._ends = np.array(ends, np.uint64)
@@ -46,6 +47,19 @@ class FusedAdam:
 
     def zero_grad(self):
         self.grad.zero_()
+
+    def moments(self, name):
+        """-> (exp_avg, exp_avg_sq) of one field, shaped like the field (views into the flat buffers)"""
+        a, b, shape = self._span[name]
+        return self.exp_avg[a:b].view(shape), self.exp_avg_sq[a:b].view(shape)
+
+    def load_moments(self, moments, step_count):
+        """moments: dict name -> (exp_avg, exp_avg_sq) shaped like the fields (densify / prune carry the surviving rows'
+        Adam state over, gs/gaussian_splatting.py:421-449, :481-522); step_count: the optimiser's step so far"""
+        for k in self.names:
+            ea, es = self.moments(k)
+            ea.copy_(moments[k][0]); es.copy_(moments[k][1])
+        self.step_count = int(step_count)
 
     def all_reduce_grad(self, group=None, average=True):
         """one collective for all fields (no-op without an initialised process group)"""
