@@ -175,6 +175,10 @@ def main():
     ap.add_argument("--latency-segments", type=int, default=8,
                     help="the same for the one-render-in-flight pass: uniform work units shorten a lone launch's tail")
     ap.add_argument("--repeats", type=int, default=0, help="repeats of the timed region (0: until 0.5 s are timed, <= 25)")
+    ap.add_argument("--geo-priority", type=int, default=int(os.environ.get("GSGEN_GEO_PRIORITY", "0")),
+                    help="1: a slot's geometry stage runs on its own HIGH-priority HIP stream, ahead of the other slot's compositing launch "
+                         "instead of in its shadow (measured: 3 333 vs 3 361 renders/s -- the chip is busy either way, "
+                         "profiles/r02_notes.md); 0 (default): everything of a slot on one stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the one-render-in-flight and hipGraph passes")
     args = ap.parse_args()
@@ -249,6 +253,10 @@ def main():
     class Slot:
         def __init__(self, stream):
             self.stream, self.s = stream, stream.cuda_stream
+            # geometry on a high-priority stream of its own: the hardware dispatches its workgroups ahead of the other slot's
+            # 20 000-workgroup compositing launch instead of behind it
+            self.geo_stream = torch.cuda.Stream(dev, priority=-1) if args.geo_priority else stream
+            self.e_geo, self.e_done, self.started = torch.cuda.Event(), torch.cuda.Event(), False
             with torch.cuda.stream(stream):
                 self.bufs = [R.FrameBuffers(N, W, H, dev) for _ in range(B)]
                 self.out = torch.empty(B, H, W, 3, device=dev)
@@ -306,7 +314,18 @@ def main():
         if sl.gather_pending:
             stream.wait_event(sl.e_gathered)
             sl.gather_pending = False
-        clock.call("geometry", lib.frame_geometry_batch, B, geo, N, p(t["mean"]), p(t["qvec"]), p(t["svec"]), W, H, p(sl.gws), s)
+        if sl.geo_stream is not stream:
+            t0 = time.perf_counter()
+            if sl.started:
+                sl.geo_stream.wait_event(sl.e_done)  # the slot's previous step has finished with the lists
+            clock.acc["events"] = clock.acc.get("events", 0.0) + time.perf_counter() - t0
+        clock.call("geometry", lib.frame_geometry_batch, B, geo, N, p(t["mean"]), p(t["qvec"]), p(t["svec"]), W, H, p(sl.gws),
+                   sl.geo_stream.cuda_stream)
+        if sl.geo_stream is not stream:
+            t0 = time.perf_counter()
+            sl.e_geo.record(sl.geo_stream)
+            stream.wait_event(sl.e_geo)
+            clock.acc["events"] = clock.acc.get("events", 0.0) + time.perf_counter() - t0
         if ev is not None:
             clock.call("events", ev[0].record, stream)
         clock.call("composite_fwd", lib.vol_render_sh_batch, B, views, N, p(t["sh"]), p(t["alpha"]), 16, nth, ntw, H, W, C,
@@ -334,6 +353,9 @@ def main():
             clock.call("events", ev[3].record, stream)
         clock.call("project_bwd", lib.project_gaussians_backward_batch, B, N, p(t["mean"]), p(t["qvec"]), p(t["svec"]), *proj,
                    p(sl.g_mean), p(sl.g_qvec), p(sl.g_svec), s)
+        if sl.geo_stream is not stream:
+            sl.e_done.record(stream)
+            sl.started = True
 
     def barrier():
         if dist is not None:
@@ -526,7 +548,8 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": WORKLOADS[args.config], "gaussians": N, "visible_after_cull": n_vis, "image": [H, W],
                    "sh_degree": C - 1, "tile_pairs_D": D, "cameras_per_step": B, "steps_in_flight": len(slots),
-                   "backward_segments_per_tile": nseg, "parallelism": f"camera-sharded x{world}",
+                   "backward_segments_per_tile": nseg, "geometry_stream": "high priority, per slot" if args.geo_priority else "the slot's stream",
+                   "parallelism": f"camera-sharded x{world}",
                    "gather": ("one rccl all_gather of the step's rendered images, on its own stream behind the step's forward"
                               if dist is not None else "none")},
         "timing": {"repeats": len(regions), "reported": "median repeat", "renders_per_s_min": world * B * K / max(els),
