@@ -498,7 +498,7 @@ class BatchRenderer:
         self._totals_event = None
         ok = True
         for i in range(self._totals_B):
-            need, s = int(self._totals_host[i]), self.slots[i]
+            need, s = R.pair_count(self._totals_host[i]), self.slots[i]
             if need > s.D_cap:
                 import warnings
                 old = s.D_cap

@@ -189,7 +189,15 @@ scan_chunks_body(uint32_t T, uint32_t nchunks, uint32_t *__restrict__ cnt, uint3
   if (lane == 0) tile_count[t] = carry;
 }
 
-// exclusive scan of tile_count[T] -> tile_off[T+1]; ctrl[0] = total, ctrl[1] = overflow flag
+// exclusive scan of tile_count[T] -> tile_off[T+1]; ctrl[0] = total, ctrl[1] = overflow flag.
+// Sums SATURATE at 2^32 - 1: a pair count beyond 32 bits (a diverged scene: millions of Gaussians each covering every tile)
+// must read as "does not fit", never wrap round to a small number that does (the emit pass would then write past the
+// pair buffer).  The offsets of an overflowing frame are not used: ctrl[1] makes every later stage bin nothing.
+__device__ __forceinline__ uint32_t sat_add_u32(uint32_t a, uint32_t b) {
+  const uint32_t s = a + b;
+  return s < a ? 0xffffffffu : s;
+}
+
 __device__ __forceinline__ void
 scan_tiles_body(uint32_t T, const uint32_t *__restrict__ tile_count, uint32_t *__restrict__ tile_off,
              uint32_t *__restrict__ ctrl, uint32_t cap, uint32_t *__restrict__ total_out) {
@@ -198,20 +206,20 @@ scan_tiles_body(uint32_t T, const uint32_t *__restrict__ tile_count, uint32_t *_
   const uint32_t per = (T + 1023u) / 1024u;
   const uint32_t b = t * per, e = min(b + per, T);
   uint32_t sum = 0;
-  for (uint32_t i = b; i < e; ++i) sum += tile_count[i];
+  for (uint32_t i = b; i < e; ++i) sum = sat_add_u32(sum, tile_count[i]);
   s_part[t] = sum;
   __syncthreads();
   // Hillis-Steele inclusive scan over 1024 partials
   for (uint32_t d = 1; d < 1024u; d <<= 1) {
     const uint32_t v = (t >= d) ? s_part[t - d] : 0u;
     __syncthreads();
-    s_part[t] += v;
+    s_part[t] = sat_add_u32(s_part[t], v);
     __syncthreads();
   }
-  uint32_t run = s_part[t] - sum;  // exclusive prefix of this thread's chunk
+  uint32_t run = (t > 0) ? s_part[t - 1] : 0u;  // exclusive prefix of this thread's chunk
   for (uint32_t i = b; i < e; ++i) {
     tile_off[i] = run;
-    run += tile_count[i];
+    run = sat_add_u32(run, tile_count[i]);
   }
   if (t == 1023u) {
     const uint32_t total = s_part[1023];
@@ -550,6 +558,7 @@ static int bin_and_sort(uint32_t N, uint32_t cap, uint32_t nth, uint32_t ntw, co
                         const int *br, const float *depth, int *ids, int *start, int *end,
                         const BinWs &w, uint32_t *total_out, hipStream_t s) {
   const uint32_t T = nth * ntw;
+  if (cap > 0x7fffffffu) return GSGEN_EINVAL;  // start / end / the list positions are int32 (the reference's layout)
   const uint32_t ngroups = ((ntw + kGroup - 1) / kGroup) * ((nth + kGroup - 1) / kGroup);
   const dim3 gpull(ngroups, w.nchunks);
   const dim3 bpull(64 * kPullWaves);
@@ -636,6 +645,7 @@ int gsgen_tile_culling_aabb_start_end(uint32_t N, uint32_t D, uint32_t n_tiles_h
   if (!start || !end || !workspace) return GSGEN_EINVAL;
   if (N && (!aabb_topleft || !aabb_bottomright || !depth)) return GSGEN_EINVAL;
   if (D && !gaussian_ids) return GSGEN_EINVAL;
+  if (D > 0x7fffffffu) return GSGEN_EINVAL;  // int32 list positions (the reference's start / end layout)
   const BinWs w = carve(workspace, N, D, T, false);
   if (w.bytes > workspace_bytes) return GSGEN_EWORKSPACE;
   return bin_and_sort(N, D, n_tiles_h, n_tiles_w, aabb_topleft, aabb_bottomright, depth, gaussian_ids,
@@ -659,6 +669,7 @@ int gsgen_frame_geometry_batch(uint32_t n_views, const gsgen_geometry_view *view
     const gsgen_geometry_view &v = views[b];
     if (!v.cam || !v.start || !v.end || !v.workspace || !v.total || !v.gaussian_ids) return GSGEN_EINVAL;
     if (N && (!v.mean2d || !v.cov2d || !v.depth || !v.mask)) return GSGEN_EINVAL;
+    if (v.D_cap > 0x7fffffffu) return GSGEN_EINVAL;  // int32 list positions
     const BinWs w = carve(v.workspace, N, v.D_cap, T, true);
     if (w.bytes > v.workspace_bytes) return GSGEN_EWORKSPACE;
     nchunks = w.nchunks;
@@ -710,6 +721,7 @@ int gsgen_frame_geometry(uint32_t N, const float *mean, const float *qvec, const
   if (T == 0) return 0;
   if (!cam || !start || !end || !workspace || !total) return GSGEN_EINVAL;
   if (N && (!mean || !qvec || !svec || !mean2d || !cov2d || !depth || !mask)) return GSGEN_EINVAL;
+  if (D_cap > 0x7fffffffu) return GSGEN_EINVAL;
   const BinWs w = carve(workspace, N, D_cap, T, true);
   if (w.bytes > workspace_bytes) return GSGEN_EWORKSPACE;
   hipStream_t s = (hipStream_t)stream;

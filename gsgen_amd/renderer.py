@@ -198,6 +198,17 @@ def n_tiles(H, W, tile_size=16):
     return (H + tile_size - 1) // tile_size, (W + tile_size - 1) // tile_size
 
 
+def pair_count(v):
+    """The device's uint32 pair count as a Python int (it lives in an int32 tensor).  Beyond int32 -- the kernels saturate at
+    2^32 - 1 -- no pair buffer can hold the frame (list positions are int32 in the reference's layout): that is a diverged
+    scene (scales far larger than the view), reported as such instead of being 'regrown' for."""
+    n = int(v) & 0xFFFFFFFF
+    if n > 0x7FFFFFFF:
+        raise RuntimeError(f"gsgen_amd: the frame needs {'at least 2^32 - 1' if n == 0xFFFFFFFF else n} (tile, Gaussian) pairs, beyond "
+                           "the int32 list positions of the reference's layout -- the Gaussians' scales have diverged")
+    return n
+
+
 class FrameBuffers:
     """Device buffers of the fused path for one (N, W, H) shape.  D_cap is the capacity of the
     (tile, Gaussian) pair list; `ensure_capacity()` grows it after an overflow."""
@@ -251,7 +262,7 @@ class FrameBuffers:
         """Host-side check (one sync): did the last frame fit?  Grows the pair buffers if not (False: that frame was
         rendered as background only -- render it again)."""
         self._total_event = None
-        need = int(self.total.item())
+        need = pair_count(self.total.item())
         if need > self.D_cap:
             self._alloc_pairs(int(need * 1.25) + 1024)
             return False
@@ -282,7 +293,7 @@ class FrameBuffers:
         if ev is None or torch.cuda.is_current_stream_capturing() or not ev.query():
             return True
         self._total_event = None
-        need = int(self._total_host.item())
+        need = pair_count(self._total_host.item())
         if need > self.D_cap:
             import warnings
             old = self.D_cap

@@ -67,7 +67,10 @@ int gsgen_culling_gaussian_bsphere(uint32_t N, const float *mean, const float *q
  * replaces tile_culling_aabb_start_end, render.h:61 -> render.cu:381-398 ->
  * tile_culling_aabb_start_end_cuda aabb_culling.h:192-260.  D = gaussian_ids length =
  * sum over Gaussians of (br-tl+1) products (the caller's N_with_dub).  Unlike the reference
- * there is no cudaMalloc/cudaFree/blocking memcpy: temporaries live in `workspace`. */
+ * there is no cudaMalloc/cudaFree/blocking memcpy: temporaries live in `workspace`.
+ * D (and D_cap of the fused entry points) must not exceed INT32_MAX -- start / end and the list positions are int32 as in
+ * the reference -- else GSGEN_EINVAL.  The fused entry points report the frame's pair count in *total; counts that do not
+ * fit 32 bits SATURATE at 2^32 - 1 (and read as "does not fit": nothing is binned), they never wrap. */
 size_t gsgen_tile_culling_workspace_bytes(uint32_t N, uint32_t D, uint32_t n_tiles);
 int gsgen_tile_culling_aabb_start_end(uint32_t N, uint32_t D, uint32_t n_tiles_h,
                                       uint32_t n_tiles_w, const int *aabb_topleft,

@@ -911,3 +911,33 @@ def test_batch_renderer_step_is_hip_graph_capturable():
     outs_a, _ = step()
     torch.cuda.synchronize()
     assert torch.equal(outs_a[0], outs_e[0])
+
+
+def test_pair_count_beyond_32_bits_reads_as_overflow_not_as_a_small_number():
+    """A diverged scene -- 300 k Gaussians each covering every tile of a 2048^2 image: 4.9e9 (tile, Gaussian) pairs -- must
+    come back as "does not fit" (the saturated count 2^32 - 1, every list empty), never as the count modulo 2^32, which
+    would fit the buffer and send the emit pass past its end.  And a capacity beyond int32 is refused: list positions are
+    int32 in the reference's layout."""
+    from gsgen_amd import renderer as R, _capi
+    L = _capi.load()
+    N, W, H = 300_000, 2048, 2048
+    rng = np.random.default_rng(0)
+    mean = (rng.normal(size=(N, 3)) * 0.01).astype(np.float32)
+    qvec = np.tile(np.array([1, 0, 0, 0], np.float32), (N, 1))
+    svec = np.full((N, 3), 50.0, np.float32)  # far larger than the view: every tile
+    cam = scenes.Camera(W, H, fx=float(W), c2w=scenes.orbit(2.5, 10, 20))
+    ci = R.CameraInfo(*cam.intr)
+    buf = R.FrameBuffers(N, W, H, dev(), D_cap=1 << 20)
+    R.frame_geometry(T_(mean), T_(qvec), T_(svec), T_(ci.pack(cam.c2w)), buf)
+    torch.cuda.synchronize()
+    assert N * buf.nth * buf.ntw > 2 ** 32
+    assert int(buf.mask.sum().item()) == N
+    assert int(buf.total.cpu().numpy().view(np.uint32)[0]) == 0xFFFFFFFF  # (2^32 - 1 on the host side whatever dtype holds it)
+    assert int((buf.start >= 0).sum().item()) == 0 and int((buf.end >= 0).sum().item()) == 0
+    with pytest.raises(RuntimeError, match="diverged"):  # the host side does not try to "regrow" for it
+        buf.ensure_capacity()
+    p = lambda t: t.data_ptr()  # noqa: E731
+    ws = torch.empty(1 << 20, dtype=torch.uint8, device=dev())
+    with pytest.raises(Exception, match="invalid argument"):
+        L.tile_culling_aabb_start_end(4, 0x80000000, 2, 2, p(buf.ids), p(buf.ids), p(buf.depth), p(buf.ids), p(buf.start), p(buf.end),
+                                      p(ws), ws.numel(), torch.cuda.current_stream().cuda_stream)
