@@ -28,7 +28,6 @@
 
 namespace gs {
 
-constexpr int kThreads = 256;
 constexpr int kSortThreads = 256;  // waves 1-3 only work on segments too long for the register sort
 constexpr uint32_t kBigGrid = 128;  // workgroups (per view) walking the long-list front of the launch order
 constexpr int kSortLds = 4096;  // keys sorted in LDS per tile (32 KiB); longer segments sort in global memory

@@ -985,3 +985,13 @@ def test_emulated_legacy_binning_matches_oracle(emu, mode):
                           1 / cam.fx, 1 / cam.fy, th, P(ws), ws.size, None)
     assert np.array_equal(ids, w_ids) and np.array_equal(td, w_td)
     assert np.array_equal(tn, w_n) and np.array_equal(off, w_off)
+
+
+def test_pair_count_is_read_as_uint32_and_a_diverged_scene_is_reported():
+    """renderer.pair_count: the device's uint32 pair count lives in an int32 tensor; beyond int32 (the kernels saturate at
+    2^32 - 1) no capacity can hold the frame -- an error naming the cause, not a negative number that 'fits'"""
+    from gsgen_amd import renderer as R
+    assert R.pair_count(np.int32(12345)) == 12345 and R.pair_count(0) == 0 and R.pair_count(np.int32(0x7FFFFFFF)) == 0x7FFFFFFF
+    for v in (np.int32(-1), np.int32(-2147483648), np.uint32(0x80000001)):
+        with pytest.raises(RuntimeError, match="diverged"):
+            R.pair_count(v)
