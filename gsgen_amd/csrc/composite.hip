@@ -38,20 +38,21 @@
 namespace gs {
 
 // ---- LDS staging ---------------------------------------------------------------------------
-template <int MODE, int CB, int KB = kBatch>
+// WITH_COL = false: no staged coefficients (the polynomial-basis kernels transform them straight from HBM, poly_transform)
+template <int MODE, int CB, int KB = kBatch, bool WITH_COL = true>
 struct Stage {
   using TR = Traits<MODE, CB>;
   float mx[KB], my[KB], a[KB];
   float c0[KB], c1[KB], c2[KB], c3[KB];
   float p0[KB], p1[KB], p2[KB];  // RGB/scalar: scaled Cholesky factor; SH: p0 = kk, p1 = 1/det
   int id[KB];
-  alignas(16) float col[KB * TR::NCOLP];
+  alignas(16) float col[WITH_COL ? KB * TR::NCOLP : 4];
 };
 
 // SCALE: the staged SH coefficients are pre-multiplied by -log2(e), so that the colour evaluation's
 // sigmoid(s) = 1 / (1 + exp2(-log2(e) s)) needs no multiply per (pixel, channel)
-template <int MODE, int CB, int NT, int KB = kBatch, bool SCALE = false>
-__device__ __forceinline__ void stage_batch(Stage<MODE, CB, KB> &S, const CompParams &p, int list_base,
+template <int MODE, int CB, int NT, int KB = kBatch, bool SCALE = false, bool WITH_COL = true>
+__device__ __forceinline__ void stage_batch(Stage<MODE, CB, KB, WITH_COL> &S, const CompParams &p, int list_base,
                                             int nb) {
   using TR = Traits<MODE, CB>;
   const int t = (int)threadIdx.x;
@@ -74,7 +75,9 @@ __device__ __forceinline__ void stage_batch(Stage<MODE, CB, KB> &S, const CompPa
   }
   if constexpr (MODE == MODE_SH) __syncthreads();  // S.id is consumed below by other lanes
   // colour / scalar / SH coefficients: NCOL contiguous floats per record in HBM
-  if constexpr (MODE == MODE_SH && TR::CCP == TR::CC) {
+  if constexpr (!WITH_COL) {
+    return;
+  } else if constexpr (MODE == MODE_SH && TR::CCP == TR::CC) {
     constexpr int Q = TR::NCOL / 4;
     for (int e = t; e < nb * Q; e += NT) {
       const int g = e / Q, k = e - g * Q;
@@ -99,8 +102,8 @@ __device__ __forceinline__ void stage_batch(Stage<MODE, CB, KB> &S, const CompPa
 }
 
 // per-Gaussian values broadcast from LDS into registers
-template <int MODE, int CB, int KB>
-__device__ __forceinline__ GRec load_rec(const Stage<MODE, CB, KB> &S, int g) {
+template <int MODE, int CB, int KB, bool WC>
+__device__ __forceinline__ GRec load_rec(const Stage<MODE, CB, KB, WC> &S, int g) {
   GRec r;
   r.mx = S.mx[g]; r.my = S.my[g]; r.a = S.a[g];
   r.c0 = S.c0[g]; r.c1 = S.c1[g]; r.c2 = S.c2[g]; r.c3 = S.c3[g];
@@ -346,17 +349,24 @@ __global__ void __launch_bounds__(TS * TS / PPL) k_composite_fwd(CompParams p_ar
 // coefficients are staged pre-scaled by -log2(e), and the two pixels' dot products are interleaved.  Decisions (skip,
 // saturated) come from gauss_sh_pair / the explicit T update, bit for bit those of every other kernel.  Same launch
 // shape and outputs (image, T, segment checkpoints and stop indices) as k_composite_fwd.
-template <int CB, int PPL, bool BATCH = false>
+// NB > 0 (= kPolyNB, SH degree 3 only): the tile-local polynomial form of the per-pixel basis, see composite_common.hpp --
+// the same kernel with 6-term contractions against coefficients transformed once per (tile, splat).
+template <int CB, int PPL, bool BATCH = false, int NB = 0>
 __global__ void __launch_bounds__(256 / PPL)
 k_composite_fwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
   static_assert(PPL == 4 || PPL == 2, "pixel pairs: 2 or 4 pixels per lane");
+  constexpr bool POLY = NB > 0;
+  static_assert(!POLY || (NB == kPolyNB && CB == 4), "polynomial basis: SH degree 3");
   uint32_t bid = blockIdx.x;
   const CompParams p = BATCH ? plist[batch_view(p_arg, bid)] : p_arg;  // see k_composite_fwd
   constexpr int MODE = MODE_SH;
   using TR = Traits<MODE, CB>;
   constexpr int NT = 256 / PPL, ROWS = NT / 16, NP = PPL / 2;
-  constexpr int CCP = TR::CCP, NPAIR = TR::NPAIR;
-  __shared__ Stage<MODE, CB> S;
+  constexpr int CCP = POLY ? NB : TR::CCP, NPAIR = CCP / 2;
+  __shared__ Stage<MODE, CB, kBatch, !POLY> S;
+  __shared__ alignas(16) float Vs[POLY ? kPolyNB * 16 : 4];           // POLY: V of this tile
+  __shared__ alignas(16) float Ws[POLY ? kBatch * 3 * kPolyNB : 4];   // POLY: transformed coefficients of the staged batch
+                                                                       // (and, before the first batch, the nine node bases)
 
   int tx, ty;
   if (!block_tile(p, tx, ty, bid)) return;  // uniform over the workgroup
@@ -386,7 +396,7 @@ k_composite_fwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
     }
     return;  // otherwise the caller's pre-initialised out / T stand (vol_render.h:1006-1013)
   }
-  if constexpr (CCP != TR::CC) {  // zero the pad lanes of the staged coefficients once
+  if constexpr (TR::CCP != TR::CC) {  // zero the pad lanes of the staged coefficients once
     for (int e = t; e < kBatch * TR::NCOLP; e += NT) S.col[e] = 0.0f;
     __syncthreads();
   }
@@ -396,7 +406,12 @@ k_composite_fwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
 #pragma unroll
   for (int j = 0; j < PPL; ++j) py2[j >> 1][j & 1] = pixel_coord(p.topleft[1], gy[j], p.psy);
   v2f Yp[PPL][NPAIR];
-  {
+  if constexpr (POLY) {
+    static_assert(kBatch * 3 * kPolyNB >= kPolyNodes * 16, "node scratch fits the coefficient buffer");
+    poly_tile_setup<NT>(p, tx, ty, Ws, Vs);
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) poly_monomials(lx, ly0 + j * ROWS, Yp[j]);
+  } else {
     float R[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) R[i] = p.rot[i];
@@ -426,8 +441,12 @@ k_composite_fwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
   for (int base = 0; base < n; base += kBatch) {
     const int nb = min(kBatch, n - base);
     if (base > 0) __syncthreads();  // everyone is done with the previous batch
-    stage_batch<MODE, CB, NT, kBatch, true>(S, p, st + base, nb);
+    stage_batch<MODE, CB, NT, kBatch, true, !POLY>(S, p, st + base, nb);
     __syncthreads();
+    if constexpr (POLY) {
+      poly_transform<NT, kBatch>(p.col, S.id, Vs, Ws, nb);
+      __syncthreads();
+    }
 
     for (int g = 0; g < nb; ++g) {
       bool any_alive = false;
@@ -478,7 +497,7 @@ k_composite_fwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
         }
       if (__ballot(any_con) == 0ull) continue;  // nobody in the wave sees this Gaussian
 
-      const float *cg = &S.col[g * TR::NCOLP];
+      const float *cg = POLY ? &Ws[g * 3 * CCP] : &S.col[g * TR::NCOLP];
       v2f w2[NP];
 #pragma unroll
       for (int jp = 0; jp < NP; ++jp) w2[jp] = (splat2(r_a) * Tr2[jp]) * G2[jp];  // (a T) G, or 0
@@ -794,21 +813,30 @@ k_composite_bwd_pixel(CompParams p_arg, const CompParams *__restrict__ plist) {
 // soon as a channel's accumulators are complete, the 7 geometric components likewise, one quad_reduce_scatter4 at the
 // end) instead of as one 64-component vector after the third channel: the same number of exchanges, but the finished
 // channels no longer sit in 32 registers while the next one is computed.
-template <int CB, int PPL, bool BATCH = false, bool CHRED = false>
+// NB > 0 (= kPolyNB; SH degree 3, CHRED, one wavefront per tile): the tile-local polynomial form of the per-pixel basis
+// (composite_common.hpp) -- 6-term contractions, 3 x 6 SH gradient components across the lanes, expanded by the tile's V
+// (through 24 floats of LDS) in front of the 48 atomics.
+template <int CB, int PPL, bool BATCH = false, bool CHRED = false, int NB = 0>
 __global__ void __launch_bounds__(256 / PPL) GSGEN_BWD_VEC_ATTR
 k_composite_bwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
   static_assert(PPL == 4 || PPL == 2, "pixel pairs: 2 or 4 pixels per lane");
+  constexpr bool POLY = NB > 0;
+  static_assert(!POLY || (NB == kPolyNB && CB == 4 && CHRED && PPL == 4), "polynomial basis: SH degree 3, one wavefront per tile");
   uint32_t bid = blockIdx.x, grid = gridDim.x;
   const CompParams p = BATCH ? plist[batch_view(p_arg, bid, &grid)] : p_arg;  // see k_composite_fwd
   constexpr int MODE = MODE_SH;
   using TR = Traits<MODE, CB>;
   constexpr int NT = 256 / PPL, ROWS = NT / 16, NP = PPL / 2;
-  constexpr int CCP = TR::CCP, NPAIR = TR::NPAIR, NSH = 3 * CCP;  // SH components incl. padding
+  constexpr int CCP = POLY ? NB : TR::CCP, NPAIR = CCP / 2, NSH = 3 * CCP;  // SH components incl. padding
   constexpr int P = (NSH + 7) <= 32 ? 32 : 64;                    // reduction width: SH | mean 2 | cov 4 | alpha 1
   static_assert(NSH % 2 == 0 && NSH + 7 <= P, "component layout");
   constexpr int KB = CHRED ? 32 : kBatch;  // CHRED: 10.6 KB of LDS per workgroup, 12+ workgroups per CU
-  __shared__ Stage<MODE, CB, KB> S;
+  __shared__ Stage<MODE, CB, KB, !POLY> S;
   __shared__ v2f go_s[CHRED ? 3 * NP * NT : 1];  // CHRED: grad_out of the lane's pixel pairs, [channel][pair][thread]
+  __shared__ alignas(16) float Vs[POLY ? kPolyNB * 16 : 4];      // POLY: V of this tile
+  __shared__ alignas(16) float Ws[POLY ? KB * 3 * kPolyNB : 4];  // POLY: transformed coefficients of the staged batch
+                                                                  // (and, before the first batch, the nine node bases)
+  __shared__ float gw_s[POLY ? 3 * 8 : 1];                       // POLY: a splat's reduced gradient in the tile's basis
 
   const int nseg = p.nseg > 1 ? p.nseg : 1;
   const uint32_t tiles_grid = grid / (uint32_t)nseg;
@@ -848,14 +876,22 @@ k_composite_bwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
     for (int j = 0; j < PPL; ++j) any |= alive0[j];
     if (__syncthreads_or((int)any) == 0) return;
   }
-  if constexpr (CCP != TR::CC) {  // zero the pad lanes of the staged coefficients once
+  if constexpr (TR::CCP != TR::CC) {  // zero the pad lanes of the staged coefficients once
     for (int e = t; e < KB * TR::NCOLP; e += NT) S.col[e] = 0.0f;
     __syncthreads();
   }
 
   // per-pixel SH basis as (k, k+1) pairs
   v2f Yp[PPL][NPAIR];
-  {
+  float Vk[POLY ? kPolyNB : 1];  // POLY: column (lane & 15) of V
+  if constexpr (POLY) {
+    static_assert(!POLY || KB * 3 * kPolyNB >= kPolyNodes * 16, "node scratch fits the coefficient buffer");
+    poly_tile_setup<NT>(p, tx, ty, Ws, Vs);
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) poly_monomials(lx, ly0 + j * ROWS, Yp[j]);
+#pragma unroll
+    for (int r = 0; r < kPolyNB; ++r) Vk[r] = Vs[r * 16 + (lane & 15)];
+  } else {
     float R[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) R[i] = p.rot[i];
@@ -897,8 +933,12 @@ k_composite_bwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
   for (int base = e_lo; base < e_hi; base += KB) {
     const int nb = min(KB, e_hi - base);
     if (base > e_lo) __syncthreads();
-    stage_batch<MODE, CB, NT, KB, true>(S, p, st + base, nb);
+    stage_batch<MODE, CB, NT, KB, true, !POLY>(S, p, st + base, nb);
     __syncthreads();
+    if constexpr (POLY) {
+      poly_transform<NT, KB>(p.col, S.id, Vs, Ws, nb);
+      __syncthreads();
+    }
 
     for (int g = 0; g < nb; ++g) {
       bool any_alive = false;
@@ -955,7 +995,7 @@ k_composite_bwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
 #pragma unroll
         for (int i = NSH / 2; i < P / 2; ++i) gr2[i] = v2f{0.0f, 0.0f};
       }
-      const float *cg = &S.col[g * TR::NCOLP];
+      const float *cg = POLY ? &Ws[g * 3 * CCP] : &S.col[g * TR::NCOLP];
       v2f w2[NP], inv1m2[NP], pAG2[NP];
 #pragma unroll
       for (int jp = 0; jp < NP; ++jp) {
@@ -1050,10 +1090,24 @@ k_composite_bwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
         const int m = lane & 3;  // the vector this lane ends up with: channel 0 / 1 / 2 / geometric
         const size_t id = (size_t)S.id[g];
         float *dst = nullptr;
-        if (m < 3) {
+        if constexpr (POLY) {
+          // d L / d sh[c][k] = sum_r gw[c][r] V[r][k]: the 18 reduced values go through LDS, lanes (c, k) = (lane / 16,
+          // lane % 16) expand them with their column of V (one wavefront per workgroup: the barrier is a wait)
+          if (m < 3 && scatter_rows_owner<PCH>(lane)) gw_s[m * 8 + scatter_comp<PCH>(lane)] = tot;
+          __syncthreads();
+          if (lane < 48) {
+            const float *gw = &gw_s[(lane >> 4) * 8];
+            float acc = gw[0] * Vk[0];
+#pragma unroll
+            for (int r = 1; r < kPolyNB; ++r) acc = fmaf(gw[r], Vk[r], acc);
+            atomicAdd(p.g_col + (size_t)TR::NCOL * id + lane, acc);  // (c, k) -> 16 c + k = lane
+          }
+          __syncthreads();  // the values are consumed before the next splat overwrites them
+        }
+        if (!POLY && m < 3) {
           const int k = scatter_comp<PCH>(lane);
           if (scatter_rows_owner<PCH>(lane) && k < TR::CC) dst = p.g_col + (size_t)TR::NCOL * id + m * TR::CC + k;
-        } else if (scatter_rows_owner<8>(lane)) {
+        } else if (m == 3 && scatter_rows_owner<8>(lane)) {
           const int e = scatter_comp<8>(lane);
           if (e < 2) dst = p.g_mean + 2 * id + e;
           else if (e < 6) dst = p.g_cov + 4 * id + (e - 2);
@@ -1768,7 +1822,18 @@ struct Variants {
   int sh_packed;  // GSGEN_BWD_SH_PACKED: 1 (default) = k_composite_bwd_sh_vec, 0 = k_composite_bwd_pixel<MODE_SH> (A/B)
   int sh_chred;   // GSGEN_BWD_SH_CHRED: channel-wise gradient reduction in k_composite_bwd_sh_vec at 4 pixels per lane
   int chan_packed;  // GSGEN_BWD_CHAN_PACKED: 1 (default) = k_composite_bwd_chan_vec for RGB / scalar / RGB + heads, 0 = k_composite_bwd_pixel
+  // GSGEN_SH_POLY: OPT-IN tile-local polynomial form of the per-pixel SH basis in the batched SH launches at degree 3
+  // (composite_common.hpp).  Value = the caller's bound S on a splat's sum of |non-constant SH coefficients| of one
+  // channel, in 1/16 units (GSGEN_SH_POLY=64: S = 4); 0 = off.  Used per launch only where the error bound holds (poly_ok).
+  int sh_poly;
 };
+// colour error of the degree-2 form <= 0.25 (sigmoid slope) x S x 0.7 delta^3, delta = half diagonal of a tile in camera
+// space (tools/tile_basis_error.py: 1.95e-6 at delta = 0.0141, 2.1e-5 at 0.0316); used when that stays below 1e-5
+static bool poly_ok(int sh_poly, float ps_max) {
+  if (sh_poly <= 0) return false;
+  const float S = (float)sh_poly * (1.0f / 16.0f), delta = 7.5f * 1.41421356f * ps_max;
+  return 0.25f * S * 0.7f * delta * delta * delta <= 1e-5f;
+}
 static int env_mfma(const char *name) {
   const char *v = getenv(name);
   if (!v) return 0;
@@ -1783,7 +1848,8 @@ static Variants &variants() {
                              getenv("GSGEN_BATCH_MAP") ? atoi(getenv("GSGEN_BATCH_MAP")) : 2,
                              getenv("GSGEN_BWD_SH_PACKED") ? (atoi(getenv("GSGEN_BWD_SH_PACKED")) != 0) : 1,
                              getenv("GSGEN_BWD_SH_CHRED") ? (atoi(getenv("GSGEN_BWD_SH_CHRED")) != 0) : 1,
-                             getenv("GSGEN_BWD_CHAN_PACKED") ? (atoi(getenv("GSGEN_BWD_CHAN_PACKED")) != 0) : 1};
+                             getenv("GSGEN_BWD_CHAN_PACKED") ? (atoi(getenv("GSGEN_BWD_CHAN_PACKED")) != 0) : 1,
+                             getenv("GSGEN_SH_POLY") ? atoi(getenv("GSGEN_SH_POLY")) : 0};
   return v;
 }
 
@@ -1877,9 +1943,16 @@ int write_params(const CompParams *host, uint32_t B, CompParams *dst, hipStream_
   return (int)hipGetLastError();
 }
 template <int CB>
-static void launch_fwd_sh_batch_c(const CompParams &p0, const CompParams *plist, uint32_t B, uint32_t nblk, hipStream_t s) {
+static void launch_fwd_sh_batch_c(const CompParams &p0, const CompParams *plist, uint32_t B, uint32_t nblk, hipStream_t s, bool poly) {
   const int ppl = variants().ppl_fwd_batch;  // wavefronts per tile = 4 / ppl
   const dim3 g(nblk * B);
+  if constexpr (CB == 4) {
+    if (poly) {  // opt-in: tile-local polynomial basis (forward and backward of a render take the same decision)
+      if (ppl == 4) hipLaunchKernelGGL((k_composite_fwd_sh_vec<4, 4, true, kPolyNB>), g, dim3(64), 0, s, p0, plist);
+      else hipLaunchKernelGGL((k_composite_fwd_sh_vec<4, 2, true, kPolyNB>), g, dim3(128), 0, s, p0, plist);
+      return;
+    }
+  }
   if (variants().sh_packed && ppl != 1) {
     if (ppl == 2) hipLaunchKernelGGL((k_composite_fwd_sh_vec<CB, 2, true>), g, dim3(128), 0, s, p0, plist);
     else hipLaunchKernelGGL((k_composite_fwd_sh_vec<CB, 4, true>), g, dim3(64), 0, s, p0, plist);
@@ -1898,21 +1971,28 @@ static CompParams batch_arg(const CompParams &p0, uint32_t B) {
   a.n_hi = variants().batch_map;
   return a;
 }
-int launch_fwd_sh_batch(int C, const CompParams &p0_, const CompParams *plist, uint32_t B, hipStream_t s) {
+int launch_fwd_sh_batch(int C, const CompParams &p0_, const CompParams *plist, uint32_t B, hipStream_t s, float ps_max) {
   const uint32_t nblk = comp_grid(p0_);
   if (p0_.ntw * p0_.nth == 0 || B == 0) return 0;
   const CompParams p0 = batch_arg(p0_, B);
+  const bool poly = C == 4 && poly_ok(variants().sh_poly, ps_max);
   switch (C) {
-    case 1: launch_fwd_sh_batch_c<1>(p0, plist, B, nblk, s); break;
-    case 2: launch_fwd_sh_batch_c<2>(p0, plist, B, nblk, s); break;
-    case 3: launch_fwd_sh_batch_c<3>(p0, plist, B, nblk, s); break;
-    default: launch_fwd_sh_batch_c<4>(p0, plist, B, nblk, s); break;
+    case 1: launch_fwd_sh_batch_c<1>(p0, plist, B, nblk, s, false); break;
+    case 2: launch_fwd_sh_batch_c<2>(p0, plist, B, nblk, s, false); break;
+    case 3: launch_fwd_sh_batch_c<3>(p0, plist, B, nblk, s, false); break;
+    default: launch_fwd_sh_batch_c<4>(p0, plist, B, nblk, s, poly); break;
   }
   return (int)hipGetLastError();
 }
 template <int CB>
-static void launch_bwd_sh_batch_c(const CompParams &p0, const CompParams *plist, uint32_t B, uint32_t nblk, hipStream_t s) {
+static void launch_bwd_sh_batch_c(const CompParams &p0, const CompParams *plist, uint32_t B, uint32_t nblk, hipStream_t s, bool poly) {
   const dim3 g(nblk * B);
+  if constexpr (CB == 4) {
+    if (poly) {
+      hipLaunchKernelGGL((k_composite_bwd_sh_vec<4, 4, true, true, kPolyNB>), g, dim3(64), 0, s, p0, plist);
+      return;
+    }
+  }
   const int mfma = variants().mfma_batch;
   if (mfma != 0) {  // opt-in matrix-core kernel
     const int w = mfma;
@@ -1932,15 +2012,16 @@ static void launch_bwd_sh_batch_c(const CompParams &p0, const CompParams *plist,
   else if (ppl == 2) hipLaunchKernelGGL((k_composite_bwd_pixel<MODE_SH, CB, 2, true>), g, dim3(128), 0, s, p0, plist);
   else hipLaunchKernelGGL((k_composite_bwd_pixel<MODE_SH, CB, 4, true>), g, dim3(64), 0, s, p0, plist);
 }
-int launch_bwd_sh_batch(int C, const CompParams &p0_, const CompParams *plist, uint32_t B, hipStream_t s) {
+int launch_bwd_sh_batch(int C, const CompParams &p0_, const CompParams *plist, uint32_t B, hipStream_t s, float ps_max) {
   const uint32_t nblk = comp_grid(p0_) * (uint32_t)(p0_.nseg > 1 ? p0_.nseg : 1);
   if (p0_.ntw * p0_.nth == 0 || B == 0) return 0;
   const CompParams p0 = batch_arg(p0_, B);
+  const bool poly = C == 4 && poly_ok(variants().sh_poly, ps_max);
   switch (C) {
-    case 1: launch_bwd_sh_batch_c<1>(p0, plist, B, nblk, s); break;
-    case 2: launch_bwd_sh_batch_c<2>(p0, plist, B, nblk, s); break;
-    case 3: launch_bwd_sh_batch_c<3>(p0, plist, B, nblk, s); break;
-    default: launch_bwd_sh_batch_c<4>(p0, plist, B, nblk, s); break;
+    case 1: launch_bwd_sh_batch_c<1>(p0, plist, B, nblk, s, false); break;
+    case 2: launch_bwd_sh_batch_c<2>(p0, plist, B, nblk, s, false); break;
+    case 3: launch_bwd_sh_batch_c<3>(p0, plist, B, nblk, s, false); break;
+    default: launch_bwd_sh_batch_c<4>(p0, plist, B, nblk, s, poly); break;
   }
   return (int)hipGetLastError();
 }
@@ -2041,6 +2122,7 @@ int gsgen_debug_set_variant(const char *name, int value) {
   else if (n == "sh_packed") { slot = &v.sh_packed; ok = value == 0 || value == 1; }
   else if (n == "sh_chred") { slot = &v.sh_chred; ok = value == 0 || value == 1; }
   else if (n == "chan_packed") { slot = &v.chan_packed; ok = value == 0 || value == 1; }
+  else if (n == "sh_poly") { slot = &v.sh_poly; ok = value >= 0 && value <= 4096; }
   if (!slot || !ok) return GSGEN_EINVAL;
   *slot = value;
   return 0;
@@ -2056,12 +2138,16 @@ int gsgen_kernel_variant(const char *stage, uint32_t C, uint32_t n_segments, cha
   char buf[160];
   int n = 0;
   auto sh_bwd = [&](int mfma, int ppl, const char *b) {
+    if (v.sh_poly > 0 && C == 4 && b[0] != 0)
+      return snprintf(buf, sizeof buf, "k_composite_bwd_sh_vec<C=4,PPL=4%s,CHRED,POLY6> where the bound allows", b);
     if (mfma) return snprintf(buf, sizeof buf, "k_composite_bwd_sh_mfma<C=%u,PPL=%d%s>%s", C, mfma, b, n_segments > 1 ? " segmented" : "");
     return snprintf(buf, sizeof buf, "%s<%sC=%u,PPL=%d%s%s>%s", (v.sh_packed && ppl != 1) ? "k_composite_bwd_sh_vec" : "k_composite_bwd_pixel",
                     (v.sh_packed && ppl != 1) ? "" : "SH,", C, ppl, b, (v.sh_packed && ppl == 4 && v.sh_chred) ? ",CHRED" : "",
                     n_segments > 1 ? " segmented" : "");
   };
   auto sh_fwd = [&](int ppl, const char *b) {
+    if (v.sh_poly > 0 && C == 4 && b[0] != 0)
+      return snprintf(buf, sizeof buf, "k_composite_fwd_sh_vec<C=4,PPL=%d%s,POLY6> where the bound allows", ppl == 4 ? 4 : 2, b);
     if (v.sh_packed && ppl != 1) return snprintf(buf, sizeof buf, "k_composite_fwd_sh_vec<C=%u,PPL=%d%s>", C, ppl, b);
     return snprintf(buf, sizeof buf, "k_composite_fwd<SH,C=%u,PPL=%d%s>", C, ppl, b);
   };
@@ -2224,6 +2310,12 @@ static int fill_view_params(uint32_t n_views, const gsgen_sh_view *views, const 
   return 0;
 }
 
+static float max_pixel_size(const std::vector<CompParams> &ps) {
+  float m = 0.0f;
+  for (const CompParams &p : ps) m = fmaxf(m, fmaxf(fabsf(p.psx), fabsf(p.psy)));
+  return m;
+}
+
 size_t gsgen_sh_batch_workspace_bytes(uint32_t n_views) { return 2 * (size_t)n_views * sizeof(CompParams); }
 
 int gsgen_vol_render_sh_batch(uint32_t n_views, const gsgen_sh_view *views, uint32_t N,
@@ -2244,7 +2336,7 @@ int gsgen_vol_render_sh_batch(uint32_t n_views, const gsgen_sh_view *views, uint
   hipStream_t s = (hipStream_t)stream;
   CompParams *dst = reinterpret_cast<CompParams *>(batch_workspace);
   if (int e = write_params(ps.data(), n_views, dst, s)) return e;
-  return launch_fwd_sh_batch((int)C, ps[0], dst, n_views, s);
+  return launch_fwd_sh_batch((int)C, ps[0], dst, n_views, s, max_pixel_size(ps));
 }
 
 int gsgen_vol_render_backward_sh_batch(uint32_t n_views, const gsgen_sh_view *views, uint32_t N,
@@ -2264,7 +2356,7 @@ int gsgen_vol_render_backward_sh_batch(uint32_t n_views, const gsgen_sh_view *vi
   hipStream_t s = (hipStream_t)stream;
   CompParams *dst = reinterpret_cast<CompParams *>(batch_workspace) + n_views;
   if (int e = write_params(ps.data(), n_views, dst, s)) return e;
-  return launch_bwd_sh_batch((int)C, ps[0], dst, n_views, s);
+  return launch_bwd_sh_batch((int)C, ps[0], dst, n_views, s, max_pixel_size(ps));
 }
 
 static int fill_rgbd_params(uint32_t n_views, const gsgen_rgbd_view *views, const float *color, const float *alpha,

@@ -302,6 +302,95 @@ __device__ __forceinline__ v2f gauss_chol_pair(float p0x, float p1, float p2, v2
   return v2f{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
 }
 
+// ---- tile-local polynomial form of the per-pixel SH basis (OPT-IN: GSGEN_SH_POLY=1, SH degree 3, batched launches) ----
+// The reference evaluates the SH basis per PIXEL, for dir = normalize(R (qx, qy, 1)) (vol_render_sh.h:48-65).  Inside a
+// 16x16 tile that direction moves by ~1e-2 rad, and Y[pixel][0..16) is a degree-2 polynomial in the tile-local offsets
+// (u, v) in [-1, 1]^2 to within 2e-6 of a basis value at f = image size (2e-5 at f = 0.7 x size: tools/tile_basis_error.py,
+// profiles/r02_notes.md): Y ~ U(u, v) V with U = (1, v, u, v^2, uv, u^2) and V[6][16] the least-squares fit through the exact
+// basis at the 3 x 3 nodes (u, v) in {-1, 0, 1}^2, set up once per tile.  The staged coefficients become
+// w[c][r] = sum_k V[r][k] sh[c][k] (18 values instead of 48, transformed once per (tile, splat)), the per-pixel contractions
+// are 6 terms instead of 16, 3 x 6 instead of 3 x 16 gradient components cross the lanes and are expanded by V in front of
+// the atomics.  The host enables it per launch only where the bound 0.25 * S * 0.7 * delta^3 (S: the caller's bound on a
+// splat's sum of |non-constant SH coefficients|, delta: the tile's half diagonal in camera space) stays below 1e-5.
+constexpr int kPolyNB = 6;
+constexpr int kPolyNodes = 9;
+constexpr float kPolyFit[kPolyNB][kPolyNodes] = {
+    {-0.111111111f, 0.222222222f, -0.111111111f, 0.222222222f, 0.555555556f, 0.222222222f, -0.111111111f, 0.222222222f, -0.111111111f},
+    {-0.166666667f, -0.166666667f, -0.166666667f, 0.0f, 0.0f, 0.0f, 0.166666667f, 0.166666667f, 0.166666667f},
+    {-0.166666667f, 0.0f, 0.166666667f, -0.166666667f, 0.0f, 0.166666667f, -0.166666667f, 0.0f, 0.166666667f},
+    {0.166666667f, 0.166666667f, 0.166666667f, -0.333333333f, -0.333333333f, -0.333333333f, 0.166666667f, 0.166666667f, 0.166666667f},
+    {0.25f, 0.0f, -0.25f, 0.0f, 0.0f, 0.0f, -0.25f, 0.0f, 0.25f},
+    {0.166666667f, -0.333333333f, 0.166666667f, 0.166666667f, -0.333333333f, 0.166666667f, 0.166666667f, -0.333333333f, 0.166666667f}};
+
+// tile-local offset of a pixel column / row index 0..15
+__device__ __forceinline__ float poly_offset(int l) { return ((float)l - 7.5f) * (1.0f / 7.5f); }
+// the six monomials of pixel (lx, ly) as (even, odd) pairs: (1, v) (u, v^2) (uv, u^2)
+__device__ __forceinline__ void poly_monomials(int lx, int ly, v2f (&U)[kPolyNB / 2]) {
+  const float u = poly_offset(lx), v = poly_offset(ly);
+  U[0] = v2f{1.0f, v};
+  U[1] = v2f{u, v * v};
+  U[2] = v2f{u * v, u * u};
+}
+// V[6][16] of tile (tx, ty) into LDS (Vs), through the exact basis at the nine nodes (Yn: 9 x 16 floats of LDS scratch).
+// All NT threads of the workgroup call it; ends with a barrier.  The fit's coefficients are compile-time literals of fully
+// unrolled loops (a table in memory, read through a dependent chain of loads, cost tens of microseconds per tile once the
+// memory system was busy with the launch's atomics).
+template <int NT>
+__device__ __forceinline__ void poly_tile_setup(const CompParams &p, int tx, int ty, float *Yn, float *Vs) {
+  const int t = (int)threadIdx.x;
+  if (t < kPolyNodes) {
+    float R[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = p.rot[i];
+    const float u = (float)(t % 3 - 1), v = (float)(t / 3 - 1);
+    const float qx = p.topleft[0] + ((float)(tx * kTile) + 7.5f + 7.5f * u) * p.psx;
+    const float qy = p.topleft[1] + ((float)(ty * kTile) + 7.5f + 7.5f * v) * p.psy;
+    float Yf[16];
+    sh_basis_of_pixel<4>(R, qx, qy, Yf);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) Yn[t * 16 + k] = Yf[k];
+  }
+  __syncthreads();
+  if (t < 16) {  // lane k: column k of V, all six rows
+    float y[kPolyNodes];
+#pragma unroll
+    for (int n = 0; n < kPolyNodes; ++n) y[n] = Yn[n * 16 + t];
+#pragma unroll
+    for (int r = 0; r < kPolyNB; ++r) {
+      float acc = 0.0f;
+#pragma unroll
+      for (int n = 0; n < kPolyNodes; ++n)
+        if (kPolyFit[r][n] != 0.0f) acc = fmaf(kPolyFit[r][n], y[n], acc);
+      Vs[r * 16 + t] = acc;
+    }
+  }
+  __syncthreads();
+}
+// the coefficients sh[id][3][16] of the nb staged splats, straight from HBM, -> w[nb][3][6] in LDS:
+// w[c][r] = -log2(e) sum_k V[r][k] sh[c][k]  (the scale of stage_batch<SCALE>: the colour evaluation's exp2 needs no multiply).
+// One (splat, channel) pair per lane and pass, rolled loops: 16 + 16 live registers.  (Loading a lane's two pairs together
+// hides one trip to memory per batch and costs 32 more registers -- a wavefront per SIMD; not taken.)
+template <int NT, int KB>
+__device__ __forceinline__ void poly_transform(const float *__restrict__ sh, const int *ids, const float *Vs, float *w, int nb) {
+#pragma unroll 1
+  for (int e = (int)threadIdx.x; e < nb * 3; e += NT) {
+    const int g = e / 3, c = e - 3 * g;
+    const float4 *q4 = reinterpret_cast<const float4 *>(sh + (size_t)ids[g] * 48 + c * 16);
+    const float4 q0 = q4[0], q1 = q4[1], q2 = q4[2], q3 = q4[3];
+#pragma unroll 1
+    for (int r = 0; r < kPolyNB; ++r) {
+      const float4 *v4 = reinterpret_cast<const float4 *>(Vs + r * 16);  // the same address in every lane: broadcast
+      const float4 a = v4[0], b = v4[1], cc = v4[2], d = v4[3];
+      float acc = q0.x * a.x;
+      acc = fmaf(q0.y, a.y, acc); acc = fmaf(q0.z, a.z, acc); acc = fmaf(q0.w, a.w, acc);
+      acc = fmaf(q1.x, b.x, acc); acc = fmaf(q1.y, b.y, acc); acc = fmaf(q1.z, b.z, acc); acc = fmaf(q1.w, b.w, acc);
+      acc = fmaf(q2.x, cc.x, acc); acc = fmaf(q2.y, cc.y, acc); acc = fmaf(q2.z, cc.z, acc); acc = fmaf(q2.w, cc.w, acc);
+      acc = fmaf(q3.x, d.x, acc); acc = fmaf(q3.y, d.y, acc); acc = fmaf(q3.z, d.z, acc); acc = fmaf(q3.w, d.w, acc);
+      w[e * kPolyNB + r] = -kLog2e * acc;
+    }
+  }
+}
+
 static inline int env_ppl(const char *name, int dflt) {
   const char *v = getenv(name);
   if (!v) return dflt;

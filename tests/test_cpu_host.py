@@ -936,10 +936,15 @@ def test_no_kernel_spills_and_hot_kernels_keep_their_occupancy(tmp_path):
     # wavefronts per tile: 3 per SIMD.  The unpacked A/B kernel (GSGEN_BWD_SH_PACKED=0) keeps its budgets too.
     # CHRED (default since round 2, session r2n): channel-wise reduction, grad_out in LDS, record in scalar registers:
     # THREE wavefronts per SIMD (<= 168 registers) and at least 12 workgroups per CU by LDS
-    for bwd in find(2, "k_composite_bwd_sh_vecILi4ELi4ELb", "ELb1EE"):
+    for bwd in find(2, "k_composite_bwd_sh_vecILi4ELi4ELb", "ELb1ELi0EE"):
         assert bwd["vgpr_count"] <= 168 and 12 * bwd["group_segment_fixed_size"] <= 160 * 1024, bwd
-    for bwd in find(2, "k_composite_bwd_sh_vecILi4ELi4ELb", "ELb0EE"):  # the 64-component reduction, A/B only
+    for bwd in find(2, "k_composite_bwd_sh_vecILi4ELi4ELb", "ELb0ELi0EE"):  # the 64-component reduction, A/B only
         assert bwd["vgpr_count"] <= 256 and 8 * bwd["group_segment_fixed_size"] <= 160 * 1024
+    # opt-in polynomial-basis kernels (batched launches only): no worse than the exact ones
+    for bwd in find(1, "k_composite_bwd_sh_vecILi4ELi4ELb1ELb1ELi6EE"):
+        assert bwd["vgpr_count"] <= 168 and 12 * bwd["group_segment_fixed_size"] <= 160 * 1024, bwd
+    for fwd in find(1, "k_composite_fwd_sh_vecILi4ELi2ELb1ELi6EE"):
+        assert fwd["vgpr_count"] <= 128 and 8 * fwd["group_segment_fixed_size"] <= 160 * 1024, fwd
     # packed backward of the post-activation modes (RGB + heads is the trainer's default): 4 wavefronts per SIMD
     for bwd in find(2, "k_composite_bwd_chan_vecILi3E"):
         assert bwd["vgpr_count"] <= 128, bwd
@@ -995,3 +1000,116 @@ def test_pair_count_is_read_as_uint32_and_a_diverged_scene_is_reported():
     for v in (np.int32(-1), np.int32(-2147483648), np.uint32(0x80000001)):
         with pytest.raises(RuntimeError, match="diverged"):
             R.pair_count(v)
+
+
+@pytest.mark.parametrize("nseg,ppl_fwd", [(0, 2), (3, 4)])
+def test_emulated_polynomial_sh_basis_batched_launches(emu, nseg, ppl_fwd):
+    """The opt-in tile-local polynomial form of the per-pixel SH basis (GSGEN_SH_POLY / variant "sh_poly": degree-2 fit of
+    the basis per tile, 6-term contractions, gradients expanded by the tile's V in front of the atomics; SH degree 3, batched
+    launches): against the oracle at north_star's tolerances, and against the exact kernels of the same launch -- the two
+    differ by the fit error only (1e-6-class at these focal lengths).  Launches whose camera is too wide for the error
+    bound stay on the exact kernels, bit for bit."""
+    from gsgen_amd._capi import ShView
+    C, W, H = 4, 40, 28
+    sc = scenes.random_scene(260, seed=17, svec=0.012, spread=0.035, C=C)
+    sc["sh"][:, :, 1:] *= 0.5  # sum of |non-constant coefficients| per channel inside the bound S = 4
+    assert np.abs(sc["sh"][:, :, 1:]).sum(-1).max() < 4.0
+    sc["alpha"] = (sc["alpha"] * 0.5).astype(np.float32)
+    Nall = sc["mean"].shape[0]
+    sh, al = np.ascontiguousarray(sc["sh"]), np.ascontiguousarray(sc["alpha"])
+    cams = [scenes.Camera(W, H, fx=520.0 + 60 * i, c2w=scenes.orbit(2.5, 10 + 20 * i, 40.0 + 100 * i)) for i in range(2)]
+    nth, ntw = cams[0].tiles
+    views = []
+    for i, cam in enumerate(cams):
+        g = scenes.oracle_geometry(sc, cam)
+        nz = np.nonzero(g["mask"])[0]
+        m2 = np.zeros((Nall, 2), np.float32); c2 = np.zeros((Nall, 2, 2), np.float32)
+        m2[nz] = g["mean2d"]; c2[nz] = g["cov2d"]
+        views.append(dict(g=g, nz=nz, m2=m2, c2=c2, st=g["start"], en=g["end"], ids=nz[g["ids"]].astype(np.int32), tlp=cam.topleft,
+                          rot=np.ascontiguousarray(cam.c2w[:3, :3].reshape(-1)), cam=cam, D=g["D"],
+                          bg=np.array([0.3, 0.1, 0.2], np.float32), go=np.random.default_rng(i).normal(size=(H, W, 3)).astype(np.float32)))
+    assert max((v["en"] - v["st"]).max() for v in views) > 40
+
+    def launch(fx_scale=1.0):
+        arr = (ShView * len(views))()
+        res = []
+        for a, v in zip(arr, views):
+            cam = v["cam"]
+            r = dict(ws=np.zeros(max(1, emu.segment_workspace_bytes(nth * ntw, nseg)), np.uint8), out=np.zeros((H, W, 3), np.float32),
+                     T=np.ones((H, W), np.float32), gm=np.zeros((Nall, 2), np.float32), gc=np.zeros((Nall, 4), np.float32))
+            a.mean, a.cov, a.start, a.end, a.gaussian_ids = P(v["m2"]), P(v["c2"]), P(v["st"]), P(v["en"]), P(v["ids"])
+            a.tile_order, a.topleft, a.c2w, a.bg_rgb = None, P(v["tlp"]), P(v["rot"]), P(v["bg"])
+            a.pixel_size_x, a.pixel_size_y = 1 / cam.fx, 1 / cam.fy
+            a.out, a.T, a.segment_workspace = P(r["out"]), P(r["T"]), (P(r["ws"]) if nseg else None)
+            a.grad_out, a.grad_mean, a.grad_cov = P(v["go"]), P(r["gm"]), P(r["gc"])
+            res.append(r)
+        bws = np.zeros(emu.sh_batch_workspace_bytes(len(views)), np.uint8)
+        emu.vol_render_sh_batch(len(views), arr, Nall, P(sh), P(al), 16, nth, ntw, H, W, C, 1e-4, nseg, P(bws), None)
+        gsh = np.zeros_like(sh); ga = np.zeros(Nall, np.float32)
+        emu.vol_render_backward_sh_batch(len(views), arr, Nall, P(sh), P(al), P(gsh), P(ga), 16, nth, ntw, H, W, C, 1e-4, nseg, P(bws), None)
+        return res, gsh, ga
+
+    emu.set_variant("ppl_fwd_batch", ppl_fwd)
+    try:
+        exact, e_gsh, e_ga = launch()
+        emu.set_variant("sh_poly", 64)  # S = 4
+        assert "POLY6" in emu.kernel_variant("sh_bwd_batch", 4) and "POLY6" in emu.kernel_variant("sh_fwd_batch", 4)
+        poly, p_gsh, p_ga = launch()
+    finally:
+        emu.set_variant("sh_poly", 0)
+        emu.set_variant("ppl_fwd_batch", 2)
+    want_gsh = np.zeros(sh.shape, np.float64); want_ga = np.zeros(Nall, np.float64)
+    for v, e, q in zip(views, exact, poly):
+        cam, g, nz = v["cam"], v["g"], v["nz"]
+        # the polynomial launch really ran (the images differ in the last bits) and differs by the fit error only
+        d = np.abs(q["out"] - e["out"]).max()
+        assert 0.0 < d <= 2e-5, d
+        assert np.array_equal(q["T"], e["T"])  # transmittance does not depend on colours
+        ref = O.render_sh_fwd(g["mean2d"], g["cov2d"], sh[nz], al[nz], g["start"], g["end"], g["ids"], cam.topleft, v["rot"], C,
+                              1 / cam.fx, 1 / cam.fy, H, W, bg=v["bg"])
+        scenes.assert_sh_image_parity(q["out"], ref, g["mean2d"], g["cov2d"], al[nz], g["start"], g["end"], g["ids"], cam.topleft,
+                                      1 / cam.fx, 1 / cam.fy, what="polynomial basis")
+        om, oc, osh, oa = O.render_sh_bwd(g["mean2d"], g["cov2d"], sh[nz], al[nz], g["start"], g["end"], g["ids"], ref, v["go"],
+                                          cam.topleft, v["rot"], C, 1 / cam.fx, 1 / cam.fy, H, W)
+        assert np.abs(q["gm"][nz] - om).max() <= 1e-3 * np.abs(om).max()
+        assert np.abs(q["gc"][nz] - oc.reshape(-1, 4)).max() <= 1e-3 * np.abs(oc).max()
+        want_gsh[nz] += osh; want_ga[nz] += oa
+    assert np.abs(p_gsh - want_gsh).max() <= 1e-3 * np.abs(want_gsh).max() and np.abs(want_gsh).max() > 0
+    assert np.abs(p_ga - want_ga).max() <= 1e-3 * np.abs(want_ga).max()
+    # ... and stays within 1e-4 of the exact kernels' gradients (relative to the largest entry)
+    assert np.abs(p_gsh - e_gsh).max() <= 1e-4 * np.abs(e_gsh).max()
+    assert np.abs(p_ga - e_ga).max() <= 1e-4 * np.abs(e_ga).max()
+
+
+def test_emulated_polynomial_sh_basis_is_not_used_beyond_its_error_bound(emu):
+    """a wide camera (pixel size 1/40: a tile spans 0.26 rad) with the knob on: the launch keeps the exact kernels, bit for bit"""
+    from gsgen_amd._capi import ShView
+    C, W, H = 4, 32, 16
+    sc = scenes.random_scene(200, seed=5, svec=0.1, C=C)
+    cam = scenes.Camera(W, H, fx=40.0)
+    g = scenes.oracle_geometry(sc, cam)
+    nz = np.nonzero(g["mask"])[0]
+    N = sc["mean"].shape[0]
+    m2 = np.zeros((N, 2), np.float32); c2 = np.zeros((N, 2, 2), np.float32)
+    m2[nz] = g["mean2d"]; c2[nz] = g["cov2d"]
+    ids = nz[g["ids"]].astype(np.int32)
+    sh, al = np.ascontiguousarray(sc["sh"]), np.ascontiguousarray(sc["alpha"])
+    rot = np.ascontiguousarray(cam.c2w[:3, :3].reshape(-1)); tlp = cam.topleft
+    nth, ntw = cam.tiles
+    outs = []
+    for knob in (0, 64):
+        emu.set_variant("sh_poly", knob)
+        try:
+            arr = (ShView * 1)()
+            out = np.zeros((H, W, 3), np.float32)
+            a = arr[0]
+            a.mean, a.cov, a.start, a.end, a.gaussian_ids = P(m2), P(c2), P(g["start"]), P(g["end"]), P(ids)
+            a.tile_order, a.topleft, a.c2w, a.bg_rgb = None, P(tlp), P(rot), None
+            a.pixel_size_x, a.pixel_size_y = 1 / cam.fx, 1 / cam.fy
+            a.out, a.T, a.segment_workspace = P(out), None, None
+            bws = np.zeros(emu.sh_batch_workspace_bytes(1), np.uint8)
+            emu.vol_render_sh_batch(1, arr, N, P(sh), P(al), 16, nth, ntw, H, W, C, 1e-4, 0, P(bws), None)
+            outs.append(out)
+        finally:
+            emu.set_variant("sh_poly", 0)
+    assert np.array_equal(outs[0], outs[1]) and np.abs(outs[0]).max() > 0.1

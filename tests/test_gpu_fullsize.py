@@ -354,3 +354,55 @@ def test_batched_heads_fuzz():
             got = P[k].grad.cpu().numpy()
             assert np.abs(got - want[k]).max() <= 1e-3 * np.abs(want[k]).max() + 1e-6, (k, B, W, H, n, seed, svec, opaque)
     run()
+
+
+def test_full_size_cfg2_polynomial_sh_basis():
+    """The OPT-IN tile-local polynomial form of the per-pixel SH basis (variant "sh_poly", composite_common.hpp) at the
+    headline size: two cfg2 cameras (100k Gaussians, 800x800, f = 800) through the batched launches with the knob on,
+    every pixel within 1e-4 of the oracle, every gradient within 1e-3 -- and within 1e-5 / 1e-4 of the exact kernels."""
+    from gsgen_amd import renderer as R, _capi
+    from gsgen_amd.batch import BatchRenderer
+    L = _capi.load()
+    sc = scenes.pointe_scene(100_000, seed=0, C=4)
+    assert float(np.abs(sc["sh"][:, :, 1:]).sum(-1).max()) < 4.0  # the bound the knob declares (S = 64 / 16)
+    N, W, H, B = sc["mean"].shape[0], 800, 800, 2
+    cams = [scenes.Camera(W, H, fx=800.0, c2w=scenes.orbit(2.5, 15.0, 30.0 + 45.0 * i)) for i in range(B)]
+    cis = [R.CameraInfo(*c.intr) for c in cams]
+    bg = np.array([0.1, 0.2, 0.3], np.float32)
+    gos = torch.randn(B, H, W, 3, device=dev(), generator=torch.Generator(device=dev()).manual_seed(5))
+    res = {}
+    for knob in (0, 64):
+        L.set_variant("sh_poly", knob)
+        try:
+            if knob:
+                assert "POLY6" in L.kernel_variant("sh_bwd_batch", 4)
+            P = {k: T_(sc[k]).requires_grad_(True) for k in KEYS}
+            br = BatchRenderer(N, W, H, dev(), max_batch=B)
+            for _ in range(2):
+                rgb, _ = br.render(P["mean"], P["qvec"], P["svec"], P["alpha"], P["sh"], cis, [c.c2w for c in cams], C=4, bg_rgb=T_(bg))
+                if br.ensure_capacity(B):
+                    break
+            (rgb * gos).sum().backward()
+            torch.cuda.synchronize()
+            res[knob] = (rgb.detach().cpu().numpy(), {k: P[k].grad.cpu().numpy() for k in KEYS})
+        finally:
+            L.set_variant("sh_poly", 0)
+    img_e, g_e = res[0]
+    img_p, g_p = res[64]
+    d = float(np.abs(img_p - img_e).max())
+    assert 0.0 < d <= 1e-5, d  # the polynomial kernels really ran, and differ by the fit error only
+    for k in ("alpha", "sh", "mean", "svec"):
+        assert rel_err(g_p[k], g_e[k]) < 1e-4, k
+    want = {k: np.zeros(sc[k].shape, np.float64) for k in KEYS}
+    for i, cam in enumerate(cams):
+        g, ref, gr = oracle_render(sc, cam, 4, gos[i].cpu().numpy(), bg)
+        m = g["mask"]
+        scenes.assert_sh_image_parity(img_p[i], ref, g["mean2d"], g["cov2d"], sc["alpha"][m], g["start"], g["end"], g["ids"],
+                                      cam.topleft, 1 / cam.fx, 1 / cam.fy, what=f"polynomial basis, camera {i}")
+        for k in KEYS:
+            want[k] += gr[k]
+    for k in KEYS:
+        if k == "qvec":  # isotropic scales: analytically zero, rounding noise on both sides
+            assert np.abs(g_p[k]).max() <= 1e-3 * np.abs(want["svec"]).max()
+            continue
+        assert rel_err(g_p[k], want[k]) < 1e-3, (k, rel_err(g_p[k], want[k]))
