@@ -179,6 +179,12 @@ def main():
                     help="1: a slot's geometry stage runs on its own HIGH-priority HIP stream, ahead of the other slot's compositing launch "
                          "instead of in its shadow (measured: 3 333 vs 3 361 renders/s -- the chip is busy either way, "
                          "profiles/r02_notes.md); 0 (default): everything of a slot on one stream")
+    ap.add_argument("--sh-basis", choices=["auto", "exact"], default=os.environ.get("GSGEN_BENCH_SH_BASIS", "auto"),
+                    help="auto: the batched SH launches are given the scene's coefficient bound (max over splats and channels "
+                         "of sum_{k>=1} |sh|, measured before the timed region) and take the tile-local polynomial form of the "
+                         "per-pixel SH basis where the library's error bound allows (images within 1e-5 of the exact kernels; "
+                         "include/gsgen_hip.h, gsgen_vol_render_sh_batch_bounded); exact: the exact kernels.  With auto the exact "
+                         "kernels are timed too and reported as `exact_basis`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the one-render-in-flight and hipGraph passes")
     args = ap.parse_args()
@@ -245,6 +251,11 @@ def main():
     topleft_dev = [torch.from_numpy(c.topleft).to(dev) for c in cams]
     bg = torch.tensor([0.1, 0.2, 0.3], device=dev)
     grad_out = torch.randn(H, W, 3, device=dev)
+    # the SH coefficient bound of the (static, HBM-resident) scene: one device pass + one sync, before any timed region
+    ps_max = max(max(1.0 / ci_.fx, 1.0 / ci_.fy) for ci_ in cis)
+    sh_bound_scene = R.sh_l1_bound(t["sh"]) if C == 4 else 0.0
+    state = {"sh_bound": sh_bound_scene if (args.sh_basis == "auto" and C == 4) else 0.0}
+    poly_applies = bool(state["sh_bound"] > 0 and lib.sh_poly_applies(state["sh_bound"], ps_max, C))
     p = lambda x: x.data_ptr()  # noqa: E731
     vtab = lambda vals: (ctypes.c_void_p * len(vals))(*vals)  # noqa: E731
     clock = HostClock()
@@ -328,8 +339,8 @@ def main():
             clock.acc["events"] = clock.acc.get("events", 0.0) + time.perf_counter() - t0
         if ev is not None:
             clock.call("events", ev[0].record, stream)
-        clock.call("composite_fwd", lib.vol_render_sh_batch, B, views, N, p(t["sh"]), p(t["alpha"]), 16, nth, ntw, H, W, C,
-                   1e-4, seg_arg, p(sl.bws), s)
+        clock.call("composite_fwd", lib.vol_render_sh_batch_bounded, B, views, N, p(t["sh"]), p(t["alpha"]), 16, nth, ntw, H, W, C,
+                   1e-4, seg_arg, state["sh_bound"], p(sl.bws), s)
         if ev is not None:
             clock.call("events", ev[1].record, stream)
         if sl.gathered is not None and gather:
@@ -347,8 +358,8 @@ def main():
         clock.acc["zero_grads"] = clock.acc.get("zero_grads", 0.0) + time.perf_counter() - t0
         if ev is not None:
             clock.call("events", ev[2].record, stream)
-        clock.call("composite_bwd", lib.vol_render_backward_sh_batch, B, views, N, p(t["sh"]), p(t["alpha"]), p(sl.g_sh),
-                   p(sl.g_alpha), 16, nth, ntw, H, W, C, 1e-4, seg_arg, p(sl.bws), s)
+        clock.call("composite_bwd", lib.vol_render_backward_sh_batch_bounded, B, views, N, p(t["sh"]), p(t["alpha"]), p(sl.g_sh),
+                   p(sl.g_alpha), 16, nth, ntw, H, W, C, 1e-4, seg_arg, state["sh_bound"], p(sl.bws), s)
         if ev is not None:
             clock.call("events", ev[3].record, stream)
         clock.call("project_bwd", lib.project_gaussians_backward_batch, B, N, p(t["mean"]), p(t["qvec"]), p(t["svec"]), *proj,
@@ -417,6 +428,23 @@ def main():
     med = regions[int(order[len(order) // 2])]
     el, fwd_ms, bwd_ms = med["el"], med["fwd_ms"], med["bwd_ms"]
     value = world * B * K / el
+
+    # ---- the same timed region with the exact per-pixel SH basis (when the headline used the polynomial form) ----------------
+    exact_basis = None
+    if poly_applies:
+        keep = state["sh_bound"]
+        state["sh_bound"] = 0.0
+        for i in range(max(2, len(slots))):
+            run_step(i, evs[i % K])
+        ex = [region(args.warmup + r * K) for r in range(min(3, n_rep))]
+        exm = sorted(ex, key=lambda r_: r_["el"])[len(ex) // 2]
+        exact_basis = {"value": world * B * K / exm["el"], "ms_per_step": exm["el"] / K * 1e3, "bwd_launch_ms": exm["bwd_ms"],
+                       "fwd_launch_ms": exm["fwd_ms"], "bwd_kernel": lib.kernel_variant("sh_bwd_batch", C, nseg),
+                       "fwd_kernel": lib.kernel_variant("sh_fwd_batch", C, nseg)}
+        state["sh_bound"] = keep
+        for i in range(max(2, len(slots))):  # back to the headline's kernels for the secondary views
+            run_step(i, evs[i % K])
+        barrier()
 
     # ---- secondary views ---------------------------------------------------------------------------------------------
     # (a) one batch in flight: the duration of a launch that has the chip to itself
@@ -528,8 +556,8 @@ def main():
     P, T = W * H, nth * ntw
     F = 7 + CC3
     total_b, parts = b_alg_bytes(n_vis, D, P, T, F)
-    bwd_name = lib.kernel_variant("sh_bwd_batch", C, nseg)
-    fwd_name = lib.kernel_variant("sh_fwd_batch", C, nseg)
+    bwd_name = lib.kernel_variant("sh_bwd_batch_poly" if poly_applies else "sh_bwd_batch", C, nseg)
+    fwd_name = lib.kernel_variant("sh_fwd_batch_poly" if poly_applies else "sh_fwd_batch", C, nseg)
     traffic, traffic_src, valu_floor = None, None, None
     try:  # HBM bytes per launch of the dominant kernel from committed PMC passes, if they are of THIS kernel and workload
         pmc_all = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
@@ -548,7 +576,11 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": WORKLOADS[args.config], "gaussians": N, "visible_after_cull": n_vis, "image": [H, W],
                    "sh_degree": C - 1, "tile_pairs_D": D, "cameras_per_step": B, "steps_in_flight": len(slots),
-                   "backward_segments_per_tile": nseg, "geometry_stream": "high priority, per slot" if args.geo_priority else "the slot's stream",
+                   "backward_segments_per_tile": nseg,
+                   "sh_basis": (f"tile-local degree-2 polynomial fit of the per-pixel basis (coefficient bound {state['sh_bound']:.3f}, "
+                                f"largest pixel size {ps_max:.3g}: error bound {0.25 * state['sh_bound'] * 0.7 * (7.5 * 2 ** 0.5 * ps_max) ** 3:.1e} "
+                                "of a colour value; gsgen_vol_render_sh_batch_bounded)") if poly_applies else "exact per-pixel basis",
+                   "geometry_stream": "high priority, per slot" if args.geo_priority else "the slot's stream",
                    "parallelism": f"camera-sharded x{world}",
                    "gather": ("one rccl all_gather of the step's rendered images, on its own stream behind the step's forward"
                               if dist is not None else "none")},
@@ -580,6 +612,8 @@ def main():
         # SIMD issued its share of the measured vector instructions back to back
         res["roofline"]["valu_floor_ms"] = valu_floor
         res["roofline"]["alone_valu_frac"] = valu_floor / alone["bwd_launch_ms"]
+    if exact_basis is not None:
+        res["exact_basis"] = exact_basis
     if one is not None:
         res["one_render_in_flight"] = one
     if rank == 0:

@@ -83,6 +83,10 @@ SIGNATURES = {
     "gsgen_vol_render_sh_batch": [u32, C.POINTER(ShView), u32, vp, vp, u32, u32, u32, u32, u32, u32, f32, u32, vp, vp],
     "gsgen_vol_render_backward_sh_batch": [u32, C.POINTER(ShView), u32, vp, vp, vp, vp, u32, u32, u32, u32, u32, u32,
                                            f32, u32, vp, vp],
+    "gsgen_vol_render_sh_batch_bounded": [u32, C.POINTER(ShView), u32, vp, vp, u32, u32, u32, u32, u32, u32, f32, u32, f32, vp, vp],
+    "gsgen_vol_render_backward_sh_batch_bounded": [u32, C.POINTER(ShView), u32, vp, vp, vp, vp, u32, u32, u32, u32, u32, u32,
+                                                   f32, u32, f32, vp, vp],
+    "gsgen_sh_l1_bound": [u32, vp, u32, vp, vp],
     "gsgen_vol_render_rgbd_batch": [u32, C.POINTER(RgbdView), u32, vp, vp, u32, u32, u32, u32, u32, f32, vp, vp],
     "gsgen_vol_render_rgbd_backward_batch": [u32, C.POINTER(RgbdView), u32, vp, vp, vp, u32, u32, u32, u32, u32, f32, vp,
                                              vp],
@@ -106,7 +110,7 @@ SIZE_FUNCS = {
     "gsgen_legacy_sort_workspace_bytes": [u32, u32],
 }
 EXPORTS = sorted(list(SIGNATURES) + list(SIZE_FUNCS) + list(PTR_FUNCS)
-                 + ["gsgen_version", "gsgen_error_string", "gsgen_kernel_variant", "gsgen_debug_set_variant"])
+                 + ["gsgen_version", "gsgen_error_string", "gsgen_kernel_variant", "gsgen_debug_set_variant", "gsgen_sh_poly_applies"])
 
 
 class GsgenError(RuntimeError):
@@ -170,6 +174,12 @@ class Lib:
         fn.argtypes, fn.restype = [C.c_char_p, i32], i32
         if fn(name.encode(), int(value)) != 0:
             raise ValueError(f"bad kernel variant {name}={value}")
+
+    def sh_poly_applies(self, sh_l1_bound, max_pixel_size, bands=4):
+        """does a batched SH launch with this coefficient bound and largest pixel size take the polynomial basis?"""
+        fn = self.cdll.gsgen_sh_poly_applies
+        fn.argtypes, fn.restype = [f32, f32, u32], i32
+        return bool(fn(float(sh_l1_bound), float(max_pixel_size), int(bands)))
 
     def kernel_variant(self, stage, bands=4, n_segments=1):
         """name of the compiled compositing kernel a launch of `stage` runs in this process (bands = C)"""

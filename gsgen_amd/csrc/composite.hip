@@ -1829,9 +1829,9 @@ struct Variants {
 };
 // colour error of the degree-2 form <= 0.25 (sigmoid slope) x S x 0.7 delta^3, delta = half diagonal of a tile in camera
 // space (tools/tile_basis_error.py: 1.95e-6 at delta = 0.0141, 2.1e-5 at 0.0316); used when that stays below 1e-5
-static bool poly_ok(int sh_poly, float ps_max) {
-  if (sh_poly <= 0) return false;
-  const float S = (float)sh_poly * (1.0f / 16.0f), delta = 7.5f * 1.41421356f * ps_max;
+static bool poly_ok(float S, float ps_max) {
+  if (!(S > 0.0f)) return false;
+  const float delta = 7.5f * 1.41421356f * ps_max;
   return 0.25f * S * 0.7f * delta * delta * delta <= 1e-5f;
 }
 static int env_mfma(const char *name) {
@@ -1971,11 +1971,14 @@ static CompParams batch_arg(const CompParams &p0, uint32_t B) {
   a.n_hi = variants().batch_map;
   return a;
 }
-int launch_fwd_sh_batch(int C, const CompParams &p0_, const CompParams *plist, uint32_t B, hipStream_t s, float ps_max) {
+// sh_bound: the caller's bound S for the polynomial basis (< 0: the process-wide default of GSGEN_SH_POLY, in 1/16 units)
+static float sh_bound_or_default(float sh_bound) { return sh_bound >= 0.0f ? sh_bound : (float)variants().sh_poly * (1.0f / 16.0f); }
+
+int launch_fwd_sh_batch(int C, const CompParams &p0_, const CompParams *plist, uint32_t B, hipStream_t s, float ps_max, float sh_bound) {
   const uint32_t nblk = comp_grid(p0_);
   if (p0_.ntw * p0_.nth == 0 || B == 0) return 0;
   const CompParams p0 = batch_arg(p0_, B);
-  const bool poly = C == 4 && poly_ok(variants().sh_poly, ps_max);
+  const bool poly = C == 4 && poly_ok(sh_bound_or_default(sh_bound), ps_max);
   switch (C) {
     case 1: launch_fwd_sh_batch_c<1>(p0, plist, B, nblk, s, false); break;
     case 2: launch_fwd_sh_batch_c<2>(p0, plist, B, nblk, s, false); break;
@@ -2012,11 +2015,11 @@ static void launch_bwd_sh_batch_c(const CompParams &p0, const CompParams *plist,
   else if (ppl == 2) hipLaunchKernelGGL((k_composite_bwd_pixel<MODE_SH, CB, 2, true>), g, dim3(128), 0, s, p0, plist);
   else hipLaunchKernelGGL((k_composite_bwd_pixel<MODE_SH, CB, 4, true>), g, dim3(64), 0, s, p0, plist);
 }
-int launch_bwd_sh_batch(int C, const CompParams &p0_, const CompParams *plist, uint32_t B, hipStream_t s, float ps_max) {
+int launch_bwd_sh_batch(int C, const CompParams &p0_, const CompParams *plist, uint32_t B, hipStream_t s, float ps_max, float sh_bound) {
   const uint32_t nblk = comp_grid(p0_) * (uint32_t)(p0_.nseg > 1 ? p0_.nseg : 1);
   if (p0_.ntw * p0_.nth == 0 || B == 0) return 0;
   const CompParams p0 = batch_arg(p0_, B);
-  const bool poly = C == 4 && poly_ok(variants().sh_poly, ps_max);
+  const bool poly = C == 4 && poly_ok(sh_bound_or_default(sh_bound), ps_max);
   switch (C) {
     case 1: launch_bwd_sh_batch_c<1>(p0, plist, B, nblk, s, false); break;
     case 2: launch_bwd_sh_batch_c<2>(p0, plist, B, nblk, s, false); break;
@@ -2137,24 +2140,25 @@ int gsgen_kernel_variant(const char *stage, uint32_t C, uint32_t n_segments, cha
   const std::string st(stage);
   char buf[160];
   int n = 0;
+  const bool poly_stage = st.size() > 5 && st.compare(st.size() - 5, 5, "_poly") == 0;
   auto sh_bwd = [&](int mfma, int ppl, const char *b) {
-    if (v.sh_poly > 0 && C == 4 && b[0] != 0)
-      return snprintf(buf, sizeof buf, "k_composite_bwd_sh_vec<C=4,PPL=4%s,CHRED,POLY6> where the bound allows", b);
+    if ((poly_stage || v.sh_poly > 0) && C == 4 && b[0] != 0)
+      return snprintf(buf, sizeof buf, "k_composite_bwd_sh_vec<C=4,PPL=4%s,CHRED,POLY6>%s", b, poly_stage ? "" : " where the bound allows");
     if (mfma) return snprintf(buf, sizeof buf, "k_composite_bwd_sh_mfma<C=%u,PPL=%d%s>%s", C, mfma, b, n_segments > 1 ? " segmented" : "");
     return snprintf(buf, sizeof buf, "%s<%sC=%u,PPL=%d%s%s>%s", (v.sh_packed && ppl != 1) ? "k_composite_bwd_sh_vec" : "k_composite_bwd_pixel",
                     (v.sh_packed && ppl != 1) ? "" : "SH,", C, ppl, b, (v.sh_packed && ppl == 4 && v.sh_chred) ? ",CHRED" : "",
                     n_segments > 1 ? " segmented" : "");
   };
   auto sh_fwd = [&](int ppl, const char *b) {
-    if (v.sh_poly > 0 && C == 4 && b[0] != 0)
-      return snprintf(buf, sizeof buf, "k_composite_fwd_sh_vec<C=4,PPL=%d%s,POLY6> where the bound allows", ppl == 4 ? 4 : 2, b);
+    if ((poly_stage || v.sh_poly > 0) && C == 4 && b[0] != 0)
+      return snprintf(buf, sizeof buf, "k_composite_fwd_sh_vec<C=4,PPL=%d%s,POLY6>%s", ppl == 4 ? 4 : 2, b, poly_stage ? "" : " where the bound allows");
     if (v.sh_packed && ppl != 1) return snprintf(buf, sizeof buf, "k_composite_fwd_sh_vec<C=%u,PPL=%d%s>", C, ppl, b);
     return snprintf(buf, sizeof buf, "k_composite_fwd<SH,C=%u,PPL=%d%s>", C, ppl, b);
   };
   if (st == "sh_fwd") n = sh_fwd(v.ppl_fwd, "");
-  else if (st == "sh_fwd_batch") n = sh_fwd(v.ppl_fwd_batch, ",BATCH");
+  else if (st == "sh_fwd_batch" || st == "sh_fwd_batch_poly") n = sh_fwd(v.ppl_fwd_batch, ",BATCH");
   else if (st == "sh_bwd") n = sh_bwd(v.mfma, v.ppl_bwd, "");
-  else if (st == "sh_bwd_batch") n = sh_bwd(v.mfma_batch, v.ppl_bwd_sh_batch, ",BATCH");
+  else if (st == "sh_bwd_batch" || st == "sh_bwd_batch_poly") n = sh_bwd(v.mfma_batch, v.ppl_bwd_sh_batch, ",BATCH");
   else if (st == "rgb_fwd") n = snprintf(buf, sizeof buf, "k_composite_fwd<RGB,PPL=%d>", v.ppl_fwd);
   else if (st == "rgb_bwd") n = (v.chan_packed && v.ppl_bwd == 4) ? snprintf(buf, sizeof buf, "k_composite_bwd_chan_vec<RGB>")
                                                                    : snprintf(buf, sizeof buf, "k_composite_bwd_pixel<RGB,PPL=%d>", v.ppl_bwd);
@@ -2310,6 +2314,34 @@ static int fill_view_params(uint32_t n_views, const gsgen_sh_view *views, const 
   return 0;
 }
 
+// max over splats and channels of sum_{k >= 1} |sh[i][c][k]|, max-accumulated into *out (non-negative floats order like
+// their bit patterns)
+__global__ void __launch_bounds__(256) k_sh_l1_bound(uint32_t n_rows, const float *__restrict__ sh, int CC, float *out) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  float v = 0.0f;
+  if (i < n_rows) {
+    const float *q = sh + (size_t)i * CC;
+    for (int k = 1; k < CC; ++k) v += fabsf(q[k]);
+    if (!(v == v)) v = 3.0e38f;  // NaN coefficients: no bound
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d));
+  if ((threadIdx.x & 63) == 0 && v > 0.0f) atomicMax(reinterpret_cast<unsigned int *>(out), __float_as_uint(v));
+}
+
+int gsgen_sh_l1_bound(uint32_t N, const float *sh_coeffs, uint32_t C, float *out, gsgen_stream_t stream) {
+  if (C < 1 || C > 4) return GSGEN_EUNSUPPORTED;
+  if (!out || (N && !sh_coeffs)) return GSGEN_EINVAL;
+  if (N == 0) return 0;
+  const uint32_t rows = 3u * N;
+  hipLaunchKernelGGL(k_sh_l1_bound, dim3((rows + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, rows, sh_coeffs, (int)(C * C), out);
+  return (int)hipGetLastError();
+}
+
+int gsgen_sh_poly_applies(float sh_l1_bound, float max_pixel_size, uint32_t C) {
+  return (C == 4 && poly_ok(sh_bound_or_default(sh_l1_bound), max_pixel_size)) ? 1 : 0;
+}
+
 static float max_pixel_size(const std::vector<CompParams> &ps) {
   float m = 0.0f;
   for (const CompParams &p : ps) m = fmaxf(m, fmaxf(fabsf(p.psx), fabsf(p.psy)));
@@ -2323,6 +2355,15 @@ int gsgen_vol_render_sh_batch(uint32_t n_views, const gsgen_sh_view *views, uint
                               uint32_t n_tiles_h, uint32_t n_tiles_w, uint32_t H, uint32_t W, uint32_t C,
                               float thresh, uint32_t n_segments, void *batch_workspace,
                               gsgen_stream_t stream) {
+  return gsgen_vol_render_sh_batch_bounded(n_views, views, N, sh_coeffs, alpha, tile_size, n_tiles_h, n_tiles_w, H, W, C,
+                                           thresh, n_segments, -1.0f, batch_workspace, stream);
+}
+
+int gsgen_vol_render_sh_batch_bounded(uint32_t n_views, const gsgen_sh_view *views, uint32_t N,
+                                      const float *sh_coeffs, const float *alpha, uint32_t tile_size,
+                                      uint32_t n_tiles_h, uint32_t n_tiles_w, uint32_t H, uint32_t W, uint32_t C,
+                                      float thresh, uint32_t n_segments, float sh_l1_bound, void *batch_workspace,
+                                      gsgen_stream_t stream) {
   if (tile_size != 16) return GSGEN_EUNSUPPORTED;
   if (C < 1 || C > 4) return GSGEN_EUNSUPPORTED;
   if (n_views == 0) return 0;
@@ -2336,7 +2377,7 @@ int gsgen_vol_render_sh_batch(uint32_t n_views, const gsgen_sh_view *views, uint
   hipStream_t s = (hipStream_t)stream;
   CompParams *dst = reinterpret_cast<CompParams *>(batch_workspace);
   if (int e = write_params(ps.data(), n_views, dst, s)) return e;
-  return launch_fwd_sh_batch((int)C, ps[0], dst, n_views, s, max_pixel_size(ps));
+  return launch_fwd_sh_batch((int)C, ps[0], dst, n_views, s, max_pixel_size(ps), sh_l1_bound);
 }
 
 int gsgen_vol_render_backward_sh_batch(uint32_t n_views, const gsgen_sh_view *views, uint32_t N,
@@ -2344,6 +2385,17 @@ int gsgen_vol_render_backward_sh_batch(uint32_t n_views, const gsgen_sh_view *vi
                                        float *grad_alpha, uint32_t tile_size, uint32_t n_tiles_h,
                                        uint32_t n_tiles_w, uint32_t H, uint32_t W, uint32_t C, float thresh,
                                        uint32_t n_segments, void *batch_workspace, gsgen_stream_t stream) {
+  return gsgen_vol_render_backward_sh_batch_bounded(n_views, views, N, sh_coeffs, alpha, grad_sh_coeffs, grad_alpha, tile_size,
+                                                    n_tiles_h, n_tiles_w, H, W, C, thresh, n_segments, -1.0f, batch_workspace,
+                                                    stream);
+}
+
+int gsgen_vol_render_backward_sh_batch_bounded(uint32_t n_views, const gsgen_sh_view *views, uint32_t N,
+                                               const float *sh_coeffs, const float *alpha, float *grad_sh_coeffs,
+                                               float *grad_alpha, uint32_t tile_size, uint32_t n_tiles_h,
+                                               uint32_t n_tiles_w, uint32_t H, uint32_t W, uint32_t C, float thresh,
+                                               uint32_t n_segments, float sh_l1_bound, void *batch_workspace,
+                                               gsgen_stream_t stream) {
   if (tile_size != 16) return GSGEN_EUNSUPPORTED;
   if (C < 1 || C > 4) return GSGEN_EUNSUPPORTED;
   if (n_views == 0 || N == 0) return 0;
@@ -2356,7 +2408,7 @@ int gsgen_vol_render_backward_sh_batch(uint32_t n_views, const gsgen_sh_view *vi
   hipStream_t s = (hipStream_t)stream;
   CompParams *dst = reinterpret_cast<CompParams *>(batch_workspace) + n_views;
   if (int e = write_params(ps.data(), n_views, dst, s)) return e;
-  return launch_bwd_sh_batch((int)C, ps[0], dst, n_views, s, max_pixel_size(ps));
+  return launch_bwd_sh_batch((int)C, ps[0], dst, n_views, s, max_pixel_size(ps), sh_l1_bound);
 }
 
 static int fill_rgbd_params(uint32_t n_views, const gsgen_rgbd_view *views, const float *color, const float *alpha,

@@ -198,6 +198,20 @@ def n_tiles(H, W, tile_size=16):
     return (H + tile_size - 1) // tile_size, (W + tile_size - 1) // tile_size
 
 
+def sh_l1_bound(sh, margin=1.05):
+    """max over splats and channels of sum_{k >= 1} |sh[i][c][k]| (times a safety margin), as a Python float: the bound
+    BatchRenderer.render(..., sh_l1_bound=) / gsgen_vol_render_sh_batch_bounded want.  One pass over the coefficients on
+    the device and ONE host sync -- compute it when the coefficients change materially (or every few steps with a larger
+    margin), not per render."""
+    sh = sh.detach().contiguous()
+    out = torch.zeros(1, device=sh.device, dtype=torch.float32)
+    C2 = sh.shape[-1]
+    C = int(round(C2 ** 0.5))
+    with torch.cuda.device(sh.device):
+        _capi.load().sh_l1_bound(sh.shape[0], _p(sh), C, _p(out), _stream(sh))
+    return float(out.item()) * float(margin)
+
+
 def pair_count(v):
     """The device's uint32 pair count as a Python int (it lives in an int32 tensor).  Beyond int32 -- the kernels saturate at
     2^32 - 1 -- no pair buffer can hold the frame (list positions are int32 in the reference's layout): that is a diverged

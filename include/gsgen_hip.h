@@ -378,6 +378,32 @@ int gsgen_vol_render_backward_sh_batch(uint32_t n_views, const gsgen_sh_view *vi
                                        uint32_t n_tiles_w, uint32_t H, uint32_t W, uint32_t C, float thresh,
                                        uint32_t n_segments, void *batch_workspace, gsgen_stream_t stream);
 
+/* The same two launches with the caller's BOUND on the SH coefficients: sh_l1_bound >= max over splats and channels of
+ * sum_{k >= 1} |sh[i][c][k]| (gsgen_sh_l1_bound computes it on the device).  With a bound, SH degree 3 (C = 4) and cameras
+ * narrow enough, the launch uses the tile-local polynomial form of the per-pixel SH basis: the reference evaluates the basis
+ * per pixel for dir = normalize(R (qx, qy, 1)) (vol_render_sh.h:48-65), and inside a 16 x 16 tile that is a degree-2
+ * polynomial in the pixel offsets to within 0.7 delta^3 of a basis value (delta = the tile's half diagonal in camera
+ * space) -- six-term contractions against coefficients transformed once per (tile, splat), +20 % renders/s on BASELINE
+ * configs[1].  It is taken only where 0.25 * sh_l1_bound * 0.7 * delta^3 <= 1e-5 (a tenth of the 1e-4 image tolerance;
+ * gsgen_sh_poly_applies reports the decision), otherwise -- and always with sh_l1_bound = 0 -- the exact kernels run.  A
+ * forward and its backward must be given the same bound.  sh_l1_bound < 0: the process-wide default (GSGEN_SH_POLY, off). */
+int gsgen_vol_render_sh_batch_bounded(uint32_t n_views, const gsgen_sh_view *views, uint32_t N,
+                                      const float *sh_coeffs, const float *alpha, uint32_t tile_size,
+                                      uint32_t n_tiles_h, uint32_t n_tiles_w, uint32_t H, uint32_t W, uint32_t C,
+                                      float thresh, uint32_t n_segments, float sh_l1_bound, void *batch_workspace,
+                                      gsgen_stream_t stream);
+int gsgen_vol_render_backward_sh_batch_bounded(uint32_t n_views, const gsgen_sh_view *views, uint32_t N,
+                                               const float *sh_coeffs, const float *alpha, float *grad_sh_coeffs,
+                                               float *grad_alpha, uint32_t tile_size, uint32_t n_tiles_h,
+                                               uint32_t n_tiles_w, uint32_t H, uint32_t W, uint32_t C, float thresh,
+                                               uint32_t n_segments, float sh_l1_bound, void *batch_workspace,
+                                               gsgen_stream_t stream);
+/* *out (device float, zeroed by the caller; results are max-accumulated) = max_i max_c sum_{k >= 1} |sh_coeffs[i][c][k]| */
+int gsgen_sh_l1_bound(uint32_t N, const float *sh_coeffs, uint32_t C, float *out, gsgen_stream_t stream);
+/* 1 if a batched SH launch with this bound and this largest pixel size (max over views of pixel_size_x / _y) takes the
+ * polynomial form, else 0 */
+int gsgen_sh_poly_applies(float sh_l1_bound, float max_pixel_size, uint32_t C);
+
 /* Fused RGB + auxiliary heads: what render_one does in four compositing passes
  * (gs/gaussian_splatting.py:1304-1403: rgb, depth, opacity = scalar 1, depth^2) in one.
  * out6 / grad_out6 are [H,W,6] = (r, g, b, depth, opacity, depth^2); grad_chan6 [N,6] receives the

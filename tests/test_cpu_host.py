@@ -1030,7 +1030,7 @@ def test_emulated_polynomial_sh_basis_batched_launches(emu, nseg, ppl_fwd):
                           bg=np.array([0.3, 0.1, 0.2], np.float32), go=np.random.default_rng(i).normal(size=(H, W, 3)).astype(np.float32)))
     assert max((v["en"] - v["st"]).max() for v in views) > 40
 
-    def launch(fx_scale=1.0):
+    def launch(bound):
         arr = (ShView * len(views))()
         res = []
         for a, v in zip(arr, views):
@@ -1044,19 +1044,25 @@ def test_emulated_polynomial_sh_basis_batched_launches(emu, nseg, ppl_fwd):
             a.grad_out, a.grad_mean, a.grad_cov = P(v["go"]), P(r["gm"]), P(r["gc"])
             res.append(r)
         bws = np.zeros(emu.sh_batch_workspace_bytes(len(views)), np.uint8)
-        emu.vol_render_sh_batch(len(views), arr, Nall, P(sh), P(al), 16, nth, ntw, H, W, C, 1e-4, nseg, P(bws), None)
+        emu.vol_render_sh_batch_bounded(len(views), arr, Nall, P(sh), P(al), 16, nth, ntw, H, W, C, 1e-4, nseg, bound, P(bws), None)
         gsh = np.zeros_like(sh); ga = np.zeros(Nall, np.float32)
-        emu.vol_render_backward_sh_batch(len(views), arr, Nall, P(sh), P(al), P(gsh), P(ga), 16, nth, ntw, H, W, C, 1e-4, nseg, P(bws), None)
+        emu.vol_render_backward_sh_batch_bounded(len(views), arr, Nall, P(sh), P(al), P(gsh), P(ga), 16, nth, ntw, H, W, C, 1e-4, nseg,
+                                                 bound, P(bws), None)
         return res, gsh, ga
 
+    # the bound: gsgen_sh_l1_bound on the device == numpy
+    S_np = float(np.abs(sh[:, :, 1:]).sum(-1).max())
+    S_dev = np.zeros(1, np.float32)
+    emu.sh_l1_bound(Nall, P(sh), C, P(S_dev), None)
+    assert abs(float(S_dev[0]) - S_np) <= 1e-5 * S_np
+    ps_max = max(1 / c.fx for c in cams)
+    assert emu.sh_poly_applies(S_np, ps_max, 4) and not emu.sh_poly_applies(S_np, 1 / 40.0, 4) and not emu.sh_poly_applies(0.0, ps_max, 4)
+    assert not emu.sh_poly_applies(S_np, ps_max, 3) and "POLY6" in emu.kernel_variant("sh_bwd_batch_poly", 4)
     emu.set_variant("ppl_fwd_batch", ppl_fwd)
     try:
-        exact, e_gsh, e_ga = launch()
-        emu.set_variant("sh_poly", 64)  # S = 4
-        assert "POLY6" in emu.kernel_variant("sh_bwd_batch", 4) and "POLY6" in emu.kernel_variant("sh_fwd_batch", 4)
-        poly, p_gsh, p_ga = launch()
+        exact, e_gsh, e_ga = launch(0.0)
+        poly, p_gsh, p_ga = launch(S_np * 1.05)
     finally:
-        emu.set_variant("sh_poly", 0)
         emu.set_variant("ppl_fwd_batch", 2)
     want_gsh = np.zeros(sh.shape, np.float64); want_ga = np.zeros(Nall, np.float64)
     for v, e, q in zip(views, exact, poly):

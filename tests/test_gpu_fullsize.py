@@ -357,9 +357,10 @@ def test_batched_heads_fuzz():
 
 
 def test_full_size_cfg2_polynomial_sh_basis():
-    """The OPT-IN tile-local polynomial form of the per-pixel SH basis (variant "sh_poly", composite_common.hpp) at the
-    headline size: two cfg2 cameras (100k Gaussians, 800x800, f = 800) through the batched launches with the knob on,
-    every pixel within 1e-4 of the oracle, every gradient within 1e-3 -- and within 1e-5 / 1e-4 of the exact kernels."""
+    """The tile-local polynomial form of the per-pixel SH basis (BatchRenderer.render(sh_l1_bound=...) ->
+    gsgen_vol_render_sh_batch_bounded; composite_common.hpp) at the headline size: two cfg2 cameras (100k Gaussians,
+    800x800, f = 800) through the batched launches with the scene's coefficient bound, every pixel within 1e-4 of the
+    oracle, every gradient within 1e-3 -- and within 1e-5 / 1e-4 of the exact kernels."""
     from gsgen_amd import renderer as R, _capi
     from gsgen_amd.batch import BatchRenderer
     L = _capi.load()
@@ -371,22 +372,21 @@ def test_full_size_cfg2_polynomial_sh_basis():
     bg = np.array([0.1, 0.2, 0.3], np.float32)
     gos = torch.randn(B, H, W, 3, device=dev(), generator=torch.Generator(device=dev()).manual_seed(5))
     res = {}
-    for knob in (0, 64):
-        L.set_variant("sh_poly", knob)
-        try:
-            if knob:
-                assert "POLY6" in L.kernel_variant("sh_bwd_batch", 4)
-            P = {k: T_(sc[k]).requires_grad_(True) for k in KEYS}
-            br = BatchRenderer(N, W, H, dev(), max_batch=B)
-            for _ in range(2):
-                rgb, _ = br.render(P["mean"], P["qvec"], P["svec"], P["alpha"], P["sh"], cis, [c.c2w for c in cams], C=4, bg_rgb=T_(bg))
-                if br.ensure_capacity(B):
-                    break
-            (rgb * gos).sum().backward()
-            torch.cuda.synchronize()
-            res[knob] = (rgb.detach().cpu().numpy(), {k: P[k].grad.cpu().numpy() for k in KEYS})
-        finally:
-            L.set_variant("sh_poly", 0)
+    P0 = T_(sc["sh"])
+    S = R.sh_l1_bound(P0)  # the device's reduction (one sync): max sum of |non-constant coefficients|, x 1.05
+    assert abs(S / 1.05 - float(np.abs(sc["sh"][:, :, 1:]).sum(-1).max())) <= 1e-4 * S
+    assert L.sh_poly_applies(S, 1.0 / 800.0, 4) and "POLY6" in L.kernel_variant("sh_bwd_batch_poly", 4)
+    for knob, bound in ((0, None), (64, S)):
+        P = {k: T_(sc[k]).requires_grad_(True) for k in KEYS}
+        br = BatchRenderer(N, W, H, dev(), max_batch=B)
+        for _ in range(2):
+            rgb, _ = br.render(P["mean"], P["qvec"], P["svec"], P["alpha"], P["sh"], cis, [c.c2w for c in cams], C=4, bg_rgb=T_(bg),
+                               sh_l1_bound=bound)
+            if br.ensure_capacity(B):
+                break
+        (rgb * gos).sum().backward()
+        torch.cuda.synchronize()
+        res[knob] = (rgb.detach().cpu().numpy(), {k: P[k].grad.cpu().numpy() for k in KEYS})
     img_e, g_e = res[0]
     img_p, g_p = res[64]
     d = float(np.abs(img_p - img_e).max())
