@@ -256,6 +256,12 @@ def main():
     sh_bound_scene = R.sh_l1_bound(t["sh"]) if C == 4 else 0.0
     state = {"sh_bound": sh_bound_scene if (args.sh_basis == "auto" and C == 4) else 0.0}
     poly_applies = bool(state["sh_bound"] > 0 and lib.sh_poly_applies(state["sh_bound"], ps_max, C))
+    if dist is not None:  # one decision for the job (the ranks' cameras may differ: cfg4), and the same regions on every rank
+        pa = torch.tensor([int(poly_applies)], device=dev)
+        dist.all_reduce(pa, op=dist.ReduceOp.MIN)
+        poly_applies = bool(pa.item())
+    if not poly_applies:
+        state["sh_bound"] = 0.0
     p = lambda x: x.data_ptr()  # noqa: E731
     vtab = lambda vals: (ctypes.c_void_p * len(vals))(*vals)  # noqa: E731
     clock = HostClock()
