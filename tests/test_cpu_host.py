@@ -1119,3 +1119,77 @@ def test_emulated_polynomial_sh_basis_is_not_used_beyond_its_error_bound(emu):
         finally:
             emu.set_variant("sh_poly", 0)
     assert np.array_equal(outs[0], outs[1]) and np.abs(outs[0]).max() > 0.1
+
+
+def test_emulated_polynomial_sh_basis_fuzz(emu):
+    """hypothesis over the polynomial-basis launches (the kernels bench.py runs by default): 1 .. 3 narrow cameras of ragged
+    image shapes (one pixel to several partial tiles), 1 .. 300 splats of any size, opaque scenes, unsegmented and segmented
+    backward, both forward shapes -- against the exact kernels of the same launch: transmittance bit-identical, images
+    within 2e-5, every gradient within 1e-4 of its largest entry."""
+    from hypothesis import given, settings, strategies as st, HealthCheck
+    from gsgen_amd._capi import ShView
+    n_ex = int(os.environ.get("GSGEN_FUZZ_EXAMPLES", "10"))
+    C = 4
+
+    @settings(max_examples=n_ex, deadline=None, derandomize=(n_ex == 10), suppress_health_check=list(HealthCheck))
+    @given(B=st.integers(1, 3), W=st.integers(1, 60), H=st.integers(1, 44), n=st.integers(1, 300), seed=st.integers(0, 10_000),
+           svec=st.sampled_from([0.003, 0.012, 0.05]), opaque=st.booleans(), nseg=st.sampled_from([0, 3]), ppl_fwd=st.sampled_from([2, 4]))
+    def run(B, W, H, n, seed, svec, opaque, nseg, ppl_fwd):
+        sc = scenes.random_scene(n, seed=seed, svec=svec, spread=0.03, C=C)
+        sc["sh"][:, :, 1:] *= 0.5
+        if opaque:
+            sc["alpha"][:] = 0.999
+        sh, al = np.ascontiguousarray(sc["sh"]), np.ascontiguousarray(sc["alpha"])
+        S = float(np.abs(sh[:, :, 1:]).sum(-1).max()) * 1.05
+        cams = [scenes.Camera(W, H, fx=560.0 + 90 * i, c2w=scenes.orbit(2.5 + 0.1 * i, 15.0 * i, 50.0 + 110.0 * i)) for i in range(B)]
+        assert emu.sh_poly_applies(S, max(1 / c.fx for c in cams), 4)
+        nth, ntw = cams[0].tiles
+        views = []
+        for i, cam in enumerate(cams):
+            g = scenes.oracle_geometry(sc, cam)
+            nz = np.nonzero(g["mask"])[0]
+            m2 = np.zeros((n, 2), np.float32); c2 = np.zeros((n, 2, 2), np.float32)
+            m2[nz] = g["mean2d"]; c2[nz] = g["cov2d"]
+            c2[~g["mask"]] = np.eye(2, dtype=np.float32)
+            views.append(dict(m2=m2, c2=c2, st=g["start"], en=g["end"], ids=np.ascontiguousarray(nz[g["ids"]].astype(np.int32)),
+                              tlp=cam.topleft, rot=np.ascontiguousarray(cam.c2w[:3, :3].reshape(-1)), cam=cam,
+                              bg=np.array([0.3, 0.1, 0.2], np.float32),
+                              go=np.random.default_rng(seed + i).normal(size=(H, W, 3)).astype(np.float32)))
+
+        def launch(bound):
+            arr = (ShView * B)()
+            res = []
+            for a, v in zip(arr, views):
+                cam = v["cam"]
+                r = dict(ws=np.zeros(max(1, emu.segment_workspace_bytes(nth * ntw, nseg)), np.uint8), out=np.zeros((H, W, 3), np.float32),
+                         T=np.ones((H, W), np.float32), gm=np.zeros((n, 2), np.float32), gc=np.zeros((n, 4), np.float32))
+                a.mean, a.cov, a.start, a.end = P(v["m2"]), P(v["c2"]), P(v["st"]), P(v["en"])
+                a.gaussian_ids = P(v["ids"]) if v["ids"].size else None
+                a.tile_order, a.topleft, a.c2w, a.bg_rgb = None, P(v["tlp"]), P(v["rot"]), P(v["bg"])
+                a.pixel_size_x, a.pixel_size_y = 1 / cam.fx, 1 / cam.fy
+                a.out, a.T, a.segment_workspace = P(r["out"]), P(r["T"]), (P(r["ws"]) if nseg else None)
+                a.grad_out, a.grad_mean, a.grad_cov = P(v["go"]), P(r["gm"]), P(r["gc"])
+                res.append(r)
+            bws = np.zeros(emu.sh_batch_workspace_bytes(B), np.uint8)
+            emu.vol_render_sh_batch_bounded(B, arr, n, P(sh), P(al), 16, nth, ntw, H, W, C, 1e-4, nseg, bound, P(bws), None)
+            gsh = np.zeros_like(sh); ga = np.zeros(n, np.float32)
+            emu.vol_render_backward_sh_batch_bounded(B, arr, n, P(sh), P(al), P(gsh), P(ga), 16, nth, ntw, H, W, C, 1e-4, nseg, bound,
+                                                     P(bws), None)
+            return res, gsh, ga
+
+        emu.set_variant("ppl_fwd_batch", ppl_fwd)
+        try:
+            exact, e_gsh, e_ga = launch(0.0)
+            poly, p_gsh, p_ga = launch(S)
+        finally:
+            emu.set_variant("ppl_fwd_batch", 2)
+        tag = (B, W, H, n, seed, svec, opaque, nseg, ppl_fwd)
+
+        def close(a_, b_, what):
+            assert np.abs(a_ - b_).max() <= 1e-4 * np.abs(b_).max() + 1e-6, (what, tag, float(np.abs(a_ - b_).max()), float(np.abs(b_).max()))
+        for e, q in zip(exact, poly):
+            assert np.array_equal(q["T"], e["T"]), tag
+            assert np.abs(q["out"] - e["out"]).max() <= 2e-5, (tag, float(np.abs(q["out"] - e["out"]).max()))
+            close(q["gm"], e["gm"], "mean2d"); close(q["gc"], e["gc"], "cov2d")
+        close(p_gsh, e_gsh, "sh"); close(p_ga, e_ga, "alpha")
+    run()
