@@ -806,6 +806,9 @@ k_composite_bwd_pixel(CompParams p_arg, const CompParams *__restrict__ plist) {
 // 256 / PPL threads); PPL = 4 (one wavefront per tile) or 2.
 #if defined(GSGEN_BWD_WAVES3)  // experiment build: three wavefronts per SIMD (168 registers), whatever it takes
 #define GSGEN_BWD_VEC_ATTR __attribute__((amdgpu_waves_per_eu(3, 3)))
+#elif defined(GSGEN_POLY_WAVES4)  // experiment build: the polynomial-basis instantiation at four wavefronts per SIMD
+// (128 registers, 64 bytes of scratch -- two reloads per list entry; not measured yet, profiles/r02_notes.md)
+#define GSGEN_BWD_VEC_ATTR __attribute__((amdgpu_waves_per_eu(NB > 0 ? 4 : 1)))
 #else
 #define GSGEN_BWD_VEC_ATTR
 #endif
