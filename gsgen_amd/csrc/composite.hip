@@ -14,10 +14,12 @@
 // exactly as the reference does (suffix = final - prefix), reduces the per-pixel gradient
 // contributions of a Gaussian across the wave with a register reduce-scatter, and issues
 // ONE vector atomic (<= 55 consecutive floats) per (tile, Gaussian) instead of the
-// reference's one LDS atomic per (pixel, Gaussian, component).  The SH backward that runs by
-// default (k_composite_bwd_sh_mfma, further down) moves the 48 SH components of that reduction
-// onto the matrix cores and can be launched per (tile, list segment) from checkpoints the forward
-// leaves behind.
+// reference's one LDS atomic per (pixel, Gaussian, component).  The SH kernels that run by default
+// (k_composite_fwd_sh_vec / k_composite_bwd_sh_vec) carry the per-pixel arithmetic as packed fp32 pixel
+// pairs; the backward can be launched per (tile, list segment) from checkpoints the forward leaves
+// behind; with a caller-supplied bound on the coefficients the batched launches evaluate the per-pixel
+// SH basis through a per-tile polynomial fit (NB = 6, composite_common.hpp).  k_composite_bwd_sh_mfma
+// (further down; opt-in) moves the 48 SH components of the reduction onto the matrix cores.
 //
 // Numerics: the per-(pixel, Gaussian) Gaussian is evaluated in fp32 on the fast path (the
 // reference uses fp64 for RGB/scalar, fp32 for SH).  For RGB/scalar the quadratic form is
