@@ -1121,75 +1121,103 @@ def test_emulated_polynomial_sh_basis_is_not_used_beyond_its_error_bound(emu):
     assert np.array_equal(outs[0], outs[1]) and np.abs(outs[0]).max() > 0.1
 
 
+def _poly_vs_exact(emu, sc, cams, nseg, ppl_fwd, tag, seed=0):
+    """batched SH launches of `cams` over scene `sc` (C = 4) with the scene's coefficient bound against the same launches
+    with the exact basis: transmittance bit-identical, images within 2e-5, gradients within 1e-4 of their largest entry"""
+    from gsgen_amd._capi import ShView
+    C = 4
+    n, B = sc["mean"].shape[0], len(cams)
+    W, H = cams[0].w, cams[0].h
+    sh, al = np.ascontiguousarray(sc["sh"]), np.ascontiguousarray(sc["alpha"])
+    S = float(np.abs(sh[:, :, 1:]).sum(-1).max()) * 1.05
+    assert emu.sh_poly_applies(S, max(max(1 / c.fx, 1 / c.fy) for c in cams), 4), tag
+    nth, ntw = cams[0].tiles
+    views = []
+    for i, cam in enumerate(cams):
+        g = scenes.oracle_geometry(sc, cam)
+        nz = np.nonzero(g["mask"])[0]
+        m2 = np.zeros((n, 2), np.float32); c2 = np.zeros((n, 2, 2), np.float32)
+        m2[nz] = g["mean2d"]; c2[nz] = g["cov2d"]
+        c2[~g["mask"]] = np.eye(2, dtype=np.float32)
+        views.append(dict(m2=m2, c2=c2, st=g["start"], en=g["end"], ids=np.ascontiguousarray(nz[g["ids"]].astype(np.int32)),
+                          tlp=cam.topleft, rot=np.ascontiguousarray(cam.c2w[:3, :3].reshape(-1)), cam=cam,
+                          bg=np.array([0.3, 0.1, 0.2], np.float32),
+                          go=np.random.default_rng(seed + i).normal(size=(H, W, 3)).astype(np.float32)))
+
+    def launch(bound):
+        arr = (ShView * B)()
+        res = []
+        for a, v in zip(arr, views):
+            cam = v["cam"]
+            r = dict(ws=np.zeros(max(1, emu.segment_workspace_bytes(nth * ntw, nseg)), np.uint8), out=np.zeros((H, W, 3), np.float32),
+                     T=np.ones((H, W), np.float32), gm=np.zeros((n, 2), np.float32), gc=np.zeros((n, 4), np.float32))
+            a.mean, a.cov, a.start, a.end = P(v["m2"]), P(v["c2"]), P(v["st"]), P(v["en"])
+            a.gaussian_ids = P(v["ids"]) if v["ids"].size else None
+            a.tile_order, a.topleft, a.c2w, a.bg_rgb = None, P(v["tlp"]), P(v["rot"]), P(v["bg"])
+            a.pixel_size_x, a.pixel_size_y = 1 / cam.fx, 1 / cam.fy
+            a.out, a.T, a.segment_workspace = P(r["out"]), P(r["T"]), (P(r["ws"]) if nseg else None)
+            a.grad_out, a.grad_mean, a.grad_cov = P(v["go"]), P(r["gm"]), P(r["gc"])
+            res.append(r)
+        bws = np.zeros(emu.sh_batch_workspace_bytes(B), np.uint8)
+        emu.vol_render_sh_batch_bounded(B, arr, n, P(sh), P(al), 16, nth, ntw, H, W, C, 1e-4, nseg, bound, P(bws), None)
+        gsh = np.zeros_like(sh); ga = np.zeros(n, np.float32)
+        emu.vol_render_backward_sh_batch_bounded(B, arr, n, P(sh), P(al), P(gsh), P(ga), 16, nth, ntw, H, W, C, 1e-4, nseg, bound,
+                                                 P(bws), None)
+        return res, gsh, ga
+
+    emu.set_variant("ppl_fwd_batch", ppl_fwd)
+    try:
+        exact, e_gsh, e_ga = launch(0.0)
+        poly, p_gsh, p_ga = launch(S)
+    finally:
+        emu.set_variant("ppl_fwd_batch", 2)
+
+    def close(a_, b_, what):
+        assert np.abs(a_ - b_).max() <= 1e-4 * np.abs(b_).max() + 1e-6, (what, tag, float(np.abs(a_ - b_).max()), float(np.abs(b_).max()))
+    worst = 0.0
+    for e, q in zip(exact, poly):
+        assert np.array_equal(q["T"], e["T"]), tag
+        worst = max(worst, float(np.abs(q["out"] - e["out"]).max()))
+        assert worst <= 2e-5, (tag, worst)
+        close(q["gm"], e["gm"], "mean2d"); close(q["gc"], e["gc"], "cov2d")
+    close(p_gsh, e_gsh, "sh"); close(p_ga, e_ga, "alpha")
+    return worst, float(max(np.abs(e["out"]).max() for e in exact))
+
+
 def test_emulated_polynomial_sh_basis_fuzz(emu):
     """hypothesis over the polynomial-basis launches (the kernels bench.py runs by default): 1 .. 3 narrow cameras of ragged
     image shapes (one pixel to several partial tiles), 1 .. 300 splats of any size, opaque scenes, unsegmented and segmented
     backward, both forward shapes -- against the exact kernels of the same launch: transmittance bit-identical, images
     within 2e-5, every gradient within 1e-4 of its largest entry."""
     from hypothesis import given, settings, strategies as st, HealthCheck
-    from gsgen_amd._capi import ShView
     n_ex = int(os.environ.get("GSGEN_FUZZ_EXAMPLES", "10"))
-    C = 4
 
     @settings(max_examples=n_ex, deadline=None, derandomize=(n_ex == 10), suppress_health_check=list(HealthCheck))
     @given(B=st.integers(1, 3), W=st.integers(1, 60), H=st.integers(1, 44), n=st.integers(1, 300), seed=st.integers(0, 10_000),
            svec=st.sampled_from([0.003, 0.012, 0.05]), opaque=st.booleans(), nseg=st.sampled_from([0, 3]), ppl_fwd=st.sampled_from([2, 4]))
     def run(B, W, H, n, seed, svec, opaque, nseg, ppl_fwd):
-        sc = scenes.random_scene(n, seed=seed, svec=svec, spread=0.03, C=C)
+        sc = scenes.random_scene(n, seed=seed, svec=svec, spread=0.03, C=4)
         sc["sh"][:, :, 1:] *= 0.5
         if opaque:
             sc["alpha"][:] = 0.999
-        sh, al = np.ascontiguousarray(sc["sh"]), np.ascontiguousarray(sc["alpha"])
-        S = float(np.abs(sh[:, :, 1:]).sum(-1).max()) * 1.05
         cams = [scenes.Camera(W, H, fx=560.0 + 90 * i, c2w=scenes.orbit(2.5 + 0.1 * i, 15.0 * i, 50.0 + 110.0 * i)) for i in range(B)]
-        assert emu.sh_poly_applies(S, max(1 / c.fx for c in cams), 4)
-        nth, ntw = cams[0].tiles
-        views = []
-        for i, cam in enumerate(cams):
-            g = scenes.oracle_geometry(sc, cam)
-            nz = np.nonzero(g["mask"])[0]
-            m2 = np.zeros((n, 2), np.float32); c2 = np.zeros((n, 2, 2), np.float32)
-            m2[nz] = g["mean2d"]; c2[nz] = g["cov2d"]
-            c2[~g["mask"]] = np.eye(2, dtype=np.float32)
-            views.append(dict(m2=m2, c2=c2, st=g["start"], en=g["end"], ids=np.ascontiguousarray(nz[g["ids"]].astype(np.int32)),
-                              tlp=cam.topleft, rot=np.ascontiguousarray(cam.c2w[:3, :3].reshape(-1)), cam=cam,
-                              bg=np.array([0.3, 0.1, 0.2], np.float32),
-                              go=np.random.default_rng(seed + i).normal(size=(H, W, 3)).astype(np.float32)))
-
-        def launch(bound):
-            arr = (ShView * B)()
-            res = []
-            for a, v in zip(arr, views):
-                cam = v["cam"]
-                r = dict(ws=np.zeros(max(1, emu.segment_workspace_bytes(nth * ntw, nseg)), np.uint8), out=np.zeros((H, W, 3), np.float32),
-                         T=np.ones((H, W), np.float32), gm=np.zeros((n, 2), np.float32), gc=np.zeros((n, 4), np.float32))
-                a.mean, a.cov, a.start, a.end = P(v["m2"]), P(v["c2"]), P(v["st"]), P(v["en"])
-                a.gaussian_ids = P(v["ids"]) if v["ids"].size else None
-                a.tile_order, a.topleft, a.c2w, a.bg_rgb = None, P(v["tlp"]), P(v["rot"]), P(v["bg"])
-                a.pixel_size_x, a.pixel_size_y = 1 / cam.fx, 1 / cam.fy
-                a.out, a.T, a.segment_workspace = P(r["out"]), P(r["T"]), (P(r["ws"]) if nseg else None)
-                a.grad_out, a.grad_mean, a.grad_cov = P(v["go"]), P(r["gm"]), P(r["gc"])
-                res.append(r)
-            bws = np.zeros(emu.sh_batch_workspace_bytes(B), np.uint8)
-            emu.vol_render_sh_batch_bounded(B, arr, n, P(sh), P(al), 16, nth, ntw, H, W, C, 1e-4, nseg, bound, P(bws), None)
-            gsh = np.zeros_like(sh); ga = np.zeros(n, np.float32)
-            emu.vol_render_backward_sh_batch_bounded(B, arr, n, P(sh), P(al), P(gsh), P(ga), 16, nth, ntw, H, W, C, 1e-4, nseg, bound,
-                                                     P(bws), None)
-            return res, gsh, ga
-
-        emu.set_variant("ppl_fwd_batch", ppl_fwd)
-        try:
-            exact, e_gsh, e_ga = launch(0.0)
-            poly, p_gsh, p_ga = launch(S)
-        finally:
-            emu.set_variant("ppl_fwd_batch", 2)
-        tag = (B, W, H, n, seed, svec, opaque, nseg, ppl_fwd)
-
-        def close(a_, b_, what):
-            assert np.abs(a_ - b_).max() <= 1e-4 * np.abs(b_).max() + 1e-6, (what, tag, float(np.abs(a_ - b_).max()), float(np.abs(b_).max()))
-        for e, q in zip(exact, poly):
-            assert np.array_equal(q["T"], e["T"]), tag
-            assert np.abs(q["out"] - e["out"]).max() <= 2e-5, (tag, float(np.abs(q["out"] - e["out"]).max()))
-            close(q["gm"], e["gm"], "mean2d"); close(q["gc"], e["gc"], "cov2d")
-        close(p_gsh, e_gsh, "sh"); close(p_ga, e_ga, "alpha")
+        _poly_vs_exact(emu, sc, cams, nseg, ppl_fwd, (B, W, H, n, seed, svec, opaque, nseg, ppl_fwd), seed)
     run()
+
+
+def test_emulated_polynomial_sh_basis_in_a_far_corner_of_a_large_image(emu):
+    """the tiles of the fuzz sit near the optical axis; the corner tiles of an 800 x 800 image at f = 800 look 33 degrees off it
+    (qx, qy ~ 0.45): the whole headline image on the emulator, the scene moved into its far corner (the other tiles are empty)"""
+    W = H = 800
+    c2w = scenes.orbit(2.5, 20.0, 70.0)
+    cam = scenes.Camera(W, H, fx=800.0, c2w=c2w)
+    sc = scenes.random_scene(260, seed=23, svec=0.004, spread=0.012, C=4)
+    sc["sh"][:, :, 1:] *= 0.5
+    centre_cam = np.array([0.455 * 2.5, 0.445 * 2.5, 0.0], np.float32)  # (qx, qy) = (0.455, 0.445) at the origin's depth
+    sc["mean"] = (sc["mean"] + c2w[:3, :3] @ centre_cam).astype(np.float32)
+    g = scenes.oracle_geometry(sc, cam)
+    assert g["mask"].sum() > 200 and g["D"] > 400
+    tiles = np.nonzero(g["end"] > g["start"])[0]
+    assert (tiles // 50).min() >= 44 and (tiles % 50).min() >= 44  # all of it in the last rows and columns of tiles
+    worst, amp = _poly_vs_exact(emu, sc, [cam], 0, 2, "corner")
+    assert amp > 0.5 and worst > 0.0  # the corner shows the scene, and the polynomial kernels ran
