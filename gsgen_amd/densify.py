@@ -22,6 +22,16 @@ from dataclasses import dataclass
 import torch
 
 FIELDS = ("mean", "qvec", "svec", "color", "alpha")  # raw (pre-activation) fields, gs/gaussian_splatting.py:55-62
+# mean / qvec / svec are what a split changes; every other per-Gaussian field of the optimiser (alpha, color -- or sh when
+# the colours are SH coefficients, specular, normal, ...) is payload: copied for clones, repeated for split samples
+
+
+def _payload(raw):
+    return [k for k in raw if k not in ("mean", "qvec", "svec")]
+
+
+def _rep(t, n):
+    return t.repeat(n, *([1] * (t.dim() - 1)))
 
 
 @dataclass
@@ -91,9 +101,9 @@ def densify_legacy(raw, svec, svec_inv_act, stats_accum, stats_cnt, cfg, generat
     keep = torch.logical_not(split)
     new = {"mean": torch.cat([raw["mean"][keep], raw["mean"][clone], smean]),
            "qvec": torch.cat([raw["qvec"][keep], raw["qvec"][clone], sqvec]),
-           "svec": torch.cat([raw["svec"][keep], raw["svec"][clone], svec_inv_act(ssvec / cfg.split_shrink / 2.0)]),
-           "color": torch.cat([raw["color"][keep], raw["color"][clone], raw["color"][split].repeat(2, 1)]),
-           "alpha": torch.cat([raw["alpha"][keep], raw["alpha"][clone], raw["alpha"][split].repeat(2)])}
+           "svec": torch.cat([raw["svec"][keep], raw["svec"][clone], svec_inv_act(ssvec / cfg.split_shrink / 2.0)])}
+    for k in _payload(raw):
+        new[k] = torch.cat([raw[k][keep], raw[k][clone], _rep(raw[k][split], 2)])
     return new, {"num_split": int(split.sum()), "num_clone": int(clone.sum())}
 
 
@@ -117,9 +127,10 @@ def densify_official(raw, moments, act, stats_accum, stats_cnt, cfg, generator=N
     grads = torch.where(torch.isnan(grads), torch.zeros_like(grads), grads)
     # clone: append copies (:614-628), new Adam moments zero (:481-522)
     clone = official_masks(grads, act["svec"](raw["svec"]), cfg)
-    raw = {k: torch.cat([raw[k], raw[k][clone]]) for k in FIELDS}
+    names = list(raw)
+    raw = {k: torch.cat([raw[k], raw[k][clone]]) for k in names}
     if moments is not None:
-        moments = {k: tuple(torch.cat([m, torch.zeros_like(m[clone])]) for m in moments[k]) for k in FIELDS}
+        moments = {k: tuple(torch.cat([m, torch.zeros_like(m[clone])]) for m in moments[k]) for k in names}
     num_clone = int(clone.sum())
     # split: gradients zero-padded behind the clones (:556-566)
     n = raw["mean"].shape[0]
@@ -128,12 +139,13 @@ def densify_official(raw, moments, act, stats_accum, stats_cnt, cfg, generator=N
     svec = act["svec"](raw["svec"])
     sel = torch.logical_and(padded >= cfg.mean2d_thresh, torch.max(svec, dim=1).values > cfg.split_thresh)
     smean, sqvec, ssvec = _split_samples(raw, svec, sel, cfg.n_splits, generator)
-    add = {"mean": smean, "qvec": sqvec, "svec": act["svec_inv"](ssvec / (cfg.n_splits * cfg.split_shrink)),
-           "color": raw["color"][sel].repeat(cfg.n_splits, 1), "alpha": raw["alpha"][sel].repeat(cfg.n_splits)}
+    add = {"mean": smean, "qvec": sqvec, "svec": act["svec_inv"](ssvec / (cfg.n_splits * cfg.split_shrink))}
+    for k in _payload(raw):
+        add[k] = _rep(raw[k][sel], cfg.n_splits)
     keep = torch.cat([torch.logical_not(sel), torch.ones(add["mean"].shape[0], dtype=torch.bool, device=sel.device)])
-    raw = {k: torch.cat([raw[k], add[k]])[keep] for k in FIELDS}
+    raw = {k: torch.cat([raw[k], add[k]])[keep] for k in names}
     if moments is not None:
-        moments = {k: tuple(torch.cat([m, torch.zeros_like(add[k])])[keep] for m in moments[k]) for k in FIELDS}
+        moments = {k: tuple(torch.cat([m, torch.zeros_like(add[k])])[keep] for m in moments[k]) for k in names}
     return raw, moments, {"num_split": int(sel.sum()), "num_clone": num_clone}
 
 
@@ -190,8 +202,11 @@ class AdaptiveControl:
         if not (dens or prun):
             return opt, stats, False
         gdist.allreduce_densify_stats(stats, self.group)
-        raw = {k: opt.params[k].detach() for k in FIELDS}
-        moments = {k: opt.moments(k) for k in FIELDS}
+        for k in ("mean", "qvec", "svec", "alpha"):
+            if k not in opt.params:
+                raise KeyError(f"AdaptiveControl needs the raw field {k!r} in the optimiser")
+        raw = {k: opt.params[k].detach() for k in opt.names}
+        moments = {k: opt.moments(k) for k in opt.names}
         dev = raw["mean"].device
         info = {}
         maxr = stats.max_radii2d
@@ -212,7 +227,7 @@ class AdaptiveControl:
             info["pruned"] = counts
             raw = {k: v[keep] for k, v in raw.items()}
             if moments is not None:
-                moments = {k: tuple(m[keep] for m in moments[k]) for k in FIELDS}
+                moments = {k: tuple(m[keep] for m in moments[k]) for k in moments}
             maxr = maxr[keep]
         n = raw["mean"].shape[0]
         new_opt = FusedAdam({k: raw[k] for k in opt.names}, opt.lrs, betas=opt.betas, eps=opt.eps)

@@ -224,3 +224,35 @@ def test_ranks_with_different_camera_shards_end_up_with_identical_clouds(dtype):
         p.join(60)
         assert p.exitcode == 0
     assert same and changed and n != 600 and info["num_split"] > 0 and info["pruned"]["alpha"] > 0
+
+
+def test_sh_coefficients_and_other_per_gaussian_fields_ride_along():
+    """the colour field may be SH coefficients [N,3,16] (and the optimiser may hold further per-Gaussian fields): they are
+    payload -- copied for clones, repeated for split samples, pruned with their rows, Adam moments alike"""
+    raw, mom, acc, cnt, maxr = _cloud(300, seed=8)
+    g = torch.Generator().manual_seed(2)
+    raw["sh"] = torch.randn(300, 3, 16, generator=g); del raw["color"]
+    raw["extra"] = torch.randn(300, 2, generator=g)
+    names = list(raw)
+    opt = FusedAdam({k: raw[k].clone() for k in names}, {k: 1e-3 for k in names})
+    for k in names:
+        ea, es = opt.moments(k)
+        ea.copy_(torch.randn(ea.shape, generator=g)); es.copy_(torch.rand(es.shape, generator=g))
+    mom0 = {k: tuple(m.clone() for m in opt.moments(k)) for k in names}
+    st = DensifyStats(300, torch.device("cpu"))
+    st.grad_accum.copy_(acc); st.cnt.copy_(cnt); st.max_radii2d.copy_(maxr)
+    ctl = DN.AdaptiveControl(DN.DensifyConfig(type="official", warm_up=0, end=10 ** 6, period=100, clone_test="per_gaussian"),
+                             DN.PruneConfig(enabled=True, warm_up=0, end=10 ** 6, period=100, radii2d_thresh=1000.0, alpha_thresh=0.15))
+    new, st2, changed = ctl.step(100, opt, st)
+    assert changed and new.names == names
+    n2 = new.params["mean"].shape[0]
+    assert new.params["sh"].shape == (n2, 3, 16) and new.params["extra"].shape == (n2, 2) and st2.cnt.shape == (n2,)
+    # every surviving row of the payload fields is a row of the old cloud, with the Adam moments of that row or zeros (new rows)
+    old_rows = {tuple(r.tolist()) for r in raw["extra"]}
+    assert all(tuple(r.tolist()) in old_rows for r in new.params["extra"].detach())
+    key = {tuple(r.tolist()): i for i, r in enumerate(raw["extra"])}
+    ea, _ = new.moments("sh")
+    for j in range(0, n2, 7):
+        i = key[tuple(new.params["extra"][j].tolist())]
+        assert torch.equal(new.params["sh"][j].detach(), raw["sh"][i])
+        assert torch.equal(ea[j], mom0["sh"][0][i]) or float(ea[j].abs().max()) == 0.0
