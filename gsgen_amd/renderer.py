@@ -203,6 +203,8 @@ def sh_l1_bound(sh, margin=1.05):
     BatchRenderer.render(..., sh_l1_bound=) / gsgen_vol_render_sh_batch_bounded want.  One pass over the coefficients on
     the device and ONE host sync -- compute it when the coefficients change materially (or every few steps with a larger
     margin), not per render."""
+    if sh.dim() != 3 or sh.shape[1] != 3 or sh.dtype != torch.float32:
+        raise ValueError("sh_l1_bound wants fp32 SH coefficients [N, 3, C*C]")
     sh = sh.detach().contiguous()
     out = torch.zeros(1, device=sh.device, dtype=torch.float32)
     C2 = sh.shape[-1]
