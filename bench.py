@@ -92,11 +92,12 @@ def b_alg_bytes(N, D, P, T, F):
 
 def choose_batch_and_slots(pairs_per_view, batch=0, slots=0):
     """cameras per launch and launches in flight for a workload of `pairs_per_view` (tile, Gaussian) pairs per camera:
-    about 6 M pairs per launch (2 .. 8 cameras), three launches in flight when a launch is light (< 5.2 M pairs), else
-    two (measured: profiles/r02_notes.md).  Explicit --batch / --slots win."""
+    about 6 M pairs per launch (2 .. 8 cameras), three launches in flight (light launches and the polynomial-basis kernels
+    gain from the third, the exact kernels of a heavy launch neither gain nor lose: profiles/r02_notes.md).  Explicit
+    --batch / --slots win."""
     d = max(1, int(pairs_per_view))
     B = batch if batch > 0 else int(min(8, max(2, round(6.0e6 / d))))
-    return B, (slots if slots > 0 else (3 if B * d < 5.2e6 else 2))
+    return B, (slots if slots > 0 else 3)
 
 
 def cpu_baseline(sc, cams, C, budget_s=20.0):
@@ -180,11 +181,16 @@ def main():
                          "instead of in its shadow (measured: 3 333 vs 3 361 renders/s -- the chip is busy either way, "
                          "profiles/r02_notes.md); 0 (default): everything of a slot on one stream")
     ap.add_argument("--sh-basis", choices=["auto", "exact"], default=os.environ.get("GSGEN_BENCH_SH_BASIS", "auto"),
-                    help="auto: the batched SH launches are given the scene's coefficient bound (max over splats and channels "
-                         "of sum_{k>=1} |sh|, measured before the timed region) and take the tile-local polynomial form of the "
-                         "per-pixel SH basis where the library's error bound allows (images within 1e-5 of the exact kernels; "
-                         "include/gsgen_hip.h, gsgen_vol_render_sh_batch_bounded); exact: the exact kernels.  With auto the exact "
-                         "kernels are timed too and reported as `exact_basis`")
+                    help="auto: EVERY step measures the coefficient bound (max over splats and channels of sum_{k>=1} |sh|) on the "
+                         "device (gsgen_sh_l1_bound, inside the timed region, no host sync) and hands its device address to the "
+                         "SH launches, which route per view on the device: the tile-local polynomial form of the per-pixel SH "
+                         "basis where the error bound allows (images within 1e-5 of the exact kernels; include/gsgen_hip.h, "
+                         "\"the coefficient bound\"), the exact kernel elsewhere; exact: the exact kernels only.  With auto the "
+                         "exact kernels are timed too and reported as `exact_basis`")
+    ap.add_argument("--variant", action="append", default=[], metavar="NAME=VALUE",
+                    help="A/B: override one entry of the library's kernel-variant table (gsgen_debug_set_variant), e.g. "
+                         "--variant ppl_fwd_batch=4; repeatable")
+    ap.add_argument("--no-surface", action="store_true", help="skip the autograd-surface pass (BatchRenderer.render + backward)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the one-render-in-flight and hipGraph passes")
     args = ap.parse_args()
@@ -220,6 +226,9 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     lib = _capi.load()
+    for kv in args.variant:
+        k_, v_ = kv.split("=")
+        lib.set_variant(k_, int(v_))
     sc, W, H = make_workload(args.config)
     C = sc["C"]
     N = sc["mean"].shape[0]
@@ -251,20 +260,10 @@ def main():
     topleft_dev = [torch.from_numpy(c.topleft).to(dev) for c in cams]
     bg = torch.tensor([0.1, 0.2, 0.3], device=dev)
     grad_out = torch.randn(H, W, 3, device=dev)
-    # the SH coefficient bound of the (static, HBM-resident) scene: one device pass + one sync, before any timed region
-    ps_max = max(max(1.0 / ci_.fx, 1.0 / ci_.fy) for ci_ in cis)
-    sh_bound_scene = R.sh_l1_bound(t["sh"]) if C == 4 else 0.0
-    state = {"sh_bound": sh_bound_scene if (args.sh_basis == "auto" and C == 4) else 0.0}
-    poly_applies = bool(state["sh_bound"] > 0 and lib.sh_poly_applies(state["sh_bound"], ps_max, C))
-    if dist is not None:  # one decision for the job (the ranks' cameras may differ: cfg4), and the same regions on every rank
-        pa = torch.tensor([int(poly_applies)], device=dev)
-        dist.all_reduce(pa, op=dist.ReduceOp.MIN)
-        poly_applies = bool(pa.item())
-    if not poly_applies:
-        state["sh_bound"] = 0.0
-    elif args.slots == 0:
-        auto_slots = 3  # the polynomial-basis kernels stall more on memory (the per-batch transform): a third step in flight
-                        # fills the gaps -- 4 146 vs 4 067 renders/s on cfg2 (3 367 vs 3 375 with the exact basis)
+    # SH basis: with "auto" (SH degree 3) every step measures the coefficient bound on the device and the launches route on it
+    # per view -- nothing about it is decided, or known, on the host while the steps run
+    ps_cam = [max(1.0 / ci_.fx, 1.0 / ci_.fy) for ci_ in cis]
+    state = {"bounded": bool(args.sh_basis == "auto" and C == 4)}
     p = lambda x: x.data_ptr()  # noqa: E731
     vtab = lambda vals: (ctypes.c_void_p * len(vals))(*vals)  # noqa: E731
     clock = HostClock()
@@ -287,6 +286,7 @@ def main():
                 self.seg_ws = [torch.empty(max(1, lib.segment_workspace_bytes(nth * ntw, nseg)), device=dev, dtype=torch.uint8)
                                for _ in range(B)]
                 self.bws = torch.empty(lib.sh_batch_workspace_bytes(B), device=dev, dtype=torch.uint8)
+                self.bound = torch.zeros(1, device=dev)  # S of the step's coefficients (gsgen_sh_l1_bound), read by its launches
                 self.gws = torch.empty(lib.frame_batch_workspace_bytes(B), device=dev, dtype=torch.uint8)
                 self.gathered = torch.empty(world, B, H, W, 3, device=dev) if dist is not None else None
             # the images of a step are complete after its forward: they are gathered on the communication stream while
@@ -346,10 +346,14 @@ def main():
             sl.e_geo.record(sl.geo_stream)
             stream.wait_event(sl.e_geo)
             clock.acc["events"] = clock.acc.get("events", 0.0) + time.perf_counter() - t0
+        bound_p = None
+        if state["bounded"]:  # the step's own measurement of its coefficients: one pass, on the step's stream, no sync
+            clock.call("sh_bound", lib.sh_l1_bound, N, p(t["sh"]), C, p(sl.bound), s)
+            bound_p = p(sl.bound)
         if ev is not None:
             clock.call("events", ev[0].record, stream)
         clock.call("composite_fwd", lib.vol_render_sh_batch_bounded, B, views, N, p(t["sh"]), p(t["alpha"]), 16, nth, ntw, H, W, C,
-                   1e-4, seg_arg, state["sh_bound"], p(sl.bws), s)
+                   1e-4, seg_arg, bound_p, p(sl.bws), s)
         if ev is not None:
             clock.call("events", ev[1].record, stream)
         if sl.gathered is not None and gather:
@@ -368,7 +372,7 @@ def main():
         if ev is not None:
             clock.call("events", ev[2].record, stream)
         clock.call("composite_bwd", lib.vol_render_backward_sh_batch_bounded, B, views, N, p(t["sh"]), p(t["alpha"]), p(sl.g_sh),
-                   p(sl.g_alpha), 16, nth, ntw, H, W, C, 1e-4, seg_arg, state["sh_bound"], p(sl.bws), s)
+                   p(sl.g_alpha), 16, nth, ntw, H, W, C, 1e-4, seg_arg, bound_p, p(sl.bws), s)
         if ev is not None:
             clock.call("events", ev[3].record, stream)
         clock.call("project_bwd", lib.project_gaussians_backward_batch, B, N, p(t["mean"]), p(t["qvec"]), p(t["svec"]), *proj,
@@ -416,14 +420,14 @@ def main():
             run_step(first + i, evs[i])
         host = time.perf_counter() - t0
         barrier()
-        el = time.perf_counter() - t0
+        el = el_local = time.perf_counter() - t0
         if dist is not None:
             tt = torch.tensor([el], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = float(tt.item())
         fwd = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))
         bwd = float(np.mean([e[2].elapsed_time(e[3]) for e in evs]))
-        return {"el": el, "host": host, "fwd_ms": fwd, "bwd_ms": bwd, "host_by_call": dict(clock.acc)}
+        return {"el": el, "el_local": el_local, "host": host, "fwd_ms": fwd, "bwd_ms": bwd, "host_by_call": dict(clock.acc)}
 
     regions = [region(args.warmup)]
     n_rep = args.repeats if args.repeats > 0 else int(min(25, max(1, np.ceil(0.5 / regions[0]["el"]))))
@@ -437,12 +441,30 @@ def main():
     med = regions[int(order[len(order) // 2])]
     el, fwd_ms, bwd_ms = med["el"], med["fwd_ms"], med["bwd_ms"]
     value = world * B * K / el
+    # Which kernel rendered which camera is the DEVICE's decision, taken per step from the bound the step measured; it is read
+    # back here, after the timed regions, for the report only (gsgen_sh_poly_applies is the same rule on the host).
+    S_dev = float(slots[0].bound.item()) if state["bounded"] else 0.0
+    poly_cams = [bool(state["bounded"] and lib.sh_poly_applies(S_dev, ps_, C)) for ps_ in ps_cam]
+    n_poly = int(sum(poly_cams))
+    if dist is not None:
+        pc = torch.tensor([n_poly, ncam], device=dev)
+        dist.all_reduce(pc)
+        n_poly_job, ncam_job = int(pc[0].item()), int(pc[1].item())
+    else:
+        n_poly_job, ncam_job = n_poly, ncam
+    poly_applies = n_poly_job > 0
+    # per-rank throughput of the reported region (the driver's scaling record can see that N ranks took part)
+    per_rank = [value / world]
+    if dist is not None:
+        pr = torch.zeros(world, device=dev, dtype=torch.float64)
+        pr[rank] = B * K / med["el_local"]
+        dist.all_reduce(pr)
+        per_rank = [float(x) for x in pr.tolist()]
 
     # ---- the same timed region with the exact per-pixel SH basis (when the headline used the polynomial form) ----------------
     exact_basis = None
-    if poly_applies:
-        keep = state["sh_bound"]
-        state["sh_bound"] = 0.0
+    if state["bounded"]:
+        state["bounded"] = False
         for i in range(max(2, len(slots))):
             run_step(i, evs[i % K])
         ex = [region(args.warmup + r * K) for r in range(min(3, n_rep))]
@@ -450,7 +472,7 @@ def main():
         exact_basis = {"value": world * B * K / exm["el"], "ms_per_step": exm["el"] / K * 1e3, "bwd_launch_ms": exm["bwd_ms"],
                        "fwd_launch_ms": exm["fwd_ms"], "bwd_kernel": lib.kernel_variant("sh_bwd_batch", C, nseg),
                        "fwd_kernel": lib.kernel_variant("sh_fwd_batch", C, nseg)}
-        state["sh_bound"] = keep
+        state["bounded"] = True
         for i in range(max(2, len(slots))):  # back to the headline's kernels for the secondary views
             run_step(i, evs[i % K])
         barrier()
@@ -482,22 +504,26 @@ def main():
             lib.frame_geometry(N, p(t["mean"]), p(t["qvec"]), p(t["svec"]), p(cam_dev[k]), W, H, b0.D_cap, p(b0.mean2d),
                                p(b0.cov2d), p(b0.depth), p(b0.mask), p(b0.ids), p(b0.start), p(b0.end), p(b0.total), p(b0.ws),
                                b0.ws.numel(), s)
+            bound_p = None
+            if state["bounded"]:
+                lib.sh_l1_bound(N, p(t["sh"]), C, p(sl0.bound), s)
+                bound_p = p(sl0.bound)
             if ev is not None:
                 ev[0].record(stream)
-            lib.vol_render_sh_segmented(N, b0.D_cap, p(b0.mean2d), p(b0.cov2d), p(t["sh"]), p(t["alpha"]), p(b0.start), p(b0.end),
-                                        p(b0.ids), p(sl0.out[0]), p(topleft_dev[k]), p(rot_dev[k]), 16, nth, ntw, 1.0 / cis[k].fx,
-                                        1.0 / cis[k].fy, H, W, C, 1e-4, p(bg), None, order_, p(lseg_ws), lseg_arg, s)
+            lib.vol_render_sh_bounded(N, b0.D_cap, p(b0.mean2d), p(b0.cov2d), p(t["sh"]), p(t["alpha"]), p(b0.start), p(b0.end),
+                                      p(b0.ids), p(sl0.out[0]), p(topleft_dev[k]), p(rot_dev[k]), 16, nth, ntw, 1.0 / cis[k].fx,
+                                      1.0 / cis[k].fy, H, W, C, 1e-4, p(bg), None, order_, p(lseg_ws), lseg_arg, bound_p, s)
             if ev is not None:
                 ev[1].record(stream)
             with torch.cuda.stream(stream):
                 g1.zero_()
             if ev is not None:
                 ev[2].record(stream)
-            lib.vol_render_backward_sh_segmented(N, b0.D_cap, p(b0.mean2d), p(b0.cov2d), p(t["sh"]), p(t["alpha"]), p(b0.start),
-                                                 p(b0.end), p(b0.ids), p(sl0.out[0]), p(g1_mean2d), p(g1_cov2d), p(g1_sh),
-                                                 p(g1_alpha), p(grad_out), p(topleft_dev[k]), p(rot_dev[k]), 16, nth, ntw,
-                                                 1.0 / cis[k].fx, 1.0 / cis[k].fy, H, W, C, 1e-4, p(bg), order_,
-                                                 p(lseg_ws), lseg_arg, s)
+            lib.vol_render_backward_sh_bounded(N, b0.D_cap, p(b0.mean2d), p(b0.cov2d), p(t["sh"]), p(t["alpha"]), p(b0.start),
+                                               p(b0.end), p(b0.ids), p(sl0.out[0]), p(g1_mean2d), p(g1_cov2d), p(g1_sh),
+                                               p(g1_alpha), p(grad_out), p(topleft_dev[k]), p(rot_dev[k]), 16, nth, ntw,
+                                               1.0 / cis[k].fx, 1.0 / cis[k].fy, H, W, C, 1e-4, p(bg), order_,
+                                               p(lseg_ws), lseg_arg, bound_p, s)
             if ev is not None:
                 ev[3].record(stream)
             lib.project_gaussians_backward_masked(N, p(t["mean"]), p(t["qvec"]), p(t["svec"]), p(cam_dev[k]), 1, p(b0.mask),
@@ -523,7 +549,8 @@ def main():
         el1 = time.perf_counter() - t1
         one = {"value": world * n1 / el1, "ms_per_render": el1 / n1 * 1e3, "renders": n1,
                "backward_segments_per_tile": lseg,
-               "fwd_kernel": lib.kernel_variant("sh_fwd", C, lseg), "bwd_kernel": lib.kernel_variant("sh_bwd", C, lseg),
+               "fwd_kernel": lib.kernel_variant("sh_fwd_poly" if poly_applies else "sh_fwd", C, lseg),
+               "bwd_kernel": lib.kernel_variant("sh_bwd_poly" if poly_applies else "sh_bwd", C, lseg),
                "fwd_kernel_ms": float(np.mean([e[0].elapsed_time(e[1]) for e in ev1])),
                "bwd_kernel_ms": float(np.mean([e[2].elapsed_time(e[3]) for e in ev1]))}
         if lseg > 1:
@@ -560,6 +587,58 @@ def main():
         except Exception as e:  # capture is an optimisation of the latency view only
             one["hipgraph_replay"] = {"error": str(e)[:200]}
 
+    # (c) the autograd surface: the same steps through gsgen_amd.BatchRenderer.render(...) + torch.autograd -- the path a
+    # training loop takes (one autograd node per camera batch; gradients to mean, qvec, svec, alpha, sh), `surface_slots`
+    # independent steps in flight on their own streams (e.g. the micro-batches of a gradient-accumulation step)
+    surface = None
+    if not args.no_surface and C > 0:
+        from gsgen_amd.batch import BatchRenderer
+        n_sf = len(slots)
+        leaf = {k: t[k].clone().requires_grad_(True) for k in ("mean", "qvec", "svec", "alpha", "sh")}
+        names = ("mean", "qvec", "svec", "alpha", "sh")
+        sf_streams = [torch.cuda.Stream(dev) for _ in range(n_sf)]
+        d_cap = int(max(b_.D_cap for sl_ in slots for b_ in sl_.bufs))
+        brs = []
+        for st_ in sf_streams:
+            with torch.cuda.stream(st_):
+                brs.append(BatchRenderer(N, W, H, dev, max_batch=B, D_cap=d_cap))
+        go_b = grad_out.unsqueeze(0).expand(B, H, W, 3).contiguous()
+        c2w_np = [c.c2w for c in cams]
+
+        def surface_step(j):
+            i = j % n_sf
+            k0 = (j * B) % ncam
+            idx = [(k0 + q) % ncam for q in range(B)]
+            with torch.cuda.stream(sf_streams[i]):
+                rgb, _ = brs[i].render(leaf["mean"], leaf["qvec"], leaf["svec"], leaf["alpha"], leaf["sh"], [cis[q] for q in idx],
+                                       [c2w_np[q] for q in idx], C=C, bg_rgb=bg, sh_basis=args.sh_basis)
+                return torch.autograd.grad([rgb], [leaf[n_] for n_ in names], [go_b])
+
+        torch.cuda.synchronize()
+        for j in range(max(args.warmup, 2 * n_sf)):
+            surface_step(j)
+        torch.cuda.synchronize()
+        assert all(br_.ensure_capacity(B) for br_ in brs), "surface pass: pair buffers overflowed"
+        sf_el = []
+        for r in range(min(3, n_rep)):
+            barrier()
+            t0 = time.perf_counter()
+            for j in range(K):
+                surface_step(args.warmup + r * K + j)
+            sf_host = time.perf_counter() - t0
+            barrier()
+            sf_el.append((time.perf_counter() - t0, sf_host))
+        sf_t, sf_h = sorted(sf_el)[len(sf_el) // 2]
+        if dist is not None:
+            tt = torch.tensor([sf_t], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            sf_t = float(tt.item())
+        surface = {"value": world * B * K / sf_t, "ms_per_step": sf_t / K * 1e3, "host_enqueue_ms_per_step": sf_h / K * 1e3,
+                   "steps_in_flight": n_sf, "fraction_of_c_abi_value": (world * B * K / sf_t) / value,
+                   "path": "gsgen_amd.BatchRenderer.render -> torch.autograd.grad (mean, qvec, svec, alpha, sh); one autograd "
+                           "node per camera batch, the coefficient bound measured inside its forward"}
+        del brs
+
     # ---- report ------------------------------------------------------------------------------------------------------
     D = float(np.mean(Ds))
     P, T = W * H, nth * ntw
@@ -586,11 +665,14 @@ def main():
         "config": {"workload": WORKLOADS[args.config], "gaussians": N, "visible_after_cull": n_vis, "image": [H, W],
                    "sh_degree": C - 1, "tile_pairs_D": D, "cameras_per_step": B, "steps_in_flight": len(slots),
                    "backward_segments_per_tile": nseg,
-                   "sh_basis": (f"tile-local degree-2 polynomial fit of the per-pixel basis (coefficient bound {state['sh_bound']:.3f}, "
-                                f"largest pixel size {ps_max:.3g}: error bound {0.25 * state['sh_bound'] * 0.7 * (7.5 * 2 ** 0.5 * ps_max) ** 3:.1e} "
-                                "of a colour value; gsgen_vol_render_sh_batch_bounded)") if poly_applies else "exact per-pixel basis",
+                   "sh_basis": (f"routed on the device, per view and per step: the coefficient bound is measured by every step inside the "
+                                f"timed region (gsgen_sh_l1_bound; read back afterwards: S = {S_dev:.3f}) and {n_poly_job} of {ncam_job} "
+                                f"cameras took the tile-local degree-2 polynomial fit of the per-pixel basis (error bound "
+                                f"{0.25 * S_dev * 0.7 * (7.5 * 2 ** 0.5 * max(ps_cam)) ** 3:.1e} of a colour value at the widest "
+                                f"camera, limit 1e-5), the others the exact kernel") if state["bounded"] else "exact per-pixel basis",
                    "geometry_stream": "high priority, per slot" if args.geo_priority else "the slot's stream",
-                   "parallelism": f"camera-sharded x{world}",
+                   "parallelism": f"camera-sharded x{world}", "rccl_world_size": (dist.get_world_size() if dist is not None else 1),
+                   "renders_per_s_per_rank": per_rank,
                    "gather": ("one rccl all_gather of the step's rendered images, on its own stream behind the step's forward"
                               if dist is not None else "none")},
         "timing": {"repeats": len(regions), "reported": "median repeat", "renders_per_s_min": world * B * K / max(els),
@@ -623,6 +705,8 @@ def main():
         res["roofline"]["alone_valu_frac"] = valu_floor / alone["bwd_launch_ms"]
     if exact_basis is not None:
         res["exact_basis"] = exact_basis
+    if surface is not None:
+        res["autograd_surface"] = surface
     if one is not None:
         res["one_render_in_flight"] = one
     if rank == 0:

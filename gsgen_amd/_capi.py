@@ -83,10 +83,15 @@ SIGNATURES = {
     "gsgen_vol_render_sh_batch": [u32, C.POINTER(ShView), u32, vp, vp, u32, u32, u32, u32, u32, u32, f32, u32, vp, vp],
     "gsgen_vol_render_backward_sh_batch": [u32, C.POINTER(ShView), u32, vp, vp, vp, vp, u32, u32, u32, u32, u32, u32,
                                            f32, u32, vp, vp],
-    "gsgen_vol_render_sh_batch_bounded": [u32, C.POINTER(ShView), u32, vp, vp, u32, u32, u32, u32, u32, u32, f32, u32, f32, vp, vp],
+    "gsgen_vol_render_sh_batch_bounded": [u32, C.POINTER(ShView), u32, vp, vp, u32, u32, u32, u32, u32, u32, f32, u32, vp, vp, vp],
     "gsgen_vol_render_backward_sh_batch_bounded": [u32, C.POINTER(ShView), u32, vp, vp, vp, vp, u32, u32, u32, u32, u32, u32,
-                                                   f32, u32, f32, vp, vp],
+                                                   f32, u32, vp, vp, vp],
+    "gsgen_vol_render_sh_bounded": [u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, u32, f32, f32,
+                                    u32, u32, u32, f32, vp, vp, vp, vp, u32, vp, vp],
+    "gsgen_vol_render_backward_sh_bounded": [u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                                             vp, u32, u32, u32, f32, f32, u32, u32, u32, f32, vp, vp, vp, u32, vp, vp],
     "gsgen_sh_l1_bound": [u32, vp, u32, vp, vp],
+    "gsgen_sh_l1_bound_check": [u32, vp, u32, vp, vp, vp],
     "gsgen_vol_render_rgbd_batch": [u32, C.POINTER(RgbdView), u32, vp, vp, u32, u32, u32, u32, u32, f32, vp, vp],
     "gsgen_vol_render_rgbd_backward_batch": [u32, C.POINTER(RgbdView), u32, vp, vp, vp, u32, u32, u32, u32, u32, f32, vp,
                                              vp],
@@ -176,7 +181,8 @@ class Lib:
             raise ValueError(f"bad kernel variant {name}={value}")
 
     def sh_poly_applies(self, sh_l1_bound, max_pixel_size, bands=4):
-        """does a batched SH launch with this coefficient bound and largest pixel size take the polynomial basis?"""
+        """the device's routing rule, on the host (for reports): does a view of this pixel size take the polynomial form of
+        the SH basis under the coefficient bound value `sh_l1_bound`?"""
         fn = self.cdll.gsgen_sh_poly_applies
         fn.argtypes, fn.restype = [f32, f32, u32], i32
         return bool(fn(float(sh_l1_bound), float(max_pixel_size), int(bands)))

@@ -30,23 +30,9 @@ __all__ = [
 
 # ---- the reference's CHECK_* macros (gs/src/include/common.h:29-54) ---------------------------
 # ---- which library the mirror drives ------------------------------------------------------------
-# The product binds the HIP library and accepts GPU tensors only (there is NO CPU path).  The tests additionally run
-# the reference's own autograd classes (gs/renderer.py, imported from /root/reference) on this mirror in the GPU-less
-# authoring container: they bind the SIMT-emulator build of the SAME kernels (oracle/_build/libgsgen_emu.so, test
-# infrastructure that is not part of the package) and hand it host tensors.  `_bind_library_for_tests` is that hook;
-# nothing in gsgen_amd calls it.
-_bound_lib = None
-_host_tensors_ok = False
-
-
-def _bind_library_for_tests(lib, host_tensors=False):
-    """lib: a gsgen_amd._capi.Lib (None restores the HIP library); host_tensors: accept CPU tensors"""
-    global _bound_lib, _host_tensors_ok
-    _bound_lib, _host_tensors_ok = lib, bool(host_tensors) and lib is not None
-
-
-def _load():
-    return _bound_lib if _bound_lib is not None else _capi.load()
+# The HIP library, GPU tensors only: there is NO CPU path in this package.
+_load = _capi.load
+_ACCEPT_HOST_TENSORS = False
 
 
 class _no_guard:
@@ -65,7 +51,7 @@ def _guard(t):
 def _check_dc(x, name, dtype, what):
     if not isinstance(x, torch.Tensor):
         raise TypeError(f"{name} must be a torch.Tensor")
-    if not x.is_cuda and not _host_tensors_ok:
+    if not x.is_cuda and not _ACCEPT_HOST_TENSORS:
         raise RuntimeError(f"{name} must be a CUDA tensor")
     if not x.is_contiguous():
         raise RuntimeError(f"{name} must be a contiguous tensor")
@@ -204,6 +190,17 @@ def tile_based_vol_rendering_scalar_backward(mean, cov, scalar, alpha, start, en
             float(pixel_size_x), float(pixel_size_y), int(H), int(W), float(thresh), _stream(mean))
 
 
+def _sh_bound(sh_coeffs, C, tile_size):
+    """SH degree 3: S = max sum_{k >= 1} |sh| of the call's coefficients, measured on the device in front of the launch (one
+    5-us pass, no sync) into a scratch float; the kernels route on it -- the tile-local polynomial form of the per-pixel basis
+    where its error bound holds, the exact kernel elsewhere (include/gsgen_hip.h, "the coefficient bound").  None otherwise."""
+    if int(C) != 4 or int(tile_size) != 16 or sh_coeffs.numel() == 0:
+        return None
+    bound = torch.empty(1, device=sh_coeffs.device, dtype=torch.float32)
+    _load().sh_l1_bound(sh_coeffs.numel() // 48, _p(sh_coeffs), 4, _p(bound), _stream(sh_coeffs))
+    return bound
+
+
 def _sh_fwd(mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out, topleft, c2w, tile_size,
             n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H, W, C, thresh, bg_rgb):
     _fwd_common(mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out, topleft, "sh_coeffs")
@@ -213,11 +210,12 @@ def _sh_fwd(mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out, topleft,
     if int(C) < 1 or int(C) > 4:
         return  # the reference's switch silently does nothing (render.cu:507-544)
     with _guard(mean):
-        _load().vol_render_sh(
+        bound = _sh_bound(sh_coeffs, C, tile_size)
+        _load().vol_render_sh_bounded(
             mean.size(0), gaussian_ids.size(0), _p(mean), _p(cov), _p(sh_coeffs), _p(alpha), _p(start),
             _p(end), _p(gaussian_ids), _p(out), _p(topleft), _p(c2w), int(tile_size), int(n_tiles_h),
             int(n_tiles_w), float(pixel_size_x), float(pixel_size_y), int(H), int(W), int(C),
-            float(thresh), _p(bg_rgb), None, _stream(mean))
+            float(thresh), _p(bg_rgb), None, None, None, 0, _p(bound), _stream(mean))
 
 
 def _sh_bwd(mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out, grad_mean, grad_cov,
@@ -233,12 +231,13 @@ def _sh_bwd(mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out, grad_mea
     if int(C) < 1 or int(C) > 4:
         return
     with _guard(mean):
-        _load().vol_render_backward_sh(
+        bound = _sh_bound(sh_coeffs, C, tile_size)  # the same coefficients: the same routing as the frame's forward
+        _load().vol_render_backward_sh_bounded(
             mean.size(0), gaussian_ids.size(0), _p(mean), _p(cov), _p(sh_coeffs), _p(alpha), _p(start),
             _p(end), _p(gaussian_ids), _p(out), _p(grad_mean), _p(grad_cov), _p(grad_sh_coeffs),
             _p(grad_alpha), _p(grad_out), _p(topleft), _p(c2w), int(tile_size), int(n_tiles_h),
             int(n_tiles_w), float(pixel_size_x), float(pixel_size_y), int(H), int(W), int(C),
-            float(thresh), _p(bg_rgb), _stream(mean))
+            float(thresh), _p(bg_rgb), None, None, 0, _p(bound), _stream(mean))
 
 
 def tile_based_vol_rendering_sh(mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out, topleft,

@@ -55,7 +55,7 @@ class _render_batch(torch.autograd.Function):
         if fused:
             return _render_batch._forward_fused(ctx, mean, qvec, svec, alpha, col, cams, br, B, C, bg_rgb, thresh,
                                                 detach_depth, stats, out, T)
-        cur = br._fork(B, (cams, out, T))
+        cur = br._fork(B, (cams, out, T) + ((br._sh_bound,) if br._sh_bound is not None else ()))
         with torch.cuda.device(dev):
             for i in range(B):
                 buf, s, ci = br.slots[i], br.streams[i % len(br.streams)].cuda_stream, br._cis[i]
@@ -67,10 +67,11 @@ class _render_batch(torch.autograd.Function):
                 if stats is not None:
                     lib.densify_update(N, _p(buf.cov2d), None, _p(buf.mask), _p(stats.max_radii2d), None, None, s)
                 if C > 0:
-                    lib.vol_render_sh_ordered(N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col), _p(alpha),
+                    lib.vol_render_sh_bounded(N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col), _p(alpha),
                                               _p(buf.start), _p(buf.end), _p(buf.ids), out_p + 12 * H * W * i, cam + 224,
                                               cam + 232, 16, buf.nth, buf.ntw, psx, psy, H, W, C, thresh,
-                                              _p(bg_rgb), T_p + 4 * H * W * i, buf.tile_order(), s)
+                                              _p(bg_rgb), T_p + 4 * H * W * i, buf.tile_order(), None, 0,
+                                              _p(br._sh_bound), s)
                 else:
                     lib.vol_render_start_end_with_T(N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col), _p(alpha),
                                                     _p(buf.start), _p(buf.end), _p(buf.ids), out_p + 12 * H * W * i,
@@ -84,7 +85,7 @@ class _render_batch(torch.autograd.Function):
         ctx.save_for_backward(mean, qvec, svec, alpha, col, cams, out, T)
         ctx.bg_shape = tuple(bg_rgb.shape) if (bg_rgb is not None and ctx.needs_input_grad[9]) else None
         ctx.br, ctx.B, ctx.C, ctx.thresh, ctx.detach, ctx.stats = br, B, C, thresh, detach_depth, stats
-        ctx.sh_bound = br._sh_bound  # forward and backward of a batch take the same SH-basis decision
+        ctx.sh_bound = br._sh_bound  # forward and backward of a batch route on the same device value
         ctx.cis = list(br._cis[:B])
         ctx.mark_non_differentiable(T)
         return out, T
@@ -123,7 +124,7 @@ class _render_batch(torch.autograd.Function):
                                          None, s)
             if C > 0:
                 lib.vol_render_sh_batch_bounded(B, views, N, _p(col), _p(alpha), 16, br.slots[0].nth, br.slots[0].ntw, H, W, C,
-                                                thresh, br.segments, br._sh_bound, _p(bws), s)
+                                                thresh, br.segments, _p(br._sh_bound), _p(bws), s)
             else:
                 lib.vol_render_rgb_batch(B, views, N, _p(col), _p(alpha), 16, br.slots[0].nth, br.slots[0].ntw, H, W,
                                          thresh, _p(bws), s)
@@ -135,7 +136,7 @@ class _render_batch(torch.autograd.Function):
         ctx.save_for_backward(mean, qvec, svec, alpha, col, cams, out, T)
         ctx.bg_shape = tuple(bg_rgb.shape) if (bg_rgb is not None and ctx.needs_input_grad[9]) else None
         ctx.br, ctx.B, ctx.C, ctx.thresh, ctx.detach, ctx.stats = br, B, C, thresh, detach_depth, stats
-        ctx.sh_bound = br._sh_bound  # forward and backward of a batch take the same SH-basis decision
+        ctx.sh_bound = br._sh_bound  # forward and backward of a batch route on the same device value
         ctx.cis = list(br._cis[:B])
         ctx.mark_non_differentiable(T)
         return out, T
@@ -168,7 +169,7 @@ class _render_batch(torch.autograd.Function):
             if C > 0:
                 lib.vol_render_backward_sh_batch_bounded(B, ctx.views, N, _p(col), _p(alpha), _p(g_col), _p(g_alpha), 16,
                                                          br.slots[0].nth, br.slots[0].ntw, H, W, C, thresh, br.segments,
-                                                         ctx.sh_bound, _p(ctx.bws), s)
+                                                         _p(ctx.sh_bound), _p(ctx.bws), s)
             else:
                 lib.vol_render_rgb_backward_batch(B, ctx.views, N, _p(col), _p(alpha), _p(g_col), _p(g_alpha), 16,
                                                   br.slots[0].nth, br.slots[0].ntw, H, W, thresh, _p(ctx.bws), s)
@@ -199,7 +200,7 @@ class _render_batch(torch.autograd.Function):
         g_svec, g_alpha = g3d[7 * N:10 * N].view(N, 3), g3d[10 * N:]
         g_col = torch.zeros_like(col)
         cams_p, out_p, grad_p, g2d_p = cams.data_ptr(), out.data_ptr(), grad.data_ptr(), g2d.data_ptr()
-        cur = br._fork(B, (grad, g2d, g3d, g_col))
+        cur = br._fork(B, (grad, g2d, g3d, g_col) + ((ctx.sh_bound,) if ctx.sh_bound is not None else ()))
         with torch.cuda.device(dev):
             for i in range(B):
                 buf, s, ci = br.slots[i], br.streams[i % len(br.streams)].cuda_stream, ctx.cis[i]
@@ -208,11 +209,12 @@ class _render_batch(torch.autograd.Function):
                 g_cov2d = g_mean2d + 8 * N
                 psx, psy = 1.0 / ci.fx, 1.0 / ci.fy
                 if C > 0:
-                    lib.vol_render_backward_sh_ordered(N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col), _p(alpha),
+                    lib.vol_render_backward_sh_bounded(N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col), _p(alpha),
                                                        _p(buf.start), _p(buf.end), _p(buf.ids), out_p + 12 * H * W * i,
                                                        g_mean2d, g_cov2d, _p(g_col), _p(g_alpha),
                                                        grad_p + 12 * H * W * i, cam + 224, cam + 232, 16, buf.nth,
-                                                       buf.ntw, psx, psy, H, W, C, thresh, None, buf.tile_order(), s)
+                                                       buf.ntw, psx, psy, H, W, C, thresh, None, buf.tile_order(), None, 0,
+                                                       _p(ctx.sh_bound), s)
                 else:
                     lib.vol_render_backward_start_end(N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col), _p(alpha),
                                                       _p(buf.start), _p(buf.end), _p(buf.ids), out_p + 12 * H * W * i,
@@ -399,7 +401,7 @@ class BatchRenderer:
         self._totals_host = torch.zeros(max_batch, dtype=torch.int32).pin_memory()
         self._totals_event, self._totals_B = None, 0
         self._generation = 0
-        self._sh_bound = -1.0
+        self._sh_bound = None
         self._table_cache = {}
         # the slots' depth buffers are the rows of one matrix (the heads' backward reads depths[:B] as one tensor)
         self._depths = torch.empty(max_batch, N, device=device, dtype=torch.float32)
@@ -531,16 +533,22 @@ class BatchRenderer:
             cur.wait_stream(st)
 
     def render(self, mean, qvec, svec, alpha, col, cam_infos, c2ws, C=0, bg_rgb=None, thresh=1e-4,
-               frustum_radius=6.0, tile_radius=6.0, detach_depth=True, stats=None, sh_l1_bound=None):
+               frustum_radius=6.0, tile_radius=6.0, detach_depth=True, stats=None, sh_basis="auto", sh_l1_bound=None,
+               verify_bound=False):
         """-> (rgb [B,H,W,3], T [B,H,W,1]); differentiable wrt mean, qvec, svec, alpha, col.
 
         cam_infos: B CameraInfo of this renderer's (W, H); c2ws: B poses [3,4] (arrays or tensors).
         col is sh_coeffs [N,3,C*C] for C in 1..4, post-activation rgb [N,3] for C == 0.
-        sh_l1_bound (C == 4, fused launches): a bound on max_i max_c sum_{k>=1} |sh[i][c][k]| (renderer.sh_l1_bound(sh)
-        computes it).  With it, and cameras narrow enough for the error bound, the launches take the tile-local polynomial
-        form of the per-pixel SH basis (include/gsgen_hip.h, gsgen_vol_render_sh_batch_bounded: images within 1e-5 of the
-        exact kernels, +20 % renders/s at 8 x 800^2); None / 0: the exact kernels.
+        sh_basis (C == 4): "auto" (default) -- the coefficient bound S = max_i max_c sum_{k>=1} |sh[i][c][k]| is measured on the
+        device in front of the launch (one 5-us pass on the render's stream, no host sync) and the kernels route on it per view:
+        the tile-local polynomial form of the per-pixel SH basis where 0.25 S 0.7 delta^3 <= 1e-5, the exact kernel elsewhere
+        (include/gsgen_hip.h "the coefficient bound"; images within 1e-5 of the exact kernels, +20 % renders/s at 8 x 800^2).
+        "exact": the exact kernels only.  sh_l1_bound: a 1-float DEVICE tensor that already holds S for THESE coefficients
+        (e.g. FusedAdam.sh_l1_bound, produced by the optimiser step that wrote them) -- skips the pass; verify_bound=True
+        checks such a tensor on the device first (debug: one host sync, raises if any row exceeds it).
         """
+        if sh_basis not in ("auto", "exact"):
+            raise ValueError("sh_basis: 'auto' or 'exact'")
         B = len(cam_infos)
         if B > len(self.slots):
             raise ValueError(f"batch of {B} cameras, renderer was sized for {len(self.slots)}")
@@ -549,7 +557,18 @@ class BatchRenderer:
                 raise ValueError("every camera of a batch must have the renderer's (W, H)")
         cams = self._upload(cam_infos, c2ws, frustum_radius, tile_radius)
         self._cis = list(cam_infos)
-        self._sh_bound = float(sh_l1_bound) if sh_l1_bound is not None else -1.0  # (-1: the library's process-wide default, off)
+        self._sh_bound = None
+        if int(C) == 4 and sh_basis == "auto":
+            if sh_l1_bound is not None:
+                if not (isinstance(sh_l1_bound, torch.Tensor) and sh_l1_bound.is_cuda and sh_l1_bound.dtype == torch.float32
+                        and sh_l1_bound.numel() == 1):
+                    raise ValueError("sh_l1_bound: a 1-float CUDA tensor (the bound lives on the device; "
+                                     "renderer.sh_l1_bound_device computes it)")
+                if verify_bound:
+                    R.verify_sh_l1_bound(col, sh_l1_bound)
+                self._sh_bound = sh_l1_bound
+            else:
+                self._sh_bound = R.sh_l1_bound_device(col)
         return _render_batch.apply(mean, qvec, svec, alpha, col, cams, self, B, int(C), bg_rgb, float(thresh),
                                    bool(detach_depth), stats)
 

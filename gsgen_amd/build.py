@@ -34,7 +34,7 @@ def _newer(src, dst, extra=()):
         return True
     t = os.path.getmtime(dst)
     deps = [src, os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "composite_common.hpp"),
-            os.path.join(CSRC, "gsgen_mfma.hpp"),
+            
             os.path.join(HERE, "..", "include", "gsgen_hip.h"), __file__, *extra]
     return any(os.path.getmtime(d) > t for d in deps)
 
@@ -76,8 +76,9 @@ def build_torch_ext(force=False, verbose=False):
     out = os.path.join(EXT_DIR, "_gs" + sysconfig.get_config_var("EXT_SUFFIX"))
     if force or _newer(src, out, extra=(lib,)):
         tdir = os.path.dirname(torch.__file__)
+        rocm = os.environ.get("ROCM_PATH") or os.environ.get("ROCM_HOME") or "/opt/rocm"
         inc = [os.path.join(tdir, "include"), os.path.join(tdir, "include", "torch", "csrc", "api", "include"),
-               "/opt/rocm/include", sysconfig.get_paths()["include"]]
+               os.path.join(rocm, "include"), sysconfig.get_paths()["include"]]
         tlib = os.path.join(tdir, "lib")
         cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-deprecated-declarations", "-D__HIP_PLATFORM_AMD__=1",
                "-DUSE_ROCM=1", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}",
@@ -89,30 +90,7 @@ def build_torch_ext(force=False, verbose=False):
     return out
 
 
-TOOLS_DIR = os.path.join(HERE, "..", "tools", "stress")
-
-
-def build_tools(force=False, verbose=False):
-    """tools/stress: the fresh-process stress harness of the SH backward variants (bwd_stress, a C++ program on the
-    C ABI, linked against the in-tree library with a relative rpath) and the stand-alone MFMA-chain reproducer
-    (mfma_first_launch).  Test tools, not product."""
-    lib = build()
-    out = []
-    for name, link in (("bwd_stress", [f"-L{LIBDIR}", "-lgsgen_hip", "-Wl,-rpath,$ORIGIN/../../gsgen_amd/lib"]),
-                       ("mfma_first_launch", [])):
-        src, exe = os.path.join(TOOLS_DIR, name + ".cpp"), os.path.join(TOOLS_DIR, name)
-        if force or _newer(src, exe, extra=(lib,)):
-            cmd = [HIPCC, "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-x", "hip", src, "-o", exe, *link]
-            if verbose:
-                print(" ".join(cmd), flush=True)
-            subprocess.check_call(cmd)
-        out.append(exe)
-    return out
-
-
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
-    if "--tools" in sys.argv:
-        print(build_tools(force="--force" in sys.argv, verbose=True))
     if "--ext" in sys.argv:
         print(build_torch_ext(force="--force" in sys.argv, verbose=True))

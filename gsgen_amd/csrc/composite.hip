@@ -17,9 +17,9 @@
 // reference's one LDS atomic per (pixel, Gaussian, component).  The SH kernels that run by default
 // (k_composite_fwd_sh_vec / k_composite_bwd_sh_vec) carry the per-pixel arithmetic as packed fp32 pixel
 // pairs; the backward can be launched per (tile, list segment) from checkpoints the forward leaves
-// behind; with a caller-supplied bound on the coefficients the batched launches evaluate the per-pixel
-// SH basis through a per-tile polynomial fit (NB = 6, composite_common.hpp).  k_composite_bwd_sh_mfma
-// (further down; opt-in) moves the 48 SH components of the reduction onto the matrix cores.
+// behind; given the device-resident bound on the coefficients (gsgen_sh_l1_bound) the SH degree-3 launches
+// evaluate the per-pixel SH basis through a per-tile polynomial fit (NB = 6, composite_common.hpp) for the views
+// whose error bound holds -- routed per view on the device (poly_route), the exact kernel renders the others.
 //
 // Numerics: the per-(pixel, Gaussian) Gaussian is evaluated in fp32 on the fast path (the
 // reference uses fp64 for RGB/scalar, fp32 for SH).  For RGB/scalar the quadratic form is
@@ -35,7 +35,6 @@
 #include <string>
 #include <type_traits>
 #include <vector>
-#include <gsgen_mfma.hpp>
 
 namespace gs {
 
@@ -158,6 +157,9 @@ __global__ void __launch_bounds__(TS * TS / PPL) k_composite_fwd(CompParams p_ar
   constexpr int NCH = TR::NCH;
   __shared__ Stage<MODE, CB> S;
 
+  if constexpr (MODE == MODE_SH && CB == 4) {
+    if (poly_route(p)) return;  // this view is rendered by the polynomial-basis kernel of the same enqueue
+  }
   int tx, ty;
   if (!block_tile(p, tx, ty, bid)) return;  // uniform over the workgroup
   const int tile = ty * p.ntw + tx;
@@ -370,6 +372,12 @@ k_composite_fwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
   __shared__ alignas(16) float Ws[POLY ? kBatch * 3 * kPolyNB : 4];   // POLY: transformed coefficients of the staged batch
                                                                        // (and, before the first batch, the nine node bases)
 
+  // one of the two kernels of a bounded enqueue renders the view (uniform over the workgroup)
+  if constexpr (POLY) {
+    if (!poly_route(p)) return;
+  } else if constexpr (CB == 4) {
+    if (poly_route(p)) return;
+  }
   int tx, ty;
   if (!block_tile(p, tx, ty, bid)) return;  // uniform over the workgroup
   const int tile = ty * p.ntw + tx;
@@ -571,10 +579,13 @@ k_composite_bwd_pixel(CompParams p_arg, const CompParams *__restrict__ plist) {
   constexpr int NCH = TR::NCH;
   constexpr int P = TR::P;
   __shared__ Stage<MODE, CB> S;
+  if constexpr (MODE == MODE_SH && CB == 4) {
+    if (poly_route(p)) return;  // this view's gradients come from the polynomial-basis kernel of the same enqueue
+  }
 
   // Segmented launch (SH only): workgroup = (tile, segment of kSegLen list entries) starting from the
-  // state the forward left in front of the segment (CompParams::ckpt / stop); segment-major order, see
-  // k_composite_bwd_sh_mfma.
+  // state the forward left in front of the segment (CompParams::ckpt / stop); segment-major order: all
+  // first segments, then all second ones, ... (the heavy tiles' segments spread over the launch).
   const int nseg = (MODE == MODE_SH && p.nseg > 1) ? p.nseg : 1;
   const uint32_t tiles_grid = grid / (uint32_t)nseg;
   const int seg = (int)(bid / tiles_grid);
@@ -806,14 +817,6 @@ k_composite_bwd_pixel(CompParams p_arg, const CompParams *__restrict__ plist) {
 // The Gaussian evaluation is gauss_sh_pair: bit for bit gauss_eval<MODE_SH>, so "skip" and "saturated" decisions
 // equal the forward's.  Same launch shapes as k_composite_bwd_pixel (one workgroup per tile or per (tile, segment),
 // 256 / PPL threads); PPL = 4 (one wavefront per tile) or 2.
-#if defined(GSGEN_BWD_WAVES3)  // experiment build: three wavefronts per SIMD (168 registers), whatever it takes
-#define GSGEN_BWD_VEC_ATTR __attribute__((amdgpu_waves_per_eu(3, 3)))
-#elif defined(GSGEN_POLY_WAVES4)  // experiment build: the polynomial-basis instantiation at four wavefronts per SIMD
-// (128 registers, 64 bytes of scratch -- two reloads per list entry; not measured yet, profiles/r02_notes.md)
-#define GSGEN_BWD_VEC_ATTR __attribute__((amdgpu_waves_per_eu(NB > 0 ? 4 : 1)))
-#else
-#define GSGEN_BWD_VEC_ATTR
-#endif
 // CHRED: the gradient vector is reduced channel by channel (wave_reduce_scatter2_rows on the 3 x CCP SH components as
 // soon as a channel's accumulators are complete, the 7 geometric components likewise, one quad_reduce_scatter4 at the
 // end) instead of as one 64-component vector after the third channel: the same number of exchanges, but the finished
@@ -822,7 +825,7 @@ k_composite_bwd_pixel(CompParams p_arg, const CompParams *__restrict__ plist) {
 // (composite_common.hpp) -- 6-term contractions, 3 x 6 SH gradient components across the lanes, expanded by the tile's V
 // (through 24 floats of LDS) in front of the 48 atomics.
 template <int CB, int PPL, bool BATCH = false, bool CHRED = false, int NB = 0>
-__global__ void __launch_bounds__(256 / PPL) GSGEN_BWD_VEC_ATTR
+__global__ void __launch_bounds__(256 / PPL)
 k_composite_bwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
   static_assert(PPL == 4 || PPL == 2, "pixel pairs: 2 or 4 pixels per lane");
   constexpr bool POLY = NB > 0;
@@ -843,6 +846,12 @@ k_composite_bwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
                                                                   // (and, before the first batch, the nine node bases)
   __shared__ float gw_s[POLY ? 3 * 8 : 1];                       // POLY: a splat's reduced gradient in the tile's basis
 
+  // one of the two kernels of a bounded enqueue handles the view (uniform over the workgroup)
+  if constexpr (POLY) {
+    if (!poly_route(p)) return;
+  } else if constexpr (CB == 4) {
+    if (poly_route(p)) return;
+  }
   const int nseg = p.nseg > 1 ? p.nseg : 1;
   const uint32_t tiles_grid = grid / (uint32_t)nseg;
   const int seg = (int)(bid / tiles_grid);
@@ -1433,389 +1442,17 @@ k_composite_bwd_chan_vec(CompParams p_arg, const CompParams *__restrict__ plist)
   }
 }
 
-// ============================================================================================
-// backward, SH, matrix-core form
-// ============================================================================================
-// d L / d sh[g][c][b] = sum over the tile's pixels of gs[pixel][g,c] * Y[pixel][b]: a contraction
-// over pixels of a per-(Gaussian, channel) scalar with the tile's FIXED per-pixel basis table,
-// i.e. a [rows = (g,c)] x [K = 256 pixels] x [16 basis] matrix product.  k_composite_bwd_pixel
-// does it as 48 FMAs per pixel plus a 48-component cross-lane reduction per Gaussian (~40 % of
-// that kernel's VALU time); here the lanes only produce the 3 scalars gs[.][g,c] per pixel, stage
-// them in LDS as split bf16 (x = hi + lo, both round-to-nearest: 2^-17 relative), and one
-// v_mfma_f32_16x16x32_bf16 chain per kNF Gaussians contracts them with Y (held in registers in
-// B-operand layout for the whole tile) with fp32 accumulation: hi*hi + hi*lo + lo*hi.  The
-// remaining 7 components (mean2d, cov2d, alpha) go through an 8-wide reduce-scatter.
-// One wavefront per tile, 4 pixels per lane; K index of pixel j of lane p is 4 p + j.
-constexpr int kNF = 3;                 // Gaussians per matrix flush (3 rows each, 16-row MFMA)
-constexpr int kKBm = 32;               // staged records per LDS round in this kernel
-
-// Staged rows: 64 * PPL pixels x bf16 plus one 16-byte pad.  The pad staggers consecutive rows by
-// one bank group, so the 16 rows an MFMA operand read touches at one k offset are conflict-free,
-// the 64 writes of one row are contiguous, and every address is (lane base) + (immediate).
-template <int PPL>
-struct MfmaCfg {
-  static constexpr int ROW_DW = 32 * PPL + 4;  // dwords per row
-  static constexpr int KSTEPS = 2 * PPL;       // 32 pixels per MFMA k-step
-  static constexpr int NW = 4 / PPL;           // wavefronts per tile
-};
-
-// lane `lane` owns pixels k = PPL * lane .. + PPL of its wavefront's K range
-template <int PPL>
-__device__ __forceinline__ void stage_split(uint32_t *hi, uint32_t *lo, int row, int lane, const float (&v)[PPL]) {
-  if constexpr (PPL == 1) {
-    const uint32_t h = pack_bf16x2(v[0], 0.0f);
-    const float r = v[0] - __uint_as_float(h << 16);
-    const int hw = 2 * row * MfmaCfg<PPL>::ROW_DW + lane;  // halfword index
-    reinterpret_cast<uint16_t *>(hi)[hw] = (uint16_t)h;
-    reinterpret_cast<uint16_t *>(lo)[hw] = (uint16_t)pack_bf16x2(r, 0.0f);
-    return;
-  }
-  constexpr int J1 = PPL > 1 ? 1 : 0;  // (keeps the PPL == 1 instantiation well-formed)
-  const int dw = row * MfmaCfg<PPL>::ROW_DW + (PPL / 2) * lane;
-  const uint32_t h0 = pack_bf16x2(v[0], v[J1]);
-  const float r0 = v[0] - __uint_as_float(h0 << 16), r1 = v[J1] - __uint_as_float(h0 & 0xffff0000u);
-  if constexpr (PPL == 4) {
-    const uint32_t h1 = pack_bf16x2(v[2], v[3]);
-    const float r2 = v[2] - __uint_as_float(h1 << 16), r3 = v[3] - __uint_as_float(h1 & 0xffff0000u);
-    *reinterpret_cast<uint2 *>(hi + dw) = make_uint2(h0, h1);
-    *reinterpret_cast<uint2 *>(lo + dw) = make_uint2(pack_bf16x2(r0, r1), pack_bf16x2(r2, r3));
-  } else {
-    hi[dw] = h0;
-    lo[dw] = pack_bf16x2(r0, r1);
-  }
-}
-// operand fragment of lane `lane` for k-step s: row `row`, pixels 32 s + 8 (lane >> 4) .. + 8
-template <int PPL>
-__device__ __forceinline__ int frag_dw(int row, int lane, int s) {
-  return row * MfmaCfg<PPL>::ROW_DW + 4 * (lane >> 4) + 16 * s;
-}
-
-// PPL = 4: one wavefront per tile.  PPL = 2: two wavefronts per tile, each contracting its own 128
-// pixels (the partial sums meet in the atomics); the records are staged once for both.
-template <int CB, int PPL, bool BATCH = false>
-__global__ void __launch_bounds__(256 / PPL) __attribute__((amdgpu_waves_per_eu(2)))
-k_composite_bwd_sh_mfma(CompParams p_arg, const CompParams *__restrict__ plist) {
-  uint32_t bid = blockIdx.x, grid = gridDim.x;
-  const CompParams p = BATCH ? plist[batch_view(p_arg, bid, &grid)] : p_arg;  // see k_composite_fwd
-  constexpr int MODE = MODE_SH;
-  using TR = Traits<MODE, CB>;
-  using MC = MfmaCfg<PPL>;
-  constexpr int NT = 256 / PPL, ROWS = NT / 16, NCH = 3, NW = MC::NW, KS = MC::KSTEPS;
-  constexpr int NROW = kNF * 3;
-  static_assert(PPL == 4 || PPL == 2 || PPL == 1, "one, two or four wavefronts per tile");
-  static_assert(NROW >= 8 && kNF <= 4, "basis table is transposed through the A buffers 8 rows at a time");
-  __shared__ Stage<MODE, CB, kKBm> S;
-  __shared__ alignas(16) uint32_t Ahi_[NW][NROW * MC::ROW_DW];
-  __shared__ alignas(16) uint32_t Alo_[NW][NROW * MC::ROW_DW];
-  __shared__ int fid_[NW][4];
-  __shared__ alignas(16) float Go[NT * 3 * PPL];  // grad_out of the lane's PPL pixels x 3 channels
-
-  // Segmented launch: workgroup = (tile, segment of kSegLen list entries); the forward left the
-  // state in front of every segment (CompParams::ckpt / stop), so segments are independent.
-  // Segment-major order (all tiles' segment 0, then all segment 1, ...): consecutive workgroup ids
-  // go round-robin over the 8 XCDs, so a tile-major order with 8 segments would park every tile's
-  // segment k on XCD k -- and only the first few segments have work.
-  const int nseg = p.nseg > 1 ? p.nseg : 1;
-  const uint32_t tiles_grid = grid / (uint32_t)nseg;
-  const int seg = (int)(bid / tiles_grid);
-  int tx, ty;
-  if (!block_tile(p, tx, ty, bid % tiles_grid)) return;
-  const int tile = ty * p.ntw + tx;
-  const int st = p.start[tile];
-  const int n = (st < 0) ? 0 : (p.end[tile] - st);
-  if (n <= 0 || n < p.n_lo || n >= p.n_hi) return;
-  const int e_lo = seg * kSegLen;
-  const int e_hi = (seg == nseg - 1) ? n : min(n, e_lo + kSegLen);  // the last segment takes the rest
-  if (e_lo >= n) return;
-  const int t = (int)threadIdx.x;
-  const int lane = t & 63, wv = t >> 6;
-  uint32_t *const Ahi = Ahi_[wv];
-  uint32_t *const Alo = Alo_[wv];
-  int *const fid = fid_[wv];
-  const int lx = t & 15, ly0 = t >> 4;
-  const int gx = tx * kTile + lx;
-
-  bool valid[PPL];
-  int gy[PPL];
-  float py[PPL];
-  const float px = pixel_coord(p.topleft[0], gx, p.psx);
-#pragma unroll
-  for (int j = 0; j < PPL; ++j) {
-    gy[j] = ty * kTile + ly0 + j * ROWS;
-    valid[j] = (gx < p.W) && (gy[j] < p.H);
-    py[j] = pixel_coord(p.topleft[1], gy[j], p.psy);
-  }
-
-  const int gy0 = ty * kTile + ly0;
-  bool alive[PPL];
-  {
-    bool any = false;
-#pragma unroll
-    for (int j = 0; j < PPL; ++j) {
-      alive[j] = valid[j];
-      if (nseg > 1) alive[j] = alive[j] && (p.stop[(size_t)tile * 256 + (ly0 + j * ROWS) * 16 + lx] > e_lo);
-      any |= alive[j];
-    }
-    if (__syncthreads_or((int)any) == 0) return;  // every pixel of the tile stopped before this segment
-  }
-  if constexpr (TR::CCP != TR::CC) {
-    for (int e = t; e < kKBm * TR::NCOLP; e += NT) S.col[e] = 0.0f;
-  }
-  // per-pixel SH basis, twice: Bh/Bl = the table in B-operand layout (lane l: basis l & 15, 8
-  // consecutive k per 32-pixel step), split in bf16, transposed through the A staging rows; Yp =
-  // the lane's own pixels in fp32 for the colour evaluation.  The two are built one after the
-  // other from separate evaluations so that their temporaries are never live together.
-  float R[9];
-#pragma unroll
-  for (int i = 0; i < 9; ++i) R[i] = p.rot[i];
-  auto basis_of_pixel = [&](float qx, float qy, float (&Y)[16]) { sh_basis_of_pixel<CB>(R, qx, qy, Y); };
-  u32x4 Bh[KS], Bl[KS];
-  {
-    float Yf[PPL][16];
-#pragma unroll
-    for (int j = 0; j < PPL; ++j) basis_of_pixel(px, py[j], Yf[j]);
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      if (half * 8 < TR::CC) {
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-          float v[PPL];
-#pragma unroll
-          for (int j = 0; j < PPL; ++j) v[j] = Yf[j][half * 8 + b];
-          stage_split<PPL>(Ahi, Alo, b, lane, v);
-        }
-      }
-      wave_lds_sync();
-      if (((lane & 15) >> 3) == half) {
-        const int b = lane & 7;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-          if (half * 8 + b < TR::CC) {
-            const int dw = frag_dw<PPL>(b, lane, s);
-            Bh[s] = *reinterpret_cast<const u32x4 *>(Ahi + dw);
-            Bl[s] = *reinterpret_cast<const u32x4 *>(Alo + dw);
-          } else {
-            Bh[s] = u32x4_zero();
-            Bl[s] = u32x4_zero();
-          }
-        }
-      }
-      wave_lds_sync();
-    }
-  }
-  v2f Yp[PPL][TR::NPAIR];
-  {
-    float pxo = px;
-    pxo = opaque(pxo);  // a second evaluation, not a second live copy of the first
-#pragma unroll
-    for (int j = 0; j < PPL; ++j) {
-      float Yf[16];
-      basis_of_pixel(pxo, py[j], Yf);
-#pragma unroll
-      for (int k = 0; k < TR::NPAIR; ++k) Yp[j][k] = v2f{Yf[2 * k], Yf[2 * k + 1]};
-      __builtin_amdgcn_sched_barrier(0);  // one pixel's temporaries at a time
-    }
-  }
-
-  // rem = final - (prefix colour including the current splat): the suffix the reference forms as
-  // final - Cpre_incl (vol_render_sh.h:328-333), carried as one running value per channel
-  float rem[PPL][NCH], Tr[PPL];
-#pragma unroll
-  for (int j = 0; j < PPL; ++j) {
-    const size_t pix = valid[j] ? ((size_t)gy[j] * p.W + gx) : 0;
-    float4 ck = make_float4(1.0f, 0.0f, 0.0f, 0.0f);  // state in front of entry e_lo: T, prefix rgb
-    if (seg > 0 && alive[j]) ck = p.ckpt[((size_t)tile * nseg + seg) * 256 + (ly0 + j * ROWS) * 16 + lx];
-    const float pre[3] = {ck.y, ck.z, ck.w};
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      Go[t * 3 * PPL + c * PPL + j] = valid[j] ? p.grad_out[NCH * pix + c] : 0.0f;
-      rem[j][c] = alive[j] ? p.final_img[NCH * pix + c] - pre[c] : 0.0f;
-    }
-    Tr[j] = alive[j] ? ck.x : 0.0f;
-  }
-
-  int nst = 0;  // Gaussians staged since the last flush (wave-uniform)
-  // MFMA row 4 * slot + c holds (staged Gaussian slot, channel c); it lives in LDS row 3 * slot + c.
-  // Lane l then receives slot l >> 4, channel r in accumulator element r, basis l & 15.
-  const int arow = 3 * ((lane & 15) >> 2) + (((lane & 3) < 3) ? (lane & 3) : 0);  // c == 3: unused row
-  const int a_dw = frag_dw<PPL>(arow < NROW ? arow : 0, lane, 0);
-  // contracts the staged rows with the basis table and adds the result to grad_sh (per wavefront)
-  auto flush = [&]() {
-    wave_lds_sync();
-    f32x4 acc0 = f32x4_zero(), acc1 = f32x4_zero(), acc2 = f32x4_zero();
-    // the chain, KG k-steps at a time, under the three rules of gsgen_mfma.hpp
-    constexpr int KG = KS < 4 ? KS : 4;
-#pragma unroll
-    for (int s0 = 0; s0 < KS; s0 += KG) {
-      __builtin_amdgcn_sched_barrier(0);
-      u32x4 ah[KG], al[KG];
-#pragma unroll
-      for (int s = 0; s < KG; ++s) {
-        ah[s] = *reinterpret_cast<const u32x4 *>(Ahi + a_dw + 16 * (s0 + s));
-        al[s] = *reinterpret_cast<const u32x4 *>(Alo + a_dw + 16 * (s0 + s));
-      }
-      if constexpr (KG == 4) {
-        mfma_operands_ready(ah[0], ah[1], ah[2], ah[3]);
-        mfma_operands_ready(al[0], al[1], al[2], al[3]);
-      } else {
-        mfma_operands_ready(ah[0], ah[1]);
-        mfma_operands_ready(al[0], al[1]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int s = 0; s < KG; ++s) {
-        acc0 = mfma_16x16x32_bf16(ah[s], Bh[s0 + s], acc0);
-        acc1 = mfma_16x16x32_bf16(ah[s], Bl[s0 + s], acc1);
-        acc2 = mfma_16x16x32_bf16(al[s], Bh[s0 + s], acc2);
-      }
-      mfma_wait_chain<PPL>(ah[0], Bh[s0], acc0, acc1, acc2);  // no-op unless built with GSGEN_MFMA_POLL
-      mfma_drain(acc0, acc1, acc2);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    const int slot = lane >> 4, b = lane & 15;
-    if (slot < nst && b < TR::CC) {
-      float *dst = p.g_col + (size_t)TR::NCOL * (size_t)fid[slot] + b;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) atomicAdd(dst + c * TR::CC, (acc0[c] + acc1[c]) + acc2[c]);
-    }
-    wave_lds_sync();
-    nst = 0;
-  };
-
-  for (int base = e_lo; base < e_hi; base += kKBm) {
-    const int nb = min(kKBm, e_hi - base);
-    if (base > e_lo) __syncthreads();
-    stage_batch<MODE, CB, NT, kKBm>(S, p, st + base, nb);
-    __syncthreads();
-
-    for (int g = 0; g < nb; ++g) {
-      bool any_alive = false;
-#pragma unroll
-      for (int j = 0; j < PPL; ++j) any_alive |= alive[j];
-      if (__ballot(any_alive) == 0ull) break;
-
-      // wave-uniform record: keep it in scalar registers (the vector file is the tight resource)
-      GRec r = load_rec(S, g);
-      auto uni = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
-      r.mx = uni(r.mx); r.my = uni(r.my); r.a = uni(r.a);
-      r.c0 = uni(r.c0); r.c1 = uni(r.c1); r.c2 = uni(r.c2); r.c3 = uni(r.c3);
-      r.p0 = uni(r.p0); r.p1 = uni(r.p1); r.p2 = uni(r.p2);
-      const float x = px - r.mx;
-      // registers are the tight resource here: the pixel rows are re-derived (3 ops) rather than
-      // kept, and a*G is carried instead of G (d/d alpha = sum(pAG * G) = sum(pAG * a*G) / a)
-      float ag[PPL], yq[PPL];
-      bool con[PPL];
-      bool any_con = false;
-#pragma unroll
-      for (int j = 0; j < PPL; ++j) {
-        const float pyj = pixel_coord(p.topleft[1], gy0 + j * ROWS, p.psy);
-        yq[j] = pyj - r.my;
-        const float G = gauss_eval<MODE>(r, x, yq[j], px, pyj, alive[j]);
-        ag[j] = r.a * G;
-        con[j] = alive[j] && !(ag[j] < kMinAlpha);
-        any_con |= con[j];
-      }
-      if (__ballot(any_con) == 0ull) continue;
-
-      const float inv_det = r.p1;
-      const float *cg = &S.col[g * TR::NCOLP];
-      float pAG[PPL], w[PPL], inv1m[PPL];
-#pragma unroll
-      for (int j = 0; j < PPL; ++j) {
-        w[j] = con[j] ? ag[j] * Tr[j] : 0.0f;
-        inv1m[j] = __builtin_amdgcn_rcpf(1.0f - ag[j]);
-        pAG[j] = 0.0f;
-      }
-      if (lane == 0) fid[nst] = S.id[g];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        v2f q[TR::NPAIR];
-#pragma unroll
-        for (int k = 0; k < TR::NPAIR; ++k) q[k] = *reinterpret_cast<const v2f *>(cg + c * TR::CCP + 2 * k);
-        float gsv[PPL], go[PPL];
-        if constexpr (PPL == 4) {
-          const float4 g4 = *reinterpret_cast<const float4 *>(&Go[t * 12 + c * 4]);  // lane-private
-          go[0] = g4.x; go[1] = g4.y; go[2] = g4.z; go[3] = g4.w;
-        } else if constexpr (PPL == 2) {
-          const float2 g2 = *reinterpret_cast<const float2 *>(&Go[t * 6 + c * 2]);
-          go[0] = g2.x; go[1] = g2.y;
-        } else {
-          go[0] = Go[t * 3 + c];
-        }
-#pragma unroll
-        for (int j = 0; j < PPL; ++j) {
-          v2f s2 = q[0] * Yp[j][0];
-#pragma unroll
-          for (int k = 1; k < TR::NPAIR; ++k) s2 = fma2(q[k], Yp[j][k], s2);
-          const float yv = sigmoid_fast(s2[0] + s2[1]);
-          rem[j][c] -= w[j] * yv;
-          gsv[j] = w[j] * (yv * (1.0f - yv)) * go[j];
-          pAG[j] += go[j] * (yv * Tr[j] - rem[j][c] * inv1m[j]);
-        }
-        stage_split<PPL>(Ahi, Alo, 3 * nst + c, lane, gsv);
-        if constexpr (PPL == 4) __builtin_amdgcn_sched_barrier(0);  // register diet: keep the next channel's coefficient loads out of this one
-      }
-      // mean2d (2) | cov2d (4) | alpha (1): kernel_gaussian_2d_backward (kernels.h:394-418)
-      float gr[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) gr[i] = 0.0f;
-#pragma unroll
-      for (int j = 0; j < PPL; ++j) {
-        const float pa = con[j] ? pAG[j] : 0.0f;
-        const float y = yq[j];
-        const float gg = pa * ag[j];
-        const float vx = (x * r.c3 - y * r.c2) * inv_det;
-        const float vy = (y * r.c0 - x * r.c1) * inv_det;
-        gr[0] += gg * vx;
-        gr[1] += gg * vy;
-        const float h = 0.5f * gg;
-        gr[2] += h * vx * vx;
-        gr[3] += h * vx * vy;
-        gr[5] += h * vy * vy;
-        gr[6] += gg;
-        const float om = ffma(-ag[j], con[j] ? 1.0f : 0.0f, 1.0f);  // as the forward: 1 - round(a G), explicit
-        Tr[j] *= om;
-        alive[j] = alive[j] && !(Tr[j] < p.thresh);
-      }
-      gr[4] = gr[3];
-      gr[6] = gr[6] / r.a;  // a contributing splat has a >= 1/255
-      // three halving levels (lane distances 32, 16, 8) leave 8 partials per component in 8
-      // consecutive lanes; three row-shift adds bring their sum to the last of them
-      wave_reduce_scatter_partial<8>(gr);
-      gr[0] = group8_sum_to_last(gr[0]);
-      const int comp = scatter_comp<8>(lane);
-      if ((lane & 7) == 7 && comp < 7) {
-        const size_t id = (size_t)S.id[g];
-        float *dst;
-        if (comp < 2) dst = p.g_mean + 2 * id + comp;
-        else if (comp < 6) dst = p.g_cov + 4 * id + (comp - 2);
-        else dst = p.g_alpha + id;
-        atomicAdd(dst, gr[0]);
-      }
-      if (++nst == kNF) flush();
-    }
-    bool any_alive = false;
-#pragma unroll
-    for (int j = 0; j < PPL; ++j) any_alive |= alive[j];
-    if (__syncthreads_or((int)any_alive) == 0) break;
-  }
-  if (nst > 0) flush();
-}
-
 // ---- launch helpers ---------------------------------------------------------------------------
-// Kernel variants, read once per process from the environment (A/B runs and the variant tests):
-//   GSGEN_PPL_FWD / GSGEN_PPL_BWD          pixels per lane of the per-camera forward / backward (4 = one wavefront
-//                                          per tile, the north_star shape; 2 / 1 = two / four wavefronts per tile
-//                                          sharing the staged records)
-//   GSGEN_PPL_FWD_BATCH / GSGEN_PPL_BWD_BATCH / GSGEN_PPL_BWD_SH_BATCH   the same for the batched launches
-//                                          (RGB + heads backward / SH backward)
-//   GSGEN_BWD_MFMA / GSGEN_BWD_MFMA_BATCH  0 (default) = SH gradient contraction on the vector ALUs
-//                                          (k_composite_bwd_pixel); 4 | 2 | 1 = the matrix-core kernel
-//                                          (k_composite_bwd_sh_mfma) with that many pixels per lane.  OPT-IN: the
-//                                          matrix-core chain has shown timing- and box-dependent corruption that is
-//                                          not root-caused (profiles/r01_notes.md), the vector kernel
-//                                          never has -- and north_star asks for "no MFMA" on this path.
-//   GSGEN_BATCH_MAP                        block order of the batched grids (batch_view)
+// Kernel variants.  The defaults below are the product; nothing is read from the environment.  The other shapes stay
+// compiled so that the variant tests (tests/test_variants.py) and A/B measurements (bench.py --variant) can select them
+// through gsgen_debug_set_variant:
+//   ppl_fwd / ppl_bwd                     pixels per lane of the per-camera forward / backward (4 = one wavefront per tile,
+//                                         the north_star shape; 2 / 1 = two / four wavefronts per tile sharing the staged
+//                                         records)
+//   ppl_fwd_batch / ppl_bwd_batch / ppl_bwd_sh_batch   the same for the batched launches (RGB + heads / SH backward)
+//   batch_map                             block order of the batched grids (batch_view)
+//   sh_packed / sh_chred / chan_packed    packed per-pixel arithmetic (k_composite_*_sh_vec / *_chan_vec) and the
+//                                         channel-wise gradient reduction, against the unpacked k_composite_bwd_pixel
 // Defaults chosen by measurement on MI355X (profiles/r01_notes.md, profiles/r02_notes.md): per-camera forward 1 pixel per
 // lane (127 us vs 195 us at 4: one wave per tile leaves 2.4 waves per SIMD and the launch ends on the centre tiles' serial
 // chains; 129 vs 153 us against the packed 2-pixel kernel), batched forward 2 (packed k_composite_fwd_sh_vec: a lone
@@ -1823,54 +1460,42 @@ k_composite_bwd_sh_mfma(CompParams p_arg, const CompParams *__restrict__ plist) 
 // another batch's backward in flight: 3 010 vs 2 885 renders/s), vector backward 4 (the per-Gaussian gradient
 // reduction costs the same per wave whatever the number of pixels behind it).
 struct Variants {
-  int ppl_fwd, ppl_bwd, mfma, ppl_fwd_batch, ppl_bwd_batch, ppl_bwd_sh_batch, mfma_batch, batch_map;
-  int sh_packed;  // GSGEN_BWD_SH_PACKED: 1 (default) = k_composite_bwd_sh_vec, 0 = k_composite_bwd_pixel<MODE_SH> (A/B)
-  int sh_chred;   // GSGEN_BWD_SH_CHRED: channel-wise gradient reduction in k_composite_bwd_sh_vec at 4 pixels per lane
-  int chan_packed;  // GSGEN_BWD_CHAN_PACKED: 1 (default) = k_composite_bwd_chan_vec for RGB / scalar / RGB + heads, 0 = k_composite_bwd_pixel
-  // GSGEN_SH_POLY: OPT-IN tile-local polynomial form of the per-pixel SH basis in the batched SH launches at degree 3
-  // (composite_common.hpp).  Value = the caller's bound S on a splat's sum of |non-constant SH coefficients| of one
-  // channel, in 1/16 units (GSGEN_SH_POLY=64: S = 4); 0 = off.  Used per launch only where the error bound holds (poly_ok).
-  int sh_poly;
+  int ppl_fwd = 1, ppl_bwd = 4, ppl_fwd_batch = 2, ppl_bwd_batch = 2, ppl_bwd_sh_batch = 4, batch_map = 2;
+  int ppl_fwd_poly = 2;  // pixels per lane (2 | 4) of the per-camera polynomial-basis forward
+  int sh_packed = 1;    // 1 = k_composite_bwd_sh_vec, 0 = k_composite_bwd_pixel<MODE_SH>
+  int sh_chred = 1;     // channel-wise gradient reduction in k_composite_bwd_sh_vec at 4 pixels per lane
+  int chan_packed = 1;  // 1 = k_composite_bwd_chan_vec for RGB / scalar / RGB + heads, 0 = k_composite_bwd_pixel
 };
-// colour error of the degree-2 form <= 0.25 (sigmoid slope) x S x 0.7 delta^3, delta = half diagonal of a tile in camera
-// space (tools/tile_basis_error.py: 1.95e-6 at delta = 0.0141, 2.1e-5 at 0.0316); used when that stays below 1e-5
-static bool poly_ok(float S, float ps_max) {
-  if (!(S > 0.0f)) return false;
-  const float delta = 7.5f * 1.41421356f * ps_max;
-  return 0.25f * S * 0.7f * delta * delta * delta <= 1e-5f;
-}
-static int env_mfma(const char *name) {
-  const char *v = getenv(name);
-  if (!v) return 0;
-  const int x = atoi(v);
-  return (x == 1 || x == 2 || x == 4) ? x : 0;
-}
 static Variants &variants() {
-  static Variants v = {env_ppl("GSGEN_PPL_FWD", 1),       env_ppl("GSGEN_PPL_BWD", 4),
-                             env_mfma("GSGEN_BWD_MFMA"),         env_ppl("GSGEN_PPL_FWD_BATCH", 2),
-                             env_ppl("GSGEN_PPL_BWD_BATCH", 2),  env_ppl("GSGEN_PPL_BWD_SH_BATCH", 4),
-                             env_mfma("GSGEN_BWD_MFMA_BATCH"),
-                             getenv("GSGEN_BATCH_MAP") ? atoi(getenv("GSGEN_BATCH_MAP")) : 2,
-                             getenv("GSGEN_BWD_SH_PACKED") ? (atoi(getenv("GSGEN_BWD_SH_PACKED")) != 0) : 1,
-                             getenv("GSGEN_BWD_SH_CHRED") ? (atoi(getenv("GSGEN_BWD_SH_CHRED")) != 0) : 1,
-                             getenv("GSGEN_BWD_CHAN_PACKED") ? (atoi(getenv("GSGEN_BWD_CHAN_PACKED")) != 0) : 1,
-                             getenv("GSGEN_SH_POLY") ? atoi(getenv("GSGEN_SH_POLY")) : 0};
+  static Variants v;
   return v;
 }
 
 template <int MODE, int CB>
-static int launch_fwd(const CompParams &p, hipStream_t s) {
+static int launch_fwd(const CompParams &p_, hipStream_t s) {
   const int ppl = variants().ppl_fwd;
+  CompParams p = p_;
   const uint32_t nblk = comp_grid(p);
   if (p.ntw * p.nth == 0) return 0;
   if (p.tile_side == 8 || p.tile_side == 32) {  // a caller's own tile size: one fixed shape of the unpacked kernel
     if constexpr (MODE == MODE_RGBD) return GSGEN_EUNSUPPORTED;
     else {
       if (p.nseg > 1) return GSGEN_EUNSUPPORTED;
+      p.sh_bound = nullptr;  // the polynomial basis is fitted to 16 x 16 tiles
       if (p.tile_side == 8) hipLaunchKernelGGL((k_composite_fwd<MODE, CB, 1, false, 8>), dim3(nblk), dim3(64), 0, s, p, (const CompParams *)nullptr);
       else hipLaunchKernelGGL((k_composite_fwd<MODE, CB, 4, false, 32>), dim3(nblk), dim3(256), 0, s, p, (const CompParams *)nullptr);
       return (int)hipGetLastError();
     }
+  }
+  if constexpr (MODE == MODE_SH && CB == 4) {
+    // with the coefficient bound: the polynomial-basis kernel in front of the exact one; each workgroup of either reads
+    // the bound and exactly one of the two renders the frame (poly_route)
+    if (p.sh_bound != nullptr) {
+      if (variants().ppl_fwd_poly == 4) hipLaunchKernelGGL((k_composite_fwd_sh_vec<4, 4, false, kPolyNB>), dim3(nblk), dim3(64), 0, s, p, (const CompParams *)nullptr);
+      else hipLaunchKernelGGL((k_composite_fwd_sh_vec<4, 2, false, kPolyNB>), dim3(nblk), dim3(128), 0, s, p, (const CompParams *)nullptr);
+    }
+  } else {
+    p.sh_bound = nullptr;
   }
   if constexpr (MODE == MODE_SH) {
     if (variants().sh_packed && ppl != 1) {  // packed per-pixel arithmetic needs pixel pairs
@@ -1886,7 +1511,7 @@ static int launch_fwd(const CompParams &p, hipStream_t s) {
 }
 template <int MODE, int CB>
 static int launch_bwd(const CompParams &p_, hipStream_t s) {
-  const int ppl = variants().ppl_bwd, mfma = variants().mfma;
+  const int ppl = variants().ppl_bwd;
   CompParams p = p_;
   if (p.n_hi == 0) p.n_hi = 0x7fffffff;
   const uint32_t nblk = comp_grid(p);
@@ -1895,22 +1520,19 @@ static int launch_bwd(const CompParams &p_, hipStream_t s) {
     if constexpr (MODE == MODE_RGBD) return GSGEN_EUNSUPPORTED;
     else {
       if (p.nseg > 1) return GSGEN_EUNSUPPORTED;
+      p.sh_bound = nullptr;
       if (p.tile_side == 8) hipLaunchKernelGGL((k_composite_bwd_pixel<MODE, CB, 1, false, 8>), dim3(nblk), dim3(64), 0, s, p, (const CompParams *)nullptr);
       else hipLaunchKernelGGL((k_composite_bwd_pixel<MODE, CB, 4, false, 32>), dim3(nblk), dim3(256), 0, s, p, (const CompParams *)nullptr);
       return (int)hipGetLastError();
     }
   }
-  if constexpr (MODE == MODE_SH) {
-    if (mfma != 0) {  // opt-in matrix-core kernel
-      const uint32_t ng = nblk * (uint32_t)(p.nseg > 1 ? p.nseg : 1);
-      const int w = mfma;
-      if (w == 1) hipLaunchKernelGGL((k_composite_bwd_sh_mfma<CB, 1>), dim3(ng), dim3(256), 0, s, p, (const CompParams *)nullptr);
-      else if (w == 2) hipLaunchKernelGGL((k_composite_bwd_sh_mfma<CB, 2>), dim3(ng), dim3(128), 0, s, p, (const CompParams *)nullptr);
-      else hipLaunchKernelGGL((k_composite_bwd_sh_mfma<CB, 4>), dim3(ng), dim3(64), 0, s, p, (const CompParams *)nullptr);
-      return (int)hipGetLastError();
-    }
-  }
   const uint32_t ng = nblk * (uint32_t)((MODE == MODE_SH && p.nseg > 1) ? p.nseg : 1);
+  if constexpr (MODE == MODE_SH && CB == 4) {
+    if (p.sh_bound != nullptr)  // as the forward: the polynomial-basis kernel in front of the exact one, routed on the device
+      hipLaunchKernelGGL((k_composite_bwd_sh_vec<4, 4, false, true, kPolyNB>), dim3(ng), dim3(64), 0, s, p, (const CompParams *)nullptr);
+  } else {
+    p.sh_bound = nullptr;
+  }
   if constexpr (MODE != MODE_SH) {
     if (variants().chan_packed && ppl == 4) {  // default: packed per-pixel arithmetic, one wavefront per tile
       hipLaunchKernelGGL((k_composite_bwd_chan_vec<MODE>), dim3(nblk), dim3(64), 0, s, p, (const CompParams *)nullptr);
@@ -1948,14 +1570,17 @@ int write_params(const CompParams *host, uint32_t B, CompParams *dst, hipStream_
   return (int)hipGetLastError();
 }
 template <int CB>
-static void launch_fwd_sh_batch_c(const CompParams &p0, const CompParams *plist, uint32_t B, uint32_t nblk, hipStream_t s, bool poly) {
+static void launch_fwd_sh_batch_c(const CompParams &p0, const CompParams *plist, uint32_t B, uint32_t nblk, hipStream_t s, bool bounded) {
   const int ppl = variants().ppl_fwd_batch;  // wavefronts per tile = 4 / ppl
   const dim3 g(nblk * B);
   if constexpr (CB == 4) {
-    if (poly) {  // opt-in: tile-local polynomial basis (forward and backward of a render take the same decision)
+    // The views carry the device address of the coefficient bound: the polynomial-basis kernel is enqueued in front of the
+    // exact one over the same grid, and every workgroup of either decides from the bound and ITS view's pixel size which
+    // of the two renders the view (poly_route; forward and backward read the same value, hence agree).  The kernel that
+    // does not take a view leaves after two scalar loads.
+    if (bounded) {
       if (ppl == 4) hipLaunchKernelGGL((k_composite_fwd_sh_vec<4, 4, true, kPolyNB>), g, dim3(64), 0, s, p0, plist);
       else hipLaunchKernelGGL((k_composite_fwd_sh_vec<4, 2, true, kPolyNB>), g, dim3(128), 0, s, p0, plist);
-      return;
     }
   }
   if (variants().sh_packed && ppl != 1) {
@@ -1976,14 +1601,11 @@ static CompParams batch_arg(const CompParams &p0, uint32_t B) {
   a.n_hi = variants().batch_map;
   return a;
 }
-// sh_bound: the caller's bound S for the polynomial basis (< 0: the process-wide default of GSGEN_SH_POLY, in 1/16 units)
-static float sh_bound_or_default(float sh_bound) { return sh_bound >= 0.0f ? sh_bound : (float)variants().sh_poly * (1.0f / 16.0f); }
-
-int launch_fwd_sh_batch(int C, const CompParams &p0_, const CompParams *plist, uint32_t B, hipStream_t s, float ps_max, float sh_bound) {
+int launch_fwd_sh_batch(int C, const CompParams &p0_, const CompParams *plist, uint32_t B, hipStream_t s, bool bounded) {
   const uint32_t nblk = comp_grid(p0_);
   if (p0_.ntw * p0_.nth == 0 || B == 0) return 0;
   const CompParams p0 = batch_arg(p0_, B);
-  const bool poly = C == 4 && poly_ok(sh_bound_or_default(sh_bound), ps_max);
+  const bool poly = C == 4 && bounded;
   switch (C) {
     case 1: launch_fwd_sh_batch_c<1>(p0, plist, B, nblk, s, false); break;
     case 2: launch_fwd_sh_batch_c<2>(p0, plist, B, nblk, s, false); break;
@@ -1993,21 +1615,11 @@ int launch_fwd_sh_batch(int C, const CompParams &p0_, const CompParams *plist, u
   return (int)hipGetLastError();
 }
 template <int CB>
-static void launch_bwd_sh_batch_c(const CompParams &p0, const CompParams *plist, uint32_t B, uint32_t nblk, hipStream_t s, bool poly) {
+static void launch_bwd_sh_batch_c(const CompParams &p0, const CompParams *plist, uint32_t B, uint32_t nblk, hipStream_t s, bool bounded) {
   const dim3 g(nblk * B);
   if constexpr (CB == 4) {
-    if (poly) {
+    if (bounded)  // as the forward: both kernels, routed per view on the device
       hipLaunchKernelGGL((k_composite_bwd_sh_vec<4, 4, true, true, kPolyNB>), g, dim3(64), 0, s, p0, plist);
-      return;
-    }
-  }
-  const int mfma = variants().mfma_batch;
-  if (mfma != 0) {  // opt-in matrix-core kernel
-    const int w = mfma;
-    if (w == 4) hipLaunchKernelGGL((k_composite_bwd_sh_mfma<CB, 4, true>), g, dim3(64), 0, s, p0, plist);
-    else if (w == 1) hipLaunchKernelGGL((k_composite_bwd_sh_mfma<CB, 1, true>), g, dim3(256), 0, s, p0, plist);
-    else hipLaunchKernelGGL((k_composite_bwd_sh_mfma<CB, 2, true>), g, dim3(128), 0, s, p0, plist);
-    return;
   }
   const int ppl = variants().ppl_bwd_sh_batch;
   if (variants().sh_packed && ppl != 1) {
@@ -2020,11 +1632,11 @@ static void launch_bwd_sh_batch_c(const CompParams &p0, const CompParams *plist,
   else if (ppl == 2) hipLaunchKernelGGL((k_composite_bwd_pixel<MODE_SH, CB, 2, true>), g, dim3(128), 0, s, p0, plist);
   else hipLaunchKernelGGL((k_composite_bwd_pixel<MODE_SH, CB, 4, true>), g, dim3(64), 0, s, p0, plist);
 }
-int launch_bwd_sh_batch(int C, const CompParams &p0_, const CompParams *plist, uint32_t B, hipStream_t s, float ps_max, float sh_bound) {
+int launch_bwd_sh_batch(int C, const CompParams &p0_, const CompParams *plist, uint32_t B, hipStream_t s, bool bounded) {
   const uint32_t nblk = comp_grid(p0_) * (uint32_t)(p0_.nseg > 1 ? p0_.nseg : 1);
   if (p0_.ntw * p0_.nth == 0 || B == 0) return 0;
   const CompParams p0 = batch_arg(p0_, B);
-  const bool poly = C == 4 && poly_ok(sh_bound_or_default(sh_bound), ps_max);
+  const bool poly = C == 4 && bounded;
   switch (C) {
     case 1: launch_bwd_sh_batch_c<1>(p0, plist, B, nblk, s, false); break;
     case 2: launch_bwd_sh_batch_c<2>(p0, plist, B, nblk, s, false); break;
@@ -2109,9 +1721,9 @@ using namespace gs;
 
 extern "C" {
 
-/* Debugging hook (tools/stress, A/B measurements inside one process): overrides one entry of the variant table that
- * the environment initialised.  Not thread-safe against concurrent launches.  name: "ppl_fwd", "ppl_bwd", "mfma",
- * "ppl_fwd_batch", "ppl_bwd_batch", "ppl_bwd_sh_batch", "mfma_batch", "batch_map", "sh_packed", "sh_chred", "chan_packed". */
+/* Debugging hook (variant tests, A/B measurements inside one process): overrides one entry of the variant table.  Not
+ * thread-safe against concurrent launches.  name: "ppl_fwd", "ppl_bwd", "ppl_fwd_poly", "ppl_fwd_batch", "ppl_bwd_batch",
+ * "ppl_bwd_sh_batch", "batch_map", "sh_packed", "sh_chred", "chan_packed". */
 int gsgen_debug_set_variant(const char *name, int value) {
   if (!name) return GSGEN_EINVAL;
   Variants &v = variants();
@@ -2124,13 +1736,11 @@ int gsgen_debug_set_variant(const char *name, int value) {
   else if (n == "ppl_fwd_batch") slot = &v.ppl_fwd_batch;
   else if (n == "ppl_bwd_batch") slot = &v.ppl_bwd_batch;
   else if (n == "ppl_bwd_sh_batch") slot = &v.ppl_bwd_sh_batch;
-  else if (n == "mfma") { slot = &v.mfma; ok = ppl_ok || value == 0; }
-  else if (n == "mfma_batch") { slot = &v.mfma_batch; ok = ppl_ok || value == 0; }
+  else if (n == "ppl_fwd_poly") { slot = &v.ppl_fwd_poly; ok = value == 2 || value == 4; }
   else if (n == "batch_map") { slot = &v.batch_map; ok = value >= 0 && value <= 2; }
   else if (n == "sh_packed") { slot = &v.sh_packed; ok = value == 0 || value == 1; }
   else if (n == "sh_chred") { slot = &v.sh_chred; ok = value == 0 || value == 1; }
   else if (n == "chan_packed") { slot = &v.chan_packed; ok = value == 0 || value == 1; }
-  else if (n == "sh_poly") { slot = &v.sh_poly; ok = value >= 0 && value <= 4096; }
   if (!slot || !ok) return GSGEN_EINVAL;
   *slot = value;
   return 0;
@@ -2145,25 +1755,25 @@ int gsgen_kernel_variant(const char *stage, uint32_t C, uint32_t n_segments, cha
   const std::string st(stage);
   char buf[160];
   int n = 0;
+  // "<stage>_poly": the polynomial-basis kernel of a bounded enqueue (SH degree 3), which renders the views whose error
+  // bound holds; "<stage>": the exact kernel (the only one without a bound, the other views' with one)
   const bool poly_stage = st.size() > 5 && st.compare(st.size() - 5, 5, "_poly") == 0;
-  auto sh_bwd = [&](int mfma, int ppl, const char *b) {
-    if ((poly_stage || v.sh_poly > 0) && C == 4 && b[0] != 0)
-      return snprintf(buf, sizeof buf, "k_composite_bwd_sh_vec<C=4,PPL=4%s,CHRED,POLY6>%s", b, poly_stage ? "" : " where the bound allows");
-    if (mfma) return snprintf(buf, sizeof buf, "k_composite_bwd_sh_mfma<C=%u,PPL=%d%s>%s", C, mfma, b, n_segments > 1 ? " segmented" : "");
+  const std::string base = poly_stage ? st.substr(0, st.size() - 5) : st;
+  auto sh_bwd = [&](int ppl, const char *b) {
+    if (poly_stage && C == 4) return snprintf(buf, sizeof buf, "k_composite_bwd_sh_vec<C=4,PPL=4%s,CHRED,POLY6>%s", b, n_segments > 1 ? " segmented" : "");
     return snprintf(buf, sizeof buf, "%s<%sC=%u,PPL=%d%s%s>%s", (v.sh_packed && ppl != 1) ? "k_composite_bwd_sh_vec" : "k_composite_bwd_pixel",
                     (v.sh_packed && ppl != 1) ? "" : "SH,", C, ppl, b, (v.sh_packed && ppl == 4 && v.sh_chred) ? ",CHRED" : "",
                     n_segments > 1 ? " segmented" : "");
   };
-  auto sh_fwd = [&](int ppl, const char *b) {
-    if ((poly_stage || v.sh_poly > 0) && C == 4 && b[0] != 0)
-      return snprintf(buf, sizeof buf, "k_composite_fwd_sh_vec<C=4,PPL=%d%s,POLY6>%s", ppl == 4 ? 4 : 2, b, poly_stage ? "" : " where the bound allows");
+  auto sh_fwd = [&](int ppl, int ppl_poly, const char *b) {
+    if (poly_stage && C == 4) return snprintf(buf, sizeof buf, "k_composite_fwd_sh_vec<C=4,PPL=%d%s,POLY6>", ppl_poly == 4 ? 4 : 2, b);
     if (v.sh_packed && ppl != 1) return snprintf(buf, sizeof buf, "k_composite_fwd_sh_vec<C=%u,PPL=%d%s>", C, ppl, b);
     return snprintf(buf, sizeof buf, "k_composite_fwd<SH,C=%u,PPL=%d%s>", C, ppl, b);
   };
-  if (st == "sh_fwd") n = sh_fwd(v.ppl_fwd, "");
-  else if (st == "sh_fwd_batch" || st == "sh_fwd_batch_poly") n = sh_fwd(v.ppl_fwd_batch, ",BATCH");
-  else if (st == "sh_bwd") n = sh_bwd(v.mfma, v.ppl_bwd, "");
-  else if (st == "sh_bwd_batch" || st == "sh_bwd_batch_poly") n = sh_bwd(v.mfma_batch, v.ppl_bwd_sh_batch, ",BATCH");
+  if (base == "sh_fwd") n = sh_fwd(v.ppl_fwd, v.ppl_fwd_poly, "");
+  else if (base == "sh_fwd_batch") n = sh_fwd(v.ppl_fwd_batch, v.ppl_fwd_batch, ",BATCH");
+  else if (base == "sh_bwd") n = sh_bwd(v.ppl_bwd, "");
+  else if (base == "sh_bwd_batch") n = sh_bwd(v.ppl_bwd_sh_batch, ",BATCH");
   else if (st == "rgb_fwd") n = snprintf(buf, sizeof buf, "k_composite_fwd<RGB,PPL=%d>", v.ppl_fwd);
   else if (st == "rgb_bwd") n = (v.chan_packed && v.ppl_bwd == 4) ? snprintf(buf, sizeof buf, "k_composite_bwd_chan_vec<RGB>")
                                                                    : snprintf(buf, sizeof buf, "k_composite_bwd_pixel<RGB,PPL=%d>", v.ppl_bwd);
@@ -2246,9 +1856,9 @@ int gsgen_vol_render_sh_ordered(uint32_t N, uint32_t D, const float *mean, const
                                 uint32_t n_tiles_w, float pixel_size_x, float pixel_size_y, uint32_t H,
                                 uint32_t W, uint32_t C, float thresh, const float *bg_rgb, float *T,
                                 const uint32_t *tile_order, gsgen_stream_t stream) {
-  return gsgen_vol_render_sh_segmented(N, D, mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out, topleft,
-                                       c2w, tile_size, n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H, W, C,
-                                       thresh, bg_rgb, T, tile_order, nullptr, 0, stream);
+  return gsgen_vol_render_sh_bounded(N, D, mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out, topleft,
+                                     c2w, tile_size, n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H, W, C,
+                                     thresh, bg_rgb, T, tile_order, nullptr, 0, nullptr, stream);
 }
 
 int gsgen_vol_render_sh_segmented(uint32_t N, uint32_t D, const float *mean, const float *cov,
@@ -2259,6 +1869,19 @@ int gsgen_vol_render_sh_segmented(uint32_t N, uint32_t D, const float *mean, con
                                   uint32_t W, uint32_t C, float thresh, const float *bg_rgb, float *T,
                                   const uint32_t *tile_order, void *segment_workspace, uint32_t n_segments,
                                   gsgen_stream_t stream) {
+  return gsgen_vol_render_sh_bounded(N, D, mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out, topleft,
+                                     c2w, tile_size, n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H, W, C,
+                                     thresh, bg_rgb, T, tile_order, segment_workspace, n_segments, nullptr, stream);
+}
+
+int gsgen_vol_render_sh_bounded(uint32_t N, uint32_t D, const float *mean, const float *cov,
+                                const float *sh_coeffs, const float *alpha, const int *start,
+                                const int *end, const int *gaussian_ids, float *out, const float *topleft,
+                                const float *c2w, uint32_t tile_size, uint32_t n_tiles_h,
+                                uint32_t n_tiles_w, float pixel_size_x, float pixel_size_y, uint32_t H,
+                                uint32_t W, uint32_t C, float thresh, const float *bg_rgb, float *T,
+                                const uint32_t *tile_order, void *segment_workspace, uint32_t n_segments,
+                                const float *sh_l1_bound, gsgen_stream_t stream) {
   if (int e = check_common(tile_size, start, end, out)) return e;
   if (n_segments > 1 && segment_workspace == nullptr) return GSGEN_EINVAL;
   if (C < 1 || C > 4) return GSGEN_EUNSUPPORTED;  // reference dispatches C = 1..4 only (render.cu:507-544)
@@ -2271,6 +1894,7 @@ int gsgen_vol_render_sh_segmented(uint32_t N, uint32_t D, const float *mean, con
   p.ntw = (int)n_tiles_w; p.nth = (int)n_tiles_h; p.H = (int)H; p.W = (int)W;
   p.psx = pixel_size_x; p.psy = pixel_size_y; p.thresh = thresh; p.tile_side = (int)tile_size;
   p.tile_order = tile_order;
+  p.sh_bound = (C == 4) ? sh_l1_bound : nullptr;
   if (n_segments > 1) {
     p.nseg = (int)n_segments;
     p.ckpt = reinterpret_cast<float4 *>(segment_workspace);
@@ -2289,7 +1913,7 @@ int gsgen_vol_render_sh_segmented(uint32_t N, uint32_t D, const float *mean, con
 static int fill_view_params(uint32_t n_views, const gsgen_sh_view *views, const float *sh_coeffs,
                             const float *alpha, float *g_sh, float *g_alpha, uint32_t ntw, uint32_t nth,
                             uint32_t H, uint32_t W, float thresh, uint32_t n_segments, bool backward,
-                            std::vector<CompParams> &ps) {
+                            const float *sh_bound, std::vector<CompParams> &ps) {
   ps.assign(n_views, CompParams{});
   for (uint32_t b = 0; b < n_views; ++b) {
     const gsgen_sh_view &v = views[b];
@@ -2304,6 +1928,7 @@ static int fill_view_params(uint32_t n_views, const gsgen_sh_view *views, const 
     p.psx = v.pixel_size_x; p.psy = v.pixel_size_y; p.thresh = thresh;
     p.tile_order = v.tile_order;
     p.n_hi = 0x7fffffff;
+    p.sh_bound = sh_bound;
     if (backward) {
       p.final_img = v.out; p.grad_out = v.grad_out;
       p.g_mean = v.grad_mean; p.g_cov = v.grad_cov; p.g_col = g_sh; p.g_alpha = g_alpha;
@@ -2319,38 +1944,86 @@ static int fill_view_params(uint32_t n_views, const gsgen_sh_view *views, const 
   return 0;
 }
 
-// max over splats and channels of sum_{k >= 1} |sh[i][c][k]|, max-accumulated into *out (non-negative floats order like
-// their bit patterns)
-__global__ void __launch_bounds__(256) k_sh_l1_bound(uint32_t n_rows, const float *__restrict__ sh, int CC, float *out) {
+}  // extern "C"
+
+// S = max over splats and channels of sum_{k >= 1} |sh[i][c][k]| (non-negative floats order like their bit patterns, so the
+// maximum is an unsigned atomicMax).  SH degree 3: one float4 per thread, perfectly coalesced -- four lanes share a row of 16
+// coefficients, the first of them drops the constant term.  CHECK: counts the rows whose sum EXCEEDS *bound instead (the
+// debug verification of a bound some other pass produced).  NaN coefficients read as "no bound" (3e38 never passes poly_ok).
+template <bool CHECK>
+__global__ void __launch_bounds__(256) k_sh_l1_rows16(uint32_t n_quads, const float4 *__restrict__ sh, float *out, const float *bound,
+                                                       uint32_t *n_bad) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  float v = 0.0f;
+  if (i < n_quads) {
+    const float4 q = sh[i];
+    v = ((i & 3u) ? fabsf(q.x) : 0.0f) + fabsf(q.y) + fabsf(q.z) + fabsf(q.w);
+  }
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);  // every lane of a row's four now holds the row's sum
+  if (!(v == v)) v = 3.0e38f;
+  if constexpr (CHECK) {
+    const unsigned long long bad = __ballot(i < n_quads && (i & 3u) == 0u && v > bound[0]);
+    if ((threadIdx.x & 63) == 0 && bad != 0ull) atomicAdd(n_bad, (uint32_t)__popcll(bad));
+  } else {
+#pragma unroll
+    for (int d = 32; d >= 4; d >>= 1) v = fmaxf(v, __shfl_xor(v, d));
+    if ((threadIdx.x & 63) == 0 && v > 0.0f) atomicMax(reinterpret_cast<unsigned int *>(out), __float_as_uint(v));
+  }
+}
+// any SH degree: one row of CC coefficients per thread
+template <bool CHECK>
+__global__ void __launch_bounds__(256) k_sh_l1_rows(uint32_t n_rows, const float *__restrict__ sh, int CC, float *out, const float *bound,
+                                                     uint32_t *n_bad) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   float v = 0.0f;
   if (i < n_rows) {
     const float *q = sh + (size_t)i * CC;
     for (int k = 1; k < CC; ++k) v += fabsf(q[k]);
-    if (!(v == v)) v = 3.0e38f;  // NaN coefficients: no bound
+    if (!(v == v)) v = 3.0e38f;
   }
+  if constexpr (CHECK) {
+    const unsigned long long bad = __ballot(i < n_rows && v > bound[0]);
+    if ((threadIdx.x & 63) == 0 && bad != 0ull) atomicAdd(n_bad, (uint32_t)__popcll(bad));
+  } else {
 #pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d));
-  if ((threadIdx.x & 63) == 0 && v > 0.0f) atomicMax(reinterpret_cast<unsigned int *>(out), __float_as_uint(v));
+    for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d));
+    if ((threadIdx.x & 63) == 0 && v > 0.0f) atomicMax(reinterpret_cast<unsigned int *>(out), __float_as_uint(v));
+  }
 }
 
-int gsgen_sh_l1_bound(uint32_t N, const float *sh_coeffs, uint32_t C, float *out, gsgen_stream_t stream) {
+template <bool CHECK>
+static int sh_l1_pass(uint32_t N, const float *sh_coeffs, uint32_t C, float *out, const float *bound, uint32_t *n_bad,
+                      hipStream_t s) {
   if (C < 1 || C > 4) return GSGEN_EUNSUPPORTED;
-  if (!out || (N && !sh_coeffs)) return GSGEN_EINVAL;
+  if ((CHECK ? (!bound || !n_bad) : !out) || (N && !sh_coeffs)) return GSGEN_EINVAL;
+  if (hipError_t e = hipMemsetAsync(CHECK ? (void *)n_bad : (void *)out, 0, 4, s)) return (int)e;
   if (N == 0) return 0;
   const uint32_t rows = 3u * N;
-  hipLaunchKernelGGL(k_sh_l1_bound, dim3((rows + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, rows, sh_coeffs, (int)(C * C), out);
+  if (C == 4 && (reinterpret_cast<uintptr_t>(sh_coeffs) & 15u) == 0) {
+    const uint32_t quads = 4u * rows;
+    hipLaunchKernelGGL((k_sh_l1_rows16<CHECK>), dim3((quads + 255u) / 256u), dim3(256), 0, s, quads,
+                       reinterpret_cast<const float4 *>(sh_coeffs), out, bound, n_bad);
+  } else {
+    hipLaunchKernelGGL((k_sh_l1_rows<CHECK>), dim3((rows + 255u) / 256u), dim3(256), 0, s, rows, sh_coeffs, (int)(C * C), out,
+                       bound, n_bad);
+  }
   return (int)hipGetLastError();
 }
 
-int gsgen_sh_poly_applies(float sh_l1_bound, float max_pixel_size, uint32_t C) {
-  return (C == 4 && poly_ok(sh_bound_or_default(sh_l1_bound), max_pixel_size)) ? 1 : 0;
+extern "C" {
+
+int gsgen_sh_l1_bound(uint32_t N, const float *sh_coeffs, uint32_t C, float *out, gsgen_stream_t stream) {
+  return sh_l1_pass<false>(N, sh_coeffs, C, out, nullptr, nullptr, (hipStream_t)stream);
 }
 
-static float max_pixel_size(const std::vector<CompParams> &ps) {
-  float m = 0.0f;
-  for (const CompParams &p : ps) m = fmaxf(m, fmaxf(fabsf(p.psx), fabsf(p.psy)));
-  return m;
+int gsgen_sh_l1_bound_check(uint32_t N, const float *sh_coeffs, uint32_t C, const float *bound, uint32_t *n_violations,
+                            gsgen_stream_t stream) {
+  return sh_l1_pass<true>(N, sh_coeffs, C, nullptr, bound, n_violations, (hipStream_t)stream);
+}
+
+int gsgen_sh_poly_applies(float sh_l1_bound, float max_pixel_size, uint32_t C) {
+  return (C == 4 && poly_ok(sh_l1_bound, max_pixel_size)) ? 1 : 0;
 }
 
 size_t gsgen_sh_batch_workspace_bytes(uint32_t n_views) { return 2 * (size_t)n_views * sizeof(CompParams); }
@@ -2361,13 +2034,13 @@ int gsgen_vol_render_sh_batch(uint32_t n_views, const gsgen_sh_view *views, uint
                               float thresh, uint32_t n_segments, void *batch_workspace,
                               gsgen_stream_t stream) {
   return gsgen_vol_render_sh_batch_bounded(n_views, views, N, sh_coeffs, alpha, tile_size, n_tiles_h, n_tiles_w, H, W, C,
-                                           thresh, n_segments, -1.0f, batch_workspace, stream);
+                                           thresh, n_segments, nullptr, batch_workspace, stream);
 }
 
 int gsgen_vol_render_sh_batch_bounded(uint32_t n_views, const gsgen_sh_view *views, uint32_t N,
                                       const float *sh_coeffs, const float *alpha, uint32_t tile_size,
                                       uint32_t n_tiles_h, uint32_t n_tiles_w, uint32_t H, uint32_t W, uint32_t C,
-                                      float thresh, uint32_t n_segments, float sh_l1_bound, void *batch_workspace,
+                                      float thresh, uint32_t n_segments, const float *sh_l1_bound, void *batch_workspace,
                                       gsgen_stream_t stream) {
   if (tile_size != 16) return GSGEN_EUNSUPPORTED;
   if (C < 1 || C > 4) return GSGEN_EUNSUPPORTED;
@@ -2377,12 +2050,12 @@ int gsgen_vol_render_sh_batch_bounded(uint32_t n_views, const gsgen_sh_view *vie
   (void)N;
   std::vector<CompParams> ps;
   if (int e = fill_view_params(n_views, views, sh_coeffs, alpha, nullptr, nullptr, n_tiles_w, n_tiles_h, H, W,
-                               thresh, n_segments, false, ps))
+                               thresh, n_segments, false, C == 4 ? sh_l1_bound : nullptr, ps))
     return e;
   hipStream_t s = (hipStream_t)stream;
   CompParams *dst = reinterpret_cast<CompParams *>(batch_workspace);
   if (int e = write_params(ps.data(), n_views, dst, s)) return e;
-  return launch_fwd_sh_batch((int)C, ps[0], dst, n_views, s, max_pixel_size(ps), sh_l1_bound);
+  return launch_fwd_sh_batch((int)C, ps[0], dst, n_views, s, sh_l1_bound != nullptr);
 }
 
 int gsgen_vol_render_backward_sh_batch(uint32_t n_views, const gsgen_sh_view *views, uint32_t N,
@@ -2391,7 +2064,7 @@ int gsgen_vol_render_backward_sh_batch(uint32_t n_views, const gsgen_sh_view *vi
                                        uint32_t n_tiles_w, uint32_t H, uint32_t W, uint32_t C, float thresh,
                                        uint32_t n_segments, void *batch_workspace, gsgen_stream_t stream) {
   return gsgen_vol_render_backward_sh_batch_bounded(n_views, views, N, sh_coeffs, alpha, grad_sh_coeffs, grad_alpha, tile_size,
-                                                    n_tiles_h, n_tiles_w, H, W, C, thresh, n_segments, -1.0f, batch_workspace,
+                                                    n_tiles_h, n_tiles_w, H, W, C, thresh, n_segments, nullptr, batch_workspace,
                                                     stream);
 }
 
@@ -2399,7 +2072,7 @@ int gsgen_vol_render_backward_sh_batch_bounded(uint32_t n_views, const gsgen_sh_
                                                const float *sh_coeffs, const float *alpha, float *grad_sh_coeffs,
                                                float *grad_alpha, uint32_t tile_size, uint32_t n_tiles_h,
                                                uint32_t n_tiles_w, uint32_t H, uint32_t W, uint32_t C, float thresh,
-                                               uint32_t n_segments, float sh_l1_bound, void *batch_workspace,
+                                               uint32_t n_segments, const float *sh_l1_bound, void *batch_workspace,
                                                gsgen_stream_t stream) {
   if (tile_size != 16) return GSGEN_EUNSUPPORTED;
   if (C < 1 || C > 4) return GSGEN_EUNSUPPORTED;
@@ -2408,12 +2081,12 @@ int gsgen_vol_render_backward_sh_batch_bounded(uint32_t n_views, const gsgen_sh_
   if (n_views > 65535) return GSGEN_EINVAL;
   std::vector<CompParams> ps;
   if (int e = fill_view_params(n_views, views, sh_coeffs, alpha, grad_sh_coeffs, grad_alpha, n_tiles_w,
-                               n_tiles_h, H, W, thresh, n_segments, true, ps))
+                               n_tiles_h, H, W, thresh, n_segments, true, C == 4 ? sh_l1_bound : nullptr, ps))
     return e;
   hipStream_t s = (hipStream_t)stream;
   CompParams *dst = reinterpret_cast<CompParams *>(batch_workspace) + n_views;
   if (int e = write_params(ps.data(), n_views, dst, s)) return e;
-  return launch_bwd_sh_batch((int)C, ps[0], dst, n_views, s, max_pixel_size(ps), sh_l1_bound);
+  return launch_bwd_sh_batch((int)C, ps[0], dst, n_views, s, sh_l1_bound != nullptr);
 }
 
 static int fill_rgbd_params(uint32_t n_views, const gsgen_rgbd_view *views, const float *color, const float *alpha,

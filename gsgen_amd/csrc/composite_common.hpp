@@ -2,8 +2,6 @@
 // splat-parallel backward (composite_bwd.hip): parameter block, the reference-arithmetic
 // Gaussian evaluations of the guard path, the SH basis, per-record preparation.
 #pragma once
-#include <stdlib.h>
-
 #include "common.hpp"
 #include "../../include/gsgen_hip.h"
 
@@ -35,6 +33,10 @@ struct CompParams {
   int tile_side;  // host side only (kernel selection): 0 / 16 = this library's tiles; 8, 32: see k_composite_fwd
   // MODE_RGBD backward with grad_out == NULL: the four head gradients as autograd delivers them (any may be NULL = 0)
   const float *go_rgb, *go_d, *go_o, *go_z2;  // [H,W,3], [H,W], [H,W], [H,W]
+  // SH degree 3: DEVICE pointer to the coefficient bound S of the scene (gsgen_sh_l1_bound), or NULL.  With a bound the
+  // host enqueues the polynomial-basis kernel AND the exact one for the same grid; every workgroup reads S and its view's
+  // pixel size, and exactly one of the two kernels renders the view (poly_route) -- no host decision, no host sync.
+  const float *sh_bound;
 };
 constexpr int kSegLen = 32;
 
@@ -302,7 +304,7 @@ __device__ __forceinline__ v2f gauss_chol_pair(float p0x, float p1, float p2, v2
   return v2f{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
 }
 
-// ---- tile-local polynomial form of the per-pixel SH basis (OPT-IN: GSGEN_SH_POLY=1, SH degree 3, batched launches) ----
+// ---- tile-local polynomial form of the per-pixel SH basis (SH degree 3, launches that are given the coefficient bound) ----
 // The reference evaluates the SH basis per PIXEL, for dir = normalize(R (qx, qy, 1)) (vol_render_sh.h:48-65).  Inside a
 // 16x16 tile that direction moves by ~1e-2 rad, and Y[pixel][0..16) is a degree-2 polynomial in the tile-local offsets
 // (u, v) in [-1, 1]^2 to within 2e-6 of a basis value at f = image size (2e-5 at f = 0.7 x size: tools/tile_basis_error.py,
@@ -310,10 +312,23 @@ __device__ __forceinline__ v2f gauss_chol_pair(float p0x, float p1, float p2, v2
 // basis at the 3 x 3 nodes (u, v) in {-1, 0, 1}^2, set up once per tile.  The staged coefficients become
 // w[c][r] = sum_k V[r][k] sh[c][k] (18 values instead of 48, transformed once per (tile, splat)), the per-pixel contractions
 // are 6 terms instead of 16, 3 x 6 instead of 3 x 16 gradient components cross the lanes and are expanded by V in front of
-// the atomics.  The host enables it per launch only where the bound 0.25 * S * 0.7 * delta^3 (S: the caller's bound on a
-// splat's sum of |non-constant SH coefficients|, delta: the tile's half diagonal in camera space) stays below 1e-5.
+// the atomics.  It renders a view only where the bound 0.25 * S * 0.7 * delta^3 (S: the scene's largest per-splat sum of
+// |non-constant SH coefficients| of one channel, measured on the device per step; delta: the tile's half diagonal in camera
+// space) stays below 1e-5 -- decided on the device by every workgroup (poly_route), the exact kernel takes the other views.
 constexpr int kPolyNB = 6;
 constexpr int kPolyNodes = 9;
+// colour error of the degree-2 form <= 0.25 (sigmoid slope) x S x 0.7 delta^3, delta = half diagonal of a tile in camera
+// space (tools/tile_basis_error.py: 1.95e-6 at delta = 0.0141, 2.1e-5 at 0.0316); used where that stays below 1e-5, a tenth
+// of the 1e-4 image tolerance.  S <= 0, NaN or infinite: never.  One function for the host's report and the kernels' routing.
+__host__ __device__ __forceinline__ bool poly_ok(float S, float ps_max) {
+  if (!(S > 0.0f) || !(S <= 3.0e38f)) return false;
+  const float delta = 7.5f * 1.41421356f * ps_max;
+  return 0.25f * S * 0.7f * delta * delta * delta <= 1e-5f;
+}
+// does the polynomial-basis kernel render this view?  (uniform over the workgroup: one scalar load)
+__device__ __forceinline__ bool poly_route(const CompParams &p) {
+  return p.sh_bound != nullptr && poly_ok(p.sh_bound[0], fmaxf(fabsf(p.psx), fabsf(p.psy)));
+}
 constexpr float kPolyFit[kPolyNB][kPolyNodes] = {
     {-0.111111111f, 0.222222222f, -0.111111111f, 0.222222222f, 0.555555556f, 0.222222222f, -0.111111111f, 0.222222222f, -0.111111111f},
     {-0.166666667f, -0.166666667f, -0.166666667f, 0.0f, 0.0f, 0.0f, 0.166666667f, 0.166666667f, 0.166666667f},
@@ -389,13 +404,6 @@ __device__ __forceinline__ void poly_transform(const float *__restrict__ sh, con
       w[e * kPolyNB + r] = -kLog2e * acc;
     }
   }
-}
-
-static inline int env_ppl(const char *name, int dflt) {
-  const char *v = getenv(name);
-  if (!v) return dflt;
-  const int x = atoi(v);
-  return (x == 1 || x == 2 || x == 4) ? x : dflt;
 }
 
 // tile_size: 16 (every kernel variant) or 8 / 32 (the unpacked vector kernels at one fixed shape; no segments, no batch)

@@ -143,6 +143,16 @@ void tile_based_vol_rendering_scalar_backward(Tensor mean, Tensor cov, Tensor sc
                                       n_tiles_w, pixel_size_x, pixel_size_y, H, W, thresh, c.stream));
 }
 
+// S = max sum_{k >= 1} |sh| of the call's coefficients into a scratch float from torch's caching allocator (stream-ordered:
+// the block is reused only behind the launches that read it); nullptr = exact kernels (other degrees / tile sizes)
+template <class C_>
+const float *sh_bound(const Tensor &sh_coeffs, uint32_t C, uint32_t tile_size, C_ &c) {
+  if (C != 4 || tile_size != 16 || sh_coeffs.numel() == 0) return nullptr;
+  Tensor b = at::empty({1}, sh_coeffs.options());
+  GS(gsgen_sh_l1_bound((uint32_t)(sh_coeffs.numel() / 48), F(sh_coeffs), C, Fm(b), c.stream));
+  return F(b);
+}
+
 void sh_forward(const Tensor &mean, const Tensor &cov, const Tensor &sh_coeffs, const Tensor &alpha, const Tensor &start,
                 const Tensor &end, const Tensor &gaussian_ids, Tensor &out, const Tensor &topleft, const Tensor &c2w,
                 uint32_t tile_size, uint32_t n_tiles_h, uint32_t n_tiles_w, float psx, float psy, uint32_t H, uint32_t W,
@@ -151,9 +161,12 @@ void sh_forward(const Tensor &mean, const Tensor &cov, const Tensor &sh_coeffs, 
   CHECK_F(out); CHECK_F(topleft); CHECK_F(c2w);
   if (C < 1 || C > 4) return;  // the reference dispatches C = 1..4 and silently does nothing otherwise (render.cu:507-544)
   Ctx c(mean);
-  GS(gsgen_vol_render_sh((uint32_t)mean.size(0), (uint32_t)gaussian_ids.size(0), F(mean), F(cov), F(sh_coeffs), F(alpha),
-                         I(start), I(end), I(gaussian_ids), Fm(out), F(topleft), F(c2w), tile_size, n_tiles_h, n_tiles_w, psx,
-                         psy, H, W, C, thresh, bg, nullptr, c.stream));
+  // SH degree 3: the coefficient bound of THESE coefficients, measured on the device in front of the launch (one 5-us pass,
+  // no sync); the kernels route on it -- polynomial form of the per-pixel basis where its error bound holds, else exact
+  const float *bound = sh_bound(sh_coeffs, C, tile_size, c);
+  GS(gsgen_vol_render_sh_bounded((uint32_t)mean.size(0), (uint32_t)gaussian_ids.size(0), F(mean), F(cov), F(sh_coeffs), F(alpha),
+                                 I(start), I(end), I(gaussian_ids), Fm(out), F(topleft), F(c2w), tile_size, n_tiles_h, n_tiles_w,
+                                 psx, psy, H, W, C, thresh, bg, nullptr, nullptr, nullptr, 0, bound, c.stream));
 }
 void sh_backward(const Tensor &mean, const Tensor &cov, const Tensor &sh_coeffs, const Tensor &alpha, const Tensor &start,
                  const Tensor &end, const Tensor &gaussian_ids, const Tensor &out, Tensor &grad_mean, Tensor &grad_cov,
@@ -165,10 +178,13 @@ void sh_backward(const Tensor &mean, const Tensor &cov, const Tensor &sh_coeffs,
   CHECK_F(grad_alpha); CHECK_F(grad_out);
   if (C < 1 || C > 4) return;
   Ctx c(mean);
-  GS(gsgen_vol_render_backward_sh((uint32_t)mean.size(0), (uint32_t)gaussian_ids.size(0), F(mean), F(cov), F(sh_coeffs),
-                                  F(alpha), I(start), I(end), I(gaussian_ids), F(out), Fm(grad_mean), Fm(grad_cov),
-                                  Fm(grad_sh_coeffs), Fm(grad_alpha), F(grad_out), F(topleft), F(c2w), tile_size, n_tiles_h,
-                                  n_tiles_w, psx, psy, H, W, C, thresh, bg, c.stream));
+  // the same coefficients give the same bound, hence the same routing as this frame's forward
+  const float *bound = sh_bound(sh_coeffs, C, tile_size, c);
+  GS(gsgen_vol_render_backward_sh_bounded((uint32_t)mean.size(0), (uint32_t)gaussian_ids.size(0), F(mean), F(cov), F(sh_coeffs),
+                                          F(alpha), I(start), I(end), I(gaussian_ids), F(out), Fm(grad_mean), Fm(grad_cov),
+                                          Fm(grad_sh_coeffs), Fm(grad_alpha), F(grad_out), F(topleft), F(c2w), tile_size,
+                                          n_tiles_h, n_tiles_w, psx, psy, H, W, C, thresh, bg, nullptr, nullptr, 0, bound,
+                                          c.stream));
 }
 // render.h:83 / render.cu:484-545
 void tile_based_vol_rendering_sh(Tensor mean, Tensor cov, Tensor sh_coeffs, Tensor alpha, Tensor start, Tensor end,

@@ -198,20 +198,39 @@ def n_tiles(H, W, tile_size=16):
     return (H + tile_size - 1) // tile_size, (W + tile_size - 1) // tile_size
 
 
-def sh_l1_bound(sh, margin=1.05):
-    """max over splats and channels of sum_{k >= 1} |sh[i][c][k]| (times a safety margin), as a Python float: the bound
-    BatchRenderer.render(..., sh_l1_bound=) / gsgen_vol_render_sh_batch_bounded want.  One pass over the coefficients on
-    the device and ONE host sync -- compute it when the coefficients change materially (or every few steps with a larger
-    margin), not per render."""
+def sh_l1_bound_device(sh, out=None):
+    """S = max over splats and channels of sum_{k >= 1} |sh[i][c][k]| as a 1-float DEVICE tensor: one coalesced pass over the
+    coefficients on the current stream (~5 us for 100 k splats), no host sync.  This is what the SH launches route on
+    (include/gsgen_hip.h, "the coefficient bound"): render_frame / BatchRenderer.render call it in their forward, so the
+    value always belongs to the coefficients being rendered."""
     if sh.dim() != 3 or sh.shape[1] != 3 or sh.dtype != torch.float32:
         raise ValueError("sh_l1_bound wants fp32 SH coefficients [N, 3, C*C]")
     sh = sh.detach().contiguous()
-    out = torch.zeros(1, device=sh.device, dtype=torch.float32)
-    C2 = sh.shape[-1]
-    C = int(round(C2 ** 0.5))
+    if out is None:
+        out = torch.empty(1, device=sh.device, dtype=torch.float32)
+    C = int(round(sh.shape[-1] ** 0.5))
     with torch.cuda.device(sh.device):
         _capi.load().sh_l1_bound(sh.shape[0], _p(sh), C, _p(out), _stream(sh))
-    return float(out.item()) * float(margin)
+    return out
+
+
+def sh_l1_bound(sh):
+    """The same value as a Python float (ONE host sync): for reports and tests, never needed by the render path."""
+    return float(sh_l1_bound_device(sh).item())
+
+
+def verify_sh_l1_bound(sh, bound):
+    """Debug check of a bound produced elsewhere (a 1-float device tensor, e.g. a by-product of an optimiser pass): counts, on
+    the device, the (splat, channel) rows whose sum_{k >= 1} |sh| exceeds it and raises if there are any (one host sync)."""
+    sh = sh.detach().contiguous()
+    n_bad = torch.empty(1, device=sh.device, dtype=torch.int32)
+    C = int(round(sh.shape[-1] ** 0.5))
+    with torch.cuda.device(sh.device):
+        _capi.load().sh_l1_bound_check(sh.shape[0], _p(sh), C, _p(bound), _p(n_bad), _stream(sh))
+    n = int(n_bad.item())
+    if n:
+        raise RuntimeError(f"gsgen_amd: the SH coefficient bound {float(bound.item()):.6g} is exceeded by {n} (splat, channel) rows: "
+                           "it is stale or wrong, and the polynomial SH basis would silently break the 1e-4 image contract")
 
 
 def pair_count(v):
@@ -360,7 +379,7 @@ class _render_frame(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, mean, qvec, svec, alpha, col, cam_dev, topleft, rot, bg_rgb, buf, cam_info, C,
-                thresh, detach_depth, stats):
+                thresh, detach_depth, stats, sh_basis):
         mean, qvec, svec = mean.contiguous(), qvec.contiguous(), svec.contiguous()
         alpha, col = alpha.contiguous(), col.contiguous()
         lib = _capi.load()
@@ -375,12 +394,15 @@ class _render_frame(torch.autograd.Function):
         T = torch.ones(H, W, 1, device=dev, dtype=torch.float32)
         psx, psy = 1.0 / cam_info.fx, 1.0 / cam_info.fy
         s = _stream(mean)
+        # SH degree 3: the coefficient bound, measured on the device in front of the launch; the kernels route on it
+        # (polynomial form of the per-pixel basis where its error bound holds, else the exact one) -- no host decision
+        ctx.sh_bound = sh_l1_bound_device(col) if (C == 4 and sh_basis == "auto") else None
         with torch.cuda.device(dev):
             if C > 0:
-                lib.vol_render_sh_segmented(buf.N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col), _p(alpha),
-                                            _p(buf.start), _p(buf.end), _p(buf.ids), _p(out), _p(topleft), _p(rot),
-                                            16, buf.nth, buf.ntw, psx, psy, H, W, C, thresh, _p(bg_rgb), _p(T),
-                                            buf.tile_order(), _p(buf.seg_ws), buf.segments, s)
+                lib.vol_render_sh_bounded(buf.N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col), _p(alpha),
+                                          _p(buf.start), _p(buf.end), _p(buf.ids), _p(out), _p(topleft), _p(rot),
+                                          16, buf.nth, buf.ntw, psx, psy, H, W, C, thresh, _p(bg_rgb), _p(T),
+                                          buf.tile_order(), _p(buf.seg_ws), buf.segments, _p(ctx.sh_bound), s)
             else:
                 lib.vol_render_start_end_with_T(buf.N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col),
                                                 _p(alpha), _p(buf.start), _p(buf.end), _p(buf.ids),
@@ -414,11 +436,11 @@ class _render_frame(torch.autograd.Function):
         s = _stream(mean)
         with torch.cuda.device(dev):
             if C > 0:
-                lib.vol_render_backward_sh_segmented(N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col), _p(alpha),
-                                                     _p(buf.start), _p(buf.end), _p(buf.ids), _p(out), _p(g_mean2d),
-                                                     _p(g_cov2d), _p(g_col), _p(g_alpha), _p(grad), _p(topleft),
-                                                     _p(rot), 16, buf.nth, buf.ntw, psx, psy, H, W, C, thresh, None,
-                                                     buf.tile_order(), _p(buf.seg_ws), buf.segments, s)
+                lib.vol_render_backward_sh_bounded(N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col), _p(alpha),
+                                                   _p(buf.start), _p(buf.end), _p(buf.ids), _p(out), _p(g_mean2d),
+                                                   _p(g_cov2d), _p(g_col), _p(g_alpha), _p(grad), _p(topleft),
+                                                   _p(rot), 16, buf.nth, buf.ntw, psx, psy, H, W, C, thresh, None,
+                                                   buf.tile_order(), _p(buf.seg_ws), buf.segments, _p(ctx.sh_bound), s)
             else:
                 lib.vol_render_backward_start_end(N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col),
                                                   _p(alpha), _p(buf.start), _p(buf.end), _p(buf.ids),
@@ -433,16 +455,20 @@ class _render_frame(torch.autograd.Function):
             ctx.stats.update_grad(g_mean2d, buf.mask)
         # d/d bg of out = ... + T * bg (gs/renderer.py:1283: nan_to_num(grad * T)), reduced to bg's shape
         g_bg = torch.nan_to_num(grad * T).sum_to_size(ctx.bg_shape) if ctx.bg_shape is not None else None
-        return (g_mean, g_qvec, g_svec, g_alpha, g_col, None, None, None, g_bg) + (None,) * 6
+        return (g_mean, g_qvec, g_svec, g_alpha, g_col, None, None, None, g_bg) + (None,) * 7
 
 
 def render_frame(mean, qvec, svec, alpha, col, cam_info, c2w, buf, C=0, bg_rgb=None, thresh=1e-4,
-                 frustum_radius=6.0, tile_radius=6.0, detach_depth=True, stats=None):
+                 frustum_radius=6.0, tile_radius=6.0, detach_depth=True, stats=None, sh_basis="auto"):
     """One differentiable render of `cam_info` at pose `c2w` ([3,4], host array or tensor).
 
     col is sh_coeffs [N,3,C*C] when C in 1..4, or post-activation rgb [N,3] when C == 0.
     Culled Gaussians keep their index (no mask gathers); gradients come back for every input.
+    sh_basis (SH degree 3): "auto" -- the tile-local polynomial form of the per-pixel basis where its error bound holds (decided
+    on the device from the coefficients of THIS call, images within 1e-5 of the exact kernels), "exact" -- the exact kernels.
     Returns (rgb [H,W,3], T [H,W,1])."""
+    if sh_basis not in ("auto", "exact"):
+        raise ValueError("sh_basis: 'auto' or 'exact'")
     c2w_np = c2w.detach().cpu().numpy() if isinstance(c2w, torch.Tensor) else np.asarray(c2w)
     dev = mean.device
     # cam block (56) | pixel origin (2) | rotation rows (9) | pad: packed on the host, sent through kernel arguments
@@ -456,4 +482,4 @@ def render_frame(mean, qvec, svec, alpha, col, cam_info, c2w, buf, C=0, bg_rgb=N
     _capi.load().upload_small(_p(block), h.ctypes.data, 272, torch.cuda.current_stream(dev).cuda_stream)
     cam_dev, topleft, rot = block[:56], block[56:58], block[58:67]
     return _render_frame.apply(mean, qvec, svec, alpha, col, cam_dev, topleft, rot, bg_rgb, buf, cam_info,
-                               int(C), float(thresh), bool(detach_depth), stats)
+                               int(C), float(thresh), bool(detach_depth), stats, sh_basis)

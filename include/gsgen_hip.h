@@ -43,16 +43,17 @@ typedef void *gsgen_stream_t; /* hipStream_t; NULL = the legacy default stream *
 const char *gsgen_version(void);
 /* HIP error string for positive return codes, own text for negative ones. */
 const char *gsgen_error_string(int code);
-/* Which compiled kernel variant a compositing launch runs in this process (the variants are selected by
- * environment variables read once: gsgen_amd/csrc/composite.hip "launch helpers").  stage: "sh_fwd", "sh_bwd",
- * "sh_fwd_batch", "sh_bwd_batch", "rgb_fwd", "rgb_bwd", "rgbd_fwd_batch", "rgbd_bwd_batch".  Writes a
- * NUL-terminated name into out[out_bytes] and returns its length, 0 for an unknown stage.  Host-only; no
- * counterpart in the reference (bench.py reports it next to the measured kernel time). */
+/* Which compiled kernel variant a compositing launch runs in this process (gsgen_amd/csrc/composite.hip "launch
+ * helpers"; the library reads nothing from the environment).  stage: "sh_fwd", "sh_bwd", "sh_fwd_batch", "sh_bwd_batch"
+ * (+ "_poly": the polynomial-basis kernel of a bounded enqueue, see gsgen_vol_render_sh_batch_bounded), "rgb_fwd",
+ * "rgb_bwd", "rgbd_fwd_batch", "rgbd_bwd_batch".  Writes a NUL-terminated name into out[out_bytes] and returns its
+ * length, 0 for an unknown stage.  Host-only; no counterpart in the reference (bench.py reports it next to the measured
+ * kernel time). */
 int gsgen_kernel_variant(const char *stage, uint32_t C, uint32_t n_segments, char *out, size_t out_bytes);
-/* Debugging hook: override one entry of that variant table after the environment initialised it ("ppl_fwd",
- * "ppl_bwd", "mfma", "ppl_fwd_batch", "ppl_bwd_batch", "ppl_bwd_sh_batch", "mfma_batch", "batch_map"; values as the
- * GSGEN_* variables).  Not thread-safe against concurrent launches; used by tools/stress to compare kernel
- * variants inside one process.  Returns 0 or GSGEN_EINVAL. */
+/* Debugging hook: override one entry of that variant table ("ppl_fwd", "ppl_bwd", "ppl_fwd_poly", "ppl_fwd_batch",
+ * "ppl_bwd_batch", "ppl_bwd_sh_batch": 1 | 2 | 4 pixels per lane; "batch_map": 0..2; "sh_packed", "sh_chred",
+ * "chan_packed": 0 | 1).  Not thread-safe against concurrent launches; used by the variant tests and bench.py --variant
+ * to compare kernel shapes.  Returns 0 or GSGEN_EINVAL. */
 int gsgen_debug_set_variant(const char *name, int value);
 
 /* ---- frustum cull ------------------------------------------------------------------
@@ -378,31 +379,64 @@ int gsgen_vol_render_backward_sh_batch(uint32_t n_views, const gsgen_sh_view *vi
                                        uint32_t n_tiles_w, uint32_t H, uint32_t W, uint32_t C, float thresh,
                                        uint32_t n_segments, void *batch_workspace, gsgen_stream_t stream);
 
-/* The same two launches with the caller's BOUND on the SH coefficients: sh_l1_bound >= max over splats and channels of
- * sum_{k >= 1} |sh[i][c][k]| (gsgen_sh_l1_bound computes it on the device).  With a bound, SH degree 3 (C = 4) and cameras
- * narrow enough, the launch uses the tile-local polynomial form of the per-pixel SH basis: the reference evaluates the basis
- * per pixel for dir = normalize(R (qx, qy, 1)) (vol_render_sh.h:48-65), and inside a 16 x 16 tile that is a degree-2
- * polynomial in the pixel offsets to within 0.7 delta^3 of a basis value (delta = the tile's half diagonal in camera
- * space) -- six-term contractions against coefficients transformed once per (tile, splat), +20 % renders/s on BASELINE
- * configs[1].  It is taken only where 0.25 * sh_l1_bound * 0.7 * delta^3 <= 1e-5 (a tenth of the 1e-4 image tolerance;
- * gsgen_sh_poly_applies reports the decision), otherwise -- and always with sh_l1_bound = 0 -- the exact kernels run.  A
- * forward and its backward must be given the same bound.  sh_l1_bound < 0: the process-wide default (GSGEN_SH_POLY, off). */
+/* ---- the coefficient bound: the fast form of the per-pixel SH basis, decided ON THE DEVICE ----------------------------
+ * The reference evaluates the SH basis per pixel for dir = normalize(R (qx, qy, 1)) (vol_render_sh.h:48-65).  Inside a
+ * 16 x 16 tile that is a degree-2 polynomial in the pixel offsets to within 0.7 delta^3 of a basis value (delta = the tile's
+ * half diagonal in camera space): six-term contractions against coefficients transformed once per (tile, splat), +20 %
+ * renders/s on BASELINE configs[1].  The colour error is <= 0.25 * S * 0.7 * delta^3 with
+ *     S = max over splats and channels of sum_{k >= 1} |sh[i][c][k]|,
+ * and the polynomial form is used for a VIEW only where that stays <= 1e-5 (a tenth of the 1e-4 image tolerance).
+ *
+ * S lives in DEVICE memory and never visits the host: gsgen_sh_l1_bound writes it (one coalesced pass over the
+ * coefficients, ~5 us for 100 k splats; enqueue it on the render's stream whenever the coefficients may have changed, i.e.
+ * every optimiser step), the *_bounded entry points below take its device address.  With a bound (SH degree 3 only) they
+ * enqueue the polynomial-basis kernel AND the exact one over the same grid; every workgroup reads S and its view's pixel
+ * size and exactly one of the two kernels renders the view -- no host decision, no synchronisation, hipGraph-capturable, and
+ * a bound that is too large only costs speed, never accuracy.  A forward and its backward must see the same value (pass the
+ * same address and do not rewrite it in between).  sh_l1_bound == NULL: the exact kernels only (gsgen_vol_render_sh_batch,
+ * gsgen_vol_render_sh_segmented, ... are exactly that). */
+int gsgen_sh_l1_bound(uint32_t N, const float *sh_coeffs, uint32_t C, float *out /* device, 1 float, OVERWRITTEN */,
+                      gsgen_stream_t stream);
+/* Debug verification of a bound some other pass produced (e.g. a fused optimiser step): *n_violations (device uint32,
+ * OVERWRITTEN) = the number of (splat, channel) rows whose sum_{k >= 1} |sh| exceeds *bound (device). */
+int gsgen_sh_l1_bound_check(uint32_t N, const float *sh_coeffs, uint32_t C, const float *bound, uint32_t *n_violations,
+                            gsgen_stream_t stream);
+/* HOST arithmetic only: 1 if a view of this pixel size (max of pixel_size_x / _y) takes the polynomial form under the
+ * bound value S -- the device's own rule, for reports */
+int gsgen_sh_poly_applies(float sh_l1_bound, float max_pixel_size, uint32_t C);
 int gsgen_vol_render_sh_batch_bounded(uint32_t n_views, const gsgen_sh_view *views, uint32_t N,
                                       const float *sh_coeffs, const float *alpha, uint32_t tile_size,
                                       uint32_t n_tiles_h, uint32_t n_tiles_w, uint32_t H, uint32_t W, uint32_t C,
-                                      float thresh, uint32_t n_segments, float sh_l1_bound, void *batch_workspace,
-                                      gsgen_stream_t stream);
+                                      float thresh, uint32_t n_segments, const float *sh_l1_bound /* device or NULL */,
+                                      void *batch_workspace, gsgen_stream_t stream);
 int gsgen_vol_render_backward_sh_batch_bounded(uint32_t n_views, const gsgen_sh_view *views, uint32_t N,
                                                const float *sh_coeffs, const float *alpha, float *grad_sh_coeffs,
                                                float *grad_alpha, uint32_t tile_size, uint32_t n_tiles_h,
                                                uint32_t n_tiles_w, uint32_t H, uint32_t W, uint32_t C, float thresh,
-                                               uint32_t n_segments, float sh_l1_bound, void *batch_workspace,
-                                               gsgen_stream_t stream);
-/* *out (device float, zeroed by the caller; results are max-accumulated) = max_i max_c sum_{k >= 1} |sh_coeffs[i][c][k]| */
-int gsgen_sh_l1_bound(uint32_t N, const float *sh_coeffs, uint32_t C, float *out, gsgen_stream_t stream);
-/* 1 if a batched SH launch with this bound and this largest pixel size (max over views of pixel_size_x / _y) takes the
- * polynomial form, else 0 */
-int gsgen_sh_poly_applies(float sh_l1_bound, float max_pixel_size, uint32_t C);
+                                               uint32_t n_segments, const float *sh_l1_bound /* device or NULL */,
+                                               void *batch_workspace, gsgen_stream_t stream);
+/* One camera (gsgen_vol_render_sh_segmented / gsgen_vol_render_backward_sh_segmented + the bound): what the `_gs` SH names
+ * (tile_based_vol_rendering_sh / _backward_sh and their _with_bg forms, gs/src/render.h:83-127) run on -- the binding
+ * computes S into a scratch float in front of each call, so the reference's call shape gets the fast kernels too. */
+int gsgen_vol_render_sh_bounded(uint32_t N, uint32_t D, const float *mean, const float *cov,
+                                const float *sh_coeffs, const float *alpha, const int *start,
+                                const int *end, const int *gaussian_ids, float *out, const float *topleft,
+                                const float *c2w, uint32_t tile_size, uint32_t n_tiles_h,
+                                uint32_t n_tiles_w, float pixel_size_x, float pixel_size_y, uint32_t H,
+                                uint32_t W, uint32_t C, float thresh, const float *bg_rgb, float *T,
+                                const uint32_t *tile_order, void *segment_workspace, uint32_t n_segments,
+                                const float *sh_l1_bound /* device or NULL */, gsgen_stream_t stream);
+int gsgen_vol_render_backward_sh_bounded(uint32_t N, uint32_t D, const float *mean, const float *cov,
+                                         const float *sh_coeffs, const float *alpha, const int *start,
+                                         const int *end, const int *gaussian_ids, const float *out,
+                                         float *grad_mean, float *grad_cov, float *grad_sh_coeffs,
+                                         float *grad_alpha, const float *grad_out, const float *topleft,
+                                         const float *c2w, uint32_t tile_size, uint32_t n_tiles_h,
+                                         uint32_t n_tiles_w, float pixel_size_x, float pixel_size_y,
+                                         uint32_t H, uint32_t W, uint32_t C, float thresh,
+                                         const float *bg_rgb, const uint32_t *tile_order,
+                                         const void *segment_workspace, uint32_t n_segments,
+                                         const float *sh_l1_bound /* device or NULL */, gsgen_stream_t stream);
 
 /* Fused RGB + auxiliary heads: what render_one does in four compositing passes
  * (gs/gaussian_splatting.py:1304-1403: rgb, depth, opacity = scalar 1, depth^2) in one.

@@ -147,3 +147,15 @@ def assert_sh_image_parity(img, ref, mean2d, cov2d, alpha, start, end, ids, topl
         assert err[y, x] <= 1.0 / 255.0 + tol, (what, y, x, err[y, x])
     assert len(bad) <= max_exceptions, f"{what}: {len(bad)} threshold-adjacent pixels: {bad[:8].tolist()}"
     return len(bad)
+
+
+def per_gaussian_grad_error(got, want):
+    """Row-wise (per Gaussian) error of a gradient tensor in units of its tolerance (rtol 1e-3, atol 1e-5 per
+    Gaussian):  max over rows i of  max_j |got_ij - want_ij| / (1e-3 max_j |want_ij| + 1e-5 max |want|).
+    <= 1 passes.  A Gaussian whose gradient is a thousandth of the largest is still held to 1 % of ITS OWN magnitude --
+    normalising by the tensor's global maximum would let it be entirely wrong."""
+    a = np.asarray(got, np.float64).reshape(len(want), -1)
+    b = np.asarray(want, np.float64).reshape(len(want), -1)
+    tol = 1e-3 * np.abs(b).max(1) + 1e-5 * np.abs(b).max()
+    ratio = np.abs(a - b).max(1) / np.maximum(tol, 1e-300)
+    return float(ratio.max()), int(ratio.argmax())

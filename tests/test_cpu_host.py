@@ -940,10 +940,10 @@ def test_no_kernel_spills_and_hot_kernels_keep_their_occupancy(tmp_path):
         assert bwd["vgpr_count"] <= 168 and 12 * bwd["group_segment_fixed_size"] <= 160 * 1024, bwd
     for bwd in find(2, "k_composite_bwd_sh_vecILi4ELi4ELb", "ELb0ELi0EE"):  # the 64-component reduction, A/B only
         assert bwd["vgpr_count"] <= 256 and 8 * bwd["group_segment_fixed_size"] <= 160 * 1024
-    # opt-in polynomial-basis kernels (batched launches only): no worse than the exact ones
-    for bwd in find(1, "k_composite_bwd_sh_vecILi4ELi4ELb1ELb1ELi6EE"):
+    # polynomial-basis kernels (per-camera and batched instantiations): no worse than the exact ones
+    for bwd in find(2, "k_composite_bwd_sh_vecILi4ELi4ELb", "ELb1ELi6EE"):
         assert bwd["vgpr_count"] <= 168 and 12 * bwd["group_segment_fixed_size"] <= 160 * 1024, bwd
-    for fwd in find(1, "k_composite_fwd_sh_vecILi4ELi2ELb1ELi6EE"):
+    for fwd in find(2, "k_composite_fwd_sh_vecILi4ELi2ELb", "ELi6EE"):
         assert fwd["vgpr_count"] <= 128 and 8 * fwd["group_segment_fixed_size"] <= 160 * 1024, fwd
     # packed backward of the post-activation modes (RGB + heads is the trainer's default): 4 wavefronts per SIMD
     for bwd in find(2, "k_composite_bwd_chan_vecILi3E"):
@@ -954,9 +954,6 @@ def test_no_kernel_spills_and_hot_kernels_keep_their_occupancy(tmp_path):
         assert bwd["vgpr_count"] <= 256
     for bwd in find(2, "k_composite_bwd_pixelILi2ELi4ELi2E", "ELi16EE"):
         assert bwd["vgpr_count"] <= 128
-    # opt-in matrix-core SH backward: 3 wavefronts per SIMD = 6 two-wavefront workgroups per CU (160 KB of LDS)
-    for bwd in find(2, "k_composite_bwd_sh_mfmaILi4ELi2E"):
-        assert bwd["vgpr_count"] <= 168 and 6 * bwd["group_segment_fixed_size"] <= 160 * 1024
     for fwd in find(2, "k_composite_fwdILi2ELi4ELi1E", "ELi16EE"):      # default SH forward: 4 wavefronts per tile
         assert fwd["vgpr_count"] <= 128
     assert find(1, "k_sort_tiles", "PKjS1_PKyPiS4_S4_")[0]["group_segment_fixed_size"] == 0  # register sort: no LDS
@@ -1004,11 +1001,11 @@ def test_pair_count_is_read_as_uint32_and_a_diverged_scene_is_reported():
 
 @pytest.mark.parametrize("nseg,ppl_fwd", [(0, 2), (3, 4)])
 def test_emulated_polynomial_sh_basis_batched_launches(emu, nseg, ppl_fwd):
-    """The opt-in tile-local polynomial form of the per-pixel SH basis (GSGEN_SH_POLY / variant "sh_poly": degree-2 fit of
-    the basis per tile, 6-term contractions, gradients expanded by the tile's V in front of the atomics; SH degree 3, batched
-    launches): against the oracle at north_star's tolerances, and against the exact kernels of the same launch -- the two
-    differ by the fit error only (1e-6-class at these focal lengths).  Launches whose camera is too wide for the error
-    bound stay on the exact kernels, bit for bit."""
+    """The tile-local polynomial form of the per-pixel SH basis (degree-2 fit of the basis per tile, 6-term contractions,
+    gradients expanded by the tile's V in front of the atomics; SH degree 3, launches that are given the DEVICE address of
+    the coefficient bound): against the oracle at north_star's tolerances, and against the exact kernels of the same launch
+    -- the two differ by the fit error only (1e-6-class at these focal lengths).  The bound is measured on the "device"
+    (gsgen_sh_l1_bound) and routed there: nothing on the host decides."""
     from gsgen_amd._capi import ShView
     C, W, H = 4, 40, 28
     sc = scenes.random_scene(260, seed=17, svec=0.012, spread=0.035, C=C)
@@ -1031,6 +1028,7 @@ def test_emulated_polynomial_sh_basis_batched_launches(emu, nseg, ppl_fwd):
     assert max((v["en"] - v["st"]).max() for v in views) > 40
 
     def launch(bound):
+        """bound: None (exact kernels) or a float32[1] "device" array"""
         arr = (ShView * len(views))()
         res = []
         for a, v in zip(arr, views):
@@ -1044,24 +1042,39 @@ def test_emulated_polynomial_sh_basis_batched_launches(emu, nseg, ppl_fwd):
             a.grad_out, a.grad_mean, a.grad_cov = P(v["go"]), P(r["gm"]), P(r["gc"])
             res.append(r)
         bws = np.zeros(emu.sh_batch_workspace_bytes(len(views)), np.uint8)
-        emu.vol_render_sh_batch_bounded(len(views), arr, Nall, P(sh), P(al), 16, nth, ntw, H, W, C, 1e-4, nseg, bound, P(bws), None)
+        emu.vol_render_sh_batch_bounded(len(views), arr, Nall, P(sh), P(al), 16, nth, ntw, H, W, C, 1e-4, nseg, P(bound), P(bws), None)
         gsh = np.zeros_like(sh); ga = np.zeros(Nall, np.float32)
         emu.vol_render_backward_sh_batch_bounded(len(views), arr, Nall, P(sh), P(al), P(gsh), P(ga), 16, nth, ntw, H, W, C, 1e-4, nseg,
-                                                 bound, P(bws), None)
+                                                 P(bound), P(bws), None)
         return res, gsh, ga
 
-    # the bound: gsgen_sh_l1_bound on the device == numpy
+    # the bound: gsgen_sh_l1_bound on the device == numpy; it OVERWRITES its output (a stale larger value does not survive)
     S_np = float(np.abs(sh[:, :, 1:]).sum(-1).max())
-    S_dev = np.zeros(1, np.float32)
+    S_dev = np.full(1, 77.0, np.float32)
     emu.sh_l1_bound(Nall, P(sh), C, P(S_dev), None)
     assert abs(float(S_dev[0]) - S_np) <= 1e-5 * S_np
+    # ... and the debug verification of somebody else's bound counts the rows above it
+    n_bad = np.full(1, 123, np.uint32)
+    emu.sh_l1_bound_check(Nall, P(sh), C, P(S_dev), P(n_bad), None)
+    assert int(n_bad[0]) == 0
+    rows = np.abs(sh[:, :, 1:]).sum(-1).reshape(-1)
+    half = np.array([np.float32(np.median(rows))])
+    emu.sh_l1_bound_check(Nall, P(sh), C, P(half), P(n_bad), None)
+    assert int(n_bad[0]) == int((rows.astype(np.float32) > half[0]).sum()) > 0
     ps_max = max(1 / c.fx for c in cams)
     assert emu.sh_poly_applies(S_np, ps_max, 4) and not emu.sh_poly_applies(S_np, 1 / 40.0, 4) and not emu.sh_poly_applies(0.0, ps_max, 4)
     assert not emu.sh_poly_applies(S_np, ps_max, 3) and "POLY6" in emu.kernel_variant("sh_bwd_batch_poly", 4)
+    assert not emu.sh_poly_applies(float("nan"), ps_max, 4) and not emu.sh_poly_applies(float("inf"), ps_max, 4)
+    assert "POLY6" not in emu.kernel_variant("sh_bwd_batch", 4)
     emu.set_variant("ppl_fwd_batch", ppl_fwd)
     try:
-        exact, e_gsh, e_ga = launch(0.0)
-        poly, p_gsh, p_ga = launch(S_np * 1.05)
+        exact, e_gsh, e_ga = launch(None)
+        poly, p_gsh, p_ga = launch(S_dev)
+        # a bound of zero / NaN (no information) keeps every view on the exact kernels, bit for bit
+        for useless in (0.0, float("nan")):
+            again, a_gsh, a_ga = launch(np.array([useless], np.float32))
+            assert all(np.array_equal(a["out"], e["out"]) and np.array_equal(a["gm"], e["gm"]) for a, e in zip(again, exact))
+            assert np.array_equal(a_gsh, e_gsh) and np.array_equal(a_ga, e_ga)
     finally:
         emu.set_variant("ppl_fwd_batch", 2)
     want_gsh = np.zeros(sh.shape, np.float64); want_ga = np.zeros(Nall, np.float64)
@@ -1087,38 +1100,84 @@ def test_emulated_polynomial_sh_basis_batched_launches(emu, nseg, ppl_fwd):
     assert np.abs(p_ga - e_ga).max() <= 1e-4 * np.abs(e_ga).max()
 
 
-def test_emulated_polynomial_sh_basis_is_not_used_beyond_its_error_bound(emu):
-    """a wide camera (pixel size 1/40: a tile spans 0.26 rad) with the knob on: the launch keeps the exact kernels, bit for bit"""
+def test_emulated_polynomial_sh_basis_is_routed_per_view_on_the_device(emu):
+    """One batched launch, two cameras, ONE device-resident bound: the narrow camera (pixel size 1/560) takes the polynomial
+    kernel, the wide one (1/40: a tile spans 0.26 rad) stays on the exact kernel bit for bit -- each workgroup decides from
+    the bound and its own view's pixel size.  The same through the per-camera entry points (gsgen_vol_render_sh_bounded)."""
     from gsgen_amd._capi import ShView
     C, W, H = 4, 32, 16
-    sc = scenes.random_scene(200, seed=5, svec=0.1, C=C)
-    cam = scenes.Camera(W, H, fx=40.0)
-    g = scenes.oracle_geometry(sc, cam)
-    nz = np.nonzero(g["mask"])[0]
+    sc = scenes.random_scene(200, seed=5, svec=0.05, spread=0.03, C=C)
+    sc["sh"][:, :, 1:] *= 0.5
+    cams = [scenes.Camera(W, H, fx=560.0), scenes.Camera(W, H, fx=40.0)]
     N = sc["mean"].shape[0]
-    m2 = np.zeros((N, 2), np.float32); c2 = np.zeros((N, 2, 2), np.float32)
-    m2[nz] = g["mean2d"]; c2[nz] = g["cov2d"]
-    ids = nz[g["ids"]].astype(np.int32)
     sh, al = np.ascontiguousarray(sc["sh"]), np.ascontiguousarray(sc["alpha"])
-    rot = np.ascontiguousarray(cam.c2w[:3, :3].reshape(-1)); tlp = cam.topleft
-    nth, ntw = cam.tiles
-    outs = []
-    for knob in (0, 64):
-        emu.set_variant("sh_poly", knob)
-        try:
-            arr = (ShView * 1)()
-            out = np.zeros((H, W, 3), np.float32)
-            a = arr[0]
-            a.mean, a.cov, a.start, a.end, a.gaussian_ids = P(m2), P(c2), P(g["start"]), P(g["end"]), P(ids)
-            a.tile_order, a.topleft, a.c2w, a.bg_rgb = None, P(tlp), P(rot), None
+    nth, ntw = cams[0].tiles
+    S = np.zeros(1, np.float32)
+    emu.sh_l1_bound(N, P(sh), C, P(S), None)
+    assert emu.sh_poly_applies(float(S[0]), 1 / 560.0, 4) and not emu.sh_poly_applies(float(S[0]), 1 / 40.0, 4)
+    views = []
+    for i, cam in enumerate(cams):
+        g = scenes.oracle_geometry(sc, cam)
+        nz = np.nonzero(g["mask"])[0]
+        m2 = np.zeros((N, 2), np.float32); c2 = np.zeros((N, 2, 2), np.float32)
+        m2[nz] = g["mean2d"]; c2[nz] = g["cov2d"]
+        views.append(dict(m2=m2, c2=c2, st=g["start"], en=g["end"], ids=nz[g["ids"]].astype(np.int32), tlp=cam.topleft,
+                          rot=np.ascontiguousarray(cam.c2w[:3, :3].reshape(-1)), cam=cam, D=g["D"],
+                          go=np.random.default_rng(i).normal(size=(H, W, 3)).astype(np.float32)))
+        assert g["D"] > 50
+
+    def batch(bound):
+        arr = (ShView * 2)()
+        res = []
+        for a, v in zip(arr, views):
+            cam = v["cam"]
+            r = dict(out=np.zeros((H, W, 3), np.float32), gm=np.zeros((N, 2), np.float32), gc=np.zeros((N, 4), np.float32))
+            a.mean, a.cov, a.start, a.end, a.gaussian_ids = P(v["m2"]), P(v["c2"]), P(v["st"]), P(v["en"]), P(v["ids"])
+            a.tile_order, a.topleft, a.c2w, a.bg_rgb = None, P(v["tlp"]), P(v["rot"]), None
             a.pixel_size_x, a.pixel_size_y = 1 / cam.fx, 1 / cam.fy
-            a.out, a.T, a.segment_workspace = P(out), None, None
-            bws = np.zeros(emu.sh_batch_workspace_bytes(1), np.uint8)
-            emu.vol_render_sh_batch(1, arr, N, P(sh), P(al), 16, nth, ntw, H, W, C, 1e-4, 0, P(bws), None)
-            outs.append(out)
-        finally:
-            emu.set_variant("sh_poly", 0)
-    assert np.array_equal(outs[0], outs[1]) and np.abs(outs[0]).max() > 0.1
+            a.out, a.T, a.segment_workspace = P(r["out"]), None, None
+            a.grad_out, a.grad_mean, a.grad_cov = P(v["go"]), P(r["gm"]), P(r["gc"])
+            res.append(r)
+        bws = np.zeros(emu.sh_batch_workspace_bytes(2), np.uint8)
+        emu.vol_render_sh_batch_bounded(2, arr, N, P(sh), P(al), 16, nth, ntw, H, W, C, 1e-4, 0, P(bound), P(bws), None)
+        gsh = np.zeros_like(sh); ga = np.zeros(N, np.float32)
+        emu.vol_render_backward_sh_batch_bounded(2, arr, N, P(sh), P(al), P(gsh), P(ga), 16, nth, ntw, H, W, C, 1e-4, 0, P(bound),
+                                                 P(bws), None)
+        return res, gsh, ga
+
+    (e0, e1), e_gsh, _ = batch(None)
+    (q0, q1), q_gsh, _ = batch(S)
+    d0 = np.abs(q0["out"] - e0["out"]).max()
+    assert 0.0 < d0 <= 2e-5, d0                                   # the narrow view: the polynomial kernel, fit error only
+    assert np.array_equal(q1["out"], e1["out"]) and np.abs(e1["out"]).max() > 0.1  # the wide view: the exact kernel, same bits
+    assert np.array_equal(q1["gm"], e1["gm"]) and np.array_equal(q1["gc"], e1["gc"])
+    assert 0.0 < np.abs(q0["gm"] - e0["gm"]).max() <= 1e-4 * np.abs(e0["gm"]).max()
+    assert np.abs(q_gsh - e_gsh).max() <= 1e-4 * np.abs(e_gsh).max()
+
+    # per-camera entry points with the bound: the same routing, and (narrow camera) the same polynomial arithmetic
+    def single(v, bound, nseg=0):
+        cam = v["cam"]
+        out = np.zeros((H, W, 3), np.float32)
+        ws = np.zeros(max(1, emu.segment_workspace_bytes(nth * ntw, nseg)), np.uint8)
+        emu.vol_render_sh_bounded(N, v["D"], P(v["m2"]), P(v["c2"]), P(sh), P(al), P(v["st"]), P(v["en"]), P(v["ids"]), P(out),
+                                  P(v["tlp"]), P(v["rot"]), 16, nth, ntw, 1 / cam.fx, 1 / cam.fy, H, W, C, 1e-4, None, None, None,
+                                  P(ws) if nseg else None, nseg, P(bound), None)
+        gm = np.zeros((N, 2), np.float32); gc = np.zeros((N, 4), np.float32); gsh = np.zeros_like(sh); ga = np.zeros(N, np.float32)
+        emu.vol_render_backward_sh_bounded(N, v["D"], P(v["m2"]), P(v["c2"]), P(sh), P(al), P(v["st"]), P(v["en"]), P(v["ids"]),
+                                           P(out), P(gm), P(gc), P(gsh), P(ga), P(v["go"]), P(v["tlp"]), P(v["rot"]), 16, nth, ntw,
+                                           1 / cam.fx, 1 / cam.fy, H, W, C, 1e-4, None, None, P(ws) if nseg else None, nseg,
+                                           P(bound), None)
+        return out, gm, gsh
+    for nseg in (0, 3):
+        o0, gm0, gsh0 = single(views[0], S, nseg)
+        assert np.abs(o0 - q0["out"]).max() <= 1e-6 and np.abs(o0 - e0["out"]).max() > 0.0   # polynomial form (2 px / lane here too)
+        assert np.abs(gm0 - q0["gm"]).max() <= 1e-5 * np.abs(q0["gm"]).max()
+        x0, xm0, xsh0 = single(views[0], None, nseg)
+        assert np.abs(xsh0 - gsh0).max() <= 1e-4 * np.abs(xsh0).max() and np.abs(xm0 - gm0).max() <= 1e-4 * np.abs(xm0).max()
+        o1, gm1, _ = single(views[1], S, nseg)
+        x1, xm1, _ = single(views[1], None, nseg)
+        assert np.array_equal(o1, x1) and np.array_equal(o1, e1["out"])                 # exact kernel, same bits
+        assert np.abs(gm1 - xm1).max() <= 1e-6 * np.abs(xm1).max()
 
 
 def _poly_vs_exact(emu, sc, cams, nseg, ppl_fwd, tag, seed=0):
@@ -1129,8 +1188,10 @@ def _poly_vs_exact(emu, sc, cams, nseg, ppl_fwd, tag, seed=0):
     n, B = sc["mean"].shape[0], len(cams)
     W, H = cams[0].w, cams[0].h
     sh, al = np.ascontiguousarray(sc["sh"]), np.ascontiguousarray(sc["alpha"])
-    S = float(np.abs(sh[:, :, 1:]).sum(-1).max()) * 1.05
-    assert emu.sh_poly_applies(S, max(max(1 / c.fx, 1 / c.fy) for c in cams), 4), tag
+    S = np.zeros(1, np.float32)
+    emu.sh_l1_bound(n, P(sh), C, P(S), None)  # on the "device", as the product path does per step
+    assert abs(float(S[0]) - float(np.abs(sh[:, :, 1:]).sum(-1).max())) <= 1e-5 * float(S[0]) + 1e-12, tag
+    assert emu.sh_poly_applies(float(S[0]), max(max(1 / c.fx, 1 / c.fy) for c in cams), 4), tag
     nth, ntw = cams[0].tiles
     views = []
     for i, cam in enumerate(cams):
@@ -1159,15 +1220,15 @@ def _poly_vs_exact(emu, sc, cams, nseg, ppl_fwd, tag, seed=0):
             a.grad_out, a.grad_mean, a.grad_cov = P(v["go"]), P(r["gm"]), P(r["gc"])
             res.append(r)
         bws = np.zeros(emu.sh_batch_workspace_bytes(B), np.uint8)
-        emu.vol_render_sh_batch_bounded(B, arr, n, P(sh), P(al), 16, nth, ntw, H, W, C, 1e-4, nseg, bound, P(bws), None)
+        emu.vol_render_sh_batch_bounded(B, arr, n, P(sh), P(al), 16, nth, ntw, H, W, C, 1e-4, nseg, P(bound), P(bws), None)
         gsh = np.zeros_like(sh); ga = np.zeros(n, np.float32)
-        emu.vol_render_backward_sh_batch_bounded(B, arr, n, P(sh), P(al), P(gsh), P(ga), 16, nth, ntw, H, W, C, 1e-4, nseg, bound,
+        emu.vol_render_backward_sh_batch_bounded(B, arr, n, P(sh), P(al), P(gsh), P(ga), 16, nth, ntw, H, W, C, 1e-4, nseg, P(bound),
                                                  P(bws), None)
         return res, gsh, ga
 
     emu.set_variant("ppl_fwd_batch", ppl_fwd)
     try:
-        exact, e_gsh, e_ga = launch(0.0)
+        exact, e_gsh, e_ga = launch(None)
         poly, p_gsh, p_ga = launch(S)
     finally:
         emu.set_variant("ppl_fwd_batch", 2)

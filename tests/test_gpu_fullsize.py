@@ -64,13 +64,17 @@ def check_lists(buf, g):
 
 
 def check_grads(P, want, anisotropic):
-    """every gradient within 1e-3 of the largest reference entry.  With isotropic scales (the Point-E-init clouds)
-    d/d qvec is analytically zero: both sides hold rounding noise, which must stay below 1e-3 of the scale gradient."""
+    """every gradient PER GAUSSIAN: row i within 1e-3 of its own largest reference entry (+ 1e-5 of the tensor's largest:
+    scenes.per_gaussian_grad_error; fp32 atomics reorder the sums, the oracle sums in fp64).  With isotropic scales (the
+    Point-E-init clouds) d/d qvec is analytically zero: both sides hold rounding noise, which must stay below 1e-3 of the
+    scale gradient."""
     for k in KEYS:
-        got = P[k].grad.cpu().numpy()
+        got = P[k].grad.cpu().numpy() if isinstance(P[k], torch.Tensor) else P[k]
         if k == "qvec" and not anisotropic:
             assert np.abs(got).max() <= 1e-3 * np.abs(want["svec"]).max()
             continue
+        worst, row = scenes.per_gaussian_grad_error(got, want[k])
+        assert worst <= 1.0, (k, worst, row, np.asarray(got).reshape(len(want[k]), -1)[row], np.asarray(want[k]).reshape(len(want[k]), -1)[row])
         assert rel_err(got, want[k]) < 1e-3, (k, rel_err(got, want[k]))
 
 
@@ -357,15 +361,14 @@ def test_batched_heads_fuzz():
 
 
 def test_full_size_cfg2_polynomial_sh_basis():
-    """The tile-local polynomial form of the per-pixel SH basis (BatchRenderer.render(sh_l1_bound=...) ->
-    gsgen_vol_render_sh_batch_bounded; composite_common.hpp) at the headline size: two cfg2 cameras (100k Gaussians,
-    800x800, f = 800) through the batched launches with the scene's coefficient bound, every pixel within 1e-4 of the
-    oracle, every gradient within 1e-3 -- and within 1e-5 / 1e-4 of the exact kernels."""
+    """The tile-local polynomial form of the per-pixel SH basis (BatchRenderer.render's default for SH degree 3 ->
+    gsgen_sh_l1_bound + gsgen_vol_render_sh_batch_bounded; composite_common.hpp) at the headline size: two cfg2 cameras (100k
+    Gaussians, 800x800, f = 800) through the batched launches, the coefficient bound measured and routed on the device, every
+    pixel within 1e-4 of the oracle, every gradient within 1e-3 -- and within 1e-5 / 1e-4 of the exact kernels."""
     from gsgen_amd import renderer as R, _capi
     from gsgen_amd.batch import BatchRenderer
     L = _capi.load()
     sc = scenes.pointe_scene(100_000, seed=0, C=4)
-    assert float(np.abs(sc["sh"][:, :, 1:]).sum(-1).max()) < 4.0  # the bound the knob declares (S = 64 / 16)
     N, W, H, B = sc["mean"].shape[0], 800, 800, 2
     cams = [scenes.Camera(W, H, fx=800.0, c2w=scenes.orbit(2.5, 15.0, 30.0 + 45.0 * i)) for i in range(B)]
     cis = [R.CameraInfo(*c.intr) for c in cams]
@@ -373,15 +376,15 @@ def test_full_size_cfg2_polynomial_sh_basis():
     gos = torch.randn(B, H, W, 3, device=dev(), generator=torch.Generator(device=dev()).manual_seed(5))
     res = {}
     P0 = T_(sc["sh"])
-    S = R.sh_l1_bound(P0)  # the device's reduction (one sync): max sum of |non-constant coefficients|, x 1.05
-    assert abs(S / 1.05 - float(np.abs(sc["sh"][:, :, 1:]).sum(-1).max())) <= 1e-4 * S
+    S = R.sh_l1_bound(P0)  # the device's reduction, read back here for the assertion only
+    assert abs(S - float(np.abs(sc["sh"][:, :, 1:]).sum(-1).max())) <= 1e-5 * S
     assert L.sh_poly_applies(S, 1.0 / 800.0, 4) and "POLY6" in L.kernel_variant("sh_bwd_batch_poly", 4)
-    for knob, bound in ((0, None), (64, S)):
+    for knob, basis in ((0, "exact"), (64, "auto")):
         P = {k: T_(sc[k]).requires_grad_(True) for k in KEYS}
         br = BatchRenderer(N, W, H, dev(), max_batch=B)
         for _ in range(2):
             rgb, _ = br.render(P["mean"], P["qvec"], P["svec"], P["alpha"], P["sh"], cis, [c.c2w for c in cams], C=4, bg_rgb=T_(bg),
-                               sh_l1_bound=bound)
+                               sh_basis=basis)
             if br.ensure_capacity(B):
                 break
         (rgb * gos).sum().backward()

@@ -4,7 +4,7 @@ this repo's `_gs` mirror, checked against the golden vectors the reference itsel
 `gs/renderer.py:20-24` does `import _gs as _backend`; here `_backend` is gsgen_amd._gs, exactly what a user of the
 reference gets after gsgen_amd.install_as_gs() / shim/_gs.py.  In this GPU-less container the mirror is bound to
 the SIMT-emulator build of the same kernels (oracle/_build/libgsgen_emu.so) and fed host tensors
-(gsgen_amd._gs._bind_library_for_tests -- a hook nothing in the product uses).  Forward AND backward of
+(the test rebinds gsgen_amd._gs._load to that build and lets it accept host tensors; the product binds the HIP library only).  Forward AND backward of
 _render_with_T (gs/renderer.py:1135-1283), _render_scalar (:999-1132), _render_sh (:674-830), _render_sh_bg
 (:833-996) and _render_start_end (:541-672), plus the reference's PyTorch projection chained in front of
 _render_sh so that gradients flow to mean / qvec / svec through the reference's whole Python graph.
@@ -41,7 +41,8 @@ def ref():
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "emu"])
     from gsgen_amd import _capi, _gs
     emu = _capi.Lib(os.path.join(ROOT, "oracle", "_build", "libgsgen_emu.so"))
-    _gs._bind_library_for_tests(emu, host_tensors=True)
+    saved = (_gs._load, _gs._ACCEPT_HOST_TENSORS)
+    _gs._load, _gs._ACCEPT_HOST_TENSORS = (lambda: emu), True  # the emulator build of the same kernels, host tensors
     refshim.install()
     sys.modules["_gs"] = _gs  # what `import _gs as _backend` finds (gs/renderer.py:20-24)
     import gs.renderer as GR
@@ -52,7 +53,7 @@ def ref():
     torch.cuda.profiler.cudart = lambda: stub
     yield GR
     torch.cuda.profiler.cudart = orig
-    _gs._bind_library_for_tests(None)
+    _gs._load, _gs._ACCEPT_HOST_TENSORS = saved
 
 
 def load(name):

@@ -1,8 +1,7 @@
-"""The compositing kernels exist in several compiled variants selected by environment variables
-read once per process (pixels per lane of the forward / backward, matrix-core vs vector SH gradient contraction and
-its wavefronts per tile).  Only one combination is the default; these tests run the parity suite in a
-subprocess for the others so that none of them rots.  CPU: on the SIMT emulator; GPU: on the
-real library."""
+"""The compositing kernels exist in several compiled shapes (pixels per lane of the forward / backward, packed vs unpacked
+per-pixel arithmetic, block order of the batched grids), selected through gsgen_debug_set_variant.  Only one combination is
+the default; these tests run parts of the parity suite in a subprocess for the others (GSGEN_TEST_VARIANTS, applied by
+tests/conftest.py to every library handle) so that none of them rots.  CPU: on the SIMT emulator; GPU: on the real library."""
 import os
 import subprocess
 import sys
@@ -12,36 +11,26 @@ import pytest
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 VARIANTS = [
-    {"GSGEN_PPL_FWD": "4", "GSGEN_PPL_BWD": "2"},
-    {"GSGEN_PPL_FWD": "2", "GSGEN_PPL_BWD": "1"},
-    {"GSGEN_BWD_SH_CHRED": "0"},  # packed SH backward with ONE 64-component gradient reduction (2 wavefronts per SIMD)
-    {"GSGEN_BWD_CHAN_PACKED": "0"},  # RGB / scalar / RGB + heads backward on the unpacked k_composite_bwd_pixel
+    {"ppl_fwd": 4, "ppl_bwd": 2},
+    {"ppl_fwd": 2, "ppl_bwd": 1},
+    {"sh_chred": 0},  # packed SH backward with ONE 64-component gradient reduction (2 wavefronts per SIMD)
+    {"chan_packed": 0},  # RGB / scalar / RGB + heads backward on the unpacked k_composite_bwd_pixel
 ]
-# The matrix-core SH backward is OPT-IN (GSGEN_BWD_MFMA = 4 | 2 | 1 pixels per lane; default 0 = vector ALUs): its
-# MFMA chain has shown box- and timing-dependent corruption on hardware that is not root-caused.
-# Its logic is still covered on the deterministic CPU emulator below; on the GPU the variants only run when
-# GSGEN_TEST_MFMA=1 asks for them (tools/stress is the tool that hunts the hazard).
-MFMA_VARIANTS = [
-    {"GSGEN_BWD_MFMA": "2"},  # two wavefronts per tile
-    {"GSGEN_BWD_MFMA": "4"},  # one wavefront per tile
-    {"GSGEN_BWD_MFMA": "1"},  # four wavefronts per tile
-]
-MFMA_ON_GPU = os.environ.get("GSGEN_TEST_MFMA") == "1"
 
 
-def _run(env_extra, args):
+def _ids(v):
+    return ",".join(f"{k}={x}" for k, x in v.items())
+
+
+def _run(variant, args):
     env = dict(os.environ)
-    env.update(env_extra)
+    env["GSGEN_TEST_VARIANTS"] = _ids(variant)
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider"] + args, cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
-# the opt-in matrix-core kernel: one shape in the default CPU run (19 s each), all three with GSGEN_TEST_MFMA=1
-EMU_VARIANTS = VARIANTS + (MFMA_VARIANTS if MFMA_ON_GPU else MFMA_VARIANTS[:1])
-
-
-@pytest.mark.parametrize("variant", EMU_VARIANTS, ids=lambda v: ",".join(f"{k}={x}" for k, x in v.items()))
+@pytest.mark.parametrize("variant", VARIANTS, ids=_ids)
 def test_variant_on_emulator(variant):
     # two SH degrees (padded and unpadded coefficient rows) + the fused RGB heads: ~20 s per variant
     _run(variant, ["tests/test_cpu_host.py", "-k",
@@ -52,48 +41,30 @@ def test_variant_on_emulator(variant):
 # order of the (camera, tile) blocks in the grid.  GPU only: the emulator runs the default of each in
 # tests/test_cpu_host.py, and one emulated batch costs ~30 s.
 BATCH_VARIANTS = [
-    {"GSGEN_BATCH_MAP": "0"},                                   # interleaved cameras
+    {"batch_map": 0},                                   # interleaved cameras
     # interleaved + rotated; 2 wavefronts per tile forward (the per-camera launches the images are compared with bit
     # for bit get the same split: different pixels-per-lane builds round a few pixels differently)
-    {"GSGEN_BATCH_MAP": "1", "GSGEN_PPL_FWD_BATCH": "2", "GSGEN_PPL_FWD": "2"},
-    {"GSGEN_PPL_BWD_SH_BATCH": "2", "GSGEN_PPL_BWD_BATCH": "4"},  # SH backward 2 wavefronts per tile, heads 1
-    {"GSGEN_PPL_BWD_SH_BATCH": "1", "GSGEN_PPL_BWD_BATCH": "1", "GSGEN_PPL_FWD_BATCH": "4", "GSGEN_PPL_FWD": "4"},
-    {"GSGEN_BWD_SH_CHRED": "0"},
-    {"GSGEN_BWD_CHAN_PACKED": "0"},
+    {"batch_map": 1, "ppl_fwd_batch": 2, "ppl_fwd": 2},
+    {"ppl_bwd_sh_batch": 2, "ppl_bwd_batch": 4},  # SH backward 2 wavefronts per tile, heads 1
+    {"ppl_bwd_sh_batch": 1, "ppl_bwd_batch": 1, "ppl_fwd_batch": 4, "ppl_fwd": 4, "ppl_fwd_poly": 4},
+    {"sh_chred": 0},
+    {"chan_packed": 0},
 ]
-MFMA_BATCH_VARIANTS = [
-    {"GSGEN_BWD_MFMA_BATCH": "2"},
-    {"GSGEN_BWD_MFMA_BATCH": "4"},
-    {"GSGEN_BWD_MFMA_BATCH": "1"},
-]
-
 
 def test_batch_block_order_variant_on_emulator():
     # the rotated interleaving exercises every branch of batch_view(); one emulated batch, ~25 s
-    _run({"GSGEN_BATCH_MAP": "1"}, ["tests/test_cpu_host.py", "-k", "emulated_batched_views_match_per_view_launches and 4-0"])
+    _run({"batch_map": 1}, ["tests/test_cpu_host.py", "-k", "emulated_batched_views_match_per_view_launches and 4-0"])
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", BATCH_VARIANTS, ids=lambda v: ",".join(f"{k}={x}" for k, x in v.items()))
+@pytest.mark.parametrize("variant", BATCH_VARIANTS, ids=_ids)
 def test_batch_variant_on_gpu(variant):
     _run(variant, ["tests/test_gpu_api.py", "-m", "gpu", "-k",
                    "batched_cameras_match_one_at_a_time and (3-4-1 or 2-2-3) or batched_fused_heads_match_oracle"])
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", VARIANTS, ids=lambda v: ",".join(f"{k}={x}" for k, x in v.items()))
+@pytest.mark.parametrize("variant", VARIANTS, ids=_ids)
 def test_variant_on_gpu(variant):
     _run(variant, ["tests/test_gpu_parity.py", "tests/test_gpu_golden.py", "-m", "gpu", "-k",
                    "forward_backward or golden"])
-
-
-@pytest.mark.gpu
-@pytest.mark.skipif(not MFMA_ON_GPU, reason="matrix-core backward is opt-in: GSGEN_TEST_MFMA=1")
-@pytest.mark.parametrize("variant", MFMA_VARIANTS + MFMA_BATCH_VARIANTS, ids=lambda v: ",".join(f"{k}={x}" for k, x in v.items()))
-def test_mfma_variant_on_gpu(variant):
-    if "GSGEN_BWD_MFMA" in variant:
-        _run(variant, ["tests/test_gpu_parity.py", "tests/test_gpu_golden.py", "-m", "gpu", "-k",
-                       "forward_backward or golden"])
-    else:
-        _run(variant, ["tests/test_gpu_api.py", "-m", "gpu", "-k",
-                       "batched_cameras_match_one_at_a_time and (3-4-1 or 2-2-3)"])

@@ -2,7 +2,7 @@ mkdir -p gpurun_out
 timeout 600 python -m pytest tests -m gpu -q 2>&1 | tail -8 > gpurun_out/pytest_gpu.log
 for f in 4 2 1; do for b in 4 2 1; do
   echo "PPL fwd=$f bwd=$b" >> gpurun_out/sweep.log
-  GSGEN_PPL_FWD=$f GSGEN_PPL_BWD=$b timeout 120 python bench.py --steps 40 --warmup 10 --no-cpu-baseline 2>/dev/null | python -c "
+  timeout 120 python bench.py --steps 40 --warmup 10 --no-cpu-baseline --variant ppl_fwd=$f --variant ppl_bwd=$b 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
