@@ -191,9 +191,15 @@ def main():
                     help="A/B: override one entry of the library's kernel-variant table (gsgen_debug_set_variant), e.g. "
                          "--variant ppl_fwd_batch=4; repeatable")
     ap.add_argument("--no-surface", action="store_true", help="skip the autograd-surface pass (BatchRenderer.render + backward)")
+    ap.add_argument("--only-timed", action="store_true",
+                    help="profiling runs: nothing but the warm-up and the timed regions launches kernels (no exact-basis region, no "
+                         "secondary views, no CPU baseline), so that a rocprofv3 kernel trace of the process averages exactly the "
+                         "launches `value` and `roofline.avg_launch_ms` are made of")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the one-render-in-flight and hipGraph passes")
     args = ap.parse_args()
+    if args.only_timed:
+        args.no_surface = args.no_latency = args.no_cpu_baseline = True
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args.gpus))
@@ -463,7 +469,7 @@ def main():
 
     # ---- the same timed region with the exact per-pixel SH basis (when the headline used the polynomial form) ----------------
     exact_basis = None
-    if state["bounded"]:
+    if state["bounded"] and not args.only_timed:
         state["bounded"] = False
         for i in range(max(2, len(slots))):
             run_step(i, evs[i % K])
@@ -479,13 +485,16 @@ def main():
 
     # ---- secondary views ---------------------------------------------------------------------------------------------
     # (a) one batch in flight: the duration of a launch that has the chip to itself
-    eva = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(min(K, 8))]
-    barrier()
-    for j in range(len(eva)):
-        run_step(j * len(slots), eva[j], gather=False)  # slot 0 every time: one stream
-    barrier()
-    alone = {"fwd_launch_ms": float(np.mean([e[0].elapsed_time(e[1]) for e in eva])),
-             "bwd_launch_ms": float(np.mean([e[2].elapsed_time(e[3]) for e in eva]))}
+    if args.only_timed:
+        alone = {"fwd_launch_ms": fwd_ms, "bwd_launch_ms": bwd_ms}  # not measured in this mode
+    else:
+        eva = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(min(K, 8))]
+        barrier()
+        for j in range(len(eva)):
+            run_step(j * len(slots), eva[j], gather=False)  # slot 0 every time: one stream
+        barrier()
+        alone = {"fwd_launch_ms": float(np.mean([e[0].elapsed_time(e[1]) for e in eva])),
+                 "bwd_launch_ms": float(np.mean([e[2].elapsed_time(e[3]) for e in eva]))}
 
     # (b) strictly one render (one camera) at a time on one stream, per-camera entry points: the latency view
     one = None
@@ -648,11 +657,14 @@ def main():
     fwd_name = lib.kernel_variant("sh_fwd_batch_poly" if poly_applies else "sh_fwd_batch", C, nseg)
     traffic, traffic_src, valu_floor = None, None, None
     try:  # HBM bytes per launch of the dominant kernel from committed PMC passes, if they are of THIS kernel and workload
-        pmc_all = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
-        ent = pmc_all.get(f"{args.config}|{bwd_name}|views={B}")
-        if ent:
-            traffic, valu_floor = ent["traffic_bytes_per_launch"], ent.get("valu_floor_ms_per_launch")
-            traffic_src = "profiles/r02_traffic.json (separate rocprofv3 --pmc passes of this kernel on this workload: 2 x FETCH_SIZE + WRITE_SIZE)"
+        for fn_ in ("r03_traffic.json", "r02_traffic.json"):
+            pmc_all = json.load(open(os.path.join(ROOT, "profiles", fn_)))
+            ent = pmc_all.get(f"{args.config}|{bwd_name}|views={B}")
+            if ent:
+                traffic, valu_floor = ent["traffic_bytes_per_launch"], ent.get("valu_floor_ms_per_launch")
+                traffic_src = (f"profiles/{fn_} (separate rocprofv3 --pmc passes of this kernel on this workload and launch shape: "
+                               "2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md's gfx950 correction)")
+                break
     except Exception:
         pass
     ach = B * parts["composite_bwd"] / (bwd_ms * 1e-3) / 1e9

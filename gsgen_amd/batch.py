@@ -398,8 +398,7 @@ class BatchRenderer:
         # the slots' pair counters live in one tensor: one copy brings a batch's counts to the host (overflow detection
         # without a sync, see FrameBuffers.check_overflow)
         self._totals = torch.zeros(max_batch, device=device, dtype=torch.int32)
-        self._totals_host = torch.zeros(max_batch, dtype=torch.int32).pin_memory()
-        self._totals_event, self._totals_B = None, 0
+        self._monitor = R.PairCountMonitor(max_batch)
         self._generation = 0
         self._sh_bound = None
         self._table_cache = {}
@@ -478,14 +477,9 @@ class BatchRenderer:
         return self._generation
 
     def _end_batch(self, B):
-        """behind the geometry enqueue: the batch's pair counts follow it to the host (one async copy, one event)"""
-        if torch.cuda.is_current_stream_capturing():  # a hipGraph of the step: an event recorded under capture cannot be
-            self._totals_event = None                 # queried afterwards; size the slots (ensure_capacity) before capturing
-            return
-        self._totals_host[:B].copy_(self._totals[:B], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.device))
-        self._totals_event, self._totals_B = ev, B
+        """behind the geometry enqueue: the batch's pair counts follow it to the host (one async copy, one event, into
+        the monitor's ring: no batch's counts are ever dropped unread)"""
+        self._monitor.record(self._totals, B, torch.cuda.current_stream(self.device))
 
     def _check_generation(self, gen):
         if gen != self._generation:
@@ -495,21 +489,22 @@ class BatchRenderer:
                                "(e.g. for gradient accumulation or an evaluation render in between).")
 
     def check_overflow(self):
-        """No sync: if the previous batch's pair counts have reached the host and one exceeded its slot's capacity,
-        grow that slot and warn (that camera was rendered as background only, with zero gradients)."""
-        ev = self._totals_event
-        if ev is None or torch.cuda.is_current_stream_capturing() or not ev.query():  # (no queries under capture)
-            return True
-        self._totals_event = None
+        """No sync (unless the host is more than PairCountMonitor.depth batches ahead): if pair counts of earlier batches
+        have reached the host and one exceeded its slot's capacity, grow that slot and warn (that camera was rendered as
+        background only, with zero gradients)."""
         ok = True
-        for i in range(self._totals_B):
-            need, s = R.pair_count(self._totals_host[i]), self.slots[i]
+        worst = {}
+        for counts in self._monitor.drain():
+            for i, need in enumerate(counts):
+                worst[i] = max(worst.get(i, 0), need)
+        for i, need in worst.items():
+            s = self.slots[i]
             if need > s.D_cap:
                 import warnings
                 old = s.D_cap
                 s._alloc_pairs(int(need * 1.25) + 1024)
                 self._generation += 1
-                warnings.warn(f"gsgen_amd: camera {i} of the previous batch needed {need} (tile, Gaussian) pairs, "
+                warnings.warn(f"gsgen_amd: camera {i} of an earlier batch needed {need} (tile, Gaussian) pairs, "
                               f"capacity was {old}: it was rendered as BACKGROUND ONLY with zero gradients.  The slot has "
                               f"been regrown to {s.D_cap}; call BatchRenderer.ensure_capacity() after a render to catch "
                               f"this synchronously.", RuntimeWarning, stacklevel=3)
@@ -590,7 +585,7 @@ class BatchRenderer:
     def ensure_capacity(self, B=None):
         """One host sync: grows any slot whose pair list overflowed in the last batch.  Returns
         False if a slot had to grow (that camera's image was rendered empty: render again)."""
-        self._totals_event = None
+        self._monitor.clear()
         ok = True
         for s in self.slots[:B]:
             ok = s.ensure_capacity() and ok

@@ -157,9 +157,6 @@ __global__ void __launch_bounds__(TS * TS / PPL) k_composite_fwd(CompParams p_ar
   constexpr int NCH = TR::NCH;
   __shared__ Stage<MODE, CB> S;
 
-  if constexpr (MODE == MODE_SH && CB == 4) {
-    if (poly_route(p)) return;  // this view is rendered by the polynomial-basis kernel of the same enqueue
-  }
   int tx, ty;
   if (!block_tile(p, tx, ty, bid)) return;  // uniform over the workgroup
   const int tile = ty * p.ntw + tx;
@@ -355,29 +352,30 @@ __global__ void __launch_bounds__(TS * TS / PPL) k_composite_fwd(CompParams p_ar
 // shape and outputs (image, T, segment checkpoints and stop indices) as k_composite_fwd.
 // NB > 0 (= kPolyNB, SH degree 3 only): the tile-local polynomial form of the per-pixel basis, see composite_common.hpp --
 // the same kernel with 6-term contractions against coefficients transformed once per (tile, splat).
-template <int CB, int PPL, bool BATCH = false, int NB = 0>
-__global__ void __launch_bounds__(256 / PPL)
-k_composite_fwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
+// NB = kRouted (SH degree 3, launches that were given the coefficient bound): ONE launch holds both forms; every workgroup
+// reads the bound and its view's pixel size (poly_route: two scalar loads, uniform over the workgroup) and runs the
+// polynomial form where the error bound holds, the exact form elsewhere.  The two forms share one block of LDS (a union) and
+// the register budget is the larger of the two -- the same occupancy class as either alone.
+constexpr int kRouted = -1;
+template <int CB, bool POLY>
+struct FwdShVecShared {
+  Stage<MODE_SH, CB, kBatch, !POLY> S;
+  alignas(16) float Vs[POLY ? kPolyNB * 16 : 4];          // POLY: V of this tile
+  alignas(16) float Ws[POLY ? kBatch * 3 * kPolyNB : 4];  // POLY: transformed coefficients of the staged batch
+                                                          // (and, before the first batch, the nine node bases)
+};
+template <int CB, int PPL, int NB>
+__device__ __forceinline__ void composite_fwd_sh_vec_tile(const CompParams &p, uint32_t bid, FwdShVecShared<CB, (NB > 0)> &sm) {
   static_assert(PPL == 4 || PPL == 2, "pixel pairs: 2 or 4 pixels per lane");
   constexpr bool POLY = NB > 0;
   static_assert(!POLY || (NB == kPolyNB && CB == 4), "polynomial basis: SH degree 3");
-  uint32_t bid = blockIdx.x;
-  const CompParams p = BATCH ? plist[batch_view(p_arg, bid)] : p_arg;  // see k_composite_fwd
   constexpr int MODE = MODE_SH;
   using TR = Traits<MODE, CB>;
   constexpr int NT = 256 / PPL, ROWS = NT / 16, NP = PPL / 2;
   constexpr int CCP = POLY ? NB : TR::CCP, NPAIR = CCP / 2;
-  __shared__ Stage<MODE, CB, kBatch, !POLY> S;
-  __shared__ alignas(16) float Vs[POLY ? kPolyNB * 16 : 4];           // POLY: V of this tile
-  __shared__ alignas(16) float Ws[POLY ? kBatch * 3 * kPolyNB : 4];   // POLY: transformed coefficients of the staged batch
-                                                                       // (and, before the first batch, the nine node bases)
-
-  // one of the two kernels of a bounded enqueue renders the view (uniform over the workgroup)
-  if constexpr (POLY) {
-    if (!poly_route(p)) return;
-  } else if constexpr (CB == 4) {
-    if (poly_route(p)) return;
-  }
+  auto &S = sm.S;
+  float *const Vs = sm.Vs;
+  float *const Ws = sm.Ws;
   int tx, ty;
   if (!block_tile(p, tx, ty, bid)) return;  // uniform over the workgroup
   const int tile = ty * p.ntw + tx;
@@ -563,6 +561,31 @@ k_composite_fwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
     for (int j = 0; j < PPL; ++j) p.stop[(size_t)tile * 256 + (ly0 + j * ROWS) * 16 + lx] = stop[j];
   }
 }
+template <int CB, int PPL, bool BATCH = false, int NB = 0>
+__global__ void __launch_bounds__(256 / PPL)
+k_composite_fwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
+  uint32_t bid = blockIdx.x;
+  if constexpr (NB == kRouted) {
+    static_assert(CB == 4, "routing exists for SH degree 3");
+    union Shared {
+      FwdShVecShared<4, true> poly;
+      FwdShVecShared<4, false> exact;
+    };
+    __shared__ Shared sm;
+    const CompParams *pp = BATCH ? &plist[batch_view(p_arg, bid)] : &p_arg;  // (see k_composite_bwd_sh_vec)
+    if (poly_route(pp->sh_bound, pp->psx, pp->psy)) {
+      const CompParams p = *pp;
+      composite_fwd_sh_vec_tile<4, PPL, kPolyNB>(p, bid, sm.poly);
+    } else {
+      const CompParams p = *pp;
+      composite_fwd_sh_vec_tile<4, PPL, 0>(p, bid, sm.exact);
+    }
+  } else {
+    const CompParams p = BATCH ? plist[batch_view(p_arg, bid)] : p_arg;  // see k_composite_fwd
+    __shared__ FwdShVecShared<CB, (NB > 0)> sm;
+    composite_fwd_sh_vec_tile<CB, PPL, NB>(p, bid, sm);
+  }
+}
 
 // ============================================================================================
 // backward
@@ -579,9 +602,6 @@ k_composite_bwd_pixel(CompParams p_arg, const CompParams *__restrict__ plist) {
   constexpr int NCH = TR::NCH;
   constexpr int P = TR::P;
   __shared__ Stage<MODE, CB> S;
-  if constexpr (MODE == MODE_SH && CB == 4) {
-    if (poly_route(p)) return;  // this view's gradients come from the polynomial-basis kernel of the same enqueue
-  }
 
   // Segmented launch (SH only): workgroup = (tile, segment of kSegLen list entries) starting from the
   // state the forward left in front of the segment (CompParams::ckpt / stop); segment-major order: all
@@ -824,34 +844,36 @@ k_composite_bwd_pixel(CompParams p_arg, const CompParams *__restrict__ plist) {
 // NB > 0 (= kPolyNB; SH degree 3, CHRED, one wavefront per tile): the tile-local polynomial form of the per-pixel basis
 // (composite_common.hpp) -- 6-term contractions, 3 x 6 SH gradient components across the lanes, expanded by the tile's V
 // (through 24 floats of LDS) in front of the 48 atomics.
-template <int CB, int PPL, bool BATCH = false, bool CHRED = false, int NB = 0>
-__global__ void __launch_bounds__(256 / PPL)
-k_composite_bwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
+// NB = kRouted: as k_composite_fwd_sh_vec -- one launch, the form chosen per workgroup from the device-resident bound.
+template <int CB, int PPL, bool CHRED, bool POLY>
+struct BwdShVecShared {
+  static constexpr int KB = CHRED ? 32 : kBatch;  // CHRED: 10.6 KB of LDS per workgroup, 12+ workgroups per CU
+  static constexpr int NT = 256 / PPL, NP = PPL / 2;
+  Stage<MODE_SH, CB, KB, !POLY> S;
+  v2f go_s[CHRED ? 3 * NP * NT : 1];                      // CHRED: grad_out of the lane's pixel pairs, [channel][pair][thread]
+  alignas(16) float Vs[POLY ? kPolyNB * 16 : 4];          // POLY: V of this tile
+  alignas(16) float Ws[POLY ? KB * 3 * kPolyNB : 4];      // POLY: transformed coefficients of the staged batch
+                                                          // (and, before the first batch, the nine node bases)
+  float gw_s[POLY ? 3 * 8 : 1];                           // POLY: a splat's reduced gradient in the tile's basis
+};
+template <int CB, int PPL, bool CHRED, int NB>
+__device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, uint32_t bid, uint32_t grid,
+                                                          BwdShVecShared<CB, PPL, CHRED, (NB > 0)> &sm) {
   static_assert(PPL == 4 || PPL == 2, "pixel pairs: 2 or 4 pixels per lane");
   constexpr bool POLY = NB > 0;
   static_assert(!POLY || (NB == kPolyNB && CB == 4 && CHRED && PPL == 4), "polynomial basis: SH degree 3, one wavefront per tile");
-  uint32_t bid = blockIdx.x, grid = gridDim.x;
-  const CompParams p = BATCH ? plist[batch_view(p_arg, bid, &grid)] : p_arg;  // see k_composite_fwd
   constexpr int MODE = MODE_SH;
   using TR = Traits<MODE, CB>;
   constexpr int NT = 256 / PPL, ROWS = NT / 16, NP = PPL / 2;
   constexpr int CCP = POLY ? NB : TR::CCP, NPAIR = CCP / 2, NSH = 3 * CCP;  // SH components incl. padding
   constexpr int P = (NSH + 7) <= 32 ? 32 : 64;                    // reduction width: SH | mean 2 | cov 4 | alpha 1
   static_assert(NSH % 2 == 0 && NSH + 7 <= P, "component layout");
-  constexpr int KB = CHRED ? 32 : kBatch;  // CHRED: 10.6 KB of LDS per workgroup, 12+ workgroups per CU
-  __shared__ Stage<MODE, CB, KB, !POLY> S;
-  __shared__ v2f go_s[CHRED ? 3 * NP * NT : 1];  // CHRED: grad_out of the lane's pixel pairs, [channel][pair][thread]
-  __shared__ alignas(16) float Vs[POLY ? kPolyNB * 16 : 4];      // POLY: V of this tile
-  __shared__ alignas(16) float Ws[POLY ? KB * 3 * kPolyNB : 4];  // POLY: transformed coefficients of the staged batch
-                                                                  // (and, before the first batch, the nine node bases)
-  __shared__ float gw_s[POLY ? 3 * 8 : 1];                       // POLY: a splat's reduced gradient in the tile's basis
-
-  // one of the two kernels of a bounded enqueue handles the view (uniform over the workgroup)
-  if constexpr (POLY) {
-    if (!poly_route(p)) return;
-  } else if constexpr (CB == 4) {
-    if (poly_route(p)) return;
-  }
+  constexpr int KB = CHRED ? 32 : kBatch;
+  auto &S = sm.S;
+  v2f *const go_s = sm.go_s;
+  float *const Vs = sm.Vs;
+  float *const Ws = sm.Ws;
+  float *const gw_s = sm.gw_s;
   const int nseg = p.nseg > 1 ? p.nseg : 1;
   const uint32_t tiles_grid = grid / (uint32_t)nseg;
   const int seg = (int)(bid / tiles_grid);
@@ -1152,6 +1174,34 @@ k_composite_bwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
 #pragma unroll
     for (int j = 0; j < PPL; ++j) any_alive |= alive(j);
     if (__syncthreads_or((int)any_alive) == 0) break;
+  }
+}
+template <int CB, int PPL, bool BATCH = false, bool CHRED = false, int NB = 0>
+__global__ void __launch_bounds__(256 / PPL)
+k_composite_bwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
+  uint32_t bid = blockIdx.x, grid = gridDim.x;
+  if constexpr (NB == kRouted) {
+    static_assert(CB == 4 && PPL == 4 && CHRED, "routing exists for SH degree 3, one wavefront per tile");
+    union Shared {
+      BwdShVecShared<4, 4, true, true> poly;
+      BwdShVecShared<4, 4, true, false> exact;
+    };
+    __shared__ Shared sm;
+    // The decision reads three words of the view's parameters; each form then takes its own copy of the block, so that
+    // neither carries the scalar registers of the other's fields across the branch (merged naively, the batched
+    // instantiation ran out of scalar registers and came out ONE vector register over the 168 of three wavefronts per SIMD).
+    const CompParams *pp = BATCH ? &plist[batch_view(p_arg, bid, &grid)] : &p_arg;
+    if (poly_route(pp->sh_bound, pp->psx, pp->psy)) {
+      const CompParams p = *pp;
+      composite_bwd_sh_vec_tile<4, 4, true, kPolyNB>(p, bid, grid, sm.poly);
+    } else {
+      const CompParams p = *pp;
+      composite_bwd_sh_vec_tile<4, 4, true, 0>(p, bid, grid, sm.exact);
+    }
+  } else {
+    const CompParams p = BATCH ? plist[batch_view(p_arg, bid, &grid)] : p_arg;  // see k_composite_fwd
+    __shared__ BwdShVecShared<CB, PPL, CHRED, (NB > 0)> sm;
+    composite_bwd_sh_vec_tile<CB, PPL, CHRED, NB>(p, bid, grid, sm);
   }
 }
 
@@ -1488,11 +1538,12 @@ static int launch_fwd(const CompParams &p_, hipStream_t s) {
     }
   }
   if constexpr (MODE == MODE_SH && CB == 4) {
-    // with the coefficient bound: the polynomial-basis kernel in front of the exact one; each workgroup of either reads
-    // the bound and exactly one of the two renders the frame (poly_route)
+    // with the coefficient bound: ONE launch of the routed kernel -- every workgroup reads the bound and runs the polynomial
+    // form of the per-pixel basis where its error bound holds, the exact form elsewhere (poly_route)
     if (p.sh_bound != nullptr) {
-      if (variants().ppl_fwd_poly == 4) hipLaunchKernelGGL((k_composite_fwd_sh_vec<4, 4, false, kPolyNB>), dim3(nblk), dim3(64), 0, s, p, (const CompParams *)nullptr);
-      else hipLaunchKernelGGL((k_composite_fwd_sh_vec<4, 2, false, kPolyNB>), dim3(nblk), dim3(128), 0, s, p, (const CompParams *)nullptr);
+      if (variants().ppl_fwd_poly == 4) hipLaunchKernelGGL((k_composite_fwd_sh_vec<4, 4, false, kRouted>), dim3(nblk), dim3(64), 0, s, p, (const CompParams *)nullptr);
+      else hipLaunchKernelGGL((k_composite_fwd_sh_vec<4, 2, false, kRouted>), dim3(nblk), dim3(128), 0, s, p, (const CompParams *)nullptr);
+      return (int)hipGetLastError();
     }
   } else {
     p.sh_bound = nullptr;
@@ -1528,8 +1579,10 @@ static int launch_bwd(const CompParams &p_, hipStream_t s) {
   }
   const uint32_t ng = nblk * (uint32_t)((MODE == MODE_SH && p.nseg > 1) ? p.nseg : 1);
   if constexpr (MODE == MODE_SH && CB == 4) {
-    if (p.sh_bound != nullptr)  // as the forward: the polynomial-basis kernel in front of the exact one, routed on the device
-      hipLaunchKernelGGL((k_composite_bwd_sh_vec<4, 4, false, true, kPolyNB>), dim3(ng), dim3(64), 0, s, p, (const CompParams *)nullptr);
+    if (p.sh_bound != nullptr) {  // as the forward: one launch, routed on the device
+      hipLaunchKernelGGL((k_composite_bwd_sh_vec<4, 4, false, true, kRouted>), dim3(ng), dim3(64), 0, s, p, (const CompParams *)nullptr);
+      return (int)hipGetLastError();
+    }
   } else {
     p.sh_bound = nullptr;
   }
@@ -1574,13 +1627,13 @@ static void launch_fwd_sh_batch_c(const CompParams &p0, const CompParams *plist,
   const int ppl = variants().ppl_fwd_batch;  // wavefronts per tile = 4 / ppl
   const dim3 g(nblk * B);
   if constexpr (CB == 4) {
-    // The views carry the device address of the coefficient bound: the polynomial-basis kernel is enqueued in front of the
-    // exact one over the same grid, and every workgroup of either decides from the bound and ITS view's pixel size which
-    // of the two renders the view (poly_route; forward and backward read the same value, hence agree).  The kernel that
-    // does not take a view leaves after two scalar loads.
+    // The views carry the device address of the coefficient bound: ONE launch of the routed kernel, in which every
+    // workgroup decides from the bound and ITS view's pixel size whether it runs the polynomial or the exact form
+    // (poly_route; forward and backward read the same value, hence agree).
     if (bounded) {
-      if (ppl == 4) hipLaunchKernelGGL((k_composite_fwd_sh_vec<4, 4, true, kPolyNB>), g, dim3(64), 0, s, p0, plist);
-      else hipLaunchKernelGGL((k_composite_fwd_sh_vec<4, 2, true, kPolyNB>), g, dim3(128), 0, s, p0, plist);
+      if (ppl == 4) hipLaunchKernelGGL((k_composite_fwd_sh_vec<4, 4, true, kRouted>), g, dim3(64), 0, s, p0, plist);
+      else hipLaunchKernelGGL((k_composite_fwd_sh_vec<4, 2, true, kRouted>), g, dim3(128), 0, s, p0, plist);
+      return;
     }
   }
   if (variants().sh_packed && ppl != 1) {
@@ -1618,8 +1671,10 @@ template <int CB>
 static void launch_bwd_sh_batch_c(const CompParams &p0, const CompParams *plist, uint32_t B, uint32_t nblk, hipStream_t s, bool bounded) {
   const dim3 g(nblk * B);
   if constexpr (CB == 4) {
-    if (bounded)  // as the forward: both kernels, routed per view on the device
-      hipLaunchKernelGGL((k_composite_bwd_sh_vec<4, 4, true, true, kPolyNB>), g, dim3(64), 0, s, p0, plist);
+    if (bounded) {  // as the forward: one launch, routed per view on the device
+      hipLaunchKernelGGL((k_composite_bwd_sh_vec<4, 4, true, true, kRouted>), g, dim3(64), 0, s, p0, plist);
+      return;
+    }
   }
   const int ppl = variants().ppl_bwd_sh_batch;
   if (variants().sh_packed && ppl != 1) {
@@ -1755,18 +1810,18 @@ int gsgen_kernel_variant(const char *stage, uint32_t C, uint32_t n_segments, cha
   const std::string st(stage);
   char buf[160];
   int n = 0;
-  // "<stage>_poly": the polynomial-basis kernel of a bounded enqueue (SH degree 3), which renders the views whose error
-  // bound holds; "<stage>": the exact kernel (the only one without a bound, the other views' with one)
+  // "<stage>_poly": the routed kernel of a bounded enqueue (SH degree 3): polynomial form of the per-pixel basis for the views
+  // whose error bound holds, exact form for the others; "<stage>": the exact kernel of an enqueue without a bound
   const bool poly_stage = st.size() > 5 && st.compare(st.size() - 5, 5, "_poly") == 0;
   const std::string base = poly_stage ? st.substr(0, st.size() - 5) : st;
   auto sh_bwd = [&](int ppl, const char *b) {
-    if (poly_stage && C == 4) return snprintf(buf, sizeof buf, "k_composite_bwd_sh_vec<C=4,PPL=4%s,CHRED,POLY6>%s", b, n_segments > 1 ? " segmented" : "");
+    if (poly_stage && C == 4) return snprintf(buf, sizeof buf, "k_composite_bwd_sh_vec<C=4,PPL=4%s,CHRED,ROUTED:POLY6|exact>%s", b, n_segments > 1 ? " segmented" : "");
     return snprintf(buf, sizeof buf, "%s<%sC=%u,PPL=%d%s%s>%s", (v.sh_packed && ppl != 1) ? "k_composite_bwd_sh_vec" : "k_composite_bwd_pixel",
                     (v.sh_packed && ppl != 1) ? "" : "SH,", C, ppl, b, (v.sh_packed && ppl == 4 && v.sh_chred) ? ",CHRED" : "",
                     n_segments > 1 ? " segmented" : "");
   };
   auto sh_fwd = [&](int ppl, int ppl_poly, const char *b) {
-    if (poly_stage && C == 4) return snprintf(buf, sizeof buf, "k_composite_fwd_sh_vec<C=4,PPL=%d%s,POLY6>", ppl_poly == 4 ? 4 : 2, b);
+    if (poly_stage && C == 4) return snprintf(buf, sizeof buf, "k_composite_fwd_sh_vec<C=4,PPL=%d%s,ROUTED:POLY6|exact>", ppl_poly == 4 ? 4 : 2, b);
     if (v.sh_packed && ppl != 1) return snprintf(buf, sizeof buf, "k_composite_fwd_sh_vec<C=%u,PPL=%d%s>", C, ppl, b);
     return snprintf(buf, sizeof buf, "k_composite_fwd<SH,C=%u,PPL=%d%s>", C, ppl, b);
   };
@@ -1947,49 +2002,73 @@ static int fill_view_params(uint32_t n_views, const gsgen_sh_view *views, const 
 }  // extern "C"
 
 // S = max over splats and channels of sum_{k >= 1} |sh[i][c][k]| (non-negative floats order like their bit patterns, so the
-// maximum is an unsigned atomicMax).  SH degree 3: one float4 per thread, perfectly coalesced -- four lanes share a row of 16
-// coefficients, the first of them drops the constant term.  CHECK: counts the rows whose sum EXCEEDS *bound instead (the
+// maximum is an unsigned atomicMax).  SH degree 3: one float4 per thread and iteration, perfectly coalesced -- four lanes share
+// a row of 16 coefficients, the first of them drops the constant term.  A FEW HUNDRED workgroups stride over the array and each
+// ends with at most one atomic: atomics of every wavefront on the one result word serialise in the memory system (18 750 of them
+// made this pass 214 us for 100 k splats; it is a 19 MB read).  CHECK: counts the rows whose sum EXCEEDS *bound instead (the
 // debug verification of a bound some other pass produced).  NaN coefficients read as "no bound" (3e38 never passes poly_ok).
+constexpr uint32_t kBoundBlocks = 512;
 template <bool CHECK>
-__global__ void __launch_bounds__(256) k_sh_l1_rows16(uint32_t n_quads, const float4 *__restrict__ sh, float *out, const float *bound,
-                                                       uint32_t *n_bad) {
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  float v = 0.0f;
-  if (i < n_quads) {
-    const float4 q = sh[i];
-    v = ((i & 3u) ? fabsf(q.x) : 0.0f) + fabsf(q.y) + fabsf(q.z) + fabsf(q.w);
-  }
-  v += __shfl_xor(v, 1);
-  v += __shfl_xor(v, 2);  // every lane of a row's four now holds the row's sum
-  if (!(v == v)) v = 3.0e38f;
+__device__ __forceinline__ void sh_l1_finish(float v, uint32_t bad, float *out, uint32_t *n_bad) {
+  __shared__ float s_max[4];
+  __shared__ uint32_t s_bad[4];
+  const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
   if constexpr (CHECK) {
-    const unsigned long long bad = __ballot(i < n_quads && (i & 3u) == 0u && v > bound[0]);
-    if ((threadIdx.x & 63) == 0 && bad != 0ull) atomicAdd(n_bad, (uint32_t)__popcll(bad));
-  } else {
 #pragma unroll
-    for (int d = 32; d >= 4; d >>= 1) v = fmaxf(v, __shfl_xor(v, d));
-    if ((threadIdx.x & 63) == 0 && v > 0.0f) atomicMax(reinterpret_cast<unsigned int *>(out), __float_as_uint(v));
-  }
-}
-// any SH degree: one row of CC coefficients per thread
-template <bool CHECK>
-__global__ void __launch_bounds__(256) k_sh_l1_rows(uint32_t n_rows, const float *__restrict__ sh, int CC, float *out, const float *bound,
-                                                     uint32_t *n_bad) {
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  float v = 0.0f;
-  if (i < n_rows) {
-    const float *q = sh + (size_t)i * CC;
-    for (int k = 1; k < CC; ++k) v += fabsf(q[k]);
-    if (!(v == v)) v = 3.0e38f;
-  }
-  if constexpr (CHECK) {
-    const unsigned long long bad = __ballot(i < n_rows && v > bound[0]);
-    if ((threadIdx.x & 63) == 0 && bad != 0ull) atomicAdd(n_bad, (uint32_t)__popcll(bad));
+    for (int d = 32; d >= 1; d >>= 1) bad += (uint32_t)__shfl_xor((int)bad, d);
+    if (lane == 0) s_bad[wave] = bad;
   } else {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d));
-    if ((threadIdx.x & 63) == 0 && v > 0.0f) atomicMax(reinterpret_cast<unsigned int *>(out), __float_as_uint(v));
+    if (lane == 0) s_max[wave] = v;
   }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if constexpr (CHECK) {
+      const uint32_t t = s_bad[0] + s_bad[1] + s_bad[2] + s_bad[3];
+      if (t != 0u) atomicAdd(n_bad, t);
+    } else {
+      const float m = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+      // (a plain look first: once a large value is in, most workgroups have nothing to add)
+      if (m > 0.0f && m > *reinterpret_cast<volatile float *>(out)) atomicMax(reinterpret_cast<unsigned int *>(out), __float_as_uint(m));
+    }
+  }
+}
+template <bool CHECK>
+__global__ void __launch_bounds__(256) k_sh_l1_rows16(uint32_t n_quads, const float4 *__restrict__ sh, float *out, const float *bound,
+                                                       uint32_t *n_bad) {
+  float vmax = 0.0f;
+  uint32_t bad = 0;
+  const float lim = CHECK ? bound[0] : 0.0f;
+  // (n_quads is a multiple of 4 and the stride a multiple of 256: the four lanes of a row stay together)
+  for (uint32_t base = blockIdx.x * 256u; base < n_quads; base += gridDim.x * 256u) {  // (uniform trip count: shuffles inside)
+    const uint32_t i = base + threadIdx.x;
+    const float4 q = i < n_quads ? sh[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float v = ((i & 3u) ? fabsf(q.x) : 0.0f) + fabsf(q.y) + fabsf(q.z) + fabsf(q.w);
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);  // every lane of a row's four now holds the row's sum
+    if (!(v == v)) v = 3.0e38f;
+    if constexpr (CHECK) bad += (i < n_quads && (i & 3u) == 0u && v > lim) ? 1u : 0u;
+    else vmax = fmaxf(vmax, v);
+  }
+  sh_l1_finish<CHECK>(vmax, bad, out, n_bad);
+}
+// any SH degree: one row of CC coefficients per thread and iteration
+template <bool CHECK>
+__global__ void __launch_bounds__(256) k_sh_l1_rows(uint32_t n_rows, const float *__restrict__ sh, int CC, float *out, const float *bound,
+                                                     uint32_t *n_bad) {
+  float vmax = 0.0f;
+  uint32_t bad = 0;
+  const float lim = CHECK ? bound[0] : 0.0f;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_rows; i += gridDim.x * 256u) {
+    const float *q = sh + (size_t)i * CC;
+    float v = 0.0f;
+    for (int k = 1; k < CC; ++k) v += fabsf(q[k]);
+    if (!(v == v)) v = 3.0e38f;
+    if constexpr (CHECK) bad += (v > lim) ? 1u : 0u;
+    else vmax = fmaxf(vmax, v);
+  }
+  sh_l1_finish<CHECK>(vmax, bad, out, n_bad);
 }
 
 template <bool CHECK>
@@ -2002,11 +2081,13 @@ static int sh_l1_pass(uint32_t N, const float *sh_coeffs, uint32_t C, float *out
   const uint32_t rows = 3u * N;
   if (C == 4 && (reinterpret_cast<uintptr_t>(sh_coeffs) & 15u) == 0) {
     const uint32_t quads = 4u * rows;
-    hipLaunchKernelGGL((k_sh_l1_rows16<CHECK>), dim3((quads + 255u) / 256u), dim3(256), 0, s, quads,
+    const uint32_t nb = (quads + 255u) / 256u;
+    hipLaunchKernelGGL((k_sh_l1_rows16<CHECK>), dim3(nb < kBoundBlocks ? nb : kBoundBlocks), dim3(256), 0, s, quads,
                        reinterpret_cast<const float4 *>(sh_coeffs), out, bound, n_bad);
   } else {
-    hipLaunchKernelGGL((k_sh_l1_rows<CHECK>), dim3((rows + 255u) / 256u), dim3(256), 0, s, rows, sh_coeffs, (int)(C * C), out,
-                       bound, n_bad);
+    const uint32_t nb = (rows + 255u) / 256u;
+    hipLaunchKernelGGL((k_sh_l1_rows<CHECK>), dim3(nb < kBoundBlocks ? nb : kBoundBlocks), dim3(256), 0, s, rows, sh_coeffs, (int)(C * C),
+                       out, bound, n_bad);
   }
   return (int)hipGetLastError();
 }

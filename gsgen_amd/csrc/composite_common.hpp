@@ -34,8 +34,8 @@ struct CompParams {
   // MODE_RGBD backward with grad_out == NULL: the four head gradients as autograd delivers them (any may be NULL = 0)
   const float *go_rgb, *go_d, *go_o, *go_z2;  // [H,W,3], [H,W], [H,W], [H,W]
   // SH degree 3: DEVICE pointer to the coefficient bound S of the scene (gsgen_sh_l1_bound), or NULL.  With a bound the
-  // host enqueues the polynomial-basis kernel AND the exact one for the same grid; every workgroup reads S and its view's
-  // pixel size, and exactly one of the two kernels renders the view (poly_route) -- no host decision, no host sync.
+  // host enqueues the ROUTED kernel (composite.hip, kRouted): every workgroup reads S and its view's pixel size and runs the
+  // polynomial form of the per-pixel basis or the exact one (poly_route) -- no host decision, no host sync.
   const float *sh_bound;
 };
 constexpr int kSegLen = 32;
@@ -314,7 +314,7 @@ __device__ __forceinline__ v2f gauss_chol_pair(float p0x, float p1, float p2, v2
 // are 6 terms instead of 16, 3 x 6 instead of 3 x 16 gradient components cross the lanes and are expanded by V in front of
 // the atomics.  It renders a view only where the bound 0.25 * S * 0.7 * delta^3 (S: the scene's largest per-splat sum of
 // |non-constant SH coefficients| of one channel, measured on the device per step; delta: the tile's half diagonal in camera
-// space) stays below 1e-5 -- decided on the device by every workgroup (poly_route), the exact kernel takes the other views.
+// space) stays below 1e-5 -- decided on the device by every workgroup (poly_route), which runs the exact form otherwise.
 constexpr int kPolyNB = 6;
 constexpr int kPolyNodes = 9;
 // colour error of the degree-2 form <= 0.25 (sigmoid slope) x S x 0.7 delta^3, delta = half diagonal of a tile in camera
@@ -325,9 +325,9 @@ __host__ __device__ __forceinline__ bool poly_ok(float S, float ps_max) {
   const float delta = 7.5f * 1.41421356f * ps_max;
   return 0.25f * S * 0.7f * delta * delta * delta <= 1e-5f;
 }
-// does the polynomial-basis kernel render this view?  (uniform over the workgroup: one scalar load)
-__device__ __forceinline__ bool poly_route(const CompParams &p) {
-  return p.sh_bound != nullptr && poly_ok(p.sh_bound[0], fmaxf(fabsf(p.psx), fabsf(p.psy)));
+// does the polynomial form render this view?  (uniform over the workgroup: one scalar load)
+__device__ __forceinline__ bool poly_route(const float *sh_bound, float psx, float psy) {
+  return sh_bound != nullptr && poly_ok(sh_bound[0], fmaxf(fabsf(psx), fabsf(psy)));
 }
 constexpr float kPolyFit[kPolyNB][kPolyNodes] = {
     {-0.111111111f, 0.222222222f, -0.111111111f, 0.222222222f, 0.555555556f, 0.222222222f, -0.111111111f, 0.222222222f, -0.111111111f},

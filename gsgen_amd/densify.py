@@ -201,7 +201,10 @@ class AdaptiveControl:
         dens, prun = self.due(step)  # trainer.py calls densify() then prune() every step
         if not (dens or prun):
             return opt, stats, False
-        gdist.allreduce_densify_stats(stats, self.group)
+        # the ranks' statistics combined into temporaries the decisions read; `stats` keeps this rank's own rows, which
+        # is what a prune-only step carries over (summing in place would count this interval world_size times at the next
+        # densify step)
+        g_maxr, g_accum, g_cnt = gdist.reduce_densify_stats(stats, self.group, with_sums=dens)
         for k in ("mean", "qvec", "svec", "alpha"):
             if k not in opt.params:
                 raise KeyError(f"AdaptiveControl needs the raw field {k!r} in the optimiser")
@@ -209,16 +212,16 @@ class AdaptiveControl:
         moments = {k: opt.moments(k) for k in opt.names}
         dev = raw["mean"].device
         info = {}
-        maxr = stats.max_radii2d
+        maxr = g_maxr
         if dens:
             gen = generator if generator is not None else (None if self.use_global_rng else self._generator(step, dev))
             d = self.densify_cfg
             if d.type == "legacy":
-                raw, info = densify_legacy(raw, self.svec_act(raw["svec"]), self.svec_inv_act, stats.grad_accum, stats.cnt, d, gen)
+                raw, info = densify_legacy(raw, self.svec_act(raw["svec"]), self.svec_inv_act, g_accum, g_cnt, d, gen)
                 moments = None  # set_optimizer(): the optimiser starts afresh (:935)
             elif d.type == "official":
                 raw, moments, info = densify_official(raw, moments, {"svec": self.svec_act, "svec_inv": self.svec_inv_act},
-                                                      stats.grad_accum, stats.cnt, d, gen)
+                                                      g_accum, g_cnt, d, gen)
             else:
                 raise NotImplementedError(f"densify type {d.type!r}")
             maxr = torch.zeros(raw["mean"].shape[0], device=dev)  # reset_densify_info (:476-479, :817)
@@ -234,8 +237,8 @@ class AdaptiveControl:
         if moments is not None:
             new_opt.load_moments(moments, opt.step_count)
         new_stats = DensifyStats(n, dev)
-        if prun and not dens:  # prune_by_mask keeps the surviving rows' statistics (:533-549)
-            new_stats.max_radii2d.copy_(maxr)
+        if prun and not dens:  # prune_by_mask keeps the surviving rows' statistics (:533-549): the job-wide maximum (a
+            new_stats.max_radii2d.copy_(maxr)  # maximum may be taken twice) and THIS RANK'S gradient sums and counts
             new_stats.grad_accum.copy_(stats.grad_accum[keep]); new_stats.cnt.copy_(stats.cnt[keep])
         elif prun:
             new_stats.max_radii2d.copy_(maxr)

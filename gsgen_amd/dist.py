@@ -29,8 +29,12 @@ def shard_sizes(n_items, world):
 
 class _AllGatherImages(torch.autograd.Function):
     """all_gather_into_tensor whose backward hands every rank the gradient of ITS OWN shard (each rank evaluates the
-    loss on the gathered batch; the other shards' gradients belong to the ranks that rendered them) -- so a loss on the
-    gathered batch trains exactly as it does at world size 1, where `local` itself is returned."""
+    loss on the gathered batch; the other shards' gradients belong to the ranks that rendered them).  Each rank's
+    parameter gradient is then ITS cameras' share of d loss / d theta, and the shares SUM to the world-size-1 gradient:
+    pair this with allreduce_gradients(..., average=False) / FusedAdam.all_reduce_grad(average=False).  (average=True is
+    for the other data-parallel form -- every rank a loss on its own images only, the job's loss their mean; with a
+    loss on the gathered batch it would hand back the gradient divided by the world size.  torch.distributed.nn.all_gather
+    differs again: it reduce-scatters the gradients of every rank's copy of the loss.)"""
 
     @staticmethod
     def forward(ctx, send, group):
@@ -50,7 +54,8 @@ def gather_images(local, n_total, group=None):
 
     local: [b_local, H, W, C] tensor of this rank's rendered cameras (b_local from shard_bounds).
     Returns [n_total, H, W, C] on every rank, in camera order; gradients of a loss on the result flow back to this
-    rank's own `local` (as they do at world size 1).  Uneven shards are padded to the
+    rank's own `local` (as they do at world size 1) -- SUM the parameter gradients over the ranks afterwards
+    (allreduce_gradients(average=False)), see _AllGatherImages.  Uneven shards are padded to the
     largest shard so that a single all_gather_into_tensor moves everything (one collective per
     batch; on MI355X a direct all-gather uses all 7 xGMI links of a GPU at once)."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
@@ -109,7 +114,10 @@ def allreduce_gradients(tensors, group=None, average=True):
     and back-propagated its own cameras, the replicated parameters' gradients are summed (or
     averaged) with ONE bucketed all_reduce -- all gradient tensors are packed into a single flat
     buffer (24 MB for 100 k Gaussians at SH degree 3; on MI355X a reduce-scatter + all-gather over
-    the 7 direct xGMI links moves that in tens of microseconds) and unpacked in place."""
+    the 7 direct xGMI links moves that in tens of microseconds) and unpacked in place.
+    average=True: every rank back-propagated a loss on ITS OWN images and the job's loss is their mean.
+    average=False: every rank back-propagated the SAME loss on the gathered batch (gather_images): the ranks hold the
+    shares of one gradient, which add up."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return tensors
     grads = [t for t in tensors if t is not None]
@@ -127,6 +135,23 @@ def allreduce_gradients(tensors, group=None, average=True):
     return tensors
 
 
+def reduce_densify_stats(stats, group=None, with_sums=True):
+    """-> (max_radii2d, grad_accum, cnt) combined over the ranks as TEMPORARIES; `stats` itself keeps this rank's own rows.
+    This is what AdaptiveControl decides on.  Reducing in place would be wrong whenever the statistics survive the step:
+    a prune-only step carries grad_accum / cnt over to the next interval, and rows that already hold the cross-rank sum
+    would be summed over the ranks AGAIN at the next densify step (counted world_size times).  with_sums=False (a
+    prune-only step never reads the gradient sums): only the MAX of max_radii2d travels."""
+    maxr = stats.max_radii2d.clone()
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return maxr, stats.grad_accum, stats.cnt
+    dist.all_reduce(maxr, op=dist.ReduceOp.MAX, group=group)
+    if not with_sums:
+        return maxr, stats.grad_accum, stats.cnt
+    both = torch.stack([stats.grad_accum, stats.cnt], 0)
+    dist.all_reduce(both, op=dist.ReduceOp.SUM, group=group)
+    return maxr, both[0], both[1]
+
+
 def allreduce_densify_stats(stats, group=None):
     """Camera sharding and the densify / prune policy (gs/gaussian_splatting.py:551-628, :1124-1132): every rank has
     accumulated the statistics of ITS cameras only (renderer.DensifyStats: max_radii2d, mean-2d-gradient sum, visit
@@ -135,7 +160,9 @@ def allreduce_densify_stats(stats, group=None):
     them: MAX for max_radii2d, SUM for the gradient sum and the count (fp32 sums in rank order: every rank receives
     the same bits, RCCL reduces deterministically for a fixed algorithm).  Two collectives on 3 N floats; a no-op
     without a process group.  With identical statistics, identical (seeded) RNG state and identical parameters the
-    reference's densify_by_split / densify_by_clone / prune produce identical clouds on every rank."""
+    reference's densify_by_split / densify_by_clone / prune produce identical clouds on every rank.
+    IN PLACE: only correct when the statistics are reset right afterwards (a densify step); AdaptiveControl uses
+    reduce_densify_stats (temporaries) for that reason."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return stats
     dist.all_reduce(stats.max_radii2d, op=dist.ReduceOp.MAX, group=group)

@@ -62,7 +62,9 @@ class FusedAdam:
         self.step_count = int(step_count)
 
     def all_reduce_grad(self, group=None, average=True):
-        """one collective for all fields (no-op without an initialised process group)"""
+        """one collective for all fields (no-op without an initialised process group).  average=True for per-rank losses whose
+        mean is the job's loss; average=False when every rank back-propagated one loss on the gathered batch
+        (dist.gather_images: the ranks hold shares of ONE gradient, which add up -- see dist.allreduce_gradients)."""
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)

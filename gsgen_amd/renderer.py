@@ -244,6 +244,56 @@ def pair_count(v):
     return n
 
 
+class PairCountMonitor:
+    """Overflow detection without a host sync that cannot lose a frame.  Every geometry enqueue is followed by an
+    asynchronous copy of its pair counts into a pinned host block of its own plus an event; `drain()` looks at every block
+    whose event has completed and returns the counts.  The blocks form a ring of `depth` entries: a loop in which the host
+    stays ahead of the GPU (the intended regime) never finds the LATEST event complete -- a single slot that each frame
+    overwrote would never be read and an overflowing scene would render as background for ever -- so when the ring is full
+    the oldest entry is waited for (it is `depth` frames old: the wait is short, and an overflow is reported within `depth`
+    frames at the latest)."""
+
+    def __init__(self, n, depth=4):
+        import collections
+        self.n, self.depth = int(n), int(depth)
+        self._free = [torch.zeros(self.n, dtype=torch.int32).pin_memory() for _ in range(self.depth)]
+        self._pending = collections.deque()
+        self._ready = []
+
+    def _collect(self):
+        while self._pending and self._pending[0][0].query():
+            ev, host, count = self._pending.popleft()
+            self._ready.append([pair_count(host[i]) for i in range(count)])
+            self._free.append(host)
+
+    def record(self, totals, count, stream):
+        """behind the geometry enqueue on `stream`: totals[:count] (device int32) travel to the host"""
+        if torch.cuda.is_current_stream_capturing():  # an event recorded under capture cannot be queried afterwards:
+            return                                    # size the buffers (ensure_capacity) before capturing
+        if not self._free:  # ring full: wait for the oldest entry (it is `depth` frames old)
+            self._pending[0][0].synchronize()
+            self._collect()
+        host = self._free.pop()
+        with torch.cuda.stream(stream):
+            host[:count].copy_(totals[:count], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(stream)
+        self._pending.append((ev, host, int(count)))
+
+    def drain(self):
+        """-> the counts (python ints, uint32 semantics), oldest first, of every frame / batch whose copy has arrived"""
+        if not torch.cuda.is_current_stream_capturing():  # (no event queries under capture)
+            self._collect()
+        out, self._ready = self._ready, []
+        return out
+
+    def clear(self):
+        """after a synchronous check (ensure_capacity): nothing pending is of interest any more"""
+        while self._pending:
+            self._free.append(self._pending.popleft()[1])
+        self._ready = []
+
+
 class FrameBuffers:
     """Device buffers of the fused path for one (N, W, H) shape.  D_cap is the capacity of the
     (tile, Gaussian) pair list; `ensure_capacity()` grows it after an overflow."""
@@ -273,13 +323,11 @@ class FrameBuffers:
         self.total = total if total is not None else torch.zeros(1, device=device, dtype=torch.int32)
         self.D_cap = 0
         # `generation` counts the forwards that rewrote these buffers (and regrowths): a backward whose forward is no
-        # longer the latest user raises instead of reading another frame's lists.  `_total_host` / `_total_event`: the
-        # pair count of the last frame travels to pinned host memory behind the frame (no sync); the next forward
-        # looks at it when it has arrived and regrows + warns after an overflow (a frame whose pair list overflowed
-        # is rendered as background only).
+        # longer the latest user raises instead of reading another frame's lists.  `_monitor`: the pair count of every
+        # frame travels to pinned host memory behind the frame (no sync); the next forwards look at what has arrived and
+        # regrow + warn after an overflow (a frame whose pair list overflowed is rendered as background only).
         self.generation = 0
-        self._total_host = torch.zeros(1, dtype=torch.int32).pin_memory()
-        self._total_event = None
+        self._monitor = PairCountMonitor(1) if total is None else None  # (BatchRenderer monitors its slots itself)
         self._alloc_pairs(D_cap if D_cap else max(16 * N, 1 << 16))
 
     def _alloc_pairs(self, D_cap):
@@ -296,7 +344,8 @@ class FrameBuffers:
     def ensure_capacity(self):
         """Host-side check (one sync): did the last frame fit?  Grows the pair buffers if not (False: that frame was
         rendered as background only -- render it again)."""
-        self._total_event = None
+        if self._monitor is not None:
+            self._monitor.clear()
         need = pair_count(self.total.item())
         if need > self.D_cap:
             self._alloc_pairs(int(need * 1.25) + 1024)
@@ -312,28 +361,21 @@ class FrameBuffers:
     def end_frame(self, stream=None):
         """after the geometry enqueue: the frame's pair count follows it to the host, asynchronously"""
         st = stream if stream is not None else torch.cuda.current_stream(self.device)
-        if torch.cuda.is_current_stream_capturing():  # see BatchRenderer._end_batch
-            self._total_event = None
-            return
-        with torch.cuda.stream(st):
-            self._total_host.copy_(self.total, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(st)
-        self._total_event = ev
+        if self._monitor is not None:
+            self._monitor.record(self.total, 1, st)
 
     def check_overflow(self):
-        """No sync: if the previous frame's pair count has reached the host and exceeded the capacity, grow the
-        buffers and warn (that frame showed background only, with zero gradients).  Returns False in that case."""
-        ev = self._total_event
-        if ev is None or torch.cuda.is_current_stream_capturing() or not ev.query():
+        """No sync (unless the host is more than PairCountMonitor.depth frames ahead): if the pair count of an earlier frame
+        has reached the host and exceeded the capacity, grow the buffers and warn (that frame showed background only, with
+        zero gradients).  Returns False in that case."""
+        if self._monitor is None:
             return True
-        self._total_event = None
-        need = pair_count(self._total_host.item())
+        need = max([c[0] for c in self._monitor.drain()], default=0)
         if need > self.D_cap:
             import warnings
             old = self.D_cap
             self._alloc_pairs(int(need * 1.25) + 1024)
-            warnings.warn(f"gsgen_amd: the previous frame through these buffers needed {need} (tile, Gaussian) pairs, "
+            warnings.warn(f"gsgen_amd: an earlier frame through these buffers needed {need} (tile, Gaussian) pairs, "
                           f"capacity was {old}: it was rendered as BACKGROUND ONLY with zero gradients.  The buffers "
                           f"have been regrown to {self.D_cap}; call FrameBuffers.ensure_capacity() after a render to "
                           f"catch this synchronously.", RuntimeWarning, stacklevel=3)

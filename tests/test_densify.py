@@ -226,6 +226,69 @@ def test_ranks_with_different_camera_shards_end_up_with_identical_clouds(dtype):
     assert same and changed and n != 600 and info["num_split"] > 0 and info["pruned"]["alpha"] > 0
 
 
+def _interval_stats(n, seed):
+    g = torch.Generator().manual_seed(seed)
+    vis = torch.rand(n, generator=g) < 0.6
+    cnt = vis.float() * torch.randint(1, 3, (n,), generator=g).float()
+    return cnt * torch.rand(n, generator=g) * 0.05, cnt, vis.float() * torch.rand(n, generator=g) * 2.0
+
+
+def _prune_then_densify(world_ranks, group_rank=None):
+    """Two intervals: statistics of interval 1, a PRUNE-ONLY step (prune period 50, densify period 100), statistics of
+    interval 2 accumulated on top, then a densify step.  world_ranks: the ranks whose cameras this process renders (both
+    for the single process, [rank] in the 2-rank job)."""
+    n = 600
+    raw, mom, acc, cnt, maxr = _cloud(n, seed=4)
+    opt = FusedAdam({k: raw[k] for k in FIELDS}, {k: 1e-3 for k in FIELDS})
+    opt.load_moments(mom, 5)
+    st = DensifyStats(n, torch.device("cpu"))
+    ctl = DN.AdaptiveControl(DN.DensifyConfig(type="official", warm_up=0, end=10 ** 6, period=100),
+                             DN.PruneConfig(enabled=True, warm_up=0, end=10 ** 6, period=50, radii2d_thresh=1000.0, alpha_thresh=0.1), seed=3)
+    assert ctl.due(150) == (False, True) and ctl.due(200) == (True, True)
+    for r in world_ranks:  # interval 1
+        a_, c_, m_ = _interval_stats(n, 100 + r)
+        st.grad_accum += a_; st.cnt += c_; st.max_radii2d.copy_(torch.maximum(st.max_radii2d, m_))
+    opt, st, changed = ctl.step(150, opt, st)  # prune only: the surviving rows keep their statistics
+    n1 = opt.params["mean"].shape[0]
+    assert changed and n1 < n
+    for r in world_ranks:  # interval 2, on the pruned cloud
+        a_, c_, m_ = _interval_stats(n1, 200 + r)
+        st.grad_accum += a_; st.cnt += c_; st.max_radii2d.copy_(torch.maximum(st.max_radii2d, m_))
+    opt, st, changed = ctl.step(200, opt, st)
+    return torch.cat([opt.flat, opt.exp_avg, opt.exp_avg_sq]), dict(ctl.last_info), n1
+
+
+def _worker_prune_only(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    flat, info, n1 = _prune_then_densify([rank])
+    q.put((rank, flat, info, n1))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_prune_only_step_does_not_count_an_interval_twice_across_ranks():
+    """the statistics used to be all-reduced IN PLACE at every due step; after a prune-only step the rows carried
+    over held the cross-rank sum and were summed over the ranks again at the next densify step.  Two ranks with different
+    camera shards must end exactly where ONE process that rendered both shards ends (sums of two fp32 numbers commute)."""
+    want, want_info, want_n1 = _prune_then_densify([0, 1])
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_prune_only, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, flat, info, n1 in got:
+        assert n1 == want_n1 and info == want_info, (rank, info, want_info)
+        assert flat.shape == want.shape and torch.equal(flat, want), rank
+    assert want_info["num_split"] + want_info["num_clone"] > 0
+
+
 def test_sh_coefficients_and_other_per_gaussian_fields_ride_along():
     """the colour field may be SH coefficients [N,3,16] (and the optimiser may hold further per-Gaussian fields): they are
     payload -- copied for clones, repeated for split samples, pruned with their rows, Adam moments alike"""

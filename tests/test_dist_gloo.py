@@ -180,6 +180,51 @@ def test_gathered_batch_is_differentiable_wrt_the_local_shard():
         assert np.array_equal(grad, want), rank
 
 
+def _gather_allreduce_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_total = 5
+    lo, hi = D.shard_bounds(n_total, rank, world)
+    torch.manual_seed(0)
+    theta = torch.randn(7, requires_grad=True)          # the replicated parameters
+    basis = torch.randn(n_total, 4, 6, 3, 7)            # "rendering": image_i = basis_i . theta
+    target = torch.randn(n_total, 4, 6, 3)
+    local = basis[lo:hi] @ theta
+    gathered = D.gather_images(local, n_total)
+    ((gathered - target) ** 2).mean().backward()        # the SAME loss on every rank, on the whole batch
+    g_sum, g_avg = theta.grad.clone(), theta.grad.clone()
+    D.allreduce_gradients([g_sum], average=False)
+    D.allreduce_gradients([g_avg], average=True)
+    q.put((rank, g_sum.numpy(), g_avg.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gathered_loss_composes_with_a_summed_gradient_all_reduce():
+    """a loss on the gathered batch followed by allreduce_gradients(average=False) is the world-size-1 gradient
+    (every rank holds its cameras' share); the averaging form, meant for per-rank losses, would hand back 1 / world of it"""
+    torch.manual_seed(0)
+    theta = torch.randn(7, requires_grad=True)
+    basis = torch.randn(5, 4, 6, 3, 7)
+    target = torch.randn(5, 4, 6, 3)
+    (((basis @ theta) - target) ** 2).mean().backward()
+    want = theta.grad.numpy()
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_allreduce_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, g_sum, g_avg in got:
+        assert np.allclose(g_sum, want, rtol=1e-5, atol=1e-6), rank
+        assert np.allclose(g_avg * world, want, rtol=1e-5, atol=1e-6), rank
+
+
 def test_bench_camera_shards_partition_the_64_poses():
     """bench.py --gpus N (BASELINE configs[3]): the ranks' camera lists are the contiguous shards of ONE seeded set of
     64 poses -- disjoint, complete, in order; and the self-launch command starts N ranks on 127.0.0.1"""

@@ -751,6 +751,18 @@ def test_stale_backward_overflow_warning_and_background_gradient():
             warnings.simplefilter("error")
             torch.cuda.synchronize()
             R.render_frame(P["mean"], P["qvec"], P["svec"], P["alpha"], P["sh"], cis[0], cams[0].c2w, small, C=2)
+    # (2b) ADVICE r2: a loop that never synchronises (the host ahead of the GPU, the intended regime) still learns of the
+    # overflow within PairCountMonitor.depth frames: the counts wait in a ring and are never dropped unread
+    small2 = R.FrameBuffers(N, W, H, dev(), D_cap=64)
+    brs = BatchRenderer(N, W, H, dev(), max_batch=3, D_cap=64)
+    with torch.no_grad(), warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        for _ in range(small2._monitor.depth + 2):
+            R.render_frame(P["mean"], P["qvec"], P["svec"], P["alpha"], P["sh"], cis[0], cams[0].c2w, small2, C=2)
+            brs.render(P["mean"], P["qvec"], P["svec"], P["alpha"], P["sh"], cis, [c.c2w for c in cams], C=2)
+    msgs = [str(w.message) for w in rec]
+    assert any("these buffers" in m_ and "BACKGROUND ONLY" in m_ for m_ in msgs) and small2.D_cap > 64
+    assert any("earlier batch" in m_ for m_ in msgs) and all(s_.D_cap > 64 for s_ in brs.slots)
     # (3) background gradients: SH batch with an rgb triple, post-activation colours with a full background image, heads
     go = torch.randn(3, H, W, 3, device=dev())
     bg3 = torch.tensor([0.2, 0.4, 0.6], device=dev(), requires_grad=True)

@@ -76,7 +76,8 @@ def test_coefficients_moving_between_steps_keep_the_image_contract():
             out[basis] = (rgb.detach().cpu().numpy(), T.cpu().numpy(), g.cpu().numpy())
         d = float(np.abs(out["auto"][0] - out["exact"][0]).max())
         if step == 1:
-            assert d == 0.0 and np.array_equal(out["auto"][2], out["exact"][2])  # routed to the exact kernels: same bits
+            assert d == 0.0                                          # routed to the exact form: the same pixels, bit for bit
+            assert rel_err(out["auto"][2], out["exact"][2]) <= 2e-6  # (gradient sums differ by atomics order only)
         else:
             assert 0.0 < d <= 1e-5, (step, d)                                    # the polynomial kernels, fit error only
             assert rel_err(out["auto"][2], out["exact"][2]) <= 1e-4
@@ -184,7 +185,7 @@ def test_gs_sh_names_take_the_routed_kernels():
     compiled = gsgen_amd.compiled_gs()
     N, W, H, C = 20_000, 256, 192, 4
     sc = scenes.pointe_scene(N, seed=6, C=C)
-    for fx, expect_poly in ((300.0, True), (60.0, False)):
+    for fx, expect_poly in ((500.0, True), (60.0, False)):
         cam = scenes.Camera(W, H, fx=fx, c2w=scenes.orbit(2.5, 15.0, 60.0))
         g = scenes.oracle_geometry(sc, cam)
         m = g["mask"]

@@ -1,11 +1,11 @@
 """Run-to-run stability of the SH backward under load (-m gpu).
 
-The matrix-core backward (k_composite_bwd_sh_mfma) once produced timing-dependent garbage when
+A matrix-core form of the backward (removed in round 3) once produced timing-dependent garbage when
 several of its wavefronts shared a matrix core (profiles/r01_notes.md, "MFMA chain hazard"): a
 single launch over a few thousand tiles, or a few launches in flight on different streams, was
-enough to see per-Gaussian gradients move by percents between identical runs.  These tests pin
-that down for every SH degree: identical launches must agree to atomics-reordering noise, alone
-and with other cameras' launches in flight."""
+enough to see per-Gaussian gradients move by percents between identical runs.  The guard stays for
+the vector kernels that ship, for every SH degree: identical launches must agree to
+atomics-reordering noise, alone and with other cameras' launches in flight."""
 import numpy as np
 import pytest
 import torch
@@ -83,25 +83,3 @@ def test_sh_backward_unchanged_by_launches_in_flight(C):
     for _ in range(16):
         con = _backward_all(dev, lib, P, cams, C, N, W, H, streams)
         assert _worst(seq, con) < 5e-6
-
-
-def test_first_launches_of_a_fresh_process_agree():
-    """The residual form of the MFMA hazard (profiles/r01_notes.md, "first-launch hazard"): with the short software
-    waits the FIRST launches of a process came out wrong on some boxes while thousands of later ones agreed, so
-    a loop inside one process never saw it.  Three fresh processes, SH degree 0 (the build it showed on) and 3:
-    the first launch is the reference, the next 8 must agree with it."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
-    for i in range(3):
-        env = dict(os.environ)
-        if i == 2:
-            env["STRESS_BATCH"] = "3"  # the batched entry point (its own kernel instantiation), 3 cameras per launch
-        r = subprocess.run([sys.executable, os.path.join(root, "tools", "mfma_stress.py"), "8", "1", "4"], cwd=root,
-                           capture_output=True, text=True, timeout=300, env=env)
-        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("C=")]
-        assert len(lines) == 2, r.stdout
-        for ln in lines:
-            assert " bad 0/8 " in ln, ln

@@ -197,4 +197,6 @@ def test_compiled_module_agrees_with_the_ctypes_mirror_and_is_cheap_to_call(ext)
             torch.cuda.synchronize()
         cost[name] = best * 1e6
     print(f"host cost per tile_based_vol_rendering_sh call: compiled {cost['compiled']:.1f} us, ctypes {cost['ctypes']:.1f} us")
-    assert cost["compiled"] < 15.0, cost
+    # (at SH degree 3 a call is three enqueues: the 4-byte clear and the pass that measure the coefficient bound, then the
+    # routed compositing kernel)
+    assert cost["compiled"] < 20.0 and cost["compiled"] < cost["ctypes"], cost

@@ -3,7 +3,7 @@
 # prints / stores per-kernel averages per launch.  BENCH_ARGS adds bench.py arguments.
 tag=$1; shift; ctrs=$1; shift
 cd /tmp && export TMPDIR=/tmp
-env "$@" timeout 400 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$tag -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-latency --repeats 1 $BENCH_ARGS > $GRAFT_REPO_ROOT/gpurun_out/pmc_$tag.log 2>&1
+env "$@" timeout 400 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$tag -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 3 --only-timed --repeats 1 $BENCH_ARGS > $GRAFT_REPO_ROOT/gpurun_out/pmc_$tag.log 2>&1
 cd $GRAFT_REPO_ROOT
 python - <<PY
 import csv,glob,collections,json
@@ -12,7 +12,7 @@ if not f: print(open('gpurun_out/pmc_$tag.log').read()[-2000:]); raise SystemExi
 rows=list(csv.DictReader(open(f[0])))
 agg=collections.defaultdict(lambda: collections.defaultdict(float)); cnt=collections.Counter()
 for r in rows:
-    k=r['Kernel_Name'][:110]; agg[k][r['Counter_Name']]+=float(r['Counter_Value'])
+    k=r['Kernel_Name'][:140]; agg[k][r['Counter_Name']]+=float(r['Counter_Value'])
     if r['Counter_Name']==rows[0]['Counter_Name']: cnt[k]+=1
 out={}
 for k,v in agg.items():
