@@ -40,6 +40,7 @@ WORKLOADS = {
     "cfg3": "BASELINE configs[2]: 500k post-densify Gaussians, 1024x1024, SH degree 3, fwd+bwd",
     "cfg4": "BASELINE configs[3]: 100k Gaussians, 64 random-pose cameras at 512x512, camera-sharded",
     "cfg1": "BASELINE configs[0]: 1k random Gaussians, 256x256, SH degree 0",
+    "dry": "dry run of the multi-rank step loop: 300 random Gaussians, 64x48, SH degree 3 (no measurement)",
 }
 
 
@@ -53,6 +54,10 @@ def make_workload(name):
         return scenes.pointe_scene(100_000, seed=0, svec=0.02, C=4), 512, 512
     if name == "cfg1":
         return scenes.random_scene(1000, seed=0, C=1), 256, 256
+    if name == "dry":  # the multi-rank dry run (tests/test_dist_gloo.py): a few hundred splats, SH degree 3
+        sc = scenes.random_scene(60, seed=0, svec=0.006, spread=0.03, C=4)
+        sc["sh"][:, :, 1:] *= 0.3
+        return sc, 40, 24
     raise SystemExit(f"unknown config {name}")
 
 
@@ -73,9 +78,9 @@ def random_pose_cameras(n_total, rank, world, W, H, seed=0):
             for i in range(a, b)]
 
 
-def camera_poses(n, rank, W, H):
+def camera_poses(n, rank, W, H, zoom=1.0):
     import scenes
-    return [scenes.Camera(W, H, fx=float(W), c2w=scenes.orbit(2.5, 15.0, 30.0 + 45.0 * i + 7.0 * rank)) for i in range(n)]
+    return [scenes.Camera(W, H, fx=float(W) * zoom, c2w=scenes.orbit(2.5, 15.0, 30.0 + 45.0 * i + 7.0 * rank)) for i in range(n)]
 
 
 def b_alg_bytes(N, D, P, T, F):
@@ -126,9 +131,42 @@ def cpu_baseline(sc, cams, C, budget_s=20.0):
         el = time.perf_counter() - t0
         if el > budget_s * 0.6 or n >= 8:
             break
-    return {"value": n / el, "unit": "renders/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"{n} whole fwd+bwd renders of the bench workload through oracle/gs_oracle.c "
-                      f"(OpenMP, {os.cpu_count()} threads) in {el:.1f} s"}
+    res = {"value": n / el, "unit": "renders/s", "cores": os.cpu_count(), "kind": "port",
+           "sample": f"{n} whole fwd+bwd renders of the bench workload through oracle/gs_oracle.c "
+                     f"(OpenMP, {os.cpu_count()} threads) in {el:.1f} s"}
+    # the contributing-pair fraction of the run, counted by the checker on the first bench camera: (tile, list
+    # entry) pairs a one-wavefront-per-tile kernel walks (some pixel of the tile still alive), those in which some pixel's a*G
+    # reaches 1/255, and the contributing (pixel, entry) pairs behind them
+    cam = cams[0]
+    g = scenes.oracle_geometry(sc, cam)
+    m = g["mask"]
+    walked, contrib, pix = O.part_workstats(g["mean2d"], g["cov2d"], sc["alpha"][m], g["start"], g["end"], g["ids"], cam.topleft,
+                                            1 / cam.fx, 1 / cam.fy, cam.h, cam.w)
+    res["workstats"] = {"tile_pairs_D": int(g["D"]), "walked_tile_entries": walked, "walked_fraction_of_D": walked / max(1, g["D"]),
+                        "contributing_tile_entries": contrib, "contributing_fraction_of_walked": contrib / max(1, walked),
+                        "contributing_pixel_pairs": pix, "contributing_pixels_per_contributing_entry": pix / max(1, contrib),
+                        "evaluated_pixel_pairs_without_early_out": 256 * int(g["D"]),
+                        "E_actual_over_E": 256 * walked / max(1, 256 * int(g["D"]))}
+    # SURVEY 8(d) CPU baseline (1): the two stages the reference itself runs in PyTorch (gs/renderer.py:391-421,
+    # gs/culling.py:8-37), restated in oracle/torch_port.py (the reference tree does not exist on this box), on this box's cores
+    try:
+        import torch
+        from oracle import torch_port as TP
+        torch.set_num_threads(os.cpu_count() or 1)
+        mean, qvec, svec = (torch.from_numpy(sc[k][m]) for k in ("mean", "qvec", "svec"))
+        c2w = torch.from_numpy(cam.c2w)
+        ts = []
+        for _ in range(5):
+            t1 = time.perf_counter()
+            m2, c2, _, _ = TP.project_gaussians(mean, qvec, svec, c2w, True)
+            TP.tile_culling_aabb_count(m2, c2, 16, cam.fx, cam.fy, cam.cx, cam.cy, cam.w, cam.h, 6.0)
+            ts.append(time.perf_counter() - t1)
+        res["torch_cpu_projection_and_aabb_count"] = {
+            "ms_per_camera": float(np.median(ts)) * 1e3, "gaussians": int(m.sum()), "torch_threads": torch.get_num_threads(),
+            "kind": "port", "what": "project_gaussians + tile_culling_aabb_count in PyTorch on the CPU, forward only, median of 5"}
+    except Exception as e:  # the baseline is a report, never a reason for the bench line to be missing
+        res["torch_cpu_projection_and_aabb_count"] = {"error": str(e)[:200]}
+    return res
 
 
 def self_launch(n_gpus):
@@ -142,6 +180,47 @@ def self_launch(n_gpus):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd, env=env)
+
+
+class DryGpu:
+    """Stand-in for torch.cuda in the multi-rank DRY RUN (--dry-run-lib: a CPU build of the library's kernels, gloo instead of
+    RCCL): the step loop, its streams / events, the broadcasts, the per-step all_gather and the reductions of the report run
+    exactly as on GPUs, in order and in shape, with nothing asynchronous underneath.  Test infrastructure
+    (tests/test_dist_gloo.py starts two such ranks before the driver ever starts eight real ones); it measures nothing."""
+
+    class Stream:
+        cuda_stream = None
+
+        def __init__(self, *a, **k):
+            pass
+
+        def wait_event(self, e):
+            pass
+
+        def wait_stream(self, s):
+            pass
+
+    class Event:
+        def __init__(self, *a, **k):
+            pass
+
+        def record(self, stream=None):
+            pass
+
+        def elapsed_time(self, other):
+            return 1.0
+
+        def query(self):
+            return True
+
+    @staticmethod
+    def stream(s):
+        import contextlib
+        return contextlib.nullcontext()
+
+    @staticmethod
+    def synchronize():
+        pass
 
 
 class HostClock:
@@ -195,9 +274,17 @@ def main():
                     help="profiling runs: nothing but the warm-up and the timed regions launches kernels (no exact-basis region, no "
                          "secondary views, no CPU baseline), so that a rocprofv3 kernel trace of the process averages exactly the "
                          "launches `value` and `roofline.avg_launch_ms` are made of")
+    ap.add_argument("--dry-run-lib", default=None, metavar="PATH",
+                    help="DRY RUN of the (multi-rank) step loop on the CPU: PATH is a host build of this library's kernels (the "
+                         "tests pass one), the process group is gloo, streams and events are stand-ins.  Checks the protocol -- "
+                         "shapes, broadcasts, collectives in the same order on every rank -- not speed; implies --only-timed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the one-render-in-flight and hipGraph passes")
     args = ap.parse_args()
+    dry = args.dry_run_lib is not None
+    if dry:
+        args.only_timed, args.config = True, "dry"
+        args.batch, args.slots = args.batch or 2, args.slots or 2
     if args.only_timed:
         args.no_surface = args.no_latency = args.no_cpu_baseline = True
 
@@ -217,9 +304,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != max(1, args.gpus):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if dry:
+        gpu, dev = DryGpu, torch.device("cpu")
+        _capi._lib = _capi.Lib(args.dry_run_lib)  # every `_capi.load()` of this process now drives the host build
+    else:
+        assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+        gpu = torch.cuda
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     dist = None
     # GSGEN_BENCH_FORCE_DIST=1: run the multi-rank code path (process group, broadcasts, the per-step all_gather on the
     # communication stream) with ONE rank -- the only way to exercise it on a single-GPU box
@@ -229,7 +321,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", str(rank))
         os.environ.setdefault("WORLD_SIZE", str(world))
-        dist.init_process_group("nccl", device_id=dev)
+        if dry:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     lib = _capi.load()
     for kv in args.variant:
@@ -244,10 +339,15 @@ def main():
     # Gaussians and 2.5 M pairs per view (cfg3) two cameras per launch beat eight (profiles/r02_notes.md); light launches
     # (< 5.2 M pairs: the 512^2 views of cfg4, cfg3's pairs of cameras) overlap better three deep than two
     # (cfg4: 6 988 vs 6 661 renders/s; cfg2, 5.7 M pairs per launch: 3 372 vs 3 368)
-    probe_cam = (random_pose_cameras(64, rank, world, W, H) if args.config == "cfg4" else camera_poses(1, rank, W, H))[0]
+    zoom = 12.0 if dry else 1.0  # (the dry run's few splats sit in a narrow view: the routed kernels take their polynomial form)
+    probe_cam = (random_pose_cameras(64, rank, world, W, H) if args.config == "cfg4" else camera_poses(1, rank, W, H, zoom))[0]
     pb = R.FrameBuffers(N, W, H, dev)
     tp = {k: torch.tensor(sc[k], device=dev) for k in ("mean", "qvec", "svec")}
-    R.frame_geometry(tp["mean"], tp["qvec"], tp["svec"], torch.from_numpy(R.CameraInfo(*probe_cam.intr).pack(probe_cam.c2w)).to(dev), pb)
+    probe_block = torch.from_numpy(R.CameraInfo(*probe_cam.intr).pack(probe_cam.c2w)).to(dev)
+    lib.frame_geometry(N, tp["mean"].data_ptr(), tp["qvec"].data_ptr(), tp["svec"].data_ptr(), probe_block.data_ptr(), W, H, pb.D_cap,
+                       pb.mean2d.data_ptr(), pb.cov2d.data_ptr(), pb.depth.data_ptr(), pb.mask.data_ptr(), pb.ids.data_ptr(),
+                       pb.start.data_ptr(), pb.end.data_ptr(), pb.total.data_ptr(), pb.ws.data_ptr(), pb.ws.numel(), None)
+    gpu.synchronize()
     d_probe = max(1, int(pb.total.item()))
     del pb, tp
     B, auto_slots = choose_batch_and_slots(d_probe, args.batch, args.slots)
@@ -255,7 +355,7 @@ def main():
         bt = torch.tensor([B, auto_slots], device=dev)
         dist.broadcast(bt, 0)
         B, auto_slots = int(bt[0].item()), int(bt[1].item())
-    cams = random_pose_cameras(64, rank, world, W, H) if args.config == "cfg4" else camera_poses(max(8, B), rank, W, H)
+    cams = random_pose_cameras(64, rank, world, W, H) if args.config == "cfg4" else camera_poses(B if dry else max(8, B), rank, W, H, zoom)
     ncam = len(cams)
     cis = [R.CameraInfo(*c.intr) for c in cams]
     nth, ntw = R.n_tiles(H, W)
@@ -280,9 +380,9 @@ def main():
             self.stream, self.s = stream, stream.cuda_stream
             # geometry on a high-priority stream of its own: the hardware dispatches its workgroups ahead of the other slot's
             # 20 000-workgroup compositing launch instead of behind it
-            self.geo_stream = torch.cuda.Stream(dev, priority=-1) if args.geo_priority else stream
-            self.e_geo, self.e_done, self.started = torch.cuda.Event(), torch.cuda.Event(), False
-            with torch.cuda.stream(stream):
+            self.geo_stream = gpu.Stream(dev, priority=-1) if args.geo_priority else stream
+            self.e_geo, self.e_done, self.started = gpu.Event(), gpu.Event(), False
+            with gpu.stream(stream):
                 self.bufs = [R.FrameBuffers(N, W, H, dev) for _ in range(B)]
                 self.out = torch.empty(B, H, W, 3, device=dev)
                 # per view: mean2d(2) | cov2d(4); shared: alpha(1) | sh -- zeroed once per step; the projection
@@ -297,7 +397,7 @@ def main():
                 self.gathered = torch.empty(world, B, H, W, 3, device=dev) if dist is not None else None
             # the images of a step are complete after its forward: they are gathered on the communication stream while
             # the step's backward runs; the slot's next forward waits for that gather before it overwrites `out`
-            self.e_fwd, self.e_gathered, self.gather_pending = torch.cuda.Event(), torch.cuda.Event(), False
+            self.e_fwd, self.e_gathered, self.gather_pending = gpu.Event(), gpu.Event(), False
             o = B * 6 * N
             self.g_alpha, self.g_sh = self.gflat[o:o + N], self.gflat[o + N:o + N * (1 + CC3)]
             self.g_mean, self.g_qvec, self.g_svec = self.g3d[:3 * N], self.g3d[3 * N:7 * N], self.g3d[7 * N:]
@@ -328,8 +428,8 @@ def main():
                 self.tables[key] = (geo, views, proj)
             return self.tables[key]
 
-    slots = [Slot(torch.cuda.Stream(dev)) for _ in range(max(1, auto_slots))]
-    comm_stream = torch.cuda.Stream(dev)
+    slots = [Slot(gpu.Stream(dev)) for _ in range(max(1, auto_slots))]
+    comm_stream = gpu.Stream(dev)
     seg_arg = nseg if nseg > 1 else 0
 
     def run_step(j, ev=None, gather=True):
@@ -366,13 +466,13 @@ def main():
             t0 = time.perf_counter()
             sl.e_fwd.record(stream)
             comm_stream.wait_event(sl.e_fwd)
-            with torch.cuda.stream(comm_stream):
-                dist.all_gather_into_tensor(sl.gathered, sl.out)
+            with gpu.stream(comm_stream):
+                dist.all_gather_into_tensor(sl.gathered.view(world * B, H, W, 3), sl.out)  # (the concatenated form: every backend takes it)
                 sl.e_gathered.record(comm_stream)
             sl.gather_pending = True
             clock.acc["gather"] = clock.acc.get("gather", 0.0) + time.perf_counter() - t0
         t0 = time.perf_counter()
-        with torch.cuda.stream(stream):
+        with gpu.stream(stream):
             sl.gflat.zero_()
         clock.acc["zero_grads"] = clock.acc.get("zero_grads", 0.0) + time.perf_counter() - t0
         if ev is not None:
@@ -390,7 +490,7 @@ def main():
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        gpu.synchronize()
 
     # size the pair buffers once, outside the timed region: step j runs on slot j % slots with camera offset
     # (j * B) % ncam, so one period of that pair covers every (slot, cameras) combination the timed steps will see
@@ -399,7 +499,7 @@ def main():
     for j in range(period):
         for _ in range(3):
             run_step(j, gather=False)
-            torch.cuda.synchronize()
+            gpu.synchronize()
             if all([b_.ensure_capacity() for b_ in slots[j % len(slots)].bufs]):
                 break
         else:
@@ -407,9 +507,15 @@ def main():
         for i, b_ in enumerate(slots[j % len(slots)].bufs):
             Ds[((j * B) % ncam + i) % ncam] = int(b_.total.item())
     n_vis = int(slots[0].bufs[0].mask.sum().item())
+    # list-length histogram of the run (tiles by the length of their depth-sorted list, slot 0's cameras)
+    edges = [0, 1, 16, 32, 64, 128, 256, 512, 1024, 2048, 1 << 30]
+    lens = torch.cat([(b_.end - b_.start).clamp(min=0).view(-1) for b_ in slots[0].bufs]).to(torch.float32)
+    hist = torch.histogram(lens.cpu(), bins=torch.tensor(edges, dtype=torch.float32)).hist.to(torch.int64).tolist()
+    list_hist = {"bin_edges": edges[:-1] + ["inf"], "tiles": hist, "views": B, "mean_length": float(lens.mean().item()),
+                 "max_length": int(lens.max().item()), "median_length": float(lens.median().item())}
 
     # warm-up: W untimed steps exactly as the timed ones (events included, so every event exists before the region)
-    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(K)]
+    evs = [[gpu.Event(enable_timing=True) for _ in range(4)] for _ in range(K)]
     for i in range(args.warmup):
         run_step(i, evs[i % K])
     for i in range(K):  # every event of the timed region has been recorded once
@@ -488,7 +594,7 @@ def main():
     if args.only_timed:
         alone = {"fwd_launch_ms": fwd_ms, "bwd_launch_ms": bwd_ms}  # not measured in this mode
     else:
-        eva = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(min(K, 8))]
+        eva = [[gpu.Event(enable_timing=True) for _ in range(4)] for _ in range(min(K, 8))]
         barrier()
         for j in range(len(eva)):
             run_step(j * len(slots), eva[j], gather=False)  # slot 0 every time: one stream
@@ -524,7 +630,7 @@ def main():
                                       1.0 / cis[k].fy, H, W, C, 1e-4, p(bg), None, order_, p(lseg_ws), lseg_arg, bound_p, s)
             if ev is not None:
                 ev[1].record(stream)
-            with torch.cuda.stream(stream):
+            with gpu.stream(stream):
                 g1.zero_()
             if ev is not None:
                 ev[2].record(stream)
@@ -541,13 +647,13 @@ def main():
         for k in range(ncam):  # this buffer now meets every camera: size its pair list (one sync each, untimed)
             for _ in range(3):
                 one_render(k)
-                torch.cuda.synchronize()
+                gpu.synchronize()
                 if b0.ensure_capacity():
                     break
             else:
                 raise AssertionError("pair buffer still too small after growing")
         n1 = int(min(B * K, 200))
-        ev1 = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(n1)]
+        ev1 = [[gpu.Event(enable_timing=True) for _ in range(4)] for _ in range(n1)]
         for i in range(min(n1, 16)):
             one_render(i % ncam, ev1[i])
         barrier()
@@ -569,7 +675,7 @@ def main():
             off = nth * ntw * 256 * lseg * 16
             for k in range(min(ncam, 8)):
                 one_render(k)
-                torch.cuda.synchronize()
+                gpu.synchronize()
                 stop_ = lseg_ws[off:off + nth * ntw * 256 * 4].view(torch.int32).view(nth * ntw, 256)
                 n_tile = (b0.end - b0.start).clamp(min=0).view(-1)
                 walked.append((float(stop_.max(dim=1).values.clamp(min=0).minimum(n_tile).sum().item()), float(n_tile.sum().item())))
@@ -577,7 +683,7 @@ def main():
             one["walked_fraction_of_D"] = float(np.sum([w_[0] for w_ in walked]) / max(1.0, np.sum([w_[1] for w_ in walked])))
         try:  # ... and replayed from one captured hipGraph per camera: same kernels, no launch gaps
             graphs = []
-            with torch.cuda.stream(sl0.stream):
+            with gpu.stream(sl0.stream):
                 for k in range(min(ncam, 8)):
                     gk = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(gk, stream=sl0.stream, capture_error_mode="thread_local"):  # RCCL's watchdog thread may query events meanwhile
@@ -587,7 +693,7 @@ def main():
                     graphs[i % len(graphs)].replay()
             barrier()
             t2 = time.perf_counter()
-            with torch.cuda.stream(sl0.stream):
+            with gpu.stream(sl0.stream):
                 for i in range(n1):
                     graphs[i % len(graphs)].replay()
             barrier()
@@ -605,11 +711,11 @@ def main():
         n_sf = len(slots)
         leaf = {k: t[k].clone().requires_grad_(True) for k in ("mean", "qvec", "svec", "alpha", "sh")}
         names = ("mean", "qvec", "svec", "alpha", "sh")
-        sf_streams = [torch.cuda.Stream(dev) for _ in range(n_sf)]
+        sf_streams = [gpu.Stream(dev) for _ in range(n_sf)]
         d_cap = int(max(b_.D_cap for sl_ in slots for b_ in sl_.bufs))
         brs = []
         for st_ in sf_streams:
-            with torch.cuda.stream(st_):
+            with gpu.stream(st_):
                 brs.append(BatchRenderer(N, W, H, dev, max_batch=B, D_cap=d_cap))
         go_b = grad_out.unsqueeze(0).expand(B, H, W, 3).contiguous()
         c2w_np = [c.c2w for c in cams]
@@ -618,15 +724,15 @@ def main():
             i = j % n_sf
             k0 = (j * B) % ncam
             idx = [(k0 + q) % ncam for q in range(B)]
-            with torch.cuda.stream(sf_streams[i]):
+            with gpu.stream(sf_streams[i]):
                 rgb, _ = brs[i].render(leaf["mean"], leaf["qvec"], leaf["svec"], leaf["alpha"], leaf["sh"], [cis[q] for q in idx],
                                        [c2w_np[q] for q in idx], C=C, bg_rgb=bg, sh_basis=args.sh_basis)
                 return torch.autograd.grad([rgb], [leaf[n_] for n_ in names], [go_b])
 
-        torch.cuda.synchronize()
+        gpu.synchronize()
         for j in range(max(args.warmup, 2 * n_sf)):
             surface_step(j)
-        torch.cuda.synchronize()
+        gpu.synchronize()
         assert all(br_.ensure_capacity(B) for br_ in brs), "surface pass: pair buffers overflowed"
         sf_el = []
         for r in range(min(3, n_rep)):
@@ -675,7 +781,8 @@ def main():
         "ms_per_step": el / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": WORKLOADS[args.config], "gaussians": N, "visible_after_cull": n_vis, "image": [H, W],
-                   "sh_degree": C - 1, "tile_pairs_D": D, "cameras_per_step": B, "steps_in_flight": len(slots),
+                   "sh_degree": C - 1, "tile_pairs_D": D, "list_length_histogram": list_hist, "cameras_per_step": B,
+                   "steps_in_flight": len(slots),
                    "backward_segments_per_tile": nseg,
                    "sh_basis": (f"routed on the device, per view and per step: the coefficient bound is measured by every step inside the "
                                 f"timed region (gsgen_sh_l1_bound; read back afterwards: S = {S_dev:.3f}) and {n_poly_job} of {ncam_job} "

@@ -256,7 +256,9 @@ class PairCountMonitor:
     def __init__(self, n, depth=4):
         import collections
         self.n, self.depth = int(n), int(depth)
-        self._free = [torch.zeros(self.n, dtype=torch.int32).pin_memory() for _ in range(self.depth)]
+        pin = torch.cuda.is_available()  # (host-only processes -- bench.py's dry run -- get pageable blocks)
+        self._free = [torch.zeros(self.n, dtype=torch.int32).pin_memory() if pin else torch.zeros(self.n, dtype=torch.int32)
+                      for _ in range(self.depth)]
         self._pending = collections.deque()
         self._ready = []
 

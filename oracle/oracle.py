@@ -251,3 +251,20 @@ def legacy_image_sort(mode, depth, tile_n, mean2d, shape, topleft, tile_size, nt
                                       C.c_float(psx), C.c_float(psy), C.c_float(thresh))
     assert tot == D, (tot, D)
     return ids[:D], td[:D], tile_n, offset
+
+
+def part_workstats(mean2d, cov2d, alpha, start, end, ids, topleft, psx, psy, H, W, rows_of_part=None, thresh=1e-4):
+    """Work statistics of the compositing walk (bench.py's cpu_baseline leg, tools/workstats.py): -> (walked, contributing,
+    pixel_pairs) -- (wavefront, list entry) pairs some pixel of the wavefront's part is still alive for, those of them in
+    which some pixel's a*G reaches 1/255, and the contributing (pixel, entry) pairs.  rows_of_part[16]: tile row -> wavefront
+    (default: one wavefront per tile, the backward's shape)."""
+    import ctypes as C
+    rows = np.zeros(16, np.int32) if rows_of_part is None else np.ascontiguousarray(rows_of_part, np.int32)
+    nth, ntw = _tiles(H, W, 16)
+    w, c, pp = C.c_longlong(), C.c_longlong(), C.c_longlong()
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    m2, c2, al, tl = _f(mean2d), _f(cov2d), _f(alpha), _f(topleft)
+    st, en, idv = _i(start), _i(end), _i(ids)
+    lib().gso_part_workstats(vp(m2), vp(c2), vp(al), vp(st), vp(en), vp(idv), vp(tl), nth, ntw, C.c_float(psx), C.c_float(psy),
+                             int(H), int(W), C.c_float(thresh), vp(rows), int(rows.max()) + 1, C.byref(w), C.byref(c), C.byref(pp))
+    return int(w.value), int(c.value), int(pp.value)

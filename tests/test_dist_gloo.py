@@ -297,3 +297,31 @@ def test_bench_accounting_and_launch_shape():
     assert bench.choose_batch_and_slots(440_000) == (8, 3)      # cfg4: light launches
     assert bench.choose_batch_and_slots(2_700) == (8, 3)        # cfg1
     assert bench.choose_batch_and_slots(713_016, batch=4, slots=1) == (4, 1)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_step_loop_dry_run_with_several_ranks(world):
+    """nobody has run bench.py with more than one rank before the driver's 8-GPU run.  `--dry-run-lib` runs
+    bench.py's OWN step loop -- slots, streams / events (stand-ins), the broadcast of the launch shape, the per-step
+    all_gather of the rendered images behind each forward, the max-over-ranks timing, the reductions of the report -- with
+    the host build of the kernels and gloo: a hang, a shape mismatch or a collective that not every rank reaches fails here.
+    The ranks' cameras differ (camera sharding), the routed SH kernels take their polynomial form (narrow views)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    subprocess.check_call(["make", "-C", os.path.join(root, "oracle"), "-s", "emu"])
+    emu = os.path.join(root, "oracle", "_build", "libgsgen_emu.so")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--dry-run-lib", emu, "--steps", "2",
+                        "--warmup", "1"], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # ONE JSON line, from rank 0
+    res = json.loads(lines[0])
+    cfg = res["config"]
+    assert res["n_gpus"] == world and cfg["rccl_world_size"] == world and res["steps"] == 2 and res["scaling"] == "weak"
+    per = cfg["renders_per_s_per_rank"]
+    assert len(per) == world and all(v > 0 for v in per)
+    assert res["value"] <= sum(per) * 1.0001  # whole-job throughput over the SLOWEST rank's time
+    assert f"{2 * world} of {2 * world} cameras" in cfg["sh_basis"] and "ROUTED" in res["roofline"]["kernel"]
+    assert "all_gather" in cfg["gather"]

@@ -189,3 +189,37 @@ def test_decision_margin_reports_threshold_adjacent_pixels():
         hit |= bool(m1[y, x, 0] <= 3e-7)
     assert hit
     assert np.median(m0[..., 0][m0[..., 0] < 1e29]) > 1e-3
+
+
+def test_torch_port_is_the_references_torch_code():
+    """oracle/torch_port.py (bench.py's CPU-baseline leg (1): the two stages the reference runs in PyTorch) against the
+    reference's OWN functions, imported from /root/reference behind the shims: project_gaussians (+ its autograd backward) and
+    tile_culling_aabb_count, bit for bit.  Authoring container only; the golden vectors carry the same outputs to the GPU box
+    (tests/golden/*.npz: mean2d / cov2d / depth / D were produced by the reference's functions)."""
+    import refshim
+    if not refshim.available():
+        pytest.skip("/root/reference is not present")
+    import torch
+    refshim.install()
+    import gs.renderer as GR
+    import gs.culling as GC
+    from utils.camera import CameraInfo
+    from oracle import torch_port as TP
+    sc = scenes.random_scene(2000, seed=3, svec=0.03, C=1)
+    cam = scenes.Camera(200, 144, fx=190.0, c2w=scenes.orbit(2.5, 25.0, 70.0))
+    c2w = torch.from_numpy(cam.c2w)
+    ins = [torch.from_numpy(sc[k]).clone().requires_grad_(True) for k in ("mean", "qvec", "svec")]
+    ins2 = [t.detach().clone().requires_grad_(True) for t in ins]
+    a = GR.project_gaussians(*ins, c2w, detach_depth=True)
+    b = TP.project_gaussians(*ins2, c2w, detach_depth=True)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    w = [torch.randn_like(x) for x in (a[0], a[1], a[3])]
+    (a[0] * w[0]).sum().add((a[1] * w[1]).sum()).add((a[3] * w[2]).sum()).backward()
+    (b[0] * w[0]).sum().add((b[1] * w[1]).sum()).add((b[3] * w[2]).sum()).backward()
+    for x, y in zip(ins, ins2):
+        assert torch.equal(x.grad, y.grad)
+    ci = CameraInfo(cam.fx, cam.fy, cam.cx, cam.cy, cam.w, cam.h, cam.near, cam.far)
+    n1, tl1, br1 = GC.tile_culling_aabb_count(a[0].detach(), a[1].detach(), 16, ci, 6.0)
+    n2, tl2, br2 = TP.tile_culling_aabb_count(b[0].detach(), b[1].detach(), 16, cam.fx, cam.fy, cam.cx, cam.cy, cam.w, cam.h, 6.0)
+    assert n1 == n2 and torch.equal(tl1, tl2) and torch.equal(br1, br2)
