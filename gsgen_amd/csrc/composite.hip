@@ -413,12 +413,16 @@ __device__ __forceinline__ void composite_fwd_sh_vec_tile(const CompParams &p, u
   v2f py2[NP];
 #pragma unroll
   for (int j = 0; j < PPL; ++j) py2[j >> 1][j & 1] = pixel_coord(p.topleft[1], gy[j], p.psy);
-  v2f Yp[PPL][NPAIR];
+  v2f Yp[POLY ? 1 : PPL][POLY ? 1 : NPAIR];
+  // POLY: the lane's column offset and its pixel pairs' row offsets -- the six monomials (1, v, u, v^2, uv, u^2) are never
+  // materialised: s = (w0 + u (w2 + u w5)) + v ((w1 + u w4) + v w3), the bracketed terms once per lane and channel
+  const float pu = poly_offset(lx);
+  v2f pv2[NP];
+#pragma unroll
+  for (int jp = 0; jp < NP; ++jp) pv2[jp] = v2f{poly_offset(ly0 + (2 * jp) * ROWS), poly_offset(ly0 + (2 * jp + 1) * ROWS)};
   if constexpr (POLY) {
     static_assert(kBatch * 3 * kPolyNB >= kPolyNodes * 16, "node scratch fits the coefficient buffer");
     poly_tile_setup<NT>(p, tx, ty, Ws, Vs);
-#pragma unroll
-    for (int j = 0; j < PPL; ++j) poly_monomials(lx, ly0 + j * ROWS, Yp[j]);
   } else {
     float R[9];
 #pragma unroll
@@ -509,23 +513,51 @@ __device__ __forceinline__ void composite_fwd_sh_vec_tile(const CompParams &p, u
       v2f w2[NP];
 #pragma unroll
       for (int jp = 0; jp < NP; ++jp) w2[jp] = (splat2(r_a) * Tr2[jp]) * G2[jp];  // (a T) G, or 0
+      if constexpr (POLY) {
+        // the three channels' denominators 1 + exp2(s_c) first, then ONE reciprocal per pixel for all of them:
+        // 1 / d_c = (1 / (d_0 d_1 d_2)) * (the other two).  (poly_transform keeps |s| <= 40: the product stays finite.)
+        v2f den[3][NP];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        v2f q[NPAIR];
+        for (int c = 0; c < 3; ++c) {
+          const v2f q0 = *reinterpret_cast<const v2f *>(cg + c * CCP), q1 = *reinterpret_cast<const v2f *>(cg + c * CCP + 2),
+                    q2 = *reinterpret_cast<const v2f *>(cg + c * CCP + 4);
+          const float A = fmaf(pu, fmaf(pu, q2[1], q1[0]), q0[0]), Bc = fmaf(pu, q2[0], q0[1]), Cc = q1[1];
 #pragma unroll
-        for (int k = 0; k < NPAIR; ++k) q[k] = *reinterpret_cast<const v2f *>(cg + c * CCP + 2 * k);
+          for (int jp = 0; jp < NP; ++jp) {
+            const v2f sp = fma2(pv2[jp], fma2(pv2[jp], splat2(Cc), splat2(Bc)), splat2(A));
+            den[c][jp] = splat2(1.0f) + v2f{__builtin_amdgcn_exp2f(sp[0]), __builtin_amdgcn_exp2f(sp[1])};
+          }
+        }
 #pragma unroll
         for (int jp = 0; jp < NP; ++jp) {
-          v2f sa = q[0] * Yp[2 * jp][0], sb = q[0] * Yp[2 * jp + 1][0];
+          const v2f d01 = den[0][jp] * den[1][jp];
+          const v2f d = d01 * den[2][jp];
+          const v2f r = v2f{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+          const v2f r01 = r * den[2][jp];  // 1 / (d0 d1)
+          acc2[jp][0] = ffma2(w2[jp], r01 * den[1][jp], acc2[jp][0]);
+          acc2[jp][1] = ffma2(w2[jp], r01 * den[0][jp], acc2[jp][1]);
+          acc2[jp][2] = ffma2(w2[jp], r * d01, acc2[jp][2]);
+        }
+      }
+      if constexpr (!POLY) {
 #pragma unroll
-          for (int k = 1; k < NPAIR; ++k) {
-            sa = ffma2(q[k], Yp[2 * jp][k], sa);
-            sb = ffma2(q[k], Yp[2 * jp + 1][k], sb);
+        for (int c = 0; c < 3; ++c) {
+          v2f q[NPAIR];
+#pragma unroll
+          for (int k = 0; k < NPAIR; ++k) q[k] = *reinterpret_cast<const v2f *>(cg + c * CCP + 2 * k);
+#pragma unroll
+          for (int jp = 0; jp < NP; ++jp) {
+            v2f sa = q[0] * Yp[2 * jp][0], sb = q[0] * Yp[2 * jp + 1][0];
+#pragma unroll
+            for (int k = 1; k < NPAIR; ++k) {
+              sa = ffma2(q[k], Yp[2 * jp][k], sa);
+              sb = ffma2(q[k], Yp[2 * jp + 1][k], sb);
+            }
+            const v2f sp = v2f{add_scalar(sa[0], sa[1]), add_scalar(sb[0], sb[1])};
+            const v2f den = splat2(1.0f) + v2f{__builtin_amdgcn_exp2f(sp[0]), __builtin_amdgcn_exp2f(sp[1])};
+            const v2f yv = v2f{__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+            acc2[jp][c] = ffma2(w2[jp], yv, acc2[jp][c]);
           }
-          const v2f sp = v2f{add_scalar(sa[0], sa[1]), add_scalar(sb[0], sb[1])};
-          const v2f den = splat2(1.0f) + v2f{__builtin_amdgcn_exp2f(sp[0]), __builtin_amdgcn_exp2f(sp[1])};
-          const v2f yv = v2f{__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
-          acc2[jp][c] = ffma2(w2[jp], yv, acc2[jp][c]);
         }
       }
 #pragma unroll
@@ -918,13 +950,16 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
   }
 
   // per-pixel SH basis as (k, k+1) pairs
-  v2f Yp[PPL][NPAIR];
+  v2f Yp[POLY ? 1 : PPL][POLY ? 1 : NPAIR];
   float Vk[POLY ? kPolyNB : 1];  // POLY: column (lane & 15) of V
+  // POLY: the lane's column offset and its pixel pairs' row offsets stand for the six monomials (see the forward)
+  const float pu = poly_offset(lx);
+  v2f pv2[NP];
+#pragma unroll
+  for (int jp = 0; jp < NP; ++jp) pv2[jp] = v2f{poly_offset(ly0 + (2 * jp) * ROWS), poly_offset(ly0 + (2 * jp + 1) * ROWS)};
   if constexpr (POLY) {
     static_assert(!POLY || KB * 3 * kPolyNB >= kPolyNodes * 16, "node scratch fits the coefficient buffer");
     poly_tile_setup<NT>(p, tx, ty, Ws, Vs);
-#pragma unroll
-    for (int j = 0; j < PPL; ++j) poly_monomials(lx, ly0 + j * ROWS, Yp[j]);
 #pragma unroll
     for (int r = 0; r < kPolyNB; ++r) Vk[r] = Vs[r * 16 + (lane & 15)];
   } else {
@@ -1036,10 +1071,63 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
 #pragma unroll
       for (int jp = 0; jp < NP; ++jp) {
         w2[jp] = (splat2(r_a) * Tr2[jp]) * G2[jp];  // the forward's (a T) G, or 0
-        const v2f om = splat2(1.0f) - ag2[jp];
-        inv1m2[jp] = v2f{__builtin_amdgcn_rcpf(om[0]), __builtin_amdgcn_rcpf(om[1])};
+        if constexpr (!POLY) {
+          const v2f om = splat2(1.0f) - ag2[jp];
+          inv1m2[jp] = v2f{__builtin_amdgcn_rcpf(om[0]), __builtin_amdgcn_rcpf(om[1])};
+        }
         pAG2[jp] = v2f{0.0f, 0.0f};
       }
+      if constexpr (POLY) {
+        // colours as in the forward: the three channels' denominators first, then ONE reciprocal per pixel for the three
+        // sigmoids and 1 / (1 - a G):  1 / x_i = (1 / prod x) * prod_{j != i} x_j  (|s| <= 40 by poly_transform, 1 - a G >= 0.01)
+        v2f den[3][NP], yv[3][NP];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const v2f q0 = *reinterpret_cast<const v2f *>(cg + c * CCP), q1 = *reinterpret_cast<const v2f *>(cg + c * CCP + 2),
+                    q2 = *reinterpret_cast<const v2f *>(cg + c * CCP + 4);
+          const float A = fmaf(pu, fmaf(pu, q2[1], q1[0]), q0[0]), Bc = fmaf(pu, q2[0], q0[1]), Cc = q1[1];
+#pragma unroll
+          for (int jp = 0; jp < NP; ++jp) {
+            const v2f sp = fma2(pv2[jp], fma2(pv2[jp], splat2(Cc), splat2(Bc)), splat2(A));
+            den[c][jp] = splat2(1.0f) + v2f{__builtin_amdgcn_exp2f(sp[0]), __builtin_amdgcn_exp2f(sp[1])};
+          }
+        }
+#pragma unroll
+        for (int jp = 0; jp < NP; ++jp) {
+          const v2f om = splat2(1.0f) - ag2[jp];
+          const v2f d01 = den[0][jp] * den[1][jp], d2o = den[2][jp] * om;
+          const v2f dd = d01 * d2o;
+          const v2f r = v2f{__builtin_amdgcn_rcpf(dd[0]), __builtin_amdgcn_rcpf(dd[1])};
+          const v2f r01 = r * d2o, r2o = r * d01;  // 1 / (d0 d1), 1 / (d2 (1 - a G))
+          yv[0][jp] = r01 * den[1][jp];
+          yv[1][jp] = r01 * den[0][jp];
+          yv[2][jp] = r2o * om;
+          inv1m2[jp] = r2o * den[2][jp];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          // d L / d w[c][r] = sum over pixels of gs * monomial_r: the lane's sums of gs, gs v, gs v^2, then its column's u
+          v2f g0, g1, g2;
+#pragma unroll
+          for (int jp = 0; jp < NP; ++jp) {
+            const v2f y_ = yv[c][jp];
+            rem2[jp][c] = fma2(-w2[jp], y_, rem2[jp][c]);
+            const v2f dy = fma2(-y_, y_, y_);  // y (1 - y)
+            const v2f go = go_s[(c * NP + jp) * NT + t];
+            const v2f gs = (w2[jp] * dy) * go;
+            const v2f sfx = rem2[jp][c] * inv1m2[jp];
+            pAG2[jp] = fma2(go, fma2(y_, Tr2[jp], -sfx), pAG2[jp]);
+            const v2f m1 = gs * pv2[jp], m2 = m1 * pv2[jp];
+            if (jp == 0) { g0 = gs; g1 = m1; g2 = m2; }
+            else { g0 = g0 + gs; g1 = g1 + m1; g2 = g2 + m2; }
+          }
+          const float G0 = add_scalar(g0[0], g0[1]), G1 = add_scalar(g1[0], g1[1]), G2s = add_scalar(g2[0], g2[1]);
+          const float uG0 = pu * G0;
+          v2f t4[PCH / 2] = {v2f{G0, G1}, v2f{uG0, G2s}, v2f{pu * G1, pu * uG0}, v2f{0.0f, 0.0f}};  // (1, v, u, v^2, uv, u^2 | 0, 0)
+          chsum[c] = wave_reduce_scatter2_rows<PCH>(t4);
+        }
+      }
+      if constexpr (!POLY) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         v2f q[NPAIR], gq[NPAIR];
@@ -1095,6 +1183,7 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
           for (int k = 0; k < NPAIR; ++k) gr2[c * NPAIR + k] = gq[k];
         }
       }
+      }  // !POLY
       // mean2d (2) | cov2d (4) | alpha (1): kernel_gaussian_2d_backward (kernels.h:394-418), packed over the pair
       // and summed over the lane's pairs; the two halves are added at the end
       const float inv_det = r_p1;

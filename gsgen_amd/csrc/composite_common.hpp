@@ -339,13 +339,6 @@ constexpr float kPolyFit[kPolyNB][kPolyNodes] = {
 
 // tile-local offset of a pixel column / row index 0..15
 __device__ __forceinline__ float poly_offset(int l) { return ((float)l - 7.5f) * (1.0f / 7.5f); }
-// the six monomials of pixel (lx, ly) as (even, odd) pairs: (1, v) (u, v^2) (uv, u^2)
-__device__ __forceinline__ void poly_monomials(int lx, int ly, v2f (&U)[kPolyNB / 2]) {
-  const float u = poly_offset(lx), v = poly_offset(ly);
-  U[0] = v2f{1.0f, v};
-  U[1] = v2f{u, v * v};
-  U[2] = v2f{u * v, u * u};
-}
 // V[6][16] of tile (tx, ty) into LDS (Vs), through the exact basis at the nine nodes (Yn: 9 x 16 floats of LDS scratch).
 // All NT threads of the workgroup call it; ends with a barrier.  The fit's coefficients are compile-time literals of fully
 // unrolled loops (a table in memory, read through a dependent chain of loads, cost tens of microseconds per tile once the
@@ -402,6 +395,17 @@ __device__ __forceinline__ void poly_transform(const float *__restrict__ sh, con
       acc = fmaf(q2.x, cc.x, acc); acc = fmaf(q2.y, cc.y, acc); acc = fmaf(q2.z, cc.z, acc); acc = fmaf(q2.w, cc.w, acc);
       acc = fmaf(q3.x, d.x, acc); acc = fmaf(q3.y, d.y, acc); acc = fmaf(q3.z, d.z, acc); acc = fmaf(q3.w, d.w, acc);
       w[e * kPolyNB + r] = -kLog2e * acc;
+    }
+    // |s| <= sum_r |w_r| on the tile (|u|, |v| <= 1).  The kernels take ONE reciprocal per pixel for the product of the three
+    // channels' 1 + exp2(s): rows that could reach |s| > 40 are scaled back to 40 -- their sigmoid is 0 or 1 to 1e-12 either way
+    // (and d sigmoid / d s ~ 1e-12: no gradient is lost that the exact kernels would deliver)
+    float l1 = 0.0f;
+#pragma unroll
+    for (int r = 0; r < kPolyNB; ++r) l1 += fabsf(w[e * kPolyNB + r]);
+    if (l1 > 40.0f) {
+      const float sc = 40.0f / l1;
+#pragma unroll
+      for (int r = 0; r < kPolyNB; ++r) w[e * kPolyNB + r] *= sc;
     }
   }
 }

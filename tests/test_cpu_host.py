@@ -1256,14 +1256,16 @@ def test_emulated_polynomial_sh_basis_fuzz(emu):
 
     @settings(max_examples=n_ex, deadline=None, derandomize=(n_ex == 10), suppress_health_check=list(HealthCheck))
     @given(B=st.integers(1, 3), W=st.integers(1, 60), H=st.integers(1, 44), n=st.integers(1, 300), seed=st.integers(0, 10_000),
-           svec=st.sampled_from([0.003, 0.012, 0.05]), opaque=st.booleans(), nseg=st.sampled_from([0, 3]), ppl_fwd=st.sampled_from([2, 4]))
-    def run(B, W, H, n, seed, svec, opaque, nseg, ppl_fwd):
+           svec=st.sampled_from([0.003, 0.012, 0.05]), opaque=st.booleans(), nseg=st.sampled_from([0, 3]), ppl_fwd=st.sampled_from([2, 4]),
+           dc=st.sampled_from([1.0, 1.0, 150.0]))
+    def run(B, W, H, n, seed, svec, opaque, nseg, ppl_fwd, dc):
         sc = scenes.random_scene(n, seed=seed, svec=svec, spread=0.03, C=4)
         sc["sh"][:, :, 1:] *= 0.5
+        sc["sh"][:, :, 0] *= dc  # 150: saturated colours, |sh . Y| in the hundreds (the kernels' one-reciprocal-per-pixel form must not overflow)
         if opaque:
             sc["alpha"][:] = 0.999
         cams = [scenes.Camera(W, H, fx=560.0 + 90 * i, c2w=scenes.orbit(2.5 + 0.1 * i, 15.0 * i, 50.0 + 110.0 * i)) for i in range(B)]
-        _poly_vs_exact(emu, sc, cams, nseg, ppl_fwd, (B, W, H, n, seed, svec, opaque, nseg, ppl_fwd), seed)
+        _poly_vs_exact(emu, sc, cams, nseg, ppl_fwd, (B, W, H, n, seed, svec, opaque, nseg, ppl_fwd, dc), seed)
     run()
 
 

@@ -143,10 +143,11 @@ def test_routed_launches_fuzz_against_the_exact_kernels():
     @settings(max_examples=n_ex, deadline=None, derandomize=(n_ex == 25), suppress_health_check=list(HealthCheck))
     @given(B=st.integers(1, 4), W=st.integers(1, 150), H=st.integers(1, 120), n=st.integers(1, 4000), seed=st.integers(0, 10_000),
            svec=st.sampled_from([0.003, 0.02, 0.08]), opaque=st.booleans(), nseg=st.sampled_from([1, 4]),
-           gain=st.sampled_from([0.2, 1.0, 8.0, 40.0]), fscale=st.sampled_from([0.4, 1.0, 2.5]))
-    def run(B, W, H, n, seed, svec, opaque, nseg, gain, fscale):
+           gain=st.sampled_from([0.2, 1.0, 8.0, 40.0]), fscale=st.sampled_from([0.4, 1.0, 2.5]), dc=st.sampled_from([1.0, 1.0, 150.0]))
+    def run(B, W, H, n, seed, svec, opaque, nseg, gain, fscale, dc):
         sc = scenes.random_scene(n, seed=seed, svec=svec, spread=0.25, C=4)
         sc["sh"][:, :, 1:] *= gain
+        sc["sh"][:, :, 0] *= dc  # 150: saturated colours (|sh . Y| in the hundreds)
         if opaque:
             sc["alpha"][:] = 0.999
         cams = [scenes.Camera(W, H, fx=fscale * (180.0 + 70 * i), c2w=scenes.orbit(2.5 + 0.1 * i, 12.0 * i, 50.0 + 95.0 * i)) for i in range(B)]
@@ -164,7 +165,7 @@ def test_routed_launches_fuzz_against_the_exact_kernels():
                     break
             grads = torch.autograd.grad([rgb], [P[k] for k in KEYS], [go])
             res[basis] = (rgb.detach().cpu().numpy(), T.cpu().numpy(), [g.cpu().numpy() for g in grads])
-        tag = (B, W, H, n, seed, svec, opaque, nseg, gain, fscale)
+        tag = (B, W, H, n, seed, svec, opaque, nseg, gain, fscale, dc)
         assert np.array_equal(res["auto"][1], res["exact"][1]), tag
         for i in range(B):
             d = float(np.abs(res["auto"][0][i] - res["exact"][0][i]).max())
