@@ -152,18 +152,29 @@ def cpu_baseline(sc, cams, C, budget_s=20.0):
     try:
         import torch
         from oracle import torch_port as TP
-        torch.set_num_threads(os.cpu_count() or 1)
         mean, qvec, svec = (torch.from_numpy(sc[k][m]) for k in ("mean", "qvec", "svec"))
         c2w = torch.from_numpy(cam.c2w)
-        ts = []
-        for _ in range(5):
+
+        def once():
             t1 = time.perf_counter()
             m2, c2, _, _ = TP.project_gaussians(mean, qvec, svec, c2w, True)
             TP.tile_culling_aabb_count(m2, c2, 16, cam.fx, cam.fy, cam.cx, cam.cy, cam.w, cam.h, 6.0)
-            ts.append(time.perf_counter() - t1)
+            return time.perf_counter() - t1
+        # all cores as SURVEY asks, and 16 threads: 80 k batched 3x3 products over 256 threads are slower than over 16 (13 s
+        # against a fraction of a second per camera on the GPU box) -- the better of the two is the baseline; bounded to a few seconds
+        best = None
+        ncpu = os.cpu_count() or 1
+        for nthr in sorted({ncpu if ncpu <= 64 else 16, min(16, ncpu)}):  # (256 threads: 13 s per camera, session r3c: not repeated)
+            torch.set_num_threads(nthr)
+            ts = [once()]
+            while len(ts) < 5 and sum(ts) < 3.0:
+                ts.append(once())
+            if best is None or float(np.median(ts)) < best[0]:
+                best = (float(np.median(ts)), nthr, len(ts))
         res["torch_cpu_projection_and_aabb_count"] = {
-            "ms_per_camera": float(np.median(ts)) * 1e3, "gaussians": int(m.sum()), "torch_threads": torch.get_num_threads(),
-            "kind": "port", "what": "project_gaussians + tile_culling_aabb_count in PyTorch on the CPU, forward only, median of 5"}
+            "ms_per_camera": best[0] * 1e3, "gaussians": int(m.sum()), "torch_threads": best[1], "runs": best[2], "kind": "port",
+            "what": "project_gaussians + tile_culling_aabb_count in PyTorch on the CPU (oracle/torch_port.py), forward only, "
+                    "median; thread count = the faster of all cores and 16"}
     except Exception as e:  # the baseline is a report, never a reason for the bench line to be missing
         res["torch_cpu_projection_and_aabb_count"] = {"error": str(e)[:200]}
     return res
