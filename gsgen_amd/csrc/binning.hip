@@ -29,8 +29,7 @@
 namespace gs {
 
 constexpr int kSortThreads = 256;  // waves 1-3 only work on segments too long for the register sort
-constexpr uint32_t kBigGrid = 128;  // workgroups (per view) walking the long-list front of the launch order
-constexpr int kSortLds = 4096;  // keys sorted in LDS per tile (32 KiB); longer segments sort in global memory
+constexpr uint32_t kBigGrid = 32;  // workgroups (per view) walking the long-list front of the launch order
 
 constexpr int kGroup = 8;      // tiles per group side: 8x8 tiles <-> 64 lanes
 constexpr int kChunk = 2048;   // Gaussians per chunk
@@ -197,19 +196,23 @@ __device__ __forceinline__ uint32_t sat_add_u32(uint32_t a, uint32_t b) {
   return s < a ? 0xffffffffu : s;
 }
 
+// One workgroup of kScanThreads = 256 (four wavefronts, one per SIMD): with 1024 threads this link of the chain needed 16
+// free wave slots on ONE compute unit and waited 0.3 ms for them whenever another batch's compositing launch filled the chip
+// (profiles/r03_notes.md: 7.9 us alone, 299 us average with three steps in flight).
+constexpr uint32_t kScanThreads = 256;
 __device__ __forceinline__ void
 scan_tiles_body(uint32_t T, const uint32_t *__restrict__ tile_count, uint32_t *__restrict__ tile_off,
              uint32_t *__restrict__ ctrl, uint32_t cap, uint32_t *__restrict__ total_out) {
-  __shared__ uint32_t s_part[1024];
+  __shared__ uint32_t s_part[kScanThreads];
   const uint32_t t = threadIdx.x;
-  const uint32_t per = (T + 1023u) / 1024u;
-  const uint32_t b = t * per, e = min(b + per, T);
+  const uint32_t per = (T + kScanThreads - 1u) / kScanThreads;
+  const uint32_t b = min(t * per, T), e = min(b + per, T);
   uint32_t sum = 0;
   for (uint32_t i = b; i < e; ++i) sum = sat_add_u32(sum, tile_count[i]);
   s_part[t] = sum;
   __syncthreads();
-  // Hillis-Steele inclusive scan over 1024 partials
-  for (uint32_t d = 1; d < 1024u; d <<= 1) {
+  // Hillis-Steele inclusive scan over the partials
+  for (uint32_t d = 1; d < kScanThreads; d <<= 1) {
     const uint32_t v = (t >= d) ? s_part[t - d] : 0u;
     __syncthreads();
     s_part[t] = sat_add_u32(s_part[t], v);
@@ -220,8 +223,8 @@ scan_tiles_body(uint32_t T, const uint32_t *__restrict__ tile_count, uint32_t *_
     tile_off[i] = run;
     run = sat_add_u32(run, tile_count[i]);
   }
-  if (t == 1023u) {
-    const uint32_t total = s_part[1023];
+  if (t == kScanThreads - 1u) {
+    const uint32_t total = s_part[kScanThreads - 1u];
     tile_off[T] = total;
     ctrl[0] = total;
     ctrl[1] = (total > cap) ? 1u : 0u;
@@ -241,14 +244,14 @@ order_tiles_body(uint32_t T, const uint32_t *__restrict__ tile_count, uint32_t *
   const uint32_t t = threadIdx.x;
   if (t < 256u) s_hist[t] = 0u;
   __syncthreads();
-  for (uint32_t i = t; i < T; i += 1024u) atomicAdd(&s_hist[255u - min(tile_count[i] >> 3, 255u)], 1u);
+  for (uint32_t i = t; i < T; i += kScanThreads) atomicAdd(&s_hist[255u - min(tile_count[i] >> 3, 255u)], 1u);
   __syncthreads();
   if (t == 0) {
     uint32_t run = 0;
     for (int b = 0; b < 256; ++b) { s_base[b] = run; run += s_hist[b]; }
   }
   __syncthreads();
-  for (uint32_t i = t; i < T; i += 1024u) {
+  for (uint32_t i = t; i < T; i += kScanThreads) {
     const uint32_t b = 255u - min(tile_count[i] >> 3, 255u);
     tile_order[atomicAdd(&s_base[b], 1u)] = i;
   }
@@ -405,14 +408,14 @@ sort_tiles_body(uint32_t tile, const uint32_t *__restrict__ tile_off, const uint
   else sort_segment_regs<32>(keys + b, ids + b, n);
 }
 
-// Segments longer than the register sort can hold: one workgroup, LDS (<= kSortLds keys) or the
-// global segment itself.  A separate launch so that the common kernel carries no LDS (32 KiB
-// of static LDS per workgroup would throttle the compositing kernels of other renders in flight).
+// Segments longer than the register sort can hold (> 2048 entries: dense clusters; none on the BASELINE workloads): one
+// workgroup runs the bitonic network on the global segment itself (L2-resident).  NO LDS: a 32 KiB staging buffer made
+// every launch of this kernel -- which normally finds nothing to do -- wait 0.23 ms on average for LDS on a chip filled by
+// another batch's compositing launch (profiles/r03_notes.md: 5 us alone), on the critical chain of every step.
 __device__ __forceinline__ void
 sort_tiles_big_body(uint32_t T, const uint32_t *__restrict__ tile_off, const uint32_t *__restrict__ ctrl,
                  unsigned long long *__restrict__ keys, int *__restrict__ ids,
                  const uint32_t *__restrict__ tile_order) {
-  __shared__ unsigned long long s_keys[kSortLds];
   const uint32_t tid = threadIdx.x;
   if (ctrl[1] != 0u) return;
   // With a launch order (order_tiles_body: every list of >= 2040 entries sits in the first bucket) a few
@@ -425,20 +428,13 @@ sort_tiles_big_body(uint32_t T, const uint32_t *__restrict__ tile_off, const uin
     const uint32_t n = e - b;
     if (tile_order != nullptr && n < 2040u) break;
     if (n <= 64u * kSortMaxK) continue;
-    if (n <= (uint32_t)kSortLds) {
-      for (uint32_t i = tid; i < n; i += kSortThreads) s_keys[i] = keys[b + i];
-      __syncthreads();
-      bitonic_sort(s_keys, n, tid, kSortThreads);
-      for (uint32_t i = tid; i < n; i += kSortThreads) ids[b + i] = (int)(uint32_t)(s_keys[i] & 0xffffffffull);
-    } else {
-      // same network directly on the global segment (one workgroup, so __syncthreads + the
-      // L2-coherent stores of this CU order the passes)
-      unsigned long long *k = keys + b;
-      __syncthreads();
-      bitonic_sort(k, n, tid, kSortThreads);
-      for (uint32_t i = tid; i < n; i += kSortThreads) ids[b + i] = (int)(uint32_t)(k[i] & 0xffffffffull);
-    }
-    __syncthreads();  // s_keys is reused by this workgroup's next tile
+    // the network directly on the global segment (one workgroup, so __syncthreads + the L2-coherent stores of this CU
+    // order the passes)
+    unsigned long long *k = keys + b;
+    __syncthreads();
+    bitonic_sort(k, n, tid, kSortThreads);
+    for (uint32_t i = tid; i < n; i += kSortThreads) ids[b + i] = (int)(uint32_t)(k[i] & 0xffffffffull);
+    __syncthreads();
   }
 }
 
@@ -470,14 +466,14 @@ k_scan_chunks_views(uint32_t T, uint32_t nchunks, const GeoView *__restrict__ vi
 }
 // tile offsets and the longest-first launch order in ONE launch: both read tile_count only, both are one workgroup --
 // as two kernels they were two ~5 us links in a lone render's chain of dependent launches
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(kScanThreads)
 k_scan_order_tiles(uint32_t T, const uint32_t *__restrict__ tile_count, uint32_t *__restrict__ tile_off,
                    uint32_t *__restrict__ ctrl, uint32_t cap, uint32_t *__restrict__ total_out,
                    uint32_t *__restrict__ tile_order) {
   scan_tiles_body(T, tile_count, tile_off, ctrl, cap, total_out);
   order_tiles_body(T, tile_count, tile_order);
 }
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(kScanThreads)
 k_scan_order_tiles_views(uint32_t T, const GeoView *__restrict__ views) {
   const GeoView v = views[blockIdx.y];
   scan_tiles_body(T, v.tile_count, v.tile_off, v.ctrl, v.cap, v.total);
@@ -570,7 +566,7 @@ static int bin_and_sort(uint32_t N, uint32_t cap, uint32_t nth, uint32_t ntw, co
   }
   hipLaunchKernelGGL(k_scan_chunks, dim3((T + 3) / 4), dim3(256), 0, s, T, w.nchunks,
                      w.cnt, w.tile_count);
-  hipLaunchKernelGGL(k_scan_order_tiles, dim3(1), dim3(1024), 0, s, T, w.tile_count, w.tile_off, w.ctrl, cap, total_out,
+  hipLaunchKernelGGL(k_scan_order_tiles, dim3(1), dim3(kScanThreads), 0, s, T, w.tile_count, w.tile_off, w.ctrl, cap, total_out,
                      w.tile_order);
   if (N)
     hipLaunchKernelGGL((k_bin_pull<true>), gpull, bpull, 0, s, N, tl, br, depth, (int)ntw, (int)nth, T,
@@ -693,7 +689,7 @@ int gsgen_frame_geometry_batch(uint32_t n_views, const gsgen_geometry_view *view
     hipLaunchKernelGGL((k_bin_pull_views<false>), gpull, bpull, 0, s, N, (int)ntw, (int)nth, T, (const GeoView *)dv);
   }
   hipLaunchKernelGGL(k_scan_chunks_views, dim3((T + 3) / 4, B), dim3(256), 0, s, T, nchunks, (const GeoView *)dv);
-  hipLaunchKernelGGL(k_scan_order_tiles_views, dim3(1, B), dim3(1024), 0, s, T, (const GeoView *)dv);
+  hipLaunchKernelGGL(k_scan_order_tiles_views, dim3(1, B), dim3(kScanThreads), 0, s, T, (const GeoView *)dv);
   if (N)
     hipLaunchKernelGGL((k_bin_pull_views<true>), gpull, bpull, 0, s, N, (int)ntw, (int)nth, T, (const GeoView *)dv);
   hipLaunchKernelGGL(k_sort_tiles_views, dim3(T * B), dim3(64), 0, s, T, B, (const GeoView *)dv);

@@ -78,8 +78,11 @@ def check_grads(P, want, anisotropic):
         assert rel_err(got, want[k]) < 1e-3, (k, rel_err(got, want[k]))
 
 
-def frame_case(sc, cam, C, anisotropic, min_longest=0):
-    from gsgen_amd import renderer as R
+def frame_case(sc, cam, C, anisotropic, min_longest=0, expect_poly=None):
+    """expect_poly (SH degree 3): True / False -- which form of the per-pixel SH basis the routed kernels must have taken for
+    this camera (the device decides from the coefficient bound it measured; checked here against an exact-basis render:
+    polynomial = differs by the fit error only, exact = bit-identical)"""
+    from gsgen_amd import renderer as R, _capi
     N = sc["mean"].shape[0]
     ci = R.CameraInfo(*cam.intr)
     P = {k: T_(sc[k]).requires_grad_(True) for k in KEYS}
@@ -99,6 +102,13 @@ def frame_case(sc, cam, C, anisotropic, min_longest=0):
     scenes.assert_sh_image_parity(rgb.detach().cpu().numpy(), ref, g["mean2d"], g["cov2d"], sc["alpha"][m], g["start"],
                                   g["end"], g["ids"], cam.topleft, 1 / cam.fx, 1 / cam.fy, what="frame")
     check_grads(P, want, anisotropic)
+    if expect_poly is not None:
+        assert _capi.load().sh_poly_applies(R.sh_l1_bound(P["sh"]), max(1 / cam.fx, 1 / cam.fy), 4) == expect_poly
+        with torch.no_grad():
+            exact, _ = R.render_frame(P["mean"], P["qvec"], P["svec"], P["alpha"], P["sh"], ci, cam.c2w, buf, C=C, bg_rgb=T_(bg),
+                                      sh_basis="exact")
+        d = float((exact - rgb.detach()).abs().max())
+        assert (0.0 < d <= 1e-5) if expect_poly else d == 0.0, (expect_poly, d)
     return longest
 
 
@@ -106,7 +116,7 @@ def test_full_size_cfg3():
     """BASELINE configs[2]: 500k post-densify Gaussians (anisotropic scales, opacities U(0.05, 1)), 1024x1024"""
     sc = scenes.densified_scene(500_000, seed=0, C=4)
     cam = scenes.Camera(1024, 1024, fx=1024.0, c2w=scenes.orbit(2.5, 15, 30))
-    frame_case(sc, cam, 4, anisotropic=True, min_longest=1024)
+    frame_case(sc, cam, 4, anisotropic=True, min_longest=1024, expect_poly=True)  # (f = image size: the polynomial form)
 
 
 def test_dense_cluster_long_lists():
@@ -159,6 +169,22 @@ def test_full_size_cfg4_64_random_poses_batched():
                 want[k] += gr[k]
     assert worst <= 4
     check_grads(P, want, anisotropic=False)
+    # which form of the SH basis the device took, per camera: the focal lengths straddle the bound (S = 2.4: f >= 0.7 x 512
+    # needs S <= 2.2, f = 1.35 x 512 allows 15.8), so the 64 poses hold both kinds; against an exact-basis render of the same
+    # batches the polynomial views differ by the fit error only and the fallen-back ones not at all
+    from gsgen_amd import _capi
+    S = R.sh_l1_bound(P["sh"])
+    applies = [_capi.load().sh_poly_applies(S, max(1 / c.fx, 1 / c.fy), 4) for c in cams]
+    assert 0 < sum(applies) < 64, (S, sum(applies))
+    with torch.no_grad():
+        for b0 in sorted({(i // B) * B for i, a_ in enumerate(applies) if not a_} | {0}):
+            batch = cams[b0:b0 + B]
+            cis = [R.CameraInfo(*c.intr) for c in batch]
+            imgs = [br.render(P["mean"], P["qvec"], P["svec"], P["alpha"], P["sh"], cis, [c.c2w for c in batch], C=C, bg_rgb=T_(bg),
+                              sh_basis=basis)[0] for basis in ("auto", "exact")]
+            for i in range(B):
+                d = float((imgs[0][i] - imgs[1][i]).abs().max())
+                assert (0.0 < d <= 1e-5) if applies[b0 + i] else d == 0.0, (b0 + i, applies[b0 + i], d, cams[b0 + i].fx)
 
 
 def test_full_size_rgb_heads_batched():
