@@ -123,8 +123,9 @@ __device__ __forceinline__ GRec load_rec(const Stage<MODE, CB, KB, WC> &S, int g
 //   0  interleaved: view = id % B -- every camera's longest lists start at once; with B = 8, XCD k
 //      (ids = k mod 8) sees one camera
 //   1  interleaved, view rotated by the block index (no camera pinned to an XCD)
-__device__ __forceinline__ uint32_t batch_view(const CompParams &p_arg, uint32_t &bid, uint32_t *grid = nullptr) {
-  const uint32_t B = (uint32_t)p_arg.n_lo, per = gridDim.x / B;
+// total: the size of the grid the map is taken over -- gridDim.x, or the virtual grid a persistent launch strides through
+__device__ __forceinline__ uint32_t batch_view(const CompParams &p_arg, uint32_t &bid, uint32_t *grid, uint32_t total) {
+  const uint32_t B = (uint32_t)p_arg.n_lo, per = total / B;
   uint32_t view;
   if (p_arg.n_hi == 2) {
     view = bid / per;
@@ -137,6 +138,9 @@ __device__ __forceinline__ uint32_t batch_view(const CompParams &p_arg, uint32_t
   }
   if (grid) *grid = per;
   return view;
+}
+__device__ __forceinline__ uint32_t batch_view(const CompParams &p_arg, uint32_t &bid, uint32_t *grid = nullptr) {
+  return batch_view(p_arg, bid, grid, gridDim.x);
 }
 
 // TS: tile side.  16 everywhere in this library's own pipeline; 8 and 32 exist for callers of the `_gs` entry points
@@ -357,6 +361,17 @@ __global__ void __launch_bounds__(TS * TS / PPL) k_composite_fwd(CompParams p_ar
 // polynomial form where the error bound holds, the exact form elsewhere.  The two forms share one block of LDS (a union) and
 // the register budget is the larger of the two -- the same occupancy class as either alone.
 constexpr int kRouted = -1;
+// PERSIST (the tile bodies below, called from a loop over tiles): the thread index is re-read through an opaque statement in
+// every iteration, so that the lane's per-tile constants are NOT hoisted out of the loop and kept in registers across it (the
+// persistent backward came out at 194 registers -- two wavefronts per SIMD -- with them hoisted)
+template <bool PERSIST>
+__device__ __forceinline__ int tile_thread_index() {
+  int t = (int)threadIdx.x;
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (PERSIST) asm volatile("" : "+v"(t));
+#endif
+  return t;
+}
 template <int CB, bool POLY>
 struct FwdShVecShared {
   Stage<MODE_SH, CB, kBatch, !POLY> S;
@@ -364,7 +379,7 @@ struct FwdShVecShared {
   alignas(16) float Ws[POLY ? kBatch * 3 * kPolyNB : 4];  // POLY: transformed coefficients of the staged batch
                                                           // (and, before the first batch, the nine node bases)
 };
-template <int CB, int PPL, int NB>
+template <int CB, int PPL, int NB, bool PERSIST = false>
 __device__ __forceinline__ void composite_fwd_sh_vec_tile(const CompParams &p, uint32_t bid, FwdShVecShared<CB, (NB > 0)> &sm) {
   static_assert(PPL == 4 || PPL == 2, "pixel pairs: 2 or 4 pixels per lane");
   constexpr bool POLY = NB > 0;
@@ -381,7 +396,7 @@ __device__ __forceinline__ void composite_fwd_sh_vec_tile(const CompParams &p, u
   const int tile = ty * p.ntw + tx;
   const int st = p.start[tile];
   const int n = (st < 0) ? 0 : (p.end[tile] - st);
-  const int t = (int)threadIdx.x;
+  const int t = tile_thread_index<PERSIST>();
   const int lx = t & 15, ly0 = t >> 4;
   const int gx = tx * kTile + lx;
 
@@ -524,7 +539,7 @@ __device__ __forceinline__ void composite_fwd_sh_vec_tile(const CompParams &p, u
           const float A = fmaf(pu, fmaf(pu, q2[1], q1[0]), q0[0]), Bc = fmaf(pu, q2[0], q0[1]), Cc = q1[1];
 #pragma unroll
           for (int jp = 0; jp < NP; ++jp) {
-            const v2f sp = fma2(pv2[jp], fma2(pv2[jp], splat2(Cc), splat2(Bc)), splat2(A));
+            const v2f sp = ffma2(pv2[jp], ffma2(pv2[jp], splat2(Cc), splat2(Bc)), splat2(A));  // (explicitly fused: every shape of the kernel agrees)
             den[c][jp] = splat2(1.0f) + v2f{__builtin_amdgcn_exp2f(sp[0]), __builtin_amdgcn_exp2f(sp[1])};
           }
         }
@@ -593,6 +608,17 @@ __device__ __forceinline__ void composite_fwd_sh_vec_tile(const CompParams &p, u
     for (int j = 0; j < PPL; ++j) p.stop[(size_t)tile * 256 + (ly0 + j * ROWS) * 16 + lx] = stop[j];
   }
 }
+// How a launch that was given the coefficient bound is made of these instantiations (launch helpers below):
+//   one camera   NB = kRouted   -- ONE kernel holding both forms (a lone launch does not fill the chip: register-limited
+//                                  occupancy is irrelevant, an extra launch is not)
+//   camera batch NB = kPolyNB   -- the polynomial form alone: 73-104 registers instead of 96-168, i.e. 4 wavefronts per SIMD in
+//                                  the backward instead of 3 (+7-11 % renders/s, profiles/r03_ab_pairskip_polyonly.txt); a
+//                                  workgroup whose view fails the bound leaves at once
+//              + NB = kFallback -- the exact form for exactly those views: a PERSISTENT launch of a few thousand workgroups
+//                                  that first asks whether any view of the batch needs it (normally none: the launch is over
+//                                  after a handful of scalar loads per workgroup) and otherwise strides over the batch's
+//                                  (view, tile) grid, skipping the views the polynomial kernel took.
+constexpr int kFallback = -2;
 template <int CB, int PPL, bool BATCH = false, int NB = 0>
 __global__ void __launch_bounds__(256 / PPL)
 k_composite_fwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
@@ -612,6 +638,29 @@ k_composite_fwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
       const CompParams p = *pp;
       composite_fwd_sh_vec_tile<4, PPL, 0>(p, bid, sm.exact);
     }
+  } else if constexpr (NB == kFallback) {
+    static_assert(CB == 4 && BATCH, "the persistent exact fallback of a bounded batch");
+    __shared__ FwdShVecShared<4, false> sm;
+    const uint32_t B = (uint32_t)p_arg.n_lo, total = p_arg.vgrid;
+    bool any = false;
+    for (uint32_t v = 0; v < B; ++v) any |= !poly_route(plist[v].sh_bound, plist[v].psx, plist[v].psy);
+    if (!any) return;  // every view of the batch took the polynomial form
+    const uint32_t per = total / B;  // camera-major, whatever the batch map of the other launches (speed only)
+    uint32_t base = 0;  // first block of the view b lies in (b only grows: no division in the loop)
+    const CompParams *pp = plist;
+    for (uint32_t b = blockIdx.x; b < total; b += gridDim.x) {
+      while (b >= base + per) { base += per; ++pp; }
+      if (poly_route(pp->sh_bound, pp->psx, pp->psy)) continue;
+      const CompParams p = *pp;
+      composite_fwd_sh_vec_tile<4, PPL, 0, true>(p, b - base, sm);
+      __syncthreads();  // the LDS block is reused by the next tile
+    }
+  } else if constexpr (NB == kPolyNB && BATCH) {
+    __shared__ FwdShVecShared<4, true> sm;
+    const CompParams *pp = &plist[batch_view(p_arg, bid)];
+    if (!poly_route(pp->sh_bound, pp->psx, pp->psy)) return;  // this view is the exact fallback's
+    const CompParams p = *pp;
+    composite_fwd_sh_vec_tile<4, PPL, kPolyNB>(p, bid, sm);
   } else {
     const CompParams p = BATCH ? plist[batch_view(p_arg, bid)] : p_arg;  // see k_composite_fwd
     __shared__ FwdShVecShared<CB, (NB > 0)> sm;
@@ -888,7 +937,7 @@ struct BwdShVecShared {
                                                           // (and, before the first batch, the nine node bases)
   float gw_s[POLY ? 3 * 8 : 1];                           // POLY: a splat's reduced gradient in the tile's basis
 };
-template <int CB, int PPL, bool CHRED, int NB>
+template <int CB, int PPL, bool CHRED, int NB, bool PERSIST = false>
 __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, uint32_t bid, uint32_t grid,
                                                           BwdShVecShared<CB, PPL, CHRED, (NB > 0)> &sm) {
   static_assert(PPL == 4 || PPL == 2, "pixel pairs: 2 or 4 pixels per lane");
@@ -918,7 +967,7 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
   const int e_lo = seg * kSegLen;
   const int e_hi = (seg == nseg - 1) ? n : min(n, e_lo + kSegLen);  // the last segment takes the rest
   if (e_lo >= n) return;
-  const int t = (int)threadIdx.x;
+  const int t = tile_thread_index<PERSIST>();
   const int lane = t & 63;
   const int lx = t & 15, ly0 = t >> 4;
   const int gx = tx * kTile + lx;
@@ -1056,6 +1105,8 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
           ag2[jp][e] = con ? ag2[jp][e] : 0.0f;
           any_con |= con;
         }
+      // (skipping a pixel PAIR none of whose 128 pixels takes part -- pair-major code, one wave-uniform test per pair -- was
+      // measured again in round 3 with the polynomial body: 4 488 vs 4 507 renders/s, profiles/r03_ab_pairskip_polyonly.txt)
       if (__ballot(any_con) == 0ull) continue;  // nobody in the wave sees this Gaussian
 
       // reduction vector as (even, odd) pairs: SH components [0, NSH) | mean | cov | alpha | zeros
@@ -1088,7 +1139,7 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
           const float A = fmaf(pu, fmaf(pu, q2[1], q1[0]), q0[0]), Bc = fmaf(pu, q2[0], q0[1]), Cc = q1[1];
 #pragma unroll
           for (int jp = 0; jp < NP; ++jp) {
-            const v2f sp = fma2(pv2[jp], fma2(pv2[jp], splat2(Cc), splat2(Bc)), splat2(A));
+            const v2f sp = ffma2(pv2[jp], ffma2(pv2[jp], splat2(Cc), splat2(Bc)), splat2(A));  // (explicitly fused: every shape of the kernel agrees)
             den[c][jp] = splat2(1.0f) + v2f{__builtin_amdgcn_exp2f(sp[0]), __builtin_amdgcn_exp2f(sp[1])};
           }
         }
@@ -1265,6 +1316,9 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
     if (__syncthreads_or((int)any_alive) == 0) break;
   }
 }
+// (the persistent fallback runs at 174 registers = TWO wavefronts per SIMD: its loop state pushes the scalar registers to their
+// limit and the allocator lands six vector registers above the 168 of the exact kernel's class; forcing three costs 32 bytes
+// of scratch per lane.  It only renders views whose coefficient bound fails while a batch mate's holds.)
 template <int CB, int PPL, bool BATCH = false, bool CHRED = false, int NB = 0>
 __global__ void __launch_bounds__(256 / PPL)
 k_composite_bwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
@@ -1287,6 +1341,29 @@ k_composite_bwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
       const CompParams p = *pp;
       composite_bwd_sh_vec_tile<4, 4, true, 0>(p, bid, grid, sm.exact);
     }
+  } else if constexpr (NB == kFallback) {  // see k_composite_fwd_sh_vec
+    static_assert(CB == 4 && PPL == 4 && CHRED && BATCH, "the persistent exact fallback of a bounded batch");
+    __shared__ BwdShVecShared<4, 4, true, false> sm;
+    const uint32_t B = (uint32_t)p_arg.n_lo, total = p_arg.vgrid;
+    bool any = false;
+    for (uint32_t v = 0; v < B; ++v) any |= !poly_route(plist[v].sh_bound, plist[v].psx, plist[v].psy);
+    if (!any) return;
+    const uint32_t per = total / B;  // camera-major, whatever the batch map of the other launches (speed only)
+    uint32_t base = 0;  // first block of the view b lies in (b only grows: no division in the loop)
+    const CompParams *pp = plist;
+    for (uint32_t b = blockIdx.x; b < total; b += gridDim.x) {
+      while (b >= base + per) { base += per; ++pp; }
+      if (poly_route(pp->sh_bound, pp->psx, pp->psy)) continue;
+      const CompParams p = *pp;
+      composite_bwd_sh_vec_tile<4, 4, true, 0, true>(p, b - base, per, sm);
+      __syncthreads();
+    }
+  } else if constexpr (NB == kPolyNB && BATCH) {
+    __shared__ BwdShVecShared<4, 4, true, true> sm;
+    const CompParams *pp = &plist[batch_view(p_arg, bid, &grid)];
+    if (!poly_route(pp->sh_bound, pp->psx, pp->psy)) return;  // this view is the exact fallback's
+    const CompParams p = *pp;
+    composite_bwd_sh_vec_tile<4, 4, true, kPolyNB>(p, bid, grid, sm);
   } else {
     const CompParams p = BATCH ? plist[batch_view(p_arg, bid, &grid)] : p_arg;  // see k_composite_fwd
     __shared__ BwdShVecShared<CB, PPL, CHRED, (NB > 0)> sm;
@@ -1600,7 +1677,8 @@ k_composite_bwd_chan_vec(CompParams p_arg, const CompParams *__restrict__ plist)
 // reduction costs the same per wave whatever the number of pixels behind it).
 struct Variants {
   int ppl_fwd = 1, ppl_bwd = 4, ppl_fwd_batch = 2, ppl_bwd_batch = 2, ppl_bwd_sh_batch = 4, batch_map = 2;
-  int ppl_fwd_poly = 2;  // pixels per lane (2 | 4) of the per-camera polynomial-basis forward
+  int ppl_fwd_poly = 2;  // pixels per lane (2 | 4) of the per-camera routed forward
+  int ppl_fwd_batch_poly = 4;  // ... of the batched polynomial forward
   int sh_packed = 1;    // 1 = k_composite_bwd_sh_vec, 0 = k_composite_bwd_pixel<MODE_SH>
   int sh_chred = 1;     // channel-wise gradient reduction in k_composite_bwd_sh_vec at 4 pixels per lane
   int chan_packed = 1;  // 1 = k_composite_bwd_chan_vec for RGB / scalar / RGB + heads, 0 = k_composite_bwd_pixel
@@ -1720,8 +1798,15 @@ static void launch_fwd_sh_batch_c(const CompParams &p0, const CompParams *plist,
     // workgroup decides from the bound and ITS view's pixel size whether it runs the polynomial or the exact form
     // (poly_route; forward and backward read the same value, hence agree).
     if (bounded) {
-      if (ppl == 4) hipLaunchKernelGGL((k_composite_fwd_sh_vec<4, 4, true, kRouted>), g, dim3(64), 0, s, p0, plist);
-      else hipLaunchKernelGGL((k_composite_fwd_sh_vec<4, 2, true, kRouted>), g, dim3(128), 0, s, p0, plist);
+      // polynomial kernel over the whole grid (one wavefront per tile: 89 registers, 5 per SIMD -- 5 020 vs 4 833 renders/s
+      // against two wavefronts per tile), then the persistent exact fallback for the views beyond the bound (10 two-wavefront
+      // workgroups per compute unit at most)
+      if (variants().ppl_fwd_batch_poly == 2) hipLaunchKernelGGL((k_composite_fwd_sh_vec<4, 2, true, kPolyNB>), g, dim3(128), 0, s, p0, plist);
+      else hipLaunchKernelGGL((k_composite_fwd_sh_vec<4, 4, true, kPolyNB>), g, dim3(64), 0, s, p0, plist);
+      CompParams pf = p0;
+      pf.vgrid = nblk * B;
+      const uint32_t gf = pf.vgrid < 2560u ? pf.vgrid : 2560u;
+      hipLaunchKernelGGL((k_composite_fwd_sh_vec<4, 2, true, kFallback>), dim3(gf), dim3(128), 0, s, pf, plist);
       return;
     }
   }
@@ -1760,8 +1845,12 @@ template <int CB>
 static void launch_bwd_sh_batch_c(const CompParams &p0, const CompParams *plist, uint32_t B, uint32_t nblk, hipStream_t s, bool bounded) {
   const dim3 g(nblk * B);
   if constexpr (CB == 4) {
-    if (bounded) {  // as the forward: one launch, routed per view on the device
-      hipLaunchKernelGGL((k_composite_bwd_sh_vec<4, 4, true, true, kRouted>), g, dim3(64), 0, s, p0, plist);
+    if (bounded) {  // as the forward: the polynomial kernel (104 registers: 4 wavefronts per SIMD), then the persistent exact fallback
+      hipLaunchKernelGGL((k_composite_bwd_sh_vec<4, 4, true, true, kPolyNB>), g, dim3(64), 0, s, p0, plist);
+      CompParams pf = p0;
+      pf.vgrid = nblk * B;
+      const uint32_t gf = pf.vgrid < 3072u ? pf.vgrid : 3072u;  // 12 one-wavefront workgroups per compute unit
+      hipLaunchKernelGGL((k_composite_bwd_sh_vec<4, 4, true, true, kFallback>), dim3(gf), dim3(64), 0, s, pf, plist);
       return;
     }
   }
@@ -1881,6 +1970,7 @@ int gsgen_debug_set_variant(const char *name, int value) {
   else if (n == "ppl_bwd_batch") slot = &v.ppl_bwd_batch;
   else if (n == "ppl_bwd_sh_batch") slot = &v.ppl_bwd_sh_batch;
   else if (n == "ppl_fwd_poly") { slot = &v.ppl_fwd_poly; ok = value == 2 || value == 4; }
+  else if (n == "ppl_fwd_batch_poly") { slot = &v.ppl_fwd_batch_poly; ok = value == 2 || value == 4; }
   else if (n == "batch_map") { slot = &v.batch_map; ok = value >= 0 && value <= 2; }
   else if (n == "sh_packed") { slot = &v.sh_packed; ok = value == 0 || value == 1; }
   else if (n == "sh_chred") { slot = &v.sh_chred; ok = value == 0 || value == 1; }
@@ -1904,18 +1994,22 @@ int gsgen_kernel_variant(const char *stage, uint32_t C, uint32_t n_segments, cha
   const bool poly_stage = st.size() > 5 && st.compare(st.size() - 5, 5, "_poly") == 0;
   const std::string base = poly_stage ? st.substr(0, st.size() - 5) : st;
   auto sh_bwd = [&](int ppl, const char *b) {
-    if (poly_stage && C == 4) return snprintf(buf, sizeof buf, "k_composite_bwd_sh_vec<C=4,PPL=4%s,CHRED,ROUTED:POLY6|exact>%s", b, n_segments > 1 ? " segmented" : "");
+    if (poly_stage && C == 4)
+      return snprintf(buf, sizeof buf, b[0] ? "k_composite_bwd_sh_vec<C=4,PPL=4%s,CHRED,POLY6>%s + persistent exact fallback"
+                                            : "k_composite_bwd_sh_vec<C=4,PPL=4%s,CHRED,ROUTED:POLY6|exact>%s", b, n_segments > 1 ? " segmented" : "");
     return snprintf(buf, sizeof buf, "%s<%sC=%u,PPL=%d%s%s>%s", (v.sh_packed && ppl != 1) ? "k_composite_bwd_sh_vec" : "k_composite_bwd_pixel",
                     (v.sh_packed && ppl != 1) ? "" : "SH,", C, ppl, b, (v.sh_packed && ppl == 4 && v.sh_chred) ? ",CHRED" : "",
                     n_segments > 1 ? " segmented" : "");
   };
   auto sh_fwd = [&](int ppl, int ppl_poly, const char *b) {
-    if (poly_stage && C == 4) return snprintf(buf, sizeof buf, "k_composite_fwd_sh_vec<C=4,PPL=%d%s,ROUTED:POLY6|exact>", ppl_poly == 4 ? 4 : 2, b);
+    if (poly_stage && C == 4)
+      return snprintf(buf, sizeof buf, b[0] ? "k_composite_fwd_sh_vec<C=4,PPL=%d%s,POLY6> + persistent exact fallback"
+                                            : "k_composite_fwd_sh_vec<C=4,PPL=%d%s,ROUTED:POLY6|exact>", ppl_poly == 4 ? 4 : 2, b);
     if (v.sh_packed && ppl != 1) return snprintf(buf, sizeof buf, "k_composite_fwd_sh_vec<C=%u,PPL=%d%s>", C, ppl, b);
     return snprintf(buf, sizeof buf, "k_composite_fwd<SH,C=%u,PPL=%d%s>", C, ppl, b);
   };
   if (base == "sh_fwd") n = sh_fwd(v.ppl_fwd, v.ppl_fwd_poly, "");
-  else if (base == "sh_fwd_batch") n = sh_fwd(v.ppl_fwd_batch, v.ppl_fwd_batch, ",BATCH");
+  else if (base == "sh_fwd_batch") n = sh_fwd(v.ppl_fwd_batch, v.ppl_fwd_batch_poly, ",BATCH");
   else if (base == "sh_bwd") n = sh_bwd(v.ppl_bwd, "");
   else if (base == "sh_bwd_batch") n = sh_bwd(v.ppl_bwd_sh_batch, ",BATCH");
   else if (st == "rgb_fwd") n = snprintf(buf, sizeof buf, "k_composite_fwd<RGB,PPL=%d>", v.ppl_fwd);
@@ -2196,6 +2290,16 @@ int gsgen_sh_poly_applies(float sh_l1_bound, float max_pixel_size, uint32_t C) {
   return (C == 4 && poly_ok(sh_l1_bound, max_pixel_size)) ? 1 : 0;
 }
 
+// Host-side shortcut of a bounded batch: if NO view of the batch could take the polynomial form even for a coefficient bound as
+// small as 1/16 (very wide cameras: a tile's half diagonal beyond ~0.1 rad), the launch is the plain exact one -- full
+// occupancy, no polynomial kernel that every workgroup would leave, no persistent fallback.  (Exact is always right; forward and
+// backward of a batch apply the same rule to the same pixel sizes.)
+static bool batch_can_be_polynomial(const std::vector<CompParams> &ps) {
+  for (const CompParams &p : ps)
+    if (poly_ok(1.0f / 16.0f, fmaxf(fabsf(p.psx), fabsf(p.psy)))) return true;
+  return false;
+}
+
 size_t gsgen_sh_batch_workspace_bytes(uint32_t n_views) { return 2 * (size_t)n_views * sizeof(CompParams); }
 
 int gsgen_vol_render_sh_batch(uint32_t n_views, const gsgen_sh_view *views, uint32_t N,
@@ -2222,10 +2326,13 @@ int gsgen_vol_render_sh_batch_bounded(uint32_t n_views, const gsgen_sh_view *vie
   if (int e = fill_view_params(n_views, views, sh_coeffs, alpha, nullptr, nullptr, n_tiles_w, n_tiles_h, H, W,
                                thresh, n_segments, false, C == 4 ? sh_l1_bound : nullptr, ps))
     return e;
+  const bool bounded = C == 4 && sh_l1_bound != nullptr && batch_can_be_polynomial(ps);
+  if (!bounded)
+    for (CompParams &p : ps) p.sh_bound = nullptr;
   hipStream_t s = (hipStream_t)stream;
   CompParams *dst = reinterpret_cast<CompParams *>(batch_workspace);
   if (int e = write_params(ps.data(), n_views, dst, s)) return e;
-  return launch_fwd_sh_batch((int)C, ps[0], dst, n_views, s, sh_l1_bound != nullptr);
+  return launch_fwd_sh_batch((int)C, ps[0], dst, n_views, s, bounded);
 }
 
 int gsgen_vol_render_backward_sh_batch(uint32_t n_views, const gsgen_sh_view *views, uint32_t N,
@@ -2253,10 +2360,13 @@ int gsgen_vol_render_backward_sh_batch_bounded(uint32_t n_views, const gsgen_sh_
   if (int e = fill_view_params(n_views, views, sh_coeffs, alpha, grad_sh_coeffs, grad_alpha, n_tiles_w,
                                n_tiles_h, H, W, thresh, n_segments, true, C == 4 ? sh_l1_bound : nullptr, ps))
     return e;
+  const bool bounded = C == 4 && sh_l1_bound != nullptr && batch_can_be_polynomial(ps);
+  if (!bounded)
+    for (CompParams &p : ps) p.sh_bound = nullptr;
   hipStream_t s = (hipStream_t)stream;
   CompParams *dst = reinterpret_cast<CompParams *>(batch_workspace) + n_views;
   if (int e = write_params(ps.data(), n_views, dst, s)) return e;
-  return launch_bwd_sh_batch((int)C, ps[0], dst, n_views, s, sh_l1_bound != nullptr);
+  return launch_bwd_sh_batch((int)C, ps[0], dst, n_views, s, bounded);
 }
 
 static int fill_rgbd_params(uint32_t n_views, const gsgen_rgbd_view *views, const float *color, const float *alpha,

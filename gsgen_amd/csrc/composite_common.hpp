@@ -37,6 +37,7 @@ struct CompParams {
   // host enqueues the ROUTED kernel (composite.hip, kRouted): every workgroup reads S and its view's pixel size and runs the
   // polynomial form of the per-pixel basis or the exact one (poly_route) -- no host decision, no host sync.
   const float *sh_bound;
+  uint32_t vgrid;  // persistent launches (the exact fallback of a bounded batch): size of the virtual grid they stride through
 };
 constexpr int kSegLen = 32;
 
