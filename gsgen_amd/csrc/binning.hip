@@ -489,6 +489,8 @@ k_sort_tiles(uint32_t T, const uint32_t *__restrict__ tile_off, const uint32_t *
 // view's long sorts (one wavefront, up to ~30 us) start at once and the launch ends on the short ones.
 // View-major order measured 134 us for 8 cfg2 views: ~2.5 views resident at a time, each waiting on
 // its longest tile.
+// (forcing this kernel from 134 to 96 registers -- five wavefronts per SIMD, so that it fits beside four polynomial-backward
+// wavefronts -- costs 84 bytes of scratch in the K = 32 path and gains 0.5 %: profiles/r03_ab_sidequeue_sort_slots.txt; not taken)
 __global__ void __launch_bounds__(64)
 k_sort_tiles_views(uint32_t T, uint32_t B, const GeoView *__restrict__ views) {
   const uint32_t rank = blockIdx.x / B;

@@ -1773,6 +1773,19 @@ static int launch_bwd(const CompParams &p_, hipStream_t s) {
   return (int)hipGetLastError();
 }
 
+// ---- the persistent exact fallback of a bounded batch: where it goes ---------------------------------
+// It normally has nothing to do, but its workgroups (174 registers in the backward) must each FIND ROOM on a chip that other
+// batches' compositing launches fill.  Measured on one box (profiles/r03_ab_fallback_order.txt, renders/s on the driver
+// command): no fallback at all (views beyond the bound would be lost) 4 993; fallback IN FRONT of the polynomial kernel on the
+// caller's stream 4 959 (it finds room while the previous stage of the chain drains); behind it 4 919; on a side stream forked
+// from and joined into the caller's stream with events -- meant to hide the wait behind the polynomial kernel -- 4 725 (a fourth
+// and fifth hardware queue in play changes the arbitration for the worse).  Hence: in front, same stream, no extra objects.
+template <class Side, class Main>
+static void launch_beside(hipStream_t s, Side &&side, Main &&main) {
+  side(s);
+  main(s);
+}
+
 // ---- batched cameras: parameters through device memory ----------------------------------------
 constexpr int kPackMax = 8;
 struct CompParamsPack { CompParams v[kPackMax]; };
@@ -1801,12 +1814,16 @@ static void launch_fwd_sh_batch_c(const CompParams &p0, const CompParams *plist,
       // polynomial kernel over the whole grid (one wavefront per tile: 89 registers, 5 per SIMD -- 5 020 vs 4 833 renders/s
       // against two wavefronts per tile), then the persistent exact fallback for the views beyond the bound (10 two-wavefront
       // workgroups per compute unit at most)
-      if (variants().ppl_fwd_batch_poly == 2) hipLaunchKernelGGL((k_composite_fwd_sh_vec<4, 2, true, kPolyNB>), g, dim3(128), 0, s, p0, plist);
-      else hipLaunchKernelGGL((k_composite_fwd_sh_vec<4, 4, true, kPolyNB>), g, dim3(64), 0, s, p0, plist);
       CompParams pf = p0;
       pf.vgrid = nblk * B;
       const uint32_t gf = pf.vgrid < 2560u ? pf.vgrid : 2560u;
-      hipLaunchKernelGGL((k_composite_fwd_sh_vec<4, 2, true, kFallback>), dim3(gf), dim3(128), 0, s, pf, plist);
+      const int ppl_poly = variants().ppl_fwd_batch_poly;
+      launch_beside(
+          s, [&](hipStream_t q) { hipLaunchKernelGGL((k_composite_fwd_sh_vec<4, 2, true, kFallback>), dim3(gf), dim3(128), 0, q, pf, plist); },
+          [&](hipStream_t q) {
+            if (ppl_poly == 2) hipLaunchKernelGGL((k_composite_fwd_sh_vec<4, 2, true, kPolyNB>), g, dim3(128), 0, q, p0, plist);
+            else hipLaunchKernelGGL((k_composite_fwd_sh_vec<4, 4, true, kPolyNB>), g, dim3(64), 0, q, p0, plist);
+          });
       return;
     }
   }
@@ -1846,11 +1863,12 @@ static void launch_bwd_sh_batch_c(const CompParams &p0, const CompParams *plist,
   const dim3 g(nblk * B);
   if constexpr (CB == 4) {
     if (bounded) {  // as the forward: the polynomial kernel (104 registers: 4 wavefronts per SIMD), then the persistent exact fallback
-      hipLaunchKernelGGL((k_composite_bwd_sh_vec<4, 4, true, true, kPolyNB>), g, dim3(64), 0, s, p0, plist);
       CompParams pf = p0;
       pf.vgrid = nblk * B;
-      const uint32_t gf = pf.vgrid < 3072u ? pf.vgrid : 3072u;  // 12 one-wavefront workgroups per compute unit
-      hipLaunchKernelGGL((k_composite_bwd_sh_vec<4, 4, true, true, kFallback>), dim3(gf), dim3(64), 0, s, pf, plist);
+      const uint32_t gf = pf.vgrid < 2048u ? pf.vgrid : 2048u;  // 8 one-wavefront workgroups per compute unit (2 per SIMD)
+      launch_beside(
+          s, [&](hipStream_t q) { hipLaunchKernelGGL((k_composite_bwd_sh_vec<4, 4, true, true, kFallback>), dim3(gf), dim3(64), 0, q, pf, plist); },
+          [&](hipStream_t q) { hipLaunchKernelGGL((k_composite_bwd_sh_vec<4, 4, true, true, kPolyNB>), g, dim3(64), 0, q, p0, plist); });
       return;
     }
   }

@@ -323,5 +323,5 @@ def test_bench_step_loop_dry_run_with_several_ranks(world):
     per = cfg["renders_per_s_per_rank"]
     assert len(per) == world and all(v > 0 for v in per)
     assert res["value"] <= sum(per) * 1.0001  # whole-job throughput over the SLOWEST rank's time
-    assert f"{2 * world} of {2 * world} cameras" in cfg["sh_basis"] and "ROUTED" in res["roofline"]["kernel"]
+    assert f"{2 * world} of {2 * world} cameras" in cfg["sh_basis"] and "POLY6" in res["roofline"]["kernel"]
     assert "all_gather" in cfg["gather"]
