@@ -253,7 +253,7 @@ class PairCountMonitor:
     the oldest entry is waited for (it is `depth` frames old: the wait is short, and an overflow is reported within `depth`
     frames at the latest)."""
 
-    def __init__(self, n, depth=4):
+    def __init__(self, n, depth=16):
         import collections
         self.n, self.depth = int(n), int(depth)
         pin = torch.cuda.is_available()  # (host-only processes -- bench.py's dry run -- get pageable blocks)
