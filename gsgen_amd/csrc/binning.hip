@@ -12,12 +12,16 @@
 // wave64), the Gaussians into chunks of 2048; wave (group, chunk) streams its chunk's
 // rectangles 64 at a time, ballots the ones that touch the group at all (~5 %), and for those
 // every lane tests its own tile.
-//   1. count       cnt[chunk][tile] = hits                                  (no atomics)
-//   2. scan        per tile over chunks, then over the T tiles -> segment offsets
-//   3. emit        the same walk again; lane writes (depth_bits<<32 | id) at
+//   1. count       cnt[chunk][tile] = hits                                  (no atomics in the walk)
+//      + scans     in the SAME launch: the last workgroup of a tile group to finish (one ticket per group) scans the
+//                  group's tiles over the chunks, the last of those scans the T tiles -> segment offsets, launch order
+//   2. emit        the same walk again; lane writes (depth_bits<<32 | id) at
 //                  tile_off[tile] + cnt_prefix[chunk][tile] + running   (id-ascending order)
-//   4. sort        one workgroup per tile sorts its segment IN LDS on the 64-bit key
-//                  (depth bits, then Gaussian id), writes ids back, fills start/end
+//   3. sort        one wavefront per tile sorts its segment in REGISTERS on the 64-bit key
+//                  (depth bits, then Gaussian id), writes ids back, fills start/end; lists longer than 2048 entries:
+//                  2048-entry blocks in registers + the merge stages that span blocks in the (L2-resident) segment
+// -- three dependent launches behind the projection (they were six: a lone render is a chain of dependent launches, each
+// link costs its drain + ~5 us of dispatch).
 // so sort traffic is one read + one write of the pairs instead of 8 global radix passes, and
 // the result is deterministic: keys are unique.  Ordering semantics are the reference's: ascending UNSIGNED float bits of depth
 // (the low word of its int64 key), so negative depths sort after positive ones.
@@ -27,9 +31,6 @@
 #include <vector>
 
 namespace gs {
-
-constexpr int kSortThreads = 256;  // waves 1-3 only work on segments too long for the register sort
-constexpr uint32_t kBigGrid = 32;  // workgroups (per view) walking the long-list front of the launch order
 
 constexpr int kGroup = 8;      // tiles per group side: 8x8 tiles <-> 64 lanes
 constexpr int kChunk = 2048;   // Gaussians per chunk
@@ -74,13 +75,27 @@ struct RectRegs {
   int x0[kIter], y0[kIter], x1[kIter], y1[kIter];
 };
 
+// What the count pass needs to finish the job itself.  done[group] counts the workgroups (one per chunk) of a tile group
+// that have written their counts, done[number of groups] the groups whose chunk scan is complete; both start a frame at
+// zero (k_frame_project / k_write_views / a memset in front of the stand-alone entry point).
+struct BinTail {
+  uint32_t *tile_count, *tile_off, *ctrl, *tile_order, *done, *total_out;
+  uint32_t cap;
+};
+__device__ __forceinline__ void scan_tiles_body(uint32_t T, const uint32_t *__restrict__ tile_count,
+                                                uint32_t *__restrict__ tile_off, uint32_t *__restrict__ ctrl, uint32_t cap,
+                                                uint32_t *__restrict__ total_out);
+__device__ __forceinline__ void order_tiles_body(uint32_t T, const uint32_t *__restrict__ tile_count,
+                                                 uint32_t *__restrict__ tile_order);
+
 template <bool EMIT>
 __device__ __forceinline__ void
 bin_pull_body(uint32_t N, const int *__restrict__ tl, const int *__restrict__ br,
            const float *__restrict__ depth, int ntw, int nth, uint32_t T,
            uint32_t *__restrict__ cnt, uint32_t *__restrict__ wcnt, const uint32_t *__restrict__ tile_off,
-           const uint32_t *__restrict__ ctrl, unsigned long long *__restrict__ keys) {
+           const uint32_t *__restrict__ ctrl, unsigned long long *__restrict__ keys, const BinTail &tail) {
   __shared__ uint32_t s_cnt[kPullWaves][64];
+  __shared__ uint32_t s_ticket;
   if (EMIT && ctrl[1] != 0u) return;  // capacity exceeded: bin nothing
   const GroupGeom q = group_geom(ntw, nth);
   const uint32_t chunk = blockIdx.y;
@@ -130,6 +145,43 @@ bin_pull_body(uint32_t N, const int *__restrict__ tl, const int *__restrict__ br
     __syncthreads();
     if (wave == 0 && q.in_grid)
       cnt[(size_t)chunk * T + q.tile] = s_cnt[0][lane] + s_cnt[1][lane] + s_cnt[2][lane] + s_cnt[3][lane];
+    // ---- the scans, by whoever finishes last (release: counts before the ticket; acquire: the others' counts after it;
+    // agent scope -- the workgroups of a group run on different XCDs, whose L2s are only coherent through these) ----
+    const uint32_t nchunks = gridDim.y, ngroups = gridDim.x;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (threadIdx.x == 0) s_ticket = atomicAdd(&tail.done[blockIdx.x], 1u);
+    __syncthreads();
+    if (s_ticket != nchunks - 1u) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    {  // this group's 64 tiles (lane <-> tile), exclusive scan over the chunks: wavefront w takes the w-th quarter of them
+      const uint32_t per = (nchunks + kPullWaves - 1u) / kPullWaves;
+      const uint32_t c0 = min((uint32_t)wave * per, nchunks), c1 = min(c0 + per, nchunks);
+      uint32_t *col = cnt + (q.in_grid ? q.tile : 0);
+      uint32_t sum = 0;
+      if (q.in_grid)
+        for (uint32_t c = c0; c < c1; ++c) sum += col[(size_t)c * T];
+      s_cnt[wave][lane] = sum;
+      __syncthreads();
+      uint32_t run = 0;
+      for (int w = 0; w < wave; ++w) run += s_cnt[w][lane];
+      if (q.in_grid) {
+        for (uint32_t c = c0; c < c1; ++c) {
+          const uint32_t v = col[(size_t)c * T];
+          col[(size_t)c * T] = run;
+          run += v;
+        }
+        if (wave == kPullWaves - 1) tail.tile_count[q.tile] = run;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (threadIdx.x == 0) s_ticket = atomicAdd(&tail.done[ngroups], 1u);
+    __syncthreads();
+    if (s_ticket != ngroups - 1u) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    scan_tiles_body(T, tail.tile_count, tail.tile_off, tail.ctrl, tail.cap, tail.total_out);
+    order_tiles_body(T, tail.tile_count, tail.tile_order);
     return;
   }
   uint32_t pos = 0;
@@ -156,37 +208,6 @@ bin_pull_body(uint32_t N, const int *__restrict__ tl, const int *__restrict__ br
   }
 }
 
-// per tile: exclusive scan of cnt[.][tile] over the chunks (in place), total -> tile_count.
-// One wave per tile, lanes <-> chunks, DPP prefix scan.
-__device__ __forceinline__ uint32_t wave_scan_add_u32(uint32_t x) {
-  int v = (int)x;
-  const int s1 = __builtin_amdgcn_update_dpp(0, v, kDppRowShr + 1, 0xf, 0xf, false);
-  const int s2 = __builtin_amdgcn_update_dpp(0, v, kDppRowShr + 2, 0xf, 0xf, false);
-  const int s3 = __builtin_amdgcn_update_dpp(0, v, kDppRowShr + 3, 0xf, 0xf, false);
-  v = v + s1 + s2 + s3;
-  v += __builtin_amdgcn_update_dpp(0, v, kDppRowShr + 4, 0xf, 0xe, false);
-  v += __builtin_amdgcn_update_dpp(0, v, kDppRowShr + 8, 0xf, 0xc, false);
-  v += __builtin_amdgcn_update_dpp(0, v, kDppRowBcast15, 0xa, 0xf, false);
-  v += __builtin_amdgcn_update_dpp(0, v, kDppRowBcast31, 0xc, 0xf, false);
-  return (uint32_t)v;
-}
-
-__device__ __forceinline__ void
-scan_chunks_body(uint32_t T, uint32_t nchunks, uint32_t *__restrict__ cnt, uint32_t *__restrict__ tile_count) {
-  const uint32_t t = blockIdx.x * 4u + (threadIdx.x >> 6);  // one wave per tile
-  if (t >= T) return;
-  const uint32_t lane = (uint32_t)lane_id();
-  uint32_t carry = 0;
-  for (uint32_t c0 = 0; c0 < nchunks; c0 += 64u) {
-    const uint32_t c = c0 + lane;
-    const uint32_t v = (c < nchunks) ? cnt[(size_t)c * T + t] : 0u;
-    const uint32_t inc = wave_scan_add_u32(v);
-    if (c < nchunks) cnt[(size_t)c * T + t] = carry + inc - v;
-    carry += (uint32_t)rd_lane((int)inc, 63);
-  }
-  if (lane == 0) tile_count[t] = carry;
-}
-
 // exclusive scan of tile_count[T] -> tile_off[T+1]; ctrl[0] = total, ctrl[1] = overflow flag.
 // Sums SATURATE at 2^32 - 1: a pair count beyond 32 bits (a diverged scene: millions of Gaussians each covering every tile)
 // must read as "does not fit", never wrap round to a small number that does (the emit pass would then write past the
@@ -200,6 +221,7 @@ __device__ __forceinline__ uint32_t sat_add_u32(uint32_t a, uint32_t b) {
 // free wave slots on ONE compute unit and waited 0.3 ms for them whenever another batch's compositing launch filled the chip
 // (profiles/r03_notes.md: 7.9 us alone, 299 us average with three steps in flight).
 constexpr uint32_t kScanThreads = 256;
+static_assert(kScanThreads == 64u * kPullWaves, "the count pass's last workgroup runs these bodies");
 __device__ __forceinline__ void
 scan_tiles_body(uint32_t T, const uint32_t *__restrict__ tile_count, uint32_t *__restrict__ tile_off,
              uint32_t *__restrict__ ctrl, uint32_t cap, uint32_t *__restrict__ total_out) {
@@ -259,34 +281,6 @@ order_tiles_body(uint32_t T, const uint32_t *__restrict__ tile_count, uint32_t *
 
 // normalised bitonic network (every comparator puts the smaller key at the lower index), so
 // a segment of arbitrary length n behaves as if padded with +inf up to the next power of two.
-// LDS / global-memory form, one workgroup: only used for segments longer than 64*kSortMaxK.
-template <typename KeyPtr>
-__device__ __forceinline__ void bitonic_sort(KeyPtr k, uint32_t n, uint32_t tid, uint32_t nthreads) {
-  uint32_t p2 = 1;
-  while (p2 < n) p2 <<= 1;
-  for (uint32_t size = 2; size <= p2; size <<= 1) {
-    // flip step: partner = i ^ (size - 1)
-    for (uint32_t i = tid; i < p2; i += nthreads) {
-      const uint32_t l = i ^ (size - 1u);
-      if (l > i && l < n) {
-        const unsigned long long a = k[i], b = k[l];
-        if (a > b) { k[i] = b; k[l] = a; }
-      }
-    }
-    __syncthreads();
-    for (uint32_t j = size >> 2; j > 0; j >>= 1) {
-      for (uint32_t i = tid; i < p2; i += nthreads) {
-        const uint32_t l = i ^ j;
-        if (l > i && l < n) {
-          const unsigned long long a = k[i], b = k[l];
-          if (a > b) { k[i] = b; k[l] = a; }
-        }
-      }
-      __syncthreads();
-    }
-  }
-}
-
 // Register form: ONE wavefront sorts 64*K keys, K per lane (element e = lane*K + r), with no
 // memory traffic and no barrier: comparators whose partner lies in the same lane are plain
 // register compare-exchanges, the others trade registers with lane ^ m.
@@ -381,12 +375,89 @@ __device__ __forceinline__ void sort_segment_regs(const u64 *__restrict__ keys, 
     if (e < n) ids[e] = (int)(uint32_t)(k[r] & 0xffffffffull);
   }
 }
-constexpr int kSortMaxK = 32;  // 2048 keys in registers; longer segments take the workgroup path
+constexpr int kSortMaxK = 32;  // 2048 keys in registers
 
-// One wavefront per tile, keys in registers, no LDS: the common case (n <= 64 * kSortMaxK).
+// Lists of more than 1024 entries, any length (dense clusters; nothing on the BASELINE workloads is beyond 2048): the SAME
+// wavefront sorts 2048-entry blocks in registers and, when there is more than one block, runs the merge stages of the network
+// that span blocks -- distance >= 2048 -- as passes over the (L2-resident) global segment, four comparators per lane in
+// flight, and every stage's remaining distances 1024 .. 1 in registers again, block by block.  A 8192-entry list is 4 + 8
+// register rounds and 3 global passes; the workgroup-wide network in global memory this replaces (its own launch, one more
+// link in every frame's chain, 91 barrier-separated passes for the same list) was ~10x slower on such a list and
+// cost every frame a launch that normally found nothing to do.
+__device__ __forceinline__ void long_pass(u64 *__restrict__ k, uint32_t n, uint32_t p2, uint32_t dist, bool flip) {
+  // comparator c of p2/2: i = (c / dist) * 2 dist + c % dist; partner i ^ (2 dist - 1) (flip) or i + dist
+  const uint32_t lane = (uint32_t)lane_id();
+  const uint32_t half = p2 >> 1;
+  for (uint32_t cbase = 0; cbase < half; cbase += 256u) {
+    u64 a[4], b[4];
+    uint32_t ia[4], ib[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t c = cbase + (uint32_t)u * 64u + lane;
+      const uint32_t off = c & (dist - 1u);
+      ia[u] = ((c - off) << 1) + off;
+      ib[u] = flip ? (ia[u] ^ (2u * dist - 1u)) : (ia[u] + dist);
+      const bool live = c < half && ib[u] < n;  // ia < ib always; a partner beyond n is +inf padding: nothing moves
+      if (!live) ib[u] = 0xffffffffu;
+      a[u] = live ? k[ia[u]] : 0ull;
+      b[u] = live ? k[ib[u]] : ~0ull;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (ib[u] != 0xffffffffu && a[u] > b[u]) { k[ia[u]] = b[u]; k[ib[u]] = a[u]; }
+  }
+  __syncthreads();  // one wavefront: orders this pass's stores before the next pass's loads
+}
+__device__ __forceinline__ void sort_segment_long(u64 *__restrict__ keys, int *__restrict__ ids, uint32_t n) {
+  constexpr int K = kSortMaxK;
+  constexpr uint32_t kBlock = 64u * K;
+  const uint32_t lane = (uint32_t)lane_id();
+  const uint32_t nblk = (n + kBlock - 1u) / kBlock;
+  u64 k[K];
+  for (uint32_t blk = 0; blk < nblk; ++blk) {
+    const uint32_t e0 = blk * kBlock + lane * K;
+#pragma unroll
+    for (int r = 0; r < K; ++r) k[r] = (e0 + r < n) ? keys[e0 + r] : ~0ull;
+    sort_regs<K>(k);
+    if (nblk == 1u) {
+#pragma unroll
+      for (int r = 0; r < K; ++r)
+        if (e0 + r < n) ids[e0 + r] = (int)(uint32_t)(k[r] & 0xffffffffull);
+      return;
+    }
+#pragma unroll
+    for (int r = 0; r < K; ++r)
+      if (e0 + r < n) keys[e0 + r] = k[r];
+  }
+  __syncthreads();
+  uint32_t p2 = kBlock;
+  while (p2 < n) p2 <<= 1;
+  for (uint32_t size = 2u * kBlock; size <= p2; size <<= 1) {
+    long_pass(keys, n, p2, size >> 1, true);
+    for (uint32_t j = size >> 2; j >= kBlock; j >>= 1) long_pass(keys, n, p2, j, false);
+    const bool last = size == p2;
+    for (uint32_t blk = 0; blk < nblk; ++blk) {
+      const uint32_t e0 = blk * kBlock + lane * K;
+#pragma unroll
+      for (int r = 0; r < K; ++r) k[r] = (e0 + r < n) ? keys[e0 + r] : ~0ull;
+      for (int j = (int)kBlock / 2; j >= K; j >>= 1) cross_step<K>(k, j / K, false);
+      local_tail<K, K / 2>(k);
+#pragma unroll
+      for (int r = 0; r < K; ++r) {
+        if (e0 + r < n) {
+          if (last) ids[e0 + r] = (int)(uint32_t)(k[r] & 0xffffffffull);
+          else keys[e0 + r] = k[r];
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// One wavefront per tile, keys in registers, no LDS.
 __device__ __forceinline__ void
 sort_tiles_body(uint32_t tile, const uint32_t *__restrict__ tile_off, const uint32_t *__restrict__ ctrl,
-             const unsigned long long *__restrict__ keys, int *__restrict__ ids, int *__restrict__ start,
+             unsigned long long *__restrict__ keys, int *__restrict__ ids, int *__restrict__ start,
              int *__restrict__ end) {
   const uint32_t tid = threadIdx.x;
   if (ctrl[1] != 0u) {
@@ -399,43 +470,13 @@ sort_tiles_body(uint32_t tile, const uint32_t *__restrict__ tile_off, const uint
     start[tile] = n ? (int)b : -1;
     end[tile] = n ? (int)e : -1;
   }
-  if (n == 0 || n > 64u * kSortMaxK) return;  // oversized segments: k_sort_tiles_big
+  if (n == 0) return;
   if (n <= 64u) sort_segment_regs<1>(keys + b, ids + b, n);
   else if (n <= 128u) sort_segment_regs<2>(keys + b, ids + b, n);
   else if (n <= 256u) sort_segment_regs<4>(keys + b, ids + b, n);
   else if (n <= 512u) sort_segment_regs<8>(keys + b, ids + b, n);
   else if (n <= 1024u) sort_segment_regs<16>(keys + b, ids + b, n);
-  else sort_segment_regs<32>(keys + b, ids + b, n);
-}
-
-// Segments longer than the register sort can hold (> 2048 entries: dense clusters; none on the BASELINE workloads): one
-// workgroup runs the bitonic network on the global segment itself (L2-resident).  NO LDS: a 32 KiB staging buffer made
-// every launch of this kernel -- which normally finds nothing to do -- wait 0.23 ms on average for LDS on a chip filled by
-// another batch's compositing launch (profiles/r03_notes.md: 5 us alone), on the critical chain of every step.
-__device__ __forceinline__ void
-sort_tiles_big_body(uint32_t T, const uint32_t *__restrict__ tile_off, const uint32_t *__restrict__ ctrl,
-                 unsigned long long *__restrict__ keys, int *__restrict__ ids,
-                 const uint32_t *__restrict__ tile_order) {
-  const uint32_t tid = threadIdx.x;
-  if (ctrl[1] != 0u) return;
-  // With a launch order (order_tiles_body: every list of >= 2040 entries sits in the first bucket) a few
-  // workgroups walk the front of it and stop at the first short list, instead of one workgroup per tile
-  // each finding it has nothing to do: 32 KiB of LDS per workgroup made 20k of those queue for 270 us
-  // behind the compositing kernels of another batch.
-  for (uint32_t r = blockIdx.x; r < T; r += gridDim.x) {
-    const uint32_t tile = tile_order != nullptr ? tile_order[r] : r;
-    const uint32_t b = tile_off[tile], e = tile_off[tile + 1];
-    const uint32_t n = e - b;
-    if (tile_order != nullptr && n < 2040u) break;
-    if (n <= 64u * kSortMaxK) continue;
-    // the network directly on the global segment (one workgroup, so __syncthreads + the L2-coherent stores of this CU
-    // order the passes)
-    unsigned long long *k = keys + b;
-    __syncthreads();
-    bitonic_sort(k, n, tid, kSortThreads);
-    for (uint32_t i = tid; i < n; i += kSortThreads) ids[b + i] = (int)(uint32_t)(k[i] & 0xffffffffull);
-    __syncthreads();
-  }
+  else sort_segment_long(keys + b, ids + b, n);
 }
 
 // ---- self test of the cross-lane primitives (tests/ only; exported for the parity suite) ----
@@ -446,42 +487,19 @@ __global__ void __launch_bounds__(64 * kPullWaves)
 k_bin_pull(uint32_t N, const int *__restrict__ tl, const int *__restrict__ br,
            const float *__restrict__ depth, int ntw, int nth, uint32_t T,
            uint32_t *__restrict__ cnt, uint32_t *__restrict__ wcnt, const uint32_t *__restrict__ tile_off,
-           const uint32_t *__restrict__ ctrl, unsigned long long *__restrict__ keys) {
-  bin_pull_body<EMIT>(N, tl, br, depth, ntw, nth, T, cnt, wcnt, tile_off, ctrl, keys);
+           const uint32_t *__restrict__ ctrl, unsigned long long *__restrict__ keys, BinTail tail) {
+  bin_pull_body<EMIT>(N, tl, br, depth, ntw, nth, T, cnt, wcnt, tile_off, ctrl, keys, tail);
 }
 template <bool EMIT>
 __global__ void __launch_bounds__(64 * kPullWaves)
 k_bin_pull_views(uint32_t N, int ntw, int nth, uint32_t T, const GeoView *__restrict__ views) {
   const GeoView v = views[blockIdx.z];
-  bin_pull_body<EMIT>(N, v.tl, v.br, v.depth, ntw, nth, T, v.cnt, v.wcnt, v.tile_off, v.ctrl, v.keys);
-}
-__global__ void __launch_bounds__(256)
-k_scan_chunks(uint32_t T, uint32_t nchunks, uint32_t *__restrict__ cnt, uint32_t *__restrict__ tile_count) {
-  scan_chunks_body(T, nchunks, cnt, tile_count);
-}
-__global__ void __launch_bounds__(256)
-k_scan_chunks_views(uint32_t T, uint32_t nchunks, const GeoView *__restrict__ views) {
-  const GeoView v = views[blockIdx.y];
-  scan_chunks_body(T, nchunks, v.cnt, v.tile_count);
-}
-// tile offsets and the longest-first launch order in ONE launch: both read tile_count only, both are one workgroup --
-// as two kernels they were two ~5 us links in a lone render's chain of dependent launches
-__global__ void __launch_bounds__(kScanThreads)
-k_scan_order_tiles(uint32_t T, const uint32_t *__restrict__ tile_count, uint32_t *__restrict__ tile_off,
-                   uint32_t *__restrict__ ctrl, uint32_t cap, uint32_t *__restrict__ total_out,
-                   uint32_t *__restrict__ tile_order) {
-  scan_tiles_body(T, tile_count, tile_off, ctrl, cap, total_out);
-  order_tiles_body(T, tile_count, tile_order);
-}
-__global__ void __launch_bounds__(kScanThreads)
-k_scan_order_tiles_views(uint32_t T, const GeoView *__restrict__ views) {
-  const GeoView v = views[blockIdx.y];
-  scan_tiles_body(T, v.tile_count, v.tile_off, v.ctrl, v.cap, v.total);
-  order_tiles_body(T, v.tile_count, v.tile_order);
+  const BinTail tail{v.tile_count, v.tile_off, v.ctrl, v.tile_order, v.done, v.total, v.cap};
+  bin_pull_body<EMIT>(N, v.tl, v.br, v.depth, ntw, nth, T, v.cnt, v.wcnt, v.tile_off, v.ctrl, v.keys, tail);
 }
 __global__ void __launch_bounds__(64)
 k_sort_tiles(uint32_t T, const uint32_t *__restrict__ tile_off, const uint32_t *__restrict__ ctrl,
-             const unsigned long long *__restrict__ keys, int *__restrict__ ids, int *__restrict__ start,
+             unsigned long long *__restrict__ keys, int *__restrict__ ids, int *__restrict__ start,
              int *__restrict__ end) {
   sort_tiles_body(xcd_swizzle(blockIdx.x, gridDim.x), tile_off, ctrl, keys, ids, start, end);
 }
@@ -497,18 +515,6 @@ k_sort_tiles_views(uint32_t T, uint32_t B, const GeoView *__restrict__ views) {
   const GeoView v = views[blockIdx.x - rank * B];
   sort_tiles_body(v.tile_order[rank], v.tile_off, v.ctrl, v.keys, v.ids, v.start, v.end);
 }
-__global__ void __launch_bounds__(kSortThreads)
-k_sort_tiles_big(uint32_t T, const uint32_t *__restrict__ tile_off, const uint32_t *__restrict__ ctrl,
-                 unsigned long long *__restrict__ keys, int *__restrict__ ids,
-                 const uint32_t *__restrict__ tile_order) {
-  sort_tiles_big_body(T, tile_off, ctrl, keys, ids, tile_order);
-}
-__global__ void __launch_bounds__(kSortThreads)
-k_sort_tiles_big_views(uint32_t T, const GeoView *__restrict__ views) {
-  const GeoView v = views[blockIdx.y];
-  sort_tiles_big_body(T, v.tile_off, v.ctrl, v.keys, v.ids, v.tile_order);
-}
-
 template <int P>
 __global__ void __launch_bounds__(64) k_selftest_reduce_scatter(const float *__restrict__ in, float *__restrict__ out) {
   float v[P];
@@ -523,7 +529,7 @@ __global__ void __launch_bounds__(64) k_selftest_reduce_scatter(const float *__r
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct BinWs {
-  uint32_t *tile_count, *tile_off, *ctrl, *cnt, *wcnt, *tile_order;
+  uint32_t *tile_count, *tile_off, *ctrl, *cnt, *wcnt, *tile_order, *done;
   unsigned long long *keys;
   int *tl, *br;  // only in the frame workspace
   uint32_t nchunks;
@@ -540,6 +546,7 @@ static BinWs carve(void *base, uint32_t N, uint32_t D, uint32_t T, bool with_rec
   w.ctrl = w.tile_count ? w.tile_count + T : nullptr;
   w.tile_off = (uint32_t *)take(sizeof(uint32_t) * ((size_t)T + 1));
   w.tile_order = (uint32_t *)take(sizeof(uint32_t) * (size_t)(T ? T : 1));
+  w.done = (uint32_t *)take(sizeof(uint32_t) * ((size_t)T + 1));  // one ticket per tile group (<= T of them) + one
   w.cnt = (uint32_t *)take(sizeof(uint32_t) * (size_t)w.nchunks * T);
   w.wcnt = (uint32_t *)take(sizeof(uint32_t) * (size_t)w.nchunks * kPullWaves * T);
   w.keys = (unsigned long long *)take(sizeof(unsigned long long) * (size_t)(D ? D : 1));
@@ -551,31 +558,30 @@ static BinWs carve(void *base, uint32_t N, uint32_t D, uint32_t T, bool with_rec
   return w;
 }
 
+static inline uint32_t tile_groups(uint32_t ntw, uint32_t nth) {
+  return ((ntw + kGroup - 1) / kGroup) * ((nth + kGroup - 1) / kGroup);
+}
+
+// tickets_zeroed: the projection kernel in front has already reset w.done (the fused frame); otherwise a memset does
 static int bin_and_sort(uint32_t N, uint32_t cap, uint32_t nth, uint32_t ntw, const int *tl,
                         const int *br, const float *depth, int *ids, int *start, int *end,
-                        const BinWs &w, uint32_t *total_out, hipStream_t s) {
+                        const BinWs &w, uint32_t *total_out, bool tickets_zeroed, hipStream_t s) {
   const uint32_t T = nth * ntw;
   if (cap > 0x7fffffffu) return GSGEN_EINVAL;  // start / end / the list positions are int32 (the reference's layout)
-  const uint32_t ngroups = ((ntw + kGroup - 1) / kGroup) * ((nth + kGroup - 1) / kGroup);
+  const uint32_t ngroups = tile_groups(ntw, nth);
   const dim3 gpull(ngroups, w.nchunks);
   const dim3 bpull(64 * kPullWaves);
-  if (N == 0) {
-    if (hipError_t e = hipMemsetAsync(w.cnt, 0, sizeof(uint32_t) * (size_t)w.nchunks * T, s)) return (int)e;
-  } else {
-    hipLaunchKernelGGL((k_bin_pull<false>), gpull, bpull, 0, s, N, tl, br, depth, (int)ntw, (int)nth, T,
-                       w.cnt, w.wcnt, (const uint32_t *)nullptr, (const uint32_t *)nullptr,
-                       (unsigned long long *)nullptr);
-  }
-  hipLaunchKernelGGL(k_scan_chunks, dim3((T + 3) / 4), dim3(256), 0, s, T, w.nchunks,
-                     w.cnt, w.tile_count);
-  hipLaunchKernelGGL(k_scan_order_tiles, dim3(1), dim3(kScanThreads), 0, s, T, w.tile_count, w.tile_off, w.ctrl, cap, total_out,
-                     w.tile_order);
+  const BinTail tail{w.tile_count, w.tile_off, w.ctrl, w.tile_order, w.done, total_out, cap};
+  if (!tickets_zeroed || N == 0)  // (no projection launch in front of an empty frame)
+    if (hipError_t e = hipMemsetAsync(w.done, 0, sizeof(uint32_t) * ((size_t)ngroups + 1), s)) return (int)e;
+  // N == 0: one chunk that walks nothing -- zero counts, and the same tail writes the empty offsets / order / total
+  hipLaunchKernelGGL((k_bin_pull<false>), gpull, bpull, 0, s, N, tl, br, depth, (int)ntw, (int)nth, T,
+                     w.cnt, w.wcnt, (const uint32_t *)nullptr, (const uint32_t *)nullptr,
+                     (unsigned long long *)nullptr, tail);
   if (N)
     hipLaunchKernelGGL((k_bin_pull<true>), gpull, bpull, 0, s, N, tl, br, depth, (int)ntw, (int)nth, T,
-                       w.cnt, w.wcnt, w.tile_off, w.ctrl, w.keys);
+                       w.cnt, w.wcnt, w.tile_off, w.ctrl, w.keys, tail);
   hipLaunchKernelGGL(k_sort_tiles, dim3(T), dim3(64), 0, s, T, w.tile_off, w.ctrl, w.keys, ids, start, end);
-  hipLaunchKernelGGL(k_sort_tiles_big, dim3(T < kBigGrid ? T : kBigGrid), dim3(kSortThreads), 0, s, T, w.tile_off,
-                     w.ctrl, w.keys, ids, (const uint32_t *)w.tile_order);
   return (int)hipGetLastError();
 }
 
@@ -587,11 +593,12 @@ extern "C" {
 
 int gsgen_internal_frame_project(uint32_t N, const float *mean, const float *qvec, const float *svec,
                                  const float *cam, int w, int h, int ntw, float *mean2d, float *cov2d,
-                                 float *depth, uint8_t *mask, int *tl, int *br, gsgen_stream_t stream);
+                                 float *depth, uint8_t *mask, int *tl, int *br, uint32_t *done, uint32_t n_done,
+                                 gsgen_stream_t stream);
 
 int gsgen_internal_frame_project_views(uint32_t N, const float *mean, const float *qvec, const float *svec,
                                        int w, int h, int ntw, const GeoView *host_views, GeoView *dev_views,
-                                       uint32_t B, gsgen_stream_t stream);
+                                       uint32_t B, uint32_t n_done, gsgen_stream_t stream);
 
 // used by legacy.hip: per-segment sort of (depth bits << 32 | id) keys, ids out (ctrl[1] must be 0)
 int gsgen_internal_sort_segments(uint32_t T, const uint32_t *tile_off, const uint32_t *ctrl,
@@ -599,8 +606,6 @@ int gsgen_internal_sort_segments(uint32_t T, const uint32_t *tile_off, const uin
   hipStream_t s = (hipStream_t)stream;
   if (T == 0) return 0;
   hipLaunchKernelGGL(k_sort_tiles, dim3(T), dim3(64), 0, s, T, tile_off, ctrl, keys, ids, start, end);
-  hipLaunchKernelGGL(k_sort_tiles_big, dim3(T), dim3(kSortThreads), 0, s, T, tile_off, ctrl, keys, ids,
-                     (const uint32_t *)nullptr);  // no launch order here: one workgroup per segment
   return (int)hipGetLastError();
 }
 
@@ -646,7 +651,7 @@ int gsgen_tile_culling_aabb_start_end(uint32_t N, uint32_t D, uint32_t n_tiles_h
   const BinWs w = carve(workspace, N, D, T, false);
   if (w.bytes > workspace_bytes) return GSGEN_EWORKSPACE;
   return bin_and_sort(N, D, n_tiles_h, n_tiles_w, aabb_topleft, aabb_bottomright, depth, gaussian_ids,
-                      start, end, w, nullptr, (hipStream_t)stream);
+                      start, end, w, nullptr, false, (hipStream_t)stream);
 }
 
 size_t gsgen_frame_batch_workspace_bytes(uint32_t n_views) { return (size_t)n_views * sizeof(GeoView); }
@@ -673,30 +678,22 @@ int gsgen_frame_geometry_batch(uint32_t n_views, const gsgen_geometry_view *view
     GeoView &g = gv[b];
     g.cam = v.cam; g.mean2d = v.mean2d; g.cov2d = v.cov2d; g.depth = v.depth; g.mask = v.mask;
     g.tl = w.tl; g.br = w.br; g.cnt = w.cnt; g.wcnt = w.wcnt; g.tile_count = w.tile_count; g.tile_off = w.tile_off;
-    g.ctrl = w.ctrl; g.tile_order = w.tile_order; g.keys = w.keys;
+    g.ctrl = w.ctrl; g.tile_order = w.tile_order; g.done = w.done; g.keys = w.keys;
     g.ids = v.gaussian_ids; g.start = v.start; g.end = v.end; g.total = v.total; g.cap = v.D_cap;
   }
   hipStream_t s = (hipStream_t)stream;
   GeoView *dv = reinterpret_cast<GeoView *>(batch_workspace);
+  const uint32_t ngroups = tile_groups(ntw, nth);
+  // five launches: view table (+ tickets) | projection | count + scans | emit | sort
   if (int e = gsgen_internal_frame_project_views(N, mean, qvec, svec, (int)W, (int)H, (int)ntw, gv.data(), dv,
-                                                 n_views, stream))
+                                                 n_views, ngroups + 1, stream))
     return e;
   const uint32_t B = n_views;
-  const uint32_t ngroups = ((ntw + kGroup - 1) / kGroup) * ((nth + kGroup - 1) / kGroup);
   const dim3 gpull(ngroups, nchunks, B), bpull(64 * kPullWaves);
-  if (N == 0) {
-    for (uint32_t b = 0; b < B; ++b)
-      if (hipError_t e = hipMemsetAsync(gv[b].cnt, 0, sizeof(uint32_t) * (size_t)nchunks * T, s)) return (int)e;
-  } else {
-    hipLaunchKernelGGL((k_bin_pull_views<false>), gpull, bpull, 0, s, N, (int)ntw, (int)nth, T, (const GeoView *)dv);
-  }
-  hipLaunchKernelGGL(k_scan_chunks_views, dim3((T + 3) / 4, B), dim3(256), 0, s, T, nchunks, (const GeoView *)dv);
-  hipLaunchKernelGGL(k_scan_order_tiles_views, dim3(1, B), dim3(kScanThreads), 0, s, T, (const GeoView *)dv);
-  if (N)
+  hipLaunchKernelGGL((k_bin_pull_views<false>), gpull, bpull, 0, s, N, (int)ntw, (int)nth, T, (const GeoView *)dv);
+  if (N)  // (N == 0: the count pass walks nothing and its tail writes the empty offsets / order / totals)
     hipLaunchKernelGGL((k_bin_pull_views<true>), gpull, bpull, 0, s, N, (int)ntw, (int)nth, T, (const GeoView *)dv);
   hipLaunchKernelGGL(k_sort_tiles_views, dim3(T * B), dim3(64), 0, s, T, B, (const GeoView *)dv);
-  hipLaunchKernelGGL(k_sort_tiles_big_views, dim3(T < kBigGrid ? T : kBigGrid, B), dim3(kSortThreads), 0, s, T,
-                     (const GeoView *)dv);
   return (int)hipGetLastError();
 }
 
@@ -722,10 +719,11 @@ int gsgen_frame_geometry(uint32_t N, const float *mean, const float *qvec, const
   const BinWs w = carve(workspace, N, D_cap, T, true);
   if (w.bytes > workspace_bytes) return GSGEN_EWORKSPACE;
   hipStream_t s = (hipStream_t)stream;
+  // four launches: projection (+ tickets) | count + scans | emit | sort
   if (int e = gsgen_internal_frame_project(N, mean, qvec, svec, cam, (int)W, (int)H, (int)ntw, mean2d,
-                                           cov2d, depth, mask, w.tl, w.br, stream))
+                                           cov2d, depth, mask, w.tl, w.br, w.done, tile_groups(ntw, nth) + 1, stream))
     return e;
-  return bin_and_sort(N, D_cap, nth, ntw, w.tl, w.br, depth, gaussian_ids, start, end, w, total, s);
+  return bin_and_sort(N, D_cap, nth, ntw, w.tl, w.br, depth, gaussian_ids, start, end, w, total, true, s);
 }
 
 }  // extern "C"

@@ -400,7 +400,7 @@ struct GeoView {
   float *mean2d, *cov2d, *depth;
   uint8_t *mask;
   int *tl, *br;
-  uint32_t *cnt, *wcnt, *tile_count, *tile_off, *ctrl, *tile_order;
+  uint32_t *cnt, *wcnt, *tile_count, *tile_off, *ctrl, *tile_order, *done;
   unsigned long long *keys;
   int *ids, *start, *end;
   uint32_t *total;

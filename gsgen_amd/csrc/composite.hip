@@ -1118,6 +1118,7 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
         for (int i = NSH / 2; i < P / 2; ++i) gr2[i] = v2f{0.0f, 0.0f};
       }
       const float *cg = POLY ? &Ws[g * 3 * CCP] : &S.col[g * TR::NCOLP];
+      v2f pch[POLY ? 3 : 1][3];  // POLY: the channels' six components each, reduced after the geometric part
       v2f w2[NP], inv1m2[NP], pAG2[NP];
 #pragma unroll
       for (int jp = 0; jp < NP; ++jp) {
@@ -1174,8 +1175,8 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
           }
           const float G0 = add_scalar(g0[0], g0[1]), G1 = add_scalar(g1[0], g1[1]), G2s = add_scalar(g2[0], g2[1]);
           const float uG0 = pu * G0;
-          v2f t4[PCH / 2] = {v2f{G0, G1}, v2f{uG0, G2s}, v2f{pu * G1, pu * uG0}, v2f{0.0f, 0.0f}};  // (1, v, u, v^2, uv, u^2 | 0, 0)
-          chsum[c] = wave_reduce_scatter2_rows<PCH>(t4);
+          // (1, v, u, v^2, uv, u^2): six of the channel's eight reduction slots; the last two carry geometric components (below)
+          pch[c][0] = v2f{G0, G1}; pch[c][1] = v2f{uG0, G2s}; pch[c][2] = v2f{pu * G1, pu * uG0};
         }
       }
       if constexpr (!POLY) {
@@ -1258,7 +1259,41 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
       const float m0 = gm0[0] + gm0[1], m1 = gm1[0] + gm1[1];
       const float c0 = gc0[0] + gc0[1], c1 = gc1[0] + gc1[1], c3 = gc3[0] + gc3[1];
       const float ga = gal[0] + gal[1];
-      if constexpr (CHRED) {
+      if constexpr (CHRED && POLY) {
+        // The six DISTINCT geometric components (grad_cov[1] and grad_cov[2] receive the same value, kernels.h:414-415) ride
+        // in the two spare slots of the three channels' 8-wide reductions: (m0, m1) | (c0, c1) | (c3, alpha).  No fourth
+        // reduction: 363 -> 348 vector instructions per (wavefront, entry).
+        v2f t0[4] = {pch[0][0], pch[0][1], pch[0][2], v2f{m0, m1}};
+        v2f t1[4] = {pch[1][0], pch[1][1], pch[1][2], v2f{c0, c1}};
+        v2f t2[4] = {pch[2][0], pch[2][1], pch[2][2], v2f{c3, ga}};
+        const float s0 = wave_reduce_scatter2_rows<8>(t0), s1 = wave_reduce_scatter2_rows<8>(t1), s2 = wave_reduce_scatter2_rows<8>(t2);
+        const float tot = quad_reduce_scatter4(s0, s1, s2, 0.0f);
+        const int m = lane & 3;  // the vector this lane ends up with: channel 0 / 1 / 2 (3: nothing)
+        const int comp = scatter_comp<8>(lane);
+        const bool owner = m < 3 && scatter_rows_owner<8>(lane);
+        const size_t id = (size_t)S.id[g];
+        // d L / d sh[c][k] = sum_r gw[c][r] V[r][k]: the 18 reduced values go through LDS, lanes (c, k) = (lane / 16,
+        // lane % 16) expand them with their column of V (one wavefront per workgroup: the barrier is a wait)
+        if (owner && comp < kPolyNB) gw_s[m * 8 + comp] = tot;
+        __syncthreads();
+        if (lane < 48) {
+          const float *gw = &gw_s[(lane >> 4) * 8];
+          float acc = gw[0] * Vk[0];
+#pragma unroll
+          for (int r = 1; r < kPolyNB; ++r) acc = fmaf(gw[r], Vk[r], acc);
+          atomicAdd(p.g_col + (size_t)TR::NCOL * id + lane, acc);  // (c, k) -> 16 c + k = lane
+        }
+        if (owner && comp >= 6) {
+          const int e = comp - 6;
+          float *dst;
+          if (m == 0) dst = p.g_mean + 2 * id + e;                   // m0, m1
+          else if (m == 1) dst = p.g_cov + 4 * id + e;               // c0, c1 (-> cov[1]; cov[2] below)
+          else dst = e == 0 ? p.g_cov + 4 * id + 3 : p.g_alpha + id; // c3, alpha
+          atomicAdd(dst, tot);
+          if (m == 1 && e == 1) atomicAdd(p.g_cov + 4 * id + 2, tot);
+        }
+        __syncthreads();  // gw_s is consumed before the next splat overwrites it
+      } else if constexpr (CHRED) {
         // grad_cov[1] and grad_cov[2] receive the same value (kernels.h:414-415)
         v2f ex[4] = {v2f{m0, m1}, v2f{c0, c1}, v2f{c1, c3}, v2f{ga, 0.0f}};
         const float exsum = wave_reduce_scatter2_rows<8>(ex);
@@ -1266,21 +1301,7 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
         const int m = lane & 3;  // the vector this lane ends up with: channel 0 / 1 / 2 / geometric
         const size_t id = (size_t)S.id[g];
         float *dst = nullptr;
-        if constexpr (POLY) {
-          // d L / d sh[c][k] = sum_r gw[c][r] V[r][k]: the 18 reduced values go through LDS, lanes (c, k) = (lane / 16,
-          // lane % 16) expand them with their column of V (one wavefront per workgroup: the barrier is a wait)
-          if (m < 3 && scatter_rows_owner<PCH>(lane)) gw_s[m * 8 + scatter_comp<PCH>(lane)] = tot;
-          __syncthreads();
-          if (lane < 48) {
-            const float *gw = &gw_s[(lane >> 4) * 8];
-            float acc = gw[0] * Vk[0];
-#pragma unroll
-            for (int r = 1; r < kPolyNB; ++r) acc = fmaf(gw[r], Vk[r], acc);
-            atomicAdd(p.g_col + (size_t)TR::NCOL * id + lane, acc);  // (c, k) -> 16 c + k = lane
-          }
-          __syncthreads();  // the values are consumed before the next splat overwrites them
-        }
-        if (!POLY && m < 3) {
+        if (m < 3) {
           const int k = scatter_comp<PCH>(lane);
           if (scatter_rows_owner<PCH>(lane) && k < TR::CC) dst = p.g_col + (size_t)TR::NCOL * id + m * TR::CC + k;
         } else if (m == 3 && scatter_rows_owner<8>(lane)) {

@@ -397,7 +397,7 @@ def test_emulated_reduce_scatter(emu, Pc):
 
 def test_emulated_sort_register_widths(emu):
     """register sort K = 1..32 and the workgroup path under emulation"""
-    sizes = (1, 64, 65, 130, 300, 600, 1100, 2049)
+    sizes = (1, 64, 65, 130, 300, 600, 1100, 2048, 2049, 4097, 9000)   # > 2048: register blocks + global merge passes
     ntw, nth = len(sizes), 1
     rng = np.random.default_rng(12)
     tl_l, dep_l = [], []
@@ -968,7 +968,8 @@ def test_no_kernel_spills_and_hot_kernels_keep_their_occupancy(tmp_path):
         assert bwd["vgpr_count"] <= 128
     for fwd in find(2, "k_composite_fwdILi2ELi4ELi1E", "ELi16EE"):      # default SH forward: 4 wavefronts per tile
         assert fwd["vgpr_count"] <= 128
-    assert find(1, "k_sort_tiles", "PKjS1_PKyPiS4_S4_")[0]["group_segment_fixed_size"] == 0  # register sort: no LDS
+    for srt in find(2, "k_sort_tiles"):   # register sort, no LDS, three wavefronts per SIMD; long lists in the same launch
+        assert srt["group_segment_fixed_size"] == 0 and srt["vgpr_count"] <= 168, srt
 
 
 @pytest.mark.parametrize("mode", [0, 1])
