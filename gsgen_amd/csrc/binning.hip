@@ -12,16 +12,13 @@
 // wave64), the Gaussians into chunks of 2048; wave (group, chunk) streams its chunk's
 // rectangles 64 at a time, ballots the ones that touch the group at all (~5 %), and for those
 // every lane tests its own tile.
-//   1. count       cnt[chunk][tile] = hits                                  (no atomics in the walk)
-//      + scans     in the SAME launch: the last workgroup of a tile group to finish (one ticket per group) scans the
-//                  group's tiles over the chunks, the last of those scans the T tiles -> segment offsets, launch order
-//   2. emit        the same walk again; lane writes (depth_bits<<32 | id) at
+//   1. count       cnt[chunk][tile] = hits                                  (no atomics)
+//   2. scan        per tile over chunks, then over the T tiles -> segment offsets
+//   3. emit        the same walk again; lane writes (depth_bits<<32 | id) at
 //                  tile_off[tile] + cnt_prefix[chunk][tile] + running   (id-ascending order)
-//   3. sort        one wavefront per tile sorts its segment in REGISTERS on the 64-bit key
+//   4. sort        one wavefront per tile sorts its segment in REGISTERS on the 64-bit key
 //                  (depth bits, then Gaussian id), writes ids back, fills start/end; lists longer than 2048 entries:
 //                  2048-entry blocks in registers + the merge stages that span blocks in the (L2-resident) segment
-// -- three dependent launches behind the projection (they were six: a lone render is a chain of dependent launches, each
-// link costs its drain + ~5 us of dispatch).
 // so sort traffic is one read + one write of the pairs instead of 8 global radix passes, and
 // the result is deterministic: keys are unique.  Ordering semantics are the reference's: ascending UNSIGNED float bits of depth
 // (the low word of its int64 key), so negative depths sort after positive ones.
@@ -75,27 +72,13 @@ struct RectRegs {
   int x0[kIter], y0[kIter], x1[kIter], y1[kIter];
 };
 
-// What the count pass needs to finish the job itself.  done[group] counts the workgroups (one per chunk) of a tile group
-// that have written their counts, done[number of groups] the groups whose chunk scan is complete; both start a frame at
-// zero (k_frame_project / k_write_views / a memset in front of the stand-alone entry point).
-struct BinTail {
-  uint32_t *tile_count, *tile_off, *ctrl, *tile_order, *done, *total_out;
-  uint32_t cap;
-};
-__device__ __forceinline__ void scan_tiles_body(uint32_t T, const uint32_t *__restrict__ tile_count,
-                                                uint32_t *__restrict__ tile_off, uint32_t *__restrict__ ctrl, uint32_t cap,
-                                                uint32_t *__restrict__ total_out);
-__device__ __forceinline__ void order_tiles_body(uint32_t T, const uint32_t *__restrict__ tile_count,
-                                                 uint32_t *__restrict__ tile_order);
-
 template <bool EMIT>
 __device__ __forceinline__ void
 bin_pull_body(uint32_t N, const int *__restrict__ tl, const int *__restrict__ br,
            const float *__restrict__ depth, int ntw, int nth, uint32_t T,
            uint32_t *__restrict__ cnt, uint32_t *__restrict__ wcnt, const uint32_t *__restrict__ tile_off,
-           const uint32_t *__restrict__ ctrl, unsigned long long *__restrict__ keys, const BinTail &tail) {
+           const uint32_t *__restrict__ ctrl, unsigned long long *__restrict__ keys) {
   __shared__ uint32_t s_cnt[kPullWaves][64];
-  __shared__ uint32_t s_ticket;
   if (EMIT && ctrl[1] != 0u) return;  // capacity exceeded: bin nothing
   const GroupGeom q = group_geom(ntw, nth);
   const uint32_t chunk = blockIdx.y;
@@ -145,43 +128,6 @@ bin_pull_body(uint32_t N, const int *__restrict__ tl, const int *__restrict__ br
     __syncthreads();
     if (wave == 0 && q.in_grid)
       cnt[(size_t)chunk * T + q.tile] = s_cnt[0][lane] + s_cnt[1][lane] + s_cnt[2][lane] + s_cnt[3][lane];
-    // ---- the scans, by whoever finishes last (release: counts before the ticket; acquire: the others' counts after it;
-    // agent scope -- the workgroups of a group run on different XCDs, whose L2s are only coherent through these) ----
-    const uint32_t nchunks = gridDim.y, ngroups = gridDim.x;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __syncthreads();
-    if (threadIdx.x == 0) s_ticket = atomicAdd(&tail.done[blockIdx.x], 1u);
-    __syncthreads();
-    if (s_ticket != nchunks - 1u) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    {  // this group's 64 tiles (lane <-> tile), exclusive scan over the chunks: wavefront w takes the w-th quarter of them
-      const uint32_t per = (nchunks + kPullWaves - 1u) / kPullWaves;
-      const uint32_t c0 = min((uint32_t)wave * per, nchunks), c1 = min(c0 + per, nchunks);
-      uint32_t *col = cnt + (q.in_grid ? q.tile : 0);
-      uint32_t sum = 0;
-      if (q.in_grid)
-        for (uint32_t c = c0; c < c1; ++c) sum += col[(size_t)c * T];
-      s_cnt[wave][lane] = sum;
-      __syncthreads();
-      uint32_t run = 0;
-      for (int w = 0; w < wave; ++w) run += s_cnt[w][lane];
-      if (q.in_grid) {
-        for (uint32_t c = c0; c < c1; ++c) {
-          const uint32_t v = col[(size_t)c * T];
-          col[(size_t)c * T] = run;
-          run += v;
-        }
-        if (wave == kPullWaves - 1) tail.tile_count[q.tile] = run;
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __syncthreads();
-    if (threadIdx.x == 0) s_ticket = atomicAdd(&tail.done[ngroups], 1u);
-    __syncthreads();
-    if (s_ticket != ngroups - 1u) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    scan_tiles_body(T, tail.tile_count, tail.tile_off, tail.ctrl, tail.cap, tail.total_out);
-    order_tiles_body(T, tail.tile_count, tail.tile_order);
     return;
   }
   uint32_t pos = 0;
@@ -208,6 +154,37 @@ bin_pull_body(uint32_t N, const int *__restrict__ tl, const int *__restrict__ br
   }
 }
 
+// per tile: exclusive scan of cnt[.][tile] over the chunks (in place), total -> tile_count.
+// One wave per tile, lanes <-> chunks, DPP prefix scan.
+__device__ __forceinline__ uint32_t wave_scan_add_u32(uint32_t x) {
+  int v = (int)x;
+  const int s1 = __builtin_amdgcn_update_dpp(0, v, kDppRowShr + 1, 0xf, 0xf, false);
+  const int s2 = __builtin_amdgcn_update_dpp(0, v, kDppRowShr + 2, 0xf, 0xf, false);
+  const int s3 = __builtin_amdgcn_update_dpp(0, v, kDppRowShr + 3, 0xf, 0xf, false);
+  v = v + s1 + s2 + s3;
+  v += __builtin_amdgcn_update_dpp(0, v, kDppRowShr + 4, 0xf, 0xe, false);
+  v += __builtin_amdgcn_update_dpp(0, v, kDppRowShr + 8, 0xf, 0xc, false);
+  v += __builtin_amdgcn_update_dpp(0, v, kDppRowBcast15, 0xa, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, kDppRowBcast31, 0xc, 0xf, false);
+  return (uint32_t)v;
+}
+
+__device__ __forceinline__ void
+scan_chunks_body(uint32_t T, uint32_t nchunks, uint32_t *__restrict__ cnt, uint32_t *__restrict__ tile_count) {
+  const uint32_t t = blockIdx.x * 4u + (threadIdx.x >> 6);  // one wave per tile
+  if (t >= T) return;
+  const uint32_t lane = (uint32_t)lane_id();
+  uint32_t carry = 0;
+  for (uint32_t c0 = 0; c0 < nchunks; c0 += 64u) {
+    const uint32_t c = c0 + lane;
+    const uint32_t v = (c < nchunks) ? cnt[(size_t)c * T + t] : 0u;
+    const uint32_t inc = wave_scan_add_u32(v);
+    if (c < nchunks) cnt[(size_t)c * T + t] = carry + inc - v;
+    carry += (uint32_t)rd_lane((int)inc, 63);
+  }
+  if (lane == 0) tile_count[t] = carry;
+}
+
 // exclusive scan of tile_count[T] -> tile_off[T+1]; ctrl[0] = total, ctrl[1] = overflow flag.
 // Sums SATURATE at 2^32 - 1: a pair count beyond 32 bits (a diverged scene: millions of Gaussians each covering every tile)
 // must read as "does not fit", never wrap round to a small number that does (the emit pass would then write past the
@@ -221,7 +198,6 @@ __device__ __forceinline__ uint32_t sat_add_u32(uint32_t a, uint32_t b) {
 // free wave slots on ONE compute unit and waited 0.3 ms for them whenever another batch's compositing launch filled the chip
 // (profiles/r03_notes.md: 7.9 us alone, 299 us average with three steps in flight).
 constexpr uint32_t kScanThreads = 256;
-static_assert(kScanThreads == 64u * kPullWaves, "the count pass's last workgroup runs these bodies");
 __device__ __forceinline__ void
 scan_tiles_body(uint32_t T, const uint32_t *__restrict__ tile_count, uint32_t *__restrict__ tile_off,
              uint32_t *__restrict__ ctrl, uint32_t cap, uint32_t *__restrict__ total_out) {
@@ -487,15 +463,38 @@ __global__ void __launch_bounds__(64 * kPullWaves)
 k_bin_pull(uint32_t N, const int *__restrict__ tl, const int *__restrict__ br,
            const float *__restrict__ depth, int ntw, int nth, uint32_t T,
            uint32_t *__restrict__ cnt, uint32_t *__restrict__ wcnt, const uint32_t *__restrict__ tile_off,
-           const uint32_t *__restrict__ ctrl, unsigned long long *__restrict__ keys, BinTail tail) {
-  bin_pull_body<EMIT>(N, tl, br, depth, ntw, nth, T, cnt, wcnt, tile_off, ctrl, keys, tail);
+           const uint32_t *__restrict__ ctrl, unsigned long long *__restrict__ keys) {
+  bin_pull_body<EMIT>(N, tl, br, depth, ntw, nth, T, cnt, wcnt, tile_off, ctrl, keys);
 }
 template <bool EMIT>
 __global__ void __launch_bounds__(64 * kPullWaves)
 k_bin_pull_views(uint32_t N, int ntw, int nth, uint32_t T, const GeoView *__restrict__ views) {
   const GeoView v = views[blockIdx.z];
-  const BinTail tail{v.tile_count, v.tile_off, v.ctrl, v.tile_order, v.done, v.total, v.cap};
-  bin_pull_body<EMIT>(N, v.tl, v.br, v.depth, ntw, nth, T, v.cnt, v.wcnt, v.tile_off, v.ctrl, v.keys, tail);
+  bin_pull_body<EMIT>(N, v.tl, v.br, v.depth, ntw, nth, T, v.cnt, v.wcnt, v.tile_off, v.ctrl, v.keys);
+}
+__global__ void __launch_bounds__(256)
+k_scan_chunks(uint32_t T, uint32_t nchunks, uint32_t *__restrict__ cnt, uint32_t *__restrict__ tile_count) {
+  scan_chunks_body(T, nchunks, cnt, tile_count);
+}
+__global__ void __launch_bounds__(256)
+k_scan_chunks_views(uint32_t T, uint32_t nchunks, const GeoView *__restrict__ views) {
+  const GeoView v = views[blockIdx.y];
+  scan_chunks_body(T, nchunks, v.cnt, v.tile_count);
+}
+// tile offsets and the longest-first launch order in ONE launch: both read tile_count only, both are one workgroup --
+// as two kernels they were two ~5 us links in a lone render's chain of dependent launches
+__global__ void __launch_bounds__(kScanThreads)
+k_scan_order_tiles(uint32_t T, const uint32_t *__restrict__ tile_count, uint32_t *__restrict__ tile_off,
+                   uint32_t *__restrict__ ctrl, uint32_t cap, uint32_t *__restrict__ total_out,
+                   uint32_t *__restrict__ tile_order) {
+  scan_tiles_body(T, tile_count, tile_off, ctrl, cap, total_out);
+  order_tiles_body(T, tile_count, tile_order);
+}
+__global__ void __launch_bounds__(kScanThreads)
+k_scan_order_tiles_views(uint32_t T, const GeoView *__restrict__ views) {
+  const GeoView v = views[blockIdx.y];
+  scan_tiles_body(T, v.tile_count, v.tile_off, v.ctrl, v.cap, v.total);
+  order_tiles_body(T, v.tile_count, v.tile_order);
 }
 __global__ void __launch_bounds__(64)
 k_sort_tiles(uint32_t T, const uint32_t *__restrict__ tile_off, const uint32_t *__restrict__ ctrl,
@@ -529,7 +528,7 @@ __global__ void __launch_bounds__(64) k_selftest_reduce_scatter(const float *__r
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct BinWs {
-  uint32_t *tile_count, *tile_off, *ctrl, *cnt, *wcnt, *tile_order, *done;
+  uint32_t *tile_count, *tile_off, *ctrl, *cnt, *wcnt, *tile_order;
   unsigned long long *keys;
   int *tl, *br;  // only in the frame workspace
   uint32_t nchunks;
@@ -546,7 +545,6 @@ static BinWs carve(void *base, uint32_t N, uint32_t D, uint32_t T, bool with_rec
   w.ctrl = w.tile_count ? w.tile_count + T : nullptr;
   w.tile_off = (uint32_t *)take(sizeof(uint32_t) * ((size_t)T + 1));
   w.tile_order = (uint32_t *)take(sizeof(uint32_t) * (size_t)(T ? T : 1));
-  w.done = (uint32_t *)take(sizeof(uint32_t) * ((size_t)T + 1));  // one ticket per tile group (<= T of them) + one
   w.cnt = (uint32_t *)take(sizeof(uint32_t) * (size_t)w.nchunks * T);
   w.wcnt = (uint32_t *)take(sizeof(uint32_t) * (size_t)w.nchunks * kPullWaves * T);
   w.keys = (unsigned long long *)take(sizeof(unsigned long long) * (size_t)(D ? D : 1));
@@ -558,29 +556,28 @@ static BinWs carve(void *base, uint32_t N, uint32_t D, uint32_t T, bool with_rec
   return w;
 }
 
-static inline uint32_t tile_groups(uint32_t ntw, uint32_t nth) {
-  return ((ntw + kGroup - 1) / kGroup) * ((nth + kGroup - 1) / kGroup);
-}
-
-// tickets_zeroed: the projection kernel in front has already reset w.done (the fused frame); otherwise a memset does
 static int bin_and_sort(uint32_t N, uint32_t cap, uint32_t nth, uint32_t ntw, const int *tl,
                         const int *br, const float *depth, int *ids, int *start, int *end,
-                        const BinWs &w, uint32_t *total_out, bool tickets_zeroed, hipStream_t s) {
+                        const BinWs &w, uint32_t *total_out, hipStream_t s) {
   const uint32_t T = nth * ntw;
   if (cap > 0x7fffffffu) return GSGEN_EINVAL;  // start / end / the list positions are int32 (the reference's layout)
-  const uint32_t ngroups = tile_groups(ntw, nth);
+  const uint32_t ngroups = ((ntw + kGroup - 1) / kGroup) * ((nth + kGroup - 1) / kGroup);
   const dim3 gpull(ngroups, w.nchunks);
   const dim3 bpull(64 * kPullWaves);
-  const BinTail tail{w.tile_count, w.tile_off, w.ctrl, w.tile_order, w.done, total_out, cap};
-  if (!tickets_zeroed || N == 0)  // (no projection launch in front of an empty frame)
-    if (hipError_t e = hipMemsetAsync(w.done, 0, sizeof(uint32_t) * ((size_t)ngroups + 1), s)) return (int)e;
-  // N == 0: one chunk that walks nothing -- zero counts, and the same tail writes the empty offsets / order / total
-  hipLaunchKernelGGL((k_bin_pull<false>), gpull, bpull, 0, s, N, tl, br, depth, (int)ntw, (int)nth, T,
-                     w.cnt, w.wcnt, (const uint32_t *)nullptr, (const uint32_t *)nullptr,
-                     (unsigned long long *)nullptr, tail);
+  if (N == 0) {
+    if (hipError_t e = hipMemsetAsync(w.cnt, 0, sizeof(uint32_t) * (size_t)w.nchunks * T, s)) return (int)e;
+  } else {
+    hipLaunchKernelGGL((k_bin_pull<false>), gpull, bpull, 0, s, N, tl, br, depth, (int)ntw, (int)nth, T,
+                       w.cnt, w.wcnt, (const uint32_t *)nullptr, (const uint32_t *)nullptr,
+                       (unsigned long long *)nullptr);
+  }
+  hipLaunchKernelGGL(k_scan_chunks, dim3((T + 3) / 4), dim3(256), 0, s, T, w.nchunks,
+                     w.cnt, w.tile_count);
+  hipLaunchKernelGGL(k_scan_order_tiles, dim3(1), dim3(kScanThreads), 0, s, T, w.tile_count, w.tile_off, w.ctrl, cap, total_out,
+                     w.tile_order);
   if (N)
     hipLaunchKernelGGL((k_bin_pull<true>), gpull, bpull, 0, s, N, tl, br, depth, (int)ntw, (int)nth, T,
-                       w.cnt, w.wcnt, w.tile_off, w.ctrl, w.keys, tail);
+                       w.cnt, w.wcnt, w.tile_off, w.ctrl, w.keys);
   hipLaunchKernelGGL(k_sort_tiles, dim3(T), dim3(64), 0, s, T, w.tile_off, w.ctrl, w.keys, ids, start, end);
   return (int)hipGetLastError();
 }
@@ -593,12 +590,11 @@ extern "C" {
 
 int gsgen_internal_frame_project(uint32_t N, const float *mean, const float *qvec, const float *svec,
                                  const float *cam, int w, int h, int ntw, float *mean2d, float *cov2d,
-                                 float *depth, uint8_t *mask, int *tl, int *br, uint32_t *done, uint32_t n_done,
-                                 gsgen_stream_t stream);
+                                 float *depth, uint8_t *mask, int *tl, int *br, gsgen_stream_t stream);
 
 int gsgen_internal_frame_project_views(uint32_t N, const float *mean, const float *qvec, const float *svec,
                                        int w, int h, int ntw, const GeoView *host_views, GeoView *dev_views,
-                                       uint32_t B, uint32_t n_done, gsgen_stream_t stream);
+                                       uint32_t B, gsgen_stream_t stream);
 
 // used by legacy.hip: per-segment sort of (depth bits << 32 | id) keys, ids out (ctrl[1] must be 0)
 int gsgen_internal_sort_segments(uint32_t T, const uint32_t *tile_off, const uint32_t *ctrl,
@@ -651,7 +647,7 @@ int gsgen_tile_culling_aabb_start_end(uint32_t N, uint32_t D, uint32_t n_tiles_h
   const BinWs w = carve(workspace, N, D, T, false);
   if (w.bytes > workspace_bytes) return GSGEN_EWORKSPACE;
   return bin_and_sort(N, D, n_tiles_h, n_tiles_w, aabb_topleft, aabb_bottomright, depth, gaussian_ids,
-                      start, end, w, nullptr, false, (hipStream_t)stream);
+                      start, end, w, nullptr, (hipStream_t)stream);
 }
 
 size_t gsgen_frame_batch_workspace_bytes(uint32_t n_views) { return (size_t)n_views * sizeof(GeoView); }
@@ -678,20 +674,26 @@ int gsgen_frame_geometry_batch(uint32_t n_views, const gsgen_geometry_view *view
     GeoView &g = gv[b];
     g.cam = v.cam; g.mean2d = v.mean2d; g.cov2d = v.cov2d; g.depth = v.depth; g.mask = v.mask;
     g.tl = w.tl; g.br = w.br; g.cnt = w.cnt; g.wcnt = w.wcnt; g.tile_count = w.tile_count; g.tile_off = w.tile_off;
-    g.ctrl = w.ctrl; g.tile_order = w.tile_order; g.done = w.done; g.keys = w.keys;
+    g.ctrl = w.ctrl; g.tile_order = w.tile_order; g.keys = w.keys;
     g.ids = v.gaussian_ids; g.start = v.start; g.end = v.end; g.total = v.total; g.cap = v.D_cap;
   }
   hipStream_t s = (hipStream_t)stream;
   GeoView *dv = reinterpret_cast<GeoView *>(batch_workspace);
-  const uint32_t ngroups = tile_groups(ntw, nth);
-  // five launches: view table (+ tickets) | projection | count + scans | emit | sort
   if (int e = gsgen_internal_frame_project_views(N, mean, qvec, svec, (int)W, (int)H, (int)ntw, gv.data(), dv,
-                                                 n_views, ngroups + 1, stream))
+                                                 n_views, stream))
     return e;
   const uint32_t B = n_views;
+  const uint32_t ngroups = ((ntw + kGroup - 1) / kGroup) * ((nth + kGroup - 1) / kGroup);
   const dim3 gpull(ngroups, nchunks, B), bpull(64 * kPullWaves);
-  hipLaunchKernelGGL((k_bin_pull_views<false>), gpull, bpull, 0, s, N, (int)ntw, (int)nth, T, (const GeoView *)dv);
-  if (N)  // (N == 0: the count pass walks nothing and its tail writes the empty offsets / order / totals)
+  if (N == 0) {
+    for (uint32_t b = 0; b < B; ++b)
+      if (hipError_t e = hipMemsetAsync(gv[b].cnt, 0, sizeof(uint32_t) * (size_t)nchunks * T, s)) return (int)e;
+  } else {
+    hipLaunchKernelGGL((k_bin_pull_views<false>), gpull, bpull, 0, s, N, (int)ntw, (int)nth, T, (const GeoView *)dv);
+  }
+  hipLaunchKernelGGL(k_scan_chunks_views, dim3((T + 3) / 4, B), dim3(256), 0, s, T, nchunks, (const GeoView *)dv);
+  hipLaunchKernelGGL(k_scan_order_tiles_views, dim3(1, B), dim3(kScanThreads), 0, s, T, (const GeoView *)dv);
+  if (N)
     hipLaunchKernelGGL((k_bin_pull_views<true>), gpull, bpull, 0, s, N, (int)ntw, (int)nth, T, (const GeoView *)dv);
   hipLaunchKernelGGL(k_sort_tiles_views, dim3(T * B), dim3(64), 0, s, T, B, (const GeoView *)dv);
   return (int)hipGetLastError();
@@ -719,11 +721,10 @@ int gsgen_frame_geometry(uint32_t N, const float *mean, const float *qvec, const
   const BinWs w = carve(workspace, N, D_cap, T, true);
   if (w.bytes > workspace_bytes) return GSGEN_EWORKSPACE;
   hipStream_t s = (hipStream_t)stream;
-  // four launches: projection (+ tickets) | count + scans | emit | sort
   if (int e = gsgen_internal_frame_project(N, mean, qvec, svec, cam, (int)W, (int)H, (int)ntw, mean2d,
-                                           cov2d, depth, mask, w.tl, w.br, w.done, tile_groups(ntw, nth) + 1, stream))
+                                           cov2d, depth, mask, w.tl, w.br, stream))
     return e;
-  return bin_and_sort(N, D_cap, nth, ntw, w.tl, w.br, depth, gaussian_ids, start, end, w, total, true, s);
+  return bin_and_sort(N, D_cap, nth, ntw, w.tl, w.br, depth, gaussian_ids, start, end, w, total, s);
 }
 
 }  // extern "C"

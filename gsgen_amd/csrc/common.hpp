@@ -36,6 +36,15 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // a value every lane of the wave holds identically (e.g. an LDS broadcast read), moved to a scalar register
+// "does any lane of the wavefront say yes": the ballot of a BOOLEAN (already a lane mask in scalar registers) -- __ballot(int)
+// first materialises the flag as an integer per lane and compares it again (two vector instructions per test)
+__device__ __forceinline__ bool wave_any(bool pred) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_ballot_w64(pred) != 0ull;
+#else
+  return __ballot((int)pred) != 0ull;
+#endif
+}
 __device__ __forceinline__ float wave_uniform(float v) {
   return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
 }
@@ -400,7 +409,7 @@ struct GeoView {
   float *mean2d, *cov2d, *depth;
   uint8_t *mask;
   int *tl, *br;
-  uint32_t *cnt, *wcnt, *tile_count, *tile_off, *ctrl, *tile_order, *done;
+  uint32_t *cnt, *wcnt, *tile_count, *tile_off, *ctrl, *tile_order;
   unsigned long long *keys;
   int *ids, *start, *end;
   uint32_t *total;

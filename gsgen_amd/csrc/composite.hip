@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(TS * TS / PPL) k_composite_fwd(CompParams p_ar
       bool any_alive = false;
 #pragma unroll
       for (int j = 0; j < PPL; ++j) any_alive |= alive[j];
-      if (__ballot(any_alive) == 0ull) break;  // this wave's 64*PPL pixels are saturated
+      if (!wave_any(any_alive)) break;  // this wave's 64*PPL pixels are saturated
       if constexpr (MODE == MODE_SH) {
         const int e = base + g;
         if (seg_out && (e % kSegLen) == 0 && e > 0 && e / kSegLen < p.nseg) {  // wave-uniform
@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(TS * TS / PPL) k_composite_fwd(CompParams p_ar
         con[j] = alive[j] && !(r.a * G[j] < kMinAlpha);
         any_con |= con[j];
       }
-      if (__ballot(any_con) == 0ull) continue;  // nobody in the wave sees this Gaussian
+      if (!wave_any(any_con)) continue;  // nobody in the wave sees this Gaussian
 
       const float *cg = &S.col[g * TR::NCOLP];
       if constexpr (MODE == MODE_SH) {
@@ -374,9 +374,11 @@ __device__ __forceinline__ int tile_thread_index() {
 }
 template <int CB, bool POLY>
 struct FwdShVecShared {
-  Stage<MODE_SH, CB, kBatch, !POLY> S;
+  // POLY: 32 records per round -- 4.8 KB of LDS per workgroup, so that 20 one-wavefront workgroups (5 per SIMD) fit a CU
+  static constexpr int KB = POLY ? 32 : kBatch;
+  Stage<MODE_SH, CB, KB, !POLY> S;
   alignas(16) float Vs[POLY ? kPolyNB * 16 : 4];          // POLY: V of this tile
-  alignas(16) float Ws[POLY ? kBatch * 3 * kPolyNB : 4];  // POLY: transformed coefficients of the staged batch
+  alignas(16) float Ws[POLY ? KB * 3 * kPolyStride : 4];  // POLY: transformed coefficients of the staged batch
                                                           // (and, before the first batch, the nine node bases)
 };
 template <int CB, int PPL, int NB, bool PERSIST = false>
@@ -388,6 +390,7 @@ __device__ __forceinline__ void composite_fwd_sh_vec_tile(const CompParams &p, u
   using TR = Traits<MODE, CB>;
   constexpr int NT = 256 / PPL, ROWS = NT / 16, NP = PPL / 2;
   constexpr int CCP = POLY ? NB : TR::CCP, NPAIR = CCP / 2;
+  constexpr int KB = FwdShVecShared<CB, POLY>::KB;
   auto &S = sm.S;
   float *const Vs = sm.Vs;
   float *const Ws = sm.Ws;
@@ -420,7 +423,7 @@ __device__ __forceinline__ void composite_fwd_sh_vec_tile(const CompParams &p, u
     return;  // otherwise the caller's pre-initialised out / T stand (vol_render.h:1006-1013)
   }
   if constexpr (TR::CCP != TR::CC) {  // zero the pad lanes of the staged coefficients once
-    for (int e = t; e < kBatch * TR::NCOLP; e += NT) S.col[e] = 0.0f;
+    for (int e = t; e < KB * TR::NCOLP; e += NT) S.col[e] = 0.0f;
     __syncthreads();
   }
 
@@ -432,11 +435,12 @@ __device__ __forceinline__ void composite_fwd_sh_vec_tile(const CompParams &p, u
   // POLY: the lane's column offset and its pixel pairs' row offsets -- the six monomials (1, v, u, v^2, uv, u^2) are never
   // materialised: s = (w0 + u (w2 + u w5)) + v ((w1 + u w4) + v w3), the bracketed terms once per lane and channel
   const float pu = poly_offset(lx);
+  const v2f pu2 = splat2(pu);
   v2f pv2[NP];
 #pragma unroll
   for (int jp = 0; jp < NP; ++jp) pv2[jp] = v2f{poly_offset(ly0 + (2 * jp) * ROWS), poly_offset(ly0 + (2 * jp + 1) * ROWS)};
   if constexpr (POLY) {
-    static_assert(kBatch * 3 * kPolyNB >= kPolyNodes * 16, "node scratch fits the coefficient buffer");
+    static_assert(KB * 3 * kPolyNB >= kPolyNodes * 16, "node scratch fits the coefficient buffer");
     poly_tile_setup<NT>(p, tx, ty, Ws, Vs);
   } else {
     float R[9];
@@ -465,13 +469,13 @@ __device__ __forceinline__ void composite_fwd_sh_vec_tile(const CompParams &p, u
   auto alive = [&](int j) { return !(Tr2[j >> 1][j & 1] < p.thresh); };
   const bool seg_out = p.nseg > 1 && p.ckpt != nullptr;
 
-  for (int base = 0; base < n; base += kBatch) {
-    const int nb = min(kBatch, n - base);
+  for (int base = 0; base < n; base += KB) {
+    const int nb = min(KB, n - base);
     if (base > 0) __syncthreads();  // everyone is done with the previous batch
-    stage_batch<MODE, CB, NT, kBatch, true, !POLY>(S, p, st + base, nb);
+    stage_batch<MODE, CB, NT, KB, true, !POLY>(S, p, st + base, nb);
     __syncthreads();
     if constexpr (POLY) {
-      poly_transform<NT, kBatch>(p.col, S.id, Vs, Ws, nb);
+      poly_transform<NT, KB>(p.col, S.id, Vs, Ws, nb);
       __syncthreads();
     }
 
@@ -479,7 +483,7 @@ __device__ __forceinline__ void composite_fwd_sh_vec_tile(const CompParams &p, u
       bool any_alive = false;
 #pragma unroll
       for (int j = 0; j < PPL; ++j) any_alive |= alive(j);
-      if (__ballot(any_alive) == 0ull) break;  // this wave's 64*PPL pixels are saturated
+      if (!wave_any(any_alive)) break;  // this wave's 64*PPL pixels are saturated
       const int e_idx = base + g;
       if (seg_out && (e_idx % kSegLen) == 0 && e_idx > 0 && e_idx / kSegLen < p.nseg) {  // wave-uniform
 #pragma unroll
@@ -503,7 +507,7 @@ __device__ __forceinline__ void composite_fwd_sh_vec_tile(const CompParams &p, u
       }
       // within rounding of the skip threshold the reference's arithmetic decides (as gauss_eval); one wave-uniform
       // test for all the lane's pixels, almost never taken
-      if (__ballot(any_guard) != 0ull) {
+      if (wave_any(any_guard)) {
 #pragma unroll
         for (int jp = 0; jp < NP; ++jp)
 #pragma unroll
@@ -522,9 +526,9 @@ __device__ __forceinline__ void composite_fwd_sh_vec_tile(const CompParams &p, u
           ag2[jp][e] = con ? ag2[jp][e] : 0.0f;
           any_con |= con;
         }
-      if (__ballot(any_con) == 0ull) continue;  // nobody in the wave sees this Gaussian
+      if (!wave_any(any_con)) continue;  // nobody in the wave sees this Gaussian
 
-      const float *cg = POLY ? &Ws[g * 3 * CCP] : &S.col[g * TR::NCOLP];
+      const float *cg = POLY ? &Ws[g * 3 * kPolyStride] : &S.col[g * TR::NCOLP];
       v2f w2[NP];
 #pragma unroll
       for (int jp = 0; jp < NP; ++jp) w2[jp] = (splat2(r_a) * Tr2[jp]) * G2[jp];  // (a T) G, or 0
@@ -534,12 +538,13 @@ __device__ __forceinline__ void composite_fwd_sh_vec_tile(const CompParams &p, u
         v2f den[3][NP];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          const v2f q0 = *reinterpret_cast<const v2f *>(cg + c * CCP), q1 = *reinterpret_cast<const v2f *>(cg + c * CCP + 2),
-                    q2 = *reinterpret_cast<const v2f *>(cg + c * CCP + 4);
-          const float A = fmaf(pu, fmaf(pu, q2[1], q1[0]), q0[0]), Bc = fmaf(pu, q2[0], q0[1]), Cc = q1[1];
+          const float *cw = cg + c * kPolyStride;  // (w0, w1 | w2, w4 | w5, 0 | w3, 0): composite_common.hpp
+          const v2f ab = ffma2(pu2, ffma2(pu2, *reinterpret_cast<const v2f *>(cw + 4), *reinterpret_cast<const v2f *>(cw + 2)),
+                               *reinterpret_cast<const v2f *>(cw));
+          const float Cc = cw[6];
 #pragma unroll
           for (int jp = 0; jp < NP; ++jp) {
-            const v2f sp = ffma2(pv2[jp], ffma2(pv2[jp], splat2(Cc), splat2(Bc)), splat2(A));  // (explicitly fused: every shape of the kernel agrees)
+            const v2f sp = ffma2(pv2[jp], ffma2(pv2[jp], splat2(Cc), splat2(ab[1])), splat2(ab[0]));  // (explicitly fused: every shape of the kernel agrees)
             den[c][jp] = splat2(1.0f) + v2f{__builtin_amdgcn_exp2f(sp[0]), __builtin_amdgcn_exp2f(sp[1])};
           }
         }
@@ -777,7 +782,7 @@ k_composite_bwd_pixel(CompParams p_arg, const CompParams *__restrict__ plist) {
       bool any_alive = false;
 #pragma unroll
       for (int j = 0; j < PPL; ++j) any_alive |= alive[j];
-      if (__ballot(any_alive) == 0ull) break;
+      if (!wave_any(any_alive)) break;
 
       const GRec r = load_rec(S, g);
       const float x = px - r.mx;
@@ -790,7 +795,7 @@ k_composite_bwd_pixel(CompParams p_arg, const CompParams *__restrict__ plist) {
         con[j] = alive[j] && !(r.a * G[j] < kMinAlpha);
         any_con |= con[j];
       }
-      if (__ballot(any_con) == 0ull) continue;
+      if (!wave_any(any_con)) continue;
 
       // per-lane partial gradient of this Gaussian over the lane's pixels
       // layout: 0,1 mean | 2 c00 3 c01 4 c10 5 c11 | 6 alpha | 7.. colour/scalar/sh
@@ -931,9 +936,9 @@ struct BwdShVecShared {
   static constexpr int KB = CHRED ? 32 : kBatch;  // CHRED: 10.6 KB of LDS per workgroup, 12+ workgroups per CU
   static constexpr int NT = 256 / PPL, NP = PPL / 2;
   Stage<MODE_SH, CB, KB, !POLY> S;
-  v2f go_s[CHRED ? 3 * NP * NT : 1];                      // CHRED: grad_out of the lane's pixel pairs, [channel][pair][thread]
+  v2f go_s[(CHRED && !POLY) ? 3 * NP * NT : 1];           // CHRED, exact form: grad_out of the lane's pixel pairs, [channel][pair][thread]
   alignas(16) float Vs[POLY ? kPolyNB * 16 : 4];          // POLY: V of this tile
-  alignas(16) float Ws[POLY ? KB * 3 * kPolyNB : 4];      // POLY: transformed coefficients of the staged batch
+  alignas(16) float Ws[POLY ? KB * 3 * kPolyStride : 4];    // POLY: transformed coefficients of the staged batch
                                                           // (and, before the first batch, the nine node bases)
   float gw_s[POLY ? 3 * 8 : 1];                           // POLY: a splat's reduced gradient in the tile's basis
 };
@@ -1003,6 +1008,7 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
   float Vk[POLY ? kPolyNB : 1];  // POLY: column (lane & 15) of V
   // POLY: the lane's column offset and its pixel pairs' row offsets stand for the six monomials (see the forward)
   const float pu = poly_offset(lx);
+  const v2f pu2 = splat2(pu);
   v2f pv2[NP];
 #pragma unroll
   for (int jp = 0; jp < NP; ++jp) pv2[jp] = v2f{poly_offset(ly0 + (2 * jp) * ROWS), poly_offset(ly0 + (2 * jp + 1) * ROWS)};
@@ -1042,7 +1048,7 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
     }
     Tr2[j >> 1][j & 1] = (alive0[j] && !(ck.x < p.thresh)) ? ck.x : -1.0f;
   }
-  if constexpr (CHRED) {  // each thread reads back only what it wrote: no barrier
+  if constexpr (CHRED && !POLY) {  // each thread reads back only what it wrote: no barrier
 #pragma unroll
     for (int jp = 0; jp < NP; ++jp)
 #pragma unroll
@@ -1064,12 +1070,13 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
       bool any_alive = false;
 #pragma unroll
       for (int j = 0; j < PPL; ++j) any_alive |= alive(j);
-      if (__ballot(any_alive) == 0ull) break;
+      if (!wave_any(any_alive)) break;
 
       // the record as plain scalars (a struct handed around by reference makes the compiler build the packed
       // operands through scratch memory)
       // (CHRED: wave-uniform values moved to scalar registers -- nine vector registers less)
-      auto uni = [&](float v) { return CHRED ? wave_uniform(v) : v; };
+      // (POLY: 108 registers leave room for the nine scalars as vector registers -- nine v_readfirstlane less per entry)
+      auto uni = [&](float v) { return (CHRED && !POLY) ? wave_uniform(v) : v; };
       const float r_mx = uni(S.mx[g]), r_my = uni(S.my[g]), r_a = uni(S.a[g]), r_c0 = uni(S.c0[g]), r_c1 = uni(S.c1[g]),
                   r_c2 = uni(S.c2[g]), r_c3 = uni(S.c3[g]), r_p0 = uni(S.p0[g]), r_p1 = uni(S.p1[g]);
       const float x = px - r_mx;
@@ -1086,7 +1093,7 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
       }
       // within rounding of the skip threshold: the reference's arithmetic decides (as gauss_eval).  One wave-uniform
       // test for all the lane's pixels: the branch is almost never taken (a handful of pixels per frame)
-      if (__ballot(any_guard) != 0ull) {
+      if (wave_any(any_guard)) {
 #pragma unroll
         for (int jp = 0; jp < NP; ++jp)
 #pragma unroll
@@ -1107,7 +1114,7 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
         }
       // (skipping a pixel PAIR none of whose 128 pixels takes part -- pair-major code, one wave-uniform test per pair -- was
       // measured again in round 3 with the polynomial body: 4 488 vs 4 507 renders/s, profiles/r03_ab_pairskip_polyonly.txt)
-      if (__ballot(any_con) == 0ull) continue;  // nobody in the wave sees this Gaussian
+      if (!wave_any(any_con)) continue;  // nobody in the wave sees this Gaussian
 
       // reduction vector as (even, odd) pairs: SH components [0, NSH) | mean | cov | alpha | zeros
       constexpr int PCH = CCP <= 2 ? 2 : (CCP <= 4 ? 4 : (CCP <= 8 ? 8 : 16));  // CHRED: one channel's components
@@ -1117,7 +1124,7 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
 #pragma unroll
         for (int i = NSH / 2; i < P / 2; ++i) gr2[i] = v2f{0.0f, 0.0f};
       }
-      const float *cg = POLY ? &Ws[g * 3 * CCP] : &S.col[g * TR::NCOLP];
+      const float *cg = POLY ? &Ws[g * 3 * kPolyStride] : &S.col[g * TR::NCOLP];
       v2f pch[POLY ? 3 : 1][3];  // POLY: the channels' six components each, reduced after the geometric part
       v2f w2[NP], inv1m2[NP], pAG2[NP];
 #pragma unroll
@@ -1135,12 +1142,13 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
         v2f den[3][NP], yv[3][NP];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          const v2f q0 = *reinterpret_cast<const v2f *>(cg + c * CCP), q1 = *reinterpret_cast<const v2f *>(cg + c * CCP + 2),
-                    q2 = *reinterpret_cast<const v2f *>(cg + c * CCP + 4);
-          const float A = fmaf(pu, fmaf(pu, q2[1], q1[0]), q0[0]), Bc = fmaf(pu, q2[0], q0[1]), Cc = q1[1];
+          const float *cw = cg + c * kPolyStride;  // (w0, w1 | w2, w4 | w5, 0 | w3, 0): composite_common.hpp
+          const v2f ab = ffma2(pu2, ffma2(pu2, *reinterpret_cast<const v2f *>(cw + 4), *reinterpret_cast<const v2f *>(cw + 2)),
+                               *reinterpret_cast<const v2f *>(cw));
+          const float Cc = cw[6];
 #pragma unroll
           for (int jp = 0; jp < NP; ++jp) {
-            const v2f sp = ffma2(pv2[jp], ffma2(pv2[jp], splat2(Cc), splat2(Bc)), splat2(A));  // (explicitly fused: every shape of the kernel agrees)
+            const v2f sp = ffma2(pv2[jp], ffma2(pv2[jp], splat2(Cc), splat2(ab[1])), splat2(ab[0]));  // (explicitly fused: every shape of the kernel agrees)
             den[c][jp] = splat2(1.0f) + v2f{__builtin_amdgcn_exp2f(sp[0]), __builtin_amdgcn_exp2f(sp[1])};
           }
         }
@@ -1165,7 +1173,7 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
             const v2f y_ = yv[c][jp];
             rem2[jp][c] = fma2(-w2[jp], y_, rem2[jp][c]);
             const v2f dy = fma2(-y_, y_, y_);  // y (1 - y)
-            const v2f go = go_s[(c * NP + jp) * NT + t];
+            const v2f go = go2[jp][c];  // (registers: this body has them to spare; the exact one reads its copy in LDS)
             const v2f gs = (w2[jp] * dy) * go;
             const v2f sfx = rem2[jp][c] * inv1m2[jp];
             pAG2[jp] = fma2(go, fma2(y_, Tr2[jp], -sfx), pAG2[jp]);
@@ -1267,14 +1275,25 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
         v2f t1[4] = {pch[1][0], pch[1][1], pch[1][2], v2f{c0, c1}};
         v2f t2[4] = {pch[2][0], pch[2][1], pch[2][2], v2f{c3, ga}};
         const float s0 = wave_reduce_scatter2_rows<8>(t0), s1 = wave_reduce_scatter2_rows<8>(t1), s2 = wave_reduce_scatter2_rows<8>(t2);
-        const float tot = quad_reduce_scatter4(s0, s1, s2, 0.0f);
-        const int m = lane & 3;  // the vector this lane ends up with: channel 0 / 1 / 2 (3: nothing)
+        // (the fourth quad lane receives channel 1's vector again: its (c0, c1) slot pays for grad_cov[2] = grad_cov[1])
+        const float tot = quad_reduce_scatter4(s0, s1, s2, s1);
+        const int m = lane & 3;  // the vector this lane ends up with: channel 0 / 1 / 2 / 1 again
         const int comp = scatter_comp<8>(lane);
-        const bool owner = m < 3 && scatter_rows_owner<8>(lane);
+        const bool owner = scatter_rows_owner<8>(lane);
         const size_t id = (size_t)S.id[g];
         // d L / d sh[c][k] = sum_r gw[c][r] V[r][k]: the 18 reduced values go through LDS, lanes (c, k) = (lane / 16,
         // lane % 16) expand them with their column of V (one wavefront per workgroup: the barrier is a wait)
-        if (owner && comp < kPolyNB) gw_s[m * 8 + comp] = tot;
+        if (owner && m < 3 && comp < kPolyNB) gw_s[m * 8 + comp] = tot;
+        // the geometric components, ONE atomic instruction: lane (m, slot e = comp - 6) -> m 0: mean[e] | 1: cov[e] |
+        // 2: cov[3], alpha | 3: -, cov[2]   (branch-free address: a switch here cost ~35 scalar instructions per entry)
+        {
+          const int e = comp - 6;
+          float *const cov = p.g_cov + 4 * id;
+          float *dst = cov + (m == 1 ? e : (m == 2 ? 3 : 2));
+          dst = m == 0 ? p.g_mean + 2 * id + e : dst;
+          dst = (m == 2 && e == 1) ? p.g_alpha + id : dst;
+          if (owner && comp >= 6 && !(m == 3 && e == 0)) atomicAdd(dst, tot);
+        }
         __syncthreads();
         if (lane < 48) {
           const float *gw = &gw_s[(lane >> 4) * 8];
@@ -1282,15 +1301,6 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
 #pragma unroll
           for (int r = 1; r < kPolyNB; ++r) acc = fmaf(gw[r], Vk[r], acc);
           atomicAdd(p.g_col + (size_t)TR::NCOL * id + lane, acc);  // (c, k) -> 16 c + k = lane
-        }
-        if (owner && comp >= 6) {
-          const int e = comp - 6;
-          float *dst;
-          if (m == 0) dst = p.g_mean + 2 * id + e;                   // m0, m1
-          else if (m == 1) dst = p.g_cov + 4 * id + e;               // c0, c1 (-> cov[1]; cov[2] below)
-          else dst = e == 0 ? p.g_cov + 4 * id + 3 : p.g_alpha + id; // c3, alpha
-          atomicAdd(dst, tot);
-          if (m == 1 && e == 1) atomicAdd(p.g_cov + 4 * id + 2, tot);
         }
         __syncthreads();  // gw_s is consumed before the next splat overwrites it
       } else if constexpr (CHRED) {
@@ -1446,7 +1456,7 @@ k_composite_fwd_chan_vec(CompParams p_arg, const CompParams *__restrict__ plist)
       bool any_alive = false;
 #pragma unroll
       for (int j = 0; j < PPL; ++j) any_alive |= alive(j);
-      if (__ballot(any_alive) == 0ull) break;  // the tile's 256 pixels are saturated
+      if (!wave_any(any_alive)) break;  // the tile's 256 pixels are saturated
 
       const float r_mx = wave_uniform(S.mx[g]), r_my = wave_uniform(S.my[g]), r_a = wave_uniform(S.a[g]),
                   r_p0 = wave_uniform(S.p0[g]), r_p1 = wave_uniform(S.p1[g]), r_p2 = wave_uniform(S.p2[g]);
@@ -1460,7 +1470,7 @@ k_composite_fwd_chan_vec(CompParams p_arg, const CompParams *__restrict__ plist)
 #pragma unroll
         for (int k = 0; k < 2; ++k) any_guard |= alive(2 * jp + k) && fabsf(ag2[jp][k] - kMinAlpha) <= kMinAlpha * kGuardTol;
       }
-      if (__ballot(any_guard) != 0ull) {  // within rounding of the skip threshold: the reference's arithmetic decides
+      if (wave_any(any_guard)) {  // within rounding of the skip threshold: the reference's arithmetic decides
         const float r_c0 = S.c0[g], r_c1 = S.c1[g], r_c2 = S.c2[g], r_c3 = S.c3[g];
 #pragma unroll
         for (int jp = 0; jp < NP; ++jp)
@@ -1480,7 +1490,7 @@ k_composite_fwd_chan_vec(CompParams p_arg, const CompParams *__restrict__ plist)
           ag2[jp][k] = con ? ag2[jp][k] : 0.0f;
           any_con |= con;
         }
-      if (__ballot(any_con) == 0ull) continue;  // nobody in the wave sees this Gaussian
+      if (!wave_any(any_con)) continue;  // nobody in the wave sees this Gaussian
 
       const float *cg = &S.col[g * TR::NCOLP];
 #pragma unroll
@@ -1570,7 +1580,7 @@ k_composite_bwd_chan_vec(CompParams p_arg, const CompParams *__restrict__ plist)
       bool any_alive = false;
 #pragma unroll
       for (int j = 0; j < PPL; ++j) any_alive |= alive(j);
-      if (__ballot(any_alive) == 0ull) break;
+      if (!wave_any(any_alive)) break;
 
       const float r_mx = wave_uniform(S.mx[g]), r_my = wave_uniform(S.my[g]), r_a = wave_uniform(S.a[g]),
                   r_p0 = wave_uniform(S.p0[g]), r_p1 = wave_uniform(S.p1[g]), r_p2 = wave_uniform(S.p2[g]);
@@ -1587,7 +1597,7 @@ k_composite_bwd_chan_vec(CompParams p_arg, const CompParams *__restrict__ plist)
 #pragma unroll
         for (int k = 0; k < 2; ++k) any_guard |= alive(2 * jp + k) && fabsf(ag2[jp][k] - kMinAlpha) <= kMinAlpha * kGuardTol;
       }
-      if (__ballot(any_guard) != 0ull) {  // within rounding of the skip threshold: the reference's arithmetic decides
+      if (wave_any(any_guard)) {  // within rounding of the skip threshold: the reference's arithmetic decides
         const float r_c0 = S.c0[g], r_c1 = S.c1[g], r_c2 = S.c2[g], r_c3 = S.c3[g];
 #pragma unroll
         for (int jp = 0; jp < NP; ++jp)
@@ -1607,7 +1617,7 @@ k_composite_bwd_chan_vec(CompParams p_arg, const CompParams *__restrict__ plist)
           ag2[jp][k] = con ? ag2[jp][k] : 0.0f;
           any_con |= con;
         }
-      if (__ballot(any_con) == 0ull) continue;  // nobody in the wave sees this Gaussian
+      if (!wave_any(any_con)) continue;  // nobody in the wave sees this Gaussian
 
       v2f gr2[P / 2];
 #pragma unroll

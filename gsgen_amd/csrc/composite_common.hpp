@@ -317,6 +317,11 @@ __device__ __forceinline__ v2f gauss_chol_pair(float p0x, float p1, float p2, v2
 // |non-constant SH coefficients| of one channel, measured on the device per step; delta: the tile's half diagonal in camera
 // space) stays below 1e-5 -- decided on the device by every workgroup (poly_route), which runs the exact form otherwise.
 constexpr int kPolyNB = 6;
+// A (splat, channel) row of transformed coefficients in LDS: eight floats (w0, w1 | w2, w4 | w5, 0 | w3, 0) for the monomials
+// r = 0..5 = (1, v, u, v^2, uv, u^2), so that the kernels form  s = (w0 + u (w2 + u w5)) + v ((w1 + u w4) + v w3)  from whole
+// register PAIRS:  (A, B) = (w0, w1) + u ((w2, w4) + u (w5, 0)),  s = A + v (B + v w3)  -- two packed FMAs per row and lane
+// instead of three scalar ones plus the moves that put their results into aligned pairs.
+constexpr int kPolyStride = 8;
 constexpr int kPolyNodes = 9;
 // colour error of the degree-2 form <= 0.25 (sigmoid slope) x S x 0.7 delta^3, delta = half diagonal of a tile in camera
 // space (tools/tile_basis_error.py: 1.95e-6 at delta = 0.0141, 2.1e-5 at 0.0316); used where that stays below 1e-5, a tenth
@@ -377,36 +382,50 @@ __device__ __forceinline__ void poly_tile_setup(const CompParams &p, int tx, int
 }
 // the coefficients sh[id][3][16] of the nb staged splats, straight from HBM, -> w[nb][3][6] in LDS:
 // w[c][r] = -log2(e) sum_k V[r][k] sh[c][k]  (the scale of stage_batch<SCALE>: the colour evaluation's exp2 needs no multiply).
-// One (splat, channel) pair per lane and pass, rolled loops: 16 + 16 live registers.  (Loading a lane's two pairs together
-// hides one trip to memory per batch and costs 32 more registers -- a wavefront per SIMD; not taken.)
+// One HALF row per lane and pass -- (splat, channel) row e = it / 2, monomials 3 (it & 1) .. +2 -- so that a batch's 6 nb
+// items fill whole passes of 64 or 128 lanes (whole rows left the second pass of a 32-record batch half empty), the dot
+// products as packed FMAs over (even, odd) coefficient pairs: 8 + 1 vector instructions per monomial instead of 16.
+// (Loading a lane's two items together hides one trip to memory per batch and costs 32 more registers -- a wavefront per
+// SIMD; not taken.)
 template <int NT, int KB>
 __device__ __forceinline__ void poly_transform(const float *__restrict__ sh, const int *ids, const float *Vs, float *w, int nb) {
+  static_assert(NT % 2 == 0, "the two halves of a row sit in neighbouring lanes");
 #pragma unroll 1
-  for (int e = (int)threadIdx.x; e < nb * 3; e += NT) {
+  for (int it0 = 0; it0 < nb * 6; it0 += NT) {  // (block-uniform trips: the lane exchange below is a wave collective)
+    const int it = it0 + (int)threadIdx.x;
+    const bool live = it < nb * 6;
+    const int e = live ? (it >> 1) : 0, half = it & 1;
     const int g = e / 3, c = e - 3 * g;
     const float4 *q4 = reinterpret_cast<const float4 *>(sh + (size_t)ids[g] * 48 + c * 16);
     const float4 q0 = q4[0], q1 = q4[1], q2 = q4[2], q3 = q4[3];
-#pragma unroll 1
-    for (int r = 0; r < kPolyNB; ++r) {
-      const float4 *v4 = reinterpret_cast<const float4 *>(Vs + r * 16);  // the same address in every lane: broadcast
+    const v2f qa = {q0.x, q0.y}, qb = {q0.z, q0.w}, qc = {q1.x, q1.y}, qd = {q1.z, q1.w}, qe = {q2.x, q2.y}, qf = {q2.z, q2.w},
+              qg = {q3.x, q3.y}, qh = {q3.z, q3.w};
+    float *row = w + e * kPolyStride;
+    // monomials (1, v, u | v^2, uv, u^2) -> slots (0, 1, 2 | 6, 3, 4); 5 and 7 stay zero (5 is multiplied by u)
+    const int s0 = half ? 6 : 0, s1 = half ? 3 : 1, s2 = half ? 4 : 2;
+#pragma unroll 1  // (rolled: unrolled, the three monomials' 48 values of V stay live -- a wavefront per SIMD)
+    for (int k = 0; k < 3; ++k) {
+      const float4 *v4 = reinterpret_cast<const float4 *>(Vs + (3 * half + k) * 16);  // two addresses per wavefront: broadcast
       const float4 a = v4[0], b = v4[1], cc = v4[2], d = v4[3];
-      float acc = q0.x * a.x;
-      acc = fmaf(q0.y, a.y, acc); acc = fmaf(q0.z, a.z, acc); acc = fmaf(q0.w, a.w, acc);
-      acc = fmaf(q1.x, b.x, acc); acc = fmaf(q1.y, b.y, acc); acc = fmaf(q1.z, b.z, acc); acc = fmaf(q1.w, b.w, acc);
-      acc = fmaf(q2.x, cc.x, acc); acc = fmaf(q2.y, cc.y, acc); acc = fmaf(q2.z, cc.z, acc); acc = fmaf(q2.w, cc.w, acc);
-      acc = fmaf(q3.x, d.x, acc); acc = fmaf(q3.y, d.y, acc); acc = fmaf(q3.z, d.z, acc); acc = fmaf(q3.w, d.w, acc);
-      w[e * kPolyNB + r] = -kLog2e * acc;
+      v2f acc = qa * v2f{a.x, a.y};
+      acc = ffma2(qb, v2f{a.z, a.w}, acc);
+      acc = ffma2(qc, v2f{b.x, b.y}, acc);
+      acc = ffma2(qd, v2f{b.z, b.w}, acc);
+      acc = ffma2(qe, v2f{cc.x, cc.y}, acc);
+      acc = ffma2(qf, v2f{cc.z, cc.w}, acc);
+      acc = ffma2(qg, v2f{d.x, d.y}, acc);
+      acc = ffma2(qh, v2f{d.z, d.w}, acc);
+      if (live) row[k == 0 ? s0 : (k == 1 ? s1 : s2)] = -kLog2e * (acc[0] + acc[1]);
     }
+    if (live) row[half ? 7 : 5] = 0.0f;
     // |s| <= sum_r |w_r| on the tile (|u|, |v| <= 1).  The kernels take ONE reciprocal per pixel for the product of the three
     // channels' 1 + exp2(s): rows that could reach |s| > 40 are scaled back to 40 -- their sigmoid is 0 or 1 to 1e-12 either way
     // (and d sigmoid / d s ~ 1e-12: no gradient is lost that the exact kernels would deliver)
-    float l1 = 0.0f;
-#pragma unroll
-    for (int r = 0; r < kPolyNB; ++r) l1 += fabsf(w[e * kPolyNB + r]);
-    if (l1 > 40.0f) {
+    const float mine = live ? fabsf(row[s0]) + fabsf(row[s1]) + fabsf(row[s2]) : 0.0f;  // (its own stores: no barrier)
+    const float l1 = xor_add<1>(mine);  // + the row's other half, one lane over
+    if (live && l1 > 40.0f) {
       const float sc = 40.0f / l1;
-#pragma unroll
-      for (int r = 0; r < kPolyNB; ++r) w[e * kPolyNB + r] *= sc;
+      row[s0] *= sc; row[s1] *= sc; row[s2] *= sc;
     }
   }
 }

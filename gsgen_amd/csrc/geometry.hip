@@ -501,27 +501,21 @@ __global__ void __launch_bounds__(kThreads)
 k_frame_project(uint32_t N, const float *__restrict__ mean, const float *__restrict__ qvec,
                 const float *__restrict__ svec, const float *__restrict__ cam, int w, int h, int ntw,
                 float *__restrict__ mean2d, float *__restrict__ cov2d, float *__restrict__ depth,
-                uint8_t *__restrict__ mask, int *__restrict__ tl, int *__restrict__ br,
-                uint32_t *__restrict__ done, uint32_t n_done) {
-  // the tickets of the binning count pass (binning.hip: its last workgroups run the scans) start every frame at zero
-  if (blockIdx.x == 0)
-    for (uint32_t i = threadIdx.x; i < n_done; i += kThreads) done[i] = 0u;
+                uint8_t *__restrict__ mask, int *__restrict__ tl, int *__restrict__ br) {
   frame_project_body(N, mean, qvec, svec, cam, w, h, ntw, mean2d, cov2d, depth, mask, tl, br);
 }
-// B views per launch: gridDim.y = views (see GeoView)
-__global__ void __launch_bounds__(kThreads)
-k_frame_project_views(uint32_t N, const float *__restrict__ mean, const float *__restrict__ qvec,
-                      const float *__restrict__ svec, int w, int h, int ntw, const GeoView *__restrict__ views) {
-  const GeoView v = views[blockIdx.y];
-  frame_project_body(N, mean, qvec, svec, v.cam, w, h, ntw, v.mean2d, v.cov2d, v.depth, v.mask, v.tl, v.br);
-}
+// Up to kViewPack views per launch: gridDim.y = views.  The per-view pointer table (GeoView) arrives in the KERNEL ARGUMENTS
+// -- copied into the dispatch packet at enqueue: nothing staged or pinned, capture-safe -- and the first workgroup of every view
+// also leaves its entry in device memory, where the later launches of the chain (binning.hip) read it.  (The table used to
+// be written by a one-workgroup launch of its own in front: one more link in every batch's chain of dependent launches.)
 constexpr int kViewPack = 8;
 struct GeoViewPack { GeoView v[kViewPack]; };
-__global__ void __launch_bounds__(64) k_write_views(GeoViewPack pack, GeoView *dst, int n, uint32_t n_done) {
-  const int i = (int)threadIdx.x;
-  if (i < n) dst[i] = pack.v[i];
-  for (int v = 0; v < n; ++v)  // the count pass's tickets (see k_frame_project)
-    for (uint32_t k = threadIdx.x; k < n_done; k += 64u) pack.v[v].done[k] = 0u;
+__global__ void __launch_bounds__(kThreads)
+k_frame_project_views(uint32_t N, const float *__restrict__ mean, const float *__restrict__ qvec,
+                      const float *__restrict__ svec, int w, int h, int ntw, GeoViewPack pack, GeoView *__restrict__ dst) {
+  const GeoView &v = pack.v[blockIdx.y];
+  if (blockIdx.x == 0 && threadIdx.x == 0) dst[blockIdx.y] = v;
+  frame_project_body(N, mean, qvec, svec, v.cam, w, h, ntw, v.mean2d, v.cov2d, v.depth, v.mask, v.tl, v.br);
 }
 
 static inline dim3 grid_for(uint32_t n) { return dim3((n + kThreads - 1) / kThreads); }
@@ -805,27 +799,25 @@ int gsgen_densify_update_batch(uint32_t n_views, uint32_t N, const float *const 
 // the projection of every view in one launch
 int gsgen_internal_frame_project_views(uint32_t N, const float *mean, const float *qvec, const float *svec,
                                        int w, int h, int ntw, const GeoView *host_views, GeoView *dev_views,
-                                       uint32_t B, uint32_t n_done, gsgen_stream_t stream) {
+                                       uint32_t B, gsgen_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
+  const uint32_t gx = N ? grid_for(N).x : 1u;  // (N == 0: one workgroup per view, for the table alone)
   for (uint32_t b0 = 0; b0 < B; b0 += kViewPack) {
     GeoViewPack pack{};
-    const int n = (int)((B - b0) < (uint32_t)kViewPack ? (B - b0) : (uint32_t)kViewPack);
-    for (int i = 0; i < n; ++i) pack.v[i] = host_views[b0 + i];
-    hipLaunchKernelGGL(k_write_views, dim3(1), dim3(64), 0, s, pack, dev_views + b0, n, n_done);
+    const uint32_t n = (B - b0) < (uint32_t)kViewPack ? (B - b0) : (uint32_t)kViewPack;
+    for (uint32_t i = 0; i < n; ++i) pack.v[i] = host_views[b0 + i];
+    hipLaunchKernelGGL(k_frame_project_views, dim3(gx, n), dim3(kThreads), 0, s, N, mean, qvec, svec, w, h, ntw, pack,
+                       dev_views + b0);
   }
-  if (N)
-    hipLaunchKernelGGL(k_frame_project_views, dim3(grid_for(N).x, B), dim3(kThreads), 0, s, N, mean, qvec, svec, w,
-                       h, ntw, (const GeoView *)dev_views);
   return (int)hipGetLastError();
 }
 
 int gsgen_internal_frame_project(uint32_t N, const float *mean, const float *qvec, const float *svec,
                                  const float *cam, int w, int h, int ntw, float *mean2d, float *cov2d,
-                                 float *depth, uint8_t *mask, int *tl, int *br, uint32_t *done, uint32_t n_done,
-                                 gsgen_stream_t stream) {
+                                 float *depth, uint8_t *mask, int *tl, int *br, gsgen_stream_t stream) {
   if (N == 0) return 0;
   hipLaunchKernelGGL(k_frame_project, grid_for(N), dim3(kThreads), 0, (hipStream_t)stream, N, mean,
-                     qvec, svec, cam, w, h, ntw, mean2d, cov2d, depth, mask, tl, br, done, n_done);
+                     qvec, svec, cam, w, h, ntw, mean2d, cov2d, depth, mask, tl, br);
   return (int)hipGetLastError();
 }
 

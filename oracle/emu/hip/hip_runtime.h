@@ -112,7 +112,6 @@ inline int emu_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mas
 #define __builtin_amdgcn_readlane(v, l) simt::shfl_idx((int)(v), (l))
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
-#define __builtin_amdgcn_fence(order, scope) ((void)0)  // workgroups run one after another on one OS thread
 
 template <typename T, typename U> inline T atomicAdd(T *p, U v) { return simt::atomic_add(p, v); }
 template <typename T, typename U> inline T atomicMax(T *p, U v) { return simt::atomic_max(p, v); }

@@ -83,3 +83,43 @@ def test_sh_backward_unchanged_by_launches_in_flight(C):
     for _ in range(16):
         con = _backward_all(dev, lib, P, cams, C, N, W, H, streams)
         assert _worst(seq, con) < 5e-6
+
+
+def test_batched_geometry_chain_identical_with_other_batches_in_flight():
+    """The binning count pass finishes its own job: the last workgroup of every tile group scans the group's counts, the last of
+    those the tile offsets -- data crossing workgroups (and XCDs, each with its own L2) INSIDE one launch.  Three camera
+    batches of the bench workload on three streams, many times: the forward has no atomics and the per-tile order is unique,
+    so every image must equal the batch rendered alone, bit for bit (a stale count read by a scanning workgroup would move
+    list entries between tiles)."""
+    from gsgen_amd.batch import BatchRenderer
+    dev = torch.device("cuda:0")
+    N, W, H, B = 100_000, 800, 800, 8
+    sc = scenes.pointe_scene(N, seed=5, C=4)
+    P = {k: torch.from_numpy(np.ascontiguousarray(sc[k])).to(dev) for k in ("mean", "qvec", "svec", "alpha", "sh")}
+    cams = [scenes.Camera(W, H, fx=float(W), c2w=scenes.orbit(2.4, 12.0 + 9 * i, 45.0 * i)) for i in range(B)]
+    cis = [R.CameraInfo(*c.intr) for c in cams]
+    c2ws = [c.c2w for c in cams]
+    brs = [BatchRenderer(N, W, H, dev, max_batch=B) for _ in range(3)]
+    streams = [torch.cuda.Stream() for _ in brs]
+
+    def render(br):
+        with torch.no_grad():
+            return br.render(P["mean"], P["qvec"], P["svec"], P["alpha"], P["sh"], cis, c2ws, C=4)[0]
+    for br in brs:  # size the pair buffers
+        for _ in range(3):
+            ref = render(br)
+            if br.ensure_capacity(B):
+                break
+    torch.cuda.synchronize()
+    ref = render(brs[0]).clone()
+    torch.cuda.synchronize()
+    assert float(ref.abs().max()) > 0.1
+    for it in range(12):
+        outs = []
+        for br, st in zip(brs, streams):
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                outs.append(render(br))
+        torch.cuda.synchronize()
+        for k, o in enumerate(outs):
+            assert torch.equal(o, ref), (it, k, float((o - ref).abs().max()))
