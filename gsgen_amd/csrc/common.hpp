@@ -169,9 +169,7 @@ __device__ __forceinline__ bool scatter_owner(int lane) {
 
 template <int L>
 __device__ __forceinline__ float xchg_any(float lo, float hi) {
-#if defined(GSGEN_ASM_DPP)
-  if constexpr (L == 8 || L == 4) return xchg_add_row<L>(lo, hi);
-#endif
+  if constexpr (L == 8 || L == 4) return xchg_add_row<L>(lo, hi);  // two fused v_add_f32_dpp instead of two moves + an add
   return xchg_add<L>(lo, hi);
 }
 template <int P, int K>
@@ -235,10 +233,10 @@ __device__ __forceinline__ void reduce_scatter2_level(v2f (&v2)[P / 2]) {
 #pragma unroll
         for (int i = 0; i < S / 2; ++i) v2[i] = xchg_add2<L>(v2[i], v2[i + S / 2]);
       } else {
-        v2[0][0] = xchg_add<L>(v2[0][0], v2[0][1]);
+        v2[0][0] = xchg_any<L>(v2[0][0], v2[0][1]);
       }
     } else {
-      v2[0][0] = xchg_add<L>(v2[0][0], v2[0][0]);
+      v2[0][0] = xchg_any<L>(v2[0][0], v2[0][0]);
     }
     reduce_scatter2_level<P, K + 1, KEND>(v2);
   }
@@ -359,6 +357,15 @@ __device__ __forceinline__ v2f ffma2(v2f a, v2f b, v2f c) {
 #else
   return v2f{__builtin_fmaf(a[0], b[0], c[0]), __builtin_fmaf(a[1], b[1], c[1])};
 #endif
+}
+
+// 1 - x with x taken AS ROUNDED, whatever produced it: under -ffp-contract=fast a subtraction whose operand is a visible
+// product a * b becomes fma(-a, b, 1) in some instantiations of a kernel and stays two roundings in others (and
+// fma(-x, 1, 1) is first folded to that subtraction: no help).  The transmittance T (1 - a G) decides "saturated" in the forward
+// AND the backward, in every shape of them -- they must agree to the bit.
+__device__ __forceinline__ v2f one_minus2(v2f x) {
+#pragma clang fp contract(off)
+  return v2f{1.0f, 1.0f} - x;
 }
 
 // Workgroup -> tile map that is both XCD-local and XCD-balanced.  Workgroup b runs on XCD

@@ -468,6 +468,7 @@ __device__ __forceinline__ void composite_fwd_sh_vec_tile(const CompParams &p, u
   }
   auto alive = [&](int j) { return !(Tr2[j >> 1][j & 1] < p.thresh); };
   const bool seg_out = p.nseg > 1 && p.ckpt != nullptr;
+  const bool track_stop = p.stop != nullptr;
 
   for (int base = 0; base < n; base += KB) {
     const int nb = min(KB, n - base);
@@ -497,14 +498,20 @@ __device__ __forceinline__ void composite_fwd_sh_vec_tile(const CompParams &p, u
       const float x = px - r_mx;
       // G2 / ag2: the Gaussian and a G, ZEROED where the pixel does not take part (skip threshold, or not alive)
       v2f G2[NP], ag2[NP];
-      bool any_con = false, any_guard = false;
+      bool any_con = false;
+      float guard_dist = 0.0f;
 #pragma unroll
       for (int jp = 0; jp < NP; ++jp) {
         G2[jp] = gauss_sh_pair(r_c0, r_c1, r_c2, r_c3, r_p0, x, py2[jp] - splat2(r_my));
         ag2[jp] = splat2(r_a) * G2[jp];
 #pragma unroll
-        for (int e = 0; e < 2; ++e) any_guard |= alive(2 * jp + e) && fabsf(ag2[jp][e] - kMinAlpha) <= kMinAlpha * kGuardTol;
+        for (int e = 0; e < 2; ++e) {
+          // the lane's smallest distance to the threshold (dead pixels included: a spurious trip re-tests per pixel)
+          const float dist = fabsf(ag2[jp][e] - kMinAlpha);
+          guard_dist = (jp == 0 && e == 0) ? dist : fminf(guard_dist, dist);
+        }
       }
+      const bool any_guard = guard_dist <= kMinAlpha * kGuardTol;
       // within rounding of the skip threshold the reference's arithmetic decides (as gauss_eval); one wave-uniform
       // test for all the lane's pixels, almost never taken
       if (wave_any(any_guard)) {
@@ -523,15 +530,22 @@ __device__ __forceinline__ void composite_fwd_sh_vec_tile(const CompParams &p, u
         for (int e = 0; e < 2; ++e) {
           const bool con = alive(2 * jp + e) && !(ag2[jp][e] < kMinAlpha);
           G2[jp][e] = con ? G2[jp][e] : 0.0f;
-          ag2[jp][e] = con ? ag2[jp][e] : 0.0f;
+          if constexpr (!POLY) ag2[jp][e] = con ? ag2[jp][e] : 0.0f;
           any_con |= con;
         }
+      if constexpr (POLY) {  // the same products again, from the masked G: two packed multiplies instead of four selects
+#pragma unroll
+        for (int jp = 0; jp < NP; ++jp) {
+          ag2[jp] = splat2(r_a) * G2[jp];
+        }
+      }
       if (!wave_any(any_con)) continue;  // nobody in the wave sees this Gaussian
 
       const float *cg = POLY ? &Ws[g * 3 * kPolyStride] : &S.col[g * TR::NCOLP];
       v2f w2[NP];
 #pragma unroll
-      for (int jp = 0; jp < NP; ++jp) w2[jp] = (splat2(r_a) * Tr2[jp]) * G2[jp];  // (a T) G, or 0
+      for (int jp = 0; jp < NP; ++jp)  // (a T) G, or 0; POLY: T (a G) -- a G is at hand (its own images only meet a tolerance)
+        w2[jp] = POLY ? Tr2[jp] * ag2[jp] : (splat2(r_a) * Tr2[jp]) * G2[jp];
       if constexpr (POLY) {
         // the three channels' denominators 1 + exp2(s_c) first, then ONE reciprocal per pixel for all of them:
         // 1 / d_c = (1 / (d_0 d_1 d_2)) * (the other two).  (poly_transform keeps |s| <= 40: the product stays finite.)
@@ -580,13 +594,18 @@ __device__ __forceinline__ void composite_fwd_sh_vec_tile(const CompParams &p, u
           }
         }
       }
+      if (track_stop) {  // (wave-uniform; a launch without the segmented backward's stop list skips 12 vector instructions)
 #pragma unroll
-      for (int jp = 0; jp < NP; ++jp) {
-        const bool was[2] = {alive(2 * jp), alive(2 * jp + 1)};
-        Tr2[jp] = Tr2[jp] * ffma2(-ag2[jp], splat2(1.0f), splat2(1.0f));  // T (1 - a G) if it contributed (explicit)
+        for (int jp = 0; jp < NP; ++jp) {
+          const bool was[2] = {alive(2 * jp), alive(2 * jp + 1)};
+          Tr2[jp] = Tr2[jp] * one_minus2(ag2[jp]);  // T (1 - a G) if it contributed (explicit)
 #pragma unroll
-        for (int e = 0; e < 2; ++e)
-          if (was[e] && !alive(2 * jp + e)) stop[2 * jp + e] = base + g + 1;
+          for (int e = 0; e < 2; ++e)
+            if (was[e] && !alive(2 * jp + e)) stop[2 * jp + e] = base + g + 1;
+        }
+      } else {
+#pragma unroll
+        for (int jp = 0; jp < NP; ++jp) Tr2[jp] = Tr2[jp] * one_minus2(ag2[jp]);
       }
     }
     bool any_alive = false;
@@ -1048,6 +1067,15 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
     }
     Tr2[j >> 1][j & 1] = (alive0[j] && !(ck.x < p.thresh)) ? ck.x : -1.0f;
   }
+  // POLY: the suffix enters d L / d (a G) only as  sum_c grad_out_c * suffix_c,  and every splat lowers that sum by
+  // w * sum_c grad_out_c * colour_c: ONE running value per pixel instead of three (two packed operations less per channel and
+  // pixel pair, eight registers less)
+  v2f R2[NP], pvsq2[NP];
+#pragma unroll
+  for (int jp = 0; jp < NP; ++jp) {
+    R2[jp] = fma2(go2[jp][2], rem2[jp][2], fma2(go2[jp][1], rem2[jp][1], go2[jp][0] * rem2[jp][0]));
+    pvsq2[jp] = pv2[jp] * pv2[jp];
+  }
   if constexpr (CHRED && !POLY) {  // each thread reads back only what it wrote: no barrier
 #pragma unroll
     for (int jp = 0; jp < NP; ++jp)
@@ -1082,15 +1110,21 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
       const float x = px - r_mx;
       // G2 / ag2: the Gaussian and a G, ZEROED where the pixel does not take part (skip threshold, or not alive)
       v2f y2[NP], G2[NP], ag2[NP];
-      bool any_con = false, any_guard = false;
+      bool any_con = false;
+      float guard_dist = 0.0f;
 #pragma unroll
       for (int jp = 0; jp < NP; ++jp) {
         y2[jp] = py2[jp] - splat2(r_my);
         G2[jp] = gauss_sh_pair(r_c0, r_c1, r_c2, r_c3, r_p0, x, y2[jp]);
         ag2[jp] = splat2(r_a) * G2[jp];
 #pragma unroll
-        for (int e = 0; e < 2; ++e) any_guard |= alive(2 * jp + e) && fabsf(ag2[jp][e] - kMinAlpha) <= kMinAlpha * kGuardTol;
+        for (int e = 0; e < 2; ++e) {
+          // the lane's smallest distance to the threshold (dead pixels included: a spurious trip re-tests per pixel)
+          const float dist = fabsf(ag2[jp][e] - kMinAlpha);
+          guard_dist = (jp == 0 && e == 0) ? dist : fminf(guard_dist, dist);
+        }
       }
+      const bool any_guard = guard_dist <= kMinAlpha * kGuardTol;
       // within rounding of the skip threshold: the reference's arithmetic decides (as gauss_eval).  One wave-uniform
       // test for all the lane's pixels: the branch is almost never taken (a handful of pixels per frame)
       if (wave_any(any_guard)) {
@@ -1109,9 +1143,15 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
         for (int e = 0; e < 2; ++e) {
           const bool con = alive(2 * jp + e) && !(ag2[jp][e] < kMinAlpha);
           G2[jp][e] = con ? G2[jp][e] : 0.0f;
-          ag2[jp][e] = con ? ag2[jp][e] : 0.0f;
+          if constexpr (!POLY) ag2[jp][e] = con ? ag2[jp][e] : 0.0f;
           any_con |= con;
         }
+      if constexpr (POLY) {  // the same products again, from the masked G: two packed multiplies instead of four selects
+#pragma unroll
+        for (int jp = 0; jp < NP; ++jp) {
+          ag2[jp] = splat2(r_a) * G2[jp];
+        }
+      }
       // (skipping a pixel PAIR none of whose 128 pixels takes part -- pair-major code, one wave-uniform test per pair -- was
       // measured again in round 3 with the polynomial body: 4 488 vs 4 507 renders/s, profiles/r03_ab_pairskip_polyonly.txt)
       if (!wave_any(any_con)) continue;  // nobody in the wave sees this Gaussian
@@ -1129,9 +1169,9 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
       v2f w2[NP], inv1m2[NP], pAG2[NP];
 #pragma unroll
       for (int jp = 0; jp < NP; ++jp) {
-        w2[jp] = (splat2(r_a) * Tr2[jp]) * G2[jp];  // the forward's (a T) G, or 0
+        w2[jp] = POLY ? Tr2[jp] * ag2[jp] : (splat2(r_a) * Tr2[jp]) * G2[jp];  // the forward's (a T) G -- POLY: T (a G) --, or 0
         if constexpr (!POLY) {
-          const v2f om = splat2(1.0f) - ag2[jp];
+          const v2f om = one_minus2(ag2[jp]);
           inv1m2[jp] = v2f{__builtin_amdgcn_rcpf(om[0]), __builtin_amdgcn_rcpf(om[1])};
         }
         pAG2[jp] = v2f{0.0f, 0.0f};
@@ -1154,7 +1194,7 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
         }
 #pragma unroll
         for (int jp = 0; jp < NP; ++jp) {
-          const v2f om = splat2(1.0f) - ag2[jp];
+          const v2f om = one_minus2(ag2[jp]);
           const v2f d01 = den[0][jp] * den[1][jp], d2o = den[2][jp] * om;
           const v2f dd = d01 * d2o;
           const v2f r = v2f{__builtin_amdgcn_rcpf(dd[0]), __builtin_amdgcn_rcpf(dd[1])};
@@ -1164,6 +1204,7 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
           yv[2][jp] = r2o * om;
           inv1m2[jp] = r2o * den[2][jp];
         }
+        v2f gy2[NP];  // sum_c grad_out_c * colour_c
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           // d L / d w[c][r] = sum over pixels of gs * monomial_r: the lane's sums of gs, gs v, gs v^2, then its column's u
@@ -1171,20 +1212,22 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
 #pragma unroll
           for (int jp = 0; jp < NP; ++jp) {
             const v2f y_ = yv[c][jp];
-            rem2[jp][c] = fma2(-w2[jp], y_, rem2[jp][c]);
             const v2f dy = fma2(-y_, y_, y_);  // y (1 - y)
             const v2f go = go2[jp][c];  // (registers: this body has them to spare; the exact one reads its copy in LDS)
             const v2f gs = (w2[jp] * dy) * go;
-            const v2f sfx = rem2[jp][c] * inv1m2[jp];
-            pAG2[jp] = fma2(go, fma2(y_, Tr2[jp], -sfx), pAG2[jp]);
-            const v2f m1 = gs * pv2[jp], m2 = m1 * pv2[jp];
-            if (jp == 0) { g0 = gs; g1 = m1; g2 = m2; }
-            else { g0 = g0 + gs; g1 = g1 + m1; g2 = g2 + m2; }
+            gy2[jp] = c == 0 ? go * y_ : fma2(go, y_, gy2[jp]);
+            if (jp == 0) { g0 = gs; g1 = gs * pv2[jp]; g2 = gs * pvsq2[jp]; }
+            else { g0 = g0 + gs; g1 = fma2(gs, pv2[jp], g1); g2 = fma2(gs, pvsq2[jp], g2); }
           }
           const float G0 = add_scalar(g0[0], g0[1]), G1 = add_scalar(g1[0], g1[1]), G2s = add_scalar(g2[0], g2[1]);
           const float uG0 = pu * G0;
           // (1, v, u, v^2, uv, u^2): six of the channel's eight reduction slots; the last two carry geometric components (below)
           pch[c][0] = v2f{G0, G1}; pch[c][1] = v2f{uG0, G2s}; pch[c][2] = v2f{pu * G1, pu * uG0};
+        }
+#pragma unroll
+        for (int jp = 0; jp < NP; ++jp) {
+          R2[jp] = fma2(-w2[jp], gy2[jp], R2[jp]);  // the suffix behind this splat (vol_render_sh.h:328-333), grad_out-weighted
+          pAG2[jp] = fma2(gy2[jp], Tr2[jp], -(R2[jp] * inv1m2[jp]));
         }
       }
       if constexpr (!POLY) {
@@ -1262,7 +1305,7 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
         gc1 = fma2(hvx, vy, gc1);
         gc3 = fma2(h * vy, vy, gc3);
         gal = fma2(pa, G2[jp], gal);
-        Tr2[jp] = Tr2[jp] * ffma2(-ag2[jp], splat2(1.0f), splat2(1.0f));  // T (1 - a G) if it contributed (explicit: as the forward)
+        Tr2[jp] = Tr2[jp] * one_minus2(ag2[jp]);  // T (1 - a G) if it contributed (explicit: as the forward)
       }
       const float m0 = gm0[0] + gm0[1], m1 = gm1[0] + gm1[1];
       const float c0 = gc0[0] + gc0[1], c1 = gc1[0] + gc1[1], c3 = gc3[0] + gc3[1];
@@ -1498,7 +1541,7 @@ k_composite_fwd_chan_vec(CompParams p_arg, const CompParams *__restrict__ plist)
         const v2f w2 = (splat2(r_a) * Tr2[jp]) * G2[jp];  // (a T) G, or 0
 #pragma unroll
         for (int c = 0; c < NCH; ++c) acc2[jp][c] = ffma2(splat2(wave_uniform(cg[c])), w2, acc2[jp][c]);
-        Tr2[jp] = Tr2[jp] * ffma2(-ag2[jp], splat2(1.0f), splat2(1.0f));  // T (1 - a G) if it contributed (explicit)
+        Tr2[jp] = Tr2[jp] * one_minus2(ag2[jp]);  // T (1 - a G) if it contributed (explicit)
       }
     }
     bool any_alive = false;
@@ -1627,7 +1670,7 @@ k_composite_bwd_chan_vec(CompParams p_arg, const CompParams *__restrict__ plist)
 #pragma unroll
       for (int jp = 0; jp < NP; ++jp) {
         w2[jp] = (splat2(r_a) * Tr2[jp]) * G2[jp];  // the forward's (a T) G, or 0
-        const v2f om = splat2(1.0f) - ag2[jp];
+        const v2f om = one_minus2(ag2[jp]);
         inv1m2[jp] = v2f{__builtin_amdgcn_rcpf(om[0]), __builtin_amdgcn_rcpf(om[1])};
         pAG2[jp] = v2f{0.0f, 0.0f};
       }
@@ -1662,7 +1705,7 @@ k_composite_bwd_chan_vec(CompParams p_arg, const CompParams *__restrict__ plist)
         gc1 = fma2(hvx, vy, gc1);
         gc3 = fma2(h * vy, vy, gc3);
         gal = fma2(pAG2[jp], G2[jp], gal);
-        Tr2[jp] = Tr2[jp] * ffma2(-ag2[jp], splat2(1.0f), splat2(1.0f));  // T (1 - a G) if it contributed (as the forward)
+        Tr2[jp] = Tr2[jp] * one_minus2(ag2[jp]);  // T (1 - a G) if it contributed (as the forward)
       }
       const float c1s = add_scalar(gc1[0], gc1[1]);
       gr2[G0 / 2 + 0] = v2f{add_scalar(gm0[0], gm0[1]), add_scalar(gm1[0], gm1[1])};
