@@ -396,7 +396,7 @@ def test_emulated_reduce_scatter(emu, Pc):
 
 
 def test_emulated_sort_register_widths(emu):
-    """register sort K = 1..32 and the workgroup path under emulation"""
+    """register sort K = 1..32 and the long-list path (2048-entry register blocks + merge passes over the segment) under emulation"""
     sizes = (1, 64, 65, 130, 300, 600, 1100, 2048, 2049, 4097, 9000)   # > 2048: register blocks + global merge passes
     ntw, nth = len(sizes), 1
     rng = np.random.default_rng(12)

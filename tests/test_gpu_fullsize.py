@@ -1,11 +1,10 @@
 """Full-size parity of the fused path against the CPU oracle at BASELINE.json's sizes (-m gpu).
 
-cfg2 (100k Gaussians, 800x800), cfg3 (500k post-densify Gaussians, 1024x1024: long per-tile lists, the
-LDS/global sort path) and cfg4 (100k Gaussians, the 64 CameraPoseProvider-style poses at 512x512 through the
+cfg2 (100k Gaussians, 800x800), cfg3 (500k post-densify Gaussians, 1024x1024: long per-tile lists) and cfg4 (100k Gaussians, the 64 CameraPoseProvider-style poses at 512x512 through the
 batched launches), each compared with the oracle on the same inputs: pair count, per-tile lists and order
 exact; the image within 1e-4 on EVERY pixel (north_star); every gradient -- mean, qvec, svec, alpha, sh --
 within 1e-3 of the largest reference entry (fp32 atomics reorder the sums; the oracle sums in fp64).  Plus a
-dense cluster whose centre tiles hold more than 2048 list entries (the k_sort_tiles_big path inside
+dense cluster whose centre tiles hold more than 2048 list entries (k_sort_tiles' block-sort + merge path inside
 gsgen_frame_geometry) and more than one staging batch per tile in the compositing kernels."""
 import os
 import sys
@@ -120,7 +119,7 @@ def test_full_size_cfg3():
 
 
 def test_dense_cluster_long_lists():
-    """centre tiles with more than 2048 list entries: the big-segment sort of the fused geometry and several LDS
+    """centre tiles with more than 2048 list entries: the long-list path of the per-tile sort (register blocks + merge passes) and several LDS
     staging batches per tile in both compositing kernels (SH degree 1, 192x192 keeps the oracle quick)"""
     sc = scenes.random_scene(40_000, seed=21, svec=0.02, spread=0.12, C=2)
     sc["alpha"] = (sc["alpha"] * 0.08).astype(np.float32)  # translucent: the lists are walked to their ends

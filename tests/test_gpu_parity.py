@@ -326,8 +326,8 @@ def test_unsupported_configs_raise():
 
 
 def test_long_tile_list_and_ties():
-    """One tile holding more pairs than the LDS sort capacity (4096) and more than one LDS
-    staging batch; many exactly equal depths (ties resolve by Gaussian id, the oracle's
+    """One tile holding more pairs than one register block of the sort (2048: block sorts + merge passes) and more
+    than one LDS staging batch; many exactly equal depths (ties resolve by Gaussian id, the oracle's
     emission order); negative depths sort after positive ones (unsigned key order)."""
     L = lib()
     N = 5000
@@ -351,10 +351,10 @@ def test_long_tile_list_and_ties():
 
 
 @pytest.mark.parametrize("sizes", [(1, 40, 64, 65, 100, 128, 129, 200, 256, 300, 511, 512, 513, 700, 1024, 1025, 1500, 2039, 2040,
-                                    2047, 2048, 2049, 3000, 4096, 4100)])
+                                    2047, 2048, 2049, 3000, 4096, 4097, 4100, 6200, 9000)])
 def test_sort_every_register_width(sizes):
     """Per-tile segments of every size class of the register sort (K = 1..32 keys per lane),
-    the LDS path and their boundaries, with duplicate depths."""
+    the long-list path (beyond 2048 entries) and their boundaries, with duplicate depths."""
     L = lib()
     ntw, nth = len(sizes), 1
     rng = np.random.default_rng(12)
