@@ -504,11 +504,11 @@ __device__ __forceinline__ void composite_fwd_sh_vec_tile(const CompParams &p, u
       for (int jp = 0; jp < NP; ++jp) {
         G2[jp] = gauss_sh_pair(r_c0, r_c1, r_c2, r_c3, r_p0, x, py2[jp] - splat2(r_my));
         ag2[jp] = splat2(r_a) * G2[jp];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
+        {
           // the lane's smallest distance to the threshold (dead pixels included: a spurious trip re-tests per pixel)
-          const float dist = fabsf(ag2[jp][e] - kMinAlpha);
-          guard_dist = (jp == 0 && e == 0) ? dist : fminf(guard_dist, dist);
+          const v2f dist = ag2[jp] - splat2(kMinAlpha);
+          const float dmin = fminf(fabsf(dist[0]), fabsf(dist[1]));
+          guard_dist = jp == 0 ? dmin : fminf(guard_dist, dmin);
         }
       }
       const bool any_guard = guard_dist <= kMinAlpha * kGuardTol;
@@ -1117,11 +1117,11 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
         y2[jp] = py2[jp] - splat2(r_my);
         G2[jp] = gauss_sh_pair(r_c0, r_c1, r_c2, r_c3, r_p0, x, y2[jp]);
         ag2[jp] = splat2(r_a) * G2[jp];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
+        {
           // the lane's smallest distance to the threshold (dead pixels included: a spurious trip re-tests per pixel)
-          const float dist = fabsf(ag2[jp][e] - kMinAlpha);
-          guard_dist = (jp == 0 && e == 0) ? dist : fminf(guard_dist, dist);
+          const v2f dist = ag2[jp] - splat2(kMinAlpha);
+          const float dmin = fminf(fabsf(dist[0]), fabsf(dist[1]));
+          guard_dist = jp == 0 ? dmin : fminf(guard_dist, dmin);
         }
       }
       const bool any_guard = guard_dist <= kMinAlpha * kGuardTol;
