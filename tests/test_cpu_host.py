@@ -970,6 +970,23 @@ def test_no_kernel_spills_and_hot_kernels_keep_their_occupancy(tmp_path):
         assert fwd["vgpr_count"] <= 128
     for srt in find(2, "k_sort_tiles"):   # register sort, no LDS, three wavefronts per SIMD; long lists in the same launch
         assert srt["group_segment_fixed_size"] == 0 and srt["vgpr_count"] <= 168, srt
+    # 1 - a G must be the subtraction of the ROUNDED product in every shape of the packed SH kernels (common.hpp one_minus2):
+    # -ffp-contract=fast once fused it into fma(-a, G, 1) in the per-camera forward and not in the batched one, and the two
+    # images differed in the last bit -- something only a GPU run could see.  No instantiation may contain the fused form.
+    fused = {}
+    for f in sorted(os.listdir(tmp_path)):
+        if "amdgcn" not in f:
+            continue
+        dis = subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", f], cwd=tmp_path, capture_output=True, text=True,
+                             check=True).stdout
+        cur = None
+        for line in dis.split("\n"):
+            m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+            if m:
+                cur = m.group(1)
+            elif cur and "_sh_vec" in cur and re.search(r"v_pk_fma_f32 .*, 1\.0 .*neg_lo:\[1,0,0\]", line):
+                fused[cur] = fused.get(cur, 0) + 1
+    assert not fused, fused
 
 
 @pytest.mark.parametrize("mode", [0, 1])
