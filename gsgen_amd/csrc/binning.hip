@@ -384,8 +384,8 @@ __device__ __forceinline__ void long_pass(u64 *__restrict__ k, uint32_t n, uint3
   }
   __syncthreads();  // one wavefront: orders this pass's stores before the next pass's loads
 }
+template <int K = kSortMaxK>
 __device__ __forceinline__ void sort_segment_long(u64 *__restrict__ keys, int *__restrict__ ids, uint32_t n) {
-  constexpr int K = kSortMaxK;
   constexpr uint32_t kBlock = 64u * K;
   const uint32_t lane = (uint32_t)lane_id();
   const uint32_t nblk = (n + kBlock - 1u) / kBlock;
@@ -452,7 +452,89 @@ sort_tiles_body(uint32_t tile, const uint32_t *__restrict__ tile_off, const uint
   else if (n <= 256u) sort_segment_regs<4>(keys + b, ids + b, n);
   else if (n <= 512u) sort_segment_regs<8>(keys + b, ids + b, n);
   else if (n <= 1024u) sort_segment_regs<16>(keys + b, ids + b, n);
-  else sort_segment_long(keys + b, ids + b, n);
+  else sort_segment_long<>(keys + b, ids + b, n);
+}
+
+// A LONE view's sort (gsgen_frame_geometry, the stand-alone binning entry point): its 2 500 wavefronts all fit the chip at once,
+// so nothing balances them -- the launch lasts as long as the SIMD that drew three 1 024-key tiles (43 us for cfg2; the same
+// tiles inside an 8-view launch, longest first and dynamically placed: 14 us per view).  Here a tile of more than 256 entries is
+// sorted by FOUR wavefronts: each sorts a quarter in registers (K = 2 / 4 / 8 keys per lane), the two merge stages that span
+// quarters run their cross-quarter distances as three passes over LDS (256 threads, a barrier each) and every stage's distances
+// inside a quarter in registers again -- ~1.5 us of work per tile instead of ~5-12.  Tiles of up to 256 entries: wavefront 0 as
+// before (the others leave at once); beyond 2 048: wavefront 0's block-sort + merge path.
+constexpr int kCoopWaves = 4;
+constexpr uint32_t kCoopMax = 2048;
+__device__ __forceinline__ void lds_pass(u64 *k, uint32_t p2, uint32_t dist, bool flip) {
+  for (uint32_t c = threadIdx.x; c < (p2 >> 1); c += 64u * kCoopWaves) {
+    const uint32_t off = c & (dist - 1u);
+    const uint32_t i = ((c - off) << 1) + off;
+    const uint32_t l = flip ? (i ^ (2u * dist - 1u)) : (i + dist);
+    const u64 a = k[i], b = k[l];  // (the segment is padded with +inf up to p2: no bounds to test)
+    if (a > b) { k[i] = b; k[l] = a; }
+  }
+  __syncthreads();
+}
+template <int KW>
+__device__ __forceinline__ void sort_segment_coop(const u64 *__restrict__ keys, int *__restrict__ ids, uint32_t n, u64 *s_keys) {
+  constexpr uint32_t kBlk = 64u * KW;  // a wavefront's quarter; p2 = 4 kBlk
+  const uint32_t wave = threadIdx.x >> 6, lane = (uint32_t)lane_id();
+  const uint32_t e0 = wave * kBlk + lane * KW;
+  u64 k[KW];
+#pragma unroll
+  for (int r = 0; r < KW; ++r) k[r] = (e0 + r < n) ? keys[e0 + r] : ~0ull;
+  sort_regs<KW>(k);
+  auto to_lds = [&]() {
+#pragma unroll
+    for (int r = 0; r < KW; ++r) s_keys[e0 + r] = k[r];
+    __syncthreads();
+  };
+  auto tail_in_registers = [&]() {  // a stage's distances kBlk / 2 .. 1: inside the quarter
+#pragma unroll
+    for (int r = 0; r < KW; ++r) k[r] = s_keys[e0 + r];
+    for (int j = (int)kBlk / 2; j >= KW; j >>= 1) cross_step<KW>(k, j / KW, false);
+    local_tail<KW, KW / 2>(k);
+  };
+  to_lds();
+  lds_pass(s_keys, 4u * kBlk, kBlk, true);         // stage 2 kBlk: its flip step
+  tail_in_registers();
+  __syncthreads();                                 // (everyone has read its quarter before it is overwritten)
+  to_lds();
+  lds_pass(s_keys, 4u * kBlk, 2u * kBlk, true);    // stage 4 kBlk: flip, then distance kBlk
+  lds_pass(s_keys, 4u * kBlk, kBlk, false);
+  tail_in_registers();
+#pragma unroll
+  for (int r = 0; r < KW; ++r)
+    if (e0 + r < n) ids[e0 + r] = (int)(uint32_t)(k[r] & 0xffffffffull);
+}
+__global__ void __launch_bounds__(64 * kCoopWaves)
+k_sort_tiles_coop(uint32_t T, const uint32_t *__restrict__ tile_off, const uint32_t *__restrict__ ctrl,
+                  unsigned long long *__restrict__ keys, int *__restrict__ ids, int *__restrict__ start,
+                  int *__restrict__ end, const uint32_t *__restrict__ tile_order) {
+  __shared__ u64 s_keys[kCoopMax];
+  const uint32_t tile = tile_order[blockIdx.x];  // longest list first (order_tiles_body): the four-wavefront sorts start at once
+  const uint32_t tid = threadIdx.x;
+  if (ctrl[1] != 0u) {
+    if (tid == 0) { start[tile] = -1; end[tile] = -1; }
+    return;
+  }
+  const uint32_t b = tile_off[tile], e = tile_off[tile + 1];
+  const uint32_t n = e - b;
+  if (tid == 0) {  // empty tiles stay -1 (aabb_culling.h:248-249)
+    start[tile] = n ? (int)b : -1;
+    end[tile] = n ? (int)e : -1;
+  }
+  if (n == 0) return;
+  if (n <= 256u || n > kCoopMax) {  // (uniform over the workgroup)
+    if (tid >= 64u) return;
+    if (n <= 64u) sort_segment_regs<1>(keys + b, ids + b, n);
+    else if (n <= 128u) sort_segment_regs<2>(keys + b, ids + b, n);
+    else if (n <= 256u) sort_segment_regs<4>(keys + b, ids + b, n);
+    else sort_segment_long<8>(keys + b, ids + b, n);  // (512-entry blocks: this kernel stays at its quarter sorts' registers)
+    return;
+  }
+  if (n <= 512u) sort_segment_coop<2>(keys + b, ids + b, n, s_keys);
+  else if (n <= 1024u) sort_segment_coop<4>(keys + b, ids + b, n, s_keys);
+  else sort_segment_coop<8>(keys + b, ids + b, n, s_keys);
 }
 
 // ---- self test of the cross-lane primitives (tests/ only; exported for the parity suite) ----
@@ -578,7 +660,8 @@ static int bin_and_sort(uint32_t N, uint32_t cap, uint32_t nth, uint32_t ntw, co
   if (N)
     hipLaunchKernelGGL((k_bin_pull<true>), gpull, bpull, 0, s, N, tl, br, depth, (int)ntw, (int)nth, T,
                        w.cnt, w.wcnt, w.tile_off, w.ctrl, w.keys);
-  hipLaunchKernelGGL(k_sort_tiles, dim3(T), dim3(64), 0, s, T, w.tile_off, w.ctrl, w.keys, ids, start, end);
+  hipLaunchKernelGGL(k_sort_tiles_coop, dim3(T), dim3(64 * kCoopWaves), 0, s, T, w.tile_off, w.ctrl, w.keys, ids, start, end,
+                     (const uint32_t *)w.tile_order);
   return (int)hipGetLastError();
 }
 

@@ -968,8 +968,10 @@ def test_no_kernel_spills_and_hot_kernels_keep_their_occupancy(tmp_path):
         assert bwd["vgpr_count"] <= 128
     for fwd in find(2, "k_composite_fwdILi2ELi4ELi1E", "ELi16EE"):      # default SH forward: 4 wavefronts per tile
         assert fwd["vgpr_count"] <= 128
-    for srt in find(2, "k_sort_tiles"):   # register sort, no LDS, three wavefronts per SIMD; long lists in the same launch
-        assert srt["group_segment_fixed_size"] == 0 and srt["vgpr_count"] <= 168, srt
+    for srt in find(2, "k_sort_tiles", "PiS3_S3_") + find(1, "k_sort_tiles_views"):   # register sort, no LDS unless cooperative
+        coop = srt["group_segment_fixed_size"] != 0   # (a lone view's launch: four wavefronts per tile, 16 KB, small quarters)
+        assert (srt["group_segment_fixed_size"] == 16384 and srt["vgpr_count"] <= 64) if coop else srt["vgpr_count"] <= 168, srt
+    assert len(find(3, "k_sort_tiles")) == 3
     # 1 - a G must be the subtraction of the ROUNDED product in every shape of the packed SH kernels (common.hpp one_minus2):
     # -ffp-contract=fast once fused it into fma(-a, G, 1) in the per-camera forward and not in the batched one, and the two
     # images differed in the last bit -- something only a GPU run could see.  No instantiation may contain the fused form.
