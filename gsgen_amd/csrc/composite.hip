@@ -635,7 +635,7 @@ __device__ __forceinline__ void composite_fwd_sh_vec_tile(const CompParams &p, u
 // How a launch that was given the coefficient bound is made of these instantiations (launch helpers below):
 //   one camera   NB = kRouted   -- ONE kernel holding both forms (a lone launch does not fill the chip: register-limited
 //                                  occupancy is irrelevant, an extra launch is not)
-//   camera batch NB = kPolyNB   -- the polynomial form alone: 73-104 registers instead of 96-168, i.e. 4 wavefronts per SIMD in
+//   camera batch NB = kPolyNB   -- the polynomial form alone: 76-120 registers instead of 96-168, i.e. 4 wavefronts per SIMD in
 //                                  the backward instead of 3 (+7-11 % renders/s, profiles/r03_ab_pairskip_polyonly.txt); a
 //                                  workgroup whose view fails the bound leaves at once
 //              + NB = kFallback -- the exact form for exactly those views: a PERSISTENT launch of a few thousand workgroups
@@ -1313,7 +1313,7 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
       if constexpr (CHRED && POLY) {
         // The six DISTINCT geometric components (grad_cov[1] and grad_cov[2] receive the same value, kernels.h:414-415) ride
         // in the two spare slots of the three channels' 8-wide reductions: (m0, m1) | (c0, c1) | (c3, alpha).  No fourth
-        // reduction: 363 -> 348 vector instructions per (wavefront, entry).
+        // reduction (363 -> 348 vector instructions per (wavefront, entry) when it went in; 321 now).
         v2f t0[4] = {pch[0][0], pch[0][1], pch[0][2], v2f{m0, m1}};
         v2f t1[4] = {pch[1][0], pch[1][1], pch[1][2], v2f{c0, c1}};
         v2f t2[4] = {pch[2][0], pch[2][1], pch[2][2], v2f{c3, ga}};
@@ -1885,7 +1885,7 @@ static void launch_fwd_sh_batch_c(const CompParams &p0, const CompParams *plist,
     // workgroup decides from the bound and ITS view's pixel size whether it runs the polynomial or the exact form
     // (poly_route; forward and backward read the same value, hence agree).
     if (bounded) {
-      // polynomial kernel over the whole grid (one wavefront per tile: 89 registers, 5 per SIMD -- 5 020 vs 4 833 renders/s
+      // polynomial kernel over the whole grid (one wavefront per tile: 96 registers, 5 per SIMD -- 5 020 vs 4 833 renders/s
       // against two wavefronts per tile), then the persistent exact fallback for the views beyond the bound (10 two-wavefront
       // workgroups per compute unit at most)
       CompParams pf = p0;
@@ -1936,7 +1936,7 @@ template <int CB>
 static void launch_bwd_sh_batch_c(const CompParams &p0, const CompParams *plist, uint32_t B, uint32_t nblk, hipStream_t s, bool bounded) {
   const dim3 g(nblk * B);
   if constexpr (CB == 4) {
-    if (bounded) {  // as the forward: the polynomial kernel (104 registers: 4 wavefronts per SIMD), then the persistent exact fallback
+    if (bounded) {  // as the forward: the polynomial kernel (120 registers: 4 wavefronts per SIMD), then the persistent exact fallback
       CompParams pf = p0;
       pf.vgrid = nblk * B;
       const uint32_t gf = pf.vgrid < 2048u ? pf.vgrid : 2048u;  // 8 one-wavefront workgroups per compute unit (2 per SIMD)

@@ -364,6 +364,49 @@ def test_emulated_batched_frame_geometry_equals_per_view(emu):
     emu.frame_geometry_batch(0, arr, N, P(sc["mean"]), P(sc["qvec"]), P(sc["svec"]), W, H, None, None)
 
 
+def test_emulated_long_lists_through_both_sort_launches(emu):
+    """A tight cluster: tiles with more than 2048 list entries (and some between 257 and 2048) through the lone view's
+    four-wavefront sort launch (gsgen_frame_geometry: quarter sorts + LDS passes; beyond 2048 its 512-entry block path) AND through
+    the batched launch's one-wavefront-per-tile sort (2048-entry register blocks + merge passes over the segment): both leave
+    the oracle's lists"""
+    from gsgen_amd import renderer as R
+    from gsgen_amd._capi import GeometryView
+    W, H = 64, 48
+    sc = scenes.random_scene(6000, seed=23, svec=0.02, spread=0.12)
+    N = sc["mean"].shape[0]
+    cam = scenes.Camera(W, H, fx=70.0, cx=38, cy=29, c2w=scenes.orbit(2.2, 15, 40))   # lists of 269, 654, 2156, 5165 entries
+    g = scenes.oracle_geometry(sc, cam)
+    nth, ntw = cam.tiles
+    T = nth * ntw
+    lens = (g["end"] - g["start"])[g["start"] >= 0]
+    assert lens.max() > 2048 and ((lens > 256) & (lens <= 2048)).any(), lens
+    cap = g["D"]
+    cv = np.ascontiguousarray(R.CameraInfo(*cam.intr).pack(cam.c2w))
+
+    def fresh():
+        return dict(m2=np.zeros((N, 2), np.float32), c2=np.zeros((N, 4), np.float32), dep=np.zeros(N, np.float32),
+                    mask=np.zeros(N, np.uint8), ids=np.full(cap, -7, np.int32), st=np.zeros(T, np.int32),
+                    en=np.zeros(T, np.int32), tot=np.zeros(1, np.uint32),
+                    ws=np.zeros(emu.frame_workspace_bytes(N, cap, T), np.uint8))
+    one, bat = fresh(), fresh()
+    emu.frame_geometry(N, P(sc["mean"]), P(sc["qvec"]), P(sc["svec"]), P(cv), W, H, cap, P(one["m2"]), P(one["c2"]),
+                       P(one["dep"]), P(one["mask"]), P(one["ids"]), P(one["st"]), P(one["en"]), P(one["tot"]), P(one["ws"]),
+                       one["ws"].size, None)
+    arr = (GeometryView * 1)()
+    a = arr[0]
+    a.cam, a.mean2d, a.cov2d, a.depth, a.mask = P(cv), P(bat["m2"]), P(bat["c2"]), P(bat["dep"]), P(bat["mask"])
+    a.gaussian_ids, a.start, a.end, a.total = P(bat["ids"]), P(bat["st"]), P(bat["en"]), P(bat["tot"])
+    a.workspace, a.workspace_bytes, a.D_cap = P(bat["ws"]), bat["ws"].size, cap
+    bws = np.zeros(emu.frame_batch_workspace_bytes(1), np.uint8)
+    emu.frame_geometry_batch(1, arr, N, P(sc["mean"]), P(sc["qvec"]), P(sc["svec"]), W, H, P(bws), None)
+    # the fused frame numbers the VISIBLE Gaussians' ids in the full array: the oracle's ids index its compacted arrays
+    vis = np.flatnonzero(g["mask"])
+    for got in (one, bat):
+        assert got["tot"][0] == g["D"]
+        assert np.array_equal(got["st"], g["start"]) and np.array_equal(got["en"], g["end"])
+        assert np.array_equal(got["ids"][:g["D"]], vis[g["ids"]])
+
+
 def test_emulated_upload_small_chunks_and_argument_checks(emu):
     """gsgen_upload_small: the bytes travel as kernel arguments, 3 584 per launch; any multiple of 4 arrives intact,
     the source may be reused at once, misaligned sizes are refused."""

@@ -128,6 +128,38 @@ def test_dense_cluster_long_lists():
     assert longest > 2048
 
 
+def test_dense_cluster_long_lists_batched():
+    """the same dense cluster through the BATCHED launches (two cameras): there a tile is sorted by ONE wavefront, and a list
+    of more than 2048 entries takes its 2048-entry register blocks + merge passes over the segment (the lone view's launch of the
+    test above sorts with four wavefronts per tile and 512-entry blocks): lists against the oracle, images too"""
+    from gsgen_amd import renderer as R
+    from gsgen_amd.batch import BatchRenderer
+    sc = scenes.random_scene(40_000, seed=21, svec=0.02, spread=0.12, C=2)
+    sc["alpha"] = (sc["alpha"] * 0.08).astype(np.float32)
+    cams = [scenes.Camera(192, 192, fx=150.0 + 20 * i, c2w=scenes.orbit(2.5, 20 + 15 * i, 50 + 60 * i)) for i in range(2)]
+    N = sc["mean"].shape[0]
+    P = {k: T_(sc[k]) for k in KEYS}
+    br = BatchRenderer(N, 192, 192, dev(), max_batch=2)
+    bg = np.array([0.1, 0.2, 0.3], np.float32)
+    cis = [R.CameraInfo(*c.intr) for c in cams]
+    for _ in range(3):
+        with torch.no_grad():
+            rgb, _ = br.render(P["mean"], P["qvec"], P["svec"], P["alpha"], P["sh"], cis, [c.c2w for c in cams], C=2, bg_rgb=T_(bg))
+        if br.ensure_capacity(2):
+            break
+    img = rgb.cpu().numpy()
+    longest = 0
+    for i, cam in enumerate(cams):
+        g = scenes.oracle_geometry(sc, cam)
+        check_lists(br.slots[i], g)
+        longest = max(longest, int((g["end"] - g["start"]).max()))
+        m = g["mask"]
+        ref = O.render_sh_fwd(g["mean2d"], g["cov2d"], sc["sh"][m], sc["alpha"][m], g["start"], g["end"], g["ids"], cam.topleft,
+                              cam.c2w[:3, :3].reshape(-1), 2, 1 / cam.fx, 1 / cam.fy, cam.h, cam.w, bg=bg)
+        assert np.abs(img[i] - ref).max() <= 1e-4
+    assert longest > 2048
+
+
 def test_full_size_cfg4_64_random_poses_batched():
     """BASELINE configs[3]: 100k Gaussians, the 64 random poses (distance U(2, 2.5), elevation arcsin-uniform in
     [-20, 90] deg, azimuth U(-180, 180), focal U(0.7, 1.35) x 512; data/__init__.py:151-205) at 512x512, 8 cameras
