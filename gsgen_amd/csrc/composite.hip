@@ -1067,7 +1067,7 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
     }
     Tr2[j >> 1][j & 1] = (alive0[j] && !(ck.x < p.thresh)) ? ck.x : -1.0f;
   }
-  // POLY: the suffix enters d L / d (a G) only as  sum_c grad_out_c * suffix_c,  and every splat lowers that sum by
+  // The suffix enters d L / d (a G) only as  sum_c grad_out_c * suffix_c,  and every splat lowers that sum by
   // w * sum_c grad_out_c * colour_c: ONE running value per pixel instead of three (two packed operations less per channel and
   // pixel pair, eight registers less)
   v2f R2[NP], pvsq2[NP];
@@ -1230,6 +1230,7 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
           pAG2[jp] = fma2(gy2[jp], Tr2[jp], -(R2[jp] * inv1m2[jp]));
         }
       }
+      v2f gyx2[NP];
       if constexpr (!POLY) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
@@ -1251,14 +1252,12 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
           const v2f sp = v2f{add_scalar(sa[0], sa[1]), add_scalar(sb[0], sb[1])};
           const v2f den = splat2(1.0f) + v2f{__builtin_amdgcn_exp2f(sp[0]), __builtin_amdgcn_exp2f(sp[1])};
           const v2f yv = v2f{__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
-          rem2[jp][c] = fma2(-w2[jp], yv, rem2[jp][c]);
           const v2f dy = fma2(-yv, yv, yv);  // y (1 - y)
           v2f go;
           if constexpr (CHRED) go = go_s[(c * NP + jp) * NT + t];
           else go = go2[jp][c];
           const v2f gs = (w2[jp] * dy) * go;
-          const v2f sfx = rem2[jp][c] * inv1m2[jp];
-          pAG2[jp] = fma2(go, fma2(yv, Tr2[jp], -sfx), pAG2[jp]);
+          gyx2[jp] = c == 0 ? go * yv : fma2(go, yv, gyx2[jp]);  // sum_c grad_out_c * colour_c (see R2)
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
             const v2f gse = splat2(gs[e]);
@@ -1285,6 +1284,11 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
 #pragma unroll
           for (int k = 0; k < NPAIR; ++k) gr2[c * NPAIR + k] = gq[k];
         }
+      }
+#pragma unroll
+      for (int jp = 0; jp < NP; ++jp) {  // the grad_out-weighted suffix behind this splat, and d L / d (a G) from it (as POLY)
+        R2[jp] = fma2(-w2[jp], gyx2[jp], R2[jp]);
+        pAG2[jp] = fma2(gyx2[jp], Tr2[jp], -(R2[jp] * inv1m2[jp]));
       }
       }  // !POLY
       // mean2d (2) | cov2d (4) | alpha (1): kernel_gaussian_2d_backward (kernels.h:394-418), packed over the pair
