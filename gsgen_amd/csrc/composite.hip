@@ -1394,9 +1394,8 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
     if (__syncthreads_or((int)any_alive) == 0) break;
   }
 }
-// (the persistent fallback runs at 174 registers = TWO wavefronts per SIMD: its loop state pushes the scalar registers to their
-// limit and the allocator lands six vector registers above the 168 of the exact kernel's class; forcing three costs 32 bytes
-// of scratch per lane.  It only renders views whose coefficient bound fails while a batch mate's holds.)
+// (the persistent fallback runs at 152 registers, the exact kernel at 148: three wavefronts per SIMD.  It only renders views whose
+// coefficient bound fails while a batch mate's holds.)
 template <int CB, int PPL, bool BATCH = false, bool CHRED = false, int NB = 0>
 __global__ void __launch_bounds__(256 / PPL)
 k_composite_bwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
@@ -1852,7 +1851,7 @@ static int launch_bwd(const CompParams &p_, hipStream_t s) {
 }
 
 // ---- the persistent exact fallback of a bounded batch: where it goes ---------------------------------
-// It normally has nothing to do, but its workgroups (174 registers in the backward) must each FIND ROOM on a chip that other
+// It normally has nothing to do, but its workgroups (152 registers in the backward) must each FIND ROOM on a chip that other
 // batches' compositing launches fill.  Measured on one box (profiles/r03_ab_fallback_order.txt, renders/s on the driver
 // command): no fallback at all (views beyond the bound would be lost) 4 993; fallback IN FRONT of the polynomial kernel on the
 // caller's stream 4 959 (it finds room while the previous stage of the chain drains); behind it 4 919; on a side stream forked

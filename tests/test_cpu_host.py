@@ -995,9 +995,9 @@ def test_no_kernel_spills_and_hot_kernels_keep_their_occupancy(tmp_path):
         assert bwd["vgpr_count"] <= 128 and 16 * bwd["group_segment_fixed_size"] <= 160 * 1024, bwd
     for fwd in find(1, "k_composite_fwd_sh_vecILi4ELi4ELb1ELi6EE"):
         assert fwd["vgpr_count"] <= 96 and 20 * fwd["group_segment_fixed_size"] <= 160 * 1024, fwd
-    # (the persistent fallback's loop state costs it a wavefront per SIMD: two in the backward, four in the forward)
+    # (the persistent fallback: three wavefronts per SIMD in the backward as the exact kernel itself, four in the forward)
     for bwd in find(1, "k_composite_bwd_sh_vecILi4ELi4ELb1ELb1ELin2EE"):
-        assert bwd["vgpr_count"] <= 176 and 8 * bwd["group_segment_fixed_size"] <= 160 * 1024, bwd
+        assert bwd["vgpr_count"] <= 168 and 12 * bwd["group_segment_fixed_size"] <= 160 * 1024, bwd
     for fwd in find(1, "k_composite_fwd_sh_vecILi4ELi2ELb1ELin2EE"):
         assert fwd["vgpr_count"] <= 128 and 8 * fwd["group_segment_fixed_size"] <= 160 * 1024, fwd
     # packed backward of the post-activation modes (RGB + heads is the trainer's default): 4 wavefronts per SIMD
