@@ -784,6 +784,18 @@ def main():
                 break
     except Exception:
         pass
+    trace_ms, trace_src = None, None
+    try:  # the same kernel's average duration in the committed rocprofv3 kernel trace of this command (--only-timed), for comparison
+        import csv
+        frag = "k_composite_bwd_sh_vec<4, 4, true, true, 6>" if poly_applies else "k_composite_bwd_sh_vec<4, 4, true, true, 0>"
+        fn_ = os.path.join(ROOT, "profiles", f"r03_bench_{args.config}_kernel_stats.csv")
+        for row in csv.DictReader(open(fn_)):
+            if frag in row["Name"] and C == 4 and B == 8:
+                trace_ms = float(row["AverageNs"]) * 1e-6
+                trace_src = f"profiles/r03_bench_{args.config}_kernel_stats.csv (rocprofv3 --kernel-trace --stats of bench.py --only-timed)"
+                break
+    except Exception:
+        pass
     ach = B * parts["composite_bwd"] / (bwd_ms * 1e-3) / 1e9
     els = [r_["el"] for r_ in regions]
     res = {
@@ -813,6 +825,11 @@ def main():
                      "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "alg_bytes_per_launch": B * parts["composite_bwd"], "views_per_launch": B, "avg_launch_ms": bwd_ms,
                      "launches_in_flight": len(slots),
+                     "avg_launch_ms_is": ("the interval between two events of the step's stream around the backward launch(es): with "
+                                          f"{len(slots)} steps in flight it contains the launch's wait for a chip the other steps' kernels fill; "
+                                          "the kernel's own duration in flight is what the kernel trace averages, alone_launch_ms what it "
+                                          "takes with the chip to itself"),
+                     "kernel_trace_avg_launch_ms": trace_ms, "kernel_trace_source": trace_src,
                      "alone_launch_ms": alone["bwd_launch_ms"],
                      "alone_achieved": B * parts["composite_bwd"] / (alone["bwd_launch_ms"] * 1e-3) / 1e9,
                      "alone_frac": B * parts["composite_bwd"] / (alone["bwd_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
