@@ -364,6 +364,43 @@ def test_emulated_batched_frame_geometry_equals_per_view(emu):
     emu.frame_geometry_batch(0, arr, N, P(sc["mean"]), P(sc["qvec"]), P(sc["svec"]), W, H, None, None)
 
 
+def test_emulated_batched_frame_geometry_more_views_than_one_argument_pack(emu):
+    """ten views: the per-view pointer table travels in the projection launch's ARGUMENTS eight views at a time (two
+    projection launches, one table in device memory for the binning launches behind them) -- every view as its own call"""
+    from gsgen_amd import renderer as R
+    from gsgen_amd._capi import GeometryView
+    W, H, B = 48, 32, 10
+    sc = scenes.random_scene(400, seed=31, svec=0.06, spread=1.2)
+    N = sc["mean"].shape[0]
+    cams = [scenes.Camera(W, H, fx=40.0 + 3 * i, c2w=scenes.orbit(2.0 + 0.05 * i, 5.0 * i - 20, 36.0 * i)) for i in range(B)]
+    nth, ntw = cams[0].tiles
+    T = nth * ntw
+    caps = [scenes.oracle_geometry(sc, c)["D"] + 3 for c in cams]
+
+    def fresh(cap):
+        return dict(m2=np.zeros((N, 2), np.float32), c2=np.zeros((N, 4), np.float32), dep=np.zeros(N, np.float32),
+                    mask=np.zeros(N, np.uint8), ids=np.full(cap, -7, np.int32), st=np.zeros(T, np.int32),
+                    en=np.zeros(T, np.int32), tot=np.zeros(1, np.uint32),
+                    ws=np.zeros(emu.frame_workspace_bytes(N, cap, T), np.uint8))
+    ref, got = [fresh(c) for c in caps], [fresh(c) for c in caps]
+    camv = [np.ascontiguousarray(R.CameraInfo(*c.intr).pack(c.c2w)) for c in cams]
+    for cap, cv, r in zip(caps, camv, ref):
+        emu.frame_geometry(N, P(sc["mean"]), P(sc["qvec"]), P(sc["svec"]), P(cv), W, H, cap, P(r["m2"]), P(r["c2"]),
+                           P(r["dep"]), P(r["mask"]), P(r["ids"]), P(r["st"]), P(r["en"]), P(r["tot"]), P(r["ws"]),
+                           r["ws"].size, None)
+    arr = (GeometryView * B)()
+    for a, cap, cv, g in zip(arr, caps, camv, got):
+        a.cam, a.mean2d, a.cov2d, a.depth, a.mask = P(cv), P(g["m2"]), P(g["c2"]), P(g["dep"]), P(g["mask"])
+        a.gaussian_ids, a.start, a.end, a.total = P(g["ids"]), P(g["st"]), P(g["en"]), P(g["tot"])
+        a.workspace, a.workspace_bytes, a.D_cap = P(g["ws"]), g["ws"].size, cap
+    bws = np.zeros(emu.frame_batch_workspace_bytes(B), np.uint8)
+    emu.frame_geometry_batch(B, arr, N, P(sc["mean"]), P(sc["qvec"]), P(sc["svec"]), W, H, P(bws), None)
+    for i, (r, g) in enumerate(zip(ref, got)):
+        assert r["tot"][0] > 0
+        for k in ("m2", "c2", "dep", "mask", "ids", "st", "en", "tot"):
+            assert np.array_equal(r[k], g[k]), (i, k)
+
+
 def test_emulated_long_lists_through_both_sort_launches(emu):
     """A tight cluster: tiles with more than 2048 list entries (and some between 257 and 2048) through the lone view's
     four-wavefront sort launch (gsgen_frame_geometry: quarter sorts + LDS passes; beyond 2048 its 512-entry block path) AND through
