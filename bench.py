@@ -255,22 +255,22 @@ def main():
     ap.add_argument("--steps", type=int, default=50, help="timed steps; a step renders --batch cameras fwd+bwd")
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="cfg2")
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("GSGEN_BATCH", "0")),
+    ap.add_argument("--batch", type=int, default=0,
                     help="cameras per step = cameras per launch of every stage (gsgen_*_batch entry points); 0 = chosen "
                          "from the workload: about 6 M (tile, Gaussian) pairs per launch, between 2 and 8 cameras")
     ap.add_argument("--slots", type=int, default=0,
                     help="steps in flight: own HIP stream and buffers each, so one batch's geometry overlaps the "
                          "other's compositing; 0 = 2, or 3 when the batch is smaller than 4 cameras")
-    ap.add_argument("--segments", type=int, default=int(os.environ.get("GSGEN_SEGMENTS", "1")),
+    ap.add_argument("--segments", type=int, default=1,
                     help="backward workgroups per tile (segments of 32 list entries); 1 = one workgroup per tile")
     ap.add_argument("--latency-segments", type=int, default=8,
                     help="the same for the one-render-in-flight pass: uniform work units shorten a lone launch's tail")
     ap.add_argument("--repeats", type=int, default=0, help="repeats of the timed region (0: until 0.5 s are timed, <= 25)")
-    ap.add_argument("--geo-priority", type=int, default=int(os.environ.get("GSGEN_GEO_PRIORITY", "0")),
+    ap.add_argument("--geo-priority", type=int, default=0,
                     help="1: a slot's geometry stage runs on its own HIGH-priority HIP stream, ahead of the other slot's compositing launch "
                          "instead of in its shadow (measured: 3 333 vs 3 361 renders/s -- the chip is busy either way, "
                          "profiles/r02_notes.md); 0 (default): everything of a slot on one stream")
-    ap.add_argument("--sh-basis", choices=["auto", "exact"], default=os.environ.get("GSGEN_BENCH_SH_BASIS", "auto"),
+    ap.add_argument("--sh-basis", choices=["auto", "exact"], default="auto",
                     help="auto: EVERY step measures the coefficient bound (max over splats and channels of sum_{k>=1} |sh|) on the "
                          "device (gsgen_sh_l1_bound, inside the timed region, no host sync) and hands its device address to the "
                          "SH launches, which route per view on the device: the tile-local polynomial form of the per-pixel SH "
@@ -426,7 +426,7 @@ def main():
                     g.gaussian_ids, g.start, g.end, g.total = p(b_.ids), p(b_.start), p(b_.end), p(b_.total)
                     g.workspace, g.workspace_bytes, g.D_cap = p(b_.ws), b_.ws.numel(), b_.D_cap
                     v.mean, v.cov, v.start, v.end, v.gaussian_ids = p(b_.mean2d), p(b_.cov2d), p(b_.start), p(b_.end), p(b_.ids)
-                    v.tile_order = None if os.environ.get("GSGEN_NO_ORDER") else b_.tile_order()
+                    v.tile_order = b_.tile_order()
                     v.topleft, v.c2w, v.bg_rgb = p(topleft_dev[k]), p(rot_dev[k]), p(bg)
                     v.pixel_size_x, v.pixel_size_y = 1.0 / cis[k].fx, 1.0 / cis[k].fy
                     v.out, v.T = p(self.out[i]), None
