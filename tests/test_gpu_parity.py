@@ -380,6 +380,43 @@ def test_sort_every_register_width(sizes):
     assert np.array_equal(ids.cpu().numpy(), oi)
 
 
+def test_sort_fuzz_segment_lengths():
+    """hypothesis over the per-tile sort: 1 .. 10 tiles with list lengths anywhere in 0 .. 6000 (every register width, the
+    four-wavefront path of the lone view's launch between 257 and 2048 entries, block sort + merge beyond), many equal depths,
+    negative depths; lists and start / end against the oracle"""
+    import os
+    from hypothesis import given, settings, strategies as st, HealthCheck
+    L = lib()
+    n_ex = int(os.environ.get("GSGEN_FUZZ_EXAMPLES", "40"))
+
+    @settings(max_examples=n_ex, deadline=None, derandomize=(n_ex == 40), suppress_health_check=list(HealthCheck))
+    @given(sizes=st.lists(st.one_of(st.integers(0, 300), st.integers(0, 2100), st.integers(0, 6000)), min_size=1, max_size=10),
+           seed=st.integers(0, 10_000), ties=st.booleans())
+    def run(sizes, seed, ties):
+        if sum(sizes) == 0:
+            sizes = sizes + [1]
+        ntw, nth = len(sizes), 1
+        rng = np.random.default_rng(seed)
+        tl = np.concatenate([np.tile(np.array([[t_, 0]], np.int32), (n, 1)) for t_, n in enumerate(sizes)])
+        depth = rng.uniform(-1.0, 5.0, len(tl)).astype(np.float32)
+        if ties:
+            depth[rng.integers(0, len(tl), len(tl) // 2)] = 1.25
+        perm = rng.permutation(len(depth))
+        tl, depth = np.ascontiguousarray(tl[perm]), np.ascontiguousarray(depth[perm])
+        br = tl.copy()
+        N = D = len(depth)
+        oi, os_, oe = O.bin_sort(tl, br, depth, nth, ntw, D)
+        ids = torch.zeros(D, dtype=torch.int32, device=dev())
+        st_ = -torch.ones(ntw, dtype=torch.int32, device=dev()); en = -torch.ones_like(st_)
+        nb = L.tile_culling_workspace_bytes(N, D, ntw)
+        ws = torch.empty(nb, dtype=torch.uint8, device=dev())
+        L.tile_culling_aabb_start_end(N, D, nth, ntw, p(T_(tl)), p(T_(br)), p(T_(depth)), p(ids), p(st_), p(en), p(ws), nb, stream())
+        torch.cuda.synchronize()
+        assert np.array_equal(st_.cpu().numpy(), os_) and np.array_equal(en.cpu().numpy(), oe), sizes
+        assert np.array_equal(ids.cpu().numpy(), oi), sizes
+    run()
+
+
 def test_run_to_run_determinism_forward(case):
     """The forward has no atomics on the image path and the per-tile order is unique:
     two runs are bit-identical."""
