@@ -16,9 +16,10 @@
 //   2. scan        per tile over chunks, then over the T tiles -> segment offsets
 //   3. emit        the same walk again; lane writes (depth_bits<<32 | id) at
 //                  tile_off[tile] + cnt_prefix[chunk][tile] + running   (id-ascending order)
-//   4. sort        one wavefront per tile sorts its segment in REGISTERS on the 64-bit key
-//                  (depth bits, then Gaussian id), writes ids back, fills start/end; lists longer than 2048 entries:
-//                  2048-entry blocks in registers + the merge stages that span blocks in the (L2-resident) segment
+//   4. sort        one workgroup of four wavefronts per tile sorts its segment on the 64-bit key (depth bits, then Gaussian
+//                  id) in REGISTERS -- quarters per wavefront, three LDS passes for the distances that span quarters -- writes
+//                  ids back, fills start/end; lists longer than 2048 entries: register blocks + merge passes over the
+//                  (L2-resident) segment
 // so sort traffic is one read + one write of the pairs instead of 8 global radix passes, and
 // the result is deterministic: keys are unique.  Ordering semantics are the reference's: ascending UNSIGNED float bits of depth
 // (the low word of its int64 key), so negative depths sort after positive ones.
@@ -351,15 +352,12 @@ __device__ __forceinline__ void sort_segment_regs(const u64 *__restrict__ keys, 
     if (e < n) ids[e] = (int)(uint32_t)(k[r] & 0xffffffffull);
   }
 }
-constexpr int kSortMaxK = 32;  // 2048 keys in registers
-
-// Lists of more than 1024 entries, any length (dense clusters; nothing on the BASELINE workloads is beyond 2048): the SAME
-// wavefront sorts 2048-entry blocks in registers and, when there is more than one block, runs the merge stages of the network
-// that span blocks -- distance >= 2048 -- as passes over the (L2-resident) global segment, four comparators per lane in
-// flight, and every stage's remaining distances 1024 .. 1 in registers again, block by block.  A 8192-entry list is 4 + 8
-// register rounds and 3 global passes; the workgroup-wide network in global memory this replaces (its own launch, one more
-// link in every frame's chain, 91 barrier-separated passes for the same list) was ~10x slower on such a list and
-// cost every frame a launch that normally found nothing to do.
+// Lists beyond the four-wavefront path (more than 2 048 entries: dense clusters; nothing on the BASELINE workloads): ONE
+// wavefront sorts blocks of 64 K entries in registers and runs the merge stages of the network that span blocks -- distance
+// >= a block -- as passes over the (L2-resident) global segment, four comparators per lane in flight, and every stage's
+// remaining distances in registers again, block by block.  The workgroup-wide network in global memory this replaces (its own
+// launch, one more link in every frame's chain, 91 barrier-separated passes for an 8 192-entry list) cost every frame a launch
+// that normally found nothing to do.
 __device__ __forceinline__ void long_pass(u64 *__restrict__ k, uint32_t n, uint32_t p2, uint32_t dist, bool flip) {
   // comparator c of p2/2: i = (c / dist) * 2 dist + c % dist; partner i ^ (2 dist - 1) (flip) or i + dist
   const uint32_t lane = (uint32_t)lane_id();
@@ -384,7 +382,7 @@ __device__ __forceinline__ void long_pass(u64 *__restrict__ k, uint32_t n, uint3
   }
   __syncthreads();  // one wavefront: orders this pass's stores before the next pass's loads
 }
-template <int K = kSortMaxK>
+template <int K>
 __device__ __forceinline__ void sort_segment_long(u64 *__restrict__ keys, int *__restrict__ ids, uint32_t n) {
   constexpr uint32_t kBlock = 64u * K;
   const uint32_t lane = (uint32_t)lane_id();
@@ -430,38 +428,15 @@ __device__ __forceinline__ void sort_segment_long(u64 *__restrict__ keys, int *_
   }
 }
 
-// One wavefront per tile, keys in registers, no LDS.
-__device__ __forceinline__ void
-sort_tiles_body(uint32_t tile, const uint32_t *__restrict__ tile_off, const uint32_t *__restrict__ ctrl,
-             unsigned long long *__restrict__ keys, int *__restrict__ ids, int *__restrict__ start,
-             int *__restrict__ end) {
-  const uint32_t tid = threadIdx.x;
-  if (ctrl[1] != 0u) {
-    if (tid == 0) { start[tile] = -1; end[tile] = -1; }
-    return;
-  }
-  const uint32_t b = tile_off[tile], e = tile_off[tile + 1];
-  const uint32_t n = e - b;
-  if (tid == 0) {  // empty tiles stay -1 (aabb_culling.h:248-249)
-    start[tile] = n ? (int)b : -1;
-    end[tile] = n ? (int)e : -1;
-  }
-  if (n == 0) return;
-  if (n <= 64u) sort_segment_regs<1>(keys + b, ids + b, n);
-  else if (n <= 128u) sort_segment_regs<2>(keys + b, ids + b, n);
-  else if (n <= 256u) sort_segment_regs<4>(keys + b, ids + b, n);
-  else if (n <= 512u) sort_segment_regs<8>(keys + b, ids + b, n);
-  else if (n <= 1024u) sort_segment_regs<16>(keys + b, ids + b, n);
-  else sort_segment_long<>(keys + b, ids + b, n);
-}
-
-// A LONE view's sort (gsgen_frame_geometry, the stand-alone binning entry point): its 2 500 wavefronts all fit the chip at once,
-// so nothing balances them -- the launch lasts as long as the SIMD that drew three 1 024-key tiles (43 us for cfg2; the same
-// tiles inside an 8-view launch, longest first and dynamically placed: 14 us per view).  Here a tile of more than 256 entries is
-// sorted by FOUR wavefronts: each sorts a quarter in registers (K = 2 / 4 / 8 keys per lane), the two merge stages that span
-// quarters run their cross-quarter distances as three passes over LDS (256 threads, a barrier each) and every stage's distances
-// inside a quarter in registers again -- ~1.5 us of work per tile instead of ~5-12.  Tiles of up to 256 entries: wavefront 0 as
-// before (the others leave at once); beyond 2 048: wavefront 0's block-sort + merge path.
+// The per-tile sort launch: one workgroup of FOUR wavefronts per tile.  Up to 256 entries: wavefront 0 sorts them in registers
+// (K = 1 / 2 / 4 keys per lane; the others leave at once).  257 .. 2 048: each wavefront sorts a quarter in registers (K = 2 / 4 / 8),
+// the two merge stages that span quarters run their cross-quarter distances as three passes over LDS (256 threads, a barrier
+// each) and every stage's distances inside a quarter in registers again.  Beyond 2 048: wavefront 0's block sort + merge passes
+// over the segment (sort_segment_long).  One wavefront per tile with up to 32 keys per lane was the shape until round 3: a lone
+// view's 2 500 wavefronts all fit the chip at once, nothing balances them, and the launch lasted as long as the SIMD that drew
+// three 1 024-key tiles (43 us against 28 now); in the 8-view launches (longest list first, dynamically placed) the two shapes
+// take the same time alone (114 / 117 us) and this one -- 46 registers instead of 145 -- finds room beside the compositing
+// kernels sooner: 0.60 instead of 0.80 ms average in flight, +0.7 .. 1.6 % renders/s (profiles/r03_notes.md, session y).
 constexpr int kCoopWaves = 4;
 constexpr uint32_t kCoopMax = 2048;
 __device__ __forceinline__ void lds_pass(u64 *k, uint32_t p2, uint32_t dist, bool flip) {
@@ -506,12 +481,10 @@ __device__ __forceinline__ void sort_segment_coop(const u64 *__restrict__ keys, 
   for (int r = 0; r < KW; ++r)
     if (e0 + r < n) ids[e0 + r] = (int)(uint32_t)(k[r] & 0xffffffffull);
 }
-__global__ void __launch_bounds__(64 * kCoopWaves)
-k_sort_tiles_coop(uint32_t T, const uint32_t *__restrict__ tile_off, const uint32_t *__restrict__ ctrl,
-                  unsigned long long *__restrict__ keys, int *__restrict__ ids, int *__restrict__ start,
-                  int *__restrict__ end, const uint32_t *__restrict__ tile_order) {
-  __shared__ u64 s_keys[kCoopMax];
-  const uint32_t tile = tile_order[blockIdx.x];  // longest list first (order_tiles_body): the four-wavefront sorts start at once
+__device__ __forceinline__ void
+sort_tiles_coop_body(uint32_t tile, const uint32_t *__restrict__ tile_off, const uint32_t *__restrict__ ctrl,
+                     unsigned long long *__restrict__ keys, int *__restrict__ ids, int *__restrict__ start,
+                     int *__restrict__ end, u64 *s_keys) {
   const uint32_t tid = threadIdx.x;
   if (ctrl[1] != 0u) {
     if (tid == 0) { start[tile] = -1; end[tile] = -1; }
@@ -529,12 +502,30 @@ k_sort_tiles_coop(uint32_t T, const uint32_t *__restrict__ tile_off, const uint3
     if (n <= 64u) sort_segment_regs<1>(keys + b, ids + b, n);
     else if (n <= 128u) sort_segment_regs<2>(keys + b, ids + b, n);
     else if (n <= 256u) sort_segment_regs<4>(keys + b, ids + b, n);
-    else sort_segment_long<8>(keys + b, ids + b, n);  // (512-entry blocks: this kernel stays at its quarter sorts' registers)
+    else sort_segment_long<8>(keys + b, ids + b, n);  // (512-entry blocks: the kernel stays at its quarter sorts' registers)
     return;
   }
   if (n <= 512u) sort_segment_coop<2>(keys + b, ids + b, n, s_keys);
   else if (n <= 1024u) sort_segment_coop<4>(keys + b, ids + b, n, s_keys);
   else sort_segment_coop<8>(keys + b, ids + b, n, s_keys);
+}
+__global__ void __launch_bounds__(64 * kCoopWaves)
+k_sort_tiles(uint32_t T, const uint32_t *__restrict__ tile_off, const uint32_t *__restrict__ ctrl,
+                  unsigned long long *__restrict__ keys, int *__restrict__ ids, int *__restrict__ start,
+                  int *__restrict__ end, const uint32_t *__restrict__ tile_order) {
+  __shared__ u64 s_keys[kCoopMax];
+  // longest list first (order_tiles_body) where the caller has an order: the four-wavefront sorts start at once
+  sort_tiles_coop_body(tile_order != nullptr ? tile_order[blockIdx.x] : blockIdx.x, tile_off, ctrl, keys, ids, start, end, s_keys);
+}
+// 1-D grid of T x B workgroups, view = id % B, tiles in order_tiles_body order (longest list first): every view's long sorts
+// start at once and the launch ends on the short ones.  (View-major order measured 134 us for 8 cfg2 views with one wavefront
+// per tile: ~2.5 views resident at a time, each waiting on its longest tile.)
+__global__ void __launch_bounds__(64 * kCoopWaves)
+k_sort_tiles_views(uint32_t T, uint32_t B, const GeoView *__restrict__ views) {
+  __shared__ u64 s_keys[kCoopMax];
+  const uint32_t rank = blockIdx.x / B;
+  const GeoView v = views[blockIdx.x - rank * B];
+  sort_tiles_coop_body(v.tile_order[rank], v.tile_off, v.ctrl, v.keys, v.ids, v.start, v.end, s_keys);
 }
 
 // ---- self test of the cross-lane primitives (tests/ only; exported for the parity suite) ----
@@ -577,24 +568,6 @@ k_scan_order_tiles_views(uint32_t T, const GeoView *__restrict__ views) {
   const GeoView v = views[blockIdx.y];
   scan_tiles_body(T, v.tile_count, v.tile_off, v.ctrl, v.cap, v.total);
   order_tiles_body(T, v.tile_count, v.tile_order);
-}
-__global__ void __launch_bounds__(64)
-k_sort_tiles(uint32_t T, const uint32_t *__restrict__ tile_off, const uint32_t *__restrict__ ctrl,
-             unsigned long long *__restrict__ keys, int *__restrict__ ids, int *__restrict__ start,
-             int *__restrict__ end) {
-  sort_tiles_body(xcd_swizzle(blockIdx.x, gridDim.x), tile_off, ctrl, keys, ids, start, end);
-}
-// 1-D grid of T x B workgroups, view = id % B, tiles in order_tiles_body order (longest list first): every
-// view's long sorts (one wavefront, up to ~30 us) start at once and the launch ends on the short ones.
-// View-major order measured 134 us for 8 cfg2 views: ~2.5 views resident at a time, each waiting on
-// its longest tile.
-// (forcing this kernel from 134 to 96 registers -- five wavefronts per SIMD, so that it fits beside four polynomial-backward
-// wavefronts -- costs 84 bytes of scratch in the K = 32 path and gains 0.5 %: profiles/r03_ab_sidequeue_sort_slots.txt; not taken)
-__global__ void __launch_bounds__(64)
-k_sort_tiles_views(uint32_t T, uint32_t B, const GeoView *__restrict__ views) {
-  const uint32_t rank = blockIdx.x / B;
-  const GeoView v = views[blockIdx.x - rank * B];
-  sort_tiles_body(v.tile_order[rank], v.tile_off, v.ctrl, v.keys, v.ids, v.start, v.end);
 }
 template <int P>
 __global__ void __launch_bounds__(64) k_selftest_reduce_scatter(const float *__restrict__ in, float *__restrict__ out) {
@@ -660,7 +633,7 @@ static int bin_and_sort(uint32_t N, uint32_t cap, uint32_t nth, uint32_t ntw, co
   if (N)
     hipLaunchKernelGGL((k_bin_pull<true>), gpull, bpull, 0, s, N, tl, br, depth, (int)ntw, (int)nth, T,
                        w.cnt, w.wcnt, w.tile_off, w.ctrl, w.keys);
-  hipLaunchKernelGGL(k_sort_tiles_coop, dim3(T), dim3(64 * kCoopWaves), 0, s, T, w.tile_off, w.ctrl, w.keys, ids, start, end,
+  hipLaunchKernelGGL(k_sort_tiles, dim3(T), dim3(64 * kCoopWaves), 0, s, T, w.tile_off, w.ctrl, w.keys, ids, start, end,
                      (const uint32_t *)w.tile_order);
   return (int)hipGetLastError();
 }
@@ -684,7 +657,8 @@ int gsgen_internal_sort_segments(uint32_t T, const uint32_t *tile_off, const uin
                                  unsigned long long *keys, int *ids, int *start, int *end, gsgen_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   if (T == 0) return 0;
-  hipLaunchKernelGGL(k_sort_tiles, dim3(T), dim3(64), 0, s, T, tile_off, ctrl, keys, ids, start, end);
+  hipLaunchKernelGGL(k_sort_tiles, dim3(T), dim3(64 * kCoopWaves), 0, s, T, tile_off, ctrl, keys, ids, start, end,
+                     (const uint32_t *)nullptr);
   return (int)hipGetLastError();
 }
 
@@ -778,7 +752,7 @@ int gsgen_frame_geometry_batch(uint32_t n_views, const gsgen_geometry_view *view
   hipLaunchKernelGGL(k_scan_order_tiles_views, dim3(1, B), dim3(kScanThreads), 0, s, T, (const GeoView *)dv);
   if (N)
     hipLaunchKernelGGL((k_bin_pull_views<true>), gpull, bpull, 0, s, N, (int)ntw, (int)nth, T, (const GeoView *)dv);
-  hipLaunchKernelGGL(k_sort_tiles_views, dim3(T * B), dim3(64), 0, s, T, B, (const GeoView *)dv);
+  hipLaunchKernelGGL(k_sort_tiles_views, dim3(T * B), dim3(64 * kCoopWaves), 0, s, T, B, (const GeoView *)dv);
   return (int)hipGetLastError();
 }
 

@@ -402,10 +402,9 @@ def test_emulated_batched_frame_geometry_more_views_than_one_argument_pack(emu):
 
 
 def test_emulated_long_lists_through_both_sort_launches(emu):
-    """A tight cluster: tiles with more than 2048 list entries (and some between 257 and 2048) through the lone view's
-    four-wavefront sort launch (gsgen_frame_geometry: quarter sorts + LDS passes; beyond 2048 its 512-entry block path) AND through
-    the batched launch's one-wavefront-per-tile sort (2048-entry register blocks + merge passes over the segment): both leave
-    the oracle's lists"""
+    """A tight cluster: tiles with more than 2048 list entries (and some between 257 and 2048) through the lone view's sort
+    launch and through the batched one (the same four-wavefront workgroup per tile: quarter sorts + LDS passes; beyond 2048
+    entries one wavefront's 512-entry block sorts + merge passes over the segment): both leave the oracle's lists"""
     from gsgen_amd import renderer as R
     from gsgen_amd._capi import GeometryView
     W, H = 64, 48
@@ -476,7 +475,7 @@ def test_emulated_reduce_scatter(emu, Pc):
 
 
 def test_emulated_sort_register_widths(emu):
-    """register sort K = 1..32 and the long-list path (2048-entry register blocks + merge passes over the segment) under emulation"""
+    """every path of the per-tile sort under emulation: one wavefront up to 256 entries, four up to 2048, block sort + merge passes beyond"""
     sizes = (1, 64, 65, 130, 300, 600, 1100, 2048, 2049, 4097, 9000)   # > 2048: register blocks + global merge passes
     ntw, nth = len(sizes), 1
     rng = np.random.default_rng(12)
@@ -1048,10 +1047,8 @@ def test_no_kernel_spills_and_hot_kernels_keep_their_occupancy(tmp_path):
         assert bwd["vgpr_count"] <= 128
     for fwd in find(2, "k_composite_fwdILi2ELi4ELi1E", "ELi16EE"):      # default SH forward: 4 wavefronts per tile
         assert fwd["vgpr_count"] <= 128
-    for srt in find(2, "k_sort_tiles", "PiS3_S3_") + find(1, "k_sort_tiles_views"):   # register sort, no LDS unless cooperative
-        coop = srt["group_segment_fixed_size"] != 0   # (a lone view's launch: four wavefronts per tile, 16 KB, small quarters)
-        assert (srt["group_segment_fixed_size"] == 16384 and srt["vgpr_count"] <= 64) if coop else srt["vgpr_count"] <= 168, srt
-    assert len(find(3, "k_sort_tiles")) == 3
+    for srt in find(2, "k_sort_tiles"):   # four wavefronts per tile, quarters in registers (K <= 8), 16 KB of LDS for the merge passes
+        assert srt["group_segment_fixed_size"] == 16384 and srt["vgpr_count"] <= 64, srt
     # 1 - a G must be the subtraction of the ROUNDED product in every shape of the packed SH kernels (common.hpp one_minus2):
     # -ffp-contract=fast once fused it into fma(-a, G, 1) in the per-camera forward and not in the batched one, and the two
     # images differed in the last bit -- something only a GPU run could see.  No instantiation may contain the fused form.

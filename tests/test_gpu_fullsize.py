@@ -4,7 +4,7 @@ cfg2 (100k Gaussians, 800x800), cfg3 (500k post-densify Gaussians, 1024x1024: lo
 batched launches), each compared with the oracle on the same inputs: pair count, per-tile lists and order
 exact; the image within 1e-4 on EVERY pixel (north_star); every gradient -- mean, qvec, svec, alpha, sh --
 within 1e-3 of the largest reference entry (fp32 atomics reorder the sums; the oracle sums in fp64).  Plus a
-dense cluster whose centre tiles hold more than 2048 list entries (k_sort_tiles' block-sort + merge path inside
+dense cluster whose centre tiles hold more than 2048 list entries (the sort's block-sort + merge path inside
 gsgen_frame_geometry) and more than one staging batch per tile in the compositing kernels."""
 import os
 import sys
@@ -129,9 +129,8 @@ def test_dense_cluster_long_lists():
 
 
 def test_dense_cluster_long_lists_batched():
-    """the same dense cluster through the BATCHED launches (two cameras): there a tile is sorted by ONE wavefront, and a list
-    of more than 2048 entries takes its 2048-entry register blocks + merge passes over the segment (the lone view's launch of the
-    test above sorts with four wavefronts per tile and 512-entry blocks): lists against the oracle, images too"""
+    """the same dense cluster through the BATCHED launches (two cameras: k_sort_tiles_views, the per-view tables, the view-interleaved
+    longest-first order): lists against the oracle, images too"""
     from gsgen_amd import renderer as R
     from gsgen_amd.batch import BatchRenderer
     sc = scenes.random_scene(40_000, seed=21, svec=0.02, spread=0.12, C=2)

@@ -353,8 +353,8 @@ def test_long_tile_list_and_ties():
 @pytest.mark.parametrize("sizes", [(1, 40, 64, 65, 100, 128, 129, 200, 256, 300, 511, 512, 513, 700, 1024, 1025, 1500, 2039, 2040,
                                     2047, 2048, 2049, 3000, 4096, 4097, 4100, 6200, 9000)])
 def test_sort_every_register_width(sizes):
-    """Per-tile segments of every size class of the register sort (K = 1..32 keys per lane),
-    the long-list path (beyond 2048 entries) and their boundaries, with duplicate depths."""
+    """Per-tile segments of every size class of the sort (one wavefront up to 256 entries, four up to 2048, block sort + merge
+    passes beyond) and their boundaries, with duplicate depths."""
     L = lib()
     ntw, nth = len(sizes), 1
     rng = np.random.default_rng(12)
@@ -382,7 +382,7 @@ def test_sort_every_register_width(sizes):
 
 def test_sort_fuzz_segment_lengths():
     """hypothesis over the per-tile sort: 1 .. 10 tiles with list lengths anywhere in 0 .. 6000 (every register width, the
-    four-wavefront path of the lone view's launch between 257 and 2048 entries, block sort + merge beyond), many equal depths,
+    four-wavefront path between 257 and 2048 entries, block sort + merge beyond), many equal depths,
     negative depths; lists and start / end against the oracle"""
     import os
     from hypothesis import given, settings, strategies as st, HealthCheck
