@@ -105,6 +105,50 @@ def choose_batch_and_slots(pairs_per_view, batch=0, slots=0):
     return B, (slots if slots > 0 else 3)
 
 
+def heads_alg_bytes(N, D, P, T):
+    """SURVEY.md 8(d)'s formula for the fused RGB + heads pass: F = 7 + 6 = 13 floats per record (mean2d 2, cov2d 4, alpha 1,
+    r g b depth 1 depth^2), the forward writes 6 channels + T per pixel (28 B), the backward reads grad_out6 + final (48 B)
+    + 4 B of pixel state; the projection backward also reads the view's channel gradients (24 B per Gaussian)."""
+    F = 13
+    parts = {
+        "project_fwd": 88 * N,
+        "bin_sort": 36 * D + 8 * T,
+        "composite_fwd": (4 + 4 * F) * D + 28 * P,
+        "composite_bwd": (4 + 4 * F) * D + 52 * P + 4 * F * D,
+        "project_bwd": (108 + 24) * N,
+    }
+    return sum(parts.values()), parts
+
+
+def committed_traffic(config, kernel, views):
+    """HBM bytes per launch of `kernel` from committed PMC passes (profiles/rNN_traffic.json), if they are of THIS kernel,
+    workload and launch shape: (bytes, valu_floor_ms, source) or (None, None, None)"""
+    for fn_ in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json"):
+        try:
+            ent = json.load(open(os.path.join(ROOT, "profiles", fn_))).get(f"{config}|{kernel}|views={views}")
+        except Exception:
+            continue
+        if ent:
+            return (ent["traffic_bytes_per_launch"], ent.get("valu_floor_ms_per_launch"),
+                    f"profiles/{fn_} (separate rocprofv3 --pmc passes of this kernel on this workload and launch shape: "
+                    "2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md's gfx950 correction)")
+    return None, None, None
+
+
+def committed_trace_ms(config, fragment, suffix=""):
+    """the kernel's average duration in the committed rocprofv3 kernel trace of this command (--only-timed)"""
+    import csv
+    for rnd in ("r04", "r03"):
+        fn_ = os.path.join(ROOT, "profiles", f"{rnd}_bench_{config}{suffix}_kernel_stats.csv")
+        try:
+            for row in csv.DictReader(open(fn_)):
+                if fragment in row["Name"]:
+                    return float(row["AverageNs"]) * 1e-6, f"profiles/{rnd}_bench_{config}{suffix}_kernel_stats.csv (rocprofv3 --kernel-trace --stats of bench.py --only-timed)"
+        except Exception:
+            continue
+    return None, None
+
+
 def cpu_baseline(sc, cams, C, budget_s=20.0):
     """The CPU oracle (a port: the reference has no CPU rasteriser) timed on this box's cores
     on a bounded sample of the same workload: whole renders of the bench cameras until
@@ -289,6 +333,19 @@ def main():
                     help="DRY RUN of the (multi-rank) step loop on the CPU: PATH is a host build of this library's kernels (the "
                          "tests pass one), the process group is gloo, streams and events are stand-ins.  Checks the protocol -- "
                          "shapes, broadcasts, collectives in the same order on every rank -- not speed; implies --only-timed")
+    ap.add_argument("--path", choices=["sh", "heads"], default="sh",
+                    help="sh (default): the metric of BASELINE.json -- SH degree 3 compositing; `heads_path` (the trainer's default "
+                         "outputs: rgb + depth + opacity + depth^2 from post-activation colours, gs/gaussian_splatting.py:1304-1416) "
+                         "is measured the same way afterwards and reported in the same line.  heads: the timed region IS the "
+                         "RGB + heads step (profiling: with --only-timed a kernel trace holds exactly its launches)")
+    ap.add_argument("--no-heads", action="store_true", help="skip the RGB + heads pass")
+    ap.add_argument("--torch-fill", action="store_true",
+                    help="A/B: zero the step's gradient accumulators with a torch fill kernel between forward and backward (rounds "
+                         "1-3) instead of inside the projection launch (gsgen_frame_geometry_batch_zero)")
+    ap.add_argument("--gather", choices=["images", "none"], default="images",
+                    help="multi-GPU: images (default) = one all_gather of the step's rendered images per step, as north_star "
+                         "asks; the same timed region WITHOUT the gather is reported next to it as `value_no_gather`, so that "
+                         "compute scaling and xGMI cost separate.  none: no gather in the headline either")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the one-render-in-flight and hipGraph passes")
     args = ap.parse_args()
@@ -297,7 +354,7 @@ def main():
         args.only_timed, args.config = True, "dry"
         args.batch, args.slots = args.batch or 2, args.slots or 2
     if args.only_timed:
-        args.no_surface = args.no_latency = args.no_cpu_baseline = True
+        args.no_surface = args.no_latency = args.no_cpu_baseline = args.no_heads = True
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args.gpus))
@@ -386,6 +443,14 @@ def main():
     clock = HostClock()
 
     # ---- one step = one batch of B cameras, one enqueue per stage, on its slot's stream --------------------------
+    Np = (N + 3) // 4 * 4                      # row counts padded so that every gradient block starts 16-byte aligned
+    n_sh4 = (N * CC3 + 3) // 4 * 4
+    fused_fill = not args.torch_fill           # gradient accumulators zeroed inside the projection launch
+    want_heads = (args.path == "heads" or not args.no_heads) and "color" in sc and not dry
+    if want_heads:
+        t["color"] = torch.tensor(sc["color"], device=dev)
+        grad_out6 = torch.randn(H, W, 6, device=dev)
+
     class Slot:
         def __init__(self, stream):
             self.stream, self.s = stream, stream.cuda_stream
@@ -396,9 +461,10 @@ def main():
             with gpu.stream(stream):
                 self.bufs = [R.FrameBuffers(N, W, H, dev) for _ in range(B)]
                 self.out = torch.empty(B, H, W, 3, device=dev)
-                # per view: mean2d(2) | cov2d(4); shared: alpha(1) | sh -- zeroed once per step; the projection
-                # backward overwrites mean(3) | qvec(4) | svec(3)
-                self.gflat = torch.empty(B * 6 * N + N * (1 + CC3), device=dev)
+                # per view: mean2d(2) | cov2d(4); shared: alpha(1) | sh -- zeroed once per step (by the projection launch
+                # of the step's geometry, or by a torch fill with --torch-fill); the projection backward overwrites
+                # mean(3) | qvec(4) | svec(3)
+                self.gflat = torch.empty(B * 6 * Np + Np + n_sh4, device=dev)
                 self.g3d = torch.empty(N * 10, device=dev)
                 self.seg_ws = [torch.empty(max(1, lib.segment_workspace_bytes(nth * ntw, nseg)), device=dev, dtype=torch.uint8)
                                for _ in range(B)]
@@ -406,25 +472,47 @@ def main():
                 self.bound = torch.zeros(1, device=dev)  # S of the step's coefficients (gsgen_sh_l1_bound), read by its launches
                 self.gws = torch.empty(lib.frame_batch_workspace_bytes(B), device=dev, dtype=torch.uint8)
                 self.gathered = torch.empty(world, B, H, W, 3, device=dev) if dist is not None else None
+                if want_heads:
+                    # RGB + heads: out6 / T are written whole by the batched forward (empty tiles included); per view
+                    # mean2d | cov2d | chan6 gradients, shared alpha; the projection backward writes colour(3) too
+                    self.out6 = torch.empty(B, H, W, 6, device=dev)
+                    self.T6 = torch.empty(B, H, W, device=dev)
+                    self.hflat = torch.empty(B * 12 * Np + Np, device=dev)
+                    self.h_color = torch.empty(N * 3, device=dev)
             # the images of a step are complete after its forward: they are gathered on the communication stream while
             # the step's backward runs; the slot's next forward waits for that gather before it overwrites `out`
             self.e_fwd, self.e_gathered, self.gather_pending = gpu.Event(), gpu.Event(), False
-            o = B * 6 * N
-            self.g_alpha, self.g_sh = self.gflat[o:o + N], self.gflat[o + N:o + N * (1 + CC3)]
+            o = B * 6 * Np
+            self.g_alpha, self.g_sh = self.gflat[o:o + N], self.gflat[o + Np:o + Np + N * CC3]
+            self.g_shared, self.n_shared = self.gflat[o:], Np + n_sh4
             self.g_mean, self.g_qvec, self.g_svec = self.g3d[:3 * N], self.g3d[3 * N:7 * N], self.g3d[7 * N:]
-            self.tables = {}
+            self.tables, self.htables = {}, {}
+
+        def _geo(self, k0, g0, stride, chan6):
+            """gsgen_geometry_view table of the step whose first camera is k0; g0: the slot's per-view gradient blocks
+            (stride floats apart: mean2d 2 Np | cov2d 4 Np [| chan6 6 Np]), zero-filled by the projection launch"""
+            geo = (_capi.GeometryView * B)()
+            for i in range(B):
+                k, b_, g = (k0 + i) % ncam, self.bufs[i], geo[i]
+                g.cam, g.mean2d, g.cov2d, g.depth, g.mask = p(cam_dev[k]), p(b_.mean2d), p(b_.cov2d), p(b_.depth), p(b_.mask)
+                g.gaussian_ids, g.start, g.end, g.total = p(b_.ids), p(b_.start), p(b_.end), p(b_.total)
+                g.workspace, g.workspace_bytes, g.D_cap = p(b_.ws), b_.ws.numel(), b_.D_cap
+                if fused_fill:
+                    g.zero_grad_mean2d = g0 + 4 * stride * i
+                    g.zero_grad_cov2d = g0 + 4 * stride * i + 4 * 2 * Np
+                    if chan6:
+                        g.zero_grad_chan6 = g0 + 4 * stride * i + 4 * 6 * Np
+            return geo
 
         def prepared(self, k0):
             """ctypes tables of the step whose first camera is k0 (built once per D_cap of the buffers)"""
             key = (k0, tuple(b_.D_cap for b_ in self.bufs))
             if key not in self.tables:
-                geo, views = (_capi.GeometryView * B)(), (_capi.ShView * B)()
+                views = (_capi.ShView * B)()
                 g0 = p(self.gflat)
+                geo = self._geo(k0, g0, 6 * Np, False)
                 for i in range(B):
-                    k, b_, g, v = (k0 + i) % ncam, self.bufs[i], geo[i], views[i]
-                    g.cam, g.mean2d, g.cov2d, g.depth, g.mask = p(cam_dev[k]), p(b_.mean2d), p(b_.cov2d), p(b_.depth), p(b_.mask)
-                    g.gaussian_ids, g.start, g.end, g.total = p(b_.ids), p(b_.start), p(b_.end), p(b_.total)
-                    g.workspace, g.workspace_bytes, g.D_cap = p(b_.ws), b_.ws.numel(), b_.D_cap
+                    k, b_, v = (k0 + i) % ncam, self.bufs[i], views[i]
                     v.mean, v.cov, v.start, v.end, v.gaussian_ids = p(b_.mean2d), p(b_.cov2d), p(b_.start), p(b_.end), p(b_.ids)
                     v.tile_order = b_.tile_order()
                     v.topleft, v.c2w, v.bg_rgb = p(topleft_dev[k]), p(rot_dev[k]), p(bg)
@@ -432,16 +520,62 @@ def main():
                     v.out, v.T = p(self.out[i]), None
                     v.segment_workspace = p(self.seg_ws[i]) if nseg > 1 else None
                     v.grad_out = p(grad_out)
-                    v.grad_mean = g0 + 4 * 6 * N * i
-                    v.grad_cov = v.grad_mean + 4 * 2 * N
+                    v.grad_mean = g0 + 4 * 6 * Np * i
+                    v.grad_cov = v.grad_mean + 4 * 2 * Np
                 proj = (vtab([p(cam_dev[(k0 + i) % ncam]) for i in range(B)]), 1, vtab([p(b_.mask) for b_ in self.bufs]),
-                        vtab([g0 + 4 * 6 * N * i for i in range(B)]), vtab([g0 + 4 * 6 * N * i + 4 * 2 * N for i in range(B)]), None)
+                        vtab([g0 + 4 * 6 * Np * i for i in range(B)]), vtab([g0 + 4 * 6 * Np * i + 4 * 2 * Np for i in range(B)]), None)
                 self.tables[key] = (geo, views, proj)
             return self.tables[key]
 
+        def prepared_heads(self, k0):
+            """the same for the RGB + heads step: gsgen_rgbd_view table, projection-backward tables with the views' channel
+            gradients and depths"""
+            key = (k0, tuple(b_.D_cap for b_ in self.bufs))
+            if key not in self.htables:
+                views = (_capi.RgbdView * B)()
+                g0 = p(self.hflat)
+                geo = self._geo(k0, g0, 12 * Np, True)
+                for i in range(B):
+                    k, b_, v = (k0 + i) % ncam, self.bufs[i], views[i]
+                    v.mean, v.cov, v.depth = p(b_.mean2d), p(b_.cov2d), p(b_.depth)
+                    v.start, v.end, v.gaussian_ids, v.tile_order = p(b_.start), p(b_.end), p(b_.ids), b_.tile_order()
+                    v.topleft = p(topleft_dev[k])
+                    v.pixel_size_x, v.pixel_size_y = 1.0 / cis[k].fx, 1.0 / cis[k].fy
+                    v.out6, v.T = p(self.out6[i]), p(self.T6[i])
+                    v.grad_out6 = p(grad_out6)
+                    v.grad_mean = g0 + 4 * 12 * Np * i
+                    v.grad_cov = v.grad_mean + 4 * 2 * Np
+                    v.grad_chan6 = v.grad_mean + 4 * 6 * Np
+                blk = [g0 + 4 * 12 * Np * i for i in range(B)]
+                proj = (vtab([p(cam_dev[(k0 + i) % ncam]) for i in range(B)]), 1, vtab([p(b_.mask) for b_ in self.bufs]),
+                        vtab(blk), vtab([a + 4 * 2 * Np for a in blk]), vtab([a + 4 * 6 * Np for a in blk]),
+                        vtab([p(b_.depth) for b_ in self.bufs]))
+                self.htables[key] = (geo, views, proj)
+            return self.htables[key]
+
     slots = [Slot(gpu.Stream(dev)) for _ in range(max(1, auto_slots))]
-    comm_stream = gpu.Stream(dev)
+    # the communication stream at HIGH priority: the gather's copy kernels must find compute units on a chip the compositing
+    # launches fill (its bytes cross xGMI while the step's backward runs)
+    comm_stream = gpu.Stream(dev, priority=-1)
     seg_arg = nseg if nseg > 1 else 0
+
+    def geometry(sl, geo, zero_ptr, zero_floats):
+        if sl.geo_stream is not sl.stream:
+            t0 = time.perf_counter()
+            if sl.started:
+                sl.geo_stream.wait_event(sl.e_done)  # the slot's previous step has finished with the lists
+            clock.acc["events"] = clock.acc.get("events", 0.0) + time.perf_counter() - t0
+        if fused_fill:
+            clock.call("geometry", lib.frame_geometry_batch_zero, B, geo, N, p(t["mean"]), p(t["qvec"]), p(t["svec"]), W, H,
+                       zero_ptr, zero_floats, p(sl.gws), sl.geo_stream.cuda_stream)
+        else:
+            clock.call("geometry", lib.frame_geometry_batch, B, geo, N, p(t["mean"]), p(t["qvec"]), p(t["svec"]), W, H, p(sl.gws),
+                       sl.geo_stream.cuda_stream)
+        if sl.geo_stream is not sl.stream:
+            t0 = time.perf_counter()
+            sl.e_geo.record(sl.geo_stream)
+            sl.stream.wait_event(sl.e_geo)
+            clock.acc["events"] = clock.acc.get("events", 0.0) + time.perf_counter() - t0
 
     def run_step(j, ev=None, gather=True):
         """step j: cameras (j*B .. j*B+B-1) mod the rank's camera set, on slot j mod slots"""
@@ -451,18 +585,7 @@ def main():
         if sl.gather_pending:
             stream.wait_event(sl.e_gathered)
             sl.gather_pending = False
-        if sl.geo_stream is not stream:
-            t0 = time.perf_counter()
-            if sl.started:
-                sl.geo_stream.wait_event(sl.e_done)  # the slot's previous step has finished with the lists
-            clock.acc["events"] = clock.acc.get("events", 0.0) + time.perf_counter() - t0
-        clock.call("geometry", lib.frame_geometry_batch, B, geo, N, p(t["mean"]), p(t["qvec"]), p(t["svec"]), W, H, p(sl.gws),
-                   sl.geo_stream.cuda_stream)
-        if sl.geo_stream is not stream:
-            t0 = time.perf_counter()
-            sl.e_geo.record(sl.geo_stream)
-            stream.wait_event(sl.e_geo)
-            clock.acc["events"] = clock.acc.get("events", 0.0) + time.perf_counter() - t0
+        geometry(sl, geo, p(sl.g_shared), sl.n_shared)
         bound_p = None
         if state["bounded"]:  # the step's own measurement of its coefficients: one pass, on the step's stream, no sync
             clock.call("sh_bound", lib.sh_l1_bound, N, p(t["sh"]), C, p(sl.bound), s)
@@ -473,7 +596,7 @@ def main():
                    1e-4, seg_arg, bound_p, p(sl.bws), s)
         if ev is not None:
             clock.call("events", ev[1].record, stream)
-        if sl.gathered is not None and gather:
+        if sl.gathered is not None and gather and state["gather"]:
             t0 = time.perf_counter()
             sl.e_fwd.record(stream)
             comm_stream.wait_event(sl.e_fwd)
@@ -482,10 +605,11 @@ def main():
                 sl.e_gathered.record(comm_stream)
             sl.gather_pending = True
             clock.acc["gather"] = clock.acc.get("gather", 0.0) + time.perf_counter() - t0
-        t0 = time.perf_counter()
-        with gpu.stream(stream):
-            sl.gflat.zero_()
-        clock.acc["zero_grads"] = clock.acc.get("zero_grads", 0.0) + time.perf_counter() - t0
+        if not fused_fill:
+            t0 = time.perf_counter()
+            with gpu.stream(stream):
+                sl.gflat.zero_()
+            clock.acc["zero_grads"] = clock.acc.get("zero_grads", 0.0) + time.perf_counter() - t0
         if ev is not None:
             clock.call("events", ev[2].record, stream)
         clock.call("composite_bwd", lib.vol_render_backward_sh_batch_bounded, B, views, N, p(t["sh"]), p(t["alpha"]), p(sl.g_sh),
@@ -498,6 +622,43 @@ def main():
             sl.e_done.record(stream)
             sl.started = True
 
+    def run_heads_step(j, ev=None, gather=True):
+        """the trainer's default outputs for the same cameras: geometry, fused rgb + depth + opacity + depth^2 compositing
+        forward, its backward for dense random gradients of all four heads, projection backward with the depth heads'
+        gradients folded in (gs/gaussian_splatting.py:1304-1416: four compositing passes in the reference, one here)"""
+        sl = slots[j % len(slots)]
+        s, stream = sl.s, sl.stream
+        geo, views, proj = sl.prepared_heads((j * B) % ncam)
+        o = B * 12 * Np
+        geometry(sl, geo, p(sl.hflat) + 4 * o, Np)
+        if ev is not None:
+            clock.call("events", ev[0].record, stream)
+        clock.call("composite_fwd", lib.vol_render_rgbd_batch, B, views, N, p(t["color"]), p(t["alpha"]), 16, nth, ntw, H, W, 1e-4,
+                   p(sl.bws), s)
+        if ev is not None:
+            clock.call("events", ev[1].record, stream)
+        if not fused_fill:
+            t0 = time.perf_counter()
+            with gpu.stream(stream):
+                sl.hflat.zero_()
+            clock.acc["zero_grads"] = clock.acc.get("zero_grads", 0.0) + time.perf_counter() - t0
+        if ev is not None:
+            clock.call("events", ev[2].record, stream)
+        clock.call("composite_bwd", lib.vol_render_rgbd_backward_batch, B, views, N, p(t["color"]), p(t["alpha"]),
+                   p(sl.hflat) + 4 * o, 16, nth, ntw, H, W, 1e-4, p(sl.bws), s)
+        if ev is not None:
+            clock.call("events", ev[3].record, stream)
+        clock.call("project_bwd", lib.project_gaussians_backward_batch_heads, B, N, p(t["mean"]), p(t["qvec"]), p(t["svec"]), *proj,
+                   p(sl.g_mean), p(sl.g_qvec), p(sl.g_svec), p(sl.h_color), s)
+        if sl.geo_stream is not stream:
+            sl.e_done.record(stream)
+            sl.started = True
+
+    state["gather"] = args.gather == "images"
+    main_step = run_heads_step if args.path == "heads" else run_step
+    if args.path == "heads":
+        state["bounded"] = False
+
     def barrier():
         if dist is not None:
             dist.barrier()
@@ -509,7 +670,7 @@ def main():
     Ds = np.zeros(ncam)
     for j in range(period):
         for _ in range(3):
-            run_step(j, gather=False)
+            main_step(j, gather=False)
             gpu.synchronize()
             if all([b_.ensure_capacity() for b_ in slots[j % len(slots)].bufs]):
                 break
@@ -528,19 +689,22 @@ def main():
     # warm-up: W untimed steps exactly as the timed ones (events included, so every event exists before the region)
     evs = [[gpu.Event(enable_timing=True) for _ in range(4)] for _ in range(K)]
     for i in range(args.warmup):
-        run_step(i, evs[i % K])
+        main_step(i, evs[i % K])
     for i in range(K):  # every event of the timed region has been recorded once
         for e in evs[i]:
             e.record(slots[i % len(slots)].stream)
     barrier()
 
     # ---- timed region: exactly K steps, repeated ------------------------------------------------------------------
-    def region(first):
+    def region(first, step=None, in_flight=0):
+        """exactly K steps between barrier + synchronize pairs; in_flight = 1: the steps on ONE slot (one stream), i.e. one
+        step in flight -- a strictly sequential optimiser's view"""
+        step = step or main_step
         clock.reset()
         barrier()
         t0 = time.perf_counter()
         for i in range(K):
-            run_step(first + i, evs[i])
+            step((first + i) * (len(slots) if in_flight == 1 else 1), evs[i])
         host = time.perf_counter() - t0
         barrier()
         el = el_local = time.perf_counter() - t0
@@ -600,18 +764,103 @@ def main():
             run_step(i, evs[i % K])
         barrier()
 
+    # ---- multi-GPU: the same timed region WITHOUT the per-step all_gather (compute scaling and xGMI cost separate) ------------
+    no_gather = None
+    if dist is not None and state["gather"] and not dry:
+        state["gather"] = False
+        barrier()
+        ng = [region(args.warmup + r * K) for r in range(min(3, n_rep))]
+        ngm = sorted(ng, key=lambda r_: r_["el"])[len(ng) // 2]
+        no_gather = {"value": world * B * K / ngm["el"], "ms_per_step": ngm["el"] / K * 1e3}
+        state["gather"] = True
+
+    # ---- one STEP in flight (a strictly sequential optimiser: every step waits for the previous one's gradients) ------------
+    one_step = None
+    if not args.only_timed:
+        o1 = [region(args.warmup + r * K, in_flight=1) for r in range(min(3, n_rep))]
+        o1m = sorted(o1, key=lambda r_: r_["el"])[len(o1) // 2]
+        one_step = {"value": world * B * K / o1m["el"], "ms_per_step": o1m["el"] / K * 1e3, "bwd_launch_ms": o1m["bwd_ms"],
+                    "fwd_launch_ms": o1m["fwd_ms"]}
+
+    # ---- the trainer's default outputs (rgb + depth + opacity + depth^2), measured exactly like `value` -------------------------
+    def heads_report(m, alone_, one_):
+        Dm = float(np.mean(Ds))
+        tot_h, parts_h = heads_alg_bytes(n_vis, Dm, W * H, nth * ntw)
+        bname, fname = lib.kernel_variant("rgbd_bwd_batch", 1, 1), lib.kernel_variant("rgbd_fwd_batch", 1, 1)
+        val = world * B * K / m["el"]
+        ach_ = B * parts_h["composite_bwd"] / (m["bwd_ms"] * 1e-3) / 1e9
+        tr, vf, tr_src = committed_traffic(args.config, bname, B)
+        tms, tms_src = committed_trace_ms(args.config, "k_composite_bwd_chan_vec<3, true>", "_heads")
+        rf = {"bound": "hbm", "kernel": bname, "achieved": ach_, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_ / HBM_PEAK_GBS,
+              "traffic": tr, "traffic_source": tr_src, "alg_bytes_per_launch": B * parts_h["composite_bwd"],
+              "alg_bytes_formula": "SURVEY 8(d) with F = 13: (4 + 4F) D + 52 P + 4F D per view (bench.heads_alg_bytes)",
+              "views_per_launch": B, "avg_launch_ms": m["bwd_ms"], "kernel_trace_avg_launch_ms": tms, "kernel_trace_source": tms_src,
+              "fwd_kernel": fname, "fwd_launch_ms": m["fwd_ms"],
+              "fwd_GBs": B * parts_h["composite_fwd"] / (m["fwd_ms"] * 1e-3) / 1e9,
+              "whole_render_alg_bytes": tot_h, "whole_render_hbm_frac": tot_h * (val / world) / (HBM_PEAK_GBS * 1e9)}
+        if alone_ is not None:
+            rf["alone_launch_ms"], rf["alone_fwd_launch_ms"] = alone_["bwd_launch_ms"], alone_["fwd_launch_ms"]
+            rf["alone_frac"] = B * parts_h["composite_bwd"] / (alone_["bwd_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        if vf is not None:
+            rf["valu_floor_ms"] = vf
+        out_ = {"metric": "fwd+bwd views/sec of the trainer's default outputs: rgb + depth + opacity + depth^2 in ONE fused "
+                          "compositing pass each way (gs/gaussian_splatting.py:1304-1416: four passes in the reference), dense "
+                          "random gradients into all four heads, backward to mean, qvec, svec, alpha, colour",
+                "value": val, "unit": "views/s", "ms_per_step": m["el"] / K * 1e3, "cameras_per_step": B,
+                "steps_in_flight": len(slots), "host_enqueue_ms_per_step": m["host"] / K * 1e3,
+                "host_enqueue_us_per_step_by_call": {k: v / K * 1e6 for k, v in m["host_by_call"].items()},
+                "path": "C ABI: gsgen_frame_geometry_batch_zero -> gsgen_vol_render_rgbd_batch -> gsgen_vol_render_rgbd_backward_batch -> "
+                        "gsgen_project_gaussians_backward_batch_heads", "roofline": rf}
+        if one_ is not None:
+            out_["one_step_in_flight"] = one_
+        return out_
+
+    def alone_pass(step):
+        eva_ = [[gpu.Event(enable_timing=True) for _ in range(4)] for _ in range(min(K, 8))]
+        barrier()
+        for j in range(len(eva_)):
+            step(j * len(slots), eva_[j], gather=False)  # slot 0 every time: one stream
+        barrier()
+        return {"fwd_launch_ms": float(np.mean([e[0].elapsed_time(e[1]) for e in eva_])),
+                "bwd_launch_ms": float(np.mean([e[2].elapsed_time(e[3]) for e in eva_]))}
+
+    if args.path == "heads":  # profiling / A-B mode: the timed region was the heads step; its line and nothing else
+        res = heads_report(med, None if args.only_timed else alone_pass(run_heads_step), one_step)
+        els_ = [r_["el"] for r_ in regions]
+        res.update({"n_gpus": world, "steps": K, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                    "dtype": "f32", "data": "synthetic",
+                    "config": {"workload": WORKLOADS[args.config] + " -- RGB + heads path", "gaussians": N, "image": [H, W],
+                               "tile_pairs_D": float(np.mean(Ds)), "zero_fill": "projection launch" if fused_fill else "torch fill"},
+                    "timing": {"repeats": len(regions), "renders_per_s_min": world * B * K / max(els_),
+                               "renders_per_s_max": world * B * K / min(els_), "timed_region_s": el}})
+        if rank == 0:
+            print(json.dumps(res), file=json_out, flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    heads = None
+    if want_heads:
+        for i in range(max(2 * len(slots), min(args.warmup, 6))):
+            run_heads_step(i, evs[i % K])
+        barrier()
+        hr = [region(args.warmup + r * K, run_heads_step) for r in range(min(5, n_rep))]
+        hm = sorted(hr, key=lambda r_: r_["el"])[len(hr) // 2]
+        h1 = [region(args.warmup + r * K, run_heads_step, in_flight=1) for r in range(min(3, n_rep))]
+        h1m = sorted(h1, key=lambda r_: r_["el"])[len(h1) // 2]
+        heads = heads_report(hm, alone_pass(run_heads_step),
+                             {"value": world * B * K / h1m["el"], "ms_per_step": h1m["el"] / K * 1e3})
+        for i in range(max(2, len(slots))):  # back to the headline's kernels for the secondary views
+            run_step(i, evs[i % K])
+        barrier()
+
     # ---- secondary views ---------------------------------------------------------------------------------------------
     # (a) one batch in flight: the duration of a launch that has the chip to itself
     if args.only_timed:
         alone = {"fwd_launch_ms": fwd_ms, "bwd_launch_ms": bwd_ms}  # not measured in this mode
     else:
-        eva = [[gpu.Event(enable_timing=True) for _ in range(4)] for _ in range(min(K, 8))]
-        barrier()
-        for j in range(len(eva)):
-            run_step(j * len(slots), eva[j], gather=False)  # slot 0 every time: one stream
-        barrier()
-        alone = {"fwd_launch_ms": float(np.mean([e[0].elapsed_time(e[1]) for e in eva])),
-                 "bwd_launch_ms": float(np.mean([e[2].elapsed_time(e[3]) for e in eva]))}
+        alone = alone_pass(run_step)
 
     # (b) strictly one render (one camera) at a time on one stream, per-camera entry points: the latency view
     one = None
@@ -772,30 +1021,9 @@ def main():
     total_b, parts = b_alg_bytes(n_vis, D, P, T, F)
     bwd_name = lib.kernel_variant("sh_bwd_batch_poly" if poly_applies else "sh_bwd_batch", C, nseg)
     fwd_name = lib.kernel_variant("sh_fwd_batch_poly" if poly_applies else "sh_fwd_batch", C, nseg)
-    traffic, traffic_src, valu_floor = None, None, None
-    try:  # HBM bytes per launch of the dominant kernel from committed PMC passes, if they are of THIS kernel and workload
-        for fn_ in ("r03_traffic.json", "r02_traffic.json"):
-            pmc_all = json.load(open(os.path.join(ROOT, "profiles", fn_)))
-            ent = pmc_all.get(f"{args.config}|{bwd_name}|views={B}")
-            if ent:
-                traffic, valu_floor = ent["traffic_bytes_per_launch"], ent.get("valu_floor_ms_per_launch")
-                traffic_src = (f"profiles/{fn_} (separate rocprofv3 --pmc passes of this kernel on this workload and launch shape: "
-                               "2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md's gfx950 correction)")
-                break
-    except Exception:
-        pass
-    trace_ms, trace_src = None, None
-    try:  # the same kernel's average duration in the committed rocprofv3 kernel trace of this command (--only-timed), for comparison
-        import csv
-        frag = "k_composite_bwd_sh_vec<4, 4, true, true, 6>" if poly_applies else "k_composite_bwd_sh_vec<4, 4, true, true, 0>"
-        fn_ = os.path.join(ROOT, "profiles", f"r03_bench_{args.config}_kernel_stats.csv")
-        for row in csv.DictReader(open(fn_)):
-            if frag in row["Name"] and C == 4 and B == 8:
-                trace_ms = float(row["AverageNs"]) * 1e-6
-                trace_src = f"profiles/r03_bench_{args.config}_kernel_stats.csv (rocprofv3 --kernel-trace --stats of bench.py --only-timed)"
-                break
-    except Exception:
-        pass
+    traffic, valu_floor, traffic_src = committed_traffic(args.config, bwd_name, B)
+    frag = "k_composite_bwd_sh_vec<4, 4, true, true, 6>" if poly_applies else "k_composite_bwd_sh_vec<4, 4, true, true, 0>"
+    trace_ms, trace_src = committed_trace_ms(args.config, frag) if (C == 4 and B == 8) else (None, None)
     ach = B * parts["composite_bwd"] / (bwd_ms * 1e-3) / 1e9
     els = [r_["el"] for r_ in regions]
     res = {
@@ -815,8 +1043,12 @@ def main():
                    "geometry_stream": "high priority, per slot" if args.geo_priority else "the slot's stream",
                    "parallelism": f"camera-sharded x{world}", "rccl_world_size": (dist.get_world_size() if dist is not None else 1),
                    "renders_per_s_per_rank": per_rank,
-                   "gather": ("one rccl all_gather of the step's rendered images, on its own stream behind the step's forward"
-                              if dist is not None else "none")},
+                   "gather": ("one rccl all_gather of the step's rendered images, on its own HIGH-priority stream behind the step's "
+                              "forward" if (dist is not None and state["gather"]) else "none"),
+                   "gather_bytes_per_step_per_rank": B * H * W * 3 * 4,
+                   "gather_ingest_bytes_per_step_per_rank": (world - 1) * B * H * W * 3 * 4,
+                   "gradient_zero_fill": ("inside the projection launch (gsgen_frame_geometry_batch_zero)" if fused_fill
+                                          else "torch fill kernel between forward and backward")},
         "timing": {"repeats": len(regions), "reported": "median repeat", "renders_per_s_min": world * B * K / max(els),
                    "renders_per_s_max": world * B * K / min(els), "timed_region_s": el,
                    "host_enqueue_ms_per_step": med["host"] / K * 1e3,
@@ -850,6 +1082,31 @@ def main():
         # SIMD issued its share of the measured vector instructions back to back
         res["roofline"]["valu_floor_ms"] = valu_floor
         res["roofline"]["alone_valu_frac"] = valu_floor / alone["bwd_launch_ms"]
+    if no_gather is not None:
+        res["value_no_gather"] = no_gather["value"]
+        res["no_gather"] = dict(no_gather, gather_cost_fraction=1.0 - value / no_gather["value"],
+                                what="the same timed region without the per-step all_gather: compute scaling alone")
+    # what N GPUs should deliver if camera sharding scales perfectly and the gather is NOT hidden -- labelled projected;
+    # the driver's SCALE record is the measurement.  Per GPU and step the gather ingests (N - 1) x the rank's image bytes over
+    # (N - 1) of its 7 xGMI links at once (direct all-gather; MI355X_MICROARCH.md: ~153 GB/s per link and direction, ~75 % of
+    # which RCCL usually sustains)
+    per_gpu = (no_gather["value"] if no_gather is not None else value) / world
+    link = 153e9 * 0.75
+    proj = {}
+    for n_ in (1, 2, 4, 8):
+        t_step = B / per_gpu
+        t_gather = 0.0 if n_ == 1 else (B * H * W * 12) / link  # (n_ - 1) peers, one link each, concurrently: one image set per link
+        proj[str(n_)] = {"perfect_scaling": n_ * per_gpu, "gather_hidden_behind_backward": n_ * per_gpu,
+                         "gather_not_hidden_at_all": n_ * B / (t_step + t_gather),
+                         "gather_ms_per_step_at_link_rate": t_gather * 1e3,
+                         "xgmi_ingest_GBs_per_gpu_needed_to_hide": (n_ - 1) * B * H * W * 12 / t_step / 1e9}
+    res["projected"] = {"label": "PROJECTED from this run's per-GPU rate (not measured): renders/s at N GPUs", "per_gpu_renders_per_s": per_gpu,
+                        "assumed_link_GBs": link / 1e9, "by_n_gpus": proj}
+    if one_step is not None:
+        res["one_step_in_flight"] = dict(one_step, what="the same steps on ONE stream: a strictly sequential optimiser's view "
+                                                        "(every step waits for the previous one's gradients)")
+    if heads is not None:
+        res["heads_path"] = heads
     if exact_basis is not None:
         res["exact_basis"] = exact_basis
     if surface is not None:

@@ -35,7 +35,8 @@ class RgbdView(C.Structure):
 class GeometryView(C.Structure):
     """gsgen_geometry_view (include/gsgen_hip.h): one camera of a batched geometry enqueue."""
     _fields_ = [("cam", vp), ("mean2d", vp), ("cov2d", vp), ("depth", vp), ("mask", vp), ("gaussian_ids", vp),
-                ("start", vp), ("end", vp), ("total", vp), ("workspace", vp), ("workspace_bytes", sz), ("D_cap", u32)]
+                ("start", vp), ("end", vp), ("total", vp), ("workspace", vp), ("workspace_bytes", sz), ("D_cap", u32),
+                ("zero_grad_mean2d", vp), ("zero_grad_cov2d", vp), ("zero_grad_chan6", vp)]
 
 
 # name -> argtypes, in the order of include/gsgen_hip.h
@@ -60,6 +61,8 @@ SIGNATURES = {
     "gsgen_project_gaussians_backward_accum": [u32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp],
     "gsgen_project_gaussians_backward_batch": [u32, u32, vp, vp, vp, C.POINTER(vp), i32, C.POINTER(vp), C.POINTER(vp),
                                                C.POINTER(vp), C.POINTER(vp), vp, vp, vp, vp],
+    "gsgen_project_gaussians_backward_batch_heads": [u32, u32, vp, vp, vp, C.POINTER(vp), i32, C.POINTER(vp), C.POINTER(vp),
+                                                     C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp, vp, vp, vp, vp],
     "gsgen_pack_camera": [vp, f32, f32, f32, f32, u32, u32, C.c_double, C.c_double, f32, f32, vp],
     "gsgen_upload_small": [vp, vp, sz, vp],
     "gsgen_pack_camera_blocks": [u32, vp, u32, vp, f32, f32, vp],
@@ -101,6 +104,7 @@ SIGNATURES = {
     "gsgen_legacy_count_tiles": [u32, u32, vp, vp, vp, u32, u32, u32, f32, f32, f32, vp, vp],
     "gsgen_legacy_image_sort": [u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, u32, f32, f32, f32, vp, sz, vp],
     "gsgen_frame_geometry_batch": [u32, C.POINTER(GeometryView), u32, vp, vp, vp, u32, u32, vp, vp],
+    "gsgen_frame_geometry_batch_zero": [u32, C.POINTER(GeometryView), u32, vp, vp, vp, u32, u32, vp, sz, vp, vp],
     "gsgen_frame_geometry": [u32, vp, vp, vp, vp, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp],
 }
 PTR_FUNCS = {

@@ -47,14 +47,16 @@ class _render_batch(torch.autograd.Function):
         alpha, col = alpha.contiguous(), col.contiguous()
         lib = _capi.load()
         H, W, N, dev = br.H, br.W, br.N, mean.device
-        out = torch.zeros(B, H, W, 3, device=dev, dtype=torch.float32)
-        T = torch.ones(B, H, W, 1, device=dev, dtype=torch.float32)
         fused = br.fused_launch and B > 0
-        cams_p, out_p, T_p = cams.data_ptr(), out.data_ptr(), T.data_ptr()
         ctx.gen = br._begin_batch(B)
-        if fused:
+        if fused:  # the batched forward writes every pixel of out / T (empty tiles included): no fill kernels
+            out = torch.empty(B, H, W, 3, device=dev, dtype=torch.float32)
+            T = torch.empty(B, H, W, 1, device=dev, dtype=torch.float32)
             return _render_batch._forward_fused(ctx, mean, qvec, svec, alpha, col, cams, br, B, C, bg_rgb, thresh,
                                                 detach_depth, stats, out, T)
+        out = torch.zeros(B, H, W, 3, device=dev, dtype=torch.float32)
+        T = torch.ones(B, H, W, 1, device=dev, dtype=torch.float32)
+        cams_p, out_p, T_p = cams.data_ptr(), out.data_ptr(), T.data_ptr()
         cur = br._fork(B, (cams, out, T) + ((br._sh_bound,) if br._sh_bound is not None else ()))
         with torch.cuda.device(dev):
             for i in range(B):
@@ -93,46 +95,50 @@ class _render_batch(torch.autograd.Function):
     @staticmethod
     def _forward_fused(ctx, mean, qvec, svec, alpha, col, cams, br, B, C, bg_rgb, thresh, detach_depth, stats, out, T):
         """the whole batch on the current stream: one enqueue of the geometry kernels (gridDim.y = cameras), one
-        compositing launch"""
+        compositing launch.  Nothing is filled between the stages: the projection launch zeroes the step's gradient
+        accumulators (the renderer's per-view blocks and the shared block allocated here, gsgen_frame_geometry_batch_zero),
+        the compositing launch writes every pixel of out / T."""
         lib = _capi.load()
         H, W, N, dev = br.H, br.W, br.N, mean.device
-        cams_p, out_p, T_p = cams.data_ptr(), out.data_ptr(), T.data_ptr()
+        out_p, T_p = out.data_ptr(), T.data_ptr()
         s = torch.cuda.current_stream(dev).cuda_stream
-        # the slots' buffer addresses sit in cached tables (BatchRenderer._tables); only what changes per call is set
+        # the slots' buffer addresses, the camera rows and the gradient blocks sit in cached tables (BatchRenderer._tables);
+        # only what changes per call is set
         geo, views = br._tables("sh" if C > 0 else "rgb")  # C == 0: post-activation colours
         bg_p = _p(bg_rgb)
-        for i in range(B):
-            ci, g, v = br._cis[i], geo[i], views[i]
-            cam = cams_p + 272 * i  # row i: cam block | topleft at +56 floats | rotation at +58
-            g.cam = cam
-            v.topleft = cam + 224
-            v.pixel_size_x, v.pixel_size_y = 1.0 / ci.fx, 1.0 / ci.fy
-            v.T = T_p + 4 * H * W * i
-            if C > 0:
-                v.c2w, v.bg_rgb, v.out = cam + 232, bg_p, out_p + 12 * H * W * i
-            else:
-                v.out6 = out_p + 12 * H * W * i  # read as [H,W,3] by the RGB entry points
-        # parameter tables of the batch: compositing (forward | backward) | geometry
-        nb_sh = lib.sh_batch_workspace_bytes(B)
-        bws = torch.empty(nb_sh + lib.frame_batch_workspace_bytes(B), device=dev, dtype=torch.uint8)
+        cis = br._cis
+        if C > 0:
+            for i in range(B):
+                ci, v = cis[i], views[i]
+                v.pixel_size_x, v.pixel_size_y = 1.0 / ci.fx, 1.0 / ci.fy
+                v.T, v.bg_rgb, v.out = T_p + 4 * H * W * i, bg_p, out_p + 12 * H * W * i
+        else:
+            for i in range(B):
+                ci, v = cis[i], views[i]
+                v.pixel_size_x, v.pixel_size_y = 1.0 / ci.fx, 1.0 / ci.fy
+                v.T, v.out6 = T_p + 4 * H * W * i, out_p + 12 * H * W * i  # read as [H,W,3] by the RGB entry points
+        # d L / d alpha [N] | d L / d col, shared by the views: returned by the backward, hence allocated per batch -- and
+        # zeroed by this forward's projection launch
+        gsh = torch.empty(br._Np + (col.numel() + 3) // 4 * 4, device=dev, dtype=torch.float32)
+        nb_sh = br._nb_sh
         with torch.cuda.device(dev):
-            lib.frame_geometry_batch(B, geo, N, _p(mean), _p(qvec), _p(svec), W, H, _p(bws) + nb_sh, s)
+            lib.frame_geometry_batch_zero(B, geo, N, _p(mean), _p(qvec), _p(svec), W, H, _p(gsh), gsh.numel(),
+                                          _p(br._bws) + nb_sh, s)
             br._end_batch(B)
             if stats is not None:
-                lib.densify_update_batch(B, N, _tab([_p(br.slots[i].cov2d) for i in range(B)]), None,
-                                         br._mask_table(B), _p(stats.max_radii2d), None,
+                lib.densify_update_batch(B, N, br._ptr_table("cov2d", B), None, br._mask_table(B), _p(stats.max_radii2d), None,
                                          None, s)
             if C > 0:
                 lib.vol_render_sh_batch_bounded(B, views, N, _p(col), _p(alpha), 16, br.slots[0].nth, br.slots[0].ntw, H, W, C,
-                                                thresh, br.segments, _p(br._sh_bound), _p(bws), s)
+                                                thresh, br.segments, _p(br._sh_bound), _p(br._bws), s)
             else:
                 lib.vol_render_rgb_batch(B, views, N, _p(col), _p(alpha), 16, br.slots[0].nth, br.slots[0].ntw, H, W,
-                                         thresh, _p(bws), s)
+                                         thresh, _p(br._bws), s)
         if C == 0 and bg_rgb is not None:
             out = out + T * bg_rgb  # gs/renderer.py:1182; `out` (saved below) is what the backward reads as final
             for i in range(B):
                 views[i].out6 = out.data_ptr() + 12 * H * W * i
-        ctx.views, ctx.bws = views, bws
+        ctx.views, ctx.gsh = views, gsh
         ctx.save_for_backward(mean, qvec, svec, alpha, col, cams, out, T)
         ctx.bg_shape = tuple(bg_rgb.shape) if (bg_rgb is not None and ctx.needs_input_grad[9]) else None
         ctx.br, ctx.B, ctx.C, ctx.thresh, ctx.detach, ctx.stats = br, B, C, thresh, detach_depth, stats
@@ -143,45 +149,42 @@ class _render_batch(torch.autograd.Function):
 
     @staticmethod
     def _backward_fused(ctx, grad):
-        import ctypes
         mean, qvec, svec, alpha, col, cams, out, T = ctx.saved_tensors
         br, B, C, thresh, stats = ctx.br, ctx.B, ctx.C, ctx.thresh, ctx.stats
         lib = _capi.load()
         H, W, N, dev = br.H, br.W, br.N, mean.device
         grad = grad.contiguous()
-        g2d = torch.zeros(B, 6 * N, device=dev, dtype=torch.float32)  # per camera: mean2d | cov2d
-        g_alpha = torch.zeros(N, device=dev, dtype=torch.float32)
-        g_col = torch.zeros_like(col)
+        Np = br._Np
+        gsh, ctx.gsh = ctx.gsh, None
+        if gsh is None:  # a second backward through the same graph (retain_graph): the accumulators were handed out
+            gsh = torch.zeros(Np + (col.numel() + 3) // 4 * 4, device=dev, dtype=torch.float32)
+            br._g2d[:B].zero_()
+        g_alpha, g_col = gsh[:N], gsh[Np:Np + col.numel()].view(col.shape)
         g3d = torch.empty(10 * N, device=dev, dtype=torch.float32)   # mean | qvec | svec: overwritten
         g_mean, g_qvec, g_svec = g3d[:3 * N].view(N, 3), g3d[3 * N:7 * N].view(N, 4), g3d[7 * N:].view(N, 3)
-        cams_p, grad_p, g2d_p = cams.data_ptr(), grad.data_ptr(), g2d.data_ptr()
+        grad_p = grad.data_ptr()
         s = torch.cuda.current_stream(dev).cuda_stream
-        for i in range(B):
-            v = ctx.views[i]
-            if C > 0:
-                v.grad_out = grad_p + 12 * H * W * i
-            else:
-                v.grad_out6 = grad_p + 12 * H * W * i
-            v.grad_mean = g2d_p + 24 * N * i
-            v.grad_cov = g2d_p + 24 * N * i + 8 * N
-        tab = lambda vals: (ctypes.c_void_p * B)(*vals)  # noqa: E731
+        views = ctx.views
+        if C > 0:
+            for i in range(B):
+                views[i].grad_out = grad_p + 12 * H * W * i
+        else:
+            for i in range(B):
+                views[i].grad_out6 = grad_p + 12 * H * W * i
         with torch.cuda.device(dev):
             if C > 0:
-                lib.vol_render_backward_sh_batch_bounded(B, ctx.views, N, _p(col), _p(alpha), _p(g_col), _p(g_alpha), 16,
+                lib.vol_render_backward_sh_batch_bounded(B, views, N, _p(col), _p(alpha), _p(g_col), _p(g_alpha), 16,
                                                          br.slots[0].nth, br.slots[0].ntw, H, W, C, thresh, br.segments,
-                                                         _p(ctx.sh_bound), _p(ctx.bws), s)
+                                                         _p(ctx.sh_bound), _p(br._bws), s)
             else:
-                lib.vol_render_rgb_backward_batch(B, ctx.views, N, _p(col), _p(alpha), _p(g_col), _p(g_alpha), 16,
-                                                  br.slots[0].nth, br.slots[0].ntw, H, W, thresh, _p(ctx.bws), s)
-            lib.project_gaussians_backward_batch(B, N, _p(mean), _p(qvec), _p(svec), tab([cams_p + 272 * i for i in range(B)]),
-                                                 int(ctx.detach), br._mask_table(B),
-                                                 tab([g2d_p + 24 * N * i for i in range(B)]),
-                                                 tab([g2d_p + 24 * N * i + 8 * N for i in range(B)]), None,
-                                                 _p(g_mean), _p(g_qvec), _p(g_svec), s)
+                lib.vol_render_rgb_backward_batch(B, views, N, _p(col), _p(alpha), _p(g_col), _p(g_alpha), 16,
+                                                  br.slots[0].nth, br.slots[0].ntw, H, W, thresh, _p(br._bws), s)
+            lib.project_gaussians_backward_batch(B, N, _p(mean), _p(qvec), _p(svec), br._ptr_table("cam", B),
+                                                 int(ctx.detach), br._mask_table(B), br._ptr_table("g_mean2d", B),
+                                                 br._ptr_table("g_cov2d", B), None, _p(g_mean), _p(g_qvec), _p(g_svec), s)
             if stats is not None:
-                lib.densify_update_batch(B, N, None, _tab([g2d_p + 24 * N * i for i in range(B)]),
-                                         br._mask_table(B), None, _p(stats.grad_accum),
-                                         _p(stats.cnt), s)
+                lib.densify_update_batch(B, N, None, br._ptr_table("g_mean2d", B), br._mask_table(B), None,
+                                         _p(stats.grad_accum), _p(stats.cnt), s)
         return (g_mean, g_qvec, g_svec, g_alpha, g_col, None, None, None, None, _bg_grad(ctx, grad, T), None, None, None)
 
     @staticmethod
@@ -242,34 +245,35 @@ class _render_batch_heads(torch.autograd.Function):
         alpha, col = alpha.contiguous(), col.contiguous()
         lib = _capi.load()
         H, W, N, dev = br.H, br.W, br.N, mean.device
-        out6 = torch.zeros(B, H, W, 6, device=dev, dtype=torch.float32)
-        T = torch.ones(B, H, W, 1, device=dev, dtype=torch.float32)
-        cams_p, out_p, T_p = cams.data_ptr(), out6.data_ptr(), T.data_ptr()
-        ctx.views = ctx.bws = None
+        ctx.views = ctx.gsh = None
         ctx.gen = br._begin_batch(B)
         if br.fused_launch and B > 0:  # one enqueue per stage for the whole batch, on the current stream
+            # (every pixel of out6 / T is written by the batched forward, the gradient accumulators are zeroed by the
+            # projection launch: no fill kernels)
+            out6 = torch.empty(B, H, W, 6, device=dev, dtype=torch.float32)
+            T = torch.empty(B, H, W, 1, device=dev, dtype=torch.float32)
+            out_p, T_p = out6.data_ptr(), T.data_ptr()
             s = torch.cuda.current_stream(dev).cuda_stream
             geo, views = br._tables("rgbd")
+            cis = br._cis
             for i in range(B):
-                ci, g, v = br._cis[i], geo[i], views[i]
-                cam = cams_p + 272 * i
-                g.cam = cam
-                v.topleft = cam + 224
+                ci, v = cis[i], views[i]
                 v.pixel_size_x, v.pixel_size_y = 1.0 / ci.fx, 1.0 / ci.fy
                 v.out6, v.T = out_p + 24 * H * W * i, T_p + 4 * H * W * i
-            nb_sh = lib.sh_batch_workspace_bytes(B)
-            bws = torch.empty(nb_sh + lib.frame_batch_workspace_bytes(B), device=dev, dtype=torch.uint8)
+            gsh = torch.empty(br._Np, device=dev, dtype=torch.float32)  # d L / d alpha, shared by the views
             with torch.cuda.device(dev):
-                lib.frame_geometry_batch(B, geo, N, _p(mean), _p(qvec), _p(svec), W, H, _p(bws) + nb_sh, s)
+                lib.frame_geometry_batch_zero(B, geo, N, _p(mean), _p(qvec), _p(svec), W, H, _p(gsh), gsh.numel(),
+                                              _p(br._bws) + br._nb_sh, s)
                 br._end_batch(B)
                 if stats is not None:
-                    lib.densify_update_batch(B, N, _tab([_p(br.slots[i].cov2d) for i in range(B)]), None,
-                                             br._mask_table(B), _p(stats.max_radii2d),
-                                             None, None, s)
+                    lib.densify_update_batch(B, N, br._ptr_table("cov2d", B), None, br._mask_table(B),
+                                             _p(stats.max_radii2d), None, None, s)
                 lib.vol_render_rgbd_batch(B, views, N, _p(col), _p(alpha), 16, br.slots[0].nth, br.slots[0].ntw, H, W,
-                                          thresh, _p(bws), s)
-            ctx.views, ctx.bws = views, bws
+                                          thresh, _p(br._bws), s)
+            ctx.views, ctx.gsh = views, gsh
         else:
+            out6 = torch.zeros(B, H, W, 6, device=dev, dtype=torch.float32)
+            T = torch.ones(B, H, W, 1, device=dev, dtype=torch.float32)
             _render_batch_heads._forward_streams(br, B, lib, mean, qvec, svec, alpha, col, cams, out6, T, thresh, stats)
         if bg_rgb is not None:
             out6[..., :3] += T * bg_rgb  # gs/renderer.py:1182
@@ -303,19 +307,58 @@ class _render_batch_heads(torch.autograd.Function):
         br._end_batch(B)
 
     @staticmethod
-    def backward(ctx, g_rgb, g_depth, g_opac, g_z2, _gT):
-        ctx.br._check_generation(ctx.gen)
+    def _backward_fused(ctx, g_rgb, g_depth, g_opac, g_z2):
+        """one compositing launch that reads the four head gradients in place (no [B,H,W,6] image is assembled: that
+        concatenation was 8 % of a step at 8 x 800^2), one projection launch that forms d L / d depth = g3 + 2 depth g5 and
+        sums the colour gradient over the views itself (gsgen_project_gaussians_backward_batch_heads)"""
         mean, qvec, svec, alpha, col, cams, out6, T = ctx.saved_tensors
         br, B, thresh, stats = ctx.br, ctx.B, ctx.thresh, ctx.stats
         lib = _capi.load()
         H, W, N, dev = br.H, br.W, br.N, mean.device
-        # the four head gradients as autograd hands them over; the batched launch reads them in place (no [B,H,W,6]
-        # image is assembled: that concatenation was 8 % of a step at 8 x 800^2), the per-camera chains want one image
         parts = [g.contiguous() if g is not None else None for g in (g_rgb, g_depth, g_opac, g_z2)]
-        go6 = None
-        if ctx.views is None:
-            z = lambda g, c: g if g is not None else torch.zeros(B, H, W, c, device=dev)  # noqa: E731
-            go6 = torch.cat([z(parts[0], 3), z(parts[1], 1), z(parts[2], 1), z(parts[3], 1)], dim=-1).contiguous()
+        gsh, ctx.gsh = ctx.gsh, None
+        if gsh is None:  # a second backward through the same graph (retain_graph): the accumulators were handed out
+            gsh = torch.zeros(br._Np, device=dev, dtype=torch.float32)
+            br._g2d[:B].zero_()
+        g_alpha = gsh[:N]
+        g3d = torch.empty(13 * N, device=dev, dtype=torch.float32)  # mean | qvec | svec | colour: overwritten
+        g_mean, g_qvec = g3d[:3 * N].view(N, 3), g3d[3 * N:7 * N].view(N, 4)
+        g_svec, g_col = g3d[7 * N:10 * N].view(N, 3), g3d[10 * N:].view(N, 3)
+        s = torch.cuda.current_stream(dev).cuda_stream
+        views = ctx.views
+        pp = [x.data_ptr() if x is not None else None for x in parts]
+        for i in range(B):
+            v = views[i]
+            v.grad_out6 = None
+            v.grad_rgb = pp[0] + 12 * H * W * i if pp[0] is not None else None
+            v.grad_depth = pp[1] + 4 * H * W * i if pp[1] is not None else None
+            v.grad_opacity = pp[2] + 4 * H * W * i if pp[2] is not None else None
+            v.grad_depth2 = pp[3] + 4 * H * W * i if pp[3] is not None else None
+        with torch.cuda.device(dev):
+            lib.vol_render_rgbd_backward_batch(B, views, N, _p(col), _p(alpha), _p(g_alpha), 16, br.slots[0].nth,
+                                               br.slots[0].ntw, H, W, thresh, _p(br._bws), s)
+            lib.project_gaussians_backward_batch_heads(B, N, _p(mean), _p(qvec), _p(svec), br._ptr_table("cam", B),
+                                                       int(ctx.detach), br._mask_table(B), br._ptr_table("g_mean2d", B),
+                                                       br._ptr_table("g_cov2d", B), br._ptr_table("g_chan6", B),
+                                                       br._ptr_table("depth", B), _p(g_mean), _p(g_qvec), _p(g_svec),
+                                                       _p(g_col), s)
+            if stats is not None:
+                lib.densify_update_batch(B, N, None, br._ptr_table("g_mean2d", B), br._mask_table(B), None,
+                                         _p(stats.grad_accum), _p(stats.cnt), s)
+        return (g_mean, g_qvec, g_svec, g_alpha, g_col, None, None, None, _bg_grad(ctx, g_rgb, T), None, None, None)
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_depth, g_opac, g_z2, _gT):
+        ctx.br._check_generation(ctx.gen)
+        if ctx.views is not None:
+            return _render_batch_heads._backward_fused(ctx, g_rgb, g_depth, g_opac, g_z2)
+        mean, qvec, svec, alpha, col, cams, out6, T = ctx.saved_tensors
+        br, B, thresh, stats = ctx.br, ctx.B, ctx.thresh, ctx.stats
+        lib = _capi.load()
+        H, W, N, dev = br.H, br.W, br.N, mean.device
+        parts = [g.contiguous() if g is not None else None for g in (g_rgb, g_depth, g_opac, g_z2)]
+        z = lambda g, c: g if g is not None else torch.zeros(B, H, W, c, device=dev)  # noqa: E731
+        go6 = torch.cat([z(parts[0], 3), z(parts[1], 1), z(parts[2], 1), z(parts[3], 1)], dim=-1).contiguous()
         gbuf = torch.zeros(2 * B * 6 * N, device=dev, dtype=torch.float32)  # one fill for both
         g2d = gbuf[:B * 6 * N].view(B, 6 * N)      # per camera: mean2d | cov2d
         gch = gbuf[B * 6 * N:].view(B, N, 6)       # per camera: rgb | depth | opacity | depth^2
@@ -324,38 +367,7 @@ class _render_batch_heads(torch.autograd.Function):
         g_mean, g_qvec = g3d[:3 * N].view(N, 3), g3d[3 * N:7 * N].view(N, 4)
         g_svec, g_alpha = g3d[7 * N:10 * N].view(N, 3), g3d[10 * N:]
         cams_p, out_p, g2d_p = cams.data_ptr(), out6.data_ptr(), g2d.data_ptr()
-        go_p = go6.data_ptr() if go6 is not None else 0
-        if ctx.views is not None:
-            import ctypes
-            s = torch.cuda.current_stream(dev).cuda_stream
-            gch_p = gch.data_ptr()
-            for i in range(B):
-                v = ctx.views[i]
-                v.grad_out6 = None
-                v.grad_rgb = parts[0].data_ptr() + 12 * H * W * i if parts[0] is not None else None
-                v.grad_depth = parts[1].data_ptr() + 4 * H * W * i if parts[1] is not None else None
-                v.grad_opacity = parts[2].data_ptr() + 4 * H * W * i if parts[2] is not None else None
-                v.grad_depth2 = parts[3].data_ptr() + 4 * H * W * i if parts[3] is not None else None
-                v.grad_mean, v.grad_cov = g2d_p + 24 * N * i, g2d_p + 24 * N * i + 8 * N
-                v.grad_chan6 = gch_p + 24 * N * i
-            tab = lambda vals: (ctypes.c_void_p * B)(*vals)  # noqa: E731
-            with torch.cuda.device(dev):
-                lib.vol_render_rgbd_backward_batch(B, ctx.views, N, _p(col), _p(alpha), _p(g_alpha), 16, br.slots[0].nth,
-                                                   br.slots[0].ntw, H, W, thresh, _p(ctx.bws), s)
-                torch.addcmul(gch[:, :, 3], br._depths[:B], gch[:, :, 5], value=2.0, out=gdp)  # depth and depth^2 heads
-                lib.project_gaussians_backward_batch(B, N, _p(mean), _p(qvec), _p(svec),
-                                                     tab([cams_p + 272 * i for i in range(B)]), int(ctx.detach),
-                                                     br._mask_table(B),
-                                                     tab([g2d_p + 24 * N * i for i in range(B)]),
-                                                     tab([g2d_p + 24 * N * i + 8 * N for i in range(B)]),
-                                                     tab([_p(gdp[i]) for i in range(B)]), _p(g_mean), _p(g_qvec),
-                                                     _p(g_svec), s)
-                if stats is not None:
-                    lib.densify_update_batch(B, N, None, _tab([g2d_p + 24 * N * i for i in range(B)]),
-                                             br._mask_table(B), None,
-                                             _p(stats.grad_accum), _p(stats.cnt), s)
-            return (g_mean, g_qvec, g_svec, g_alpha, gch[:, :, :3].sum(0), None, None, None, _bg_grad(ctx, g_rgb, T), None,
-                    None, None)
+        go_p = go6.data_ptr()
         cur = br._fork(B, (go6, g2d, gch, gdp, g3d))
         with torch.cuda.device(dev):
             for i in range(B):
@@ -409,6 +421,17 @@ class BatchRenderer:
                       for i in range(max_batch)]
         self._ptr_tabs = {}
         self.streams = [torch.cuda.Stream(device=device) for _ in range(max(1, n_streams))]
+        # Buffers a step needs and nobody else sees live as long as the renderer (round 4: nothing is allocated or filled per
+        # step except what is handed to the caller): the camera rows of the batch in flight, the kernel-parameter tables of its
+        # launches, and the per-view gradient accumulators mean2d (2) | cov2d (4) | channels (6) x Np -- zeroed by the
+        # projection launch of the step's forward (gsgen_frame_geometry_batch_zero).  Only one batch per renderer is between
+        # forward and backward (_check_generation), so one set is enough.
+        lib = _capi.load()
+        self._Np = (N + 3) // 4 * 4
+        self._cams = torch.empty(max_batch, 68, device=device, dtype=torch.float32)
+        self._nb_sh = lib.sh_batch_workspace_bytes(max_batch)
+        self._bws = torch.empty(self._nb_sh + lib.frame_batch_workspace_bytes(max_batch), device=device, dtype=torch.uint8)
+        self._g2d = torch.empty(max_batch, 12 * self._Np, device=device, dtype=torch.float32)
         # per camera: cam block (56) | topleft (2) | rotation rows (9) | pad -> 68 floats, packed on the host and sent
         # through kernel arguments (gsgen_upload_small): no pinned ring, no copy event, the host never waits
         self._host = np.zeros((max_batch, 68), np.float32)
@@ -429,10 +452,10 @@ class BatchRenderer:
             intr[i] = (ci.fx, ci.fy, ci.cx, ci.cy, ci.w, ci.h, ci.near_plane, ci.far_plane)
         lib = _capi.load()
         lib.pack_camera_blocks(B, poses.ctypes.data, 12, intr.ctypes.data, frustum_radius, tile_radius, h.ctypes.data)
-        # a fresh device block per batch: the rows are saved for the batch's backward
-        dev = torch.empty(B, 68, device=self.device, dtype=torch.float32)
-        lib.upload_small(_p(dev), h.ctypes.data, B * 272, torch.cuda.current_stream(self.device).cuda_stream)
-        return dev
+        # the renderer's own device block: its rows are read by the batch's backward, and no other batch of this renderer
+        # may come between a forward and its backward (_check_generation)
+        lib.upload_small(_p(self._cams), h.ctypes.data, B * 272, torch.cuda.current_stream(self.device).cuda_stream)
+        return self._cams[:B]
 
     def _mask_table(self, B):
         """void*[B] of the slots' visibility masks (they never move): built once per batch size"""
@@ -440,6 +463,31 @@ class BatchRenderer:
         if t is None:
             import ctypes
             t = self._ptr_tabs[B] = (ctypes.c_void_p * B)(*[_p(self.slots[i].mask) for i in range(B)])
+        return t
+
+    def _ptr_table(self, kind, B):
+        """void*[B] of per-view addresses that never move: the camera rows, the slots' cov2d / depth buffers, the per-view
+        gradient blocks (built once per kind and batch size)"""
+        key = (kind, B)
+        t = self._ptr_tabs.get(key)
+        if t is None:
+            import ctypes
+            g0, st = self._g2d.data_ptr(), 4 * 12 * self._Np
+            if kind == "cam":
+                a = [self._cams.data_ptr() + 272 * i for i in range(B)]
+            elif kind == "cov2d":
+                a = [_p(self.slots[i].cov2d) for i in range(B)]
+            elif kind == "depth":
+                a = [_p(self.slots[i].depth) for i in range(B)]
+            elif kind == "g_mean2d":
+                a = [g0 + st * i for i in range(B)]
+            elif kind == "g_cov2d":
+                a = [g0 + st * i + 4 * 2 * self._Np for i in range(B)]
+            elif kind == "g_chan6":
+                a = [g0 + st * i + 4 * 6 * self._Np for i in range(B)]
+            else:
+                raise KeyError(kind)
+            t = self._ptr_tabs[key] = (ctypes.c_void_p * B)(*a)
         return t
 
     def _tables(self, kind):
@@ -454,17 +502,27 @@ class BatchRenderer:
         n = len(self.slots)
         geo = (_capi.GeometryView * n)()
         views = ((_capi.ShView if kind == "sh" else _capi.RgbdView) * n)()
+        cams_p, g0, st = self._cams.data_ptr(), self._g2d.data_ptr(), 4 * 12 * self._Np
         for i, buf in enumerate(self.slots):
             g, v = geo[i], views[i]
+            cam = cams_p + 272 * i  # row i: cam block | topleft at +56 floats | rotation at +58
+            g.cam = cam
             g.mean2d, g.cov2d, g.depth, g.mask = _p(buf.mean2d), _p(buf.cov2d), _p(buf.depth), _p(buf.mask)
             g.gaussian_ids, g.start, g.end, g.total = _p(buf.ids), _p(buf.start), _p(buf.end), _p(buf.total)
             g.workspace, g.workspace_bytes, g.D_cap = _p(buf.ws), buf.ws.numel(), buf.D_cap
+            # this view's gradient accumulators: zero-filled by the projection launch, read by the projection backward
+            g.zero_grad_mean2d = v.grad_mean = g0 + st * i
+            g.zero_grad_cov2d = v.grad_cov = g0 + st * i + 4 * 2 * self._Np
             v.mean, v.cov, v.start, v.end, v.gaussian_ids = _p(buf.mean2d), _p(buf.cov2d), _p(buf.start), _p(buf.end), _p(buf.ids)
             v.tile_order = buf.tile_order()
+            v.topleft = cam + 224
             if kind == "sh":
+                v.c2w = cam + 232
                 v.segment_workspace = _p(buf.seg_ws) if self.segments > 1 else None
             else:
                 v.depth = _p(buf.depth)
+                if kind == "rgbd":
+                    g.zero_grad_chan6 = v.grad_chan6 = g0 + st * i + 4 * 6 * self._Np
         self._table_cache[kind] = (caps, geo, views)
         return geo, views
 

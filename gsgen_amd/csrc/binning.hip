@@ -650,7 +650,7 @@ int gsgen_internal_frame_project(uint32_t N, const float *mean, const float *qve
 
 int gsgen_internal_frame_project_views(uint32_t N, const float *mean, const float *qvec, const float *svec,
                                        int w, int h, int ntw, const GeoView *host_views, GeoView *dev_views,
-                                       uint32_t B, gsgen_stream_t stream);
+                                       uint32_t B, float *zero_shared, size_t zero_shared_floats, gsgen_stream_t stream);
 
 // used by legacy.hip: per-segment sort of (depth bits << 32 | id) keys, ids out (ctrl[1] must be 0)
 int gsgen_internal_sort_segments(uint32_t T, const uint32_t *tile_off, const uint32_t *ctrl,
@@ -712,6 +712,15 @@ size_t gsgen_frame_batch_workspace_bytes(uint32_t n_views) { return (size_t)n_vi
 int gsgen_frame_geometry_batch(uint32_t n_views, const gsgen_geometry_view *views, uint32_t N, const float *mean,
                                const float *qvec, const float *svec, uint32_t W, uint32_t H,
                                void *batch_workspace, gsgen_stream_t stream) {
+  return gsgen_frame_geometry_batch_zero(n_views, views, N, mean, qvec, svec, W, H, nullptr, 0, batch_workspace, stream);
+}
+
+int gsgen_frame_geometry_batch_zero(uint32_t n_views, const gsgen_geometry_view *views, uint32_t N, const float *mean,
+                                    const float *qvec, const float *svec, uint32_t W, uint32_t H, float *zero_shared,
+                                    size_t zero_shared_floats, void *batch_workspace, gsgen_stream_t stream) {
+  if (zero_shared_floats && (!zero_shared || (zero_shared_floats & 3u) || (reinterpret_cast<uintptr_t>(zero_shared) & 15u) ||
+                             zero_shared_floats / 4 > 0xffffffffull))
+    return GSGEN_EINVAL;
   const uint32_t ntw = (W + kTile - 1) / kTile, nth = (H + kTile - 1) / kTile;
   const uint32_t T = ntw * nth;
   if (T == 0 || n_views == 0) return 0;
@@ -733,11 +742,16 @@ int gsgen_frame_geometry_batch(uint32_t n_views, const gsgen_geometry_view *view
     g.tl = w.tl; g.br = w.br; g.cnt = w.cnt; g.wcnt = w.wcnt; g.tile_count = w.tile_count; g.tile_off = w.tile_off;
     g.ctrl = w.ctrl; g.tile_order = w.tile_order; g.keys = w.keys;
     g.ids = v.gaussian_ids; g.start = v.start; g.end = v.end; g.total = v.total; g.cap = v.D_cap;
+    g.z_mean2d = v.zero_grad_mean2d; g.z_cov2d = v.zero_grad_cov2d; g.z_chan6 = v.zero_grad_chan6;
+    if ((reinterpret_cast<uintptr_t>(g.z_mean2d) & 7u) || (reinterpret_cast<uintptr_t>(g.z_cov2d) & 15u) ||
+        (reinterpret_cast<uintptr_t>(g.z_chan6) & 7u))
+      return GSGEN_EINVAL;
   }
   hipStream_t s = (hipStream_t)stream;
   GeoView *dv = reinterpret_cast<GeoView *>(batch_workspace);
   if (int e = gsgen_internal_frame_project_views(N, mean, qvec, svec, (int)W, (int)H, (int)ntw, gv.data(), dv,
-                                                 n_views, stream))
+                                                 n_views, zero_shared_floats ? zero_shared : nullptr, zero_shared_floats,
+                                                 stream))
     return e;
   const uint32_t B = n_views;
   const uint32_t ngroups = ((ntw + kGroup - 1) / kGroup) * ((nth + kGroup - 1) / kGroup);

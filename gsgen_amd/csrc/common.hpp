@@ -421,6 +421,9 @@ struct GeoView {
   int *ids, *start, *end;
   uint32_t *total;
   uint32_t cap, pad_;
+  // optional per-view gradient accumulators of the step's backward ([N,2], [N,2,2], [N,6]; any may be NULL): zero-filled by
+  // the projection launch, which touches every Gaussian of the view anyway (gsgen_frame_geometry_batch_zero)
+  float *z_mean2d, *z_cov2d, *z_chan6;
 };
 
 }  // namespace gs

@@ -179,13 +179,18 @@ __global__ void __launch_bounds__(TS * TS / PPL) k_composite_fwd(CompParams p_ar
   }
 
   if (n == 0) {  // uniform over the workgroup
-    if (p.bg != nullptr) {  // vol_render_bg.h:34-53: empty tiles show the background
+    if constexpr (MODE == MODE_SH) {
+      if (p.bg != nullptr || p.fill_empty) {  // vol_render_bg.h:34-53: empty tiles show the background
 #pragma unroll
-      for (int j = 0; j < PPL; ++j)
-        if (valid[j]) {
-          float *o = p.out + 3 * ((size_t)gy[j] * p.W + gx);
-          o[0] = p.bg[0]; o[1] = p.bg[1]; o[2] = p.bg[2];
-        }
+        for (int j = 0; j < PPL; ++j)
+          if (valid[j]) {
+            const size_t pix = (size_t)gy[j] * p.W + gx;
+            float *o = p.out + 3 * pix;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o[c] = p.bg != nullptr ? p.bg[c] : 0.0f;
+            if (p.fill_empty && p.T != nullptr) p.T[pix] = 1.0f;  // batched launches write the whole image (CompParams::fill_empty)
+          }
+      }
     }
     return;  // otherwise the caller's pre-initialised out / T stand (vol_render.h:1006-1013)
   }
@@ -412,12 +417,15 @@ __device__ __forceinline__ void composite_fwd_sh_vec_tile(const CompParams &p, u
     stop[j] = valid[j] ? n : 0;
   }
   if (n == 0) {  // uniform over the workgroup
-    if (p.bg != nullptr) {  // vol_render_bg.h:34-53: empty tiles show the background
+    if (p.bg != nullptr || p.fill_empty) {  // vol_render_bg.h:34-53: empty tiles show the background
 #pragma unroll
       for (int j = 0; j < PPL; ++j)
         if (valid[j]) {
-          float *o = p.out + 3 * ((size_t)gy[j] * p.W + gx);
-          o[0] = p.bg[0]; o[1] = p.bg[1]; o[2] = p.bg[2];
+          const size_t pix = (size_t)gy[j] * p.W + gx;
+          float *o = p.out + 3 * pix;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) o[c] = p.bg != nullptr ? p.bg[c] : 0.0f;
+          if (p.fill_empty && p.T != nullptr) p.T[pix] = 1.0f;  // batched launches write the whole image (CompParams::fill_empty)
         }
     }
     return;  // otherwise the caller's pre-initialised out / T stand (vol_render.h:1006-1013)
@@ -1470,10 +1478,26 @@ k_composite_fwd_chan_vec(CompParams p_arg, const CompParams *__restrict__ plist)
   const int tile = ty * p.ntw + tx;
   const int st = p.start[tile];
   const int n = (st < 0) ? 0 : (p.end[tile] - st);
-  if (n == 0) return;  // the caller's pre-initialised out / T stand (vol_render.h:1006-1013)
   const int t = (int)threadIdx.x;
   const int lx = t & 15, ly0 = t >> 4;
   const int gx = tx * kTile + lx;
+  if (n == 0) {  // uniform over the workgroup
+    // per-camera entry points: the caller's pre-initialised out / T stand (vol_render.h:1006-1013); batched launches that
+    // ask for it write the empty tile themselves (CompParams::fill_empty)
+    if (p.fill_empty) {
+#pragma unroll
+      for (int j = 0; j < PPL; ++j) {
+        const int gyj = ty * kTile + ly0 + j * ROWS;
+        if (gx < p.W && gyj < p.H) {
+          const size_t pix = (size_t)gyj * p.W + gx;
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) p.out[NCH * pix + c] = 0.0f;
+          if (p.T != nullptr) p.T[pix] = 1.0f;
+        }
+      }
+    }
+    return;
+  }
   const float px = pixel_coord(p.topleft[0], gx, p.psx);
 
   bool valid[PPL];
@@ -1571,7 +1595,12 @@ k_composite_fwd_chan_vec(CompParams p_arg, const CompParams *__restrict__ plist)
 // (wavefront, list entry) on it at 2 pixels per lane -- a third of them register moves around its per-pixel branches.
 // This is k_composite_bwd_sh_vec without the SH part: one wavefront per tile, 4 pixels per lane as two pixel PAIRS,
 // every per-pixel quantity packed, contribution mask folded into G and a G, `alive` = (T >= thresh), one wave-uniform
-// guard branch, the record in scalar registers, the NCH + 7 gradient components reduced as (even, odd) pairs.
+// guard branch, the NCH + 7 gradient components reduced as (even, odd) pairs.
+// Round 4 (the trainer's default path measured in the driver line): as in the SH kernels the suffix colour enters
+// d L / d (a G) only as  sum_c grad_out_c * suffix_c,  so ONE running grad_out-weighted suffix per pixel replaces the NCH
+// per-channel suffixes (6 -> 1 register pairs per pixel pair on RGB + heads, 4 packed operations per channel and pixel pair ->
+// 2); the atomics' target is base(lane) + id * stride(lane), both fixed per lane before the list walk (the select chain
+// over four arrays per entry compiled to nested exec-mask branches and a flat atomic).
 // Reduction vector: channels [0, NCH) | pad to even | mean 2 | cov 4 | alpha 1.
 template <int MODE, bool BATCH = false>
 __global__ void __launch_bounds__(64)
@@ -1600,21 +1629,36 @@ k_composite_bwd_chan_vec(CompParams p_arg, const CompParams *__restrict__ plist)
   const int gx = tx * kTile + lx;
   const float px = pixel_coord(p.topleft[0], gx, p.psx);
 
-  v2f py2[NP], go2[NP][NCH], rem2[NP][NCH], Tr2[NP];
+  // R2 = sum_c grad_out_c * (final_c - prefix_c): the grad_out-weighted suffix colour behind the current splat
+  v2f py2[NP], go2[NP][NCH], R2[NP], Tr2[NP];
 #pragma unroll
   for (int j = 0; j < PPL; ++j) {
     const int gy = ty * kTile + ly0 + j * ROWS;
     const bool valid = (gx < p.W) && (gy < p.H);
     py2[j >> 1][j & 1] = pixel_coord(p.topleft[1], gy, p.psy);
     const size_t pix = valid ? ((size_t)gy * p.W + gx) : 0;
+    float r = 0.0f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-      go2[j >> 1][c][j & 1] = valid ? load_grad_out<MODE, NCH>(p, pix, c) : 0.0f;
-      rem2[j >> 1][c][j & 1] = valid ? p.final_img[NCH * pix + c] : 0.0f;  // final - prefix, prefix = 0
+      const float g = valid ? load_grad_out<MODE, NCH>(p, pix, c) : 0.0f;
+      go2[j >> 1][c][j & 1] = g;
+      r = fmaf(g, valid ? p.final_img[NCH * pix + c] : 0.0f, r);  // prefix = 0 in front of the list
     }
+    R2[j >> 1][j & 1] = r;
     Tr2[j >> 1][j & 1] = valid ? 1.0f : -1.0f;  // alive = (T >= thresh); pixels outside never are
   }
   auto alive = [&](int j) { return !(Tr2[j >> 1][j & 1] < p.thresh); };
+
+  // where this lane's component of the reduced gradient goes: dst = base + id * stride (bytes); no target: base = 0
+  const int comp = scatter_comp<P>(lane);
+  char *a_base = nullptr;
+  uint32_t a_stride = 0;
+  if (scatter_owner<P>(lane)) {
+    if (comp < NCH) { a_base = reinterpret_cast<char *>(p.g_col + comp); a_stride = 4u * (uint32_t)TR::NCOL; }
+    else if (comp >= G0 && comp < G0 + 2) { a_base = reinterpret_cast<char *>(p.g_mean + (comp - G0)); a_stride = 8u; }
+    else if (comp >= G0 + 2 && comp < G0 + 6) { a_base = reinterpret_cast<char *>(p.g_cov + (comp - G0 - 2)); a_stride = 16u; }
+    else if (comp == G0 + 6) { a_base = reinterpret_cast<char *>(p.g_alpha); a_stride = 4u; }
+  }
 
   for (int base = 0; base < n; base += kBatch) {
     const int nb = min(kBatch, n - base);
@@ -1628,8 +1672,9 @@ k_composite_bwd_chan_vec(CompParams p_arg, const CompParams *__restrict__ plist)
       for (int j = 0; j < PPL; ++j) any_alive |= alive(j);
       if (!wave_any(any_alive)) break;
 
-      const float r_mx = wave_uniform(S.mx[g]), r_my = wave_uniform(S.my[g]), r_a = wave_uniform(S.a[g]),
-                  r_p0 = wave_uniform(S.p0[g]), r_p1 = wave_uniform(S.p1[g]), r_p2 = wave_uniform(S.p2[g]);
+      // (the record as plain vector registers -- LDS broadcasts: the single-suffix form leaves room for them, and the six
+      // v_readfirstlane + six more for the channel values per entry are gone)
+      const float r_mx = S.mx[g], r_my = S.my[g], r_a = S.a[g], r_p0 = S.p0[g], r_p1 = S.p1[g], r_p2 = S.p2[g];
       const float x = px - r_mx;
       // G2 / ag2: the Gaussian (gauss_eval's Cholesky form) and a G, ZEROED where the pixel does not take part
       v2f y2[NP], G2[NP], ag2[NP];
@@ -1669,24 +1714,20 @@ k_composite_bwd_chan_vec(CompParams p_arg, const CompParams *__restrict__ plist)
 #pragma unroll
       for (int i = 0; i < P / 2; ++i) gr2[i] = v2f{0.0f, 0.0f};
       const float *cg = &S.col[g * TR::NCOLP];
-      v2f w2[NP], inv1m2[NP], pAG2[NP];
+      v2f w2[NP], om2[NP], gy2[NP];
 #pragma unroll
       for (int jp = 0; jp < NP; ++jp) {
         w2[jp] = (splat2(r_a) * Tr2[jp]) * G2[jp];  // the forward's (a T) G, or 0
-        const v2f om = one_minus2(ag2[jp]);
-        inv1m2[jp] = v2f{__builtin_amdgcn_rcpf(om[0]), __builtin_amdgcn_rcpf(om[1])};
-        pAG2[jp] = v2f{0.0f, 0.0f};
+        om2[jp] = one_minus2(ag2[jp]);
       }
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
-        const float val = wave_uniform(cg[c]);
-        v2f gacc = v2f{0.0f, 0.0f};
+        const v2f val = splat2(cg[c]);
+        v2f gacc;
 #pragma unroll
         for (int jp = 0; jp < NP; ++jp) {
-          rem2[jp][c] = fma2(-w2[jp], splat2(val), rem2[jp][c]);        // suffix colour behind this splat
-          gacc = fma2(w2[jp], go2[jp][c], gacc);                        // d/d(channel value)
-          const v2f sfx = rem2[jp][c] * inv1m2[jp];
-          pAG2[jp] = fma2(go2[jp][c], fma2(splat2(val), Tr2[jp], -sfx), pAG2[jp]);
+          gacc = jp == 0 ? w2[jp] * go2[jp][c] : fma2(w2[jp], go2[jp][c], gacc);             // d / d (channel value)
+          gy2[jp] = c == 0 ? go2[jp][c] * val : fma2(go2[jp][c], val, gy2[jp]);            // sum_c grad_out_c * value_c
         }
         gr2[c >> 1][c & 1] = add_scalar(gacc[0], gacc[1]);
       }
@@ -1696,7 +1737,12 @@ k_composite_bwd_chan_vec(CompParams p_arg, const CompParams *__restrict__ plist)
       v2f gm0 = {0.f, 0.f}, gm1 = gm0, gc0 = gm0, gc1 = gm0, gc3 = gm0, gal = gm0;
 #pragma unroll
       for (int jp = 0; jp < NP; ++jp) {
-        const v2f gg = pAG2[jp] * ag2[jp];
+        // the suffix behind this splat, grad_out-weighted, and d L / d (a G) from it:
+        //   sum_c grad_out_c (value_c T - suffix_c / (1 - a G))      (vol_render.h:379-409)
+        R2[jp] = fma2(-w2[jp], gy2[jp], R2[jp]);
+        const v2f inv1m = v2f{__builtin_amdgcn_rcpf(om2[jp][0]), __builtin_amdgcn_rcpf(om2[jp][1])};
+        const v2f pAG = fma2(gy2[jp], Tr2[jp], -(R2[jp] * inv1m));
+        const v2f gg = pAG * ag2[jp];
         const v2f u = fma2(splat2(r_p1), y2[jp], splat2(p0x));
         const v2f vx = splat2(k0) * u;
         const v2f vy = fma2(splat2(k1), u, (splat2(k2) * splat2(r_p2)) * y2[jp]);
@@ -1707,8 +1753,8 @@ k_composite_bwd_chan_vec(CompParams p_arg, const CompParams *__restrict__ plist)
         gc0 = fma2(hvx, vx, gc0);
         gc1 = fma2(hvx, vy, gc1);
         gc3 = fma2(h * vy, vy, gc3);
-        gal = fma2(pAG2[jp], G2[jp], gal);
-        Tr2[jp] = Tr2[jp] * one_minus2(ag2[jp]);  // T (1 - a G) if it contributed (as the forward)
+        gal = fma2(pAG, G2[jp], gal);
+        Tr2[jp] = Tr2[jp] * om2[jp];  // T (1 - a G) if it contributed (as the forward: 1 - round(a G))
       }
       const float c1s = add_scalar(gc1[0], gc1[1]);
       gr2[G0 / 2 + 0] = v2f{add_scalar(gm0[0], gm0[1]), add_scalar(gm1[0], gm1[1])};
@@ -1717,16 +1763,7 @@ k_composite_bwd_chan_vec(CompParams p_arg, const CompParams *__restrict__ plist)
       gr2[G0 / 2 + 3] = v2f{add_scalar(gal[0], gal[1]), 0.0f};
 
       wave_reduce_scatter2<P>(gr2);
-      const int comp = scatter_comp<P>(lane);
-      if (scatter_owner<P>(lane)) {
-        const size_t id = (size_t)S.id[g];
-        float *dst = nullptr;
-        if (comp < NCH) dst = p.g_col + (size_t)TR::NCOL * id + comp;
-        else if (comp >= G0 && comp < G0 + 2) dst = p.g_mean + 2 * id + (comp - G0);
-        else if (comp >= G0 + 2 && comp < G0 + 6) dst = p.g_cov + 4 * id + (comp - G0 - 2);
-        else if (comp == G0 + 6) dst = p.g_alpha + id;
-        if (dst != nullptr) atomicAdd(dst, gr2[0][0]);
-      }
+      if (a_base != nullptr) atomicAdd(reinterpret_cast<float *>(a_base + (size_t)(uint32_t)S.id[g] * a_stride), gr2[0][0]);
     }
     bool any_alive = false;
 #pragma unroll
@@ -2267,6 +2304,7 @@ static int fill_view_params(uint32_t n_views, const gsgen_sh_view *views, const 
       p.g_mean = v.grad_mean; p.g_cov = v.grad_cov; p.g_col = g_sh; p.g_alpha = g_alpha;
     } else {
       p.bg = v.bg_rgb; p.out = v.out; p.T = v.T;
+      p.fill_empty = 1;  // the batched forward writes every pixel of out / T (include/gsgen_hip.h)
     }
     if (n_segments > 1) {
       p.nseg = (int)n_segments;
@@ -2490,6 +2528,7 @@ static int fill_rgbd_params(uint32_t n_views, const gsgen_rgbd_view *views, cons
       p.g_mean = v.grad_mean; p.g_cov = v.grad_cov; p.g_col = heads ? v.grad_chan6 : g_color; p.g_alpha = g_alpha;
     } else {
       p.out = v.out6; p.T = v.T;
+      p.fill_empty = 1;  // the batched forward writes every pixel of out6 / T (include/gsgen_hip.h)
     }
   }
   return 0;

@@ -38,6 +38,10 @@ struct CompParams {
   // polynomial form of the per-pixel basis or the exact one (poly_route) -- no host decision, no host sync.
   const float *sh_bound;
   uint32_t vgrid;  // persistent launches (the exact fallback of a bounded batch): size of the virtual grid they stride through
+  // post-activation channel modes, batched launches: the forward WRITES the empty tiles too (channels 0, T = 1), so the caller
+  // need not pre-initialise [B,H,W,NCH] + [B,H,W] every step (the reference's contract -- "out zeroed, T set to 1 by the
+  // caller", vol_render.h:1006-1013 -- stays that of the per-camera `_gs` entry points)
+  int fill_empty;
 };
 constexpr int kSegLen = 32;
 

@@ -259,8 +259,7 @@ __device__ __forceinline__ ProjGrad project_bwd_one(uint32_t n, const float *__r
                                                     const float *__restrict__ qvec, const float *__restrict__ svec,
                                                     const float *__restrict__ c2w, int detach_depth,
                                                     const float *__restrict__ g_mean2d,
-                                                    const float *__restrict__ g_cov2d,
-                                                    const float *__restrict__ g_depth) {
+                                                    const float *__restrict__ g_cov2d, float g_depth_n) {
   ProjGrad o;
   float Rc[9], t[3];
   load_pose(c2w, Rc, t);
@@ -335,7 +334,7 @@ __device__ __forceinline__ ProjGrad project_bwd_one(uint32_t n, const float *__r
 #pragma unroll
   for (int k = 0; k < 4; ++k) o.gq[k] = (dq[k] - qh[k] * dot) / nq;
   const float gm0 = g_mean2d[2 * (size_t)n], gm1 = g_mean2d[2 * (size_t)n + 1];
-  float du[3] = {gm0 * iz, gm1 * iz, g_depth != nullptr ? g_depth[n] : 0.0f};
+  float du[3] = {gm0 * iz, gm1 * iz, g_depth_n};
   if (!detach_depth) du[2] += -(ux * gm0 + uy * gm1) * iz * iz;
 #pragma unroll
   for (int j = 0; j < 3; ++j) o.gm[j] = Rc[j * 3] * du[0] + Rc[j * 3 + 1] * du[1] + Rc[j * 3 + 2] * du[2];
@@ -364,7 +363,8 @@ k_project_bwd(uint32_t N, const float *__restrict__ mean, const float *__restric
     if constexpr (ACC) atomicAdd(dst, v);
     else *dst = v;
   };
-  const ProjGrad o = project_bwd_one(n, mean, qvec, svec, c2w, detach_depth, g_mean2d, g_cov2d, g_depth);
+  const ProjGrad o = project_bwd_one(n, mean, qvec, svec, c2w, detach_depth, g_mean2d, g_cov2d,
+                                     g_depth != nullptr ? g_depth[n] : 0.0f);
 #pragma unroll
   for (int j = 0; j < 3; ++j) put(gs_ + j, o.gs[j]);
 #pragma unroll
@@ -381,24 +381,40 @@ struct ProjBwdViews {
   const float *cam[kProjViews];
   const uint8_t *mask[kProjViews];
   const float *g_mean2d[kProjViews], *g_cov2d[kProjViews], *g_depth[kProjViews];
+  // RGB + heads (gsgen_project_gaussians_backward_batch_heads): the view's channel gradients [N,6] = d L / d (r, g, b, d, 1, d*d)
+  // and its depths [N]; d L / d depth = g3 + 2 d g5 is formed here, the colour gradient summed over the views
+  const float *g_chan6[kProjViews], *depth[kProjViews];
 };
 __global__ void __launch_bounds__(kThreads)
 k_project_bwd_views(uint32_t N, const float *__restrict__ mean, const float *__restrict__ qvec,
                     const float *__restrict__ svec, ProjBwdViews pv, int n_views, int detach_depth, int accumulate,
-                    float *__restrict__ g_mean, float *__restrict__ g_qvec, float *__restrict__ g_svec) {
+                    float *__restrict__ g_mean, float *__restrict__ g_qvec, float *__restrict__ g_svec,
+                    float *__restrict__ g_color) {
   const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
   float *gm = g_mean + 3 * (size_t)n, *gq = g_qvec + 4 * (size_t)n, *gs_ = g_svec + 3 * (size_t)n;
+  float *gc_ = g_color != nullptr ? g_color + 3 * (size_t)n : nullptr;
   ProjGrad a;
+  float gc[3];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) { a.gm[j] = accumulate ? gm[j] : 0.f; a.gs[j] = accumulate ? gs_[j] : 0.f; }
+  for (int j = 0; j < 3; ++j) {
+    a.gm[j] = accumulate ? gm[j] : 0.f; a.gs[j] = accumulate ? gs_[j] : 0.f;
+    gc[j] = (accumulate && gc_ != nullptr) ? gc_[j] : 0.f;
+  }
 #pragma unroll
   for (int k = 0; k < 4; ++k) a.gq[k] = accumulate ? gq[k] : 0.f;
   for (int v = 0; v < n_views; ++v) {
     const uint8_t *m = pv.mask[v];
     if (m != nullptr && m[n] == 0) continue;
-    const ProjGrad o = project_bwd_one(n, mean, qvec, svec, pv.cam[v], detach_depth, pv.g_mean2d[v], pv.g_cov2d[v],
-                                       pv.g_depth[v]);
+    const float *ch = pv.g_chan6[v];
+    float gd = pv.g_depth[v] != nullptr ? pv.g_depth[v][n] : 0.f;
+    if (ch != nullptr) {  // the depth head and the depth^2 head both feed the view-space depth (include/gsgen_hip.h)
+      const float2 *c2 = reinterpret_cast<const float2 *>(ch + 6 * (size_t)n);
+      const float2 c01 = c2[0], c23 = c2[1], c45 = c2[2];
+      gc[0] += c01.x; gc[1] += c01.y; gc[2] += c23.x;
+      gd = c23.y + 2.0f * pv.depth[v][n] * c45.y;
+    }
+    const ProjGrad o = project_bwd_one(n, mean, qvec, svec, pv.cam[v], detach_depth, pv.g_mean2d[v], pv.g_cov2d[v], gd);
 #pragma unroll
     for (int j = 0; j < 3; ++j) { a.gm[j] += o.gm[j]; a.gs[j] += o.gs[j]; }
 #pragma unroll
@@ -408,6 +424,7 @@ k_project_bwd_views(uint32_t N, const float *__restrict__ mean, const float *__r
   for (int j = 0; j < 3; ++j) { gm[j] = a.gm[j]; gs_[j] = a.gs[j]; }
 #pragma unroll
   for (int k = 0; k < 4; ++k) gq[k] = a.gq[k];
+  if (gc_ != nullptr) { gc_[0] = gc[0]; gc_[1] = gc[1]; gc_[2] = gc[2]; }
 }
 
 // ---- AABB -> tile rectangle -------------------------------------------------------------------
@@ -510,11 +527,30 @@ k_frame_project(uint32_t N, const float *__restrict__ mean, const float *__restr
 // be written by a one-workgroup launch of its own in front: one more link in every batch's chain of dependent launches.)
 constexpr int kViewPack = 8;
 struct GeoViewPack { GeoView v[kViewPack]; };
+// z_shared / z_quads: an optional block of float4s every view's backward accumulates into (d L / d alpha, d L / d sh or colour),
+// zero-filled by ALL workgroups of the launch together (grid-stride over the launch's threads) -- with the per-view targets of
+// GeoView this replaces the caller's fill kernel between forward and backward (38.8 MB per 8-view step at cfg2: a launch of its
+// own in every step's chain).
 __global__ void __launch_bounds__(kThreads)
 k_frame_project_views(uint32_t N, const float *__restrict__ mean, const float *__restrict__ qvec,
-                      const float *__restrict__ svec, int w, int h, int ntw, GeoViewPack pack, GeoView *__restrict__ dst) {
+                      const float *__restrict__ svec, int w, int h, int ntw, GeoViewPack pack, GeoView *__restrict__ dst,
+                      float4 *__restrict__ z_shared, uint32_t z_quads) {
   const GeoView &v = pack.v[blockIdx.y];
   if (blockIdx.x == 0 && threadIdx.x == 0) dst[blockIdx.y] = v;
+  if (z_shared != nullptr) {
+    const uint32_t nthr = gridDim.x * gridDim.y * blockDim.x;
+    for (uint32_t i = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; i < z_quads; i += nthr)
+      z_shared[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) {
+    if (v.z_mean2d != nullptr) *reinterpret_cast<float2 *>(v.z_mean2d + 2 * (size_t)i) = make_float2(0.f, 0.f);
+    if (v.z_cov2d != nullptr) *reinterpret_cast<float4 *>(v.z_cov2d + 4 * (size_t)i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (v.z_chan6 != nullptr) {
+      float2 *z = reinterpret_cast<float2 *>(v.z_chan6 + 6 * (size_t)i);
+      z[0] = z[1] = z[2] = make_float2(0.f, 0.f);
+    }
+  }
   frame_project_body(N, mean, qvec, svec, v.cam, w, h, ntw, v.mean2d, v.cov2d, v.depth, v.mask, v.tl, v.br);
 }
 
@@ -608,16 +644,19 @@ int gsgen_project_gaussians_backward_accum(uint32_t N, const float *mean, const 
   return (int)hipGetLastError();
 }
 
-int gsgen_project_gaussians_backward_batch(uint32_t n_views, uint32_t N, const float *mean, const float *qvec,
-                                           const float *svec, const float *const *c2w, int detach_depth,
-                                           const uint8_t *const *mask, const float *const *g_mean2d,
-                                           const float *const *g_cov2d, const float *const *g_depth,
-                                           float *g_mean, float *g_qvec, float *g_svec, gsgen_stream_t stream) {
+static int project_bwd_batch(uint32_t n_views, uint32_t N, const float *mean, const float *qvec, const float *svec,
+                             const float *const *c2w, int detach_depth, const uint8_t *const *mask,
+                             const float *const *g_mean2d, const float *const *g_cov2d, const float *const *g_depth,
+                             const float *const *g_chan6, const float *const *depth, float *g_mean, float *g_qvec,
+                             float *g_svec, float *g_color, gsgen_stream_t stream) {
   if (N == 0) return 0;
   if (!mean || !qvec || !svec || !g_mean || !g_qvec || !g_svec) return GSGEN_EINVAL;
   if (n_views && (!c2w || !g_mean2d || !g_cov2d)) return GSGEN_EINVAL;
-  for (uint32_t v = 0; v < n_views; ++v)
+  if ((g_chan6 != nullptr) != (depth != nullptr) || (g_chan6 != nullptr) != (g_color != nullptr)) return GSGEN_EINVAL;
+  for (uint32_t v = 0; v < n_views; ++v) {
     if (!c2w[v] || !g_mean2d[v] || !g_cov2d[v]) return GSGEN_EINVAL;
+    if (g_chan6 && (!g_chan6[v] || !depth[v])) return GSGEN_EINVAL;
+  }
   uint32_t v0 = 0;
   do {  // (an empty batch still zero-fills)
     ProjBwdViews pv{};
@@ -628,12 +667,34 @@ int gsgen_project_gaussians_backward_batch(uint32_t n_views, uint32_t N, const f
       pv.g_mean2d[i] = g_mean2d[v0 + i];
       pv.g_cov2d[i] = g_cov2d[v0 + i];
       pv.g_depth[i] = g_depth ? g_depth[v0 + i] : nullptr;
+      pv.g_chan6[i] = g_chan6 ? g_chan6[v0 + i] : nullptr;
+      pv.depth[i] = depth ? depth[v0 + i] : nullptr;
     }
     hipLaunchKernelGGL(k_project_bwd_views, grid_for(N), dim3(kThreads), 0, (hipStream_t)stream, N, mean, qvec,
-                       svec, pv, (int)nv, detach_depth, v0 ? 1 : 0, g_mean, g_qvec, g_svec);
+                       svec, pv, (int)nv, detach_depth, v0 ? 1 : 0, g_mean, g_qvec, g_svec, g_color);
     v0 += nv;
   } while (v0 < n_views);
   return (int)hipGetLastError();
+}
+
+int gsgen_project_gaussians_backward_batch(uint32_t n_views, uint32_t N, const float *mean, const float *qvec,
+                                           const float *svec, const float *const *c2w, int detach_depth,
+                                           const uint8_t *const *mask, const float *const *g_mean2d,
+                                           const float *const *g_cov2d, const float *const *g_depth,
+                                           float *g_mean, float *g_qvec, float *g_svec, gsgen_stream_t stream) {
+  return project_bwd_batch(n_views, N, mean, qvec, svec, c2w, detach_depth, mask, g_mean2d, g_cov2d, g_depth, nullptr,
+                           nullptr, g_mean, g_qvec, g_svec, nullptr, stream);
+}
+
+int gsgen_project_gaussians_backward_batch_heads(uint32_t n_views, uint32_t N, const float *mean, const float *qvec,
+                                                 const float *svec, const float *const *c2w, int detach_depth,
+                                                 const uint8_t *const *mask, const float *const *g_mean2d,
+                                                 const float *const *g_cov2d, const float *const *g_chan6,
+                                                 const float *const *depth, float *g_mean, float *g_qvec, float *g_svec,
+                                                 float *g_color, gsgen_stream_t stream) {
+  if (!g_chan6 || !depth || !g_color) return GSGEN_EINVAL;
+  return project_bwd_batch(n_views, N, mean, qvec, svec, c2w, detach_depth, mask, g_mean2d, g_cov2d, nullptr, g_chan6,
+                           depth, g_mean, g_qvec, g_svec, g_color, stream);
 }
 
 // Host side: the 56-float camera block of gsgen_frame_geometry.  Frustum planes as
@@ -799,15 +860,17 @@ int gsgen_densify_update_batch(uint32_t n_views, uint32_t N, const float *const 
 // the projection of every view in one launch
 int gsgen_internal_frame_project_views(uint32_t N, const float *mean, const float *qvec, const float *svec,
                                        int w, int h, int ntw, const GeoView *host_views, GeoView *dev_views,
-                                       uint32_t B, gsgen_stream_t stream) {
+                                       uint32_t B, float *zero_shared, size_t zero_shared_floats, gsgen_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   const uint32_t gx = N ? grid_for(N).x : 1u;  // (N == 0: one workgroup per view, for the table alone)
   for (uint32_t b0 = 0; b0 < B; b0 += kViewPack) {
     GeoViewPack pack{};
     const uint32_t n = (B - b0) < (uint32_t)kViewPack ? (B - b0) : (uint32_t)kViewPack;
     for (uint32_t i = 0; i < n; ++i) pack.v[i] = host_views[b0 + i];
+    // (the shared block is zeroed by the first launch of the batch; zero_shared_floats is a multiple of 4, checked by the caller)
     hipLaunchKernelGGL(k_frame_project_views, dim3(gx, n), dim3(kThreads), 0, s, N, mean, qvec, svec, w, h, ntw, pack,
-                       dev_views + b0);
+                       dev_views + b0, b0 == 0 ? reinterpret_cast<float4 *>(zero_shared) : (float4 *)nullptr,
+                       (uint32_t)(zero_shared_floats / 4));
   }
   return (int)hipGetLastError();
 }

@@ -188,6 +188,17 @@ int gsgen_project_gaussians_backward_batch(uint32_t n_views, uint32_t N, const f
  * conf/base.yaml:8-11) over one flat fp32 vector that holds every parameter field back to back,
  * in place.  group_end[k] (HOST array, ascending, last == n) closes parameter group k, group_lr[k]
  * (HOST) is its learning rate for this step; step counts from 1.  At most 8 groups. */
+/* gsgen_project_gaussians_backward_batch behind the fused RGB + heads compositing (gsgen_vol_render_rgbd_backward_batch): takes
+ * each view's channel gradients g_chan6[v] [N,6] = d L / d (r, g, b, depth, 1, depth^2) and its depths depth[v] [N] and forms
+ * d L / d depth = g3 + 2 depth g5 itself (the depth head and the depth^2 head, gs/gaussian_splatting.py:1334-1403), and writes
+ * the colour gradient g_color [N,3] = sum over the views of g_chan6[v][:, 0:3] in the same pass -- the two torch kernels the
+ * caller ran between the compositing backward and the projection backward.  Rows a view's mask excludes contribute nothing. */
+int gsgen_project_gaussians_backward_batch_heads(uint32_t n_views, uint32_t N, const float *mean, const float *qvec,
+                                                 const float *svec, const float *const *c2w, int detach_depth,
+                                                 const uint8_t *const *mask, const float *const *g_mean2d,
+                                                 const float *const *g_cov2d, const float *const *g_chan6,
+                                                 const float *const *depth, float *g_mean, float *g_qvec, float *g_svec,
+                                                 float *g_color, gsgen_stream_t stream);
 int gsgen_adam_step(uint64_t n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
                     uint32_t n_groups, const uint64_t *group_end, const float *group_lr, float beta1,
                     float beta2, float eps, uint32_t step, gsgen_stream_t stream);
@@ -287,11 +298,23 @@ typedef struct gsgen_geometry_view {
   void *workspace;
   size_t workspace_bytes;
   uint32_t D_cap;
+  /* optional (NULL = leave alone): this view's gradient accumulators of the step's backward -- d L / d mean2d [N,2] (8-byte
+   * aligned), d L / d cov2d [N,2,2] (16-byte aligned), d L / d (r, g, b, depth, 1, depth^2) [N,6] (8-byte aligned) -- ZERO-FILLED
+   * by the projection launch, which writes a record per Gaussian of the view anyway: the compositing backward kernels
+   * accumulate into caller-zeroed arrays (as the reference's, vol_render.h:866-992), and the fill between forward and
+   * backward was a launch of its own in every step's chain */
+  float *zero_grad_mean2d, *zero_grad_cov2d, *zero_grad_chan6;
 } gsgen_geometry_view;
 size_t gsgen_frame_batch_workspace_bytes(uint32_t n_views);
 int gsgen_frame_geometry_batch(uint32_t n_views, const gsgen_geometry_view *views, uint32_t N, const float *mean,
                                const float *qvec, const float *svec, uint32_t W, uint32_t H,
                                void *batch_workspace, gsgen_stream_t stream);
+/* The same, and the launch also zero-fills `zero_shared` (zero_shared_floats floats: a multiple of 4, 16-byte aligned; 0 = none):
+ * the gradient accumulators the views of the batch SHARE (d L / d alpha [N] and d L / d sh [N,3,C*C] or d L / d colour, laid out
+ * back to back by the caller).  With the per-view targets above no fill kernel is left between a step's forward and backward. */
+int gsgen_frame_geometry_batch_zero(uint32_t n_views, const gsgen_geometry_view *views, uint32_t N, const float *mean,
+                                    const float *qvec, const float *svec, uint32_t W, uint32_t H, float *zero_shared,
+                                    size_t zero_shared_floats, void *batch_workspace, gsgen_stream_t stream);
 
 /* Launch order for the compositing kernels produced by gsgen_frame_geometry: a device array
  * of n_tiles tile indices, longest list first (pointer into `workspace`; pure host arithmetic).
@@ -354,7 +377,9 @@ int gsgen_vol_render_backward_sh_segmented(uint32_t N, uint32_t D, const float *
  * gsgen_vol_render_sh_segmented / gsgen_vol_render_backward_sh_segmented on the same inputs
  * (gradient sums up to fp32 atomic order).  `views` is HOST memory, read before the call returns.
  * batch_workspace: device, gsgen_sh_batch_workspace_bytes(n_views) bytes, one per batch in flight
- * (it carries the per-view kernel parameters from the forward launch to the end of the backward). */
+ * (it carries the per-view kernel parameters from the forward launch to the end of the backward).
+ * The batched forward writes EVERY pixel of out / T: empty tiles receive bg_rgb (0 without one) and T = 1, so the caller
+ * need not pre-initialise the images (the per-camera entry points keep the reference's contract, vol_render.h:1006-1013). */
 typedef struct gsgen_sh_view {
   const float *mean, *cov;                 /* [N,2], [N,2,2] of this view */
   const int *start, *end, *gaussian_ids;   /* [n_tiles], [n_tiles], [D] */
@@ -475,6 +500,8 @@ typedef struct gsgen_rgbd_view {
    * autograd engine delivers them (one tensor per output; any may be NULL = zero) -- no [H,W,6] image to assemble */
   const float *grad_rgb, *grad_depth, *grad_opacity, *grad_depth2;
 } gsgen_rgbd_view;
+/* The batched forwards (rgbd and rgb) write EVERY pixel of out6 / T, empty tiles included (channels 0, T = 1): the caller need
+ * not pre-initialise the images (the per-camera entry points above keep the reference's contract: empty tiles are left alone). */
 int gsgen_vol_render_rgbd_batch(uint32_t n_views, const gsgen_rgbd_view *views, uint32_t N, const float *color,
                                 const float *alpha, uint32_t tile_size, uint32_t n_tiles_h, uint32_t n_tiles_w,
                                 uint32_t H, uint32_t W, float thresh, void *batch_workspace,

@@ -42,3 +42,18 @@ def _apply_test_variants():
 
 
 _apply_test_variants()
+
+
+def pytest_terminal_summary(terminalreporter):
+    """what the parity helpers observed (tests/scenes.py: PARITY_LOG), whatever the capture mode: per frame the largest pixel
+    error against the oracle and the number of pixels that needed the threshold-adjacent exception"""
+    try:
+        import scenes
+    except Exception:
+        return
+    if scenes.PARITY_LOG:
+        n_exc = sum(int(line.rsplit("= ", 1)[1]) for line in scenes.PARITY_LOG)
+        terminalreporter.write_sep("-", f"image parity: {len(scenes.PARITY_LOG)} frames against the oracle, "
+                                        f"{n_exc} threshold-adjacent exception pixels in total")
+        for line in scenes.PARITY_LOG[:200]:
+            terminalreporter.write_line("[parity] " + line)

@@ -364,6 +364,90 @@ def test_emulated_batched_frame_geometry_equals_per_view(emu):
     emu.frame_geometry_batch(0, arr, N, P(sc["mean"]), P(sc["qvec"]), P(sc["svec"]), W, H, None, None)
 
 
+def test_emulated_frame_geometry_batch_zero_fills_the_gradient_accumulators(emu):
+    """gsgen_frame_geometry_batch_zero: the projection launch zero-fills the per-view gradient blocks named in the view table
+    and the shared block, and leaves every geometry output exactly as gsgen_frame_geometry_batch does (round 4: no fill kernel
+    between a step's forward and backward)"""
+    from gsgen_amd import renderer as R
+    from gsgen_amd._capi import GeometryView
+    W, H, B = 64, 48, 3
+    sc = scenes.random_scene(700, seed=5, svec=0.05, spread=1.2)
+    N = sc["mean"].shape[0]
+    cams = [scenes.Camera(W, H, fx=60.0 + 5 * i, c2w=scenes.orbit(2.2, 10.0 + 20 * i, 40.0 * i)) for i in range(B)]
+    T = cams[0].tiles[0] * cams[0].tiles[1]
+    cap = max(scenes.oracle_geometry(sc, c)["D"] for c in cams) + 5
+
+    def fresh():
+        return dict(m2=np.zeros((N, 2), np.float32), c2=np.zeros((N, 4), np.float32), dep=np.zeros(N, np.float32),
+                    mask=np.zeros(N, np.uint8), ids=np.full(cap, -7, np.int32), st=np.zeros(T, np.int32),
+                    en=np.zeros(T, np.int32), tot=np.zeros(1, np.uint32), ws=np.zeros(emu.frame_workspace_bytes(N, cap, T), np.uint8))
+    camv = [np.ascontiguousarray(R.CameraInfo(*c.intr).pack(c.c2w)) for c in cams]
+
+    def table(bufs):
+        arr = (GeometryView * B)()
+        for a, cv, g in zip(arr, camv, bufs):
+            a.cam, a.mean2d, a.cov2d, a.depth, a.mask = P(cv), P(g["m2"]), P(g["c2"]), P(g["dep"]), P(g["mask"])
+            a.gaussian_ids, a.start, a.end, a.total = P(g["ids"]), P(g["st"]), P(g["en"]), P(g["tot"])
+            a.workspace, a.workspace_bytes, a.D_cap = P(g["ws"]), g["ws"].size, cap
+        return arr
+    ref, got = [fresh() for _ in range(B)], [fresh() for _ in range(B)]
+    bws = np.zeros(emu.frame_batch_workspace_bytes(B), np.uint8)
+    emu.frame_geometry_batch(B, table(ref), N, P(sc["mean"]), P(sc["qvec"]), P(sc["svec"]), W, H, P(bws), None)
+    arr = table(got)
+    gm = [np.full((N, 2), 7.0, np.float32) for _ in range(B)]
+    gc = [np.full((N, 4), 7.0, np.float32) for _ in range(B)]
+    gch = [np.full((N, 6), 7.0, np.float32) for _ in range(B)]
+    for i, a in enumerate(arr):
+        a.zero_grad_mean2d, a.zero_grad_cov2d = P(gm[i]), P(gc[i])
+        if i != 1:
+            a.zero_grad_chan6 = P(gch[i])   # view 1 names no channel block: left alone
+    shared = np.full(N * 49 + 8, 7.0, np.float32)
+    nz = (N * 49 + 3) // 4 * 4
+    emu.frame_geometry_batch_zero(B, arr, N, P(sc["mean"]), P(sc["qvec"]), P(sc["svec"]), W, H, P(shared), nz, P(bws), None)
+    for i, (r, g) in enumerate(zip(ref, got)):
+        for k in ("m2", "c2", "dep", "mask", "ids", "st", "en", "tot", "ws"):
+            assert np.array_equal(r[k], g[k]), (i, k)
+        assert not gm[i].any() and not gc[i].any()
+        assert (not gch[i].any()) if i != 1 else (gch[i] == 7.0).all()
+    assert not shared[:nz].any() and (shared[nz:] == 7.0).all()
+    with pytest.raises(Exception, match="invalid"):   # the shared block is zeroed as float4s
+        emu.frame_geometry_batch_zero(B, arr, N, P(sc["mean"]), P(sc["qvec"]), P(sc["svec"]), W, H, P(shared), nz - 1, P(bws), None)
+
+
+def test_emulated_projection_backward_folds_the_heads(emu):
+    """gsgen_project_gaussians_backward_batch_heads == gsgen_project_gaussians_backward_batch fed d L / d depth =
+    g3 + 2 depth g5 (the depth and depth^2 heads, gs/gaussian_splatting.py:1334-1403), plus the colour gradient summed
+    over the views -- the two torch kernels BatchRenderer ran between the two backward launches until round 3"""
+    import ctypes as C
+    from gsgen_amd import renderer as R
+    rng = np.random.default_rng(3)
+    sc = scenes.random_scene(500, seed=9, svec=0.05)
+    N, B = sc["mean"].shape[0], 3
+    cams = [scenes.Camera(64, 48, fx=60.0, c2w=scenes.orbit(2.3, 15.0 * i, 50.0 * i)) for i in range(B)]
+    camv = [np.ascontiguousarray(R.CameraInfo(*c.intr).pack(c.c2w)) for c in cams]
+    masks = [(rng.uniform(size=N) > 0.2).astype(np.uint8) for _ in range(B)]
+    g2 = [rng.normal(size=(N, 2)).astype(np.float32) for _ in range(B)]
+    gc = [rng.normal(size=(N, 4)).astype(np.float32) for _ in range(B)]
+    gch = [(rng.normal(size=(N, 6)) * m[:, None]).astype(np.float32) for m in masks]  # (rows a view never saw hold zeros)
+    dep = [rng.uniform(1.5, 3.5, N).astype(np.float32) for _ in range(B)]
+    gd = [np.ascontiguousarray(c[:, 3] + np.float32(2.0) * d * c[:, 5]) for c, d in zip(gch, dep)]
+    tab = lambda xs: (C.c_void_p * B)(*[x.ctypes.data for x in xs])  # noqa: E731
+    out = {k: [np.zeros((N, n), np.float32) for n in (3, 4, 3)] for k in ("ref", "got")}
+    for detach in (1, 0):
+        emu.project_gaussians_backward_batch(B, N, P(sc["mean"]), P(sc["qvec"]), P(sc["svec"]), tab(camv), detach, tab(masks),
+                                             tab(g2), tab(gc), tab(gd), *[P(a) for a in out["ref"]], None)
+        gcol = np.full((N, 3), 5.0, np.float32)
+        emu.project_gaussians_backward_batch_heads(B, N, P(sc["mean"]), P(sc["qvec"]), P(sc["svec"]), tab(camv), detach, tab(masks),
+                                                   tab(g2), tab(gc), tab(gch), tab(dep), *[P(a) for a in out["got"]], P(gcol), None)
+        for a, b in zip(out["ref"], out["got"]):
+            assert np.abs(a).max() > 0 and np.abs(a - b).max() <= 1e-6 * np.abs(a).max()
+        want = sum(c[:, :3].astype(np.float64) for c in gch)
+        assert np.abs(gcol - want).max() <= 1e-6 * np.abs(want).max()
+    with pytest.raises(Exception, match="invalid"):
+        emu.project_gaussians_backward_batch_heads(B, N, P(sc["mean"]), P(sc["qvec"]), P(sc["svec"]), tab(camv), 1, tab(masks), tab(g2),
+                                                   tab(gc), tab(gch), None, *[P(a) for a in out["got"]], P(gcol), None)
+
+
 def test_emulated_batched_frame_geometry_more_views_than_one_argument_pack(emu):
     """ten views: the per-view pointer table travels in the projection launch's ARGUMENTS eight views at a time (two
     projection launches, one table in device memory for the binning launches behind them) -- every view as its own call"""
@@ -562,7 +646,8 @@ def test_emulated_batched_rgb_heads_match_per_view_launches(emu):
     arr = (RgbdView * len(views))()
     for a, v in zip(arr, views):
         cam = v["cam"]
-        v["out"] = np.zeros((H, W, 6), np.float32); v["T"] = np.ones((H, W), np.float32)
+        # (the batched forward writes every pixel, empty tiles included: no pre-initialised images -- round 4)
+        v["out"] = np.full((H, W, 6), 9.0, np.float32); v["T"] = np.full((H, W), 9.0, np.float32)
         v["gm"] = np.zeros((Nall, 2), np.float32); v["gc"] = np.zeros((Nall, 4), np.float32); v["gch"] = np.zeros((Nall, 6), np.float32)
         a.mean, a.cov, a.depth, a.start, a.end, a.gaussian_ids = P(v["m2"]), P(v["c2"]), P(v["dv"]), P(v["st"]), P(v["en"]), P(v["ids"])
         a.tile_order, a.topleft, a.pixel_size_x, a.pixel_size_y = None, P(v["tlp"]), 1 / cam.fx, 1 / cam.fy

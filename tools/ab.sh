@@ -6,7 +6,7 @@ for v in "$@"; do
   echo "== $v" >> gpurun_out/ab.log
   envs=""; args=""
   for w in $v; do case "$w" in *=*) if [ -z "$args" ] && [[ "$w" != --* ]]; then envs="$envs $w"; else args="$args $w"; fi;; --) ;; *) args="$args $w";; esac; done
-  env $envs timeout 200 python bench.py --steps 40 --warmup 10 --no-latency --no-surface --no-cpu-baseline $args 2>/dev/null | python -c "
+  env $envs timeout 200 python bench.py --steps 40 --warmup 10 --no-latency --no-surface --no-cpu-baseline --no-heads $args 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
