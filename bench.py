@@ -40,7 +40,9 @@ WORKLOADS = {
     "cfg3": "BASELINE configs[2]: 500k post-densify Gaussians, 1024x1024, SH degree 3, fwd+bwd",
     "cfg4": "BASELINE configs[3]: 100k Gaussians, 64 random-pose cameras at 512x512, camera-sharded",
     "cfg1": "BASELINE configs[0]: 1k random Gaussians, 256x256, SH degree 0",
-    "dry": "dry run of the multi-rank step loop: 300 random Gaussians, 64x48, SH degree 3 (no measurement)",
+    "dry": "dry run of the multi-rank step loop: 60 random Gaussians, 40x24, SH degree 3 (no measurement)",
+    "dry4": "dry run of the multi-rank step loop on cfg4's camera split: 64 random poses sharded over the ranks, 60 random "
+            "Gaussians, 40x24, SH degree 3 (no measurement)",
 }
 
 
@@ -54,14 +56,14 @@ def make_workload(name):
         return scenes.pointe_scene(100_000, seed=0, svec=0.02, C=4), 512, 512
     if name == "cfg1":
         return scenes.random_scene(1000, seed=0, C=1), 256, 256
-    if name == "dry":  # the multi-rank dry run (tests/test_dist_gloo.py): a few hundred splats, SH degree 3
+    if name in ("dry", "dry4"):  # the multi-rank dry run (tests/test_dist_gloo.py): a few dozen splats, SH degree 3
         sc = scenes.random_scene(60, seed=0, svec=0.006, spread=0.03, C=4)
         sc["sh"][:, :, 1:] *= 0.3
         return sc, 40, 24
     raise SystemExit(f"unknown config {name}")
 
 
-def random_pose_cameras(n_total, rank, world, W, H, seed=0):
+def random_pose_cameras(n_total, rank, world, W, H, seed=0, zoom=1.0):
     """cfg4: poses sampled like CameraPoseProvider.sample_one (data/__init__.py:151-205): distance
     U(2, 2.5), elevation arcsin-uniform in [-20, 90] deg, azimuth U(-180, 180), focal U(0.7, 1.35) x reso;
     the 64-camera batch is split contiguously over the ranks (gsgen_amd.dist.shard_bounds)."""
@@ -72,7 +74,7 @@ def random_pose_cameras(n_total, rank, world, W, H, seed=0):
     lo, hi = np.sin(np.deg2rad(-20.0)), np.sin(np.deg2rad(90.0))
     elev = np.rad2deg(np.arcsin(rng.uniform(lo, hi, n_total)))
     azim = rng.uniform(-180.0, 180.0, n_total)
-    focal = rng.uniform(0.7, 1.35, n_total) * W
+    focal = rng.uniform(0.7, 1.35, n_total) * W * zoom
     a, b = shard_bounds(n_total, rank, world)
     return [scenes.Camera(W, H, fx=float(focal[i]), c2w=scenes.orbit(float(dist_[i]), float(min(elev[i], 89.0)), float(azim[i])))
             for i in range(a, b)]
@@ -350,9 +352,10 @@ def main():
     ap.add_argument("--no-latency", action="store_true", help="skip the one-render-in-flight and hipGraph passes")
     args = ap.parse_args()
     dry = args.dry_run_lib is not None
-    if dry:
-        args.only_timed, args.config = True, "dry"
-        args.batch, args.slots = args.batch or 2, args.slots or 2
+    if dry:  # (--config cfg4: the 64-pose camera split of BASELINE configs[3] over the ranks, 8 cameras per step)
+        cfg4_split = args.config == "cfg4"
+        args.only_timed, args.config = True, ("dry4" if cfg4_split else "dry")
+        args.batch, args.slots = args.batch or (8 if cfg4_split else 2), args.slots or 2
     if args.only_timed:
         args.no_surface = args.no_latency = args.no_cpu_baseline = args.no_heads = True
 
@@ -408,7 +411,8 @@ def main():
     # (< 5.2 M pairs: the 512^2 views of cfg4, cfg3's pairs of cameras) overlap better three deep than two
     # (cfg4: 6 988 vs 6 661 renders/s; cfg2, 5.7 M pairs per launch: 3 372 vs 3 368)
     zoom = 12.0 if dry else 1.0  # (the dry run's few splats sit in a narrow view: the routed kernels take their polynomial form)
-    probe_cam = (random_pose_cameras(64, rank, world, W, H) if args.config == "cfg4" else camera_poses(1, rank, W, H, zoom))[0]
+    pose_split = args.config in ("cfg4", "dry4")
+    probe_cam = (random_pose_cameras(64, rank, world, W, H, zoom=zoom) if pose_split else camera_poses(1, rank, W, H, zoom))[0]
     pb = R.FrameBuffers(N, W, H, dev)
     tp = {k: torch.tensor(sc[k], device=dev) for k in ("mean", "qvec", "svec")}
     probe_block = torch.from_numpy(R.CameraInfo(*probe_cam.intr).pack(probe_cam.c2w)).to(dev)
@@ -423,7 +427,7 @@ def main():
         bt = torch.tensor([B, auto_slots], device=dev)
         dist.broadcast(bt, 0)
         B, auto_slots = int(bt[0].item()), int(bt[1].item())
-    cams = random_pose_cameras(64, rank, world, W, H) if args.config == "cfg4" else camera_poses(B if dry else max(8, B), rank, W, H, zoom)
+    cams = random_pose_cameras(64, rank, world, W, H, zoom=zoom) if pose_split else camera_poses(B if dry else max(8, B), rank, W, H, zoom)
     ncam = len(cams)
     cis = [R.CameraInfo(*c.intr) for c in cams]
     nth, ntw = R.n_tiles(H, W)
@@ -766,7 +770,7 @@ def main():
 
     # ---- multi-GPU: the same timed region WITHOUT the per-step all_gather (compute scaling and xGMI cost separate) ------------
     no_gather = None
-    if dist is not None and state["gather"] and not dry:
+    if dist is not None and state["gather"]:
         state["gather"] = False
         barrier()
         ng = [region(args.warmup + r * K) for r in range(min(3, n_rep))]

@@ -190,14 +190,50 @@ def tile_based_vol_rendering_scalar_backward(mean, cov, scalar, alpha, start, en
             float(pixel_size_x), float(pixel_size_y), int(H), int(W), float(thresh), _stream(mean))
 
 
-def _sh_bound(sh_coeffs, C, tile_size):
+# The reference's SH entry points have no argument that could say which form of the per-pixel SH basis to use, so the choice is a
+# module-level switch ("SH basis"):  "auto" (default) -- SH degree 3 launches measure the coefficient bound on the
+# device and route on it (tile-local polynomial form of the basis where its error bound holds: images within 1.4e-5 of the exact
+# kernels', i.e. inside the 1e-4 contract); "exact" -- the reference's per-pixel basis (vol_render_sh.h:48-65), always.
+SH_BASIS = "auto"
+
+
+def set_sh_basis(mode):
+    """'auto' | 'exact' for every later tile_based_vol_rendering_sh* call of this module"""
+    global SH_BASIS
+    if mode not in ("auto", "exact"):
+        raise ValueError("SH basis: 'auto' or 'exact'")
+    SH_BASIS = mode
+    _bound_cache.clear()
+
+
+def get_sh_basis():
+    return SH_BASIS
+
+
+# forward -> backward: the bound a forward measured, keyed on the coefficient tensor's storage and version counter -- the
+# matching backward routes on the SAME device value (and skips its own pass); coefficients modified in place in between
+# (another version) are measured again
+_bound_cache = {}
+
+
+def _sh_bound(sh_coeffs, C, tile_size, reuse=False):
     """SH degree 3: S = max sum_{k >= 1} |sh| of the call's coefficients, measured on the device in front of the launch (one
     5-us pass, no sync) into a scratch float; the kernels route on it -- the tile-local polynomial form of the per-pixel basis
-    where its error bound holds, the exact kernel elsewhere (include/gsgen_hip.h, "the coefficient bound").  None otherwise."""
-    if int(C) != 4 or int(tile_size) != 16 or sh_coeffs.numel() == 0:
+    where its error bound holds, the exact kernel elsewhere (include/gsgen_hip.h, "the coefficient bound").  None otherwise,
+    and with SH_BASIS == "exact".  reuse: the backward of a frame takes the bound its forward left for these coefficients."""
+    if SH_BASIS == "exact" or int(C) != 4 or int(tile_size) != 16 or sh_coeffs.numel() == 0:
         return None
+    key = (sh_coeffs.device, sh_coeffs.data_ptr(), sh_coeffs.numel())
+    ver = sh_coeffs._version
+    if reuse:
+        hit = _bound_cache.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
     bound = torch.empty(1, device=sh_coeffs.device, dtype=torch.float32)
     _load().sh_l1_bound(sh_coeffs.numel() // 48, _p(sh_coeffs), 4, _p(bound), _stream(sh_coeffs))
+    if len(_bound_cache) > 64:
+        _bound_cache.clear()
+    _bound_cache[key] = (ver, bound)
     return bound
 
 
@@ -231,7 +267,7 @@ def _sh_bwd(mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out, grad_mea
     if int(C) < 1 or int(C) > 4:
         return
     with _guard(mean):
-        bound = _sh_bound(sh_coeffs, C, tile_size)  # the same coefficients: the same routing as the frame's forward
+        bound = _sh_bound(sh_coeffs, C, tile_size, reuse=True)  # the forward's own device value: the same routing
         _load().vol_render_backward_sh_bounded(
             mean.size(0), gaussian_ids.size(0), _p(mean), _p(cov), _p(sh_coeffs), _p(alpha), _p(start),
             _p(end), _p(gaussian_ids), _p(out), _p(grad_mean), _p(grad_cov), _p(grad_sh_coeffs),

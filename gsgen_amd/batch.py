@@ -33,6 +33,23 @@ def _bg_grad(ctx, grad_rgb, T):
     return torch.nan_to_num(grad_rgb * T).sum_to_size(ctx.bg_shape)
 
 
+class _NoGuard:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def _on(dev):
+    """`with _on(dev):` = torch.cuda.device(dev), free when dev is already the current device (the context manager costs
+    ~5 us per use; a step of the fused path entered it four times)"""
+    return _NO_GUARD if torch.cuda.current_device() == dev.index else torch.cuda.device(dev)
+
+
 def _tab(addresses):
     """host array of device pointers for the *_batch entry points"""
     return (ctypes.c_void_p * len(addresses))(*addresses)
@@ -121,7 +138,7 @@ class _render_batch(torch.autograd.Function):
         # zeroed by this forward's projection launch
         gsh = torch.empty(br._Np + (col.numel() + 3) // 4 * 4, device=dev, dtype=torch.float32)
         nb_sh = br._nb_sh
-        with torch.cuda.device(dev):
+        with _on(dev):
             lib.frame_geometry_batch_zero(B, geo, N, _p(mean), _p(qvec), _p(svec), W, H, _p(gsh), gsh.numel(),
                                           _p(br._bws) + nb_sh, s)
             br._end_batch(B)
@@ -171,7 +188,7 @@ class _render_batch(torch.autograd.Function):
         else:
             for i in range(B):
                 views[i].grad_out6 = grad_p + 12 * H * W * i
-        with torch.cuda.device(dev):
+        with _on(dev):
             if C > 0:
                 lib.vol_render_backward_sh_batch_bounded(B, views, N, _p(col), _p(alpha), _p(g_col), _p(g_alpha), 16,
                                                          br.slots[0].nth, br.slots[0].ntw, H, W, C, thresh, br.segments,
@@ -261,7 +278,7 @@ class _render_batch_heads(torch.autograd.Function):
                 v.pixel_size_x, v.pixel_size_y = 1.0 / ci.fx, 1.0 / ci.fy
                 v.out6, v.T = out_p + 24 * H * W * i, T_p + 4 * H * W * i
             gsh = torch.empty(br._Np, device=dev, dtype=torch.float32)  # d L / d alpha, shared by the views
-            with torch.cuda.device(dev):
+            with _on(dev):
                 lib.frame_geometry_batch_zero(B, geo, N, _p(mean), _p(qvec), _p(svec), W, H, _p(gsh), gsh.numel(),
                                               _p(br._bws) + br._nb_sh, s)
                 br._end_batch(B)
@@ -334,7 +351,7 @@ class _render_batch_heads(torch.autograd.Function):
             v.grad_depth = pp[1] + 4 * H * W * i if pp[1] is not None else None
             v.grad_opacity = pp[2] + 4 * H * W * i if pp[2] is not None else None
             v.grad_depth2 = pp[3] + 4 * H * W * i if pp[3] is not None else None
-        with torch.cuda.device(dev):
+        with _on(dev):
             lib.vol_render_rgbd_backward_batch(B, views, N, _p(col), _p(alpha), _p(g_alpha), 16, br.slots[0].nth,
                                                br.slots[0].ntw, H, W, thresh, _p(br._bws), s)
             lib.project_gaussians_backward_batch_heads(B, N, _p(mean), _p(qvec), _p(svec), br._ptr_table("cam", B),
@@ -411,6 +428,9 @@ class BatchRenderer:
         # without a sync, see FrameBuffers.check_overflow)
         self._totals = torch.zeros(max_batch, device=device, dtype=torch.int32)
         self._monitor = R.PairCountMonitor(max_batch)
+        # pair counts follow every `monitor_every`-th batch to the host (an async copy + an event each: ~25 us of host time;
+        # an overflowing scene overflows in the following batches too, so sampling delays the report by a few batches)
+        self.monitor_every, self._tick = 4, 0
         self._generation = 0
         self._sh_bound = None
         self._table_cache = {}
@@ -432,6 +452,7 @@ class BatchRenderer:
         self._nb_sh = lib.sh_batch_workspace_bytes(max_batch)
         self._bws = torch.empty(self._nb_sh + lib.frame_batch_workspace_bytes(max_batch), device=device, dtype=torch.uint8)
         self._g2d = torch.empty(max_batch, 12 * self._Np, device=device, dtype=torch.float32)
+        self._bound = torch.zeros(1, device=device, dtype=torch.float32)  # S of the batch in flight (gsgen_sh_l1_bound)
         # per camera: cam block (56) | topleft (2) | rotation rows (9) | pad -> 68 floats, packed on the host and sent
         # through kernel arguments (gsgen_upload_small): no pinned ring, no copy event, the host never waits
         self._host = np.zeros((max_batch, 68), np.float32)
@@ -445,10 +466,15 @@ class BatchRenderer:
         camera: a tenth of a 4 x 512^2 step.)"""
         B = len(cam_infos)
         poses, intr, h = self._poses, self._intr, self._host
-        for i, (ci, c2w) in enumerate(zip(cam_infos, c2ws)):
-            if isinstance(c2w, torch.Tensor):
-                c2w = c2w.detach().cpu().numpy()
-            poses[i] = np.asarray(c2w, np.float32).reshape(-1)[:12]
+        if isinstance(c2ws, np.ndarray) and c2ws.ndim == 3:  # poses already stacked: [B, 3 or 4, 4]
+            poses[:B] = c2ws[:, :3, :4].reshape(B, 12)
+        else:
+            for i, c2w in enumerate(c2ws):
+                if isinstance(c2w, torch.Tensor):
+                    c2w = c2w.detach().cpu().numpy()
+                poses[i] = c2w.ravel()[:12] if (type(c2w) is np.ndarray and c2w.dtype == np.float32) else \
+                    np.asarray(c2w, np.float32).reshape(-1)[:12]
+        for i, ci in enumerate(cam_infos):
             intr[i] = (ci.fx, ci.fy, ci.cx, ci.cy, ci.w, ci.h, ci.near_plane, ci.far_plane)
         lib = _capi.load()
         lib.pack_camera_blocks(B, poses.ctypes.data, 12, intr.ctypes.data, frustum_radius, tile_radius, h.ctypes.data)
@@ -537,7 +563,9 @@ class BatchRenderer:
     def _end_batch(self, B):
         """behind the geometry enqueue: the batch's pair counts follow it to the host (one async copy, one event, into
         the monitor's ring: no batch's counts are ever dropped unread)"""
-        self._monitor.record(self._totals, B, torch.cuda.current_stream(self.device))
+        self._tick += 1
+        if self._tick % self.monitor_every == 1 or self.monitor_every <= 1:
+            self._monitor.record(self._totals, B, torch.cuda.current_stream(self.device))
 
     def _check_generation(self, gen):
         if gen != self._generation:
@@ -552,6 +580,8 @@ class BatchRenderer:
         background only, with zero gradients)."""
         ok = True
         worst = {}
+        if not self._monitor.has_news():
+            return ok
         for counts in self._monitor.drain():
             for i, need in enumerate(counts):
                 worst[i] = max(worst.get(i, 0), need)
@@ -597,7 +627,7 @@ class BatchRenderer:
         the tile-local polynomial form of the per-pixel SH basis where 0.25 S 0.7 delta^3 <= 1e-5, the exact kernel elsewhere
         (include/gsgen_hip.h "the coefficient bound"; images within 1e-5 of the exact kernels, +20 % renders/s at 8 x 800^2).
         "exact": the exact kernels only.  sh_l1_bound: a 1-float DEVICE tensor that already holds S for THESE coefficients
-        (e.g. FusedAdam.sh_l1_bound, produced by the optimiser step that wrote them) -- skips the pass; verify_bound=True
+        (e.g. renderer.sh_l1_bound_device(sh) evaluated once for several batches of one optimiser step) -- skips the pass; verify_bound=True
         checks such a tensor on the device first (debug: one host sync, raises if any row exceeds it).
         """
         if sh_basis not in ("auto", "exact"):
@@ -621,9 +651,18 @@ class BatchRenderer:
                     R.verify_sh_l1_bound(col, sh_l1_bound)
                 self._sh_bound = sh_l1_bound
             else:
-                self._sh_bound = R.sh_l1_bound_device(col)
+                self._sh_bound = self._measure_bound(col)
         return _render_batch.apply(mean, qvec, svec, alpha, col, cams, self, B, int(C), bg_rgb, float(thresh),
                                    bool(detach_depth), stats)
+
+    def _measure_bound(self, col):
+        """renderer.sh_l1_bound_device into the renderer's own float (read by this batch's forward and backward only)"""
+        if col.dim() != 3 or col.shape[1] != 3 or col.shape[2] != 16 or col.dtype != torch.float32 or not col.is_contiguous():
+            return R.sh_l1_bound_device(col)  # (other layouts: the checked path)
+        with _on(self.device):
+            _capi.load().sh_l1_bound(col.shape[0], col.data_ptr(), 4, self._bound.data_ptr(),
+                                     torch.cuda.current_stream(self.device).cuda_stream)
+        return self._bound
 
     def render_heads(self, mean, qvec, svec, alpha, color, cam_infos, c2ws, bg_rgb=None, thresh=1e-4,
                      frustum_radius=6.0, tile_radius=6.0, detach_depth=True, stats=None):

@@ -380,7 +380,8 @@ __device__ __forceinline__ void long_pass(u64 *__restrict__ k, uint32_t n, uint3
     for (int u = 0; u < 4; ++u)
       if (ib[u] != 0xffffffffu && a[u] > b[u]) { k[ia[u]] = b[u]; k[ib[u]] = a[u]; }
   }
-  __syncthreads();  // one wavefront: orders this pass's stores before the next pass's loads
+  wave_mem_fence();  // ONE wavefront runs these passes (the others of the workgroup may have left): orders this pass's stores
+                     // before the next pass's loads without a workgroup barrier
 }
 template <int K>
 __device__ __forceinline__ void sort_segment_long(u64 *__restrict__ keys, int *__restrict__ ids, uint32_t n) {
@@ -403,7 +404,7 @@ __device__ __forceinline__ void sort_segment_long(u64 *__restrict__ keys, int *_
     for (int r = 0; r < K; ++r)
       if (e0 + r < n) keys[e0 + r] = k[r];
   }
-  __syncthreads();
+  wave_mem_fence();
   uint32_t p2 = kBlock;
   while (p2 < n) p2 <<= 1;
   for (uint32_t size = 2u * kBlock; size <= p2; size <<= 1) {
@@ -424,7 +425,7 @@ __device__ __forceinline__ void sort_segment_long(u64 *__restrict__ keys, int *_
         }
       }
     }
-    __syncthreads();
+    wave_mem_fence();
   }
 }
 

@@ -45,6 +45,19 @@ __device__ __forceinline__ bool wave_any(bool pred) {
   return __ballot((int)pred) != 0ull;
 #endif
 }
+// Orders the memory operations (LDS and global) of THIS wavefront's lanes: what any lane stored before the call is visible to
+// every lane of the same wavefront after it.  No s_barrier: correct wherever only one wavefront is involved -- including code
+// that the other wavefronts of the workgroup have already LEFT (a __syncthreads() there relies on the hardware dropping
+// terminated wavefronts from the barrier count, which HIP's model does not promise).
+__device__ __forceinline__ void wave_mem_fence() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#else
+  (void)__ballot(1);  // (the CPU emulator runs lanes as fibers: a wave collective is its wave-level rendezvous)
+#endif
+}
 __device__ __forceinline__ float wave_uniform(float v) {
   return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
 }

@@ -1463,7 +1463,7 @@ k_composite_bwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
 // wavefronts per tile; with the lane's 4 pixels as two packed pairs, one wavefront per tile, the record in scalar
 // registers and one wave-uniform guard branch it is ~70 per tile and entry.  Same structure as k_composite_fwd_sh_vec.
 template <int MODE, bool BATCH = false>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5)))  // (98 -> 96 registers: five wavefronts per SIMD)
 k_composite_fwd_chan_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
   static_assert(MODE == MODE_RGB || MODE == MODE_SCALAR || MODE == MODE_RGBD, "post-activation channel modes");
   uint32_t bid = blockIdx.x;
@@ -1557,9 +1557,11 @@ k_composite_fwd_chan_vec(CompParams p_arg, const CompParams *__restrict__ plist)
         for (int k = 0; k < 2; ++k) {
           const bool con = alive(2 * jp + k) && !(ag2[jp][k] < kMinAlpha);
           G2[jp][k] = con ? G2[jp][k] : 0.0f;
-          ag2[jp][k] = con ? ag2[jp][k] : 0.0f;
           any_con |= con;
         }
+#pragma unroll
+      for (int jp = 0; jp < NP; ++jp) ag2[jp] = splat2(r_a) * G2[jp];  // the same products from the masked G (bit-identical where
+                                                                       // the pixel takes part, 0 elsewhere): no second select
       if (!wave_any(any_con)) continue;  // nobody in the wave sees this Gaussian
 
       const float *cg = &S.col[g * TR::NCOLP];
@@ -1603,7 +1605,7 @@ k_composite_fwd_chan_vec(CompParams p_arg, const CompParams *__restrict__ plist)
 // over four arrays per entry compiled to nested exec-mask branches and a flat atomic).
 // Reduction vector: channels [0, NCH) | pad to even | mean 2 | cov 4 | alpha 1.
 template <int MODE, bool BATCH = false>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5)))
 k_composite_bwd_chan_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
   static_assert(MODE == MODE_RGB || MODE == MODE_SCALAR || MODE == MODE_RGBD, "post-activation channel modes");
   uint32_t bid = blockIdx.x, grid = gridDim.x;
@@ -1705,9 +1707,11 @@ k_composite_bwd_chan_vec(CompParams p_arg, const CompParams *__restrict__ plist)
         for (int k = 0; k < 2; ++k) {
           const bool con = alive(2 * jp + k) && !(ag2[jp][k] < kMinAlpha);
           G2[jp][k] = con ? G2[jp][k] : 0.0f;
-          ag2[jp][k] = con ? ag2[jp][k] : 0.0f;
           any_con |= con;
         }
+#pragma unroll
+      for (int jp = 0; jp < NP; ++jp) ag2[jp] = splat2(r_a) * G2[jp];  // the same products from the masked G (bit-identical where
+                                                                       // the pixel takes part, 0 elsewhere): no second select
       if (!wave_any(any_con)) continue;  // nobody in the wave sees this Gaussian
 
       v2f gr2[P / 2];

@@ -143,13 +143,33 @@ void tile_based_vol_rendering_scalar_backward(Tensor mean, Tensor cov, Tensor sc
                                       n_tiles_w, pixel_size_x, pixel_size_y, H, W, thresh, c.stream));
 }
 
+// The reference's SH entry points cannot say which form of the per-pixel SH basis to use: a module-level switch
+// (set_sh_basis("auto" | "exact"), INTEGRATION.md "SH basis").  exact = the reference's per-pixel basis, always.
+bool g_sh_exact = false;
+// forward -> backward: the bound a forward measured for a coefficient tensor (storage + version counter); the matching backward
+// routes on the SAME device value and skips its own pass.  Coefficients modified in place in between are measured again.
+struct BoundCache {
+  const void *ptr = nullptr;
+  int64_t numel = 0;
+  uint32_t version = 0;
+  int device = -1;
+  Tensor bound;
+} g_bound;
+
 // S = max sum_{k >= 1} |sh| of the call's coefficients into a scratch float from torch's caching allocator (stream-ordered:
-// the block is reused only behind the launches that read it); nullptr = exact kernels (other degrees / tile sizes)
+// the block is reused only behind the launches that read it); nullptr = exact kernels (other degrees / tile sizes, or the switch)
 template <class C_>
-const float *sh_bound(const Tensor &sh_coeffs, uint32_t C, uint32_t tile_size, C_ &c) {
-  if (C != 4 || tile_size != 16 || sh_coeffs.numel() == 0) return nullptr;
+const float *sh_bound(const Tensor &sh_coeffs, uint32_t C, uint32_t tile_size, C_ &c, bool reuse = false) {
+  if (g_sh_exact || C != 4 || tile_size != 16 || sh_coeffs.numel() == 0) return nullptr;
+  const void *ptr = sh_coeffs.data_ptr();
+  const uint32_t ver = (uint32_t)sh_coeffs._version();
+  const int dev = (int)sh_coeffs.get_device();
+  if (reuse && g_bound.bound.defined() && g_bound.ptr == ptr && g_bound.numel == sh_coeffs.numel() && g_bound.version == ver &&
+      g_bound.device == dev)
+    return F(g_bound.bound);
   Tensor b = at::empty({1}, sh_coeffs.options());
   GS(gsgen_sh_l1_bound((uint32_t)(sh_coeffs.numel() / 48), F(sh_coeffs), C, Fm(b), c.stream));
+  g_bound.ptr = ptr; g_bound.numel = sh_coeffs.numel(); g_bound.version = ver; g_bound.device = dev; g_bound.bound = b;
   return F(b);
 }
 
@@ -178,8 +198,8 @@ void sh_backward(const Tensor &mean, const Tensor &cov, const Tensor &sh_coeffs,
   CHECK_F(grad_alpha); CHECK_F(grad_out);
   if (C < 1 || C > 4) return;
   Ctx c(mean);
-  // the same coefficients give the same bound, hence the same routing as this frame's forward
-  const float *bound = sh_bound(sh_coeffs, C, tile_size, c);
+  // the bound this frame's forward measured for these coefficients (same storage, same version): the same routing
+  const float *bound = sh_bound(sh_coeffs, C, tile_size, c, true);
   GS(gsgen_vol_render_backward_sh_bounded((uint32_t)mean.size(0), (uint32_t)gaussian_ids.size(0), F(mean), F(cov), F(sh_coeffs),
                                           F(alpha), I(start), I(end), I(gaussian_ids), F(out), Fm(grad_mean), Fm(grad_cov),
                                           Fm(grad_sh_coeffs), Fm(grad_alpha), F(grad_out), F(topleft), F(c2w), tile_size,
@@ -350,4 +370,10 @@ PYBIND11_MODULE(_gs, m) {
   m.def("tile_based_vol_rendering_start_end_with_T", &tile_based_vol_rendering_start_end_with_T,
         "Tile based volume rendering with start and end array, returning the transmittance");
   m.def("gsgen_version", []() { return std::string(gsgen_version()); }, "version of the HIP library underneath");
+  m.def("set_sh_basis", [](const std::string &mode) {
+    TORCH_CHECK(mode == "auto" || mode == "exact", "SH basis: 'auto' or 'exact'");
+    g_sh_exact = mode == "exact";
+    g_bound = BoundCache{};
+  }, "SH degree 3: 'auto' (default: device-routed polynomial / exact per-pixel basis) or 'exact' (the reference's basis, always)");
+  m.def("get_sh_basis", []() { return std::string(g_sh_exact ? "exact" : "auto"); });
 }

@@ -12,8 +12,8 @@ updated by the fused paths):
   prune (:1124-1177): by screen-space radius, by opacity, by 3-D scale; Adam moments follow (:421-449).
 
 With camera sharding every rank renders its own cameras, so the statistics differ per rank while the parameters are
-replicated.  `AdaptiveControl.step` first combines the statistics (dist.allreduce_densify_stats: every rank then holds
-the bits a single process would) and draws the split noise from a generator seeded by (seed, step): every rank takes
+replicated.  `AdaptiveControl.step` first combines the statistics (dist.reduce_densify_stats: all-reduced into
+temporaries, so that a prune-only step does not count an interval twice; every rank then holds the bits a single process would) and draws the split noise from a generator seeded by (seed, step): every rank takes
 the same decisions and writes the same new parameters -- no parameter broadcast.  Pure torch (any device): this is the
 caller-side bookkeeping around the HIP path, not a kernel.
 """

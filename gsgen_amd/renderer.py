@@ -203,12 +203,16 @@ def sh_l1_bound_device(sh, out=None):
     coefficients on the current stream (~5 us for 100 k splats), no host sync.  This is what the SH launches route on
     (include/gsgen_hip.h, "the coefficient bound"): render_frame / BatchRenderer.render call it in their forward, so the
     value always belongs to the coefficients being rendered."""
-    if sh.dim() != 3 or sh.shape[1] != 3 or sh.dtype != torch.float32:
-        raise ValueError("sh_l1_bound wants fp32 SH coefficients [N, 3, C*C]")
+    if sh.dtype != torch.float32:
+        raise ValueError("sh_l1_bound wants fp32 SH coefficients [N, 3, C*C] (or the same memory as [N, 3*C*C])")
     sh = sh.detach().contiguous()
+    if sh.dim() == 2 and sh.shape[1] % 3 == 0:  # the flat layout some callers keep: [N, 3 C*C]
+        sh = sh.view(sh.shape[0], 3, sh.shape[1] // 3)
+    C = int(round(sh.shape[-1] ** 0.5)) if sh.dim() == 3 else 0
+    if sh.dim() != 3 or sh.shape[1] != 3 or C * C != sh.shape[-1] or not 1 <= C <= 4:
+        raise ValueError("sh_l1_bound wants fp32 SH coefficients [N, 3, C*C] (or the same memory as [N, 3*C*C]), C in 1..4")
     if out is None:
         out = torch.empty(1, device=sh.device, dtype=torch.float32)
-    C = int(round(sh.shape[-1] ** 0.5))
     with torch.cuda.device(sh.device):
         _capi.load().sh_l1_bound(sh.shape[0], _p(sh), C, _p(out), _stream(sh))
     return out
@@ -249,9 +253,12 @@ class PairCountMonitor:
     asynchronous copy of its pair counts into a pinned host block of its own plus an event; `drain()` looks at every block
     whose event has completed and returns the counts.  The blocks form a ring of `depth` entries: a loop in which the host
     stays ahead of the GPU (the intended regime) never finds the LATEST event complete -- a single slot that each frame
-    overwrote would never be read and an overflowing scene would render as background for ever -- so when the ring is full
-    the oldest entry is waited for (it is `depth` frames old: the wait is short, and an overflow is reported within `depth`
-    frames at the latest)."""
+    overwrote would never be read and an overflowing scene would render as background for ever.  record() NEVER blocks: when
+    the ring is full and its oldest copy has not arrived yet (the host is more than `depth` frames ahead of the GPU), this
+    frame's counts are simply not sent (`skipped` counts them) -- an overflowing scene overflows in the following frames too,
+    so the report is delayed by the frames it takes the GPU to catch up, never lost.  Under stream capture nothing can be
+    recorded (an event recorded under capture cannot be queried): a one-time warning says so unless the buffers were sized
+    synchronously before (ensure_capacity -> clear())."""
 
     def __init__(self, n, depth=16):
         import collections
@@ -261,6 +268,9 @@ class PairCountMonitor:
                       for _ in range(self.depth)]
         self._pending = collections.deque()
         self._ready = []
+        self.skipped = 0            # frames whose counts were not sent because the ring was full
+        self._sized = False         # a synchronous capacity check has happened (clear())
+        self._capture_warned = False
 
     def _collect(self):
         while self._pending and self._pending[0][0].query():
@@ -271,16 +281,28 @@ class PairCountMonitor:
     def record(self, totals, count, stream):
         """behind the geometry enqueue on `stream`: totals[:count] (device int32) travel to the host"""
         if torch.cuda.is_current_stream_capturing():  # an event recorded under capture cannot be queried afterwards:
-            return                                    # size the buffers (ensure_capacity) before capturing
-        if not self._free:  # ring full: wait for the oldest entry (it is `depth` frames old)
-            self._pending[0][0].synchronize()
+            if not self._sized and not self._capture_warned:  # size the buffers (ensure_capacity) before capturing
+                import warnings
+                self._capture_warned = True
+                warnings.warn("gsgen_amd: rendering under stream capture without a prior ensure_capacity(): pair-list overflow "
+                              "cannot be detected inside a captured step (an overflowing camera renders as background only)",
+                              RuntimeWarning, stacklevel=4)
+            return
+        if not self._free:  # ring full: take what has arrived; never wait for the GPU
             self._collect()
+            if not self._free:
+                self.skipped += 1
+                return
         host = self._free.pop()
         with torch.cuda.stream(stream):
             host[:count].copy_(totals[:count], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(stream)
         self._pending.append((ev, host, int(count)))
+
+    def has_news(self):
+        """anything recorded and not yet handed out?  (lets callers skip drain()'s event queries on the common path)"""
+        return bool(self._pending) or bool(self._ready)
 
     def drain(self):
         """-> the counts (python ints, uint32 semantics), oldest first, of every frame / batch whose copy has arrived"""
@@ -294,6 +316,7 @@ class PairCountMonitor:
         while self._pending:
             self._free.append(self._pending.popleft()[1])
         self._ready = []
+        self._sized = True
 
 
 class FrameBuffers:

@@ -325,3 +325,30 @@ def test_bench_step_loop_dry_run_with_several_ranks(world):
     assert res["value"] <= sum(per) * 1.0001  # whole-job throughput over the SLOWEST rank's time
     assert f"{2 * world} of {2 * world} cameras" in cfg["sh_basis"] and "POLY6" in res["roofline"]["kernel"]
     assert "all_gather" in cfg["gather"]
+
+
+def test_bench_step_loop_dry_run_eight_ranks_on_the_cfg4_camera_split():
+    """the driver's scaling run starts EIGHT ranks; until now only 2 and 3 had ever run bench.py's step loop.  The
+    same dry run (gloo + the host build of the kernels) with 8 ranks on BASELINE configs[3]'s camera partition: the 64 random
+    poses split 8 per rank, one 8-camera step per rank and slot, the per-step all_gather of [8 ranks x 8 cameras] images, and the
+    second timed region without the gather (`value_no_gather`: compute scaling and xGMI cost separate in the driver's record)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    subprocess.check_call(["make", "-C", os.path.join(root, "oracle"), "-s", "emu"])
+    emu = os.path.join(root, "oracle", "_build", "libgsgen_emu.so")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--config", "cfg4", "--dry-run-lib", emu,
+                        "--steps", "2", "--warmup", "1"], cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    res = json.loads(lines[0])
+    cfg = res["config"]
+    assert res["n_gpus"] == 8 and cfg["rccl_world_size"] == 8 and cfg["cameras_per_step"] == 8
+    assert len(cfg["renders_per_s_per_rank"]) == 8 and all(v > 0 for v in cfg["renders_per_s_per_rank"])
+    assert "64 of 64 cameras" in cfg["sh_basis"]  # every rank's 8 poses, counted over the job
+    assert "all_gather" in cfg["gather"] and cfg["gather_bytes_per_step_per_rank"] == 8 * 24 * 40 * 3 * 4
+    assert cfg["gather_ingest_bytes_per_step_per_rank"] == 7 * cfg["gather_bytes_per_step_per_rank"]
+    assert res["value_no_gather"] > 0 and "gather_cost_fraction" in res["no_gather"]
+    assert set(res["projected"]["by_n_gpus"]) == {"1", "2", "4", "8"} and "PROJECTED" in res["projected"]["label"]

@@ -39,8 +39,10 @@ def ext():
 
 
 def test_compiled_module_exports_the_reference_surface(ext):
-    names = sorted(n for n in dir(ext) if not n.startswith("_") and n != "gsgen_version")
+    extra = {"gsgen_version", "set_sh_basis", "get_sh_basis"}  # additive: the library's version, the SH-basis switch
+    names = sorted(n for n in dir(ext) if not n.startswith("_") and n not in extra)
     assert names == REFERENCE_NAMES and len(names) == 23
+    assert extra <= set(dir(ext)) and ext.get_sh_basis() == "auto"
     ref = "/root/reference/gs/src/bindings.cpp"
     if os.path.exists(ref):  # the list above is the reference's, not ours
         assert sorted(re.findall(r'm\.def\(\s*"(\w+)"', open(ref).read())) == REFERENCE_NAMES

@@ -11,8 +11,9 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT)
 rnd, cfg, B = sys.argv[1], sys.argv[2], int(sys.argv[3])
 tags = sys.argv[4:]
+src_dir = os.environ.get("PMC_DIR", os.path.join(ROOT, "gpurun_out"))
 from gsgen_amd import _capi  # noqa: E402
-lib = _capi.load()
+lib = _capi.load()  # (names only: works without a GPU)
 # raw (demangled) kernel name fragments -> the library's descriptive variant names
 names = {
     "k_composite_bwd_sh_vec<4, 4, true, true, 6>": lib.kernel_variant("sh_bwd_batch_poly", 4, 1),
@@ -21,6 +22,13 @@ names = {
     "k_composite_fwd_sh_vec<4, 2, true, -2>": "persistent exact fallback of the bounded forward (normally leaves at once)",
     "k_composite_bwd_sh_vec<4, 4, true, true, 0>": lib.kernel_variant("sh_bwd_batch", 4, 1),
     "k_composite_fwd_sh_vec<4, 2, true, 0>": lib.kernel_variant("sh_fwd_batch", 4, 1),
+    "k_composite_bwd_chan_vec<3, true>": lib.kernel_variant("rgbd_bwd_batch", 1, 1),
+    "k_composite_fwd_chan_vec<3, true>": lib.kernel_variant("rgbd_fwd_batch", 1, 1),
+    # the geometry chain of a batch (same kernels behind the SH and the RGB + heads step)
+    "k_frame_project_views": "k_frame_project_views", "k_bin_pull_views<false>": "k_bin_pull_views<count>",
+    "k_bin_pull_views<true>": "k_bin_pull_views<emit>", "k_sort_tiles_views": "k_sort_tiles_views",
+    "k_scan_chunks_views": "k_scan_chunks_views", "k_scan_order_tiles_views": "k_scan_order_tiles_views",
+    "k_project_bwd_views": "k_project_bwd_views",
 }
 out_path = os.path.join(ROOT, "profiles", f"{rnd}_traffic.json")
 out = json.load(open(out_path)) if os.path.exists(out_path) else {}
@@ -28,7 +36,7 @@ out["note"] = ("rocprofv3 --pmc, separate passes (tools/pmc.sh), bench.py --only
                "FETCH_SIZE / WRITE_SIZE in KB; traffic = 2*FETCH + WRITE (MI355X_MICROARCH.md gfx950 correction; WRITE_SIZE uncalibrated). "
                "valu_floor = SQ_ACTIVE_INST_VALU (quad-cycles) * 4 / 1024 SIMDs / 2.4 GHz.")
 for tag in tags:
-    d = json.load(open(os.path.join(ROOT, "gpurun_out", f"pmc_{tag}.json")))
+    d = json.load(open(os.path.join(src_dir, f"pmc_{tag}.json")))
     for raw, vals in d.items():
         for frag, nice in names.items():
             if frag in raw.replace("gs::", ""):
