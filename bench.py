@@ -323,9 +323,6 @@ def main():
                          "basis where the error bound allows (images within 1e-5 of the exact kernels; include/gsgen_hip.h, "
                          "\"the coefficient bound\"), the exact kernel elsewhere; exact: the exact kernels only.  With auto the "
                          "exact kernels are timed too and reported as `exact_basis`")
-    ap.add_argument("--variant", action="append", default=[], metavar="NAME=VALUE",
-                    help="A/B: override one entry of the library's kernel-variant table (gsgen_debug_set_variant), e.g. "
-                         "--variant ppl_fwd_batch=4; repeatable")
     ap.add_argument("--no-surface", action="store_true", help="skip the autograd-surface pass (BatchRenderer.render + backward)")
     ap.add_argument("--only-timed", action="store_true",
                     help="profiling runs: nothing but the warm-up and the timed regions launches kernels (no exact-basis region, no "
@@ -398,9 +395,6 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
 
     lib = _capi.load()
-    for kv in args.variant:
-        k_, v_ = kv.split("=")
-        lib.set_variant(k_, int(v_))
     sc, W, H = make_workload(args.config)
     C = sc["C"]
     N = sc["mean"].shape[0]
@@ -1026,8 +1020,8 @@ def main():
     bwd_name = lib.kernel_variant("sh_bwd_batch_poly" if poly_applies else "sh_bwd_batch", C, nseg)
     fwd_name = lib.kernel_variant("sh_fwd_batch_poly" if poly_applies else "sh_fwd_batch", C, nseg)
     traffic, valu_floor, traffic_src = committed_traffic(args.config, bwd_name, B)
-    frag = "k_composite_bwd_sh_vec<4, 4, true, true, 6>" if poly_applies else "k_composite_bwd_sh_vec<4, 4, true, true, 0>"
-    trace_ms, trace_src = committed_trace_ms(args.config, frag) if (C == 4 and B == 8) else (None, None)
+    frag = "k_composite_bwd_sh_vec<4, 4, true, 6>" if poly_applies else "k_composite_bwd_sh_vec<4, 4, true, 0>"
+    trace_ms, trace_src = committed_trace_ms(args.config, frag) if C == 4 else (None, None)
     ach = B * parts["composite_bwd"] / (bwd_ms * 1e-3) / 1e9
     els = [r_["el"] for r_ in regions]
     res = {

@@ -119,7 +119,7 @@ SIZE_FUNCS = {
     "gsgen_legacy_sort_workspace_bytes": [u32, u32],
 }
 EXPORTS = sorted(list(SIGNATURES) + list(SIZE_FUNCS) + list(PTR_FUNCS)
-                 + ["gsgen_version", "gsgen_error_string", "gsgen_kernel_variant", "gsgen_debug_set_variant", "gsgen_sh_poly_applies"])
+                 + ["gsgen_version", "gsgen_error_string", "gsgen_kernel_variant", "gsgen_sh_poly_applies"])
 
 
 class GsgenError(RuntimeError):
@@ -176,13 +176,6 @@ class Lib:
 
     def version(self):
         return self.cdll.gsgen_version().decode()
-
-    def set_variant(self, name, value):
-        """debugging hook: override one entry of the kernel-variant table (see include/gsgen_hip.h)"""
-        fn = self.cdll.gsgen_debug_set_variant
-        fn.argtypes, fn.restype = [C.c_char_p, i32], i32
-        if fn(name.encode(), int(value)) != 0:
-            raise ValueError(f"bad kernel variant {name}={value}")
 
     def sh_poly_applies(self, sh_l1_bound, max_pixel_size, bands=4):
         """the device's routing rule, on the host (for reports): does a view of this pixel size take the polynomial form of

@@ -9,6 +9,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// occupancy hint for the register allocator (the CPU emulator build compiles these files with g++, which does not know it)
+#if defined(__clang__)
+#define GS_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n)))
+#else
+#define GS_WAVES_PER_EU(n)
+#endif
+
 namespace gs {
 
 constexpr int kTile = 16;

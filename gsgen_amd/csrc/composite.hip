@@ -118,24 +118,14 @@ __device__ __forceinline__ GRec load_rec(const Stage<MODE, CB, KB, WC> &S, int g
 // BATCH: one launch renders B cameras, each workgroup taking its camera's parameters from plist[view]
 // (device memory) instead of the kernel argument -- a single launch's tail (the never-saturating
 // sparse tiles) is then paid once per batch instead of once per camera.  The grid is 1-D, B x the
-// per-camera grid; p_arg only carries B (n_lo) and the workgroup -> (view, per-camera block) map (n_hi):
-//   2  camera-major (default): all blocks of camera 0, then camera 1, ...
-//   0  interleaved: view = id % B -- every camera's longest lists start at once; with B = 8, XCD k
-//      (ids = k mod 8) sees one camera
-//   1  interleaved, view rotated by the block index (no camera pinned to an XCD)
+// per-camera grid, camera-major (all blocks of camera 0, then camera 1, ...; measured against two interleaved orders in
+// round 1: as fast on cfg2, faster on the 64 random cameras of cfg4 -- an interleaved B = 8 pins each camera to one XCD);
+// p_arg only carries B (n_lo).
 // total: the size of the grid the map is taken over -- gridDim.x, or the virtual grid a persistent launch strides through
 __device__ __forceinline__ uint32_t batch_view(const CompParams &p_arg, uint32_t &bid, uint32_t *grid, uint32_t total) {
   const uint32_t B = (uint32_t)p_arg.n_lo, per = total / B;
-  uint32_t view;
-  if (p_arg.n_hi == 2) {
-    view = bid / per;
-    bid -= view * per;
-  } else {
-    const uint32_t r = bid / B;
-    view = bid - r * B;
-    if (p_arg.n_hi == 1) view = (view + r) % B;
-    bid = r;
-  }
+  const uint32_t view = bid / per;
+  bid -= view * per;
   if (grid) *grid = per;
   return view;
 }
@@ -147,12 +137,11 @@ __device__ __forceinline__ uint32_t batch_view(const CompParams &p_arg, uint32_t
 // that configure another `tile_size` (the reference takes it as a parameter, conf/base.yaml:132; its launch is
 // tile_size x tile_size threads, vol_render.h:1001-1004): TS = 8 runs one wavefront per tile (PPL = 1), TS = 32 four
 // wavefronts at 4 pixels per lane.  Per-pixel results do not depend on the tile size.
-template <int MODE, int CB, int PPL, bool BATCH = false, int TS = 16>
-__global__ void __launch_bounds__(TS * TS / PPL) k_composite_fwd(CompParams p_arg, const CompParams *__restrict__ plist) {
+template <int MODE, int CB, int PPL, int TS = 16>
+__global__ void __launch_bounds__(TS * TS / PPL) k_composite_fwd(CompParams p) {
   // by value: read once with scalar loads; through a reference every use in the entry loop would be
   // re-read from memory (the kernel's own stores may alias it as far as the compiler knows)
-  uint32_t bid = blockIdx.x;
-  const CompParams p = BATCH ? plist[batch_view(p_arg, bid)] : p_arg;
+  const uint32_t bid = blockIdx.x;
   using TR = Traits<MODE, CB>;
   constexpr int NT = TS * TS / PPL;
   constexpr int ROWS = NT / TS;
@@ -677,7 +666,7 @@ k_composite_fwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
     bool any = false;
     for (uint32_t v = 0; v < B; ++v) any |= !poly_route(plist[v].sh_bound, plist[v].psx, plist[v].psy);
     if (!any) return;  // every view of the batch took the polynomial form
-    const uint32_t per = total / B;  // camera-major, whatever the batch map of the other launches (speed only)
+    const uint32_t per = total / B;  // camera-major
     uint32_t base = 0;  // first block of the view b lies in (b only grows: no division in the loop)
     const CompParams *pp = plist;
     for (uint32_t b = blockIdx.x; b < total; b += gridDim.x) {
@@ -703,11 +692,12 @@ k_composite_fwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
 // ============================================================================================
 // backward
 // ============================================================================================
-template <int MODE, int CB, int PPL, bool BATCH = false, int TS = 16>  // TS: tile side, see k_composite_fwd
+// The unpacked vector form of the backward: the shape behind the `_gs` entry points for callers that configure a tile side of 8
+// or 32 (see k_composite_fwd); 16 x 16 tiles run the packed kernels below.
+template <int MODE, int CB, int PPL, int TS>  // TS: tile side, see k_composite_fwd
 __global__ void __launch_bounds__(TS * TS / PPL)
-k_composite_bwd_pixel(CompParams p_arg, const CompParams *__restrict__ plist) {
-  uint32_t bid = blockIdx.x, grid = gridDim.x;
-  const CompParams p = BATCH ? plist[batch_view(p_arg, bid, &grid)] : p_arg;  // see k_composite_fwd
+k_composite_bwd_pixel(CompParams p) {
+  const uint32_t bid = blockIdx.x, grid = gridDim.x;
   using TR = Traits<MODE, CB>;
   constexpr int NT = TS * TS / PPL;
   static_assert(NT >= kBatch && NT % 64 == 0, "a staging round needs one thread per record");
@@ -950,38 +940,38 @@ k_composite_bwd_pixel(CompParams p_arg, const CompParams *__restrict__ plist) {
 // The Gaussian evaluation is gauss_sh_pair: bit for bit gauss_eval<MODE_SH>, so "skip" and "saturated" decisions
 // equal the forward's.  Same launch shapes as k_composite_bwd_pixel (one workgroup per tile or per (tile, segment),
 // 256 / PPL threads); PPL = 4 (one wavefront per tile) or 2.
-// CHRED: the gradient vector is reduced channel by channel (wave_reduce_scatter2_rows on the 3 x CCP SH components as
+// The gradient vector is reduced CHANNEL BY CHANNEL (wave_reduce_scatter2_rows on the 3 x CCP SH components as
 // soon as a channel's accumulators are complete, the 7 geometric components likewise, one quad_reduce_scatter4 at the
 // end) instead of as one 64-component vector after the third channel: the same number of exchanges, but the finished
-// channels no longer sit in 32 registers while the next one is computed.
-// NB > 0 (= kPolyNB; SH degree 3, CHRED, one wavefront per tile): the tile-local polynomial form of the per-pixel basis
+// channels no longer sit in 32 registers while the next one is computed (190 -> 164 registers in round 2: the single-reduction
+// form, `CHRED = false`, is in the history up to round 3).
+// NB > 0 (= kPolyNB; SH degree 3, one wavefront per tile): the tile-local polynomial form of the per-pixel basis
 // (composite_common.hpp) -- 6-term contractions, 3 x 6 SH gradient components across the lanes, expanded by the tile's V
 // (through 24 floats of LDS) in front of the 48 atomics.
 // NB = kRouted: as k_composite_fwd_sh_vec -- one launch, the form chosen per workgroup from the device-resident bound.
-template <int CB, int PPL, bool CHRED, bool POLY>
+template <int CB, int PPL, bool POLY>
 struct BwdShVecShared {
-  static constexpr int KB = CHRED ? 32 : kBatch;  // CHRED: 10.6 KB of LDS per workgroup, 12+ workgroups per CU
+  static constexpr int KB = 32;  // records per staging round: 10.6 KB of LDS per workgroup, 12+ workgroups per CU
   static constexpr int NT = 256 / PPL, NP = PPL / 2;
   Stage<MODE_SH, CB, KB, !POLY> S;
-  v2f go_s[(CHRED && !POLY) ? 3 * NP * NT : 1];           // CHRED, exact form: grad_out of the lane's pixel pairs, [channel][pair][thread]
+  v2f go_s[!POLY ? 3 * NP * NT : 1];                      // exact form: grad_out of the lane's pixel pairs, [channel][pair][thread]
   alignas(16) float Vs[POLY ? kPolyNB * 16 : 4];          // POLY: V of this tile
   alignas(16) float Ws[POLY ? KB * 3 * kPolyStride : 4];    // POLY: transformed coefficients of the staged batch
                                                           // (and, before the first batch, the nine node bases)
   float gw_s[POLY ? 3 * 8 : 1];                           // POLY: a splat's reduced gradient in the tile's basis
 };
-template <int CB, int PPL, bool CHRED, int NB, bool PERSIST = false>
+template <int CB, int PPL, int NB, bool PERSIST = false>
 __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, uint32_t bid, uint32_t grid,
-                                                          BwdShVecShared<CB, PPL, CHRED, (NB > 0)> &sm) {
+                                                          BwdShVecShared<CB, PPL, (NB > 0)> &sm) {
   static_assert(PPL == 4 || PPL == 2, "pixel pairs: 2 or 4 pixels per lane");
   constexpr bool POLY = NB > 0;
-  static_assert(!POLY || (NB == kPolyNB && CB == 4 && CHRED && PPL == 4), "polynomial basis: SH degree 3, one wavefront per tile");
+  static_assert(!POLY || (NB == kPolyNB && CB == 4 && PPL == 4), "polynomial basis: SH degree 3, one wavefront per tile");
   constexpr int MODE = MODE_SH;
   using TR = Traits<MODE, CB>;
   constexpr int NT = 256 / PPL, ROWS = NT / 16, NP = PPL / 2;
   constexpr int CCP = POLY ? NB : TR::CCP, NPAIR = CCP / 2, NSH = 3 * CCP;  // SH components incl. padding
-  constexpr int P = (NSH + 7) <= 32 ? 32 : 64;                    // reduction width: SH | mean 2 | cov 4 | alpha 1
-  static_assert(NSH % 2 == 0 && NSH + 7 <= P, "component layout");
-  constexpr int KB = CHRED ? 32 : kBatch;
+  static_assert(NSH % 2 == 0, "component layout");
+  constexpr int KB = BwdShVecShared<CB, PPL, POLY>::KB;
   auto &S = sm.S;
   v2f *const go_s = sm.go_s;
   float *const Vs = sm.Vs;
@@ -1084,7 +1074,7 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
     R2[jp] = fma2(go2[jp][2], rem2[jp][2], fma2(go2[jp][1], rem2[jp][1], go2[jp][0] * rem2[jp][0]));
     pvsq2[jp] = pv2[jp] * pv2[jp];
   }
-  if constexpr (CHRED && !POLY) {  // each thread reads back only what it wrote: no barrier
+  if constexpr (!POLY) {  // each thread reads back only what it wrote: no barrier
 #pragma unroll
     for (int jp = 0; jp < NP; ++jp)
 #pragma unroll
@@ -1110,9 +1100,9 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
 
       // the record as plain scalars (a struct handed around by reference makes the compiler build the packed
       // operands through scratch memory)
-      // (CHRED: wave-uniform values moved to scalar registers -- nine vector registers less)
+      // (exact form: wave-uniform values moved to scalar registers -- nine vector registers less)
       // (POLY: 108 registers leave room for the nine scalars as vector registers -- nine v_readfirstlane less per entry)
-      auto uni = [&](float v) { return (CHRED && !POLY) ? wave_uniform(v) : v; };
+      auto uni = [&](float v) { return !POLY ? wave_uniform(v) : v; };
       const float r_mx = uni(S.mx[g]), r_my = uni(S.my[g]), r_a = uni(S.a[g]), r_c0 = uni(S.c0[g]), r_c1 = uni(S.c1[g]),
                   r_c2 = uni(S.c2[g]), r_c3 = uni(S.c3[g]), r_p0 = uni(S.p0[g]), r_p1 = uni(S.p1[g]);
       const float x = px - r_mx;
@@ -1164,14 +1154,8 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
       // measured again in round 3 with the polynomial body: 4 488 vs 4 507 renders/s, profiles/r03_ab_pairskip_polyonly.txt)
       if (!wave_any(any_con)) continue;  // nobody in the wave sees this Gaussian
 
-      // reduction vector as (even, odd) pairs: SH components [0, NSH) | mean | cov | alpha | zeros
-      constexpr int PCH = CCP <= 2 ? 2 : (CCP <= 4 ? 4 : (CCP <= 8 ? 8 : 16));  // CHRED: one channel's components
-      v2f gr2[CHRED ? 1 : P / 2];
+      constexpr int PCH = CCP <= 2 ? 2 : (CCP <= 4 ? 4 : (CCP <= 8 ? 8 : 16));  // one channel's components in its reduction
       float chsum[3] = {0.0f, 0.0f, 0.0f};
-      if constexpr (!CHRED) {
-#pragma unroll
-        for (int i = NSH / 2; i < P / 2; ++i) gr2[i] = v2f{0.0f, 0.0f};
-      }
       const float *cg = POLY ? &Ws[g * 3 * kPolyStride] : &S.col[g * TR::NCOLP];
       v2f pch[POLY ? 3 : 1][3];  // POLY: the channels' six components each, reduced after the geometric part
       v2f w2[NP], inv1m2[NP], pAG2[NP];
@@ -1261,9 +1245,7 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
           const v2f den = splat2(1.0f) + v2f{__builtin_amdgcn_exp2f(sp[0]), __builtin_amdgcn_exp2f(sp[1])};
           const v2f yv = v2f{__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
           const v2f dy = fma2(-yv, yv, yv);  // y (1 - y)
-          v2f go;
-          if constexpr (CHRED) go = go_s[(c * NP + jp) * NT + t];
-          else go = go2[jp][c];
+          const v2f go = go_s[(c * NP + jp) * NT + t];
           const v2f gs = (w2[jp] * dy) * go;
           gyx2[jp] = c == 0 ? go * yv : fma2(go, yv, gyx2[jp]);  // sum_c grad_out_c * colour_c (see R2)
 #pragma unroll
@@ -1283,14 +1265,11 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
         // registers; not kept)
         pair_colour(std::integral_constant<int, 0>{}, std::true_type{});
         if constexpr (NP > 1) pair_colour(std::integral_constant<int, NP - 1>{}, std::false_type{});
-        if constexpr (CHRED) {
+        {
           v2f t[PCH / 2];
 #pragma unroll
           for (int k = 0; k < PCH / 2; ++k) t[k] = k < NPAIR ? gq[k < NPAIR ? k : 0] : v2f{0.0f, 0.0f};
           chsum[c] = wave_reduce_scatter2_rows<PCH>(t);
-        } else {
-#pragma unroll
-          for (int k = 0; k < NPAIR; ++k) gr2[c * NPAIR + k] = gq[k];
         }
       }
 #pragma unroll
@@ -1322,7 +1301,7 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
       const float m0 = gm0[0] + gm0[1], m1 = gm1[0] + gm1[1];
       const float c0 = gc0[0] + gc0[1], c1 = gc1[0] + gc1[1], c3 = gc3[0] + gc3[1];
       const float ga = gal[0] + gal[1];
-      if constexpr (CHRED && POLY) {
+      if constexpr (POLY) {
         // The six DISTINCT geometric components (grad_cov[1] and grad_cov[2] receive the same value, kernels.h:414-415) ride
         // in the two spare slots of the three channels' 8-wide reductions: (m0, m1) | (c0, c1) | (c3, alpha).  No fourth
         // reduction (363 -> 348 vector instructions per (wavefront, entry) when it went in; 321 now).
@@ -1358,7 +1337,7 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
           atomicAdd(p.g_col + (size_t)TR::NCOL * id + lane, acc);  // (c, k) -> 16 c + k = lane
         }
         __syncthreads();  // gw_s is consumed before the next splat overwrites it
-      } else if constexpr (CHRED) {
+      } else {
         // grad_cov[1] and grad_cov[2] receive the same value (kernels.h:414-415)
         v2f ex[4] = {v2f{m0, m1}, v2f{c0, c1}, v2f{c1, c3}, v2f{ga, 0.0f}};
         const float exsum = wave_reduce_scatter2_rows<8>(ex);
@@ -1376,24 +1355,6 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
           else if (e == 6) dst = p.g_alpha + id;
         }
         if (dst != nullptr) atomicAdd(dst, tot);
-      } else {
-        gr2[NSH / 2 + 0] = v2f{m0, m1};
-        gr2[NSH / 2 + 1] = v2f{c0, c1};
-        gr2[NSH / 2 + 2] = v2f{c1, c3};  // grad_cov[1] and grad_cov[2] receive the same value (kernels.h:414-415)
-        gr2[NSH / 2 + 3] = v2f{ga, 0.0f};
-        wave_reduce_scatter2<P>(gr2);
-        const int comp = scatter_comp<P>(lane);
-        if (scatter_owner<P>(lane) && comp < NSH + 7) {
-          const size_t id = (size_t)S.id[g];
-          float *dst = nullptr;
-          if (comp < NSH) {
-            const int c = comp / CCP, k = comp - c * CCP;
-            if (k < TR::CC) dst = p.g_col + (size_t)TR::NCOL * id + c * TR::CC + k;
-          } else if (comp < NSH + 2) dst = p.g_mean + 2 * id + (comp - NSH);
-          else if (comp < NSH + 6) dst = p.g_cov + 4 * id + (comp - NSH - 2);
-          else dst = p.g_alpha + id;
-          if (dst != nullptr) atomicAdd(dst, gr2[0][0]);
-        }
       }
     }
     bool any_alive = false;
@@ -1404,15 +1365,15 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
 }
 // (the persistent fallback runs at 152 registers, the exact kernel at 148: three wavefronts per SIMD.  It only renders views whose
 // coefficient bound fails while a batch mate's holds.)
-template <int CB, int PPL, bool BATCH = false, bool CHRED = false, int NB = 0>
+template <int CB, int PPL, bool BATCH = false, int NB = 0>
 __global__ void __launch_bounds__(256 / PPL)
 k_composite_bwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
   uint32_t bid = blockIdx.x, grid = gridDim.x;
   if constexpr (NB == kRouted) {
-    static_assert(CB == 4 && PPL == 4 && CHRED, "routing exists for SH degree 3, one wavefront per tile");
+    static_assert(CB == 4 && PPL == 4, "routing exists for SH degree 3, one wavefront per tile");
     union Shared {
-      BwdShVecShared<4, 4, true, true> poly;
-      BwdShVecShared<4, 4, true, false> exact;
+      BwdShVecShared<4, 4, true> poly;
+      BwdShVecShared<4, 4, false> exact;
     };
     __shared__ Shared sm;
     // The decision reads three words of the view's parameters; each form then takes its own copy of the block, so that
@@ -1421,38 +1382,38 @@ k_composite_bwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
     const CompParams *pp = BATCH ? &plist[batch_view(p_arg, bid, &grid)] : &p_arg;
     if (poly_route(pp->sh_bound, pp->psx, pp->psy)) {
       const CompParams p = *pp;
-      composite_bwd_sh_vec_tile<4, 4, true, kPolyNB>(p, bid, grid, sm.poly);
+      composite_bwd_sh_vec_tile<4, 4, kPolyNB>(p, bid, grid, sm.poly);
     } else {
       const CompParams p = *pp;
-      composite_bwd_sh_vec_tile<4, 4, true, 0>(p, bid, grid, sm.exact);
+      composite_bwd_sh_vec_tile<4, 4, 0>(p, bid, grid, sm.exact);
     }
   } else if constexpr (NB == kFallback) {  // see k_composite_fwd_sh_vec
-    static_assert(CB == 4 && PPL == 4 && CHRED && BATCH, "the persistent exact fallback of a bounded batch");
-    __shared__ BwdShVecShared<4, 4, true, false> sm;
+    static_assert(CB == 4 && PPL == 4 && BATCH, "the persistent exact fallback of a bounded batch");
+    __shared__ BwdShVecShared<4, 4, false> sm;
     const uint32_t B = (uint32_t)p_arg.n_lo, total = p_arg.vgrid;
     bool any = false;
     for (uint32_t v = 0; v < B; ++v) any |= !poly_route(plist[v].sh_bound, plist[v].psx, plist[v].psy);
     if (!any) return;
-    const uint32_t per = total / B;  // camera-major, whatever the batch map of the other launches (speed only)
+    const uint32_t per = total / B;  // camera-major
     uint32_t base = 0;  // first block of the view b lies in (b only grows: no division in the loop)
     const CompParams *pp = plist;
     for (uint32_t b = blockIdx.x; b < total; b += gridDim.x) {
       while (b >= base + per) { base += per; ++pp; }
       if (poly_route(pp->sh_bound, pp->psx, pp->psy)) continue;
       const CompParams p = *pp;
-      composite_bwd_sh_vec_tile<4, 4, true, 0, true>(p, b - base, per, sm);
+      composite_bwd_sh_vec_tile<4, 4, 0, true>(p, b - base, per, sm);
       __syncthreads();
     }
   } else if constexpr (NB == kPolyNB && BATCH) {
-    __shared__ BwdShVecShared<4, 4, true, true> sm;
+    __shared__ BwdShVecShared<4, 4, true> sm;
     const CompParams *pp = &plist[batch_view(p_arg, bid, &grid)];
     if (!poly_route(pp->sh_bound, pp->psx, pp->psy)) return;  // this view is the exact fallback's
     const CompParams p = *pp;
-    composite_bwd_sh_vec_tile<4, 4, true, kPolyNB>(p, bid, grid, sm);
+    composite_bwd_sh_vec_tile<4, 4, kPolyNB>(p, bid, grid, sm);
   } else {
     const CompParams p = BATCH ? plist[batch_view(p_arg, bid, &grid)] : p_arg;  // see k_composite_fwd
-    __shared__ BwdShVecShared<CB, PPL, CHRED, (NB > 0)> sm;
-    composite_bwd_sh_vec_tile<CB, PPL, CHRED, NB>(p, bid, grid, sm);
+    __shared__ BwdShVecShared<CB, PPL, (NB > 0)> sm;
+    composite_bwd_sh_vec_tile<CB, PPL, NB>(p, bid, grid, sm);
   }
 }
 
@@ -1463,7 +1424,7 @@ k_composite_bwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
 // wavefronts per tile; with the lane's 4 pixels as two packed pairs, one wavefront per tile, the record in scalar
 // registers and one wave-uniform guard branch it is ~70 per tile and entry.  Same structure as k_composite_fwd_sh_vec.
 template <int MODE, bool BATCH = false>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5)))  // (98 -> 96 registers: five wavefronts per SIMD)
+__global__ void __launch_bounds__(64) GS_WAVES_PER_EU(5)  // RGB + heads: 98 -> 81 registers, six wavefronts per SIMD (+1 .. 2 %, profiles/r04_notes.md)
 k_composite_fwd_chan_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
   static_assert(MODE == MODE_RGB || MODE == MODE_SCALAR || MODE == MODE_RGBD, "post-activation channel modes");
   uint32_t bid = blockIdx.x;
@@ -1605,7 +1566,7 @@ k_composite_fwd_chan_vec(CompParams p_arg, const CompParams *__restrict__ plist)
 // over four arrays per entry compiled to nested exec-mask branches and a flat atomic).
 // Reduction vector: channels [0, NCH) | pad to even | mean 2 | cov 4 | alpha 1.
 template <int MODE, bool BATCH = false>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5)))
+__global__ void __launch_bounds__(64) GS_WAVES_PER_EU(5)  // RGB + heads: 106 -> 96 registers (16 bytes of scratch outside the entry loop): five per SIMD
 k_composite_bwd_chan_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
   static_assert(MODE == MODE_RGB || MODE == MODE_SCALAR || MODE == MODE_RGBD, "post-activation channel modes");
   uint32_t bid = blockIdx.x, grid = gridDim.x;
@@ -1777,38 +1738,21 @@ k_composite_bwd_chan_vec(CompParams p_arg, const CompParams *__restrict__ plist)
 }
 
 // ---- launch helpers ---------------------------------------------------------------------------
-// Kernel variants.  The defaults below are the product; nothing is read from the environment.  The other shapes stay
-// compiled so that the variant tests (tests/test_variants.py) and A/B measurements (bench.py --variant) can select them
-// through gsgen_debug_set_variant:
-//   ppl_fwd / ppl_bwd                     pixels per lane of the per-camera forward / backward (4 = one wavefront per tile,
-//                                         the north_star shape; 2 / 1 = two / four wavefronts per tile sharing the staged
-//                                         records)
-//   ppl_fwd_batch / ppl_bwd_batch / ppl_bwd_sh_batch   the same for the batched launches (RGB + heads / SH backward)
-//   batch_map                             block order of the batched grids (batch_view)
-//   sh_packed / sh_chred / chan_packed    packed per-pixel arithmetic (k_composite_*_sh_vec / *_chan_vec) and the
-//                                         channel-wise gradient reduction, against the unpacked k_composite_bwd_pixel
-// Defaults chosen by measurement on MI355X (profiles/r01_notes.md, profiles/r02_notes.md): per-camera forward 1 pixel per
-// lane (127 us vs 195 us at 4: one wave per tile leaves 2.4 waves per SIMD and the launch ends on the centre tiles' serial
-// chains; 129 vs 153 us against the packed 2-pixel kernel), batched forward 2 (packed k_composite_fwd_sh_vec: a lone
-// 8-view launch is 4 % slower than at 1 pixel per lane but issues fewer vector instructions, which is what counts with
-// another batch's backward in flight: 3 010 vs 2 885 renders/s), vector backward 4 (the per-Gaussian gradient
-// reduction costs the same per wave whatever the number of pixels behind it).
-struct Variants {
-  int ppl_fwd = 1, ppl_bwd = 4, ppl_fwd_batch = 2, ppl_bwd_batch = 2, ppl_bwd_sh_batch = 4, batch_map = 2;
-  int ppl_fwd_poly = 2;  // pixels per lane (2 | 4) of the per-camera routed forward
-  int ppl_fwd_batch_poly = 4;  // ... of the batched polynomial forward
-  int sh_packed = 1;    // 1 = k_composite_bwd_sh_vec, 0 = k_composite_bwd_pixel<MODE_SH>
-  int sh_chred = 1;     // channel-wise gradient reduction in k_composite_bwd_sh_vec at 4 pixels per lane
-  int chan_packed = 1;  // 1 = k_composite_bwd_chan_vec for RGB / scalar / RGB + heads, 0 = k_composite_bwd_pixel
-};
-static Variants &variants() {
-  static Variants v;
-  return v;
-}
-
+// One shape per job, chosen by measurement on MI355X (profiles/r01_notes.md .. r04_notes.md); the A/B shapes of rounds 1-3
+// (pixels per lane 1 / 2 / 4 of every kernel, the unpacked backward for 16 x 16 tiles, the single-reduction SH backward, two
+// interleaved batch orders, a run-time variant table behind gsgen_debug_set_variant) are gone from the tree with round 4:
+//   per-camera forward, every mode          k_composite_fwd<MODE, CB, 1>: 4 wavefronts per tile (127 us vs 195 us at one: a lone
+//                                           launch leaves 2.4 wavefronts per SIMD and ends on the centre tiles' serial chains)
+//   per-camera forward, SH degree 3 + bound k_composite_fwd_sh_vec<4, 2, false, kRouted>: both forms of the basis in one kernel
+//   per-camera backward                     one wavefront per tile, packed: k_composite_bwd_sh_vec<CB, 4> (routed with a bound),
+//                                           k_composite_bwd_chan_vec<MODE> for RGB / scalar / RGB + heads
+//   batched forward                         SH: k_composite_fwd_sh_vec<CB, 2, true> (two wavefronts per tile); with a bound the
+//                                           polynomial kernel <4, 4, true, kPolyNB> + the persistent exact fallback;
+//                                           RGB, RGB + heads: k_composite_fwd_chan_vec<MODE, true>
+//   batched backward                        k_composite_bwd_sh_vec<CB, 4, true> (+ polynomial / fallback pair), chan_vec
+//   tile sides 8 / 32 (`_gs` callers only)  the unpacked k_composite_fwd / k_composite_bwd_pixel at one fixed shape each
 template <int MODE, int CB>
 static int launch_fwd(const CompParams &p_, hipStream_t s) {
-  const int ppl = variants().ppl_fwd;
   CompParams p = p_;
   const uint32_t nblk = comp_grid(p);
   if (p.ntw * p.nth == 0) return 0;
@@ -1817,8 +1761,8 @@ static int launch_fwd(const CompParams &p_, hipStream_t s) {
     else {
       if (p.nseg > 1) return GSGEN_EUNSUPPORTED;
       p.sh_bound = nullptr;  // the polynomial basis is fitted to 16 x 16 tiles
-      if (p.tile_side == 8) hipLaunchKernelGGL((k_composite_fwd<MODE, CB, 1, false, 8>), dim3(nblk), dim3(64), 0, s, p, (const CompParams *)nullptr);
-      else hipLaunchKernelGGL((k_composite_fwd<MODE, CB, 4, false, 32>), dim3(nblk), dim3(256), 0, s, p, (const CompParams *)nullptr);
+      if (p.tile_side == 8) hipLaunchKernelGGL((k_composite_fwd<MODE, CB, 1, 8>), dim3(nblk), dim3(64), 0, s, p);
+      else hipLaunchKernelGGL((k_composite_fwd<MODE, CB, 4, 32>), dim3(nblk), dim3(256), 0, s, p);
       return (int)hipGetLastError();
     }
   }
@@ -1826,28 +1770,17 @@ static int launch_fwd(const CompParams &p_, hipStream_t s) {
     // with the coefficient bound: ONE launch of the routed kernel -- every workgroup reads the bound and runs the polynomial
     // form of the per-pixel basis where its error bound holds, the exact form elsewhere (poly_route)
     if (p.sh_bound != nullptr) {
-      if (variants().ppl_fwd_poly == 4) hipLaunchKernelGGL((k_composite_fwd_sh_vec<4, 4, false, kRouted>), dim3(nblk), dim3(64), 0, s, p, (const CompParams *)nullptr);
-      else hipLaunchKernelGGL((k_composite_fwd_sh_vec<4, 2, false, kRouted>), dim3(nblk), dim3(128), 0, s, p, (const CompParams *)nullptr);
+      hipLaunchKernelGGL((k_composite_fwd_sh_vec<4, 2, false, kRouted>), dim3(nblk), dim3(128), 0, s, p, (const CompParams *)nullptr);
       return (int)hipGetLastError();
     }
   } else {
     p.sh_bound = nullptr;
   }
-  if constexpr (MODE == MODE_SH) {
-    if (variants().sh_packed && ppl != 1) {  // packed per-pixel arithmetic needs pixel pairs
-      if (ppl == 2) hipLaunchKernelGGL((k_composite_fwd_sh_vec<CB, 2>), dim3(nblk), dim3(128), 0, s, p, (const CompParams *)nullptr);
-      else hipLaunchKernelGGL((k_composite_fwd_sh_vec<CB, 4>), dim3(nblk), dim3(64), 0, s, p, (const CompParams *)nullptr);
-      return (int)hipGetLastError();
-    }
-  }
-  if (ppl == 1) hipLaunchKernelGGL((k_composite_fwd<MODE, CB, 1>), dim3(nblk), dim3(256), 0, s, p, (const CompParams *)nullptr);
-  else if (ppl == 2) hipLaunchKernelGGL((k_composite_fwd<MODE, CB, 2>), dim3(nblk), dim3(128), 0, s, p, (const CompParams *)nullptr);
-  else hipLaunchKernelGGL((k_composite_fwd<MODE, CB, 4>), dim3(nblk), dim3(64), 0, s, p, (const CompParams *)nullptr);
+  hipLaunchKernelGGL((k_composite_fwd<MODE, CB, 1>), dim3(nblk), dim3(256), 0, s, p);
   return (int)hipGetLastError();
 }
 template <int MODE, int CB>
 static int launch_bwd(const CompParams &p_, hipStream_t s) {
-  const int ppl = variants().ppl_bwd;
   CompParams p = p_;
   if (p.n_hi == 0) p.n_hi = 0x7fffffff;
   const uint32_t nblk = comp_grid(p);
@@ -1857,37 +1790,26 @@ static int launch_bwd(const CompParams &p_, hipStream_t s) {
     else {
       if (p.nseg > 1) return GSGEN_EUNSUPPORTED;
       p.sh_bound = nullptr;
-      if (p.tile_side == 8) hipLaunchKernelGGL((k_composite_bwd_pixel<MODE, CB, 1, false, 8>), dim3(nblk), dim3(64), 0, s, p, (const CompParams *)nullptr);
-      else hipLaunchKernelGGL((k_composite_bwd_pixel<MODE, CB, 4, false, 32>), dim3(nblk), dim3(256), 0, s, p, (const CompParams *)nullptr);
+      if (p.tile_side == 8) hipLaunchKernelGGL((k_composite_bwd_pixel<MODE, CB, 1, 8>), dim3(nblk), dim3(64), 0, s, p);
+      else hipLaunchKernelGGL((k_composite_bwd_pixel<MODE, CB, 4, 32>), dim3(nblk), dim3(256), 0, s, p);
       return (int)hipGetLastError();
     }
-  }
-  const uint32_t ng = nblk * (uint32_t)((MODE == MODE_SH && p.nseg > 1) ? p.nseg : 1);
-  if constexpr (MODE == MODE_SH && CB == 4) {
-    if (p.sh_bound != nullptr) {  // as the forward: one launch, routed on the device
-      hipLaunchKernelGGL((k_composite_bwd_sh_vec<4, 4, false, true, kRouted>), dim3(ng), dim3(64), 0, s, p, (const CompParams *)nullptr);
-      return (int)hipGetLastError();
-    }
-  } else {
-    p.sh_bound = nullptr;
   }
   if constexpr (MODE != MODE_SH) {
-    if (variants().chan_packed && ppl == 4) {  // default: packed per-pixel arithmetic, one wavefront per tile
-      hipLaunchKernelGGL((k_composite_bwd_chan_vec<MODE>), dim3(nblk), dim3(64), 0, s, p, (const CompParams *)nullptr);
-      return (int)hipGetLastError();
+    p.sh_bound = nullptr;
+    hipLaunchKernelGGL((k_composite_bwd_chan_vec<MODE>), dim3(nblk), dim3(64), 0, s, p, (const CompParams *)nullptr);
+  } else {
+    const uint32_t ng = nblk * (uint32_t)(p.nseg > 1 ? p.nseg : 1);
+    if constexpr (CB == 4) {
+      if (p.sh_bound != nullptr) {  // as the forward: one launch, routed on the device
+        hipLaunchKernelGGL((k_composite_bwd_sh_vec<4, 4, false, kRouted>), dim3(ng), dim3(64), 0, s, p, (const CompParams *)nullptr);
+        return (int)hipGetLastError();
+      }
+    } else {
+      p.sh_bound = nullptr;
     }
+    hipLaunchKernelGGL((k_composite_bwd_sh_vec<CB, 4>), dim3(ng), dim3(64), 0, s, p, (const CompParams *)nullptr);
   }
-  if constexpr (MODE == MODE_SH) {
-    if (variants().sh_packed && ppl != 1) {  // default SH backward: packed per-pixel arithmetic
-      if (ppl == 2) hipLaunchKernelGGL((k_composite_bwd_sh_vec<CB, 2>), dim3(ng), dim3(128), 0, s, p, (const CompParams *)nullptr);
-      else if (variants().sh_chred) hipLaunchKernelGGL((k_composite_bwd_sh_vec<CB, 4, false, true>), dim3(ng), dim3(64), 0, s, p, (const CompParams *)nullptr);
-      else hipLaunchKernelGGL((k_composite_bwd_sh_vec<CB, 4>), dim3(ng), dim3(64), 0, s, p, (const CompParams *)nullptr);
-      return (int)hipGetLastError();
-    }
-  }
-  if (ppl == 1) hipLaunchKernelGGL((k_composite_bwd_pixel<MODE, CB, 1>), dim3(ng), dim3(256), 0, s, p, (const CompParams *)nullptr);
-  else if (ppl == 2) hipLaunchKernelGGL((k_composite_bwd_pixel<MODE, CB, 2>), dim3(ng), dim3(128), 0, s, p, (const CompParams *)nullptr);
-  else hipLaunchKernelGGL((k_composite_bwd_pixel<MODE, CB, 4>), dim3(ng), dim3(64), 0, s, p, (const CompParams *)nullptr);
   return (int)hipGetLastError();
 }
 
@@ -1922,45 +1844,30 @@ int write_params(const CompParams *host, uint32_t B, CompParams *dst, hipStream_
 }
 template <int CB>
 static void launch_fwd_sh_batch_c(const CompParams &p0, const CompParams *plist, uint32_t B, uint32_t nblk, hipStream_t s, bool bounded) {
-  const int ppl = variants().ppl_fwd_batch;  // wavefronts per tile = 4 / ppl
   const dim3 g(nblk * B);
   if constexpr (CB == 4) {
-    // The views carry the device address of the coefficient bound: ONE launch of the routed kernel, in which every
-    // workgroup decides from the bound and ITS view's pixel size whether it runs the polynomial or the exact form
-    // (poly_route; forward and backward read the same value, hence agree).
+    // The views carry the device address of the coefficient bound: every workgroup decides from the bound and ITS view's pixel
+    // size which form renders the view (poly_route; forward and backward read the same value, hence agree).
     if (bounded) {
-      // polynomial kernel over the whole grid (one wavefront per tile: 96 registers, 5 per SIMD -- 5 020 vs 4 833 renders/s
-      // against two wavefronts per tile), then the persistent exact fallback for the views beyond the bound (10 two-wavefront
-      // workgroups per compute unit at most)
+      // the persistent exact fallback for the views beyond the bound (10 two-wavefront workgroups per compute unit at most), then
+      // the polynomial kernel over the whole grid (one wavefront per tile: 96 registers, 5 per SIMD -- 5 020 vs 4 833 renders/s
+      // against two wavefronts per tile in round 3, 5 448 vs 5 271 in round 4)
       CompParams pf = p0;
       pf.vgrid = nblk * B;
       const uint32_t gf = pf.vgrid < 2560u ? pf.vgrid : 2560u;
-      const int ppl_poly = variants().ppl_fwd_batch_poly;
       launch_beside(
           s, [&](hipStream_t q) { hipLaunchKernelGGL((k_composite_fwd_sh_vec<4, 2, true, kFallback>), dim3(gf), dim3(128), 0, q, pf, plist); },
-          [&](hipStream_t q) {
-            if (ppl_poly == 2) hipLaunchKernelGGL((k_composite_fwd_sh_vec<4, 2, true, kPolyNB>), g, dim3(128), 0, q, p0, plist);
-            else hipLaunchKernelGGL((k_composite_fwd_sh_vec<4, 4, true, kPolyNB>), g, dim3(64), 0, q, p0, plist);
-          });
+          [&](hipStream_t q) { hipLaunchKernelGGL((k_composite_fwd_sh_vec<4, 4, true, kPolyNB>), g, dim3(64), 0, q, p0, plist); });
       return;
     }
   }
-  if (variants().sh_packed && ppl != 1) {
-    if (ppl == 2) hipLaunchKernelGGL((k_composite_fwd_sh_vec<CB, 2, true>), g, dim3(128), 0, s, p0, plist);
-    else hipLaunchKernelGGL((k_composite_fwd_sh_vec<CB, 4, true>), g, dim3(64), 0, s, p0, plist);
-    return;
-  }
-  if (ppl == 1) hipLaunchKernelGGL((k_composite_fwd<MODE_SH, CB, 1, true>), g, dim3(256), 0, s, p0, plist);
-  else if (ppl == 2) hipLaunchKernelGGL((k_composite_fwd<MODE_SH, CB, 2, true>), g, dim3(128), 0, s, p0, plist);
-  else hipLaunchKernelGGL((k_composite_fwd<MODE_SH, CB, 4, true>), g, dim3(64), 0, s, p0, plist);
+  // exact basis: packed, two wavefronts per tile (a lone 8-view launch is 4 % slower than at four but issues fewer vector
+  // instructions, which is what counts with another batch's backward in flight: 3 010 vs 2 885 renders/s, round 2)
+  hipLaunchKernelGGL((k_composite_fwd_sh_vec<CB, 2, true>), g, dim3(128), 0, s, p0, plist);
 }
 static CompParams batch_arg(const CompParams &p0, uint32_t B) {
-  // measured (profiles/r01_notes.md): camera-major is as fast as either interleaving on cfg2 (2820-2860 vs
-  // 2790-2850 renders/s) and faster on the 64 random cameras of cfg4 (5440-5590 vs 5030 / 5290-5360: an
-  // interleaved B = 8 pins each camera to one XCD, and random cameras differ in work)
   CompParams a = p0;
-  a.n_lo = (int)B;
-  a.n_hi = variants().batch_map;
+  a.n_lo = (int)B;  // (the batched grids are camera-major: batch_view)
   return a;
 }
 int launch_fwd_sh_batch(int C, const CompParams &p0_, const CompParams *plist, uint32_t B, hipStream_t s, bool bounded) {
@@ -1980,26 +1887,19 @@ template <int CB>
 static void launch_bwd_sh_batch_c(const CompParams &p0, const CompParams *plist, uint32_t B, uint32_t nblk, hipStream_t s, bool bounded) {
   const dim3 g(nblk * B);
   if constexpr (CB == 4) {
-    if (bounded) {  // as the forward: the polynomial kernel (120 registers: 4 wavefronts per SIMD), then the persistent exact fallback
+    if (bounded) {  // as the forward: the persistent exact fallback, then the polynomial kernel (120 registers: 4 wavefronts per SIMD)
       CompParams pf = p0;
       pf.vgrid = nblk * B;
       const uint32_t gf = pf.vgrid < 2048u ? pf.vgrid : 2048u;  // 8 one-wavefront workgroups per compute unit (2 per SIMD)
       launch_beside(
-          s, [&](hipStream_t q) { hipLaunchKernelGGL((k_composite_bwd_sh_vec<4, 4, true, true, kFallback>), dim3(gf), dim3(64), 0, q, pf, plist); },
-          [&](hipStream_t q) { hipLaunchKernelGGL((k_composite_bwd_sh_vec<4, 4, true, true, kPolyNB>), g, dim3(64), 0, q, p0, plist); });
+          s, [&](hipStream_t q) { hipLaunchKernelGGL((k_composite_bwd_sh_vec<4, 4, true, kFallback>), dim3(gf), dim3(64), 0, q, pf, plist); },
+          [&](hipStream_t q) { hipLaunchKernelGGL((k_composite_bwd_sh_vec<4, 4, true, kPolyNB>), g, dim3(64), 0, q, p0, plist); });
       return;
     }
   }
-  const int ppl = variants().ppl_bwd_sh_batch;
-  if (variants().sh_packed && ppl != 1) {
-    if (ppl == 2) hipLaunchKernelGGL((k_composite_bwd_sh_vec<CB, 2, true>), g, dim3(128), 0, s, p0, plist);
-    else if (variants().sh_chred) hipLaunchKernelGGL((k_composite_bwd_sh_vec<CB, 4, true, true>), g, dim3(64), 0, s, p0, plist);
-    else hipLaunchKernelGGL((k_composite_bwd_sh_vec<CB, 4, true>), g, dim3(64), 0, s, p0, plist);
-    return;
-  }
-  if (ppl == 1) hipLaunchKernelGGL((k_composite_bwd_pixel<MODE_SH, CB, 1, true>), g, dim3(256), 0, s, p0, plist);
-  else if (ppl == 2) hipLaunchKernelGGL((k_composite_bwd_pixel<MODE_SH, CB, 2, true>), g, dim3(128), 0, s, p0, plist);
-  else hipLaunchKernelGGL((k_composite_bwd_pixel<MODE_SH, CB, 4, true>), g, dim3(64), 0, s, p0, plist);
+  // one wavefront per tile: the per-Gaussian gradient reduction costs the same per wavefront whatever the number of pixels behind
+  // it (two wavefronts per tile: 2 838 vs 3 492 renders/s on the exact basis, profiles/r04_ab_shapes.txt)
+  hipLaunchKernelGGL((k_composite_bwd_sh_vec<CB, 4, true>), g, dim3(64), 0, s, p0, plist);
 }
 int launch_bwd_sh_batch(int C, const CompParams &p0_, const CompParams *plist, uint32_t B, hipStream_t s, bool bounded) {
   const uint32_t nblk = comp_grid(p0_) * (uint32_t)(p0_.nseg > 1 ? p0_.nseg : 1);
@@ -2015,62 +1915,21 @@ int launch_bwd_sh_batch(int C, const CompParams &p0_, const CompParams *plist, u
   return (int)hipGetLastError();
 }
 
-// fused RGB + heads, B cameras per launch (4 wavefronts per tile forward, 2 backward)
-int launch_fwd_rgbd_batch(const CompParams &p0_, const CompParams *plist, uint32_t B, hipStream_t s) {
+// post-activation channels, B cameras per launch: packed, one wavefront per tile (the same operation sequence as the per-camera
+// kernels: identical bits).  MODE_RGBD = fused RGB + heads, MODE_RGB = colours only.
+template <int MODE>
+static int launch_chan_batch(bool backward, const CompParams &p0_, const CompParams *plist, uint32_t B, hipStream_t s) {
   const uint32_t nblk = comp_grid(p0_);
   if (p0_.ntw * p0_.nth == 0 || B == 0) return 0;
   const CompParams p0 = batch_arg(p0_, B);
-  if (variants().chan_packed) {  // default: packed per-pixel arithmetic, one wavefront per tile
-    hipLaunchKernelGGL((k_composite_fwd_chan_vec<MODE_RGBD, true>), dim3(nblk * B), dim3(64), 0, s, p0, plist);
-    return (int)hipGetLastError();
-  }
-  const int ppl = variants().ppl_fwd_batch;
-  if (ppl == 1) hipLaunchKernelGGL((k_composite_fwd<MODE_RGBD, 1, 1, true>), dim3(nblk * B), dim3(256), 0, s, p0, plist);
-  else if (ppl == 2) hipLaunchKernelGGL((k_composite_fwd<MODE_RGBD, 1, 2, true>), dim3(nblk * B), dim3(128), 0, s, p0, plist);
-  else hipLaunchKernelGGL((k_composite_fwd<MODE_RGBD, 1, 4, true>), dim3(nblk * B), dim3(64), 0, s, p0, plist);
+  if (backward) hipLaunchKernelGGL((k_composite_bwd_chan_vec<MODE, true>), dim3(nblk * B), dim3(64), 0, s, p0, plist);
+  else hipLaunchKernelGGL((k_composite_fwd_chan_vec<MODE, true>), dim3(nblk * B), dim3(64), 0, s, p0, plist);
   return (int)hipGetLastError();
 }
-int launch_bwd_rgbd_batch(const CompParams &p0_, const CompParams *plist, uint32_t B, hipStream_t s) {
-  const uint32_t nblk = comp_grid(p0_);
-  if (p0_.ntw * p0_.nth == 0 || B == 0) return 0;
-  const CompParams p0 = batch_arg(p0_, B);
-  // two wavefronts per tile: 6 087 / 3 588 views/s at 8 x 512^2 / 8 x 800^2 against 5 902 / 3 522 with one and
-  // 5 753 / 3 138 with four (tools/bench_batch.py --heads)
-  // ... all of them measured on the unpacked kernel; the packed one (default) runs one wavefront per tile
-  if (variants().chan_packed) {
-    hipLaunchKernelGGL((k_composite_bwd_chan_vec<MODE_RGBD, true>), dim3(nblk * B), dim3(64), 0, s, p0, plist);
-    return (int)hipGetLastError();
-  }
-  const int ppl = variants().ppl_bwd_batch;
-  if (ppl == 1) hipLaunchKernelGGL((k_composite_bwd_pixel<MODE_RGBD, 1, 1, true>), dim3(nblk * B), dim3(256), 0, s, p0, plist);
-  else if (ppl == 2) hipLaunchKernelGGL((k_composite_bwd_pixel<MODE_RGBD, 1, 2, true>), dim3(nblk * B), dim3(128), 0, s, p0, plist);
-  else hipLaunchKernelGGL((k_composite_bwd_pixel<MODE_RGBD, 1, 4, true>), dim3(nblk * B), dim3(64), 0, s, p0, plist);
-  return (int)hipGetLastError();
-}
-
-// post-activation RGB (C = 0), B cameras per launch
-int launch_fwd_rgb_batch(const CompParams &p0_, const CompParams *plist, uint32_t B, hipStream_t s) {
-  const uint32_t nblk = comp_grid(p0_);
-  if (p0_.ntw * p0_.nth == 0 || B == 0) return 0;
-  const CompParams p0 = batch_arg(p0_, B);
-  // packed, one wavefront per tile (default); same operation sequence as the per-camera kernel: identical bits
-  if (variants().chan_packed) hipLaunchKernelGGL((k_composite_fwd_chan_vec<MODE_RGB, true>), dim3(nblk * B), dim3(64), 0, s, p0, plist);
-  else hipLaunchKernelGGL((k_composite_fwd<MODE_RGB, 1, 1, true>), dim3(nblk * B), dim3(256), 0, s, p0, plist);
-  return (int)hipGetLastError();
-}
-int launch_bwd_rgb_batch(const CompParams &p0_, const CompParams *plist, uint32_t B, hipStream_t s) {
-  const uint32_t nblk = comp_grid(p0_);
-  if (p0_.ntw * p0_.nth == 0 || B == 0) return 0;
-  const CompParams p0 = batch_arg(p0_, B);
-  if (variants().chan_packed) {
-    hipLaunchKernelGGL((k_composite_bwd_chan_vec<MODE_RGB, true>), dim3(nblk * B), dim3(64), 0, s, p0, plist);
-    return (int)hipGetLastError();
-  }
-  const int ppl = variants().ppl_bwd_batch;
-  if (ppl == 4) hipLaunchKernelGGL((k_composite_bwd_pixel<MODE_RGB, 1, 4, true>), dim3(nblk * B), dim3(64), 0, s, p0, plist);
-  else hipLaunchKernelGGL((k_composite_bwd_pixel<MODE_RGB, 1, 2, true>), dim3(nblk * B), dim3(128), 0, s, p0, plist);
-  return (int)hipGetLastError();
-}
+int launch_fwd_rgbd_batch(const CompParams &p0, const CompParams *plist, uint32_t B, hipStream_t s) { return launch_chan_batch<MODE_RGBD>(false, p0, plist, B, s); }
+int launch_bwd_rgbd_batch(const CompParams &p0, const CompParams *plist, uint32_t B, hipStream_t s) { return launch_chan_batch<MODE_RGBD>(true, p0, plist, B, s); }
+int launch_fwd_rgb_batch(const CompParams &p0, const CompParams *plist, uint32_t B, hipStream_t s) { return launch_chan_batch<MODE_RGB>(false, p0, plist, B, s); }
+int launch_bwd_rgb_batch(const CompParams &p0, const CompParams *plist, uint32_t B, hipStream_t s) { return launch_chan_batch<MODE_RGB>(true, p0, plist, B, s); }
 
 int launch_bwd_pixel_dispatch(int mode, int C, const CompParams &p, hipStream_t s) {
   if (mode == MODE_RGB) return launch_bwd<MODE_RGB, 1>(p, s);
@@ -2090,71 +1949,34 @@ using namespace gs;
 
 extern "C" {
 
-/* Debugging hook (variant tests, A/B measurements inside one process): overrides one entry of the variant table.  Not
- * thread-safe against concurrent launches.  name: "ppl_fwd", "ppl_bwd", "ppl_fwd_poly", "ppl_fwd_batch", "ppl_bwd_batch",
- * "ppl_bwd_sh_batch", "batch_map", "sh_packed", "sh_chred", "chan_packed". */
-int gsgen_debug_set_variant(const char *name, int value) {
-  if (!name) return GSGEN_EINVAL;
-  Variants &v = variants();
-  const std::string n(name);
-  const bool ppl_ok = value == 1 || value == 2 || value == 4;
-  int *slot = nullptr;
-  bool ok = ppl_ok;
-  if (n == "ppl_fwd") slot = &v.ppl_fwd;
-  else if (n == "ppl_bwd") slot = &v.ppl_bwd;
-  else if (n == "ppl_fwd_batch") slot = &v.ppl_fwd_batch;
-  else if (n == "ppl_bwd_batch") slot = &v.ppl_bwd_batch;
-  else if (n == "ppl_bwd_sh_batch") slot = &v.ppl_bwd_sh_batch;
-  else if (n == "ppl_fwd_poly") { slot = &v.ppl_fwd_poly; ok = value == 2 || value == 4; }
-  else if (n == "ppl_fwd_batch_poly") { slot = &v.ppl_fwd_batch_poly; ok = value == 2 || value == 4; }
-  else if (n == "batch_map") { slot = &v.batch_map; ok = value >= 0 && value <= 2; }
-  else if (n == "sh_packed") { slot = &v.sh_packed; ok = value == 0 || value == 1; }
-  else if (n == "sh_chred") { slot = &v.sh_chred; ok = value == 0 || value == 1; }
-  else if (n == "chan_packed") { slot = &v.chan_packed; ok = value == 0 || value == 1; }
-  if (!slot || !ok) return GSGEN_EINVAL;
-  *slot = value;
-  return 0;
-}
-
-/* Name of the compositing kernel a launch of `stage` would run in this process ("sh_fwd", "sh_bwd", "sh_fwd_batch",
- * "sh_bwd_batch", "rgb_fwd", "rgb_bwd", "rgbd_fwd_batch", "rgbd_bwd_batch") at SH degree C-1, derived from the same
- * variant table the launchers use.  Returns the length written (excluding the terminator), 0 for an unknown stage. */
+/* Name of the compositing kernel a launch of `stage` runs ("sh_fwd", "sh_bwd", "sh_fwd_batch", "sh_bwd_batch" -- with the suffix
+ * "_poly" for an enqueue that carries the coefficient bound (SH degree 3) --, "rgb_fwd", "rgb_bwd", "rgbd_fwd_batch",
+ * "rgbd_bwd_batch") at SH degree C-1: one fixed shape per job since round 4 (launch helpers above).  Returns the length written
+ * (excluding the terminator), 0 for an unknown stage. */
 int gsgen_kernel_variant(const char *stage, uint32_t C, uint32_t n_segments, char *out, size_t out_bytes) {
   if (!stage || !out || out_bytes == 0) return 0;
-  const Variants &v = variants();
   const std::string st(stage);
   char buf[160];
   int n = 0;
-  // "<stage>_poly": the routed kernel of a bounded enqueue (SH degree 3): polynomial form of the per-pixel basis for the views
-  // whose error bound holds, exact form for the others; "<stage>": the exact kernel of an enqueue without a bound
-  const bool poly_stage = st.size() > 5 && st.compare(st.size() - 5, 5, "_poly") == 0;
-  const std::string base = poly_stage ? st.substr(0, st.size() - 5) : st;
-  auto sh_bwd = [&](int ppl, const char *b) {
-    if (poly_stage && C == 4)
-      return snprintf(buf, sizeof buf, b[0] ? "k_composite_bwd_sh_vec<C=4,PPL=4%s,CHRED,POLY6>%s + persistent exact fallback"
-                                            : "k_composite_bwd_sh_vec<C=4,PPL=4%s,CHRED,ROUTED:POLY6|exact>%s", b, n_segments > 1 ? " segmented" : "");
-    return snprintf(buf, sizeof buf, "%s<%sC=%u,PPL=%d%s%s>%s", (v.sh_packed && ppl != 1) ? "k_composite_bwd_sh_vec" : "k_composite_bwd_pixel",
-                    (v.sh_packed && ppl != 1) ? "" : "SH,", C, ppl, b, (v.sh_packed && ppl == 4 && v.sh_chred) ? ",CHRED" : "",
-                    n_segments > 1 ? " segmented" : "");
-  };
-  auto sh_fwd = [&](int ppl, int ppl_poly, const char *b) {
-    if (poly_stage && C == 4)
-      return snprintf(buf, sizeof buf, b[0] ? "k_composite_fwd_sh_vec<C=4,PPL=%d%s,POLY6> + persistent exact fallback"
-                                            : "k_composite_fwd_sh_vec<C=4,PPL=%d%s,ROUTED:POLY6|exact>", ppl_poly == 4 ? 4 : 2, b);
-    if (v.sh_packed && ppl != 1) return snprintf(buf, sizeof buf, "k_composite_fwd_sh_vec<C=%u,PPL=%d%s>", C, ppl, b);
-    return snprintf(buf, sizeof buf, "k_composite_fwd<SH,C=%u,PPL=%d%s>", C, ppl, b);
-  };
-  if (base == "sh_fwd") n = sh_fwd(v.ppl_fwd, v.ppl_fwd_poly, "");
-  else if (base == "sh_fwd_batch") n = sh_fwd(v.ppl_fwd_batch, v.ppl_fwd_batch_poly, ",BATCH");
-  else if (base == "sh_bwd") n = sh_bwd(v.ppl_bwd, "");
-  else if (base == "sh_bwd_batch") n = sh_bwd(v.ppl_bwd_sh_batch, ",BATCH");
-  else if (st == "rgb_fwd") n = snprintf(buf, sizeof buf, "k_composite_fwd<RGB,PPL=%d>", v.ppl_fwd);
-  else if (st == "rgb_bwd") n = (v.chan_packed && v.ppl_bwd == 4) ? snprintf(buf, sizeof buf, "k_composite_bwd_chan_vec<RGB>")
-                                                                   : snprintf(buf, sizeof buf, "k_composite_bwd_pixel<RGB,PPL=%d>", v.ppl_bwd);
-  else if (st == "rgbd_fwd_batch") n = v.chan_packed ? snprintf(buf, sizeof buf, "k_composite_fwd_chan_vec<RGBD,BATCH>")
-                                                     : snprintf(buf, sizeof buf, "k_composite_fwd<RGBD,PPL=%d,BATCH>", v.ppl_fwd_batch);
-  else if (st == "rgbd_bwd_batch") n = v.chan_packed ? snprintf(buf, sizeof buf, "k_composite_bwd_chan_vec<RGBD,BATCH>")
-                                                     : snprintf(buf, sizeof buf, "k_composite_bwd_pixel<RGBD,PPL=%d,BATCH>", v.ppl_bwd_batch);
+  const bool poly_stage = st.size() > 5 && st.compare(st.size() - 5, 5, "_poly") == 0 && C == 4;
+  const std::string base = (st.size() > 5 && st.compare(st.size() - 5, 5, "_poly") == 0) ? st.substr(0, st.size() - 5) : st;
+  const char *seg = n_segments > 1 ? " segmented" : "";
+  if (base == "sh_fwd")
+    n = poly_stage ? snprintf(buf, sizeof buf, "k_composite_fwd_sh_vec<C=4,PPL=2,ROUTED:POLY6|exact>")
+                   : snprintf(buf, sizeof buf, "k_composite_fwd<SH,C=%u,PPL=1>", C);
+  else if (base == "sh_fwd_batch")
+    n = poly_stage ? snprintf(buf, sizeof buf, "k_composite_fwd_sh_vec<C=4,PPL=4,BATCH,POLY6> + persistent exact fallback")
+                   : snprintf(buf, sizeof buf, "k_composite_fwd_sh_vec<C=%u,PPL=2,BATCH>", C);
+  else if (base == "sh_bwd")
+    n = poly_stage ? snprintf(buf, sizeof buf, "k_composite_bwd_sh_vec<C=4,PPL=4,ROUTED:POLY6|exact>%s", seg)
+                   : snprintf(buf, sizeof buf, "k_composite_bwd_sh_vec<C=%u,PPL=4>%s", C, seg);
+  else if (base == "sh_bwd_batch")
+    n = poly_stage ? snprintf(buf, sizeof buf, "k_composite_bwd_sh_vec<C=4,PPL=4,BATCH,POLY6>%s + persistent exact fallback", seg)
+                   : snprintf(buf, sizeof buf, "k_composite_bwd_sh_vec<C=%u,PPL=4,BATCH>%s", C, seg);
+  else if (st == "rgb_fwd") n = snprintf(buf, sizeof buf, "k_composite_fwd<RGB,PPL=1>");
+  else if (st == "rgb_bwd") n = snprintf(buf, sizeof buf, "k_composite_bwd_chan_vec<RGB>");
+  else if (st == "rgbd_fwd_batch") n = snprintf(buf, sizeof buf, "k_composite_fwd_chan_vec<RGBD,BATCH>");
+  else if (st == "rgbd_bwd_batch") n = snprintf(buf, sizeof buf, "k_composite_bwd_chan_vec<RGBD,BATCH>");
   else return 0;
   if (n < 0) return 0;
   if ((size_t)n >= out_bytes) n = (int)out_bytes - 1;

@@ -22,28 +22,6 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip_gpu)
 
 
-def _apply_test_variants():
-    """GSGEN_TEST_VARIANTS="ppl_fwd=4,ppl_bwd=2": the compositing kernels exist in several compiled shapes, selected through
-    gsgen_debug_set_variant (the library reads nothing from the environment).  tests/test_variants.py runs parts of this
-    suite in a subprocess with another shape; this hook applies it to every library handle the tests open (the HIP library
-    and the emulator build alike)."""
-    spec = os.environ.get("GSGEN_TEST_VARIANTS", "")
-    if not spec:
-        return
-    from gsgen_amd import _capi
-    pairs = [kv.split("=") for kv in spec.split(",") if kv]
-    init = _capi.Lib.__init__
-
-    def patched(self, path=None):
-        init(self, path)
-        for k, v in pairs:
-            self.set_variant(k, int(v))
-    _capi.Lib.__init__ = patched
-
-
-_apply_test_variants()
-
-
 def pytest_terminal_summary(terminalreporter):
     """what the parity helpers observed (tests/scenes.py: PARITY_LOG), whatever the capture mode: per frame the largest pixel
     error against the oracle and the number of pixels that needed the threshold-adjacent exception"""
