@@ -345,6 +345,12 @@ def main():
                     help="multi-GPU: images (default) = one all_gather of the step's rendered images per step, as north_star "
                          "asks; the same timed region WITHOUT the gather is reported next to it as `value_no_gather`, so that "
                          "compute scaling and xGMI cost separate.  none: no gather in the headline either")
+    ap.add_argument("--focal-scale", type=float, default=1.0,
+                    help="stress test of the SH routing: every camera's focal length times this (0.7 = the widest camera of BASELINE "
+                         "configs[3]: under round 3's per-view rule such views fell back to the exact kernels)")
+    ap.add_argument("--outlier-fraction", type=float, default=0.0,
+                    help="stress test of the SH routing: this fraction of the splats gets its higher-band SH coefficients multiplied by "
+                         "60 (beyond any view's bound): their tiles go to the exact kernel, the others stay polynomial")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the one-render-in-flight and hipGraph passes")
     args = ap.parse_args()
@@ -396,6 +402,10 @@ def main():
 
     lib = _capi.load()
     sc, W, H = make_workload(args.config)
+    if args.outlier_fraction > 0.0:
+        rng_o = np.random.default_rng(99)
+        pick = rng_o.choice(sc["sh"].shape[0], max(1, int(round(args.outlier_fraction * sc["sh"].shape[0]))), replace=False)
+        sc["sh"][pick, :, 1:] *= 60.0
     C = sc["C"]
     N = sc["mean"].shape[0]
     K, nseg = max(1, args.steps), max(1, args.segments)
@@ -404,7 +414,7 @@ def main():
     # Gaussians and 2.5 M pairs per view (cfg3) two cameras per launch beat eight (profiles/r02_notes.md); light launches
     # (< 5.2 M pairs: the 512^2 views of cfg4, cfg3's pairs of cameras) overlap better three deep than two
     # (cfg4: 6 988 vs 6 661 renders/s; cfg2, 5.7 M pairs per launch: 3 372 vs 3 368)
-    zoom = 12.0 if dry else 1.0  # (the dry run's few splats sit in a narrow view: the routed kernels take their polynomial form)
+    zoom = (12.0 if dry else 1.0) * args.focal_scale  # (the dry run's few splats sit in a narrow view: the routed kernels take their polynomial form)
     pose_split = args.config in ("cfg4", "dry4")
     probe_cam = (random_pose_cameras(64, rank, world, W, H, zoom=zoom) if pose_split else camera_poses(1, rank, W, H, zoom))[0]
     pb = R.FrameBuffers(N, W, H, dev)
@@ -466,8 +476,11 @@ def main():
                 self.g3d = torch.empty(N * 10, device=dev)
                 self.seg_ws = [torch.empty(max(1, lib.segment_workspace_bytes(nth * ntw, nseg)), device=dev, dtype=torch.uint8)
                                for _ in range(B)]
-                self.bws = torch.empty(lib.sh_batch_workspace_bytes(B), device=dev, dtype=torch.uint8)
-                self.bound = torch.zeros(1, device=dev)  # S of the step's coefficients (gsgen_sh_l1_bound), read by its launches
+                self.bws = torch.zeros(lib.sh_batch_workspace_bytes_routed(B, nth * ntw), device=dev, dtype=torch.uint8)
+                # the step's own measurement of its coefficients (gsgen_sh_l1_bound_rows): per-splat bounds the launches route on
+                # PER TILE, and their maximum (reported; the per-view rule of round 3 routed on it)
+                self.bound = torch.zeros(1, device=dev)
+                self.rows = torch.zeros(N, device=dev)
                 self.gws = torch.empty(lib.frame_batch_workspace_bytes(B), device=dev, dtype=torch.uint8)
                 self.gathered = torch.empty(world, B, H, W, 3, device=dev) if dist is not None else None
                 if want_heads:
@@ -584,14 +597,14 @@ def main():
             stream.wait_event(sl.e_gathered)
             sl.gather_pending = False
         geometry(sl, geo, p(sl.g_shared), sl.n_shared)
-        bound_p = None
+        rows_p = None
         if state["bounded"]:  # the step's own measurement of its coefficients: one pass, on the step's stream, no sync
-            clock.call("sh_bound", lib.sh_l1_bound, N, p(t["sh"]), C, p(sl.bound), s)
-            bound_p = p(sl.bound)
+            clock.call("sh_bound", lib.sh_l1_bound_rows, N, p(t["sh"]), C, p(sl.bound), p(sl.rows), s)
+            rows_p = p(sl.rows)
         if ev is not None:
             clock.call("events", ev[0].record, stream)
-        clock.call("composite_fwd", lib.vol_render_sh_batch_bounded, B, views, N, p(t["sh"]), p(t["alpha"]), 16, nth, ntw, H, W, C,
-                   1e-4, seg_arg, bound_p, p(sl.bws), s)
+        clock.call("composite_fwd", lib.vol_render_sh_batch_routed, B, views, N, p(t["sh"]), p(t["alpha"]), 16, nth, ntw, H, W, C,
+                   1e-4, seg_arg, None, rows_p, p(sl.bws), s)
         if ev is not None:
             clock.call("events", ev[1].record, stream)
         if sl.gathered is not None and gather and state["gather"]:
@@ -610,8 +623,8 @@ def main():
             clock.acc["zero_grads"] = clock.acc.get("zero_grads", 0.0) + time.perf_counter() - t0
         if ev is not None:
             clock.call("events", ev[2].record, stream)
-        clock.call("composite_bwd", lib.vol_render_backward_sh_batch_bounded, B, views, N, p(t["sh"]), p(t["alpha"]), p(sl.g_sh),
-                   p(sl.g_alpha), 16, nth, ntw, H, W, C, 1e-4, seg_arg, bound_p, p(sl.bws), s)
+        clock.call("composite_bwd", lib.vol_render_backward_sh_batch_routed, B, views, N, p(t["sh"]), p(t["alpha"]), p(sl.g_sh),
+                   p(sl.g_alpha), 16, nth, ntw, H, W, C, 1e-4, seg_arg, None, rows_p, p(sl.bws), s)
         if ev is not None:
             clock.call("events", ev[3].record, stream)
         clock.call("project_bwd", lib.project_gaussians_backward_batch, B, N, p(t["mean"]), p(t["qvec"]), p(t["svec"]), *proj,
@@ -737,7 +750,21 @@ def main():
         n_poly_job, ncam_job = int(pc[0].item()), int(pc[1].item())
     else:
         n_poly_job, ncam_job = n_poly, ncam
-    poly_applies = n_poly_job > 0
+    # ... and per TILE (round 4): the flag bytes the polynomial forward of each slot's last step left (1 = the tile went to the
+    # exact kernel because a splat it staged exceeds the bound for its view's pixel size)
+    tiles_exact = tiles_nonempty = 0
+    if state["bounded"]:
+        for sl_ in slots:
+            o_ = lib.sh_batch_workspace_bytes(B)
+            fl_ = sl_.bws[o_:o_ + B * nth * ntw].view(B, nth * ntw)
+            ne_ = torch.stack([(b_.end > b_.start) & (b_.start >= 0) for b_ in sl_.bufs]).view(B, -1)
+            tiles_exact += int((fl_.bool() & ne_).sum().item())
+            tiles_nonempty += int(ne_.sum().item())
+        if dist is not None:
+            tc = torch.tensor([tiles_exact, tiles_nonempty], device=dev)
+            dist.all_reduce(tc)
+            tiles_exact, tiles_nonempty = int(tc[0].item()), int(tc[1].item())
+    poly_applies = state["bounded"] and tiles_exact < max(1, tiles_nonempty)
     # per-rank throughput of the reported region (the driver's scaling record can see that N ranks took part)
     per_rank = [value / world]
     if dist is not None:
@@ -877,26 +904,26 @@ def main():
             lib.frame_geometry(N, p(t["mean"]), p(t["qvec"]), p(t["svec"]), p(cam_dev[k]), W, H, b0.D_cap, p(b0.mean2d),
                                p(b0.cov2d), p(b0.depth), p(b0.mask), p(b0.ids), p(b0.start), p(b0.end), p(b0.total), p(b0.ws),
                                b0.ws.numel(), s)
-            bound_p = None
+            rows_p = None
             if state["bounded"]:
-                lib.sh_l1_bound(N, p(t["sh"]), C, p(sl0.bound), s)
-                bound_p = p(sl0.bound)
+                lib.sh_l1_bound_rows(N, p(t["sh"]), C, p(sl0.bound), p(sl0.rows), s)
+                rows_p = p(sl0.rows)
             if ev is not None:
                 ev[0].record(stream)
-            lib.vol_render_sh_bounded(N, b0.D_cap, p(b0.mean2d), p(b0.cov2d), p(t["sh"]), p(t["alpha"]), p(b0.start), p(b0.end),
-                                      p(b0.ids), p(sl0.out[0]), p(topleft_dev[k]), p(rot_dev[k]), 16, nth, ntw, 1.0 / cis[k].fx,
-                                      1.0 / cis[k].fy, H, W, C, 1e-4, p(bg), None, order_, p(lseg_ws), lseg_arg, bound_p, s)
+            lib.vol_render_sh_routed(N, b0.D_cap, p(b0.mean2d), p(b0.cov2d), p(t["sh"]), p(t["alpha"]), p(b0.start), p(b0.end),
+                                     p(b0.ids), p(sl0.out[0]), p(topleft_dev[k]), p(rot_dev[k]), 16, nth, ntw, 1.0 / cis[k].fx,
+                                     1.0 / cis[k].fy, H, W, C, 1e-4, p(bg), None, order_, p(lseg_ws), lseg_arg, None, rows_p, s)
             if ev is not None:
                 ev[1].record(stream)
             with gpu.stream(stream):
                 g1.zero_()
             if ev is not None:
                 ev[2].record(stream)
-            lib.vol_render_backward_sh_bounded(N, b0.D_cap, p(b0.mean2d), p(b0.cov2d), p(t["sh"]), p(t["alpha"]), p(b0.start),
-                                               p(b0.end), p(b0.ids), p(sl0.out[0]), p(g1_mean2d), p(g1_cov2d), p(g1_sh),
-                                               p(g1_alpha), p(grad_out), p(topleft_dev[k]), p(rot_dev[k]), 16, nth, ntw,
-                                               1.0 / cis[k].fx, 1.0 / cis[k].fy, H, W, C, 1e-4, p(bg), order_,
-                                               p(lseg_ws), lseg_arg, bound_p, s)
+            lib.vol_render_backward_sh_routed(N, b0.D_cap, p(b0.mean2d), p(b0.cov2d), p(t["sh"]), p(t["alpha"]), p(b0.start),
+                                              p(b0.end), p(b0.ids), p(sl0.out[0]), p(g1_mean2d), p(g1_cov2d), p(g1_sh),
+                                              p(g1_alpha), p(grad_out), p(topleft_dev[k]), p(rot_dev[k]), 16, nth, ntw,
+                                              1.0 / cis[k].fx, 1.0 / cis[k].fy, H, W, C, 1e-4, p(bg), order_,
+                                              p(lseg_ws), lseg_arg, None, rows_p, s)
             if ev is not None:
                 ev[3].record(stream)
             lib.project_gaussians_backward_masked(N, p(t["mean"]), p(t["qvec"]), p(t["svec"]), p(cam_dev[k]), 1, p(b0.mask),
@@ -1033,11 +1060,14 @@ def main():
                    "sh_degree": C - 1, "tile_pairs_D": D, "list_length_histogram": list_hist, "cameras_per_step": B,
                    "steps_in_flight": len(slots),
                    "backward_segments_per_tile": nseg,
-                   "sh_basis": (f"routed on the device, per view and per step: the coefficient bound is measured by every step inside the "
-                                f"timed region (gsgen_sh_l1_bound; read back afterwards: S = {S_dev:.3f}) and {n_poly_job} of {ncam_job} "
-                                f"cameras took the tile-local degree-2 polynomial fit of the per-pixel basis (error bound "
-                                f"{0.25 * S_dev * 0.7 * (7.5 * 2 ** 0.5 * max(ps_cam)) ** 3:.1e} of a colour value at the widest "
-                                f"camera, limit 1e-5), the others the exact kernel") if state["bounded"] else "exact per-pixel basis",
+                   "sh_basis": (f"routed on the device, per TILE and per step: per-splat coefficient bounds are measured by every step inside "
+                                f"the timed region (gsgen_sh_l1_bound_rows; read back afterwards: largest S = {S_dev:.3f}); a tile takes the "
+                                f"tile-local degree-2 polynomial fit of the per-pixel basis while every splat it stages stays within the "
+                                f"bound for its view's pixel size, else the exact kernel: {tiles_exact} of {tiles_nonempty} non-empty tiles "
+                                f"of the slots' last steps went exact.  (Round 3's per-view rule on the global S: {n_poly_job} of "
+                                f"{ncam_job} cameras polynomial.)") if state["bounded"] else "exact per-pixel basis",
+                   "tiles_exact_of_nonempty": [tiles_exact, tiles_nonempty],
+                   "stress": {"focal_scale": args.focal_scale, "outlier_fraction": args.outlier_fraction},
                    "geometry_stream": "high priority, per slot" if args.geo_priority else "the slot's stream",
                    "parallelism": f"camera-sharded x{world}", "rccl_world_size": (dist.get_world_size() if dist is not None else 1),
                    "renders_per_s_per_rank": per_rank,

@@ -63,6 +63,14 @@ SIGNATURES = {
                                                C.POINTER(vp), C.POINTER(vp), vp, vp, vp, vp],
     "gsgen_project_gaussians_backward_batch_heads": [u32, u32, vp, vp, vp, C.POINTER(vp), i32, C.POINTER(vp), C.POINTER(vp),
                                                      C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp, vp, vp, vp, vp],
+    "gsgen_sh_l1_bound_rows": [u32, vp, u32, vp, vp, vp],
+    "gsgen_vol_render_sh_batch_routed": [u32, C.POINTER(ShView), u32, vp, vp, u32, u32, u32, u32, u32, u32, f32, u32, vp, vp, vp, vp],
+    "gsgen_vol_render_backward_sh_batch_routed": [u32, C.POINTER(ShView), u32, vp, vp, vp, vp, u32, u32, u32, u32, u32, u32, f32, u32,
+                                                  vp, vp, vp, vp],
+    "gsgen_vol_render_sh_routed": [u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, u32, f32, f32, u32, u32, u32, f32,
+                                   vp, vp, vp, vp, u32, vp, vp, vp],
+    "gsgen_vol_render_backward_sh_routed": [u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, u32,
+                                            f32, f32, u32, u32, u32, f32, vp, vp, vp, u32, vp, vp, vp],
     "gsgen_pack_camera": [vp, f32, f32, f32, f32, u32, u32, C.c_double, C.c_double, f32, f32, vp],
     "gsgen_upload_small": [vp, vp, sz, vp],
     "gsgen_pack_camera_blocks": [u32, vp, u32, vp, f32, f32, vp],
@@ -115,6 +123,7 @@ SIZE_FUNCS = {
     "gsgen_frame_workspace_bytes": [u32, u32, u32],
     "gsgen_segment_workspace_bytes": [u32, u32],
     "gsgen_sh_batch_workspace_bytes": [u32],
+    "gsgen_sh_batch_workspace_bytes_routed": [u32, u32],
     "gsgen_frame_batch_workspace_bytes": [u32],
     "gsgen_legacy_sort_workspace_bytes": [u32, u32],
 }

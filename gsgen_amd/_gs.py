@@ -217,10 +217,11 @@ _bound_cache = {}
 
 
 def _sh_bound(sh_coeffs, C, tile_size, reuse=False):
-    """SH degree 3: S = max sum_{k >= 1} |sh| of the call's coefficients, measured on the device in front of the launch (one
-    5-us pass, no sync) into a scratch float; the kernels route on it -- the tile-local polynomial form of the per-pixel basis
-    where its error bound holds, the exact kernel elsewhere (include/gsgen_hip.h, "the coefficient bound").  None otherwise,
-    and with SH_BASIS == "exact".  reuse: the backward of a frame takes the bound its forward left for these coefficients."""
+    """SH degree 3: the per-splat bounds S_i = max_c sum_{k >= 1} |sh[i][c][k]| of the call's coefficients, measured on the device
+    in front of the launch (one ~10-us pass, no sync) into a scratch tensor [N]; the kernels route PER TILE on them -- the
+    tile-local polynomial form of the per-pixel basis for the tiles whose splats stay within the bound, the exact kernel for the
+    others (include/gsgen_hip.h, "per-TILE routing").  None otherwise, and with SH_BASIS == "exact".  reuse: the backward of a
+    frame takes the bounds its forward left for these coefficients."""
     if SH_BASIS == "exact" or int(C) != 4 or int(tile_size) != 16 or sh_coeffs.numel() == 0:
         return None
     key = (sh_coeffs.device, sh_coeffs.data_ptr(), sh_coeffs.numel())
@@ -229,8 +230,8 @@ def _sh_bound(sh_coeffs, C, tile_size, reuse=False):
         hit = _bound_cache.get(key)
         if hit is not None and hit[0] == ver:
             return hit[1]
-    bound = torch.empty(1, device=sh_coeffs.device, dtype=torch.float32)
-    _load().sh_l1_bound(sh_coeffs.numel() // 48, _p(sh_coeffs), 4, _p(bound), _stream(sh_coeffs))
+    bound = torch.empty(sh_coeffs.numel() // 48, device=sh_coeffs.device, dtype=torch.float32)  # per SPLAT: routed per tile
+    _load().sh_l1_bound_rows(sh_coeffs.numel() // 48, _p(sh_coeffs), 4, None, _p(bound), _stream(sh_coeffs))
     if len(_bound_cache) > 64:
         _bound_cache.clear()
     _bound_cache[key] = (ver, bound)
@@ -247,11 +248,11 @@ def _sh_fwd(mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out, topleft,
         return  # the reference's switch silently does nothing (render.cu:507-544)
     with _guard(mean):
         bound = _sh_bound(sh_coeffs, C, tile_size)
-        _load().vol_render_sh_bounded(
+        _load().vol_render_sh_routed(
             mean.size(0), gaussian_ids.size(0), _p(mean), _p(cov), _p(sh_coeffs), _p(alpha), _p(start),
             _p(end), _p(gaussian_ids), _p(out), _p(topleft), _p(c2w), int(tile_size), int(n_tiles_h),
             int(n_tiles_w), float(pixel_size_x), float(pixel_size_y), int(H), int(W), int(C),
-            float(thresh), _p(bg_rgb), None, None, None, 0, _p(bound), _stream(mean))
+            float(thresh), _p(bg_rgb), None, None, None, 0, None, _p(bound), _stream(mean))
 
 
 def _sh_bwd(mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out, grad_mean, grad_cov,
@@ -268,12 +269,12 @@ def _sh_bwd(mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out, grad_mea
         return
     with _guard(mean):
         bound = _sh_bound(sh_coeffs, C, tile_size, reuse=True)  # the forward's own device value: the same routing
-        _load().vol_render_backward_sh_bounded(
+        _load().vol_render_backward_sh_routed(
             mean.size(0), gaussian_ids.size(0), _p(mean), _p(cov), _p(sh_coeffs), _p(alpha), _p(start),
             _p(end), _p(gaussian_ids), _p(out), _p(grad_mean), _p(grad_cov), _p(grad_sh_coeffs),
             _p(grad_alpha), _p(grad_out), _p(topleft), _p(c2w), int(tile_size), int(n_tiles_h),
             int(n_tiles_w), float(pixel_size_x), float(pixel_size_y), int(H), int(W), int(C),
-            float(thresh), _p(bg_rgb), None, None, 0, _p(bound), _stream(mean))
+            float(thresh), _p(bg_rgb), None, None, 0, None, _p(bound), _stream(mean))
 
 
 def tile_based_vol_rendering_sh(mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out, topleft,

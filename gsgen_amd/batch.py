@@ -74,7 +74,7 @@ class _render_batch(torch.autograd.Function):
         out = torch.zeros(B, H, W, 3, device=dev, dtype=torch.float32)
         T = torch.ones(B, H, W, 1, device=dev, dtype=torch.float32)
         cams_p, out_p, T_p = cams.data_ptr(), out.data_ptr(), T.data_ptr()
-        cur = br._fork(B, (cams, out, T) + ((br._sh_bound,) if br._sh_bound is not None else ()))
+        cur = br._fork(B, (cams, out, T) + tuple(x for x in (br._sh_bound, br._sh_rows) if x is not None))
         with torch.cuda.device(dev):
             for i in range(B):
                 buf, s, ci = br.slots[i], br.streams[i % len(br.streams)].cuda_stream, br._cis[i]
@@ -86,11 +86,11 @@ class _render_batch(torch.autograd.Function):
                 if stats is not None:
                     lib.densify_update(N, _p(buf.cov2d), None, _p(buf.mask), _p(stats.max_radii2d), None, None, s)
                 if C > 0:
-                    lib.vol_render_sh_bounded(N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col), _p(alpha),
-                                              _p(buf.start), _p(buf.end), _p(buf.ids), out_p + 12 * H * W * i, cam + 224,
-                                              cam + 232, 16, buf.nth, buf.ntw, psx, psy, H, W, C, thresh,
-                                              _p(bg_rgb), T_p + 4 * H * W * i, buf.tile_order(), None, 0,
-                                              _p(br._sh_bound), s)
+                    lib.vol_render_sh_routed(N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col), _p(alpha),
+                                             _p(buf.start), _p(buf.end), _p(buf.ids), out_p + 12 * H * W * i, cam + 224,
+                                             cam + 232, 16, buf.nth, buf.ntw, psx, psy, H, W, C, thresh,
+                                             _p(bg_rgb), T_p + 4 * H * W * i, buf.tile_order(), None, 0,
+                                             _p(br._sh_bound), _p(br._sh_rows), s)
                 else:
                     lib.vol_render_start_end_with_T(N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col), _p(alpha),
                                                     _p(buf.start), _p(buf.end), _p(buf.ids), out_p + 12 * H * W * i,
@@ -104,7 +104,7 @@ class _render_batch(torch.autograd.Function):
         ctx.save_for_backward(mean, qvec, svec, alpha, col, cams, out, T)
         ctx.bg_shape = tuple(bg_rgb.shape) if (bg_rgb is not None and ctx.needs_input_grad[9]) else None
         ctx.br, ctx.B, ctx.C, ctx.thresh, ctx.detach, ctx.stats = br, B, C, thresh, detach_depth, stats
-        ctx.sh_bound = br._sh_bound  # forward and backward of a batch route on the same device value
+        ctx.sh_bound, ctx.sh_rows = br._sh_bound, br._sh_rows  # forward and backward of a batch route on the same device values
         ctx.cis = list(br._cis[:B])
         ctx.mark_non_differentiable(T)
         return out, T
@@ -146,8 +146,8 @@ class _render_batch(torch.autograd.Function):
                 lib.densify_update_batch(B, N, br._ptr_table("cov2d", B), None, br._mask_table(B), _p(stats.max_radii2d), None,
                                          None, s)
             if C > 0:
-                lib.vol_render_sh_batch_bounded(B, views, N, _p(col), _p(alpha), 16, br.slots[0].nth, br.slots[0].ntw, H, W, C,
-                                                thresh, br.segments, _p(br._sh_bound), _p(br._bws), s)
+                lib.vol_render_sh_batch_routed(B, views, N, _p(col), _p(alpha), 16, br.slots[0].nth, br.slots[0].ntw, H, W, C,
+                                               thresh, br.segments, _p(br._sh_bound), _p(br._sh_rows), _p(br._bws), s)
             else:
                 lib.vol_render_rgb_batch(B, views, N, _p(col), _p(alpha), 16, br.slots[0].nth, br.slots[0].ntw, H, W,
                                          thresh, _p(br._bws), s)
@@ -159,7 +159,7 @@ class _render_batch(torch.autograd.Function):
         ctx.save_for_backward(mean, qvec, svec, alpha, col, cams, out, T)
         ctx.bg_shape = tuple(bg_rgb.shape) if (bg_rgb is not None and ctx.needs_input_grad[9]) else None
         ctx.br, ctx.B, ctx.C, ctx.thresh, ctx.detach, ctx.stats = br, B, C, thresh, detach_depth, stats
-        ctx.sh_bound = br._sh_bound  # forward and backward of a batch route on the same device value
+        ctx.sh_bound, ctx.sh_rows = br._sh_bound, br._sh_rows  # forward and backward of a batch route on the same device values
         ctx.cis = list(br._cis[:B])
         ctx.mark_non_differentiable(T)
         return out, T
@@ -190,9 +190,9 @@ class _render_batch(torch.autograd.Function):
                 views[i].grad_out6 = grad_p + 12 * H * W * i
         with _on(dev):
             if C > 0:
-                lib.vol_render_backward_sh_batch_bounded(B, views, N, _p(col), _p(alpha), _p(g_col), _p(g_alpha), 16,
-                                                         br.slots[0].nth, br.slots[0].ntw, H, W, C, thresh, br.segments,
-                                                         _p(ctx.sh_bound), _p(br._bws), s)
+                lib.vol_render_backward_sh_batch_routed(B, views, N, _p(col), _p(alpha), _p(g_col), _p(g_alpha), 16,
+                                                        br.slots[0].nth, br.slots[0].ntw, H, W, C, thresh, br.segments,
+                                                        _p(ctx.sh_bound), _p(ctx.sh_rows), _p(br._bws), s)
             else:
                 lib.vol_render_rgb_backward_batch(B, views, N, _p(col), _p(alpha), _p(g_col), _p(g_alpha), 16,
                                                   br.slots[0].nth, br.slots[0].ntw, H, W, thresh, _p(br._bws), s)
@@ -220,7 +220,7 @@ class _render_batch(torch.autograd.Function):
         g_svec, g_alpha = g3d[7 * N:10 * N].view(N, 3), g3d[10 * N:]
         g_col = torch.zeros_like(col)
         cams_p, out_p, grad_p, g2d_p = cams.data_ptr(), out.data_ptr(), grad.data_ptr(), g2d.data_ptr()
-        cur = br._fork(B, (grad, g2d, g3d, g_col) + ((ctx.sh_bound,) if ctx.sh_bound is not None else ()))
+        cur = br._fork(B, (grad, g2d, g3d, g_col) + tuple(x for x in (ctx.sh_bound, ctx.sh_rows) if x is not None))
         with torch.cuda.device(dev):
             for i in range(B):
                 buf, s, ci = br.slots[i], br.streams[i % len(br.streams)].cuda_stream, ctx.cis[i]
@@ -229,12 +229,12 @@ class _render_batch(torch.autograd.Function):
                 g_cov2d = g_mean2d + 8 * N
                 psx, psy = 1.0 / ci.fx, 1.0 / ci.fy
                 if C > 0:
-                    lib.vol_render_backward_sh_bounded(N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col), _p(alpha),
-                                                       _p(buf.start), _p(buf.end), _p(buf.ids), out_p + 12 * H * W * i,
-                                                       g_mean2d, g_cov2d, _p(g_col), _p(g_alpha),
-                                                       grad_p + 12 * H * W * i, cam + 224, cam + 232, 16, buf.nth,
-                                                       buf.ntw, psx, psy, H, W, C, thresh, None, buf.tile_order(), None, 0,
-                                                       _p(ctx.sh_bound), s)
+                    lib.vol_render_backward_sh_routed(N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col), _p(alpha),
+                                                      _p(buf.start), _p(buf.end), _p(buf.ids), out_p + 12 * H * W * i,
+                                                      g_mean2d, g_cov2d, _p(g_col), _p(g_alpha),
+                                                      grad_p + 12 * H * W * i, cam + 224, cam + 232, 16, buf.nth,
+                                                      buf.ntw, psx, psy, H, W, C, thresh, None, buf.tile_order(), None, 0,
+                                                      _p(ctx.sh_bound), _p(ctx.sh_rows), s)
                 else:
                     lib.vol_render_backward_start_end(N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col), _p(alpha),
                                                       _p(buf.start), _p(buf.end), _p(buf.ids), out_p + 12 * H * W * i,
@@ -432,7 +432,7 @@ class BatchRenderer:
         # an overflowing scene overflows in the following batches too, so sampling delays the report by a few batches)
         self.monitor_every, self._tick = 4, 0
         self._generation = 0
-        self._sh_bound = None
+        self._sh_bound = self._sh_rows = None
         self._table_cache = {}
         # the slots' depth buffers are the rows of one matrix (the heads' backward reads depths[:B] as one tensor)
         self._depths = torch.empty(max_batch, N, device=device, dtype=torch.float32)
@@ -449,10 +449,11 @@ class BatchRenderer:
         lib = _capi.load()
         self._Np = (N + 3) // 4 * 4
         self._cams = torch.empty(max_batch, 68, device=device, dtype=torch.float32)
-        self._nb_sh = lib.sh_batch_workspace_bytes(max_batch)
+        nth_, ntw_ = R.n_tiles(H, W)
+        self._nb_sh = lib.sh_batch_workspace_bytes_routed(max_batch, nth_ * ntw_)  # parameter tables + per-tile routing flags
         self._bws = torch.empty(self._nb_sh + lib.frame_batch_workspace_bytes(max_batch), device=device, dtype=torch.uint8)
         self._g2d = torch.empty(max_batch, 12 * self._Np, device=device, dtype=torch.float32)
-        self._bound = torch.zeros(1, device=device, dtype=torch.float32)  # S of the batch in flight (gsgen_sh_l1_bound)
+        self._rows = torch.zeros(N, device=device, dtype=torch.float32)  # per-splat bounds of the batch in flight (gsgen_sh_l1_bound_rows)
         # per camera: cam block (56) | topleft (2) | rotation rows (9) | pad -> 68 floats, packed on the host and sent
         # through kernel arguments (gsgen_upload_small): no pinned ring, no copy event, the host never waits
         self._host = np.zeros((max_batch, 68), np.float32)
@@ -640,7 +641,7 @@ class BatchRenderer:
                 raise ValueError("every camera of a batch must have the renderer's (W, H)")
         cams = self._upload(cam_infos, c2ws, frustum_radius, tile_radius)
         self._cis = list(cam_infos)
-        self._sh_bound = None
+        self._sh_bound = self._sh_rows = None
         if int(C) == 4 and sh_basis == "auto":
             if sh_l1_bound is not None:
                 if not (isinstance(sh_l1_bound, torch.Tensor) and sh_l1_bound.is_cuda and sh_l1_bound.dtype == torch.float32
@@ -650,19 +651,20 @@ class BatchRenderer:
                 if verify_bound:
                     R.verify_sh_l1_bound(col, sh_l1_bound)
                 self._sh_bound = sh_l1_bound
-            else:
-                self._sh_bound = self._measure_bound(col)
+            else:  # per-splat bounds: the launches route per tile on them
+                self._sh_rows = self._measure_bound(col)
         return _render_batch.apply(mean, qvec, svec, alpha, col, cams, self, B, int(C), bg_rgb, float(thresh),
                                    bool(detach_depth), stats)
 
     def _measure_bound(self, col):
-        """renderer.sh_l1_bound_device into the renderer's own float (read by this batch's forward and backward only)"""
-        if col.dim() != 3 or col.shape[1] != 3 or col.shape[2] != 16 or col.dtype != torch.float32 or not col.is_contiguous():
-            return R.sh_l1_bound_device(col)  # (other layouts: the checked path)
+        """renderer.sh_row_bounds_device into the renderer's own [N] floats (read by this batch's forward and backward only)"""
+        if col.dim() != 3 or col.shape[1] != 3 or col.shape[2] != 16 or col.dtype != torch.float32 or not col.is_contiguous() \
+                or col.shape[0] != self.N:
+            return R.sh_row_bounds_device(col)  # (other layouts: the checked path)
         with _on(self.device):
-            _capi.load().sh_l1_bound(col.shape[0], col.data_ptr(), 4, self._bound.data_ptr(),
-                                     torch.cuda.current_stream(self.device).cuda_stream)
-        return self._bound
+            _capi.load().sh_l1_bound_rows(self.N, col.data_ptr(), 4, None, self._rows.data_ptr(),
+                                          torch.cuda.current_stream(self.device).cuda_stream)
+        return self._rows
 
     def render_heads(self, mean, qvec, svec, alpha, color, cam_infos, c2ws, bg_rgb=None, thresh=1e-4,
                      frustum_radius=6.0, tile_radius=6.0, detach_depth=True, stats=None):
@@ -678,6 +680,15 @@ class BatchRenderer:
         self._cis = list(cam_infos)
         return _render_batch_heads.apply(mean, qvec, svec, alpha, color, cams, self, B, bg_rgb, float(thresh),
                                          bool(detach_depth), stats)
+
+    def routing_flags(self, B):
+        """uint8 [B, n_tiles] (a view of the batch workspace): what the last SH degree-3 batch's polynomial forward decided per
+        tile -- 1 = a splat the tile staged exceeds the bound for the view's pixel size, the exact kernel rendered it; 0 = the
+        polynomial form (empty tiles: 0).  Reports and tests only; reading it synchronises like any tensor read."""
+        lib = _capi.load()
+        T = self.slots[0].nth * self.slots[0].ntw
+        o = lib.sh_batch_workspace_bytes(B)  # (behind the two parameter tables of a B-view batch)
+        return self._bws[o:o + B * T].view(B, T)
 
     def ensure_capacity(self, B=None):
         """One host sync: grows any slot whose pair list overflowed in the last batch.  Returns

@@ -405,6 +405,9 @@ __device__ __forceinline__ void composite_fwd_sh_vec_tile(const CompParams &p, u
     valid[j] = (gx < p.W) && (gy[j] < p.H);
     stop[j] = valid[j] ? n : 0;
   }
+  if constexpr (POLY) {  // (per-tile routing: this tile is the polynomial kernel's until a staged batch says otherwise)
+    if (t == 0 && p.tile_flags != nullptr) p.tile_flags[tile] = 0;
+  }
   if (n == 0) {  // uniform over the workgroup
     if (p.bg != nullptr || p.fill_empty) {  // vol_render_bg.h:34-53: empty tiles show the background
 #pragma unroll
@@ -471,9 +474,18 @@ __device__ __forceinline__ void composite_fwd_sh_vec_tile(const CompParams &p, u
     const int nb = min(KB, n - base);
     if (base > 0) __syncthreads();  // everyone is done with the previous batch
     stage_batch<MODE, CB, NT, KB, true, !POLY>(S, p, st + base, nb);
-    __syncthreads();
     if constexpr (POLY) {
+      // per-tile routing: a staged splat beyond the bound for this view's pixel size sends the WHOLE tile to the exact
+      // kernel (nothing has been written yet; CompParams::tile_flags).  The test rides on the barrier that was here anyway.
+      bool bad = false;
+      if (p.sh_rows != nullptr && t < nb) bad = !poly_row_ok(p.sh_rows[S.id[t]], fmaxf(fabsf(p.psx), fabsf(p.psy)));
+      if (__syncthreads_or((int)bad) != 0) {
+        if (t == 0 && p.tile_flags != nullptr) p.tile_flags[tile] = 1;
+        return;
+      }
       poly_transform<NT, KB>(p.col, S.id, Vs, Ws, nb);
+      __syncthreads();
+    } else {
       __syncthreads();
     }
 
@@ -640,8 +652,30 @@ __device__ __forceinline__ void composite_fwd_sh_vec_tile(const CompParams &p, u
 //                                  after a handful of scalar loads per workgroup) and otherwise strides over the batch's
 //                                  (view, tile) grid, skipping the views the polynomial kernel took.
 constexpr int kFallback = -2;
+// Per-camera launches that route per TILE (CompParams::sh_rows without tile_flags): does every splat of the tile's list satisfy
+// the bound for this view's pixel size?  All threads of the workgroup call it (it ends in a barrier); forward and backward scan
+// the same list, hence take the same form.  `bid`: the workgroup's index in the view's tile grid.
+__device__ __forceinline__ bool tile_list_within_bound(const CompParams &p, uint32_t bid) {
+  int tx, ty;
+  if (!block_tile(p, tx, ty, bid)) return true;  // (no tile: the body leaves at once either way)
+  const int tile = ty * p.ntw + tx;
+  const int st = p.start[tile];
+  const int n = (st < 0) ? 0 : (p.end[tile] - st);
+  const float ps = fmaxf(fabsf(p.psx), fabsf(p.psy));
+  bool bad = false;
+  for (int k = (int)threadIdx.x; k < n; k += (int)blockDim.x) bad |= !poly_row_ok(p.sh_rows[p.ids[st + k]], ps);
+  return __syncthreads_or((int)bad) == 0;
+}
+// which tile does workgroup `bid` of a view's grid render, and is it flagged for the exact kernel?  (persistent fallback, per-tile
+// routing)
+__device__ __forceinline__ bool tile_flagged(const CompParams &p, uint32_t bid) {
+  int tx, ty;
+  if (!block_tile(p, tx, ty, bid)) return false;
+  return p.tile_flags[ty * p.ntw + tx] != 0;
+}
 template <int CB, int PPL, bool BATCH = false, int NB = 0>
 __global__ void __launch_bounds__(256 / PPL)
+GS_WAVES_PER_EU((NB == kPolyNB && BATCH && PPL == 4) ? 5 : 1)  // the batched polynomial forward: five wavefronts per SIMD (<= 96 registers)
 k_composite_fwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
   uint32_t bid = blockIdx.x;
   if constexpr (NB == kRouted) {
@@ -652,7 +686,8 @@ k_composite_fwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
     };
     __shared__ Shared sm;
     const CompParams *pp = BATCH ? &plist[batch_view(p_arg, bid)] : &p_arg;  // (see k_composite_bwd_sh_vec)
-    if (poly_route(pp->sh_bound, pp->psx, pp->psy)) {
+    const bool poly = pp->sh_rows != nullptr ? tile_list_within_bound(*pp, bid) : poly_route(pp->sh_bound, pp->psx, pp->psy);
+    if (poly) {
       const CompParams p = *pp;
       composite_fwd_sh_vec_tile<4, PPL, kPolyNB>(p, bid, sm.poly);
     } else {
@@ -663,15 +698,20 @@ k_composite_fwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
     static_assert(CB == 4 && BATCH, "the persistent exact fallback of a bounded batch");
     __shared__ FwdShVecShared<4, false> sm;
     const uint32_t B = (uint32_t)p_arg.n_lo, total = p_arg.vgrid;
-    bool any = false;
-    for (uint32_t v = 0; v < B; ++v) any |= !poly_route(plist[v].sh_bound, plist[v].psx, plist[v].psy);
-    if (!any) return;  // every view of the batch took the polynomial form
+    const bool per_tile = plist[0].sh_rows != nullptr;  // (one mode per launch)
+    if (!per_tile) {
+      bool any = false;
+      for (uint32_t v = 0; v < B; ++v) any |= !poly_route(plist[v].sh_bound, plist[v].psx, plist[v].psy);
+      if (!any) return;  // every view of the batch took the polynomial form
+    }
     const uint32_t per = total / B;  // camera-major
     uint32_t base = 0;  // first block of the view b lies in (b only grows: no division in the loop)
     const CompParams *pp = plist;
     for (uint32_t b = blockIdx.x; b < total; b += gridDim.x) {
       while (b >= base + per) { base += per; ++pp; }
-      if (poly_route(pp->sh_bound, pp->psx, pp->psy)) continue;
+      // per-view routing: the views the polynomial kernel left; per-tile routing (this launch runs BEHIND the polynomial
+      // kernel): the tiles it flagged
+      if (per_tile ? !tile_flagged(*pp, b - base) : poly_route(pp->sh_bound, pp->psx, pp->psy)) continue;
       const CompParams p = *pp;
       composite_fwd_sh_vec_tile<4, PPL, 0, true>(p, b - base, sm);
       __syncthreads();  // the LDS block is reused by the next tile
@@ -679,7 +719,7 @@ k_composite_fwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
   } else if constexpr (NB == kPolyNB && BATCH) {
     __shared__ FwdShVecShared<4, true> sm;
     const CompParams *pp = &plist[batch_view(p_arg, bid)];
-    if (!poly_route(pp->sh_bound, pp->psx, pp->psy)) return;  // this view is the exact fallback's
+    if (pp->sh_rows == nullptr && !poly_route(pp->sh_bound, pp->psx, pp->psy)) return;  // this view is the exact fallback's
     const CompParams p = *pp;
     composite_fwd_sh_vec_tile<4, PPL, kPolyNB>(p, bid, sm);
   } else {
@@ -986,6 +1026,9 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
   const int st = p.start[tile];
   const int n = (st < 0) ? 0 : (p.end[tile] - st);
   if (n == 0 || n < p.n_lo || n >= p.n_hi) return;
+  if constexpr (POLY) {  // per-tile routing: the forward sent this tile to the exact kernel (CompParams::tile_flags)
+    if (p.tile_flags != nullptr && p.tile_flags[tile] != 0) return;
+  }
   const int e_lo = seg * kSegLen;
   const int e_hi = (seg == nseg - 1) ? n : min(n, e_lo + kSegLen);  // the last segment takes the rest
   if (e_lo >= n) return;
@@ -1380,7 +1423,10 @@ k_composite_bwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
     // neither carries the scalar registers of the other's fields across the branch (merged naively, the batched
     // instantiation ran out of scalar registers and came out ONE vector register over the 168 of three wavefronts per SIMD).
     const CompParams *pp = BATCH ? &plist[batch_view(p_arg, bid, &grid)] : &p_arg;
-    if (poly_route(pp->sh_bound, pp->psx, pp->psy)) {
+    // (segmented launches: workgroup = (tile, segment), tile index = bid modulo the view's tile grid)
+    const uint32_t tiles_grid = grid / (uint32_t)(pp->nseg > 1 ? pp->nseg : 1);
+    const bool poly = pp->sh_rows != nullptr ? tile_list_within_bound(*pp, bid % tiles_grid) : poly_route(pp->sh_bound, pp->psx, pp->psy);
+    if (poly) {
       const CompParams p = *pp;
       composite_bwd_sh_vec_tile<4, 4, kPolyNB>(p, bid, grid, sm.poly);
     } else {
@@ -1391,15 +1437,19 @@ k_composite_bwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
     static_assert(CB == 4 && PPL == 4 && BATCH, "the persistent exact fallback of a bounded batch");
     __shared__ BwdShVecShared<4, 4, false> sm;
     const uint32_t B = (uint32_t)p_arg.n_lo, total = p_arg.vgrid;
-    bool any = false;
-    for (uint32_t v = 0; v < B; ++v) any |= !poly_route(plist[v].sh_bound, plist[v].psx, plist[v].psy);
-    if (!any) return;
+    const bool per_tile = plist[0].sh_rows != nullptr;
+    if (!per_tile) {
+      bool any = false;
+      for (uint32_t v = 0; v < B; ++v) any |= !poly_route(plist[v].sh_bound, plist[v].psx, plist[v].psy);
+      if (!any) return;
+    }
     const uint32_t per = total / B;  // camera-major
+    const uint32_t tiles_grid = per / (uint32_t)(plist[0].nseg > 1 ? plist[0].nseg : 1);
     uint32_t base = 0;  // first block of the view b lies in (b only grows: no division in the loop)
     const CompParams *pp = plist;
     for (uint32_t b = blockIdx.x; b < total; b += gridDim.x) {
       while (b >= base + per) { base += per; ++pp; }
-      if (poly_route(pp->sh_bound, pp->psx, pp->psy)) continue;
+      if (per_tile ? !tile_flagged(*pp, (b - base) % tiles_grid) : poly_route(pp->sh_bound, pp->psx, pp->psy)) continue;
       const CompParams p = *pp;
       composite_bwd_sh_vec_tile<4, 4, 0, true>(p, b - base, per, sm);
       __syncthreads();
@@ -1407,7 +1457,7 @@ k_composite_bwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
   } else if constexpr (NB == kPolyNB && BATCH) {
     __shared__ BwdShVecShared<4, 4, true> sm;
     const CompParams *pp = &plist[batch_view(p_arg, bid, &grid)];
-    if (!poly_route(pp->sh_bound, pp->psx, pp->psy)) return;  // this view is the exact fallback's
+    if (pp->sh_rows == nullptr && !poly_route(pp->sh_bound, pp->psx, pp->psy)) return;  // this view is the exact fallback's
     const CompParams p = *pp;
     composite_bwd_sh_vec_tile<4, 4, kPolyNB>(p, bid, grid, sm);
   } else {
@@ -1760,7 +1810,7 @@ static int launch_fwd(const CompParams &p_, hipStream_t s) {
     if constexpr (MODE == MODE_RGBD) return GSGEN_EUNSUPPORTED;
     else {
       if (p.nseg > 1) return GSGEN_EUNSUPPORTED;
-      p.sh_bound = nullptr;  // the polynomial basis is fitted to 16 x 16 tiles
+      p.sh_bound = p.sh_rows = nullptr;  // the polynomial basis is fitted to 16 x 16 tiles
       if (p.tile_side == 8) hipLaunchKernelGGL((k_composite_fwd<MODE, CB, 1, 8>), dim3(nblk), dim3(64), 0, s, p);
       else hipLaunchKernelGGL((k_composite_fwd<MODE, CB, 4, 32>), dim3(nblk), dim3(256), 0, s, p);
       return (int)hipGetLastError();
@@ -1769,12 +1819,12 @@ static int launch_fwd(const CompParams &p_, hipStream_t s) {
   if constexpr (MODE == MODE_SH && CB == 4) {
     // with the coefficient bound: ONE launch of the routed kernel -- every workgroup reads the bound and runs the polynomial
     // form of the per-pixel basis where its error bound holds, the exact form elsewhere (poly_route)
-    if (p.sh_bound != nullptr) {
+    if (p.sh_bound != nullptr || p.sh_rows != nullptr) {
       hipLaunchKernelGGL((k_composite_fwd_sh_vec<4, 2, false, kRouted>), dim3(nblk), dim3(128), 0, s, p, (const CompParams *)nullptr);
       return (int)hipGetLastError();
     }
   } else {
-    p.sh_bound = nullptr;
+    p.sh_bound = p.sh_rows = nullptr;
   }
   hipLaunchKernelGGL((k_composite_fwd<MODE, CB, 1>), dim3(nblk), dim3(256), 0, s, p);
   return (int)hipGetLastError();
@@ -1789,7 +1839,7 @@ static int launch_bwd(const CompParams &p_, hipStream_t s) {
     if constexpr (MODE == MODE_RGBD) return GSGEN_EUNSUPPORTED;
     else {
       if (p.nseg > 1) return GSGEN_EUNSUPPORTED;
-      p.sh_bound = nullptr;
+      p.sh_bound = p.sh_rows = nullptr;
       if (p.tile_side == 8) hipLaunchKernelGGL((k_composite_bwd_pixel<MODE, CB, 1, 8>), dim3(nblk), dim3(64), 0, s, p);
       else hipLaunchKernelGGL((k_composite_bwd_pixel<MODE, CB, 4, 32>), dim3(nblk), dim3(256), 0, s, p);
       return (int)hipGetLastError();
@@ -1801,12 +1851,12 @@ static int launch_bwd(const CompParams &p_, hipStream_t s) {
   } else {
     const uint32_t ng = nblk * (uint32_t)(p.nseg > 1 ? p.nseg : 1);
     if constexpr (CB == 4) {
-      if (p.sh_bound != nullptr) {  // as the forward: one launch, routed on the device
+      if (p.sh_bound != nullptr || p.sh_rows != nullptr) {  // as the forward: one launch, routed on the device
         hipLaunchKernelGGL((k_composite_bwd_sh_vec<4, 4, false, kRouted>), dim3(ng), dim3(64), 0, s, p, (const CompParams *)nullptr);
         return (int)hipGetLastError();
       }
     } else {
-      p.sh_bound = nullptr;
+      p.sh_bound = p.sh_rows = nullptr;
     }
     hipLaunchKernelGGL((k_composite_bwd_sh_vec<CB, 4>), dim3(ng), dim3(64), 0, s, p, (const CompParams *)nullptr);
   }
@@ -1855,6 +1905,11 @@ static void launch_fwd_sh_batch_c(const CompParams &p0, const CompParams *plist,
       CompParams pf = p0;
       pf.vgrid = nblk * B;
       const uint32_t gf = pf.vgrid < 2560u ? pf.vgrid : 2560u;
+      if (p0.sh_rows != nullptr) {  // per-tile routing: the polynomial kernel flags the tiles the fallback BEHIND it renders
+        hipLaunchKernelGGL((k_composite_fwd_sh_vec<4, 4, true, kPolyNB>), g, dim3(64), 0, s, p0, plist);
+        hipLaunchKernelGGL((k_composite_fwd_sh_vec<4, 2, true, kFallback>), dim3(gf), dim3(128), 0, s, pf, plist);
+        return;
+      }
       launch_beside(
           s, [&](hipStream_t q) { hipLaunchKernelGGL((k_composite_fwd_sh_vec<4, 2, true, kFallback>), dim3(gf), dim3(128), 0, q, pf, plist); },
           [&](hipStream_t q) { hipLaunchKernelGGL((k_composite_fwd_sh_vec<4, 4, true, kPolyNB>), g, dim3(64), 0, q, p0, plist); });
@@ -1890,7 +1945,9 @@ static void launch_bwd_sh_batch_c(const CompParams &p0, const CompParams *plist,
     if (bounded) {  // as the forward: the persistent exact fallback, then the polynomial kernel (120 registers: 4 wavefronts per SIMD)
       CompParams pf = p0;
       pf.vgrid = nblk * B;
-      const uint32_t gf = pf.vgrid < 2048u ? pf.vgrid : 2048u;  // 8 one-wavefront workgroups per compute unit (2 per SIMD)
+      // 12 one-wavefront workgroups per compute unit (3 per SIMD: the exact body's occupancy at 152 registers) -- with per-tile
+      // routing this launch may carry a large share of the tiles (2 per SIMD until round 4, when it only ever took whole views)
+      const uint32_t gf = pf.vgrid < 3072u ? pf.vgrid : 3072u;
       launch_beside(
           s, [&](hipStream_t q) { hipLaunchKernelGGL((k_composite_bwd_sh_vec<4, 4, true, kFallback>), dim3(gf), dim3(64), 0, q, pf, plist); },
           [&](hipStream_t q) { hipLaunchKernelGGL((k_composite_bwd_sh_vec<4, 4, true, kPolyNB>), g, dim3(64), 0, q, p0, plist); });
@@ -2078,6 +2135,19 @@ int gsgen_vol_render_sh_bounded(uint32_t N, uint32_t D, const float *mean, const
                                 uint32_t W, uint32_t C, float thresh, const float *bg_rgb, float *T,
                                 const uint32_t *tile_order, void *segment_workspace, uint32_t n_segments,
                                 const float *sh_l1_bound, gsgen_stream_t stream) {
+  return gsgen_vol_render_sh_routed(N, D, mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out, topleft, c2w, tile_size,
+                                    n_tiles_h, n_tiles_w, pixel_size_x, pixel_size_y, H, W, C, thresh, bg_rgb, T, tile_order,
+                                    segment_workspace, n_segments, sh_l1_bound, nullptr, stream);
+}
+
+int gsgen_vol_render_sh_routed(uint32_t N, uint32_t D, const float *mean, const float *cov,
+                               const float *sh_coeffs, const float *alpha, const int *start,
+                               const int *end, const int *gaussian_ids, float *out, const float *topleft,
+                               const float *c2w, uint32_t tile_size, uint32_t n_tiles_h,
+                               uint32_t n_tiles_w, float pixel_size_x, float pixel_size_y, uint32_t H,
+                               uint32_t W, uint32_t C, float thresh, const float *bg_rgb, float *T,
+                               const uint32_t *tile_order, void *segment_workspace, uint32_t n_segments,
+                               const float *sh_l1_bound, const float *sh_row_bounds, gsgen_stream_t stream) {
   if (int e = check_common(tile_size, start, end, out)) return e;
   if (n_segments > 1 && segment_workspace == nullptr) return GSGEN_EINVAL;
   if (C < 1 || C > 4) return GSGEN_EUNSUPPORTED;  // reference dispatches C = 1..4 only (render.cu:507-544)
@@ -2090,7 +2160,8 @@ int gsgen_vol_render_sh_bounded(uint32_t N, uint32_t D, const float *mean, const
   p.ntw = (int)n_tiles_w; p.nth = (int)n_tiles_h; p.H = (int)H; p.W = (int)W;
   p.psx = pixel_size_x; p.psy = pixel_size_y; p.thresh = thresh; p.tile_side = (int)tile_size;
   p.tile_order = tile_order;
-  p.sh_bound = (C == 4) ? sh_l1_bound : nullptr;
+  p.sh_bound = (C == 4 && sh_row_bounds == nullptr) ? sh_l1_bound : nullptr;
+  p.sh_rows = (C == 4) ? sh_row_bounds : nullptr;  // (per-tile routing wins over the per-view bound)
   if (n_segments > 1) {
     p.nseg = (int)n_segments;
     p.ckpt = reinterpret_cast<float4 *>(segment_workspace);
@@ -2109,7 +2180,8 @@ int gsgen_vol_render_sh_bounded(uint32_t N, uint32_t D, const float *mean, const
 static int fill_view_params(uint32_t n_views, const gsgen_sh_view *views, const float *sh_coeffs,
                             const float *alpha, float *g_sh, float *g_alpha, uint32_t ntw, uint32_t nth,
                             uint32_t H, uint32_t W, float thresh, uint32_t n_segments, bool backward,
-                            const float *sh_bound, std::vector<CompParams> &ps) {
+                            const float *sh_bound, std::vector<CompParams> &ps, const float *sh_rows = nullptr,
+                            uint8_t *tile_flags = nullptr) {
   ps.assign(n_views, CompParams{});
   for (uint32_t b = 0; b < n_views; ++b) {
     const gsgen_sh_view &v = views[b];
@@ -2124,7 +2196,9 @@ static int fill_view_params(uint32_t n_views, const gsgen_sh_view *views, const 
     p.psx = v.pixel_size_x; p.psy = v.pixel_size_y; p.thresh = thresh;
     p.tile_order = v.tile_order;
     p.n_hi = 0x7fffffff;
-    p.sh_bound = sh_bound;
+    p.sh_bound = sh_rows == nullptr ? sh_bound : nullptr;
+    p.sh_rows = sh_rows;
+    p.tile_flags = (sh_rows != nullptr && tile_flags != nullptr) ? tile_flags + (size_t)b * ntw * nth : nullptr;
     if (backward) {
       p.final_img = v.out; p.grad_out = v.grad_out;
       p.g_mean = v.grad_mean; p.g_cov = v.grad_cov; p.g_col = g_sh; p.g_alpha = g_alpha;
@@ -2213,6 +2287,54 @@ __global__ void __launch_bounds__(256) k_sh_l1_rows(uint32_t n_rows, const float
   sh_l1_finish<CHECK>(vmax, bad, out, n_bad);
 }
 
+// The per-SPLAT form (per-tile routing): rows[i] = max over the three channels of splat i of sum_{k >= 1} |sh[i][c][k]|, and the
+// global maximum as before.  SH degree 3: 192 threads take 16 splats per iteration -- one float4 per thread, perfectly coalesced
+// (a splat is 12 float4s), partial sums through LDS, 16 threads finish the splats.  No atomics but the one per workgroup.
+__global__ void __launch_bounds__(192) k_sh_l1_splats16(uint32_t N, const float4 *__restrict__ sh, float *out, float *__restrict__ rows) {
+  __shared__ float part[192];
+  __shared__ float s_max[16];
+  const uint32_t t = threadIdx.x;
+  float vmax = 0.0f;
+  for (uint32_t base = blockIdx.x * 16u; base < N; base += gridDim.x * 16u) {  // (uniform trip count: barriers inside)
+    const size_t i = (size_t)base * 12u + t;
+    const float4 q = i < (size_t)N * 12u ? sh[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    part[t] = ((t & 3u) ? fabsf(q.x) : 0.0f) + fabsf(q.y) + fabsf(q.z) + fabsf(q.w);  // (12 = 3 rows of 4 quarters: t & 3 = quarter)
+    __syncthreads();
+    if (t < 16u) {
+      const float *r = &part[12u * t];
+      const float s0 = (r[0] + r[1]) + (r[2] + r[3]), s1 = (r[4] + r[5]) + (r[6] + r[7]), s2 = (r[8] + r[9]) + (r[10] + r[11]);
+      float m = fmaxf(fmaxf(s0, s1), s2);
+      if (!(s0 == s0) || !(s1 == s1) || !(s2 == s2)) m = 3.0e38f;  // NaN coefficients: no bound (never passes poly_row_ok)
+      if (base + t < N) { rows[base + t] = m; vmax = fmaxf(vmax, m); }
+    }
+    __syncthreads();
+  }
+  if (t < 16u) s_max[t] = vmax;
+  __syncthreads();
+  if (t == 0 && out != nullptr) {
+    float m = s_max[0];
+    for (int k = 1; k < 16; ++k) m = fmaxf(m, s_max[k]);
+    if (m > 0.0f && m > *reinterpret_cast<volatile float *>(out)) atomicMax(reinterpret_cast<unsigned int *>(out), __float_as_uint(m));
+  }
+}
+// any SH degree: one splat per thread
+__global__ void __launch_bounds__(256) k_sh_l1_splats(uint32_t N, const float *__restrict__ sh, int CC, float *out, float *__restrict__ rows) {
+  float vmax = 0.0f;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < N; i += gridDim.x * 256u) {
+    float m = 0.0f;
+    for (int c = 0; c < 3; ++c) {
+      const float *q = sh + ((size_t)i * 3 + c) * CC;
+      float v = 0.0f;
+      for (int k = 1; k < CC; ++k) v += fabsf(q[k]);
+      if (!(v == v)) v = 3.0e38f;
+      m = fmaxf(m, v);
+    }
+    rows[i] = m;
+    vmax = fmaxf(vmax, m);
+  }
+  if (out != nullptr) sh_l1_finish<false>(vmax, 0u, out, nullptr);
+}
+
 template <bool CHECK>
 static int sh_l1_pass(uint32_t N, const float *sh_coeffs, uint32_t C, float *out, const float *bound, uint32_t *n_bad,
                       hipStream_t s) {
@@ -2240,6 +2362,25 @@ int gsgen_sh_l1_bound(uint32_t N, const float *sh_coeffs, uint32_t C, float *out
   return sh_l1_pass<false>(N, sh_coeffs, C, out, nullptr, nullptr, (hipStream_t)stream);
 }
 
+int gsgen_sh_l1_bound_rows(uint32_t N, const float *sh_coeffs, uint32_t C, float *out_max, float *out_rows, gsgen_stream_t stream) {
+  if (C < 1 || C > 4) return GSGEN_EUNSUPPORTED;
+  if (N && (!sh_coeffs || !out_rows)) return GSGEN_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (out_max != nullptr)
+    if (hipError_t e = hipMemsetAsync(out_max, 0, 4, s)) return (int)e;
+  if (N == 0) return 0;
+  if (C == 4 && (reinterpret_cast<uintptr_t>(sh_coeffs) & 15u) == 0) {
+    const uint32_t nb = (N + 15u) / 16u;
+    hipLaunchKernelGGL(k_sh_l1_splats16, dim3(nb < 1024u ? nb : 1024u), dim3(192), 0, s, N, reinterpret_cast<const float4 *>(sh_coeffs),
+                       out_max, out_rows);
+  } else {
+    const uint32_t nb = (N + 255u) / 256u;
+    hipLaunchKernelGGL(k_sh_l1_splats, dim3(nb < kBoundBlocks ? nb : kBoundBlocks), dim3(256), 0, s, N, sh_coeffs, (int)(C * C), out_max,
+                       out_rows);
+  }
+  return (int)hipGetLastError();
+}
+
 int gsgen_sh_l1_bound_check(uint32_t N, const float *sh_coeffs, uint32_t C, const float *bound, uint32_t *n_violations,
                             gsgen_stream_t stream) {
   return sh_l1_pass<true>(N, sh_coeffs, C, nullptr, bound, n_violations, (hipStream_t)stream);
@@ -2260,6 +2401,10 @@ static bool batch_can_be_polynomial(const std::vector<CompParams> &ps) {
 }
 
 size_t gsgen_sh_batch_workspace_bytes(uint32_t n_views) { return 2 * (size_t)n_views * sizeof(CompParams); }
+// ... + one flag byte per (view, tile) for the per-tile routing of the *_routed entry points
+size_t gsgen_sh_batch_workspace_bytes_routed(uint32_t n_views, uint32_t n_tiles) {
+  return gsgen_sh_batch_workspace_bytes(n_views) + (((size_t)n_views * n_tiles + 15u) & ~(size_t)15u);
+}
 
 int gsgen_vol_render_sh_batch(uint32_t n_views, const gsgen_sh_view *views, uint32_t N,
                               const float *sh_coeffs, const float *alpha, uint32_t tile_size,
@@ -2275,6 +2420,15 @@ int gsgen_vol_render_sh_batch_bounded(uint32_t n_views, const gsgen_sh_view *vie
                                       uint32_t n_tiles_h, uint32_t n_tiles_w, uint32_t H, uint32_t W, uint32_t C,
                                       float thresh, uint32_t n_segments, const float *sh_l1_bound, void *batch_workspace,
                                       gsgen_stream_t stream) {
+  return gsgen_vol_render_sh_batch_routed(n_views, views, N, sh_coeffs, alpha, tile_size, n_tiles_h, n_tiles_w, H, W, C, thresh,
+                                          n_segments, sh_l1_bound, nullptr, batch_workspace, stream);
+}
+
+int gsgen_vol_render_sh_batch_routed(uint32_t n_views, const gsgen_sh_view *views, uint32_t N,
+                                     const float *sh_coeffs, const float *alpha, uint32_t tile_size,
+                                     uint32_t n_tiles_h, uint32_t n_tiles_w, uint32_t H, uint32_t W, uint32_t C,
+                                     float thresh, uint32_t n_segments, const float *sh_l1_bound, const float *sh_row_bounds,
+                                     void *batch_workspace, gsgen_stream_t stream) {
   if (tile_size != 16) return GSGEN_EUNSUPPORTED;
   if (C < 1 || C > 4) return GSGEN_EUNSUPPORTED;
   if (n_views == 0) return 0;
@@ -2282,12 +2436,14 @@ int gsgen_vol_render_sh_batch_bounded(uint32_t n_views, const gsgen_sh_view *vie
   if (n_views > 65535) return GSGEN_EINVAL;
   (void)N;
   std::vector<CompParams> ps;
+  // (per-tile routing: the flag bytes sit behind the two parameter tables of gsgen_sh_batch_workspace_bytes_routed)
+  uint8_t *flags = reinterpret_cast<uint8_t *>(batch_workspace) + gsgen_sh_batch_workspace_bytes(n_views);
   if (int e = fill_view_params(n_views, views, sh_coeffs, alpha, nullptr, nullptr, n_tiles_w, n_tiles_h, H, W,
-                               thresh, n_segments, false, C == 4 ? sh_l1_bound : nullptr, ps))
+                               thresh, n_segments, false, C == 4 ? sh_l1_bound : nullptr, ps, C == 4 ? sh_row_bounds : nullptr, flags))
     return e;
-  const bool bounded = C == 4 && sh_l1_bound != nullptr && batch_can_be_polynomial(ps);
+  const bool bounded = C == 4 && (sh_l1_bound != nullptr || sh_row_bounds != nullptr) && batch_can_be_polynomial(ps);
   if (!bounded)
-    for (CompParams &p : ps) p.sh_bound = nullptr;
+    for (CompParams &p : ps) { p.sh_bound = nullptr; p.sh_rows = nullptr; p.tile_flags = nullptr; }
   hipStream_t s = (hipStream_t)stream;
   CompParams *dst = reinterpret_cast<CompParams *>(batch_workspace);
   if (int e = write_params(ps.data(), n_views, dst, s)) return e;
@@ -2310,18 +2466,31 @@ int gsgen_vol_render_backward_sh_batch_bounded(uint32_t n_views, const gsgen_sh_
                                                uint32_t n_tiles_w, uint32_t H, uint32_t W, uint32_t C, float thresh,
                                                uint32_t n_segments, const float *sh_l1_bound, void *batch_workspace,
                                                gsgen_stream_t stream) {
+  return gsgen_vol_render_backward_sh_batch_routed(n_views, views, N, sh_coeffs, alpha, grad_sh_coeffs, grad_alpha, tile_size,
+                                                   n_tiles_h, n_tiles_w, H, W, C, thresh, n_segments, sh_l1_bound, nullptr,
+                                                   batch_workspace, stream);
+}
+
+int gsgen_vol_render_backward_sh_batch_routed(uint32_t n_views, const gsgen_sh_view *views, uint32_t N,
+                                              const float *sh_coeffs, const float *alpha, float *grad_sh_coeffs,
+                                              float *grad_alpha, uint32_t tile_size, uint32_t n_tiles_h,
+                                              uint32_t n_tiles_w, uint32_t H, uint32_t W, uint32_t C, float thresh,
+                                              uint32_t n_segments, const float *sh_l1_bound, const float *sh_row_bounds,
+                                              void *batch_workspace, gsgen_stream_t stream) {
   if (tile_size != 16) return GSGEN_EUNSUPPORTED;
   if (C < 1 || C > 4) return GSGEN_EUNSUPPORTED;
   if (n_views == 0 || N == 0) return 0;
   if (!views || !batch_workspace || !grad_sh_coeffs || !grad_alpha) return GSGEN_EINVAL;
   if (n_views > 65535) return GSGEN_EINVAL;
   std::vector<CompParams> ps;
+  uint8_t *flags = reinterpret_cast<uint8_t *>(batch_workspace) + gsgen_sh_batch_workspace_bytes(n_views);  // (the forward's)
   if (int e = fill_view_params(n_views, views, sh_coeffs, alpha, grad_sh_coeffs, grad_alpha, n_tiles_w,
-                               n_tiles_h, H, W, thresh, n_segments, true, C == 4 ? sh_l1_bound : nullptr, ps))
+                               n_tiles_h, H, W, thresh, n_segments, true, C == 4 ? sh_l1_bound : nullptr, ps,
+                               C == 4 ? sh_row_bounds : nullptr, flags))
     return e;
-  const bool bounded = C == 4 && sh_l1_bound != nullptr && batch_can_be_polynomial(ps);
+  const bool bounded = C == 4 && (sh_l1_bound != nullptr || sh_row_bounds != nullptr) && batch_can_be_polynomial(ps);
   if (!bounded)
-    for (CompParams &p : ps) p.sh_bound = nullptr;
+    for (CompParams &p : ps) { p.sh_bound = nullptr; p.sh_rows = nullptr; p.tile_flags = nullptr; }
   hipStream_t s = (hipStream_t)stream;
   CompParams *dst = reinterpret_cast<CompParams *>(batch_workspace) + n_views;
   if (int e = write_params(ps.data(), n_views, dst, s)) return e;

@@ -143,6 +143,23 @@ int gsgen_vol_render_backward_sh_bounded(uint32_t N, uint32_t D, const float *me
                                          const float *bg_rgb, const uint32_t *tile_order,
                                          const void *segment_workspace, uint32_t n_segments,
                                          const float *sh_l1_bound, gsgen_stream_t stream) {
+  return gsgen_vol_render_backward_sh_routed(N, D, mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out, grad_mean, grad_cov,
+                                             grad_sh_coeffs, grad_alpha, grad_out, topleft, c2w, tile_size, n_tiles_h, n_tiles_w,
+                                             pixel_size_x, pixel_size_y, H, W, C, thresh, bg_rgb, tile_order, segment_workspace,
+                                             n_segments, sh_l1_bound, nullptr, stream);
+}
+
+int gsgen_vol_render_backward_sh_routed(uint32_t N, uint32_t D, const float *mean, const float *cov,
+                                        const float *sh_coeffs, const float *alpha, const int *start,
+                                        const int *end, const int *gaussian_ids, const float *out,
+                                        float *grad_mean, float *grad_cov, float *grad_sh_coeffs,
+                                        float *grad_alpha, const float *grad_out, const float *topleft,
+                                        const float *c2w, uint32_t tile_size, uint32_t n_tiles_h,
+                                        uint32_t n_tiles_w, float pixel_size_x, float pixel_size_y,
+                                        uint32_t H, uint32_t W, uint32_t C, float thresh,
+                                        const float *bg_rgb, const uint32_t *tile_order,
+                                        const void *segment_workspace, uint32_t n_segments,
+                                        const float *sh_l1_bound, const float *sh_row_bounds, gsgen_stream_t stream) {
   (void)bg_rgb;  // the background only enters through `out` (= final incl. bg*T)
   if (int e = check_common(tile_size, start, end, out)) return e;
   if (n_segments > 1 && segment_workspace == nullptr) return GSGEN_EINVAL;
@@ -157,7 +174,8 @@ int gsgen_vol_render_backward_sh_bounded(uint32_t N, uint32_t D, const float *me
   p.ntw = (int)n_tiles_w; p.nth = (int)n_tiles_h; p.H = (int)H; p.W = (int)W;
   p.psx = pixel_size_x; p.psy = pixel_size_y; p.thresh = thresh; p.tile_side = (int)tile_size;
   p.tile_order = tile_order;
-  p.sh_bound = (C == 4) ? sh_l1_bound : nullptr;
+  p.sh_bound = (C == 4 && sh_row_bounds == nullptr) ? sh_l1_bound : nullptr;
+  p.sh_rows = (C == 4) ? sh_row_bounds : nullptr;
   if (n_segments > 1) {
     p.nseg = (int)n_segments;
     p.ckpt = reinterpret_cast<float4 *>(const_cast<void *>(segment_workspace));

@@ -37,6 +37,16 @@ struct CompParams {
   // host enqueues the ROUTED kernel (composite.hip, kRouted): every workgroup reads S and its view's pixel size and runs the
   // polynomial form of the per-pixel basis or the exact one (poly_route) -- no host decision, no host sync.
   const float *sh_bound;
+  // Per-TILE routing (round 4; the *_routed entry points): sh_rows[i] = the largest sum_{k>=1} |sh| over the three channels of
+  // splat i (gsgen_sh_l1_bound_rows), measured on the device per step.  A tile takes the polynomial form as long as every splat
+  // it STAGES satisfies the bound for its view's pixel size (poly_row_ok); the first staged batch that holds a splat beyond it
+  // sends the tile to the exact kernel: batched launches through tile_flags (one byte per tile of the view, written by the
+  // polynomial forward -- 1 = exact -- and read by the exact fallback behind it and by both backward kernels), per-camera
+  // launches by scanning the tile's list first (forward and backward scan the same list: the same decision).  One splat with
+  // large higher-band coefficients, or a wide camera, then costs the tiles it touches, not the view.  NULL: per-view routing
+  // on sh_bound as in round 3.
+  const float *sh_rows;
+  uint8_t *tile_flags;
   uint32_t vgrid;  // persistent launches (the exact fallback of a bounded batch): size of the virtual grid they stride through
   // post-activation channel modes, batched launches: the forward WRITES the empty tiles too (channels 0, T = 1), so the caller
   // need not pre-initialise [B,H,W,NCH] + [B,H,W] every step (the reference's contract -- "out zeroed, T set to 1 by the
@@ -332,6 +342,12 @@ constexpr int kPolyNodes = 9;
 // of the 1e-4 image tolerance.  S <= 0, NaN or infinite: never.  One function for the host's report and the kernels' routing.
 __host__ __device__ __forceinline__ bool poly_ok(float S, float ps_max) {
   if (!(S > 0.0f) || !(S <= 3.0e38f)) return false;
+  const float delta = 7.5f * 1.41421356f * ps_max;
+  return 0.25f * S * 0.7f * delta * delta * delta <= 1e-5f;
+}
+// per-splat form of the same rule: may a splat whose rows sum to at most S be rendered through the polynomial basis in a view of
+// this pixel size?  S = 0 (no higher bands: the fit of the constant term is exact) passes; NaN does not.
+__host__ __device__ __forceinline__ bool poly_row_ok(float S, float ps_max) {
   const float delta = 7.5f * 1.41421356f * ps_max;
   return 0.25f * S * 0.7f * delta * delta * delta <= 1e-5f;
 }

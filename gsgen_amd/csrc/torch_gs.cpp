@@ -156,8 +156,9 @@ struct BoundCache {
   Tensor bound;
 } g_bound;
 
-// S = max sum_{k >= 1} |sh| of the call's coefficients into a scratch float from torch's caching allocator (stream-ordered:
-// the block is reused only behind the launches that read it); nullptr = exact kernels (other degrees / tile sizes, or the switch)
+// The per-splat bounds S_i = max_c sum_{k >= 1} |sh[i][c][k]| of the call's coefficients into a scratch tensor [N] from torch's
+// caching allocator (stream-ordered: the block is reused only behind the launches that read it); the SH kernels route PER TILE
+// on them (include/gsgen_hip.h "per-TILE routing").  nullptr = exact kernels (other degrees / tile sizes, or the switch)
 template <class C_>
 const float *sh_bound(const Tensor &sh_coeffs, uint32_t C, uint32_t tile_size, C_ &c, bool reuse = false) {
   if (g_sh_exact || C != 4 || tile_size != 16 || sh_coeffs.numel() == 0) return nullptr;
@@ -167,8 +168,8 @@ const float *sh_bound(const Tensor &sh_coeffs, uint32_t C, uint32_t tile_size, C
   if (reuse && g_bound.bound.defined() && g_bound.ptr == ptr && g_bound.numel == sh_coeffs.numel() && g_bound.version == ver &&
       g_bound.device == dev)
     return F(g_bound.bound);
-  Tensor b = at::empty({1}, sh_coeffs.options());
-  GS(gsgen_sh_l1_bound((uint32_t)(sh_coeffs.numel() / 48), F(sh_coeffs), C, Fm(b), c.stream));
+  Tensor b = at::empty({sh_coeffs.numel() / 48}, sh_coeffs.options());  // per SPLAT: the kernels route per tile
+  GS(gsgen_sh_l1_bound_rows((uint32_t)(sh_coeffs.numel() / 48), F(sh_coeffs), C, nullptr, Fm(b), c.stream));
   g_bound.ptr = ptr; g_bound.numel = sh_coeffs.numel(); g_bound.version = ver; g_bound.device = dev; g_bound.bound = b;
   return F(b);
 }
@@ -184,9 +185,9 @@ void sh_forward(const Tensor &mean, const Tensor &cov, const Tensor &sh_coeffs, 
   // SH degree 3: the coefficient bound of THESE coefficients, measured on the device in front of the launch (one 5-us pass,
   // no sync); the kernels route on it -- polynomial form of the per-pixel basis where its error bound holds, else exact
   const float *bound = sh_bound(sh_coeffs, C, tile_size, c);
-  GS(gsgen_vol_render_sh_bounded((uint32_t)mean.size(0), (uint32_t)gaussian_ids.size(0), F(mean), F(cov), F(sh_coeffs), F(alpha),
-                                 I(start), I(end), I(gaussian_ids), Fm(out), F(topleft), F(c2w), tile_size, n_tiles_h, n_tiles_w,
-                                 psx, psy, H, W, C, thresh, bg, nullptr, nullptr, nullptr, 0, bound, c.stream));
+  GS(gsgen_vol_render_sh_routed((uint32_t)mean.size(0), (uint32_t)gaussian_ids.size(0), F(mean), F(cov), F(sh_coeffs), F(alpha),
+                                I(start), I(end), I(gaussian_ids), Fm(out), F(topleft), F(c2w), tile_size, n_tiles_h, n_tiles_w,
+                                psx, psy, H, W, C, thresh, bg, nullptr, nullptr, nullptr, 0, nullptr, bound, c.stream));
 }
 void sh_backward(const Tensor &mean, const Tensor &cov, const Tensor &sh_coeffs, const Tensor &alpha, const Tensor &start,
                  const Tensor &end, const Tensor &gaussian_ids, const Tensor &out, Tensor &grad_mean, Tensor &grad_cov,
@@ -200,11 +201,11 @@ void sh_backward(const Tensor &mean, const Tensor &cov, const Tensor &sh_coeffs,
   Ctx c(mean);
   // the bound this frame's forward measured for these coefficients (same storage, same version): the same routing
   const float *bound = sh_bound(sh_coeffs, C, tile_size, c, true);
-  GS(gsgen_vol_render_backward_sh_bounded((uint32_t)mean.size(0), (uint32_t)gaussian_ids.size(0), F(mean), F(cov), F(sh_coeffs),
-                                          F(alpha), I(start), I(end), I(gaussian_ids), F(out), Fm(grad_mean), Fm(grad_cov),
-                                          Fm(grad_sh_coeffs), Fm(grad_alpha), F(grad_out), F(topleft), F(c2w), tile_size,
-                                          n_tiles_h, n_tiles_w, psx, psy, H, W, C, thresh, bg, nullptr, nullptr, 0, bound,
-                                          c.stream));
+  GS(gsgen_vol_render_backward_sh_routed((uint32_t)mean.size(0), (uint32_t)gaussian_ids.size(0), F(mean), F(cov), F(sh_coeffs),
+                                         F(alpha), I(start), I(end), I(gaussian_ids), F(out), Fm(grad_mean), Fm(grad_cov),
+                                         Fm(grad_sh_coeffs), Fm(grad_alpha), F(grad_out), F(topleft), F(c2w), tile_size,
+                                         n_tiles_h, n_tiles_w, psx, psy, H, W, C, thresh, bg, nullptr, nullptr, 0, nullptr, bound,
+                                         c.stream));
 }
 // render.h:83 / render.cu:484-545
 void tile_based_vol_rendering_sh(Tensor mean, Tensor cov, Tensor sh_coeffs, Tensor alpha, Tensor start, Tensor end,

@@ -218,6 +218,26 @@ def sh_l1_bound_device(sh, out=None):
     return out
 
 
+def sh_row_bounds_device(sh, out=None, out_max=None):
+    """Per-SPLAT coefficient bounds as a DEVICE tensor [N]: rows[i] = max over the three channels of sum_{k >= 1} |sh[i][c][k]|
+    (gsgen_sh_l1_bound_rows: one coalesced pass on the current stream, no host sync).  The SH launches of the fused paths
+    route per TILE on it (include/gsgen_hip.h, "per-TILE routing"): a splat with large higher-band coefficients, or a wide
+    camera, costs the tiles it touches, not the view.  out_max (optional, 1 float): receives the global maximum."""
+    if sh.dtype != torch.float32:
+        raise ValueError("sh_row_bounds wants fp32 SH coefficients [N, 3, C*C]")
+    sh = sh.detach().contiguous()
+    if sh.dim() == 2 and sh.shape[1] % 3 == 0:
+        sh = sh.view(sh.shape[0], 3, sh.shape[1] // 3)
+    C = int(round(sh.shape[-1] ** 0.5)) if sh.dim() == 3 else 0
+    if sh.dim() != 3 or sh.shape[1] != 3 or C * C != sh.shape[-1] or not 1 <= C <= 4:
+        raise ValueError("sh_row_bounds wants fp32 SH coefficients [N, 3, C*C], C in 1..4")
+    if out is None:
+        out = torch.empty(sh.shape[0], device=sh.device, dtype=torch.float32)
+    with torch.cuda.device(sh.device):
+        _capi.load().sh_l1_bound_rows(sh.shape[0], _p(sh), C, _p(out_max), _p(out), _stream(sh))
+    return out
+
+
 def sh_l1_bound(sh):
     """The same value as a Python float (ONE host sync): for reports and tests, never needed by the render path."""
     return float(sh_l1_bound_device(sh).item())
@@ -362,6 +382,12 @@ class FrameBuffers:
         nbytes = _capi.load().frame_workspace_bytes(self.N, self.D_cap, self.nth * self.ntw)
         self.ws = torch.empty(nbytes, device=self.device, dtype=torch.uint8)
 
+    def row_bounds(self):
+        """float32 [N]: the per-splat coefficient bounds of the frame in flight (sh_row_bounds_device), read by its backward"""
+        if getattr(self, "_rows", None) is None:
+            self._rows = torch.empty(self.N, device=self.device, dtype=torch.float32)
+        return self._rows
+
     def tile_order(self):
         """device address of the longest-list-first launch order written by frame_geometry"""
         return _capi.load().frame_tile_order(self.ws.data_ptr(), self.N, self.D_cap, self.nth * self.ntw)
@@ -461,15 +487,14 @@ class _render_frame(torch.autograd.Function):
         T = torch.ones(H, W, 1, device=dev, dtype=torch.float32)
         psx, psy = 1.0 / cam_info.fx, 1.0 / cam_info.fy
         s = _stream(mean)
-        # SH degree 3: the coefficient bound, measured on the device in front of the launch; the kernels route on it
-        # (polynomial form of the per-pixel basis where its error bound holds, else the exact one) -- no host decision
-        ctx.sh_bound = sh_l1_bound_device(col) if (C == 4 and sh_basis == "auto") else None
+        # SH degree 3, "auto": per-splat bounds measured on the device, the kernels route per tile on them
+        ctx.sh_bound = sh_row_bounds_device(col, out=buf.row_bounds()) if (C == 4 and sh_basis == "auto") else None
         with torch.cuda.device(dev):
             if C > 0:
-                lib.vol_render_sh_bounded(buf.N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col), _p(alpha),
+                lib.vol_render_sh_routed(buf.N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col), _p(alpha),
                                           _p(buf.start), _p(buf.end), _p(buf.ids), _p(out), _p(topleft), _p(rot),
                                           16, buf.nth, buf.ntw, psx, psy, H, W, C, thresh, _p(bg_rgb), _p(T),
-                                          buf.tile_order(), _p(buf.seg_ws), buf.segments, _p(ctx.sh_bound), s)
+                                          buf.tile_order(), _p(buf.seg_ws), buf.segments, None, _p(ctx.sh_bound), s)
             else:
                 lib.vol_render_start_end_with_T(buf.N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col),
                                                 _p(alpha), _p(buf.start), _p(buf.end), _p(buf.ids),
@@ -503,11 +528,11 @@ class _render_frame(torch.autograd.Function):
         s = _stream(mean)
         with torch.cuda.device(dev):
             if C > 0:
-                lib.vol_render_backward_sh_bounded(N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col), _p(alpha),
+                lib.vol_render_backward_sh_routed(N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col), _p(alpha),
                                                    _p(buf.start), _p(buf.end), _p(buf.ids), _p(out), _p(g_mean2d),
                                                    _p(g_cov2d), _p(g_col), _p(g_alpha), _p(grad), _p(topleft),
                                                    _p(rot), 16, buf.nth, buf.ntw, psx, psy, H, W, C, thresh, None,
-                                                   buf.tile_order(), _p(buf.seg_ws), buf.segments, _p(ctx.sh_bound), s)
+                                                   buf.tile_order(), _p(buf.seg_ws), buf.segments, None, _p(ctx.sh_bound), s)
             else:
                 lib.vol_render_backward_start_end(N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col),
                                                   _p(alpha), _p(buf.start), _p(buf.end), _p(buf.ids),

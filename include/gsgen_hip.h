@@ -460,6 +460,54 @@ int gsgen_vol_render_backward_sh_bounded(uint32_t N, uint32_t D, const float *me
                                          const void *segment_workspace, uint32_t n_segments,
                                          const float *sh_l1_bound /* device or NULL */, gsgen_stream_t stream);
 
+/* ---- per-TILE routing of the polynomial SH basis (round 4) ------------------------------------------------------------------
+ * The *_bounded entry points above route per VIEW on one number, the scene's largest per-row coefficient sum: one splat with large
+ * higher-band coefficients, or a wide camera, sends the whole view to the exact kernels.  The *_routed entry points take the
+ * bound per SPLAT -- sh_row_bounds[i] = max over the three channels of sum_{k >= 1} |sh[i][c][k]|, DEVICE memory, [N], measured per
+ * step by gsgen_sh_l1_bound_rows (one coalesced pass, no atomics but one per workgroup; out_max, optional, receives the global
+ * maximum the per-view rule uses) -- and decide per TILE: a tile is rendered through the polynomial form as long as every splat it
+ * stages satisfies 0.25 * S_i * 0.7 delta^3 <= 1e-5 for its view's pixel size (the same rule, per splat); the first staged batch
+ * holding a splat beyond it sends that tile -- and only that tile -- to the exact kernel.  Splats behind the point where the
+ * tile's pixels saturate are never staged and never count.  Batched launches record the decision in one byte per (view, tile)
+ * inside batch_workspace (gsgen_sh_batch_workspace_bytes_routed): the polynomial forward writes it, the exact fallback behind it
+ * and both backward kernels read it, so forward and backward agree by construction; per-camera launches scan the tile's list
+ * first, forward and backward alike.  sh_row_bounds == NULL: exactly the *_bounded behaviour on sh_l1_bound.  SH degree 3 only
+ * (C != 4: the exact kernels).  No counterpart in the reference (vol_render_sh.h:48-65 evaluates the basis per pixel). */
+int gsgen_sh_l1_bound_rows(uint32_t N, const float *sh_coeffs, uint32_t C, float *out_max /* device, 1 float, or NULL */,
+                           float *out_rows /* device, [N] */, gsgen_stream_t stream);
+size_t gsgen_sh_batch_workspace_bytes_routed(uint32_t n_views, uint32_t n_tiles);
+int gsgen_vol_render_sh_batch_routed(uint32_t n_views, const gsgen_sh_view *views, uint32_t N,
+                                     const float *sh_coeffs, const float *alpha, uint32_t tile_size,
+                                     uint32_t n_tiles_h, uint32_t n_tiles_w, uint32_t H, uint32_t W, uint32_t C,
+                                     float thresh, uint32_t n_segments, const float *sh_l1_bound /* device or NULL */,
+                                     const float *sh_row_bounds /* device [N] or NULL */, void *batch_workspace,
+                                     gsgen_stream_t stream);
+int gsgen_vol_render_backward_sh_batch_routed(uint32_t n_views, const gsgen_sh_view *views, uint32_t N,
+                                              const float *sh_coeffs, const float *alpha, float *grad_sh_coeffs,
+                                              float *grad_alpha, uint32_t tile_size, uint32_t n_tiles_h,
+                                              uint32_t n_tiles_w, uint32_t H, uint32_t W, uint32_t C, float thresh,
+                                              uint32_t n_segments, const float *sh_l1_bound, const float *sh_row_bounds,
+                                              void *batch_workspace, gsgen_stream_t stream);
+int gsgen_vol_render_sh_routed(uint32_t N, uint32_t D, const float *mean, const float *cov,
+                               const float *sh_coeffs, const float *alpha, const int *start,
+                               const int *end, const int *gaussian_ids, float *out, const float *topleft,
+                               const float *c2w, uint32_t tile_size, uint32_t n_tiles_h,
+                               uint32_t n_tiles_w, float pixel_size_x, float pixel_size_y, uint32_t H,
+                               uint32_t W, uint32_t C, float thresh, const float *bg_rgb, float *T,
+                               const uint32_t *tile_order, void *segment_workspace, uint32_t n_segments,
+                               const float *sh_l1_bound, const float *sh_row_bounds, gsgen_stream_t stream);
+int gsgen_vol_render_backward_sh_routed(uint32_t N, uint32_t D, const float *mean, const float *cov,
+                                        const float *sh_coeffs, const float *alpha, const int *start,
+                                        const int *end, const int *gaussian_ids, const float *out,
+                                        float *grad_mean, float *grad_cov, float *grad_sh_coeffs,
+                                        float *grad_alpha, const float *grad_out, const float *topleft,
+                                        const float *c2w, uint32_t tile_size, uint32_t n_tiles_h,
+                                        uint32_t n_tiles_w, float pixel_size_x, float pixel_size_y,
+                                        uint32_t H, uint32_t W, uint32_t C, float thresh,
+                                        const float *bg_rgb, const uint32_t *tile_order,
+                                        const void *segment_workspace, uint32_t n_segments,
+                                        const float *sh_l1_bound, const float *sh_row_bounds, gsgen_stream_t stream);
+
 /* Fused RGB + auxiliary heads: what render_one does in four compositing passes
  * (gs/gaussian_splatting.py:1304-1403: rgb, depth, opacity = scalar 1, depth^2) in one.
  * out6 / grad_out6 are [H,W,6] = (r, g, b, depth, opacity, depth^2); grad_chan6 [N,6] receives the

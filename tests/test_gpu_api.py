@@ -342,7 +342,9 @@ def test_fused_adam_tracks_torch_adam_through_a_render():
         fa.all_reduce_grad()  # no process group: a no-op
         fa.step(new_lrs); opt.step()
         for k in keys:
-            assert rel_err(fa.params[k].detach().cpu().numpy(), ref[k].detach().cpu().numpy()) < 2e-5, (it, k)
+            # (the two backward passes sum their atomics in different orders; Adam's first steps are sign-like, so a gradient
+            # that differs in its last bits moves a parameter by up to ~lr * 1e-3: seen between 0.3e-5 and 2.1e-5 over runs)
+            assert rel_err(fa.params[k].detach().cpu().numpy(), ref[k].detach().cpu().numpy()) < 4e-5, (it, k)
 
 
 @pytest.mark.parametrize("C", [2, 4])

@@ -211,10 +211,19 @@ def test_full_size_cfg4_64_random_poses_batched():
             batch = cams[b0:b0 + B]
             cis = [R.CameraInfo(*c.intr) for c in batch]
             imgs = [br.render(P["mean"], P["qvec"], P["svec"], P["alpha"], P["sh"], cis, [c.c2w for c in batch], C=C, bg_rgb=T_(bg),
-                              sh_basis=basis)[0] for basis in ("auto", "exact")]
+                              sh_basis=basis)[0] for basis in ("exact", "auto")][::-1]
+            flags = br.routing_flags(B).cpu().numpy().astype(bool)   # (of the last render: the exact one leaves none)
             for i in range(B):
                 d = float((imgs[0][i] - imgs[1][i]).abs().max())
-                assert (0.0 < d <= 1e-5) if applies[b0 + i] else d == 0.0, (b0 + i, applies[b0 + i], d, cams[b0 + i].fx)
+                # round 4, per-tile routing: the views round 3 sent to the exact kernels whole are polynomial too, except the
+                # few tiles that stage a splat beyond the bound
+                assert 0.0 < d <= 1.4e-5, (b0 + i, applies[b0 + i], d, cams[b0 + i].fx)
+                nonempty = (br.slots[i].end > br.slots[i].start).cpu().numpy()
+                n_fl = int((flags[i] & nonempty).sum())
+                assert (n_fl == 0) if applies[b0 + i] else (n_fl < 0.25 * nonempty.sum()), (b0 + i, n_fl, int(nonempty.sum()))
+                if not applies[b0 + i]:
+                    scenes.PARITY_LOG.append(f"cfg4 camera {b0 + i} (focal {cams[b0 + i].fx / 512:.2f} x size, beyond the per-view bound): "
+                                             f"{n_fl} of {int(nonempty.sum())} non-empty tiles exact = 0")
 
 
 def test_full_size_rgb_heads_batched():
