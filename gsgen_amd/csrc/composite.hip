@@ -115,8 +115,19 @@ __device__ __forceinline__ GRec load_rec(const Stage<MODE, CB, KB, WC> &S, int g
 // ============================================================================================
 // forward
 // ============================================================================================
+// The parameter blocks of a batched launch travel in the kernel arguments themselves (<= kPackMax views per launch; larger
+// batches are launched in chunks): no table in device memory, no launch that writes one (until round 4 a one-workgroup
+// k_write_params launch in front of every batched forward and backward).
+constexpr int kPackMax = 8;
+template <bool BATCH> struct ViewPack {
+  CompParams v[kPackMax];
+  __host__ __device__ const CompParams *table() const { return v; }
+};
+template <> struct ViewPack<false> {
+  __host__ __device__ const CompParams *table() const { return nullptr; }
+};
 // BATCH: one launch renders B cameras, each workgroup taking its camera's parameters from plist[view]
-// (device memory) instead of the kernel argument -- a single launch's tail (the never-saturating
+// (the kernel-argument table) instead of p_arg -- a single launch's tail (the never-saturating
 // sparse tiles) is then paid once per batch instead of once per camera.  The grid is 1-D, B x the
 // per-camera grid, camera-major (all blocks of camera 0, then camera 1, ...; measured against two interleaved orders in
 // round 1: as fast on cfg2, faster on the 64 random cameras of cfg4 -- an interleaved B = 8 pins each camera to one XCD);
@@ -676,7 +687,8 @@ __device__ __forceinline__ bool tile_flagged(const CompParams &p, uint32_t bid) 
 template <int CB, int PPL, bool BATCH = false, int NB = 0>
 __global__ void __launch_bounds__(256 / PPL)
 GS_WAVES_PER_EU((NB == kPolyNB && BATCH && PPL == 4) ? 5 : 1)  // the batched polynomial forward: five wavefronts per SIMD (<= 96 registers)
-k_composite_fwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
+k_composite_fwd_sh_vec(CompParams p_arg, ViewPack<BATCH> pack) {
+  const CompParams *plist = pack.table();  // (kernel-argument memory: scalar loads, no table in device memory)
   uint32_t bid = blockIdx.x;
   if constexpr (NB == kRouted) {
     static_assert(CB == 4, "routing exists for SH degree 3");
@@ -706,9 +718,10 @@ k_composite_fwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
     }
     const uint32_t per = total / B;  // camera-major
     uint32_t base = 0;  // first block of the view b lies in (b only grows: no division in the loop)
-    const CompParams *pp = plist;
+    uint32_t view = 0;  // (an index, not a walking pointer: the table stays in kernel-argument memory)
     for (uint32_t b = blockIdx.x; b < total; b += gridDim.x) {
-      while (b >= base + per) { base += per; ++pp; }
+      while (b >= base + per) { base += per; ++view; }
+      const CompParams *pp = &plist[view];
       // per-view routing: the views the polynomial kernel left; per-tile routing (this launch runs BEHIND the polynomial
       // kernel): the tiles it flagged
       if (per_tile ? !tile_flagged(*pp, b - base) : poly_route(pp->sh_bound, pp->psx, pp->psy)) continue;
@@ -1410,7 +1423,8 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
 // coefficient bound fails while a batch mate's holds.)
 template <int CB, int PPL, bool BATCH = false, int NB = 0>
 __global__ void __launch_bounds__(256 / PPL)
-k_composite_bwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
+k_composite_bwd_sh_vec(CompParams p_arg, ViewPack<BATCH> pack) {
+  const CompParams *plist = pack.table();  // (kernel-argument memory: scalar loads, no table in device memory)
   uint32_t bid = blockIdx.x, grid = gridDim.x;
   if constexpr (NB == kRouted) {
     static_assert(CB == 4 && PPL == 4, "routing exists for SH degree 3, one wavefront per tile");
@@ -1446,9 +1460,10 @@ k_composite_bwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
     const uint32_t per = total / B;  // camera-major
     const uint32_t tiles_grid = per / (uint32_t)(plist[0].nseg > 1 ? plist[0].nseg : 1);
     uint32_t base = 0;  // first block of the view b lies in (b only grows: no division in the loop)
-    const CompParams *pp = plist;
+    uint32_t view = 0;
     for (uint32_t b = blockIdx.x; b < total; b += gridDim.x) {
-      while (b >= base + per) { base += per; ++pp; }
+      while (b >= base + per) { base += per; ++view; }
+      const CompParams *pp = &plist[view];
       if (per_tile ? !tile_flagged(*pp, (b - base) % tiles_grid) : poly_route(pp->sh_bound, pp->psx, pp->psy)) continue;
       const CompParams p = *pp;
       composite_bwd_sh_vec_tile<4, 4, 0, true>(p, b - base, per, sm);
@@ -1474,8 +1489,9 @@ k_composite_bwd_sh_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
 // wavefronts per tile; with the lane's 4 pixels as two packed pairs, one wavefront per tile, the record in scalar
 // registers and one wave-uniform guard branch it is ~70 per tile and entry.  Same structure as k_composite_fwd_sh_vec.
 template <int MODE, bool BATCH = false>
-__global__ void __launch_bounds__(64) GS_WAVES_PER_EU(5)  // RGB + heads: 98 -> 81 registers, six wavefronts per SIMD (+1 .. 2 %, profiles/r04_notes.md)
-k_composite_fwd_chan_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
+__global__ void __launch_bounds__(64) GS_WAVES_PER_EU(6)  // RGB + heads: 98 -> 80 registers (one dword spilled outside the entry loop): six wavefronts per SIMD
+k_composite_fwd_chan_vec(CompParams p_arg, ViewPack<BATCH> pack) {
+  const CompParams *plist = pack.table();  // (kernel-argument memory: scalar loads, no table in device memory)
   static_assert(MODE == MODE_RGB || MODE == MODE_SCALAR || MODE == MODE_RGBD, "post-activation channel modes");
   uint32_t bid = blockIdx.x;
   const CompParams p = BATCH ? plist[batch_view(p_arg, bid)] : p_arg;
@@ -1617,7 +1633,8 @@ k_composite_fwd_chan_vec(CompParams p_arg, const CompParams *__restrict__ plist)
 // Reduction vector: channels [0, NCH) | pad to even | mean 2 | cov 4 | alpha 1.
 template <int MODE, bool BATCH = false>
 __global__ void __launch_bounds__(64) GS_WAVES_PER_EU(5)  // RGB + heads: 106 -> 96 registers (16 bytes of scratch outside the entry loop): five per SIMD
-k_composite_bwd_chan_vec(CompParams p_arg, const CompParams *__restrict__ plist) {
+k_composite_bwd_chan_vec(CompParams p_arg, ViewPack<BATCH> pack) {
+  const CompParams *plist = pack.table();  // (kernel-argument memory: scalar loads, no table in device memory)
   static_assert(MODE == MODE_RGB || MODE == MODE_SCALAR || MODE == MODE_RGBD, "post-activation channel modes");
   uint32_t bid = blockIdx.x, grid = gridDim.x;
   const CompParams p = BATCH ? plist[batch_view(p_arg, bid, &grid)] : p_arg;
@@ -1820,7 +1837,7 @@ static int launch_fwd(const CompParams &p_, hipStream_t s) {
     // with the coefficient bound: ONE launch of the routed kernel -- every workgroup reads the bound and runs the polynomial
     // form of the per-pixel basis where its error bound holds, the exact form elsewhere (poly_route)
     if (p.sh_bound != nullptr || p.sh_rows != nullptr) {
-      hipLaunchKernelGGL((k_composite_fwd_sh_vec<4, 2, false, kRouted>), dim3(nblk), dim3(128), 0, s, p, (const CompParams *)nullptr);
+      hipLaunchKernelGGL((k_composite_fwd_sh_vec<4, 2, false, kRouted>), dim3(nblk), dim3(128), 0, s, p, ViewPack<false>{});
       return (int)hipGetLastError();
     }
   } else {
@@ -1847,18 +1864,18 @@ static int launch_bwd(const CompParams &p_, hipStream_t s) {
   }
   if constexpr (MODE != MODE_SH) {
     p.sh_bound = nullptr;
-    hipLaunchKernelGGL((k_composite_bwd_chan_vec<MODE>), dim3(nblk), dim3(64), 0, s, p, (const CompParams *)nullptr);
+    hipLaunchKernelGGL((k_composite_bwd_chan_vec<MODE>), dim3(nblk), dim3(64), 0, s, p, ViewPack<false>{});
   } else {
     const uint32_t ng = nblk * (uint32_t)(p.nseg > 1 ? p.nseg : 1);
     if constexpr (CB == 4) {
       if (p.sh_bound != nullptr || p.sh_rows != nullptr) {  // as the forward: one launch, routed on the device
-        hipLaunchKernelGGL((k_composite_bwd_sh_vec<4, 4, false, kRouted>), dim3(ng), dim3(64), 0, s, p, (const CompParams *)nullptr);
+        hipLaunchKernelGGL((k_composite_bwd_sh_vec<4, 4, false, kRouted>), dim3(ng), dim3(64), 0, s, p, ViewPack<false>{});
         return (int)hipGetLastError();
       }
     } else {
       p.sh_bound = p.sh_rows = nullptr;
     }
-    hipLaunchKernelGGL((k_composite_bwd_sh_vec<CB, 4>), dim3(ng), dim3(64), 0, s, p, (const CompParams *)nullptr);
+    hipLaunchKernelGGL((k_composite_bwd_sh_vec<CB, 4>), dim3(ng), dim3(64), 0, s, p, ViewPack<false>{});
   }
   return (int)hipGetLastError();
 }
@@ -1876,24 +1893,24 @@ static void launch_beside(hipStream_t s, Side &&side, Main &&main) {
   main(s);
 }
 
-// ---- batched cameras: parameters through device memory ----------------------------------------
-constexpr int kPackMax = 8;
-struct CompParamsPack { CompParams v[kPackMax]; };
-__global__ void __launch_bounds__(64) k_write_params(CompParamsPack pack, CompParams *dst, int n) {
-  const int i = (int)threadIdx.x;
-  if (i < n) dst[i] = pack.v[i];
+// ---- batched cameras: parameters through the kernel arguments -----------------------------------
+static ViewPack<true> make_pack(const CompParams *host, uint32_t n) {
+  ViewPack<true> pack{};
+  for (uint32_t i = 0; i < n; ++i) pack.v[i] = host[i];
+  return pack;
 }
-int write_params(const CompParams *host, uint32_t B, CompParams *dst, hipStream_t s) {
-  for (uint32_t b0 = 0; b0 < B; b0 += kPackMax) {
-    CompParamsPack pack{};
-    const int n = (int)((B - b0) < (uint32_t)kPackMax ? (B - b0) : (uint32_t)kPackMax);
-    for (int i = 0; i < n; ++i) pack.v[i] = host[b0 + i];
-    hipLaunchKernelGGL(k_write_params, dim3(1), dim3(64), 0, s, pack, dst + b0, n);
+// f(first view's block with n_lo = the chunk's view count, the chunk's pack, the chunk's view count) per chunk of <= kPackMax views
+template <class F>
+static void for_each_chunk(const CompParams *host, uint32_t B, F &&f) {
+  for (uint32_t b0 = 0; b0 < B; b0 += (uint32_t)kPackMax) {
+    const uint32_t n = (B - b0) < (uint32_t)kPackMax ? (B - b0) : (uint32_t)kPackMax;
+    CompParams a = host[b0];
+    a.n_lo = (int)n;  // (the batched grids are camera-major: batch_view)
+    f(a, make_pack(host + b0, n), n);
   }
-  return (int)hipGetLastError();
 }
 template <int CB>
-static void launch_fwd_sh_batch_c(const CompParams &p0, const CompParams *plist, uint32_t B, uint32_t nblk, hipStream_t s, bool bounded) {
+static void launch_fwd_sh_batch_c(const CompParams &p0, const ViewPack<true> &plist, uint32_t B, uint32_t nblk, hipStream_t s, bool bounded) {
   const dim3 g(nblk * B);
   if constexpr (CB == 4) {
     // The views carry the device address of the coefficient bound: every workgroup decides from the bound and ITS view's pixel
@@ -1920,26 +1937,22 @@ static void launch_fwd_sh_batch_c(const CompParams &p0, const CompParams *plist,
   // instructions, which is what counts with another batch's backward in flight: 3 010 vs 2 885 renders/s, round 2)
   hipLaunchKernelGGL((k_composite_fwd_sh_vec<CB, 2, true>), g, dim3(128), 0, s, p0, plist);
 }
-static CompParams batch_arg(const CompParams &p0, uint32_t B) {
-  CompParams a = p0;
-  a.n_lo = (int)B;  // (the batched grids are camera-major: batch_view)
-  return a;
-}
-int launch_fwd_sh_batch(int C, const CompParams &p0_, const CompParams *plist, uint32_t B, hipStream_t s, bool bounded) {
-  const uint32_t nblk = comp_grid(p0_);
-  if (p0_.ntw * p0_.nth == 0 || B == 0) return 0;
-  const CompParams p0 = batch_arg(p0_, B);
+int launch_fwd_sh_batch(int C, const CompParams *host, uint32_t B, hipStream_t s, bool bounded) {
+  if (B == 0 || host[0].ntw * host[0].nth == 0) return 0;
+  const uint32_t nblk = comp_grid(host[0]);
   const bool poly = C == 4 && bounded;
-  switch (C) {
-    case 1: launch_fwd_sh_batch_c<1>(p0, plist, B, nblk, s, false); break;
-    case 2: launch_fwd_sh_batch_c<2>(p0, plist, B, nblk, s, false); break;
-    case 3: launch_fwd_sh_batch_c<3>(p0, plist, B, nblk, s, false); break;
-    default: launch_fwd_sh_batch_c<4>(p0, plist, B, nblk, s, poly); break;
-  }
+  for_each_chunk(host, B, [&](const CompParams &p0, const ViewPack<true> &pack, uint32_t n) {
+    switch (C) {
+      case 1: launch_fwd_sh_batch_c<1>(p0, pack, n, nblk, s, false); break;
+      case 2: launch_fwd_sh_batch_c<2>(p0, pack, n, nblk, s, false); break;
+      case 3: launch_fwd_sh_batch_c<3>(p0, pack, n, nblk, s, false); break;
+      default: launch_fwd_sh_batch_c<4>(p0, pack, n, nblk, s, poly); break;
+    }
+  });
   return (int)hipGetLastError();
 }
 template <int CB>
-static void launch_bwd_sh_batch_c(const CompParams &p0, const CompParams *plist, uint32_t B, uint32_t nblk, hipStream_t s, bool bounded) {
+static void launch_bwd_sh_batch_c(const CompParams &p0, const ViewPack<true> &plist, uint32_t B, uint32_t nblk, hipStream_t s, bool bounded) {
   const dim3 g(nblk * B);
   if constexpr (CB == 4) {
     if (bounded) {  // as the forward: the persistent exact fallback, then the polynomial kernel (120 registers: 4 wavefronts per SIMD)
@@ -1958,35 +1971,37 @@ static void launch_bwd_sh_batch_c(const CompParams &p0, const CompParams *plist,
   // it (two wavefronts per tile: 2 838 vs 3 492 renders/s on the exact basis, profiles/r04_ab_shapes.txt)
   hipLaunchKernelGGL((k_composite_bwd_sh_vec<CB, 4, true>), g, dim3(64), 0, s, p0, plist);
 }
-int launch_bwd_sh_batch(int C, const CompParams &p0_, const CompParams *plist, uint32_t B, hipStream_t s, bool bounded) {
-  const uint32_t nblk = comp_grid(p0_) * (uint32_t)(p0_.nseg > 1 ? p0_.nseg : 1);
-  if (p0_.ntw * p0_.nth == 0 || B == 0) return 0;
-  const CompParams p0 = batch_arg(p0_, B);
+int launch_bwd_sh_batch(int C, const CompParams *host, uint32_t B, hipStream_t s, bool bounded) {
+  if (B == 0 || host[0].ntw * host[0].nth == 0) return 0;
+  const uint32_t nblk = comp_grid(host[0]) * (uint32_t)(host[0].nseg > 1 ? host[0].nseg : 1);
   const bool poly = C == 4 && bounded;
-  switch (C) {
-    case 1: launch_bwd_sh_batch_c<1>(p0, plist, B, nblk, s, false); break;
-    case 2: launch_bwd_sh_batch_c<2>(p0, plist, B, nblk, s, false); break;
-    case 3: launch_bwd_sh_batch_c<3>(p0, plist, B, nblk, s, false); break;
-    default: launch_bwd_sh_batch_c<4>(p0, plist, B, nblk, s, poly); break;
-  }
+  for_each_chunk(host, B, [&](const CompParams &p0, const ViewPack<true> &pack, uint32_t n) {
+    switch (C) {
+      case 1: launch_bwd_sh_batch_c<1>(p0, pack, n, nblk, s, false); break;
+      case 2: launch_bwd_sh_batch_c<2>(p0, pack, n, nblk, s, false); break;
+      case 3: launch_bwd_sh_batch_c<3>(p0, pack, n, nblk, s, false); break;
+      default: launch_bwd_sh_batch_c<4>(p0, pack, n, nblk, s, poly); break;
+    }
+  });
   return (int)hipGetLastError();
 }
 
 // post-activation channels, B cameras per launch: packed, one wavefront per tile (the same operation sequence as the per-camera
 // kernels: identical bits).  MODE_RGBD = fused RGB + heads, MODE_RGB = colours only.
 template <int MODE>
-static int launch_chan_batch(bool backward, const CompParams &p0_, const CompParams *plist, uint32_t B, hipStream_t s) {
-  const uint32_t nblk = comp_grid(p0_);
-  if (p0_.ntw * p0_.nth == 0 || B == 0) return 0;
-  const CompParams p0 = batch_arg(p0_, B);
-  if (backward) hipLaunchKernelGGL((k_composite_bwd_chan_vec<MODE, true>), dim3(nblk * B), dim3(64), 0, s, p0, plist);
-  else hipLaunchKernelGGL((k_composite_fwd_chan_vec<MODE, true>), dim3(nblk * B), dim3(64), 0, s, p0, plist);
+static int launch_chan_batch(bool backward, const CompParams *host, uint32_t B, hipStream_t s) {
+  if (B == 0 || host[0].ntw * host[0].nth == 0) return 0;
+  const uint32_t nblk = comp_grid(host[0]);
+  for_each_chunk(host, B, [&](const CompParams &p0, const ViewPack<true> &pack, uint32_t n) {
+    if (backward) hipLaunchKernelGGL((k_composite_bwd_chan_vec<MODE, true>), dim3(nblk * n), dim3(64), 0, s, p0, pack);
+    else hipLaunchKernelGGL((k_composite_fwd_chan_vec<MODE, true>), dim3(nblk * n), dim3(64), 0, s, p0, pack);
+  });
   return (int)hipGetLastError();
 }
-int launch_fwd_rgbd_batch(const CompParams &p0, const CompParams *plist, uint32_t B, hipStream_t s) { return launch_chan_batch<MODE_RGBD>(false, p0, plist, B, s); }
-int launch_bwd_rgbd_batch(const CompParams &p0, const CompParams *plist, uint32_t B, hipStream_t s) { return launch_chan_batch<MODE_RGBD>(true, p0, plist, B, s); }
-int launch_fwd_rgb_batch(const CompParams &p0, const CompParams *plist, uint32_t B, hipStream_t s) { return launch_chan_batch<MODE_RGB>(false, p0, plist, B, s); }
-int launch_bwd_rgb_batch(const CompParams &p0, const CompParams *plist, uint32_t B, hipStream_t s) { return launch_chan_batch<MODE_RGB>(true, p0, plist, B, s); }
+int launch_fwd_rgbd_batch(const CompParams *host, uint32_t B, hipStream_t s) { return launch_chan_batch<MODE_RGBD>(false, host, B, s); }
+int launch_bwd_rgbd_batch(const CompParams *host, uint32_t B, hipStream_t s) { return launch_chan_batch<MODE_RGBD>(true, host, B, s); }
+int launch_fwd_rgb_batch(const CompParams *host, uint32_t B, hipStream_t s) { return launch_chan_batch<MODE_RGB>(false, host, B, s); }
+int launch_bwd_rgb_batch(const CompParams *host, uint32_t B, hipStream_t s) { return launch_chan_batch<MODE_RGB>(true, host, B, s); }
 
 int launch_bwd_pixel_dispatch(int mode, int C, const CompParams &p, hipStream_t s) {
   if (mode == MODE_RGB) return launch_bwd<MODE_RGB, 1>(p, s);
@@ -2445,9 +2460,7 @@ int gsgen_vol_render_sh_batch_routed(uint32_t n_views, const gsgen_sh_view *view
   if (!bounded)
     for (CompParams &p : ps) { p.sh_bound = nullptr; p.sh_rows = nullptr; p.tile_flags = nullptr; }
   hipStream_t s = (hipStream_t)stream;
-  CompParams *dst = reinterpret_cast<CompParams *>(batch_workspace);
-  if (int e = write_params(ps.data(), n_views, dst, s)) return e;
-  return launch_fwd_sh_batch((int)C, ps[0], dst, n_views, s, bounded);
+  return launch_fwd_sh_batch((int)C, ps.data(), n_views, s, bounded);
 }
 
 int gsgen_vol_render_backward_sh_batch(uint32_t n_views, const gsgen_sh_view *views, uint32_t N,
@@ -2492,9 +2505,7 @@ int gsgen_vol_render_backward_sh_batch_routed(uint32_t n_views, const gsgen_sh_v
   if (!bounded)
     for (CompParams &p : ps) { p.sh_bound = nullptr; p.sh_rows = nullptr; p.tile_flags = nullptr; }
   hipStream_t s = (hipStream_t)stream;
-  CompParams *dst = reinterpret_cast<CompParams *>(batch_workspace) + n_views;
-  if (int e = write_params(ps.data(), n_views, dst, s)) return e;
-  return launch_bwd_sh_batch((int)C, ps[0], dst, n_views, s, bounded);
+  return launch_bwd_sh_batch((int)C, ps.data(), n_views, s, bounded);
 }
 
 static int fill_rgbd_params(uint32_t n_views, const gsgen_rgbd_view *views, const float *color, const float *alpha,
@@ -2541,9 +2552,7 @@ int gsgen_vol_render_rgbd_batch(uint32_t n_views, const gsgen_rgbd_view *views, 
   if (int e = fill_rgbd_params(n_views, views, color, alpha, nullptr, n_tiles_w, n_tiles_h, H, W, thresh, false, ps))
     return e;
   hipStream_t s = (hipStream_t)stream;
-  CompParams *dst = reinterpret_cast<CompParams *>(batch_workspace);
-  if (int e = write_params(ps.data(), n_views, dst, s)) return e;
-  return launch_fwd_rgbd_batch(ps[0], dst, n_views, s);
+  return launch_fwd_rgbd_batch(ps.data(), n_views, s);
 }
 
 int gsgen_vol_render_rgbd_backward_batch(uint32_t n_views, const gsgen_rgbd_view *views, uint32_t N,
@@ -2558,9 +2567,7 @@ int gsgen_vol_render_rgbd_backward_batch(uint32_t n_views, const gsgen_rgbd_view
   if (int e = fill_rgbd_params(n_views, views, color, alpha, grad_alpha, n_tiles_w, n_tiles_h, H, W, thresh, true, ps))
     return e;
   hipStream_t s = (hipStream_t)stream;
-  CompParams *dst = reinterpret_cast<CompParams *>(batch_workspace) + n_views;
-  if (int e = write_params(ps.data(), n_views, dst, s)) return e;
-  return launch_bwd_rgbd_batch(ps[0], dst, n_views, s);
+  return launch_bwd_rgbd_batch(ps.data(), n_views, s);
 }
 
 int gsgen_vol_render_rgb_batch(uint32_t n_views, const gsgen_rgbd_view *views, uint32_t N, const float *color,
@@ -2575,9 +2582,7 @@ int gsgen_vol_render_rgb_batch(uint32_t n_views, const gsgen_rgbd_view *views, u
                                false))
     return e;
   hipStream_t s = (hipStream_t)stream;
-  CompParams *dst = reinterpret_cast<CompParams *>(batch_workspace);
-  if (int e = write_params(ps.data(), n_views, dst, s)) return e;
-  return launch_fwd_rgb_batch(ps[0], dst, n_views, s);
+  return launch_fwd_rgb_batch(ps.data(), n_views, s);
 }
 
 int gsgen_vol_render_rgb_backward_batch(uint32_t n_views, const gsgen_rgbd_view *views, uint32_t N,
@@ -2594,9 +2599,7 @@ int gsgen_vol_render_rgb_backward_batch(uint32_t n_views, const gsgen_rgbd_view 
                                false, grad_color))
     return e;
   hipStream_t s = (hipStream_t)stream;
-  CompParams *dst = reinterpret_cast<CompParams *>(batch_workspace) + n_views;
-  if (int e = write_params(ps.data(), n_views, dst, s)) return e;
-  return launch_bwd_rgb_batch(ps[0], dst, n_views, s);
+  return launch_bwd_rgb_batch(ps.data(), n_views, s);
 }
 
 int gsgen_vol_render_sh(uint32_t N, uint32_t D, const float *mean, const float *cov,

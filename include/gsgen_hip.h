@@ -366,13 +366,14 @@ int gsgen_vol_render_backward_sh_segmented(uint32_t N, uint32_t D, const float *
 /* Batched cameras in ONE launch (the reference loops over the cameras of a batch in
  * Python, gs/gaussian_splatting.py:1423-1466, calling render_sh / its backward once per camera).  A
  * single 800x800 launch ends on a tail of long sparse tiles that leaves most of the chip idle;
- * gridDim.y = n_views pays that tail once per batch.  Every view has its own projected records,
+ * one launch per (at most 8) views pays that tail once per batch.  Every view has its own projected records,
  * lists and outputs; sh_coeffs / alpha and their gradients are shared, the gradients accumulating
  * atomically over views exactly as they do over tiles.  Per view the result is bit-identical to
  * gsgen_vol_render_sh_segmented / gsgen_vol_render_backward_sh_segmented on the same inputs
  * (gradient sums up to fp32 atomic order).  `views` is HOST memory, read before the call returns.
- * batch_workspace: device, gsgen_sh_batch_workspace_bytes(n_views) bytes, one per batch in flight
- * (it carries the per-view kernel parameters from the forward launch to the end of the backward).
+ * batch_workspace: device, gsgen_sh_batch_workspace_bytes(n_views) bytes, one per batch in flight.  (Since round 4 the per-view
+ * kernel parameters travel in the kernel arguments, 8 views per launch, and the plain batched entry points no longer write
+ * to it; the routed ones keep their per-tile routing bytes behind it -- size and argument stay for ABI stability.)
  * The batched forward writes EVERY pixel of out / T: empty tiles receive bg_rgb (0 without one) and T = 1, so the caller
  * need not pre-initialise the images (the per-camera entry points keep the reference's contract, vol_render.h:1006-1013). */
 typedef struct gsgen_sh_view {

@@ -992,18 +992,19 @@ def test_emulated_segmented_backward_matches_unsegmented(emu, C, nseg):
                                     P(bg), None, None, None, nseg, None)
 
 
-@pytest.mark.parametrize("C,nseg", [(4, 0), (3, 3)])
-def test_emulated_batched_views_match_per_view_launches(emu, C, nseg):
-    """gsgen_vol_render_sh_batch / _backward_sh_batch (gridDim.y = views, parameters through device
-    memory) == one gsgen_vol_render_sh_segmented / _backward_sh_segmented call per view, shared SH and
-    opacity gradients accumulated over the views"""
+@pytest.mark.parametrize("C,nseg,n_views", [(4, 0, 2), (3, 3, 3), (4, 0, 11), (2, 2, 9)])
+def test_emulated_batched_views_match_per_view_launches(emu, C, nseg, n_views):
+    """gsgen_vol_render_sh_batch / _backward_sh_batch (one launch per <= 8 views, the views' parameter blocks in the kernel
+    arguments; 9 and 11 views: a second launch with 1 / 3 views) == one gsgen_vol_render_sh_segmented /
+    _backward_sh_segmented call per view, shared SH and opacity gradients accumulated over the views"""
     from gsgen_amd._capi import ShView
     W, H = 32, 16
     sc = scenes.random_scene(420, seed=41, svec=0.1, C=C)
     sc["alpha"] = (sc["alpha"] * 0.3).astype(np.float32)
     Nall = sc["mean"].shape[0]
     sh, al = np.ascontiguousarray(sc["sh"]), np.ascontiguousarray(sc["alpha"])
-    cams = [scenes.Camera(W, H, fx=40.0, c2w=scenes.look_at(e)) for e in ((2.5, 0, 0), (0, 2.4, 0.6), (-1.5, -1.5, 1.2))][:2 + (nseg > 0)]
+    eyes = [(2.5, 0, 0), (0, 2.4, 0.6), (-1.5, -1.5, 1.2)] + [(2.4 * np.cos(t), 2.4 * np.sin(t), 0.3 * np.sin(3 * t)) for t in np.linspace(0.4, 5.6, 8)]
+    cams = [scenes.Camera(W, H, fx=40.0, c2w=scenes.look_at(e)) for e in eyes[:n_views]]
     nth, ntw = cams[0].tiles
     views, keep = [], []
     for cam in cams:
@@ -1088,12 +1089,11 @@ def test_no_kernel_spills_and_hot_kernels_keep_their_occupancy(tmp_path):
             kernels[name] = {k: int(re.search(rf"\.{k}:\s+(\d+)", blk).group(1))
                              for k in ("private_segment_fixed_size", "vgpr_count", "group_segment_fixed_size")}
     assert len(kernels) > 40
-    # no kernel may use scratch memory -- except the RGB + heads backward, which was given five wavefronts per SIMD in round 4
-    # (106 -> 96 registers) at the price of FOUR dwords spilled outside its per-entry loop (profiles/r04_notes.md)
+    # no kernel may use scratch memory -- except the batched RGB + heads kernels, which were given five (backward, 106 -> 96
+    # registers) and six (forward, 98 -> 80) wavefronts per SIMD in round 4 at the price of FOUR / ONE dwords spilled outside
+    # their per-entry loops (profiles/r04_notes.md)
     spilling = {k: v["private_segment_fixed_size"] for k, v in kernels.items() if v["private_segment_fixed_size"] != 0}
-    # ... and the batched polynomial SH forward, whose per-tile routing test (round 4) cost four registers: held at five wavefronts
-    # per SIMD (96) with TWO dwords spilled around its tile set-up, outside the per-entry loop
-    allowed = ("k_composite_bwd_chan_vecILi3E", "k_composite_fwd_sh_vecILi4ELi4ELb1ELi6EE")
+    allowed = ("k_composite_bwd_chan_vecILi3E", "k_composite_fwd_chan_vecILi3ELb1EE")
     assert all(any(a in k for a in allowed) and v <= 16 for k, v in spilling.items()), spilling
 
     def find(n, *parts):
@@ -1126,7 +1126,7 @@ def test_no_kernel_spills_and_hot_kernels_keep_their_occupancy(tmp_path):
     for bwd in find(2, "k_composite_bwd_chan_vecILi3E"):
         assert bwd["vgpr_count"] <= 96 and 20 * bwd["group_segment_fixed_size"] <= 160 * 1024, bwd
     for fwd in find(1, "k_composite_fwd_chan_vecILi3ELb1EE"):
-        assert fwd["vgpr_count"] <= 84 and 24 * fwd["group_segment_fixed_size"] <= 160 * 1024, fwd
+        assert fwd["vgpr_count"] <= 80 and 24 * fwd["group_segment_fixed_size"] <= 160 * 1024, fwd
     for fwd in find(1, "k_composite_fwdILi2ELi4ELi1ELi16EE"):      # per-camera SH forward: 4 wavefronts per tile
         assert fwd["vgpr_count"] <= 128
     # what round 4 pruned stays pruned: no unpacked backward for 16 x 16 tiles, no two-wavefront packed backward
