@@ -1559,14 +1559,17 @@ k_composite_fwd_chan_vec(CompParams p_arg, ViewPack<BATCH> pack) {
                   r_p0 = wave_uniform(S.p0[g]), r_p1 = wave_uniform(S.p1[g]), r_p2 = wave_uniform(S.p2[g]);
       const float p0x = r_p0 * (px - r_mx);
       v2f G2[NP], ag2[NP];
-      bool any_con = false, any_guard = false;
+      bool any_con = false;
+      float guard_dist = 0.0f;  // the lane's smallest distance to the threshold (dead pixels included: a spurious trip re-tests per pixel)
 #pragma unroll
       for (int jp = 0; jp < NP; ++jp) {
         G2[jp] = gauss_chol_pair(p0x, r_p1, r_p2, py2[jp] - splat2(r_my));
         ag2[jp] = splat2(r_a) * G2[jp];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) any_guard |= alive(2 * jp + k) && fabsf(ag2[jp][k] - kMinAlpha) <= kMinAlpha * kGuardTol;
+        const v2f dist = ag2[jp] - splat2(kMinAlpha);
+        const float dmin = fminf(fabsf(dist[0]), fabsf(dist[1]));
+        guard_dist = jp == 0 ? dmin : fminf(guard_dist, dmin);
       }
+      const bool any_guard = guard_dist <= kMinAlpha * kGuardTol;
       if (wave_any(any_guard)) {  // within rounding of the skip threshold: the reference's arithmetic decides
         const float r_c0 = S.c0[g], r_c1 = S.c1[g], r_c2 = S.c2[g], r_c3 = S.c3[g];
 #pragma unroll
@@ -1708,16 +1711,19 @@ k_composite_bwd_chan_vec(CompParams p_arg, ViewPack<BATCH> pack) {
       const float x = px - r_mx;
       // G2 / ag2: the Gaussian (gauss_eval's Cholesky form) and a G, ZEROED where the pixel does not take part
       v2f y2[NP], G2[NP], ag2[NP];
-      bool any_con = false, any_guard = false;
+      bool any_con = false;
+      float guard_dist = 0.0f;  // (as the forward: one distance per lane, dead pixels included)
       const float p0x = r_p0 * x;
 #pragma unroll
       for (int jp = 0; jp < NP; ++jp) {
         y2[jp] = py2[jp] - splat2(r_my);
         G2[jp] = gauss_chol_pair(p0x, r_p1, r_p2, y2[jp]);
         ag2[jp] = splat2(r_a) * G2[jp];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) any_guard |= alive(2 * jp + k) && fabsf(ag2[jp][k] - kMinAlpha) <= kMinAlpha * kGuardTol;
+        const v2f dist = ag2[jp] - splat2(kMinAlpha);
+        const float dmin = fminf(fabsf(dist[0]), fabsf(dist[1]));
+        guard_dist = jp == 0 ? dmin : fminf(guard_dist, dmin);
       }
+      const bool any_guard = guard_dist <= kMinAlpha * kGuardTol;
       if (wave_any(any_guard)) {  // within rounding of the skip threshold: the reference's arithmetic decides
         const float r_c0 = S.c0[g], r_c1 = S.c1[g], r_c2 = S.c2[g], r_c3 = S.c3[g];
 #pragma unroll
