@@ -1060,10 +1060,11 @@ def main():
                    "sh_degree": C - 1, "tile_pairs_D": D, "list_length_histogram": list_hist, "cameras_per_step": B,
                    "steps_in_flight": len(slots),
                    "backward_segments_per_tile": nseg,
-                   "sh_basis": (f"routed on the device, per TILE and per step: per-splat coefficient bounds are measured by every step inside "
-                                f"the timed region (gsgen_sh_l1_bound_rows; read back afterwards: largest S = {S_dev:.3f}); a tile takes the "
-                                f"tile-local degree-2 polynomial fit of the per-pixel basis while every splat it stages stays within the "
-                                f"bound for its view's pixel size, else the exact kernel: {tiles_exact} of {tiles_nonempty} non-empty tiles "
+                   "sh_basis": (f"routed on the device, per ENTRY and per TILE, every step: per-splat coefficient bounds are measured by every "
+                                f"step inside the timed region (gsgen_sh_l1_bound_rows; read back afterwards: largest S = {S_dev:.3f}); a splat "
+                                f"within the bound for its view's pixel size takes the tile-local degree-2 polynomial fit of the per-pixel "
+                                f"basis, one beyond it is evaluated exactly inside the same kernel, a tile whose staged batch holds more than "
+                                f"a quarter of such splats goes to the exact kernel: {tiles_exact} of {tiles_nonempty} non-empty tiles "
                                 f"of the slots' last steps went exact.  (Round 3's per-view rule on the global S: {n_poly_job} of "
                                 f"{ncam_job} cameras polynomial.)") if state["bounded"] else "exact per-pixel basis",
                    "tiles_exact_of_nonempty": [tiles_exact, tiles_nonempty],

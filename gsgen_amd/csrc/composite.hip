@@ -377,6 +377,91 @@ __device__ __forceinline__ int tile_thread_index() {
 #endif
   return t;
 }
+// ---- the per-entry exact tier of the polynomial kernels ---------------------------------------------------------------------
+// A splat beyond the coefficient bound of this view's pixel size (poly_row_ok fails) inside a tile that is otherwise the polynomial
+// kernel's: its three logits are evaluated EXACTLY at the lane's pixels -- the pixel's SH basis (the table of sh_basis) against the
+// raw coefficients, read through a wave-uniform address -- and enter the same denominators 1 + exp2(s) the polynomial values
+// would have.  Wave-uniform branch per entry (a bit of the staged batch's mask: scalar instructions only for every other entry),
+// about three times an ordinary entry's instructions; a batch with more than a quarter of such splats sends the tile to the exact
+// kernel instead (kExactTierShare).  The backward takes the splat's gradient through the tile's polynomial basis like any other
+// entry's: that error is the basis's own (<= 0.175 delta^3 per unit of d L / d s: 5e-7 at the headline pixel size), whatever the
+// coefficients.
+constexpr int kExactTierShare = 4;
+struct Logits3 { float s0, s1, s2; };
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const float __attribute__((address_space(4))) *uniform_floats;  // (constant address space + a scalar address: s_load)
+__device__ __forceinline__ uniform_floats uniform_pointer(const float *q) {
+  const uintptr_t u = (uintptr_t)q;
+  return (uniform_floats)(((uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) |
+                          (uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u));
+}
+__device__ __forceinline__ float rsqrt_fast(float v) { return __builtin_amdgcn_rsqf(v); }
+#else
+typedef const float *uniform_floats;  // (the host pass of hipcc and the CPU emulator build)
+__device__ __forceinline__ uniform_floats uniform_pointer(const float *q) { return q; }
+__device__ __forceinline__ float rsqrt_fast(float v) { return 1.0f / sqrtf(v); }
+#endif
+// One pixel's three logits -log2(e) * (sh_c . Y(pixel)), |s| <= 40 (as poly_transform keeps the polynomial's: the product of three
+// denominators stays finite).  NOT inlined, and written to stay small: the polynomial kernels' register budgets are their entry
+// loops' (inlined with a basis table, the backward went from 114 to 170 registers).  Both addresses are wave-uniform: scalar
+// loads; every basis value goes straight into the three dot products.
+__device__ __attribute__((noinline)) Logits3 exact_tier_logits(const float *rot_, const float *q_, float qx, float qy) {
+  const uniform_floats rot = uniform_pointer(rot_), q = uniform_pointer(q_);
+  float x = rot[0] * qx + rot[1] * qy + rot[2];
+  float y = rot[3] * qx + rot[4] * qy + rot[5];
+  float z = rot[6] * qx + rot[7] * qy + rot[8];
+  const float rl = rsqrt_fast(x * x + y * y + z * z);
+  x *= rl; y *= rl; z *= rl;
+  float a0 = 0.28209479177387814f * q[0], a1 = 0.28209479177387814f * q[16], a2 = 0.28209479177387814f * q[32];
+  auto add = [&](int k, float v) { a0 = fmaf(v, q[k], a0); a1 = fmaf(v, q[16 + k], a1); a2 = fmaf(v, q[32 + k], a2); };
+  add(1, -0.48860251190291987f * y);
+  add(2, 0.48860251190291987f * z);
+  add(3, -0.48860251190291987f * x);
+  __builtin_amdgcn_sched_barrier(0);  // (a few coefficients in flight at a time: scalar registers are the caller's parameters)
+  const float x2 = x * x, y2 = y * y, z2 = z * z;
+  add(4, 1.0925484305920792f * (x * y));
+  add(5, -1.0925484305920792f * (y * z));
+  add(6, 0.94617469575755997f * z2 - 0.31539156525251999f);
+  add(7, -1.0925484305920792f * (x * z));
+  add(8, 0.54627421529603959f * x2 - 0.54627421529603959f * y2);
+  __builtin_amdgcn_sched_barrier(0);
+  add(9, 0.59004358992664352f * y * (-3.0f * x2 + y2));
+  add(10, 2.8906114426405538f * (x * y) * z);
+  add(11, 0.45704579946446572f * y * (1.0f - 5.0f * z2));
+  add(12, 0.3731763325901154f * z * (5.0f * z2 - 3.0f));
+  __builtin_amdgcn_sched_barrier(0);
+  add(13, 0.45704579946446572f * x * (1.0f - 5.0f * z2));
+  add(14, 1.4453057213202769f * z * (x2 - y2));
+  add(15, 0.59004358992664352f * x * (-x2 + 3.0f * y2));
+  auto fin = [](float a) { return fminf(fmaxf(-kLog2e * a, -40.0f), 40.0f); };
+  return Logits3{fin(a0), fin(a1), fin(a2)};
+}
+template <int PPL>
+__device__ __forceinline__ void exact_tier_denominators(const CompParams &p, int id_uniform, float px, const v2f (&py2)[PPL / 2],
+                                                        v2f (&den)[3][PPL / 2]) {
+  const float *q = p.col + (size_t)id_uniform * 48u;
+#pragma unroll
+  for (int j = 0; j < PPL; ++j) {
+    const Logits3 l = exact_tier_logits(p.rot, q, px, py2[j >> 1][j & 1]);
+    den[0][j >> 1][j & 1] = 1.0f + __builtin_amdgcn_exp2f(l.s0);
+    den[1][j >> 1][j & 1] = 1.0f + __builtin_amdgcn_exp2f(l.s1);
+    den[2][j >> 1][j & 1] = 1.0f + __builtin_amdgcn_exp2f(l.s2);
+  }
+}
+// the staged batch's mask of such splats (bit g = entry g of the batch; KB <= 32).  NT threads, the first nb of them hold an entry.
+template <int NT>
+__device__ __forceinline__ uint32_t exact_tier_mask(const CompParams &p, const int *ids, int nb, int t, uint32_t *slot) {
+  bool bad = false;
+  if (p.sh_rows != nullptr && t < nb) bad = !poly_row_ok(p.sh_rows[ids[t]], fmaxf(fabsf(p.psx), fabsf(p.psy)));
+  const uint32_t m = (uint32_t)__ballot((int)bad);
+  if constexpr (NT == 64) {
+    (void)slot;
+    return m;
+  } else {  // the entries sit in the first wavefront: through LDS to the others (the caller's barrier follows)
+    if (t == 0) *slot = m;
+    return 0u;
+  }
+}
 template <int CB, bool POLY>
 struct FwdShVecShared {
   // POLY: 32 records per round -- 4.8 KB of LDS per workgroup, so that 20 one-wavefront workgroups (5 per SIMD) fit a CU
@@ -385,8 +470,10 @@ struct FwdShVecShared {
   alignas(16) float Vs[POLY ? kPolyNB * 16 : 4];          // POLY: V of this tile
   alignas(16) float Ws[POLY ? KB * 3 * kPolyStride : 4];  // POLY: transformed coefficients of the staged batch
                                                           // (and, before the first batch, the nine node bases)
+  uint32_t exact_mask;                                    // POLY, two wavefronts per tile: exact_tier_mask of the staged batch
 };
-template <int CB, int PPL, int NB, bool PERSIST = false>
+// TRACK = false: a launch known (on the host) to carry no stop list -- four registers of running state less
+template <int CB, int PPL, int NB, bool PERSIST = false, bool TRACK = true>
 __device__ __forceinline__ void composite_fwd_sh_vec_tile(const CompParams &p, uint32_t bid, FwdShVecShared<CB, (NB > 0)> &sm) {
   static_assert(PPL == 4 || PPL == 2, "pixel pairs: 2 or 4 pixels per lane");
   constexpr bool POLY = NB > 0;
@@ -479,18 +566,22 @@ __device__ __forceinline__ void composite_fwd_sh_vec_tile(const CompParams &p, u
   }
   auto alive = [&](int j) { return !(Tr2[j >> 1][j & 1] < p.thresh); };
   const bool seg_out = p.nseg > 1 && p.ckpt != nullptr;
-  const bool track_stop = p.stop != nullptr;
+  const bool track_stop = TRACK && p.stop != nullptr;
 
+  uint32_t exact_mask = 0u;  // POLY: the staged batch's splats of the per-entry exact tier
   for (int base = 0; base < n; base += KB) {
     const int nb = min(KB, n - base);
     if (base > 0) __syncthreads();  // everyone is done with the previous batch
     stage_batch<MODE, CB, NT, KB, true, !POLY>(S, p, st + base, nb);
     if constexpr (POLY) {
-      // per-tile routing: a staged splat beyond the bound for this view's pixel size sends the WHOLE tile to the exact
-      // kernel (nothing has been written yet; CompParams::tile_flags).  The test rides on the barrier that was here anyway.
-      bool bad = false;
-      if (p.sh_rows != nullptr && t < nb) bad = !poly_row_ok(p.sh_rows[S.id[t]], fmaxf(fabsf(p.psx), fabsf(p.psy)));
-      if (__syncthreads_or((int)bad) != 0) {
+      // per-tile routing: splats beyond the bound for this view's pixel size take the per-entry exact tier
+      // (exact_tier_denominators); more than a quarter of a staged batch sends the WHOLE tile to the exact kernel (nothing has
+      // been written yet; CompParams::tile_flags).
+      exact_mask = exact_tier_mask<NT>(p, S.id, nb, t, &sm.exact_mask);
+      __syncthreads();
+      if constexpr (NT != 64) exact_mask = sm.exact_mask;
+      exact_mask = (uint32_t)__builtin_amdgcn_readfirstlane((int)exact_mask);
+      if (__popcll((unsigned long long)exact_mask) * kExactTierShare > nb) {  // (uniform over the workgroup)
         if (t == 0 && p.tile_flags != nullptr) p.tile_flags[tile] = 1;
         return;
       }
@@ -563,13 +654,17 @@ __device__ __forceinline__ void composite_fwd_sh_vec_tile(const CompParams &p, u
 
       const float *cg = POLY ? &Ws[g * 3 * kPolyStride] : &S.col[g * TR::NCOLP];
       v2f w2[NP];
+      if constexpr (!POLY) {
 #pragma unroll
-      for (int jp = 0; jp < NP; ++jp)  // (a T) G, or 0; POLY: T (a G) -- a G is at hand (its own images only meet a tolerance)
-        w2[jp] = POLY ? Tr2[jp] * ag2[jp] : (splat2(r_a) * Tr2[jp]) * G2[jp];
+        for (int jp = 0; jp < NP; ++jp) w2[jp] = (splat2(r_a) * Tr2[jp]) * G2[jp];  // (a T) G, or 0
+      }
       if constexpr (POLY) {
         // the three channels' denominators 1 + exp2(s_c) first, then ONE reciprocal per pixel for all of them:
         // 1 / d_c = (1 / (d_0 d_1 d_2)) * (the other two).  (poly_transform keeps |s| <= 40: the product stays finite.)
         v2f den[3][NP];
+        if ((exact_mask >> g) & 1u) {  // the per-entry exact tier (wave-uniform: scalar instructions only on the ordinary path)
+          exact_tier_denominators<PPL>(p, __builtin_amdgcn_readfirstlane(S.id[g]), px, py2, den);
+        } else {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           const float *cw = cg + c * kPolyStride;  // (w0, w1 | w2, w4 | w5, 0 | w3, 0): composite_common.hpp
@@ -582,6 +677,9 @@ __device__ __forceinline__ void composite_fwd_sh_vec_tile(const CompParams &p, u
             den[c][jp] = splat2(1.0f) + v2f{__builtin_amdgcn_exp2f(sp[0]), __builtin_amdgcn_exp2f(sp[1])};
           }
         }
+        }
+#pragma unroll
+        for (int jp = 0; jp < NP; ++jp) w2[jp] = Tr2[jp] * ag2[jp];  // T (a G), or 0 (formed BEHIND the exact tier's calls: four registers less across them)
 #pragma unroll
         for (int jp = 0; jp < NP; ++jp) {
           const v2f d01 = den[0][jp] * den[1][jp];
@@ -684,9 +782,11 @@ __device__ __forceinline__ bool tile_flagged(const CompParams &p, uint32_t bid) 
   if (!block_tile(p, tx, ty, bid)) return false;
   return p.tile_flags[ty * p.ntw + tx] != 0;
 }
-template <int CB, int PPL, bool BATCH = false, int NB = 0>
+// TRACK = false (the batched polynomial kernel of an unsegmented launch only): no stop list to keep -- with the per-entry exact
+// tier's calls in the entry loop, those four registers decide whether the loop fits 96 without reloading spilled values per entry
+template <int CB, int PPL, bool BATCH = false, int NB = 0, bool TRACK = true>
 __global__ void __launch_bounds__(256 / PPL)
-GS_WAVES_PER_EU((NB == kPolyNB && BATCH && PPL == 4) ? 5 : 1)  // the batched polynomial forward: five wavefronts per SIMD (<= 96 registers)
+GS_WAVES_PER_EU((NB == kPolyNB && BATCH && PPL == 4 && !TRACK) ? 5 : 1)  // that kernel: five wavefronts per SIMD (<= 96 registers)
 k_composite_fwd_sh_vec(CompParams p_arg, ViewPack<BATCH> pack) {
   const CompParams *plist = pack.table();  // (kernel-argument memory: scalar loads, no table in device memory)
   uint32_t bid = blockIdx.x;
@@ -734,7 +834,7 @@ k_composite_fwd_sh_vec(CompParams p_arg, ViewPack<BATCH> pack) {
     const CompParams *pp = &plist[batch_view(p_arg, bid)];
     if (pp->sh_rows == nullptr && !poly_route(pp->sh_bound, pp->psx, pp->psy)) return;  // this view is the exact fallback's
     const CompParams p = *pp;
-    composite_fwd_sh_vec_tile<4, PPL, kPolyNB>(p, bid, sm);
+    composite_fwd_sh_vec_tile<4, PPL, kPolyNB, false, TRACK>(p, bid, sm);
   } else {
     const CompParams p = BATCH ? plist[batch_view(p_arg, bid)] : p_arg;  // see k_composite_fwd
     __shared__ FwdShVecShared<CB, (NB > 0)> sm;
@@ -1138,12 +1238,15 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
   }
   auto alive = [&](int j) { return !(Tr2[j >> 1][j & 1] < p.thresh); };
 
+  uint32_t exact_mask = 0u;
   for (int base = e_lo; base < e_hi; base += KB) {
     const int nb = min(KB, e_hi - base);
     if (base > e_lo) __syncthreads();
     stage_batch<MODE, CB, NT, KB, true, !POLY>(S, p, st + base, nb);
     __syncthreads();
     if constexpr (POLY) {
+      // (the forward's per-entry exact tier: the same splats, the same test -- a tile the forward gave up is not walked here)
+      exact_mask = (uint32_t)__builtin_amdgcn_readfirstlane((int)exact_tier_mask<NT>(p, S.id, nb, t, nullptr));
       poly_transform<NT, KB>(p.col, S.id, Vs, Ws, nb);
       __syncthreads();
     }
@@ -1228,6 +1331,9 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
         // colours as in the forward: the three channels' denominators first, then ONE reciprocal per pixel for the three
         // sigmoids and 1 / (1 - a G):  1 / x_i = (1 / prod x) * prod_{j != i} x_j  (|s| <= 40 by poly_transform, 1 - a G >= 0.01)
         v2f den[3][NP], yv[3][NP];
+        if ((exact_mask >> g) & 1u) {  // the forward's per-entry exact tier (wave-uniform)
+          exact_tier_denominators<PPL>(p, __builtin_amdgcn_readfirstlane(S.id[g]), px, py2, den);
+        } else {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           const float *cw = cg + c * kPolyStride;  // (w0, w1 | w2, w4 | w5, 0 | w3, 0): composite_common.hpp
@@ -1239,6 +1345,7 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
             const v2f sp = ffma2(pv2[jp], ffma2(pv2[jp], splat2(Cc), splat2(ab[1])), splat2(ab[0]));  // (explicitly fused: every shape of the kernel agrees)
             den[c][jp] = splat2(1.0f) + v2f{__builtin_amdgcn_exp2f(sp[0]), __builtin_amdgcn_exp2f(sp[1])};
           }
+        }
         }
 #pragma unroll
         for (int jp = 0; jp < NP; ++jp) {
@@ -1929,13 +2036,17 @@ static void launch_fwd_sh_batch_c(const CompParams &p0, const ViewPack<true> &pl
       pf.vgrid = nblk * B;
       const uint32_t gf = pf.vgrid < 2560u ? pf.vgrid : 2560u;
       if (p0.sh_rows != nullptr) {  // per-tile routing: the polynomial kernel flags the tiles the fallback BEHIND it renders
-        hipLaunchKernelGGL((k_composite_fwd_sh_vec<4, 4, true, kPolyNB>), g, dim3(64), 0, s, p0, plist);
+        if (p0.stop == nullptr) hipLaunchKernelGGL((k_composite_fwd_sh_vec<4, 4, true, kPolyNB, false>), g, dim3(64), 0, s, p0, plist);
+        else hipLaunchKernelGGL((k_composite_fwd_sh_vec<4, 4, true, kPolyNB>), g, dim3(64), 0, s, p0, plist);
         hipLaunchKernelGGL((k_composite_fwd_sh_vec<4, 2, true, kFallback>), dim3(gf), dim3(128), 0, s, pf, plist);
         return;
       }
       launch_beside(
           s, [&](hipStream_t q) { hipLaunchKernelGGL((k_composite_fwd_sh_vec<4, 2, true, kFallback>), dim3(gf), dim3(128), 0, q, pf, plist); },
-          [&](hipStream_t q) { hipLaunchKernelGGL((k_composite_fwd_sh_vec<4, 4, true, kPolyNB>), g, dim3(64), 0, q, p0, plist); });
+          [&](hipStream_t q) {
+            if (p0.stop == nullptr) hipLaunchKernelGGL((k_composite_fwd_sh_vec<4, 4, true, kPolyNB, false>), g, dim3(64), 0, q, p0, plist);
+            else hipLaunchKernelGGL((k_composite_fwd_sh_vec<4, 4, true, kPolyNB>), g, dim3(64), 0, q, p0, plist);
+          });
       return;
     }
   }

@@ -466,10 +466,11 @@ int gsgen_vol_render_backward_sh_bounded(uint32_t N, uint32_t D, const float *me
  * higher-band coefficients, or a wide camera, sends the whole view to the exact kernels.  The *_routed entry points take the
  * bound per SPLAT -- sh_row_bounds[i] = max over the three channels of sum_{k >= 1} |sh[i][c][k]|, DEVICE memory, [N], measured per
  * step by gsgen_sh_l1_bound_rows (one coalesced pass, no atomics but one per workgroup; out_max, optional, receives the global
- * maximum the per-view rule uses) -- and decide per TILE: a tile is rendered through the polynomial form as long as every splat it
- * stages satisfies 0.25 * S_i * 0.7 delta^3 <= 1e-5 for its view's pixel size (the same rule, per splat); the first staged batch
- * holding a splat beyond it sends that tile -- and only that tile -- to the exact kernel.  Splats behind the point where the
- * tile's pixels saturate are never staged and never count.  Batched launches record the decision in one byte per (view, tile)
+ * maximum the per-view rule uses) -- and decide per ENTRY and per TILE: a splat that satisfies 0.25 * S_i * 0.7 delta^3 <= 1e-5
+ * for its view's pixel size (the same rule, per splat) is evaluated through the tile's polynomial form; one beyond it is evaluated
+ * exactly, entry by entry, inside the same kernel (the pixel's own SH basis against its raw coefficients); a staged batch of 32
+ * records with more than a quarter of such splats sends its tile -- and only that tile -- to the exact kernel.  Splats behind the
+ * point where the tile's pixels saturate are never staged and never count.  Batched launches record the decision in one byte per (view, tile)
  * inside batch_workspace (gsgen_sh_batch_workspace_bytes_routed): the polynomial forward writes it, the exact fallback behind it
  * and both backward kernels read it, so forward and backward agree by construction; per-camera launches scan the tile's list
  * first, forward and backward alike.  sh_row_bounds == NULL: exactly the *_bounded behaviour on sh_l1_bound.  SH degree 3 only

@@ -1094,7 +1094,45 @@ def test_no_kernel_spills_and_hot_kernels_keep_their_occupancy(tmp_path):
     # their per-entry loops (profiles/r04_notes.md)
     spilling = {k: v["private_segment_fixed_size"] for k, v in kernels.items() if v["private_segment_fixed_size"] != 0}
     allowed = ("k_composite_bwd_chan_vecILi3E", "k_composite_fwd_chan_vecILi3ELb1EE")
-    assert all(any(a in k for a in allowed) and v <= 16 for k, v in spilling.items()), spilling
+    # ... and the kernels that carry the polynomial SH body: its per-entry exact tier calls exact_tier_logits (8 bytes of the
+    # callee's), and the batched forward, held at five wavefronts per SIMD, spills inside the tier's copy of the entry body --
+    # never inside the ordinary entries' loop (checked on the disassembly below)
+    tier = ("sh_vecILi4ELi4ELb1ELi6E", "sh_vecILi4ELi4ELb0ELin1E", "sh_vecILi4ELi2ELb0ELin1E")
+    for k, v in spilling.items():
+        assert (any(a in k for a in allowed) and v <= 16) or (any(a in k for a in tier) and v <= 96), spilling
+    # disassembly: the entry loop -- the smallest loop (backward branch) that holds the body's calls, one gauss_ref and one
+    # exact_tier_logits per pixel of a lane -- holds no scratch access: what is spilled is spilled around the loop
+    n_checked = 0
+    for f in sorted(os.listdir(tmp_path)):
+        if "amdgcn" not in f:
+            continue
+        dis = subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", "--no-show-raw-insn", f], cwd=tmp_path, capture_output=True,
+                             text=True, check=True).stdout
+        for blk in re.split(r"\n(?=[0-9a-f]+ <)", dis):
+            m = re.match(r"[0-9a-f]+ <(\S+)>:", blk)
+            if not m or not any(a in m.group(1) for a in tier) or not m.group(1).startswith("_ZN2gs22k_composite"):
+                continue
+            ins = [(int(a, 16), t.strip()) for t, a in re.findall(r"^\s+(\S.*?)\s+// ([0-9A-Fa-f]+):", blk, flags=re.M)]
+            assert len(ins) > 500, m.group(1)
+            scratch = [a for a, t in ins if t.startswith("scratch_")]
+            calls = [a for a, t in ins if t.startswith("s_swappc")]
+            ppl = 4 if "sh_vecILi4ELi4E" in m.group(1) else 2
+            entry_loops = []
+            for a, t in ins:
+                b = re.match(r"s_c?branch\S*\s+(\d+)", t)
+                if not b:
+                    continue
+                # (objdump prints branch targets as the signed word offset from the next instruction)
+                off = int(b.group(1)); off = off - 65536 if off >= 32768 else off
+                tgt = a + 4 + 4 * off
+                if tgt <= a and sum(tgt <= c <= a for c in calls) == 2 * ppl:
+                    entry_loops.append((a - tgt, tgt, a))
+            assert entry_loops, m.group(1)
+            _, lo, hi = min(entry_loops)
+            assert 600 <= hi - lo <= 3200, (m.group(1), hi - lo)   # (150 .. 800 instructions: an entry body)
+            assert not any(lo <= x <= hi for x in scratch), (m.group(1), hex(lo), hex(hi))
+            n_checked += 1
+    assert n_checked >= 5, n_checked
 
     def find(n, *parts):
         hits = [v for k, v in kernels.items() if all(p in k for p in parts)]
@@ -1111,16 +1149,19 @@ def test_no_kernel_spills_and_hot_kernels_keep_their_occupancy(tmp_path):
     # fallback (the exact kernels' budgets).
     for bwd in find(1, "k_composite_bwd_sh_vecILi4ELi4ELb0ELin1EE"):
         assert bwd["vgpr_count"] <= 168 and 12 * bwd["group_segment_fixed_size"] <= 160 * 1024, bwd
-    for fwd in find(1, "k_composite_fwd_sh_vecILi4ELi2ELb0ELin1EE"):
+    for fwd in find(1, "k_composite_fwd_sh_vecILi4ELi2ELb0ELin1E"):
         assert fwd["vgpr_count"] <= 96 and 10 * fwd["group_segment_fixed_size"] <= 160 * 1024, fwd
     for bwd in find(1, "k_composite_bwd_sh_vecILi4ELi4ELb1ELi6EE"):
         assert bwd["vgpr_count"] <= 128 and 16 * bwd["group_segment_fixed_size"] <= 160 * 1024, bwd
-    for fwd in find(1, "k_composite_fwd_sh_vecILi4ELi4ELb1ELi6EE"):
+    # (the forward of an unsegmented batch keeps no stop list: <..., TRACK = false>, the one held at five; a segmented batch's four)
+    for fwd in find(1, "k_composite_fwd_sh_vecILi4ELi4ELb1ELi6ELb0EE"):
         assert fwd["vgpr_count"] <= 96 and 20 * fwd["group_segment_fixed_size"] <= 160 * 1024, fwd
+    for fwd in find(1, "k_composite_fwd_sh_vecILi4ELi4ELb1ELi6ELb1EE"):
+        assert fwd["vgpr_count"] <= 128 and 16 * fwd["group_segment_fixed_size"] <= 160 * 1024, fwd
     # (the persistent fallback: three wavefronts per SIMD in the backward as the exact kernel itself, four in the forward)
     for bwd in find(1, "k_composite_bwd_sh_vecILi4ELi4ELb1ELin2EE"):
         assert bwd["vgpr_count"] <= 168 and 12 * bwd["group_segment_fixed_size"] <= 160 * 1024, bwd
-    for fwd in find(1, "k_composite_fwd_sh_vecILi4ELi2ELb1ELin2EE"):
+    for fwd in find(1, "k_composite_fwd_sh_vecILi4ELi2ELb1ELin2E"):
         assert fwd["vgpr_count"] <= 128 and 8 * fwd["group_segment_fixed_size"] <= 160 * 1024, fwd
     # the trainer's default outputs (RGB + heads, packed, one wavefront per tile): FIVE wavefronts per SIMD backward, SIX forward
     for bwd in find(2, "k_composite_bwd_chan_vecILi3E"):
@@ -1292,23 +1333,30 @@ def test_emulated_polynomial_sh_basis_batched_launches(emu, nseg):
 
 @pytest.mark.parametrize("nseg", [0, 3])
 def test_emulated_polynomial_sh_basis_is_routed_per_tile(emu, nseg):
-    """Round 4: the *_routed entry points decide per TILE from per-SPLAT bounds (gsgen_sh_l1_bound_rows).  A scene in which a few
-    splats carry large higher-band coefficients: the tiles whose walked lists hold one are rendered by the exact kernel -- bit
-    for bit what the all-exact launch leaves in those tiles -- every other tile by the polynomial form (fit error only); the
-    per-view rule of round 3 would have sent both views to the exact kernels.  The backward takes the same decisions (flags
-    written by the forward) and its gradients match the exact launch's to the fit error.  Also through the per-camera entry
-    points (the routed kernel scans each tile's list first)."""
+    """gsgen_vol_render_sh_batch_routed with per-splat bounds (round 4).  A scene whose bulk passes the routing rule while four
+    splats carry large higher-band coefficients: inside the polynomial kernel those splats take the PER-ENTRY EXACT TIER (their
+    logits from the pixel's own SH basis), so a tile that holds one is still the polynomial kernel's and still within the fit
+    error of the all-exact launch -- whereas rendering them through the polynomial (bounds of zero) is visibly wrong; only a
+    staged batch with more than a quarter of such splats sends its tile to the exact kernel -- bit for bit what the all-exact
+    launch leaves there.  The per-view rule of round 3 would have sent both views to the exact kernels.  The backward takes the
+    same decisions (flags written by the forward, the same per-splat test) and its gradients match the exact launch's to the
+    fit error.  Also through the per-camera entry points (the routed kernel scans each tile's list first)."""
     from gsgen_amd._capi import ShView
     C, W, H = 4, 64, 48
-    sc = scenes.random_scene(300, seed=23, svec=0.012, spread=0.045, C=C)
-    sc["sh"][:, :, 1:] *= 0.5
+    sc = scenes.random_scene(300, seed=23, svec=0.048, spread=0.18, C=C)
+    sc["sh"][:, :, 1:] *= 0.0078
     rng = np.random.default_rng(4)
-    outl = rng.choice(300, 4, replace=False)
-    sc["sh"][outl, :, 1:] *= 40.0   # four outlier splats: sum |sh| ~ 100, far beyond any view's bound here
+    # outlier splats: four at random and a cluster of ten neighbours (a staged batch with more than a quarter of them), all of
+    # their weight coherent in the degree-3 band: sum |sh| = 21, far beyond any view's bound here
+    lone = rng.choice(300, 4, replace=False)
+    centre = sc["mean"][int(rng.integers(300))]
+    outl = np.union1d(lone, np.argsort(np.linalg.norm(sc["mean"] - centre, axis=1))[:10])
+    sc["sh"][outl, :, 9:] = 3.0
+    sc["sh"][outl, :, 0] = 0.0
     sc["alpha"] = (sc["alpha"] * 0.5).astype(np.float32)
     N = sc["mean"].shape[0]
     sh, al = np.ascontiguousarray(sc["sh"]), np.ascontiguousarray(sc["alpha"])
-    cams = [scenes.Camera(W, H, fx=520.0 + 60 * i, c2w=scenes.orbit(2.5, 10 + 20 * i, 40.0 + 100 * i)) for i in range(2)]
+    cams = [scenes.Camera(W, H, fx=130.0 + 15 * i, c2w=scenes.orbit(2.5, 10 + 20 * i, 40.0 + 100 * i)) for i in range(2)]
     nth, ntw = cams[0].tiles
     T = nth * ntw
     # the per-splat bounds on the "device" == numpy; the global maximum comes along
@@ -1319,7 +1367,7 @@ def test_emulated_polynomial_sh_basis_is_routed_per_tile(emu, nseg):
     ps_max = max(1 / c.fx for c in cams)
     assert not emu.sh_poly_applies(float(gmax[0]), ps_max, 4)          # round 3: the whole view exact
     ok = np.array([emu.sh_poly_applies(float(r), ps_max, 4) or r == 0.0 for r in rows])
-    assert (~ok).sum() == 4 and set(np.nonzero(~ok)[0]) == set(outl)
+    assert set(np.nonzero(~ok)[0]) == set(outl)
     views = []
     for i, cam in enumerate(cams):
         g = scenes.oracle_geometry(sc, cam)
@@ -1353,16 +1401,30 @@ def test_emulated_polynomial_sh_basis_is_routed_per_tile(emu, nseg):
 
     exact, e_gsh, e_ga, _ = launch(None)
     routed, r_gsh, r_ga, flags = launch(rows)
-    n_flagged = 0
-    for vi, (v, e, q) in enumerate(zip(views, exact, routed)):
+    naive, _, _, naive_flags = launch(np.zeros(N, np.float32))  # every splat "within the bound": the polynomial for the outliers too
+    assert not naive_flags.any()
+    n_flagged = n_tier = 0
+    worst_naive = 0.0
+    for vi, (v, e, q, nv) in enumerate(zip(views, exact, routed, naive)):
         st, en, ids = v["st"], v["en"], v["ids"]
+
+        def crowded(t, only_first):  # a staged batch (32 entries) of tile t with more than a quarter of outliers
+            if st[t] < 0:
+                return False
+            for b0 in range(st[t], st[t] + 32 if only_first else en[t], 32):
+                chunk = ids[b0:min(en[t], b0 + 32)]
+                if len(chunk) and 4 * int(np.isin(chunk, outl).sum()) > len(chunk):
+                    return True
+            return False
         has_outlier = np.array([st[t] >= 0 and bool(np.isin(ids[st[t]:en[t]], outl).any()) for t in range(T)])
-        first_batch = np.array([st[t] >= 0 and bool(np.isin(ids[st[t]:min(en[t], st[t] + 32)], outl).any()) for t in range(T)])
+        may_flag = np.array([crowded(t, False) for t in range(T)])
+        must_flag = np.array([crowded(t, True) for t in range(T)])
         fl = flags[vi].astype(bool)
-        assert not (fl & ~has_outlier).any()          # only tiles that hold an outlier are ever flagged
-        assert (fl | ~first_batch).all()              # an outlier in the first staged batch always flags
+        assert not (fl & ~may_flag).any()             # only a crowded batch ever flags a tile ...
+        assert (fl | ~must_flag).all()                # ... and a crowded FIRST batch always does (later ones may never be staged)
         assert set(np.unique(flags[vi])) <= {0, 1}    # every tile's flag was written (the workspace started as 7s)
         n_flagged += int(fl.sum())
+        n_tier += int((has_outlier & ~fl).sum())
         assert np.array_equal(q["T"], e["T"])
         for t in range(T):
             ty, tx = divmod(t, ntw)
@@ -1370,11 +1432,17 @@ def test_emulated_polynomial_sh_basis_is_routed_per_tile(emu, nseg):
             if fl[t]:
                 assert np.array_equal(q["out"][sl], e["out"][sl]), (vi, t)   # the exact kernel rendered it: the same bits
             else:
-                assert np.abs(q["out"][sl] - e["out"][sl]).max() <= 2e-5, (vi, t)
+                assert np.abs(q["out"][sl] - e["out"][sl]).max() <= 2e-6, (vi, t)   # (the bulk's bound is 1e-5 * 0.1 here)
+                if has_outlier[t]:
+                    worst_naive = max(worst_naive, float(np.abs(nv["out"][sl] - e["out"][sl]).max()))
         assert np.abs(q["gm"] - e["gm"]).max() <= 1e-4 * np.abs(e["gm"]).max()
         assert np.abs(q["gc"] - e["gc"]).max() <= 1e-4 * np.abs(e["gc"]).max()
-    assert 0 < n_flagged < 2 * T and np.abs(np.concatenate([q["out"] - e["out"] for q, e in zip(routed, exact)])).max() > 0
-    assert np.abs(r_gsh - e_gsh).max() <= 1e-4 * np.abs(e_gsh).max() and np.abs(r_ga - e_ga).max() <= 1e-4 * np.abs(e_ga).max()
+    assert n_tier >= 4 and 0 < n_flagged < n_tier      # most outlier tiles stay with the polynomial kernel, the cluster's do not
+    assert worst_naive > 1e-5                          # ... where the polynomial alone is an order of magnitude further off
+    assert np.abs(np.concatenate([q["out"] - e["out"] for q, e in zip(routed, exact)])).max() > 0
+    # (d L / d sh goes through the tile's polynomial basis for EVERY entry: that basis is off by <= 0.175 delta^3 = 1.2e-4 per
+    # unit of d L / d s at these cameras -- the widest pixel size the rule admits at all -- whatever the coefficients)
+    assert np.abs(r_gsh - e_gsh).max() <= 5e-4 * np.abs(e_gsh).max() and np.abs(r_ga - e_ga).max() <= 1e-4 * np.abs(e_ga).max()
     # NaN coefficients: their splat never passes the bound (its tiles go exact), nothing else changes
     sh_nan = sh.copy(); sh_nan[outl[0], 1, 5] = np.nan
     rows_nan = np.zeros(N, np.float32)
@@ -1405,9 +1473,9 @@ def test_emulated_polynomial_sh_basis_is_routed_per_tile(emu, nseg):
             assert np.array_equal(outs["routed"][0][sl], outs["exact"][0][sl]), t
             n_exact_tiles += 1
         else:
-            assert np.abs(outs["routed"][0][sl] - outs["exact"][0][sl]).max() <= 2e-5
+            assert np.abs(outs["routed"][0][sl] - outs["exact"][0][sl]).max() <= 2e-6
     assert 0 < n_exact_tiles < T and np.abs(outs["routed"][0] - outs["exact"][0]).max() > 0
-    assert np.abs(outs["routed"][1] - outs["exact"][1]).max() <= 1e-4 * np.abs(outs["exact"][1]).max()
+    assert np.abs(outs["routed"][1] - outs["exact"][1]).max() <= 5e-4 * np.abs(outs["exact"][1]).max()   # (as above)
     assert np.abs(outs["routed"][2] - outs["exact"][2]).max() <= 1e-4 * np.abs(outs["exact"][2]).max()
 
 

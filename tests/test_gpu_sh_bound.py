@@ -136,11 +136,12 @@ def test_one_batch_narrow_and_wide_cameras_are_routed_per_view():
         assert np.array_equal(one.cpu().numpy(), img["auto"][i]), i
 
 
-def test_outlier_splats_cost_their_tiles_not_the_view():
-    """Round 4, per-tile routing: 0.2 % of the splats carry higher-band coefficients 60 x larger than the rest.  Round 3's per-view
-    rule sends both views to the exact kernels; now only the tiles that STAGE such a splat go exact (a minority), every other
-    tile stays polynomial, the images stay within 1e-4 of the oracle on every pixel and the gradients within 1e-4 of the exact
-    launch's.  The tiles the polynomial forward flagged are bit-identical to the exact launch's."""
+def test_outlier_splats_cost_their_entries_not_the_view():
+    """Round 4, per-tile routing with a per-entry exact tier: 0.2 % of the splats carry higher-band coefficients 60 x larger than
+    the rest.  Round 3's per-view rule sends both views to the exact kernels; now those splats alone are evaluated exactly,
+    entry by entry, inside the polynomial kernel -- a tile only goes to the exact kernel when more than a quarter of a staged
+    batch is such splats (here: almost none) --, the images stay within 1e-4 of the oracle on every pixel and the gradients
+    within 1e-4 of the exact launch's.  Tiles the polynomial forward did flag are bit-identical to the exact launch's."""
     from gsgen_amd import renderer as R, _capi
     from gsgen_amd.batch import BatchRenderer
     L = _capi.load()
@@ -170,7 +171,7 @@ def test_outlier_splats_cost_their_tiles_not_the_view():
         out[basis] = (rgb.detach().cpu().numpy(), T.cpu().numpy(), g.cpu().numpy())
     frac = flags.sum() / max(1, nonempty.sum())
     scenes.PARITY_LOG.append(f"per-tile routing, 0.2 % outlier splats: {int(flags.sum())} of {int(nonempty.sum())} non-empty tiles exact = 0")
-    assert 0.0 < frac < 0.5, frac
+    assert frac < 0.02, frac
     assert np.array_equal(out["auto"][1], out["exact"][1])
     ntw = (W + 15) // 16
     for i in range(B):
