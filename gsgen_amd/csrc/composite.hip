@@ -1331,9 +1331,6 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
         // colours as in the forward: the three channels' denominators first, then ONE reciprocal per pixel for the three
         // sigmoids and 1 / (1 - a G):  1 / x_i = (1 / prod x) * prod_{j != i} x_j  (|s| <= 40 by poly_transform, 1 - a G >= 0.01)
         v2f den[3][NP], yv[3][NP];
-        if ((exact_mask >> g) & 1u) {  // the forward's per-entry exact tier (wave-uniform)
-          exact_tier_denominators<PPL>(p, __builtin_amdgcn_readfirstlane(S.id[g]), px, py2, den);
-        } else {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           const float *cw = cg + c * kPolyStride;  // (w0, w1 | w2, w4 | w5, 0 | w3, 0): composite_common.hpp
@@ -1346,7 +1343,8 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
             den[c][jp] = splat2(1.0f) + v2f{__builtin_amdgcn_exp2f(sp[0]), __builtin_amdgcn_exp2f(sp[1])};
           }
         }
-        }
+        if ((exact_mask >> g) & 1u)  // the forward's per-entry exact tier (wave-uniform): overwrites the polynomial's denominators
+          exact_tier_denominators<PPL>(p, __builtin_amdgcn_readfirstlane(S.id[g]), px, py2, den);
 #pragma unroll
         for (int jp = 0; jp < NP; ++jp) {
           const v2f om = one_minus2(ag2[jp]);
