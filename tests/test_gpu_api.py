@@ -275,15 +275,15 @@ def test_batched_geometry_and_projection_backward_c_abi():
         assert int(g.total.item()) == Ds[i]
         for k in ("mean2d", "cov2d", "depth", "mask", "ids", "start", "end"):
             assert torch.equal(getattr(r, k), getattr(g, k)), (i, k)
-        # the workspace too (counts, offsets, keys, rectangles), except the launch order: tiles of one
-        # length bucket are placed by LDS atomics, so only "same buckets, a permutation" is defined
+        # the workspace's public part too (list lengths + control words, offsets), except the launch order: tiles of one
+        # length bucket are placed by LDS atomics, so only "same buckets, a permutation" is defined.  (Behind it the batch's
+        # push binning fills the key segments in no particular order within a chunk: the sort makes the lists.)
         wr, wg = r.ws.clone(), g.ws.clone()
         o = r.tile_order() - r.ws.data_ptr()
         orders = []
         for w in (wr, wg):
             orders.append(w[o:o + 4 * T].view(torch.int32).clone())
-            w[o:o + 4 * T] = 0
-        assert torch.equal(wr, wg), i
+        assert torch.equal(wr[:o], wg[:o]), i
         cnt = (r.end - r.start).clamp(min=0)
         for od in orders:
             assert torch.equal(od.sort().values, torch.arange(T, device=dev(), dtype=torch.int32))
