@@ -585,32 +585,39 @@ k_scan_order_tiles_views(uint32_t T, const GeoView *__restrict__ views) {
 constexpr int kPushOwn = 12;
 constexpr uint32_t kPushMaxTiles = 8192;  // 32 KB of LDS: 2 048 x 1 024 pixels and the like
 constexpr int kPushThreads = 256;
+// the counters: T words of dynamic LDS (10 KB at 800 x 800: a workgroup finds room beside the compositing kernels' blocks
+// sooner than with the 32 KB of the largest image); the CPU emulator build has no dynamic LDS and takes the maximum
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GS_PUSH_COUNTERS(name) extern __shared__ uint32_t name[]
+#else
+#define GS_PUSH_COUNTERS(name) __shared__ uint32_t name[kPushMaxTiles]
+#endif
 template <bool EMIT>
-__global__ void __launch_bounds__(kPushThreads)
-k_bin_push_views(uint32_t N, int ntw, int nth, uint32_t T, const GeoView *__restrict__ views) {
-  __shared__ uint32_t s_tile[kPushMaxTiles];
-  const GeoView v = views[blockIdx.y];
-  if (EMIT && v.ctrl[1] != 0u) return;  // capacity exceeded: bin nothing
+__device__ __forceinline__ void
+bin_push_body(uint32_t N, const int *__restrict__ tl, const int *__restrict__ br, const float *__restrict__ depth, int ntw, int nth,
+              uint32_t T, uint32_t *__restrict__ cnt, const uint32_t *__restrict__ tile_off, const uint32_t *__restrict__ ctrl,
+              unsigned long long *__restrict__ keys, uint32_t *s_tile) {
+  if (EMIT && ctrl[1] != 0u) return;  // capacity exceeded: bin nothing
   const uint32_t chunk = blockIdx.x;
-  uint32_t *const crow = v.cnt + (size_t)chunk * T;
-  for (uint32_t t = threadIdx.x; t < T; t += (uint32_t)kPushThreads) s_tile[t] = EMIT ? v.tile_off[t] + crow[t] : 0u;
+  uint32_t *const crow = cnt + (size_t)chunk * T;
+  for (uint32_t t = threadIdx.x; t < T; t += (uint32_t)kPushThreads) s_tile[t] = EMIT ? tile_off[t] + crow[t] : 0u;
   __syncthreads();
   const int lane = lane_id();
   const uint32_t stop = min(N, chunk * (uint32_t)kChunk + (uint32_t)kChunk);
   auto visit = [&](int tile, uint32_t id, unsigned dbits) {
     const uint32_t pos = atomicAdd(&s_tile[tile], 1u);
-    if (EMIT) v.keys[pos] = ((unsigned long long)dbits << 32) | (unsigned long long)id;
+    if (EMIT) keys[pos] = ((unsigned long long)dbits << 32) | (unsigned long long)id;
   };
   for (uint32_t i0 = chunk * (uint32_t)kChunk; i0 < stop; i0 += (uint32_t)kPushThreads) {  // (uniform trip count: ballots inside)
     const uint32_t i = i0 + threadIdx.x;
     int x0 = 0, y0 = 0, x1 = -1, y1 = -1;
     unsigned db = 0u;
     if (i < stop) {
-      const int2 a = *reinterpret_cast<const int2 *>(v.tl + 2 * (size_t)i);
-      const int2 c = *reinterpret_cast<const int2 *>(v.br + 2 * (size_t)i);
+      const int2 a = *reinterpret_cast<const int2 *>(tl + 2 * (size_t)i);
+      const int2 c = *reinterpret_cast<const int2 *>(br + 2 * (size_t)i);
       // rectangles clamped to the grid, as the pull kernels take them
       x0 = max(a.x, 0); y0 = max(a.y, 0); x1 = min(c.x, ntw - 1); y1 = min(c.y, nth - 1);
-      if (EMIT) db = __float_as_uint(v.depth[i]);
+      if (EMIT) db = __float_as_uint(depth[i]);
     }
     const int rw = x1 - x0 + 1, rh = y1 - y0 + 1;
     const int n = (rw > 0 && rh > 0) ? rw * rh : 0;
@@ -639,6 +646,22 @@ k_bin_push_views(uint32_t N, int ntw, int nth, uint32_t T, const GeoView *__rest
     __syncthreads();
     for (uint32_t t = threadIdx.x; t < T; t += (uint32_t)kPushThreads) crow[t] = s_tile[t];
   }
+}
+
+template <bool EMIT>
+__global__ void __launch_bounds__(kPushThreads)
+k_bin_push(uint32_t N, const int *__restrict__ tl, const int *__restrict__ br, const float *__restrict__ depth, int ntw, int nth,
+           uint32_t T, uint32_t *__restrict__ cnt, const uint32_t *__restrict__ tile_off, const uint32_t *__restrict__ ctrl,
+           unsigned long long *__restrict__ keys) {
+  GS_PUSH_COUNTERS(s_tile);
+  bin_push_body<EMIT>(N, tl, br, depth, ntw, nth, T, cnt, tile_off, ctrl, keys, s_tile);
+}
+template <bool EMIT>
+__global__ void __launch_bounds__(kPushThreads)
+k_bin_push_views(uint32_t N, int ntw, int nth, uint32_t T, const GeoView *__restrict__ views) {
+  GS_PUSH_COUNTERS(s_tile);
+  const GeoView v = views[blockIdx.y];
+  bin_push_body<EMIT>(N, v.tl, v.br, v.depth, ntw, nth, T, v.cnt, v.tile_off, v.ctrl, v.keys, s_tile);
 }
 
 template <int P>
@@ -691,8 +714,12 @@ static int bin_and_sort(uint32_t N, uint32_t cap, uint32_t nth, uint32_t ntw, co
   const uint32_t ngroups = ((ntw + kGroup - 1) / kGroup) * ((nth + kGroup - 1) / kGroup);
   const dim3 gpull(ngroups, w.nchunks);
   const dim3 bpull(64 * kPullWaves);
+  const bool push = T <= kPushMaxTiles;  // (per-tile counters in LDS: bin_push_body)
   if (N == 0) {
     if (hipError_t e = hipMemsetAsync(w.cnt, 0, sizeof(uint32_t) * (size_t)w.nchunks * T, s)) return (int)e;
+  } else if (push) {
+    hipLaunchKernelGGL((k_bin_push<false>), dim3(w.nchunks), dim3(kPushThreads), sizeof(uint32_t) * T, s, N, tl, br, depth, (int)ntw, (int)nth, T, w.cnt,
+                       (const uint32_t *)nullptr, (const uint32_t *)nullptr, (unsigned long long *)nullptr);
   } else {
     hipLaunchKernelGGL((k_bin_pull<false>), gpull, bpull, 0, s, N, tl, br, depth, (int)ntw, (int)nth, T,
                        w.cnt, w.wcnt, (const uint32_t *)nullptr, (const uint32_t *)nullptr,
@@ -702,7 +729,10 @@ static int bin_and_sort(uint32_t N, uint32_t cap, uint32_t nth, uint32_t ntw, co
                      w.cnt, w.tile_count);
   hipLaunchKernelGGL(k_scan_order_tiles, dim3(1), dim3(kScanThreads), 0, s, T, w.tile_count, w.tile_off, w.ctrl, cap, total_out,
                      w.tile_order);
-  if (N)
+  if (N && push)
+    hipLaunchKernelGGL((k_bin_push<true>), dim3(w.nchunks), dim3(kPushThreads), sizeof(uint32_t) * T, s, N, tl, br, depth, (int)ntw, (int)nth, T, w.cnt,
+                       (const uint32_t *)w.tile_off, (const uint32_t *)w.ctrl, w.keys);
+  else if (N)
     hipLaunchKernelGGL((k_bin_pull<true>), gpull, bpull, 0, s, N, tl, br, depth, (int)ntw, (int)nth, T,
                        w.cnt, w.wcnt, w.tile_off, w.ctrl, w.keys);
   hipLaunchKernelGGL(k_sort_tiles, dim3(T), dim3(64 * kCoopWaves), 0, s, T, w.tile_off, w.ctrl, w.keys, ids, start, end,
@@ -834,14 +864,14 @@ int gsgen_frame_geometry_batch_zero(uint32_t n_views, const gsgen_geometry_view 
     for (uint32_t b = 0; b < B; ++b)
       if (hipError_t e = hipMemsetAsync(gv[b].cnt, 0, sizeof(uint32_t) * (size_t)nchunks * T, s)) return (int)e;
   } else if (push) {
-    hipLaunchKernelGGL((k_bin_push_views<false>), gpush, bpush, 0, s, N, (int)ntw, (int)nth, T, (const GeoView *)dv);
+    hipLaunchKernelGGL((k_bin_push_views<false>), gpush, bpush, sizeof(uint32_t) * T, s, N, (int)ntw, (int)nth, T, (const GeoView *)dv);
   } else {
     hipLaunchKernelGGL((k_bin_pull_views<false>), gpull, bpull, 0, s, N, (int)ntw, (int)nth, T, (const GeoView *)dv);
   }
   hipLaunchKernelGGL(k_scan_chunks_views, dim3((T + 3) / 4, B), dim3(256), 0, s, T, nchunks, (const GeoView *)dv);
   hipLaunchKernelGGL(k_scan_order_tiles_views, dim3(1, B), dim3(kScanThreads), 0, s, T, (const GeoView *)dv);
   if (N && push)
-    hipLaunchKernelGGL((k_bin_push_views<true>), gpush, bpush, 0, s, N, (int)ntw, (int)nth, T, (const GeoView *)dv);
+    hipLaunchKernelGGL((k_bin_push_views<true>), gpush, bpush, sizeof(uint32_t) * T, s, N, (int)ntw, (int)nth, T, (const GeoView *)dv);
   else if (N)
     hipLaunchKernelGGL((k_bin_pull_views<true>), gpull, bpull, 0, s, N, (int)ntw, (int)nth, T, (const GeoView *)dv);
   hipLaunchKernelGGL(k_sort_tiles_views, dim3(T * B), dim3(64 * kCoopWaves), 0, s, T, B, (const GeoView *)dv);

