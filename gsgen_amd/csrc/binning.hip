@@ -26,6 +26,7 @@
 // Everything is enqueued on the caller's stream with no host synchronisation.
 #include "common.hpp"
 #include "../../include/gsgen_hip.h"
+#include <cstdlib>
 #include <vector>
 
 namespace gs {
@@ -585,6 +586,15 @@ k_scan_order_tiles_views(uint32_t T, const GeoView *__restrict__ views) {
 constexpr int kPushOwn = 12;
 constexpr uint32_t kPushMaxTiles = 8192;  // 32 KB of LDS: 2 048 x 1 024 pixels and the like
 constexpr int kPushThreads = 256;
+constexpr uint32_t kPushMinWorkgroups = 128;  // (chunks x views) below which the pull kernels are the faster launch
+// (GSGEN_BIN_PUSH_MIN_WORKGROUPS overrides it, read at every call: the CPU tests run both forms on scenes of a few chunks)
+// A camera batch is a throughput launch (other steps' kernels fill the chip around it): there the fewer instructions win from
+// a quarter of that on.
+constexpr uint32_t kPushMinWorkgroupsBatch = 32;
+static uint32_t push_min_workgroups(bool batch) {
+  const char *e = getenv("GSGEN_BIN_PUSH_MIN_WORKGROUPS");
+  return e != nullptr ? (uint32_t)strtoul(e, nullptr, 10) : (batch ? kPushMinWorkgroupsBatch : kPushMinWorkgroups);
+}
 // the counters: T words of dynamic LDS (10 KB at 800 x 800: a workgroup finds room beside the compositing kernels' blocks
 // sooner than with the 32 KB of the largest image); the CPU emulator build has no dynamic LDS and takes the maximum
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -714,7 +724,9 @@ static int bin_and_sort(uint32_t N, uint32_t cap, uint32_t nth, uint32_t ntw, co
   const uint32_t ngroups = ((ntw + kGroup - 1) / kGroup) * ((nth + kGroup - 1) / kGroup);
   const dim3 gpull(ngroups, w.nchunks);
   const dim3 bpull(64 * kPullWaves);
-  const bool push = T <= kPushMaxTiles;  // (per-tile counters in LDS: bin_push_body)
+  // per-tile counters in LDS (bin_push_body) where there are enough chunks to fill the chip; a lone view of 100 k Gaussians is
+  // 49 workgroups -- there the pull kernels' 2 401 finish sooner (0.44 vs 0.38 ms per render with one render in flight)
+  const bool push = T <= kPushMaxTiles && w.nchunks >= push_min_workgroups(false);
   if (N == 0) {
     if (hipError_t e = hipMemsetAsync(w.cnt, 0, sizeof(uint32_t) * (size_t)w.nchunks * T, s)) return (int)e;
   } else if (push) {
@@ -858,7 +870,7 @@ int gsgen_frame_geometry_batch_zero(uint32_t n_views, const gsgen_geometry_view 
   const uint32_t B = n_views;
   const uint32_t ngroups = ((ntw + kGroup - 1) / kGroup) * ((nth + kGroup - 1) / kGroup);
   const dim3 gpull(ngroups, nchunks, B), bpull(64 * kPullWaves);
-  const bool push = T <= kPushMaxTiles;  // (per-tile counters in LDS: k_bin_push_views)
+  const bool push = T <= kPushMaxTiles && nchunks * B >= push_min_workgroups(true);  // (per-tile counters in LDS: k_bin_push_views)
   const dim3 gpush(nchunks, B), bpush(kPushThreads);
   if (N == 0) {
     for (uint32_t b = 0; b < B; ++b)

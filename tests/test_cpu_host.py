@@ -166,6 +166,10 @@ def test_camera_blocks_in_one_call_match_per_camera_packing():
 def emu():
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "emu"])
     from gsgen_amd import _capi
+    # binning: per-tile counters in LDS (the push kernels) from two (chunk, view) workgroups on, the pull kernels below -- these
+    # scenes are one or two 2 048-Gaussian chunks: a lone view of one chunk takes the pull form, every batch the push form
+    # (the library's own threshold, 128 workgroups, would leave the push kernels unreached here; read at every call)
+    os.environ["GSGEN_BIN_PUSH_MIN_WORKGROUPS"] = "2"
     return _capi.Lib(os.path.join(ROOT, "oracle", "_build", "libgsgen_emu.so"))
 
 
@@ -298,7 +302,8 @@ def test_emulated_fused_frame_geometry(emu):
     camv = ci.pack(cam.c2w)
     N = sc["mean"].shape[0]; nth, ntw = cam.tiles
     assert 0 < g["mask"].sum() < N  # the cull does something
-    for cap in (g["D"] + 5, g["D"] - 1):
+    for cap, min_wg in ((g["D"] + 5, "2"), (g["D"] - 1, "2"), (g["D"] + 5, "1"), (g["D"] - 1, "1")):  # pull, pull, push, push
+        os.environ["GSGEN_BIN_PUSH_MIN_WORKGROUPS"] = min_wg
         m2 = np.zeros((N, 2), np.float32); c2 = np.zeros((N, 4), np.float32); dep = np.zeros(N, np.float32)
         mask = np.zeros(N, np.uint8); ids = np.zeros(max(cap, 1), np.int32)
         st = np.zeros(nth * ntw, np.int32); en = np.zeros(nth * ntw, np.int32); tot = np.zeros(1, np.uint32)
@@ -314,6 +319,7 @@ def test_emulated_fused_frame_geometry(emu):
             assert np.array_equal(m2[g["mask"]], g["mean2d"])
         else:  # overflow: nothing binned, required size reported
             assert (st == -1).all() and (en == -1).all()
+    os.environ["GSGEN_BIN_PUSH_MIN_WORKGROUPS"] = "2"
 
 
 def test_emulated_frame_geometry_beyond_the_lds_counters(emu):

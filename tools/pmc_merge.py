@@ -27,7 +27,8 @@ names = {
     "k_composite_fwd_chan_vec<3, true>": lib.kernel_variant("rgbd_fwd_batch", 1, 1),
     # the geometry chain of a batch (same kernels behind the SH and the RGB + heads step)
     "k_frame_project_views": "k_frame_project_views", "k_bin_pull_views<false>": "k_bin_pull_views<count>",
-    "k_bin_pull_views<true>": "k_bin_pull_views<emit>", "k_sort_tiles_views": "k_sort_tiles_views",
+    "k_bin_pull_views<true>": "k_bin_pull_views<emit>", "k_bin_push_views<false>": "k_bin_push_views<count>",
+    "k_bin_push_views<true>": "k_bin_push_views<emit>", "k_sort_tiles_views": "k_sort_tiles_views",
     "k_scan_chunks_views": "k_scan_chunks_views", "k_scan_order_tiles_views": "k_scan_order_tiles_views",
     "k_project_bwd_views": "k_project_bwd_views",
 }
