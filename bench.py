@@ -912,7 +912,8 @@ def main():
                 ev[0].record(stream)
             lib.vol_render_sh_routed(N, b0.D_cap, p(b0.mean2d), p(b0.cov2d), p(t["sh"]), p(t["alpha"]), p(b0.start), p(b0.end),
                                      p(b0.ids), p(sl0.out[0]), p(topleft_dev[k]), p(rot_dev[k]), 16, nth, ntw, 1.0 / cis[k].fx,
-                                     1.0 / cis[k].fy, H, W, C, 1e-4, p(bg), None, order_, p(lseg_ws), lseg_arg, None, rows_p, s)
+                                     1.0 / cis[k].fy, H, W, C, 1e-4, p(bg), None, order_, p(lseg_ws), lseg_arg,
+                                     p(sl0.bound) if rows_p else None, rows_p, s)  # (the view's bound first, then the lists)
             if ev is not None:
                 ev[1].record(stream)
             with gpu.stream(stream):
@@ -923,7 +924,7 @@ def main():
                                               p(b0.end), p(b0.ids), p(sl0.out[0]), p(g1_mean2d), p(g1_cov2d), p(g1_sh),
                                               p(g1_alpha), p(grad_out), p(topleft_dev[k]), p(rot_dev[k]), 16, nth, ntw,
                                               1.0 / cis[k].fx, 1.0 / cis[k].fy, H, W, C, 1e-4, p(bg), order_,
-                                              p(lseg_ws), lseg_arg, None, rows_p, s)
+                                              p(lseg_ws), lseg_arg, p(sl0.bound) if rows_p else None, rows_p, s)
             if ev is not None:
                 ev[3].record(stream)
             lib.project_gaussians_backward_masked(N, p(t["mean"]), p(t["qvec"]), p(t["svec"]), p(cam_dev[k]), 1, p(b0.mask),

@@ -216,6 +216,11 @@ def get_sh_basis():
 _bound_cache = {}
 
 
+def _pmax(bound):
+    """device address of the maximum behind the per-splat bounds of _sh_bound (None without bounds)"""
+    return None if bound is None else bound.data_ptr() + 4 * (bound.numel() - 1)
+
+
 def _sh_bound(sh_coeffs, C, tile_size, reuse=False):
     """SH degree 3: the per-splat bounds S_i = max_c sum_{k >= 1} |sh[i][c][k]| of the call's coefficients, measured on the device
     in front of the launch (one ~10-us pass, no sync) into a scratch tensor [N]; the kernels route PER TILE on them -- the
@@ -230,8 +235,11 @@ def _sh_bound(sh_coeffs, C, tile_size, reuse=False):
         hit = _bound_cache.get(key)
         if hit is not None and hit[0] == ver:
             return hit[1]
-    bound = torch.empty(sh_coeffs.numel() // 48, device=sh_coeffs.device, dtype=torch.float32)  # per SPLAT: routed per tile
-    _load().sh_l1_bound_rows(sh_coeffs.numel() // 48, _p(sh_coeffs), 4, None, _p(bound), _stream(sh_coeffs))
+    n = sh_coeffs.numel() // 48
+    # per SPLAT [N] (routed per tile and per entry) + their maximum behind them (a scene wholly within the view's bound needs no
+    # look at the lists)
+    bound = torch.empty(n + 1, device=sh_coeffs.device, dtype=torch.float32)
+    _load().sh_l1_bound_rows(n, _p(sh_coeffs), 4, bound.data_ptr() + 4 * n, _p(bound), _stream(sh_coeffs))
     if len(_bound_cache) > 64:
         _bound_cache.clear()
     _bound_cache[key] = (ver, bound)
@@ -252,7 +260,7 @@ def _sh_fwd(mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out, topleft,
             mean.size(0), gaussian_ids.size(0), _p(mean), _p(cov), _p(sh_coeffs), _p(alpha), _p(start),
             _p(end), _p(gaussian_ids), _p(out), _p(topleft), _p(c2w), int(tile_size), int(n_tiles_h),
             int(n_tiles_w), float(pixel_size_x), float(pixel_size_y), int(H), int(W), int(C),
-            float(thresh), _p(bg_rgb), None, None, None, 0, None, _p(bound), _stream(mean))
+            float(thresh), _p(bg_rgb), None, None, None, 0, _pmax(bound), _p(bound), _stream(mean))
 
 
 def _sh_bwd(mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out, grad_mean, grad_cov,
@@ -274,7 +282,7 @@ def _sh_bwd(mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out, grad_mea
             _p(end), _p(gaussian_ids), _p(out), _p(grad_mean), _p(grad_cov), _p(grad_sh_coeffs),
             _p(grad_alpha), _p(grad_out), _p(topleft), _p(c2w), int(tile_size), int(n_tiles_h),
             int(n_tiles_w), float(pixel_size_x), float(pixel_size_y), int(H), int(W), int(C),
-            float(thresh), _p(bg_rgb), None, None, 0, None, _p(bound), _stream(mean))
+            float(thresh), _p(bg_rgb), None, None, 0, _pmax(bound), _p(bound), _stream(mean))
 
 
 def tile_based_vol_rendering_sh(mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out, topleft,

@@ -782,6 +782,13 @@ __device__ __forceinline__ bool tile_flagged(const CompParams &p, uint32_t bid) 
   if (!block_tile(p, tx, ty, bid)) return false;
   return p.tile_flags[ty * p.ntw + tx] != 0;
 }
+// per-camera routed launches (both forms in one kernel): the form of tile bid.  The view's bound first -- a scene wholly within it,
+// the normal case, needs no look at the lists (scanning them cost the one-render-in-flight path 10 %: a scan covers the whole list,
+// the walk a quarter of it) --, then the tile's list against the per-splat bounds.
+__device__ __forceinline__ bool routed_tile_is_polynomial(const CompParams &p, uint32_t bid) {
+  if (p.sh_bound != nullptr && poly_route(p.sh_bound, p.psx, p.psy)) return true;
+  return p.sh_rows != nullptr && tile_list_within_bound(p, bid);
+}
 // TRACK = false (the batched polynomial kernel of an unsegmented launch only): no stop list to keep -- with the per-entry exact
 // tier's calls in the entry loop, those four registers decide whether the loop fits 96 without reloading spilled values per entry
 template <int CB, int PPL, bool BATCH = false, int NB = 0, bool TRACK = true>
@@ -798,7 +805,7 @@ k_composite_fwd_sh_vec(CompParams p_arg, ViewPack<BATCH> pack) {
     };
     __shared__ Shared sm;
     const CompParams *pp = BATCH ? &plist[batch_view(p_arg, bid)] : &p_arg;  // (see k_composite_bwd_sh_vec)
-    const bool poly = pp->sh_rows != nullptr ? tile_list_within_bound(*pp, bid) : poly_route(pp->sh_bound, pp->psx, pp->psy);
+    const bool poly = routed_tile_is_polynomial(*pp, bid);
     if (poly) {
       const CompParams p = *pp;
       composite_fwd_sh_vec_tile<4, PPL, kPolyNB>(p, bid, sm.poly);
@@ -1544,7 +1551,7 @@ k_composite_bwd_sh_vec(CompParams p_arg, ViewPack<BATCH> pack) {
     const CompParams *pp = BATCH ? &plist[batch_view(p_arg, bid, &grid)] : &p_arg;
     // (segmented launches: workgroup = (tile, segment), tile index = bid modulo the view's tile grid)
     const uint32_t tiles_grid = grid / (uint32_t)(pp->nseg > 1 ? pp->nseg : 1);
-    const bool poly = pp->sh_rows != nullptr ? tile_list_within_bound(*pp, bid % tiles_grid) : poly_route(pp->sh_bound, pp->psx, pp->psy);
+    const bool poly = routed_tile_is_polynomial(*pp, bid % tiles_grid);
     if (poly) {
       const CompParams p = *pp;
       composite_bwd_sh_vec_tile<4, 4, kPolyNB>(p, bid, grid, sm.poly);
@@ -2290,8 +2297,9 @@ int gsgen_vol_render_sh_routed(uint32_t N, uint32_t D, const float *mean, const 
   p.ntw = (int)n_tiles_w; p.nth = (int)n_tiles_h; p.H = (int)H; p.W = (int)W;
   p.psx = pixel_size_x; p.psy = pixel_size_y; p.thresh = thresh; p.tile_side = (int)tile_size;
   p.tile_order = tile_order;
-  p.sh_bound = (C == 4 && sh_row_bounds == nullptr) ? sh_l1_bound : nullptr;
-  p.sh_rows = (C == 4) ? sh_row_bounds : nullptr;  // (per-tile routing wins over the per-view bound)
+  // (both given: the view's bound decides first -- a scene within it needs no look at the lists --, the per-splat bounds per tile otherwise)
+  p.sh_bound = (C == 4) ? sh_l1_bound : nullptr;
+  p.sh_rows = (C == 4) ? sh_row_bounds : nullptr;
   if (n_segments > 1) {
     p.nseg = (int)n_segments;
     p.ckpt = reinterpret_cast<float4 *>(segment_workspace);

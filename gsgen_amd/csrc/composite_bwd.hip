@@ -174,7 +174,7 @@ int gsgen_vol_render_backward_sh_routed(uint32_t N, uint32_t D, const float *mea
   p.ntw = (int)n_tiles_w; p.nth = (int)n_tiles_h; p.H = (int)H; p.W = (int)W;
   p.psx = pixel_size_x; p.psy = pixel_size_y; p.thresh = thresh; p.tile_side = (int)tile_size;
   p.tile_order = tile_order;
-  p.sh_bound = (C == 4 && sh_row_bounds == nullptr) ? sh_l1_bound : nullptr;
+  p.sh_bound = (C == 4) ? sh_l1_bound : nullptr;  // (both given: the view's bound first, then the tile's list -- as the forward)
   p.sh_rows = (C == 4) ? sh_row_bounds : nullptr;
   if (n_segments > 1) {
     p.nseg = (int)n_segments;

@@ -168,8 +168,11 @@ const float *sh_bound(const Tensor &sh_coeffs, uint32_t C, uint32_t tile_size, C
   if (reuse && g_bound.bound.defined() && g_bound.ptr == ptr && g_bound.numel == sh_coeffs.numel() && g_bound.version == ver &&
       g_bound.device == dev)
     return F(g_bound.bound);
-  Tensor b = at::empty({sh_coeffs.numel() / 48}, sh_coeffs.options());  // per SPLAT: the kernels route per tile
-  GS(gsgen_sh_l1_bound_rows((uint32_t)(sh_coeffs.numel() / 48), F(sh_coeffs), C, nullptr, Fm(b), c.stream));
+  // per SPLAT [N] (the kernels route per tile and per entry on them) + their maximum behind them (a scene wholly within the
+  // view's bound needs no look at the lists)
+  const int64_t n = sh_coeffs.numel() / 48;
+  Tensor b = at::empty({n + 1}, sh_coeffs.options());
+  GS(gsgen_sh_l1_bound_rows((uint32_t)n, F(sh_coeffs), C, Fm(b) + n, Fm(b), c.stream));
   g_bound.ptr = ptr; g_bound.numel = sh_coeffs.numel(); g_bound.version = ver; g_bound.device = dev; g_bound.bound = b;
   return F(b);
 }
@@ -187,7 +190,8 @@ void sh_forward(const Tensor &mean, const Tensor &cov, const Tensor &sh_coeffs, 
   const float *bound = sh_bound(sh_coeffs, C, tile_size, c);
   GS(gsgen_vol_render_sh_routed((uint32_t)mean.size(0), (uint32_t)gaussian_ids.size(0), F(mean), F(cov), F(sh_coeffs), F(alpha),
                                 I(start), I(end), I(gaussian_ids), Fm(out), F(topleft), F(c2w), tile_size, n_tiles_h, n_tiles_w,
-                                psx, psy, H, W, C, thresh, bg, nullptr, nullptr, nullptr, 0, nullptr, bound, c.stream));
+                                psx, psy, H, W, C, thresh, bg, nullptr, nullptr, nullptr, 0, bound ? bound + sh_coeffs.numel() / 48 : nullptr, bound,
+                                c.stream));
 }
 void sh_backward(const Tensor &mean, const Tensor &cov, const Tensor &sh_coeffs, const Tensor &alpha, const Tensor &start,
                  const Tensor &end, const Tensor &gaussian_ids, const Tensor &out, Tensor &grad_mean, Tensor &grad_cov,
@@ -204,8 +208,8 @@ void sh_backward(const Tensor &mean, const Tensor &cov, const Tensor &sh_coeffs,
   GS(gsgen_vol_render_backward_sh_routed((uint32_t)mean.size(0), (uint32_t)gaussian_ids.size(0), F(mean), F(cov), F(sh_coeffs),
                                          F(alpha), I(start), I(end), I(gaussian_ids), F(out), Fm(grad_mean), Fm(grad_cov),
                                          Fm(grad_sh_coeffs), Fm(grad_alpha), F(grad_out), F(topleft), F(c2w), tile_size,
-                                         n_tiles_h, n_tiles_w, psx, psy, H, W, C, thresh, bg, nullptr, nullptr, 0, nullptr, bound,
-                                         c.stream));
+                                         n_tiles_h, n_tiles_w, psx, psy, H, W, C, thresh, bg, nullptr, nullptr, 0,
+                                         bound ? bound + sh_coeffs.numel() / 48 : nullptr, bound, c.stream));
 }
 // render.h:83 / render.cu:484-545
 void tile_based_vol_rendering_sh(Tensor mean, Tensor cov, Tensor sh_coeffs, Tensor alpha, Tensor start, Tensor end,

@@ -383,9 +383,10 @@ class FrameBuffers:
         self.ws = torch.empty(nbytes, device=self.device, dtype=torch.uint8)
 
     def row_bounds(self):
-        """float32 [N]: the per-splat coefficient bounds of the frame in flight (sh_row_bounds_device), read by its backward"""
+        """float32 [N + 1]: the per-splat coefficient bounds of the frame in flight (sh_row_bounds_device) and their maximum
+        behind them, read by its backward"""
         if getattr(self, "_rows", None) is None:
-            self._rows = torch.empty(self.N, device=self.device, dtype=torch.float32)
+            self._rows = torch.empty(self.N + 1, device=self.device, dtype=torch.float32)
         return self._rows
 
     def tile_order(self):
@@ -488,13 +489,17 @@ class _render_frame(torch.autograd.Function):
         psx, psy = 1.0 / cam_info.fx, 1.0 / cam_info.fy
         s = _stream(mean)
         # SH degree 3, "auto": per-splat bounds measured on the device, the kernels route per tile on them
-        ctx.sh_bound = sh_row_bounds_device(col, out=buf.row_bounds()) if (C == 4 and sh_basis == "auto") else None
+        ctx.sh_bound = None
+        if C == 4 and sh_basis == "auto":
+            ctx.sh_bound = buf.row_bounds()
+            sh_row_bounds_device(col, out=ctx.sh_bound[:buf.N], out_max=ctx.sh_bound[buf.N:])
+        smax = None if ctx.sh_bound is None else ctx.sh_bound.data_ptr() + 4 * buf.N  # (the view's bound: decides first)
         with torch.cuda.device(dev):
             if C > 0:
                 lib.vol_render_sh_routed(buf.N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col), _p(alpha),
                                           _p(buf.start), _p(buf.end), _p(buf.ids), _p(out), _p(topleft), _p(rot),
                                           16, buf.nth, buf.ntw, psx, psy, H, W, C, thresh, _p(bg_rgb), _p(T),
-                                          buf.tile_order(), _p(buf.seg_ws), buf.segments, None, _p(ctx.sh_bound), s)
+                                          buf.tile_order(), _p(buf.seg_ws), buf.segments, smax, _p(ctx.sh_bound), s)
             else:
                 lib.vol_render_start_end_with_T(buf.N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col),
                                                 _p(alpha), _p(buf.start), _p(buf.end), _p(buf.ids),
@@ -532,7 +537,9 @@ class _render_frame(torch.autograd.Function):
                                                    _p(buf.start), _p(buf.end), _p(buf.ids), _p(out), _p(g_mean2d),
                                                    _p(g_cov2d), _p(g_col), _p(g_alpha), _p(grad), _p(topleft),
                                                    _p(rot), 16, buf.nth, buf.ntw, psx, psy, H, W, C, thresh, None,
-                                                   buf.tile_order(), _p(buf.seg_ws), buf.segments, None, _p(ctx.sh_bound), s)
+                                                   buf.tile_order(), _p(buf.seg_ws), buf.segments,
+                                                   None if ctx.sh_bound is None else ctx.sh_bound.data_ptr() + 4 * N,
+                                                   _p(ctx.sh_bound), s)
             else:
                 lib.vol_render_backward_start_end(N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col),
                                                   _p(alpha), _p(buf.start), _p(buf.end), _p(buf.ids),

@@ -472,8 +472,10 @@ int gsgen_vol_render_backward_sh_bounded(uint32_t N, uint32_t D, const float *me
  * records with more than a quarter of such splats sends its tile -- and only that tile -- to the exact kernel.  Splats behind the
  * point where the tile's pixels saturate are never staged and never count.  Batched launches record the decision in one byte per (view, tile)
  * inside batch_workspace (gsgen_sh_batch_workspace_bytes_routed): the polynomial forward writes it, the exact fallback behind it
- * and both backward kernels read it, so forward and backward agree by construction; per-camera launches scan the tile's list
- * first, forward and backward alike.  sh_row_bounds == NULL: exactly the *_bounded behaviour on sh_l1_bound.  SH degree 3 only
+ * and both backward kernels read it, so forward and backward agree by construction; per-camera launches decide before they touch
+ * a tile, forward and backward alike: with sh_l1_bound given as well (the maximum gsgen_sh_l1_bound_rows leaves in out_max) a
+ * view wholly within its bound -- the normal case -- takes the polynomial form without a look at the lists, otherwise the
+ * tile's list is scanned against the per-splat bounds (any splat beyond them: the exact form for that tile).  sh_row_bounds == NULL: exactly the *_bounded behaviour on sh_l1_bound.  SH degree 3 only
  * (C != 4: the exact kernels).  No counterpart in the reference (vol_render_sh.h:48-65 evaluates the basis per pixel). */
 int gsgen_sh_l1_bound_rows(uint32_t N, const float *sh_coeffs, uint32_t C, float *out_max /* device, 1 float, or NULL */,
                            float *out_rows /* device, [N] */, gsgen_stream_t stream);
