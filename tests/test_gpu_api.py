@@ -230,6 +230,46 @@ def test_batched_cameras_match_one_at_a_time(n_streams, C, fused, ncam):
         br.render(Pb["mean"], Pb["qvec"], Pb["svec"], Pb["alpha"], Pb[ck], cis * 2, [c.c2w for c in cams] * 2, C=C)
 
 
+@pytest.mark.parametrize("min_wg", ["1", "1000000"])
+def test_batched_binning_push_and_pull_forms_against_the_oracle(min_wg, monkeypatch):
+    """gsgen_frame_geometry_batch through both binning forms -- the push kernels (per-tile counters in LDS; a rectangle of more
+    than 12 tiles is finished by the whole wavefront) and the pull kernels -- on a scene with two dozen giant, near Gaussians
+    whose rectangles cover hundreds of tiles: every view's lists are the oracle's, bit for bit."""
+    from gsgen_amd import _capi, renderer as R
+    monkeypatch.setenv("GSGEN_BIN_PUSH_MIN_WORKGROUPS", min_wg)
+    lib = _capi.load()
+    W, H, B = 304, 208, 8
+    sc = scenes.random_scene(9000, seed=35, svec=0.03)
+    rng = np.random.default_rng(2)
+    big = rng.choice(9000, 24, replace=False)
+    sc["svec"][big] *= 25.0          # rectangles of up to the whole 19 x 13 tile grid
+    N = sc["mean"].shape[0]
+    cams = [scenes.Camera(W, H, fx=230.0 + 9 * i, c2w=scenes.orbit(2.3 + 0.05 * i, 25 - 8 * i, 40.0 + 45 * i)) for i in range(B)]
+    gs_ = [scenes.oracle_geometry(sc, c) for c in cams]
+    assert max(int(((g["br"] - g["tl"] + 1).clip(min=0).prod(-1)).max()) for g in gs_) > 150   # tiles of the largest rectangle
+    cam_dev = [T_(R.CameraInfo(*c.intr).pack(c.c2w)) for c in cams]
+    mean, qvec, svec = T_(sc["mean"]), T_(sc["qvec"]), T_(sc["svec"])
+    p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+    bufs = [R.FrameBuffers(N, W, H, dev(), D_cap=g["D"] + 16) for g in gs_]
+    arr = (_capi.GeometryView * B)()
+    for a, b_, cd in zip(arr, bufs, cam_dev):
+        b_.ids.fill_(-3)
+        a.cam, a.mean2d, a.cov2d, a.depth, a.mask = p(cd), p(b_.mean2d), p(b_.cov2d), p(b_.depth), p(b_.mask)
+        a.gaussian_ids, a.start, a.end, a.total = p(b_.ids), p(b_.start), p(b_.end), p(b_.total)
+        a.workspace, a.workspace_bytes, a.D_cap = p(b_.ws), b_.ws.numel(), b_.D_cap
+    bws = torch.empty(lib.frame_batch_workspace_bytes(B), device=dev(), dtype=torch.uint8)
+    lib.frame_geometry_batch(B, arr, N, p(mean), p(qvec), p(svec), W, H, p(bws), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    longest = 0
+    for g, b_ in zip(gs_, bufs):
+        assert int(b_.total.item()) == g["D"]
+        full = np.nonzero(g["mask"])[0]
+        assert np.array_equal(b_.start.cpu().numpy().ravel(), g["start"]) and np.array_equal(b_.end.cpu().numpy().ravel(), g["end"])
+        assert np.array_equal(b_.ids.cpu().numpy()[:g["D"]], full[g["ids"]])
+        longest = max(longest, int((g["end"] - g["start"]).max()))
+    assert longest > 64
+
+
 def test_batched_geometry_and_projection_backward_c_abi():
     """gsgen_frame_geometry_batch leaves bit for bit what one gsgen_frame_geometry call per view leaves (lists,
     records, mask, pair count, launch order, one view overflowing its pair buffer), and
