@@ -604,7 +604,7 @@ def main():
         if ev is not None:
             clock.call("events", ev[0].record, stream)
         clock.call("composite_fwd", lib.vol_render_sh_batch_routed, B, views, N, p(t["sh"]), p(t["alpha"]), 16, nth, ntw, H, W, C,
-                   1e-4, seg_arg, None, rows_p, p(sl.bws), s)
+                   1e-4, seg_arg, (p(sl.bound) if rows_p else None), rows_p, p(sl.bws), s)
         if ev is not None:
             clock.call("events", ev[1].record, stream)
         if sl.gathered is not None and gather and state["gather"]:
@@ -624,7 +624,7 @@ def main():
         if ev is not None:
             clock.call("events", ev[2].record, stream)
         clock.call("composite_bwd", lib.vol_render_backward_sh_batch_routed, B, views, N, p(t["sh"]), p(t["alpha"]), p(sl.g_sh),
-                   p(sl.g_alpha), 16, nth, ntw, H, W, C, 1e-4, seg_arg, None, rows_p, p(sl.bws), s)
+                   p(sl.g_alpha), 16, nth, ntw, H, W, C, 1e-4, seg_arg, (p(sl.bound) if rows_p else None), rows_p, p(sl.bws), s)
         if ev is not None:
             clock.call("events", ev[3].record, stream)
         clock.call("project_bwd", lib.project_gaussians_backward_batch, B, N, p(t["mean"]), p(t["qvec"]), p(t["svec"]), *proj,

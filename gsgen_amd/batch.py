@@ -454,6 +454,7 @@ class BatchRenderer:
         self._bws = torch.empty(self._nb_sh + lib.frame_batch_workspace_bytes(max_batch), device=device, dtype=torch.uint8)
         self._g2d = torch.empty(max_batch, 12 * self._Np, device=device, dtype=torch.float32)
         self._rows = torch.zeros(N, device=device, dtype=torch.float32)  # per-splat bounds of the batch in flight (gsgen_sh_l1_bound_rows)
+        self._smax = torch.zeros(1, device=device, dtype=torch.float32)  # ... and their maximum (a scene within a view's bound skips the per-entry tests)
         # per camera: cam block (56) | topleft (2) | rotation rows (9) | pad -> 68 floats, packed on the host and sent
         # through kernel arguments (gsgen_upload_small): no pinned ring, no copy event, the host never waits
         self._host = np.zeros((max_batch, 68), np.float32)
@@ -651,8 +652,9 @@ class BatchRenderer:
                 if verify_bound:
                     R.verify_sh_l1_bound(col, sh_l1_bound)
                 self._sh_bound = sh_l1_bound
-            else:  # per-splat bounds: the launches route per tile on them
+            else:  # per-splat bounds + their maximum: the launches take the view's bound first, then route per entry / tile
                 self._sh_rows = self._measure_bound(col)
+                self._sh_bound = self._smax if self._sh_rows is self._rows else None
         return _render_batch.apply(mean, qvec, svec, alpha, col, cams, self, B, int(C), bg_rgb, float(thresh),
                                    bool(detach_depth), stats)
 
@@ -662,7 +664,7 @@ class BatchRenderer:
                 or col.shape[0] != self.N:
             return R.sh_row_bounds_device(col)  # (other layouts: the checked path)
         with _on(self.device):
-            _capi.load().sh_l1_bound_rows(self.N, col.data_ptr(), 4, None, self._rows.data_ptr(),
+            _capi.load().sh_l1_bound_rows(self.N, col.data_ptr(), 4, self._smax.data_ptr(), self._rows.data_ptr(),
                                           torch.cuda.current_stream(self.device).cuda_stream)
         return self._rows
 

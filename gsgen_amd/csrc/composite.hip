@@ -577,13 +577,18 @@ __device__ __forceinline__ void composite_fwd_sh_vec_tile(const CompParams &p, u
       // per-tile routing: splats beyond the bound for this view's pixel size take the per-entry exact tier
       // (exact_tier_denominators); more than a quarter of a staged batch sends the WHOLE tile to the exact kernel (nothing has
       // been written yet; CompParams::tile_flags).
-      exact_mask = exact_tier_mask<NT>(p, S.id, nb, t, &sm.exact_mask);
-      __syncthreads();
-      if constexpr (NT != 64) exact_mask = sm.exact_mask;
-      exact_mask = (uint32_t)__builtin_amdgcn_readfirstlane((int)exact_mask);
-      if (__popcll((unsigned long long)exact_mask) * kExactTierShare > nb) {  // (uniform over the workgroup)
-        if (t == 0 && p.tile_flags != nullptr) p.tile_flags[tile] = 1;
-        return;
+      if (p.sh_rows != nullptr) {  // (uniform over the launch; known to be false where the caller proved every splat within the bound)
+        exact_mask = exact_tier_mask<NT>(p, S.id, nb, t, &sm.exact_mask);
+        __syncthreads();
+        if constexpr (NT != 64) exact_mask = sm.exact_mask;
+        exact_mask = (uint32_t)__builtin_amdgcn_readfirstlane((int)exact_mask);
+        if (__popcll((unsigned long long)exact_mask) * kExactTierShare > nb) {  // (uniform over the workgroup)
+          if (t == 0 && p.tile_flags != nullptr) p.tile_flags[tile] = 1;
+          return;
+        }
+      } else {
+        exact_mask = 0u;
+        __syncthreads();
       }
       poly_transform<NT, KB>(p.col, S.id, Vs, Ws, nb);
       __syncthreads();
@@ -807,7 +812,8 @@ k_composite_fwd_sh_vec(CompParams p_arg, ViewPack<BATCH> pack) {
     const CompParams *pp = BATCH ? &plist[batch_view(p_arg, bid)] : &p_arg;  // (see k_composite_bwd_sh_vec)
     const bool poly = routed_tile_is_polynomial(*pp, bid);
     if (poly) {
-      const CompParams p = *pp;
+      CompParams p = *pp;
+      p.sh_rows = nullptr;  // (every splat of this tile is within the bound: no per-entry tests, no exact tier)
       composite_fwd_sh_vec_tile<4, PPL, kPolyNB>(p, bid, sm.poly);
     } else {
       const CompParams p = *pp;
@@ -839,8 +845,10 @@ k_composite_fwd_sh_vec(CompParams p_arg, ViewPack<BATCH> pack) {
   } else if constexpr (NB == kPolyNB && BATCH) {
     __shared__ FwdShVecShared<4, true> sm;
     const CompParams *pp = &plist[batch_view(p_arg, bid)];
-    if (pp->sh_rows == nullptr && !poly_route(pp->sh_bound, pp->psx, pp->psy)) return;  // this view is the exact fallback's
-    const CompParams p = *pp;
+    const bool view_ok = pp->sh_bound != nullptr && poly_route(pp->sh_bound, pp->psx, pp->psy);
+    if (pp->sh_rows == nullptr && !view_ok) return;  // per-view routing: this view is the exact fallback's
+    CompParams p = *pp;
+    if (view_ok) p.sh_rows = nullptr;  // the whole scene is within this view's bound: no per-entry tests (tile_flags stay 0)
     composite_fwd_sh_vec_tile<4, PPL, kPolyNB, false, TRACK>(p, bid, sm);
   } else {
     const CompParams p = BATCH ? plist[batch_view(p_arg, bid)] : p_arg;  // see k_composite_fwd
@@ -1553,7 +1561,8 @@ k_composite_bwd_sh_vec(CompParams p_arg, ViewPack<BATCH> pack) {
     const uint32_t tiles_grid = grid / (uint32_t)(pp->nseg > 1 ? pp->nseg : 1);
     const bool poly = routed_tile_is_polynomial(*pp, bid % tiles_grid);
     if (poly) {
-      const CompParams p = *pp;
+      CompParams p = *pp;
+      p.sh_rows = nullptr;  // (as the forward)
       composite_bwd_sh_vec_tile<4, 4, kPolyNB>(p, bid, grid, sm.poly);
     } else {
       const CompParams p = *pp;
@@ -1584,8 +1593,10 @@ k_composite_bwd_sh_vec(CompParams p_arg, ViewPack<BATCH> pack) {
   } else if constexpr (NB == kPolyNB && BATCH) {
     __shared__ BwdShVecShared<4, 4, true> sm;
     const CompParams *pp = &plist[batch_view(p_arg, bid, &grid)];
-    if (pp->sh_rows == nullptr && !poly_route(pp->sh_bound, pp->psx, pp->psy)) return;  // this view is the exact fallback's
-    const CompParams p = *pp;
+    const bool view_ok = pp->sh_bound != nullptr && poly_route(pp->sh_bound, pp->psx, pp->psy);
+    if (pp->sh_rows == nullptr && !view_ok) return;  // per-view routing: this view is the exact fallback's
+    CompParams p = *pp;
+    if (view_ok) p.sh_rows = nullptr;  // (as the forward: the same device value, the same decision)
     composite_bwd_sh_vec_tile<4, 4, kPolyNB>(p, bid, grid, sm);
   } else {
     const CompParams p = BATCH ? plist[batch_view(p_arg, bid, &grid)] : p_arg;  // see k_composite_fwd
@@ -2334,7 +2345,7 @@ static int fill_view_params(uint32_t n_views, const gsgen_sh_view *views, const 
     p.psx = v.pixel_size_x; p.psy = v.pixel_size_y; p.thresh = thresh;
     p.tile_order = v.tile_order;
     p.n_hi = 0x7fffffff;
-    p.sh_bound = sh_rows == nullptr ? sh_bound : nullptr;
+    p.sh_bound = sh_bound;  // (both given: the view's bound first -- a scene within it skips the per-entry tests --, then the rows)
     p.sh_rows = sh_rows;
     p.tile_flags = (sh_rows != nullptr && tile_flags != nullptr) ? tile_flags + (size_t)b * ntw * nth : nullptr;
     if (backward) {

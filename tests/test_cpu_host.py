@@ -1145,10 +1145,9 @@ def test_no_kernel_spills_and_hot_kernels_keep_their_occupancy(tmp_path):
     # their per-entry loops (profiles/r04_notes.md)
     spilling = {k: v["private_segment_fixed_size"] for k, v in kernels.items() if v["private_segment_fixed_size"] != 0}
     allowed = ("k_composite_bwd_chan_vecILi3E", "k_composite_fwd_chan_vecILi3ELb1EE")
-    # ... and the kernels that carry the polynomial SH body: its per-entry exact tier calls exact_tier_logits (8 bytes of the
-    # callee's), and the batched forward, held at five wavefronts per SIMD, spills inside the tier's copy of the entry body --
-    # never inside the ordinary entries' loop (checked on the disassembly below)
-    tier = ("sh_vecILi4ELi4ELb1ELi6E", "sh_vecILi4ELi4ELb0ELin1E", "sh_vecILi4ELi2ELb0ELin1E")
+    # ... and the batched kernels that carry the polynomial SH body: its per-entry exact tier calls exact_tier_logits (8 bytes of
+    # the callee's); whatever else they spill stays outside the entry loop (checked on the disassembly below)
+    tier = ("sh_vecILi4ELi4ELb1ELi6E",)  # (the per-camera kernels decide per tile before they touch it: no tier in their bodies)
     for k, v in spilling.items():
         assert (any(a in k for a in allowed) and v <= 16) or (any(a in k for a in tier) and v <= 96), spilling
     # disassembly: the entry loop -- the smallest loop (backward branch) that holds the body's calls, one gauss_ref and one
@@ -1183,7 +1182,7 @@ def test_no_kernel_spills_and_hot_kernels_keep_their_occupancy(tmp_path):
             assert 600 <= hi - lo <= 3200, (m.group(1), hi - lo)   # (150 .. 800 instructions: an entry body)
             assert not any(lo <= x <= hi for x in scratch), (m.group(1), hex(lo), hex(hi))
             n_checked += 1
-    assert n_checked >= 5, n_checked
+    assert n_checked >= 3, n_checked
 
     def find(n, *parts):
         hits = [v for k, v in kernels.items() if all(p in k for p in parts)]
