@@ -351,6 +351,9 @@ def main():
     ap.add_argument("--outlier-fraction", type=float, default=0.0,
                     help="stress test of the SH routing: this fraction of the splats gets its higher-band SH coefficients multiplied by "
                          "60 (beyond any view's bound): their tiles go to the exact kernel, the others stay polynomial")
+    ap.add_argument("--join-every", type=int, default=0, metavar="J",
+                    help="experiment: after every J steps all slot streams wait for each other -- with --batch B/2 --slots 2 "
+                         "--join-every 2 a strictly sequential optimiser whose step is two half-batches on two streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the one-render-in-flight and hipGraph passes")
     args = ap.parse_args()
@@ -716,6 +719,13 @@ def main():
         t0 = time.perf_counter()
         for i in range(K):
             step((first + i) * (len(slots) if in_flight == 1 else 1), evs[i])
+            if args.join_every > 0 and in_flight != 1 and (i + 1) % args.join_every == 0:
+                jev = [gpu.Event() for _ in slots]
+                for e_, sl_ in zip(jev, slots):
+                    e_.record(sl_.stream)
+                for sl_ in slots:
+                    for e_ in jev:
+                        sl_.stream.wait_event(e_)
         host = time.perf_counter() - t0
         barrier()
         el = el_local = time.perf_counter() - t0
