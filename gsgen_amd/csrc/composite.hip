@@ -433,7 +433,8 @@ __device__ __attribute__((noinline)) Logits3 exact_tier_logits(const float *rot_
   add(13, 0.45704579946446572f * x * (1.0f - 5.0f * z2));
   add(14, 1.4453057213202769f * z * (x2 - y2));
   add(15, 0.59004358992664352f * x * (-x2 + 3.0f * y2));
-  auto fin = [](float a) { return fminf(fmaxf(-kLog2e * a, -40.0f), 40.0f); };
+  // (a NaN coefficient stays a NaN in the image, as in the exact kernels and the reference: fminf / fmaxf would drop it)
+  auto fin = [](float a) { return a == a ? fminf(fmaxf(-kLog2e * a, -40.0f), 40.0f) : a; };
   return Logits3{fin(a0), fin(a1), fin(a2)};
 }
 template <int PPL>

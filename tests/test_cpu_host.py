@@ -1498,6 +1498,16 @@ def test_emulated_polynomial_sh_basis_is_routed_per_tile(emu, nseg):
     rows_nan = np.zeros(N, np.float32)
     emu.sh_l1_bound_rows(N, P(sh_nan), C, None, P(rows_nan), None)
     assert rows_nan[outl[0]] >= 3e38 and np.array_equal(np.delete(rows_nan, outl[0]), np.delete(rows, outl[0]))
+    # ... and stays a NaN in the image, exactly where the exact kernels (and the reference) put one: the exact tier hands it on
+    sh_ok, sh = sh, sh_nan
+    ex_n, _, _, _ = launch(None)
+    rt_n, _, _, _ = launch(rows_nan)
+    sh = sh_ok
+    n_nan = 0
+    for e, q in zip(ex_n, rt_n):
+        assert np.array_equal(np.isnan(e["out"]).any(-1), np.isnan(q["out"]).any(-1))
+        n_nan += int(np.isnan(e["out"]).any(-1).sum())
+    assert n_nan > 0
     if nseg:
         return
     # the per-camera entry points: the routed kernel scans the tile's list and takes one form per tile, forward and backward alike
