@@ -587,13 +587,15 @@ constexpr int kPushOwn = 12;
 constexpr uint32_t kPushMaxTiles = 8192;  // 32 KB of LDS: 2 048 x 1 024 pixels and the like
 constexpr int kPushThreads = 256;
 constexpr uint32_t kPushMinWorkgroups = 128;  // (chunks x views) below which the pull kernels are the faster launch
-// (GSGEN_BIN_PUSH_MIN_WORKGROUPS overrides it, read at every call: the CPU tests run both forms on scenes of a few chunks)
 // A camera batch is a throughput launch (other steps' kernels fill the chip around it): there the fewer instructions win from
 // a quarter of that on.
 constexpr uint32_t kPushMinWorkgroupsBatch = 32;
 static uint32_t push_min_workgroups(bool batch) {
-  const char *e = getenv("GSGEN_BIN_PUSH_MIN_WORKGROUPS");
-  return e != nullptr ? (uint32_t)strtoul(e, nullptr, 10) : (batch ? kPushMinWorkgroupsBatch : kPushMinWorkgroups);
+#if defined(GSGEN_EMU_KNOBS)  // the CPU emulator build of the tests only (oracle/Makefile): their scenes are one or two chunks, the
+  // variable lets them reach both forms; the product library reads nothing from the environment
+  if (const char *e = getenv("GSGEN_BIN_PUSH_MIN_WORKGROUPS")) return (uint32_t)strtoul(e, nullptr, 10);
+#endif
+  return batch ? kPushMinWorkgroupsBatch : kPushMinWorkgroups;
 }
 // the counters: T words of dynamic LDS (10 KB at 800 x 800: a workgroup finds room beside the compositing kernels' blocks
 // sooner than with the 32 KB of the largest image); the CPU emulator build has no dynamic LDS and takes the maximum

@@ -230,15 +230,15 @@ def test_batched_cameras_match_one_at_a_time(n_streams, C, fused, ncam):
         br.render(Pb["mean"], Pb["qvec"], Pb["svec"], Pb["alpha"], Pb[ck], cis * 2, [c.c2w for c in cams] * 2, C=C)
 
 
-@pytest.mark.parametrize("min_wg", ["1", "1000000"])
-def test_batched_binning_push_and_pull_forms_against_the_oracle(min_wg, monkeypatch):
-    """gsgen_frame_geometry_batch through both binning forms -- the push kernels (per-tile counters in LDS; a rectangle of more
-    than 12 tiles is finished by the whole wavefront) and the pull kernels -- on a scene with two dozen giant, near Gaussians
-    whose rectangles cover hundreds of tiles: every view's lists are the oracle's, bit for bit."""
+@pytest.mark.parametrize("B", [8, 5])
+def test_batched_binning_push_and_pull_forms_against_the_oracle(B):
+    """gsgen_frame_geometry_batch through both binning forms -- 8 views of 5 chunks are 40 workgroups: the push kernels
+    (per-tile counters in LDS; a rectangle of more than 12 tiles is finished by the whole wavefront); 5 views are 25: the pull
+    kernels -- on a scene with two dozen giant, near Gaussians whose rectangles cover hundreds of tiles: every view's lists are
+    the oracle's, bit for bit."""
     from gsgen_amd import _capi, renderer as R
-    monkeypatch.setenv("GSGEN_BIN_PUSH_MIN_WORKGROUPS", min_wg)
     lib = _capi.load()
-    W, H, B = 304, 208, 8
+    W, H = 304, 208
     sc = scenes.random_scene(9000, seed=35, svec=0.03)
     rng = np.random.default_rng(2)
     big = rng.choice(9000, 24, replace=False)
@@ -270,42 +270,55 @@ def test_batched_binning_push_and_pull_forms_against_the_oracle(min_wg, monkeypa
     assert longest > 64
 
 
-def test_batched_binning_forms_agree_on_random_batches(monkeypatch):
-    """the push form (per-tile counters in LDS, slots in arrival order) and the pull form (no atomics, ascending id) of the
-    batched binning leave the same lists on a dozen random batches: ragged image sizes, 1 .. 9 views, scales from sub-pixel to
-    half the image, pair buffers with and without room"""
+def test_batched_binning_forms_agree_on_random_batches():
+    """the batched binning takes the push form (per-tile counters in LDS, slots in arrival order) from 32 (chunk, view)
+    workgroups on, the per-camera entry point the pull form (no atomics, ascending id): the same lists on a dozen random
+    batches -- ragged image sizes, 1 .. 9 views, scales from sub-pixel to half the image, pair buffers with and without room"""
     from gsgen_amd import _capi, renderer as R
     lib = _capi.load()
     rng = np.random.default_rng(11)
     p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+    n_push = n_pull = 0
     for trial in range(12):
         W, H = int(rng.integers(40, 400)), int(rng.integers(40, 300))
-        B, N = int(rng.integers(1, 10)), int(rng.integers(1, 6000))
+        B, N = int(rng.integers(1, 10)), int(rng.integers(1, 24000))
+        if (N + 2047) // 2048 * B >= 32:
+            n_push += 1
+        else:
+            n_pull += 1
         sc = scenes.random_scene(N, seed=100 + trial, svec=float(rng.choice([0.004, 0.03, 0.3])), spread=float(rng.uniform(0.3, 1.5)))
         cams = [scenes.Camera(W, H, fx=float(rng.uniform(0.5, 1.6) * W), c2w=scenes.orbit(float(rng.uniform(1.5, 3.0)),
                 float(rng.uniform(-40, 60)), float(rng.uniform(0, 360)))) for _ in range(B)]
         cam_dev = [T_(R.CameraInfo(*c.intr).pack(c.c2w)) for c in cams]
         mean, qvec, svec = T_(sc["mean"]), T_(sc["qvec"]), T_(sc["svec"])
+        s_ = torch.cuda.current_stream().cuda_stream
         outs = {}
-        for form, min_wg in (("push", "1"), ("pull", "1000000")):
-            monkeypatch.setenv("GSGEN_BIN_PUSH_MIN_WORKGROUPS", min_wg)
-            cap = 200_000 if trial % 4 else 50   # (every fourth batch: too small a pair buffer -- nothing binned, sizes reported)
+        for form in ("batch", "per view"):
+            cap = 400_000 if trial % 4 else 50   # (every fourth batch: too small a pair buffer -- nothing binned, sizes reported)
             bufs = [R.FrameBuffers(N, W, H, dev(), D_cap=cap) for _ in cams]
-            arr = (_capi.GeometryView * B)()
-            for a, b_, cd in zip(arr, bufs, cam_dev):
+            for b_ in bufs:
                 b_.ids.fill_(-3)
-                a.cam, a.mean2d, a.cov2d, a.depth, a.mask = p(cd), p(b_.mean2d), p(b_.cov2d), p(b_.depth), p(b_.mask)
-                a.gaussian_ids, a.start, a.end, a.total = p(b_.ids), p(b_.start), p(b_.end), p(b_.total)
-                a.workspace, a.workspace_bytes, a.D_cap = p(b_.ws), b_.ws.numel(), b_.D_cap
-            bws = torch.empty(lib.frame_batch_workspace_bytes(B), device=dev(), dtype=torch.uint8)
-            lib.frame_geometry_batch(B, arr, N, p(mean), p(qvec), p(svec), W, H, p(bws), torch.cuda.current_stream().cuda_stream)
+            if form == "batch":
+                arr = (_capi.GeometryView * B)()
+                for a, b_, cd in zip(arr, bufs, cam_dev):
+                    a.cam, a.mean2d, a.cov2d, a.depth, a.mask = p(cd), p(b_.mean2d), p(b_.cov2d), p(b_.depth), p(b_.mask)
+                    a.gaussian_ids, a.start, a.end, a.total = p(b_.ids), p(b_.start), p(b_.end), p(b_.total)
+                    a.workspace, a.workspace_bytes, a.D_cap = p(b_.ws), b_.ws.numel(), b_.D_cap
+                bws = torch.empty(lib.frame_batch_workspace_bytes(B), device=dev(), dtype=torch.uint8)
+                lib.frame_geometry_batch(B, arr, N, p(mean), p(qvec), p(svec), W, H, p(bws), s_)
+            else:
+                for b_, cd in zip(bufs, cam_dev):
+                    lib.frame_geometry(N, p(mean), p(qvec), p(svec), p(cd), W, H, b_.D_cap, p(b_.mean2d), p(b_.cov2d),
+                                       p(b_.depth), p(b_.mask), p(b_.ids), p(b_.start), p(b_.end), p(b_.total), p(b_.ws),
+                                       b_.ws.numel(), s_)
             torch.cuda.synchronize()
             outs[form] = [(int(b_.total.item()), b_.start.cpu().numpy().copy(), b_.end.cpu().numpy().copy(),
                            b_.ids.cpu().numpy().copy()) for b_ in bufs]
-        for v, (a_, b_) in enumerate(zip(outs["push"], outs["pull"])):
+        for v, (a_, b_) in enumerate(zip(outs["batch"], outs["per view"])):
             assert a_[0] == b_[0], (trial, v)
             assert np.array_equal(a_[1], b_[1]) and np.array_equal(a_[2], b_[2]), (trial, v)
             assert np.array_equal(a_[3], b_[3]), (trial, v)
+    assert n_push >= 3 and n_pull >= 3, (n_push, n_pull)
 
 
 def test_batched_geometry_and_projection_backward_c_abi():
