@@ -99,11 +99,11 @@ def b_alg_bytes(N, D, P, T, F):
 
 def choose_batch_and_slots(pairs_per_view, batch=0, slots=0):
     """cameras per launch and launches in flight for a workload of `pairs_per_view` (tile, Gaussian) pairs per camera:
-    about 6 M pairs per launch (2 .. 8 cameras), three launches in flight (light launches and the polynomial-basis kernels
-    gain from the third, the exact kernels of a heavy launch neither gain nor lose: profiles/r02_notes.md).  Explicit
-    --batch / --slots win."""
+    about 9 M pairs per launch (2 .. 8 cameras; 6 M until round 4, when cfg3 measured +2.5 % at four cameras per launch instead
+    of two: profiles/r04_notes.md 11), three launches in flight (light launches and the polynomial-basis kernels gain from the
+    third, the exact kernels of a heavy launch neither gain nor lose: profiles/r02_notes.md).  Explicit --batch / --slots win."""
     d = max(1, int(pairs_per_view))
-    B = batch if batch > 0 else int(min(8, max(2, round(6.0e6 / d))))
+    B = batch if batch > 0 else int(min(8, max(2, round(9.0e6 / d))))
     return B, (slots if slots > 0 else 3)
 
 

@@ -293,7 +293,7 @@ def test_bench_accounting_and_launch_shape():
     assert parts["composite_fwd"] == (4 + 4 * 55) * 713_016 + 16 * 640_000
     assert total == sum(parts.values()) and abs(total / 0.5457e9 - 1) < 0.01  # 0.546 GB per render at cfg2
     assert bench.choose_batch_and_slots(713_016) == (8, 3)      # cfg2: 5.7 M pairs per launch, three steps in flight
-    assert bench.choose_batch_and_slots(2_470_000) == (2, 3)    # cfg3: two cameras per launch, three in flight
+    assert bench.choose_batch_and_slots(2_470_000) == (4, 3)    # cfg3: four cameras per launch (9.9 M pairs), three in flight
     assert bench.choose_batch_and_slots(440_000) == (8, 3)      # cfg4: light launches
     assert bench.choose_batch_and_slots(2_700) == (8, 3)        # cfg1
     assert bench.choose_batch_and_slots(713_016, batch=4, slots=1) == (4, 1)
