@@ -19,6 +19,13 @@ import sys
 __version__ = "0.1.0"
 
 
+def __getattr__(name):  # (lazy: importing the package must not import torch)
+    if name == "PairListOverflow":
+        from .renderer import PairListOverflow
+        return PairListOverflow
+    raise AttributeError(name)
+
+
 def compiled_gs():
     """The compiled `_gs` CPython module (gsgen_amd/ext/_gs.*.so, built by gsgen_amd.build.build_torch_ext from
     csrc/torch_gs.cpp: torch::Tensor in, C ABI underneath -- what the reference builds from gs/src/bindings.cpp), or

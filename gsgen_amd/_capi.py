@@ -36,7 +36,7 @@ class GeometryView(C.Structure):
     """gsgen_geometry_view (include/gsgen_hip.h): one camera of a batched geometry enqueue."""
     _fields_ = [("cam", vp), ("mean2d", vp), ("cov2d", vp), ("depth", vp), ("mask", vp), ("gaussian_ids", vp),
                 ("start", vp), ("end", vp), ("total", vp), ("workspace", vp), ("workspace_bytes", sz), ("D_cap", u32),
-                ("zero_grad_mean2d", vp), ("zero_grad_cov2d", vp), ("zero_grad_chan6", vp)]
+                ("zero_grad_mean2d", vp), ("zero_grad_cov2d", vp), ("zero_grad_chan6", vp), ("pair_report", vp)]
 
 
 # name -> argtypes, in the order of include/gsgen_hip.h
@@ -64,6 +64,7 @@ SIGNATURES = {
     "gsgen_project_gaussians_backward_batch_heads": [u32, u32, vp, vp, vp, C.POINTER(vp), i32, C.POINTER(vp), C.POINTER(vp),
                                                      C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp, vp, vp, vp, vp],
     "gsgen_sh_l1_bound_rows": [u32, vp, u32, vp, vp, vp],
+    "gsgen_sh_l1_bound_rows_running": [u32, vp, u32, vp, vp, vp],
     "gsgen_vol_render_sh_batch_routed": [u32, C.POINTER(ShView), u32, vp, vp, u32, u32, u32, u32, u32, u32, f32, u32, vp, vp, vp, vp],
     "gsgen_vol_render_backward_sh_batch_routed": [u32, C.POINTER(ShView), u32, vp, vp, vp, vp, u32, u32, u32, u32, u32, u32, f32, u32,
                                                   vp, vp, vp, vp],
@@ -114,9 +115,11 @@ SIGNATURES = {
     "gsgen_frame_geometry_batch": [u32, C.POINTER(GeometryView), u32, vp, vp, vp, u32, u32, vp, vp],
     "gsgen_frame_geometry_batch_zero": [u32, C.POINTER(GeometryView), u32, vp, vp, vp, u32, u32, vp, sz, vp, vp],
     "gsgen_frame_geometry": [u32, vp, vp, vp, vp, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp],
+    "gsgen_frame_geometry_report": [u32, vp, vp, vp, vp, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp],
 }
 PTR_FUNCS = {
     "gsgen_frame_tile_order": [vp, u32, u32, u32],
+    "gsgen_host_device_pointer": [vp],
 }
 SIZE_FUNCS = {
     "gsgen_tile_culling_workspace_bytes": [u32, u32, u32],

@@ -3,17 +3,24 @@
 The reference renders the cameras of a batch strictly one after another in a Python loop and
 stacks the per-camera dicts (gs/gaussian_splatting.py:1423-1466).  One 800x800 frame of 100k
 Gaussians does not fill an MI355X (2.5k tiles on 256 CUs, each kernel ending on its longest
-tiles), so this caller keeps several cameras in flight instead: camera i is enqueued on HIP
-stream i % n_streams with its own FrameBuffers, all per-camera constants go up in ONE host to
-device copy, and nothing synchronises with the host.  The whole batch is ONE autograd node: its
-backward fans out over the same streams, and every camera adds atomically into one set of
-parameter gradients (compositing already accumulates; the projection backward runs in its
-accumulate form), so there is no per-camera zero-fill of the SH gradient (19 MB at 100k, C=4)
-and no B-way gradient sum afterwards.
+tiles), so this caller renders the batch with ONE enqueue per stage -- geometry, compositing forward,
+compositing backward, projection backward each launch once for all cameras (gridDim = views x tiles) --
+and nothing synchronises with the host.  The whole batch is ONE autograd node; every camera adds
+atomically into one set of parameter gradients (no per-camera zero-fill of the SH gradient, 19 MB at
+100k and C = 4, and no B-way gradient sum afterwards).
+
+A strictly sequential caller (a training loop: one step in flight) leaves the chip idle between the
+stages of one step -- the geometry chain is six small launches.  From 4 cameras on, the renderer
+therefore runs the batch as TWO half-batches on two streams (its own side stream, forked from and
+joined to the caller's stream inside the call): one half's geometry hides behind the other's
+compositing.  Images are the same bits, gradients the same up to the order of the atomics
+(profiles/r04_notes.md section 14, profiles/r05_notes.md: +4 .. 9 % with one step in flight).
 
 Every camera of the batch owns a FrameBuffers slot because its backward needs the lists and
-projected records of its forward (22 + 12 B x D_cap per slot; 64 cameras at cfg2 ~ 2 GB of the
-288 GB).
+projected records of its forward (22 B x N + 12 B x D_cap per slot).
+
+Pair-list overflow (a camera needing more (tile, Gaussian) pairs than its slot holds) is never a
+finite blank image: see renderer.FrameBuffers and BatchRenderer.check_overflow.
 """
 import ctypes
 
@@ -22,7 +29,7 @@ import torch
 
 from . import _capi
 from . import renderer as R
-from .renderer import _p
+from .renderer import _p, PairListOverflow
 
 
 def _bg_grad(ctx, grad_rgb, T):
@@ -50,9 +57,12 @@ def _on(dev):
     return _NO_GUARD if torch.cuda.current_device() == dev.index else torch.cuda.device(dev)
 
 
-def _tab(addresses):
-    """host array of device pointers for the *_batch entry points"""
-    return (ctypes.c_void_p * len(addresses))(*addresses)
+def _sub(table, lo, n):
+    """rows lo .. lo + n of a ctypes array as an array of its own (the same memory: what a half-batch hands the C ABI)"""
+    if lo == 0 and n == len(table):
+        return table
+    et = table._type_
+    return (et * n).from_address(ctypes.addressof(table) + lo * ctypes.sizeof(et))
 
 
 class _render_batch(torch.autograd.Function):
@@ -60,112 +70,65 @@ class _render_batch(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, mean, qvec, svec, alpha, col, cams, br, B, C, bg_rgb, thresh, detach_depth, stats):
+        """one enqueue of the geometry kernels (gridDim.y = cameras) and one compositing launch per half-batch.  Nothing is
+        filled between the stages: the projection launch zeroes the step's gradient accumulators (the renderer's per-view
+        blocks and the shared block allocated here, gsgen_frame_geometry_batch_zero), the compositing launch writes every
+        pixel of out / T."""
         mean, qvec, svec = mean.contiguous(), qvec.contiguous(), svec.contiguous()
         alpha, col = alpha.contiguous(), col.contiguous()
         lib = _capi.load()
         H, W, N, dev = br.H, br.W, br.N, mean.device
-        fused = br.fused_launch and B > 0
-        ctx.gen = br._begin_batch(B)
-        if fused:  # the batched forward writes every pixel of out / T (empty tiles included): no fill kernels
-            out = torch.empty(B, H, W, 3, device=dev, dtype=torch.float32)
-            T = torch.empty(B, H, W, 1, device=dev, dtype=torch.float32)
-            return _render_batch._forward_fused(ctx, mean, qvec, svec, alpha, col, cams, br, B, C, bg_rgb, thresh,
-                                                detach_depth, stats, out, T)
-        out = torch.zeros(B, H, W, 3, device=dev, dtype=torch.float32)
-        T = torch.ones(B, H, W, 1, device=dev, dtype=torch.float32)
-        cams_p, out_p, T_p = cams.data_ptr(), out.data_ptr(), T.data_ptr()
-        cur = br._fork(B, (cams, out, T) + tuple(x for x in (br._sh_bound, br._sh_rows) if x is not None))
-        with torch.cuda.device(dev):
-            for i in range(B):
-                buf, s, ci = br.slots[i], br.streams[i % len(br.streams)].cuda_stream, br._cis[i]
-                cam = cams_p + 272 * i  # row i: cam block | topleft at +56 floats | rotation at +58
-                psx, psy = 1.0 / ci.fx, 1.0 / ci.fy
-                lib.frame_geometry(N, _p(mean), _p(qvec), _p(svec), cam, W, H, buf.D_cap, _p(buf.mean2d),
-                                   _p(buf.cov2d), _p(buf.depth), _p(buf.mask), _p(buf.ids), _p(buf.start), _p(buf.end),
-                                   _p(buf.total), _p(buf.ws), buf.ws.numel(), s)
-                if stats is not None:
-                    lib.densify_update(N, _p(buf.cov2d), None, _p(buf.mask), _p(stats.max_radii2d), None, None, s)
-                if C > 0:
-                    lib.vol_render_sh_routed(N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col), _p(alpha),
-                                             _p(buf.start), _p(buf.end), _p(buf.ids), out_p + 12 * H * W * i, cam + 224,
-                                             cam + 232, 16, buf.nth, buf.ntw, psx, psy, H, W, C, thresh,
-                                             _p(bg_rgb), T_p + 4 * H * W * i, buf.tile_order(), None, 0,
-                                             _p(br._sh_bound), _p(br._sh_rows), s)
-                else:
-                    lib.vol_render_start_end_with_T(N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col), _p(alpha),
-                                                    _p(buf.start), _p(buf.end), _p(buf.ids), out_p + 12 * H * W * i,
-                                                    cam + 224, 16, buf.nth, buf.ntw, psx, psy, H, W, thresh,
-                                                    T_p + 4 * H * W * i, s)
-        br._join(B, cur)
-        br._end_batch(B)
-        ctx.views = ctx.bws = None
-        if C == 0 and bg_rgb is not None:
-            out = out + T * bg_rgb  # gs/renderer.py:1182
-        ctx.save_for_backward(mean, qvec, svec, alpha, col, cams, out, T)
-        ctx.bg_shape = tuple(bg_rgb.shape) if (bg_rgb is not None and ctx.needs_input_grad[9]) else None
-        ctx.br, ctx.B, ctx.C, ctx.thresh, ctx.detach, ctx.stats = br, B, C, thresh, detach_depth, stats
-        ctx.sh_bound, ctx.sh_rows = br._sh_bound, br._sh_rows  # forward and backward of a batch route on the same device values
-        ctx.cis = list(br._cis[:B])
-        ctx.mark_non_differentiable(T)
-        return out, T
-
-    @staticmethod
-    def _forward_fused(ctx, mean, qvec, svec, alpha, col, cams, br, B, C, bg_rgb, thresh, detach_depth, stats, out, T):
-        """the whole batch on the current stream: one enqueue of the geometry kernels (gridDim.y = cameras), one
-        compositing launch.  Nothing is filled between the stages: the projection launch zeroes the step's gradient
-        accumulators (the renderer's per-view blocks and the shared block allocated here, gsgen_frame_geometry_batch_zero),
-        the compositing launch writes every pixel of out / T."""
-        lib = _capi.load()
-        H, W, N, dev = br.H, br.W, br.N, mean.device
+        br._begin_batch(B)
+        out = torch.empty(B, H, W, 3, device=dev, dtype=torch.float32)
+        T = torch.empty(B, H, W, 1, device=dev, dtype=torch.float32)
         out_p, T_p = out.data_ptr(), T.data_ptr()
-        s = torch.cuda.current_stream(dev).cuda_stream
-        # the slots' buffer addresses, the camera rows and the gradient blocks sit in cached tables (BatchRenderer._tables);
-        # only what changes per call is set
-        geo, views = br._tables("sh" if C > 0 else "rgb")  # C == 0: post-activation colours
-        bg_p = _p(bg_rgb)
-        cis = br._cis
-        if C > 0:
-            for i in range(B):
-                ci, v = cis[i], views[i]
-                v.pixel_size_x, v.pixel_size_y = 1.0 / ci.fx, 1.0 / ci.fy
-                v.T, v.bg_rgb, v.out = T_p + 4 * H * W * i, bg_p, out_p + 12 * H * W * i
-        else:
-            for i in range(B):
-                ci, v = cis[i], views[i]
-                v.pixel_size_x, v.pixel_size_y = 1.0 / ci.fx, 1.0 / ci.fy
-                v.T, v.out6 = T_p + 4 * H * W * i, out_p + 12 * H * W * i  # read as [H,W,3] by the RGB entry points
+        kind = "sh" if C > 0 else "rgb"  # C == 0: post-activation colours
         # d L / d alpha [N] | d L / d col, shared by the views: returned by the backward, hence allocated per batch -- and
         # zeroed by this forward's projection launch
         gsh = torch.empty(br._Np + (col.numel() + 3) // 4 * 4, device=dev, dtype=torch.float32)
-        nb_sh = br._nb_sh
         with _on(dev):
-            lib.frame_geometry_batch_zero(B, geo, N, _p(mean), _p(qvec), _p(svec), W, H, _p(gsh), gsh.numel(),
-                                          _p(br._bws) + nb_sh, s)
-            br._end_batch(B)
+            parts = br._fork(B)
+            views = br._geometry(kind, B, parts, mean, qvec, svec, gsh)
+            bg_p = _p(bg_rgb)
+            cis = br._cis
+            if C > 0:
+                for i in range(B):
+                    ci, v = cis[i], views[i]
+                    v.pixel_size_x, v.pixel_size_y = 1.0 / ci.fx, 1.0 / ci.fy
+                    v.T, v.bg_rgb, v.out = T_p + 4 * H * W * i, bg_p, out_p + 12 * H * W * i
+            else:
+                for i in range(B):
+                    ci, v = cis[i], views[i]
+                    v.pixel_size_x, v.pixel_size_y = 1.0 / ci.fx, 1.0 / ci.fy
+                    v.T, v.out6 = T_p + 4 * H * W * i, out_p + 12 * H * W * i  # read as [H,W,3] by the RGB entry points
+            nth, ntw = br.slots[0].nth, br.slots[0].ntw
+            for k, (lo, n, s) in enumerate(parts):
+                if C > 0:
+                    lib.vol_render_sh_batch_routed(n, _sub(views, lo, n), N, _p(col), _p(alpha), 16, nth, ntw, H, W, C,
+                                                   thresh, br.segments, _p(br._sh_bound), _p(br._sh_rows), _p(br._bws[k]), s)
+                else:
+                    lib.vol_render_rgb_batch(n, _sub(views, lo, n), N, _p(col), _p(alpha), 16, nth, ntw, H, W, thresh,
+                                             _p(br._bws[k]), s)
+            br._join(parts)
             if stats is not None:
                 lib.densify_update_batch(B, N, br._ptr_table("cov2d", B), None, br._mask_table(B), _p(stats.max_radii2d), None,
-                                         None, s)
-            if C > 0:
-                lib.vol_render_sh_batch_routed(B, views, N, _p(col), _p(alpha), 16, br.slots[0].nth, br.slots[0].ntw, H, W, C,
-                                               thresh, br.segments, _p(br._sh_bound), _p(br._sh_rows), _p(br._bws), s)
-            else:
-                lib.vol_render_rgb_batch(B, views, N, _p(col), _p(alpha), 16, br.slots[0].nth, br.slots[0].ntw, H, W,
-                                         thresh, _p(br._bws), s)
+                                         None, parts[0][2])
         if C == 0 and bg_rgb is not None:
             out = out + T * bg_rgb  # gs/renderer.py:1182; `out` (saved below) is what the backward reads as final
             for i in range(B):
                 views[i].out6 = out.data_ptr() + 12 * H * W * i
-        ctx.views, ctx.gsh = views, gsh
+        ctx.gen = br._generation
+        ctx.views, ctx.gsh, ctx.parts = views, gsh, [(lo, n) for lo, n, _ in parts]
         ctx.save_for_backward(mean, qvec, svec, alpha, col, cams, out, T)
         ctx.bg_shape = tuple(bg_rgb.shape) if (bg_rgb is not None and ctx.needs_input_grad[9]) else None
         ctx.br, ctx.B, ctx.C, ctx.thresh, ctx.detach, ctx.stats = br, B, C, thresh, detach_depth, stats
         ctx.sh_bound, ctx.sh_rows = br._sh_bound, br._sh_rows  # forward and backward of a batch route on the same device values
-        ctx.cis = list(br._cis[:B])
         ctx.mark_non_differentiable(T)
         return out, T
 
     @staticmethod
-    def _backward_fused(ctx, grad):
+    def backward(ctx, grad, _gT):
+        ctx.br._check_generation(ctx.gen)
         mean, qvec, svec, alpha, col, cams, out, T = ctx.saved_tensors
         br, B, C, thresh, stats = ctx.br, ctx.B, ctx.C, ctx.thresh, ctx.stats
         lib = _capi.load()
@@ -180,7 +143,6 @@ class _render_batch(torch.autograd.Function):
         g3d = torch.empty(10 * N, device=dev, dtype=torch.float32)   # mean | qvec | svec: overwritten
         g_mean, g_qvec, g_svec = g3d[:3 * N].view(N, 3), g3d[3 * N:7 * N].view(N, 4), g3d[7 * N:].view(N, 3)
         grad_p = grad.data_ptr()
-        s = torch.cuda.current_stream(dev).cuda_stream
         views = ctx.views
         if C > 0:
             for i in range(B):
@@ -188,66 +150,25 @@ class _render_batch(torch.autograd.Function):
         else:
             for i in range(B):
                 views[i].grad_out6 = grad_p + 12 * H * W * i
+        nth, ntw = br.slots[0].nth, br.slots[0].ntw
         with _on(dev):
-            if C > 0:
-                lib.vol_render_backward_sh_batch_routed(B, views, N, _p(col), _p(alpha), _p(g_col), _p(g_alpha), 16,
-                                                        br.slots[0].nth, br.slots[0].ntw, H, W, C, thresh, br.segments,
-                                                        _p(ctx.sh_bound), _p(ctx.sh_rows), _p(br._bws), s)
-            else:
-                lib.vol_render_rgb_backward_batch(B, views, N, _p(col), _p(alpha), _p(g_col), _p(g_alpha), 16,
-                                                  br.slots[0].nth, br.slots[0].ntw, H, W, thresh, _p(br._bws), s)
+            parts = br._fork(B, ctx.parts)
+            for k, (lo, n, s) in enumerate(parts):
+                if C > 0:
+                    lib.vol_render_backward_sh_batch_routed(n, _sub(views, lo, n), N, _p(col), _p(alpha), _p(g_col), _p(g_alpha),
+                                                            16, nth, ntw, H, W, C, thresh, br.segments, _p(ctx.sh_bound),
+                                                            _p(ctx.sh_rows), _p(br._bws[k]), s)
+                else:
+                    lib.vol_render_rgb_backward_batch(n, _sub(views, lo, n), N, _p(col), _p(alpha), _p(g_col), _p(g_alpha), 16,
+                                                      nth, ntw, H, W, thresh, _p(br._bws[k]), s)
+            br._join(parts)
+            s = parts[0][2]
             lib.project_gaussians_backward_batch(B, N, _p(mean), _p(qvec), _p(svec), br._ptr_table("cam", B),
                                                  int(ctx.detach), br._mask_table(B), br._ptr_table("g_mean2d", B),
                                                  br._ptr_table("g_cov2d", B), None, _p(g_mean), _p(g_qvec), _p(g_svec), s)
             if stats is not None:
                 lib.densify_update_batch(B, N, None, br._ptr_table("g_mean2d", B), br._mask_table(B), None,
                                          _p(stats.grad_accum), _p(stats.cnt), s)
-        return (g_mean, g_qvec, g_svec, g_alpha, g_col, None, None, None, None, _bg_grad(ctx, grad, T), None, None, None)
-
-    @staticmethod
-    def backward(ctx, grad, _gT):
-        ctx.br._check_generation(ctx.gen)
-        if ctx.views is not None:
-            return _render_batch._backward_fused(ctx, grad)
-        mean, qvec, svec, alpha, col, cams, out, T = ctx.saved_tensors
-        br, B, C, thresh, stats = ctx.br, ctx.B, ctx.C, ctx.thresh, ctx.stats
-        lib = _capi.load()
-        H, W, N, dev = br.H, br.W, br.N, mean.device
-        grad = grad.contiguous()
-        g2d = torch.zeros(B, 6 * N, device=dev, dtype=torch.float32)  # per camera: mean2d | cov2d
-        g3d = torch.zeros(11 * N, device=dev, dtype=torch.float32)   # shared: mean | qvec | svec | alpha
-        g_mean, g_qvec = g3d[:3 * N].view(N, 3), g3d[3 * N:7 * N].view(N, 4)
-        g_svec, g_alpha = g3d[7 * N:10 * N].view(N, 3), g3d[10 * N:]
-        g_col = torch.zeros_like(col)
-        cams_p, out_p, grad_p, g2d_p = cams.data_ptr(), out.data_ptr(), grad.data_ptr(), g2d.data_ptr()
-        cur = br._fork(B, (grad, g2d, g3d, g_col) + tuple(x for x in (ctx.sh_bound, ctx.sh_rows) if x is not None))
-        with torch.cuda.device(dev):
-            for i in range(B):
-                buf, s, ci = br.slots[i], br.streams[i % len(br.streams)].cuda_stream, ctx.cis[i]
-                cam = cams_p + 272 * i
-                g_mean2d = g2d_p + 24 * N * i
-                g_cov2d = g_mean2d + 8 * N
-                psx, psy = 1.0 / ci.fx, 1.0 / ci.fy
-                if C > 0:
-                    lib.vol_render_backward_sh_routed(N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col), _p(alpha),
-                                                      _p(buf.start), _p(buf.end), _p(buf.ids), out_p + 12 * H * W * i,
-                                                      g_mean2d, g_cov2d, _p(g_col), _p(g_alpha),
-                                                      grad_p + 12 * H * W * i, cam + 224, cam + 232, 16, buf.nth,
-                                                      buf.ntw, psx, psy, H, W, C, thresh, None, buf.tile_order(), None, 0,
-                                                      _p(ctx.sh_bound), _p(ctx.sh_rows), s)
-                else:
-                    lib.vol_render_backward_start_end(N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col), _p(alpha),
-                                                      _p(buf.start), _p(buf.end), _p(buf.ids), out_p + 12 * H * W * i,
-                                                      g_mean2d, g_cov2d, _p(g_col), _p(g_alpha),
-                                                      grad_p + 12 * H * W * i, cam + 224, 16, buf.nth, buf.ntw, psx,
-                                                      psy, H, W, thresh, s)
-                lib.project_gaussians_backward_accum(N, _p(mean), _p(qvec), _p(svec), cam, int(ctx.detach),
-                                                     _p(buf.mask), g_mean2d, g_cov2d, None, _p(g_mean),
-                                                     _p(g_qvec), _p(g_svec), s)
-                if stats is not None:
-                    lib.densify_update(N, None, g_mean2d, _p(buf.mask), None, _p(stats.grad_accum),
-                                       _p(stats.cnt), s)
-        br._join(B, cur)
         return (g_mean, g_qvec, g_svec, g_alpha, g_col, None, None, None, None, _bg_grad(ctx, grad, T), None, None, None)
 
 
@@ -262,88 +183,62 @@ class _render_batch_heads(torch.autograd.Function):
         alpha, col = alpha.contiguous(), col.contiguous()
         lib = _capi.load()
         H, W, N, dev = br.H, br.W, br.N, mean.device
-        ctx.views = ctx.gsh = None
-        ctx.gen = br._begin_batch(B)
-        if br.fused_launch and B > 0:  # one enqueue per stage for the whole batch, on the current stream
-            # (every pixel of out6 / T is written by the batched forward, the gradient accumulators are zeroed by the
-            # projection launch: no fill kernels)
-            out6 = torch.empty(B, H, W, 6, device=dev, dtype=torch.float32)
-            T = torch.empty(B, H, W, 1, device=dev, dtype=torch.float32)
-            out_p, T_p = out6.data_ptr(), T.data_ptr()
-            s = torch.cuda.current_stream(dev).cuda_stream
-            geo, views = br._tables("rgbd")
+        br._begin_batch(B)
+        # (every pixel of out6 / T is written by the batched forward, the gradient accumulators are zeroed by the
+        # projection launch: no fill kernels)
+        out6 = torch.empty(B, H, W, 6, device=dev, dtype=torch.float32)
+        T = torch.empty(B, H, W, 1, device=dev, dtype=torch.float32)
+        out_p, T_p = out6.data_ptr(), T.data_ptr()
+        gsh = torch.empty(br._Np, device=dev, dtype=torch.float32)  # d L / d alpha, shared by the views
+        with _on(dev):
+            parts = br._fork(B)
+            views = br._geometry("rgbd", B, parts, mean, qvec, svec, gsh)
             cis = br._cis
             for i in range(B):
                 ci, v = cis[i], views[i]
                 v.pixel_size_x, v.pixel_size_y = 1.0 / ci.fx, 1.0 / ci.fy
                 v.out6, v.T = out_p + 24 * H * W * i, T_p + 4 * H * W * i
-            gsh = torch.empty(br._Np, device=dev, dtype=torch.float32)  # d L / d alpha, shared by the views
-            with _on(dev):
-                lib.frame_geometry_batch_zero(B, geo, N, _p(mean), _p(qvec), _p(svec), W, H, _p(gsh), gsh.numel(),
-                                              _p(br._bws) + br._nb_sh, s)
-                br._end_batch(B)
-                if stats is not None:
-                    lib.densify_update_batch(B, N, br._ptr_table("cov2d", B), None, br._mask_table(B),
-                                             _p(stats.max_radii2d), None, None, s)
-                lib.vol_render_rgbd_batch(B, views, N, _p(col), _p(alpha), 16, br.slots[0].nth, br.slots[0].ntw, H, W,
-                                          thresh, _p(br._bws), s)
-            ctx.views, ctx.gsh = views, gsh
-        else:
-            out6 = torch.zeros(B, H, W, 6, device=dev, dtype=torch.float32)
-            T = torch.ones(B, H, W, 1, device=dev, dtype=torch.float32)
-            _render_batch_heads._forward_streams(br, B, lib, mean, qvec, svec, alpha, col, cams, out6, T, thresh, stats)
+            nth, ntw = br.slots[0].nth, br.slots[0].ntw
+            for k, (lo, n, s) in enumerate(parts):
+                lib.vol_render_rgbd_batch(n, _sub(views, lo, n), N, _p(col), _p(alpha), 16, nth, ntw, H, W, thresh,
+                                          _p(br._bws[k]), s)
+            br._join(parts)
+            if stats is not None:
+                lib.densify_update_batch(B, N, br._ptr_table("cov2d", B), None, br._mask_table(B),
+                                         _p(stats.max_radii2d), None, None, parts[0][2])
         if bg_rgb is not None:
             out6[..., :3] += T * bg_rgb  # gs/renderer.py:1182
+        ctx.gen = br._generation
+        ctx.views, ctx.gsh, ctx.parts = views, gsh, [(lo, n) for lo, n, _ in parts]
         ctx.save_for_backward(mean, qvec, svec, alpha, col, cams, out6, T)
         ctx.bg_shape = tuple(bg_rgb.shape) if (bg_rgb is not None and ctx.needs_input_grad[8]) else None
         ctx.br, ctx.B, ctx.thresh, ctx.detach, ctx.stats = br, B, thresh, detach_depth, stats
-        ctx.cis = list(br._cis[:B])
         ctx.mark_non_differentiable(T)
         return out6[..., :3], out6[..., 3:4], out6[..., 4:5], out6[..., 5:6], T
 
     @staticmethod
-    def _forward_streams(br, B, lib, mean, qvec, svec, alpha, col, cams, out6, T, thresh, stats):
-        """one chain per camera on the side streams"""
-        H, W, N, dev = br.H, br.W, br.N, mean.device
-        cur = br._fork(B, (cams, out6, T))
-        cams_p, out_p, T_p = cams.data_ptr(), out6.data_ptr(), T.data_ptr()
-        with torch.cuda.device(dev):
-            for i in range(B):
-                buf, s, ci = br.slots[i], br.streams[i % len(br.streams)].cuda_stream, br._cis[i]
-                cam = cams_p + 272 * i
-                lib.frame_geometry(N, _p(mean), _p(qvec), _p(svec), cam, W, H, buf.D_cap, _p(buf.mean2d),
-                                   _p(buf.cov2d), _p(buf.depth), _p(buf.mask), _p(buf.ids), _p(buf.start), _p(buf.end),
-                                   _p(buf.total), _p(buf.ws), buf.ws.numel(), s)
-                if stats is not None:
-                    lib.densify_update(N, _p(buf.cov2d), None, _p(buf.mask), _p(stats.max_radii2d), None, None, s)
-                lib.vol_render_rgbd(N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col), _p(buf.depth), _p(alpha),
-                                    _p(buf.start), _p(buf.end), _p(buf.ids), out_p + 24 * H * W * i, cam + 224, 16,
-                                    buf.nth, buf.ntw, 1.0 / ci.fx, 1.0 / ci.fy, H, W, thresh, T_p + 4 * H * W * i,
-                                    buf.tile_order(), s)
-        br._join(B, cur)
-        br._end_batch(B)
-
-    @staticmethod
-    def _backward_fused(ctx, g_rgb, g_depth, g_opac, g_z2):
-        """one compositing launch that reads the four head gradients in place (no [B,H,W,6] image is assembled: that
-        concatenation was 8 % of a step at 8 x 800^2), one projection launch that forms d L / d depth = g3 + 2 depth g5 and
-        sums the colour gradient over the views itself (gsgen_project_gaussians_backward_batch_heads)"""
+    def backward(ctx, g_rgb, g_depth, g_opac, g_z2, _gT):
+        """one compositing launch per half-batch that reads the four head gradients in place (no [B,H,W,6] image is
+        assembled: that concatenation was 8 % of a step at 8 x 800^2), one projection launch that forms
+        d L / d depth = g3 + 2 depth g5 and sums the colour gradient over the views itself
+        (gsgen_project_gaussians_backward_batch_heads)"""
+        ctx.br._check_generation(ctx.gen)
         mean, qvec, svec, alpha, col, cams, out6, T = ctx.saved_tensors
         br, B, thresh, stats = ctx.br, ctx.B, ctx.thresh, ctx.stats
         lib = _capi.load()
         H, W, N, dev = br.H, br.W, br.N, mean.device
-        parts = [g.contiguous() if g is not None else None for g in (g_rgb, g_depth, g_opac, g_z2)]
+        parts_g = [g.contiguous() if g is not None else None for g in (g_rgb, g_depth, g_opac, g_z2)]
         gsh, ctx.gsh = ctx.gsh, None
         if gsh is None:  # a second backward through the same graph (retain_graph): the accumulators were handed out
             gsh = torch.zeros(br._Np, device=dev, dtype=torch.float32)
             br._g2d[:B].zero_()
+            br._chan6()[:B].zero_()
         g_alpha = gsh[:N]
         g3d = torch.empty(13 * N, device=dev, dtype=torch.float32)  # mean | qvec | svec | colour: overwritten
         g_mean, g_qvec = g3d[:3 * N].view(N, 3), g3d[3 * N:7 * N].view(N, 4)
         g_svec, g_col = g3d[7 * N:10 * N].view(N, 3), g3d[10 * N:].view(N, 3)
-        s = torch.cuda.current_stream(dev).cuda_stream
         views = ctx.views
-        pp = [x.data_ptr() if x is not None else None for x in parts]
+        pp = [x.data_ptr() if x is not None else None for x in parts_g]
         for i in range(B):
             v = views[i]
             v.grad_out6 = None
@@ -351,9 +246,14 @@ class _render_batch_heads(torch.autograd.Function):
             v.grad_depth = pp[1] + 4 * H * W * i if pp[1] is not None else None
             v.grad_opacity = pp[2] + 4 * H * W * i if pp[2] is not None else None
             v.grad_depth2 = pp[3] + 4 * H * W * i if pp[3] is not None else None
+        nth, ntw = br.slots[0].nth, br.slots[0].ntw
         with _on(dev):
-            lib.vol_render_rgbd_backward_batch(B, views, N, _p(col), _p(alpha), _p(g_alpha), 16, br.slots[0].nth,
-                                               br.slots[0].ntw, H, W, thresh, _p(br._bws), s)
+            parts = br._fork(B, ctx.parts)
+            for k, (lo, n, s) in enumerate(parts):
+                lib.vol_render_rgbd_backward_batch(n, _sub(views, lo, n), N, _p(col), _p(alpha), _p(g_alpha), 16, nth, ntw, H, W,
+                                                   thresh, _p(br._bws[k]), s)
+            br._join(parts)
+            s = parts[0][2]
             lib.project_gaussians_backward_batch_heads(B, N, _p(mean), _p(qvec), _p(svec), br._ptr_table("cam", B),
                                                        int(ctx.detach), br._mask_table(B), br._ptr_table("g_mean2d", B),
                                                        br._ptr_table("g_cov2d", B), br._ptr_table("g_chan6", B),
@@ -364,95 +264,60 @@ class _render_batch_heads(torch.autograd.Function):
                                          _p(stats.grad_accum), _p(stats.cnt), s)
         return (g_mean, g_qvec, g_svec, g_alpha, g_col, None, None, None, _bg_grad(ctx, g_rgb, T), None, None, None)
 
-    @staticmethod
-    def backward(ctx, g_rgb, g_depth, g_opac, g_z2, _gT):
-        ctx.br._check_generation(ctx.gen)
-        if ctx.views is not None:
-            return _render_batch_heads._backward_fused(ctx, g_rgb, g_depth, g_opac, g_z2)
-        mean, qvec, svec, alpha, col, cams, out6, T = ctx.saved_tensors
-        br, B, thresh, stats = ctx.br, ctx.B, ctx.thresh, ctx.stats
-        lib = _capi.load()
-        H, W, N, dev = br.H, br.W, br.N, mean.device
-        parts = [g.contiguous() if g is not None else None for g in (g_rgb, g_depth, g_opac, g_z2)]
-        z = lambda g, c: g if g is not None else torch.zeros(B, H, W, c, device=dev)  # noqa: E731
-        go6 = torch.cat([z(parts[0], 3), z(parts[1], 1), z(parts[2], 1), z(parts[3], 1)], dim=-1).contiguous()
-        gbuf = torch.zeros(2 * B * 6 * N, device=dev, dtype=torch.float32)  # one fill for both
-        g2d = gbuf[:B * 6 * N].view(B, 6 * N)      # per camera: mean2d | cov2d
-        gch = gbuf[B * 6 * N:].view(B, N, 6)       # per camera: rgb | depth | opacity | depth^2
-        gdp = torch.empty(B, N, device=dev, dtype=torch.float32)       # per camera: d L / d (view-space depth)
-        g3d = torch.zeros(11 * N, device=dev, dtype=torch.float32)     # shared: mean | qvec | svec | alpha
-        g_mean, g_qvec = g3d[:3 * N].view(N, 3), g3d[3 * N:7 * N].view(N, 4)
-        g_svec, g_alpha = g3d[7 * N:10 * N].view(N, 3), g3d[10 * N:]
-        cams_p, out_p, g2d_p = cams.data_ptr(), out6.data_ptr(), g2d.data_ptr()
-        go_p = go6.data_ptr()
-        cur = br._fork(B, (go6, g2d, gch, gdp, g3d))
-        with torch.cuda.device(dev):
-            for i in range(B):
-                buf, stream, ci = br.slots[i], br.streams[i % len(br.streams)], ctx.cis[i]
-                s = stream.cuda_stream
-                cam = cams_p + 272 * i
-                g_mean2d = g2d_p + 24 * N * i
-                g_cov2d = g_mean2d + 8 * N
-                lib.vol_render_rgbd_backward(N, buf.D_cap, _p(buf.mean2d), _p(buf.cov2d), _p(col), _p(buf.depth), _p(alpha),
-                                             _p(buf.start), _p(buf.end), _p(buf.ids), out_p + 24 * H * W * i, g_mean2d,
-                                             g_cov2d, _p(gch[i]), _p(g_alpha), go_p + 24 * H * W * i, cam + 224, 16,
-                                             buf.nth, buf.ntw, 1.0 / ci.fx, 1.0 / ci.fy, H, W, thresh, buf.tile_order(), s)
-                with torch.cuda.stream(stream):  # the depth head and the depth^2 head both feed the depth
-                    torch.addcmul(gch[i, :, 3], buf.depth.view(-1), gch[i, :, 5], value=2.0, out=gdp[i])
-                lib.project_gaussians_backward_accum(N, _p(mean), _p(qvec), _p(svec), cam, int(ctx.detach),
-                                                     _p(buf.mask), g_mean2d, g_cov2d, _p(gdp[i]), _p(g_mean),
-                                                     _p(g_qvec), _p(g_svec), s)
-                if stats is not None:
-                    lib.densify_update(N, None, g_mean2d, _p(buf.mask), None, _p(stats.grad_accum),
-                                       _p(stats.cnt), s)
-        br._join(B, cur)
-        g_col = gch[:, :, :3].sum(0)
-        return (g_mean, g_qvec, g_svec, g_alpha, g_col, None, None, None, _bg_grad(ctx, g_rgb, T), None, None, None)
-
 
 class BatchRenderer:
     """Renders [B] cameras of one (W, H) shape for a fixed Gaussian count N."""
 
-    def __init__(self, N, W, H, device, max_batch, n_streams=3, D_cap=None, fused_launch=True, segments=1):
-        """fused_launch: an SH batch is ONE enqueue per stage on the current stream -- geometry, compositing
-        forward, compositing backward and projection backward each launch once for all cameras
-        (gsgen_frame_geometry_batch, gsgen_vol_render_sh_batch, ..._backward_sh_batch,
-        gsgen_project_gaussians_backward_batch) -- instead of one chain per camera spread over
-        `n_streams` side streams; post-activation colours (C = 0: gsgen_vol_render_rgb_batch) and render_heads
-        (gsgen_vol_render_rgbd_batch / _backward_batch) likewise.
-        cfg2: 2850 vs 2710 renders/s (profiles/r01_notes.md).  segments: backward workgroups per tile
-        (FrameBuffers), fused launches only."""
+    def __init__(self, N, W, H, device, max_batch, D_cap=None, segments=1, strict=False, pipeline="auto"):
+        """D_cap: capacity of every slot's (tile, Gaussian) pair list.  None (default): the FIRST batch is rendered
+        synchronously (one host sync) and sizes all slots at 1.5 x the largest count it saw; later batches report their
+        counts through the geometry launch itself (no sync, renderer.PairCountReport) and the lists are regrown before the
+        scene outgrows them.  A camera that still overflows is rendered as NaN, never as a finite blank image, and the next
+        render()/check_overflow() raises PairListOverflow with the lists already regrown.
+        strict=True: every batch is rendered synchronously (count read back, regrown and binned again if it did not fit):
+        lossless, one host sync per batch -- what the reference pays per CAMERA (gs/culling.py:34).
+        pipeline: "auto" (default) -- batches of 4 and more cameras run as two half-batches on two streams (the caller's and the
+        renderer's own, forked and joined inside the call): the right shape for ONE step in flight (a training loop);
+        False -- one launch per stage for the whole batch: the right shape when the caller keeps several independent
+        batches in flight on streams of its own (bench.py's headline loop).
+        segments: backward workgroups per tile (FrameBuffers)."""
         self.N, self.W, self.H, self.device = N, W, H, torch.device(device)
-        self.fused_launch, self.segments = bool(fused_launch), int(segments) if fused_launch else 1
-        # the slots' pair counters live in one tensor: one copy brings a batch's counts to the host (overflow detection
-        # without a sync, see FrameBuffers.check_overflow)
+        self.segments = int(segments)
+        self.strict = bool(strict)
+        if pipeline not in ("auto", True, False):
+            raise ValueError("pipeline: 'auto', True or False")
+        self.pipeline = pipeline
+        # the slots' pair counters live in one tensor (one copy brings a batch's counts to the host where a sync is wanted)
         self._totals = torch.zeros(max_batch, device=device, dtype=torch.int32)
-        self._monitor = R.PairCountMonitor(max_batch)
-        # pair counts follow every `monitor_every`-th batch to the host (an async copy + an event each: ~25 us of host time;
-        # an overflowing scene overflows in the following batches too, so sampling delays the report by a few batches)
-        self.monitor_every, self._tick = 4, 0
+        self._report = R.PairCountReport(max_batch)
         self._generation = 0
         self._sh_bound = self._sh_rows = None
         self._table_cache = {}
         # the slots' depth buffers are the rows of one matrix (the heads' backward reads depths[:B] as one tensor)
         self._depths = torch.empty(max_batch, N, device=device, dtype=torch.float32)
         self.slots = [R.FrameBuffers(N, W, H, device, D_cap=D_cap, segments=self.segments, total=self._totals[i:i + 1],
-                                     depth=self._depths[i].view(N, 1))
+                                     depth=self._depths[i].view(N, 1), report=(self._report, i))
                       for i in range(max_batch)]
         self._ptr_tabs = {}
-        self.streams = [torch.cuda.Stream(device=device) for _ in range(max(1, n_streams))]
+        self._side = None      # the second stream of a pipelined batch, made on first use
+        self._ev = None
         # Buffers a step needs and nobody else sees live as long as the renderer (round 4: nothing is allocated or filled per
         # step except what is handed to the caller): the camera rows of the batch in flight, the kernel-parameter tables of its
-        # launches, and the per-view gradient accumulators mean2d (2) | cov2d (4) | channels (6) x Np -- zeroed by the
-        # projection launch of the step's forward (gsgen_frame_geometry_batch_zero).  Only one batch per renderer is between
-        # forward and backward (_check_generation), so one set is enough.
+        # launches, and the per-view gradient accumulators mean2d (2) | cov2d (4) x Np (+ the six channels of render_heads, made
+        # on its first call: 24 B x N per slot) -- zeroed by the projection launch of the step's forward
+        # (gsgen_frame_geometry_batch_zero).  Only one batch per renderer is between forward and backward
+        # (_check_generation), so one set is enough.  Memory per slot beyond the lists: (22 + 24 [+ 24]) B x N.
         lib = _capi.load()
         self._Np = (N + 3) // 4 * 4
         self._cams = torch.empty(max_batch, 68, device=device, dtype=torch.float32)
         nth_, ntw_ = R.n_tiles(H, W)
         self._nb_sh = lib.sh_batch_workspace_bytes_routed(max_batch, nth_ * ntw_)  # parameter tables + per-tile routing flags
-        self._bws = torch.empty(self._nb_sh + lib.frame_batch_workspace_bytes(max_batch), device=device, dtype=torch.uint8)
-        self._g2d = torch.empty(max_batch, 12 * self._Np, device=device, dtype=torch.float32)
+        # one batch workspace per half (routing flags of its views) + the geometry launches' view tables
+        self._bws = [torch.empty(self._nb_sh, device=device, dtype=torch.uint8) for _ in range(2)]
+        self._gws = torch.empty(lib.frame_batch_workspace_bytes(max_batch), device=device, dtype=torch.uint8)
+        self._gv_bytes = lib.frame_batch_workspace_bytes(1)
+        self._g2d = torch.empty(max_batch, 6 * self._Np, device=device, dtype=torch.float32)
+        self._gch = None
         self._rows = torch.zeros(N, device=device, dtype=torch.float32)  # per-splat bounds of the batch in flight (gsgen_sh_l1_bound_rows)
         self._smax = torch.zeros(1, device=device, dtype=torch.float32)  # ... and their maximum (a scene within a view's bound skips the per-entry tests)
         # per camera: cam block (56) | topleft (2) | rotation rows (9) | pad -> 68 floats, packed on the host and sent
@@ -461,6 +326,17 @@ class BatchRenderer:
         self._poses = np.zeros((max_batch, 12), np.float32)
         self._intr = np.zeros((max_batch, 8), np.float64)
         self._cis = []
+        self._last_parts = [(0, 0)]
+        self._bound_tick = 0
+
+    # ---- buffers and tables ------------------------------------------------------------------------------------------
+    def _chan6(self):
+        """[max_batch, 6 Np]: the per-view accumulators of d L / d (r, g, b, depth, 1, depth^2) (render_heads only)"""
+        if self._gch is None:
+            self._gch = torch.empty(len(self.slots), 6 * self._Np, device=self.device, dtype=torch.float32)
+            self._ptr_tabs.clear()
+            self._table_cache.clear()
+        return self._gch
 
     def _upload(self, cam_infos, c2ws, frustum_radius, tile_radius):
         """The batch's camera blocks, packed by ONE library call (gsgen_pack_camera_blocks) and sent through kernel
@@ -489,7 +365,6 @@ class BatchRenderer:
         """void*[B] of the slots' visibility masks (they never move): built once per batch size"""
         t = self._ptr_tabs.get(B)
         if t is None:
-            import ctypes
             t = self._ptr_tabs[B] = (ctypes.c_void_p * B)(*[_p(self.slots[i].mask) for i in range(B)])
         return t
 
@@ -499,8 +374,7 @@ class BatchRenderer:
         key = (kind, B)
         t = self._ptr_tabs.get(key)
         if t is None:
-            import ctypes
-            g0, st = self._g2d.data_ptr(), 4 * 12 * self._Np
+            g0, st = self._g2d.data_ptr(), 4 * 6 * self._Np
             if kind == "cam":
                 a = [self._cams.data_ptr() + 272 * i for i in range(B)]
             elif kind == "cov2d":
@@ -512,7 +386,8 @@ class BatchRenderer:
             elif kind == "g_cov2d":
                 a = [g0 + st * i + 4 * 2 * self._Np for i in range(B)]
             elif kind == "g_chan6":
-                a = [g0 + st * i + 4 * 6 * self._Np for i in range(B)]
+                c0 = self._chan6().data_ptr()
+                a = [c0 + st * i for i in range(B)]
             else:
                 raise KeyError(kind)
             t = self._ptr_tabs[key] = (ctypes.c_void_p * B)(*a)
@@ -520,17 +395,18 @@ class BatchRenderer:
 
     def _tables(self, kind):
         """(GeometryView[max_batch], ShView | RgbdView[max_batch]) with every per-slot buffer address filled in; rebuilt
-        when a slot's pair list is regrown.  One set per kind ("sh", "rgb", "rgbd"): a batch's backward reads the
+        when the pair lists are regrown.  One set per kind ("sh", "rgb", "rgbd"): a batch's backward reads the
         view table its forward filled, and only one batch per BatchRenderer is between forward and backward
         (_check_generation)."""
-        caps = tuple(s.D_cap for s in self.slots)
+        cap = self.slots[0].D_cap
         hit = self._table_cache.get(kind)
-        if hit is not None and hit[0] == caps:
+        if hit is not None and hit[0] == cap:
             return hit[1], hit[2]
         n = len(self.slots)
         geo = (_capi.GeometryView * n)()
         views = ((_capi.ShView if kind == "sh" else _capi.RgbdView) * n)()
-        cams_p, g0, st = self._cams.data_ptr(), self._g2d.data_ptr(), 4 * 12 * self._Np
+        cams_p, g0, st = self._cams.data_ptr(), self._g2d.data_ptr(), 4 * 6 * self._Np
+        c0 = self._chan6().data_ptr() if kind == "rgbd" else None
         for i, buf in enumerate(self.slots):
             g, v = geo[i], views[i]
             cam = cams_p + 272 * i  # row i: cam block | topleft at +56 floats | rotation at +58
@@ -538,6 +414,7 @@ class BatchRenderer:
             g.mean2d, g.cov2d, g.depth, g.mask = _p(buf.mean2d), _p(buf.cov2d), _p(buf.depth), _p(buf.mask)
             g.gaussian_ids, g.start, g.end, g.total = _p(buf.ids), _p(buf.start), _p(buf.end), _p(buf.total)
             g.workspace, g.workspace_bytes, g.D_cap = _p(buf.ws), buf.ws.numel(), buf.D_cap
+            g.pair_report = self._report.ptr(i)
             # this view's gradient accumulators: zero-filled by the projection launch, read by the projection backward
             g.zero_grad_mean2d = v.grad_mean = g0 + st * i
             g.zero_grad_cov2d = v.grad_cov = g0 + st * i + 4 * 2 * self._Np
@@ -550,24 +427,74 @@ class BatchRenderer:
             else:
                 v.depth = _p(buf.depth)
                 if kind == "rgbd":
-                    g.zero_grad_chan6 = v.grad_chan6 = g0 + st * i + 4 * 6 * self._Np
-        self._table_cache[kind] = (caps, geo, views)
+                    g.zero_grad_chan6 = v.grad_chan6 = c0 + st * i
+        self._table_cache[kind] = (cap, geo, views)
         return geo, views
+
+    # ---- half-batches --------------------------------------------------------------------------------------------------
+    def _fork(self, B, split=None):
+        """-> [(first view, views, raw stream)]: the batch as one part on the current stream, or as two halves -- the second
+        on the renderer's side stream, which waits for everything enqueued on the current stream so far.  `split`: the
+        forward's partition, for its backward."""
+        cur = torch.cuda.current_stream(self.device)
+        if split is None:
+            two = B >= 2 and (self.pipeline is True or (self.pipeline == "auto" and B >= 4))
+            h = (B + 1) // 2
+            split = [(0, h), (h, B - h)] if two else [(0, B)]
+        self._last_parts = split
+        if len(split) == 1:
+            return [(0, split[0][1], cur.cuda_stream)]
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+            self._ev = [torch.cuda.Event(), torch.cuda.Event()]
+        self._ev[0].record(cur)
+        self._side.wait_event(self._ev[0])
+        return [(split[0][0], split[0][1], cur.cuda_stream), (split[1][0], split[1][1], self._side.cuda_stream)]
+
+    def _join(self, parts):
+        """the current stream waits for the side stream's half (what the call allocated on the current stream and used on
+        the side stream is therefore free to be reused in current-stream order: no record_stream needed)"""
+        if len(parts) > 1:
+            self._ev[1].record(self._side)
+            torch.cuda.current_stream(self.device).wait_event(self._ev[1])
+
+    def _geometry(self, kind, B, parts, mean, qvec, svec, gsh):
+        """the geometry chain of every part (the first one zero-fills the shared gradient block) -> the view table.  While
+        the lists are unsized (or strict) the counts are read back -- one host sync -- and, if a camera's pairs did not
+        fit, all lists are regrown and the batch binned again: lossless."""
+        lib = _capi.load()
+        N = self.N
+        sync = self.slots[0].needs_sync_sizing() if B else False
+        while True:
+            geo, views = self._tables(kind)
+            for k, (lo, n, s) in enumerate(parts):
+                lib.frame_geometry_batch_zero(n, _sub(geo, lo, n), N, _p(mean), _p(qvec), _p(svec), self.W, self.H,
+                                              _p(gsh) if k == 0 else None, gsh.numel() if k == 0 else 0,
+                                              _p(self._gws) + lo * self._gv_bytes, s)
+            if not sync:
+                return views
+            if len(parts) > 1:
+                self._side.synchronize()
+            need = max(R.pair_count(c) for c in self._totals[:B].tolist())  # (the sync)
+            self._report.clear()
+            if need <= self.slots[0].D_cap:
+                for s_ in self.slots:
+                    s_.sized = True
+                return views
+            self._regrow(need)
+
+    def _regrow(self, need):
+        for s_ in self.slots:
+            s_._alloc_pairs(R._cap_for(need))
+            s_.sized = True
+        self._generation += 1  # a pending backward would read freed lists
 
     # ---- one-forward-one-backward contract and overflow detection ------------------------------------------------
     def _begin_batch(self, B):
         """Every forward starts here.  The batch's backward reads the lists its forward left in the slots, so a
-        later render (or a regrown slot) invalidates it: the generation it returns is checked in backward."""
+        later render (or a regrown slot) invalidates it: the generation the forward stores is checked in backward."""
         self.check_overflow()
         self._generation += 1
-        return self._generation
-
-    def _end_batch(self, B):
-        """behind the geometry enqueue: the batch's pair counts follow it to the host (one async copy, one event, into
-        the monitor's ring: no batch's counts are ever dropped unread)"""
-        self._tick += 1
-        if self._tick % self.monitor_every == 1 or self.monitor_every <= 1:
-            self._monitor.record(self._totals, B, torch.cuda.current_stream(self.device))
 
     def _check_generation(self, gen):
         if gen != self._generation:
@@ -577,45 +504,51 @@ class BatchRenderer:
                                "(e.g. for gradient accumulation or an evaluation render in between).")
 
     def check_overflow(self):
-        """No sync (unless the host is more than PairCountMonitor.depth batches ahead): if pair counts of earlier batches
-        have reached the host and one exceeded its slot's capacity, grow that slot and warn (that camera was rendered as
-        background only, with zero gradients)."""
-        ok = True
-        worst = {}
-        if not self._monitor.has_news():
-            return ok
-        for counts in self._monitor.drain():
-            for i, need in enumerate(counts):
-                worst[i] = max(worst.get(i, 0), need)
-        for i, need in worst.items():
-            s = self.slots[i]
-            if need > s.D_cap:
-                import warnings
-                old = s.D_cap
-                s._alloc_pairs(int(need * 1.25) + 1024)
-                self._generation += 1
-                warnings.warn(f"gsgen_amd: camera {i} of an earlier batch needed {need} (tile, Gaussian) pairs, "
-                              f"capacity was {old}: it was rendered as BACKGROUND ONLY with zero gradients.  The slot has "
-                              f"been regrown to {s.D_cap}; call BatchRenderer.ensure_capacity() after a render to catch "
-                              f"this synchronously.", RuntimeWarning, stacklevel=3)
-                ok = False
-        return ok
+        """No sync.  Reads what the geometry launches of earlier batches reported (every batch, every view -- nothing is
+        sampled): a camera whose pairs did not fit -> all lists regrown, PairListOverflow raised (that camera's image was
+        NaN, it contributed no gradients: repeat the step); the largest count within 25 % of the capacity -> regrown quietly,
+        before anything overflows.  Called by every render; call it yourself after replaying a captured step."""
+        rep = self._report
+        if rep.any_overflow():
+            bad = {i: rep.overflow(i) for i in range(rep.n) if rep.overflow(i)}
+            rep.clear()
+            old = self.slots[0].D_cap
+            need = max(bad.values())
+            if need > old:
+                self._regrow(need)
+            raise PairListOverflow(
+                f"gsgen_amd: camera(s) {sorted(bad)} of an earlier batch needed up to {need} (tile, Gaussian) pairs, capacity was "
+                f"{old}: their images and T are NaN and they contributed no gradients.  The lists have been regrown to "
+                f"{self.slots[0].D_cap}: repeat that step (or use strict=True / ensure_capacity() to rule this out).")
+        if self.slots[0].sized:
+            last = max(rep.last(i) for i in range(rep.n))
+            cap = self.slots[0].D_cap
+            if last <= cap and last * 1.25 > cap:
+                self._regrow(last)
+        return True
 
-    def _fork(self, B, tensors):
-        """side streams wait for the current stream; `tensors` (allocated on the current stream)
-        are about to be used on them"""
-        cur = torch.cuda.current_stream(self.device)
-        ready = torch.cuda.Event()
-        ready.record(cur)
-        for st in self.streams[:min(B, len(self.streams))]:
-            st.wait_event(ready)
-            for t in tensors:
-                t.record_stream(st)
-        return cur
+    def ensure_capacity(self, B=None):
+        """One host sync: did every camera of the last batch fit?  Regrows the lists if not (False: those cameras' images
+        are NaN -- render again)."""
+        counts = [R.pair_count(c) for c in self._totals[:B].tolist()]
+        self._report.clear()
+        for s_ in self.slots:
+            s_.sized = True
+        need = max(counts, default=0)
+        if need > self.slots[0].D_cap:
+            self._regrow(need)
+            return False
+        return True
 
-    def _join(self, B, cur):
-        for st in self.streams[:min(B, len(self.streams))]:
-            cur.wait_stream(st)
+    # ---- the public calls ----------------------------------------------------------------------------------------------
+    def _check_batch(self, cam_infos):
+        B = len(cam_infos)
+        if B > len(self.slots):
+            raise ValueError(f"batch of {B} cameras, renderer was sized for {len(self.slots)}")
+        for ci in cam_infos:
+            if (ci.w, ci.h) != (self.W, self.H):
+                raise ValueError("every camera of a batch must have the renderer's (W, H)")
+        return B
 
     def render(self, mean, qvec, svec, alpha, col, cam_infos, c2ws, C=0, bg_rgb=None, thresh=1e-4,
                frustum_radius=6.0, tile_radius=6.0, detach_depth=True, stats=None, sh_basis="auto", sh_l1_bound=None,
@@ -624,22 +557,20 @@ class BatchRenderer:
 
         cam_infos: B CameraInfo of this renderer's (W, H); c2ws: B poses [3,4] (arrays or tensors).
         col is sh_coeffs [N,3,C*C] for C in 1..4, post-activation rgb [N,3] for C == 0.
-        sh_basis (C == 4): "auto" (default) -- the coefficient bound S = max_i max_c sum_{k>=1} |sh[i][c][k]| is measured on the
-        device in front of the launch (one 5-us pass on the render's stream, no host sync) and the kernels route on it per view:
-        the tile-local polynomial form of the per-pixel SH basis where 0.25 S 0.7 delta^3 <= 1e-5, the exact kernel elsewhere
-        (include/gsgen_hip.h "the coefficient bound"; images within 1e-5 of the exact kernels, +20 % renders/s at 8 x 800^2).
-        "exact": the exact kernels only.  sh_l1_bound: a 1-float DEVICE tensor that already holds S for THESE coefficients
-        (e.g. renderer.sh_l1_bound_device(sh) evaluated once for several batches of one optimiser step) -- skips the pass; verify_bound=True
-        checks such a tensor on the device first (debug: one host sync, raises if any row exceeds it).
+        sh_basis (C == 4): "auto" (default) -- the per-splat coefficient bounds S_i = max_c sum_{k>=1} |sh[i][c][k]| are measured
+        on the device in front of the launch (one 10-us pass on the render's stream, no host sync) and the kernels route on them
+        per list entry and per tile: the tile-local polynomial form of the per-pixel SH basis where 0.25 S_i 0.7 delta^3 <= 1e-5
+        (colours within 1.4e-5 of the exact kernels'), the exact evaluation elsewhere (include/gsgen_hip.h "the coefficient
+        bound").  "exact": the exact kernels only.  sh_l1_bound: a 1-float DEVICE tensor that already holds max_i S_i for THESE
+        coefficients (e.g. renderer.sh_l1_bound_device(sh) evaluated once for several batches of one optimiser step) -- skips
+        the pass; verify_bound=True checks such a tensor on the device first (debug: one host sync, raises if any row exceeds it).
         """
         if sh_basis not in ("auto", "exact"):
             raise ValueError("sh_basis: 'auto' or 'exact'")
-        B = len(cam_infos)
-        if B > len(self.slots):
-            raise ValueError(f"batch of {B} cameras, renderer was sized for {len(self.slots)}")
-        for ci in cam_infos:
-            if (ci.w, ci.h) != (self.W, self.H):
-                raise ValueError("every camera of a batch must have the renderer's (W, H)")
+        B = self._check_batch(cam_infos)
+        if B == 0:
+            z = torch.zeros(0, self.H, self.W, 3, device=self.device)
+            return z, z[..., :1]
         cams = self._upload(cam_infos, c2ws, frustum_radius, tile_radius)
         self._cis = list(cam_infos)
         self._sh_bound = self._sh_rows = None
@@ -663,42 +594,38 @@ class BatchRenderer:
         if col.dim() != 3 or col.shape[1] != 3 or col.shape[2] != 16 or col.dtype != torch.float32 or not col.is_contiguous() \
                 or col.shape[0] != self.N:
             return R.sh_row_bounds_device(col)  # (other layouts: the checked path)
+        # the maximum is a RUNNING one (no 4-byte fill kernel in front of every step's pass: it was a launch of its own in the
+        # step's chain): always an upper bound of the current coefficients' -- what the per-view shortcut needs -- and made
+        # tight again every 64th batch
+        self._bound_tick += 1
         with _on(self.device):
-            _capi.load().sh_l1_bound_rows(self.N, col.data_ptr(), 4, self._smax.data_ptr(), self._rows.data_ptr(),
-                                          torch.cuda.current_stream(self.device).cuda_stream)
+            if self._bound_tick % 64 == 1 and not torch.cuda.is_current_stream_capturing():
+                self._smax.zero_()
+            _capi.load().sh_l1_bound_rows_running(self.N, col.data_ptr(), 4, self._smax.data_ptr(), self._rows.data_ptr(),
+                                                  torch.cuda.current_stream(self.device).cuda_stream)
         return self._rows
 
     def render_heads(self, mean, qvec, svec, alpha, color, cam_infos, c2ws, bg_rgb=None, thresh=1e-4,
                      frustum_radius=6.0, tile_radius=6.0, detach_depth=True, stats=None):
         """-> (rgb [B,H,W,3], depth, opacity, depth2, T [B,H,W,1]) from post-activation colours [N,3]: what
         GaussianSplattingRenderer.forward returns with rgb_only = False, one compositing pass per camera."""
-        B = len(cam_infos)
-        if B > len(self.slots):
-            raise ValueError(f"batch of {B} cameras, renderer was sized for {len(self.slots)}")
-        for ci in cam_infos:
-            if (ci.w, ci.h) != (self.W, self.H):
-                raise ValueError("every camera of a batch must have the renderer's (W, H)")
+        B = self._check_batch(cam_infos)
+        if B == 0:
+            z = torch.zeros(0, self.H, self.W, 3, device=self.device)
+            return z, z[..., :1], z[..., :1], z[..., :1], z[..., :1]
         cams = self._upload(cam_infos, c2ws, frustum_radius, tile_radius)
         self._cis = list(cam_infos)
         return _render_batch_heads.apply(mean, qvec, svec, alpha, color, cams, self, B, bg_rgb, float(thresh),
                                          bool(detach_depth), stats)
 
     def routing_flags(self, B):
-        """uint8 [B, n_tiles] (a view of the batch workspace): what the last SH degree-3 batch's polynomial forward decided per
-        tile -- 1 = a splat the tile staged exceeds the bound for the view's pixel size, the exact kernel rendered it; 0 = the
+        """uint8 [B, n_tiles]: what the last SH degree-3 batch's polynomial forward decided per tile -- 1 = a quarter of a staged
+        batch of the tile's list exceeds the bound for the view's pixel size, the exact kernel rendered it; 0 = the
         polynomial form (empty tiles: 0).  Reports and tests only; reading it synchronises like any tensor read."""
         lib = _capi.load()
         T = self.slots[0].nth * self.slots[0].ntw
-        o = lib.sh_batch_workspace_bytes(B)  # (behind the two parameter tables of a B-view batch)
-        return self._bws[o:o + B * T].view(B, T)
-
-    def ensure_capacity(self, B=None):
-        """One host sync: grows any slot whose pair list overflowed in the last batch.  Returns
-        False if a slot had to grow (that camera's image was rendered empty: render again)."""
-        self._monitor.clear()
-        ok = True
-        for s in self.slots[:B]:
-            ok = s.ensure_capacity() and ok
-        if not ok:
-            self._generation += 1  # a pending backward would read freed lists
-        return ok
+        rows = []
+        for k, (lo, n) in enumerate(self._last_parts):
+            o = lib.sh_batch_workspace_bytes(n)  # (behind the two parameter tables of an n-view batch)
+            rows.append(self._bws[k][o:o + n * T].view(n, T))
+        return torch.cat(rows)[:B] if len(rows) > 1 else rows[0][:B]

@@ -200,9 +200,23 @@ __device__ __forceinline__ uint32_t sat_add_u32(uint32_t a, uint32_t b) {
 // free wave slots on ONE compute unit and waited 0.3 ms for them whenever another batch's compositing launch filled the chip
 // (profiles/r03_notes.md: 7.9 us alone, 299 us average with three steps in flight).
 constexpr uint32_t kScanThreads = 256;
+// report (optional): two words the HOST can read while the stream runs (pinned, device-mapped host memory): [0] takes every
+// frame's pair count (so the host can grow a buffer BEFORE it overflows), [1] the largest count of a frame that did not fit
+// (never overwritten by a later frame that does: the host clears it when it has dealt with it).  One 4-byte store over the
+// fabric per view and frame; nothing is copied, no event, nothing the host waits for, and a hipGraph replay reports the same way.
+__device__ __forceinline__ void report_pair_count(uint32_t *report, uint32_t total, bool overflow) {
+  if (report == nullptr) return;
+#if defined(__HIP_DEVICE_COMPILE__)
+  __hip_atomic_store(report, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (overflow) __hip_atomic_fetch_max(report + 1, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#else
+  report[0] = total;
+  if (overflow && report[1] < total) report[1] = total;
+#endif
+}
 __device__ __forceinline__ void
 scan_tiles_body(uint32_t T, const uint32_t *__restrict__ tile_count, uint32_t *__restrict__ tile_off,
-             uint32_t *__restrict__ ctrl, uint32_t cap, uint32_t *__restrict__ total_out) {
+             uint32_t *__restrict__ ctrl, uint32_t cap, uint32_t *__restrict__ total_out, uint32_t *report = nullptr) {
   __shared__ uint32_t s_part[kScanThreads];
   const uint32_t t = threadIdx.x;
   const uint32_t per = (T + kScanThreads - 1u) / kScanThreads;
@@ -229,6 +243,7 @@ scan_tiles_body(uint32_t T, const uint32_t *__restrict__ tile_count, uint32_t *_
     ctrl[0] = total;
     ctrl[1] = (total > cap) ? 1u : 0u;
     if (total_out != nullptr) *total_out = total;
+    report_pair_count(report, total, total > cap);
   }
 }
 
@@ -488,8 +503,9 @@ sort_tiles_coop_body(uint32_t tile, const uint32_t *__restrict__ tile_off, const
                      unsigned long long *__restrict__ keys, int *__restrict__ ids, int *__restrict__ start,
                      int *__restrict__ end, u64 *s_keys) {
   const uint32_t tid = threadIdx.x;
-  if (ctrl[1] != 0u) {
-    if (tid == 0) { start[tile] = -1; end[tile] = -1; }
+  if (ctrl[1] != 0u) {  // the frame's pairs do not fit the caller's list: NOT "every tile empty" (that is a valid, finite, blank
+    // image) but kListOverflow -- the compositing forwards write NaN into such a tile, the backwards skip it
+    if (tid == 0) { start[tile] = kListOverflow; end[tile] = kListOverflow; }
     return;
   }
   const uint32_t b = tile_off[tile], e = tile_off[tile + 1];
@@ -561,14 +577,14 @@ k_scan_chunks_views(uint32_t T, uint32_t nchunks, const GeoView *__restrict__ vi
 __global__ void __launch_bounds__(kScanThreads)
 k_scan_order_tiles(uint32_t T, const uint32_t *__restrict__ tile_count, uint32_t *__restrict__ tile_off,
                    uint32_t *__restrict__ ctrl, uint32_t cap, uint32_t *__restrict__ total_out,
-                   uint32_t *__restrict__ tile_order) {
-  scan_tiles_body(T, tile_count, tile_off, ctrl, cap, total_out);
+                   uint32_t *__restrict__ tile_order, uint32_t *report) {
+  scan_tiles_body(T, tile_count, tile_off, ctrl, cap, total_out, report);
   order_tiles_body(T, tile_count, tile_order);
 }
 __global__ void __launch_bounds__(kScanThreads)
 k_scan_order_tiles_views(uint32_t T, const GeoView *__restrict__ views) {
   const GeoView v = views[blockIdx.y];
-  scan_tiles_body(T, v.tile_count, v.tile_off, v.ctrl, v.cap, v.total);
+  scan_tiles_body(T, v.tile_count, v.tile_off, v.ctrl, v.cap, v.total, v.report);
   order_tiles_body(T, v.tile_count, v.tile_order);
 }
 // ---- push binning of a camera batch (round 4) ------------------------------------------------------------------------------
@@ -720,7 +736,7 @@ static BinWs carve(void *base, uint32_t N, uint32_t D, uint32_t T, bool with_rec
 
 static int bin_and_sort(uint32_t N, uint32_t cap, uint32_t nth, uint32_t ntw, const int *tl,
                         const int *br, const float *depth, int *ids, int *start, int *end,
-                        const BinWs &w, uint32_t *total_out, hipStream_t s) {
+                        const BinWs &w, uint32_t *total_out, hipStream_t s, uint32_t *report = nullptr) {
   const uint32_t T = nth * ntw;
   if (cap > 0x7fffffffu) return GSGEN_EINVAL;  // start / end / the list positions are int32 (the reference's layout)
   const uint32_t ngroups = ((ntw + kGroup - 1) / kGroup) * ((nth + kGroup - 1) / kGroup);
@@ -742,7 +758,7 @@ static int bin_and_sort(uint32_t N, uint32_t cap, uint32_t nth, uint32_t ntw, co
   hipLaunchKernelGGL(k_scan_chunks, dim3((T + 3) / 4), dim3(256), 0, s, T, w.nchunks,
                      w.cnt, w.tile_count);
   hipLaunchKernelGGL(k_scan_order_tiles, dim3(1), dim3(kScanThreads), 0, s, T, w.tile_count, w.tile_off, w.ctrl, cap, total_out,
-                     w.tile_order);
+                     w.tile_order, report);
   if (N && push)
     hipLaunchKernelGGL((k_bin_push<true>), dim3(w.nchunks), dim3(kPushThreads), sizeof(uint32_t) * T, s, N, tl, br, depth, (int)ntw, (int)nth, T, w.cnt,
                        (const uint32_t *)w.tile_off, (const uint32_t *)w.ctrl, w.keys);
@@ -857,7 +873,7 @@ int gsgen_frame_geometry_batch_zero(uint32_t n_views, const gsgen_geometry_view 
     g.cam = v.cam; g.mean2d = v.mean2d; g.cov2d = v.cov2d; g.depth = v.depth; g.mask = v.mask;
     g.tl = w.tl; g.br = w.br; g.cnt = w.cnt; g.wcnt = w.wcnt; g.tile_count = w.tile_count; g.tile_off = w.tile_off;
     g.ctrl = w.ctrl; g.tile_order = w.tile_order; g.keys = w.keys;
-    g.ids = v.gaussian_ids; g.start = v.start; g.end = v.end; g.total = v.total; g.cap = v.D_cap;
+    g.ids = v.gaussian_ids; g.start = v.start; g.end = v.end; g.total = v.total; g.cap = v.D_cap; g.report = v.pair_report;
     g.z_mean2d = v.zero_grad_mean2d; g.z_cov2d = v.zero_grad_cov2d; g.z_chan6 = v.zero_grad_chan6;
     if ((reinterpret_cast<uintptr_t>(g.z_mean2d) & 7u) || (reinterpret_cast<uintptr_t>(g.z_cov2d) & 15u) ||
         (reinterpret_cast<uintptr_t>(g.z_chan6) & 7u))
@@ -892,6 +908,15 @@ int gsgen_frame_geometry_batch_zero(uint32_t n_views, const gsgen_geometry_view 
   return (int)hipGetLastError();
 }
 
+void *gsgen_host_device_pointer(void *pinned_host) {
+  void *dev = nullptr;
+  if (pinned_host == nullptr || hipHostGetDevicePointer(&dev, pinned_host, 0) != hipSuccess) {
+    (void)hipGetLastError();  // (not sticky: an unmapped block is an answer, not a fault)
+    return nullptr;
+  }
+  return dev;
+}
+
 const uint32_t *gsgen_frame_tile_order(void *workspace, uint32_t N, uint32_t D_cap, uint32_t n_tiles) {
   return carve(workspace, N, D_cap, n_tiles, true).tile_order;
 }
@@ -905,6 +930,15 @@ int gsgen_frame_geometry(uint32_t N, const float *mean, const float *qvec, const
                          float *cov2d, float *depth, uint8_t *mask, int *gaussian_ids, int *start,
                          int *end, uint32_t *total, void *workspace, size_t workspace_bytes,
                          gsgen_stream_t stream) {
+  return gsgen_frame_geometry_report(N, mean, qvec, svec, cam, W, H, D_cap, mean2d, cov2d, depth, mask, gaussian_ids, start, end,
+                                     total, nullptr, workspace, workspace_bytes, stream);
+}
+
+int gsgen_frame_geometry_report(uint32_t N, const float *mean, const float *qvec, const float *svec,
+                                const float *cam, uint32_t W, uint32_t H, uint32_t D_cap, float *mean2d,
+                                float *cov2d, float *depth, uint8_t *mask, int *gaussian_ids, int *start,
+                                int *end, uint32_t *total, uint32_t *pair_report, void *workspace, size_t workspace_bytes,
+                                gsgen_stream_t stream) {
   const uint32_t ntw = (W + kTile - 1) / kTile, nth = (H + kTile - 1) / kTile;
   const uint32_t T = ntw * nth;
   if (T == 0) return 0;
@@ -917,7 +951,7 @@ int gsgen_frame_geometry(uint32_t N, const float *mean, const float *qvec, const
   if (int e = gsgen_internal_frame_project(N, mean, qvec, svec, cam, (int)W, (int)H, (int)ntw, mean2d,
                                            cov2d, depth, mask, w.tl, w.br, stream))
     return e;
-  return bin_and_sort(N, D_cap, nth, ntw, w.tl, w.br, depth, gaussian_ids, start, end, w, total, s);
+  return bin_and_sort(N, D_cap, nth, ntw, w.tl, w.br, depth, gaussian_ids, start, end, w, total, s, pair_report);
 }
 
 }  // extern "C"

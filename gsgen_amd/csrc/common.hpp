@@ -19,6 +19,7 @@
 namespace gs {
 
 constexpr int kTile = 16;
+constexpr int kListOverflow = -2;  // start / end of every tile of a frame whose pairs did not fit the list (GSGEN_LIST_OVERFLOW)
 constexpr float kMinAlpha = 0.00392156862745098f;  // 1/255  (reference common.h:89)
 constexpr float kAlphaClamp = 0.99f;               // reference vol_render.h:212
 constexpr float kLog2e = 1.4426950408889634f;
@@ -441,6 +442,7 @@ struct GeoView {
   int *ids, *start, *end;
   uint32_t *total;
   uint32_t cap, pad_;
+  uint32_t *report;  // optional, HOST-visible (pinned) memory: [0] = the view's pair count, [1] = max over the overflowing frames
   // optional per-view gradient accumulators of the step's backward ([N,2], [N,2,2], [N,6]; any may be NULL): zero-filled by
   // the projection launch, which touches every Gaussian of the view anyway (gsgen_frame_geometry_batch_zero)
   float *z_mean2d, *z_cov2d, *z_chan6;

@@ -115,6 +115,15 @@ __device__ __forceinline__ GRec load_rec(const Stage<MODE, CB, KB, WC> &S, int g
 // ============================================================================================
 // forward
 // ============================================================================================
+// A tile of a frame whose (tile, Gaussian) pairs did not fit the caller's list (start == kListOverflow, binning.hip): NaN in
+// every channel and in T.  A blank-but-finite view would train on silently; this one kills the loss.
+template <int NCH>
+__device__ __forceinline__ void poison_pixel(const CompParams &p, size_t pix) {
+  const float nan = __builtin_nanf("");
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) p.out[NCH * pix + c] = nan;
+  if (p.T != nullptr) p.T[pix] = nan;
+}
 // The parameter blocks of a batched launch travel in the kernel arguments themselves (<= kPackMax views per launch; larger
 // batches are launched in chunks): no table in device memory, no launch that writes one (until round 4 a one-workgroup
 // k_write_params launch in front of every batched forward and backward).
@@ -178,6 +187,12 @@ __global__ void __launch_bounds__(TS * TS / PPL) k_composite_fwd(CompParams p) {
     valid[j] = (gx < p.W) && (gy[j] < p.H);
   }
 
+  if (st == kListOverflow) {  // the frame's pairs did not fit the list (GSGEN_LIST_OVERFLOW): never a finite blank tile
+#pragma unroll
+    for (int j = 0; j < PPL; ++j)
+      if (valid[j]) poison_pixel<NCH>(p, (size_t)gy[j] * p.W + gx);
+    return;
+  }
   if (n == 0) {  // uniform over the workgroup
     if constexpr (MODE == MODE_SH) {
       if (p.bg != nullptr || p.fill_empty) {  // vol_render_bg.h:34-53: empty tiles show the background
@@ -506,6 +521,12 @@ __device__ __forceinline__ void composite_fwd_sh_vec_tile(const CompParams &p, u
   }
   if constexpr (POLY) {  // (per-tile routing: this tile is the polynomial kernel's until a staged batch says otherwise)
     if (t == 0 && p.tile_flags != nullptr) p.tile_flags[tile] = 0;
+  }
+  if (st == kListOverflow) {  // the frame's pairs did not fit the list (GSGEN_LIST_OVERFLOW): never a finite blank tile
+#pragma unroll
+    for (int j = 0; j < PPL; ++j)
+      if (valid[j]) poison_pixel<3>(p, (size_t)gy[j] * p.W + gx);
+    return;
   }
   if (n == 0) {  // uniform over the workgroup
     if (p.bg != nullptr || p.fill_empty) {  // vol_render_bg.h:34-53: empty tiles show the background
@@ -1632,6 +1653,14 @@ k_composite_fwd_chan_vec(CompParams p_arg, ViewPack<BATCH> pack) {
   const int t = (int)threadIdx.x;
   const int lx = t & 15, ly0 = t >> 4;
   const int gx = tx * kTile + lx;
+  if (st == kListOverflow) {  // the frame's pairs did not fit the list (GSGEN_LIST_OVERFLOW): never a finite blank tile
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) {
+      const int gyj = ty * kTile + ly0 + j * ROWS;
+      if (gx < p.W && gyj < p.H) poison_pixel<NCH>(p, (size_t)gyj * p.W + gx);
+    }
+    return;
+  }
   if (n == 0) {  // uniform over the workgroup
     // per-camera entry points: the caller's pre-initialised out / T stand (vol_render.h:1006-1013); batched launches that
     // ask for it write the empty tile themselves (CompParams::fill_empty)
@@ -2512,11 +2541,18 @@ int gsgen_sh_l1_bound(uint32_t N, const float *sh_coeffs, uint32_t C, float *out
   return sh_l1_pass<false>(N, sh_coeffs, C, out, nullptr, nullptr, (hipStream_t)stream);
 }
 
+static int sh_l1_rows_pass(uint32_t N, const float *sh_coeffs, uint32_t C, float *out_max, float *out_rows, bool running, hipStream_t s);
 int gsgen_sh_l1_bound_rows(uint32_t N, const float *sh_coeffs, uint32_t C, float *out_max, float *out_rows, gsgen_stream_t stream) {
+  return sh_l1_rows_pass(N, sh_coeffs, C, out_max, out_rows, false, (hipStream_t)stream);
+}
+int gsgen_sh_l1_bound_rows_running(uint32_t N, const float *sh_coeffs, uint32_t C, float *running_max, float *out_rows,
+                                   gsgen_stream_t stream) {
+  return sh_l1_rows_pass(N, sh_coeffs, C, running_max, out_rows, true, (hipStream_t)stream);
+}
+static int sh_l1_rows_pass(uint32_t N, const float *sh_coeffs, uint32_t C, float *out_max, float *out_rows, bool running, hipStream_t s) {
   if (C < 1 || C > 4) return GSGEN_EUNSUPPORTED;
   if (N && (!sh_coeffs || !out_rows)) return GSGEN_EINVAL;
-  hipStream_t s = (hipStream_t)stream;
-  if (out_max != nullptr)
+  if (out_max != nullptr && !running)
     if (hipError_t e = hipMemsetAsync(out_max, 0, 4, s)) return (int)e;
   if (N == 0) return 0;
   if (C == 4 && (reinterpret_cast<uintptr_t>(sh_coeffs) & 15u) == 0) {

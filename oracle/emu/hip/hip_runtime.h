@@ -30,6 +30,7 @@ typedef void *hipStream_t;
 typedef int hipError_t;
 #define hipSuccess 0
 inline hipError_t hipGetLastError() { return 0; }
+inline hipError_t hipHostGetDevicePointer(void **dev, void *host, unsigned) { *dev = host; return 0; }  // (one address space)
 inline const char *hipGetErrorString(hipError_t) { return "emulated"; }
 inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { std::memset(p, v, n); return 0; }
 

@@ -46,7 +46,20 @@ def mock_scene():
     return s, cam
 
 
+def long_list_scene():
+    """tile lists that cross every LDS batch boundary of the reference's kernels -- 1 200 entries in the RGB
+    forward, 472 in its backward (vol_render.h:501, :442), 218 / 109 in the SH degree-3 forward / backward
+    (vol_render_sh.h:171-248, :353-455) -- on a 32 x 32 image (4 tiles) that nearly every splat of a dense cloud touches.  The
+    splats on the left of the view are almost transparent (pixels there walk their whole list: deep walks), those on the right
+    are ordinary (pixels saturate and stop early: early termination), so both exits of the entry loop are taken."""
+    sc = scenes.random_scene(3200, seed=21, svec=0.09, spread=0.5, C=4)
+    left = sc["mean"][:, 1] < 0.0
+    sc["alpha"] = np.where(left, sc["alpha"] * 0.02, sc["alpha"]).astype(np.float32)
+    return sc, scenes.Camera(32, 32, fx=26.0, c2w=scenes.look_at((2.6, 0.0, 0.3)))
+
+
 CASES = {
+    "long_lists": long_list_scene,
     "mock2": mock_scene,
     "rand_c1": lambda: (scenes.random_scene(400, seed=11, svec=0.05, C=1), scenes.Camera(96, 64, fx=90.0)),
     "rand_c3": lambda: (scenes.random_scene(500, seed=12, svec=0.06, C=3),
@@ -117,7 +130,8 @@ if __name__ == "__main__":
     if not refshim.available():
         raise SystemExit("needs /root/reference")
     ref_build.build()
-    for n in CASES:
+    for n in (sys.argv[1:] or CASES):
         o = generate(n)
-        print(n, "N_visible", int(o["mask"].sum()), "D", int(o["D"]), "rgb mean", float(o["rgb"].mean()),
+        print(n, "N_visible", int(o["mask"].sum()), "D", int(o["D"]), "longest list", int((o["end"] - o["start"]).max()),
+              "T range", float(o["T"].min()), float(o["T"].max()), "rgb mean", float(o["rgb"].mean()),
               os.path.getsize(os.path.join(HERE, n + ".npz")) // 1024, "KiB")

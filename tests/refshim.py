@@ -21,10 +21,22 @@ import types
 import torch
 
 REF = "/root/reference"
+STAGED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_refpy.zip")  # tests/stage_refpy.py: what travels to the GPU box (zipimport)
 
 
 def available():
     return os.path.isdir(os.path.join(REF, "gs"))
+
+
+def staged_available():
+    return os.path.isfile(STAGED)
+
+
+def root():
+    """where the reference's Python is imported from: /root/reference in the authoring container, the staged copy elsewhere"""
+    if os.environ.get("GSGEN_TEST_REFPY") == "staged":  # (checks that the archive alone serves the tests, in the container that has both)
+        return STAGED if staged_available() else None
+    return REF if available() else (STAGED if staged_available() else None)
 
 
 def _kornia_quat_to_rotmat(quaternion, order=None):
@@ -52,9 +64,10 @@ class _Sub:
         return a[0] if a and callable(a[0]) else self
 
 
-def install():
-    if not available():
-        raise RuntimeError("/root/reference is not present")
+def install(force_root=None):
+    base = force_root or root()
+    if base is None:
+        raise RuntimeError("/root/reference is not present (and tests/_refpy has not been staged)")
     if "_refshim_installed" in sys.modules:
         return
     def mod(name, **attrs):
@@ -85,8 +98,8 @@ def install():
         except Exception:
             mod(name)
     mod("_refshim_installed")
-    if REF not in sys.path:
-        sys.path.insert(0, REF)
+    if base not in sys.path:
+        sys.path.insert(0, base)
 
 
 def reference_api():

@@ -317,8 +317,17 @@ def test_emulated_fused_frame_geometry(emu):
             assert np.array_equal(st, g["start"]) and np.array_equal(en, g["end"])
             assert np.array_equal(ids[:g["D"]], full[g["ids"]])
             assert np.array_equal(m2[g["mask"]], g["mean2d"])
-        else:  # overflow: nothing binned, required size reported
-            assert (st == -1).all() and (en == -1).all()
+        else:  # overflow: nothing binned, required size reported, every tile marked GSGEN_LIST_OVERFLOW (never "empty")
+            assert (st == -2).all() and (en == -2).all()
+        # the launch's own report to the host (pair_report): [0] the count of every frame, [1] only of a frame that did not fit
+        rep = np.zeros(2, np.uint32)
+        emu.frame_geometry_report(N, P(sc["mean"]), P(sc["qvec"]), P(sc["svec"]), P(camv), cam.w, cam.h, cap, P(m2), P(c2),
+                                  P(dep), P(mask), P(ids), P(st), P(en), P(tot), P(rep), P(ws), ws.size, None)
+        assert rep[0] == g["D"] and rep[1] == (0 if cap >= g["D"] else g["D"])
+        rep[1] = 0xFFFFFFF0  # (a larger earlier overflow is kept: the host clears it)
+        emu.frame_geometry_report(N, P(sc["mean"]), P(sc["qvec"]), P(sc["svec"]), P(camv), cam.w, cam.h, cap, P(m2), P(c2),
+                                  P(dep), P(mask), P(ids), P(st), P(en), P(tot), P(rep), P(ws), ws.size, None)
+        assert rep[1] == 0xFFFFFFF0
     os.environ["GSGEN_BIN_PUSH_MIN_WORKGROUPS"] = "2"
 
 
@@ -406,7 +415,15 @@ def test_emulated_batched_frame_geometry_equals_per_view(emu):
         al = lambda n: (n + 255) // 256 * 256
         head = al(4 * (T + 4)) + al(4 * (T + 1)) + al(4 * T)
         assert np.array_equal(r["ws"][:head], g["ws"][:head]), i
-    assert (got[1]["st"] == -1).all() and (got[0]["st"] >= 0).any()
+    assert (got[1]["st"] == -2).all() and (got[0]["st"] >= 0).any()
+    # ... and with pair_report words: view 1 reports its overflow, the others only their counts
+    reps = np.zeros((3, 2), np.uint32)
+    for i, a in enumerate(arr):
+        a.pair_report = reps[i].ctypes.data
+    emu.frame_geometry_batch(3, arr, N, P(sc["mean"]), P(sc["qvec"]), P(sc["svec"]), W, H, P(bws), None)
+    assert reps[:, 0].tolist() == Ds and reps[:, 1].tolist() == [0, Ds[1], 0]
+    for a in arr:
+        a.pair_report = None
     arr[2].workspace_bytes = 16
     with pytest.raises(Exception, match="workspace"):
         emu.frame_geometry_batch(3, arr, N, P(sc["mean"]), P(sc["qvec"]), P(sc["svec"]), W, H, P(bws), None)
@@ -796,6 +813,103 @@ def test_emulated_batched_rgb_matches_per_view_launches(emu):
     with pytest.raises(Exception, match="invalid"):
         emu.vol_render_rgb_backward_batch(len(views), arr, Nall, P(col), P(al), None, P(ga), 16, nth, ntw, H, W, 1e-4,
                                           P(bws), None)
+
+
+def test_emulated_overflowed_lists_render_nan_never_a_finite_blank_image(emu):
+    """a frame whose (tile, Gaussian) pairs did not fit its list (start == end == GSGEN_LIST_OVERFLOW, written by
+    the fused geometry launch) must not come out as a finite blank image.  Every compositing FORWARD -- the per-camera kernels at
+    the three tile sides, the batched SH kernels (polynomial + exact fallback, and the exact ones), the batched RGB and
+    RGB + heads kernels -- writes NaN into every channel and into T of such a tile; every BACKWARD skips it (no gradient, no
+    fault).  One view of each batch overflowed, the other one regular: the regular one is untouched."""
+    from gsgen_amd._capi import ShView, RgbdView
+    C, W, H = 4, 40, 28
+    sc = scenes.random_scene(200, seed=5, svec=0.012, spread=0.035, C=C)
+    sc["sh"][:, :, 1:] *= 0.3
+    N = sc["mean"].shape[0]
+    cam = scenes.Camera(W, H, fx=520.0, c2w=scenes.orbit(2.5, 10, 40.0))
+    nth, ntw = cam.tiles
+    T = nth * ntw
+    g = scenes.oracle_geometry(sc, cam)
+    nz = np.nonzero(g["mask"])[0]
+    m2 = np.zeros((N, 2), np.float32); c2 = np.zeros((N, 2, 2), np.float32); dv = np.zeros(N, np.float32)
+    m2[nz] = g["mean2d"]; c2[nz] = g["cov2d"]; dv[nz] = g["depth"].ravel()
+    ids = nz[g["ids"]].astype(np.int32)
+    over = np.full(T, -2, np.int32)
+    tlp = cam.topleft  # (a property that builds a new array: keep it alive)
+    sh, al, col = np.ascontiguousarray(sc["sh"]), np.ascontiguousarray(sc["alpha"]), np.ascontiguousarray(sc["color"])
+    rot = np.ascontiguousarray(cam.c2w[:3, :3].reshape(-1))
+    bg = np.array([0.3, 0.1, 0.2], np.float32)
+    geo = lambda ts: (ts, (H + ts - 1) // ts, (W + ts - 1) // ts, 1 / cam.fx, 1 / cam.fy, H, W, 1e-4)  # noqa: E731
+    # per-camera entry points (k_composite_fwd at tile sides 8 / 16 / 32; the `_gs` names reach these)
+    for ts in (16, 8, 32):
+        Tts = geo(ts)[1] * geo(ts)[2]
+        ov = np.full(Tts, -2, np.int32)
+        out = np.zeros((H, W, 3), np.float32); Tm = np.ones((H, W), np.float32)
+        emu.vol_render_start_end_with_T(N, g["D"], P(m2), P(c2), P(col), P(al), P(ov), P(ov), P(ids), P(out), P(tlp),
+                                        *geo(ts), P(Tm), None)
+        assert np.isnan(out).all() and np.isnan(Tm).all(), ts
+        out = np.zeros((H, W, 3), np.float32); Tm = np.ones((H, W), np.float32)
+        emu.vol_render_sh(N, g["D"], P(m2), P(c2), P(sh), P(al), P(ov), P(ov), P(ids), P(out), P(tlp), P(rot), *geo(ts)[:7],
+                          C, 1e-4, P(bg), P(Tm), None)
+        assert np.isnan(out).all() and np.isnan(Tm).all(), ts
+        gm = np.zeros((N, 2), np.float32); gc = np.zeros((N, 4), np.float32); gs = np.zeros_like(sh); ga = np.zeros(N, np.float32)
+        go = np.ones((H, W, 3), np.float32)
+        emu.vol_render_backward_sh(N, g["D"], P(m2), P(c2), P(sh), P(al), P(ov), P(ov), P(ids), P(out), P(gm), P(gc), P(gs), P(ga),
+                                   P(go), P(tlp), P(rot), *geo(ts)[:7], C, 1e-4, P(bg), None)
+        assert not gm.any() and not gs.any() and not ga.any()
+    # batched SH: view 0 overflowed, view 1 regular; routed (polynomial + fallback) and exact
+    rows = np.zeros(N, np.float32); smax = np.zeros(1, np.float32)
+    emu.sh_l1_bound_rows(N, P(sh), C, P(smax), P(rows), None)
+    for bound in (True, False):
+        arr = (ShView * 2)()
+        res = []
+        for i, a in enumerate(arr):
+            r = dict(out=np.full((H, W, 3), 7.0, np.float32), T=np.full((H, W), 7.0, np.float32), gm=np.zeros((N, 2), np.float32),
+                     gc=np.zeros((N, 4), np.float32))
+            st, en = (over, over) if i == 0 else (g["start"], g["end"])
+            a.mean, a.cov, a.start, a.end, a.gaussian_ids = P(m2), P(c2), P(st), P(en), P(ids)
+            a.tile_order, a.topleft, a.c2w, a.bg_rgb = None, P(tlp), P(rot), P(bg)
+            a.pixel_size_x, a.pixel_size_y, a.out, a.T = 1 / cam.fx, 1 / cam.fy, P(r["out"]), P(r["T"])
+            a.grad_out, a.grad_mean, a.grad_cov = P(np.ones((H, W, 3), np.float32)), P(r["gm"]), P(r["gc"])
+            res.append(r)
+        go_keep = np.ones((H, W, 3), np.float32)
+        for a in arr:
+            a.grad_out = P(go_keep)
+        bws = np.zeros(emu.sh_batch_workspace_bytes_routed(2, T), np.uint8)
+        emu.vol_render_sh_batch_routed(2, arr, N, P(sh), P(al), 16, nth, ntw, H, W, C, 1e-4, 0, P(smax) if bound else None,
+                                       P(rows) if bound else None, P(bws), None)
+        assert np.isnan(res[0]["out"]).all() and np.isnan(res[0]["T"]).all(), bound
+        assert np.isfinite(res[1]["out"]).all() and np.isfinite(res[1]["T"]).all() and np.abs(res[1]["out"] - 7.0).min() > 0
+        gs = np.zeros_like(sh); ga = np.zeros(N, np.float32)
+        emu.vol_render_backward_sh_batch_routed(2, arr, N, P(sh), P(al), P(gs), P(ga), 16, nth, ntw, H, W, C, 1e-4, 0,
+                                                P(smax) if bound else None, P(rows) if bound else None, P(bws), None)
+        assert not res[0]["gm"].any() and res[1]["gm"].any() and np.isfinite(gs).all()
+    # batched RGB + heads and batched RGB
+    for heads in (True, False):
+        nch = 6 if heads else 3
+        arr = (RgbdView * 2)()
+        res = []
+        go6 = np.ones((H, W, nch), np.float32)
+        for i, a in enumerate(arr):
+            r = dict(out=np.full((H, W, nch), 7.0, np.float32), T=np.full((H, W), 7.0, np.float32), gm=np.zeros((N, 2), np.float32),
+                     gc=np.zeros((N, 4), np.float32), gch=np.zeros((N, 6), np.float32))
+            st, en = (over, over) if i == 0 else (g["start"], g["end"])
+            a.mean, a.cov, a.depth, a.start, a.end, a.gaussian_ids = P(m2), P(c2), P(dv), P(st), P(en), P(ids)
+            a.tile_order, a.topleft, a.pixel_size_x, a.pixel_size_y = None, P(tlp), 1 / cam.fx, 1 / cam.fy
+            a.out6, a.T, a.grad_out6 = P(r["out"]), P(r["T"]), P(go6)
+            a.grad_mean, a.grad_cov, a.grad_chan6 = P(r["gm"]), P(r["gc"]), P(r["gch"])
+            res.append(r)
+        bws = np.zeros(emu.sh_batch_workspace_bytes(2), np.uint8)
+        ga = np.zeros(N, np.float32); gcol = np.zeros((N, 3), np.float32)
+        if heads:
+            emu.vol_render_rgbd_batch(2, arr, N, P(col), P(al), 16, nth, ntw, H, W, 1e-4, P(bws), None)
+            emu.vol_render_rgbd_backward_batch(2, arr, N, P(col), P(al), P(ga), 16, nth, ntw, H, W, 1e-4, P(bws), None)
+        else:
+            emu.vol_render_rgb_batch(2, arr, N, P(col), P(al), 16, nth, ntw, H, W, 1e-4, P(bws), None)
+            emu.vol_render_rgb_backward_batch(2, arr, N, P(col), P(al), P(gcol), P(ga), 16, nth, ntw, H, W, 1e-4, P(bws), None)
+        assert np.isnan(res[0]["out"]).all() and np.isnan(res[0]["T"]).all(), heads
+        assert np.isfinite(res[1]["out"]).all() and np.isfinite(res[1]["T"]).all()
+        assert not res[0]["gm"].any() and res[1]["gm"].any() and np.isfinite(ga).all() and ga.any()
 
 
 def test_emulated_batch_entry_points_on_empty_inputs(emu):

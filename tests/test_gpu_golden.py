@@ -35,6 +35,16 @@ def rel(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
 
 
+def rows_ok(a, b, rtol=1e-3, atol_frac=1e-5):
+    """PER ROW: every Gaussian's gradient within rtol of that row's own largest entry + atol_frac of the
+    tensor's largest -- the tolerance of the full-size tests (DESIGN.md 4): small rows are checked too, not only the tensor's
+    maximum.  -> the worst row in units of its tolerance (<= 1 passes)"""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    a, b = a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)
+    tol = rtol * np.abs(b).max(axis=1, keepdims=True) + atol_frac * np.abs(b).max() + 1e-30
+    return float((np.abs(a - b) / tol).max())
+
+
 @pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(q)[:-4] for q in GOLD])
 def test_hip_path_reproduces_reference_golden(path):
     from gsgen_amd import _capi
@@ -87,12 +97,12 @@ def test_hip_path_reproduces_reference_golden(path):
     L.vol_render_backward_start_end(N, D, p(m2), p(c2), p(col), p(al), p(st), p(en), p(ids), p(final), p(gm), p(gc),
                                     p(gcol), p(ga), p(go), p(topleft), 16, nth, ntw, 1 / fx, 1 / fy, h, w, 1e-4, s)
     for a, k in ((gm, "rgb_gmean"), (gc, "rgb_gcov"), (gcol, "rgb_gcol"), (ga, "rgb_galpha")):
-        assert rel(a.cpu().numpy(), g[k]) < 1e-3, k
+        assert rows_ok(a.cpu().numpy(), g[k]) <= 1.0, (k, rows_ok(a.cpu().numpy(), g[k]))
     g3m, g3q, g3s = torch.empty_like(mean), torch.empty_like(q), torch.empty_like(sv)
     L.project_gaussians_backward(N, p(mean), p(q), p(sv), p(c2w), 1, p(T_(g["rgb_gmean"])), p(T_(g["rgb_gcov"])), None,
                                  p(g3m), p(g3q), p(g3s), s)
     for a, k in ((g3m, "proj_gmean"), (g3q, "proj_gqvec"), (g3s, "proj_gsvec")):
-        assert rel(a.cpu().numpy(), g[k]) < 1e-3, k
+        assert rows_ok(a.cpu().numpy(), g[k]) <= 1.0, (k, rows_ok(a.cpu().numpy(), g[k]))
     C = int(g["C"])
     rot = T_(np.ascontiguousarray(g["c2w"][:3, :3]).reshape(-1).copy())
     sh = T_(g["in_sh"][m])
@@ -110,9 +120,8 @@ def test_hip_path_reproduces_reference_golden(path):
         L.vol_render_backward_sh(N, D, p(m2), p(c2), p(sh), p(al), p(st), p(en), p(ids), p(T_(g[tag + "_img"])), p(gm),
                                  p(gc), p(gsh), p(ga), p(go), p(topleft), p(rot), 16, nth, ntw, 1 / fx, 1 / fy, h, w, C,
                                  1e-4, p(bg), s)
-        tol = 1e-3
         for a, k in ((gm, "_gmean"), (gc, "_gcov"), (gsh, "_gsh"), (ga, "_galpha")):
-            assert rel(a.cpu().numpy(), g[tag + k]) < tol, tag + k
+            assert rows_ok(a.cpu().numpy(), g[tag + k]) <= 1.0, (tag + k, rows_ok(a.cpu().numpy(), g[tag + k]))
 
 
 def test_fused_model_path_matches_the_reference_model_golden():

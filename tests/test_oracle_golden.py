@@ -28,7 +28,7 @@ def close(a, b, tol=GTOL):
 
 
 def test_golden_files_present():
-    assert len(GOLD) >= 4
+    assert len(GOLD) >= 5 and any(p.endswith('long_lists.npz') for p in GOLD)
 
 
 @pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[:-4] for p in GOLD])
@@ -118,6 +118,53 @@ def test_oracle_vs_reference_kernels_live(seed, W, H, C):
     og = O.render_sh_bwd(*a, sh, al, st, en, ids, o, go, cam.topleft, rot, C, 1 / cam.fx, 1 / cam.fy, H, W)
     for x, y in zip(rg, og):
         assert close(x, y)
+
+
+@needs_ref
+@pytest.mark.parametrize("C", [4, 2])
+def test_oracle_vs_reference_kernels_live_on_long_lists(C):
+    """the oracle-vs-reference pin on lists that cross every LDS batch boundary of the reference's kernels
+    (RGB forward 1 200 entries, RGB backward 472: vol_render.h:501, :442; SH degree-3 forward 218, backward 109:
+    vol_render_sh.h:171-248, :353-455): 4 000 splats on a 32 x 32 image, the longest list beyond 1 400 entries, opacities scaled
+    so that the pixels of one half walk their whole list and those of the other saturate early.  Images and T bit for bit,
+    gradients to the summation-order tolerance."""
+    W = H = 32
+    cam = scenes.Camera(W, H, fx=26.0, c2w=scenes.look_at((2.6, 0.0, 0.3)))
+    sc = scenes.random_scene(4000, seed=31 + C, svec=0.09, spread=0.5, C=C)
+    sc["alpha"] = np.where(sc["mean"][:, 1] < 0.0, sc["alpha"] * 0.02, sc["alpha"]).astype(np.float32)
+    g = scenes.oracle_geometry(sc, cam)
+    m = g["mask"]
+    nth, ntw = cam.tiles
+    ids, st, en = Rf.bin_sort(g["tl"], g["br"], g["depth"], nth, ntw, g["D"])
+    assert np.array_equal(ids, g["ids"]) and np.array_equal(st, g["start"]) and np.array_equal(en, g["end"])
+    assert int((en - st).max()) > 1400
+    a = (g["mean2d"], g["cov2d"])
+    al = sc["alpha"][m]
+    geo = (st, en, ids, cam.topleft, 1 / cam.fx, 1 / cam.fy, H, W)
+    col = sc["color"][m]
+    r, rT = Rf.render_rgb_fwd(*a, col, al, *geo)
+    o, oT = O.render_rgb_fwd(*a, col, al, *geo)
+    assert np.array_equal(r, o) and np.array_equal(rT, oT)
+    assert float(oT.min()) < 1e-4 and float(oT.max()) > 0.05  # early termination AND deep walks
+    go = np.random.default_rng(C).normal(size=(H, W, 3)).astype(np.float32)
+    rg = Rf.render_rgb_bwd(*a, col, al, st, en, ids, o, go, cam.topleft, 1 / cam.fx, 1 / cam.fy, H, W)
+    og = O.render_rgb_bwd(*a, col, al, st, en, ids, o, go, cam.topleft, 1 / cam.fx, 1 / cam.fy, H, W)
+    for x, y in zip(rg, og):
+        assert close(x, y)
+    sv = g["depth"].ravel()
+    r, rT = Rf.render_scalar_fwd(*a, sv, al, *geo)
+    o, oT = O.render_scalar_fwd(*a, sv, al, *geo)
+    assert np.array_equal(r, o) and np.array_equal(rT, oT)
+    rot = cam.c2w[:3, :3].reshape(-1)
+    sh = np.ascontiguousarray(sc["sh"][m])
+    for bg in (None, np.array([0.3, 0.1, 0.8], np.float32)):
+        r = Rf.render_sh_fwd(*a, sh, al, st, en, ids, cam.topleft, rot, C, 1 / cam.fx, 1 / cam.fy, H, W, bg=bg)
+        o = O.render_sh_fwd(*a, sh, al, st, en, ids, cam.topleft, rot, C, 1 / cam.fx, 1 / cam.fy, H, W, bg=bg)
+        assert np.array_equal(r, o)
+        rg = Rf.render_sh_bwd(*a, sh, al, st, en, ids, o, go, cam.topleft, rot, C, 1 / cam.fx, 1 / cam.fy, H, W, bg=bg)
+        og = O.render_sh_bwd(*a, sh, al, st, en, ids, o, go, cam.topleft, rot, C, 1 / cam.fx, 1 / cam.fy, H, W)
+        for x, y in zip(rg, og):
+            assert close(x, y)
 
 
 @needs_ref

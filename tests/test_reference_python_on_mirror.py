@@ -27,12 +27,7 @@ import refshim
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 GOLD = os.path.join(ROOT, "tests", "golden")
-pytestmark = pytest.mark.skipif(not refshim.available(), reason="/root/reference is not present")
-
-
-def rel(a, b):
-    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
-    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+pytestmark = pytest.mark.skipif(refshim.root() is None, reason="neither /root/reference nor tests/_refpy.zip is present")
 
 
 @pytest.fixture(scope="module")
@@ -56,100 +51,30 @@ def ref():
     _gs._load, _gs._ACCEPT_HOST_TENSORS = saved
 
 
-def load(name):
-    g = dict(np.load(os.path.join(GOLD, name + ".npz")))
-    m = g["mask"].astype(bool)
-    fx, fy, cx, cy, w, h = g["cam_intr"][:6]
-    t = lambda a, **k: torch.tensor(np.ascontiguousarray(a), **k)  # noqa: E731
-    c = {"g": g, "m": m, "H": int(h), "W": int(w), "fx": float(fx), "fy": float(fy),
-         "topleft": t(np.array([-cx / fx, -cy / fy], np.float32)),
-         "start": t(g["start"]), "end": t(g["end"]), "ids": t(g["ids"]),
-         "nth": (int(h) + 15) // 16, "ntw": (int(w) + 15) // 16, "t": t}
-    return c
+import refpy_cases as RC
+from refpy_cases import rel  # noqa: F401,E402  (re-exported: the model test below uses it)
 
 
-def geo_args(c):
-    return (c["start"], c["end"], c["ids"], c["topleft"], 16, c["nth"], c["ntw"], 1 / c["fx"], 1 / c["fy"], c["H"],
-            c["W"], 1e-4)
-
-
-@pytest.mark.parametrize("name", ["mock2", "rand_c1", "rand_c3", "rand_c4"])
+@pytest.mark.parametrize("name", ["mock2", "rand_c1", "rand_c3", "rand_c4", "long_lists"])
 def test_reference_render_with_T_and_start_end(ref, name):
-    c = load(name); g, m, t = c["g"], c["m"], c["t"]
-    P = [t(g["mean2d"], requires_grad=True), t(g["cov2d"], requires_grad=True),
-         t(g["in_color"][m], requires_grad=True), t(g["in_alpha"][m], requires_grad=True)]
-    bg = t(g["bg_img"], requires_grad=True)
-    out = ref._render_with_T.apply(*P, *geo_args(c), bg)
-    want = g["rgb"] + g["T"] * g["bg_img"]
-    assert out.shape == (c["H"], c["W"], 3)
-    assert np.abs(out.detach().numpy() - want).max() <= 1e-4
-    (out * t(g["grad_out"])).sum().backward()
-    for a, k in zip(P, ("rgb_gmean", "rgb_gcov", "rgb_gcol", "rgb_galpha")):
-        assert rel(a.grad.numpy(), g[k]) < 1e-3, k
-    assert np.abs(bg.grad.numpy() - g["grad_out"] * g["T"]).max() <= 1e-5  # gs/renderer.py:1283
-    # render_start_end: flat image, no background (gs/renderer.py:541-672)
-    Q = [t(g["mean2d"], requires_grad=True), t(g["cov2d"], requires_grad=True),
-         t(g["in_color"][m], requires_grad=True), t(g["in_alpha"][m], requires_grad=True)]
-    flat = ref.render_start_end(*Q, *geo_args(c))
-    assert flat.shape == (c["H"] * c["W"] * 3,)
-    assert np.abs(flat.detach().numpy().reshape(c["H"], c["W"], 3) - g["rgb"]).max() <= 1e-4
+    RC.case_render_with_T_and_start_end(ref, "cpu", name)
 
 
 @pytest.mark.parametrize("name", ["mock2", "rand_c3"])
 def test_reference_render_scalar(ref, name):
-    c = load(name); g, m, t = c["g"], c["m"], c["t"]
-    P = [t(g["mean2d"], requires_grad=True), t(g["cov2d"], requires_grad=True),
-         t(g["depth"], requires_grad=True), t(g["in_alpha"][m], requires_grad=True)]  # depth as [N,1], as render_one passes it
-    T = torch.ones(c["H"], c["W"], 1)
-    out = ref.render_scalar(*P, *geo_args(c), T)
-    assert out.shape == (c["H"] * c["W"],)
-    assert np.abs(out.detach().numpy().reshape(c["H"], c["W"]) - g["depth_img"]).max() <= 1e-4 * max(1.0, np.abs(g["depth_img"]).max())
-    assert np.abs(T.numpy() - g["depth_T"]).max() <= 1e-5  # the caller's T is overwritten in place
-    (out * t(np.ascontiguousarray(g["grad_out"][..., 0])).reshape(-1)).sum().backward()
-    for a, k in zip(P, ("sc_gmean", "sc_gcov", "sc_gscalar", "sc_galpha")):
-        assert rel(a.grad.numpy().reshape(g[k].shape), g[k]) < 1e-3, k
+    RC.case_render_scalar(ref, "cpu", name)
 
 
-@pytest.mark.parametrize("name", ["mock2", "rand_c1", "rand_c3", "rand_c4"])
+@pytest.mark.parametrize("name", ["mock2", "rand_c1", "rand_c3", "rand_c4", "long_lists"])
 @pytest.mark.parametrize("with_bg", [False, True])
 def test_reference_render_sh(ref, name, with_bg):
-    c = load(name); g, m, t = c["g"], c["m"], c["t"]
-    C = int(g["C"])
-    tag = "shbg" if with_bg else "sh"
-    P = [t(g["mean2d"], requires_grad=True), t(g["cov2d"], requires_grad=True),
-         t(g["in_sh"][m], requires_grad=True), t(g["in_alpha"][m], requires_grad=True)]
-    c2w = t(g["c2w"][:3, :3])  # contiguous [3,3]: the kernels read 9 packed floats (vol_render_sh.h:48-55)
-    a = (*P, c["start"], c["end"], c["ids"], c["topleft"], c2w, 16, c["nth"], c["ntw"], 1 / c["fx"], 1 / c["fy"],
-         c["H"], c["W"], C, 1e-4)
-    out = ref.render_sh_bg(*a, t(g["bg_rgb"])) if with_bg else ref.render_sh(*a)
-    assert out.shape == (c["H"] * c["W"] * 3,)
-    assert np.abs(out.detach().numpy().reshape(c["H"], c["W"], 3) - g[tag + "_img"]).max() <= 1e-4
-    (out.reshape(c["H"], c["W"], 3) * t(g["grad_out"])).sum().backward()
-    for p_, k in zip(P, ("_gmean", "_gcov", "_gsh", "_galpha")):
-        assert rel(p_.grad.numpy(), g[tag + k]) < 1e-3, tag + k
+    RC.case_render_sh(ref, "cpu", name, with_bg)
 
 
 def test_reference_projection_chained_into_reference_render_sh(ref):
     """project_gaussians (the reference's PyTorch, gs/renderer.py:391-421) -> _render_sh on the mirror: one autograd
     graph, all of it the reference's Python; gradients reach mean / qvec / svec"""
-    c = load("rand_c4"); g, m, t = c["g"], c["m"], c["t"]
-    C = int(g["C"])
-    mean, qvec, svec = (t(g["in_" + k][m], requires_grad=True) for k in ("mean", "qvec", "svec"))
-    c2w_full = t(g["c2w"])
-    mean2d, cov2d, JW, depth = ref.project_gaussians(mean, qvec, svec, c2w_full, True)
-    assert np.abs(mean2d.detach().numpy() - g["mean2d"]).max() <= 1e-6
-    sh, al = t(g["in_sh"][m], requires_grad=True), t(g["in_alpha"][m], requires_grad=True)
-    out = ref.render_sh(mean2d.contiguous(), cov2d.contiguous(), sh, al, c["start"], c["end"], c["ids"], c["topleft"],
-                        t(g["c2w"][:3, :3]), 16, c["nth"], c["ntw"], 1 / c["fx"], 1 / c["fy"], c["H"], c["W"], C, 1e-4)
-    (out.reshape(c["H"], c["W"], 3) * t(g["grad_out"])).sum().backward()
-    assert rel(sh.grad.numpy(), g["sh_gsh"]) < 1e-3
-    # the projection backward of the golden was fed the RGB path's 2-D gradients; rebuild the expectation for the SH
-    # path with the reference's own autograd on the golden 2-D gradients
-    m2, q2, s2 = (t(g["in_" + k][m], requires_grad=True) for k in ("mean", "qvec", "svec"))
-    a2, b2, _, _ = ref.project_gaussians(m2, q2, s2, c2w_full, True)
-    ((a2 * t(g["sh_gmean"])).sum() + (b2 * t(g["sh_gcov"])).sum()).backward()
-    for got, want, k in ((mean, m2, "mean"), (qvec, q2, "qvec"), (svec, s2, "svec")):
-        assert rel(got.grad.numpy(), want.grad.numpy()) < 2e-3, k
+    RC.case_projection_chained_into_reference_render_sh(ref, "cpu")
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -159,58 +84,23 @@ def test_reference_projection_chained_into_reference_render_sh(ref):
 # render_with_T + three render_scalar passes, :1198-1466), backward of a loss on all four outputs, post_backward()
 # (update_densify_info, :464-469).  Every `_backend.*` call in that file lands in this repo's `_gs`.
 # ---------------------------------------------------------------------------------------------------------------
-class _Cfg(dict):
-    """what the reference reads its OmegaConf node through: attribute access, .get, hasattr"""
-
-    def __getattr__(self, k):
-        try:
-            return self[k]
-        except KeyError:
-            raise AttributeError(k) from None
-
-
 @pytest.fixture(scope="module")
 def refmodel(ref):
     """-> (gs.gaussian_splatting module with _backend = the mirror, gs.renderer module)"""
     from gsgen_amd import _gs
-    dm = types.ModuleType("kornia.geometry.depth")  # utils/ops.py:5 imports depth_to_3d (unused on this path)
-    dm.depth_to_3d = None
-    sys.modules["kornia.geometry.depth"] = dm
-    sys.modules["kornia"].__path__ = []
-    sys.modules["kornia.geometry"].__path__ = []
-    import gs.gaussian_splatting as M
-    M._backend = _gs
-    return M, ref
+    return RC.import_reference_model(_gs), ref
 
 
 def test_reference_model_forward_backward_and_densify_info_on_the_mirror(refmodel):
-    import scenes
     from oracle import oracle as O
-    from utils.camera import CameraInfo
     M, GR = refmodel
-    sys.path.insert(0, GOLD)
-    import make_golden_model as MG  # the scene, cameras and config the committed fixture was generated from
-    bg = MG.BG
-    sc, cams = MG.case()
-    gold = np.load(os.path.join(GOLD, "model", "model_batch.npz"))
-    t = lambda a, **k: torch.tensor(np.ascontiguousarray(a), **k)  # noqa: E731
-    model = M.GaussianSplattingRenderer(_Cfg(MG.model_cfg()), {k: t(sc[k]) for k in ("mean", "qvec", "svec", "color", "alpha")})
-    model.train()
+    run = RC.run_reference_model(M, "cpu")
+    model, out, go, masks, g_mean2d, raw, sc, cams, bg = (run[k] for k in ("model", "out", "go", "masks", "g_mean2d", "raw", "sc", "cams", "bg"))
     N = sc["mean"].shape[0]
-    out = model({"c2w": torch.stack([t(c.c2w) for c in cams]), "camera_info": [CameraInfo(*c.intr) for c in cams]})
-    assert {k: tuple(v.shape) for k, v in out.items()} == {"rgb": (2, 56, 72, 3), "depth": (2, 56, 72, 1),
-                                                          "opacity": (2, 56, 72, 1), "z_var": (2, 56, 72, 1)}
-    rng = np.random.default_rng(5)
-    go = {k: rng.normal(size=tuple(v.shape)).astype(np.float32) for k, v in out.items()}
-    sum((out[k] * t(go[k])).sum() for k in out).backward()
-    masks = [m_.numpy().copy() for m_ in model.masks]
-    g_mean2d = [m_.grad.numpy().copy() for m_ in model.mean_2ds]  # retained by render_one for update_densify_info
-    model.post_backward()
+    t = lambda a, **k: torch.tensor(np.ascontiguousarray(a), **k)  # noqa: E731
 
     # ---- the expectation: the reference's torch projection (same bits as inside the model) in front of the oracle's
     # cull / count / bin / sort / four compositing passes and their backward, chained to the raw parameters by autograd
-    raw = {"mean": model.mean, "qvec": model.qvec, "svec": model.svec_before_activation,
-           "color": model.color_before_activation, "alpha": model.alpha_before_activation}
     P = {k: v.detach().clone().requires_grad_(True) for k, v in raw.items()}
     svec_a, color_a, alpha_a = torch.exp(P["svec"]), torch.sigmoid(P["color"]), torch.sigmoid(P["alpha"])
     want_maxr, want_acc, want_cnt = np.zeros(N, np.float32), np.zeros(N, np.float32), np.zeros(N, np.float32)
@@ -267,14 +157,4 @@ def test_reference_model_forward_backward_and_densify_info_on_the_mirror(refmode
     assert np.abs(model.max_radii2d.numpy() - want_maxr).max() <= 1e-6 * max(1.0, float(want_maxr.max()))
     assert np.array_equal(model.cnt.numpy(), want_cnt)
     assert rel(model.mean_2d_grad_accum.numpy(), want_acc) < 1e-3
-    # ... and against the fixture the reference's own kernels produced under the same model class
-    # (tests/golden/make_golden_model.py): images, raw-parameter gradients, densify statistics
-    assert np.array_equal(np.stack(masks), gold["masks"])
-    for k in out:
-        scale = max(1.0, float(np.abs(gold["out_" + k]).max()))
-        assert np.abs(out[k].detach().numpy() - gold["out_" + k]).max() <= 1e-4 * scale, k
-    for k in raw:
-        assert rel(raw[k].grad.numpy(), gold["grad_" + k]) < 1e-3, k
-    assert np.array_equal(model.cnt.numpy(), gold["cnt"])
-    assert rel(model.max_radii2d.numpy(), gold["max_radii2d"]) < 1e-6
-    assert rel(model.mean_2d_grad_accum.numpy(), gold["grad_accum"]) < 1e-3
+    RC.check_model_against_fixture(run)

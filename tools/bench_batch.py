@@ -27,7 +27,7 @@ cams = [scenes.Camera(a.res, a.res, fx=float(rng.uniform(0.7, 1.35) * a.res),
         for _ in range(a.batch)]
 cis = [R.CameraInfo(*c.intr) for c in cams]
 c2ws = [c.c2w for c in cams]
-br = BatchRenderer(a.n, a.res, a.res, dev, max_batch=a.batch, n_streams=a.streams)
+br = BatchRenderer(a.n, a.res, a.res, dev, max_batch=a.batch)
 go = torch.randn(a.batch, a.res, a.res, 3, device=dev)
 stats = None if a.no_stats else R.DensifyStats(a.n, dev)
 
@@ -49,6 +49,6 @@ for _ in range(a.steps):
     step()
 t_host = time.perf_counter() - t0
 torch.cuda.synchronize(); t1 = time.perf_counter() - t0
-print(json.dumps({"path": "BatchRenderer autograd" + (" rgb+heads" if a.heads else " sh"), "n": a.n, "res": a.res, "batch": a.batch, "streams": a.streams,
+print(json.dumps({"path": "BatchRenderer autograd" + (" rgb+heads" if a.heads else " sh"), "n": a.n, "res": a.res, "batch": a.batch, 
                   "renders_per_s": a.batch * a.steps / t1, "ms_per_render": 1e3 * t1 / (a.batch * a.steps),
                   "host_enqueue_ms_per_render": 1e3 * t_host / (a.batch * a.steps)}))

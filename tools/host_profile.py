@@ -26,7 +26,6 @@ wrap(F, "forward", "Function.forward")
 wrap(F, "backward", "Function.backward (engine thread)")
 wrap(BatchRenderer, "_upload", "  _upload")
 wrap(BatchRenderer, "_begin_batch", "  _begin_batch")
-wrap(BatchRenderer, "_end_batch", "  _end_batch")
 R.sh_l1_bound_device = timed("  sh_l1_bound_device", R.sh_l1_bound_device)
 lib = _capi.load()
 for nm in ("frame_geometry_batch_zero", "vol_render_sh_batch_bounded", "vol_render_backward_sh_batch_bounded", "project_gaussians_backward_batch",

@@ -21,7 +21,6 @@ wrap(Bm._render_batch, "forward", "sh.forward")
 wrap(Bm._render_batch, "backward", "sh.backward")
 wrap(BatchRenderer, "_upload", "upload")
 wrap(BatchRenderer, "_begin_batch", "begin_batch")
-wrap(BatchRenderer, "_end_batch", "end_batch")
 res, B = int(sys.argv[1]) if len(sys.argv) > 1 else 512, int(sys.argv[2]) if len(sys.argv) > 2 else 4
 sh_mode = len(sys.argv) > 3 and sys.argv[3] == "sh"
 dev = torch.device("cuda:0")

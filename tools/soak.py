@@ -26,7 +26,7 @@ cams = [scenes.Camera(a.res, a.res, fx=float(rng.uniform(0.8, 1.3) * a.res),
                       c2w=scenes.orbit(float(rng.uniform(2.1, 2.6)), float(rng.uniform(-10, 50)), float(rng.uniform(0, 360))))
         for _ in range(a.batch)]
 cis = [R.CameraInfo(*c.intr) for c in cams]; c2ws = [c.c2w for c in cams]
-br = BatchRenderer(a.n, a.res, a.res, dev, max_batch=a.batch, n_streams=3)
+br = BatchRenderer(a.n, a.res, a.res, dev, max_batch=a.batch)
 go = torch.randn(a.batch, a.res, a.res, 3, device=dev)
 ref = None
 worst = {k: 0.0 for k in keys}; worst["rgb"] = 0.0
