@@ -9,12 +9,13 @@ and nothing synchronises with the host.  The whole batch is ONE autograd node; e
 atomically into one set of parameter gradients (no per-camera zero-fill of the SH gradient, 19 MB at
 100k and C = 4, and no B-way gradient sum afterwards).
 
-A strictly sequential caller (a training loop: one step in flight) leaves the chip idle between the
-stages of one step -- the geometry chain is six small launches.  From 4 cameras on, the renderer
-therefore runs the batch as TWO half-batches on two streams (its own side stream, forked from and
-joined to the caller's stream inside the call): one half's geometry hides behind the other's
-compositing.  Images are the same bits, gradients the same up to the order of the atomics
-(profiles/r04_notes.md section 14, profiles/r05_notes.md: +4 .. 9 % with one step in flight).
+Optionally (pipeline=True) the batch runs as TWO half-batches on two streams -- the renderer's own side stream, forked from
+and joined to the caller's stream around the forward and around the backward (a loss needs every image of the batch before
+any backward starts).  Measured in round 5 (profiles/r05_notes.md): with that join the split gains nothing with one step in
+flight (cfg2 SH 4 823 vs 4 821 renders/s, RGB + heads +0.7 %) and LOSES 6-8 % at the trainer's 4 x 512^2 (917 vs 863 it/s) --
+the two 4-view launches of a stage are less efficient than one 8-view launch, and what round 4 had measured as +4..9 % came
+from letting one half's backward overlap the other's forward, which no real training step can do.  Hence off by default;
+images are the same bits either way, gradients the same up to the order of the atomics.
 
 Every camera of the batch owns a FrameBuffers slot because its backward needs the lists and
 projected records of its forward (22 B x N + 12 B x D_cap per slot).
@@ -166,7 +167,7 @@ class _render_batch(torch.autograd.Function):
             lib.project_gaussians_backward_batch(B, N, _p(mean), _p(qvec), _p(svec), br._ptr_table("cam", B),
                                                  int(ctx.detach), br._mask_table(B), br._ptr_table("g_mean2d", B),
                                                  br._ptr_table("g_cov2d", B), None, _p(g_mean), _p(g_qvec), _p(g_svec), s)
-            if stats is not None:
+            if stats is not None and stats.grad_accum is not None:
                 lib.densify_update_batch(B, N, None, br._ptr_table("g_mean2d", B), br._mask_table(B), None,
                                          _p(stats.grad_accum), _p(stats.cnt), s)
         return (g_mean, g_qvec, g_svec, g_alpha, g_col, None, None, None, None, _bg_grad(ctx, grad, T), None, None, None)
@@ -259,7 +260,7 @@ class _render_batch_heads(torch.autograd.Function):
                                                        br._ptr_table("g_cov2d", B), br._ptr_table("g_chan6", B),
                                                        br._ptr_table("depth", B), _p(g_mean), _p(g_qvec), _p(g_svec),
                                                        _p(g_col), s)
-            if stats is not None:
+            if stats is not None and stats.grad_accum is not None:
                 lib.densify_update_batch(B, N, None, br._ptr_table("g_mean2d", B), br._mask_table(B), None,
                                          _p(stats.grad_accum), _p(stats.cnt), s)
         return (g_mean, g_qvec, g_svec, g_alpha, g_col, None, None, None, _bg_grad(ctx, g_rgb, T), None, None, None)
@@ -268,7 +269,7 @@ class _render_batch_heads(torch.autograd.Function):
 class BatchRenderer:
     """Renders [B] cameras of one (W, H) shape for a fixed Gaussian count N."""
 
-    def __init__(self, N, W, H, device, max_batch, D_cap=None, segments=1, strict=False, pipeline="auto"):
+    def __init__(self, N, W, H, device, max_batch, D_cap=None, segments=1, strict=False, pipeline=False):
         """D_cap: capacity of every slot's (tile, Gaussian) pair list.  None (default): the FIRST batch is rendered
         synchronously (one host sync) and sizes all slots at 1.5 x the largest count it saw; later batches report their
         counts through the geometry launch itself (no sync, renderer.PairCountReport) and the lists are regrown before the
@@ -276,10 +277,9 @@ class BatchRenderer:
         render()/check_overflow() raises PairListOverflow with the lists already regrown.
         strict=True: every batch is rendered synchronously (count read back, regrown and binned again if it did not fit):
         lossless, one host sync per batch -- what the reference pays per CAMERA (gs/culling.py:34).
-        pipeline: "auto" (default) -- batches of 4 and more cameras run as two half-batches on two streams (the caller's and the
-        renderer's own, forked and joined inside the call): the right shape for ONE step in flight (a training loop);
-        False -- one launch per stage for the whole batch: the right shape when the caller keeps several independent
-        batches in flight on streams of its own (bench.py's headline loop).
+        pipeline: False (default) -- one launch per stage for the whole batch; True -- two half-batches on two streams (the
+        caller's and the renderer's own, forked and joined inside the call); "auto" -- True from 4 cameras on.  Measured not to
+        pay under the join a loss imposes (module docstring); kept for callers whose backward may start per half.
         segments: backward workgroups per tile (FrameBuffers)."""
         self.N, self.W, self.H, self.device = N, W, H, torch.device(device)
         self.segments = int(segments)
@@ -296,7 +296,7 @@ class BatchRenderer:
         # the slots' depth buffers are the rows of one matrix (the heads' backward reads depths[:B] as one tensor)
         self._depths = torch.empty(max_batch, N, device=device, dtype=torch.float32)
         self.slots = [R.FrameBuffers(N, W, H, device, D_cap=D_cap, segments=self.segments, total=self._totals[i:i + 1],
-                                     depth=self._depths[i].view(N, 1), report=(self._report, i))
+                                     depth=self._depths[i].view(N, 1), report=(self._report, i), strict=self.strict)
                       for i in range(max_batch)]
         self._ptr_tabs = {}
         self._side = None      # the second stream of a pipelined batch, made on first use

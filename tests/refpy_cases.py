@@ -163,8 +163,10 @@ def run_reference_model(M, dev):
     import make_golden_model as MG  # the scene, cameras and config the committed fixture was generated from
     sc, cams = MG.case()
     t = lambda a, **k: torch.tensor(np.ascontiguousarray(a), device=dev, **k)  # noqa: E731
-    model = M.GaussianSplattingRenderer(Cfg(MG.model_cfg()), {k: t(sc[k]) for k in ("mean", "qvec", "svec", "color", "alpha")})
-    model = model.to(dev)
+    cfg = Cfg(MG.model_cfg())
+    cfg["device"] = dev  # (the fixture was generated on the CPU; the class keeps its device in the config node)
+    cfg["background"] = Cfg(cfg["background"], device=dev)
+    model = M.GaussianSplattingRenderer(cfg, {k: t(sc[k]) for k in ("mean", "qvec", "svec", "color", "alpha")})
     model.train()
     out = model({"c2w": torch.stack([t(c.c2w) for c in cams]), "camera_info": [CameraInfo(*c.intr) for c in cams]})
     assert {k: tuple(v.shape) for k, v in out.items()} == {"rgb": (2, 56, 72, 3), "depth": (2, 56, 72, 1),

@@ -382,7 +382,7 @@ def test_batched_geometry_and_projection_backward_c_abi():
             assert torch.equal(od.sort().values, torch.arange(T, device=dev(), dtype=torch.int32))
             b = cnt[od.long()] >> 3
             assert bool((b[1:] <= b[:-1]).all())  # longest lists first, in buckets of 8 entries
-    assert bool((got[3].start == -1).all()) and bool((got[0].start >= 0).any())
+    assert bool((got[3].start == -2).all()) and bool((got[0].start >= 0).any())
 
     gen = torch.Generator(device=dev()).manual_seed(1)
     g2d = torch.randn(B, 6 * N, device=dev(), generator=gen)

@@ -385,7 +385,7 @@ def test_batched_launches_fuzz():
         cis = [R.CameraInfo(*c.intr) for c in cams]
         bg = np.array([0.1, 0.2, 0.3], np.float32)
         P = {k: T_(sc[k]).requires_grad_(True) for k in KEYS}
-        br = BatchRenderer(n, W, H, dev(), max_batch=B, fused_launch=True, segments=nseg)
+        br = BatchRenderer(n, W, H, dev(), max_batch=B, segments=nseg)
         for _ in range(2):
             rgb, _ = br.render(P["mean"], P["qvec"], P["svec"], P["alpha"], P["sh"], cis, [c.c2w for c in cams], C=C, bg_rgb=T_(bg))
             if br.ensure_capacity(B):

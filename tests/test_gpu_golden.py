@@ -124,8 +124,12 @@ def test_hip_path_reproduces_reference_golden(path):
             assert rows_ok(a.cpu().numpy(), g[tag + k]) <= 1.0, (tag + k, rows_ok(a.cpu().numpy(), g[tag + k]))
 
 
-def test_fused_model_path_matches_the_reference_model_golden():
-    """tests/golden/model/model_batch.npz: the reference's GaussianSplattingRenderer (its Python, its kernels compiled for
+@pytest.mark.parametrize("through", ["render_heads", "model_class"])
+def test_fused_model_path_matches_the_reference_model_golden(through):
+    """through = "model_class": the same through gsgen_amd.model.GaussianSplattingRenderer -- the reference's constructor
+    arguments, parameter names, `forward(batch)` -> dict and `post_backward()` (gs/gaussian_splatting.py:68-112, :1423-1473) on
+    the fused batched path.
+    tests/golden/model/model_batch.npz: the reference's GaussianSplattingRenderer (its Python, its kernels compiled for
     the CPU) on a two-camera batch -- four output images, gradients of the five RAW parameter fields, densify statistics
     (make_golden_model.py).  Here the same raw parameters, cameras and output gradients go through this repo's fused
     product path: torch activations -> BatchRenderer.render_heads (one geometry + one compositing enqueue for the batch,
@@ -140,12 +144,37 @@ def test_fused_model_path_matches_the_reference_model_golden():
                         float(g["cam_intr"][b][6]), float(g["cam_intr"][b][7])) for b in range(B)]
     c2ws = [np.ascontiguousarray(g["c2w"][b]) for b in range(B)]
     N, W, H = raw["mean"].shape[0], cis[0].w, cis[0].h
-    br = BatchRenderer(N, W, H, dev(), max_batch=B)
-    stats = R.DensifyStats(N, dev())
-    rgb, depth, opac, z2, _ = br.render_heads(raw["mean"], raw["qvec"], svec, alpha, color, cis, c2ws,
-                                              bg_rgb=T_(g["bg"]), stats=stats)
-    out = {"rgb": rgb, "depth": depth, "opacity": opac, "z_var": z2 - depth * depth}  # gs/gaussian_splatting.py:1397
-    sum((out[k] * T_(g["go_" + k])).sum() for k in out).backward()
+    if through == "model_class":
+        import sys
+        sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+        import make_golden_model as MG
+        from gsgen_amd.model import GaussianSplattingRenderer
+        cfg = MG.model_cfg()
+        cfg["device"] = "cuda:0"
+        model = GaussianSplattingRenderer(cfg, {"raw": True, **{k: torch.tensor(g["raw_" + k]) for k in raw}})
+        model.train()
+        assert [n_ for n_, _ in model.named_parameters()][:5] == ["mean", "qvec", "svec_before_activation",
+                                                                  "color_before_activation", "alpha_before_activation"]
+        out = model({"c2w": torch.tensor(g["c2w"]), "camera_info": cis})
+        assert set(out) == {"rgb", "depth", "opacity", "z_var"} and out["rgb"].shape == (B, H, W, 3) and out["z_var"].shape == (B, H, W, 1)
+        assert set(model({"c2w": torch.tensor(g["c2w"]), "camera_info": cis}, rgb_only=True)) == {"rgb"}
+        model.reset_densify_info()
+        out = model({"c2w": torch.tensor(g["c2w"]), "camera_info": cis})
+        sum((out[k] * T_(g["go_" + k])).sum() for k in out).backward()
+        model.post_backward()
+        raw = {"mean": model.mean, "qvec": model.qvec, "svec": model.svec_before_activation,
+               "color": model.color_before_activation, "alpha": model.alpha_before_activation}
+        svec, color, alpha = model.svec, model.color, model.alpha
+        br = model._br
+        stats = R.DensifyStats(N, dev())
+        stats.max_radii2d, stats.grad_accum, stats.cnt = model.max_radii2d, model.mean_2d_grad_accum, model.cnt
+    else:
+        br = BatchRenderer(N, W, H, dev(), max_batch=B)
+        stats = R.DensifyStats(N, dev())
+        rgb, depth, opac, z2, _ = br.render_heads(raw["mean"], raw["qvec"], svec, alpha, color, cis, c2ws,
+                                                  bg_rgb=T_(g["bg"]), stats=stats)
+        out = {"rgb": rgb, "depth": depth, "opacity": opac, "z_var": z2 - depth * depth}  # gs/gaussian_splatting.py:1397
+        sum((out[k] * T_(g["go_" + k])).sum() for k in out).backward()
     torch.cuda.synchronize()
     assert br.ensure_capacity(B)
     mask_diff = 0  # (a Gaussian whose bounding sphere touches a frustum plane to the ulp may be culled on one side only)

@@ -26,7 +26,8 @@ def setup():
     from gsgen_amd import renderer as R
     sc = scenes.random_scene(3000, seed=4, svec=0.03, C=2)
     W, H = 96, 64
-    cams = [scenes.Camera(W, H, fx=90.0, c2w=scenes.orbit(2.4, 10 + 5 * i, 60.0 * i)) for i in range(4)]
+    # camera 2 has the whole cloud in view (3 808 pairs), the others are zoomed in on its middle (about 2 170 each)
+    cams = [scenes.Camera(W, H, fx=90.0 if i == 2 else 260.0, c2w=scenes.orbit(2.4, 10 + 5 * i, 60.0 * i)) for i in range(4)]
     cis = [R.CameraInfo(*c.intr) for c in cams]
     refs, refs_rgb, Ds = [], [], []
     for cam in cams:
@@ -104,8 +105,8 @@ def test_batch_renderer_overflow_every_batch_every_view(setup, heads, pipeline):
     s = setup
     P, cis, c2ws = s["P"], s["cis"], [c.c2w for c in s["cams"]]
     bad = int(np.argmax(s["Ds"]))
-    cap = sorted(s["Ds"])[-2] + 8
-    assert s["Ds"][bad] > cap
+    cap = int(1.3 * sorted(s["Ds"])[-2])  # (beyond the 25 % margin inside which the lists are regrown BEFORE they overflow)
+    assert bad == 2 and s["Ds"][bad] > 1.2 * cap
 
     ok = (bad + 1) % 4  # a batch in which camera `ok` stands in for camera `bad` fits
 
@@ -165,7 +166,7 @@ def test_lists_are_regrown_before_a_growing_scene_overflows(setup):
     from gsgen_amd.batch import BatchRenderer
     s = setup
     P, cis, c2ws = s["P"], s["cis"], [c.c2w for c in s["cams"]]
-    br = BatchRenderer(s["N"], s["W"], s["H"], dev(), max_batch=4)
+    br = BatchRenderer(s["N"], s["W"], s["H"], dev(), max_batch=4, D_cap=int(1.3 * max(s["Ds"])))
     caps = []
     with torch.no_grad():
         sv = P["svec"].clone()
@@ -199,10 +200,11 @@ def test_capture_requires_sized_lists_and_a_replay_reports_overflow(setup):
                 step(br0)
     torch.cuda.synchronize()
     # (2) sized eagerly, captured, replayed on a scene that has outgrown the lists meanwhile: NaN + a report
-    br = BatchRenderer(s["N"], s["W"], s["H"], dev(), max_batch=4)
+    br = BatchRenderer(s["N"], s["W"], s["H"], dev(), max_batch=4, D_cap=int(1.5 * max(s["Ds"])))
     with torch.no_grad():
         step(br)
         torch.cuda.synchronize()
+        assert br.ensure_capacity(4)
         cap0 = br.slots[0].D_cap
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):

@@ -32,6 +32,7 @@ ap.add_argument("--batch", type=int, default=4, help="views per step (conf/base.
 ap.add_argument("--steps", type=int, default=100)
 ap.add_argument("--warmup", type=int, default=20)
 ap.add_argument("--graph", action="store_true", help="replay the whole step from one hipGraph")
+ap.add_argument("--pipeline", choices=["auto", "on", "off"], default="auto", help="BatchRenderer(pipeline=...): two half-batches on two streams")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 sc = scenes.pointe_scene(a.n, seed=0, C=1)
@@ -46,7 +47,7 @@ cams = [scenes.Camera(a.res, a.res, fx=float(rng.uniform(0.7, 1.35) * a.res),
                       c2w=scenes.orbit(float(rng.uniform(2, 2.5)), float(rng.uniform(-20, 60)), float(rng.uniform(-180, 180))))
         for _ in range(a.batch)]
 cis, c2ws = [R.CameraInfo(*c.intr) for c in cams], [c.c2w for c in cams]
-br = BatchRenderer(a.n, a.res, a.res, dev, max_batch=a.batch)
+br = BatchRenderer(a.n, a.res, a.res, dev, max_batch=a.batch, pipeline={'auto': 'auto', 'on': True, 'off': False}[a.pipeline])
 stats = R.DensifyStats(a.n, dev)
 g_sds = torch.randn(a.batch, a.res, a.res, 3, device=dev) * 1e-4  # the guidance's gradient on the rendered batch
 bg = torch.tensor([0.5, 0.5, 0.5], device=dev)
@@ -95,7 +96,7 @@ torch.cuda.synchronize()
 t1 = time.perf_counter() - t0
 print(json.dumps({"metric": "optimisation-step iters/sec, renderer + optimiser share (guidance stubbed)", "value": a.steps / t1,
                   "unit": "iters/s", "ms_per_iter": 1e3 * t1 / a.steps, "host_ms_per_iter": 1e3 * t_host / a.steps,
-                  "views_per_s": a.batch * a.steps / t1, "hipgraph": bool(a.graph) and graph_error is None, "hipgraph_error": graph_error,
+                  "views_per_s": a.batch * a.steps / t1, "hipgraph": bool(a.graph) and graph_error is None, "pipeline": a.pipeline, "hipgraph_error": graph_error,
                   "config": {"workload": "BASELINE configs[4] without the diffusion model: 100k Gaussians, "
                                          f"{a.batch} views at {a.res}x{a.res}, rgb + depth + opacity + z_var, "
                                          "densify statistics, Adam on the five raw fields", "gaussians": a.n}}))
