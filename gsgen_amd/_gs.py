@@ -192,7 +192,7 @@ def tile_based_vol_rendering_scalar_backward(mean, cov, scalar, alpha, start, en
 
 # The reference's SH entry points have no argument that could say which form of the per-pixel SH basis to use, so the choice is a
 # module-level switch ("SH basis"):  "auto" (default) -- SH degree 3 launches measure the coefficient bound on the
-# device and route on it (tile-local polynomial form of the basis where its error bound holds: images within 1.4e-5 of the exact
+# device and route on it (tile-local polynomial form of the basis where its error bound holds: images within 1e-5 of the exact
 # kernels', i.e. inside the 1e-4 contract); "exact" -- the reference's per-pixel basis (vol_render_sh.h:48-65), always.
 SH_BASIS = "auto"
 
@@ -203,17 +203,10 @@ def set_sh_basis(mode):
     if mode not in ("auto", "exact"):
         raise ValueError("SH basis: 'auto' or 'exact'")
     SH_BASIS = mode
-    _bound_cache.clear()
 
 
 def get_sh_basis():
     return SH_BASIS
-
-
-# forward -> backward: the bound a forward measured, keyed on the coefficient tensor's storage and version counter -- the
-# matching backward routes on the SAME device value (and skips its own pass); coefficients modified in place in between
-# (another version) are measured again
-_bound_cache = {}
 
 
 def _pmax(bound):
@@ -221,28 +214,19 @@ def _pmax(bound):
     return None if bound is None else bound.data_ptr() + 4 * (bound.numel() - 1)
 
 
-def _sh_bound(sh_coeffs, C, tile_size, reuse=False):
+def _sh_bound(sh_coeffs, C, tile_size):
     """SH degree 3: the per-splat bounds S_i = max_c sum_{k >= 1} |sh[i][c][k]| of the call's coefficients, measured on the device
-    in front of the launch (one ~10-us pass, no sync) into a scratch tensor [N]; the kernels route PER TILE on them -- the
-    tile-local polynomial form of the per-pixel basis for the tiles whose splats stay within the bound, the exact kernel for the
-    others (include/gsgen_hip.h, "per-TILE routing").  None otherwise, and with SH_BASIS == "exact".  reuse: the backward of a
-    frame takes the bounds its forward left for these coefficients."""
+    in front of the launch (one ~10-us pass, no sync) into a scratch tensor [N + 1] (their maximum behind them: a scene wholly
+    within the view's bound needs no look at the lists); the kernels route PER TILE on them -- the tile-local polynomial form of
+    the per-pixel basis for the tiles whose splats stay within the bound, the exact kernel for the others (include/gsgen_hip.h,
+    "per-TILE routing").  None otherwise, and with SH_BASIS == "exact".  Forward AND backward measure (round 5: no cache keyed on
+    storage and version between them -- process-global state that `.data` edits and concurrent callers could make stale, ADVICE
+    r4; the same coefficients give the same bounds, hence the same routing)."""
     if SH_BASIS == "exact" or int(C) != 4 or int(tile_size) != 16 or sh_coeffs.numel() == 0:
         return None
-    key = (sh_coeffs.device, sh_coeffs.data_ptr(), sh_coeffs.numel())
-    ver = sh_coeffs._version
-    if reuse:
-        hit = _bound_cache.get(key)
-        if hit is not None and hit[0] == ver:
-            return hit[1]
     n = sh_coeffs.numel() // 48
-    # per SPLAT [N] (routed per tile and per entry) + their maximum behind them (a scene wholly within the view's bound needs no
-    # look at the lists)
     bound = torch.empty(n + 1, device=sh_coeffs.device, dtype=torch.float32)
     _load().sh_l1_bound_rows(n, _p(sh_coeffs), 4, bound.data_ptr() + 4 * n, _p(bound), _stream(sh_coeffs))
-    if len(_bound_cache) > 64:
-        _bound_cache.clear()
-    _bound_cache[key] = (ver, bound)
     return bound
 
 
@@ -276,7 +260,7 @@ def _sh_bwd(mean, cov, sh_coeffs, alpha, start, end, gaussian_ids, out, grad_mea
     if int(C) < 1 or int(C) > 4:
         return
     with _guard(mean):
-        bound = _sh_bound(sh_coeffs, C, tile_size, reuse=True)  # the forward's own device value: the same routing
+        bound = _sh_bound(sh_coeffs, C, tile_size)  # the forward's own device value: the same routing
         _load().vol_render_backward_sh_routed(
             mean.size(0), gaussian_ids.size(0), _p(mean), _p(cov), _p(sh_coeffs), _p(alpha), _p(start),
             _p(end), _p(gaussian_ids), _p(out), _p(grad_mean), _p(grad_cov), _p(grad_sh_coeffs),

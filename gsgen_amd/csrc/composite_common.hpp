@@ -327,7 +327,7 @@ __device__ __forceinline__ v2f gauss_chol_pair(float p0x, float p1, float p2, v2
 // basis at the 3 x 3 nodes (u, v) in {-1, 0, 1}^2, set up once per tile.  The staged coefficients become
 // w[c][r] = sum_k V[r][k] sh[c][k] (18 values instead of 48, transformed once per (tile, splat)), the per-pixel contractions
 // are 6 terms instead of 16, 3 x 6 instead of 3 x 16 gradient components cross the lanes and are expanded by V in front of
-// the atomics.  It renders a view only where the bound 0.25 * S * 0.7 * delta^3 (S: the scene's largest per-splat sum of
+// the atomics.  It renders a view only where the bound 0.25 * S * kPolyFitErr * delta^3 (S: the scene's largest per-splat sum of
 // |non-constant SH coefficients| of one channel, measured on the device per step; delta: the tile's half diagonal in camera
 // space) stays below 1e-5 -- decided on the device by every workgroup (poly_route), which runs the exact form otherwise.
 constexpr int kPolyNB = 6;
@@ -337,19 +337,22 @@ constexpr int kPolyNB = 6;
 // instead of three scalar ones plus the moves that put their results into aligned pairs.
 constexpr int kPolyStride = 8;
 constexpr int kPolyNodes = 9;
-// colour error of the degree-2 form <= 0.25 (sigmoid slope) x S x 0.7 delta^3, delta = half diagonal of a tile in camera
-// space (tools/tile_basis_error.py: 1.95e-6 at delta = 0.0141, 2.1e-5 at 0.0316); used where that stays below 1e-5, a tenth
-// of the 1e-4 image tolerance.  S <= 0, NaN or infinite: never.  One function for the host's report and the kernels' routing.
+// colour error of the degree-2 form <= 0.25 (sigmoid slope) x S x kPolyFitErr delta^3, delta = half diagonal of a tile in
+// camera space; used where that stays below 1e-5, a tenth of the 1e-4 image tolerance.  kPolyFitErr = 1.0: the SHIPPED fit's
+// largest basis error is 0.93 delta^3 (tests/test_poly_fit_bound.py sweeps kPolyFit over rotations, tile positions and focal
+// lengths).  Rounds 2-4 routed on 0.7 -- a calibration of a different interpolation -- which made the promise 1.4e-5.
+// S <= 0, NaN or infinite: never.  One function for the host's report and the kernels' routing.
+constexpr float kPolyFitErr = 1.0f;
 __host__ __device__ __forceinline__ bool poly_ok(float S, float ps_max) {
   if (!(S > 0.0f) || !(S <= 3.0e38f)) return false;
   const float delta = 7.5f * 1.41421356f * ps_max;
-  return 0.25f * S * 0.7f * delta * delta * delta <= 1e-5f;
+  return 0.25f * S * kPolyFitErr * delta * delta * delta <= 1e-5f;
 }
 // per-splat form of the same rule: may a splat whose rows sum to at most S be rendered through the polynomial basis in a view of
 // this pixel size?  S = 0 (no higher bands: the fit of the constant term is exact) passes; NaN does not.
 __host__ __device__ __forceinline__ bool poly_row_ok(float S, float ps_max) {
   const float delta = 7.5f * 1.41421356f * ps_max;
-  return 0.25f * S * 0.7f * delta * delta * delta <= 1e-5f;
+  return 0.25f * S * kPolyFitErr * delta * delta * delta <= 1e-5f;
 }
 // does the polynomial form render this view?  (uniform over the workgroup: one scalar load)
 __device__ __forceinline__ bool poly_route(const float *sh_bound, float psx, float psy) {

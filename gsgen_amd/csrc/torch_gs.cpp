@@ -146,35 +146,19 @@ void tile_based_vol_rendering_scalar_backward(Tensor mean, Tensor cov, Tensor sc
 // The reference's SH entry points cannot say which form of the per-pixel SH basis to use: a module-level switch
 // (set_sh_basis("auto" | "exact"), INTEGRATION.md "SH basis").  exact = the reference's per-pixel basis, always.
 bool g_sh_exact = false;
-// forward -> backward: the bound a forward measured for a coefficient tensor (storage + version counter); the matching backward
-// routes on the SAME device value and skips its own pass.  Coefficients modified in place in between are measured again.
-struct BoundCache {
-  const void *ptr = nullptr;
-  int64_t numel = 0;
-  uint32_t version = 0;
-  int device = -1;
-  Tensor bound;
-} g_bound;
-
-// The per-splat bounds S_i = max_c sum_{k >= 1} |sh[i][c][k]| of the call's coefficients into a scratch tensor [N] from torch's
-// caching allocator (stream-ordered: the block is reused only behind the launches that read it); the SH kernels route PER TILE
-// on them (include/gsgen_hip.h "per-TILE routing").  nullptr = exact kernels (other degrees / tile sizes, or the switch)
+// The per-splat bounds S_i = max_c sum_{k >= 1} |sh[i][c][k]| of the call's coefficients into a scratch tensor [N + 1] (their
+// maximum behind them) from torch's caching allocator (stream-ordered: the block is reused only behind the launches that read
+// it); the SH kernels route PER TILE on them (include/gsgen_hip.h "per-TILE routing").  Undefined tensor = exact kernels (other
+// degrees / tile sizes, or the switch).  Forward AND backward measure (one ~10-us pass each): round 4 kept the forward's tensor in
+// a process-global cache keyed on storage and version for the backward -- unsynchronised, blind to `.data` edits, destroyed after
+// the allocator at exit; the same coefficients give the same bounds, so nothing is lost but the pass.
 template <class C_>
-const float *sh_bound(const Tensor &sh_coeffs, uint32_t C, uint32_t tile_size, C_ &c, bool reuse = false) {
-  if (g_sh_exact || C != 4 || tile_size != 16 || sh_coeffs.numel() == 0) return nullptr;
-  const void *ptr = sh_coeffs.data_ptr();
-  const uint32_t ver = (uint32_t)sh_coeffs._version();
-  const int dev = (int)sh_coeffs.get_device();
-  if (reuse && g_bound.bound.defined() && g_bound.ptr == ptr && g_bound.numel == sh_coeffs.numel() && g_bound.version == ver &&
-      g_bound.device == dev)
-    return F(g_bound.bound);
-  // per SPLAT [N] (the kernels route per tile and per entry on them) + their maximum behind them (a scene wholly within the
-  // view's bound needs no look at the lists)
+Tensor sh_bound(const Tensor &sh_coeffs, uint32_t C, uint32_t tile_size, C_ &c) {
+  if (g_sh_exact || C != 4 || tile_size != 16 || sh_coeffs.numel() == 0) return Tensor();
   const int64_t n = sh_coeffs.numel() / 48;
   Tensor b = at::empty({n + 1}, sh_coeffs.options());
   GS(gsgen_sh_l1_bound_rows((uint32_t)n, F(sh_coeffs), C, Fm(b) + n, Fm(b), c.stream));
-  g_bound.ptr = ptr; g_bound.numel = sh_coeffs.numel(); g_bound.version = ver; g_bound.device = dev; g_bound.bound = b;
-  return F(b);
+  return b;
 }
 
 void sh_forward(const Tensor &mean, const Tensor &cov, const Tensor &sh_coeffs, const Tensor &alpha, const Tensor &start,
@@ -187,7 +171,8 @@ void sh_forward(const Tensor &mean, const Tensor &cov, const Tensor &sh_coeffs, 
   Ctx c(mean);
   // SH degree 3: the coefficient bound of THESE coefficients, measured on the device in front of the launch (one 5-us pass,
   // no sync); the kernels route on it -- polynomial form of the per-pixel basis where its error bound holds, else exact
-  const float *bound = sh_bound(sh_coeffs, C, tile_size, c);
+  const Tensor bound_t = sh_bound(sh_coeffs, C, tile_size, c);  // (held until the launch is enqueued)
+  const float *bound = bound_t.defined() ? F(bound_t) : nullptr;
   GS(gsgen_vol_render_sh_routed((uint32_t)mean.size(0), (uint32_t)gaussian_ids.size(0), F(mean), F(cov), F(sh_coeffs), F(alpha),
                                 I(start), I(end), I(gaussian_ids), Fm(out), F(topleft), F(c2w), tile_size, n_tiles_h, n_tiles_w,
                                 psx, psy, H, W, C, thresh, bg, nullptr, nullptr, nullptr, 0, bound ? bound + sh_coeffs.numel() / 48 : nullptr, bound,
@@ -203,8 +188,9 @@ void sh_backward(const Tensor &mean, const Tensor &cov, const Tensor &sh_coeffs,
   CHECK_F(grad_alpha); CHECK_F(grad_out);
   if (C < 1 || C > 4) return;
   Ctx c(mean);
-  // the bound this frame's forward measured for these coefficients (same storage, same version): the same routing
-  const float *bound = sh_bound(sh_coeffs, C, tile_size, c, true);
+  // the same coefficients, the same bounds, the same routing as this frame's forward
+  const Tensor bound_t = sh_bound(sh_coeffs, C, tile_size, c);
+  const float *bound = bound_t.defined() ? F(bound_t) : nullptr;
   GS(gsgen_vol_render_backward_sh_routed((uint32_t)mean.size(0), (uint32_t)gaussian_ids.size(0), F(mean), F(cov), F(sh_coeffs),
                                          F(alpha), I(start), I(end), I(gaussian_ids), F(out), Fm(grad_mean), Fm(grad_cov),
                                          Fm(grad_sh_coeffs), Fm(grad_alpha), F(grad_out), F(topleft), F(c2w), tile_size,
@@ -378,7 +364,6 @@ PYBIND11_MODULE(_gs, m) {
   m.def("set_sh_basis", [](const std::string &mode) {
     TORCH_CHECK(mode == "auto" || mode == "exact", "SH basis: 'auto' or 'exact'");
     g_sh_exact = mode == "exact";
-    g_bound = BoundCache{};
   }, "SH degree 3: 'auto' (default: device-routed polynomial / exact per-pixel basis) or 'exact' (the reference's basis, always)");
   m.def("get_sh_basis", []() { return std::string(g_sh_exact ? "exact" : "auto"); });
 }

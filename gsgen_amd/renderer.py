@@ -233,6 +233,10 @@ def sh_row_bounds_device(sh, out=None, out_max=None):
         raise ValueError("sh_row_bounds wants fp32 SH coefficients [N, 3, C*C], C in 1..4")
     if out is None:
         out = torch.empty(sh.shape[0], device=sh.device, dtype=torch.float32)
+    for name, t_, need in (("out", out, sh.shape[0]), ("out_max", out_max, 1)):
+        if t_ is not None and not (isinstance(t_, torch.Tensor) and t_.dtype == torch.float32 and t_.device == sh.device
+                                   and t_.is_contiguous() and t_.numel() >= need):  # (the kernel writes `need` floats through a raw pointer)
+            raise ValueError(f"sh_row_bounds: {name} must be a contiguous fp32 tensor of at least {need} element(s) on {sh.device}")
     with torch.cuda.device(sh.device):
         _capi.load().sh_l1_bound_rows(sh.shape[0], _p(sh), C, _p(out_max), _p(out), _stream(sh))
     return out
@@ -501,6 +505,8 @@ class _render_frame(torch.autograd.Function):
         # SH degree 3, "auto": per-splat bounds measured on the device, the kernels route per tile on them
         ctx.sh_bound = None
         if C == 4 and sh_basis == "auto":
+            if col.shape[0] != buf.N:
+                raise ValueError(f"render_frame: {col.shape[0]} coefficient rows for buffers of {buf.N} Gaussians")
             ctx.sh_bound = buf.row_bounds()
             sh_row_bounds_device(col, out=ctx.sh_bound[:buf.N], out_max=ctx.sh_bound[buf.N:])
         smax = None if ctx.sh_bound is None else ctx.sh_bound.data_ptr() + 4 * buf.N  # (the view's bound: decides first)

@@ -420,13 +420,13 @@ int gsgen_vol_render_backward_sh_batch(uint32_t n_views, const gsgen_sh_view *vi
 
 /* ---- the coefficient bound: the fast form of the per-pixel SH basis, decided ON THE DEVICE ----------------------------
  * The reference evaluates the SH basis per pixel for dir = normalize(R (qx, qy, 1)) (vol_render_sh.h:48-65).  Inside a
- * 16 x 16 tile that is a degree-2 polynomial in the pixel offsets to within 0.7 delta^3 of a basis value (delta = the tile's
- * half diagonal in camera space): six-term contractions against coefficients transformed once per (tile, splat), +20 %
- * renders/s on BASELINE configs[1].  The colour error is <= 0.25 * S * 0.7 * delta^3 with
+ * 16 x 16 tile that is a degree-2 polynomial in the pixel offsets to within 1.0 delta^3 of a basis value (delta = the tile's
+ * half diagonal in camera space; the fit that ships reaches 0.93 delta^3 -- tests/test_poly_fit_bound.py sweeps it over rotations,
+ * tile positions and focal lengths): six-term contractions against coefficients transformed once per (tile, splat), +56 %
+ * renders/s on BASELINE configs[1].  The colour error is <= 0.25 * S * delta^3 with
  *     S = max over splats and channels of sum_{k >= 1} |sh[i][c][k]|,
- * and the polynomial form is used for a VIEW only where that stays <= 1e-5.  (The 0.7 was calibrated on a different interpolation;
- * the fit that ships reaches 0.93 delta^3 -- tests/test_poly_fit_bound.py sweeps it over rotations -- so what the library promises
- * is: routed colours within 1.4e-5 of the exact kernels', a seventh of the 1e-4 image tolerance.)
+ * and the polynomial form is used only where that stays <= 1e-5: routed colours within 1e-5 of the exact kernels', a tenth of
+ * the 1e-4 image tolerance.  (Rounds 2-4 routed on 0.7 delta^3, a calibration of a different interpolation: 1.4e-5.)
  *
  * S lives in DEVICE memory and never visits the host: gsgen_sh_l1_bound writes it (one coalesced pass over the
  * coefficients, ~5 us for 100 k splats; enqueue it on the render's stream whenever the coefficients may have changed, i.e.
@@ -484,7 +484,7 @@ int gsgen_vol_render_backward_sh_bounded(uint32_t N, uint32_t D, const float *me
  * higher-band coefficients, or a wide camera, sends the whole view to the exact kernels.  The *_routed entry points take the
  * bound per SPLAT -- sh_row_bounds[i] = max over the three channels of sum_{k >= 1} |sh[i][c][k]|, DEVICE memory, [N], measured per
  * step by gsgen_sh_l1_bound_rows (one coalesced pass, no atomics but one per workgroup; out_max, optional, receives the global
- * maximum the per-view rule uses) -- and decide per ENTRY and per TILE: a splat that satisfies 0.25 * S_i * 0.7 delta^3 <= 1e-5
+ * maximum the per-view rule uses) -- and decide per ENTRY and per TILE: a splat that satisfies 0.25 * S_i * delta^3 <= 1e-5
  * for its view's pixel size (the same rule, per splat) is evaluated through the tile's polynomial form; one beyond it is evaluated
  * exactly, entry by entry, inside the same kernel (the pixel's own SH basis against its raw coefficients); a staged batch of 32
  * records with more than a quarter of such splats sends its tile -- and only that tile -- to the exact kernel.  Splats behind the

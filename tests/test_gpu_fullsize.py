@@ -199,8 +199,8 @@ def test_full_size_cfg4_64_random_poses_batched():
                 want[k] += gr[k]
     assert worst <= 4
     check_grads(P, want, anisotropic=False)
-    # which form of the SH basis the device took, per camera: the focal lengths straddle the bound (S = 2.4: f >= 0.7 x 512
-    # needs S <= 2.2, f = 1.35 x 512 allows 15.8), so the 64 poses hold both kinds; against an exact-basis render of the same
+    # which form of the SH basis the device took, per camera: the focal lengths straddle the bound (S = 2.4: f = 0.7 x 512
+    # needs S <= 1.5, f = 1.35 x 512 allows 11), so the 64 poses hold both kinds; against an exact-basis render of the same
     # batches the polynomial views differ by the fit error only and the fallen-back ones not at all
     from gsgen_amd import _capi
     S = R.sh_l1_bound(P["sh"])
@@ -217,10 +217,12 @@ def test_full_size_cfg4_64_random_poses_batched():
                 d = float((imgs[0][i] - imgs[1][i]).abs().max())
                 # round 4, per-tile routing: the views round 3 sent to the exact kernels whole are polynomial too, except the
                 # few tiles that stage a splat beyond the bound
-                assert 0.0 < d <= 1.4e-5, (b0 + i, applies[b0 + i], d, cams[b0 + i].fx)
+                assert 0.0 < d <= 1e-5, (b0 + i, applies[b0 + i], d, cams[b0 + i].fx)
                 nonempty = (br.slots[i].end > br.slots[i].start).cpu().numpy()
                 n_fl = int((flags[i] & nonempty).sum())
-                assert (n_fl == 0) if applies[b0 + i] else (n_fl < 0.25 * nonempty.sum()), (b0 + i, n_fl, int(nonempty.sum()))
+                # (a wide view whose bound half of the scene's splats exceed sends the tiles where they crowd a staged batch --
+                # more than a quarter of its 32 records -- to the exact kernel: up to ~40 % of its tiles at 0.7 x focal)
+                assert (n_fl == 0) if applies[b0 + i] else (n_fl < 0.6 * nonempty.sum()), (b0 + i, n_fl, int(nonempty.sum()))
                 if not applies[b0 + i]:
                     scenes.PARITY_LOG.append(f"cfg4 camera {b0 + i} (focal {cams[b0 + i].fx / 512:.2f} x size, beyond the per-view bound): "
                                              f"{n_fl} of {int(nonempty.sum())} non-empty tiles exact = 0")

@@ -53,7 +53,7 @@ def test_coefficients_moving_between_steps_keep_the_image_contract():
     L = _capi.load()
     N, W, H, B = 20_000, 320, 240, 2
     sc = scenes.pointe_scene(N, seed=4, C=4)
-    cams = [scenes.Camera(W, H, fx=400.0 + 40 * i, c2w=scenes.orbit(2.5, 10.0 + 25 * i, 20.0 + 80 * i)) for i in range(B)]
+    cams = [scenes.Camera(W, H, fx=430.0 + 40 * i, c2w=scenes.orbit(2.5, 10.0 + 25 * i, 20.0 + 80 * i)) for i in range(B)]
     cis = [R.CameraInfo(*c.intr) for c in cams]
     bg = np.array([0.1, 0.2, 0.3], np.float32)
     br = BatchRenderer(N, W, H, dev(), max_batch=B)
@@ -176,7 +176,7 @@ def test_outlier_splats_cost_their_entries_not_the_view():
     ntw = (W + 15) // 16
     for i in range(B):
         d = np.abs(out["auto"][0][i] - out["exact"][0][i]).max(-1)
-        assert 0.0 < d.max() <= 1.4e-5
+        assert 0.0 < d.max() <= 1e-5
         for t in np.nonzero(flags[i])[0]:
             ty, tx = divmod(int(t), ntw)
             assert d[16 * ty:16 * ty + 16, 16 * tx:16 * tx + 16].max() == 0.0, (i, t)   # rendered by the exact kernel
