@@ -33,6 +33,25 @@ from . import renderer as R
 from .renderer import _p, PairListOverflow
 
 
+_EXT = [False]  # the compiled `_gsbatch` module (csrc/torch_batch.cpp), None when it is not built; looked up once
+
+
+def _batch_ext():
+    if _EXT[0] is False:
+        import glob
+        import importlib.util
+        import os
+        hits = glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "ext", "_gsbatch.*.so"))
+        mod = None
+        if hits:
+            _capi.load()  # (libgsgen_hip.so and torch's HIP runtime first: one libamdhip64 per process)
+            spec = importlib.util.spec_from_file_location("_gsbatch", hits[0])
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+        _EXT[0] = mod
+    return _EXT[0]
+
+
 def _bg_grad(ctx, grad_rgb, T):
     """d/d bg of rgb = ... + T * bg (gs/renderer.py:1283: nan_to_num(grad * T)), reduced to bg's shape; None unless
     the background takes part in the graph (the reference's ConstBackground / MLPBackground are trainable)"""
@@ -290,7 +309,9 @@ class BatchRenderer:
         # the slots' pair counters live in one tensor (one copy brings a batch's counts to the host where a sync is wanted)
         self._totals = torch.zeros(max_batch, device=device, dtype=torch.int32)
         self._report = R.PairCountReport(max_batch)
-        self._generation = 0
+        self._gen = np.zeros(1, np.int64)  # the generation counter, in memory the C++ autograd node reads too
+        self._plans = {}
+        self.use_ext = True    # the C++ autograd node (csrc/torch_batch.cpp) where it is built and applicable
         self._sh_bound = self._sh_rows = None
         self._table_cache = {}
         # the slots' depth buffers are the rows of one matrix (the heads' backward reads depths[:B] as one tensor)
@@ -329,6 +350,14 @@ class BatchRenderer:
         self._last_parts = [(0, 0)]
         self._bound_tick = 0
 
+    @property
+    def _generation(self):
+        return int(self._gen[0])
+
+    @_generation.setter
+    def _generation(self, v):
+        self._gen[0] = v
+
     # ---- buffers and tables ------------------------------------------------------------------------------------------
     def _chan6(self):
         """[max_batch, 6 Np]: the per-view accumulators of d L / d (r, g, b, depth, 1, depth^2) (render_heads only)"""
@@ -336,6 +365,7 @@ class BatchRenderer:
             self._gch = torch.empty(len(self.slots), 6 * self._Np, device=self.device, dtype=torch.float32)
             self._ptr_tabs.clear()
             self._table_cache.clear()
+            self._plans.clear()
         return self._gch
 
     def _upload(self, cam_infos, c2ws, frustum_radius, tile_radius):
@@ -352,8 +382,7 @@ class BatchRenderer:
                     c2w = c2w.detach().cpu().numpy()
                 poses[i] = c2w.ravel()[:12] if (type(c2w) is np.ndarray and c2w.dtype == np.float32) else \
                     np.asarray(c2w, np.float32).reshape(-1)[:12]
-        for i, ci in enumerate(cam_infos):
-            intr[i] = (ci.fx, ci.fy, ci.cx, ci.cy, ci.w, ci.h, ci.near_plane, ci.far_plane)
+        intr[:B] = [(ci.fx, ci.fy, ci.cx, ci.cy, ci.w, ci.h, ci.near_plane, ci.far_plane) for ci in cam_infos]  # (one assignment)
         lib = _capi.load()
         lib.pack_camera_blocks(B, poses.ctypes.data, 12, intr.ctypes.data, frustum_radius, tile_radius, h.ctypes.data)
         # the renderer's own device block: its rows are read by the batch's backward, and no other batch of this renderer
@@ -431,6 +460,41 @@ class BatchRenderer:
         self._table_cache[kind] = (cap, geo, views)
         return geo, views
 
+    # ---- the C++ autograd node ---------------------------------------------------------------------------------------
+    def _plan(self, kind, B):
+        """-> (address of the _gsbatch.Plan of this (kind, batch size), the view table) when the batch can take the C++ node:
+        the module is built, the lists are sized, no host sync is wanted (strict), one launch per stage (no half-batches);
+        else None (the Python Functions: same launches)."""
+        ext = _batch_ext() if self.use_ext else None
+        if ext is None or self.strict or B == 0 or len(self._split(B)) > 1 or self.slots[0].needs_sync_sizing():
+            return None
+        cap = self.slots[0].D_cap
+        key = (kind, B)
+        hit = self._plans.get(key)
+        if hit is not None and hit[0] == cap:
+            return hit[2], hit[3]
+        geo, views = self._tables(kind)
+        adr = ctypes.addressof
+        heads = kind == "rgbd"
+        plan = ext.Plan({"rgbd": 0, "rgb": 1, "sh": 2}[kind], B, self.N, self._Np, self.W, self.H, self.slots[0].nth, self.slots[0].ntw,
+                        self.segments, adr(geo), adr(views), adr(self._ptr_table("cam", B)), adr(self._mask_table(B)),
+                        adr(self._ptr_table("g_mean2d", B)), adr(self._ptr_table("g_cov2d", B)),
+                        adr(self._ptr_table("g_chan6", B)) if heads else 0, adr(self._ptr_table("depth", B)),
+                        adr(self._ptr_table("cov2d", B)), _p(self._gws), _p(self._bws[0]), self._gen.ctypes.data, self._g2d,
+                        self._chan6() if heads else None,
+                        # what a pending backward of this plan needs alive even if the renderer is dropped first: the host tables,
+                        # the generation cell, the slots' buffers as they are NOW (a regrowth replaces them and the plan), the
+                        # workspaces -- not the renderer itself (it caches the plan: a cycle Python could not collect)
+                        [geo, views, dict(self._ptr_tabs), self._gen, self._cams, self._gws, self._bws[0], self._rows, self._smax,
+                         [(b_.mean2d, b_.cov2d, b_.depth, b_.mask, b_.ids, b_.start, b_.end, b_.ws, b_.total, b_.seg_ws)
+                          for b_ in self.slots[:B]]])
+        va = np.ctypeslib.as_array(ctypes.cast(views, ctypes.POINTER(ctypes.c_uint8)), (ctypes.sizeof(views),)).view(np.dtype(views._type_))
+        self._plans[key] = (cap, plan, plan.address(), va)
+        return plan.address(), va
+
+    def _stats_args(self, stats):
+        return (None, None, None) if stats is None else (stats.max_radii2d, stats.grad_accum, stats.cnt)
+
     # ---- half-batches --------------------------------------------------------------------------------------------------
     def _fork(self, B, split=None):
         """-> [(first view, views, raw stream)]: the batch as one part on the current stream, or as two halves -- the second
@@ -438,9 +502,7 @@ class BatchRenderer:
         forward's partition, for its backward."""
         cur = torch.cuda.current_stream(self.device)
         if split is None:
-            two = B >= 2 and (self.pipeline is True or (self.pipeline == "auto" and B >= 4))
-            h = (B + 1) // 2
-            split = [(0, h), (h, B - h)] if two else [(0, B)]
+            split = self._split(B)
         self._last_parts = split
         if len(split) == 1:
             return [(0, split[0][1], cur.cuda_stream)]
@@ -450,6 +512,11 @@ class BatchRenderer:
         self._ev[0].record(cur)
         self._side.wait_event(self._ev[0])
         return [(split[0][0], split[0][1], cur.cuda_stream), (split[1][0], split[1][1], self._side.cuda_stream)]
+
+    def _split(self, B):
+        two = B >= 2 and (self.pipeline is True or (self.pipeline == "auto" and B >= 4))
+        h = (B + 1) // 2
+        return [(0, h), (h, B - h)] if two else [(0, B)]
 
     def _join(self, parts):
         """the current stream waits for the side stream's half (what the call allocated on the current stream and used on
@@ -586,6 +653,16 @@ class BatchRenderer:
             else:  # per-splat bounds + their maximum: the launches take the view's bound first, then route per entry / tile
                 self._sh_rows = self._measure_bound(col)
                 self._sh_bound = self._smax if self._sh_rows is self._rows else None
+        fast = self._plan("sh" if int(C) > 0 else "rgb", B)
+        if fast is not None:  # one C++ autograd node (csrc/torch_batch.cpp): the same launches, a third of the host time
+            self._begin_batch(B)
+            self._last_parts = [(0, B)]
+            va = fast[1]
+            va["pixel_size_x"][:B] = 1.0 / self._intr[:B, 0]
+            va["pixel_size_y"][:B] = 1.0 / self._intr[:B, 1]
+            out, T = _batch_ext().render(fast[0], mean, qvec, svec, alpha, col, bg_rgb, int(C), float(thresh), bool(detach_depth),
+                                         self._sh_bound, self._sh_rows, *self._stats_args(stats))
+            return out, T
         return _render_batch.apply(mean, qvec, svec, alpha, col, cams, self, B, int(C), bg_rgb, float(thresh),
                                    bool(detach_depth), stats)
 
@@ -615,6 +692,15 @@ class BatchRenderer:
             return z, z[..., :1], z[..., :1], z[..., :1], z[..., :1]
         cams = self._upload(cam_infos, c2ws, frustum_radius, tile_radius)
         self._cis = list(cam_infos)
+        fast = self._plan("rgbd", B)
+        if fast is not None:  # one C++ autograd node (csrc/torch_batch.cpp)
+            self._begin_batch(B)
+            self._last_parts = [(0, B)]
+            va = fast[1]
+            va["pixel_size_x"][:B] = 1.0 / self._intr[:B, 0]
+            va["pixel_size_y"][:B] = 1.0 / self._intr[:B, 1]
+            return tuple(_batch_ext().render_heads(fast[0], mean, qvec, svec, alpha, color, bg_rgb, float(thresh),
+                                                   bool(detach_depth), *self._stats_args(stats)))
         return _render_batch_heads.apply(mean, qvec, svec, alpha, color, cams, self, B, bg_rgb, float(thresh),
                                          bool(detach_depth), stats)
 

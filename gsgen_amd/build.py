@@ -64,16 +64,13 @@ def build(force=False, verbose=False, extra_flags=()):
 EXT_DIR = os.path.join(HERE, "ext")
 
 
-def build_torch_ext(force=False, verbose=False):
-    """gsgen_amd/ext/_gs.<abi>.so: the `_gs` CPython module (torch::Tensor in, C ABI underneath, gsgen_amd/csrc/
-    torch_gs.cpp) -- what the reference builds from gs/src/bindings.cpp.  Plain host C++: compiled with g++ against
-    torch's headers and linked to the in-tree HIP library (relative rpath) and torch's own libraries."""
+def _build_ext(name, source, force=False, verbose=False):
     import sysconfig
     import torch
     lib = build()
     os.makedirs(EXT_DIR, exist_ok=True)
-    src = os.path.join(CSRC, "torch_gs.cpp")
-    out = os.path.join(EXT_DIR, "_gs" + sysconfig.get_config_var("EXT_SUFFIX"))
+    src = os.path.join(CSRC, source)
+    out = os.path.join(EXT_DIR, name + sysconfig.get_config_var("EXT_SUFFIX"))
     if force or _newer(src, out, extra=(lib,)):
         tdir = os.path.dirname(torch.__file__)
         rocm = os.environ.get("ROCM_PATH") or os.environ.get("ROCM_HOME") or "/opt/rocm"
@@ -81,7 +78,7 @@ def build_torch_ext(force=False, verbose=False):
                os.path.join(rocm, "include"), sysconfig.get_paths()["include"]]
         tlib = os.path.join(tdir, "lib")
         cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-deprecated-declarations", "-D__HIP_PLATFORM_AMD__=1",
-               "-DUSE_ROCM=1", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}",
+               "-DUSE_ROCM=1", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", f"-DTORCH_EXTENSION_NAME={name}",
                *[f"-I{i}" for i in inc], src, "-o", out, f"-L{LIBDIR}", "-lgsgen_hip", f"-L{tlib}", "-ltorch", "-ltorch_cpu",
                "-ltorch_python", "-lc10", "-lc10_hip", "-ltorch_hip", "-Wl,-rpath,$ORIGIN/../lib", f"-Wl,-rpath,{tlib}"]
         if verbose:
@@ -90,7 +87,21 @@ def build_torch_ext(force=False, verbose=False):
     return out
 
 
+def build_torch_ext(force=False, verbose=False):
+    """gsgen_amd/ext/_gs.<abi>.so: the `_gs` CPython module (torch::Tensor in, C ABI underneath, gsgen_amd/csrc/
+    torch_gs.cpp) -- what the reference builds from gs/src/bindings.cpp.  Plain host C++: compiled with g++ against
+    torch's headers and linked to the in-tree HIP library (relative rpath) and torch's own libraries."""
+    return _build_ext("_gs", "torch_gs.cpp", force, verbose)
+
+
+def build_batch_ext(force=False, verbose=False):
+    """gsgen_amd/ext/_gsbatch.<abi>.so: the camera batch as one C++ autograd node (gsgen_amd/csrc/torch_batch.cpp), the host side
+    of BatchRenderer's fast path.  Optional: without it BatchRenderer runs its Python autograd Functions (same launches)."""
+    return _build_ext("_gsbatch", "torch_batch.cpp", force, verbose)
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
     if "--ext" in sys.argv:
         print(build_torch_ext(force="--force" in sys.argv, verbose=True))
+        print(build_batch_ext(force="--force" in sys.argv, verbose=True))

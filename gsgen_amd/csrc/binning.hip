@@ -156,35 +156,39 @@ bin_pull_body(uint32_t N, const int *__restrict__ tl, const int *__restrict__ br
   }
 }
 
-// per tile: exclusive scan of cnt[.][tile] over the chunks (in place), total -> tile_count.
-// One wave per tile, lanes <-> chunks, DPP prefix scan.
-__device__ __forceinline__ uint32_t wave_scan_add_u32(uint32_t x) {
-  int v = (int)x;
-  const int s1 = __builtin_amdgcn_update_dpp(0, v, kDppRowShr + 1, 0xf, 0xf, false);
-  const int s2 = __builtin_amdgcn_update_dpp(0, v, kDppRowShr + 2, 0xf, 0xf, false);
-  const int s3 = __builtin_amdgcn_update_dpp(0, v, kDppRowShr + 3, 0xf, 0xf, false);
-  v = v + s1 + s2 + s3;
-  v += __builtin_amdgcn_update_dpp(0, v, kDppRowShr + 4, 0xf, 0xe, false);
-  v += __builtin_amdgcn_update_dpp(0, v, kDppRowShr + 8, 0xf, 0xc, false);
-  v += __builtin_amdgcn_update_dpp(0, v, kDppRowBcast15, 0xa, 0xf, false);
-  v += __builtin_amdgcn_update_dpp(0, v, kDppRowBcast31, 0xc, 0xf, false);
-  return (uint32_t)v;
-}
-
+// per tile: exclusive scan of cnt[.][tile] over the chunks (in place), total -> tile_count (scan_chunks_body below).
+// Round 5: lanes <-> TILES (64 consecutive tiles per workgroup), the chunks walked serially -- every load and store of a
+// wavefront is one contiguous 256-byte run of cnt[chunk][tile0 .. tile0 + 63].  (Until round 4: one wavefront per tile, lanes
+// <-> chunks: each lane's 4 bytes lay T words from its neighbour's, a cache line per lane -- 209 MB moved per 4-view launch of
+// BASELINE configs[2] for 8 T chunks = 32 MB of scan, profiles/r04_traffic.json.)  Four wavefronts per workgroup split the
+// chunk range: each sums its quarter, the quarters' sums meet in LDS, each then rewrites its quarter with the exclusive
+// prefixes: 2 reads (the second from L2) + 1 write per counter.
+// NW wavefronts per workgroup: 4 in a camera batch (hundreds of workgroups), 16 for a lone camera (40 workgroups at 800 x 800:
+// the chain of dependent chunk steps per wavefront is what a lone render waits for).
+constexpr uint32_t kScanChunkTiles = 64;
+template <uint32_t NW>
 __device__ __forceinline__ void
 scan_chunks_body(uint32_t T, uint32_t nchunks, uint32_t *__restrict__ cnt, uint32_t *__restrict__ tile_count) {
-  const uint32_t t = blockIdx.x * 4u + (threadIdx.x >> 6);  // one wave per tile
-  if (t >= T) return;
-  const uint32_t lane = (uint32_t)lane_id();
-  uint32_t carry = 0;
-  for (uint32_t c0 = 0; c0 < nchunks; c0 += 64u) {
-    const uint32_t c = c0 + lane;
-    const uint32_t v = (c < nchunks) ? cnt[(size_t)c * T + t] : 0u;
-    const uint32_t inc = wave_scan_add_u32(v);
-    if (c < nchunks) cnt[(size_t)c * T + t] = carry + inc - v;
-    carry += (uint32_t)rd_lane((int)inc, 63);
+  __shared__ uint32_t s_part[NW][kScanChunkTiles];
+  const uint32_t lane = (uint32_t)lane_id(), w = threadIdx.x >> 6;
+  const uint32_t t = blockIdx.x * kScanChunkTiles + lane;
+  const uint32_t q = (nchunks + NW - 1u) / NW;
+  const uint32_t c0 = min(w * q, nchunks), c1 = min(c0 + q, nchunks);
+  uint32_t sum = 0;
+  if (t < T)
+    for (uint32_t c = c0; c < c1; ++c) sum += cnt[(size_t)c * T + t];
+  s_part[w][lane] = sum;
+  __syncthreads();
+  uint32_t run = 0;
+  for (uint32_t k = 0; k < w; ++k) run += s_part[k][lane];
+  if (t < T) {
+    for (uint32_t c = c0; c < c1; ++c) {
+      const uint32_t v = cnt[(size_t)c * T + t];
+      cnt[(size_t)c * T + t] = run;
+      run += v;
+    }
+    if (w == NW - 1u) tile_count[t] = run;  // (the last part ends on the tile's total, also when its chunk range is empty)
   }
-  if (lane == 0) tile_count[t] = carry;
 }
 
 // exclusive scan of tile_count[T] -> tile_off[T+1]; ctrl[0] = total, ctrl[1] = overflow flag.
@@ -563,14 +567,14 @@ k_bin_pull_views(uint32_t N, int ntw, int nth, uint32_t T, const GeoView *__rest
   const GeoView v = views[blockIdx.z];
   bin_pull_body<EMIT>(N, v.tl, v.br, v.depth, ntw, nth, T, v.cnt, v.wcnt, v.tile_off, v.ctrl, v.keys);
 }
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k_scan_chunks(uint32_t T, uint32_t nchunks, uint32_t *__restrict__ cnt, uint32_t *__restrict__ tile_count) {
-  scan_chunks_body(T, nchunks, cnt, tile_count);
+  scan_chunks_body<16>(T, nchunks, cnt, tile_count);
 }
 __global__ void __launch_bounds__(256)
 k_scan_chunks_views(uint32_t T, uint32_t nchunks, const GeoView *__restrict__ views) {
   const GeoView v = views[blockIdx.y];
-  scan_chunks_body(T, nchunks, v.cnt, v.tile_count);
+  scan_chunks_body<4>(T, nchunks, v.cnt, v.tile_count);
 }
 // tile offsets and the longest-first launch order in ONE launch: both read tile_count only, both are one workgroup --
 // as two kernels they were two ~5 us links in a lone render's chain of dependent launches
@@ -755,7 +759,7 @@ static int bin_and_sort(uint32_t N, uint32_t cap, uint32_t nth, uint32_t ntw, co
                        w.cnt, w.wcnt, (const uint32_t *)nullptr, (const uint32_t *)nullptr,
                        (unsigned long long *)nullptr);
   }
-  hipLaunchKernelGGL(k_scan_chunks, dim3((T + 3) / 4), dim3(256), 0, s, T, w.nchunks,
+  hipLaunchKernelGGL(k_scan_chunks, dim3((T + kScanChunkTiles - 1) / kScanChunkTiles), dim3(1024), 0, s, T, w.nchunks,
                      w.cnt, w.tile_count);
   hipLaunchKernelGGL(k_scan_order_tiles, dim3(1), dim3(kScanThreads), 0, s, T, w.tile_count, w.tile_off, w.ctrl, cap, total_out,
                      w.tile_order, report);
@@ -898,7 +902,7 @@ int gsgen_frame_geometry_batch_zero(uint32_t n_views, const gsgen_geometry_view 
   } else {
     hipLaunchKernelGGL((k_bin_pull_views<false>), gpull, bpull, 0, s, N, (int)ntw, (int)nth, T, (const GeoView *)dv);
   }
-  hipLaunchKernelGGL(k_scan_chunks_views, dim3((T + 3) / 4, B), dim3(256), 0, s, T, nchunks, (const GeoView *)dv);
+  hipLaunchKernelGGL(k_scan_chunks_views, dim3((T + kScanChunkTiles - 1) / kScanChunkTiles, B), dim3(256), 0, s, T, nchunks, (const GeoView *)dv);
   hipLaunchKernelGGL(k_scan_order_tiles_views, dim3(1, B), dim3(kScanThreads), 0, s, T, (const GeoView *)dv);
   if (N && push)
     hipLaunchKernelGGL((k_bin_push_views<true>), gpush, bpush, sizeof(uint32_t) * T, s, N, (int)ntw, (int)nth, T, (const GeoView *)dv);

@@ -1,0 +1,341 @@
+// torch_batch.cpp -- the camera batch as ONE C++ autograd node (module `_gsbatch`, gsgen_amd/ext/_gsbatch.<abi>.so).
+//
+// Replaces, on the host side, what gsgen_amd/batch.py's torch.autograd.Functions do per call: the reference's camera loop
+// (gs/gaussian_splatting.py:1423-1466 over render_one :1198-1421) is one enqueue per stage here, and with 8 cameras those
+// enqueues are ~50 us of C-ABI calls -- the remaining 250 us of a step's host time were Python: the Function's forward and
+// backward, per-view ctypes field stores, tensor allocations through the Python API, the autograd engine re-acquiring the
+// GIL for a Python node (profiles/r05_host_profile_*.txt).  Here forward and backward are
+// torch::autograd::Function<> members: tensors are allocated with at::empty, the per-view pointers are written straight into
+// the view tables, the C-ABI entry points of include/gsgen_hip.h are called directly, and the engine runs the backward
+// without the GIL.
+//
+// State stays where it was: gsgen_amd.batch.BatchRenderer owns the slots, lists, workspaces, camera upload, overflow
+// handling and the one-forward-one-backward generation counter; it hands this file a Plan -- the host addresses of its
+// (ctypes) view tables and pointer tables, the device addresses of its workspaces, the shape -- built once per (kind, batch
+// size, list capacity).  BatchRenderer takes this path when the lists are sized, `strict` and `pipeline` are off and the module
+// is built; otherwise the Python Functions (same launches, same results).  No device code in this file (g++ builds it).
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+#include <torch/extension.h>
+
+#include "../../include/gsgen_hip.h"
+
+using torch::Tensor;
+using torch::autograd::AutogradContext;
+using torch::autograd::variable_list;
+
+namespace {
+
+void check_status(int rc, const char *fn) {
+  TORCH_CHECK(rc == 0, fn, " failed: ", gsgen_error_string(rc), " (code ", rc, ")");
+}
+#define GS(call) check_status((call), #call)
+
+gsgen_stream_t current_stream(const Tensor &t) {
+  return (gsgen_stream_t)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream();
+}
+
+enum Kind { kRgbd = 0, kRgb = 1, kSh = 2 };
+
+// What BatchRenderer built for one (kind, batch size, list capacity).  Addresses are plain integers from Python: the host
+// tables are ctypes arrays the renderer keeps alive (BatchRenderer._table_cache / _ptr_tabs), the device blocks are its tensors.
+// What a pending backward needs alive besides the Plan's own tensors: the renderer's host tables, its generation cell, the
+// slots' device buffers -- Python objects, released under the GIL wherever the last reference happens to drop (the autograd
+// engine's thread included).  The renderer itself is NOT among them (no reference cycle through the plan it caches).
+struct Keep {
+  pybind11::object o;
+  explicit Keep(pybind11::object x) : o(std::move(x)) {}
+  ~Keep() {
+    pybind11::gil_scoped_acquire gil;
+    o = pybind11::object();
+  }
+};
+
+struct Plan : std::enable_shared_from_this<Plan> {
+  int kind = kRgbd;
+  int64_t B = 0, N = 0, Np = 0, W = 0, H = 0, nth = 0, ntw = 0, segments = 1;
+  uintptr_t geo = 0, views = 0;  // gsgen_geometry_view[B], gsgen_rgbd_view[B] | gsgen_sh_view[B]  (host)
+  uintptr_t cam_tab = 0, mask_tab = 0, gmean_tab = 0, gcov_tab = 0, gchan_tab = 0, depth_tab = 0, cov2d_tab = 0;  // void*[B] (host)
+  uintptr_t gws = 0, bws = 0;    // device: the geometry launch's view table, the compositing launches' batch workspace
+  uintptr_t generation = 0;      // host int64: BatchRenderer's generation counter (a later render invalidates this batch's lists)
+  Tensor g2d, gch;               // the renderer's per-view gradient accumulators (zeroed again for a second backward)
+  std::shared_ptr<Keep> keep;
+};
+// a graph node's reference to its plan (kept in the node's saved_data as a capsule): a backward may run after the renderer
+// that built the plan is gone -- it then fails the generation check or runs on buffers this reference kept alive, never on
+// freed memory
+struct PlanRef : torch::CustomClassHolder {
+  std::shared_ptr<Plan> p;
+  explicit PlanRef(std::shared_ptr<Plan> x) : p(std::move(x)) {}
+};
+c10::IValue plan_ref(const Plan &p) {
+  return c10::IValue::make_capsule(c10::make_intrusive<PlanRef>(const_cast<Plan &>(p).shared_from_this()));
+}
+
+const char *kStale =
+    "gsgen_amd.BatchRenderer: another render() / render_heads() (or a regrown slot) came between this batch's forward and "
+    "its backward -- the lists the backward needs are gone. Call backward before the next render, or use one BatchRenderer "
+    "per batch in flight (e.g. for gradient accumulation or an evaluation render in between).";
+
+template <class T>
+T *tab(uintptr_t a) { return reinterpret_cast<T *>(a); }
+
+// optional tensor arguments travel through Function::apply as std::optional (an UNDEFINED at::Tensor argument would be taken for
+// a variable input and asked for its device)
+using OptT = c10::optional<Tensor>;
+Tensor opt(const OptT &t) { return (t.has_value() && t->defined()) ? *t : Tensor(); }
+
+Tensor bg_grad(const Tensor &g_rgb, const Tensor &T, const Tensor &bg) {
+  // d / d bg of rgb = ... + T * bg (gs/renderer.py:1283: nan_to_num(grad * T)), reduced to bg's shape
+  return at::nan_to_num(g_rgb * T).sum_to_size(bg.sizes());
+}
+
+// ---- rgb + depth + opacity + depth^2 (the trainer's default outputs) ---------------------------------------------------
+struct HeadsFn : public torch::autograd::Function<HeadsFn> {
+  static variable_list forward(AutogradContext *ctx, Tensor mean, Tensor qvec, Tensor svec, Tensor alpha, Tensor color,
+                               OptT bg_, int64_t plan_addr, double thresh, bool detach_depth, OptT max_radii2d_,
+                               OptT grad_accum_, OptT cnt_) {
+    const Plan &p = *reinterpret_cast<const Plan *>(plan_addr);
+    const Tensor bg = opt(bg_), max_radii2d = opt(max_radii2d_), grad_accum = opt(grad_accum_), cnt = opt(cnt_);
+    mean = mean.contiguous(); qvec = qvec.contiguous(); svec = svec.contiguous();
+    alpha = alpha.contiguous(); color = color.contiguous();
+    c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(mean.device());
+    const gsgen_stream_t s = current_stream(mean);
+    const int64_t B = p.B, H = p.H, W = p.W, N = p.N;
+    Tensor out6 = at::empty({B, H, W, 6}, mean.options());
+    Tensor T = at::empty({B, H, W, 1}, mean.options());
+    Tensor gsh = at::empty({p.Np}, mean.options());  // d L / d alpha, shared by the views: zeroed by the projection launch
+    gsgen_rgbd_view *v = tab<gsgen_rgbd_view>(p.views);
+    float *o = out6.data_ptr<float>(), *t = T.data_ptr<float>();
+    for (int64_t i = 0; i < B; ++i) { v[i].out6 = o + 6 * H * W * i; v[i].T = t + H * W * i; }
+    GS(gsgen_frame_geometry_batch_zero((uint32_t)B, tab<gsgen_geometry_view>(p.geo), (uint32_t)N, mean.data_ptr<float>(),
+                                       qvec.data_ptr<float>(), svec.data_ptr<float>(), (uint32_t)W, (uint32_t)H,
+                                       gsh.data_ptr<float>(), (size_t)p.Np, tab<void>(p.gws), s));
+    if (max_radii2d.defined())
+      GS(gsgen_densify_update_batch((uint32_t)B, (uint32_t)N, tab<const float *const>(p.cov2d_tab), nullptr,
+                                    tab<const uint8_t *const>(p.mask_tab), max_radii2d.data_ptr<float>(), nullptr, nullptr, s));
+    GS(gsgen_vol_render_rgbd_batch((uint32_t)B, v, (uint32_t)N, color.data_ptr<float>(), alpha.data_ptr<float>(), 16,
+                                   (uint32_t)p.nth, (uint32_t)p.ntw, (uint32_t)H, (uint32_t)W, (float)thresh, tab<void>(p.bws), s));
+    if (bg.defined()) out6.slice(-1, 0, 3).add_(T * bg);  // gs/renderer.py:1182
+    ctx->save_for_backward({mean, qvec, svec, alpha, color, out6, T, bg});
+    ctx->saved_data["plan"] = plan_addr;
+    ctx->saved_data["plan_ref"] = plan_ref(p);
+    ctx->saved_data["gen"] = *tab<const int64_t>(p.generation);
+    ctx->saved_data["thresh"] = thresh;
+    ctx->saved_data["detach"] = detach_depth;
+    ctx->saved_data["gsh"] = gsh;
+    ctx->saved_data["grad_accum"] = grad_accum;
+    ctx->saved_data["cnt"] = cnt;
+    ctx->mark_non_differentiable({T});
+    return {out6.slice(-1, 0, 3), out6.slice(-1, 3, 4), out6.slice(-1, 4, 5), out6.slice(-1, 5, 6), T};
+  }
+
+  static variable_list backward(AutogradContext *ctx, variable_list g) {
+    const int64_t plan_addr = ctx->saved_data["plan"].toInt();
+    const Plan &p = *reinterpret_cast<const Plan *>(plan_addr);
+    TORCH_CHECK(*tab<const int64_t>(p.generation) == ctx->saved_data["gen"].toInt(), kStale);
+    auto saved = ctx->get_saved_variables();
+    const Tensor &mean = saved[0], &qvec = saved[1], &svec = saved[2], &alpha = saved[3], &color = saved[4], &T = saved[6],
+                 &bg = saved[7];
+    c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(mean.device());
+    const gsgen_stream_t s = current_stream(mean);
+    const int64_t B = p.B, H = p.H, W = p.W, N = p.N;
+    Tensor parts[4];
+    for (int k = 0; k < 4; ++k)
+      if (g[k].defined()) parts[k] = g[k].contiguous();
+    Tensor gsh = ctx->saved_data["gsh"].toTensor();
+    if (ctx->saved_data.count("used")) {  // a second backward through the same graph (retain_graph): fresh accumulators
+      gsh = at::zeros({p.Np}, mean.options());
+      p.g2d.narrow(0, 0, B).zero_();
+      p.gch.narrow(0, 0, B).zero_();
+    }
+    ctx->saved_data["used"] = true;
+    Tensor g3d = at::empty({13 * N}, mean.options());  // mean | qvec | svec | colour: overwritten
+    Tensor g_mean = g3d.narrow(0, 0, 3 * N).view({N, 3}), g_qvec = g3d.narrow(0, 3 * N, 4 * N).view({N, 4});
+    Tensor g_svec = g3d.narrow(0, 7 * N, 3 * N).view({N, 3}), g_col = g3d.narrow(0, 10 * N, 3 * N).view({N, 3});
+    gsgen_rgbd_view *v = tab<gsgen_rgbd_view>(p.views);
+    const float *pp[4];
+    for (int k = 0; k < 4; ++k) pp[k] = parts[k].defined() ? parts[k].data_ptr<float>() : nullptr;
+    for (int64_t i = 0; i < B; ++i) {
+      v[i].grad_out6 = nullptr;
+      v[i].grad_rgb = pp[0] ? pp[0] + 3 * H * W * i : nullptr;
+      v[i].grad_depth = pp[1] ? pp[1] + H * W * i : nullptr;
+      v[i].grad_opacity = pp[2] ? pp[2] + H * W * i : nullptr;
+      v[i].grad_depth2 = pp[3] ? pp[3] + H * W * i : nullptr;
+    }
+    GS(gsgen_vol_render_rgbd_backward_batch((uint32_t)B, v, (uint32_t)N, color.data_ptr<float>(), alpha.data_ptr<float>(),
+                                            gsh.data_ptr<float>(), 16, (uint32_t)p.nth, (uint32_t)p.ntw, (uint32_t)H, (uint32_t)W,
+                                            (float)ctx->saved_data["thresh"].toDouble(), tab<void>(p.bws), s));
+    GS(gsgen_project_gaussians_backward_batch_heads(
+        (uint32_t)B, (uint32_t)N, mean.data_ptr<float>(), qvec.data_ptr<float>(), svec.data_ptr<float>(),
+        tab<const float *const>(p.cam_tab), ctx->saved_data["detach"].toBool() ? 1 : 0, tab<const uint8_t *const>(p.mask_tab),
+        tab<const float *const>(p.gmean_tab), tab<const float *const>(p.gcov_tab), tab<const float *const>(p.gchan_tab),
+        tab<const float *const>(p.depth_tab), g_mean.data_ptr<float>(), g_qvec.data_ptr<float>(), g_svec.data_ptr<float>(),
+        g_col.data_ptr<float>(), s));
+    const auto &ga = ctx->saved_data["grad_accum"];
+    if (ga.isTensor() && ga.toTensor().defined()) {
+      Tensor acc = ga.toTensor(), cnt = ctx->saved_data["cnt"].toTensor();
+      GS(gsgen_densify_update_batch((uint32_t)B, (uint32_t)N, nullptr, tab<const float *const>(p.gmean_tab),
+                                    tab<const uint8_t *const>(p.mask_tab), nullptr, acc.data_ptr<float>(),
+                                    cnt.defined() ? cnt.data_ptr<float>() : nullptr, s));
+    }
+    Tensor g_bg;
+    if (bg.defined() && ctx->needs_input_grad(5) && g[0].defined()) g_bg = bg_grad(g[0], T, bg);
+    return {g_mean, g_qvec, g_svec, gsh.narrow(0, 0, N), g_col, g_bg, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+  }
+};
+
+// ---- rgb (+ T) from SH coefficients (C = 1..4) or post-activation colours (C = 0) ----------------------------------------
+struct RenderFn : public torch::autograd::Function<RenderFn> {
+  static variable_list forward(AutogradContext *ctx, Tensor mean, Tensor qvec, Tensor svec, Tensor alpha, Tensor col, OptT bg_,
+                               int64_t plan_addr, int64_t C, double thresh, bool detach_depth, OptT sh_bound_, OptT sh_rows_,
+                               OptT max_radii2d_, OptT grad_accum_, OptT cnt_) {
+    const Plan &p = *reinterpret_cast<const Plan *>(plan_addr);
+    const Tensor bg = opt(bg_), sh_bound = opt(sh_bound_), sh_rows = opt(sh_rows_), max_radii2d = opt(max_radii2d_),
+                 grad_accum = opt(grad_accum_), cnt = opt(cnt_);
+    TORCH_CHECK((C > 0) == (p.kind == kSh), "plan / C mismatch");
+    mean = mean.contiguous(); qvec = qvec.contiguous(); svec = svec.contiguous();
+    alpha = alpha.contiguous(); col = col.contiguous();
+    c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(mean.device());
+    const gsgen_stream_t s = current_stream(mean);
+    const int64_t B = p.B, H = p.H, W = p.W, N = p.N;
+    Tensor out = at::empty({B, H, W, 3}, mean.options());
+    Tensor T = at::empty({B, H, W, 1}, mean.options());
+    const int64_t ncol4 = (col.numel() + 3) / 4 * 4;
+    Tensor gsh = at::empty({p.Np + ncol4}, mean.options());  // d L / d alpha [N] | d L / d col: zeroed by the projection launch
+    float *o = out.data_ptr<float>(), *t = T.data_ptr<float>();
+    if (p.kind == kSh) {
+      gsgen_sh_view *v = tab<gsgen_sh_view>(p.views);
+      const float *bgp = bg.defined() ? bg.data_ptr<float>() : nullptr;
+      for (int64_t i = 0; i < B; ++i) { v[i].out = o + 3 * H * W * i; v[i].T = t + H * W * i; v[i].bg_rgb = bgp; }
+    } else {
+      gsgen_rgbd_view *v = tab<gsgen_rgbd_view>(p.views);
+      for (int64_t i = 0; i < B; ++i) { v[i].out6 = o + 3 * H * W * i; v[i].T = t + H * W * i; }
+    }
+    GS(gsgen_frame_geometry_batch_zero((uint32_t)B, tab<gsgen_geometry_view>(p.geo), (uint32_t)N, mean.data_ptr<float>(),
+                                       qvec.data_ptr<float>(), svec.data_ptr<float>(), (uint32_t)W, (uint32_t)H,
+                                       gsh.data_ptr<float>(), (size_t)gsh.numel(), tab<void>(p.gws), s));
+    if (max_radii2d.defined())
+      GS(gsgen_densify_update_batch((uint32_t)B, (uint32_t)N, tab<const float *const>(p.cov2d_tab), nullptr,
+                                    tab<const uint8_t *const>(p.mask_tab), max_radii2d.data_ptr<float>(), nullptr, nullptr, s));
+    if (p.kind == kSh) {
+      GS(gsgen_vol_render_sh_batch_routed((uint32_t)B, tab<gsgen_sh_view>(p.views), (uint32_t)N, col.data_ptr<float>(),
+                                          alpha.data_ptr<float>(), 16, (uint32_t)p.nth, (uint32_t)p.ntw, (uint32_t)H, (uint32_t)W,
+                                          (uint32_t)C, (float)thresh, (uint32_t)p.segments,
+                                          sh_bound.defined() ? sh_bound.data_ptr<float>() : nullptr,
+                                          sh_rows.defined() ? sh_rows.data_ptr<float>() : nullptr, tab<void>(p.bws), s));
+    } else {
+      GS(gsgen_vol_render_rgb_batch((uint32_t)B, tab<gsgen_rgbd_view>(p.views), (uint32_t)N, col.data_ptr<float>(),
+                                    alpha.data_ptr<float>(), 16, (uint32_t)p.nth, (uint32_t)p.ntw, (uint32_t)H, (uint32_t)W,
+                                    (float)thresh, tab<void>(p.bws), s));
+      if (bg.defined()) {
+        out = out + T * bg;  // gs/renderer.py:1182; `out` (saved below) is what the backward reads as final
+        gsgen_rgbd_view *v = tab<gsgen_rgbd_view>(p.views);
+        float *o2 = out.data_ptr<float>();
+        for (int64_t i = 0; i < B; ++i) v[i].out6 = o2 + 3 * H * W * i;
+      }
+    }
+    ctx->save_for_backward({mean, qvec, svec, alpha, col, out, T, bg, sh_bound, sh_rows});
+    ctx->saved_data["plan"] = plan_addr;
+    ctx->saved_data["plan_ref"] = plan_ref(p);
+    ctx->saved_data["gen"] = *tab<const int64_t>(p.generation);
+    ctx->saved_data["C"] = C;
+    ctx->saved_data["thresh"] = thresh;
+    ctx->saved_data["detach"] = detach_depth;
+    ctx->saved_data["gsh"] = gsh;
+    ctx->saved_data["grad_accum"] = grad_accum;
+    ctx->saved_data["cnt"] = cnt;
+    ctx->mark_non_differentiable({T});
+    return {out, T};
+  }
+
+  static variable_list backward(AutogradContext *ctx, variable_list g) {
+    const int64_t plan_addr = ctx->saved_data["plan"].toInt();
+    const Plan &p = *reinterpret_cast<const Plan *>(plan_addr);
+    TORCH_CHECK(*tab<const int64_t>(p.generation) == ctx->saved_data["gen"].toInt(), kStale);
+    auto saved = ctx->get_saved_variables();
+    const Tensor &mean = saved[0], &qvec = saved[1], &svec = saved[2], &alpha = saved[3], &col = saved[4], &T = saved[6],
+                 &bg = saved[7], &sh_bound = saved[8], &sh_rows = saved[9];
+    c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(mean.device());
+    const gsgen_stream_t s = current_stream(mean);
+    const int64_t B = p.B, H = p.H, W = p.W, N = p.N, C = ctx->saved_data["C"].toInt();
+    const float thresh = (float)ctx->saved_data["thresh"].toDouble();
+    Tensor grad = g[0].contiguous();
+    const int64_t ncol4 = (col.numel() + 3) / 4 * 4;
+    Tensor gsh = ctx->saved_data["gsh"].toTensor();
+    if (ctx->saved_data.count("used")) {  // a second backward through the same graph (retain_graph): fresh accumulators
+      gsh = at::zeros({p.Np + ncol4}, mean.options());
+      p.g2d.narrow(0, 0, B).zero_();
+    }
+    ctx->saved_data["used"] = true;
+    Tensor g_alpha = gsh.narrow(0, 0, N), g_col = gsh.narrow(0, p.Np, col.numel()).view(col.sizes());
+    Tensor g3d = at::empty({10 * N}, mean.options());  // mean | qvec | svec: overwritten
+    Tensor g_mean = g3d.narrow(0, 0, 3 * N).view({N, 3}), g_qvec = g3d.narrow(0, 3 * N, 4 * N).view({N, 4});
+    Tensor g_svec = g3d.narrow(0, 7 * N, 3 * N).view({N, 3});
+    const float *gp = grad.data_ptr<float>();
+    if (p.kind == kSh) {
+      gsgen_sh_view *v = tab<gsgen_sh_view>(p.views);
+      for (int64_t i = 0; i < B; ++i) v[i].grad_out = gp + 3 * H * W * i;
+      GS(gsgen_vol_render_backward_sh_batch_routed(
+          (uint32_t)B, v, (uint32_t)N, col.data_ptr<float>(), alpha.data_ptr<float>(), g_col.data_ptr<float>(),
+          g_alpha.data_ptr<float>(), 16, (uint32_t)p.nth, (uint32_t)p.ntw, (uint32_t)H, (uint32_t)W, (uint32_t)C, thresh,
+          (uint32_t)p.segments, sh_bound.defined() ? sh_bound.data_ptr<float>() : nullptr,
+          sh_rows.defined() ? sh_rows.data_ptr<float>() : nullptr, tab<void>(p.bws), s));
+    } else {
+      gsgen_rgbd_view *v = tab<gsgen_rgbd_view>(p.views);
+      for (int64_t i = 0; i < B; ++i) v[i].grad_out6 = gp + 3 * H * W * i;
+      GS(gsgen_vol_render_rgb_backward_batch((uint32_t)B, v, (uint32_t)N, col.data_ptr<float>(), alpha.data_ptr<float>(),
+                                             g_col.data_ptr<float>(), g_alpha.data_ptr<float>(), 16, (uint32_t)p.nth,
+                                             (uint32_t)p.ntw, (uint32_t)H, (uint32_t)W, thresh, tab<void>(p.bws), s));
+    }
+    GS(gsgen_project_gaussians_backward_batch(
+        (uint32_t)B, (uint32_t)N, mean.data_ptr<float>(), qvec.data_ptr<float>(), svec.data_ptr<float>(),
+        tab<const float *const>(p.cam_tab), ctx->saved_data["detach"].toBool() ? 1 : 0, tab<const uint8_t *const>(p.mask_tab),
+        tab<const float *const>(p.gmean_tab), tab<const float *const>(p.gcov_tab), nullptr, g_mean.data_ptr<float>(),
+        g_qvec.data_ptr<float>(), g_svec.data_ptr<float>(), s));
+    const auto &ga = ctx->saved_data["grad_accum"];
+    if (ga.isTensor() && ga.toTensor().defined()) {
+      Tensor acc = ga.toTensor(), cnt = ctx->saved_data["cnt"].toTensor();
+      GS(gsgen_densify_update_batch((uint32_t)B, (uint32_t)N, nullptr, tab<const float *const>(p.gmean_tab),
+                                    tab<const uint8_t *const>(p.mask_tab), nullptr, acc.data_ptr<float>(),
+                                    cnt.defined() ? cnt.data_ptr<float>() : nullptr, s));
+    }
+    Tensor g_bg;
+    if (bg.defined() && ctx->needs_input_grad(5)) g_bg = bg_grad(grad, T, bg);
+    return {g_mean, g_qvec, g_svec, g_alpha, g_col, g_bg, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(),
+            Tensor(), Tensor()};
+  }
+};
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+  m.doc() = "gsgen_amd: the camera batch as one C++ autograd node over the C ABI of libgsgen_hip.so (see gsgen_amd/batch.py)";
+  pybind11::class_<Plan, std::shared_ptr<Plan>>(m, "Plan")
+      .def(pybind11::init([](int kind, int64_t B, int64_t N, int64_t Np, int64_t W, int64_t H, int64_t nth, int64_t ntw,
+                             int64_t segments, uintptr_t geo, uintptr_t views, uintptr_t cam_tab, uintptr_t mask_tab,
+                             uintptr_t gmean_tab, uintptr_t gcov_tab, uintptr_t gchan_tab, uintptr_t depth_tab, uintptr_t cov2d_tab,
+                             uintptr_t gws, uintptr_t bws, uintptr_t generation, Tensor g2d, c10::optional<Tensor> gch,
+                             pybind11::object keep) {
+        auto sp = std::make_shared<Plan>();
+        Plan &p = *sp;
+        p.kind = kind; p.B = B; p.N = N; p.Np = Np; p.W = W; p.H = H; p.nth = nth; p.ntw = ntw; p.segments = segments;
+        p.geo = geo; p.views = views; p.cam_tab = cam_tab; p.mask_tab = mask_tab; p.gmean_tab = gmean_tab; p.gcov_tab = gcov_tab;
+        p.gchan_tab = gchan_tab; p.depth_tab = depth_tab; p.cov2d_tab = cov2d_tab; p.gws = gws; p.bws = bws;
+        p.generation = generation; p.g2d = g2d; p.gch = opt(gch);
+        p.keep = std::make_shared<Keep>(std::move(keep));
+        return sp;
+      }))
+      .def("address", [](const Plan &p) { return (int64_t) reinterpret_cast<uintptr_t>(&p); });
+  m.def("render_heads", [](int64_t plan, Tensor mean, Tensor qvec, Tensor svec, Tensor alpha, Tensor color, c10::optional<Tensor> bg,
+                           double thresh, bool detach_depth, c10::optional<Tensor> max_radii2d, c10::optional<Tensor> grad_accum,
+                           c10::optional<Tensor> cnt) {
+    return HeadsFn::apply(mean, qvec, svec, alpha, color, bg, plan, thresh, detach_depth, max_radii2d, grad_accum, cnt);
+  }, "-> [rgb, depth, opacity, depth2, T]");
+  m.def("render", [](int64_t plan, Tensor mean, Tensor qvec, Tensor svec, Tensor alpha, Tensor col, c10::optional<Tensor> bg, int64_t C,
+                     double thresh, bool detach_depth, c10::optional<Tensor> sh_bound, c10::optional<Tensor> sh_rows,
+                     c10::optional<Tensor> max_radii2d, c10::optional<Tensor> grad_accum, c10::optional<Tensor> cnt) {
+    return RenderFn::apply(mean, qvec, svec, alpha, col, bg, plan, C, thresh, detach_depth, sh_bound, sh_rows, max_radii2d, grad_accum,
+                           cnt);
+  }, "-> [rgb, T]");
+}

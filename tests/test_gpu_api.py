@@ -1024,3 +1024,87 @@ def test_pair_count_beyond_32_bits_reads_as_overflow_not_as_a_small_number():
     with pytest.raises(Exception, match="invalid argument"):
         L.tile_culling_aabb_start_end(4, 0x80000000, 2, 2, p(buf.ids), p(buf.ids), p(buf.depth), p(buf.ids), p(buf.start), p(buf.end),
                                       p(ws), ws.numel(), torch.cuda.current_stream().cuda_stream)
+
+
+@pytest.mark.parametrize("kind", ["heads", "sh", "rgb"])
+def test_cpp_autograd_node_equals_the_python_functions(kind):
+    """BatchRenderer's fast path -- the camera batch as ONE C++ autograd node (csrc/torch_batch.cpp -> gsgen_amd/ext/_gsbatch) --
+    against its Python autograd Functions (use_ext = False): the same launches, so images bit for bit, gradients to the order
+    of the atomics, densify statistics, background gradient; a second backward through a retained graph; the stale-backward
+    error; and a backward that runs after the renderer itself has been dropped (the node keeps what it needs alive)."""
+    import gc
+    from gsgen_amd import renderer as R
+    from gsgen_amd import batch as Bm
+    assert Bm._batch_ext() is not None, "gsgen_amd/ext/_gsbatch.*.so is not built (python -m gsgen_amd.build --ext)"
+    C = {"heads": 0, "sh": 4, "rgb": 0}[kind]
+    sc = scenes.random_scene(4000, seed=8, svec=0.03, C=max(C, 1))
+    if C == 4:
+        sc["sh"][:, :, 1:] *= 0.3
+    N, W, H, B = sc["mean"].shape[0], 144, 96, 3
+    cams = [scenes.Camera(W, H, fx=230.0 + 20 * i, c2w=scenes.orbit(2.4, 5 + 12 * i, 50.0 + 100 * i)) for i in range(B)]
+    cis, c2ws = [R.CameraInfo(*c.intr) for c in cams], [c.c2w for c in cams]
+    ck = "sh" if C > 0 else "color"
+    keys = ("mean", "qvec", "svec", "alpha", ck)
+    gen = torch.Generator(device=dev()).manual_seed(3)
+    gos = [torch.randn(B, H, W, c, device=dev(), generator=gen) for c in ((3, 1, 1, 1) if kind == "heads" else (3,))]
+
+    def run(use_ext):
+        P_ = {k: T_(sc[k]).requires_grad_(True) for k in keys}
+        bg = torch.tensor([0.2, 0.5, 0.7], device=dev(), requires_grad=True)
+        br = Bm.BatchRenderer(N, W, H, dev(), max_batch=B)
+        br.use_ext = use_ext
+        stats = R.DensifyStats(N, dev())
+        outs = None
+        for _ in range(2):  # (the first batch sizes the lists synchronously: Python path either way; the second is the one compared)
+            for v in list(P_.values()) + [bg]:
+                v.grad = None
+            stats = R.DensifyStats(N, dev())
+            if kind == "heads":
+                outs = br.render_heads(P_["mean"], P_["qvec"], P_["svec"], P_["alpha"], P_[ck], cis, c2ws, bg_rgb=bg, stats=stats)
+            else:
+                outs = br.render(P_["mean"], P_["qvec"], P_["svec"], P_["alpha"], P_[ck], cis, c2ws, C=C, bg_rgb=bg, stats=stats)
+            if _ > 0:  # which autograd node rendered this batch
+                name = outs[0].grad_fn.name()
+                assert (("HeadsFn" if kind == "heads" else "RenderFn") in name) == use_ext, name
+            loss = sum((o * g_).sum() for o, g_ in zip(outs, gos))
+            loss.backward(retain_graph=True)
+        g1 = {k: P_[k].grad.clone() for k in keys}
+        for v in list(P_.values()) + [bg]:
+            v.grad = None
+        loss.backward()  # a second backward through the retained graph: fresh accumulators, the same gradients
+        for k in keys:
+            assert rel_err(P_[k].grad.cpu().numpy(), g1[k].cpu().numpy()) < 1e-4, k
+        return br, P_, bg, stats, [o.detach().clone() for o in outs], g1
+
+    br_e, Pe, bge, se, oe, ge = run(True)
+    br_p, Pp, bgp, sp, op, gp = run(False)
+    for a, b in zip(oe, op):
+        assert torch.equal(a, b)
+    for k in keys:
+        assert rel_err(ge[k].cpu().numpy(), gp[k].cpu().numpy()) < 1e-4, k
+    assert torch.allclose(bge.grad, bgp.grad, rtol=1e-5, atol=1e-5)
+    assert torch.equal(se.max_radii2d, sp.max_radii2d) and torch.equal(se.cnt, sp.cnt)
+    assert rel_err(se.grad_accum.cpu().numpy(), sp.grad_accum.cpu().numpy()) < 1e-5
+    # stale backward: a later render through the same renderer invalidates the pending one (the C++ node raises the same error)
+    f = (lambda: br_e.render_heads(Pe["mean"], Pe["qvec"], Pe["svec"], Pe["alpha"], Pe[ck], cis, c2ws)[0]) if kind == "heads" else \
+        (lambda: br_e.render(Pe["mean"], Pe["qvec"], Pe["svec"], Pe["alpha"], Pe[ck], cis, c2ws, C=C)[0])
+    a, b = f(), f()
+    with pytest.raises(RuntimeError, match="between this batch's forward and its backward"):
+        a.sum().backward()
+    b.sum().backward()
+    # the renderer dropped before the backward: the node holds the tables and buffers it needs
+    for v in Pe.values():
+        v.grad = None
+    f().sum().backward()
+    want = {k: Pe[k].grad.clone() for k in keys}
+    for v in Pe.values():
+        v.grad = None
+    c = f()
+    del br_e, f, a, b
+    gc.collect()
+    junk = [torch.randn(1 << 20, device=dev()) for _ in range(8)]  # (whatever was freed would be handed out again here)
+    c.sum().backward()
+    torch.cuda.synchronize()
+    for k in keys:
+        assert rel_err(Pe[k].grad.cpu().numpy(), want[k].cpu().numpy()) < 1e-4, k
+    del junk

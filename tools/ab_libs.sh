@@ -13,7 +13,7 @@ for l in sys.stdin:
     if l.startswith('{'):
         r=json.loads(l); ro=r['roofline']; o=r.get('one_render_in_flight') or {}
         print('$v', 'round $r:', round(r['value'],1),'renders/s  bwd alone',round(ro['alone_launch_ms'],4),'fwd alone',round(ro['alone_fwd_launch_ms'],4),
-              'one-render', round(o.get('value',0),1), 'graph', round((o.get('hipgraph_replay') or {}).get('value',0),1), 'exact', round((r.get('exact_basis') or {}).get('value',0)))
+              'one-step', round((r.get('one_step_in_flight') or {}).get('value',0),1), 'heads', round((r.get('heads_path') or {}).get('value',0),1), 'one-render', round(o.get('value',0),1), 'graph', round((o.get('hipgraph_replay') or {}).get('value',0),1), 'exact', round((r.get('exact_basis') or {}).get('value',0)))
 " >> $out
   done
 done
