@@ -125,7 +125,7 @@ def heads_alg_bytes(N, D, P, T):
 def committed_traffic(config, kernel, views):
     """HBM bytes per launch of `kernel` from committed PMC passes (profiles/rNN_traffic.json), if they are of THIS kernel,
     workload and launch shape: (bytes, valu_floor_ms, source) or (None, None, None)"""
-    for fn_ in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json"):
+    for fn_ in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json"):
         try:
             ent = json.load(open(os.path.join(ROOT, "profiles", fn_))).get(f"{config}|{kernel}|views={views}")
         except Exception:
@@ -140,7 +140,7 @@ def committed_traffic(config, kernel, views):
 def committed_trace_ms(config, fragment, suffix=""):
     """the kernel's average duration in the committed rocprofv3 kernel trace of this command (--only-timed)"""
     import csv
-    for rnd in ("r04", "r03"):
+    for rnd in ("r05", "r04", "r03"):
         fn_ = os.path.join(ROOT, "profiles", f"{rnd}_bench_{config}{suffix}_kernel_stats.csv")
         try:
             for row in csv.DictReader(open(fn_)):
@@ -518,6 +518,10 @@ def main():
     d_probe = max(1, int(pb.total.item()))
     del pb, tp
     B, auto_slots = choose_batch_and_slots(d_probe, args.batch, args.slots)
+    # the pair lists start at 1.5 x the probe camera's count (the sizing pass below still grows them where a camera needs more):
+    # no launch of the run, sizing pass included, works on an overflowed -- empty -- frame, so per-launch averages of a
+    # profiler run over this process are not diluted by launches that do nothing
+    cap0 = int(1.5 * d_probe) + 4096
     if dist is not None:  # one shape for the job (the gathered tensor is [world, B, H, W, 3])
         bt = torch.tensor([B, auto_slots], device=dev)
         dist.broadcast(bt, 0)
@@ -558,7 +562,7 @@ def main():
             self.geo_stream = gpu.Stream(dev, priority=-1) if args.geo_priority else stream
             self.e_geo, self.e_done, self.started = gpu.Event(), gpu.Event(), False
             with gpu.stream(stream):
-                self.bufs = [R.FrameBuffers(N, W, H, dev) for _ in range(B)]
+                self.bufs = [R.FrameBuffers(N, W, H, dev, D_cap=cap0) for _ in range(B)]
                 self.out = torch.empty(B, H, W, 3, device=dev)
                 # per view: mean2d(2) | cov2d(4); shared: alpha(1) | sh -- zeroed once per step (by the projection launch
                 # of the step's geometry, or by a torch fill with --torch-fill); the projection backward overwrites
@@ -1297,6 +1301,11 @@ def main():
         # SIMD issued its share of the measured vector instructions back to back
         res["roofline"]["valu_floor_ms"] = valu_floor
         res["roofline"]["alone_valu_frac"] = valu_floor / alone["bwd_launch_ms"]
+    f_traffic, f_floor, _ = committed_traffic(args.config, fwd_name, B)  # ... and the same for the forward
+    if f_floor is not None:
+        res["roofline"]["fwd_traffic"] = f_traffic
+        res["roofline"]["fwd_valu_floor_ms"] = f_floor
+        res["roofline"]["alone_fwd_valu_frac"] = f_floor / alone["fwd_launch_ms"]
     if no_gather is not None:
         res["value_no_gather"] = no_gather["value"]
         res["no_gather"] = dict(no_gather, gather_cost_fraction=1.0 - value / no_gather["value"],

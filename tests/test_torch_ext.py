@@ -202,3 +202,16 @@ def test_compiled_module_agrees_with_the_ctypes_mirror_and_is_cheap_to_call(ext)
     # (at SH degree 3 a call is three enqueues: the 4-byte clear and the pass that measure the coefficient bound, then the
     # routed compositing kernel)
     assert cost["compiled"] < 20.0 and cost["compiled"] < cost["ctypes"], cost
+
+
+def test_batch_node_module_builds_and_exports_its_surface():
+    """gsgen_amd/ext/_gsbatch.*.so (csrc/torch_batch.cpp: the camera batch as one C++ autograd node, BatchRenderer's fast path):
+    built by gsgen_amd.build.build_batch_ext and __graft_entry__.build(), loadable without a GPU, exporting what batch.py calls"""
+    from gsgen_amd import build, batch
+    assert os.path.exists(build.build_batch_ext())
+    mod = batch._batch_ext()
+    assert mod is not None and callable(mod.render) and callable(mod.render_heads) and hasattr(mod, "Plan")
+    import numpy as np
+    gen = np.zeros(1, np.int64)
+    plan = mod.Plan(0, 2, 10, 12, 32, 16, 1, 2, 1, *([0] * 11), gen.ctypes.data, torch.zeros(2, 6 * 12), None, [gen])
+    assert plan.address() != 0
