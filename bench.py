@@ -929,7 +929,9 @@ def main():
           "pid": os.getpid(), "cameras": ncam, "renders_per_s": B * K / med["el_local"]}
     if not dry:
         try:
-            me["pci_bus_id"] = torch.cuda.get_device_properties(dev).pci_bus_id
+            pr_ = torch.cuda.get_device_properties(dev)
+            me["arch"], me["compute_units"] = getattr(pr_, "gcnArchName", None), getattr(pr_, "multi_processor_count", None)
+            me["pci_bus_id"] = pr_.pci_bus_id
         except Exception:
             pass
     ranks_view = [me]

@@ -815,7 +815,7 @@ int gsgen_selftest_reduce_scatter(uint32_t P, const float *in /*[64,P]*/, float 
 
 const char *gsgen_error_string(int code) {
   if (code == 0) return "success";
-  if (code == GSGEN_EUNSUPPORTED) return "unsupported configuration (tile_size 8 | 16 | 32 -- 16 only for the batched / segmented / fused entry points --, C in 1..4)";
+  if (code == GSGEN_EUNSUPPORTED) return "unsupported configuration (tile_size 1 .. 32 -- 16 only for the batched / segmented / fused entry points --, C in 1..4)";
   if (code == GSGEN_EINVAL) return "invalid argument (null pointer or inconsistent sizes)";
   if (code == GSGEN_EWORKSPACE) return "workspace too small";
   if (code > 0) return hipGetErrorString((hipError_t)code);

@@ -153,7 +153,7 @@ __device__ __forceinline__ uint32_t batch_view(const CompParams &p_arg, uint32_t
   return batch_view(p_arg, bid, grid, gridDim.x);
 }
 
-// TS: tile side.  16 everywhere in this library's own pipeline; 8 and 32 exist for callers of the `_gs` entry points
+// TS: tile side.  16 everywhere in this library's own pipeline; 8 and 32 (= every other side from 1 to 32) exist for callers of the `_gs` entry points
 // that configure another `tile_size` (the reference takes it as a parameter, conf/base.yaml:132; its launch is
 // tile_size x tile_size threads, vol_render.h:1001-1004): TS = 8 runs one wavefront per tile (PPL = 1), TS = 32 four
 // wavefronts at 4 pixels per lane.  Per-pixel results do not depend on the tile size.
@@ -177,14 +177,17 @@ __global__ void __launch_bounds__(TS * TS / PPL) k_composite_fwd(CompParams p) {
   const int n = (st < 0) ? 0 : (p.end[tile] - st);
   const int t = (int)threadIdx.x;
   const int lx = t % TS, ly0 = t / TS;
-  const int gx = tx * TS + lx;
+  // TS = 32 serves every caller tile side that is not 8 or 16 (1 .. 32): the workgroup covers a 32 x 32 patch of which the
+  // caller's side x side tile is the top-left part; the threads beyond it own no pixel
+  const int side = (TS == 32) ? p.tile_side : TS;
+  const int gx = tx * side + lx;
 
   bool valid[PPL];
   int gy[PPL];
 #pragma unroll
   for (int j = 0; j < PPL; ++j) {
-    gy[j] = ty * TS + ly0 + j * ROWS;
-    valid[j] = (gx < p.W) && (gy[j] < p.H);
+    gy[j] = ty * side + ly0 + j * ROWS;
+    valid[j] = (gx < p.W) && (gy[j] < p.H) && (TS != 32 || (lx < side && ly0 + j * ROWS < side));
   }
 
   if (st == kListOverflow) {  // the frame's pairs did not fit the list (GSGEN_LIST_OVERFLOW): never a finite blank tile
@@ -914,7 +917,8 @@ k_composite_bwd_pixel(CompParams p) {
   const int t = (int)threadIdx.x;
   const int lane = t & 63;
   const int lx = t % TS, ly0 = t / TS;
-  const int gx = tx * TS + lx;
+  const int side = (TS == 32) ? p.tile_side : TS;  // (TS = 32: any caller tile side that is not 8 or 16, see k_composite_fwd)
+  const int gx = tx * side + lx;
 
   bool valid[PPL];
   int gy[PPL];
@@ -922,8 +926,8 @@ k_composite_bwd_pixel(CompParams p) {
   const float px = pixel_coord(p.topleft[0], gx, p.psx);
 #pragma unroll
   for (int j = 0; j < PPL; ++j) {
-    gy[j] = ty * TS + ly0 + j * ROWS;
-    valid[j] = (gx < p.W) && (gy[j] < p.H);
+    gy[j] = ty * side + ly0 + j * ROWS;
+    valid[j] = (gx < p.W) && (gy[j] < p.H) && (TS != 32 || (lx < side && ly0 + j * ROWS < side));
     py[j] = pixel_coord(p.topleft[1], gy[j], p.psy);
   }
 
@@ -1982,7 +1986,7 @@ static int launch_fwd(const CompParams &p_, hipStream_t s) {
   CompParams p = p_;
   const uint32_t nblk = comp_grid(p);
   if (p.ntw * p.nth == 0) return 0;
-  if (p.tile_side == 8 || p.tile_side == 32) {  // a caller's own tile size: one fixed shape of the unpacked kernel
+  if (p.tile_side != 16) {  // a caller's own tile size (1 .. 32): the unpacked kernel at one wavefront (8) or four per tile (a 32 x 32 patch)
     if constexpr (MODE == MODE_RGBD) return GSGEN_EUNSUPPORTED;
     else {
       if (p.nseg > 1) return GSGEN_EUNSUPPORTED;
@@ -2011,7 +2015,7 @@ static int launch_bwd(const CompParams &p_, hipStream_t s) {
   if (p.n_hi == 0) p.n_hi = 0x7fffffff;
   const uint32_t nblk = comp_grid(p);
   if (p.ntw * p.nth == 0) return 0;
-  if (p.tile_side == 8 || p.tile_side == 32) {  // a caller's own tile size: one fixed shape of the unpacked kernel
+  if (p.tile_side != 16) {  // a caller's own tile size (1 .. 32): the unpacked kernel at one wavefront (8) or four per tile (a 32 x 32 patch)
     if constexpr (MODE == MODE_RGBD) return GSGEN_EUNSUPPORTED;
     else {
       if (p.nseg > 1) return GSGEN_EUNSUPPORTED;

@@ -455,7 +455,7 @@ __device__ __forceinline__ void poly_transform(const float *__restrict__ sh, con
 
 // tile_size: 16 (every kernel variant) or 8 / 32 (the unpacked vector kernels at one fixed shape; no segments, no batch)
 static inline int check_common(uint32_t tile_size, const void *a, const void *b, const void *c) {
-  if (tile_size != 8u && tile_size != 16u && tile_size != 32u) return GSGEN_EUNSUPPORTED;
+  if (tile_size < 1u || tile_size > 32u) return GSGEN_EUNSUPPORTED;  // (the reference launches tile_size^2 <= 1024 threads per tile)
   if (!a || !b || !c) return GSGEN_EINVAL;
   return 0;
 }

@@ -436,9 +436,10 @@ __device__ __forceinline__ int to_i32_trunc(float v) {
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 struct Rect { int x0, y0, x1, y1; };
-// shift = log2(tile side): 4 in this library's own pipeline; the `_gs` entry point also takes 8 (3) and 32 (5)
+// shift = log2(tile side): 4 in this library's own pipeline; the `_gs` entry point takes any side 1 .. 32 (side > 0: a division
+// by a side that is no power of two -- gs/culling.py:27-30 divides by whatever tile_size the config holds)
 __device__ __forceinline__ Rect tile_rect(float m2x, float m2y, float c00, float c11, float Dr,
-                                          float fx, float fy, float cx, float cy, int w, int h, int shift = 4) {
+                                          float fx, float fy, float cx, float cy, int w, int h, int shift = 4, int side = 0) {
   const float ax = sqrtf(Dr * c00), ay = sqrtf(Dr * c11);
   const float tlx = m2x - ax, tly = m2y - ay, brx = m2x + ax, bry = m2y + ay;
   float m;
@@ -449,20 +450,21 @@ __device__ __forceinline__ Rect tile_rect(float m2x, float m2y, float c00, float
   px0 = clampi(px0, 0, w - 1); px1 = clampi(px1, 0, w - 1);
   py0 = clampi(py0, 0, h - 1); py1 = clampi(py1, 0, h - 1);
   Rect r;  // clamped pixels are >= 0, so floor division == shift
+  if (side > 0) { r.x0 = px0 / side; r.y0 = py0 / side; r.x1 = px1 / side; r.y1 = py1 / side; return r; }
   r.x0 = px0 >> shift; r.y0 = py0 >> shift; r.x1 = px1 >> shift; r.y1 = py1 >> shift;
   return r;
 }
 
 __global__ void __launch_bounds__(kThreads)
 k_aabb_count(uint32_t N, const float *__restrict__ mean2d, const float *__restrict__ cov2d,
-             float fx, float fy, float cx, float cy, int w, int h, float Dr, int shift,
+             float fx, float fy, float cx, float cy, int w, int h, float Dr, int shift, int side,
              int *__restrict__ tl, int *__restrict__ br, uint32_t *__restrict__ total) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t cnt = 0;
   if (i < N) {
     const float2 m = *reinterpret_cast<const float2 *>(mean2d + 2 * (size_t)i);
     const float4 c = *reinterpret_cast<const float4 *>(cov2d + 4 * (size_t)i);
-    const Rect r = tile_rect(m.x, m.y, c.x, c.w, Dr, fx, fy, cx, cy, w, h, shift);
+    const Rect r = tile_rect(m.x, m.y, c.x, c.w, Dr, fx, fy, cx, cy, w, h, shift, side);
     *reinterpret_cast<int2 *>(tl + 2 * (size_t)i) = make_int2(r.x0, r.y0);
     *reinterpret_cast<int2 *>(br + 2 * (size_t)i) = make_int2(r.x1, r.y1);
     cnt = (uint32_t)((r.x1 - r.x0 + 1) * (r.y1 - r.y0 + 1));
@@ -783,15 +785,18 @@ int gsgen_tile_culling_aabb_count(uint32_t N, const float *mean2d, const float *
                                   uint32_t tile_size, float fx, float fy, float cx, float cy,
                                   uint32_t w, uint32_t h, float D, int *aabb_topleft,
                                   int *aabb_bottomright, uint32_t *total, gsgen_stream_t stream) {
-  if (tile_size != 8u && tile_size != 16u && tile_size != 32u) return GSGEN_EUNSUPPORTED;
-  const int shift = tile_size == 8u ? 3 : (tile_size == 16u ? 4 : 5);
+  if (tile_size < 1u || tile_size > 32u) return GSGEN_EUNSUPPORTED;  // (the reference: tile_size^2 <= 1024 threads per tile)
+  const bool pow2 = (tile_size & (tile_size - 1u)) == 0u;
+  int shift = 0;
+  while ((1u << shift) < tile_size) ++shift;
+  const int side = pow2 ? 0 : (int)tile_size;
   if (!total) return GSGEN_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   if (hipError_t e = hipMemsetAsync(total, 0, sizeof(uint32_t), s)) return (int)e;
   if (N == 0) return 0;
   if (!mean2d || !cov2d || !aabb_topleft || !aabb_bottomright) return GSGEN_EINVAL;
   hipLaunchKernelGGL(k_aabb_count, grid_for(N), dim3(kThreads), 0, s, N, mean2d, cov2d, fx, fy, cx, cy,
-                     (int)w, (int)h, D, shift, aabb_topleft, aabb_bottomright, total);
+                     (int)w, (int)h, D, shift, side, aabb_topleft, aabb_bottomright, total);
   return (int)hipGetLastError();
 }
 

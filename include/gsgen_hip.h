@@ -21,9 +21,10 @@
  * tile_size: 16 is the reference's only configured value (conf/base.yaml:132) and the size every tuned kernel variant,
  * the batched, segmented and fused entry points are built for.  The per-camera entry points of the `_gs` surface
  * (gsgen_tile_culling_aabb_count, gsgen_vol_render_start_end_with_T / _backward_start_end, _scalar / _scalar_backward,
- * _sh / _backward_sh) also take 8 and 32, as the reference's launch of tile_size x tile_size threads does
- * (vol_render.h:1001-1004); binning works on tile-index rectangles and is size-agnostic.  Anything else returns
- * GSGEN_EUNSUPPORTED.  Per-pixel results do not depend on the tile size.
+ * _sh / _backward_sh) take ANY tile_size from 1 to 32, as the reference's launch of tile_size x tile_size <= 1024 threads does
+ * (vol_render.h:1001-1004): 8 runs one wavefront per tile, every other side a four-wavefront workgroup over a 32 x 32 patch of
+ * which the caller's tile is the top-left part (untuned: a compatibility path); binning works on tile-index rectangles and is
+ * size-agnostic.  tile_size 0 or > 32 returns GSGEN_EUNSUPPORTED.  Per-pixel results do not depend on the tile size.
  */
 #ifndef GSGEN_HIP_H
 #define GSGEN_HIP_H
@@ -36,7 +37,7 @@ extern "C" {
 
 typedef void *gsgen_stream_t; /* hipStream_t; NULL = the legacy default stream */
 
-#define GSGEN_EUNSUPPORTED (-2) /* tile_size not in {8, 16, 32} (16 only: batched / segmented / fused), C not in 1..4 */
+#define GSGEN_EUNSUPPORTED (-2) /* tile_size not in 1 .. 32 (16 only: batched / segmented / fused), C not in 1..4 */
 #define GSGEN_EINVAL (-3)       /* null pointer / inconsistent sizes */
 #define GSGEN_EWORKSPACE (-4)   /* workspace too small */
 

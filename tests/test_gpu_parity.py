@@ -320,9 +320,10 @@ def test_unsupported_configs_raise():
     from gsgen_amd._capi import GsgenError
     L = lib()
     z = torch.zeros(4, device=dev()); zi = torch.zeros(4, dtype=torch.int32, device=dev())
-    with pytest.raises(GsgenError):
-        L.vol_render_start_end_with_T(1, 1, p(z), p(z), p(z), p(z), p(zi), p(zi), p(zi), p(z), p(z), 12, 1, 1, 1.0, 1.0,
-                                      8, 8, 1e-4, p(z), stream())  # tile sizes: 8, 16, 32
+    for bad in (0, 33, 64):  # tile sizes: 1 .. 32 (the reference's limit: tile_size^2 <= 1024 threads per tile)
+        with pytest.raises(GsgenError):
+            L.vol_render_start_end_with_T(1, 1, p(z), p(z), p(z), p(z), p(zi), p(zi), p(zi), p(z), p(z), bad, 1, 1, 1.0, 1.0,
+                                          8, 8, 1e-4, p(z), stream())
 
 
 def test_long_tile_list_and_ties():
@@ -458,9 +459,10 @@ class _DeviceArrays:
         return self.Arr(a)
 
 
-@pytest.mark.parametrize("ts,C,W,H", [(8, 4, 133, 90), (32, 4, 200, 120), (8, 1, 64, 48), (32, 2, 97, 65), (8, 3, 80, 80)])
+@pytest.mark.parametrize("ts,C,W,H", [(8, 4, 133, 90), (32, 4, 200, 120), (8, 1, 64, 48), (32, 2, 97, 65), (8, 3, 80, 80), (12, 4, 131, 77),
+                                      (20, 2, 99, 64), (4, 1, 50, 33), (27, 3, 140, 90), (1, 1, 9, 7)])
 def test_other_tile_sizes(ts, C, W, H):
-    """tile_size 8 and 32 through the C ABI: count, bin / sort, RGB / scalar / SH forward and backward against the
+    """tile sizes other than 16 (8, 32, and sides that are no power of two) through the C ABI: count, bin / sort, RGB / scalar / SH forward and backward against the
     oracle at that tile size (the reference takes the tile size as a parameter, conf/base.yaml:132)"""
     from tile_chain import other_tile_size_chain
     other_tile_size_chain(_DeviceArrays(), ts, C, W, H, sync=torch.cuda.synchronize)
@@ -476,7 +478,7 @@ def test_chain_fuzz():
     n_ex = int(os.environ.get("GSGEN_FUZZ_EXAMPLES", "40"))
 
     @settings(max_examples=n_ex, deadline=None, derandomize=(n_ex == 40), suppress_health_check=list(HealthCheck))
-    @given(ts=st.sampled_from([8, 16, 32]), C=st.integers(1, 4), W=st.integers(1, 200), H=st.integers(1, 150),
+    @given(ts=st.sampled_from([8, 16, 32, 5, 12, 27]), C=st.integers(1, 4), W=st.integers(1, 200), H=st.integers(1, 150),
            n=st.integers(1, 3000), seed=st.integers(0, 10_000), svec=st.sampled_from([0.01, 0.05, 0.2]),
            opaque=st.booleans())
     def run(ts, C, W, H, n, seed, svec, opaque):

@@ -1,4 +1,4 @@
-"""The per-camera chain of `_gs` entry points at a caller-chosen tile size (8 / 32), against the oracle at that tile size.
+"""The per-camera chain of `_gs` entry points at a caller-chosen tile size (any side from 1 to 32), against the oracle at that tile size.
 Shared by the emulator test (tests/test_cpu_host.py) and the GPU test (tests/test_gpu_parity.py): `L` provides
 `lib` (the ctypes binding), `stream`, and `to_dev(array)` -> object with `.p` (address), `.n` (elements), `.get()`."""
 import numpy as np
@@ -109,7 +109,8 @@ def other_tile_size_chain(L, ts, C, W, H, sync=lambda: None, rtol=1e-4, n=300, s
     if atol == 0.0 or margin.min() > 4e-7:
         for a, b in ((g["gm"], om), (g["gc"], oc.reshape(-1, 4)), (g["gsh"], osh), (g["ga"], oa)):
             close(a.get(), b)
-    # tile sizes the kernels do not exist for are refused, not misrendered
-    with pytest.raises(Exception, match="unsupported"):
-        L.lib.vol_render_sh(N, D, h["m2"].p, h["c2"].p, shd.p, d["al"].p, st.p, en.p, ids.p, out.p, d["tlp"].p, rotd.p, 12, nth,
-                            ntw, psx, psy, H, W, C, 1e-4, bgd.p, None, L.stream)
+    # tile sizes beyond the reference's own limit (tile_size^2 <= 1024 threads per tile) are refused, not misrendered
+    for bad in (0, 33):
+        with pytest.raises(Exception, match="unsupported"):
+            L.lib.vol_render_sh(N, D, h["m2"].p, h["c2"].p, shd.p, d["al"].p, st.p, en.p, ids.p, out.p, d["tlp"].p, rotd.p, bad, nth,
+                                ntw, psx, psy, H, W, C, 1e-4, bgd.p, None, L.stream)
