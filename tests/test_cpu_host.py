@@ -267,8 +267,7 @@ class _HostArrays:
         return self.Arr(a)
 
 
-@pytest.mark.parametrize("ts,C,W,H", [(8, 4, 33, 20), (32, 3, 70, 40), (8, 1, 24, 17), (32, 2, 40, 40), (12, 2, 40, 29), (5, 1, 23, 17),
-                                      (24, 4, 50, 50)])
+@pytest.mark.parametrize("ts,C,W,H", [(8, 4, 33, 20), (32, 3, 70, 40), (8, 1, 24, 17), (12, 2, 40, 29), (5, 1, 23, 17), (24, 4, 40, 40)])
 def test_emulated_other_tile_sizes(emu, ts, C, W, H):
     """tile_size 8 and 32 (the reference takes the tile size as a parameter, conf/base.yaml:132): the whole per-camera
     chain of `_gs` entry points against the oracle at that tile size"""
@@ -283,9 +282,9 @@ def test_emulated_chain_fuzz(emu):
     from hypothesis import given, settings, strategies as st, HealthCheck
     from tile_chain import other_tile_size_chain
 
-    n_ex = int(os.environ.get("GSGEN_FUZZ_EXAMPLES", "14"))  # a longer hunt: GSGEN_FUZZ_EXAMPLES=300 (random seeds)
+    n_ex = int(os.environ.get("GSGEN_FUZZ_EXAMPLES", "10"))  # a longer hunt: GSGEN_FUZZ_EXAMPLES=300 (random seeds)
 
-    @settings(max_examples=n_ex, deadline=None, derandomize=(n_ex == 14), suppress_health_check=list(HealthCheck))
+    @settings(max_examples=n_ex, deadline=None, derandomize=(n_ex == 10), suppress_health_check=list(HealthCheck))
     @given(ts=st.sampled_from([8, 16, 32, 5, 12, 27]), C=st.integers(1, 4), W=st.integers(1, 70), H=st.integers(1, 50),
            n=st.integers(1, 400), seed=st.integers(0, 10_000), svec=st.sampled_from([0.01, 0.05, 0.2]),
            opaque=st.booleans())

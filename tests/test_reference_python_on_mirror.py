@@ -65,8 +65,8 @@ def test_reference_render_scalar(ref, name):
     RC.case_render_scalar(ref, "cpu", name)
 
 
-@pytest.mark.parametrize("name", ["mock2", "rand_c1", "rand_c3", "rand_c4", "long_lists"])
-@pytest.mark.parametrize("with_bg", [False, True])
+@pytest.mark.parametrize("name,with_bg", [(n_, b_) for n_ in ("mock2", "rand_c1", "rand_c3", "rand_c4") for b_ in (False, True)] +
+                         [("long_lists", True)])  # (the emulator walks 1 500-entry lists slowly: one variant here, both on the GPU)
 def test_reference_render_sh(ref, name, with_bg):
     RC.case_render_sh(ref, "cpu", name, with_bg)
 
