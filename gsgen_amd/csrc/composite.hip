@@ -490,6 +490,7 @@ struct FwdShVecShared {
   alignas(16) float Ws[POLY ? KB * 3 * kPolyStride : 4];  // POLY: transformed coefficients of the staged batch
                                                           // (and, before the first batch, the nine node bases)
   uint32_t exact_mask;                                    // POLY, two wavefronts per tile: exact_tier_mask of the staged batch
+  float tay_ok[POLY ? KB * 3 : 1];                        // POLY: rows of the staged batch that may take the Taylor tier (poly_transform)
 };
 // TRACK = false: a launch known (on the host) to carry no stop list -- four registers of running state less
 template <int CB, int PPL, int NB, bool PERSIST = false, bool TRACK = true>
@@ -594,6 +595,7 @@ __device__ __forceinline__ void composite_fwd_sh_vec_tile(const CompParams &p, u
   const bool track_stop = TRACK && p.stop != nullptr;
 
   uint32_t exact_mask = 0u;  // POLY: the staged batch's splats of the per-entry exact tier
+  uint32_t tay_mask = 0u;    // POLY: ... and those of the Taylor tier (no exponential per pixel: composite_common.hpp)
   for (int base = 0; base < n; base += KB) {
     const int nb = min(KB, n - base);
     if (base > 0) __syncthreads();  // everyone is done with the previous batch
@@ -615,8 +617,9 @@ __device__ __forceinline__ void composite_fwd_sh_vec_tile(const CompParams &p, u
         exact_mask = 0u;
         __syncthreads();
       }
-      poly_transform<NT, KB>(p.col, S.id, Vs, Ws, nb);
+      poly_transform<NT, KB>(p.col, S.id, Vs, Ws, nb, sm.tay_ok);
       __syncthreads();
+      tay_mask = (uint32_t)__builtin_amdgcn_readfirstlane((int)(taylor_mask(sm.tay_ok, nb) & ~exact_mask));
     } else {
       __syncthreads();
     }
@@ -689,6 +692,23 @@ __device__ __forceinline__ void composite_fwd_sh_vec_tile(const CompParams &p, u
         for (int jp = 0; jp < NP; ++jp) w2[jp] = (splat2(r_a) * Tr2[jp]) * G2[jp];  // (a T) G, or 0
       }
       if constexpr (POLY) {
+       if ((tay_mask >> g) & 1u) {  // the Taylor tier (wave-uniform; the ordinary case): colour = f0 + d (f1 + d f2), no exponential
+#pragma unroll
+        for (int jp = 0; jp < NP; ++jp) w2[jp] = Tr2[jp] * ag2[jp];  // T (a G), or 0
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float *cw = cg + c * kPolyStride;  // (w0, w1 | w2, w4 | w5, 0 | w3, f0 | 0, w1 | f1, f2)
+          const v2f ab = ffma2(pu2, ffma2(pu2, *reinterpret_cast<const v2f *>(cw + 4), *reinterpret_cast<const v2f *>(cw + 2)),
+                               *reinterpret_cast<const v2f *>(cw + 8));  // u (w2 + u w5) | w1 + u w4
+          const float Cc = cw[6], f0 = cw[7], f1 = cw[10], f2 = cw[11];
+#pragma unroll
+          for (int jp = 0; jp < NP; ++jp) {
+            const v2f d = ffma2(pv2[jp], ffma2(pv2[jp], splat2(Cc), splat2(ab[1])), splat2(ab[0]));
+            const v2f yv = ffma2(d, ffma2(d, splat2(f2), splat2(f1)), splat2(f0));
+            acc2[jp][c] = ffma2(w2[jp], yv, acc2[jp][c]);
+          }
+        }
+       } else {
         // the three channels' denominators 1 + exp2(s_c) first, then ONE reciprocal per pixel for all of them:
         // 1 / d_c = (1 / (d_0 d_1 d_2)) * (the other two).  (poly_transform keeps |s| <= 40: the product stays finite.)
         v2f den[3][NP];
@@ -720,6 +740,7 @@ __device__ __forceinline__ void composite_fwd_sh_vec_tile(const CompParams &p, u
           acc2[jp][1] = ffma2(w2[jp], r01 * den[0][jp], acc2[jp][1]);
           acc2[jp][2] = ffma2(w2[jp], r * d01, acc2[jp][2]);
         }
+       }
       }
       if constexpr (!POLY) {
 #pragma unroll
@@ -1153,6 +1174,7 @@ struct BwdShVecShared {
   alignas(16) float Ws[POLY ? KB * 3 * kPolyStride : 4];    // POLY: transformed coefficients of the staged batch
                                                           // (and, before the first batch, the nine node bases)
   float gw_s[POLY ? 3 * 8 : 1];                           // POLY: a splat's reduced gradient in the tile's basis
+  float tay_ok[POLY ? KB * 3 : 1];                        // POLY: rows of the staged batch that may take the Taylor tier (poly_transform)
 };
 template <int CB, int PPL, int NB, bool PERSIST = false>
 __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, uint32_t bid, uint32_t grid,
@@ -1279,7 +1301,7 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
   }
   auto alive = [&](int j) { return !(Tr2[j >> 1][j & 1] < p.thresh); };
 
-  uint32_t exact_mask = 0u;
+  uint32_t exact_mask = 0u, tay_mask = 0u;
   for (int base = e_lo; base < e_hi; base += KB) {
     const int nb = min(KB, e_hi - base);
     if (base > e_lo) __syncthreads();
@@ -1288,8 +1310,9 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
     if constexpr (POLY) {
       // (the forward's per-entry exact tier: the same splats, the same test -- a tile the forward gave up is not walked here)
       exact_mask = (uint32_t)__builtin_amdgcn_readfirstlane((int)exact_tier_mask<NT>(p, S.id, nb, t, nullptr));
-      poly_transform<NT, KB>(p.col, S.id, Vs, Ws, nb);
+      poly_transform<NT, KB>(p.col, S.id, Vs, Ws, nb, sm.tay_ok);
       __syncthreads();
+      tay_mask = (uint32_t)__builtin_amdgcn_readfirstlane((int)(taylor_mask(sm.tay_ok, nb) & ~exact_mask));  // (as the forward)
     }
 
     for (int g = 0; g < nb; ++g) {
@@ -1371,10 +1394,30 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
       if constexpr (POLY) {
         // colours as in the forward: the three channels' denominators first, then ONE reciprocal per pixel for the three
         // sigmoids and 1 / (1 - a G):  1 / x_i = (1 / prod x) * prod_{j != i} x_j  (|s| <= 40 by poly_transform, 1 - a G >= 0.01)
-        v2f den[3][NP], yv[3][NP];
+        v2f yv[3][NP];
+        if ((tay_mask >> g) & 1u) {  // the forward's Taylor tier (wave-uniform; the ordinary case): the same colours, no exponential
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const float *cw = cg + c * kPolyStride;  // (w0, w1 | w2, w4 | w5, 0 | w3, f0 | 0, w1 | f1, f2)
+            const v2f ab = ffma2(pu2, ffma2(pu2, *reinterpret_cast<const v2f *>(cw + 4), *reinterpret_cast<const v2f *>(cw + 2)),
+                                 *reinterpret_cast<const v2f *>(cw + 8));  // u (w2 + u w5) | w1 + u w4
+            const float Cc = cw[6], f0 = cw[7], f1 = cw[10], f2 = cw[11];
+#pragma unroll
+            for (int jp = 0; jp < NP; ++jp) {
+              const v2f d = ffma2(pv2[jp], ffma2(pv2[jp], splat2(Cc), splat2(ab[1])), splat2(ab[0]));
+              yv[c][jp] = ffma2(d, ffma2(d, splat2(f2), splat2(f1)), splat2(f0));
+            }
+          }
+#pragma unroll
+          for (int jp = 0; jp < NP; ++jp) {
+            const v2f om = one_minus2(ag2[jp]);
+            inv1m2[jp] = v2f{__builtin_amdgcn_rcpf(om[0]), __builtin_amdgcn_rcpf(om[1])};
+          }
+        } else {
+        v2f den[3][NP];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          const float *cw = cg + c * kPolyStride;  // (w0, w1 | w2, w4 | w5, 0 | w3, 0): composite_common.hpp
+          const float *cw = cg + c * kPolyStride;  // (w0, w1 | w2, w4 | w5, 0 | w3, ..): composite_common.hpp
           const v2f ab = ffma2(pu2, ffma2(pu2, *reinterpret_cast<const v2f *>(cw + 4), *reinterpret_cast<const v2f *>(cw + 2)),
                                *reinterpret_cast<const v2f *>(cw));
           const float Cc = cw[6];
@@ -1397,6 +1440,7 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
           yv[1][jp] = r01 * den[0][jp];
           yv[2][jp] = r2o * om;
           inv1m2[jp] = r2o * den[2][jp];
+        }
         }
         v2f gy2[NP];  // sum_c grad_out_c * colour_c
 #pragma unroll
@@ -1569,6 +1613,7 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
 // coefficient bound fails while a batch mate's holds.)
 template <int CB, int PPL, bool BATCH = false, int NB = 0>
 __global__ void __launch_bounds__(256 / PPL)
+GS_WAVES_PER_EU((NB == kPolyNB && BATCH) ? 4 : 1)  // the batched polynomial backward: four wavefronts per SIMD (<= 128 registers)
 k_composite_bwd_sh_vec(CompParams p_arg, ViewPack<BATCH> pack) {
   const CompParams *plist = pack.table();  // (kernel-argument memory: scalar loads, no table in device memory)
   uint32_t bid = blockIdx.x, grid = gridDim.x;

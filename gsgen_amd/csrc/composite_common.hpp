@@ -335,7 +335,21 @@ constexpr int kPolyNB = 6;
 // r = 0..5 = (1, v, u, v^2, uv, u^2), so that the kernels form  s = (w0 + u (w2 + u w5)) + v ((w1 + u w4) + v w3)  from whole
 // register PAIRS:  (A, B) = (w0, w1) + u ((w2, w4) + u (w5, 0)),  s = A + v (B + v w3)  -- two packed FMAs per row and lane
 // instead of three scalar ones plus the moves that put their results into aligned pairs.
-constexpr int kPolyStride = 8;
+// Round 5 -- the Taylor tier: inside a tile the logit of a (splat, channel) moves by d = s(u, v) - s(0, 0), |d| <= sum_{r >= 1} |w_r|
+// =: dmax -- a few hundredths of the scaled unit on every BASELINE workload (median 0.006, largest 0.03 at 800^2 and at cfg4's widest
+// cameras) --, so its sigmoid  f(z) = 1 / (1 + 2^z)  is its second-order Taylor polynomial around the tile centre to within
+// max |third derivative| / 6 * d^3 <= 0.00694 d^3: below 8.7e-7 for dmax <= kTaylorDmax = 0.05.  poly_transform evaluates f, its first
+// derivative and half its second ONCE per (tile, splat, channel) -- three exponentials per splat and tile -- and the entry loops of
+// the polynomial kernels form
+//     colour = f0 + d (f1 + d f2)
+// with two packed FMAs per pixel pair and channel: no exponential and no reciprocal per pixel (until round 5: 12 exponentials +
+// 4 reciprocals per lane and entry, 80 of the forward's 154 issue slots per (wavefront, entry), 64 of the backward's 328).  A splat
+// with dmax > kTaylorDmax in any channel -- outliers with large higher bands, very wide cameras -- keeps the exponentials, entry by
+// entry (a wave-uniform bit per staged record, as the exact tier); forward and backward take the same bit, hence the same values.
+// Row layout (12 floats per (splat, channel)): (w0, w1 | w2, w4 | w5, 0 | w3, f0 | 0, w1 | f1, f2): the pair at +8 is the base of
+// d's column part, u (w2 + u w5) | w1 + u w4, without the constant term.
+constexpr int kPolyStride = 12;
+constexpr float kTaylorDmax = 0.05f;
 constexpr int kPolyNodes = 9;
 // colour error of the degree-2 form <= 0.25 (sigmoid slope) x S x kPolyFitErr delta^3, delta = half diagonal of a tile in
 // camera space; used where that stays below 1e-5, a tenth of the 1e-4 image tolerance.  kPolyFitErr = 1.0: the SHIPPED fit's
@@ -411,7 +425,8 @@ __device__ __forceinline__ void poly_tile_setup(const CompParams &p, int tx, int
 // (Loading a lane's two items together hides one trip to memory per batch and costs 32 more registers -- a wavefront per
 // SIMD; not taken.)
 template <int NT, int KB>
-__device__ __forceinline__ void poly_transform(const float *__restrict__ sh, const int *ids, const float *Vs, float *w, int nb) {
+__device__ __forceinline__ void poly_transform(const float *__restrict__ sh, const int *ids, const float *Vs, float *w, int nb,
+                                               float *tay_ok /* [KB * 3]: 1 where the row may take the Taylor tier */) {
   static_assert(NT % 2 == 0, "the two halves of a row sit in neighbouring lanes");
 #pragma unroll 1
   for (int it0 = 0; it0 < nb * 6; it0 += NT) {  // (block-uniform trips: the lane exchange below is a wave collective)
@@ -440,7 +455,7 @@ __device__ __forceinline__ void poly_transform(const float *__restrict__ sh, con
       acc = ffma2(qh, v2f{d.z, d.w}, acc);
       if (live) row[k == 0 ? s0 : (k == 1 ? s1 : s2)] = -kLog2e * (acc[0] + acc[1]);
     }
-    if (live) row[half ? 7 : 5] = 0.0f;
+    if (live && !half) row[5] = 0.0f;
     // |s| <= sum_r |w_r| on the tile (|u|, |v| <= 1).  The kernels take ONE reciprocal per pixel for the product of the three
     // channels' 1 + exp2(s): rows that could reach |s| > 40 are scaled back to 40 -- their sigmoid is 0 or 1 to 1e-12 either way
     // (and d sigmoid / d s ~ 1e-12: no gradient is lost that the exact kernels would deliver)
@@ -450,7 +465,29 @@ __device__ __forceinline__ void poly_transform(const float *__restrict__ sh, con
       const float sc = 40.0f / l1;
       row[s0] *= sc; row[s1] *= sc; row[s2] *= sc;
     }
+    // the Taylor tier's constants, by the lane that holds the row's first half (w0, w1, w2): f = 1 / (1 + 2^z) at the tile centre
+    // z0 = w0 -- the very expression the exponential path evaluates, so the two agree to the bit where d = 0 --, df/dz = -ln2 f (1 - f),
+    // half the second derivative = (ln2^2 / 2) f (1 - f) (1 - 2 f)
+    if (live && !half) {
+      const float z0 = row[0];
+      const float f0 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z0));
+      const float ff = f0 * (1.0f - f0);
+      row[7] = f0;
+      row[8] = 0.0f;
+      row[9] = row[1];
+      row[10] = -0.6931471805599453f * ff;
+      row[11] = 0.2402265069591007f * ff * (1.0f - 2.0f * f0);
+      const float dmax = l1 - fabsf(z0);  // (of the unscaled row; a row scaled back to 40 is far beyond the tier anyway)
+      tay_ok[e] = (l1 <= 40.0f && dmax <= kTaylorDmax) ? 1.0f : 0.0f;  // (NaN coefficients: false)
+    }
   }
+}
+// the staged batch's mask of splats whose three channels may take the Taylor tier (bit g = entry g; KB <= 32): every wavefront forms
+// it for itself from the flags poly_transform left in LDS (behind the barrier that follows it)
+__device__ __forceinline__ uint32_t taylor_mask(const float *tay_ok, int nb) {
+  const int l = lane_id();
+  const bool ok = l < nb && tay_ok[3 * l] != 0.0f && tay_ok[3 * l + 1] != 0.0f && tay_ok[3 * l + 2] != 0.0f;
+  return (uint32_t)__ballot((int)ok);
 }
 
 // tile_size: 16 (every kernel variant) or 8 / 32 (the unpacked vector kernels at one fixed shape; no segments, no batch)
