@@ -456,15 +456,29 @@ __device__ __attribute__((noinline)) Logits3 exact_tier_logits(const float *rot_
   return Logits3{fin(a0), fin(a1), fin(a2)};
 }
 template <int PPL>
-__device__ __forceinline__ void exact_tier_denominators(const CompParams &p, int id_uniform, float px, const v2f (&py2)[PPL / 2],
-                                                        v2f (&den)[3][PPL / 2]) {
+__device__ __forceinline__ void exact_tier_logits_all(const CompParams &p, int id_uniform, float px, const v2f (&py2)[PPL / 2],
+                                                      v2f (&lg)[3][PPL / 2]) {
   const float *q = p.col + (size_t)id_uniform * 48u;
 #pragma unroll
   for (int j = 0; j < PPL; ++j) {
     const Logits3 l = exact_tier_logits(p.rot, q, px, py2[j >> 1][j & 1]);
-    den[0][j >> 1][j & 1] = 1.0f + __builtin_amdgcn_exp2f(l.s0);
-    den[1][j >> 1][j & 1] = 1.0f + __builtin_amdgcn_exp2f(l.s1);
-    den[2][j >> 1][j & 1] = 1.0f + __builtin_amdgcn_exp2f(l.s2);
+    lg[0][j >> 1][j & 1] = l.s0;
+    lg[1][j >> 1][j & 1] = l.s1;
+    lg[2][j >> 1][j & 1] = l.s2;
+  }
+}
+// A staged polynomial row at the lane's pixel pairs: five packed FMAs per pair and channel, explicitly fused (every shape of the
+// kernel agrees).  The Taylor tier's rows deliver the colour, all others the logit (composite_common.hpp).
+template <int NP>
+__device__ __forceinline__ void poly_rows_at_pixels(const float *cg, v2f pu2, const v2f (&pv2)[NP], v2f (&yv)[3][NP]) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float *cw = cg + c * kPolyStride;  // (w0, w1 | w2, w4 | w5, 0 | w3, -)
+    const v2f ab = ffma2(pu2, ffma2(pu2, *reinterpret_cast<const v2f *>(cw + 4), *reinterpret_cast<const v2f *>(cw + 2)),
+                         *reinterpret_cast<const v2f *>(cw));  // w0 + u (w2 + u w5) | w1 + u w4
+    const float Cc = cw[6];
+#pragma unroll
+    for (int jp = 0; jp < NP; ++jp) yv[c][jp] = ffma2(pv2[jp], ffma2(pv2[jp], splat2(Cc), splat2(ab[1])), splat2(ab[0]));
   }
 }
 // the staged batch's mask of such splats (bit g = entry g of the batch; KB <= 32).  NT threads, the first nb of them hold an entry.
@@ -620,6 +634,8 @@ __device__ __forceinline__ void composite_fwd_sh_vec_tile(const CompParams &p, u
       poly_transform<NT, KB>(p.col, S.id, Vs, Ws, nb, sm.tay_ok);
       __syncthreads();
       tay_mask = (uint32_t)__builtin_amdgcn_readfirstlane((int)(taylor_mask(sm.tay_ok, nb) & ~exact_mask));
+      taylor_convert<NT>(Ws, tay_mask, nb);
+      __syncthreads();
     } else {
       __syncthreads();
     }
@@ -692,55 +708,35 @@ __device__ __forceinline__ void composite_fwd_sh_vec_tile(const CompParams &p, u
         for (int jp = 0; jp < NP; ++jp) w2[jp] = (splat2(r_a) * Tr2[jp]) * G2[jp];  // (a T) G, or 0
       }
       if constexpr (POLY) {
-       if ((tay_mask >> g) & 1u) {  // the Taylor tier (wave-uniform; the ordinary case): colour = f0 + d (f1 + d f2), no exponential
-#pragma unroll
-        for (int jp = 0; jp < NP; ++jp) w2[jp] = Tr2[jp] * ag2[jp];  // T (a G), or 0
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const float *cw = cg + c * kPolyStride;  // (w0, w1 | w2, w4 | w5, 0 | w3, f0 | 0, w1 | f1, f2)
-          const v2f ab = ffma2(pu2, ffma2(pu2, *reinterpret_cast<const v2f *>(cw + 4), *reinterpret_cast<const v2f *>(cw + 2)),
-                               *reinterpret_cast<const v2f *>(cw + 8));  // u (w2 + u w5) | w1 + u w4
-          const float Cc = cw[6], f0 = cw[7], f1 = cw[10], f2 = cw[11];
-#pragma unroll
-          for (int jp = 0; jp < NP; ++jp) {
-            const v2f d = ffma2(pv2[jp], ffma2(pv2[jp], splat2(Cc), splat2(ab[1])), splat2(ab[0]));
-            const v2f yv = ffma2(d, ffma2(d, splat2(f2), splat2(f1)), splat2(f0));
-            acc2[jp][c] = ffma2(w2[jp], yv, acc2[jp][c]);
-          }
-        }
-       } else {
-        // the three channels' denominators 1 + exp2(s_c) first, then ONE reciprocal per pixel for all of them:
-        // 1 / d_c = (1 / (d_0 d_1 d_2)) * (the other two).  (poly_transform keeps |s| <= 40: the product stays finite.)
-        v2f den[3][NP];
-        if ((exact_mask >> g) & 1u) {  // the per-entry exact tier (wave-uniform: scalar instructions only on the ordinary path)
-          exact_tier_denominators<PPL>(p, __builtin_amdgcn_readfirstlane(S.id[g]), px, py2, den);
-        } else {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const float *cw = cg + c * kPolyStride;  // (w0, w1 | w2, w4 | w5, 0 | w3, 0): composite_common.hpp
-          const v2f ab = ffma2(pu2, ffma2(pu2, *reinterpret_cast<const v2f *>(cw + 4), *reinterpret_cast<const v2f *>(cw + 2)),
-                               *reinterpret_cast<const v2f *>(cw));
-          const float Cc = cw[6];
+        // the staged rows at the lane's pixels -- or, for the staged batch's few splats of the exact tier (a wave-uniform bit:
+        // scalar instructions only on the ordinary path), the logits from the pixel's own basis
+        v2f yv[3][NP];
+        if ((exact_mask >> g) & 1u) exact_tier_logits_all<PPL>(p, __builtin_amdgcn_readfirstlane(S.id[g]), px, py2, yv);
+        else poly_rows_at_pixels<NP>(cg, pu2, pv2, yv);
+        if (!((tay_mask >> g) & 1u)) {
+          // not the Taylor tier (wave-uniform; the rare case): yv holds logits.  The three channels' denominators 1 + exp2(s_c)
+          // first, then ONE reciprocal per pixel for all of them: 1 / d_c = (1 / (d_0 d_1 d_2)) * (the other two).
+          // (poly_transform keeps |s| <= 40: the product stays finite.)
 #pragma unroll
           for (int jp = 0; jp < NP; ++jp) {
-            const v2f sp = ffma2(pv2[jp], ffma2(pv2[jp], splat2(Cc), splat2(ab[1])), splat2(ab[0]));  // (explicitly fused: every shape of the kernel agrees)
-            den[c][jp] = splat2(1.0f) + v2f{__builtin_amdgcn_exp2f(sp[0]), __builtin_amdgcn_exp2f(sp[1])};
+            v2f den[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) den[c] = splat2(1.0f) + v2f{__builtin_amdgcn_exp2f(yv[c][jp][0]), __builtin_amdgcn_exp2f(yv[c][jp][1])};
+            const v2f d01 = den[0] * den[1];
+            const v2f d = d01 * den[2];
+            const v2f r = v2f{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+            const v2f r01 = r * den[2];  // 1 / (d0 d1)
+            yv[0][jp] = r01 * den[1];
+            yv[1][jp] = r01 * den[0];
+            yv[2][jp] = r * d01;
           }
         }
-        }
-#pragma unroll
-        for (int jp = 0; jp < NP; ++jp) w2[jp] = Tr2[jp] * ag2[jp];  // T (a G), or 0 (formed BEHIND the exact tier's calls: four registers less across them)
 #pragma unroll
         for (int jp = 0; jp < NP; ++jp) {
-          const v2f d01 = den[0][jp] * den[1][jp];
-          const v2f d = d01 * den[2][jp];
-          const v2f r = v2f{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
-          const v2f r01 = r * den[2][jp];  // 1 / (d0 d1)
-          acc2[jp][0] = ffma2(w2[jp], r01 * den[1][jp], acc2[jp][0]);
-          acc2[jp][1] = ffma2(w2[jp], r01 * den[0][jp], acc2[jp][1]);
-          acc2[jp][2] = ffma2(w2[jp], r * d01, acc2[jp][2]);
+          w2[jp] = Tr2[jp] * ag2[jp];  // T (a G), or 0 (formed BEHIND the exact tier's calls: four registers less across them)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) acc2[jp][c] = ffma2(w2[jp], yv[c][jp], acc2[jp][c]);
         }
-       }
       }
       if constexpr (!POLY) {
 #pragma unroll
@@ -1313,6 +1309,8 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
       poly_transform<NT, KB>(p.col, S.id, Vs, Ws, nb, sm.tay_ok);
       __syncthreads();
       tay_mask = (uint32_t)__builtin_amdgcn_readfirstlane((int)(taylor_mask(sm.tay_ok, nb) & ~exact_mask));  // (as the forward)
+      taylor_convert<NT>(Ws, tay_mask, nb);
+      __syncthreads();
     }
 
     for (int g = 0; g < nb; ++g) {
@@ -1392,55 +1390,34 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
         pAG2[jp] = v2f{0.0f, 0.0f};
       }
       if constexpr (POLY) {
-        // colours as in the forward: the three channels' denominators first, then ONE reciprocal per pixel for the three
-        // sigmoids and 1 / (1 - a G):  1 / x_i = (1 / prod x) * prod_{j != i} x_j  (|s| <= 40 by poly_transform, 1 - a G >= 0.01)
+        // colours as in the forward: the staged rows at the lane's pixels (or the exact tier's logits), colours already in the
+        // Taylor tier -- otherwise the three channels' denominators and ONE reciprocal per pixel for the three sigmoids and
+        // 1 / (1 - a G):  1 / x_i = (1 / prod x) * prod_{j != i} x_j  (|s| <= 40 by poly_transform, 1 - a G >= 0.01)
         v2f yv[3][NP];
-        if ((tay_mask >> g) & 1u) {  // the forward's Taylor tier (wave-uniform; the ordinary case): the same colours, no exponential
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            const float *cw = cg + c * kPolyStride;  // (w0, w1 | w2, w4 | w5, 0 | w3, f0 | 0, w1 | f1, f2)
-            const v2f ab = ffma2(pu2, ffma2(pu2, *reinterpret_cast<const v2f *>(cw + 4), *reinterpret_cast<const v2f *>(cw + 2)),
-                                 *reinterpret_cast<const v2f *>(cw + 8));  // u (w2 + u w5) | w1 + u w4
-            const float Cc = cw[6], f0 = cw[7], f1 = cw[10], f2 = cw[11];
-#pragma unroll
-            for (int jp = 0; jp < NP; ++jp) {
-              const v2f d = ffma2(pv2[jp], ffma2(pv2[jp], splat2(Cc), splat2(ab[1])), splat2(ab[0]));
-              yv[c][jp] = ffma2(d, ffma2(d, splat2(f2), splat2(f1)), splat2(f0));
-            }
-          }
+        if ((exact_mask >> g) & 1u) exact_tier_logits_all<PPL>(p, __builtin_amdgcn_readfirstlane(S.id[g]), px, py2, yv);
+        else poly_rows_at_pixels<NP>(cg, pu2, pv2, yv);
+        if ((tay_mask >> g) & 1u) {  // (wave-uniform; the ordinary case)
 #pragma unroll
           for (int jp = 0; jp < NP; ++jp) {
             const v2f om = one_minus2(ag2[jp]);
             inv1m2[jp] = v2f{__builtin_amdgcn_rcpf(om[0]), __builtin_amdgcn_rcpf(om[1])};
           }
         } else {
-        v2f den[3][NP];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const float *cw = cg + c * kPolyStride;  // (w0, w1 | w2, w4 | w5, 0 | w3, ..): composite_common.hpp
-          const v2f ab = ffma2(pu2, ffma2(pu2, *reinterpret_cast<const v2f *>(cw + 4), *reinterpret_cast<const v2f *>(cw + 2)),
-                               *reinterpret_cast<const v2f *>(cw));
-          const float Cc = cw[6];
 #pragma unroll
           for (int jp = 0; jp < NP; ++jp) {
-            const v2f sp = ffma2(pv2[jp], ffma2(pv2[jp], splat2(Cc), splat2(ab[1])), splat2(ab[0]));  // (explicitly fused: every shape of the kernel agrees)
-            den[c][jp] = splat2(1.0f) + v2f{__builtin_amdgcn_exp2f(sp[0]), __builtin_amdgcn_exp2f(sp[1])};
-          }
-        }
-        if ((exact_mask >> g) & 1u)  // the forward's per-entry exact tier (wave-uniform): overwrites the polynomial's denominators
-          exact_tier_denominators<PPL>(p, __builtin_amdgcn_readfirstlane(S.id[g]), px, py2, den);
+            v2f den[3];
 #pragma unroll
-        for (int jp = 0; jp < NP; ++jp) {
-          const v2f om = one_minus2(ag2[jp]);
-          const v2f d01 = den[0][jp] * den[1][jp], d2o = den[2][jp] * om;
-          const v2f dd = d01 * d2o;
-          const v2f r = v2f{__builtin_amdgcn_rcpf(dd[0]), __builtin_amdgcn_rcpf(dd[1])};
-          const v2f r01 = r * d2o, r2o = r * d01;  // 1 / (d0 d1), 1 / (d2 (1 - a G))
-          yv[0][jp] = r01 * den[1][jp];
-          yv[1][jp] = r01 * den[0][jp];
-          yv[2][jp] = r2o * om;
-          inv1m2[jp] = r2o * den[2][jp];
-        }
+            for (int c = 0; c < 3; ++c) den[c] = splat2(1.0f) + v2f{__builtin_amdgcn_exp2f(yv[c][jp][0]), __builtin_amdgcn_exp2f(yv[c][jp][1])};
+            const v2f om = one_minus2(ag2[jp]);
+            const v2f d01 = den[0] * den[1], d2o = den[2] * om;
+            const v2f dd = d01 * d2o;
+            const v2f r = v2f{__builtin_amdgcn_rcpf(dd[0]), __builtin_amdgcn_rcpf(dd[1])};
+            const v2f r01 = r * d2o, r2o = r * d01;  // 1 / (d0 d1), 1 / (d2 (1 - a G))
+            yv[0][jp] = r01 * den[1];
+            yv[1][jp] = r01 * den[0];
+            yv[2][jp] = r2o * om;
+            inv1m2[jp] = r2o * den[2];
+          }
         }
         v2f gy2[NP];  // sum_c grad_out_c * colour_c
 #pragma unroll

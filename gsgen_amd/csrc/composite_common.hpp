@@ -335,21 +335,29 @@ constexpr int kPolyNB = 6;
 // r = 0..5 = (1, v, u, v^2, uv, u^2), so that the kernels form  s = (w0 + u (w2 + u w5)) + v ((w1 + u w4) + v w3)  from whole
 // register PAIRS:  (A, B) = (w0, w1) + u ((w2, w4) + u (w5, 0)),  s = A + v (B + v w3)  -- two packed FMAs per row and lane
 // instead of three scalar ones plus the moves that put their results into aligned pairs.
-// Round 5 -- the Taylor tier: inside a tile the logit of a (splat, channel) moves by d = s(u, v) - s(0, 0), |d| <= sum_{r >= 1} |w_r|
-// =: dmax -- a few hundredths of the scaled unit on every BASELINE workload (median 0.006, largest 0.03 at 800^2 and at cfg4's widest
-// cameras) --, so its sigmoid  f(z) = 1 / (1 + 2^z)  is its second-order Taylor polynomial around the tile centre to within
-// max |third derivative| / 6 * d^3 <= 0.00694 d^3: below 8.7e-7 for dmax <= kTaylorDmax = 0.05.  poly_transform evaluates f, its first
-// derivative and half its second ONCE per (tile, splat, channel) -- three exponentials per splat and tile -- and the entry loops of
-// the polynomial kernels form
-//     colour = f0 + d (f1 + d f2)
-// with two packed FMAs per pixel pair and channel: no exponential and no reciprocal per pixel (until round 5: 12 exponentials +
-// 4 reciprocals per lane and entry, 80 of the forward's 154 issue slots per (wavefront, entry), 64 of the backward's 328).  A splat
-// with dmax > kTaylorDmax in any channel -- outliers with large higher bands, very wide cameras -- keeps the exponentials, entry by
-// entry (a wave-uniform bit per staged record, as the exact tier); forward and backward take the same bit, hence the same values.
-// Row layout (12 floats per (splat, channel)): (w0, w1 | w2, w4 | w5, 0 | w3, f0 | 0, w1 | f1, f2): the pair at +8 is the base of
-// d's column part, u (w2 + u w5) | w1 + u w4, without the constant term.
-constexpr int kPolyStride = 12;
-constexpr float kTaylorDmax = 0.05f;
+// Round 5 -- the Taylor tier: inside a tile the logit of a (splat, channel) moves by d = s(u, v) - s(0, 0) = L + Q, its linear part
+// L = w1 v + w2 u, |L| <= l := |w1| + |w2|, and its quadratic part Q, |Q| <= q := |w3| + |w4| + |w5|; dmax := l + q is a few
+// hundredths of the scaled unit on every BASELINE workload (median 0.006, largest 0.03 at 800^2 and at cfg4's widest cameras),
+// and q is another factor delta ~ 0.01 below l.  The sigmoid  f(z) = 1 / (1 + 2^z)  around the tile centre z0 = w0 is
+//     f(z0 + d) = f0 + f1 d + f2 d^2 + R3,   |R3| <= max |f'''| / 6 * |d|^3 <= 0.00694 dmax^3,
+// and d^2 = L^2 + (2 L Q + Q^2), the bracket at most q (2 l + q): so the COLOUR ITSELF is the quadratic
+//     c(u, v) = f0 + f1 (L + Q) + f2 L^2
+//             = f0 + (f1 w1) v + (f1 w2) u + (f1 w3 + f2 w1^2) v^2 + (f1 w4 + 2 f2 w1 w2) u v + (f1 w5 + f2 w2^2) u^2
+// to within  0.00694 dmax^3 + max |f2| q (2 l + q),  max |f2| = 0.02312.  Rows whose bound stays below kTaylorErr = 8.7e-7 (the
+// cubic term alone reaches it at dmax = 0.05) are the Taylor tier: poly_transform tests them, taylor_convert overwrites the
+// six logit coefficients of such a splat IN PLACE with the six colour coefficients -- one exponential per (tile, splat, channel)
+// --, and the entry loops of the polynomial kernels evaluate the row ONCE, by the same five packed FMAs per pixel pair and channel
+// whatever it holds: a Taylor row delivers the colour (no exponential, no reciprocal per pixel; until round 5: 12 exponentials +
+// 4 reciprocals per lane and entry, 80 of the forward's 154 issue slots per (wavefront, entry), 64 of the backward's 328), any
+// other row the logit, which takes the exponentials entry by entry as before (a wave-uniform bit per staged record, as the exact
+// tier: outliers with large higher bands, very wide cameras).  Forward and backward take the same bit, hence the same values.
+// Row layout (8 floats per (splat, channel)): (w0, w1 | w2, w4 | w5, 0 | w3, -) for the monomials (1, v | u, uv | u^2, - | v^2).
+constexpr int kPolyStride = 8;
+constexpr float kTaylorErr = 8.7e-7f;
+__host__ __device__ __forceinline__ bool taylor_row_ok(float l, float q) {  // (NaN: false)
+  const float d = l + q;
+  return 0.00694f * d * d * d + 0.02312f * q * (2.0f * l + q) <= kTaylorErr;
+}
 constexpr int kPolyNodes = 9;
 // colour error of the degree-2 form <= 0.25 (sigmoid slope) x S x kPolyFitErr delta^3, delta = half diagonal of a tile in
 // camera space; used where that stays below 1e-5, a tenth of the 1e-4 image tolerance.  kPolyFitErr = 1.0: the SHIPPED fit's
@@ -439,7 +447,7 @@ __device__ __forceinline__ void poly_transform(const float *__restrict__ sh, con
     const v2f qa = {q0.x, q0.y}, qb = {q0.z, q0.w}, qc = {q1.x, q1.y}, qd = {q1.z, q1.w}, qe = {q2.x, q2.y}, qf = {q2.z, q2.w},
               qg = {q3.x, q3.y}, qh = {q3.z, q3.w};
     float *row = w + e * kPolyStride;
-    // monomials (1, v, u | v^2, uv, u^2) -> slots (0, 1, 2 | 6, 3, 4); 5 and 7 stay zero (5 is multiplied by u)
+    // monomials (1, v, u | v^2, uv, u^2) -> slots (0, 1, 2 | 6, 3, 4); 5 stays zero (it is multiplied by u), 7 is padding
     const int s0 = half ? 6 : 0, s1 = half ? 3 : 1, s2 = half ? 4 : 2;
 #pragma unroll 1  // (rolled: unrolled, the three monomials' 48 values of V stay live -- a wavefront per SIMD)
     for (int k = 0; k < 3; ++k) {
@@ -465,21 +473,34 @@ __device__ __forceinline__ void poly_transform(const float *__restrict__ sh, con
       const float sc = 40.0f / l1;
       row[s0] *= sc; row[s1] *= sc; row[s2] *= sc;
     }
-    // the Taylor tier's constants, by the lane that holds the row's first half (w0, w1, w2): f = 1 / (1 + 2^z) at the tile centre
-    // z0 = w0 -- the very expression the exponential path evaluates, so the two agree to the bit where d = 0 --, df/dz = -ln2 f (1 - f),
-    // half the second derivative = (ln2^2 / 2) f (1 - f) (1 - 2 f)
+    // the Taylor tier's test, by the lane that holds the row's first half (w0, w1, w2): l from its own sum, q from its neighbour's
+    // (of the unscaled row; a row scaled back to 40 is far beyond the tier anyway)
     if (live && !half) {
-      const float z0 = row[0];
-      const float f0 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z0));
-      const float ff = f0 * (1.0f - f0);
-      row[7] = f0;
-      row[8] = 0.0f;
-      row[9] = row[1];
-      row[10] = -0.6931471805599453f * ff;
-      row[11] = 0.2402265069591007f * ff * (1.0f - 2.0f * f0);
-      const float dmax = l1 - fabsf(z0);  // (of the unscaled row; a row scaled back to 40 is far beyond the tier anyway)
-      tay_ok[e] = (l1 <= 40.0f && dmax <= kTaylorDmax) ? 1.0f : 0.0f;  // (NaN coefficients: false)
+      const float l = mine - fabsf(row[0]), q = l1 - mine;
+      tay_ok[e] = (l1 <= 40.0f && taylor_row_ok(l, q)) ? 1.0f : 0.0f;  // (NaN coefficients: false)
     }
+  }
+}
+// ... and the conversion of the Taylor tier's rows (bit g of mask = entry g of the staged batch), behind the barrier that follows
+// poly_transform and before the one the entry loop waits for: logit coefficients -> colour coefficients, in place.
+// f0 = 1 / (1 + 2^w0) is the very expression the exponential path evaluates -- the two agree to the bit where d = 0 --,
+// f1 = df/dz = -ln2 f (1 - f), f2 = half the second derivative = (ln2^2 / 2) f (1 - f) (1 - 2 f).
+template <int NT>
+__device__ __forceinline__ void taylor_convert(float *w, uint32_t mask, int nb) {
+#pragma unroll 1
+  for (int e = (int)threadIdx.x; e < nb * 3; e += NT) {
+    if (!((mask >> (e / 3)) & 1u)) continue;
+    float *row = w + e * kPolyStride;
+    const float w1 = row[1], w2 = row[2], w4 = row[3], w5 = row[4], w3 = row[6];
+    const float f0 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(row[0]));
+    const float ff = f0 * (1.0f - f0);
+    const float f1 = -0.6931471805599453f * ff, f2 = 0.2402265069591007f * ff * (1.0f - 2.0f * f0);
+    row[0] = f0;
+    row[1] = f1 * w1;
+    row[2] = f1 * w2;
+    row[3] = fmaf(f1, w4, 2.0f * f2 * w1 * w2);
+    row[4] = fmaf(f1, w5, f2 * w2 * w2);
+    row[6] = fmaf(f1, w3, f2 * w1 * w1);
   }
 }
 // the staged batch's mask of splats whose three channels may take the Taylor tier (bit g = entry g; KB <= 32): every wavefront forms
