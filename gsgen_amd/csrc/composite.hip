@@ -1237,7 +1237,11 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
 
   // per-pixel SH basis as (k, k+1) pairs
   v2f Yp[POLY ? 1 : PPL][POLY ? 1 : NPAIR];
-  float Vk[POLY ? kPolyNB : 1];  // POLY: column (lane & 15) of V
+  // POLY: where this lane's geometric component goes (see the reduction at the end of the entry loop): its base address and its
+  // stride per splat, nullptr for lanes that hold none -- three registers instead of the selects, shifts and spilled lane masks
+  // that formed the address per entry (13 vector instructions per (wavefront, entry) less)
+  float *geo_base = nullptr;
+  uint32_t geo_stride = 0u;
   // POLY: the lane's column offset and its pixel pairs' row offsets stand for the six monomials (see the forward)
   const float pu = poly_offset(lx);
   const v2f pu2 = splat2(pu);
@@ -1247,8 +1251,14 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
   if constexpr (POLY) {
     static_assert(!POLY || KB * 3 * kPolyNB >= kPolyNodes * 16, "node scratch fits the coefficient buffer");
     poly_tile_setup<NT>(p, tx, ty, Ws, Vs);
-#pragma unroll
-    for (int r = 0; r < kPolyNB; ++r) Vk[r] = Vs[r * 16 + (lane & 15)];
+    {
+      // lane (m, slot e = comp - 6) -> m 0: mean[e] | 1: cov[e] | 2: cov[3], alpha | 3: -, cov[2]
+      const int m = lane & 3, e = scatter_comp<8>(lane) - 6;
+      if (scatter_rows_owner<8>(lane) && e >= 0 && !(m == 3 && e == 0)) {
+        geo_base = m == 0 ? p.g_mean + e : ((m == 2 && e == 1) ? p.g_alpha : p.g_cov + (m == 1 ? e : (m == 2 ? 3 : 2)));
+        geo_stride = m == 0 ? 2u : ((m == 2 && e == 1) ? 1u : 4u);
+      }
+    }
   } else {
     float R[9];
 #pragma unroll
@@ -1396,19 +1406,19 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
         v2f yv[3][NP];
         if ((exact_mask >> g) & 1u) exact_tier_logits_all<PPL>(p, __builtin_amdgcn_readfirstlane(S.id[g]), px, py2, yv);
         else poly_rows_at_pixels<NP>(cg, pu2, pv2, yv);
+        v2f om2[NP];  // 1 - a G (>= 0.01)
+#pragma unroll
+        for (int jp = 0; jp < NP; ++jp) om2[jp] = one_minus2(ag2[jp]);
         if ((tay_mask >> g) & 1u) {  // (wave-uniform; the ordinary case)
 #pragma unroll
-          for (int jp = 0; jp < NP; ++jp) {
-            const v2f om = one_minus2(ag2[jp]);
-            inv1m2[jp] = v2f{__builtin_amdgcn_rcpf(om[0]), __builtin_amdgcn_rcpf(om[1])};
-          }
+          for (int jp = 0; jp < NP; ++jp) inv1m2[jp] = v2f{__builtin_amdgcn_rcpf(om2[jp][0]), __builtin_amdgcn_rcpf(om2[jp][1])};
         } else {
 #pragma unroll
           for (int jp = 0; jp < NP; ++jp) {
             v2f den[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) den[c] = splat2(1.0f) + v2f{__builtin_amdgcn_exp2f(yv[c][jp][0]), __builtin_amdgcn_exp2f(yv[c][jp][1])};
-            const v2f om = one_minus2(ag2[jp]);
+            const v2f om = om2[jp];
             const v2f d01 = den[0] * den[1], d2o = den[2] * om;
             const v2f dd = d01 * d2o;
             const v2f r = v2f{__builtin_amdgcn_rcpf(dd[0]), __builtin_amdgcn_rcpf(dd[1])};
@@ -1541,22 +1551,15 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
         // d L / d sh[c][k] = sum_r gw[c][r] V[r][k]: the 18 reduced values go through LDS, lanes (c, k) = (lane / 16,
         // lane % 16) expand them with their column of V (one wavefront per workgroup: the barrier is a wait)
         if (owner && m < 3 && comp < kPolyNB) gw_s[m * 8 + comp] = tot;
-        // the geometric components, ONE atomic instruction: lane (m, slot e = comp - 6) -> m 0: mean[e] | 1: cov[e] |
-        // 2: cov[3], alpha | 3: -, cov[2]   (branch-free address: a switch here cost ~35 scalar instructions per entry)
-        {
-          const int e = comp - 6;
-          float *const cov = p.g_cov + 4 * id;
-          float *dst = cov + (m == 1 ? e : (m == 2 ? 3 : 2));
-          dst = m == 0 ? p.g_mean + 2 * id + e : dst;
-          dst = (m == 2 && e == 1) ? p.g_alpha + id : dst;
-          if (owner && comp >= 6 && !(m == 3 && e == 0)) atomicAdd(dst, tot);
-        }
+        // the geometric components, ONE atomic instruction (geo_base / geo_stride: the lane's slot, fixed before the loop)
+        if (geo_base != nullptr) atomicAdd(geo_base + id * geo_stride, tot);
         __syncthreads();
         if (lane < 48) {
           const float *gw = &gw_s[(lane >> 4) * 8];
-          float acc = gw[0] * Vk[0];
+          const float *vk = &Vs[lane & 15];  // column (lane & 15) of V, from LDS as the sums are: six registers less across the loop
+          float acc = gw[0] * vk[0];
 #pragma unroll
-          for (int r = 1; r < kPolyNB; ++r) acc = fmaf(gw[r], Vk[r], acc);
+          for (int r = 1; r < kPolyNB; ++r) acc = fmaf(gw[r], vk[r * 16], acc);
           atomicAdd(p.g_col + (size_t)TR::NCOL * id + lane, acc);  // (c, k) -> 16 c + k = lane
         }
         __syncthreads();  // gw_s is consumed before the next splat overwrites it
