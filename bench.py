@@ -58,7 +58,7 @@ def make_workload(name):
         return scenes.random_scene(1000, seed=0, C=1), 256, 256
     if name in ("dry", "dry4"):  # the multi-rank dry run (tests/test_dist_gloo.py): a few dozen splats, SH degree 3
         sc = scenes.random_scene(60, seed=0, svec=0.006, spread=0.03, C=4)
-        sc["sh"][:, :, 1:] *= 0.2  # (every splat within every dry-run view's coefficient bound)
+        sc["sh"][:, :, 1:] *= 0.17  # (every splat within every dry-run view's coefficient bound)
         return sc, 40, 24
     raise SystemExit(f"unknown config {name}")
 

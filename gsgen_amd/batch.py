@@ -626,7 +626,7 @@ class BatchRenderer:
         col is sh_coeffs [N,3,C*C] for C in 1..4, post-activation rgb [N,3] for C == 0.
         sh_basis (C == 4): "auto" (default) -- the per-splat coefficient bounds S_i = max_c sum_{k>=1} |sh[i][c][k]| are measured
         on the device in front of the launch (one 10-us pass on the render's stream, no host sync) and the kernels route on them
-        per list entry and per tile: the tile-local polynomial form of the per-pixel SH basis where 0.25 S_i delta^3 <= 1e-5
+        per list entry and per tile: the tile-local polynomial form of the per-pixel SH basis where 0.25 S_i delta^3 <= 1e-5 - 8.7e-7
         (colours within 1e-5 of the exact kernels'), the exact evaluation elsewhere (include/gsgen_hip.h "the coefficient
         bound").  "exact": the exact kernels only.  sh_l1_bound: a 1-float DEVICE tensor that already holds max_i S_i for THESE
         coefficients (e.g. renderer.sh_l1_bound_device(sh) evaluated once for several batches of one optimiser step) -- skips

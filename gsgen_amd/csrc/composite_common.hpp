@@ -360,21 +360,23 @@ __host__ __device__ __forceinline__ bool taylor_row_ok(float l, float q) {  // (
 }
 constexpr int kPolyNodes = 9;
 // colour error of the degree-2 form <= 0.25 (sigmoid slope) x S x kPolyFitErr delta^3, delta = half diagonal of a tile in
-// camera space; used where that stays below 1e-5, a tenth of the 1e-4 image tolerance.  kPolyFitErr = 1.0: the SHIPPED fit's
+// camera space; used where that stays below kPolyFitTol = 1e-5 - kTaylorErr: with the Taylor tier's 8.7e-7 on top a routed colour
+// is within 1e-5 of the exact kernels', a tenth of the 1e-4 image tolerance.  kPolyFitErr = 1.0: the SHIPPED fit's
 // largest basis error is 0.93 delta^3 (tests/test_poly_fit_bound.py sweeps kPolyFit over rotations, tile positions and focal
 // lengths).  Rounds 2-4 routed on 0.7 -- a calibration of a different interpolation -- which made the promise 1.4e-5.
 // S <= 0, NaN or infinite: never.  One function for the host's report and the kernels' routing.
 constexpr float kPolyFitErr = 1.0f;
+constexpr float kPolyFitTol = 1e-5f - kTaylorErr;
 __host__ __device__ __forceinline__ bool poly_ok(float S, float ps_max) {
   if (!(S > 0.0f) || !(S <= 3.0e38f)) return false;
   const float delta = 7.5f * 1.41421356f * ps_max;
-  return 0.25f * S * kPolyFitErr * delta * delta * delta <= 1e-5f;
+  return 0.25f * S * kPolyFitErr * delta * delta * delta <= kPolyFitTol;
 }
 // per-splat form of the same rule: may a splat whose rows sum to at most S be rendered through the polynomial basis in a view of
 // this pixel size?  S = 0 (no higher bands: the fit of the constant term is exact) passes; NaN does not.
 __host__ __device__ __forceinline__ bool poly_row_ok(float S, float ps_max) {
   const float delta = 7.5f * 1.41421356f * ps_max;
-  return 0.25f * S * kPolyFitErr * delta * delta * delta <= 1e-5f;
+  return 0.25f * S * kPolyFitErr * delta * delta * delta <= kPolyFitTol;
 }
 // does the polynomial form render this view?  (uniform over the workgroup: one scalar load)
 __device__ __forceinline__ bool poly_route(const float *sh_bound, float psx, float psy) {

@@ -426,8 +426,12 @@ int gsgen_vol_render_backward_sh_batch(uint32_t n_views, const gsgen_sh_view *vi
  * tile positions and focal lengths): six-term contractions against coefficients transformed once per (tile, splat), +56 %
  * renders/s on BASELINE configs[1].  The colour error is <= 0.25 * S * delta^3 with
  *     S = max over splats and channels of sum_{k >= 1} |sh[i][c][k]|,
- * and the polynomial form is used only where that stays <= 1e-5: routed colours within 1e-5 of the exact kernels', a tenth of
- * the 1e-4 image tolerance.  (Rounds 2-4 routed on 0.7 delta^3, a calibration of a different interpolation: 1.4e-5.)
+ * and the polynomial form is used only where that stays <= 1e-5 - 8.7e-7.  The 8.7e-7 belong to the Taylor tier (round 5): a
+ * splat whose logits move little enough across the tile -- remainder bound 0.00694 (l + q)^3 + 0.02312 q (2 l + q) <= 8.7e-7
+ * for the linear and quadratic parts l, q of its row's coefficient sum, the ordinary case by a factor of hundreds -- gets its
+ * COLOUR as a quadratic in the pixel offsets, formed once per (tile, splat): no exponential per pixel.  Together: routed colours
+ * within 1e-5 of the exact kernels', a tenth of the 1e-4 image tolerance.  (Rounds 2-4 routed on 0.7 delta^3, a calibration
+ * of a different interpolation: 1.4e-5.)
  *
  * S lives in DEVICE memory and never visits the host: gsgen_sh_l1_bound writes it (one coalesced pass over the
  * coefficients, ~5 us for 100 k splats; enqueue it on the render's stream whenever the coefficients may have changed, i.e.
@@ -485,7 +489,7 @@ int gsgen_vol_render_backward_sh_bounded(uint32_t N, uint32_t D, const float *me
  * higher-band coefficients, or a wide camera, sends the whole view to the exact kernels.  The *_routed entry points take the
  * bound per SPLAT -- sh_row_bounds[i] = max over the three channels of sum_{k >= 1} |sh[i][c][k]|, DEVICE memory, [N], measured per
  * step by gsgen_sh_l1_bound_rows (one coalesced pass, no atomics but one per workgroup; out_max, optional, receives the global
- * maximum the per-view rule uses) -- and decide per ENTRY and per TILE: a splat that satisfies 0.25 * S_i * delta^3 <= 1e-5
+ * maximum the per-view rule uses) -- and decide per ENTRY and per TILE: a splat that satisfies 0.25 * S_i * delta^3 <= 1e-5 - 8.7e-7
  * for its view's pixel size (the same rule, per splat) is evaluated through the tile's polynomial form; one beyond it is evaluated
  * exactly, entry by entry, inside the same kernel (the pixel's own SH basis against its raw coefficients); a staged batch of 32
  * records with more than a quarter of such splats sends its tile -- and only that tile -- to the exact kernel.  Splats behind the

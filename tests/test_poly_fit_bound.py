@@ -1,7 +1,7 @@
 """The routing constant of the tile-local polynomial SH basis against the fit that actually ships.
 
-composite_common.hpp routes a splat to the polynomial form where  0.25 * S * kPolyFitErr * delta^3 <= 1e-5  (poly_ok /
-poly_row_ok): 0.25 = the sigmoid's largest slope, S = the largest sum_{k>=1} |sh| of one (splat, channel) row, delta = a tile's
+composite_common.hpp routes a splat to the polynomial form where  0.25 * S * kPolyFitErr * delta^3 <= 1e-5 - 8.7e-7  (poly_ok /
+poly_row_ok; the 8.7e-7 are the Taylor tier's share of the budget, kTaylorErr): 0.25 = the sigmoid's largest slope, S = the largest sum_{k>=1} |sh| of one (splat, channel) row, delta = a tile's
 half diagonal in camera space, and "kPolyFitErr delta^3" stands for the largest error of one basis function under the degree-2
 fit.  Rounds 2-4 shipped 0.7 there, calibrated with a different interpolation and a single rotation (tools/tile_basis_error.py),
 which made the real guarantee 1.4e-5; since round 5 the constant is the measured one, 1.0.  This test evaluates the SHIPPED fit
@@ -88,7 +88,10 @@ def test_shipped_fit_error_constant():
 def test_documented_guarantee_matches_the_routing_rule():
     """poly_ok's constants as shipped, and the guarantee the documents state for them"""
     src = open(os.path.join(ROOT, "gsgen_amd", "csrc", "composite_common.hpp")).read()
-    assert src.count("return 0.25f * S * kPolyFitErr * delta * delta * delta <= 1e-5f;") == 2 and "constexpr float kPolyFitErr = 1.0f;" in src
+    assert src.count("return 0.25f * S * kPolyFitErr * delta * delta * delta <= kPolyFitTol;") == 2 and "constexpr float kPolyFitErr = 1.0f;" in src
+    # the fit's share and the Taylor tier's share add up to the promise
+    assert "constexpr float kPolyFitTol = 1e-5f - kTaylorErr;" in src and "constexpr float kTaylorErr = 8.7e-7f;" in src
+    assert "0.00694f * d * d * d + 0.02312f * q * (2.0f * l + q) <= kTaylorErr" in src
     for doc in ("DESIGN.md", os.path.join("include", "gsgen_hip.h")):
         text = open(os.path.join(ROOT, doc)).read()
         assert "within 1e-5 of the exact" in text, doc
