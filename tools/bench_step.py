@@ -32,7 +32,7 @@ ap.add_argument("--batch", type=int, default=4, help="views per step (conf/base.
 ap.add_argument("--steps", type=int, default=100)
 ap.add_argument("--warmup", type=int, default=20)
 ap.add_argument("--graph", action="store_true", help="replay the whole step from one hipGraph")
-ap.add_argument("--pipeline", choices=["auto", "on", "off"], default="auto", help="BatchRenderer(pipeline=...): two half-batches on two streams")
+ap.add_argument("--pipeline", choices=["auto", "on", "off"], default="off", help="BatchRenderer(pipeline=...): two half-batches on two streams")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 sc = scenes.pointe_scene(a.n, seed=0, C=1)
