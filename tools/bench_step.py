@@ -32,6 +32,7 @@ ap.add_argument("--batch", type=int, default=4, help="views per step (conf/base.
 ap.add_argument("--steps", type=int, default=100)
 ap.add_argument("--warmup", type=int, default=20)
 ap.add_argument("--graph", action="store_true", help="replay the whole step from one hipGraph")
+ap.add_argument("--profile", action="store_true", help="torch.profiler CPU table of 20 eager steps on stderr (where the host time goes)")
 ap.add_argument("--pipeline", choices=["auto", "on", "off"], default="off", help="BatchRenderer(pipeline=...): two half-batches on two streams")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -87,6 +88,14 @@ if a.graph:
         run = gr.replay
     except Exception as e:  # report, and time the eager step instead
         graph_error = f"{type(e).__name__}: {str(e)[:300]}"
+if a.profile:
+    from torch.profiler import profile, ProfilerActivity
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CPU]) as prof:
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize()
+    print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=40, max_name_column_width=60), file=sys.stderr)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(a.steps):
