@@ -616,7 +616,7 @@ __device__ __forceinline__ void composite_fwd_sh_vec_tile(const CompParams &p, u
     stage_batch<MODE, CB, NT, KB, true, !POLY>(S, p, st + base, nb);
     if constexpr (POLY) {
       // per-tile routing: splats beyond the bound for this view's pixel size take the per-entry exact tier
-      // (exact_tier_denominators); more than a quarter of a staged batch sends the WHOLE tile to the exact kernel (nothing has
+      // (exact_tier_logits_all); more than a quarter of a staged batch sends the WHOLE tile to the exact kernel (nothing has
       // been written yet; CompParams::tile_flags).
       if (p.sh_rows != nullptr) {  // (uniform over the launch; known to be false where the caller proved every splat within the bound)
         exact_mask = exact_tier_mask<NT>(p, S.id, nb, t, &sm.exact_mask);
