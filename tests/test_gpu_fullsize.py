@@ -13,6 +13,7 @@ import numpy as np
 import pytest
 import torch
 
+from tile_chain import FUZZ_ATOL
 import scenes
 from oracle import oracle as O
 
@@ -421,8 +422,10 @@ def test_batched_launches_fuzz():
         if margin > 4e-7:  # (a flipped threshold decision moves the gradients by up to 1e-4 of an O(1) term)
             for k in KEYS:
                 got = P[k].grad.cpu().numpy()
-                assert np.abs(got - want[k]).max() <= 1e-3 * np.abs(want[k]).max() + 1e-6, (k, B, C, W, H, n, seed, svec, opaque, nseg)
+                # (the absolute floor: tile_chain.FUZZ_ATOL -- fp32 epsilon x an O(1) colour x 1 / (1 - 0.99))
+                assert np.abs(got - want[k]).max() <= 1e-3 * np.abs(want[k]).max() + FUZZ_ATOL, (k, B, C, W, H, n, seed, svec, opaque, nseg)
     run()
+    run.hypothesis.inner_test(1, 1, 1, 1, 1715, 249, 0.2, False, 1)  # found by a 1 500-example hunt (round 5): 7.0e-6 on a tensor whose largest entry is 3.2e-3
 
 
 def oracle_heads(sc, cam, go_rgb, go_d, go_o, go_z, bg):
@@ -496,7 +499,7 @@ def test_batched_heads_fuzz():
                 want[k] += gr[k]
         for k in keys:
             got = P[k].grad.cpu().numpy()
-            assert np.abs(got - want[k]).max() <= 1e-3 * np.abs(want[k]).max() + 1e-6, (k, B, W, H, n, seed, svec, opaque)
+            assert np.abs(got - want[k]).max() <= 1e-3 * np.abs(want[k]).max() + FUZZ_ATOL, (k, B, W, H, n, seed, svec, opaque)
     run()
 
 
