@@ -425,6 +425,9 @@ def main():
                          "is measured the same way afterwards and reported in the same line.  heads: the timed region IS the "
                          "RGB + heads step (profiling: with --only-timed a kernel trace holds exactly its launches)")
     ap.add_argument("--no-heads", action="store_true", help="skip the RGB + heads pass")
+    ap.add_argument("--heads-grad-form", choices=["moments", "plain"], default="moments",
+                    help="RGB + heads backward: the moment form BatchRenderer.render_heads runs (gsgen_vol_render_rgbd_backward_batch_"
+                         "moments, round 6) or the plain thirteen-component form, for same-box A/Bs")
     ap.add_argument("--torch-fill", action="store_true",
                     help="A/B: zero the step's gradient accumulators with a torch fill kernel between forward and backward (rounds "
                          "1-3) instead of inside the projection launch (gsgen_frame_geometry_batch_zero)")
@@ -549,6 +552,7 @@ def main():
     Np = (N + 3) // 4 * 4                      # row counts padded so that every gradient block starts 16-byte aligned
     n_sh4 = (N * CC3 + 3) // 4 * 4
     fused_fill = not args.torch_fill           # gradient accumulators zeroed inside the projection launch
+    heads_moments = args.heads_grad_form == "moments"
     want_heads = (args.path == "heads" or not args.no_heads) and "color" in sc and not dry
     if want_heads:
         t["color"] = torch.tensor(sc["color"], device=dev)
@@ -660,6 +664,8 @@ def main():
                 proj = (vtab([p(cam_dev[(k0 + i) % ncam]) for i in range(B)]), 1, vtab([p(b_.mask) for b_ in self.bufs]),
                         vtab(blk), vtab([a + 4 * 2 * Np for a in blk]), vtab([a + 4 * 6 * Np for a in blk]),
                         vtab([p(b_.depth) for b_ in self.bufs]))
+                if heads_moments:  # + the views' cov2d: the projection backward expands the moments (include/gsgen_hip.h)
+                    proj = proj + (vtab([p(b_.cov2d) for b_ in self.bufs]),)
                 self.htables[key] = (geo, views, proj)
             return self.htables[key]
 
@@ -767,6 +773,10 @@ def main():
             sl.e_done.record(stream)
             sl.started = True
 
+    # the RGB + heads backward in its moment form (round 6: what BatchRenderer.render_heads runs) or, for same-box A/Bs, the plain one
+    heads_bwd = lib.vol_render_rgbd_backward_batch_moments if heads_moments else lib.vol_render_rgbd_backward_batch
+    heads_proj_bwd = lib.project_gaussians_backward_batch_heads_moments if heads_moments else lib.project_gaussians_backward_batch_heads
+
     def run_heads_step(j, ev=None, gather=True, halves=False):
         """the trainer's default outputs for the same cameras: geometry, fused rgb + depth + opacity + depth^2 compositing
         forward, its backward for dense random gradients of all four heads, projection backward with the depth heads'
@@ -795,12 +805,12 @@ def main():
         if ev is not None:
             clock.call("events", ev[2].record, stream)
         for lo, n_, s_, bws_ in parts:
-            clock.call("composite_bwd", lib.vol_render_rgbd_backward_batch, n_, _sub(views, lo, n_), N, p(t["color"]), p(t["alpha"]),
+            clock.call("composite_bwd", heads_bwd, n_, _sub(views, lo, n_), N, p(t["color"]), p(t["alpha"]),
                        p(sl.hflat) + 4 * o, 16, nth, ntw, H, W, 1e-4, p(bws_), s_)
         if ev is not None:
             clock.call("events", ev[3].record, stream)
         join(sl, parts)
-        clock.call("project_bwd", lib.project_gaussians_backward_batch_heads, B, N, p(t["mean"]), p(t["qvec"]), p(t["svec"]), *proj,
+        clock.call("project_bwd", heads_proj_bwd, B, N, p(t["mean"]), p(t["qvec"]), p(t["svec"]), *proj,
                    p(sl.g_mean), p(sl.g_qvec), p(sl.g_svec), p(sl.h_color), s)
         if sl.geo_stream is not stream:
             sl.e_done.record(stream)
@@ -993,7 +1003,7 @@ def main():
     def heads_report(m, alone_, one_):
         Dm = float(np.mean(Ds))
         tot_h, parts_h = heads_alg_bytes(n_vis, Dm, W * H, nth * ntw)
-        bname, fname = lib.kernel_variant("rgbd_bwd_batch", 1, 1), lib.kernel_variant("rgbd_fwd_batch", 1, 1)
+        bname, fname = lib.kernel_variant("rgbd_bwd_batch_moments" if heads_moments else "rgbd_bwd_batch", 1, 1), lib.kernel_variant("rgbd_fwd_batch", 1, 1)
         val = world * B * K / m["el"]
         ach_ = B * parts_h["composite_bwd"] / (m["bwd_ms"] * 1e-3) / 1e9
         tr, vf, tr_src = committed_traffic(args.config, bname, B)

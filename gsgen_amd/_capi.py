@@ -63,6 +63,9 @@ SIGNATURES = {
                                                C.POINTER(vp), C.POINTER(vp), vp, vp, vp, vp],
     "gsgen_project_gaussians_backward_batch_heads": [u32, u32, vp, vp, vp, C.POINTER(vp), i32, C.POINTER(vp), C.POINTER(vp),
                                                      C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp, vp, vp, vp, vp],
+    "gsgen_project_gaussians_backward_batch_heads_moments": [u32, u32, vp, vp, vp, C.POINTER(vp), i32, C.POINTER(vp), C.POINTER(vp),
+                                                             C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp, vp, vp,
+                                                             vp, vp],
     "gsgen_sh_l1_bound_rows": [u32, vp, u32, vp, vp, vp],
     "gsgen_sh_l1_bound_rows_running": [u32, vp, u32, vp, vp, vp],
     "gsgen_vol_render_sh_batch_routed": [u32, C.POINTER(ShView), u32, vp, vp, u32, u32, u32, u32, u32, u32, f32, u32, vp, vp, vp, vp],
@@ -107,6 +110,8 @@ SIGNATURES = {
     "gsgen_vol_render_rgbd_batch": [u32, C.POINTER(RgbdView), u32, vp, vp, u32, u32, u32, u32, u32, f32, vp, vp],
     "gsgen_vol_render_rgbd_backward_batch": [u32, C.POINTER(RgbdView), u32, vp, vp, vp, u32, u32, u32, u32, u32, f32, vp,
                                              vp],
+    "gsgen_vol_render_rgbd_backward_batch_moments": [u32, C.POINTER(RgbdView), u32, vp, vp, vp, u32, u32, u32, u32, u32, f32, vp,
+                                                     vp],
     "gsgen_vol_render_rgb_batch": [u32, C.POINTER(RgbdView), u32, vp, vp, u32, u32, u32, u32, u32, f32, vp, vp],
     "gsgen_vol_render_rgb_backward_batch": [u32, C.POINTER(RgbdView), u32, vp, vp, vp, vp, u32, u32, u32, u32, u32, f32,
                                             vp, vp],

@@ -270,15 +270,17 @@ class _render_batch_heads(torch.autograd.Function):
         with _on(dev):
             parts = br._fork(B, ctx.parts)
             for k, (lo, n, s) in enumerate(parts):
-                lib.vol_render_rgbd_backward_batch(n, _sub(views, lo, n), N, _p(col), _p(alpha), _p(g_alpha), 16, nth, ntw, H, W,
-                                                   thresh, _p(br._bws[k]), s)
+                # the moment form (round 6, include/gsgen_hip.h): ten components per (tile, Gaussian) instead of thirteen
+                lib.vol_render_rgbd_backward_batch_moments(n, _sub(views, lo, n), N, _p(col), _p(alpha), _p(g_alpha), 16, nth, ntw,
+                                                           H, W, thresh, _p(br._bws[k]), s)
             br._join(parts)
             s = parts[0][2]
-            lib.project_gaussians_backward_batch_heads(B, N, _p(mean), _p(qvec), _p(svec), br._ptr_table("cam", B),
-                                                       int(ctx.detach), br._mask_table(B), br._ptr_table("g_mean2d", B),
-                                                       br._ptr_table("g_cov2d", B), br._ptr_table("g_chan6", B),
-                                                       br._ptr_table("depth", B), _p(g_mean), _p(g_qvec), _p(g_svec),
-                                                       _p(g_col), s)
+            # ... expanded per (view, Gaussian); leaves d L / d mean2d in the per-view blocks for the statistics below
+            lib.project_gaussians_backward_batch_heads_moments(B, N, _p(mean), _p(qvec), _p(svec), br._ptr_table("cam", B),
+                                                               int(ctx.detach), br._mask_table(B), br._ptr_table("g_mean2d", B),
+                                                               br._ptr_table("g_cov2d", B), br._ptr_table("g_chan6", B),
+                                                               br._ptr_table("depth", B), br._ptr_table("cov2d", B), _p(g_mean),
+                                                               _p(g_qvec), _p(g_svec), _p(g_col), s)
             if stats is not None and stats.grad_accum is not None:
                 lib.densify_update_batch(B, N, None, br._ptr_table("g_mean2d", B), br._mask_table(B), None,
                                          _p(stats.grad_accum), _p(stats.cnt), s)

@@ -292,6 +292,32 @@ __device__ __forceinline__ bool scatter_rows_owner(int lane) {
   return (lane & rest) == 0;
 }
 
+// Reduce-scatter of TEN components (round 6: the moment form of the RGB + heads backward).  c[0], c[1] = pairs A, B and c[3], c[4]
+// = pairs C, D are exchanged whole at lane distance 32 (A <-> C, B <-> D), the two singles e, f = c[2] against each other; at
+// distance 16 the surviving pairs are exchanged against each other and the single is all-reduced; distances 8 and 4 finish
+// (W0, W1, Z, Z) like a four-component scatter, 2 and 1 are all-reduce steps.  8 lane swaps + 5 adds at the two cross-row
+// levels instead of the 12 + 6 of a 16-wide scatter with six empty slots.  Returns the lane's total; component numbering
+// (scatter10_comp): 0 1 = A, 2 3 = B, 4 5 = C, 6 7 = D, 8 = e, 9 = f, i.e. c = {(0,1), (2,3), (8,9), (4,5), (6,7)}.
+__device__ __forceinline__ float wave_reduce_scatter10(v2f (&c)[5]) {
+  const v2f X = xchg_add2<32>(c[0], c[3]);                 // lanes < 32: A, lanes >= 32: C
+  const v2f Y = xchg_add2<32>(c[1], c[4]);                 // B | D
+  float Z = xchg_any<32>(c[2][0], c[2][1]);                // e | f
+  const v2f W = xchg_add2<16>(X, Y);                       // bit 16 clear: X's pair, set: Y's pair
+  Z = xchg_any<16>(Z, Z);
+  const float P1 = xchg_any<8>(W[0], Z), P2 = xchg_any<8>(W[1], Z);  // bit 8 clear: (W0, W1), set: (Z, Z)
+  float Q = xchg_any<4>(P1, P2);
+  Q = xchg_any<2>(Q, Q);
+  return xchg_any<1>(Q, Q);
+}
+__device__ __forceinline__ int scatter10_comp(int lane) {
+  if (lane & 8) return (lane & 32) ? 9 : 8;
+  return ((lane & 32) ? 4 : 0) + ((lane & 16) ? 2 : 0) + ((lane & 4) ? 1 : 0);
+}
+__device__ __forceinline__ bool scatter10_owner(int lane) {
+  if (lane & 3) return false;
+  return (lane & 8) ? (lane & (16 | 4)) == 0 : true;
+}
+
 // Only the log2(P) halving levels: every lane ends with the partial sum of component
 // scatter_comp<P>(lane) over the lanes that agree with it on the remaining lane bits (64 / P
 // partials per component, to be combined by the caller -- e.g. by the atomics that follow anyway).

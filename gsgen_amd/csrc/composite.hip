@@ -1816,11 +1816,24 @@ k_composite_fwd_chan_vec(CompParams p_arg, ViewPack<BATCH> pack) {
 // 2); the atomics' target is base(lane) + id * stride(lane), both fixed per lane before the list walk (the select chain
 // over four arrays per entry compiled to nested exec-mask branches and a flat atomic).
 // Reduction vector: channels [0, NCH) | pad to even | mean 2 | cov 4 | alpha 1.
-template <int MODE, bool BATCH = false>
+// MOM (round 6; RGB + heads, the batched launch of gsgen_vol_render_rgbd_backward_batch_moments): the MOMENT form of the
+// gradients.  Every geometric gradient of a splat is a moment of ONE per-pixel weight g = d L / d (a G) * a G against the
+// whitened offsets (u, v) = (p0 x + p1 y, p2 y) the Gaussian is evaluated through anyway (gauss_chol_pair):
+//   d mean2d = sum g Sigma^-1 d,  d cov2d = 0.5 sum g (Sigma^-1 d)(Sigma^-1 d)^T,  Sigma^-1 d = (k0 u, k1 u + k2 v)
+// are linear in (Mu, Mv) = sum g (u, v) and (Muu, Muv, Mvv) = sum g (u u, u v, v v): the kernel accumulates those five (14
+// packed operations per entry instead of 26 + 3) and the projection backward, one thread per (view, Gaussian), expands them
+// (geometry.hip, moments_to_grads).  The three depth heads' channels (d, 1, d d) fold into ONE gradient component,
+// d L / d depth = sum w (go_d + 2 d go_dd) (the "1" channel's gradient has no consumer), and their part of the suffix weight is
+// go_o + d (go_d + d go_dd): two packed FMAs per pixel pair instead of three channels' six.  Ten components instead of
+// thirteen cross the lanes, through a reduce-scatter shaped for ten (wave_reduce_scatter10: 8 lane swaps instead of 12).
+// Component order: r g | b dd | Mu Mv | Muu Muv | Mvv alpha  ->  grad_chan6[.][0..3], grad_mean (as [N,2] moments),
+// grad_cov (as [N,4]: three moments, the fourth float untouched), grad_alpha.
+template <int MODE, bool BATCH = false, bool MOM = false>
 __global__ void __launch_bounds__(64) GS_WAVES_PER_EU(5)  // RGB + heads: 106 -> 96 registers (16 bytes of scratch outside the entry loop): five per SIMD
 k_composite_bwd_chan_vec(CompParams p_arg, ViewPack<BATCH> pack) {
   const CompParams *plist = pack.table();  // (kernel-argument memory: scalar loads, no table in device memory)
   static_assert(MODE == MODE_RGB || MODE == MODE_SCALAR || MODE == MODE_RGBD, "post-activation channel modes");
+  static_assert(!MOM || MODE == MODE_RGBD, "the moment form exists for RGB + heads");
   uint32_t bid = blockIdx.x, grid = gridDim.x;
   const CompParams p = BATCH ? plist[batch_view(p_arg, bid, &grid)] : p_arg;
   (void)grid;
@@ -1865,10 +1878,17 @@ k_composite_bwd_chan_vec(CompParams p_arg, ViewPack<BATCH> pack) {
   auto alive = [&](int j) { return !(Tr2[j >> 1][j & 1] < p.thresh); };
 
   // where this lane's component of the reduced gradient goes: dst = base + id * stride (bytes); no target: base = 0
-  const int comp = scatter_comp<P>(lane);
+  const int comp = MOM ? scatter10_comp(lane) : scatter_comp<P>(lane);
   char *a_base = nullptr;
   uint32_t a_stride = 0;
-  if (scatter_owner<P>(lane)) {
+  if constexpr (MOM) {
+    if (scatter10_owner(lane)) {
+      if (comp < 4) { a_base = reinterpret_cast<char *>(p.g_col + comp); a_stride = 4u * (uint32_t)TR::NCOL; }
+      else if (comp < 6) { a_base = reinterpret_cast<char *>(p.g_mean + (comp - 4)); a_stride = 8u; }
+      else if (comp < 9) { a_base = reinterpret_cast<char *>(p.g_cov + (comp - 6)); a_stride = 16u; }
+      else { a_base = reinterpret_cast<char *>(p.g_alpha); a_stride = 4u; }
+    }
+  } else if (scatter_owner<P>(lane)) {
     if (comp < NCH) { a_base = reinterpret_cast<char *>(p.g_col + comp); a_stride = 4u * (uint32_t)TR::NCOL; }
     else if (comp >= G0 && comp < G0 + 2) { a_base = reinterpret_cast<char *>(p.g_mean + (comp - G0)); a_stride = 8u; }
     else if (comp >= G0 + 2 && comp < G0 + 6) { a_base = reinterpret_cast<char *>(p.g_cov + (comp - G0 - 2)); a_stride = 16u; }
@@ -1892,14 +1912,14 @@ k_composite_bwd_chan_vec(CompParams p_arg, ViewPack<BATCH> pack) {
       const float r_mx = S.mx[g], r_my = S.my[g], r_a = S.a[g], r_p0 = S.p0[g], r_p1 = S.p1[g], r_p2 = S.p2[g];
       const float x = px - r_mx;
       // G2 / ag2: the Gaussian (gauss_eval's Cholesky form) and a G, ZEROED where the pixel does not take part
-      v2f y2[NP], G2[NP], ag2[NP];
+      v2f y2[NP], G2[NP], ag2[NP], u2[NP], v2[NP];
       bool any_con = false;
       float guard_dist = 0.0f;  // (as the forward: one distance per lane, dead pixels included)
       const float p0x = r_p0 * x;
 #pragma unroll
       for (int jp = 0; jp < NP; ++jp) {
         y2[jp] = py2[jp] - splat2(r_my);
-        G2[jp] = gauss_chol_pair(p0x, r_p1, r_p2, y2[jp]);
+        G2[jp] = gauss_chol_pair(p0x, r_p1, r_p2, y2[jp], u2[jp], v2[jp]);
         ag2[jp] = splat2(r_a) * G2[jp];
         const v2f dist = ag2[jp] - splat2(kMinAlpha);
         const float dmin = fminf(fabsf(dist[0]), fabsf(dist[1]));
@@ -1930,9 +1950,6 @@ k_composite_bwd_chan_vec(CompParams p_arg, ViewPack<BATCH> pack) {
                                                                        // the pixel takes part, 0 elsewhere): no second select
       if (!wave_any(any_con)) continue;  // nobody in the wave sees this Gaussian
 
-      v2f gr2[P / 2];
-#pragma unroll
-      for (int i = 0; i < P / 2; ++i) gr2[i] = v2f{0.0f, 0.0f};
       const float *cg = &S.col[g * TR::NCOLP];
       v2f w2[NP], om2[NP], gy2[NP];
 #pragma unroll
@@ -1940,6 +1957,59 @@ k_composite_bwd_chan_vec(CompParams p_arg, ViewPack<BATCH> pack) {
         w2[jp] = (splat2(r_a) * Tr2[jp]) * G2[jp];  // the forward's (a T) G, or 0
         om2[jp] = one_minus2(ag2[jp]);
       }
+      if constexpr (MOM) {
+        v2f c5[5];
+        float gch[4];
+        // the three depth heads first: their share of  sum_c grad_out_c value_c  is  go_o + d (go_d + d go_dd),  their one gradient
+        // component  sum w (go_d + 2 d go_dd)
+        const float d = cg[3], dd2 = d + d;
+        v2f gacc;
+#pragma unroll
+        for (int jp = 0; jp < NP; ++jp) {
+          gy2[jp] = fma2(splat2(d), fma2(splat2(d), go2[jp][5], go2[jp][3]), go2[jp][4]);
+          const v2f h = fma2(splat2(dd2), go2[jp][5], go2[jp][3]);
+          gacc = jp == 0 ? w2[jp] * h : fma2(w2[jp], h, gacc);
+        }
+        gch[3] = add_scalar(gacc[0], gacc[1]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const v2f val = splat2(cg[c]);
+#pragma unroll
+          for (int jp = 0; jp < NP; ++jp) {
+            gacc = jp == 0 ? w2[jp] * go2[jp][c] : fma2(w2[jp], go2[jp][c], gacc);  // d / d (channel value)
+            gy2[jp] = fma2(go2[jp][c], val, gy2[jp]);                                 // sum_c grad_out_c * value_c
+          }
+          gch[c] = add_scalar(gacc[0], gacc[1]);
+        }
+        v2f Mu, Mv, Muu, Muv, Mvv, gal;
+#pragma unroll
+        for (int jp = 0; jp < NP; ++jp) {
+          // the suffix behind this splat, grad_out-weighted, and d L / d (a G) from it (vol_render.h:379-409)
+          R2[jp] = fma2(-w2[jp], gy2[jp], R2[jp]);
+          const v2f inv1m = v2f{__builtin_amdgcn_rcpf(om2[jp][0]), __builtin_amdgcn_rcpf(om2[jp][1])};
+          const v2f pAG = fma2(gy2[jp], Tr2[jp], -(R2[jp] * inv1m));
+          const v2f gg = pAG * ag2[jp];
+          const v2f t = gg * u2[jp], sv = gg * v2[jp];
+          Mu = jp == 0 ? t : Mu + t;
+          Mv = jp == 0 ? sv : Mv + sv;
+          Muu = jp == 0 ? t * u2[jp] : fma2(t, u2[jp], Muu);
+          Muv = jp == 0 ? t * v2[jp] : fma2(t, v2[jp], Muv);
+          Mvv = jp == 0 ? sv * v2[jp] : fma2(sv, v2[jp], Mvv);
+          gal = jp == 0 ? pAG * G2[jp] : fma2(pAG, G2[jp], gal);
+          Tr2[jp] = Tr2[jp] * om2[jp];  // T (1 - a G) if it contributed (as the forward: 1 - round(a G))
+        }
+        // wave_reduce_scatter10's order: (r g) (b dd) (Mvv alpha) (Mu Mv) (Muu Muv)
+        c5[0] = v2f{gch[0], gch[1]};
+        c5[1] = v2f{gch[2], gch[3]};
+        c5[2] = v2f{add_scalar(Mvv[0], Mvv[1]), add_scalar(gal[0], gal[1])};
+        c5[3] = v2f{add_scalar(Mu[0], Mu[1]), add_scalar(Mv[0], Mv[1])};
+        c5[4] = v2f{add_scalar(Muu[0], Muu[1]), add_scalar(Muv[0], Muv[1])};
+        const float tot = wave_reduce_scatter10(c5);
+        if (a_base != nullptr) atomicAdd(reinterpret_cast<float *>(a_base + (size_t)(uint32_t)S.id[g] * a_stride), tot);
+      } else {
+      v2f gr2[P / 2];
+#pragma unroll
+      for (int i = 0; i < P / 2; ++i) gr2[i] = v2f{0.0f, 0.0f};
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
         const v2f val = splat2(cg[c]);
@@ -1984,6 +2054,7 @@ k_composite_bwd_chan_vec(CompParams p_arg, ViewPack<BATCH> pack) {
 
       wave_reduce_scatter2<P>(gr2);
       if (a_base != nullptr) atomicAdd(reinterpret_cast<float *>(a_base + (size_t)(uint32_t)S.id[g] * a_stride), gr2[0][0]);
+      }
     }
     bool any_alive = false;
 #pragma unroll
@@ -2180,18 +2251,19 @@ int launch_bwd_sh_batch(int C, const CompParams *host, uint32_t B, hipStream_t s
 
 // post-activation channels, B cameras per launch: packed, one wavefront per tile (the same operation sequence as the per-camera
 // kernels: identical bits).  MODE_RGBD = fused RGB + heads, MODE_RGB = colours only.
-template <int MODE>
+template <int MODE, bool MOM = false>
 static int launch_chan_batch(bool backward, const CompParams *host, uint32_t B, hipStream_t s) {
   if (B == 0 || host[0].ntw * host[0].nth == 0) return 0;
   const uint32_t nblk = comp_grid(host[0]);
   for_each_chunk(host, B, [&](const CompParams &p0, const ViewPack<true> &pack, uint32_t n) {
-    if (backward) hipLaunchKernelGGL((k_composite_bwd_chan_vec<MODE, true>), dim3(nblk * n), dim3(64), 0, s, p0, pack);
+    if (backward) hipLaunchKernelGGL((k_composite_bwd_chan_vec<MODE, true, MOM>), dim3(nblk * n), dim3(64), 0, s, p0, pack);
     else hipLaunchKernelGGL((k_composite_fwd_chan_vec<MODE, true>), dim3(nblk * n), dim3(64), 0, s, p0, pack);
   });
   return (int)hipGetLastError();
 }
 int launch_fwd_rgbd_batch(const CompParams *host, uint32_t B, hipStream_t s) { return launch_chan_batch<MODE_RGBD>(false, host, B, s); }
 int launch_bwd_rgbd_batch(const CompParams *host, uint32_t B, hipStream_t s) { return launch_chan_batch<MODE_RGBD>(true, host, B, s); }
+int launch_bwd_rgbd_batch_moments(const CompParams *host, uint32_t B, hipStream_t s) { return launch_chan_batch<MODE_RGBD, true>(true, host, B, s); }
 int launch_fwd_rgb_batch(const CompParams *host, uint32_t B, hipStream_t s) { return launch_chan_batch<MODE_RGB>(false, host, B, s); }
 int launch_bwd_rgb_batch(const CompParams *host, uint32_t B, hipStream_t s) { return launch_chan_batch<MODE_RGB>(true, host, B, s); }
 
@@ -2241,6 +2313,7 @@ int gsgen_kernel_variant(const char *stage, uint32_t C, uint32_t n_segments, cha
   else if (st == "rgb_bwd") n = snprintf(buf, sizeof buf, "k_composite_bwd_chan_vec<RGB>");
   else if (st == "rgbd_fwd_batch") n = snprintf(buf, sizeof buf, "k_composite_fwd_chan_vec<RGBD,BATCH>");
   else if (st == "rgbd_bwd_batch") n = snprintf(buf, sizeof buf, "k_composite_bwd_chan_vec<RGBD,BATCH>");
+  else if (st == "rgbd_bwd_batch_moments") n = snprintf(buf, sizeof buf, "k_composite_bwd_chan_vec<RGBD,BATCH,MOMENTS>");
   else return 0;
   if (n < 0) return 0;
   if ((size_t)n >= out_bytes) n = (int)out_bytes - 1;
@@ -2768,6 +2841,21 @@ int gsgen_vol_render_rgbd_backward_batch(uint32_t n_views, const gsgen_rgbd_view
     return e;
   hipStream_t s = (hipStream_t)stream;
   return launch_bwd_rgbd_batch(ps.data(), n_views, s);
+}
+
+int gsgen_vol_render_rgbd_backward_batch_moments(uint32_t n_views, const gsgen_rgbd_view *views, uint32_t N,
+                                                 const float *color, const float *alpha, float *grad_alpha,
+                                                 uint32_t tile_size, uint32_t n_tiles_h, uint32_t n_tiles_w, uint32_t H,
+                                                 uint32_t W, float thresh, void *batch_workspace, gsgen_stream_t stream) {
+  if (tile_size != 16) return GSGEN_EUNSUPPORTED;
+  if (n_views == 0 || N == 0) return 0;
+  if (!views || !batch_workspace || !grad_alpha) return GSGEN_EINVAL;
+  if (n_views > 65535) return GSGEN_EINVAL;
+  std::vector<CompParams> ps;
+  if (int e = fill_rgbd_params(n_views, views, color, alpha, grad_alpha, n_tiles_w, n_tiles_h, H, W, thresh, true, ps))
+    return e;
+  hipStream_t s = (hipStream_t)stream;
+  return launch_bwd_rgbd_batch_moments(ps.data(), n_views, s);
 }
 
 int gsgen_vol_render_rgb_batch(uint32_t n_views, const gsgen_rgbd_view *views, uint32_t N, const float *color,

@@ -310,13 +310,18 @@ __device__ __forceinline__ v2f gauss_sh_pair(float c0, float c1, float c2, float
 
 // The Cholesky-form Gaussian (RGB / scalar / RGB + heads) of the two pixels (x, y2[0]), (x, y2[1]) of one lane: the
 // operation sequence of gauss_eval's non-SH branch element for element, without the threshold guard.  p0x = p0 * x.
-__device__ __forceinline__ v2f gauss_chol_pair(float p0x, float p1, float p2, v2f y2) {
+// u, v: the whitened offsets u = p0 x + p1 y, v = p2 y the value is formed from (the moment form of the backward sums against them).
+__device__ __forceinline__ v2f gauss_chol_pair(float p0x, float p1, float p2, v2f y2, v2f &u, v2f &v) {
 #pragma clang fp contract(off)
-  const v2f u = ffma2(splat2(p1), y2, splat2(p0x));
-  const v2f v = splat2(p2) * y2;
+  u = ffma2(splat2(p1), y2, splat2(p0x));
+  v = splat2(p2) * y2;
   const v2f vv = v * v;
   const v2f e = -ffma2(u, u, vv);
   return v2f{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+}
+__device__ __forceinline__ v2f gauss_chol_pair(float p0x, float p1, float p2, v2f y2) {
+  v2f u, v;
+  return gauss_chol_pair(p0x, p1, p2, y2, u, v);
 }
 
 // ---- tile-local polynomial form of the per-pixel SH basis (SH degree 3, launches that are given the coefficient bound) ----

@@ -253,92 +253,133 @@ k_densify_update_views(uint32_t N, DensifyViews dv, int n_views, float *__restri
 // added atomically into caller-zeroed arrays shared by the cameras of a batch, which may run on
 // concurrent streams (masked-out rows are left alone).
 struct ProjGrad { float gm[3], gq[4], gs[3]; };
+// The Cholesky factor the compositing kernels evaluate an RGB / scalar / RGB + heads Gaussian through (prep_record in
+// composite_common.hpp: the same fp64 expressions, rounded to fp32 like the staged record), as k_i = kInvSc2 * p_i -- so that
+// Sigma^-1 d = (k0 u, k1 u + k2 v) for the kernels' u = p0 x + p1 y, v = p2 y.  A degenerate record never contributed: zeros.
+struct CholK { double k0, k1, k2; };
+__device__ __forceinline__ CholK chol_k_of(const float *__restrict__ cov2d_n) {
+  const double d0 = cov2d_n[0], d1 = cov2d_n[1], d2 = cov2d_n[2], d3 = cov2d_n[3];
+  const double det = d0 * d3 - d1 * d2;
+  bool ok = (det > 0.0) && (d3 > 0.0) && (fabs(d0) <= 3.402823466e+38) && (fabs(d1) <= 3.402823466e+38) &&
+            (fabs(d2) <= 3.402823466e+38) && (fabs(d3) <= 3.402823466e+38);
+  const double sdet = ok ? det : 1.0, s3 = ok ? d3 : 1.0;
+  const double qa = s3 / sdet, qb = -0.5 * (d1 + d2) / sdet, qc = d0 / sdet;
+  const double l11 = sqrt(qa), l21 = qb / l11;
+  const double l22s = qc - l21 * l21;
+  ok = ok && (l22s > 0.0);
+  const double l22 = sqrt(ok ? l22s : 1.0);
+  const double sc = 0.84932180028801904;  // sqrt(0.5 log2 e)
+  CholK k{0.0, 0.0, 0.0};
+  if (ok) {
+    k.k0 = (double)kInvSc2 * (double)(float)(l11 * sc);
+    k.k1 = (double)kInvSc2 * (double)(float)(l21 * sc);
+    k.k2 = (double)kInvSc2 * (double)(float)(l22 * sc);
+  }
+  return k;
+}
 // gradients of one Gaussian through one view's projection (rows of the reference's autograd graph,
-// gs/renderer.py:366-421)
+// gs/renderer.py:366-421).  Round 6: evaluated in fp64 from the fp32 inputs -- the oracle's arithmetic.  The chain
+// d cov2d -> d Sigma -> d M -> d R -> d q cancels STRUCTURALLY for near-isotropic scales (d q is proportional to differences
+// of s_j^2): in fp32 the nine-term sums of d q lost up to 1.2e-3 of the tensor's largest entry on image-sized splats and
+// the result moved with the order of the compositing atomics (profiles/r05_notes.md section 11).  One thread per
+// (Gaussian, view), ~400 flops: the launch stays bound by its 132 B of traffic per Gaussian.
+// gcov: d L / d cov2d (4 entries, row-major), gm0 / gm1: d L / d mean2d.
 __device__ __forceinline__ ProjGrad project_bwd_one(uint32_t n, const float *__restrict__ mean,
                                                     const float *__restrict__ qvec, const float *__restrict__ svec,
                                                     const float *__restrict__ c2w, int detach_depth,
-                                                    const float *__restrict__ g_mean2d,
-                                                    const float *__restrict__ g_cov2d, float g_depth_n) {
+                                                    double gm0, double gm1, const double (&gc)[4], float g_depth_n) {
   ProjGrad o;
-  float Rc[9], t[3];
-  load_pose(c2w, Rc, t);
-  const float *p = mean + 3 * (size_t)n, *q = qvec + 4 * (size_t)n, *s = svec + 3 * (size_t)n;
-  const float d0 = p[0] - t[0], d1 = p[1] - t[1], d2 = p[2] - t[2];
-  float u[3];
+  double Rc[9], t[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) Rc[i * 3 + j] = (double)c2w[i * 4 + j];
+    t[i] = (double)c2w[i * 4 + 3];
+  }
+  const float *p = mean + 3 * (size_t)n, *q = qvec + 4 * (size_t)n, *sf = svec + 3 * (size_t)n;
+  const double s[3] = {(double)sf[0], (double)sf[1], (double)sf[2]};
+  const double d0 = (double)p[0] - t[0], d1 = (double)p[1] - t[1], d2 = (double)p[2] - t[2];
+  double u[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) u[i] = Rc[i] * d0 + Rc[3 + i] * d1 + Rc[6 + i] * d2;
-  float nq = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-  nq = fmaxf(nq, 1e-12f);
-  const float w = q[0] / nq, x = q[1] / nq, y = q[2] / nq, z = q[3] / nq;
-  const float Rq[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
-                       2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
-                       2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)};
-  float M[9];
+  double nq = sqrt((double)q[0] * q[0] + (double)q[1] * q[1] + (double)q[2] * q[2] + (double)q[3] * q[3]);
+  nq = nq < 1e-12 ? 1e-12 : nq;
+  const double w = q[0] / nq, x = q[1] / nq, y = q[2] / nq, z = q[3] / nq;
+  const double Rq[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                        2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                        2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)};
+  double M[9];
 #pragma unroll
   for (int i = 0; i < 3; ++i)
 #pragma unroll
     for (int j = 0; j < 3; ++j) M[i * 3 + j] = s[j] * Rq[i * 3 + j];
-  const float ux = u[0], uy = u[1], uz = u[2];
-  const float iz = 1.0f / uz;
-  const float J[6] = {iz, 0.0f, -ux * iz * iz, 0.0f, iz, -uy * iz * iz};
-  float A[6];
+  const double ux = u[0], uy = u[1], uz = u[2];
+  const double iz = 1.0 / uz;
+  const double J[6] = {iz, 0.0, -ux * iz * iz, 0.0, iz, -uy * iz * iz};
+  double A[6];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int k = 0; k < 3; ++k)
       A[a * 3 + k] = J[a * 3] * Rc[k * 3] + J[a * 3 + 1] * Rc[k * 3 + 1] + J[a * 3 + 2] * Rc[k * 3 + 2];
-  const float4 g = *reinterpret_cast<const float4 *>(g_cov2d + 4 * (size_t)n);
-  const float gc[4] = {g.x, g.y, g.z, g.w};
   // dSigma = A^T G A ; only the symmetrised form enters dM
-  float dS[9];
+  double dS[9];
 #pragma unroll
   for (int j = 0; j < 3; ++j)
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      float acc = 0.f;
+      double acc = 0.0;
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc += A[a * 3 + j] * gc[a * 2 + b] * A[b * 3 + k];
       dS[j * 3 + k] = acc;
     }
-  float dM[9];
+  double dM[9];
 #pragma unroll
   for (int i = 0; i < 3; ++i)
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      float acc = 0.f;
+      double acc = 0.0;
 #pragma unroll
       for (int k = 0; k < 3; ++k) acc += (dS[i * 3 + k] + dS[k * 3 + i]) * M[k * 3 + j];
       dM[i * 3 + j] = acc;
     }
-  float dR[9];
+  double dR[9];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
-    float acc = 0.f;
+    double acc = 0.0;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       acc += dM[i * 3 + j] * Rq[i * 3 + j];
       dR[i * 3 + j] = dM[i * 3 + j] * s[j];
     }
-    o.gs[j] = acc;
+    o.gs[j] = (float)acc;
   }
-  float dq[4];
+  double dq[4];
   dq[0] = 2 * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]);
   dq[1] = 2 * (y * dR[1] + z * dR[2] + y * dR[3] - 2 * x * dR[4] - w * dR[5] + z * dR[6] + w * dR[7] - 2 * x * dR[8]);
   dq[2] = 2 * (-2 * y * dR[0] + x * dR[1] + w * dR[2] + x * dR[3] + z * dR[5] - w * dR[6] + z * dR[7] - 2 * y * dR[8]);
   dq[3] = 2 * (-2 * z * dR[0] - w * dR[1] + x * dR[2] + w * dR[3] - 2 * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
-  const float qh[4] = {w, x, y, z};
-  const float dot = qh[0] * dq[0] + qh[1] * dq[1] + qh[2] * dq[2] + qh[3] * dq[3];
+  const double qh[4] = {w, x, y, z};
+  const double dot = qh[0] * dq[0] + qh[1] * dq[1] + qh[2] * dq[2] + qh[3] * dq[3];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) o.gq[k] = (dq[k] - qh[k] * dot) / nq;
-  const float gm0 = g_mean2d[2 * (size_t)n], gm1 = g_mean2d[2 * (size_t)n + 1];
-  float du[3] = {gm0 * iz, gm1 * iz, g_depth_n};
+  for (int k = 0; k < 4; ++k) o.gq[k] = (float)((dq[k] - qh[k] * dot) / nq);
+  double du[3] = {gm0 * iz, gm1 * iz, (double)g_depth_n};
   if (!detach_depth) du[2] += -(ux * gm0 + uy * gm1) * iz * iz;
 #pragma unroll
-  for (int j = 0; j < 3; ++j) o.gm[j] = Rc[j * 3] * du[0] + Rc[j * 3 + 1] * du[1] + Rc[j * 3 + 2] * du[2];
+  for (int j = 0; j < 3; ++j) o.gm[j] = (float)(Rc[j * 3] * du[0] + Rc[j * 3 + 1] * du[1] + Rc[j * 3 + 2] * du[2]);
   return o;
+}
+__device__ __forceinline__ ProjGrad project_bwd_one(uint32_t n, const float *__restrict__ mean,
+                                                    const float *__restrict__ qvec, const float *__restrict__ svec,
+                                                    const float *__restrict__ c2w, int detach_depth,
+                                                    const float *__restrict__ g_mean2d,
+                                                    const float *__restrict__ g_cov2d, float g_depth_n) {
+  const float4 g = *reinterpret_cast<const float4 *>(g_cov2d + 4 * (size_t)n);
+  const double gc[4] = {(double)g.x, (double)g.y, (double)g.z, (double)g.w};
+  return project_bwd_one(n, mean, qvec, svec, c2w, detach_depth, (double)g_mean2d[2 * (size_t)n],
+                         (double)g_mean2d[2 * (size_t)n + 1], gc, g_depth_n);
 }
 
 template <bool ACC>
@@ -384,11 +425,30 @@ struct ProjBwdViews {
   // RGB + heads (gsgen_project_gaussians_backward_batch_heads): the view's channel gradients [N,6] = d L / d (r, g, b, d, 1, d*d)
   // and its depths [N]; d L / d depth = g3 + 2 d g5 is formed here, the colour gradient summed over the views
   const float *g_chan6[kProjViews], *depth[kProjViews];
+  // moment form (gsgen_project_gaussians_backward_batch_heads_moments): the view's cov2d [N,2,2]; g_mean2d / g_cov2d then hold
+  // the MOMENTS (Mu, Mv) / (Muu, Muv, Mvv, -) of the compositing backward's per-pixel weight against the whitened offsets
+  // (u, v) of the Cholesky-form Gaussian, expanded here (moments_to_grads)
+  const float *cov2d[kProjViews];
 };
+// d L / d mean2d and d L / d cov2d from the moments  M_ab = sum_pixels g a b,  g = d L / d (a G) * a G,  (a, b) in (u, v):
+// with Sigma^-1 d = (k0 u, k1 u + k2 v) (chol_k_of) the reference's sums (kernels.h:394-418)
+//   d mean2d += g Sigma^-1 d,   d cov2d += 0.5 g (Sigma^-1 d)(Sigma^-1 d)^T
+// are linear in (Mu, Mv) and (Muu, Muv, Mvv) -- once per (view, Gaussian) here instead of 13 packed operations per pixel
+// pair in the compositing backward's entry loop.
+__device__ __forceinline__ void moments_to_grads(const CholK &k, const float *__restrict__ mom2, const float *__restrict__ mom4,
+                                                 double &gm0, double &gm1, double (&gc)[4]) {
+  const double Mu = (double)mom2[0], Mv = (double)mom2[1];
+  const double Muu = (double)mom4[0], Muv = (double)mom4[1], Mvv = (double)mom4[2];
+  gm0 = k.k0 * Mu;
+  gm1 = k.k1 * Mu + k.k2 * Mv;
+  gc[0] = 0.5 * k.k0 * k.k0 * Muu;
+  gc[1] = gc[2] = 0.5 * k.k0 * (k.k1 * Muu + k.k2 * Muv);  // both off-diagonals receive the same value (kernels.h:414-415)
+  gc[3] = 0.5 * (k.k1 * k.k1 * Muu + 2.0 * k.k1 * k.k2 * Muv + k.k2 * k.k2 * Mvv);
+}
 __global__ void __launch_bounds__(kThreads)
 k_project_bwd_views(uint32_t N, const float *__restrict__ mean, const float *__restrict__ qvec,
                     const float *__restrict__ svec, ProjBwdViews pv, int n_views, int detach_depth, int accumulate,
-                    float *__restrict__ g_mean, float *__restrict__ g_qvec, float *__restrict__ g_svec,
+                    int moments, float *__restrict__ g_mean, float *__restrict__ g_qvec, float *__restrict__ g_svec,
                     float *__restrict__ g_color) {
   const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
@@ -414,7 +474,18 @@ k_project_bwd_views(uint32_t N, const float *__restrict__ mean, const float *__r
       gc[0] += c01.x; gc[1] += c01.y; gc[2] += c23.x;
       gd = c23.y + 2.0f * pv.depth[v][n] * c45.y;
     }
-    const ProjGrad o = project_bwd_one(n, mean, qvec, svec, pv.cam[v], detach_depth, pv.g_mean2d[v], pv.g_cov2d[v], gd);
+    ProjGrad o;
+    if (moments) {
+      double gm0, gm1, gcv[4];
+      moments_to_grads(chol_k_of(pv.cov2d[v] + 4 * (size_t)n), pv.g_mean2d[v] + 2 * (size_t)n, pv.g_cov2d[v] + 4 * (size_t)n,
+                       gm0, gm1, gcv);
+      // the view's d L / d mean2d in place of its two first moments: the densify statistics read it (gsgen_densify_update_batch,
+      // gs/gaussian_splatting.py:464-469)
+      *reinterpret_cast<float2 *>(const_cast<float *>(pv.g_mean2d[v]) + 2 * (size_t)n) = make_float2((float)gm0, (float)gm1);
+      o = project_bwd_one(n, mean, qvec, svec, pv.cam[v], detach_depth, gm0, gm1, gcv, gd);
+    } else {
+      o = project_bwd_one(n, mean, qvec, svec, pv.cam[v], detach_depth, pv.g_mean2d[v], pv.g_cov2d[v], gd);
+    }
 #pragma unroll
     for (int j = 0; j < 3; ++j) { a.gm[j] += o.gm[j]; a.gs[j] += o.gs[j]; }
 #pragma unroll
@@ -650,7 +721,7 @@ static int project_bwd_batch(uint32_t n_views, uint32_t N, const float *mean, co
                              const float *const *c2w, int detach_depth, const uint8_t *const *mask,
                              const float *const *g_mean2d, const float *const *g_cov2d, const float *const *g_depth,
                              const float *const *g_chan6, const float *const *depth, float *g_mean, float *g_qvec,
-                             float *g_svec, float *g_color, gsgen_stream_t stream) {
+                             float *g_svec, float *g_color, gsgen_stream_t stream, const float *const *cov2d = nullptr) {
   if (N == 0) return 0;
   if (!mean || !qvec || !svec || !g_mean || !g_qvec || !g_svec) return GSGEN_EINVAL;
   if (n_views && (!c2w || !g_mean2d || !g_cov2d)) return GSGEN_EINVAL;
@@ -658,6 +729,7 @@ static int project_bwd_batch(uint32_t n_views, uint32_t N, const float *mean, co
   for (uint32_t v = 0; v < n_views; ++v) {
     if (!c2w[v] || !g_mean2d[v] || !g_cov2d[v]) return GSGEN_EINVAL;
     if (g_chan6 && (!g_chan6[v] || !depth[v])) return GSGEN_EINVAL;
+    if (cov2d && !cov2d[v]) return GSGEN_EINVAL;
   }
   uint32_t v0 = 0;
   do {  // (an empty batch still zero-fills)
@@ -671,9 +743,10 @@ static int project_bwd_batch(uint32_t n_views, uint32_t N, const float *mean, co
       pv.g_depth[i] = g_depth ? g_depth[v0 + i] : nullptr;
       pv.g_chan6[i] = g_chan6 ? g_chan6[v0 + i] : nullptr;
       pv.depth[i] = depth ? depth[v0 + i] : nullptr;
+      pv.cov2d[i] = cov2d ? cov2d[v0 + i] : nullptr;
     }
     hipLaunchKernelGGL(k_project_bwd_views, grid_for(N), dim3(kThreads), 0, (hipStream_t)stream, N, mean, qvec,
-                       svec, pv, (int)nv, detach_depth, v0 ? 1 : 0, g_mean, g_qvec, g_svec, g_color);
+                       svec, pv, (int)nv, detach_depth, v0 ? 1 : 0, cov2d ? 1 : 0, g_mean, g_qvec, g_svec, g_color);
     v0 += nv;
   } while (v0 < n_views);
   return (int)hipGetLastError();
@@ -697,6 +770,18 @@ int gsgen_project_gaussians_backward_batch_heads(uint32_t n_views, uint32_t N, c
   if (!g_chan6 || !depth || !g_color) return GSGEN_EINVAL;
   return project_bwd_batch(n_views, N, mean, qvec, svec, c2w, detach_depth, mask, g_mean2d, g_cov2d, nullptr, g_chan6,
                            depth, g_mean, g_qvec, g_svec, g_color, stream);
+}
+
+int gsgen_project_gaussians_backward_batch_heads_moments(uint32_t n_views, uint32_t N, const float *mean, const float *qvec,
+                                                         const float *svec, const float *const *c2w, int detach_depth,
+                                                         const uint8_t *const *mask, float *const *g_mom2,
+                                                         const float *const *g_mom4, const float *const *g_chan6,
+                                                         const float *const *depth, const float *const *cov2d,
+                                                         float *g_mean, float *g_qvec, float *g_svec, float *g_color,
+                                                         gsgen_stream_t stream) {
+  if (!g_chan6 || !depth || !g_color || !cov2d) return GSGEN_EINVAL;
+  return project_bwd_batch(n_views, N, mean, qvec, svec, c2w, detach_depth, mask, g_mom2, g_mom4, nullptr, g_chan6, depth,
+                           g_mean, g_qvec, g_svec, g_color, stream, cov2d);
 }
 
 // Host side: the 56-float camera block of gsgen_frame_geometry.  Frustum planes as

@@ -85,6 +85,21 @@ T *tab(uintptr_t a) { return reinterpret_cast<T *>(a); }
 using OptT = c10::optional<Tensor>;
 Tensor opt(const OptT &t) { return (t.has_value() && t->defined()) ? *t : Tensor(); }
 
+// The kernels take raw pointers and the Plan's N: a renderer reused after densify / prune, or a wrongly shaped statistics buffer,
+// must be an error here, not an out-of-bounds access on the device.
+void check_param(const Tensor &t, const char *name, int64_t N, int64_t per, const Tensor &like) {
+  TORCH_CHECK(t.defined() && t.is_cuda() && t.scalar_type() == at::kFloat, "gsgen_amd: ", name, " must be a float32 CUDA tensor");
+  TORCH_CHECK(t.device() == like.device(), "gsgen_amd: ", name, " is on ", t.device(), ", mean on ", like.device());
+  TORCH_CHECK(t.numel() == N * per && (t.dim() == 0 || t.size(0) == N || per == 1),
+              "gsgen_amd: ", name, " has ", t.numel(), " elements, the renderer was built for N = ", N, " (", N * per,
+              "); build a new BatchRenderer after densify / prune");
+}
+void check_stats(const Tensor &t, const char *name, int64_t N, const Tensor &like) {
+  if (!t.defined()) return;
+  TORCH_CHECK(t.is_cuda() && t.scalar_type() == at::kFloat && t.is_contiguous() && t.device() == like.device() && t.numel() >= N,
+              "gsgen_amd: ", name, " must be a contiguous float32 CUDA tensor of at least N = ", N, " elements on ", like.device());
+}
+
 Tensor bg_grad(const Tensor &g_rgb, const Tensor &T, const Tensor &bg) {
   // d / d bg of rgb = ... + T * bg (gs/renderer.py:1283: nan_to_num(grad * T)), reduced to bg's shape
   return at::nan_to_num(g_rgb * T).sum_to_size(bg.sizes());
@@ -97,6 +112,10 @@ struct HeadsFn : public torch::autograd::Function<HeadsFn> {
                                OptT grad_accum_, OptT cnt_) {
     const Plan &p = *reinterpret_cast<const Plan *>(plan_addr);
     const Tensor bg = opt(bg_), max_radii2d = opt(max_radii2d_), grad_accum = opt(grad_accum_), cnt = opt(cnt_);
+    check_param(mean, "mean", p.N, 3, mean); check_param(qvec, "qvec", p.N, 4, mean); check_param(svec, "svec", p.N, 3, mean);
+    check_param(alpha, "alpha", p.N, 1, mean); check_param(color, "color", p.N, 3, mean);
+    check_stats(max_radii2d, "max_radii2d", p.N, mean); check_stats(grad_accum, "grad_accum", p.N, mean); check_stats(cnt, "cnt", p.N, mean);
+    TORCH_CHECK(p.kind == kRgbd && p.gch.defined(), "plan / call mismatch");
     mean = mean.contiguous(); qvec = qvec.contiguous(); svec = svec.contiguous();
     alpha = alpha.contiguous(); color = color.contiguous();
     c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(mean.device());
@@ -163,15 +182,17 @@ struct HeadsFn : public torch::autograd::Function<HeadsFn> {
       v[i].grad_opacity = pp[2] ? pp[2] + H * W * i : nullptr;
       v[i].grad_depth2 = pp[3] ? pp[3] + H * W * i : nullptr;
     }
-    GS(gsgen_vol_render_rgbd_backward_batch((uint32_t)B, v, (uint32_t)N, color.data_ptr<float>(), alpha.data_ptr<float>(),
-                                            gsh.data_ptr<float>(), 16, (uint32_t)p.nth, (uint32_t)p.ntw, (uint32_t)H, (uint32_t)W,
-                                            (float)ctx->saved_data["thresh"].toDouble(), tab<void>(p.bws), s));
-    GS(gsgen_project_gaussians_backward_batch_heads(
+    // the moment form (round 6): ten components per (tile, Gaussian) cross the lanes instead of thirteen; the projection backward
+    // expands the moments per (view, Gaussian) and leaves d L / d mean2d in the per-view blocks for the densify statistics below
+    GS(gsgen_vol_render_rgbd_backward_batch_moments((uint32_t)B, v, (uint32_t)N, color.data_ptr<float>(), alpha.data_ptr<float>(),
+                                                    gsh.data_ptr<float>(), 16, (uint32_t)p.nth, (uint32_t)p.ntw, (uint32_t)H,
+                                                    (uint32_t)W, (float)ctx->saved_data["thresh"].toDouble(), tab<void>(p.bws), s));
+    GS(gsgen_project_gaussians_backward_batch_heads_moments(
         (uint32_t)B, (uint32_t)N, mean.data_ptr<float>(), qvec.data_ptr<float>(), svec.data_ptr<float>(),
         tab<const float *const>(p.cam_tab), ctx->saved_data["detach"].toBool() ? 1 : 0, tab<const uint8_t *const>(p.mask_tab),
-        tab<const float *const>(p.gmean_tab), tab<const float *const>(p.gcov_tab), tab<const float *const>(p.gchan_tab),
-        tab<const float *const>(p.depth_tab), g_mean.data_ptr<float>(), g_qvec.data_ptr<float>(), g_svec.data_ptr<float>(),
-        g_col.data_ptr<float>(), s));
+        tab<float *const>(p.gmean_tab), tab<const float *const>(p.gcov_tab), tab<const float *const>(p.gchan_tab),
+        tab<const float *const>(p.depth_tab), tab<const float *const>(p.cov2d_tab), g_mean.data_ptr<float>(),
+        g_qvec.data_ptr<float>(), g_svec.data_ptr<float>(), g_col.data_ptr<float>(), s));
     const auto &ga = ctx->saved_data["grad_accum"];
     if (ga.isTensor() && ga.toTensor().defined()) {
       Tensor acc = ga.toTensor(), cnt = ctx->saved_data["cnt"].toTensor();
@@ -193,7 +214,13 @@ struct RenderFn : public torch::autograd::Function<RenderFn> {
     const Plan &p = *reinterpret_cast<const Plan *>(plan_addr);
     const Tensor bg = opt(bg_), sh_bound = opt(sh_bound_), sh_rows = opt(sh_rows_), max_radii2d = opt(max_radii2d_),
                  grad_accum = opt(grad_accum_), cnt = opt(cnt_);
-    TORCH_CHECK((C > 0) == (p.kind == kSh), "plan / C mismatch");
+    TORCH_CHECK((C > 0) == (p.kind == kSh) && C >= 0 && C <= 4 && p.kind != kRgbd, "plan / C mismatch");
+    check_param(mean, "mean", p.N, 3, mean); check_param(qvec, "qvec", p.N, 4, mean); check_param(svec, "svec", p.N, 3, mean);
+    check_param(alpha, "alpha", p.N, 1, mean); check_param(col, C > 0 ? "sh_coeffs" : "color", p.N, C > 0 ? 3 * C * C : 3, mean);
+    check_stats(max_radii2d, "max_radii2d", p.N, mean); check_stats(grad_accum, "grad_accum", p.N, mean); check_stats(cnt, "cnt", p.N, mean);
+    check_stats(sh_rows, "sh_row_bounds", p.N, mean);
+    TORCH_CHECK(!sh_bound.defined() || (sh_bound.is_cuda() && sh_bound.scalar_type() == at::kFloat && sh_bound.numel() >= 1),
+                "gsgen_amd: sh_l1_bound must be a float32 CUDA tensor");
     mean = mean.contiguous(); qvec = qvec.contiguous(); svec = svec.contiguous();
     alpha = alpha.contiguous(); col = col.contiguous();
     c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(mean.device());

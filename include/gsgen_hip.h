@@ -195,6 +195,21 @@ int gsgen_project_gaussians_backward_batch_heads(uint32_t n_views, uint32_t N, c
                                                  const float *const *g_cov2d, const float *const *g_chan6,
                                                  const float *const *depth, float *g_mean, float *g_qvec, float *g_svec,
                                                  float *g_color, gsgen_stream_t stream);
+/* The same behind the MOMENT form of that compositing backward (gsgen_vol_render_rgbd_backward_batch_moments, round 6):
+ * g_mom2[v] [N,2] = (Mu, Mv) and g_mom4[v] [N,4] = (Muu, Muv, Mvv, -) are sums over the view's pixels of the per-pixel weight
+ * g = d L / d (a G) * a G against the whitened offsets (u, v) of the Cholesky-form Gaussian; with Sigma^-1 d = (k0 u, k1 u + k2 v),
+ * k from the view's cov2d[v] [N,2,2] exactly as the compositing kernels prepare it, the reference's sums (kernels.h:394-418)
+ *   d mean2d = (k0 Mu, k1 Mu + k2 Mv),  d cov2d = 0.5 [k0^2 Muu, k0 (k1 Muu + k2 Muv); same, k1^2 Muu + 2 k1 k2 Muv + k2^2 Mvv]
+ * are formed here in fp64, once per (view, Gaussian), and chained through the projection as above.  g_chan6[v][:, 3] holds the
+ * folded d L / d depth of the three depth heads (columns 4, 5 stay zero).  g_mom2[v] is OVERWRITTEN with the view's
+ * d L / d mean2d (what gsgen_densify_update_batch reads, gs/gaussian_splatting.py:464-469). */
+int gsgen_project_gaussians_backward_batch_heads_moments(uint32_t n_views, uint32_t N, const float *mean, const float *qvec,
+                                                         const float *svec, const float *const *c2w, int detach_depth,
+                                                         const uint8_t *const *mask, float *const *g_mom2,
+                                                         const float *const *g_mom4, const float *const *g_chan6,
+                                                         const float *const *depth, const float *const *cov2d,
+                                                         float *g_mean, float *g_qvec, float *g_svec, float *g_color,
+                                                         gsgen_stream_t stream);
 int gsgen_adam_step(uint64_t n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
                     uint32_t n_groups, const uint64_t *group_end, const float *group_lr, float beta1,
                     float beta2, float eps, uint32_t step, gsgen_stream_t stream);
@@ -587,6 +602,18 @@ int gsgen_vol_render_rgbd_backward_batch(uint32_t n_views, const gsgen_rgbd_view
                                          const float *color, const float *alpha, float *grad_alpha,
                                          uint32_t tile_size, uint32_t n_tiles_h, uint32_t n_tiles_w, uint32_t H,
                                          uint32_t W, float thresh, void *batch_workspace, gsgen_stream_t stream);
+/* The MOMENT form of gsgen_vol_render_rgbd_backward_batch (round 6; replaces vol_render.h:866-992 + vol_render_scalar.h:104-234
+ * for the trainer's default outputs, gs/gaussian_splatting.py:1304-1416).  Same arguments; what the per-view accumulators
+ * receive differs: grad_mean [N,2] the two first moments (Mu, Mv), grad_cov [N,4] the three second moments (Muu, Muv, Mvv; the
+ * fourth float is not written) of the per-pixel weight d L / d (a G) * a G against the whitened offsets u = p0 x + p1 y,
+ * v = p2 y of the Cholesky-form Gaussian, grad_chan6 [N,6] = (d r, d g, d b, d L / d depth with the depth^2 head folded in
+ * -- sum w (go_d + 2 d go_dd) --, untouched, untouched).  gsgen_project_gaussians_backward_batch_heads_moments expands them: the
+ * entry loop sums 10 components per (tile, Gaussian) instead of 13 and spends 14 packed operations on the geometric part
+ * instead of 29.  Gradients agree with the plain form to fp32 rounding (tests/test_cpu_host.py, tests/test_gpu_api.py). */
+int gsgen_vol_render_rgbd_backward_batch_moments(uint32_t n_views, const gsgen_rgbd_view *views, uint32_t N,
+                                                 const float *color, const float *alpha, float *grad_alpha,
+                                                 uint32_t tile_size, uint32_t n_tiles_h, uint32_t n_tiles_w, uint32_t H,
+                                                 uint32_t W, float thresh, void *batch_workspace, gsgen_stream_t stream);
 /* Post-activation RGB only (gsgen_vol_render_start_end_with_T / gsgen_vol_render_backward_start_end for the
  * cameras of a batch): the same view array with out6 / grad_out6 read as [H,W,3] images, depth and grad_chan6
  * unused (may be NULL); the colour gradient [N,3] is shared and accumulates over the views like grad_alpha. */

@@ -761,6 +761,86 @@ def test_emulated_batched_rgb_heads_match_per_view_launches(emu):
         emu.vol_render_rgbd_batch(len(views), arr, Nall, P(col), P(al), 16, nth, ntw, H, W, 1e-4, P(bws), None)
 
 
+def test_emulated_rgb_heads_moment_form_equals_the_plain_backward(emu):
+    """Round 6: gsgen_vol_render_rgbd_backward_batch_moments + gsgen_project_gaussians_backward_batch_heads_moments (ten components
+    per (tile, Gaussian): r g b, one folded depth gradient, five moments of the per-pixel weight against the whitened offsets,
+    opacity; expanded per (view, Gaussian) in fp64) == the plain pair (thirteen components, kernels.h:394-418 evaluated per pixel):
+    every parameter gradient, the colour gradient, and the per-view d L / d mean2d the densify statistics read -- on round and on
+    strongly anisotropic splats, with the four head gradients as one [H,W,6] image and as four images."""
+    import ctypes as C
+    from gsgen_amd._capi import RgbdView
+    from gsgen_amd import renderer as R
+    W, H = 52, 36
+    for seed, aniso in ((43, False), (7, True)):
+        sc = scenes.random_scene(500, seed=seed, svec=0.07)
+        if aniso:
+            sc["svec"] = np.ascontiguousarray(sc["svec"] * np.array([4.0, 0.25, 1.0], np.float32))
+        Nall = sc["mean"].shape[0]
+        col, al = np.ascontiguousarray(sc["color"]), np.ascontiguousarray(sc["alpha"])
+        cams = [scenes.Camera(W, H, fx=46.0, c2w=scenes.look_at(e)) for e in ((2.5, 0, 0), (0.3, 2.4, 0.6), (-1.5, -1.5, 1.2))]
+        B = len(cams)
+        nth, ntw = cams[0].tiles
+        views = []
+        for i, cam in enumerate(cams):
+            g = scenes.oracle_geometry(sc, cam)
+            nz = np.nonzero(g["mask"])[0]
+            m2 = np.zeros((Nall, 2), np.float32); c2 = np.zeros((Nall, 2, 2), np.float32); dv = np.zeros(Nall, np.float32)
+            c2[:] = np.eye(2, dtype=np.float32)
+            m2[nz] = g["mean2d"]; c2[nz] = g["cov2d"]; dv[nz] = g["depth"].ravel()
+            views.append(dict(m2=m2, c2=c2, dv=dv, st=g["start"], en=g["end"], ids=nz[g["ids"]].astype(np.int32), tlp=cam.topleft,
+                              cam=cam, mask=g["mask"].astype(np.uint8),
+                              go=np.random.default_rng(10 * seed + i).normal(size=(H, W, 6)).astype(np.float32)))
+        arr = (RgbdView * B)()
+        for a, v in zip(arr, views):
+            cam = v["cam"]
+            v["out"] = np.zeros((H, W, 6), np.float32); v["T"] = np.zeros((H, W), np.float32)
+            a.mean, a.cov, a.depth, a.start, a.end, a.gaussian_ids = P(v["m2"]), P(v["c2"]), P(v["dv"]), P(v["st"]), P(v["en"]), P(v["ids"])
+            a.tile_order, a.topleft, a.pixel_size_x, a.pixel_size_y = None, P(v["tlp"]), 1 / cam.fx, 1 / cam.fy
+            a.out6, a.T = P(v["out"]), P(v["T"])
+        bws = np.zeros(emu.sh_batch_workspace_bytes(B), np.uint8)
+        emu.vol_render_rgbd_batch(B, arr, Nall, P(col), P(al), 16, nth, ntw, H, W, 1e-4, P(bws), None)
+        camv = [np.ascontiguousarray(R.CameraInfo(*v["cam"].intr).pack(v["cam"].c2w)) for v in views]
+        tab = lambda xs: (C.c_void_p * B)(*[x.ctypes.data for x in xs])  # noqa: E731
+        res = {}
+        for split in (False, True):
+            for form in ("plain", "moments"):
+                for a, v in zip(arr, views):
+                    v["gm"] = np.zeros((Nall, 2), np.float32); v["gc"] = np.zeros((Nall, 4), np.float32)
+                    v["gch"] = np.zeros((Nall, 6), np.float32)
+                    a.grad_mean, a.grad_cov, a.grad_chan6 = P(v["gm"]), P(v["gc"]), P(v["gch"])
+                    if split:
+                        v["go_parts"] = [np.ascontiguousarray(v["go"][..., :3]), np.ascontiguousarray(v["go"][..., 3]),
+                                         np.ascontiguousarray(v["go"][..., 4]), np.ascontiguousarray(v["go"][..., 5])]
+                        a.grad_out6 = None
+                        a.grad_rgb, a.grad_depth, a.grad_opacity, a.grad_depth2 = (P(x) for x in v["go_parts"])
+                    else:
+                        a.grad_out6 = P(v["go"])
+                ga = np.zeros(Nall, np.float32)
+                out = [np.zeros((Nall, n), np.float32) for n in (3, 4, 3, 3)]
+                common = (B, Nall, P(sc["mean"]), P(sc["qvec"]), P(sc["svec"]), tab(camv), 1, tab([v["mask"] for v in views]),
+                          tab([v["gm"] for v in views]), tab([v["gc"] for v in views]), tab([v["gch"] for v in views]),
+                          tab([v["dv"] for v in views]))
+                if form == "plain":
+                    emu.vol_render_rgbd_backward_batch(B, arr, Nall, P(col), P(al), P(ga), 16, nth, ntw, H, W, 1e-4, P(bws), None)
+                    gm2d = [v["gm"].copy() for v in views]
+                    emu.project_gaussians_backward_batch_heads(*common, *[P(a) for a in out], None)
+                else:
+                    emu.vol_render_rgbd_backward_batch_moments(B, arr, Nall, P(col), P(al), P(ga), 16, nth, ntw, H, W, 1e-4, P(bws), None)
+                    for v in views:  # the untouched slots: the fourth float of the second moments, channels 4 and 5
+                        assert not v["gc"][:, 3].any() and not v["gch"][:, 4:].any() and np.abs(v["gch"][:, 3]).max() > 0
+                    emu.project_gaussians_backward_batch_heads_moments(*common, tab([v["c2"] for v in views]), *[P(a) for a in out], None)
+                    gm2d = [v["gm"].copy() for v in views]  # overwritten with d L / d mean2d
+                res[form] = dict(ga=ga, out=out, gm2d=gm2d)
+            a_, b_ = res["plain"], res["moments"]
+            assert np.abs(a_["ga"]).max() > 0 and np.abs(a_["ga"] - b_["ga"]).max() <= 3e-6 * np.abs(a_["ga"]).max()
+            for x, y, name in zip(a_["out"], b_["out"], ("mean", "qvec", "svec", "color")):
+                assert np.abs(x).max() > 0 and np.abs(x - y).max() <= 2e-5 * np.abs(x).max(), (name, seed, split)
+            for x, y in zip(a_["gm2d"], b_["gm2d"]):
+                assert np.abs(x - y).max() <= 1e-5 * np.abs(x).max()
+    with pytest.raises(Exception, match="invalid"):
+        emu.project_gaussians_backward_batch_heads_moments(*common, None, *[P(a) for a in out], None)
+
+
 def test_emulated_batched_rgb_matches_per_view_launches(emu):
     """gsgen_vol_render_rgb_batch / _backward_batch (post-activation colours, no heads) == one
     gsgen_vol_render_start_end_with_T / gsgen_vol_render_backward_start_end call per view, colour and opacity

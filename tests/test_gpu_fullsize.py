@@ -456,51 +456,68 @@ def oracle_heads(sc, cam, go_rgb, go_d, go_o, go_z, bg):
     return g, (img, outs[0], outs[1], outs[2]), grads
 
 
+def heads_case(B, W, H, n, seed, svec, opaque, atol=FUZZ_ATOL):
+    """one example of the trainer's default outputs through BatchRenderer.render_heads against the reference's four passes in the
+    oracle: lists, the four images, all five parameter gradients"""
+    from gsgen_amd import renderer as R
+    from gsgen_amd.batch import BatchRenderer
+    keys = ("mean", "qvec", "svec", "alpha", "color")
+    sc = scenes.random_scene(n, seed=seed, svec=svec, C=1)
+    if opaque:
+        sc["alpha"][:] = 0.999
+    cams = [scenes.Camera(W, H, fx=float(max(W, 4)) * (0.8 + 0.25 * i), c2w=scenes.orbit(2.4 + 0.1 * i, 12.0 * i, 35.0 + 95.0 * i))
+            for i in range(B)]
+    cis = [R.CameraInfo(*c.intr) for c in cams]
+    bg = np.array([0.1, 0.2, 0.3], np.float32)
+    P = {k: T_(sc[k]).requires_grad_(True) for k in keys}
+    br = BatchRenderer(n, W, H, dev(), max_batch=B)
+    for _ in range(2):
+        outs = br.render_heads(P["mean"], P["qvec"], P["svec"], P["alpha"], P["color"], cis, [c.c2w for c in cams], bg_rgb=T_(bg))[:4]
+        if br.ensure_capacity(B):
+            break
+    gen = torch.Generator(device=dev()).manual_seed(seed)
+    gos = [torch.randn(B, H, W, c, device=dev(), generator=gen) for c in (3, 1, 1, 1)]
+    sum((o * g_).sum() for o, g_ in zip(outs, gos)).backward()
+    torch.cuda.synchronize()
+    want = {k: np.zeros(sc[k].shape, np.float64) for k in keys}
+    for i, cam in enumerate(cams):
+        gnp = [g_[i].cpu().numpy() for g_ in gos]
+        g, imgs, gr = oracle_heads(sc, cam, np.ascontiguousarray(gnp[0]), gnp[1][..., 0], gnp[2][..., 0], gnp[3][..., 0], bg)
+        check_lists(br.slots[i], g)
+        for o, ref in zip(outs, imgs):
+            got = o[i].detach().cpu().numpy().reshape(ref.shape)
+            assert np.abs(got - ref).max() <= 1e-4 * max(1.0, float(np.abs(ref).max())), (i, B, W, H, n, seed, svec, opaque)
+        for k in keys:
+            want[k] += gr[k]
+    for k in keys:
+        got = P[k].grad.cpu().numpy()
+        assert np.abs(got - want[k]).max() <= 1e-3 * np.abs(want[k]).max() + atol, (k, B, W, H, n, seed, svec, opaque)
+
+
 def test_batched_heads_fuzz():
     """hypothesis over the trainer's default outputs through BatchRenderer.render_heads (rgb + depth + opacity + depth^2 in
     one compositing pass per camera: k_composite_{fwd,bwd}_chan_vec<RGBD, BATCH>) against the reference's four passes in
     the oracle: ragged shapes, 1 .. 4 cameras, 1 .. 3000 Gaussians, opaque scenes, with and without a detached depth"""
     from hypothesis import given, settings, strategies as st, HealthCheck
-    from gsgen_amd import renderer as R
-    from gsgen_amd.batch import BatchRenderer
     n_ex = int(os.environ.get("GSGEN_FUZZ_EXAMPLES", "25"))
-    keys = ("mean", "qvec", "svec", "alpha", "color")
 
     @settings(max_examples=n_ex, deadline=None, derandomize=(n_ex == 25), suppress_health_check=list(HealthCheck))
     @given(B=st.integers(1, 4), W=st.integers(1, 150), H=st.integers(1, 120), n=st.integers(1, 3000),
            seed=st.integers(0, 10_000), svec=st.sampled_from([0.01, 0.05, 0.2]), opaque=st.booleans())
     def run(B, W, H, n, seed, svec, opaque):
-        sc = scenes.random_scene(n, seed=seed, svec=svec, C=1)
-        if opaque:
-            sc["alpha"][:] = 0.999
-        cams = [scenes.Camera(W, H, fx=float(max(W, 4)) * (0.8 + 0.25 * i), c2w=scenes.orbit(2.4 + 0.1 * i, 12.0 * i, 35.0 + 95.0 * i))
-                for i in range(B)]
-        cis = [R.CameraInfo(*c.intr) for c in cams]
-        bg = np.array([0.1, 0.2, 0.3], np.float32)
-        P = {k: T_(sc[k]).requires_grad_(True) for k in keys}
-        br = BatchRenderer(n, W, H, dev(), max_batch=B)
-        for _ in range(2):
-            outs = br.render_heads(P["mean"], P["qvec"], P["svec"], P["alpha"], P["color"], cis, [c.c2w for c in cams], bg_rgb=T_(bg))[:4]
-            if br.ensure_capacity(B):
-                break
-        gen = torch.Generator(device=dev()).manual_seed(seed)
-        gos = [torch.randn(B, H, W, c, device=dev(), generator=gen) for c in (3, 1, 1, 1)]
-        sum((o * g_).sum() for o, g_ in zip(outs, gos)).backward()
-        torch.cuda.synchronize()
-        want = {k: np.zeros(sc[k].shape, np.float64) for k in keys}
-        for i, cam in enumerate(cams):
-            gnp = [g_[i].cpu().numpy() for g_ in gos]
-            g, imgs, gr = oracle_heads(sc, cam, np.ascontiguousarray(gnp[0]), gnp[1][..., 0], gnp[2][..., 0], gnp[3][..., 0], bg)
-            check_lists(br.slots[i], g)
-            for o, ref in zip(outs, imgs):
-                got = o[i].detach().cpu().numpy().reshape(ref.shape)
-                assert np.abs(got - ref).max() <= 1e-4 * max(1.0, float(np.abs(ref).max())), (i, B, W, H, n, seed, svec, opaque)
-            for k in keys:
-                want[k] += gr[k]
-        for k in keys:
-            got = P[k].grad.cpu().numpy()
-            assert np.abs(got - want[k]).max() <= 1e-3 * np.abs(want[k]).max() + FUZZ_ATOL, (k, B, W, H, n, seed, svec, opaque)
+        heads_case(B, W, H, n, seed, svec, opaque)
     run()
+
+
+def test_near_isotropic_quaternion_gradient_twenty_runs():
+    """The example a 1 500-example hunt found in round 5 (profiles/r05_notes.md section 11): 2 cameras 1 x 107, 2 opaque image-sized
+    splats, seed 2 -- d L / d qvec came out 1.2e-3 of the tensor's largest entry off the oracle and failed one run in two with the
+    order of the fp32 atomics.  d q is proportional to differences of the squared scales: the nine-term sums of the chain
+    d cov2d -> d Sigma -> d M -> d R -> d q cancel structurally, and in fp32 their rounding was all that was left.  Round 6 evaluates
+    the chain in fp64 per (view, Gaussian) (geometry.hip, project_bwd_one -- the oracle's arithmetic, as autograd through
+    gs/renderer.py:391-421 in fp32 would not): twenty consecutive runs, the ordinary rtol 1e-3 and NO absolute floor."""
+    for _ in range(20):
+        heads_case(2, 107, 1, 2, 2, 0.2, True, atol=0.0)
 
 
 def test_full_size_cfg2_polynomial_sh_basis():
