@@ -98,7 +98,7 @@ class _render_batch(torch.autograd.Function):
         alpha, col = alpha.contiguous(), col.contiguous()
         lib = _capi.load()
         H, W, N, dev = br.H, br.W, br.N, mean.device
-        br._begin_batch(B)
+        # (BatchRenderer.render has run _begin_batch: overflow check + generation)
         out = torch.empty(B, H, W, 3, device=dev, dtype=torch.float32)
         T = torch.empty(B, H, W, 1, device=dev, dtype=torch.float32)
         out_p, T_p = out.data_ptr(), T.data_ptr()
@@ -203,8 +203,7 @@ class _render_batch_heads(torch.autograd.Function):
         alpha, col = alpha.contiguous(), col.contiguous()
         lib = _capi.load()
         H, W, N, dev = br.H, br.W, br.N, mean.device
-        br._begin_batch(B)
-        # (every pixel of out6 / T is written by the batched forward, the gradient accumulators are zeroed by the
+        # (BatchRenderer.render_heads has run _begin_batch; every pixel of out6 / T is written by the batched forward, the gradient accumulators are zeroed by the
         # projection launch: no fill kernels)
         out6 = torch.empty(B, H, W, 6, device=dev, dtype=torch.float32)
         T = torch.empty(B, H, W, 1, device=dev, dtype=torch.float32)
@@ -311,6 +310,7 @@ class BatchRenderer:
         # the slots' pair counters live in one tensor (one copy brings a batch's counts to the host where a sync is wanted)
         self._totals = torch.zeros(max_batch, device=device, dtype=torch.int32)
         self._report = R.PairCountReport(max_batch)
+        self.strict = self.strict or self._report.unmapped  # (no report channel: size every batch with the read-back)
         self._gen = np.zeros(1, np.int64)  # the generation counter, in memory the C++ autograd node reads too
         self._plans = {}
         self.use_ext = True    # the C++ autograd node (csrc/torch_batch.cpp) where it is built and applicable
@@ -554,7 +554,7 @@ class BatchRenderer:
 
     def _regrow(self, need):
         for s_ in self.slots:
-            s_._alloc_pairs(R._cap_for(need))
+            s_._alloc_pairs(R._cap_for(need), need)  # (raises beyond 2^31 - 1 pairs: no list can hold that frame)
             s_.sized = True
         self._generation += 1  # a pending backward would read freed lists
 
@@ -610,6 +610,21 @@ class BatchRenderer:
         return True
 
     # ---- the public calls ----------------------------------------------------------------------------------------------
+    def _check_params(self, mean, qvec, svec, alpha, col, ncol, stats):
+        """shapes against the renderer's N (a renderer reused after densify / prune must be an error, not an out-of-bounds access
+        on the device: the launches take raw pointers and self.N -- ADVICE r5)"""
+        N = self.N
+        for name, t, per in (("mean", mean, 3), ("qvec", qvec, 4), ("svec", svec, 3), ("alpha", alpha, 1), ("colour", col, ncol)):
+            if not (isinstance(t, torch.Tensor) and t.dtype == torch.float32 and t.device == mean.device and t.numel() == N * per
+                    and (per == 1 or t.shape[0] == N)):
+                raise ValueError(f"gsgen_amd.BatchRenderer: {name} must be a float32 tensor of {N} x {per} elements on {mean.device} "
+                                 f"(got {tuple(getattr(t, 'shape', ()))}); build a new BatchRenderer after densify / prune")
+        if stats is not None:
+            for name in ("max_radii2d", "grad_accum", "cnt"):
+                t = getattr(stats, name, None)
+                if t is not None and (t.numel() < N or t.dtype != torch.float32 or t.device != mean.device or not t.is_contiguous()):
+                    raise ValueError(f"gsgen_amd.BatchRenderer: stats.{name} must be a contiguous float32 tensor of >= {N} elements on {mean.device}")
+
     def _check_batch(self, cam_infos):
         B = len(cam_infos)
         if B > len(self.slots):
@@ -640,6 +655,7 @@ class BatchRenderer:
         if B == 0:
             z = torch.zeros(0, self.H, self.W, 3, device=self.device)
             return z, z[..., :1]
+        self._check_params(mean, qvec, svec, alpha, col, 3 * int(C) * int(C) if int(C) > 0 else 3, stats)
         cams = self._upload(cam_infos, c2ws, frustum_radius, tile_radius)
         self._cis = list(cam_infos)
         self._sh_bound = self._sh_rows = None
@@ -655,9 +671,11 @@ class BatchRenderer:
             else:  # per-splat bounds + their maximum: the launches take the view's bound first, then route per entry / tile
                 self._sh_rows = self._measure_bound(col)
                 self._sh_bound = self._smax if self._sh_rows is self._rows else None
+        # every forward starts with the overflow check -- BEFORE the plan is fetched: a quiet regrow replaces the slots' lists and
+        # the plan that points at them (the step it was triggered for used to run on the stale plan)
+        self._begin_batch(B)
         fast = self._plan("sh" if int(C) > 0 else "rgb", B)
         if fast is not None:  # one C++ autograd node (csrc/torch_batch.cpp): the same launches, a third of the host time
-            self._begin_batch(B)
             self._last_parts = [(0, B)]
             va = fast[1]
             va["pixel_size_x"][:B] = 1.0 / self._intr[:B, 0]
@@ -692,11 +710,12 @@ class BatchRenderer:
         if B == 0:
             z = torch.zeros(0, self.H, self.W, 3, device=self.device)
             return z, z[..., :1], z[..., :1], z[..., :1], z[..., :1]
+        self._check_params(mean, qvec, svec, alpha, color, 3, stats)
         cams = self._upload(cam_infos, c2ws, frustum_radius, tile_radius)
         self._cis = list(cam_infos)
+        self._begin_batch(B)  # (before the plan: see render)
         fast = self._plan("rgbd", B)
         if fast is not None:  # one C++ autograd node (csrc/torch_batch.cpp)
-            self._begin_batch(B)
             self._last_parts = [(0, B)]
             va = fast[1]
             va["pixel_size_x"][:B] = 1.0 / self._intr[:B, 0]

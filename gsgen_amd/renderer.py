@@ -291,9 +291,19 @@ class PairCountReport:
         self.n = int(n)
         self.host = torch.zeros(self.n, 2, dtype=torch.int32)
         self._dev = None
+        # unmapped: a GPU process whose pinned block has no device-side address -- nothing would ever be reported, an outgrown
+        # list would render NaN frames for ever with nobody told.  FrameBuffers / BatchRenderer then size every
+        # frame with the synchronous read-back (as strict=True does): lossless, one host sync per frame or batch.
+        self.unmapped = False
         if torch.cuda.is_available():  # (host-only processes -- bench.py's dry run, the CPU tests -- keep a plain block)
             self.host = self.host.pin_memory()
             self._dev = _capi.load().host_device_pointer(self.host.data_ptr())
+            if not self._dev:
+                import warnings
+                self._dev, self.unmapped = None, True
+                warnings.warn("gsgen_amd: the pinned pair-count report block is not mapped into the device's address space; every "
+                              "frame will be sized with a host read-back (as strict=True) instead of running unmonitored",
+                              RuntimeWarning, stacklevel=3)
         self._np = self.host.numpy().view(np.uint32)  # the same memory
 
     def ptr(self, i):
@@ -365,11 +375,18 @@ class FrameBuffers:
         self.strict = bool(strict)
         self._owns_report = report is None
         self._report, self._ri = (PairCountReport(1), 0) if report is None else report
+        self.strict = self.strict or self._report.unmapped
         # sized: the capacity comes from a measured frame (or from the caller, who then answers for it)
         self.sized = D_cap is not None
         self._alloc_pairs(D_cap if D_cap else max(4 * N, 1 << 16))
 
-    def _alloc_pairs(self, D_cap):
+    def _alloc_pairs(self, D_cap, need=0):
+        """need: the pair count this (re)allocation answers to.  List positions are int32 (the reference's start / end layout): a
+        frame beyond 2^31 - 1 pairs cannot be held by ANY list -- an error, not another round of the callers' retry loops
+        (a clamped capacity that no longer grows made frame_geometry / BatchRenderer._geometry spin)."""
+        if int(need) > 0x7FFFFFFF:
+            raise RuntimeError(f"gsgen_amd: a frame needs {int(need)} (tile, Gaussian) pairs, beyond the int32 list positions of the "
+                               "reference's layout -- the Gaussians' scales have diverged")
         self.generation += 1  # pending backwards hold pointers into the old lists
         self.D_cap = int(min(D_cap, 0x7FFFFFFF))
         self.ids = torch.empty(self.D_cap, device=self.device, dtype=torch.int32)
@@ -398,7 +415,7 @@ class FrameBuffers:
         if self._owns_report:
             self._report.clear()
         if need > self.D_cap:
-            self._alloc_pairs(_cap_for(need))
+            self._alloc_pairs(_cap_for(need), need)
             return False
         return True
 
@@ -431,7 +448,7 @@ class FrameBuffers:
             old = self.D_cap
             self._report.clear(self._ri)
             if need > self.D_cap:
-                self._alloc_pairs(_cap_for(need))
+                self._alloc_pairs(_cap_for(need), need)
             raise PairListOverflow(
                 f"gsgen_amd: an earlier frame through these buffers needed {need} (tile, Gaussian) pairs, capacity was {old}: "
                 f"its image and T are NaN and it contributed no gradients.  The buffers have been regrown to {self.D_cap}: "

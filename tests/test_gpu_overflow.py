@@ -179,6 +179,44 @@ def test_lists_are_regrown_before_a_growing_scene_overflows(setup):
     assert caps[-1] > 2 * caps[0]
 
 
+@pytest.mark.parametrize("heads", [False, True])
+def test_a_quiet_regrow_protects_the_step_that_triggered_it(setup, heads):
+    """on the C++ fast path the Plan used to be fetched BEFORE the overflow check, so the batch whose check regrew the
+    lists still ran on the old Plan (old buffers, old capacity) while slots[i].ids / tile_order() already named the new ones.  Now
+    the check comes first: the step that triggers the regrow bins into the NEW lists -- they hold the oracle's lists afterwards,
+    ensure_capacity() speaks about the frame that was actually rendered, and the backward runs."""
+    from gsgen_amd.batch import BatchRenderer
+    s = setup
+    P, cis, c2ws = s["P"], s["cis"], [c.c2w for c in s["cams"]]
+    br = BatchRenderer(s["N"], s["W"], s["H"], dev(), max_batch=4, D_cap=int(1.3 * max(s["Ds"])))
+    assert br.use_ext
+    sv = P["svec"].clone()
+    regrown = 0
+    for step in range(24):
+        cap0 = br.slots[0].D_cap
+        mean = P["mean"].clone().requires_grad_(True)
+        if heads:
+            img = br.render_heads(mean, P["qvec"], sv, P["alpha"], P["color"], cis, c2ws)[0]
+        else:
+            img = br.render(mean, P["qvec"], sv, P["alpha"], P["sh"], cis, c2ws, C=2)[0]
+        img.sum().backward()
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(img).all()) and bool(torch.isfinite(mean.grad).all()), step
+        if br.slots[0].D_cap != cap0:  # this step's own check regrew the lists
+            regrown += 1
+            sc2 = dict(s["sc"]); sc2["svec"] = sv.cpu().numpy()
+            for i in (0, 2):
+                g = scenes.oracle_geometry(sc2, s["cams"][i])
+                nz = np.nonzero(g["mask"])[0]
+                sl = br.slots[i]
+                assert int(sl.total.item()) == g["D"] <= sl.D_cap
+                assert np.array_equal(sl.start.cpu().numpy(), g["start"]) and np.array_equal(sl.end.cpu().numpy(), g["end"])
+                assert np.array_equal(sl.ids[:g["D"]].cpu().numpy(), nz[g["ids"]])
+            assert br.ensure_capacity(4)
+        sv = sv * 1.05
+    assert regrown >= 2
+
+
 def test_capture_requires_sized_lists_and_a_replay_reports_overflow(setup):
     from gsgen_amd.batch import BatchRenderer
     from gsgen_amd import PairListOverflow
