@@ -425,6 +425,8 @@ def main():
                          "is measured the same way afterwards and reported in the same line.  heads: the timed region IS the "
                          "RGB + heads step (profiling: with --only-timed a kernel trace holds exactly its launches)")
     ap.add_argument("--no-heads", action="store_true", help="skip the RGB + heads pass")
+    ap.add_argument("--sh-grad-form", choices=["moments", "plain"], default="moments",
+                    help="SH backward: the moment form BatchRenderer.render runs (round 6) or the plain one, for same-box A/Bs")
     ap.add_argument("--heads-grad-form", choices=["moments", "plain"], default="moments",
                     help="RGB + heads backward: the moment form BatchRenderer.render_heads runs (gsgen_vol_render_rgbd_backward_batch_"
                          "moments, round 6) or the plain thirteen-component form, for same-box A/Bs")
@@ -553,6 +555,7 @@ def main():
     n_sh4 = (N * CC3 + 3) // 4 * 4
     fused_fill = not args.torch_fill           # gradient accumulators zeroed inside the projection launch
     heads_moments = args.heads_grad_form == "moments"
+    sh_moments = args.sh_grad_form == "moments"
     want_heads = (args.path == "heads" or not args.no_heads) and "color" in sc and not dry
     if want_heads:
         t["color"] = torch.tensor(sc["color"], device=dev)
@@ -637,7 +640,8 @@ def main():
                     v.grad_mean = g0 + 4 * 6 * Np * i
                     v.grad_cov = v.grad_mean + 4 * 2 * Np
                 proj = (vtab([p(cam_dev[(k0 + i) % ncam]) for i in range(B)]), 1, vtab([p(b_.mask) for b_ in self.bufs]),
-                        vtab([g0 + 4 * 6 * Np * i for i in range(B)]), vtab([g0 + 4 * 6 * Np * i + 4 * 2 * Np for i in range(B)]), None)
+                        vtab([g0 + 4 * 6 * Np * i for i in range(B)]), vtab([g0 + 4 * 6 * Np * i + 4 * 2 * Np for i in range(B)]),
+                        vtab([p(b_.cov2d) for b_ in self.bufs]) if sh_moments else None)  # (moments: the views' cov2d; plain: no d L / d depth)
                 self.tables[key] = (geo, views, proj)
             return self.tables[key]
 
@@ -762,17 +766,20 @@ def main():
         if ev is not None:
             clock.call("events", ev[2].record, stream)
         for lo, n_, s_, bws_ in parts:
-            clock.call("composite_bwd", lib.vol_render_backward_sh_batch_routed, n_, _sub(views, lo, n_), N, p(t["sh"]), p(t["alpha"]), p(sl.g_sh),
+            clock.call("composite_bwd", sh_bwd, n_, _sub(views, lo, n_), N, p(t["sh"]), p(t["alpha"]), p(sl.g_sh),
                        p(sl.g_alpha), 16, nth, ntw, H, W, C, 1e-4, seg_arg, (p(sl.bound) if rows_p else None), rows_p, p(bws_), s_)
         if ev is not None:
             clock.call("events", ev[3].record, stream)
         join(sl, parts)
-        clock.call("project_bwd", lib.project_gaussians_backward_batch, B, N, p(t["mean"]), p(t["qvec"]), p(t["svec"]), *proj,
+        clock.call("project_bwd", sh_proj_bwd, B, N, p(t["mean"]), p(t["qvec"]), p(t["svec"]), *proj,
                    p(sl.g_mean), p(sl.g_qvec), p(sl.g_svec), s)
         if sl.geo_stream is not stream:
             sl.e_done.record(stream)
             sl.started = True
 
+    # the SH backward likewise (gsgen_vol_render_backward_sh_batch_routed_moments + gsgen_project_gaussians_backward_batch_moments_sh)
+    sh_bwd = lib.vol_render_backward_sh_batch_routed_moments if sh_moments else lib.vol_render_backward_sh_batch_routed
+    sh_proj_bwd = lib.project_gaussians_backward_batch_moments_sh if sh_moments else lib.project_gaussians_backward_batch
     # the RGB + heads backward in its moment form (round 6: what BatchRenderer.render_heads runs) or, for same-box A/Bs, the plain one
     heads_bwd = lib.vol_render_rgbd_backward_batch_moments if heads_moments else lib.vol_render_rgbd_backward_batch
     heads_proj_bwd = lib.project_gaussians_backward_batch_heads_moments if heads_moments else lib.project_gaussians_backward_batch_heads

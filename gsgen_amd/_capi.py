@@ -63,6 +63,8 @@ SIGNATURES = {
                                                C.POINTER(vp), C.POINTER(vp), vp, vp, vp, vp],
     "gsgen_project_gaussians_backward_batch_heads": [u32, u32, vp, vp, vp, C.POINTER(vp), i32, C.POINTER(vp), C.POINTER(vp),
                                                      C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp, vp, vp, vp, vp],
+    "gsgen_project_gaussians_backward_batch_moments_sh": [u32, u32, vp, vp, vp, C.POINTER(vp), i32, C.POINTER(vp), C.POINTER(vp),
+                                                          C.POINTER(vp), C.POINTER(vp), vp, vp, vp, vp],
     "gsgen_project_gaussians_backward_batch_heads_moments": [u32, u32, vp, vp, vp, C.POINTER(vp), i32, C.POINTER(vp), C.POINTER(vp),
                                                              C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp, vp, vp,
                                                              vp, vp],
@@ -71,6 +73,8 @@ SIGNATURES = {
     "gsgen_vol_render_sh_batch_routed": [u32, C.POINTER(ShView), u32, vp, vp, u32, u32, u32, u32, u32, u32, f32, u32, vp, vp, vp, vp],
     "gsgen_vol_render_backward_sh_batch_routed": [u32, C.POINTER(ShView), u32, vp, vp, vp, vp, u32, u32, u32, u32, u32, u32, f32, u32,
                                                   vp, vp, vp, vp],
+    "gsgen_vol_render_backward_sh_batch_routed_moments": [u32, C.POINTER(ShView), u32, vp, vp, vp, vp, u32, u32, u32, u32, u32, u32, f32,
+                                                          u32, vp, vp, vp, vp],
     "gsgen_vol_render_sh_routed": [u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, u32, f32, f32, u32, u32, u32, f32,
                                    vp, vp, vp, vp, u32, vp, vp, vp],
     "gsgen_vol_render_backward_sh_routed": [u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, u32,

@@ -174,18 +174,24 @@ class _render_batch(torch.autograd.Function):
         with _on(dev):
             parts = br._fork(B, ctx.parts)
             for k, (lo, n, s) in enumerate(parts):
-                if C > 0:
-                    lib.vol_render_backward_sh_batch_routed(n, _sub(views, lo, n), N, _p(col), _p(alpha), _p(g_col), _p(g_alpha),
-                                                            16, nth, ntw, H, W, C, thresh, br.segments, _p(ctx.sh_bound),
-                                                            _p(ctx.sh_rows), _p(br._bws[k]), s)
+                if C > 0:  # the moment form (round 6, include/gsgen_hip.h): expanded by the projection backward below
+                    lib.vol_render_backward_sh_batch_routed_moments(n, _sub(views, lo, n), N, _p(col), _p(alpha), _p(g_col),
+                                                                    _p(g_alpha), 16, nth, ntw, H, W, C, thresh, br.segments,
+                                                                    _p(ctx.sh_bound), _p(ctx.sh_rows), _p(br._bws[k]), s)
                 else:
                     lib.vol_render_rgb_backward_batch(n, _sub(views, lo, n), N, _p(col), _p(alpha), _p(g_col), _p(g_alpha), 16,
                                                       nth, ntw, H, W, thresh, _p(br._bws[k]), s)
             br._join(parts)
             s = parts[0][2]
-            lib.project_gaussians_backward_batch(B, N, _p(mean), _p(qvec), _p(svec), br._ptr_table("cam", B),
-                                                 int(ctx.detach), br._mask_table(B), br._ptr_table("g_mean2d", B),
-                                                 br._ptr_table("g_cov2d", B), None, _p(g_mean), _p(g_qvec), _p(g_svec), s)
+            if C > 0:
+                lib.project_gaussians_backward_batch_moments_sh(B, N, _p(mean), _p(qvec), _p(svec), br._ptr_table("cam", B),
+                                                                int(ctx.detach), br._mask_table(B), br._ptr_table("g_mean2d", B),
+                                                                br._ptr_table("g_cov2d", B), br._ptr_table("cov2d", B), _p(g_mean),
+                                                                _p(g_qvec), _p(g_svec), s)
+            else:
+                lib.project_gaussians_backward_batch(B, N, _p(mean), _p(qvec), _p(svec), br._ptr_table("cam", B),
+                                                     int(ctx.detach), br._mask_table(B), br._ptr_table("g_mean2d", B),
+                                                     br._ptr_table("g_cov2d", B), None, _p(g_mean), _p(g_qvec), _p(g_svec), s)
             if stats is not None and stats.grad_accum is not None:
                 lib.densify_update_batch(B, N, None, br._ptr_table("g_mean2d", B), br._mask_table(B), None,
                                          _p(stats.grad_accum), _p(stats.cnt), s)

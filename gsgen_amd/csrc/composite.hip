@@ -347,6 +347,7 @@ __global__ void __launch_bounds__(TS * TS / PPL) k_composite_fwd(CompParams p) {
     if constexpr (MODE == MODE_SCALAR) {
       p.out[pix] = acc[j][0];
     } else if constexpr (MODE == MODE_RGBD) {
+      acc[j][4] = 1.0f - Tr[j];  // opacity = sum w = 1 - T, as k_composite_fwd_chan_vec forms it (the same T, hence the same bits)
 #pragma unroll
       for (int c = 0; c < NCH; ++c) p.out[NCH * pix + c] = acc[j][c];
     } else {
@@ -1172,7 +1173,12 @@ struct BwdShVecShared {
   float gw_s[POLY ? 3 * 8 : 1];                           // POLY: a splat's reduced gradient in the tile's basis
   float tay_ok[POLY ? KB * 3 : 1];                        // POLY: rows of the staged batch that may take the Taylor tier (poly_transform)
 };
-template <int CB, int PPL, int NB, bool PERSIST = false>
+// MOM (round 6; the batched launches of gsgen_vol_render_backward_sh_batch_routed_moments): the geometric gradients leave the kernel
+// as MOMENTS of the per-pixel weight g = d L / d (a G) * a G against (tx, ty) = det * Sigma^-1 d, the offsets gauss_sh_pair forms
+// anyway -- (Mx, My) into grad_mean, (Mxx, Mxy, Myy) into grad_cov[0..2] -- and the projection backward scales them by 1 / det and
+// 0.5 / det^2 per (view, Gaussian) (geometry.hip, moments_to_grads_sh): 7 packed operations per pixel pair instead of 13, one
+// atomic per entry less (grad_cov[2] = grad_cov[1] is formed there too).
+template <int CB, int PPL, int NB, bool PERSIST = false, bool MOM = false>
 __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, uint32_t bid, uint32_t grid,
                                                           BwdShVecShared<CB, PPL, (NB > 0)> &sm) {
   static_assert(PPL == 4 || PPL == 2, "pixel pairs: 2 or 4 pixels per lane");
@@ -1254,7 +1260,12 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
     {
       // lane (m, slot e = comp - 6) -> m 0: mean[e] | 1: cov[e] | 2: cov[3], alpha | 3: -, cov[2]
       const int m = lane & 3, e = scatter_comp<8>(lane) - 6;
-      if (scatter_rows_owner<8>(lane) && e >= 0 && !(m == 3 && e == 0)) {
+      if constexpr (MOM) {  // m 0: (Mx, My) -> mean[e] | 1: (Mxx, Mxy) -> cov[e] | 2: (Myy, alpha) -> cov[2], alpha | 3: -
+        if (scatter_rows_owner<8>(lane) && e >= 0 && m < 3) {
+          geo_base = m == 0 ? p.g_mean + e : (m == 1 ? p.g_cov + e : (e == 0 ? p.g_cov + 2 : p.g_alpha));
+          geo_stride = m == 0 ? 2u : ((m == 2 && e == 1) ? 1u : 4u);
+        }
+      } else if (scatter_rows_owner<8>(lane) && e >= 0 && !(m == 3 && e == 0)) {
         geo_base = m == 0 ? p.g_mean + e : ((m == 2 && e == 1) ? p.g_alpha : p.g_cov + (m == 1 ? e : (m == 2 ? 3 : 2)));
         geo_stride = m == 0 ? 2u : ((m == 2 && e == 1) ? 1u : 4u);
       }
@@ -1338,13 +1349,13 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
                   r_c2 = uni(S.c2[g]), r_c3 = uni(S.c3[g]), r_p0 = uni(S.p0[g]), r_p1 = uni(S.p1[g]);
       const float x = px - r_mx;
       // G2 / ag2: the Gaussian and a G, ZEROED where the pixel does not take part (skip threshold, or not alive)
-      v2f y2[NP], G2[NP], ag2[NP];
+      v2f y2[NP], G2[NP], ag2[NP], tx2[NP], ty2[NP];
       bool any_con = false;
       float guard_dist = 0.0f;
 #pragma unroll
       for (int jp = 0; jp < NP; ++jp) {
         y2[jp] = py2[jp] - splat2(r_my);
-        G2[jp] = gauss_sh_pair(r_c0, r_c1, r_c2, r_c3, r_p0, x, y2[jp]);
+        G2[jp] = gauss_sh_pair(r_c0, r_c1, r_c2, r_c3, r_p0, x, y2[jp], tx2[jp], ty2[jp]);
         ag2[jp] = splat2(r_a) * G2[jp];
         {
           // the lane's smallest distance to the threshold (dead pixels included: a spurious trip re-tests per pixel)
@@ -1519,15 +1530,24 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
       for (int jp = 0; jp < NP; ++jp) {
         const v2f pa = pAG2[jp];  // (its uses below are products with the masked G / a G)
         const v2f gg = pa * ag2[jp];
-        const v2f vx = (splat2(x * r_c3) - y2[jp] * splat2(r_c2)) * splat2(inv_det);
-        const v2f vy = (y2[jp] * splat2(r_c0) - splat2(x * r_c1)) * splat2(inv_det);
-        gm0 = fma2(gg, vx, gm0);
-        gm1 = fma2(gg, vy, gm1);
-        const v2f h = splat2(0.5f) * gg;
-        const v2f hvx = h * vx;
-        gc0 = fma2(hvx, vx, gc0);
-        gc1 = fma2(hvx, vy, gc1);
-        gc3 = fma2(h * vy, vy, gc3);
+        if constexpr (MOM) {  // (gm0, gm1 | gc0, gc1, gc3) hold the moments (Mx, My | Mxx, Mxy, Myy)
+          const v2f t_ = gg * tx2[jp], s_ = gg * ty2[jp];
+          gm0 = jp == 0 ? t_ : gm0 + t_;
+          gm1 = jp == 0 ? s_ : gm1 + s_;
+          gc0 = jp == 0 ? t_ * tx2[jp] : fma2(t_, tx2[jp], gc0);
+          gc1 = jp == 0 ? t_ * ty2[jp] : fma2(t_, ty2[jp], gc1);
+          gc3 = jp == 0 ? s_ * ty2[jp] : fma2(s_, ty2[jp], gc3);
+        } else {
+          const v2f vx = (splat2(x * r_c3) - y2[jp] * splat2(r_c2)) * splat2(inv_det);
+          const v2f vy = (y2[jp] * splat2(r_c0) - splat2(x * r_c1)) * splat2(inv_det);
+          gm0 = fma2(gg, vx, gm0);
+          gm1 = fma2(gg, vy, gm1);
+          const v2f h = splat2(0.5f) * gg;
+          const v2f hvx = h * vx;
+          gc0 = fma2(hvx, vx, gc0);
+          gc1 = fma2(hvx, vy, gc1);
+          gc3 = fma2(h * vy, vy, gc3);
+        }
         gal = fma2(pa, G2[jp], gal);
         Tr2[jp] = Tr2[jp] * one_minus2(ag2[jp]);  // T (1 - a G) if it contributed (explicit: as the forward)
       }
@@ -1565,7 +1585,8 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
         __syncthreads();  // gw_s is consumed before the next splat overwrites it
       } else {
         // grad_cov[1] and grad_cov[2] receive the same value (kernels.h:414-415)
-        v2f ex[4] = {v2f{m0, m1}, v2f{c0, c1}, v2f{c1, c3}, v2f{ga, 0.0f}};
+        // (MOM: (Mx, My) (Mxx, Mxy) (Myy, alpha) -> mean[0..1], cov[0..1], cov[2], alpha)
+        v2f ex[4] = {v2f{m0, m1}, v2f{c0, c1}, MOM ? v2f{c3, ga} : v2f{c1, c3}, MOM ? v2f{0.0f, 0.0f} : v2f{ga, 0.0f}};
         const float exsum = wave_reduce_scatter2_rows<8>(ex);
         const float tot = quad_reduce_scatter4(chsum[0], chsum[1], chsum[2], exsum);
         const int m = lane & 3;  // the vector this lane ends up with: channel 0 / 1 / 2 / geometric
@@ -1577,8 +1598,8 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
         } else if (m == 3 && scatter_rows_owner<8>(lane)) {
           const int e = scatter_comp<8>(lane);
           if (e < 2) dst = p.g_mean + 2 * id + e;
-          else if (e < 6) dst = p.g_cov + 4 * id + (e - 2);
-          else if (e == 6) dst = p.g_alpha + id;
+          else if (e < (MOM ? 5 : 6)) dst = p.g_cov + 4 * id + (e - 2);
+          else if (e == (MOM ? 5 : 6)) dst = p.g_alpha + id;
         }
         if (dst != nullptr) atomicAdd(dst, tot);
       }
@@ -1591,10 +1612,11 @@ __device__ __forceinline__ void composite_bwd_sh_vec_tile(const CompParams &p, u
 }
 // (the persistent fallback runs at 152 registers, the exact kernel at 148: three wavefronts per SIMD.  It only renders views whose
 // coefficient bound fails while a batch mate's holds.)
-template <int CB, int PPL, bool BATCH = false, int NB = 0>
+template <int CB, int PPL, bool BATCH = false, int NB = 0, bool MOM = false>
 __global__ void __launch_bounds__(256 / PPL)
 GS_WAVES_PER_EU((NB == kPolyNB && BATCH) ? 4 : 1)  // the batched polynomial backward: four wavefronts per SIMD (<= 128 registers)
 k_composite_bwd_sh_vec(CompParams p_arg, ViewPack<BATCH> pack) {
+  static_assert(!MOM || (BATCH && NB != kRouted), "the moment form exists for the batched launches");
   const CompParams *plist = pack.table();  // (kernel-argument memory: scalar loads, no table in device memory)
   uint32_t bid = blockIdx.x, grid = gridDim.x;
   if constexpr (NB == kRouted) {
@@ -1638,7 +1660,7 @@ k_composite_bwd_sh_vec(CompParams p_arg, ViewPack<BATCH> pack) {
       const CompParams *pp = &plist[view];
       if (per_tile ? !tile_flagged(*pp, (b - base) % tiles_grid) : poly_route(pp->sh_bound, pp->psx, pp->psy)) continue;
       const CompParams p = *pp;
-      composite_bwd_sh_vec_tile<4, 4, 0, true>(p, b - base, per, sm);
+      composite_bwd_sh_vec_tile<4, 4, 0, true, MOM>(p, b - base, per, sm);
       __syncthreads();
     }
   } else if constexpr (NB == kPolyNB && BATCH) {
@@ -1648,11 +1670,11 @@ k_composite_bwd_sh_vec(CompParams p_arg, ViewPack<BATCH> pack) {
     if (pp->sh_rows == nullptr && !view_ok) return;  // per-view routing: this view is the exact fallback's
     CompParams p = *pp;
     if (view_ok) p.sh_rows = nullptr;  // (as the forward: the same device value, the same decision)
-    composite_bwd_sh_vec_tile<4, 4, kPolyNB>(p, bid, grid, sm);
+    composite_bwd_sh_vec_tile<4, 4, kPolyNB, false, MOM>(p, bid, grid, sm);
   } else {
     const CompParams p = BATCH ? plist[batch_view(p_arg, bid, &grid)] : p_arg;  // see k_composite_fwd
     __shared__ BwdShVecShared<CB, PPL, (NB > 0)> sm;
-    composite_bwd_sh_vec_tile<CB, PPL, NB>(p, bid, grid, sm);
+    composite_bwd_sh_vec_tile<CB, PPL, NB, false, MOM>(p, bid, grid, sm);
   }
 }
 
@@ -1737,8 +1759,9 @@ k_composite_fwd_chan_vec(CompParams p_arg, ViewPack<BATCH> pack) {
       for (int j = 0; j < PPL; ++j) any_alive |= alive(j);
       if (!wave_any(any_alive)) break;  // the tile's 256 pixels are saturated
 
-      const float r_mx = wave_uniform(S.mx[g]), r_my = wave_uniform(S.my[g]), r_a = wave_uniform(S.a[g]),
-                  r_p0 = wave_uniform(S.p0[g]), r_p1 = wave_uniform(S.p1[g]), r_p2 = wave_uniform(S.p2[g]);
+      // (round 6: the record and the channel values as plain vector registers -- LDS broadcasts -- as in the backward: twelve
+      // v_readfirstlane per entry less, still 80 registers; forward alone 0.247 -> 0.220 ms per 8 cfg2 views, profiles/r06_s2_*)
+      const float r_mx = S.mx[g], r_my = S.my[g], r_a = S.a[g], r_p0 = S.p0[g], r_p1 = S.p1[g], r_p2 = S.p2[g];
       const float p0x = r_p0 * (px - r_mx);
       v2f G2[NP], ag2[NP];
       bool any_con = false;
@@ -1781,7 +1804,10 @@ k_composite_fwd_chan_vec(CompParams p_arg, ViewPack<BATCH> pack) {
       for (int jp = 0; jp < NP; ++jp) {
         const v2f w2 = (splat2(r_a) * Tr2[jp]) * G2[jp];  // (a T) G, or 0
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) acc2[jp][c] = ffma2(splat2(wave_uniform(cg[c])), w2, acc2[jp][c]);
+        for (int c = 0; c < NCH; ++c) {
+          if (MODE == MODE_RGBD && c == 4) continue;  // the opacity head's value is 1: sum w = 1 - T telescopes, formed in the epilogue
+          acc2[jp][c] = ffma2(splat2(cg[c]), w2, acc2[jp][c]);
+        }
         Tr2[jp] = Tr2[jp] * one_minus2(ag2[jp]);  // T (1 - a G) if it contributed (explicit)
       }
     }
@@ -1795,6 +1821,10 @@ k_composite_fwd_chan_vec(CompParams p_arg, ViewPack<BATCH> pack) {
   for (int j = 0; j < PPL; ++j) {
     if (!valid[j]) continue;
     const size_t pix = (size_t)gy[j] * p.W + gx;
+    // opacity (gs/gaussian_splatting.py:1352-1373: render_scalar of ones) = sum_i w_i = 1 - T: T_i+1 = T_i - w_i exactly in the
+    // reals, to fp32 rounding here (<= 2e-7 of the oracle's sum, tests/test_gpu_parity.py) -- one accumulator pair per pixel pair
+    // and two packed FMAs per entry less
+    if constexpr (MODE == MODE_RGBD) acc2[j >> 1][4][j & 1] = 1.0f - Tr2[j >> 1][j & 1];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) p.out[NCH * pix + c] = acc2[j >> 1][c][j & 1];
     if (p.T != nullptr) p.T[pix] = Tr2[j >> 1][j & 1];
@@ -1954,7 +1984,7 @@ k_composite_bwd_chan_vec(CompParams p_arg, ViewPack<BATCH> pack) {
       v2f w2[NP], om2[NP], gy2[NP];
 #pragma unroll
       for (int jp = 0; jp < NP; ++jp) {
-        w2[jp] = (splat2(r_a) * Tr2[jp]) * G2[jp];  // the forward's (a T) G, or 0
+        w2[jp] = MOM ? Tr2[jp] * ag2[jp] : (splat2(r_a) * Tr2[jp]) * G2[jp];  // the forward's (a T) G -- MOM: T (a G), equal to an ulp --, or 0
         om2[jp] = one_minus2(ag2[jp]);
       }
       if constexpr (MOM) {
@@ -2214,7 +2244,7 @@ int launch_fwd_sh_batch(int C, const CompParams *host, uint32_t B, hipStream_t s
   });
   return (int)hipGetLastError();
 }
-template <int CB>
+template <int CB, bool MOM>
 static void launch_bwd_sh_batch_c(const CompParams &p0, const ViewPack<true> &plist, uint32_t B, uint32_t nblk, hipStream_t s, bool bounded) {
   const dim3 g(nblk * B);
   if constexpr (CB == 4) {
@@ -2225,28 +2255,32 @@ static void launch_bwd_sh_batch_c(const CompParams &p0, const ViewPack<true> &pl
       // routing this launch may carry a large share of the tiles (2 per SIMD until round 4, when it only ever took whole views)
       const uint32_t gf = pf.vgrid < 3072u ? pf.vgrid : 3072u;
       launch_beside(
-          s, [&](hipStream_t q) { hipLaunchKernelGGL((k_composite_bwd_sh_vec<4, 4, true, kFallback>), dim3(gf), dim3(64), 0, q, pf, plist); },
-          [&](hipStream_t q) { hipLaunchKernelGGL((k_composite_bwd_sh_vec<4, 4, true, kPolyNB>), g, dim3(64), 0, q, p0, plist); });
+          s, [&](hipStream_t q) { hipLaunchKernelGGL((k_composite_bwd_sh_vec<4, 4, true, kFallback, MOM>), dim3(gf), dim3(64), 0, q, pf, plist); },
+          [&](hipStream_t q) { hipLaunchKernelGGL((k_composite_bwd_sh_vec<4, 4, true, kPolyNB, MOM>), g, dim3(64), 0, q, p0, plist); });
       return;
     }
   }
   // one wavefront per tile: the per-Gaussian gradient reduction costs the same per wavefront whatever the number of pixels behind
   // it (two wavefronts per tile: 2 838 vs 3 492 renders/s on the exact basis, profiles/r04_ab_shapes.txt)
-  hipLaunchKernelGGL((k_composite_bwd_sh_vec<CB, 4, true>), g, dim3(64), 0, s, p0, plist);
+  hipLaunchKernelGGL((k_composite_bwd_sh_vec<CB, 4, true, 0, MOM>), g, dim3(64), 0, s, p0, plist);
 }
-int launch_bwd_sh_batch(int C, const CompParams *host, uint32_t B, hipStream_t s, bool bounded) {
+template <bool MOM>
+static int launch_bwd_sh_batch_m(int C, const CompParams *host, uint32_t B, hipStream_t s, bool bounded) {
   if (B == 0 || host[0].ntw * host[0].nth == 0) return 0;
   const uint32_t nblk = comp_grid(host[0]) * (uint32_t)(host[0].nseg > 1 ? host[0].nseg : 1);
   const bool poly = C == 4 && bounded;
   for_each_chunk(host, B, [&](const CompParams &p0, const ViewPack<true> &pack, uint32_t n) {
     switch (C) {
-      case 1: launch_bwd_sh_batch_c<1>(p0, pack, n, nblk, s, false); break;
-      case 2: launch_bwd_sh_batch_c<2>(p0, pack, n, nblk, s, false); break;
-      case 3: launch_bwd_sh_batch_c<3>(p0, pack, n, nblk, s, false); break;
-      default: launch_bwd_sh_batch_c<4>(p0, pack, n, nblk, s, poly); break;
+      case 1: launch_bwd_sh_batch_c<1, MOM>(p0, pack, n, nblk, s, false); break;
+      case 2: launch_bwd_sh_batch_c<2, MOM>(p0, pack, n, nblk, s, false); break;
+      case 3: launch_bwd_sh_batch_c<3, MOM>(p0, pack, n, nblk, s, false); break;
+      default: launch_bwd_sh_batch_c<4, MOM>(p0, pack, n, nblk, s, poly); break;
     }
   });
   return (int)hipGetLastError();
+}
+int launch_bwd_sh_batch(int C, const CompParams *host, uint32_t B, hipStream_t s, bool bounded, bool moments = false) {
+  return moments ? launch_bwd_sh_batch_m<true>(C, host, B, s, bounded) : launch_bwd_sh_batch_m<false>(C, host, B, s, bounded);
 }
 
 // post-activation channels, B cameras per launch: packed, one wavefront per tile (the same operation sequence as the per-camera
@@ -2757,12 +2791,12 @@ int gsgen_vol_render_backward_sh_batch_bounded(uint32_t n_views, const gsgen_sh_
                                                    batch_workspace, stream);
 }
 
-int gsgen_vol_render_backward_sh_batch_routed(uint32_t n_views, const gsgen_sh_view *views, uint32_t N,
-                                              const float *sh_coeffs, const float *alpha, float *grad_sh_coeffs,
-                                              float *grad_alpha, uint32_t tile_size, uint32_t n_tiles_h,
-                                              uint32_t n_tiles_w, uint32_t H, uint32_t W, uint32_t C, float thresh,
-                                              uint32_t n_segments, const float *sh_l1_bound, const float *sh_row_bounds,
-                                              void *batch_workspace, gsgen_stream_t stream) {
+static int backward_sh_batch_routed(bool moments, uint32_t n_views, const gsgen_sh_view *views, uint32_t N,
+                                    const float *sh_coeffs, const float *alpha, float *grad_sh_coeffs,
+                                    float *grad_alpha, uint32_t tile_size, uint32_t n_tiles_h,
+                                    uint32_t n_tiles_w, uint32_t H, uint32_t W, uint32_t C, float thresh,
+                                    uint32_t n_segments, const float *sh_l1_bound, const float *sh_row_bounds,
+                                    void *batch_workspace, gsgen_stream_t stream) {
   if (tile_size != 16) return GSGEN_EUNSUPPORTED;
   if (C < 1 || C > 4) return GSGEN_EUNSUPPORTED;
   if (n_views == 0 || N == 0) return 0;
@@ -2778,7 +2812,25 @@ int gsgen_vol_render_backward_sh_batch_routed(uint32_t n_views, const gsgen_sh_v
   if (!bounded)
     for (CompParams &p : ps) { p.sh_bound = nullptr; p.sh_rows = nullptr; p.tile_flags = nullptr; }
   hipStream_t s = (hipStream_t)stream;
-  return launch_bwd_sh_batch((int)C, ps.data(), n_views, s, bounded);
+  return launch_bwd_sh_batch((int)C, ps.data(), n_views, s, bounded, moments);
+}
+int gsgen_vol_render_backward_sh_batch_routed(uint32_t n_views, const gsgen_sh_view *views, uint32_t N,
+                                              const float *sh_coeffs, const float *alpha, float *grad_sh_coeffs,
+                                              float *grad_alpha, uint32_t tile_size, uint32_t n_tiles_h,
+                                              uint32_t n_tiles_w, uint32_t H, uint32_t W, uint32_t C, float thresh,
+                                              uint32_t n_segments, const float *sh_l1_bound, const float *sh_row_bounds,
+                                              void *batch_workspace, gsgen_stream_t stream) {
+  return backward_sh_batch_routed(false, n_views, views, N, sh_coeffs, alpha, grad_sh_coeffs, grad_alpha, tile_size, n_tiles_h,
+                                  n_tiles_w, H, W, C, thresh, n_segments, sh_l1_bound, sh_row_bounds, batch_workspace, stream);
+}
+int gsgen_vol_render_backward_sh_batch_routed_moments(uint32_t n_views, const gsgen_sh_view *views, uint32_t N,
+                                                      const float *sh_coeffs, const float *alpha, float *grad_sh_coeffs,
+                                                      float *grad_alpha, uint32_t tile_size, uint32_t n_tiles_h,
+                                                      uint32_t n_tiles_w, uint32_t H, uint32_t W, uint32_t C, float thresh,
+                                                      uint32_t n_segments, const float *sh_l1_bound, const float *sh_row_bounds,
+                                                      void *batch_workspace, gsgen_stream_t stream) {
+  return backward_sh_batch_routed(true, n_views, views, N, sh_coeffs, alpha, grad_sh_coeffs, grad_alpha, tile_size, n_tiles_h,
+                                  n_tiles_w, H, W, C, thresh, n_segments, sh_l1_bound, sh_row_bounds, batch_workspace, stream);
 }
 
 static int fill_rgbd_params(uint32_t n_views, const gsgen_rgbd_view *views, const float *color, const float *alpha,

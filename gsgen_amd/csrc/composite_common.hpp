@@ -293,12 +293,13 @@ __device__ __forceinline__ float gauss_eval(const GRec &r, float x, float y, flo
 // MODE_SH Gaussian values of the two pixels (x, y2[0]) and (x, y2[1]) of one lane: the operation sequence of
 // gauss_eval<MODE_SH> element for element (v_pk_mul / v_pk_fma round exactly like their scalar forms), without the
 // threshold guard -- the caller applies it per pixel with gauss_ref_f32 as gauss_eval does.
-__device__ __forceinline__ v2f gauss_sh_pair(float c0, float c1, float c2, float c3, float p0, float x, v2f y2) {
+// tx, ty: det * Sigma^-1 d, the offsets the value is formed from (the moment form of the backward sums against them).
+__device__ __forceinline__ v2f gauss_sh_pair(float c0, float c1, float c2, float c3, float p0, float x, v2f y2, v2f &tx, v2f &ty) {
 #pragma clang fp contract(off)
   const float xc1 = x * c1;
   const v2f yc2 = y2 * splat2(c2);
-  const v2f tx = ffma2(splat2(x), splat2(c3), -yc2);
-  const v2f ty = ffma2(y2, splat2(c0), -splat2(xc1));
+  tx = ffma2(splat2(x), splat2(c3), -yc2);
+  ty = ffma2(y2, splat2(c0), -splat2(xc1));
   const v2f tyy = ty * y2;
   const v2f q2 = ffma2(tx, splat2(x), tyy);
   const v2f e = splat2(p0) * q2;
@@ -306,6 +307,10 @@ __device__ __forceinline__ v2f gauss_sh_pair(float c0, float c1, float c2, float
   G[0] = (q2[0] < 0.0f) ? 0.0f : G[0];
   G[1] = (q2[1] < 0.0f) ? 0.0f : G[1];
   return G;
+}
+__device__ __forceinline__ v2f gauss_sh_pair(float c0, float c1, float c2, float c3, float p0, float x, v2f y2) {
+  v2f tx, ty;
+  return gauss_sh_pair(c0, c1, c2, c3, p0, x, y2, tx, ty);
 }
 
 // The Cholesky-form Gaussian (RGB / scalar / RGB + heads) of the two pixels (x, y2[0]), (x, y2[1]) of one lane: the

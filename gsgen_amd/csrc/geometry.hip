@@ -445,51 +445,96 @@ __device__ __forceinline__ void moments_to_grads(const CholK &k, const float *__
   gc[1] = gc[2] = 0.5 * k.k0 * (k.k1 * Muu + k.k2 * Muv);  // both off-diagonals receive the same value (kernels.h:414-415)
   gc[3] = 0.5 * (k.k1 * k.k1 * Muu + 2.0 * k.k1 * k.k2 * Muv + k.k2 * k.k2 * Mvv);
 }
+// ... and from the SH kernels' moments against (tx, ty) = det Sigma^-1 d (gauss_sh_pair; det in fp32 as prep_record<MODE_SH> forms
+// it, kernels.h:179):  d mean2d = M1 / det,  d cov2d = 0.5 M2 / det^2.  A degenerate record (det <= 0) never contributed.
+__device__ __forceinline__ void moments_to_grads_sh(const float *__restrict__ cov2d_n, const float *__restrict__ mom2,
+                                                    const float *__restrict__ mom4, double &gm0, double &gm1, double (&gc)[4]) {
+  const float det = cov2d_n[0] * cov2d_n[3] - cov2d_n[1] * cov2d_n[2];  // (this file is compiled with -ffp-contract=off)
+  const bool ok = (det > 0.0f) && (fabsf(det) <= 3.402823466e+38f);
+  const double inv = ok ? 1.0 / (double)det : 0.0;
+  const double h = 0.5 * inv * inv;
+  gm0 = inv * (double)mom2[0];
+  gm1 = inv * (double)mom2[1];
+  gc[0] = h * (double)mom4[0];
+  gc[1] = gc[2] = h * (double)mom4[1];
+  gc[3] = h * (double)mom4[2];
+}
+// Round 6: a workgroup is 64 Gaussians x 4 VIEW LANES (one wavefront each): wavefront q takes the views q, q + 4, ... of its 64
+// Gaussians, the four partial sums meet in LDS and wavefront 0 writes.  One thread per Gaussian looping over all views (rounds
+// 1-5) left a 100 k-Gaussian launch at 1.5 wavefronts per SIMD, each running eight dependent fp64 chains back to back: 43 us per
+// 8 views on MI355X once the chain went to fp64 -- four times the wavefronts, a quarter of the serial work each.
+constexpr int kPbvGauss = 64, kPbvLanes = kThreads / kPbvGauss;
 __global__ void __launch_bounds__(kThreads)
 k_project_bwd_views(uint32_t N, const float *__restrict__ mean, const float *__restrict__ qvec,
                     const float *__restrict__ svec, ProjBwdViews pv, int n_views, int detach_depth, int accumulate,
                     int moments, float *__restrict__ g_mean, float *__restrict__ g_qvec, float *__restrict__ g_svec,
                     float *__restrict__ g_color) {
-  const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
+  __shared__ float part[kPbvLanes - 1][13][kPbvGauss];  // the other view lanes' partial sums, [component][Gaussian]: conflict-free
+  const int gl = (int)(threadIdx.x & (kPbvGauss - 1)), vq = (int)(threadIdx.x / kPbvGauss);
+  const uint32_t n = blockIdx.x * kPbvGauss + gl;
+  const bool live = n < N;
+  ProjGrad a;
+  float gc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 3; ++j) { a.gm[j] = 0.f; a.gs[j] = 0.f; }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) a.gq[k] = 0.f;
+  if (live) {
+    for (int v = vq; v < n_views; v += kPbvLanes) {
+      const uint8_t *m = pv.mask[v];
+      if (m != nullptr && m[n] == 0) continue;
+      const float *ch = pv.g_chan6[v];
+      float gd = pv.g_depth[v] != nullptr ? pv.g_depth[v][n] : 0.f;
+      if (ch != nullptr) {  // the depth head and the depth^2 head both feed the view-space depth (include/gsgen_hip.h)
+        const float2 *c2 = reinterpret_cast<const float2 *>(ch + 6 * (size_t)n);
+        const float2 c01 = c2[0], c23 = c2[1], c45 = c2[2];
+        gc[0] += c01.x; gc[1] += c01.y; gc[2] += c23.x;
+        gd = c23.y + 2.0f * pv.depth[v][n] * c45.y;
+      }
+      ProjGrad o;
+      if (moments) {
+        double gm0, gm1, gcv[4];
+        if (moments == 2)
+          moments_to_grads_sh(pv.cov2d[v] + 4 * (size_t)n, pv.g_mean2d[v] + 2 * (size_t)n, pv.g_cov2d[v] + 4 * (size_t)n, gm0, gm1, gcv);
+        else
+          moments_to_grads(chol_k_of(pv.cov2d[v] + 4 * (size_t)n), pv.g_mean2d[v] + 2 * (size_t)n, pv.g_cov2d[v] + 4 * (size_t)n,
+                           gm0, gm1, gcv);
+        // the view's d L / d mean2d in place of its two first moments: the densify statistics read it (gsgen_densify_update_batch,
+        // gs/gaussian_splatting.py:464-469)
+        *reinterpret_cast<float2 *>(const_cast<float *>(pv.g_mean2d[v]) + 2 * (size_t)n) = make_float2((float)gm0, (float)gm1);
+        o = project_bwd_one(n, mean, qvec, svec, pv.cam[v], detach_depth, gm0, gm1, gcv, gd);
+      } else {
+        o = project_bwd_one(n, mean, qvec, svec, pv.cam[v], detach_depth, pv.g_mean2d[v], pv.g_cov2d[v], gd);
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { a.gm[j] += o.gm[j]; a.gs[j] += o.gs[j]; }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) a.gq[k] += o.gq[k];
+    }
+  }
+  if (vq > 0) {
+    float (*mine)[kPbvGauss] = part[vq - 1];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { mine[j][gl] = a.gm[j]; mine[3 + j][gl] = a.gs[j]; mine[10 + j][gl] = gc[j]; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) mine[6 + k][gl] = a.gq[k];
+  }
+  __syncthreads();
+  if (vq > 0 || !live) return;
   float *gm = g_mean + 3 * (size_t)n, *gq = g_qvec + 4 * (size_t)n, *gs_ = g_svec + 3 * (size_t)n;
   float *gc_ = g_color != nullptr ? g_color + 3 * (size_t)n : nullptr;
-  ProjGrad a;
-  float gc[3];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    a.gm[j] = accumulate ? gm[j] : 0.f; a.gs[j] = accumulate ? gs_[j] : 0.f;
-    gc[j] = (accumulate && gc_ != nullptr) ? gc_[j] : 0.f;
+  for (int q = 0; q < kPbvLanes - 1; ++q) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { a.gm[j] += part[q][j][gl]; a.gs[j] += part[q][3 + j][gl]; gc[j] += part[q][10 + j][gl]; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a.gq[k] += part[q][6 + k][gl];
   }
+  if (accumulate) {
 #pragma unroll
-  for (int k = 0; k < 4; ++k) a.gq[k] = accumulate ? gq[k] : 0.f;
-  for (int v = 0; v < n_views; ++v) {
-    const uint8_t *m = pv.mask[v];
-    if (m != nullptr && m[n] == 0) continue;
-    const float *ch = pv.g_chan6[v];
-    float gd = pv.g_depth[v] != nullptr ? pv.g_depth[v][n] : 0.f;
-    if (ch != nullptr) {  // the depth head and the depth^2 head both feed the view-space depth (include/gsgen_hip.h)
-      const float2 *c2 = reinterpret_cast<const float2 *>(ch + 6 * (size_t)n);
-      const float2 c01 = c2[0], c23 = c2[1], c45 = c2[2];
-      gc[0] += c01.x; gc[1] += c01.y; gc[2] += c23.x;
-      gd = c23.y + 2.0f * pv.depth[v][n] * c45.y;
-    }
-    ProjGrad o;
-    if (moments) {
-      double gm0, gm1, gcv[4];
-      moments_to_grads(chol_k_of(pv.cov2d[v] + 4 * (size_t)n), pv.g_mean2d[v] + 2 * (size_t)n, pv.g_cov2d[v] + 4 * (size_t)n,
-                       gm0, gm1, gcv);
-      // the view's d L / d mean2d in place of its two first moments: the densify statistics read it (gsgen_densify_update_batch,
-      // gs/gaussian_splatting.py:464-469)
-      *reinterpret_cast<float2 *>(const_cast<float *>(pv.g_mean2d[v]) + 2 * (size_t)n) = make_float2((float)gm0, (float)gm1);
-      o = project_bwd_one(n, mean, qvec, svec, pv.cam[v], detach_depth, gm0, gm1, gcv, gd);
-    } else {
-      o = project_bwd_one(n, mean, qvec, svec, pv.cam[v], detach_depth, pv.g_mean2d[v], pv.g_cov2d[v], gd);
-    }
+    for (int j = 0; j < 3; ++j) { a.gm[j] += gm[j]; a.gs[j] += gs_[j]; if (gc_ != nullptr) gc[j] += gc_[j]; }
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { a.gm[j] += o.gm[j]; a.gs[j] += o.gs[j]; }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) a.gq[k] += o.gq[k];
+    for (int k = 0; k < 4; ++k) a.gq[k] += gq[k];
   }
 #pragma unroll
   for (int j = 0; j < 3; ++j) { gm[j] = a.gm[j]; gs_[j] = a.gs[j]; }
@@ -721,7 +766,8 @@ static int project_bwd_batch(uint32_t n_views, uint32_t N, const float *mean, co
                              const float *const *c2w, int detach_depth, const uint8_t *const *mask,
                              const float *const *g_mean2d, const float *const *g_cov2d, const float *const *g_depth,
                              const float *const *g_chan6, const float *const *depth, float *g_mean, float *g_qvec,
-                             float *g_svec, float *g_color, gsgen_stream_t stream, const float *const *cov2d = nullptr) {
+                             float *g_svec, float *g_color, gsgen_stream_t stream, const float *const *cov2d = nullptr,
+                             int moments_form = 1) {
   if (N == 0) return 0;
   if (!mean || !qvec || !svec || !g_mean || !g_qvec || !g_svec) return GSGEN_EINVAL;
   if (n_views && (!c2w || !g_mean2d || !g_cov2d)) return GSGEN_EINVAL;
@@ -745,8 +791,8 @@ static int project_bwd_batch(uint32_t n_views, uint32_t N, const float *mean, co
       pv.depth[i] = depth ? depth[v0 + i] : nullptr;
       pv.cov2d[i] = cov2d ? cov2d[v0 + i] : nullptr;
     }
-    hipLaunchKernelGGL(k_project_bwd_views, grid_for(N), dim3(kThreads), 0, (hipStream_t)stream, N, mean, qvec,
-                       svec, pv, (int)nv, detach_depth, v0 ? 1 : 0, cov2d ? 1 : 0, g_mean, g_qvec, g_svec, g_color);
+    hipLaunchKernelGGL(k_project_bwd_views, dim3((N + kPbvGauss - 1) / kPbvGauss), dim3(kThreads), 0, (hipStream_t)stream, N, mean, qvec,
+                       svec, pv, (int)nv, detach_depth, v0 ? 1 : 0, cov2d ? moments_form : 0, g_mean, g_qvec, g_svec, g_color);
     v0 += nv;
   } while (v0 < n_views);
   return (int)hipGetLastError();
@@ -770,6 +816,16 @@ int gsgen_project_gaussians_backward_batch_heads(uint32_t n_views, uint32_t N, c
   if (!g_chan6 || !depth || !g_color) return GSGEN_EINVAL;
   return project_bwd_batch(n_views, N, mean, qvec, svec, c2w, detach_depth, mask, g_mean2d, g_cov2d, nullptr, g_chan6,
                            depth, g_mean, g_qvec, g_svec, g_color, stream);
+}
+
+int gsgen_project_gaussians_backward_batch_moments_sh(uint32_t n_views, uint32_t N, const float *mean, const float *qvec,
+                                                      const float *svec, const float *const *c2w, int detach_depth,
+                                                      const uint8_t *const *mask, float *const *g_mom2,
+                                                      const float *const *g_mom4, const float *const *cov2d, float *g_mean,
+                                                      float *g_qvec, float *g_svec, gsgen_stream_t stream) {
+  if (!cov2d) return GSGEN_EINVAL;
+  return project_bwd_batch(n_views, N, mean, qvec, svec, c2w, detach_depth, mask, g_mom2, g_mom4, nullptr, nullptr, nullptr, g_mean,
+                           g_qvec, g_svec, nullptr, stream, cov2d, 2);
 }
 
 int gsgen_project_gaussians_backward_batch_heads_moments(uint32_t n_views, uint32_t N, const float *mean, const float *qvec,

@@ -303,7 +303,7 @@ struct RenderFn : public torch::autograd::Function<RenderFn> {
     if (p.kind == kSh) {
       gsgen_sh_view *v = tab<gsgen_sh_view>(p.views);
       for (int64_t i = 0; i < B; ++i) v[i].grad_out = gp + 3 * H * W * i;
-      GS(gsgen_vol_render_backward_sh_batch_routed(
+      GS(gsgen_vol_render_backward_sh_batch_routed_moments(  // (the moment form: expanded by the projection backward below)
           (uint32_t)B, v, (uint32_t)N, col.data_ptr<float>(), alpha.data_ptr<float>(), g_col.data_ptr<float>(),
           g_alpha.data_ptr<float>(), 16, (uint32_t)p.nth, (uint32_t)p.ntw, (uint32_t)H, (uint32_t)W, (uint32_t)C, thresh,
           (uint32_t)p.segments, sh_bound.defined() ? sh_bound.data_ptr<float>() : nullptr,
@@ -315,11 +315,18 @@ struct RenderFn : public torch::autograd::Function<RenderFn> {
                                              g_col.data_ptr<float>(), g_alpha.data_ptr<float>(), 16, (uint32_t)p.nth,
                                              (uint32_t)p.ntw, (uint32_t)H, (uint32_t)W, thresh, tab<void>(p.bws), s));
     }
-    GS(gsgen_project_gaussians_backward_batch(
-        (uint32_t)B, (uint32_t)N, mean.data_ptr<float>(), qvec.data_ptr<float>(), svec.data_ptr<float>(),
-        tab<const float *const>(p.cam_tab), ctx->saved_data["detach"].toBool() ? 1 : 0, tab<const uint8_t *const>(p.mask_tab),
-        tab<const float *const>(p.gmean_tab), tab<const float *const>(p.gcov_tab), nullptr, g_mean.data_ptr<float>(),
-        g_qvec.data_ptr<float>(), g_svec.data_ptr<float>(), s));
+    if (p.kind == kSh)
+      GS(gsgen_project_gaussians_backward_batch_moments_sh(
+          (uint32_t)B, (uint32_t)N, mean.data_ptr<float>(), qvec.data_ptr<float>(), svec.data_ptr<float>(),
+          tab<const float *const>(p.cam_tab), ctx->saved_data["detach"].toBool() ? 1 : 0, tab<const uint8_t *const>(p.mask_tab),
+          tab<float *const>(p.gmean_tab), tab<const float *const>(p.gcov_tab), tab<const float *const>(p.cov2d_tab),
+          g_mean.data_ptr<float>(), g_qvec.data_ptr<float>(), g_svec.data_ptr<float>(), s));
+    else
+      GS(gsgen_project_gaussians_backward_batch(
+          (uint32_t)B, (uint32_t)N, mean.data_ptr<float>(), qvec.data_ptr<float>(), svec.data_ptr<float>(),
+          tab<const float *const>(p.cam_tab), ctx->saved_data["detach"].toBool() ? 1 : 0, tab<const uint8_t *const>(p.mask_tab),
+          tab<const float *const>(p.gmean_tab), tab<const float *const>(p.gcov_tab), nullptr, g_mean.data_ptr<float>(),
+          g_qvec.data_ptr<float>(), g_svec.data_ptr<float>(), s));
     const auto &ga = ctx->saved_data["grad_accum"];
     if (ga.isTensor() && ga.toTensor().defined()) {
       Tensor acc = ga.toTensor(), cnt = ctx->saved_data["cnt"].toTensor();

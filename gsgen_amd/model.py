@@ -53,6 +53,42 @@ def _get(cfg, key, default=None):
     return getattr(cfg, key, default)
 
 
+def _to_plain(v):
+    """OmegaConf nodes -> python containers (utils/misc.py:200-211), without importing omegaconf"""
+    if v is None or isinstance(v, (int, float, str, list, dict)):
+        return v
+    try:
+        from omegaconf import OmegaConf
+        return OmegaConf.to_container(v, resolve=True)
+    except Exception:
+        return dict(v) if hasattr(v, "keys") else list(v)
+
+
+def _lr_schedule(spec):
+    """-> f(step) for one field of the trainer's `lr` config (gs/gaussian_splatting.py:267-292 over utils/schedulers.py:6-41 and
+    utils/misc.py:218-260)"""
+    if isinstance(spec, (int, float)):
+        return lambda step, v=float(spec): v
+    if not isinstance(spec, (list, tuple)) or len(spec) not in (4, 5):
+        raise ValueError(f"Invalid lr schedule {spec}")
+    if len(spec) == 4 and isinstance(spec[3], str):
+        lr0, lr1, total, kind = float(spec[0]), float(spec[1]), float(spec[2]), spec[3]
+        if kind == "nothing":
+            return lambda step: lr0
+        if kind == "exp":  # log-linear from lr_start to lr_end over max_steps
+            return lambda step: float(np.exp(np.log(lr0) + (np.log(lr1) - np.log(lr0)) * min(max(step / total, 0.0), 1.0)))
+        if kind == "cosine":
+            return lambda step: lr1 + (lr0 - lr1) * (1.0 + float(np.cos(np.pi * step / total))) / 2.0
+        raise ValueError(f"Invalid lr schedule {spec}")
+    s0, v0, v1, s1 = (float(x) for x in spec[:4])  # piecewise: linear (or sqrt) from (s0, v0) to (s1, v1), constant outside
+    root = len(spec) == 5 and spec[4] == "sqrt"
+
+    def f(step):
+        w = min(max((step - s0) / (s1 - s0), 0.0), 1.0)
+        return v1 - (v1 - v0) * float(np.sqrt(w)) if root else v0 + (v1 - v0) * w
+    return f
+
+
 class _Background(nn.Module):
     """gs/backgrounds.py: `fixed` (a constant colour held as a Parameter, :33-45), `random` (one torch.rand(3) per camera while
     training, black in eval, :48-70 -- drawn from torch's CPU generator exactly as the reference draws it, one draw per camera
@@ -62,6 +98,8 @@ class _Background(nn.Module):
         super().__init__()
         self.type = _get(cfg, "type", "random")
         self.range = list(_get(cfg, "range", [0.0, 1.0]))
+        self.random_aug = bool(_get(cfg, "random_aug", False)) and self.type != "fixed"  # (FixedBackground disables it, gs/backgrounds.py:44-45)
+        self.random_aug_prob = float(_get(cfg, "random_aug_prob", 0.0))
         if self.type == "fixed":
             self.bg_color = nn.Parameter(torch.tensor(list(_get(cfg, "color")), dtype=torch.float32))
         elif self.type == "learned_const":
@@ -70,7 +108,22 @@ class _Background(nn.Module):
             raise NotImplementedError(f"gsgen_amd.model: background type {self.type!r} (MLPBackground needs tinycudann; pass the "
                                       "colours yourself through BatchRenderer.render_heads(bg_rgb=...))")
 
-    def forward(self, B, device):
+    def forward(self, B, device=None):
+        """B cameras -> [B, 1, 1, 3] (what the batched forward composites); or, called as the reference calls it -- bg(rays_d) with
+        rays_d [H, W, 3], gs/gaussian_splatting.py:1321 -- -> [H, W, 3] for one camera"""
+        if isinstance(B, torch.Tensor):
+            rays = B
+            return self.forward(1, rays.device).view(1, 1, 3).expand(rays.shape[0], rays.shape[1], 3).to(rays.dtype)
+        if self.random_aug and self.training and self.type != "fixed":
+            # gs/backgrounds.py:24-36: with probability 1 - random_aug_prob a camera's background is one random colour
+            import random
+            cols = self._colours(B, device)
+            pick = torch.tensor([random.random() >= self.random_aug_prob for _ in range(B)], device=cols.device)
+            rnd = torch.stack([torch.rand(3) for _ in range(B)]).to(cols).view(B, 1, 1, 3)
+            return torch.where(pick.view(B, 1, 1, 1), rnd, cols)
+        return self._colours(B, device)
+
+    def _colours(self, B, device):
         if self.type == "random":
             if self.training:
                 cols = torch.stack([torch.rand(3) for _ in range(B)])  # (CPU generator, one draw per camera: gs/backgrounds.py:58)
@@ -249,6 +302,151 @@ class GaussianSplattingRenderer(nn.Module):
     def check_overflow(self):
         """no sync: raises PairListOverflow if a camera of an earlier batch did not fit its pair list (its images were NaN)"""
         return True if self._br is None else self._br.check_overflow()
+
+    # ---- what trainer.py calls around the render (ADVICE r5: the class is only a drop-in if these exist) ------------------------
+    # trainer.py:163-164, :230, :287, :469, :600-616, :800-801.  Optimiser and schedules follow gs/gaussian_splatting.py:267-292,
+    # :383-419, :451-462 (one torch.optim group per field, named, lr re-evaluated every step); densify / prune delegate to
+    # gsgen_amd.densify (the reference's policies :751-948, :1124-1177 restated there and tested against the reference's own code).
+    def setup_lr(self, cfg):
+        """cfg[field] for mean, qvec, svec, color, alpha, bg: a number, [lr_start, lr_end, max_steps, 'exp' | 'cosine' | 'nothing'], or
+        the reference's piecewise form [start_step, start_value, end_value, end_step(, 'linear' | 'sqrt')] (utils/misc.py:218-260)"""
+        for field in self.fields + ["bg"]:
+            setattr(self, f"{field}_lr_scheduler", _lr_schedule(_to_plain(_get(cfg, field))))
+
+    def get_param_groups(self):
+        return {"mean": self.mean, "qvec": self.qvec, "svec": self.svec_before_activation, "color": self.color_before_activation,
+                "alpha": self.alpha_before_activation, "bg": list(self.bg.parameters())}
+
+    def set_optimizer(self, cfg, step=0):
+        groups = []
+        for name, params in self.get_param_groups().items():
+            params = params if isinstance(params, list) else [params]
+            if params:  # (a `random` background has no parameters: torch refuses an empty group)
+                groups.append({"params": params, "lr": float(getattr(self, f"{name}_lr_scheduler")(step)), "name": name})
+        self.opt_cfg = cfg
+        args = _to_plain(_get(cfg, "opt_args")) or {}
+        self.optimizer = getattr(torch.optim, _get(cfg, "type", "Adam"))(groups, lr=0.0, **args)
+
+    def update_lr(self, step):
+        for g in self.optimizer.param_groups:
+            g["lr"] = float(getattr(self, f"{g['name']}_lr_scheduler")(step))
+
+    def update(self, step):
+        """trainer.py:287 (the reference also toggles its gradient mask here: `mask` configs are outside this class)"""
+        self.step = step
+        self.update_lr(step)
+
+    @property
+    def is_densifying(self):
+        return self.densify_enabled
+
+    def _raw(self):
+        return {"mean": self.mean.data, "qvec": self.qvec.data, "svec": self.svec_before_activation.data,
+                "color": self.color_before_activation.data, "alpha": self.alpha_before_activation.data}
+
+    def _adopt(self, raw, moments=None, step=0):
+        """new Gaussian set: Parameters, statistics, optimiser (fresh -- densify_legacy, :935 -- or with the surviving rows' Adam state)"""
+        self.mean, self.qvec = nn.Parameter(raw["mean"]), nn.Parameter(raw["qvec"])
+        self.svec_before_activation = nn.Parameter(raw["svec"])
+        self.color_before_activation, self.alpha_before_activation = nn.Parameter(raw["color"]), nn.Parameter(raw["alpha"])
+        self.N = self.mean.shape[0]
+        if getattr(self, "optimizer", None) is not None:
+            old_state = {g["name"]: self.optimizer.state.get(g["params"][0], None) for g in self.optimizer.param_groups}
+            self.set_optimizer(self.opt_cfg, step)
+            if moments is not None:
+                for g in self.optimizer.param_groups:
+                    k = g["name"]
+                    if k in moments and old_state.get(k):
+                        st = dict(old_state[k])
+                        st["exp_avg"], st["exp_avg_sq"] = moments[k][0].contiguous(), moments[k][1].contiguous()
+                        self.optimizer.state[g["params"][0]] = st
+
+    def _moments(self):
+        out = {}
+        for g in getattr(self, "optimizer", None).param_groups if getattr(self, "optimizer", None) is not None else []:
+            st = self.optimizer.state.get(g["params"][0], None)
+            if g["name"] != "bg" and st and "exp_avg" in st:
+                out[g["name"]] = (st["exp_avg"], st["exp_avg_sq"])
+        return out
+
+    @torch.no_grad()
+    def densify(self, step, verbose=True):
+        """gs/gaussian_splatting.py:751-948 through gsgen_amd.densify (`use_legacy`: split / clone from the accumulated screen-space
+        gradient, the optimiser starts afresh; otherwise clone-then-split with the Adam state carried over)"""
+        from . import densify as D
+        c = self.densify_cfg
+        if not (self.densify_enabled and _get(c, "warm_up", 0) <= step <= _get(c, "end", 0)
+                and D.step_check(step, int(_get(c, "period", 1000)), True)):
+            return 0
+        dc = D.DensifyConfig(enabled=True, type="legacy" if _get(c, "use_legacy", True) else "official",
+                             warm_up=int(_get(c, "warm_up", 0)), end=int(_get(c, "end", 0)), period=int(_get(c, "period", 1000)),
+                             mean2d_thresh=float(_get(c, "mean2d_thresh", 0.02)), split_thresh=float(_get(c, "split_thresh", 0.02)),
+                             n_splits=int(_get(c, "n_splits", 2)), split_shrink=float(_get(c, "split_shrink", 0.8)))
+        raw, n0 = self._raw(), self.N
+        if dc.type == "legacy":
+            raw, info = D.densify_legacy(raw, self.svec.data, self.svec_inv_act, self.mean_2d_grad_accum, self.cnt, dc)
+            moments = None
+        else:
+            raw, moments, info = D.densify_official(raw, self._moments(), {"svec": self.svec_act, "svec_inv": self.svec_inv_act},
+                                                    self.mean_2d_grad_accum, self.cnt, dc)
+        self._adopt(raw, moments, step)
+        self.reset_densify_info()
+        if verbose:
+            print(f"[gsgen_amd] densify at step {step}: {n0} -> {self.N} Gaussians {info}")
+        return self.N - n0
+
+    @torch.no_grad()
+    def prune(self, step, verbose=True):
+        """gs/gaussian_splatting.py:1124-1177 (by screen-space radius, opacity, 3-D scale); the Adam state follows the survivors"""
+        from . import densify as D
+        c = self.prune_cfg
+        if not (_get(c, "enabled", False) and _get(c, "warm_up", 0) <= step <= _get(c, "end", 0)
+                and D.step_check(step, int(_get(c, "period", 500)))):
+            return 0
+        pc = D.PruneConfig(enabled=True, warm_up=int(_get(c, "warm_up", 0)), end=int(_get(c, "end", 0)), period=int(_get(c, "period", 500)),
+                           radii2d_thresh=float(_get(c, "radii2d_thresh", 1000.0)), alpha_thresh=float(_get(c, "alpha_thresh", 1000.0)),
+                           radii3d_thresh=float(_get(c, "radii3d_thresh", 0.0)))
+        keep, counts = D.prune_masks(step, pc, self.max_radii2d, self.alpha.data, self.svec.data)
+        n0 = self.N
+        if bool(keep.all()):
+            return 0
+        stats = (self.max_radii2d[keep], self.mean_2d_grad_accum[keep] if self.densify_enabled else None,
+                 self.cnt[keep] if self.densify_enabled else None)
+        mom = {k: (a[keep], b[keep]) for k, (a, b) in self._moments().items()}
+        self._adopt({k: v[keep] for k, v in self._raw().items()}, mom or None, step)
+        self.max_radii2d = stats[0]
+        if self.densify_enabled:
+            self.mean_2d_grad_accum, self.cnt = stats[1], stats[2]
+        if verbose:
+            print(f"[gsgen_amd] prune at step {step}: {n0} -> {self.N} Gaussians {counts}")
+        return n0 - self.N
+
+    def densify_by_compatness(self, K=1):
+        raise NotImplementedError("gsgen_amd.model: densify_by_compatness (gs/gaussian_splatting.py:682-739, the upsample-tune stage of "
+                                  "trainer.py:796-801) is outside the rasterizer path this library replaces (SURVEY.md section 2)")
+
+    def auxiliary_loss(self, step, writer=None):
+        """trainer.py:469: the sum of the configured penalty losses (gs/gaussian_splatting.py:950-1122).  They are plain torch on the
+        parameters, outside the rasterizer path: an empty `penalty` config gives the zero the trainer adds; a configured one raises."""
+        keys = list(_get(self.cfg, "penalty", None) or [])
+        if keys:
+            raise NotImplementedError(f"gsgen_amd.model: penalty losses {keys} are outside the rasterizer path this library replaces")
+        return self.mean.new_zeros(())
+
+    @torch.no_grad()
+    def log(self, writer, step):
+        """trainer.py:603 / :841: scalars a TensorBoard-like writer takes (the reference logs bounds, gradient bounds, statistics,
+        learning rates and the max_radii2d histogram, gs/gaussian_splatting.py:1477-1566)"""
+        if writer is None:
+            return
+        writer.add_scalar("statistics/n_gaussians", self.N, step)
+        for name, t in (("mean", self.mean), ("svec", self.svec), ("alpha", self.alpha)):
+            writer.add_scalar(f"bounds/{name}_max", float(t.max()), step)
+            writer.add_scalar(f"bounds/{name}_min", float(t.min()), step)
+        for g in getattr(self, "optimizer", None).param_groups if getattr(self, "optimizer", None) is not None else []:
+            writer.add_scalar(f"lr/{g['name']}", g["lr"], step)
+        if hasattr(writer, "add_histogram"):
+            writer.add_histogram("hists/max_radii2d", self.max_radii2d, step)
 
     def get_params_for_save(self):  # gs/gaussian_splatting.py:294-311 (the five raw fields; gsgen_amd.io writes them)
         return {k: getattr(self, k).detach() for k in self.raw_fields}

@@ -203,6 +203,14 @@ int gsgen_project_gaussians_backward_batch_heads(uint32_t n_views, uint32_t N, c
  * are formed here in fp64, once per (view, Gaussian), and chained through the projection as above.  g_chan6[v][:, 3] holds the
  * folded d L / d depth of the three depth heads (columns 4, 5 stay zero).  g_mom2[v] is OVERWRITTEN with the view's
  * d L / d mean2d (what gsgen_densify_update_batch reads, gs/gaussian_splatting.py:464-469). */
+/* ... and behind the SH kernels' moment form (gsgen_vol_render_backward_sh_batch_routed_moments): g_mom2[v] = sum g (tx, ty),
+ * g_mom4[v] = sum g (tx tx, tx ty, ty ty, -) with (tx, ty) = det Sigma^-1 d; d mean2d = M1 / det, d cov2d = 0.5 M2 / det^2 with the
+ * fp32 determinant of cov2d[v] the kernels use (kernels.h:179).  g_mom2[v] is overwritten with d L / d mean2d as above. */
+int gsgen_project_gaussians_backward_batch_moments_sh(uint32_t n_views, uint32_t N, const float *mean, const float *qvec,
+                                                      const float *svec, const float *const *c2w, int detach_depth,
+                                                      const uint8_t *const *mask, float *const *g_mom2,
+                                                      const float *const *g_mom4, const float *const *cov2d, float *g_mean,
+                                                      float *g_qvec, float *g_svec, gsgen_stream_t stream);
 int gsgen_project_gaussians_backward_batch_heads_moments(uint32_t n_views, uint32_t N, const float *mean, const float *qvec,
                                                          const float *svec, const float *const *c2w, int detach_depth,
                                                          const uint8_t *const *mask, float *const *g_mom2,
@@ -535,6 +543,17 @@ int gsgen_vol_render_backward_sh_batch_routed(uint32_t n_views, const gsgen_sh_v
                                               uint32_t n_tiles_w, uint32_t H, uint32_t W, uint32_t C, float thresh,
                                               uint32_t n_segments, const float *sh_l1_bound, const float *sh_row_bounds,
                                               void *batch_workspace, gsgen_stream_t stream);
+/* The MOMENT form of gsgen_vol_render_backward_sh_batch_routed (round 6; vol_render_sh.h:353-455 / vol_render_bg.h:131-242 for the
+ * cameras of a batch): same arguments and routing; the views' grad_mean [N,2] receive sum g (tx, ty), grad_cov [N,4] sum g
+ * (tx tx, tx ty, ty ty; the fourth float is not written), g = d L / d (a G) * a G per pixel, (tx, ty) = det Sigma^-1 d as the
+ * Gaussian is evaluated (kernels.h:172-193) -- seven packed operations per pixel pair instead of thirteen and one atomic per
+ * (tile, Gaussian) less.  gsgen_project_gaussians_backward_batch_moments_sh expands them per (view, Gaussian). */
+int gsgen_vol_render_backward_sh_batch_routed_moments(uint32_t n_views, const gsgen_sh_view *views, uint32_t N,
+                                                      const float *sh_coeffs, const float *alpha, float *grad_sh_coeffs,
+                                                      float *grad_alpha, uint32_t tile_size, uint32_t n_tiles_h,
+                                                      uint32_t n_tiles_w, uint32_t H, uint32_t W, uint32_t C, float thresh,
+                                                      uint32_t n_segments, const float *sh_l1_bound, const float *sh_row_bounds,
+                                                      void *batch_workspace, gsgen_stream_t stream);
 int gsgen_vol_render_sh_routed(uint32_t N, uint32_t D, const float *mean, const float *cov,
                                const float *sh_coeffs, const float *alpha, const int *start,
                                const int *end, const int *gaussian_ids, float *out, const float *topleft,

@@ -761,6 +761,95 @@ def test_emulated_batched_rgb_heads_match_per_view_launches(emu):
         emu.vol_render_rgbd_batch(len(views), arr, Nall, P(col), P(al), 16, nth, ntw, H, W, 1e-4, P(bws), None)
 
 
+@pytest.mark.parametrize("C,nseg,routed", [(4, 0, True), (4, 2, True), (4, 0, False), (2, 0, False), (3, 2, False)])
+def test_emulated_sh_moment_form_equals_the_plain_backward(emu, C, nseg, routed):
+    """Round 6: gsgen_vol_render_backward_sh_batch_routed_moments + gsgen_project_gaussians_backward_batch_moments_sh (the geometric
+    gradients as five moments of the per-pixel weight against (tx, ty) = det Sigma^-1 d, scaled by 1 / det and 0.5 / det^2 per (view,
+    Gaussian)) == the plain pair, through every kernel of a batched SH backward: the polynomial kernel with its per-entry exact tier,
+    the persistent exact fallback behind flagged tiles (planted outlier splats), the exact batch kernels of the other degrees,
+    segmented and not."""
+    import ctypes as Ct
+    from gsgen_amd._capi import ShView
+    from gsgen_amd import renderer as R
+    W, H = 64, 48
+    sc = scenes.random_scene(300, seed=23, svec=0.048, spread=0.18, C=C)
+    sc["svec"] = np.ascontiguousarray(sc["svec"] * np.array([2.0, 0.6, 1.0], np.float32))
+    rows = None
+    if C == 4:
+        sc["sh"][:, :, 1:] *= 0.0078
+        if routed:
+            rng = np.random.default_rng(4)
+            lone = rng.choice(300, 4, replace=False)
+            centre = sc["mean"][int(rng.integers(300))]
+            outl = np.union1d(lone, np.argsort(np.linalg.norm(sc["mean"] - centre, axis=1))[:10])
+            sc["sh"][outl, :, 9:] = 3.0
+            sc["sh"][outl, :, 0] = 0.0
+    sc["alpha"] = (sc["alpha"] * 0.5).astype(np.float32)
+    N = sc["mean"].shape[0]
+    sh, al = np.ascontiguousarray(sc["sh"]), np.ascontiguousarray(sc["alpha"])
+    cams = [scenes.Camera(W, H, fx=130.0 + 15 * i, c2w=scenes.orbit(2.5, 10 + 20 * i, 40.0 + 100 * i)) for i in range(2)]
+    B = len(cams)
+    nth, ntw = cams[0].tiles
+    T = nth * ntw
+    if C == 4 and routed:
+        rows = np.full(N, -1.0, np.float32); gmax = np.zeros(1, np.float32)
+        emu.sh_l1_bound_rows(N, P(sh), C, P(gmax), P(rows), None)
+    views = []
+    for i, cam in enumerate(cams):
+        g = scenes.oracle_geometry(sc, cam)
+        nz = np.nonzero(g["mask"])[0]
+        m2 = np.zeros((N, 2), np.float32); c2 = np.zeros((N, 2, 2), np.float32)
+        c2[:] = np.eye(2, dtype=np.float32)
+        m2[nz] = g["mean2d"]; c2[nz] = g["cov2d"]
+        views.append(dict(m2=m2, c2=c2, st=g["start"], en=g["end"], ids=nz[g["ids"]].astype(np.int32), tlp=cam.topleft,
+                          rot=np.ascontiguousarray(cam.c2w[:3, :3].reshape(-1)), cam=cam, mask=g["mask"].astype(np.uint8),
+                          bg=np.array([0.3, 0.1, 0.2], np.float32), go=np.random.default_rng(i).normal(size=(H, W, 3)).astype(np.float32)))
+    camv = [np.ascontiguousarray(R.CameraInfo(*v["cam"].intr).pack(v["cam"].c2w)) for v in views]
+    tab = lambda xs: (Ct.c_void_p * B)(*[x.ctypes.data for x in xs])  # noqa: E731
+    arr = (ShView * B)()
+    for a, v in zip(arr, views):
+        cam = v["cam"]
+        v["ws"] = np.zeros(max(1, emu.segment_workspace_bytes(T, max(nseg, 1))), np.uint8)
+        v["out"] = np.zeros((H, W, 3), np.float32); v["T"] = np.zeros((H, W), np.float32)
+        a.mean, a.cov, a.start, a.end, a.gaussian_ids = P(v["m2"]), P(v["c2"]), P(v["st"]), P(v["en"]), P(v["ids"])
+        a.tile_order, a.topleft, a.c2w, a.bg_rgb = None, P(v["tlp"]), P(v["rot"]), P(v["bg"])
+        a.pixel_size_x, a.pixel_size_y = 1 / cam.fx, 1 / cam.fy
+        a.out, a.T, a.segment_workspace = P(v["out"]), P(v["T"]), (P(v["ws"]) if nseg else None)
+        a.grad_out = P(v["go"])
+    bws = np.zeros(emu.sh_batch_workspace_bytes_routed(B, T), np.uint8)
+    emu.vol_render_sh_batch_routed(B, arr, N, P(sh), P(al), 16, nth, ntw, H, W, C, 1e-4, nseg, None, P(rows), P(bws), None)
+    if rows is not None:  # both kernels of a routed batch take part
+        flags = bws[emu.sh_batch_workspace_bytes(B):][:B * T]
+        assert flags.any() and not flags.all()
+    res = {}
+    for form in ("plain", "moments"):
+        for a, v in zip(arr, views):
+            v["gm"] = np.zeros((N, 2), np.float32); v["gc"] = np.zeros((N, 4), np.float32)
+            a.grad_mean, a.grad_cov = P(v["gm"]), P(v["gc"])
+        gsh = np.zeros_like(sh); ga = np.zeros(N, np.float32)
+        out = [np.zeros((N, n), np.float32) for n in (3, 4, 3)]
+        common = (B, N, P(sc["mean"]), P(sc["qvec"]), P(sc["svec"]), tab(camv), 1, tab([v["mask"] for v in views]),
+                  tab([v["gm"] for v in views]), tab([v["gc"] for v in views]))
+        bwd = emu.vol_render_backward_sh_batch_routed if form == "plain" else emu.vol_render_backward_sh_batch_routed_moments
+        bwd(B, arr, N, P(sh), P(al), P(gsh), P(ga), 16, nth, ntw, H, W, C, 1e-4, nseg, None, P(rows), P(bws), None)
+        if form == "plain":
+            gm2d = [v["gm"].copy() for v in views]
+            emu.project_gaussians_backward_batch(*common, None, *[P(a) for a in out], None)
+        else:
+            for v in views:
+                assert not v["gc"][:, 3].any() and np.abs(v["gc"][:, :3]).max() > 0
+            emu.project_gaussians_backward_batch_moments_sh(*common, tab([v["c2"] for v in views]), *[P(a) for a in out], None)
+            gm2d = [v["gm"].copy() for v in views]  # overwritten with d L / d mean2d
+        res[form] = dict(gsh=gsh, ga=ga, out=out, gm2d=gm2d)
+    a_, b_ = res["plain"], res["moments"]
+    assert np.abs(a_["gsh"]).max() > 0 and np.array_equal(a_["gsh"], b_["gsh"])  # the colour part is untouched
+    assert np.abs(a_["ga"] - b_["ga"]).max() <= 3e-6 * np.abs(a_["ga"]).max()
+    for x, y, name in zip(a_["out"], b_["out"], ("mean", "qvec", "svec")):
+        assert np.abs(x).max() > 0 and np.abs(x - y).max() <= 2e-5 * np.abs(x).max(), name
+    for x, y in zip(a_["gm2d"], b_["gm2d"]):
+        assert np.abs(x - y).max() <= 1e-5 * np.abs(x).max()
+
+
 def test_emulated_rgb_heads_moment_form_equals_the_plain_backward(emu):
     """Round 6: gsgen_vol_render_rgbd_backward_batch_moments + gsgen_project_gaussians_backward_batch_heads_moments (ten components
     per (tile, Gaussian): r g b, one folded depth gradient, five moments of the per-pixel weight against the whitened offsets,
@@ -1387,17 +1476,19 @@ def test_no_kernel_spills_and_hot_kernels_keep_their_occupancy(tmp_path):
     # One shape per job since round 4 (composite.hip "launch helpers").  The exact SH backward (one wavefront per tile, packed
     # per-pixel arithmetic, channel-wise gradient reduction, grad_out in LDS, record in scalar registers): THREE wavefronts per
     # SIMD (<= 168 registers) and at least 12 workgroups per CU by LDS; per-camera and batched instantiation.
-    for bwd in find(1, "k_composite_bwd_sh_vecILi4ELi4ELb0ELi0EE") + find(1, "k_composite_bwd_sh_vecILi4ELi4ELb1ELi0EE"):
+    # (round 6: the batched backward kernels exist in two forms -- <..., MOM = false> the plain gradients of the `_batch*` entry points,
+    # <..., MOM = true> the moment form BatchRenderer runs: the same budgets)
+    for bwd in find(1, "k_composite_bwd_sh_vecILi4ELi4ELb0ELi0ELb0EE") + find(2, "k_composite_bwd_sh_vecILi4ELi4ELb1ELi0ELb"):
         assert bwd["vgpr_count"] <= 168 and 12 * bwd["group_segment_fixed_size"] <= 160 * 1024, bwd
     # SH degree 3 with the device-resident coefficient bound.  One camera: the ROUTED kernel (polynomial and exact form in one
     # launch, one LDS block shared by the two): the occupancy class of the exact kernel.  Camera batches: the polynomial form
     # alone -- FOUR wavefronts per SIMD in the backward, five in the one-wavefront-per-tile forward -- plus the persistent exact
     # fallback (the exact kernels' budgets).
-    for bwd in find(1, "k_composite_bwd_sh_vecILi4ELi4ELb0ELin1EE"):
+    for bwd in find(1, "k_composite_bwd_sh_vecILi4ELi4ELb0ELin1ELb0EE"):
         assert bwd["vgpr_count"] <= 168 and 12 * bwd["group_segment_fixed_size"] <= 160 * 1024, bwd
     for fwd in find(1, "k_composite_fwd_sh_vecILi4ELi2ELb0ELin1E"):
         assert fwd["vgpr_count"] <= 96 and 10 * fwd["group_segment_fixed_size"] <= 160 * 1024, fwd
-    for bwd in find(1, "k_composite_bwd_sh_vecILi4ELi4ELb1ELi6EE"):
+    for bwd in find(2, "k_composite_bwd_sh_vecILi4ELi4ELb1ELi6ELb"):
         assert bwd["vgpr_count"] <= 128 and 16 * bwd["group_segment_fixed_size"] <= 160 * 1024, bwd
     # (the forward of an unsegmented batch keeps no stop list: <..., TRACK = false>, the one held at five; a segmented batch's four)
     for fwd in find(1, "k_composite_fwd_sh_vecILi4ELi4ELb1ELi6ELb0EE"):
@@ -1405,12 +1496,12 @@ def test_no_kernel_spills_and_hot_kernels_keep_their_occupancy(tmp_path):
     for fwd in find(1, "k_composite_fwd_sh_vecILi4ELi4ELb1ELi6ELb1EE"):
         assert fwd["vgpr_count"] <= 128 and 16 * fwd["group_segment_fixed_size"] <= 160 * 1024, fwd
     # (the persistent fallback: three wavefronts per SIMD in the backward as the exact kernel itself, four in the forward)
-    for bwd in find(1, "k_composite_bwd_sh_vecILi4ELi4ELb1ELin2EE"):
+    for bwd in find(2, "k_composite_bwd_sh_vecILi4ELi4ELb1ELin2ELb"):
         assert bwd["vgpr_count"] <= 168 and 12 * bwd["group_segment_fixed_size"] <= 160 * 1024, bwd
     for fwd in find(1, "k_composite_fwd_sh_vecILi4ELi2ELb1ELin2E"):
         assert fwd["vgpr_count"] <= 128 and 8 * fwd["group_segment_fixed_size"] <= 160 * 1024, fwd
     # the trainer's default outputs (RGB + heads, packed, one wavefront per tile): FIVE wavefronts per SIMD backward, SIX forward
-    for bwd in find(2, "k_composite_bwd_chan_vecILi3E"):
+    for bwd in find(3, "k_composite_bwd_chan_vecILi3E"):  # per camera, batched, batched in the moment form
         assert bwd["vgpr_count"] <= 96 and 20 * bwd["group_segment_fixed_size"] <= 160 * 1024, bwd
     for fwd in find(1, "k_composite_fwd_chan_vecILi3ELb1EE"):
         assert fwd["vgpr_count"] <= 80 and 24 * fwd["group_segment_fixed_size"] <= 160 * 1024, fwd
