@@ -29,7 +29,9 @@ class RgbdView(C.Structure):
     _fields_ = [("mean", vp), ("cov", vp), ("depth", vp), ("start", vp), ("end", vp), ("gaussian_ids", vp),
                 ("tile_order", vp), ("topleft", vp), ("pixel_size_x", f32), ("pixel_size_y", f32), ("out6", vp),
                 ("T", vp), ("grad_out6", vp), ("grad_mean", vp), ("grad_cov", vp), ("grad_chan6", vp),
-                ("grad_rgb", vp), ("grad_depth", vp), ("grad_opacity", vp), ("grad_depth2", vp)]
+                ("grad_rgb", vp), ("grad_depth", vp), ("grad_opacity", vp), ("grad_depth2", vp),
+                ("out_rgb", vp), ("out_depth", vp), ("out_opacity", vp), ("out_depth2", vp), ("bg_rgb", vp), ("grad_bg", vp),
+                ("depth_variance", u32)]
 
 
 class GeometryView(C.Structure):

@@ -198,23 +198,36 @@ class _render_batch(torch.autograd.Function):
         return (g_mean, g_qvec, g_svec, g_alpha, g_col, None, None, None, None, _bg_grad(ctx, grad, T), None, None, None)
 
 
+def _bg_rows(bg, B):
+    """-> (tensor to keep alive, [address of view i's background colour]) for bg_rgb of 3 or 3 B elements (any broadcastable shape)"""
+    if bg is None:
+        return None, [None] * B
+    if bg.numel() == 3 and bg.is_contiguous():
+        return bg, [bg.data_ptr()] * B
+    rows = bg.detach().expand(B, 1, 1, 3).contiguous()
+    return rows, [rows.data_ptr() + 12 * i for i in range(B)]
+
+
 class _render_batch_heads(torch.autograd.Function):
-    """(mean, qvec, svec, alpha, color) -> rgb [B,H,W,3], depth, opacity, depth^2, T [B,H,W,1]: the default
+    """(mean, qvec, svec, alpha, color) -> rgb [B,H,W,3], depth, opacity, depth^2 (or z_var), T [B,H,W,1]: the default
     (rgb_only = False) output set of GaussianSplattingRenderer.forward (gs/gaussian_splatting.py:1304-1416,
-    :1423-1466), one fused compositing pass per camera (gsgen_vol_render_rgbd) instead of four."""
+    :1423-1466), one fused compositing pass per camera (gsgen_vol_render_rgbd) instead of four.  Round 6: four separate contiguous
+    images, the background and (z_var) the depth variance formed inside the launches -- see csrc/torch_batch.cpp, HeadsFn."""
 
     @staticmethod
-    def forward(ctx, mean, qvec, svec, alpha, col, cams, br, B, bg_rgb, thresh, detach_depth, stats):
+    def forward(ctx, mean, qvec, svec, alpha, col, cams, br, B, bg_rgb, thresh, detach_depth, stats, z_var):
         mean, qvec, svec = mean.contiguous(), qvec.contiguous(), svec.contiguous()
         alpha, col = alpha.contiguous(), col.contiguous()
         lib = _capi.load()
         H, W, N, dev = br.H, br.W, br.N, mean.device
-        # (BatchRenderer.render_heads has run _begin_batch; every pixel of out6 / T is written by the batched forward, the gradient accumulators are zeroed by the
-        # projection launch: no fill kernels)
-        out6 = torch.empty(B, H, W, 6, device=dev, dtype=torch.float32)
-        T = torch.empty(B, H, W, 1, device=dev, dtype=torch.float32)
-        out_p, T_p = out6.data_ptr(), T.data_ptr()
-        gsh = torch.empty(br._Np, device=dev, dtype=torch.float32)  # d L / d alpha, shared by the views
+        # (BatchRenderer.render_heads has run _begin_batch; every pixel of the images / T is written by the batched forward, the
+        # gradient accumulators are zeroed by the projection launch: no fill kernels)
+        f = dict(device=dev, dtype=torch.float32)
+        rgb = torch.empty(B, H, W, 3, **f)
+        dep, opa, zz, T = (torch.empty(B, H, W, 1, **f) for _ in range(4))
+        bg_grad = bg_rgb is not None and ctx.needs_input_grad[8]
+        gsh = torch.empty(br._Np + (256 * B if bg_grad else 0), **f)  # d L / d alpha, shared by the views | d L / d bg partial rows
+        bg_keep, bg_ptrs = _bg_rows(bg_rgb, B)
         with _on(dev):
             parts = br._fork(B)
             views = br._geometry("rgbd", B, parts, mean, qvec, svec, gsh)
@@ -222,7 +235,11 @@ class _render_batch_heads(torch.autograd.Function):
             for i in range(B):
                 ci, v = cis[i], views[i]
                 v.pixel_size_x, v.pixel_size_y = 1.0 / ci.fx, 1.0 / ci.fy
-                v.out6, v.T = out_p + 24 * H * W * i, T_p + 4 * H * W * i
+                v.out6, v.T = None, T.data_ptr() + 4 * H * W * i
+                v.out_rgb = rgb.data_ptr() + 12 * H * W * i
+                v.out_depth, v.out_opacity, v.out_depth2 = (x.data_ptr() + 4 * H * W * i for x in (dep, opa, zz))
+                v.bg_rgb, v.depth_variance = bg_ptrs[i], 1 if z_var else 0
+                v.grad_bg = gsh.data_ptr() + 4 * (br._Np + 256 * i) if bg_grad else None
             nth, ntw = br.slots[0].nth, br.slots[0].ntw
             for k, (lo, n, s) in enumerate(parts):
                 lib.vol_render_rgbd_batch(n, _sub(views, lo, n), N, _p(col), _p(alpha), 16, nth, ntw, H, W, thresh,
@@ -231,31 +248,29 @@ class _render_batch_heads(torch.autograd.Function):
             if stats is not None:
                 lib.densify_update_batch(B, N, br._ptr_table("cov2d", B), None, br._mask_table(B),
                                          _p(stats.max_radii2d), None, None, parts[0][2])
-        if bg_rgb is not None:
-            out6[..., :3] += T * bg_rgb  # gs/renderer.py:1182
         ctx.gen = br._generation
         ctx.views, ctx.gsh, ctx.parts = views, gsh, [(lo, n) for lo, n, _ in parts]
-        ctx.save_for_backward(mean, qvec, svec, alpha, col, cams, out6, T)
-        ctx.bg_shape = tuple(bg_rgb.shape) if (bg_rgb is not None and ctx.needs_input_grad[8]) else None
+        ctx.save_for_backward(mean, qvec, svec, alpha, col, cams, rgb, dep, opa, zz, T)
+        ctx.bg_keep, ctx.bg_grad = bg_keep, bg_grad
+        ctx.bg_shape = tuple(bg_rgb.shape) if bg_grad else None
         ctx.br, ctx.B, ctx.thresh, ctx.detach, ctx.stats = br, B, thresh, detach_depth, stats
         ctx.mark_non_differentiable(T)
-        return out6[..., :3], out6[..., 3:4], out6[..., 4:5], out6[..., 5:6], T
+        return rgb, dep, opa, zz, T
 
     @staticmethod
     def backward(ctx, g_rgb, g_depth, g_opac, g_z2, _gT):
-        """one compositing launch per half-batch that reads the four head gradients in place (no [B,H,W,6] image is
-        assembled: that concatenation was 8 % of a step at 8 x 800^2), one projection launch that forms
-        d L / d depth = g3 + 2 depth g5 and sums the colour gradient over the views itself
-        (gsgen_project_gaussians_backward_batch_heads)"""
+        """one compositing launch per half-batch that reads the four head gradients in place, forms the depth variance's chain rule and
+        the background's gradient itself, one projection launch that expands the moments, forms d L / d depth = g3 + 2 depth g5 and
+        sums the colour gradient over the views (gsgen_project_gaussians_backward_batch_heads_moments)"""
         ctx.br._check_generation(ctx.gen)
-        mean, qvec, svec, alpha, col, cams, out6, T = ctx.saved_tensors
+        mean, qvec, svec, alpha, col, cams = ctx.saved_tensors[:6]
         br, B, thresh, stats = ctx.br, ctx.B, ctx.thresh, ctx.stats
         lib = _capi.load()
         H, W, N, dev = br.H, br.W, br.N, mean.device
         parts_g = [g.contiguous() if g is not None else None for g in (g_rgb, g_depth, g_opac, g_z2)]
         gsh, ctx.gsh = ctx.gsh, None
         if gsh is None:  # a second backward through the same graph (retain_graph): the accumulators were handed out
-            gsh = torch.zeros(br._Np, device=dev, dtype=torch.float32)
+            gsh = torch.zeros(br._Np + (256 * B if ctx.bg_grad else 0), device=dev, dtype=torch.float32)
             br._g2d[:B].zero_()
             br._chan6()[:B].zero_()
         g_alpha = gsh[:N]
@@ -271,6 +286,7 @@ class _render_batch_heads(torch.autograd.Function):
             v.grad_depth = pp[1] + 4 * H * W * i if pp[1] is not None else None
             v.grad_opacity = pp[2] + 4 * H * W * i if pp[2] is not None else None
             v.grad_depth2 = pp[3] + 4 * H * W * i if pp[3] is not None else None
+            v.grad_bg = gsh.data_ptr() + 4 * (br._Np + 256 * i) if ctx.bg_grad else None
         nth, ntw = br.slots[0].nth, br.slots[0].ntw
         with _on(dev):
             parts = br._fork(B, ctx.parts)
@@ -289,7 +305,10 @@ class _render_batch_heads(torch.autograd.Function):
             if stats is not None and stats.grad_accum is not None:
                 lib.densify_update_batch(B, N, None, br._ptr_table("g_mean2d", B), br._mask_table(B), None,
                                          _p(stats.grad_accum), _p(stats.cnt), s)
-        return (g_mean, g_qvec, g_svec, g_alpha, g_col, None, None, None, _bg_grad(ctx, g_rgb, T), None, None, None)
+        g_bg = None
+        if ctx.bg_grad and g_rgb is not None:
+            g_bg = gsh[br._Np:br._Np + 256 * B].view(B, 64, 4)[..., :3].sum(1).view(B, 1, 1, 3).sum_to_size(ctx.bg_shape)
+        return (g_mean, g_qvec, g_svec, g_alpha, g_col, None, None, None, g_bg, None, None, None, None)
 
 
 class BatchRenderer:
@@ -709,9 +728,12 @@ class BatchRenderer:
         return self._rows
 
     def render_heads(self, mean, qvec, svec, alpha, color, cam_infos, c2ws, bg_rgb=None, thresh=1e-4,
-                     frustum_radius=6.0, tile_radius=6.0, detach_depth=True, stats=None):
+                     frustum_radius=6.0, tile_radius=6.0, detach_depth=True, stats=None, z_var=False):
         """-> (rgb [B,H,W,3], depth, opacity, depth2, T [B,H,W,1]) from post-activation colours [N,3]: what
-        GaussianSplattingRenderer.forward returns with rgb_only = False, one compositing pass per camera."""
+        GaussianSplattingRenderer.forward returns with rgb_only = False, one compositing pass per camera.  Five separate contiguous
+        tensors.  bg_rgb (3 or 3 B elements, any broadcastable shape; differentiable): composited inside the forward launch.
+        z_var=True: the fourth output is the depth variance depth2 - depth^2 the reference's model returns
+        (gs/gaussian_splatting.py:1397), formed -- and differentiated -- inside the launches."""
         B = self._check_batch(cam_infos)
         if B == 0:
             z = torch.zeros(0, self.H, self.W, 3, device=self.device)
@@ -727,9 +749,9 @@ class BatchRenderer:
             va["pixel_size_x"][:B] = 1.0 / self._intr[:B, 0]
             va["pixel_size_y"][:B] = 1.0 / self._intr[:B, 1]
             return tuple(_batch_ext().render_heads(fast[0], mean, qvec, svec, alpha, color, bg_rgb, float(thresh),
-                                                   bool(detach_depth), *self._stats_args(stats)))
+                                                   bool(detach_depth), *self._stats_args(stats), bool(z_var)))
         return _render_batch_heads.apply(mean, qvec, svec, alpha, color, cams, self, B, bg_rgb, float(thresh),
-                                         bool(detach_depth), stats)
+                                         bool(detach_depth), stats, bool(z_var))
 
     def routing_flags(self, B):
         """uint8 [B, n_tiles]: what the last SH degree-3 batch's polynomial forward decided per tile -- 1 = a quarter of a staged

@@ -120,9 +120,44 @@ __device__ __forceinline__ GRec load_rec(const Stage<MODE, CB, KB, WC> &S, int g
 template <int NCH>
 __device__ __forceinline__ void poison_pixel(const CompParams &p, size_t pix) {
   const float nan = __builtin_nanf("");
+  if (NCH == 6 && p.pl_rgb != nullptr) {  // (the heads as separate images: gsgen_rgbd_view::out_rgb ...)
+    p.pl_rgb[3 * pix] = nan; p.pl_rgb[3 * pix + 1] = nan; p.pl_rgb[3 * pix + 2] = nan;
+    p.pl_d[pix] = nan; p.pl_o[pix] = nan; p.pl_z[pix] = nan;
+  } else {
 #pragma unroll
-  for (int c = 0; c < NCH; ++c) p.out[NCH * pix + c] = nan;
+    for (int c = 0; c < NCH; ++c) p.out[NCH * pix + c] = nan;
+  }
   if (p.T != nullptr) p.T[pix] = nan;
+}
+// RGB + heads: the epilogue of a pixel of the batched forward -- the background behind what is left of the transmittance
+// (gs/renderer.py:1182: out + T * bg, product rounded before the sum as torch forms it) and, where the caller asks for it, the depth
+// variance in place of the second moment (gs/gaussian_splatting.py:1397: z_var = depth2 - depth * depth)
+__device__ __forceinline__ void heads_epilogue(const CompParams &p, float (&e)[6], float T) {
+#pragma clang fp contract(off)
+  if (p.bg != nullptr) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float tb = T * p.bg[c];
+      e[c] = e[c] + tb;
+    }
+  }
+  if (p.zvar) {
+    const float dd = e[3] * e[3];
+    e[5] = e[5] - dd;
+  }
+}
+// one pixel's channels to the image(s): [H,W,NCH] interleaved, or -- RGB + heads with separate images -- rgb [H,W,3] + three [H,W]
+template <int MODE, int NCH>
+__device__ __forceinline__ void store_heads(const CompParams &p, size_t pix, const float (&e)[NCH]) {
+  if constexpr (MODE == MODE_RGBD) {
+    if (p.pl_rgb != nullptr) {  // (uniform over the launch)
+      p.pl_rgb[3 * pix] = e[0]; p.pl_rgb[3 * pix + 1] = e[1]; p.pl_rgb[3 * pix + 2] = e[2];
+      p.pl_d[pix] = e[3]; p.pl_o[pix] = e[4]; p.pl_z[pix] = e[5];
+      return;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) p.out[NCH * pix + c] = e[c];
 }
 // The parameter blocks of a batched launch travel in the kernel arguments themselves (<= kPackMax views per launch; larger
 // batches are launched in chunks): no table in device memory, no launch that writes one (until round 4 a one-workgroup
@@ -1721,8 +1756,10 @@ k_composite_fwd_chan_vec(CompParams p_arg, ViewPack<BATCH> pack) {
         const int gyj = ty * kTile + ly0 + j * ROWS;
         if (gx < p.W && gyj < p.H) {
           const size_t pix = (size_t)gyj * p.W + gx;
+          float e[NCH];
 #pragma unroll
-          for (int c = 0; c < NCH; ++c) p.out[NCH * pix + c] = 0.0f;
+          for (int c = 0; c < NCH; ++c) e[c] = (MODE == MODE_RGBD && c < 3 && p.bg != nullptr) ? p.bg[c] : 0.0f;  // (T = 1: the background)
+          store_heads<MODE, NCH>(p, pix, e);
           if (p.T != nullptr) p.T[pix] = 1.0f;
         }
       }
@@ -1825,8 +1862,11 @@ k_composite_fwd_chan_vec(CompParams p_arg, ViewPack<BATCH> pack) {
     // reals, to fp32 rounding here (<= 2e-7 of the oracle's sum, tests/test_gpu_parity.py) -- one accumulator pair per pixel pair
     // and two packed FMAs per entry less
     if constexpr (MODE == MODE_RGBD) acc2[j >> 1][4][j & 1] = 1.0f - Tr2[j >> 1][j & 1];
+    float e[NCH];
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) p.out[NCH * pix + c] = acc2[j >> 1][c][j & 1];
+    for (int c = 0; c < NCH; ++c) e[c] = acc2[j >> 1][c][j & 1];
+    if constexpr (MODE == MODE_RGBD) heads_epilogue(p, e, Tr2[j >> 1][j & 1]);
+    store_heads<MODE, NCH>(p, pix, e);
     if (p.T != nullptr) p.T[pix] = Tr2[j >> 1][j & 1];
   }
 }
@@ -1880,30 +1920,79 @@ k_composite_bwd_chan_vec(CompParams p_arg, ViewPack<BATCH> pack) {
   const int tile = ty * p.ntw + tx;
   const int st = p.start[tile];
   const int n = (st < 0) ? 0 : (p.end[tile] - st);
-  if (n == 0 || n < p.n_lo || n >= p.n_hi) return;
   const int t = (int)threadIdx.x;
   const int lane = t & 63;
   const int lx = t & 15, ly0 = t >> 4;
   const int gx = tx * kTile + lx;
+  if (n == 0 || n < p.n_lo || n >= p.n_hi) {
+    if constexpr (MODE == MODE_RGBD) {
+      // an EMPTY tile still shows the background (T = 1): its pixels' share of d L / d bg (gs/renderer.py:1283)
+      if (st == -1 && p.g_bg != nullptr && p.T != nullptr && p.go_rgb != nullptr) {
+        float sb[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int gy = ty * kTile + ly0 + j * 4;
+          if (gx < p.W && gy < p.H) {
+            const size_t pix = (size_t)gy * p.W + gx;
+            const float Tf = p.T[pix];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) sb[c] += nan_to_num_f(p.go_rgb[3 * pix + c] * Tf);
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float tot = wave_sum(sb[c]);
+          if (lane == 0) atomicAdd(p.g_bg + 4 * (tile & 63) + c, tot);
+        }
+      }
+    }
+    return;
+  }
   const float px = pixel_coord(p.topleft[0], gx, p.psx);
 
   // R2 = sum_c grad_out_c * (final_c - prefix_c): the grad_out-weighted suffix colour behind the current splat
   v2f py2[NP], go2[NP][NCH], R2[NP], Tr2[NP];
+  float bgs[3] = {0.0f, 0.0f, 0.0f};
+  (void)bgs;
 #pragma unroll
   for (int j = 0; j < PPL; ++j) {
     const int gy = ty * kTile + ly0 + j * ROWS;
     const bool valid = (gx < p.W) && (gy < p.H);
     py2[j >> 1][j & 1] = pixel_coord(p.topleft[1], gy, p.psy);
     const size_t pix = valid ? ((size_t)gy * p.W + gx) : 0;
-    float r = 0.0f;
+    float r = 0.0f, gq[NCH], fin[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-      const float g = valid ? load_grad_out<MODE, NCH>(p, pix, c) : 0.0f;
-      go2[j >> 1][c][j & 1] = g;
-      r = fmaf(g, valid ? p.final_img[NCH * pix + c] : 0.0f, r);  // prefix = 0 in front of the list
+      gq[c] = valid ? load_grad_out<MODE, NCH>(p, pix, c) : 0.0f;
+      fin[c] = valid ? load_final<MODE, NCH>(p, pix, c) : 0.0f;
+    }
+    if constexpr (MODE == MODE_RGBD) {
+      if (p.g_bg != nullptr && p.T != nullptr) {  // d L / d bg = sum nan_to_num(grad_rgb * T) (gs/renderer.py:1283), T the forward's
+        const float Tf = valid ? p.T[pix] : 0.0f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) bgs[c] += nan_to_num_f(gq[c] * Tf);
+      }
+      if (p.zvar) {  // the sixth head is z_var = depth2 - D^2, D the composited depth: d depth2 = g, d D -= 2 D g; final depth2 = z_var + D^2
+        gq[3] = fmaf(-2.0f * fin[3], gq[5], gq[3]);
+        fin[5] = fmaf(fin[3], fin[3], fin[5]);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      go2[j >> 1][c][j & 1] = gq[c];
+      r = fmaf(gq[c], fin[c], r);  // prefix = 0 in front of the list
     }
     R2[j >> 1][j & 1] = r;
     Tr2[j >> 1][j & 1] = valid ? 1.0f : -1.0f;  // alive = (T >= thresh); pixels outside never are
+  }
+  if constexpr (MODE == MODE_RGBD) {
+    if (p.g_bg != nullptr && p.T != nullptr) {  // the tile's sums into slot (tile % 64): 64 addresses per view share the atomics
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float tot = wave_sum(bgs[c]);
+        if (lane == 0) atomicAdd(p.g_bg + 4 * (tile & 63) + c, tot);
+      }
+    }
   }
   auto alive = [&](int j) { return !(Tr2[j >> 1][j & 1] < p.thresh); };
 
@@ -2840,7 +2929,12 @@ static int fill_rgbd_params(uint32_t n_views, const gsgen_rgbd_view *views, cons
   ps.assign(n_views, CompParams{});
   for (uint32_t b = 0; b < n_views; ++b) {
     const gsgen_rgbd_view &v = views[b];
-    if (!v.start || !v.end || !v.out6 || (heads && !v.depth)) return GSGEN_EINVAL;
+    const bool planes = heads && v.out_rgb != nullptr;
+    if (heads && ((v.out_rgb != nullptr) != (v.out_depth != nullptr) || (v.out_rgb != nullptr) != (v.out_opacity != nullptr) ||
+                  (v.out_rgb != nullptr) != (v.out_depth2 != nullptr)))
+      return GSGEN_EINVAL;  // the four separate images: all or none
+    if (!v.start || !v.end || (!v.out6 && !planes) || (heads && !v.depth)) return GSGEN_EINVAL;
+    if (planes && backward && v.grad_out6 != nullptr) return GSGEN_EINVAL;  // separate images go with the four-image gradient form
     if ((v.tile_order == nullptr) != (views[0].tile_order == nullptr)) return GSGEN_EINVAL;
     if (backward && (!v.grad_mean || !v.grad_cov || (heads && !v.grad_chan6))) return GSGEN_EINVAL;
     if (backward && !v.grad_out6 && !heads) return GSGEN_EINVAL;  // the split form exists for the heads only
@@ -2857,9 +2951,14 @@ static int fill_rgbd_params(uint32_t n_views, const gsgen_rgbd_view *views, cons
         p.go_rgb = v.grad_rgb; p.go_d = v.grad_depth; p.go_o = v.grad_opacity; p.go_z2 = v.grad_depth2;
       }
       p.g_mean = v.grad_mean; p.g_cov = v.grad_cov; p.g_col = heads ? v.grad_chan6 : g_color; p.g_alpha = g_alpha;
+      if (heads) { p.T = v.T; p.g_bg = v.grad_bg; }  // (T: read by the background gradient only)
     } else {
       p.out = v.out6; p.T = v.T;
       p.fill_empty = 1;  // the batched forward writes every pixel of out6 / T (include/gsgen_hip.h)
+    }
+    if (heads) {
+      p.pl_rgb = v.out_rgb; p.pl_d = v.out_depth; p.pl_o = v.out_opacity; p.pl_z = v.out_depth2;
+      p.bg = v.bg_rgb; p.zvar = v.depth_variance ? 1 : 0;
     }
   }
   return 0;

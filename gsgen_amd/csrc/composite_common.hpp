@@ -52,6 +52,14 @@ struct CompParams {
   // need not pre-initialise [B,H,W,NCH] + [B,H,W] every step (the reference's contract -- "out zeroed, T set to 1 by the
   // caller", vol_render.h:1006-1013 -- stays that of the per-camera `_gs` entry points)
   int fill_empty;
+  // RGB + heads, batched launches (round 6; gsgen_rgbd_view's optional fields): the four heads as separate contiguous images
+  // (pl_rgb [H,W,3], pl_d / pl_o / pl_z [H,W]; the forward writes them instead of out, the backward reads them as the final image),
+  // the background composited in the forward's epilogue (bg: rgb + T bg, gs/renderer.py:1182), its gradient summed by the
+  // backward's prologue into 64 slots of g_bg ([64][4], slot = tile % 64: sum nan_to_num(grad_rgb T), gs/renderer.py:1283), and the
+  // sixth head delivered as z_var = depth2 - depth^2 (gs/gaussian_splatting.py:1397) with grad_depth2 read as d L / d z_var.
+  float *pl_rgb, *pl_d, *pl_o, *pl_z;
+  float *g_bg;
+  int zvar;
 };
 constexpr int kSegLen = 32;
 
@@ -187,6 +195,23 @@ __device__ __forceinline__ float load_grad_out(const CompParams &p, size_t pix, 
     }
   }
   return p.grad_out[NCH * pix + c];
+}
+
+// the forward's image at pix, channel c: [H,W,NCH], or (RGB + heads with separate images) rgb [H,W,3] + three [H,W]
+template <int MODE, int NCH>
+__device__ __forceinline__ float load_final(const CompParams &p, size_t pix, int c) {
+  if constexpr (MODE == MODE_RGBD) {
+    if (p.pl_rgb != nullptr) {  // uniform over the launch
+      if (c < 3) return p.pl_rgb[3 * pix + c];
+      return (c == 3 ? p.pl_d : (c == 4 ? p.pl_o : p.pl_z))[pix];
+    }
+  }
+  return p.final_img[NCH * pix + c];
+}
+// torch.nan_to_num with its defaults: NaN -> 0, +-inf -> +-FLT_MAX
+__device__ __forceinline__ float nan_to_num_f(float v) {
+  if (!(v == v)) return 0.0f;
+  return fminf(fmaxf(v, -3.402823466e+38f), 3.402823466e+38f);
 }
 
 // the NCOL per-Gaussian channel values of the non-SH modes

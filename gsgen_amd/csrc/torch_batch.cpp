@@ -106,37 +106,69 @@ Tensor bg_grad(const Tensor &g_rgb, const Tensor &T, const Tensor &bg) {
 }
 
 // ---- rgb + depth + opacity + depth^2 (the trainer's default outputs) ---------------------------------------------------
+// Round 6: the four heads are SEPARATE contiguous images (gsgen_rgbd_view::out_rgb ...: coalesced stores in the kernel, vectorised
+// torch kernels for whatever the caller does with them -- [B,H,W,6] slices ran torch's strided loops at half speed), the
+// background is composited by the forward's epilogue and its gradient summed by the backward's prologue (no T * bg / add_ / mul /
+// nan_to_num / sum launches), and with z_var = true the sixth head is the depth variance the reference's model returns
+// (gs/gaussian_splatting.py:1397) with its chain rule inside the backward launch (no mul / sub forward, no four-kernel backward).
+const float *bg_pointer(const Tensor &bg, int64_t B, int64_t i, Tensor &keep) {
+  if (!bg.defined()) return nullptr;
+  if (bg.numel() == 3 && bg.is_contiguous()) return bg.data_ptr<float>();
+  if (bg.numel() == 3 * B && bg.is_contiguous()) return bg.data_ptr<float>() + 3 * i;
+  if (bg.dim() >= 1 && bg.size(-1) == 3 && bg.stride(-1) == 1 && bg.storage().nbytes() >= 12 && bg.numel() == 3 * B) {
+    bool expanded = true;  // one colour expanded over the batch: every other stride 0 or over a dimension of size 1
+    for (int64_t d = 0; d + 1 < bg.dim(); ++d) expanded = expanded && (bg.size(d) == 1 || bg.stride(d) == 0);
+    if (expanded) return bg.data_ptr<float>();
+  }
+  if (!keep.defined()) keep = bg.expand({B, 1, 1, 3}).contiguous();
+  return keep.data_ptr<float>() + 3 * i;
+}
+
 struct HeadsFn : public torch::autograd::Function<HeadsFn> {
   static variable_list forward(AutogradContext *ctx, Tensor mean, Tensor qvec, Tensor svec, Tensor alpha, Tensor color,
                                OptT bg_, int64_t plan_addr, double thresh, bool detach_depth, OptT max_radii2d_,
-                               OptT grad_accum_, OptT cnt_) {
+                               OptT grad_accum_, OptT cnt_, bool z_var) {
     const Plan &p = *reinterpret_cast<const Plan *>(plan_addr);
     const Tensor bg = opt(bg_), max_radii2d = opt(max_radii2d_), grad_accum = opt(grad_accum_), cnt = opt(cnt_);
     check_param(mean, "mean", p.N, 3, mean); check_param(qvec, "qvec", p.N, 4, mean); check_param(svec, "svec", p.N, 3, mean);
     check_param(alpha, "alpha", p.N, 1, mean); check_param(color, "color", p.N, 3, mean);
     check_stats(max_radii2d, "max_radii2d", p.N, mean); check_stats(grad_accum, "grad_accum", p.N, mean); check_stats(cnt, "cnt", p.N, mean);
     TORCH_CHECK(p.kind == kRgbd && p.gch.defined(), "plan / call mismatch");
+    TORCH_CHECK(!bg.defined() || (bg.is_cuda() && bg.scalar_type() == at::kFloat && bg.device() == mean.device()),
+                "gsgen_amd: bg_rgb must be a float32 tensor on ", mean.device());
     mean = mean.contiguous(); qvec = qvec.contiguous(); svec = svec.contiguous();
     alpha = alpha.contiguous(); color = color.contiguous();
     c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(mean.device());
     const gsgen_stream_t s = current_stream(mean);
     const int64_t B = p.B, H = p.H, W = p.W, N = p.N;
-    Tensor out6 = at::empty({B, H, W, 6}, mean.options());
+    Tensor rgb = at::empty({B, H, W, 3}, mean.options()), dep = at::empty({B, H, W, 1}, mean.options());
+    Tensor opa = at::empty({B, H, W, 1}, mean.options()), zz = at::empty({B, H, W, 1}, mean.options());
     Tensor T = at::empty({B, H, W, 1}, mean.options());
-    Tensor gsh = at::empty({p.Np}, mean.options());  // d L / d alpha, shared by the views: zeroed by the projection launch
+    // d L / d alpha [Np], shared by the views | d L / d bg, 64 partial rows of 4 floats per view: zeroed by the projection launch
+    const bool bg_grad_wanted = bg.defined() && bg.requires_grad();
+    Tensor gsh = at::empty({p.Np + (bg_grad_wanted ? 256 * B : 0)}, mean.options());
     gsgen_rgbd_view *v = tab<gsgen_rgbd_view>(p.views);
-    float *o = out6.data_ptr<float>(), *t = T.data_ptr<float>();
-    for (int64_t i = 0; i < B; ++i) { v[i].out6 = o + 6 * H * W * i; v[i].T = t + H * W * i; }
+    Tensor bg_keep;
+    for (int64_t i = 0; i < B; ++i) {
+      v[i].out6 = nullptr;
+      v[i].out_rgb = rgb.data_ptr<float>() + 3 * H * W * i;
+      v[i].out_depth = dep.data_ptr<float>() + H * W * i;
+      v[i].out_opacity = opa.data_ptr<float>() + H * W * i;
+      v[i].out_depth2 = zz.data_ptr<float>() + H * W * i;
+      v[i].T = T.data_ptr<float>() + H * W * i;
+      v[i].bg_rgb = bg_pointer(bg, B, i, bg_keep);
+      v[i].grad_bg = bg_grad_wanted ? gsh.data_ptr<float>() + p.Np + 256 * i : nullptr;
+      v[i].depth_variance = z_var ? 1u : 0u;
+    }
     GS(gsgen_frame_geometry_batch_zero((uint32_t)B, tab<gsgen_geometry_view>(p.geo), (uint32_t)N, mean.data_ptr<float>(),
                                        qvec.data_ptr<float>(), svec.data_ptr<float>(), (uint32_t)W, (uint32_t)H,
-                                       gsh.data_ptr<float>(), (size_t)p.Np, tab<void>(p.gws), s));
+                                       gsh.data_ptr<float>(), (size_t)gsh.numel(), tab<void>(p.gws), s));
     if (max_radii2d.defined())
       GS(gsgen_densify_update_batch((uint32_t)B, (uint32_t)N, tab<const float *const>(p.cov2d_tab), nullptr,
                                     tab<const uint8_t *const>(p.mask_tab), max_radii2d.data_ptr<float>(), nullptr, nullptr, s));
     GS(gsgen_vol_render_rgbd_batch((uint32_t)B, v, (uint32_t)N, color.data_ptr<float>(), alpha.data_ptr<float>(), 16,
                                    (uint32_t)p.nth, (uint32_t)p.ntw, (uint32_t)H, (uint32_t)W, (float)thresh, tab<void>(p.bws), s));
-    if (bg.defined()) out6.slice(-1, 0, 3).add_(T * bg);  // gs/renderer.py:1182
-    ctx->save_for_backward({mean, qvec, svec, alpha, color, out6, T, bg});
+    ctx->save_for_backward({mean, qvec, svec, alpha, color, rgb, dep, opa, zz, T, bg, bg_keep});
     ctx->saved_data["plan"] = plan_addr;
     ctx->saved_data["plan_ref"] = plan_ref(p);
     ctx->saved_data["gen"] = *tab<const int64_t>(p.generation);
@@ -145,8 +177,9 @@ struct HeadsFn : public torch::autograd::Function<HeadsFn> {
     ctx->saved_data["gsh"] = gsh;
     ctx->saved_data["grad_accum"] = grad_accum;
     ctx->saved_data["cnt"] = cnt;
+    ctx->saved_data["bg_grad"] = bg_grad_wanted;
     ctx->mark_non_differentiable({T});
-    return {out6.slice(-1, 0, 3), out6.slice(-1, 3, 4), out6.slice(-1, 4, 5), out6.slice(-1, 5, 6), T};
+    return {rgb, dep, opa, zz, T};
   }
 
   static variable_list backward(AutogradContext *ctx, variable_list g) {
@@ -154,17 +187,17 @@ struct HeadsFn : public torch::autograd::Function<HeadsFn> {
     const Plan &p = *reinterpret_cast<const Plan *>(plan_addr);
     TORCH_CHECK(*tab<const int64_t>(p.generation) == ctx->saved_data["gen"].toInt(), kStale);
     auto saved = ctx->get_saved_variables();
-    const Tensor &mean = saved[0], &qvec = saved[1], &svec = saved[2], &alpha = saved[3], &color = saved[4], &T = saved[6],
-                 &bg = saved[7];
+    const Tensor &mean = saved[0], &qvec = saved[1], &svec = saved[2], &alpha = saved[3], &color = saved[4], &bg = saved[10];
     c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(mean.device());
     const gsgen_stream_t s = current_stream(mean);
     const int64_t B = p.B, H = p.H, W = p.W, N = p.N;
+    const bool bg_grad_wanted = ctx->saved_data["bg_grad"].toBool();
     Tensor parts[4];
     for (int k = 0; k < 4; ++k)
       if (g[k].defined()) parts[k] = g[k].contiguous();
     Tensor gsh = ctx->saved_data["gsh"].toTensor();
     if (ctx->saved_data.count("used")) {  // a second backward through the same graph (retain_graph): fresh accumulators
-      gsh = at::zeros({p.Np}, mean.options());
+      gsh = at::zeros({gsh.numel()}, mean.options());
       p.g2d.narrow(0, 0, B).zero_();
       p.gch.narrow(0, 0, B).zero_();
     }
@@ -181,6 +214,7 @@ struct HeadsFn : public torch::autograd::Function<HeadsFn> {
       v[i].grad_depth = pp[1] ? pp[1] + H * W * i : nullptr;
       v[i].grad_opacity = pp[2] ? pp[2] + H * W * i : nullptr;
       v[i].grad_depth2 = pp[3] ? pp[3] + H * W * i : nullptr;
+      v[i].grad_bg = bg_grad_wanted ? gsh.data_ptr<float>() + p.Np + 256 * i : nullptr;
     }
     // the moment form (round 6): ten components per (tile, Gaussian) cross the lanes instead of thirteen; the projection backward
     // expands the moments per (view, Gaussian) and leaves d L / d mean2d in the per-view blocks for the densify statistics below
@@ -201,8 +235,10 @@ struct HeadsFn : public torch::autograd::Function<HeadsFn> {
                                     cnt.defined() ? cnt.data_ptr<float>() : nullptr, s));
     }
     Tensor g_bg;
-    if (bg.defined() && ctx->needs_input_grad(5) && g[0].defined()) g_bg = bg_grad(g[0], T, bg);
-    return {g_mean, g_qvec, g_svec, gsh.narrow(0, 0, N), g_col, g_bg, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+    if (bg_grad_wanted && ctx->needs_input_grad(5) && g[0].defined())  // the 64 partial rows of every view -> [B,1,1,3] -> bg's shape
+      g_bg = gsh.narrow(0, p.Np, 256 * B).view({B, 64, 4}).slice(-1, 0, 3).sum(1).view({B, 1, 1, 3}).sum_to_size(bg.sizes());
+    return {g_mean, g_qvec, g_svec, gsh.narrow(0, 0, N), g_col, g_bg, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(),
+            Tensor()};
   }
 };
 
@@ -363,9 +399,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def("address", [](const Plan &p) { return (int64_t) reinterpret_cast<uintptr_t>(&p); });
   m.def("render_heads", [](int64_t plan, Tensor mean, Tensor qvec, Tensor svec, Tensor alpha, Tensor color, c10::optional<Tensor> bg,
                            double thresh, bool detach_depth, c10::optional<Tensor> max_radii2d, c10::optional<Tensor> grad_accum,
-                           c10::optional<Tensor> cnt) {
-    return HeadsFn::apply(mean, qvec, svec, alpha, color, bg, plan, thresh, detach_depth, max_radii2d, grad_accum, cnt);
-  }, "-> [rgb, depth, opacity, depth2, T]");
+                           c10::optional<Tensor> cnt, bool z_var) {
+    return HeadsFn::apply(mean, qvec, svec, alpha, color, bg, plan, thresh, detach_depth, max_radii2d, grad_accum, cnt, z_var);
+  }, "-> [rgb, depth, opacity, depth2 | z_var, T]");
   m.def("render", [](int64_t plan, Tensor mean, Tensor qvec, Tensor svec, Tensor alpha, Tensor col, c10::optional<Tensor> bg, int64_t C,
                      double thresh, bool detach_depth, c10::optional<Tensor> sh_bound, c10::optional<Tensor> sh_rows,
                      c10::optional<Tensor> max_radii2d, c10::optional<Tensor> grad_accum, c10::optional<Tensor> cnt) {

@@ -279,10 +279,11 @@ class GaussianSplattingRenderer(nn.Module):
             rgb, _ = br.render(self.mean, self.qvec, self.svec, self.alpha, color, cis, c2ws, C=0, bg_rgb=bg, thresh=self.T_thresh,
                                frustum_radius=fr, tile_radius=self.tile_culling_radius, detach_depth=self.depth_detach, stats=stats)
             return {"rgb": rgb}
-        rgb, depth, opacity, z2, _ = br.render_heads(self.mean, self.qvec, self.svec, self.alpha, color, cis, c2ws, bg_rgb=bg,
-                                                     thresh=self.T_thresh, frustum_radius=fr, tile_radius=self.tile_culling_radius,
-                                                     detach_depth=self.depth_detach, stats=stats)
-        return {"rgb": rgb, "depth": depth, "opacity": opacity, "z_var": z2 - depth * depth}  # :1397
+        # (z_var = depth2 - depth^2, :1397, and the background, gs/renderer.py:1182, are formed inside the launches: round 6)
+        rgb, depth, opacity, z_var, _ = br.render_heads(self.mean, self.qvec, self.svec, self.alpha, color, cis, c2ws, bg_rgb=bg,
+                                                        thresh=self.T_thresh, frustum_radius=fr, tile_radius=self.tile_culling_radius,
+                                                        detach_depth=self.depth_detach, stats=stats, z_var=True)
+        return {"rgb": rgb, "depth": depth, "opacity": opacity, "z_var": z_var}
 
     def render_one(self, c2w, camera_info, use_bg=True, rgb_only=False, overrides=None, return_T=False):
         """gs/gaussian_splatting.py:1198-1421 for one camera (the viewer's and the evaluation loop's call): -> the same dict

@@ -610,6 +610,21 @@ typedef struct gsgen_rgbd_view {
   /* backward of the heads with grad_out6 == NULL: d L / d rgb [H,W,3], / d depth, / d opacity, / d depth^2 [H,W] as an
    * autograd engine delivers them (one tensor per output; any may be NULL = zero) -- no [H,W,6] image to assemble */
   const float *grad_rgb, *grad_depth, *grad_opacity, *grad_depth2;
+  /* Round 6, optional (zero-initialised = the layout above), RGB + heads launches only -- what the reference's model computes in
+   * torch around its four compositing passes, folded into the two launches:
+   *   out_rgb [H,W,3], out_depth, out_opacity, out_depth2 [H,W]: the four heads as separate contiguous images instead of out6 (all
+   *     four or none; out6 may then be NULL).  The backward reads them as the forward's final image; grad_out6 must be NULL (the
+   *     four-image gradient form).
+   *   bg_rgb [3] (device): the forward writes rgb + T * bg (gs/renderer.py:1182; empty tiles show bg); the backward takes that sum
+   *     as the final image, as the reference's does.
+   *   grad_bg [64][4] (device, zeroed by the caller), backward: row (tile % 64) accumulates the tile's sum over pixels of
+   *     nan_to_num(grad_rgb * T) (gs/renderer.py:1283: d L / d bg), T the forward's; the caller adds the 64 rows.
+   *   depth_variance = 1: the sixth head is z_var = depth2 - depth^2 (gs/gaussian_splatting.py:1397) -- written so by the forward,
+   *     and grad_depth2 is d L / d z_var (the backward forms d depth2 = g and d depth -= 2 depth g itself). */
+  float *out_rgb, *out_depth, *out_opacity, *out_depth2;
+  const float *bg_rgb;
+  float *grad_bg;
+  uint32_t depth_variance;
 } gsgen_rgbd_view;
 /* The batched forwards (rgbd and rgb) write EVERY pixel of out6 / T, empty tiles included (channels 0, T = 1): the caller need
  * not pre-initialise the images (the per-camera entry points above keep the reference's contract: empty tiles are left alone). */

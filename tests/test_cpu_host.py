@@ -930,6 +930,95 @@ def test_emulated_rgb_heads_moment_form_equals_the_plain_backward(emu):
         emu.project_gaussians_backward_batch_heads_moments(*common, None, *[P(a) for a in out], None)
 
 
+def test_emulated_rgb_heads_separate_images_background_and_depth_variance(emu):
+    """Round 6, gsgen_rgbd_view's optional fields: the four heads as separate contiguous images, the background composited by the
+    forward (rgb + T bg, gs/renderer.py:1182; empty tiles show it) with its gradient summed by the backward
+    (sum nan_to_num(grad_rgb T), gs/renderer.py:1283, 64 partial rows per view), the sixth head as z_var = depth2 - depth^2
+    (gs/gaussian_splatting.py:1397) with its chain rule inside the backward -- against the interleaved launches + those torch
+    operations done by hand, in both backward forms."""
+    from gsgen_amd._capi import RgbdView
+    W, H = 100, 68
+    sc = scenes.random_scene(60, seed=5, svec=0.03)   # (sparse: empty tiles take part)
+    Nall = sc["mean"].shape[0]
+    col, al = np.ascontiguousarray(sc["color"]), np.ascontiguousarray(sc["alpha"])
+    cams = [scenes.Camera(W, H, fx=90.0, c2w=scenes.look_at(e)) for e in ((2.5, 0, 0), (0.3, 2.4, 0.6))]
+    B = len(cams)
+    nth, ntw = cams[0].tiles
+    rng = np.random.default_rng(11)
+    views = []
+    for i, cam in enumerate(cams):
+        g = scenes.oracle_geometry(sc, cam)
+        nz = np.nonzero(g["mask"])[0]
+        m2 = np.zeros((Nall, 2), np.float32); c2 = np.zeros((Nall, 2, 2), np.float32); dv = np.zeros(Nall, np.float32)
+        c2[:] = np.eye(2, dtype=np.float32)
+        m2[nz] = g["mean2d"]; c2[nz] = g["cov2d"]; dv[nz] = g["depth"].ravel()
+        assert (g["start"] < 0).any()
+        views.append(dict(m2=m2, c2=c2, dv=dv, st=g["start"], en=g["end"], ids=nz[g["ids"]].astype(np.int32), tlp=cam.topleft, cam=cam,
+                          bg=rng.uniform(0.1, 0.9, 3).astype(np.float32),
+                          g=[rng.normal(size=(H, W, 3)).astype(np.float32)] + [rng.normal(size=(H, W)).astype(np.float32) for _ in range(3)]))
+    arr = (RgbdView * B)()
+    bws = np.zeros(emu.sh_batch_workspace_bytes(B), np.uint8)
+    for a, v in zip(arr, views):
+        cam = v["cam"]
+        a.mean, a.cov, a.depth, a.start, a.end, a.gaussian_ids = P(v["m2"]), P(v["c2"]), P(v["dv"]), P(v["st"]), P(v["en"]), P(v["ids"])
+        a.tile_order, a.topleft, a.pixel_size_x, a.pixel_size_y = None, P(v["tlp"]), 1 / cam.fx, 1 / cam.fy
+        v["out6"] = np.zeros((H, W, 6), np.float32); v["T"] = np.zeros((H, W), np.float32)
+        a.out6, a.T = P(v["out6"]), P(v["T"])
+    emu.vol_render_rgbd_batch(B, arr, Nall, P(col), P(al), 16, nth, ntw, H, W, 1e-4, P(bws), None)
+    # the new form: separate images, background, depth variance
+    for a, v in zip(arr, views):
+        v["rgb"] = np.full((H, W, 3), 7.0, np.float32)
+        v["d"], v["o"], v["z"], v["T2"] = (np.full((H, W), 7.0, np.float32) for _ in range(4))
+        a.out6, a.T = None, P(v["T2"])
+        a.out_rgb, a.out_depth, a.out_opacity, a.out_depth2 = P(v["rgb"]), P(v["d"]), P(v["o"]), P(v["z"])
+        a.bg_rgb, a.depth_variance = P(v["bg"]), 1
+    emu.vol_render_rgbd_batch(B, arr, Nall, P(col), P(al), 16, nth, ntw, H, W, 1e-4, P(bws), None)
+    for v in views:
+        o6, T = v["out6"], v["T"]
+        assert np.array_equal(v["T2"], T)
+        want_rgb = o6[..., :3] + T[..., None] * v["bg"]
+        assert np.array_equal(v["rgb"], want_rgb.astype(np.float32))
+        assert np.array_equal(v["d"], o6[..., 3]) and np.array_equal(v["o"], o6[..., 4])
+        assert np.array_equal(v["z"], (o6[..., 5] - o6[..., 3] * o6[..., 3]).astype(np.float32))
+        assert (T == 1.0).any()  # empty tiles: the background
+    with pytest.raises(Exception, match="invalid"):
+        arr[1].out_depth = None
+        emu.vol_render_rgbd_batch(B, arr, Nall, P(col), P(al), 16, nth, ntw, H, W, 1e-4, P(bws), None)
+    arr[1].out_depth = P(views[1]["d"])
+    for moments in (False, True):
+        bwd = emu.vol_render_rgbd_backward_batch_moments if moments else emu.vol_render_rgbd_backward_batch
+        res = {}
+        for form in ("by hand", "in the launch"):
+            for a, v in zip(arr, views):
+                v["gm"] = np.zeros((Nall, 2), np.float32); v["gc"] = np.zeros((Nall, 4), np.float32); v["gch"] = np.zeros((Nall, 6), np.float32)
+                a.grad_mean, a.grad_cov, a.grad_chan6, a.grad_out6 = P(v["gm"]), P(v["gc"]), P(v["gch"]), None
+                g_rgb, g_d, g_o, g_zv = v["g"]
+                if form == "by hand":  # the interleaved final image with the background in it; z_var's chain rule by hand
+                    v["fin6"] = v["out6"].copy(); v["fin6"][..., :3] = v["rgb"]
+                    v["gd_eff"] = (g_d - 2.0 * v["out6"][..., 3] * g_zv).astype(np.float32)
+                    a.out6, a.out_rgb, a.out_depth, a.out_opacity, a.out_depth2 = P(v["fin6"]), None, None, None, None
+                    a.bg_rgb, a.grad_bg, a.depth_variance = None, None, 0
+                    a.grad_rgb, a.grad_depth, a.grad_opacity, a.grad_depth2 = P(g_rgb), P(v["gd_eff"]), P(g_o), P(g_zv)
+                else:
+                    v["gbg"] = np.zeros((64, 4), np.float32)
+                    a.out6, a.T = None, P(v["T2"])
+                    a.out_rgb, a.out_depth, a.out_opacity, a.out_depth2 = P(v["rgb"]), P(v["d"]), P(v["o"]), P(v["z"])
+                    a.bg_rgb, a.grad_bg, a.depth_variance = P(v["bg"]), P(v["gbg"]), 1
+                    a.grad_rgb, a.grad_depth, a.grad_opacity, a.grad_depth2 = P(g_rgb), P(g_d), P(g_o), P(g_zv)
+            ga = np.zeros(Nall, np.float32)
+            bwd(B, arr, Nall, P(col), P(al), P(ga), 16, nth, ntw, H, W, 1e-4, P(bws), None)
+            res[form] = (ga, [(v["gm"].copy(), v["gc"].copy(), v["gch"].copy()) for v in views])
+        a_, b_ = res["by hand"], res["in the launch"]
+        assert np.abs(a_[0]).max() > 0 and np.abs(a_[0] - b_[0]).max() <= 2e-6 * np.abs(a_[0]).max()
+        for x3, y3 in zip(a_[1], b_[1]):
+            for x, y in zip(x3, y3):
+                assert np.abs(x).max() > 0 and np.abs(x - y).max() <= 2e-6 * np.abs(x).max()
+        for v in views:
+            want = (v["g"][0].astype(np.float64) * v["T"][..., None]).sum((0, 1))
+            got = v["gbg"][:, :3].astype(np.float64).sum(0)
+            assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max() and not v["gbg"][:, 3].any()
+
+
 def test_emulated_batched_rgb_matches_per_view_launches(emu):
     """gsgen_vol_render_rgb_batch / _backward_batch (post-activation colours, no heads) == one
     gsgen_vol_render_start_end_with_T / gsgen_vol_render_backward_start_end call per view, colour and opacity
