@@ -425,6 +425,9 @@ def main():
                          "is measured the same way afterwards and reported in the same line.  heads: the timed region IS the "
                          "RGB + heads step (profiling: with --only-timed a kernel trace holds exactly its launches)")
     ap.add_argument("--no-heads", action="store_true", help="skip the RGB + heads pass")
+    ap.add_argument("--no-heads-chol", action="store_true",
+                    help="RGB + heads: stage the records with the fp64 preparation per staged (tile, Gaussian) record (rounds 1-5) instead of "
+                         "reading what the projection launch prepared per (view, Gaussian) (gsgen_geometry_view::chol, round 6): same-box A/Bs")
     ap.add_argument("--sh-grad-form", choices=["moments", "plain"], default="moments",
                     help="SH backward: the moment form BatchRenderer.render runs (round 6) or the plain one, for same-box A/Bs")
     ap.add_argument("--heads-grad-form", choices=["moments", "plain"], default="moments",
@@ -556,6 +559,7 @@ def main():
     fused_fill = not args.torch_fill           # gradient accumulators zeroed inside the projection launch
     heads_moments = args.heads_grad_form == "moments"
     sh_moments = args.sh_grad_form == "moments"
+    heads_chol = not args.no_heads_chol
     want_heads = (args.path == "heads" or not args.no_heads) and "color" in sc and not dry
     if want_heads:
         t["color"] = torch.tensor(sc["color"], device=dev)
@@ -595,6 +599,7 @@ def main():
                     self.out6 = torch.empty(B, H, W, 6, device=dev)
                     self.T6 = torch.empty(B, H, W, device=dev)
                     self.hflat = torch.empty(B * 12 * Np + Np, device=dev)
+                    self.chol = torch.empty(B, Np, 4, device=dev)
                     self.h_color = torch.empty(N * 3, device=dev)
             # the images of a step are complete after its forward: they are gathered on the communication stream while
             # the step's backward runs; the slot's next forward waits for that gather before it overwrites `out`
@@ -664,12 +669,14 @@ def main():
                     v.grad_mean = g0 + 4 * 12 * Np * i
                     v.grad_cov = v.grad_mean + 4 * 2 * Np
                     v.grad_chan6 = v.grad_mean + 4 * 6 * Np
+                    if heads_chol:  # the evaluation records prepared by the projection launch (gsgen_geometry_view::chol, round 6)
+                        geo[i].chol = v.chol = p(self.chol[i])
                 blk = [g0 + 4 * 12 * Np * i for i in range(B)]
                 proj = (vtab([p(cam_dev[(k0 + i) % ncam]) for i in range(B)]), 1, vtab([p(b_.mask) for b_ in self.bufs]),
                         vtab(blk), vtab([a + 4 * 2 * Np for a in blk]), vtab([a + 4 * 6 * Np for a in blk]),
                         vtab([p(b_.depth) for b_ in self.bufs]))
-                if heads_moments:  # + the views' cov2d: the projection backward expands the moments (include/gsgen_hip.h)
-                    proj = proj + (vtab([p(b_.cov2d) for b_ in self.bufs]),)
+                if heads_moments:  # + the views' cov2d (and prepared records): the projection backward expands the moments (include/gsgen_hip.h)
+                    proj = proj + (vtab([p(b_.cov2d) for b_ in self.bufs]), vtab([p(self.chol[i]) for i in range(B)]) if heads_chol else None)
                 self.htables[key] = (geo, views, proj)
             return self.htables[key]
 

@@ -300,8 +300,9 @@ class _render_batch_heads(torch.autograd.Function):
             lib.project_gaussians_backward_batch_heads_moments(B, N, _p(mean), _p(qvec), _p(svec), br._ptr_table("cam", B),
                                                                int(ctx.detach), br._mask_table(B), br._ptr_table("g_mean2d", B),
                                                                br._ptr_table("g_cov2d", B), br._ptr_table("g_chan6", B),
-                                                               br._ptr_table("depth", B), br._ptr_table("cov2d", B), _p(g_mean),
-                                                               _p(g_qvec), _p(g_svec), _p(g_col), s)
+                                                               br._ptr_table("depth", B), br._ptr_table("cov2d", B),
+                                                               br._ptr_table("chol", B), _p(g_mean), _p(g_qvec), _p(g_svec),
+                                                               _p(g_col), s)
             if stats is not None and stats.grad_accum is not None:
                 lib.densify_update_batch(B, N, None, br._ptr_table("g_mean2d", B), br._mask_table(B), None,
                                          _p(stats.grad_accum), _p(stats.cnt), s)
@@ -366,6 +367,7 @@ class BatchRenderer:
         self._gv_bytes = lib.frame_batch_workspace_bytes(1)
         self._g2d = torch.empty(max_batch, 6 * self._Np, device=device, dtype=torch.float32)
         self._gch = None
+        self._chols = None
         self._rows = torch.zeros(N, device=device, dtype=torch.float32)  # per-splat bounds of the batch in flight (gsgen_sh_l1_bound_rows)
         self._smax = torch.zeros(1, device=device, dtype=torch.float32)  # ... and their maximum (a scene within a view's bound skips the per-entry tests)
         # per camera: cam block (56) | topleft (2) | rotation rows (9) | pad -> 68 floats, packed on the host and sent
@@ -394,6 +396,12 @@ class BatchRenderer:
             self._table_cache.clear()
             self._plans.clear()
         return self._gch
+
+    def _chol(self, i):
+        """slot i's [N,4] prepared evaluation records (gsgen_geometry_view::chol; RGB and RGB + heads batches only)"""
+        if self._chols is None:
+            self._chols = torch.empty(len(self.slots), self._Np, 4, device=self.device, dtype=torch.float32)
+        return self._chols[i]
 
     def _upload(self, cam_infos, c2ws, frustum_radius, tile_radius):
         """The batch's camera blocks, packed by ONE library call (gsgen_pack_camera_blocks) and sent through kernel
@@ -437,6 +445,8 @@ class BatchRenderer:
                 a = [_p(self.slots[i].cov2d) for i in range(B)]
             elif kind == "depth":
                 a = [_p(self.slots[i].depth) for i in range(B)]
+            elif kind == "chol":
+                a = [_p(self._chol(i)) for i in range(B)]
             elif kind == "g_mean2d":
                 a = [g0 + st * i for i in range(B)]
             elif kind == "g_cov2d":
@@ -471,6 +481,8 @@ class BatchRenderer:
             g.gaussian_ids, g.start, g.end, g.total = _p(buf.ids), _p(buf.start), _p(buf.end), _p(buf.total)
             g.workspace, g.workspace_bytes, g.D_cap = _p(buf.ws), buf.ws.numel(), buf.D_cap
             g.pair_report = self._report.ptr(i)
+            if kind != "sh":  # the compositing kernels' evaluation records, prepared by the projection launch (include/gsgen_hip.h)
+                g.chol = v.chol = _p(self._chol(i))
             # this view's gradient accumulators: zero-filled by the projection launch, read by the projection backward
             g.zero_grad_mean2d = v.grad_mean = g0 + st * i
             g.zero_grad_cov2d = v.grad_cov = g0 + st * i + 4 * 2 * self._Np
@@ -507,12 +519,13 @@ class BatchRenderer:
                         self.segments, adr(geo), adr(views), adr(self._ptr_table("cam", B)), adr(self._mask_table(B)),
                         adr(self._ptr_table("g_mean2d", B)), adr(self._ptr_table("g_cov2d", B)),
                         adr(self._ptr_table("g_chan6", B)) if heads else 0, adr(self._ptr_table("depth", B)),
-                        adr(self._ptr_table("cov2d", B)), _p(self._gws), _p(self._bws[0]), self._gen.ctypes.data, self._g2d,
+                        adr(self._ptr_table("cov2d", B)), adr(self._ptr_table("chol", B)) if kind != "sh" else 0, _p(self._gws),
+                        _p(self._bws[0]), self._gen.ctypes.data, self._g2d,
                         self._chan6() if heads else None,
                         # what a pending backward of this plan needs alive even if the renderer is dropped first: the host tables,
                         # the generation cell, the slots' buffers as they are NOW (a regrowth replaces them and the plan), the
                         # workspaces -- not the renderer itself (it caches the plan: a cycle Python could not collect)
-                        [geo, views, dict(self._ptr_tabs), self._gen, self._cams, self._gws, self._bws[0], self._rows, self._smax,
+                        [geo, views, dict(self._ptr_tabs), self._gen, self._cams, self._gws, self._bws[0], self._rows, self._smax, self._chols,
                          [(b_.mean2d, b_.cov2d, b_.depth, b_.mask, b_.ids, b_.start, b_.end, b_.ws, b_.total, b_.seg_ws)
                           for b_ in self.slots[:B]]])
         va = np.ctypeslib.as_array(ctypes.cast(views, ctypes.POINTER(ctypes.c_uint8)), (ctypes.sizeof(views),)).view(np.dtype(views._type_))

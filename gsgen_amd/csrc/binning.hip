@@ -879,8 +879,9 @@ int gsgen_frame_geometry_batch_zero(uint32_t n_views, const gsgen_geometry_view 
     g.ctrl = w.ctrl; g.tile_order = w.tile_order; g.keys = w.keys;
     g.ids = v.gaussian_ids; g.start = v.start; g.end = v.end; g.total = v.total; g.cap = v.D_cap; g.report = v.pair_report;
     g.z_mean2d = v.zero_grad_mean2d; g.z_cov2d = v.zero_grad_cov2d; g.z_chan6 = v.zero_grad_chan6;
+    g.chol = v.chol;
     if ((reinterpret_cast<uintptr_t>(g.z_mean2d) & 7u) || (reinterpret_cast<uintptr_t>(g.z_cov2d) & 15u) ||
-        (reinterpret_cast<uintptr_t>(g.z_chan6) & 7u))
+        (reinterpret_cast<uintptr_t>(g.z_chan6) & 7u) || (reinterpret_cast<uintptr_t>(g.chol) & 15u))
       return GSGEN_EINVAL;
   }
   hipStream_t s = (hipStream_t)stream;

@@ -34,6 +34,30 @@ constexpr float kInvSc2 = 1.3862943611198906f;  // 1 / (0.5 log2 e) = 2 ln 2
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 
+// The evaluation record of an RGB / scalar / RGB + heads Gaussian: p = L * sqrt(0.5 log2 e), L L^T = Sigma^-1 (symmetrised), in fp64
+// from the fp32 cov2d, rounded to fp32; ok = false for a degenerate or non-finite covariance (such a record never contributes).
+// ONE function with contraction off for every translation unit that forms it -- the compositing kernels' staging (prep_record), the
+// projection launch that prepares it once per (view, Gaussian) for the batched launches (round 6: gsgen_geometry_view::chol), the
+// projection backward's moment expansion -- so that all of them hold the same bits.
+struct CholRec { float p0, p1, p2; bool ok; };
+__device__ __forceinline__ CholRec chol_prep(float c0, float c1, float c2, float c3) {
+#pragma clang fp contract(off)
+  const double d0 = c0, d1 = c1, d2 = c2, d3 = c3;
+  const double det = d0 * d3 - d1 * d2;
+  bool ok = (fabsf(c0) <= 3.402823466e+38f) && (fabsf(c1) <= 3.402823466e+38f) && (fabsf(c2) <= 3.402823466e+38f) &&
+            (fabsf(c3) <= 3.402823466e+38f) && (det > 0.0) && (d3 > 0.0);
+  const double sdet = ok ? det : 1.0, s3 = ok ? d3 : 1.0;
+  const double qa = s3 / sdet, qb = -0.5 * (d1 + d2) / sdet, qc = d0 / sdet;
+  const double l11 = sqrt(qa), l21 = qb / l11;
+  const double l22s = qc - l21 * l21;
+  ok = ok && (l22s > 0.0);
+  const double l22 = sqrt(ok ? l22s : 1.0);
+  const double sc = 0.84932180028801904;  // sqrt(0.5 log2 e)
+  CholRec r{0.0f, 0.0f, 0.0f, ok};
+  if (ok) { r.p0 = (float)(l11 * sc); r.p1 = (float)(l21 * sc); r.p2 = (float)(l22 * sc); }
+  return r;
+}
+
 // two packed fp32 values: arithmetic on v2f lowers to v_pk_mul / v_pk_add / v_pk_fma_f32
 typedef float v2f __attribute__((vector_size(8)));
 
@@ -472,6 +496,7 @@ struct GeoView {
   // optional per-view gradient accumulators of the step's backward ([N,2], [N,2,2], [N,6]; any may be NULL): zero-filled by
   // the projection launch, which touches every Gaussian of the view anyway (gsgen_frame_geometry_batch_zero)
   float *z_mean2d, *z_cov2d, *z_chan6;
+  float *chol;  // optional [N,4]: (p0, p1, p2, ok) of chol_prep per Gaussian of the view, for the batched RGB / RGB + heads compositing launches
 };
 
 }  // namespace gs

@@ -62,16 +62,27 @@ __device__ __forceinline__ void stage_batch(Stage<MODE, CB, KB, WITH_COL> &S, co
     int id = 0;
     float mx = 0.f, my = 0.f, a = 0.f, c0 = 1.f, c1 = 0.f, c2 = 0.f, c3 = 1.f, p0 = 0.f, p1 = 0.f,
           p2 = 0.f;
+    bool prepared = false;
+    if constexpr (MODE != MODE_SH) prepared = p.chol != nullptr;  // (uniform over the launch)
     if (t < nb) {
       id = p.ids[list_base + t];
       const float2 m = *reinterpret_cast<const float2 *>(p.mean + 2 * (size_t)id);
-      const float4 c = *reinterpret_cast<const float4 *>(p.cov + 4 * (size_t)id);
-      mx = m.x; my = m.y; c0 = c.x; c1 = c.y; c2 = c.z; c3 = c.w;
-      const GRec r = prep_record<MODE>(mx, my, c0, c1, c2, c3, p.alpha[id]);
-      a = r.a; p0 = r.p0; p1 = r.p1; p2 = r.p2;
+      mx = m.x; my = m.y;
+      if (prepared) {
+        // the record the projection launch prepared for this (view, Gaussian) (gsgen_geometry_view::chol): no fp64 chain here
+        const float4 q = *reinterpret_cast<const float4 *>(p.chol + 4 * (size_t)id);
+        const float al = fminf(p.alpha[id], kAlphaClamp);
+        const bool ok = q.w != 0.0f && finite_f(mx) && finite_f(my) && finite_f(al);
+        a = ok ? al : 0.0f; p0 = ok ? q.x : 0.0f; p1 = ok ? q.y : 0.0f; p2 = ok ? q.z : 0.0f;
+      } else {
+        const float4 c = *reinterpret_cast<const float4 *>(p.cov + 4 * (size_t)id);
+        c0 = c.x; c1 = c.y; c2 = c.z; c3 = c.w;
+        const GRec r = prep_record<MODE>(mx, my, c0, c1, c2, c3, p.alpha[id]);
+        a = r.a; p0 = r.p0; p1 = r.p1; p2 = r.p2;
+      }
     }
     S.id[t] = id; S.mx[t] = mx; S.my[t] = my; S.a[t] = a;
-    S.c0[t] = c0; S.c1[t] = c1; S.c2[t] = c2; S.c3[t] = c3;
+    if (!prepared) { S.c0[t] = c0; S.c1[t] = c1; S.c2[t] = c2; S.c3[t] = c3; }  // (prepared: the guard path reads cov from memory)
     S.p0[t] = p0; S.p1[t] = p1; S.p2[t] = p2;
   }
   if constexpr (MODE == MODE_SH) __syncthreads();  // S.id is consumed below by other lanes
@@ -102,6 +113,18 @@ __device__ __forceinline__ void stage_batch(Stage<MODE, CB, KB, WITH_COL> &S, co
   }
 }
 
+// the raw covariance of staged record g for the threshold guard's reference arithmetic: staged in LDS, or -- launches that stage the
+// projection's prepared records (CompParams::chol) -- from memory (a handful of pixels per frame take this path)
+template <int MODE, int CB, int KB, bool WC>
+__device__ __forceinline__ void guard_cov(const Stage<MODE, CB, KB, WC> &S, const CompParams &p, int g, float &c0, float &c1,
+                                          float &c2, float &c3) {
+  if (MODE != MODE_SH && p.chol != nullptr) {
+    const float4 c = *reinterpret_cast<const float4 *>(p.cov + 4 * (size_t)S.id[g]);
+    c0 = c.x; c1 = c.y; c2 = c.z; c3 = c.w;
+  } else {
+    c0 = S.c0[g]; c1 = S.c1[g]; c2 = S.c2[g]; c3 = S.c3[g];
+  }
+}
 // per-Gaussian values broadcast from LDS into registers
 template <int MODE, int CB, int KB, bool WC>
 __device__ __forceinline__ GRec load_rec(const Stage<MODE, CB, KB, WC> &S, int g) {
@@ -1813,7 +1836,8 @@ k_composite_fwd_chan_vec(CompParams p_arg, ViewPack<BATCH> pack) {
       }
       const bool any_guard = guard_dist <= kMinAlpha * kGuardTol;
       if (wave_any(any_guard)) {  // within rounding of the skip threshold: the reference's arithmetic decides
-        const float r_c0 = S.c0[g], r_c1 = S.c1[g], r_c2 = S.c2[g], r_c3 = S.c3[g];
+        float r_c0, r_c1, r_c2, r_c3;
+        guard_cov(S, p, g, r_c0, r_c1, r_c2, r_c3);
 #pragma unroll
         for (int jp = 0; jp < NP; ++jp)
 #pragma unroll
@@ -2046,7 +2070,8 @@ k_composite_bwd_chan_vec(CompParams p_arg, ViewPack<BATCH> pack) {
       }
       const bool any_guard = guard_dist <= kMinAlpha * kGuardTol;
       if (wave_any(any_guard)) {  // within rounding of the skip threshold: the reference's arithmetic decides
-        const float r_c0 = S.c0[g], r_c1 = S.c1[g], r_c2 = S.c2[g], r_c3 = S.c3[g];
+        float r_c0, r_c1, r_c2, r_c3;
+        guard_cov(S, p, g, r_c0, r_c1, r_c2, r_c3);
 #pragma unroll
         for (int jp = 0; jp < NP; ++jp)
 #pragma unroll
@@ -2960,6 +2985,7 @@ static int fill_rgbd_params(uint32_t n_views, const gsgen_rgbd_view *views, cons
       p.pl_rgb = v.out_rgb; p.pl_d = v.out_depth; p.pl_o = v.out_opacity; p.pl_z = v.out_depth2;
       p.bg = v.bg_rgb; p.zvar = v.depth_variance ? 1 : 0;
     }
+    p.chol = v.chol;
   }
   return 0;
 }

@@ -60,6 +60,10 @@ struct CompParams {
   float *pl_rgb, *pl_d, *pl_o, *pl_z;
   float *g_bg;
   int zvar;
+  // RGB / RGB + heads, batched launches: the view's prepared records [N,4] = (p0, p1, p2, ok) (gsgen_geometry_view::chol, written by
+  // the projection launch once per (view, Gaussian)) -- staging reads them instead of running chol_prep's fp64 chain per staged
+  // (tile, Gaussian) record in both kernels; the raw covariance is then fetched from `cov` only by the rare threshold guard.
+  const float *chol;
 };
 constexpr int kSegLen = 32;
 
@@ -257,17 +261,9 @@ __device__ __forceinline__ GRec prep_record(float mx, float my, float c0, float 
     r.p0 = -0.5f * kLog2e * inv;
     r.p1 = inv;
   } else {
-    const double d0 = c0, d1 = c1, d2 = c2, d3 = c3;
-    const double det = d0 * d3 - d1 * d2;
-    ok = ok && (det > 0.0) && (d3 > 0.0);
-    const double sdet = ok ? det : 1.0, s3 = ok ? d3 : 1.0;
-    const double qa = s3 / sdet, qb = -0.5 * (d1 + d2) / sdet, qc = d0 / sdet;
-    const double l11 = sqrt(qa), l21 = qb / l11;
-    const double l22s = qc - l21 * l21;
-    ok = ok && (l22s > 0.0);
-    const double l22 = sqrt(ok ? l22s : 1.0);
-    const double sc = 0.84932180028801904;  // sqrt(0.5*log2(e))
-    if (ok) { r.p0 = (float)(l11 * sc); r.p1 = (float)(l21 * sc); r.p2 = (float)(l22 * sc); }
+    const CholRec c = chol_prep(c0, c1, c2, c3);  // (common.hpp: the same bits wherever it is formed)
+    ok = ok && c.ok;
+    if (ok) { r.p0 = c.p0; r.p1 = c.p1; r.p2 = c.p2; }
   }
   r.a = ok ? a : 0.0f;
   return r;

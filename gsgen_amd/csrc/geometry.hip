@@ -258,23 +258,9 @@ struct ProjGrad { float gm[3], gq[4], gs[3]; };
 // Sigma^-1 d = (k0 u, k1 u + k2 v) for the kernels' u = p0 x + p1 y, v = p2 y.  A degenerate record never contributed: zeros.
 struct CholK { double k0, k1, k2; };
 __device__ __forceinline__ CholK chol_k_of(const float *__restrict__ cov2d_n) {
-  const double d0 = cov2d_n[0], d1 = cov2d_n[1], d2 = cov2d_n[2], d3 = cov2d_n[3];
-  const double det = d0 * d3 - d1 * d2;
-  bool ok = (det > 0.0) && (d3 > 0.0) && (fabs(d0) <= 3.402823466e+38) && (fabs(d1) <= 3.402823466e+38) &&
-            (fabs(d2) <= 3.402823466e+38) && (fabs(d3) <= 3.402823466e+38);
-  const double sdet = ok ? det : 1.0, s3 = ok ? d3 : 1.0;
-  const double qa = s3 / sdet, qb = -0.5 * (d1 + d2) / sdet, qc = d0 / sdet;
-  const double l11 = sqrt(qa), l21 = qb / l11;
-  const double l22s = qc - l21 * l21;
-  ok = ok && (l22s > 0.0);
-  const double l22 = sqrt(ok ? l22s : 1.0);
-  const double sc = 0.84932180028801904;  // sqrt(0.5 log2 e)
+  const CholRec c = chol_prep(cov2d_n[0], cov2d_n[1], cov2d_n[2], cov2d_n[3]);  // (common.hpp: the staged record's bits)
   CholK k{0.0, 0.0, 0.0};
-  if (ok) {
-    k.k0 = (double)kInvSc2 * (double)(float)(l11 * sc);
-    k.k1 = (double)kInvSc2 * (double)(float)(l21 * sc);
-    k.k2 = (double)kInvSc2 * (double)(float)(l22 * sc);
-  }
+  if (c.ok) { k.k0 = (double)kInvSc2 * (double)c.p0; k.k1 = (double)kInvSc2 * (double)c.p1; k.k2 = (double)kInvSc2 * (double)c.p2; }
   return k;
 }
 // gradients of one Gaussian through one view's projection (rows of the reference's autograd graph,
@@ -288,6 +274,10 @@ __device__ __forceinline__ ProjGrad project_bwd_one(uint32_t n, const float *__r
                                                     const float *__restrict__ qvec, const float *__restrict__ svec,
                                                     const float *__restrict__ c2w, int detach_depth,
                                                     double gm0, double gm1, const double (&gc)[4], float g_depth_n) {
+  // (fp64 throughout, fused multiply-adds allowed: the launch is bound by its fp64 issue -- 42 us per 8 x 100 k (view, Gaussian) chains
+  // on MI355X with every product and sum a separate instruction and nine divisions; the exact zeros of J are left out, the two
+  // normalisations multiply by one reciprocal each)
+#pragma clang fp contract(fast)
   ProjGrad o;
   double Rc[9], t[3];
 #pragma unroll
@@ -304,7 +294,8 @@ __device__ __forceinline__ ProjGrad project_bwd_one(uint32_t n, const float *__r
   for (int i = 0; i < 3; ++i) u[i] = Rc[i] * d0 + Rc[3 + i] * d1 + Rc[6 + i] * d2;
   double nq = sqrt((double)q[0] * q[0] + (double)q[1] * q[1] + (double)q[2] * q[2] + (double)q[3] * q[3]);
   nq = nq < 1e-12 ? 1e-12 : nq;
-  const double w = q[0] / nq, x = q[1] / nq, y = q[2] / nq, z = q[3] / nq;
+  const double inq = 1.0 / nq;
+  const double w = q[0] * inq, x = q[1] * inq, y = q[2] * inq, z = q[3] * inq;
   const double Rq[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
                         2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
                         2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)};
@@ -315,26 +306,26 @@ __device__ __forceinline__ ProjGrad project_bwd_one(uint32_t n, const float *__r
     for (int j = 0; j < 3; ++j) M[i * 3 + j] = s[j] * Rq[i * 3 + j];
   const double ux = u[0], uy = u[1], uz = u[2];
   const double iz = 1.0 / uz;
-  const double J[6] = {iz, 0.0, -ux * iz * iz, 0.0, iz, -uy * iz * iz};
+  // J = [[iz, 0, -ux iz^2], [0, iz, -uy iz^2]]: A = J Rc^T (the first two rows of JW)
+  const double j02 = -ux * iz * iz, j12 = -uy * iz * iz;
   double A[6];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int k = 0; k < 3; ++k) {
+    A[k] = iz * Rc[k * 3] + j02 * Rc[k * 3 + 2];
+    A[3 + k] = iz * Rc[k * 3 + 1] + j12 * Rc[k * 3 + 2];
+  }
+  // dSigma = A^T G A through G A (2 x 3); only the symmetrised form enters dM
+  double GA[6];
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
-      A[a * 3 + k] = J[a * 3] * Rc[k * 3] + J[a * 3 + 1] * Rc[k * 3 + 1] + J[a * 3 + 2] * Rc[k * 3 + 2];
-  // dSigma = A^T G A ; only the symmetrised form enters dM
+  for (int k = 0; k < 3; ++k) {
+    GA[k] = gc[0] * A[k] + gc[1] * A[3 + k];
+    GA[3 + k] = gc[2] * A[k] + gc[3] * A[3 + k];
+  }
   double dS[9];
 #pragma unroll
   for (int j = 0; j < 3; ++j)
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      double acc = 0.0;
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) acc += A[a * 3 + j] * gc[a * 2 + b] * A[b * 3 + k];
-      dS[j * 3 + k] = acc;
-    }
+    for (int k = 0; k < 3; ++k) dS[j * 3 + k] = A[j] * GA[k] + A[3 + j] * GA[3 + k];
   double dM[9];
 #pragma unroll
   for (int i = 0; i < 3; ++i)
@@ -364,7 +355,7 @@ __device__ __forceinline__ ProjGrad project_bwd_one(uint32_t n, const float *__r
   const double qh[4] = {w, x, y, z};
   const double dot = qh[0] * dq[0] + qh[1] * dq[1] + qh[2] * dq[2] + qh[3] * dq[3];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) o.gq[k] = (float)((dq[k] - qh[k] * dot) / nq);
+  for (int k = 0; k < 4; ++k) o.gq[k] = (float)((dq[k] - qh[k] * dot) * inq);
   double du[3] = {gm0 * iz, gm1 * iz, (double)g_depth_n};
   if (!detach_depth) du[2] += -(ux * gm0 + uy * gm1) * iz * iz;
 #pragma unroll
@@ -429,6 +420,9 @@ struct ProjBwdViews {
   // the MOMENTS (Mu, Mv) / (Muu, Muv, Mvv, -) of the compositing backward's per-pixel weight against the whitened offsets
   // (u, v) of the Cholesky-form Gaussian, expanded here (moments_to_grads)
   const float *cov2d[kProjViews];
+  // ... or (RGB + heads) the records the projection launch prepared from it, [N,4] = (p0, p1, p2, ok) (gsgen_geometry_view::chol): no
+  // second fp64 Cholesky per (view, Gaussian)
+  const float *chol[kProjViews];
 };
 // d L / d mean2d and d L / d cov2d from the moments  M_ab = sum_pixels g a b,  g = d L / d (a G) * a G,  (a, b) in (u, v):
 // with Sigma^-1 d = (k0 u, k1 u + k2 v) (chol_k_of) the reference's sums (kernels.h:394-418)
@@ -496,9 +490,17 @@ k_project_bwd_views(uint32_t N, const float *__restrict__ mean, const float *__r
         double gm0, gm1, gcv[4];
         if (moments == 2)
           moments_to_grads_sh(pv.cov2d[v] + 4 * (size_t)n, pv.g_mean2d[v] + 2 * (size_t)n, pv.g_cov2d[v] + 4 * (size_t)n, gm0, gm1, gcv);
-        else
-          moments_to_grads(chol_k_of(pv.cov2d[v] + 4 * (size_t)n), pv.g_mean2d[v] + 2 * (size_t)n, pv.g_cov2d[v] + 4 * (size_t)n,
-                           gm0, gm1, gcv);
+        else {
+          CholK ck;
+          if (pv.chol[v] != nullptr) {
+            const float4 c = *reinterpret_cast<const float4 *>(pv.chol[v] + 4 * (size_t)n);
+            const double on = c.w != 0.0f ? (double)kInvSc2 : 0.0;
+            ck = CholK{on * (double)c.x, on * (double)c.y, on * (double)c.z};
+          } else {
+            ck = chol_k_of(pv.cov2d[v] + 4 * (size_t)n);
+          }
+          moments_to_grads(ck, pv.g_mean2d[v] + 2 * (size_t)n, pv.g_cov2d[v] + 4 * (size_t)n, gm0, gm1, gcv);
+        }
         // the view's d L / d mean2d in place of its two first moments: the densify statistics read it (gsgen_densify_update_batch,
         // gs/gaussian_splatting.py:464-469)
         *reinterpret_cast<float2 *>(const_cast<float *>(pv.g_mean2d[v]) + 2 * (size_t)n) = make_float2((float)gm0, (float)gm1);
@@ -599,7 +601,7 @@ __device__ __forceinline__ void
 frame_project_body(uint32_t N, const float *__restrict__ mean, const float *__restrict__ qvec,
                 const float *__restrict__ svec, const float *__restrict__ cam, int w, int h, int ntw,
                 float *__restrict__ mean2d, float *__restrict__ cov2d, float *__restrict__ depth,
-                uint8_t *__restrict__ mask, int *__restrict__ tl, int *__restrict__ br) {
+                uint8_t *__restrict__ mask, int *__restrict__ tl, int *__restrict__ br, float *__restrict__ chol = nullptr) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   float Rc[9], t[3];
@@ -625,6 +627,10 @@ frame_project_body(uint32_t N, const float *__restrict__ mean, const float *__re
   }
   *reinterpret_cast<float2 *>(mean2d + 2 * (size_t)i) = m2;
   *reinterpret_cast<float4 *>(cov2d + 4 * (size_t)i) = c2;
+  if (chol != nullptr) {  // the compositing kernels' evaluation record, once per (view, Gaussian) (gsgen_geometry_view::chol)
+    const CholRec c = chol_prep(c2.x, c2.y, c2.z, c2.w);
+    *reinterpret_cast<float4 *>(chol + 4 * (size_t)i) = make_float4(c.p0, c.p1, c.p2, (in && c.ok) ? 1.0f : 0.0f);
+  }
   depth[i] = z;
   mask[i] = in ? 1 : 0;
   *reinterpret_cast<int2 *>(tl + 2 * (size_t)i) = make_int2(rc.x0, rc.y0);
@@ -669,7 +675,7 @@ k_frame_project_views(uint32_t N, const float *__restrict__ mean, const float *_
       z[0] = z[1] = z[2] = make_float2(0.f, 0.f);
     }
   }
-  frame_project_body(N, mean, qvec, svec, v.cam, w, h, ntw, v.mean2d, v.cov2d, v.depth, v.mask, v.tl, v.br);
+  frame_project_body(N, mean, qvec, svec, v.cam, w, h, ntw, v.mean2d, v.cov2d, v.depth, v.mask, v.tl, v.br, v.chol);
 }
 
 static inline dim3 grid_for(uint32_t n) { return dim3((n + kThreads - 1) / kThreads); }
@@ -767,7 +773,7 @@ static int project_bwd_batch(uint32_t n_views, uint32_t N, const float *mean, co
                              const float *const *g_mean2d, const float *const *g_cov2d, const float *const *g_depth,
                              const float *const *g_chan6, const float *const *depth, float *g_mean, float *g_qvec,
                              float *g_svec, float *g_color, gsgen_stream_t stream, const float *const *cov2d = nullptr,
-                             int moments_form = 1) {
+                             int moments_form = 1, const float *const *chol = nullptr) {
   if (N == 0) return 0;
   if (!mean || !qvec || !svec || !g_mean || !g_qvec || !g_svec) return GSGEN_EINVAL;
   if (n_views && (!c2w || !g_mean2d || !g_cov2d)) return GSGEN_EINVAL;
@@ -790,6 +796,7 @@ static int project_bwd_batch(uint32_t n_views, uint32_t N, const float *mean, co
       pv.g_chan6[i] = g_chan6 ? g_chan6[v0 + i] : nullptr;
       pv.depth[i] = depth ? depth[v0 + i] : nullptr;
       pv.cov2d[i] = cov2d ? cov2d[v0 + i] : nullptr;
+      pv.chol[i] = chol ? chol[v0 + i] : nullptr;
     }
     hipLaunchKernelGGL(k_project_bwd_views, dim3((N + kPbvGauss - 1) / kPbvGauss), dim3(kThreads), 0, (hipStream_t)stream, N, mean, qvec,
                        svec, pv, (int)nv, detach_depth, v0 ? 1 : 0, cov2d ? moments_form : 0, g_mean, g_qvec, g_svec, g_color);
@@ -833,11 +840,11 @@ int gsgen_project_gaussians_backward_batch_heads_moments(uint32_t n_views, uint3
                                                          const uint8_t *const *mask, float *const *g_mom2,
                                                          const float *const *g_mom4, const float *const *g_chan6,
                                                          const float *const *depth, const float *const *cov2d,
-                                                         float *g_mean, float *g_qvec, float *g_svec, float *g_color,
-                                                         gsgen_stream_t stream) {
+                                                         const float *const *chol, float *g_mean, float *g_qvec, float *g_svec,
+                                                         float *g_color, gsgen_stream_t stream) {
   if (!g_chan6 || !depth || !g_color || !cov2d) return GSGEN_EINVAL;
   return project_bwd_batch(n_views, N, mean, qvec, svec, c2w, detach_depth, mask, g_mom2, g_mom4, nullptr, g_chan6, depth,
-                           g_mean, g_qvec, g_svec, g_color, stream, cov2d);
+                           g_mean, g_qvec, g_svec, g_color, stream, cov2d, 1, chol);
 }
 
 // Host side: the 56-float camera block of gsgen_frame_geometry.  Frustum planes as

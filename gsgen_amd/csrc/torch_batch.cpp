@@ -55,7 +55,7 @@ struct Plan : std::enable_shared_from_this<Plan> {
   int kind = kRgbd;
   int64_t B = 0, N = 0, Np = 0, W = 0, H = 0, nth = 0, ntw = 0, segments = 1;
   uintptr_t geo = 0, views = 0;  // gsgen_geometry_view[B], gsgen_rgbd_view[B] | gsgen_sh_view[B]  (host)
-  uintptr_t cam_tab = 0, mask_tab = 0, gmean_tab = 0, gcov_tab = 0, gchan_tab = 0, depth_tab = 0, cov2d_tab = 0;  // void*[B] (host)
+  uintptr_t cam_tab = 0, mask_tab = 0, gmean_tab = 0, gcov_tab = 0, gchan_tab = 0, depth_tab = 0, cov2d_tab = 0, chol_tab = 0;  // void*[B] (host)
   uintptr_t gws = 0, bws = 0;    // device: the geometry launch's view table, the compositing launches' batch workspace
   uintptr_t generation = 0;      // host int64: BatchRenderer's generation counter (a later render invalidates this batch's lists)
   Tensor g2d, gch;               // the renderer's per-view gradient accumulators (zeroed again for a second backward)
@@ -225,8 +225,9 @@ struct HeadsFn : public torch::autograd::Function<HeadsFn> {
         (uint32_t)B, (uint32_t)N, mean.data_ptr<float>(), qvec.data_ptr<float>(), svec.data_ptr<float>(),
         tab<const float *const>(p.cam_tab), ctx->saved_data["detach"].toBool() ? 1 : 0, tab<const uint8_t *const>(p.mask_tab),
         tab<float *const>(p.gmean_tab), tab<const float *const>(p.gcov_tab), tab<const float *const>(p.gchan_tab),
-        tab<const float *const>(p.depth_tab), tab<const float *const>(p.cov2d_tab), g_mean.data_ptr<float>(),
-        g_qvec.data_ptr<float>(), g_svec.data_ptr<float>(), g_col.data_ptr<float>(), s));
+        tab<const float *const>(p.depth_tab), tab<const float *const>(p.cov2d_tab),
+        p.chol_tab ? tab<const float *const>(p.chol_tab) : nullptr, g_mean.data_ptr<float>(), g_qvec.data_ptr<float>(),
+        g_svec.data_ptr<float>(), g_col.data_ptr<float>(), s));
     const auto &ga = ctx->saved_data["grad_accum"];
     if (ga.isTensor() && ga.toTensor().defined()) {
       Tensor acc = ga.toTensor(), cnt = ctx->saved_data["cnt"].toTensor();
@@ -385,13 +386,13 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def(pybind11::init([](int kind, int64_t B, int64_t N, int64_t Np, int64_t W, int64_t H, int64_t nth, int64_t ntw,
                              int64_t segments, uintptr_t geo, uintptr_t views, uintptr_t cam_tab, uintptr_t mask_tab,
                              uintptr_t gmean_tab, uintptr_t gcov_tab, uintptr_t gchan_tab, uintptr_t depth_tab, uintptr_t cov2d_tab,
-                             uintptr_t gws, uintptr_t bws, uintptr_t generation, Tensor g2d, c10::optional<Tensor> gch,
+                             uintptr_t chol_tab, uintptr_t gws, uintptr_t bws, uintptr_t generation, Tensor g2d, c10::optional<Tensor> gch,
                              pybind11::object keep) {
         auto sp = std::make_shared<Plan>();
         Plan &p = *sp;
         p.kind = kind; p.B = B; p.N = N; p.Np = Np; p.W = W; p.H = H; p.nth = nth; p.ntw = ntw; p.segments = segments;
         p.geo = geo; p.views = views; p.cam_tab = cam_tab; p.mask_tab = mask_tab; p.gmean_tab = gmean_tab; p.gcov_tab = gcov_tab;
-        p.gchan_tab = gchan_tab; p.depth_tab = depth_tab; p.cov2d_tab = cov2d_tab; p.gws = gws; p.bws = bws;
+        p.gchan_tab = gchan_tab; p.depth_tab = depth_tab; p.cov2d_tab = cov2d_tab; p.chol_tab = chol_tab; p.gws = gws; p.bws = bws;
         p.generation = generation; p.g2d = g2d; p.gch = opt(gch);
         p.keep = std::make_shared<Keep>(std::move(keep));
         return sp;

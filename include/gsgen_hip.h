@@ -216,6 +216,7 @@ int gsgen_project_gaussians_backward_batch_heads_moments(uint32_t n_views, uint3
                                                          const uint8_t *const *mask, float *const *g_mom2,
                                                          const float *const *g_mom4, const float *const *g_chan6,
                                                          const float *const *depth, const float *const *cov2d,
+                                                         const float *const *chol /* or NULL: the views' gsgen_geometry_view::chol */,
                                                          float *g_mean, float *g_qvec, float *g_svec, float *g_color,
                                                          gsgen_stream_t stream);
 int gsgen_adam_step(uint64_t n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
@@ -341,6 +342,11 @@ typedef struct gsgen_geometry_view {
    * backward was a launch of its own in every step's chain */
   float *zero_grad_mean2d, *zero_grad_cov2d, *zero_grad_chan6;
   uint32_t *pair_report;                   /* optional, HOST-visible [2]: see "pair_report" above */
+  /* optional (round 6): [N,4] floats, 16-byte aligned -- the projection launch also prepares the evaluation record of the RGB / scalar /
+   * RGB + heads compositing kernels once per Gaussian of the view: (p0, p1, p2) = sqrt(0.5 log2 e) * the Cholesky factor of the
+   * symmetrised Sigma^-1, formed in fp64 from cov2d and rounded to fp32, and a validity flag (0 for a degenerate or non-finite
+   * covariance).  gsgen_rgbd_view::chol hands it to the compositing launches. */
+  float *chol;
 } gsgen_geometry_view;
 size_t gsgen_frame_batch_workspace_bytes(uint32_t n_views);
 int gsgen_frame_geometry_batch(uint32_t n_views, const gsgen_geometry_view *views, uint32_t N, const float *mean,
@@ -625,6 +631,10 @@ typedef struct gsgen_rgbd_view {
   const float *bg_rgb;
   float *grad_bg;
   uint32_t depth_variance;
+  /* optional (rgbd and rgb launches): the view's prepared evaluation records [N,4] as gsgen_geometry_view::chol delivers them -- staging
+   * then reads 16 bytes per record instead of running the fp64 Cholesky preparation (kernels.h:195-224 evaluates the quadratic form in
+   * fp64; here its factor is prepared in fp64) per staged (tile, Gaussian) record in the forward and again in the backward */
+  const float *chol;
 } gsgen_rgbd_view;
 /* The batched forwards (rgbd and rgb) write EVERY pixel of out6 / T, empty tiles included (channels 0, T = 1): the caller need
  * not pre-initialise the images (the per-camera entry points above keep the reference's contract: empty tiles are left alone). */

@@ -484,6 +484,92 @@ def test_emulated_frame_geometry_batch_zero_fills_the_gradient_accumulators(emu)
         emu.frame_geometry_batch_zero(B, arr, N, P(sc["mean"]), P(sc["qvec"]), P(sc["svec"]), W, H, P(shared), nz - 1, P(bws), None)
 
 
+def test_emulated_prepared_evaluation_records(emu):
+    """Round 6, gsgen_geometry_view::chol -> gsgen_rgbd_view::chol: the projection launch prepares the Cholesky-form evaluation record
+    once per (view, Gaussian) -- (p0, p1, p2) = sqrt(0.5 log2 e) x the factor of the symmetrised Sigma^-1, in fp64 from cov2d, and a
+    validity flag -- and the batched RGB + heads launches that stage it instead of preparing it per staged (tile, Gaussian) record give
+    the SAME BITS, forward and backward, anisotropic splats and a degenerate covariance included."""
+    from gsgen_amd import renderer as R
+    from gsgen_amd._capi import GeometryView, RgbdView
+    W, H, B = 64, 48, 2
+    sc = scenes.random_scene(500, seed=8, svec=0.05, spread=1.2)
+    sc["svec"] = np.ascontiguousarray(sc["svec"] * np.array([3.0, 0.3, 1.0], np.float32))
+    sc["svec"][7] = 0.0  # a degenerate splat: cov2d = 0 -> flag 0, never contributes
+    N = sc["mean"].shape[0]
+    cams = [scenes.Camera(W, H, fx=60.0 + 5 * i, c2w=scenes.orbit(2.2, 10.0 + 20 * i, 40.0 * i)) for i in range(B)]
+    nth, ntw = cams[0].tiles
+    T = nth * ntw
+    cap = 40000
+    bufs = [dict(m2=np.zeros((N, 2), np.float32), c2=np.zeros((N, 4), np.float32), dep=np.zeros(N, np.float32), mask=np.zeros(N, np.uint8),
+                 ids=np.zeros(cap, np.int32), st=np.zeros(T, np.int32), en=np.zeros(T, np.int32), tot=np.zeros(1, np.uint32),
+                 ws=np.zeros(emu.frame_workspace_bytes(N, cap, T), np.uint8), chol=np.full((N, 4), 9.0, np.float32)) for _ in range(B)]
+    camv = [np.ascontiguousarray(R.CameraInfo(*c.intr).pack(c.c2w)) for c in cams]
+    geo = (GeometryView * B)()
+    for a, cv, g in zip(geo, camv, bufs):
+        a.cam, a.mean2d, a.cov2d, a.depth, a.mask = P(cv), P(g["m2"]), P(g["c2"]), P(g["dep"]), P(g["mask"])
+        a.gaussian_ids, a.start, a.end, a.total = P(g["ids"]), P(g["st"]), P(g["en"]), P(g["tot"])
+        a.workspace, a.workspace_bytes, a.D_cap, a.chol = P(g["ws"]), g["ws"].size, cap, P(g["chol"])
+    gws = np.zeros(emu.frame_batch_workspace_bytes(B), np.uint8)
+    emu.frame_geometry_batch(B, geo, N, P(sc["mean"]), P(sc["qvec"]), P(sc["svec"]), W, H, P(gws), None)
+    for g in bufs:  # against the formula in numpy fp64
+        assert int(g["tot"][0]) <= cap
+        c = g["c2"].astype(np.float64)
+        det = c[:, 0] * c[:, 3] - c[:, 1] * c[:, 2]
+        vis = g["mask"].astype(bool)
+        ok = vis & (det > 0) & (c[:, 3] > 0)
+        with np.errstate(all="ignore"):
+            qa, qb, qc = c[:, 3] / det, -0.5 * (c[:, 1] + c[:, 2]) / det, c[:, 0] / det
+            l11 = np.sqrt(qa); l21 = qb / l11; l22 = np.sqrt(qc - l21 * l21)
+        sc_ = 0.84932180028801904
+        want = np.stack([l11 * sc_, l21 * sc_, l22 * sc_], 1)
+        assert ok.sum() > 100 and np.array_equal(g["chol"][:, 3] != 0, ok) and g["chol"][7, 3] == 0
+        assert np.abs(g["chol"][ok, :3] - want[ok]).max() <= 2e-7 * np.abs(want[ok]).max()
+    col, al = np.ascontiguousarray(sc["color"]), np.ascontiguousarray(sc["alpha"])
+    res = {}
+    for use in (False, True):
+        views = (RgbdView * B)()
+        outs = []
+        for a, g, cam in zip(views, bufs, cams):
+            o = dict(out=np.zeros((H, W, 6), np.float32), T=np.zeros((H, W), np.float32), gm=np.zeros((N, 2), np.float32),
+                     gc=np.zeros((N, 4), np.float32), gch=np.zeros((N, 6), np.float32),
+                     go=np.random.default_rng(3).normal(size=(H, W, 6)).astype(np.float32), tlp=cam.topleft)
+            a.mean, a.cov, a.depth, a.start, a.end, a.gaussian_ids = P(g["m2"]), P(g["c2"]), P(g["dep"]), P(g["st"]), P(g["en"]), P(g["ids"])
+            a.tile_order, a.topleft, a.pixel_size_x, a.pixel_size_y = None, P(o["tlp"]), 1 / cam.fx, 1 / cam.fy
+            a.out6, a.T, a.grad_out6 = P(o["out"]), P(o["T"]), P(o["go"])
+            a.grad_mean, a.grad_cov, a.grad_chan6 = P(o["gm"]), P(o["gc"]), P(o["gch"])
+            a.chol = P(g["chol"]) if use else None
+            outs.append(o)
+        bws = np.zeros(emu.sh_batch_workspace_bytes(B), np.uint8)
+        ga = np.zeros(N, np.float32)
+        emu.vol_render_rgbd_batch(B, views, N, P(col), P(al), 16, nth, ntw, H, W, 1e-4, P(bws), None)
+        emu.vol_render_rgbd_backward_batch_moments(B, views, N, P(col), P(al), P(ga), 16, nth, ntw, H, W, 1e-4, P(bws), None)
+        res[use] = (outs, ga)
+    for a, b in zip(res[False][0], res[True][0]):
+        for k in ("out", "T", "gm", "gc", "gch"):
+            assert np.array_equal(a[k], b[k]), k
+        assert np.abs(a["out"]).max() > 0.1 and np.abs(a["gm"]).max() > 0
+    assert np.array_equal(res[False][1], res[True][1])
+    # ... and the projection backward's moment expansion takes them instead of a second fp64 Cholesky per (view, Gaussian): same bits
+    import ctypes as Ct
+    tab = lambda xs: (Ct.c_void_p * B)(*[x.ctypes.data for x in xs])  # noqa: E731
+    outs = res[True][0]
+    got = {}
+    for use in (False, True):
+        gm = [o["gm"].copy() for o in outs]
+        out = [np.zeros((N, n), np.float32) for n in (3, 4, 3, 3)]
+        emu.project_gaussians_backward_batch_heads_moments(
+            B, N, P(sc["mean"]), P(sc["qvec"]), P(sc["svec"]), tab(camv), 1, tab([g["mask"] for g in bufs]), tab(gm),
+            tab([o["gc"] for o in outs]), tab([o["gch"] for o in outs]), tab([g["dep"] for g in bufs]), tab([g["c2"] for g in bufs]),
+            tab([g["chol"] for g in bufs]) if use else None, *[P(a) for a in out], None)
+        got[use] = out + gm
+    for x, y in zip(got[False], got[True]):
+        assert np.array_equal(x, y) and np.isfinite(x).all()
+    assert np.abs(got[True][1]).max() > 0
+    geo[1].chol = P(bufs[1]["chol"]) + 4  # (16-byte alignment)
+    with pytest.raises(Exception, match="invalid"):
+        emu.frame_geometry_batch(B, geo, N, P(sc["mean"]), P(sc["qvec"]), P(sc["svec"]), W, H, P(gws), None)
+
+
 def test_emulated_projection_backward_folds_the_heads(emu):
     """gsgen_project_gaussians_backward_batch_heads == gsgen_project_gaussians_backward_batch fed d L / d depth =
     g3 + 2 depth g5 (the depth and depth^2 heads, gs/gaussian_splatting.py:1334-1403), plus the colour gradient summed
@@ -917,7 +1003,7 @@ def test_emulated_rgb_heads_moment_form_equals_the_plain_backward(emu):
                     emu.vol_render_rgbd_backward_batch_moments(B, arr, Nall, P(col), P(al), P(ga), 16, nth, ntw, H, W, 1e-4, P(bws), None)
                     for v in views:  # the untouched slots: the fourth float of the second moments, channels 4 and 5
                         assert not v["gc"][:, 3].any() and not v["gch"][:, 4:].any() and np.abs(v["gch"][:, 3]).max() > 0
-                    emu.project_gaussians_backward_batch_heads_moments(*common, tab([v["c2"] for v in views]), *[P(a) for a in out], None)
+                    emu.project_gaussians_backward_batch_heads_moments(*common, tab([v["c2"] for v in views]), None, *[P(a) for a in out], None)
                     gm2d = [v["gm"].copy() for v in views]  # overwritten with d L / d mean2d
                 res[form] = dict(ga=ga, out=out, gm2d=gm2d)
             a_, b_ = res["plain"], res["moments"]
@@ -927,7 +1013,7 @@ def test_emulated_rgb_heads_moment_form_equals_the_plain_backward(emu):
             for x, y in zip(a_["gm2d"], b_["gm2d"]):
                 assert np.abs(x - y).max() <= 1e-5 * np.abs(x).max()
     with pytest.raises(Exception, match="invalid"):
-        emu.project_gaussians_backward_batch_heads_moments(*common, None, *[P(a) for a in out], None)
+        emu.project_gaussians_backward_batch_heads_moments(*common, None, None, *[P(a) for a in out], None)
 
 
 def test_emulated_rgb_heads_separate_images_background_and_depth_variance(emu):
