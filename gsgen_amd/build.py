@@ -26,7 +26,9 @@ SOURCES = {
     "binning.hip": [],
     "legacy.hip": ["-ffp-contract=off"],
 }
-COMMON = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-Wall", "-Wno-unused-function", f"-I{CSRC}"]
+# -fvisibility=hidden: the dynamic symbol table holds the entry points of include/gsgen_hip.h and nothing else (three
+# cross-file helpers used to be exported beside them)
+COMMON = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function", f"-I{CSRC}"]
 
 
 def _newer(src, dst, extra=()):

@@ -34,6 +34,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: exactly the entry points declared in this header are exported (the declarations
+ * carry default visibility; the cross-file helpers of the implementation stay out of the dynamic symbol table). */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 typedef void *gsgen_stream_t; /* hipStream_t; NULL = the legacy default stream */
 
@@ -675,6 +680,9 @@ int gsgen_vol_render_rgb_backward_batch(uint32_t n_views, const gsgen_rgbd_view 
  * lane owns (-1: duplicate holder); P in {8,16,32,64}. */
 int gsgen_selftest_reduce_scatter(uint32_t P, const float *in, float *out, gsgen_stream_t stream);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -27,6 +27,13 @@ def test_c_abi_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(cdll, name), name
     assert set(_capi.EXPORTS) >= set(declared)
+    # ... and nothing else of its own: built with -fvisibility=hidden, the dynamic symbol table holds no cross-file helper (VERDICT r5:
+    # gsgen_internal_frame_project, ..._frame_project_views, ..._sort_segments used to sit there); what remains beside the entry points
+    # are the kernels' host stubs, which the HIP runtime registers by name
+    dyn = subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in dyn.splitlines() if ln.strip()}
+    assert {n for n in exported if n.startswith("gsgen_")} == set(declared)
+    assert not [n for n in exported if "launch_" in n or "internal" in n], [n for n in exported if "launch_" in n or "internal" in n]
     h = _capi.Lib(lib)
     assert "gfx950" in h.version()
     # gfx950 code object is really in there
