@@ -290,6 +290,36 @@ class _Cfg(dict):
             raise AttributeError(k) from None
 
 
+def other_configs(steps=10, warmup=3):
+    """The other BASELINE workloads and the routing stress, measured by the driver's own command (until round 5 only the
+    builder ever ran them): cfg3 (500 k Gaussians, 1024^2), cfg4 (64 random poses at 512^2), cfg2 with 1 % outlier splats and with
+    0.7 x focal length -- each as `bench.py --config ... --only-timed` in a process of its own (nothing but warm-up + timed regions:
+    the same timed core as `value`), a few seconds each; value, step time and the dominant kernel's roofline fraction per line."""
+    import subprocess
+    out = {}
+    me = os.path.abspath(__file__)
+    for name, extra in (("cfg3", ["--config", "cfg3"]), ("cfg4", ["--config", "cfg4"]),
+                        ("cfg2_outliers_0.01", ["--config", "cfg2", "--outlier-fraction", "0.01"]),
+                        ("cfg2_focal_0.7", ["--config", "cfg2", "--focal-scale", "0.7"])):
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run([sys.executable, me, "--gpus", "1", "--steps", str(steps), "--warmup", str(warmup), "--only-timed", "--repeats", "3",
+                                *extra], capture_output=True, text=True, timeout=180)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not line:
+                out[name] = {"error": (r.stderr or r.stdout)[-300:]}
+                continue
+            j = json.loads(line[-1])
+            ro = j.get("roofline") or {}
+            out[name] = {"value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "cameras_per_step": (j.get("config") or {}).get("cameras_per_step"),
+                         "workload": (j.get("config") or {}).get("workload"), "dominant_kernel": ro.get("kernel"),
+                         "roofline_frac": ro.get("frac"), "avg_launch_ms": ro.get("avg_launch_ms"), "whole_render_hbm_frac": ro.get("whole_render_hbm_frac"),
+                         "tiles_exact_of_nonempty": (j.get("config") or {}).get("tiles_exact_of_nonempty"), "wall_s": round(time.perf_counter() - t0, 1)}
+        except Exception as e:  # a line that cannot be produced is reported as such, never dropped silently
+            out[name] = {"error": repr(e)[:300]}
+    return out
+
+
 def model_surfaces(sc, cams, dev, B, K, H, W):
     """views/s of the model-level training call on the bench workload (B cameras per step, one step in flight, dense random
     gradients into all four outputs, gradients to the five raw parameter fields, densify statistics updated):
@@ -450,6 +480,7 @@ def main():
                     help="experiment: after every J steps all slot streams wait for each other -- with --batch B/2 --slots 2 "
                          "--join-every 2 a strictly sequential optimiser whose step is two half-batches on two streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the cfg3 / cfg4 / routing-stress lines (`other_configs`)")
     ap.add_argument("--no-latency", action="store_true", help="skip the one-render-in-flight and hipGraph passes")
     args = ap.parse_args()
     dry = args.dry_run_lib is not None
@@ -458,7 +489,7 @@ def main():
         args.only_timed, args.config = True, ("dry4" if cfg4_split else "dry")
         args.batch, args.slots = args.batch or (8 if cfg4_split else 2), args.slots or 2
     if args.only_timed:
-        args.no_surface = args.no_latency = args.no_cpu_baseline = args.no_heads = True
+        args.no_surface = args.no_latency = args.no_cpu_baseline = args.no_heads = args.no_other_configs = True
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args.gpus))
@@ -1370,6 +1401,8 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(sc, cams, C)
+        if world == 1 and args.config == "cfg2" and not args.no_other_configs and args.focal_scale == 1.0 and args.outlier_fraction == 0.0:
+            res["other_configs"] = other_configs()
         print(json.dumps(res), file=json_out, flush=True)
     if dist is not None:
         dist.barrier()

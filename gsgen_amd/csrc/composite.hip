@@ -155,12 +155,13 @@ __device__ __forceinline__ void poison_pixel(const CompParams &p, size_t pix) {
 // RGB + heads: the epilogue of a pixel of the batched forward -- the background behind what is left of the transmittance
 // (gs/renderer.py:1182: out + T * bg, product rounded before the sum as torch forms it) and, where the caller asks for it, the depth
 // variance in place of the second moment (gs/gaussian_splatting.py:1397: z_var = depth2 - depth * depth)
-__device__ __forceinline__ void heads_epilogue(const CompParams &p, float (&e)[6], float T) {
+__device__ __forceinline__ void heads_epilogue(const CompParams &p, const float (&bg)[3], float (&e)[6], float T) {
 #pragma clang fp contract(off)
-  if (p.bg != nullptr) {
+  if (p.bg != nullptr) {  // (bg: the three floats, loaded ONCE at the top of the kernel -- read here, behind the image stores of the
+    // lane's previous pixel, the compiler must assume they alias and fetch them again per pixel: a round trip to memory each)
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const float tb = T * p.bg[c];
+      const float tb = T * bg[c];
       e[c] = e[c] + tb;
     }
   }
@@ -168,6 +169,14 @@ __device__ __forceinline__ void heads_epilogue(const CompParams &p, float (&e)[6
     const float dd = e[3] * e[3];
     e[5] = e[5] - dd;
   }
+}
+// the tile's three background-gradient sums into row (tile % 64) of the view's partial block: one 4-component reduce-scatter on the
+// vector ALU's cross-lane instructions (three ds_bpermute butterflies cost 18 LDS round trips in front of every tile's list walk)
+__device__ __forceinline__ void bg_grad_atomics(const CompParams &p, int tile, int lane, const float (&sums)[3]) {
+  float v[4] = {sums[0], sums[1], sums[2], 0.0f};
+  wave_reduce_scatter<4>(v);
+  const int comp = scatter_comp<4>(lane);
+  if (scatter_owner<4>(lane) && comp < 3) atomicAdd(p.g_bg + 4 * (tile & 63) + comp, v[0]);
 }
 // one pixel's channels to the image(s): [H,W,NCH] interleaved, or -- RGB + heads with separate images -- rgb [H,W,3] + three [H,W]
 template <int MODE, int NCH>
@@ -1762,6 +1771,10 @@ k_composite_fwd_chan_vec(CompParams p_arg, ViewPack<BATCH> pack) {
   const int t = (int)threadIdx.x;
   const int lx = t & 15, ly0 = t >> 4;
   const int gx = tx * kTile + lx;
+  float bgv[3] = {0.0f, 0.0f, 0.0f};  // the view's background colour (RGB + heads, gsgen_rgbd_view::bg_rgb), or zeros
+  if constexpr (MODE == MODE_RGBD) {
+    if (p.bg != nullptr) { bgv[0] = p.bg[0]; bgv[1] = p.bg[1]; bgv[2] = p.bg[2]; }
+  }
   if (st == kListOverflow) {  // the frame's pairs did not fit the list (GSGEN_LIST_OVERFLOW): never a finite blank tile
 #pragma unroll
     for (int j = 0; j < PPL; ++j) {
@@ -1781,7 +1794,7 @@ k_composite_fwd_chan_vec(CompParams p_arg, ViewPack<BATCH> pack) {
           const size_t pix = (size_t)gyj * p.W + gx;
           float e[NCH];
 #pragma unroll
-          for (int c = 0; c < NCH; ++c) e[c] = (MODE == MODE_RGBD && c < 3 && p.bg != nullptr) ? p.bg[c] : 0.0f;  // (T = 1: the background)
+          for (int c = 0; c < NCH; ++c) e[c] = (MODE == MODE_RGBD && c < 3) ? bgv[c] : 0.0f;  // (T = 1: the background)
           store_heads<MODE, NCH>(p, pix, e);
           if (p.T != nullptr) p.T[pix] = 1.0f;
         }
@@ -1889,7 +1902,7 @@ k_composite_fwd_chan_vec(CompParams p_arg, ViewPack<BATCH> pack) {
     float e[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) e[c] = acc2[j >> 1][c][j & 1];
-    if constexpr (MODE == MODE_RGBD) heads_epilogue(p, e, Tr2[j >> 1][j & 1]);
+    if constexpr (MODE == MODE_RGBD) heads_epilogue(p, bgv, e, Tr2[j >> 1][j & 1]);
     store_heads<MODE, NCH>(p, pix, e);
     if (p.T != nullptr) p.T[pix] = Tr2[j >> 1][j & 1];
   }
@@ -1963,11 +1976,7 @@ k_composite_bwd_chan_vec(CompParams p_arg, ViewPack<BATCH> pack) {
             for (int c = 0; c < 3; ++c) sb[c] += nan_to_num_f(p.go_rgb[3 * pix + c] * Tf);
           }
         }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const float tot = wave_sum(sb[c]);
-          if (lane == 0) atomicAdd(p.g_bg + 4 * (tile & 63) + c, tot);
-        }
+        bg_grad_atomics(p, tile, lane, sb);
       }
     }
     return;
@@ -2011,11 +2020,7 @@ k_composite_bwd_chan_vec(CompParams p_arg, ViewPack<BATCH> pack) {
   }
   if constexpr (MODE == MODE_RGBD) {
     if (p.g_bg != nullptr && p.T != nullptr) {  // the tile's sums into slot (tile % 64): 64 addresses per view share the atomics
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const float tot = wave_sum(bgs[c]);
-        if (lane == 0) atomicAdd(p.g_bg + 4 * (tile & 63) + c, tot);
-      }
+      bg_grad_atomics(p, tile, lane, bgs);
     }
   }
   auto alive = [&](int j) { return !(Tr2[j >> 1][j & 1] < p.thresh); };
