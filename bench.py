@@ -455,6 +455,9 @@ def main():
                          "is measured the same way afterwards and reported in the same line.  heads: the timed region IS the "
                          "RGB + heads step (profiling: with --only-timed a kernel trace holds exactly its launches)")
     ap.add_argument("--no-heads", action="store_true", help="skip the RGB + heads pass")
+    ap.add_argument("--always-fallback", action="store_true",
+                    help="SH degree 3: enqueue the persistent exact fallback kernels with every batch (rounds 3-5) instead of only while the "
+                         "polynomial forward reports crowded tiles (gsgen_sh_view::route_report / no_fallback, round 6): same-box A/Bs")
     ap.add_argument("--no-heads-chol", action="store_true",
                     help="RGB + heads: stage the records with the fp64 preparation per staged (tile, Gaussian) record (rounds 1-5) instead of "
                          "reading what the projection launch prepared per (view, Gaussian) (gsgen_geometry_view::chol, round 6): same-box A/Bs")
@@ -591,6 +594,7 @@ def main():
     heads_moments = args.heads_grad_form == "moments"
     sh_moments = args.sh_grad_form == "moments"
     heads_chol = not args.no_heads_chol
+    route_hint = not args.always_fallback and not dry
     want_heads = (args.path == "heads" or not args.no_heads) and "color" in sc and not dry
     if want_heads:
         t["color"] = torch.tensor(sc["color"], device=dev)
@@ -640,6 +644,7 @@ def main():
             self.g_shared, self.n_shared = self.gflat[o:], Np + n_sh4
             self.g_mean, self.g_qvec, self.g_svec = self.g3d[:3 * N], self.g3d[3 * N:7 * N], self.g3d[7 * N:]
             self.tables, self.htables = {}, {}
+            self.route, self.route_clean, self.route_nf, self.route_set = (R.PairCountReport(1) if not dry else None), 0, 0, {}
 
         def _geo(self, k0, g0, stride, chan6):
             """gsgen_geometry_view table of the step whose first camera is k0; g0: the slot's per-view gradient blocks
@@ -776,6 +781,18 @@ def main():
             # maximum is a running one (no 4-byte fill launch per step; the slot zeroed it once: always an upper bound)
             clock.call("sh_bound", lib.sh_l1_bound_rows_running, N, p(t["sh"]), C, p(sl.bound), p(sl.rows), s)
             rows_p = p(sl.rows)
+            if route_hint:  # the exact fallbacks are enqueued only while crowded tiles are being reported (gsgen_sh_view::no_fallback)
+                t0 = time.perf_counter()
+                seen = int(sl.route._np[0, 0])
+                sl.route._np[0, 0] = 0
+                sl.route_clean = 0 if seen else sl.route_clean + 1
+                nf = 1 if sl.route_clean >= 3 else 0
+                if nf != sl.route_nf or not sl.route_set.get(id(views)):
+                    for i in range(B):
+                        views[i].route_report, views[i].no_fallback = sl.route.ptr(0), nf
+                    sl.route_nf, sl.route_set[id(views)] = nf, True
+                state["no_fallback_steps"] = state.get("no_fallback_steps", 0) + nf
+                clock.acc["route_hint"] = clock.acc.get("route_hint", 0.0) + time.perf_counter() - t0
         fork(sl, parts)
         geometry(sl, geo, p(sl.g_shared), sl.n_shared, parts)
         if ev is not None:
@@ -1315,6 +1332,10 @@ def main():
                                 f"of the slots' last steps went exact.  (Round 3's per-view rule on the global S: {n_poly_job} of "
                                 f"{ncam_job} cameras polynomial.)") if state["bounded"] else "exact per-pixel basis",
                    "tiles_exact_of_nonempty": [tiles_exact, tiles_nonempty],
+                   "exact_fallback_launches": ("only while the polynomial forward reports crowded tiles (gsgen_sh_view::route_report, a host-"
+                                               "visible word read without a sync): three clean reports in a row and they are no longer "
+                                               f"enqueued -- {state.get('no_fallback_steps', 0)} steps of this process ran without them"
+                                               if (route_hint and state["bounded"]) else "with every batch"),
                    "stress": {"focal_scale": args.focal_scale, "outlier_fraction": args.outlier_fraction},
                    "geometry_stream": "high priority, per slot" if args.geo_priority else "the slot's stream",
                    "parallelism": f"camera-sharded x{world}", "rccl_world_size": (dist.get_world_size() if dist is not None else 1),

@@ -21,7 +21,8 @@ class ShView(C.Structure):
     _fields_ = [("mean", vp), ("cov", vp), ("start", vp), ("end", vp), ("gaussian_ids", vp),
                 ("tile_order", vp), ("topleft", vp), ("c2w", vp), ("bg_rgb", vp),
                 ("pixel_size_x", f32), ("pixel_size_y", f32), ("out", vp), ("T", vp),
-                ("segment_workspace", vp), ("grad_out", vp), ("grad_mean", vp), ("grad_cov", vp)]
+                ("segment_workspace", vp), ("grad_out", vp), ("grad_mean", vp), ("grad_cov", vp), ("route_report", vp),
+                ("no_fallback", u32)]
 
 
 class RgbdView(C.Structure):

@@ -112,10 +112,12 @@ class _render_batch(torch.autograd.Function):
             bg_p = _p(bg_rgb)
             cis = br._cis
             if C > 0:
+                rr, nf = br._route_args
                 for i in range(B):
                     ci, v = cis[i], views[i]
                     v.pixel_size_x, v.pixel_size_y = 1.0 / ci.fx, 1.0 / ci.fy
                     v.T, v.bg_rgb, v.out = T_p + 4 * H * W * i, bg_p, out_p + 12 * H * W * i
+                    v.route_report, v.no_fallback = rr, nf
             else:
                 for i in range(B):
                     ci, v = cis[i], views[i]
@@ -336,6 +338,13 @@ class BatchRenderer:
         # the slots' pair counters live in one tensor (one copy brings a batch's counts to the host where a sync is wanted)
         self._totals = torch.zeros(max_batch, device=device, dtype=torch.int32)
         self._report = R.PairCountReport(max_batch)
+        # SH degree 3, per-tile routing: one more host-visible word -- "a tile crowded with splats beyond the bound was seen" -- written by
+        # the polynomial forward (gsgen_sh_view::route_report).  Three clean reports in a row and the persistent exact fallbacks are no
+        # longer enqueued (no_fallback: their workgroups, 152 registers each, otherwise have to find room on a full chip to discover
+        # that they have nothing to do -- 0.23 + 0.09 ms of stream time per step in flight in round 5's trace); one report brings them back.
+        self._route = R.PairCountReport(1)
+        self._route_clean = 0
+        self._route_args = (None, 0)
         self.strict = self.strict or self._report.unmapped  # (no report channel: size every batch with the read-back)
         self._gen = np.zeros(1, np.int64)  # the generation counter, in memory the C++ autograd node reads too
         self._plans = {}
@@ -712,17 +721,33 @@ class BatchRenderer:
         # every forward starts with the overflow check -- BEFORE the plan is fetched: a quiet regrow replaces the slots' lists and
         # the plan that points at them (the step it was triggered for used to run on the stale plan)
         self._begin_batch(B)
+        self._route_args = self._route_mode() if (int(C) == 4 and self._sh_rows is not None) else (None, 0)
         fast = self._plan("sh" if int(C) > 0 else "rgb", B)
         if fast is not None:  # one C++ autograd node (csrc/torch_batch.cpp): the same launches, a third of the host time
             self._last_parts = [(0, B)]
             va = fast[1]
             va["pixel_size_x"][:B] = 1.0 / self._intr[:B, 0]
             va["pixel_size_y"][:B] = 1.0 / self._intr[:B, 1]
+            if int(C) > 0:
+                va["route_report"][:B] = self._route_args[0] or 0
+                va["no_fallback"][:B] = self._route_args[1]
             out, T = _batch_ext().render(fast[0], mean, qvec, svec, alpha, col, bg_rgb, int(C), float(thresh), bool(detach_depth),
                                          self._sh_bound, self._sh_rows, *self._stats_args(stats))
             return out, T
         return _render_batch.apply(mean, qvec, svec, alpha, col, cams, self, B, int(C), bg_rgb, float(thresh),
                                    bool(detach_depth), stats)
+
+    def _route_mode(self):
+        """-> (device address of the crowded-tile report word or None, no_fallback 0 | 1) for the batch about to be enqueued: reads and
+        clears what earlier batches reported (plain host memory: no sync; an answer may be a batch or two late -- it is a hint, either
+        mode renders every tile correctly)"""
+        rep = self._route
+        if rep.ptr(0) is None:
+            return None, 0
+        seen = int(rep._np[0, 0])
+        rep._np[0, 0] = 0
+        self._route_clean = 0 if seen else self._route_clean + 1
+        return rep.ptr(0), 1 if self._route_clean >= 3 else 0
 
     def _measure_bound(self, col):
         """renderer.sh_row_bounds_device into the renderer's own [N] floats (read by this batch's forward and backward only)"""

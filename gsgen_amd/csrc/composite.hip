@@ -138,6 +138,14 @@ __device__ __forceinline__ GRec load_rec(const Stage<MODE, CB, KB, WC> &S, int g
 // ============================================================================================
 // forward
 // ============================================================================================
+// "a tile crowded with splats beyond the bound was seen" into the caller's host-visible word (pinned, device-mapped: a system-scope store)
+__device__ __forceinline__ void report_crowded_tile(uint32_t *word) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __hip_atomic_store(word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#else
+  *word = 1u;
+#endif
+}
 // A tile of a frame whose (tile, Gaussian) pairs did not fit the caller's list (start == kListOverflow, binning.hip): NaN in
 // every channel and in T.  A blank-but-finite view would train on silently; this one kills the loss.
 template <int NCH>
@@ -692,8 +700,12 @@ __device__ __forceinline__ void composite_fwd_sh_vec_tile(const CompParams &p, u
         if constexpr (NT != 64) exact_mask = sm.exact_mask;
         exact_mask = (uint32_t)__builtin_amdgcn_readfirstlane((int)exact_mask);
         if (__popcll((unsigned long long)exact_mask) * kExactTierShare > nb) {  // (uniform over the workgroup)
-          if (t == 0 && p.tile_flags != nullptr) p.tile_flags[tile] = 1;
-          return;
+          if (t == 0 && p.route_report != nullptr) report_crowded_tile(p.route_report);  // (the host's hint: CompParams::route_report)
+          if (!p.no_fallback) {
+            if (t == 0 && p.tile_flags != nullptr) p.tile_flags[tile] = 1;
+            return;
+          }
+          // no_fallback: no exact kernel runs behind this one -- the tile stays, its splats beyond the bound through the per-entry tier
         }
       } else {
         exact_mask = 0u;
@@ -2333,7 +2345,8 @@ static void launch_fwd_sh_batch_c(const CompParams &p0, const ViewPack<true> &pl
       if (p0.sh_rows != nullptr) {  // per-tile routing: the polynomial kernel flags the tiles the fallback BEHIND it renders
         if (p0.stop == nullptr) hipLaunchKernelGGL((k_composite_fwd_sh_vec<4, 4, true, kPolyNB, false>), g, dim3(64), 0, s, p0, plist);
         else hipLaunchKernelGGL((k_composite_fwd_sh_vec<4, 4, true, kPolyNB>), g, dim3(64), 0, s, p0, plist);
-        hipLaunchKernelGGL((k_composite_fwd_sh_vec<4, 2, true, kFallback>), dim3(gf), dim3(128), 0, s, pf, plist);
+        // (no_fallback: the caller's earlier batches reported no crowded tile -- nothing is handed over, nothing is launched)
+        if (!p0.no_fallback) hipLaunchKernelGGL((k_composite_fwd_sh_vec<4, 2, true, kFallback>), dim3(gf), dim3(128), 0, s, pf, plist);
         return;
       }
       launch_beside(
@@ -2374,7 +2387,10 @@ static void launch_bwd_sh_batch_c(const CompParams &p0, const ViewPack<true> &pl
       // routing this launch may carry a large share of the tiles (2 per SIMD until round 4, when it only ever took whole views)
       const uint32_t gf = pf.vgrid < 3072u ? pf.vgrid : 3072u;
       launch_beside(
-          s, [&](hipStream_t q) { hipLaunchKernelGGL((k_composite_bwd_sh_vec<4, 4, true, kFallback, MOM>), dim3(gf), dim3(64), 0, q, pf, plist); },
+          s, [&](hipStream_t q) {
+            if (p0.sh_rows != nullptr && p0.no_fallback) return;  // (as the forward: no tile was handed over)
+            hipLaunchKernelGGL((k_composite_bwd_sh_vec<4, 4, true, kFallback, MOM>), dim3(gf), dim3(64), 0, q, pf, plist);
+          },
           [&](hipStream_t q) { hipLaunchKernelGGL((k_composite_bwd_sh_vec<4, 4, true, kPolyNB, MOM>), g, dim3(64), 0, q, p0, plist); });
       return;
     }
@@ -2633,6 +2649,9 @@ static int fill_view_params(uint32_t n_views, const gsgen_sh_view *views, const 
     p.sh_bound = sh_bound;  // (both given: the view's bound first -- a scene within it skips the per-entry tests --, then the rows)
     p.sh_rows = sh_rows;
     p.tile_flags = (sh_rows != nullptr && tile_flags != nullptr) ? tile_flags + (size_t)b * ntw * nth : nullptr;
+    // (per-tile routing only: without per-splat bounds a view beyond the scene's bound is the fallback's as a whole)
+    p.route_report = sh_rows != nullptr ? v.route_report : nullptr;
+    p.no_fallback = (sh_rows != nullptr && views[0].no_fallback) ? 1 : 0;
     if (backward) {
       p.final_img = v.out; p.grad_out = v.grad_out;
       p.g_mean = v.grad_mean; p.g_cov = v.grad_cov; p.g_col = g_sh; p.g_alpha = g_alpha;

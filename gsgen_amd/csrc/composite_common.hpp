@@ -64,6 +64,10 @@ struct CompParams {
   // the projection launch once per (view, Gaussian)) -- staging reads them instead of running chol_prep's fp64 chain per staged
   // (tile, Gaussian) record in both kernels; the raw covariance is then fetched from `cov` only by the rare threshold guard.
   const float *chol;
+  // SH degree 3, per-tile routing (gsgen_sh_view::route_report / no_fallback): the host-visible word a crowded tile is reported in,
+  // and "no exact fallback is launched behind this kernel: keep every tile, take the per-entry exact tier"
+  uint32_t *route_report;
+  int no_fallback;
 };
 constexpr int kSegLen = 32;
 

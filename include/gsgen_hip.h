@@ -440,6 +440,17 @@ typedef struct gsgen_sh_view {
   void *segment_workspace;                 /* gsgen_segment_workspace_bytes, or NULL if n_segments <= 1 */
   const float *grad_out;                   /* backward: [H,W,3] */
   float *grad_mean, *grad_cov;             /* backward: [N,2], [N,2,2] of this view, accumulated into */
+  /* Round 6, optional (zero = as before), the *_routed launches with per-splat bounds (sh_row_bounds) only -- the persistent exact
+   * fallback kernels are launched only when they may have something to do:
+   *   route_report: one uint32 in HOST-visible memory (pinned + device-mapped, as pair_report): the polynomial forward stores 1 there
+   *     whenever a tile's staged batch holds more than a quarter of splats beyond the bound -- the condition that hands the tile to the
+   *     exact fallback.  No copy, no event, no sync; the host reads (and clears) it before a later batch.
+   *   no_fallback = 1 (the same in every view, forward and backward of a batch alike): the two fallback launches are NOT enqueued and
+   *     the polynomial kernels never hand a tile over -- every splat beyond the bound takes the per-entry exact tier instead, however
+   *     many a tile holds.  Always correct (the same colours within the routing's 1e-5), slower on tiles crowded with such splats:
+   *     meant for callers whose earlier batches reported none (gsgen_amd.BatchRenderer, bench.py: three clean reports in a row). */
+  uint32_t *route_report;
+  uint32_t no_fallback;
 } gsgen_sh_view;
 size_t gsgen_sh_batch_workspace_bytes(uint32_t n_views);
 int gsgen_vol_render_sh_batch(uint32_t n_views, const gsgen_sh_view *views, uint32_t N,

@@ -943,6 +943,87 @@ def test_emulated_sh_moment_form_equals_the_plain_backward(emu, C, nseg, routed)
         assert np.abs(x - y).max() <= 1e-5 * np.abs(x).max()
 
 
+def test_emulated_exact_fallback_only_when_crowded_tiles_are_reported(emu):
+    """Round 6, gsgen_sh_view::route_report / no_fallback: the polynomial forward tells the host -- one word of host-visible memory -- when
+    a tile crowded with splats beyond the bound turns up; with no_fallback the two persistent exact fallback launches are not enqueued
+    and such a tile stays with the polynomial kernels, its splats through the per-entry exact tier: the same image within the routing's
+    1e-5, the same gradients within the basis error, no tile flagged.  A clean scene reports nothing."""
+    from gsgen_amd._capi import ShView
+    C, W, H, nseg = 4, 64, 48, 0
+    sc = scenes.random_scene(300, seed=23, svec=0.048, spread=0.18, C=C)
+    sc["sh"][:, :, 1:] *= 0.0078
+    rng = np.random.default_rng(4)
+    lone = rng.choice(300, 4, replace=False)
+    centre = sc["mean"][int(rng.integers(300))]
+    outl = np.union1d(lone, np.argsort(np.linalg.norm(sc["mean"] - centre, axis=1))[:10])
+    sc["sh"][outl, :, 9:] = 3.0
+    sc["sh"][outl, :, 0] = 0.0
+    sc["alpha"] = (sc["alpha"] * 0.5).astype(np.float32)
+    N = sc["mean"].shape[0]
+    sh, al = np.ascontiguousarray(sc["sh"]), np.ascontiguousarray(sc["alpha"])
+    cams = [scenes.Camera(W, H, fx=130.0 + 15 * i, c2w=scenes.orbit(2.5, 10 + 20 * i, 40.0 + 100 * i)) for i in range(2)]
+    B = len(cams)
+    nth, ntw = cams[0].tiles
+    T = nth * ntw
+    rows = np.full(N, -1.0, np.float32); gmax = np.zeros(1, np.float32)
+    emu.sh_l1_bound_rows(N, P(sh), C, P(gmax), P(rows), None)
+    views = []
+    for i, cam in enumerate(cams):
+        g = scenes.oracle_geometry(sc, cam)
+        nz = np.nonzero(g["mask"])[0]
+        m2 = np.zeros((N, 2), np.float32); c2 = np.zeros((N, 2, 2), np.float32)
+        c2[:] = np.eye(2, dtype=np.float32)
+        m2[nz] = g["mean2d"]; c2[nz] = g["cov2d"]
+        views.append(dict(m2=m2, c2=c2, st=g["start"], en=g["end"], ids=nz[g["ids"]].astype(np.int32), tlp=cam.topleft,
+                          rot=np.ascontiguousarray(cam.c2w[:3, :3].reshape(-1)), cam=cam, bg=np.array([0.3, 0.1, 0.2], np.float32),
+                          go=np.random.default_rng(i).normal(size=(H, W, 3)).astype(np.float32)))
+
+    def launch(row_bounds, no_fallback, word):
+        arr = (ShView * B)()
+        res = []
+        for a, v in zip(arr, views):
+            cam = v["cam"]
+            r = dict(out=np.full((H, W, 3), 9.0, np.float32), T=np.full((H, W), 9.0, np.float32), gm=np.zeros((N, 2), np.float32),
+                     gc=np.zeros((N, 4), np.float32))
+            a.mean, a.cov, a.start, a.end, a.gaussian_ids = P(v["m2"]), P(v["c2"]), P(v["st"]), P(v["en"]), P(v["ids"])
+            a.tile_order, a.topleft, a.c2w, a.bg_rgb = None, P(v["tlp"]), P(v["rot"]), P(v["bg"])
+            a.pixel_size_x, a.pixel_size_y = 1 / cam.fx, 1 / cam.fy
+            a.out, a.T, a.segment_workspace = P(r["out"]), P(r["T"]), None
+            a.grad_out, a.grad_mean, a.grad_cov = P(v["go"]), P(r["gm"]), P(r["gc"])
+            a.route_report, a.no_fallback = P(word), no_fallback
+            res.append(r)
+        bws = np.full(emu.sh_batch_workspace_bytes_routed(B, T), 7, np.uint8)
+        emu.vol_render_sh_batch_routed(B, arr, N, P(sh), P(al), 16, nth, ntw, H, W, C, 1e-4, nseg, None, P(row_bounds), P(bws), None)
+        gsh = np.zeros_like(sh); ga = np.zeros(N, np.float32)
+        emu.vol_render_backward_sh_batch_routed_moments(B, arr, N, P(sh), P(al), P(gsh), P(ga), 16, nth, ntw, H, W, C, 1e-4, nseg, None,
+                                                        P(row_bounds), P(bws), None)
+        flags = bws[emu.sh_batch_workspace_bytes(B):][:B * T].reshape(B, T).copy()
+        return res, gsh, ga, flags
+
+    w_exact, w_routed, w_kept, w_clean = (np.zeros(1, np.uint32) for _ in range(4))
+    exact, e_gsh, e_ga, _ = launch(None, 0, w_exact)                      # the exact kernels
+    routed, r_gsh, r_ga, r_flags = launch(rows, 0, w_routed)             # polynomial + fallback behind flagged tiles
+    kept, k_gsh, k_ga, k_flags = launch(rows, 1, w_kept)                 # polynomial only, crowded tiles through the per-entry tier
+    assert w_exact[0] == 0 and w_routed[0] == 1 and w_kept[0] == 1
+    assert r_flags.any() and not k_flags.any()
+    for e, q, k in zip(exact, routed, kept):
+        assert np.array_equal(q["T"], e["T"]) and np.array_equal(k["T"], e["T"])
+        assert np.abs(q["out"] - e["out"]).max() <= 1e-5 and np.abs(k["out"] - e["out"]).max() <= 1e-5
+        for key in ("gm", "gc"):
+            sc_ = np.abs(e[key]).max()
+            assert np.abs(k[key] - e[key]).max() <= 2e-4 * sc_ and np.abs(q[key] - e[key]).max() <= 2e-4 * sc_
+    # (d L / d sh goes through the tile's polynomial basis for every entry -- off by <= 0.175 delta^3 = 1.2e-4 per unit here --, in either mode)
+    for got in ((r_gsh, r_ga), (k_gsh, k_ga)):
+        assert np.abs(got[0] - e_gsh).max() <= 5e-4 * np.abs(e_gsh).max() and np.abs(got[1] - e_ga).max() <= 2e-4 * np.abs(e_ga).max()
+    # a scene whose every splat is within the bound reports nothing, flags nothing
+    clean_rows = np.where(np.isin(np.arange(N), outl), 0.0, rows).astype(np.float32)
+    sh_keep = sh.copy()
+    sh[outl, :, 1:] = 0.0
+    _, _, _, c_flags = launch(clean_rows, 1, w_clean)
+    sh[:] = sh_keep
+    assert w_clean[0] == 0 and not c_flags.any()
+
+
 def test_emulated_rgb_heads_moment_form_equals_the_plain_backward(emu):
     """Round 6: gsgen_vol_render_rgbd_backward_batch_moments + gsgen_project_gaussians_backward_batch_heads_moments (ten components
     per (tile, Gaussian): r g b, one folded depth gradient, five moments of the per-pixel weight against the whitened offsets,

@@ -187,6 +187,50 @@ def test_outlier_splats_cost_their_entries_not_the_view():
     assert rel_err(out["auto"][2], out["exact"][2]) <= 1e-4
 
 
+def test_exact_fallbacks_are_enqueued_only_while_crowded_tiles_are_reported():
+    """Round 6: the polynomial forward reports tiles crowded with splats beyond the bound into a host-visible word
+    (gsgen_sh_view::route_report); BatchRenderer reads it without a sync and, after three clean reports in a row, stops enqueueing the
+    two persistent exact fallback launches (no_fallback) -- on a clean scene the images do not change by a bit.  A cluster of splats
+    with large higher bands is reported, brings the fallbacks back within a batch or two, and -- rendered in either mode -- stays
+    within 1e-5 of the exact kernels' image."""
+    from gsgen_amd import renderer as R
+    from gsgen_amd.batch import BatchRenderer
+    N, W, H, B = 20_000, 320, 240, 2
+    sc = scenes.pointe_scene(N, seed=4, C=4)
+    cams = [scenes.Camera(W, H, fx=400.0 + 40 * i, c2w=scenes.orbit(2.5, 10.0 + 25 * i, 20.0 + 80 * i)) for i in range(B)]
+    cis, c2ws = [R.CameraInfo(*c.intr) for c in cams], [c.c2w for c in cams]
+    P = {k: T_(sc[k]) for k in KEYS}
+    br = BatchRenderer(N, W, H, dev(), max_batch=B)
+    assert br._route.ptr(0) is not None
+    imgs, modes = [], []
+    for step in range(6):
+        sh = P["sh"].clone().requires_grad_(True)
+        rgb, _ = br.render(P["mean"], P["qvec"], P["svec"], P["alpha"], sh, cis, c2ws, C=4)
+        modes.append(br._route_args[1])
+        (rgb * rgb).sum().backward()
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(sh.grad).all())
+        imgs.append(rgb.detach().cpu().numpy())
+    assert modes[0] == 0 and modes[-1] == 1, modes          # the first batches carry the fallbacks, a clean scene drops them
+    for im in imgs[1:]:
+        assert np.array_equal(im, imgs[0])
+    # a crowded cluster appears: 300 neighbouring splats with higher bands 60 x larger
+    centre = sc["mean"][17]
+    near = np.argsort(np.linalg.norm(sc["mean"] - centre, axis=1))[:300]
+    sh_np = sc["sh"].copy()
+    sh_np[near, :, 1:] *= 60.0
+    sh_d = T_(sh_np)
+    exact = br.render(P["mean"], P["qvec"], P["svec"], P["alpha"], sh_d, cis, c2ws, C=4, sh_basis="exact")[0].cpu().numpy()
+    seen_modes = []
+    for step in range(5):
+        rgb = br.render(P["mean"], P["qvec"], P["svec"], P["alpha"], sh_d, cis, c2ws, C=4)[0]
+        seen_modes.append(br._route_args[1])
+        torch.cuda.synchronize()
+        assert np.abs(rgb.cpu().numpy() - exact).max() <= 1e-5, (step, seen_modes)
+    assert seen_modes[0] == 1 and seen_modes[-1] == 0, seen_modes   # reported by the first such batch: the fallbacks are back
+    assert bool(br.routing_flags(B).any())
+
+
 def test_routed_launches_fuzz_against_the_exact_kernels():
     """hypothesis on the GPU over the launches BatchRenderer runs by default at SH degree 3: 1 .. 4 cameras of ragged shapes and
     focal lengths on both sides of the bound, 1 .. 4000 splats of any size, coefficient magnitudes over two decades, opaque
