@@ -125,7 +125,7 @@ def heads_alg_bytes(N, D, P, T):
 def committed_traffic(config, kernel, views):
     """HBM bytes per launch of `kernel` from committed PMC passes (profiles/rNN_traffic.json), if they are of THIS kernel,
     workload and launch shape: (bytes, valu_floor_ms, source) or (None, None, None)"""
-    for fn_ in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json"):
+    for fn_ in ("r06_traffic.json", "r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json"):
         try:
             ent = json.load(open(os.path.join(ROOT, "profiles", fn_))).get(f"{config}|{kernel}|views={views}")
         except Exception:
@@ -140,7 +140,7 @@ def committed_traffic(config, kernel, views):
 def committed_trace_ms(config, fragment, suffix=""):
     """the kernel's average duration in the committed rocprofv3 kernel trace of this command (--only-timed)"""
     import csv
-    for rnd in ("r05", "r04", "r03"):
+    for rnd in ("r06", "r05", "r04", "r03"):
         fn_ = os.path.join(ROOT, "profiles", f"{rnd}_bench_{config}{suffix}_kernel_stats.csv")
         try:
             for row in csv.DictReader(open(fn_)):
@@ -827,7 +827,7 @@ def main():
             clock.call("events", ev[3].record, stream)
         join(sl, parts)
         clock.call("project_bwd", sh_proj_bwd, B, N, p(t["mean"]), p(t["qvec"]), p(t["svec"]), *proj,
-                   p(sl.g_mean), p(sl.g_qvec), p(sl.g_svec), s)
+                   p(sl.g_mean), p(sl.g_qvec), p(sl.g_svec), *((None, None) if sh_moments else ()), s)
         if sl.geo_stream is not stream:
             sl.e_done.record(stream)
             sl.started = True
@@ -873,7 +873,7 @@ def main():
             clock.call("events", ev[3].record, stream)
         join(sl, parts)
         clock.call("project_bwd", heads_proj_bwd, B, N, p(t["mean"]), p(t["qvec"]), p(t["svec"]), *proj,
-                   p(sl.g_mean), p(sl.g_qvec), p(sl.g_svec), p(sl.h_color), s)
+                   p(sl.g_mean), p(sl.g_qvec), p(sl.g_svec), p(sl.h_color), *((None, None) if heads_moments else ()), s)
         if sl.geo_stream is not stream:
             sl.e_done.record(stream)
             sl.started = True
@@ -1069,7 +1069,7 @@ def main():
         val = world * B * K / m["el"]
         ach_ = B * parts_h["composite_bwd"] / (m["bwd_ms"] * 1e-3) / 1e9
         tr, vf, tr_src = committed_traffic(args.config, bname, B)
-        tms, tms_src = committed_trace_ms(args.config, "k_composite_bwd_chan_vec<3, true>", "_heads")
+        tms, tms_src = committed_trace_ms(args.config, "k_composite_bwd_chan_vec<3, true, true>" if heads_moments else "k_composite_bwd_chan_vec<3, true, false>", "_heads")
         rf = {"bound": "hbm", "kernel": bname, "achieved": ach_, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_ / HBM_PEAK_GBS,
               "traffic": tr, "traffic_source": tr_src, "alg_bytes_per_launch": B * parts_h["composite_bwd"],
               "alg_bytes_formula": "SURVEY 8(d) with F = 13: (4 + 4F) D + 52 P + 4F D per view (bench.heads_alg_bytes)",
@@ -1311,7 +1311,8 @@ def main():
     bwd_name = lib.kernel_variant("sh_bwd_batch_poly" if poly_applies else "sh_bwd_batch", C, nseg)
     fwd_name = lib.kernel_variant("sh_fwd_batch_poly" if poly_applies else "sh_fwd_batch", C, nseg)
     traffic, valu_floor, traffic_src = committed_traffic(args.config, bwd_name, B)
-    frag = "k_composite_bwd_sh_vec<4, 4, true, 6>" if poly_applies else "k_composite_bwd_sh_vec<4, 4, true, 0>"
+    mom_ = "true" if sh_moments else "false"  # (round 6: <..., MOM>; committed traces of round 5 hold the shorter names)
+    frag = f"k_composite_bwd_sh_vec<4, 4, true, 6, {mom_}>" if poly_applies else f"k_composite_bwd_sh_vec<4, 4, true, 0, {mom_}>"
     trace_ms, trace_src = committed_trace_ms(args.config, frag) if C == 4 else (None, None)
     ach = B * parts["composite_bwd"] / (bwd_ms * 1e-3) / 1e9
     els = [r_["el"] for r_ in regions]

@@ -39,7 +39,8 @@ class GeometryView(C.Structure):
     """gsgen_geometry_view (include/gsgen_hip.h): one camera of a batched geometry enqueue."""
     _fields_ = [("cam", vp), ("mean2d", vp), ("cov2d", vp), ("depth", vp), ("mask", vp), ("gaussian_ids", vp),
                 ("start", vp), ("end", vp), ("total", vp), ("workspace", vp), ("workspace_bytes", sz), ("D_cap", u32),
-                ("zero_grad_mean2d", vp), ("zero_grad_cov2d", vp), ("zero_grad_chan6", vp), ("pair_report", vp), ("chol", vp)]
+                ("zero_grad_mean2d", vp), ("zero_grad_cov2d", vp), ("zero_grad_chan6", vp), ("pair_report", vp), ("chol", vp),
+                ("max_radii2d", vp)]
 
 
 # name -> argtypes, in the order of include/gsgen_hip.h
@@ -67,10 +68,10 @@ SIGNATURES = {
     "gsgen_project_gaussians_backward_batch_heads": [u32, u32, vp, vp, vp, C.POINTER(vp), i32, C.POINTER(vp), C.POINTER(vp),
                                                      C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp, vp, vp, vp, vp],
     "gsgen_project_gaussians_backward_batch_moments_sh": [u32, u32, vp, vp, vp, C.POINTER(vp), i32, C.POINTER(vp), C.POINTER(vp),
-                                                          C.POINTER(vp), C.POINTER(vp), vp, vp, vp, vp],
+                                                          C.POINTER(vp), C.POINTER(vp), vp, vp, vp, vp, vp, vp],
     "gsgen_project_gaussians_backward_batch_heads_moments": [u32, u32, vp, vp, vp, C.POINTER(vp), i32, C.POINTER(vp), C.POINTER(vp),
                                                              C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
-                                                             vp, vp, vp, vp, vp],
+                                                             vp, vp, vp, vp, vp, vp, vp],
     "gsgen_sh_l1_bound_rows": [u32, vp, u32, vp, vp, vp],
     "gsgen_sh_l1_bound_rows_running": [u32, vp, u32, vp, vp, vp],
     "gsgen_vol_render_sh_batch_routed": [u32, C.POINTER(ShView), u32, vp, vp, u32, u32, u32, u32, u32, u32, f32, u32, vp, vp, vp, vp],

@@ -108,7 +108,7 @@ class _render_batch(torch.autograd.Function):
         gsh = torch.empty(br._Np + (col.numel() + 3) // 4 * 4, device=dev, dtype=torch.float32)
         with _on(dev):
             parts = br._fork(B)
-            views = br._geometry(kind, B, parts, mean, qvec, svec, gsh)
+            views = br._geometry(kind, B, parts, mean, qvec, svec, gsh, stats)
             bg_p = _p(bg_rgb)
             cis = br._cis
             if C > 0:
@@ -132,9 +132,6 @@ class _render_batch(torch.autograd.Function):
                     lib.vol_render_rgb_batch(n, _sub(views, lo, n), N, _p(col), _p(alpha), 16, nth, ntw, H, W, thresh,
                                              _p(br._bws[k]), s)
             br._join(parts)
-            if stats is not None:
-                lib.densify_update_batch(B, N, br._ptr_table("cov2d", B), None, br._mask_table(B), _p(stats.max_radii2d), None,
-                                         None, parts[0][2])
         if C == 0 and bg_rgb is not None:
             out = out + T * bg_rgb  # gs/renderer.py:1182; `out` (saved below) is what the backward reads as final
             for i in range(B):
@@ -185,18 +182,19 @@ class _render_batch(torch.autograd.Function):
                                                       nth, ntw, H, W, thresh, _p(br._bws[k]), s)
             br._join(parts)
             s = parts[0][2]
-            if C > 0:
+            acc = stats.grad_accum if stats is not None else None
+            if C > 0:  # (the backward's statistics -- sum |d L / d mean2d|, visits -- are summed by this launch itself)
                 lib.project_gaussians_backward_batch_moments_sh(B, N, _p(mean), _p(qvec), _p(svec), br._ptr_table("cam", B),
                                                                 int(ctx.detach), br._mask_table(B), br._ptr_table("g_mean2d", B),
                                                                 br._ptr_table("g_cov2d", B), br._ptr_table("cov2d", B), _p(g_mean),
-                                                                _p(g_qvec), _p(g_svec), s)
+                                                                _p(g_qvec), _p(g_svec), _p(acc), _p(stats.cnt) if acc is not None else None, s)
             else:
                 lib.project_gaussians_backward_batch(B, N, _p(mean), _p(qvec), _p(svec), br._ptr_table("cam", B),
                                                      int(ctx.detach), br._mask_table(B), br._ptr_table("g_mean2d", B),
                                                      br._ptr_table("g_cov2d", B), None, _p(g_mean), _p(g_qvec), _p(g_svec), s)
-            if stats is not None and stats.grad_accum is not None:
-                lib.densify_update_batch(B, N, None, br._ptr_table("g_mean2d", B), br._mask_table(B), None,
-                                         _p(stats.grad_accum), _p(stats.cnt), s)
+                if acc is not None:
+                    lib.densify_update_batch(B, N, None, br._ptr_table("g_mean2d", B), br._mask_table(B), None,
+                                             _p(stats.grad_accum), _p(stats.cnt), s)
         return (g_mean, g_qvec, g_svec, g_alpha, g_col, None, None, None, None, _bg_grad(ctx, grad, T), None, None, None)
 
 
@@ -232,7 +230,7 @@ class _render_batch_heads(torch.autograd.Function):
         bg_keep, bg_ptrs = _bg_rows(bg_rgb, B)
         with _on(dev):
             parts = br._fork(B)
-            views = br._geometry("rgbd", B, parts, mean, qvec, svec, gsh)
+            views = br._geometry("rgbd", B, parts, mean, qvec, svec, gsh, stats)
             cis = br._cis
             for i in range(B):
                 ci, v = cis[i], views[i]
@@ -247,9 +245,6 @@ class _render_batch_heads(torch.autograd.Function):
                 lib.vol_render_rgbd_batch(n, _sub(views, lo, n), N, _p(col), _p(alpha), 16, nth, ntw, H, W, thresh,
                                           _p(br._bws[k]), s)
             br._join(parts)
-            if stats is not None:
-                lib.densify_update_batch(B, N, br._ptr_table("cov2d", B), None, br._mask_table(B),
-                                         _p(stats.max_radii2d), None, None, parts[0][2])
         ctx.gen = br._generation
         ctx.views, ctx.gsh, ctx.parts = views, gsh, [(lo, n) for lo, n, _ in parts]
         ctx.save_for_backward(mean, qvec, svec, alpha, col, cams, rgb, dep, opa, zz, T)
@@ -304,10 +299,8 @@ class _render_batch_heads(torch.autograd.Function):
                                                                br._ptr_table("g_cov2d", B), br._ptr_table("g_chan6", B),
                                                                br._ptr_table("depth", B), br._ptr_table("cov2d", B),
                                                                br._ptr_table("chol", B), _p(g_mean), _p(g_qvec), _p(g_svec),
-                                                               _p(g_col), s)
-            if stats is not None and stats.grad_accum is not None:
-                lib.densify_update_batch(B, N, None, br._ptr_table("g_mean2d", B), br._mask_table(B), None,
-                                         _p(stats.grad_accum), _p(stats.cnt), s)
+                                                               _p(g_col), _p(stats.grad_accum) if stats is not None else None,
+                                                               _p(stats.cnt) if (stats is not None and stats.grad_accum is not None) else None, s)
         g_bg = None
         if ctx.bg_grad and g_rgb is not None:
             g_bg = gsh[br._Np:br._Np + 256 * B].view(B, 64, 4)[..., :3].sum(1).view(B, 1, 1, 3).sum_to_size(ctx.bg_shape)
@@ -574,7 +567,7 @@ class BatchRenderer:
             self._ev[1].record(self._side)
             torch.cuda.current_stream(self.device).wait_event(self._ev[1])
 
-    def _geometry(self, kind, B, parts, mean, qvec, svec, gsh):
+    def _geometry(self, kind, B, parts, mean, qvec, svec, gsh, stats=None):
         """the geometry chain of every part (the first one zero-fills the shared gradient block) -> the view table.  While
         the lists are unsized (or strict) the counts are read back -- one host sync -- and, if a camera's pairs did not
         fit, all lists are regrown and the batch binned again: lossless."""
@@ -583,6 +576,9 @@ class BatchRenderer:
         sync = self.slots[0].needs_sync_sizing() if B else False
         while True:
             geo, views = self._tables(kind)
+            mr = _p(stats.max_radii2d) if stats is not None else None  # the forward's statistic, raised by the projection launch
+            for i in range(B):
+                geo[i].max_radii2d = mr
             for k, (lo, n, s) in enumerate(parts):
                 lib.frame_geometry_batch_zero(n, _sub(geo, lo, n), N, _p(mean), _p(qvec), _p(svec), self.W, self.H,
                                               _p(gsh) if k == 0 else None, gsh.numel() if k == 0 else 0,

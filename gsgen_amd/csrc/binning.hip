@@ -32,7 +32,7 @@
 namespace gs {
 
 constexpr int kGroup = 8;      // tiles per group side: 8x8 tiles <-> 64 lanes
-constexpr int kChunk = 2048;   // Gaussians per chunk
+constexpr int kChunk = 2048;   // Gaussians per chunk (round 6: 1 024 and 512 measured -- twice / four times the workgroups for the push kernels -- no gain: profiles/r06_s10_*)
 
 struct GroupGeom {
   int gx0, gy0, tx, ty, tile;
@@ -879,7 +879,7 @@ int gsgen_frame_geometry_batch_zero(uint32_t n_views, const gsgen_geometry_view 
     g.ctrl = w.ctrl; g.tile_order = w.tile_order; g.keys = w.keys;
     g.ids = v.gaussian_ids; g.start = v.start; g.end = v.end; g.total = v.total; g.cap = v.D_cap; g.report = v.pair_report;
     g.z_mean2d = v.zero_grad_mean2d; g.z_cov2d = v.zero_grad_cov2d; g.z_chan6 = v.zero_grad_chan6;
-    g.chol = v.chol;
+    g.chol = v.chol; g.max_r = v.max_radii2d;
     if ((reinterpret_cast<uintptr_t>(g.z_mean2d) & 7u) || (reinterpret_cast<uintptr_t>(g.z_cov2d) & 15u) ||
         (reinterpret_cast<uintptr_t>(g.z_chan6) & 7u) || (reinterpret_cast<uintptr_t>(g.chol) & 15u))
       return GSGEN_EINVAL;

@@ -497,6 +497,7 @@ struct GeoView {
   // the projection launch, which touches every Gaussian of the view anyway (gsgen_frame_geometry_batch_zero)
   float *z_mean2d, *z_cov2d, *z_chan6;
   float *chol;  // optional [N,4]: (p0, p1, p2, ok) of chol_prep per Gaussian of the view, for the batched RGB / RGB + heads compositing launches
+  float *max_r;  // optional [N], shared by the views: running maximum of the screen-space radius (gs/gaussian_splatting.py:1240-1245)
 };
 
 }  // namespace gs

@@ -462,13 +462,14 @@ __global__ void __launch_bounds__(kThreads)
 k_project_bwd_views(uint32_t N, const float *__restrict__ mean, const float *__restrict__ qvec,
                     const float *__restrict__ svec, ProjBwdViews pv, int n_views, int detach_depth, int accumulate,
                     int moments, float *__restrict__ g_mean, float *__restrict__ g_qvec, float *__restrict__ g_svec,
-                    float *__restrict__ g_color) {
-  __shared__ float part[kPbvLanes - 1][13][kPbvGauss];  // the other view lanes' partial sums, [component][Gaussian]: conflict-free
+                    float *__restrict__ g_color, float *__restrict__ stat_accum, float *__restrict__ stat_cnt) {
+  __shared__ float part[kPbvLanes - 1][15][kPbvGauss];  // the other view lanes' partial sums, [component][Gaussian]: conflict-free
   const int gl = (int)(threadIdx.x & (kPbvGauss - 1)), vq = (int)(threadIdx.x / kPbvGauss);
   const uint32_t n = blockIdx.x * kPbvGauss + gl;
   const bool live = n < N;
   ProjGrad a;
   float gc[3] = {0.f, 0.f, 0.f};
+  float gsum = 0.f, visits = 0.f;  // the densify statistics of the backward (gs/gaussian_splatting.py:464-469): sum |d L / d mean2d|, visits
 #pragma unroll
   for (int j = 0; j < 3; ++j) { a.gm[j] = 0.f; a.gs[j] = 0.f; }
 #pragma unroll
@@ -504,8 +505,18 @@ k_project_bwd_views(uint32_t N, const float *__restrict__ mean, const float *__r
         // the view's d L / d mean2d in place of its two first moments: the densify statistics read it (gsgen_densify_update_batch,
         // gs/gaussian_splatting.py:464-469)
         *reinterpret_cast<float2 *>(const_cast<float *>(pv.g_mean2d[v]) + 2 * (size_t)n) = make_float2((float)gm0, (float)gm1);
+        if (stat_accum != nullptr) {
+          const float gx = (float)gm0, gy = (float)gm1;
+          gsum += sqrtf(gx * gx + gy * gy);
+          visits += 1.0f;
+        }
         o = project_bwd_one(n, mean, qvec, svec, pv.cam[v], detach_depth, gm0, gm1, gcv, gd);
       } else {
+        if (stat_accum != nullptr) {
+          const float2 g2 = *reinterpret_cast<const float2 *>(pv.g_mean2d[v] + 2 * (size_t)n);
+          gsum += sqrtf(g2.x * g2.x + g2.y * g2.y);
+          visits += 1.0f;
+        }
         o = project_bwd_one(n, mean, qvec, svec, pv.cam[v], detach_depth, pv.g_mean2d[v], pv.g_cov2d[v], gd);
       }
 #pragma unroll
@@ -520,6 +531,7 @@ k_project_bwd_views(uint32_t N, const float *__restrict__ mean, const float *__r
     for (int j = 0; j < 3; ++j) { mine[j][gl] = a.gm[j]; mine[3 + j][gl] = a.gs[j]; mine[10 + j][gl] = gc[j]; }
 #pragma unroll
     for (int k = 0; k < 4; ++k) mine[6 + k][gl] = a.gq[k];
+    mine[13][gl] = gsum; mine[14][gl] = visits;
   }
   __syncthreads();
   if (vq > 0 || !live) return;
@@ -531,6 +543,11 @@ k_project_bwd_views(uint32_t N, const float *__restrict__ mean, const float *__r
     for (int j = 0; j < 3; ++j) { a.gm[j] += part[q][j][gl]; a.gs[j] += part[q][3 + j][gl]; gc[j] += part[q][10 + j][gl]; }
 #pragma unroll
     for (int k = 0; k < 4; ++k) a.gq[k] += part[q][6 + k][gl];
+    gsum += part[q][13][gl]; visits += part[q][14][gl];
+  }
+  if (stat_accum != nullptr && visits > 0.0f) {  // (atomics: other batches may be updating the same statistics from other streams)
+    atomicAdd(stat_accum + n, gsum);
+    if (stat_cnt != nullptr) atomicAdd(stat_cnt + n, visits);
   }
   if (accumulate) {
 #pragma unroll
@@ -601,7 +618,8 @@ __device__ __forceinline__ void
 frame_project_body(uint32_t N, const float *__restrict__ mean, const float *__restrict__ qvec,
                 const float *__restrict__ svec, const float *__restrict__ cam, int w, int h, int ntw,
                 float *__restrict__ mean2d, float *__restrict__ cov2d, float *__restrict__ depth,
-                uint8_t *__restrict__ mask, int *__restrict__ tl, int *__restrict__ br, float *__restrict__ chol = nullptr) {
+                uint8_t *__restrict__ mask, int *__restrict__ tl, int *__restrict__ br, float *__restrict__ chol = nullptr,
+                float *__restrict__ max_radii2d = nullptr) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   float Rc[9], t[3];
@@ -630,6 +648,15 @@ frame_project_body(uint32_t N, const float *__restrict__ mean, const float *__re
   if (chol != nullptr) {  // the compositing kernels' evaluation record, once per (view, Gaussian) (gsgen_geometry_view::chol)
     const CholRec c = chol_prep(c2.x, c2.y, c2.z, c2.w);
     *reinterpret_cast<float4 *>(chol + 4 * (size_t)i) = make_float4(c.p0, c.p1, c.p2, (in && c.ok) ? 1.0f : 0.0f);
+  }
+  if (max_radii2d != nullptr && in) {
+    // the densify / prune statistic of the forward (gs/gaussian_splatting.py:1240-1245; k_densify_update_views: the same arithmetic), in
+    // the launch that forms cov2d anyway: a NaN radius sticks, a negative one never raises the maximum
+    const float mm = (c2.x + c2.w) / 2.0f;
+    const float det = c2.x * c2.w - c2.y * c2.z;
+    const float r = mm + sqrtf(fmaxf(mm * mm - det, 0.0f));
+    if (r != r) atomicMax(reinterpret_cast<unsigned int *>(max_radii2d) + i, 0x7fc00000u);
+    else if (!(r < 0.0f)) atomicMax(reinterpret_cast<unsigned int *>(max_radii2d) + i, __float_as_uint(r));
   }
   depth[i] = z;
   mask[i] = in ? 1 : 0;
@@ -675,7 +702,7 @@ k_frame_project_views(uint32_t N, const float *__restrict__ mean, const float *_
       z[0] = z[1] = z[2] = make_float2(0.f, 0.f);
     }
   }
-  frame_project_body(N, mean, qvec, svec, v.cam, w, h, ntw, v.mean2d, v.cov2d, v.depth, v.mask, v.tl, v.br, v.chol);
+  frame_project_body(N, mean, qvec, svec, v.cam, w, h, ntw, v.mean2d, v.cov2d, v.depth, v.mask, v.tl, v.br, v.chol, v.max_r);
 }
 
 static inline dim3 grid_for(uint32_t n) { return dim3((n + kThreads - 1) / kThreads); }
@@ -773,7 +800,8 @@ static int project_bwd_batch(uint32_t n_views, uint32_t N, const float *mean, co
                              const float *const *g_mean2d, const float *const *g_cov2d, const float *const *g_depth,
                              const float *const *g_chan6, const float *const *depth, float *g_mean, float *g_qvec,
                              float *g_svec, float *g_color, gsgen_stream_t stream, const float *const *cov2d = nullptr,
-                             int moments_form = 1, const float *const *chol = nullptr) {
+                             int moments_form = 1, const float *const *chol = nullptr, float *stat_accum = nullptr,
+                             float *stat_cnt = nullptr) {
   if (N == 0) return 0;
   if (!mean || !qvec || !svec || !g_mean || !g_qvec || !g_svec) return GSGEN_EINVAL;
   if (n_views && (!c2w || !g_mean2d || !g_cov2d)) return GSGEN_EINVAL;
@@ -799,7 +827,8 @@ static int project_bwd_batch(uint32_t n_views, uint32_t N, const float *mean, co
       pv.chol[i] = chol ? chol[v0 + i] : nullptr;
     }
     hipLaunchKernelGGL(k_project_bwd_views, dim3((N + kPbvGauss - 1) / kPbvGauss), dim3(kThreads), 0, (hipStream_t)stream, N, mean, qvec,
-                       svec, pv, (int)nv, detach_depth, v0 ? 1 : 0, cov2d ? moments_form : 0, g_mean, g_qvec, g_svec, g_color);
+                       svec, pv, (int)nv, detach_depth, v0 ? 1 : 0, cov2d ? moments_form : 0, g_mean, g_qvec, g_svec, g_color,
+                       stat_accum, stat_cnt);
     v0 += nv;
   } while (v0 < n_views);
   return (int)hipGetLastError();
@@ -829,10 +858,11 @@ int gsgen_project_gaussians_backward_batch_moments_sh(uint32_t n_views, uint32_t
                                                       const float *svec, const float *const *c2w, int detach_depth,
                                                       const uint8_t *const *mask, float *const *g_mom2,
                                                       const float *const *g_mom4, const float *const *cov2d, float *g_mean,
-                                                      float *g_qvec, float *g_svec, gsgen_stream_t stream) {
+                                                      float *g_qvec, float *g_svec, float *stat_grad_accum, float *stat_cnt,
+                                                      gsgen_stream_t stream) {
   if (!cov2d) return GSGEN_EINVAL;
   return project_bwd_batch(n_views, N, mean, qvec, svec, c2w, detach_depth, mask, g_mom2, g_mom4, nullptr, nullptr, nullptr, g_mean,
-                           g_qvec, g_svec, nullptr, stream, cov2d, 2);
+                           g_qvec, g_svec, nullptr, stream, cov2d, 2, nullptr, stat_grad_accum, stat_cnt);
 }
 
 int gsgen_project_gaussians_backward_batch_heads_moments(uint32_t n_views, uint32_t N, const float *mean, const float *qvec,
@@ -841,10 +871,11 @@ int gsgen_project_gaussians_backward_batch_heads_moments(uint32_t n_views, uint3
                                                          const float *const *g_mom4, const float *const *g_chan6,
                                                          const float *const *depth, const float *const *cov2d,
                                                          const float *const *chol, float *g_mean, float *g_qvec, float *g_svec,
-                                                         float *g_color, gsgen_stream_t stream) {
+                                                         float *g_color, float *stat_grad_accum, float *stat_cnt,
+                                                         gsgen_stream_t stream) {
   if (!g_chan6 || !depth || !g_color || !cov2d) return GSGEN_EINVAL;
   return project_bwd_batch(n_views, N, mean, qvec, svec, c2w, detach_depth, mask, g_mom2, g_mom4, nullptr, g_chan6, depth,
-                           g_mean, g_qvec, g_svec, g_color, stream, cov2d, 1, chol);
+                           g_mean, g_qvec, g_svec, g_color, stream, cov2d, 1, chol, stat_grad_accum, stat_cnt);
 }
 
 // Host side: the 56-float camera block of gsgen_frame_geometry.  Frustum planes as

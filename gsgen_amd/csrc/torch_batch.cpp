@@ -160,12 +160,14 @@ struct HeadsFn : public torch::autograd::Function<HeadsFn> {
       v[i].grad_bg = bg_grad_wanted ? gsh.data_ptr<float>() + p.Np + 256 * i : nullptr;
       v[i].depth_variance = z_var ? 1u : 0u;
     }
+    {  // the forward's densify statistic (max_radii2d) is raised by the projection launch itself (gsgen_geometry_view::max_radii2d)
+      gsgen_geometry_view *gv = tab<gsgen_geometry_view>(p.geo);
+      float *mr = max_radii2d.defined() ? max_radii2d.data_ptr<float>() : nullptr;
+      for (int64_t i = 0; i < B; ++i) gv[i].max_radii2d = mr;
+    }
     GS(gsgen_frame_geometry_batch_zero((uint32_t)B, tab<gsgen_geometry_view>(p.geo), (uint32_t)N, mean.data_ptr<float>(),
                                        qvec.data_ptr<float>(), svec.data_ptr<float>(), (uint32_t)W, (uint32_t)H,
                                        gsh.data_ptr<float>(), (size_t)gsh.numel(), tab<void>(p.gws), s));
-    if (max_radii2d.defined())
-      GS(gsgen_densify_update_batch((uint32_t)B, (uint32_t)N, tab<const float *const>(p.cov2d_tab), nullptr,
-                                    tab<const uint8_t *const>(p.mask_tab), max_radii2d.data_ptr<float>(), nullptr, nullptr, s));
     GS(gsgen_vol_render_rgbd_batch((uint32_t)B, v, (uint32_t)N, color.data_ptr<float>(), alpha.data_ptr<float>(), 16,
                                    (uint32_t)p.nth, (uint32_t)p.ntw, (uint32_t)H, (uint32_t)W, (float)thresh, tab<void>(p.bws), s));
     ctx->save_for_backward({mean, qvec, svec, alpha, color, rgb, dep, opa, zz, T, bg, bg_keep});
@@ -216,8 +218,19 @@ struct HeadsFn : public torch::autograd::Function<HeadsFn> {
       v[i].grad_depth2 = pp[3] ? pp[3] + H * W * i : nullptr;
       v[i].grad_bg = bg_grad_wanted ? gsh.data_ptr<float>() + p.Np + 256 * i : nullptr;
     }
+    // the backward's densify statistics (sum |d L / d mean2d|, visits: gs/gaussian_splatting.py:464-469) are summed by the projection
+    // backward itself, which holds every view's d L / d mean2d in registers
+    float *stat_acc = nullptr, *stat_cnt = nullptr;
+    {
+      const auto &ga = ctx->saved_data["grad_accum"];
+      if (ga.isTensor() && ga.toTensor().defined()) {
+        stat_acc = ga.toTensor().data_ptr<float>();
+        const Tensor cnt = ctx->saved_data["cnt"].toTensor();
+        stat_cnt = cnt.defined() ? cnt.data_ptr<float>() : nullptr;
+      }
+    }
     // the moment form (round 6): ten components per (tile, Gaussian) cross the lanes instead of thirteen; the projection backward
-    // expands the moments per (view, Gaussian) and leaves d L / d mean2d in the per-view blocks for the densify statistics below
+    // expands the moments per (view, Gaussian)
     GS(gsgen_vol_render_rgbd_backward_batch_moments((uint32_t)B, v, (uint32_t)N, color.data_ptr<float>(), alpha.data_ptr<float>(),
                                                     gsh.data_ptr<float>(), 16, (uint32_t)p.nth, (uint32_t)p.ntw, (uint32_t)H,
                                                     (uint32_t)W, (float)ctx->saved_data["thresh"].toDouble(), tab<void>(p.bws), s));
@@ -227,14 +240,7 @@ struct HeadsFn : public torch::autograd::Function<HeadsFn> {
         tab<float *const>(p.gmean_tab), tab<const float *const>(p.gcov_tab), tab<const float *const>(p.gchan_tab),
         tab<const float *const>(p.depth_tab), tab<const float *const>(p.cov2d_tab),
         p.chol_tab ? tab<const float *const>(p.chol_tab) : nullptr, g_mean.data_ptr<float>(), g_qvec.data_ptr<float>(),
-        g_svec.data_ptr<float>(), g_col.data_ptr<float>(), s));
-    const auto &ga = ctx->saved_data["grad_accum"];
-    if (ga.isTensor() && ga.toTensor().defined()) {
-      Tensor acc = ga.toTensor(), cnt = ctx->saved_data["cnt"].toTensor();
-      GS(gsgen_densify_update_batch((uint32_t)B, (uint32_t)N, nullptr, tab<const float *const>(p.gmean_tab),
-                                    tab<const uint8_t *const>(p.mask_tab), nullptr, acc.data_ptr<float>(),
-                                    cnt.defined() ? cnt.data_ptr<float>() : nullptr, s));
-    }
+        g_svec.data_ptr<float>(), g_col.data_ptr<float>(), stat_acc, stat_cnt, s));
     Tensor g_bg;
     if (bg_grad_wanted && ctx->needs_input_grad(5) && g[0].defined())  // the 64 partial rows of every view -> [B,1,1,3] -> bg's shape
       g_bg = gsh.narrow(0, p.Np, 256 * B).view({B, 64, 4}).slice(-1, 0, 3).sum(1).view({B, 1, 1, 3}).sum_to_size(bg.sizes());
@@ -276,12 +282,14 @@ struct RenderFn : public torch::autograd::Function<RenderFn> {
       gsgen_rgbd_view *v = tab<gsgen_rgbd_view>(p.views);
       for (int64_t i = 0; i < B; ++i) { v[i].out6 = o + 3 * H * W * i; v[i].T = t + H * W * i; }
     }
+    {  // the forward's densify statistic (max_radii2d) is raised by the projection launch itself (gsgen_geometry_view::max_radii2d)
+      gsgen_geometry_view *gv = tab<gsgen_geometry_view>(p.geo);
+      float *mr = max_radii2d.defined() ? max_radii2d.data_ptr<float>() : nullptr;
+      for (int64_t i = 0; i < B; ++i) gv[i].max_radii2d = mr;
+    }
     GS(gsgen_frame_geometry_batch_zero((uint32_t)B, tab<gsgen_geometry_view>(p.geo), (uint32_t)N, mean.data_ptr<float>(),
                                        qvec.data_ptr<float>(), svec.data_ptr<float>(), (uint32_t)W, (uint32_t)H,
                                        gsh.data_ptr<float>(), (size_t)gsh.numel(), tab<void>(p.gws), s));
-    if (max_radii2d.defined())
-      GS(gsgen_densify_update_batch((uint32_t)B, (uint32_t)N, tab<const float *const>(p.cov2d_tab), nullptr,
-                                    tab<const uint8_t *const>(p.mask_tab), max_radii2d.data_ptr<float>(), nullptr, nullptr, s));
     if (p.kind == kSh) {
       GS(gsgen_vol_render_sh_batch_routed((uint32_t)B, tab<gsgen_sh_view>(p.views), (uint32_t)N, col.data_ptr<float>(),
                                           alpha.data_ptr<float>(), 16, (uint32_t)p.nth, (uint32_t)p.ntw, (uint32_t)H, (uint32_t)W,
@@ -337,6 +345,15 @@ struct RenderFn : public torch::autograd::Function<RenderFn> {
     Tensor g_mean = g3d.narrow(0, 0, 3 * N).view({N, 3}), g_qvec = g3d.narrow(0, 3 * N, 4 * N).view({N, 4});
     Tensor g_svec = g3d.narrow(0, 7 * N, 3 * N).view({N, 3});
     const float *gp = grad.data_ptr<float>();
+    float *stat_acc = nullptr, *stat_cnt = nullptr;  // (the backward's densify statistics: summed by the SH path's projection backward)
+    {
+      const auto &ga = ctx->saved_data["grad_accum"];
+      if (ga.isTensor() && ga.toTensor().defined()) {
+        stat_acc = ga.toTensor().data_ptr<float>();
+        const Tensor cnt = ctx->saved_data["cnt"].toTensor();
+        stat_cnt = cnt.defined() ? cnt.data_ptr<float>() : nullptr;
+      }
+    }
     if (p.kind == kSh) {
       gsgen_sh_view *v = tab<gsgen_sh_view>(p.views);
       for (int64_t i = 0; i < B; ++i) v[i].grad_out = gp + 3 * H * W * i;
@@ -357,20 +374,16 @@ struct RenderFn : public torch::autograd::Function<RenderFn> {
           (uint32_t)B, (uint32_t)N, mean.data_ptr<float>(), qvec.data_ptr<float>(), svec.data_ptr<float>(),
           tab<const float *const>(p.cam_tab), ctx->saved_data["detach"].toBool() ? 1 : 0, tab<const uint8_t *const>(p.mask_tab),
           tab<float *const>(p.gmean_tab), tab<const float *const>(p.gcov_tab), tab<const float *const>(p.cov2d_tab),
-          g_mean.data_ptr<float>(), g_qvec.data_ptr<float>(), g_svec.data_ptr<float>(), s));
+          g_mean.data_ptr<float>(), g_qvec.data_ptr<float>(), g_svec.data_ptr<float>(), stat_acc, stat_cnt, s));
     else
       GS(gsgen_project_gaussians_backward_batch(
           (uint32_t)B, (uint32_t)N, mean.data_ptr<float>(), qvec.data_ptr<float>(), svec.data_ptr<float>(),
           tab<const float *const>(p.cam_tab), ctx->saved_data["detach"].toBool() ? 1 : 0, tab<const uint8_t *const>(p.mask_tab),
           tab<const float *const>(p.gmean_tab), tab<const float *const>(p.gcov_tab), nullptr, g_mean.data_ptr<float>(),
           g_qvec.data_ptr<float>(), g_svec.data_ptr<float>(), s));
-    const auto &ga = ctx->saved_data["grad_accum"];
-    if (ga.isTensor() && ga.toTensor().defined()) {
-      Tensor acc = ga.toTensor(), cnt = ctx->saved_data["cnt"].toTensor();
+    if (p.kind != kSh && stat_acc != nullptr)  // (post-activation colours: the plain projection backward, the statistics in a launch of their own)
       GS(gsgen_densify_update_batch((uint32_t)B, (uint32_t)N, nullptr, tab<const float *const>(p.gmean_tab),
-                                    tab<const uint8_t *const>(p.mask_tab), nullptr, acc.data_ptr<float>(),
-                                    cnt.defined() ? cnt.data_ptr<float>() : nullptr, s));
-    }
+                                    tab<const uint8_t *const>(p.mask_tab), nullptr, stat_acc, stat_cnt, s));
     Tensor g_bg;
     if (bg.defined() && ctx->needs_input_grad(5)) g_bg = bg_grad(grad, T, bg);
     return {g_mean, g_qvec, g_svec, g_alpha, g_col, g_bg, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(),

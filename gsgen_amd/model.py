@@ -15,12 +15,15 @@ no host sync).  A user of the reference swaps
 
     from gs.gaussian_splatting import GaussianSplattingRenderer     ->     from gsgen_amd.model import GaussianSplattingRenderer
 
-and nothing else; the per-camera `_gs` drop-in (gsgen_amd.install_as_gs) stays available for code that calls the 23 names
-directly, at the reference's serial shape (bench.py reports both: `dropin_gs_surface` against `model_surface`).
+and, for the calls listed in INTEGRATION.md section 0 (the table of trainer.py lines), nothing else: setup_lr / set_optimizer /
+optimizer / update / densify / prune / log / auxiliary_loss / bg(rays_d) exist since round 6.  The per-camera `_gs`
+drop-in (gsgen_amd.install_as_gs) stays available for code that calls the 23 names directly, at the reference's serial shape
+(bench.py reports both: `dropin_gs_surface` against `model_surface`).
 
-What is NOT carried over (raises NotImplementedError when configured): normal_as_rgb, pbr / specular shading, MLPBackground
-(tinycudann), overrides; the densify / prune policies live in gsgen_amd.densify (AdaptiveControl works on the same raw fields
-and statistics), the optimiser in gsgen_amd.optim.
+What is NOT carried over (raises NotImplementedError when configured or called): normal_as_rgb, pbr / specular shading, MLPBackground
+(tinycudann), overrides, the penalty losses behind auxiliary_loss, densify_by_compatness, the gradient-mask windows of update().
+The densify / prune policies themselves live in gsgen_amd.densify (this class delegates; AdaptiveControl is the multi-rank form on a
+FusedAdam), the flat-buffer optimiser in gsgen_amd.optim.
 """
 import numpy as np
 import torch

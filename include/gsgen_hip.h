@@ -215,7 +215,10 @@ int gsgen_project_gaussians_backward_batch_moments_sh(uint32_t n_views, uint32_t
                                                       const float *svec, const float *const *c2w, int detach_depth,
                                                       const uint8_t *const *mask, float *const *g_mom2,
                                                       const float *const *g_mom4, const float *const *cov2d, float *g_mean,
-                                                      float *g_qvec, float *g_svec, gsgen_stream_t stream);
+                                                      float *g_qvec, float *g_svec,
+                                                      float *stat_grad_accum /* or NULL: [N], += sum over the views of |d L / d mean2d| */,
+                                                      float *stat_cnt /* or NULL: [N], += the views that saw the Gaussian (gs/gaussian_splatting.py:464-469) */,
+                                                      gsgen_stream_t stream);
 int gsgen_project_gaussians_backward_batch_heads_moments(uint32_t n_views, uint32_t N, const float *mean, const float *qvec,
                                                          const float *svec, const float *const *c2w, int detach_depth,
                                                          const uint8_t *const *mask, float *const *g_mom2,
@@ -223,6 +226,7 @@ int gsgen_project_gaussians_backward_batch_heads_moments(uint32_t n_views, uint3
                                                          const float *const *depth, const float *const *cov2d,
                                                          const float *const *chol /* or NULL: the views' gsgen_geometry_view::chol */,
                                                          float *g_mean, float *g_qvec, float *g_svec, float *g_color,
+                                                         float *stat_grad_accum /* or NULL, as above */, float *stat_cnt /* or NULL */,
                                                          gsgen_stream_t stream);
 int gsgen_adam_step(uint64_t n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
                     uint32_t n_groups, const uint64_t *group_end, const float *group_lr, float beta1,
@@ -352,6 +356,10 @@ typedef struct gsgen_geometry_view {
    * symmetrised Sigma^-1, formed in fp64 from cov2d and rounded to fp32, and a validity flag (0 for a degenerate or non-finite
    * covariance).  gsgen_rgbd_view::chol hands it to the compositing launches. */
   float *chol;
+  /* optional (round 6): [N] floats shared by the views of every batch -- the projection launch raises them to each visible Gaussian's
+   * screen-space radius m + sqrt(max(m^2 - det, 0)), m = (c0 + c3) / 2 of this view's cov2d: the `max_radii2d` statistic the trainer's prune
+   * step reads (gs/gaussian_splatting.py:1240-1245), what gsgen_densify_update_batch(cov2d, ...) computes in a launch of its own */
+  float *max_radii2d;
 } gsgen_geometry_view;
 size_t gsgen_frame_batch_workspace_bytes(uint32_t n_views);
 int gsgen_frame_geometry_batch(uint32_t n_views, const gsgen_geometry_view *views, uint32_t N, const float *mean,

@@ -561,17 +561,30 @@ def test_emulated_prepared_evaluation_records(emu):
     tab = lambda xs: (Ct.c_void_p * B)(*[x.ctypes.data for x in xs])  # noqa: E731
     outs = res[True][0]
     got = {}
+    st_acc = {u: np.zeros(N, np.float32) for u in (False, True)}; st_cnt = {u: np.zeros(N, np.float32) for u in (False, True)}
     for use in (False, True):
         gm = [o["gm"].copy() for o in outs]
         out = [np.zeros((N, n), np.float32) for n in (3, 4, 3, 3)]
         emu.project_gaussians_backward_batch_heads_moments(
             B, N, P(sc["mean"]), P(sc["qvec"]), P(sc["svec"]), tab(camv), 1, tab([g["mask"] for g in bufs]), tab(gm),
             tab([o["gc"] for o in outs]), tab([o["gch"] for o in outs]), tab([g["dep"] for g in bufs]), tab([g["c2"] for g in bufs]),
-            tab([g["chol"] for g in bufs]) if use else None, *[P(a) for a in out], None)
-        got[use] = out + gm
+            tab([g["chol"] for g in bufs]) if use else None, *[P(a) for a in out], P(st_acc[use]), P(st_cnt[use]), None)
+        got[use] = out + gm + [st_acc[use], st_cnt[use]]
     for x, y in zip(got[False], got[True]):
         assert np.array_equal(x, y) and np.isfinite(x).all()
     assert np.abs(got[True][1]).max() > 0
+    # the densify statistics of the backward, summed by the same launch: sum over the views of |d L / d mean2d| and the views' visits
+    # (gs/gaussian_splatting.py:464-469), against the launch of their own (gsgen_densify_update_batch) on the expanded gradients
+    ref_acc, ref_cnt = np.zeros(N, np.float32), np.zeros(N, np.float32)
+    emu.densify_update_batch(B, N, None, tab(got[True][4:4 + B]), tab([g["mask"] for g in bufs]), None, P(ref_acc), P(ref_cnt), None)
+    assert np.abs(ref_acc).max() > 0 and np.abs(st_acc[True] - ref_acc).max() <= 1e-6 * np.abs(ref_acc).max() and np.array_equal(st_cnt[True], ref_cnt)
+    # ... and the forward's (max_radii2d) by the projection launch (gsgen_geometry_view::max_radii2d)
+    mr_ref, mr = np.zeros(N, np.float32), np.zeros(N, np.float32)
+    emu.densify_update_batch(B, N, tab([g["c2"] for g in bufs]), None, tab([g["mask"] for g in bufs]), P(mr_ref), None, None, None)
+    for a in geo:
+        a.max_radii2d = P(mr)
+    emu.frame_geometry_batch(B, geo, N, P(sc["mean"]), P(sc["qvec"]), P(sc["svec"]), W, H, P(gws), None)
+    assert mr_ref.max() > 0 and np.array_equal(mr, mr_ref)
     geo[1].chol = P(bufs[1]["chol"]) + 4  # (16-byte alignment)
     with pytest.raises(Exception, match="invalid"):
         emu.frame_geometry_batch(B, geo, N, P(sc["mean"]), P(sc["qvec"]), P(sc["svec"]), W, H, P(gws), None)
@@ -931,7 +944,7 @@ def test_emulated_sh_moment_form_equals_the_plain_backward(emu, C, nseg, routed)
         else:
             for v in views:
                 assert not v["gc"][:, 3].any() and np.abs(v["gc"][:, :3]).max() > 0
-            emu.project_gaussians_backward_batch_moments_sh(*common, tab([v["c2"] for v in views]), *[P(a) for a in out], None)
+            emu.project_gaussians_backward_batch_moments_sh(*common, tab([v["c2"] for v in views]), *[P(a) for a in out], None, None, None)
             gm2d = [v["gm"].copy() for v in views]  # overwritten with d L / d mean2d
         res[form] = dict(gsh=gsh, ga=ga, out=out, gm2d=gm2d)
     a_, b_ = res["plain"], res["moments"]
@@ -1091,7 +1104,7 @@ def test_emulated_rgb_heads_moment_form_equals_the_plain_backward(emu):
                     emu.vol_render_rgbd_backward_batch_moments(B, arr, Nall, P(col), P(al), P(ga), 16, nth, ntw, H, W, 1e-4, P(bws), None)
                     for v in views:  # the untouched slots: the fourth float of the second moments, channels 4 and 5
                         assert not v["gc"][:, 3].any() and not v["gch"][:, 4:].any() and np.abs(v["gch"][:, 3]).max() > 0
-                    emu.project_gaussians_backward_batch_heads_moments(*common, tab([v["c2"] for v in views]), None, *[P(a) for a in out], None)
+                    emu.project_gaussians_backward_batch_heads_moments(*common, tab([v["c2"] for v in views]), None, *[P(a) for a in out], None, None, None)
                     gm2d = [v["gm"].copy() for v in views]  # overwritten with d L / d mean2d
                 res[form] = dict(ga=ga, out=out, gm2d=gm2d)
             a_, b_ = res["plain"], res["moments"]
@@ -1101,7 +1114,7 @@ def test_emulated_rgb_heads_moment_form_equals_the_plain_backward(emu):
             for x, y in zip(a_["gm2d"], b_["gm2d"]):
                 assert np.abs(x - y).max() <= 1e-5 * np.abs(x).max()
     with pytest.raises(Exception, match="invalid"):
-        emu.project_gaussians_backward_batch_heads_moments(*common, None, None, *[P(a) for a in out], None)
+        emu.project_gaussians_backward_batch_heads_moments(*common, None, None, *[P(a) for a in out], None, None, None)
 
 
 def test_emulated_rgb_heads_separate_images_background_and_depth_variance(emu):

@@ -213,5 +213,5 @@ def test_batch_node_module_builds_and_exports_its_surface():
     assert mod is not None and callable(mod.render) and callable(mod.render_heads) and hasattr(mod, "Plan")
     import numpy as np
     gen = np.zeros(1, np.int64)
-    plan = mod.Plan(0, 2, 10, 12, 32, 16, 1, 2, 1, *([0] * 11), gen.ctypes.data, torch.zeros(2, 6 * 12), None, [gen])
+    plan = mod.Plan(0, 2, 10, 12, 32, 16, 1, 2, 1, *([0] * 12), gen.ctypes.data, torch.zeros(2, 6 * 12), None, [gen])  # (12 table addresses: chol_tab since round 6)
     assert plan.address() != 0

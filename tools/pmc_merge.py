@@ -16,14 +16,18 @@ from gsgen_amd import _capi  # noqa: E402
 lib = _capi.load()  # (names only: works without a GPU)
 # raw (demangled) kernel name fragments -> the library's descriptive variant names
 names = {
-    "k_composite_bwd_sh_vec<4, 4, true, 6>": lib.kernel_variant("sh_bwd_batch_poly", 4, 1),
+    "k_composite_bwd_sh_vec<4, 4, true, 6, true>": lib.kernel_variant("sh_bwd_batch_poly", 4, 1),   # (round 6: the moment form is what bench.py runs)
+    "k_composite_bwd_sh_vec<4, 4, true, 6, false>": lib.kernel_variant("sh_bwd_batch_poly", 4, 1) + " (plain gradients)",
     "k_composite_fwd_sh_vec<4, 4, true, 6, false>": lib.kernel_variant("sh_fwd_batch_poly", 4, 1),
     "k_composite_fwd_sh_vec<4, 4, true, 6, true>": lib.kernel_variant("sh_fwd_batch_poly", 4, 2),
-    "k_composite_bwd_sh_vec<4, 4, true, -2>": "persistent exact fallback of the bounded backward (normally leaves at once)",
+    "k_composite_bwd_sh_vec<4, 4, true, -2, true>": "persistent exact fallback of the bounded backward (normally leaves at once)",
+    "k_composite_bwd_sh_vec<4, 4, true, -2, false>": "persistent exact fallback of the bounded backward (normally leaves at once; plain gradients)",
     "k_composite_fwd_sh_vec<4, 2, true, -2, true>": "persistent exact fallback of the bounded forward (normally leaves at once)",
-    "k_composite_bwd_sh_vec<4, 4, true, 0>": lib.kernel_variant("sh_bwd_batch", 4, 1),
+    "k_composite_bwd_sh_vec<4, 4, true, 0, true>": lib.kernel_variant("sh_bwd_batch", 4, 1),
+    "k_composite_bwd_sh_vec<4, 4, true, 0, false>": lib.kernel_variant("sh_bwd_batch", 4, 1) + " (plain gradients)",
     "k_composite_fwd_sh_vec<4, 2, true, 0, true>": lib.kernel_variant("sh_fwd_batch", 4, 1),
-    "k_composite_bwd_chan_vec<3, true>": lib.kernel_variant("rgbd_bwd_batch", 1, 1),
+    "k_composite_bwd_chan_vec<3, true, true>": lib.kernel_variant("rgbd_bwd_batch_moments", 1, 1),
+    "k_composite_bwd_chan_vec<3, true, false>": lib.kernel_variant("rgbd_bwd_batch", 1, 1),
     "k_composite_fwd_chan_vec<3, true>": lib.kernel_variant("rgbd_fwd_batch", 1, 1),
     # the geometry chain of a batch (same kernels behind the SH and the RGB + heads step)
     "k_frame_project_views": "k_frame_project_views", "k_bin_pull_views<false>": "k_bin_pull_views<count>",
