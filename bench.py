@@ -413,6 +413,17 @@ class HostClock:
 
 
 def main():
+    """AUDIT GUIDE.  Everything `value` is made of sits in three places:
+      * run_step(j)            -- ONE step: the enqueues of one camera batch (coefficient bounds, geometry, compositing forward,
+                                  compositing backward, projection backward) on slot j's stream.  run_heads_step: the RGB + heads step.
+      * region(first, ...)     -- THE TIMED REGION: barrier + synchronize, exactly K steps, barrier + synchronize, max over ranks; HIP
+                                  events on the launch stream bracket every step's compositing launches.  Nothing else is timed.
+      * the block under "timed region" -- W warm-up steps, then region() repeated until 0.5 s are timed; the MEDIAN repeat is `value`.
+    What follows are secondary views, one function each, none of which touches `value`: exact_basis_view (the same region, exact SH
+    basis), the no-gather region (multi-GPU), one_in_flight (one step at a time), heads_report (the RGB + heads step measured like
+    `value`), alone_pass (one launch in flight), latency_view (one camera at a time), autograd_surface_view (BatchRenderer + autograd),
+    model_surfaces (the model-level call; module level), other_configs (cfg3 / cfg4 / stress lines; module level), cpu_baseline
+    (the oracle; module level).  `--only-timed` runs warm-up + timed regions and none of them."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50, help="timed steps; a step renders --batch cameras fwd+bwd")
@@ -1012,8 +1023,8 @@ def main():
         dist.all_gather_object(ranks_view, me)
 
     # ---- the same timed region with the exact per-pixel SH basis (when the headline used the polynomial form) ----------------
-    exact_basis = None
-    if state["bounded"] and not args.only_timed:
+    def exact_basis_view():
+        """-> `exact_basis`: the timed region again with the exact per-pixel SH basis in every tile"""
         state["bounded"] = False
         for i in range(max(2, len(slots))):
             run_step(i, evs[i % K])
@@ -1026,6 +1037,9 @@ def main():
         for i in range(max(2, len(slots))):  # back to the headline's kernels for the secondary views
             run_step(i, evs[i % K])
         barrier()
+        return exact_basis
+
+    exact_basis = exact_basis_view() if (state["bounded"] and not args.only_timed) else None
 
     # ---- multi-GPU: the same timed region WITHOUT the per-step all_gather (compute scaling and xGMI cost separate) ------------
     no_gather = None
@@ -1139,8 +1153,8 @@ def main():
         alone = alone_pass(run_step)
 
     # (b) strictly one render (one camera) at a time on one stream, per-camera entry points: the latency view
-    one = None
-    if not args.no_latency:
+    def latency_view():
+        """-> `one_render_in_flight`: one camera at a time through the per-camera entry points (+ the same from a hipGraph)"""
         sl0 = slots[0]
         b0 = sl0.bufs[0]
         lseg = max(1, args.latency_segments)
@@ -1238,12 +1252,15 @@ def main():
             one["hipgraph_replay"] = {"value": world * n1 / el2, "ms_per_render": el2 / n1 * 1e3}
         except Exception as e:  # capture is an optimisation of the latency view only
             one["hipgraph_replay"] = {"error": str(e)[:200]}
+        return one
+
+    one = latency_view() if not args.no_latency else None
 
     # (c) the autograd surface: the same steps through gsgen_amd.BatchRenderer.render(...) + torch.autograd -- the path a
     # training loop takes (one autograd node per camera batch; gradients to mean, qvec, svec, alpha, sh), `surface_slots`
     # independent steps in flight on their own streams (e.g. the micro-batches of a gradient-accumulation step)
-    surface = None
-    if not args.no_surface and C > 0:
+    def autograd_surface_view():
+        """-> `autograd_surface`: the timed steps again through BatchRenderer.render + torch.autograd.grad (the C++ autograd node)"""
         from gsgen_amd.batch import BatchRenderer
         n_sf = len(slots)
         leaf = {k: t[k].clone().requires_grad_(True) for k in ("mean", "qvec", "svec", "alpha", "sh")}
@@ -1290,6 +1307,9 @@ def main():
                    "path": "gsgen_amd.BatchRenderer.render -> torch.autograd.grad (mean, qvec, svec, alpha, sh); one autograd "
                            "node per camera batch, the coefficient bound measured inside its forward"}
         del brs
+        return surface
+
+    surface = autograd_surface_view() if (not args.no_surface and C > 0) else None
 
     # (d) the MODEL-LEVEL call a trainer makes -- forward(batch) -> {rgb, depth, opacity, z_var}, loss.backward(), post_backward()
     # (trainer.py:291-422 without guidance and optimiser) -- through gsgen_amd.model.GaussianSplattingRenderer, and, where
