@@ -72,6 +72,8 @@ SIGNATURES = {
     "gsgen_project_gaussians_backward_batch_heads_moments": [u32, u32, vp, vp, vp, C.POINTER(vp), i32, C.POINTER(vp), C.POINTER(vp),
                                                              C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
                                                              vp, vp, vp, vp, vp, vp, vp],
+    "gsgen_activate_fields": [u32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp],
+    "gsgen_activate_fields_backward": [u32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp],
     "gsgen_sh_l1_bound_rows": [u32, vp, u32, vp, vp, vp],
     "gsgen_sh_l1_bound_rows_running": [u32, vp, u32, vp, vp, vp],
     "gsgen_vol_render_sh_batch_routed": [u32, C.POINTER(ShView), u32, vp, vp, u32, u32, u32, u32, u32, u32, f32, u32, vp, vp, vp, vp],

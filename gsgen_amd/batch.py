@@ -33,6 +33,12 @@ from . import renderer as R
 from .renderer import _p, PairListOverflow
 
 
+# utils/activations.py:36-57 as gsgen_activate_fields numbers them (include/gsgen_hip.h), and their torch forms (the fallback path)
+ACTIVATION_CODES = {"nothing": 0, "exp": 1, "sigmoid": 2, "abs": 3, "relu": 4, "softplus": 5, "biased_relu": 6, "biased_abs": 7}
+TORCH_ACTIVATIONS = {"nothing": lambda x: x, "exp": torch.exp, "sigmoid": torch.sigmoid, "abs": torch.abs, "relu": torch.relu,
+                     "softplus": torch.nn.functional.softplus, "biased_relu": lambda x: torch.relu(x) + 1e-3,
+                     "biased_abs": lambda x: torch.abs(x) + 1e-3}
+
 _EXT = [False]  # the compiled `_gsbatch` module (csrc/torch_batch.cpp), None when it is not built; looked up once
 
 
@@ -762,12 +768,21 @@ class BatchRenderer:
         return self._rows
 
     def render_heads(self, mean, qvec, svec, alpha, color, cam_infos, c2ws, bg_rgb=None, thresh=1e-4,
-                     frustum_radius=6.0, tile_radius=6.0, detach_depth=True, stats=None, z_var=False):
+                     frustum_radius=6.0, tile_radius=6.0, detach_depth=True, stats=None, z_var=False, activations=None):
         """-> (rgb [B,H,W,3], depth, opacity, depth2, T [B,H,W,1]) from post-activation colours [N,3]: what
         GaussianSplattingRenderer.forward returns with rgb_only = False, one compositing pass per camera.  Five separate contiguous
         tensors.  bg_rgb (3 or 3 B elements, any broadcastable shape; differentiable): composited inside the forward launch.
         z_var=True: the fourth output is the depth variance depth2 - depth^2 the reference's model returns
-        (gs/gaussian_splatting.py:1397), formed -- and differentiated -- inside the launches."""
+        (gs/gaussian_splatting.py:1397), formed -- and differentiated -- inside the launches.
+        activations=(svec_act, alpha_act, color_act) -- names of utils/activations.py:36-57: svec / alpha / color are then the model's
+        RAW parameters (svec_before_activation ...), activated by one launch inside the batch's autograd node (and differentiated by
+        one) instead of three torch kernels and three autograd nodes: host time of a small training step."""
+        if activations is not None:
+            codes = [ACTIVATION_CODES.get(a) for a in activations]
+            if None in codes:
+                raise ValueError(f"activations {activations}: known are {sorted(ACTIVATION_CODES)}")
+        else:
+            codes = [-1, -1, -1]
         B = self._check_batch(cam_infos)
         if B == 0:
             z = torch.zeros(0, self.H, self.W, 3, device=self.device)
@@ -783,7 +798,9 @@ class BatchRenderer:
             va["pixel_size_x"][:B] = 1.0 / self._intr[:B, 0]
             va["pixel_size_y"][:B] = 1.0 / self._intr[:B, 1]
             return tuple(_batch_ext().render_heads(fast[0], mean, qvec, svec, alpha, color, bg_rgb, float(thresh),
-                                                   bool(detach_depth), *self._stats_args(stats), bool(z_var)))
+                                                   bool(detach_depth), *self._stats_args(stats), bool(z_var), *codes))
+        if activations is not None:  # (the Python Functions take activated fields: torch's own kernels, the same values)
+            svec, alpha, color = (TORCH_ACTIVATIONS[a](x) for a, x in zip(activations, (svec, alpha, color)))
         return _render_batch_heads.apply(mean, qvec, svec, alpha, color, cams, self, B, bg_rgb, float(thresh),
                                          bool(detach_depth), stats, bool(z_var))
 

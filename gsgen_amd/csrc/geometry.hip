@@ -711,6 +711,80 @@ static inline dim3 grid_for(uint32_t n) { return dim3((n + kThreads - 1) / kThre
 
 using namespace gs;
 
+// ---- the model's parameter activations (utils/activations.py:36-57, applied at gs/gaussian_splatting.py:113-124) ---------------------
+// svec = act(svec_before_activation) etc. are three torch kernels forward and three autograd nodes backward in the reference's model
+// -- launch-latency-sized work on [N,3] / [N] tensors, but ~120 us of HOST time per step of a small training step.  One launch each
+// way here, enqueued by the camera batch's C++ autograd node (csrc/torch_batch.cpp) on raw parameters.
+// codes: 0 nothing, 1 exp, 2 sigmoid, 3 abs, 4 relu, 5 softplus, 6 biased_relu (+1e-3), 7 biased_abs (+1e-3)
+namespace gs {
+constexpr float kMinScale = 1e-3f;  // utils/activations.py:17
+__device__ __forceinline__ float act_fwd(int code, float x) {
+  switch (code) {
+    case 1: return expf(x);
+    case 2: return 1.0f / (1.0f + expf(-x));
+    case 3: return fabsf(x);
+    case 4: return fmaxf(x, 0.0f);
+    case 5: return x > 20.0f ? x : log1pf(expf(x));  // torch.nn.functional.softplus (beta 1, threshold 20)
+    case 6: return fmaxf(x, 0.0f) + kMinScale;
+    case 7: return fabsf(x) + kMinScale;
+    default: return x;
+  }
+}
+// d act / d x from the raw value x and the activated value y
+__device__ __forceinline__ float act_bwd(int code, float x, float y) {
+  switch (code) {
+    case 1: return y;
+    case 2: return y * (1.0f - y);
+    case 3: case 7: return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f);
+    case 4: case 6: return x > 0.0f ? 1.0f : 0.0f;
+    case 5: return x > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-x));
+    default: return 1.0f;
+  }
+}
+__global__ void __launch_bounds__(kThreads)
+k_activate_fields(uint32_t N, const float *__restrict__ svec_raw, const float *__restrict__ alpha_raw,
+                  const float *__restrict__ color_raw, int sa, int aa, int ca, float *__restrict__ svec, float *__restrict__ alpha,
+                  float *__restrict__ color) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 3 * N) return;
+  svec[i] = act_fwd(sa, svec_raw[i]);
+  color[i] = act_fwd(ca, color_raw[i]);
+  if (i < N) alpha[i] = act_fwd(aa, alpha_raw[i]);
+}
+__global__ void __launch_bounds__(kThreads)
+k_activate_fields_bwd(uint32_t N, const float *__restrict__ svec_raw, const float *__restrict__ alpha_raw,
+                      const float *__restrict__ color_raw, const float *__restrict__ svec, const float *__restrict__ alpha,
+                      const float *__restrict__ color, int sa, int aa, int ca, float *__restrict__ g_svec, float *__restrict__ g_alpha,
+                      float *__restrict__ g_color) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 3 * N) return;
+  g_svec[i] *= act_bwd(sa, svec_raw[i], svec[i]);
+  g_color[i] *= act_bwd(ca, color_raw[i], color[i]);
+  if (i < N) g_alpha[i] *= act_bwd(aa, alpha_raw[i], alpha[i]);
+}
+}  // namespace gs
+extern "C" int gsgen_activate_fields(uint32_t N, const float *svec_raw, const float *alpha_raw, const float *color_raw,
+                                     int svec_act, int alpha_act, int color_act, float *svec, float *alpha, float *color,
+                                     gsgen_stream_t stream) {
+  if (N == 0) return 0;
+  if (!svec_raw || !alpha_raw || !color_raw || !svec || !alpha || !color) return GSGEN_EINVAL;
+  if (svec_act < 0 || svec_act > 7 || alpha_act < 0 || alpha_act > 7 || color_act < 0 || color_act > 7) return GSGEN_EUNSUPPORTED;
+  hipLaunchKernelGGL(gs::k_activate_fields, gs::grid_for(3 * N), dim3(gs::kThreads), 0, (hipStream_t)stream, N, svec_raw, alpha_raw,
+                     color_raw, svec_act, alpha_act, color_act, svec, alpha, color);
+  return (int)hipGetLastError();
+}
+extern "C" int gsgen_activate_fields_backward(uint32_t N, const float *svec_raw, const float *alpha_raw, const float *color_raw,
+                                              const float *svec, const float *alpha, const float *color, int svec_act,
+                                              int alpha_act, int color_act, float *g_svec, float *g_alpha, float *g_color,
+                                              gsgen_stream_t stream) {
+  if (N == 0) return 0;
+  if (!svec_raw || !alpha_raw || !color_raw || !svec || !alpha || !color || !g_svec || !g_alpha || !g_color) return GSGEN_EINVAL;
+  if (svec_act < 0 || svec_act > 7 || alpha_act < 0 || alpha_act > 7 || color_act < 0 || color_act > 7) return GSGEN_EUNSUPPORTED;
+  hipLaunchKernelGGL(gs::k_activate_fields_bwd, gs::grid_for(3 * N), dim3(gs::kThreads), 0, (hipStream_t)stream, N, svec_raw, alpha_raw,
+                     color_raw, svec, alpha, color, svec_act, alpha_act, color_act, g_svec, g_alpha, g_color);
+  return (int)hipGetLastError();
+}
+
 // ---- small host -> device uploads through kernel arguments ------------------------------------------------------
 // Per-render constants (a camera block is 272 bytes) reach the device as the ARGUMENTS of a one-workgroup kernel
 // instead of a hipMemcpyAsync: the bytes are copied into the dispatch packet when the launch is enqueued, so the

@@ -127,7 +127,7 @@ const float *bg_pointer(const Tensor &bg, int64_t B, int64_t i, Tensor &keep) {
 struct HeadsFn : public torch::autograd::Function<HeadsFn> {
   static variable_list forward(AutogradContext *ctx, Tensor mean, Tensor qvec, Tensor svec, Tensor alpha, Tensor color,
                                OptT bg_, int64_t plan_addr, double thresh, bool detach_depth, OptT max_radii2d_,
-                               OptT grad_accum_, OptT cnt_, bool z_var) {
+                               OptT grad_accum_, OptT cnt_, bool z_var, int64_t svec_act, int64_t alpha_act, int64_t color_act) {
     const Plan &p = *reinterpret_cast<const Plan *>(plan_addr);
     const Tensor bg = opt(bg_), max_radii2d = opt(max_radii2d_), grad_accum = opt(grad_accum_), cnt = opt(cnt_);
     check_param(mean, "mean", p.N, 3, mean); check_param(qvec, "qvec", p.N, 4, mean); check_param(svec, "svec", p.N, 3, mean);
@@ -141,6 +141,19 @@ struct HeadsFn : public torch::autograd::Function<HeadsFn> {
     c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(mean.device());
     const gsgen_stream_t s = current_stream(mean);
     const int64_t B = p.B, H = p.H, W = p.W, N = p.N;
+    // raw parameters (svec_act >= 0: the model's svec_before_activation / alpha_before_activation / color_before_activation and its
+    // activation codes, include/gsgen_hip.h gsgen_activate_fields): one launch here instead of three torch kernels and, backward,
+    // three autograd nodes -- host time of a small training step, not device time
+    const bool raw = svec_act >= 0;
+    Tensor svec_raw, alpha_raw, color_raw;
+    if (raw) {
+      svec_raw = svec; alpha_raw = alpha; color_raw = color;
+      Tensor act = at::empty({7 * N}, mean.options());
+      svec = act.narrow(0, 0, 3 * N).view({N, 3}); color = act.narrow(0, 3 * N, 3 * N).view({N, 3}); alpha = act.narrow(0, 6 * N, N);
+      GS(gsgen_activate_fields((uint32_t)N, svec_raw.data_ptr<float>(), alpha_raw.data_ptr<float>(), color_raw.data_ptr<float>(),
+                               (int)svec_act, (int)alpha_act, (int)color_act, svec.data_ptr<float>(), alpha.data_ptr<float>(),
+                               color.data_ptr<float>(), s));
+    }
     Tensor rgb = at::empty({B, H, W, 3}, mean.options()), dep = at::empty({B, H, W, 1}, mean.options());
     Tensor opa = at::empty({B, H, W, 1}, mean.options()), zz = at::empty({B, H, W, 1}, mean.options());
     Tensor T = at::empty({B, H, W, 1}, mean.options());
@@ -170,7 +183,8 @@ struct HeadsFn : public torch::autograd::Function<HeadsFn> {
                                        gsh.data_ptr<float>(), (size_t)gsh.numel(), tab<void>(p.gws), s));
     GS(gsgen_vol_render_rgbd_batch((uint32_t)B, v, (uint32_t)N, color.data_ptr<float>(), alpha.data_ptr<float>(), 16,
                                    (uint32_t)p.nth, (uint32_t)p.ntw, (uint32_t)H, (uint32_t)W, (float)thresh, tab<void>(p.bws), s));
-    ctx->save_for_backward({mean, qvec, svec, alpha, color, rgb, dep, opa, zz, T, bg, bg_keep});
+    ctx->save_for_backward({mean, qvec, svec, alpha, color, rgb, dep, opa, zz, T, bg, bg_keep, svec_raw, alpha_raw, color_raw});
+    ctx->saved_data["acts"] = std::vector<int64_t>{svec_act, alpha_act, color_act};
     ctx->saved_data["plan"] = plan_addr;
     ctx->saved_data["plan_ref"] = plan_ref(p);
     ctx->saved_data["gen"] = *tab<const int64_t>(p.generation);
@@ -244,8 +258,17 @@ struct HeadsFn : public torch::autograd::Function<HeadsFn> {
     Tensor g_bg;
     if (bg_grad_wanted && ctx->needs_input_grad(5) && g[0].defined())  // the 64 partial rows of every view -> [B,1,1,3] -> bg's shape
       g_bg = gsh.narrow(0, p.Np, 256 * B).view({B, 64, 4}).slice(-1, 0, 3).sum(1).view({B, 1, 1, 3}).sum_to_size(bg.sizes());
-    return {g_mean, g_qvec, g_svec, gsh.narrow(0, 0, N), g_col, g_bg, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(),
-            Tensor()};
+    Tensor g_alpha = gsh.narrow(0, 0, N);
+    const auto acts = ctx->saved_data["acts"].toIntVector();
+    if (acts[0] >= 0) {  // raw parameters went in: d L / d raw = d L / d activated * act'(raw), in place, one launch
+      const Tensor &svec_raw = saved[12], &alpha_raw = saved[13], &color_raw = saved[14];
+      GS(gsgen_activate_fields_backward((uint32_t)N, svec_raw.data_ptr<float>(), alpha_raw.data_ptr<float>(), color_raw.data_ptr<float>(),
+                                        svec.data_ptr<float>(), alpha.data_ptr<float>(), color.data_ptr<float>(), (int)acts[0],
+                                        (int)acts[1], (int)acts[2], g_svec.data_ptr<float>(), g_alpha.data_ptr<float>(),
+                                        g_col.data_ptr<float>(), s));
+    }
+    return {g_mean, g_qvec, g_svec, g_alpha, g_col, g_bg, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(),
+            Tensor(), Tensor(), Tensor(), Tensor()};
   }
 };
 
@@ -413,9 +436,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def("address", [](const Plan &p) { return (int64_t) reinterpret_cast<uintptr_t>(&p); });
   m.def("render_heads", [](int64_t plan, Tensor mean, Tensor qvec, Tensor svec, Tensor alpha, Tensor color, c10::optional<Tensor> bg,
                            double thresh, bool detach_depth, c10::optional<Tensor> max_radii2d, c10::optional<Tensor> grad_accum,
-                           c10::optional<Tensor> cnt, bool z_var) {
-    return HeadsFn::apply(mean, qvec, svec, alpha, color, bg, plan, thresh, detach_depth, max_radii2d, grad_accum, cnt, z_var);
-  }, "-> [rgb, depth, opacity, depth2 | z_var, T]");
+                           c10::optional<Tensor> cnt, bool z_var, int64_t svec_act, int64_t alpha_act, int64_t color_act) {
+    return HeadsFn::apply(mean, qvec, svec, alpha, color, bg, plan, thresh, detach_depth, max_radii2d, grad_accum, cnt, z_var, svec_act,
+                          alpha_act, color_act);
+  }, "-> [rgb, depth, opacity, depth2 | z_var, T]; svec_act >= 0: svec / alpha / color are RAW parameters, activated inside");
   m.def("render", [](int64_t plan, Tensor mean, Tensor qvec, Tensor svec, Tensor alpha, Tensor col, c10::optional<Tensor> bg, int64_t C,
                      double thresh, bool detach_depth, c10::optional<Tensor> sh_bound, c10::optional<Tensor> sh_rows,
                      c10::optional<Tensor> max_radii2d, c10::optional<Tensor> grad_accum, c10::optional<Tensor> cnt) {

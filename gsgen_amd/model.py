@@ -157,6 +157,7 @@ class GaussianSplattingRenderer(nn.Module):
         for k in ("pbr", "normal_as_rgb"):
             if _get(cfg, k, False):
                 raise NotImplementedError(f"gsgen_amd.model: cfg.{k} is outside the rasterizer path this library replaces")
+        self._act_names = tuple(_get(cfg, k) for k in ("svec_act", "alpha_act", "color_act"))
         self.svec_act, self.alpha_act, self.color_act = (activations[_get(cfg, k)] for k in ("svec_act", "alpha_act", "color_act"))
         self.svec_inv_act, self.alpha_inv_act, self.color_inv_act = (
             inv_activations[_get(cfg, k)] for k in ("svec_act", "alpha_act", "color_act"))
@@ -277,15 +278,17 @@ class GaussianSplattingRenderer(nn.Module):
                            self.cnt if self.densify_enabled else None)
         bg = self.bg(B, self.mean.device)
         fr = 0.0 if self.skip_frustum_culling else self.frustum_culling_radius
-        color = self.color
         if rgb_only:
-            rgb, _ = br.render(self.mean, self.qvec, self.svec, self.alpha, color, cis, c2ws, C=0, bg_rgb=bg, thresh=self.T_thresh,
+            rgb, _ = br.render(self.mean, self.qvec, self.svec, self.alpha, self.color, cis, c2ws, C=0, bg_rgb=bg, thresh=self.T_thresh,
                                frustum_radius=fr, tile_radius=self.tile_culling_radius, detach_depth=self.depth_detach, stats=stats)
             return {"rgb": rgb}
-        # (z_var = depth2 - depth^2, :1397, and the background, gs/renderer.py:1182, are formed inside the launches: round 6)
-        rgb, depth, opacity, z_var, _ = br.render_heads(self.mean, self.qvec, self.svec, self.alpha, color, cis, c2ws, bg_rgb=bg,
+        # (z_var = depth2 - depth^2, :1397, the background, gs/renderer.py:1182, and the three activations, :113-124, are formed inside
+        # the launches / the batch's autograd node: round 6)
+        rgb, depth, opacity, z_var, _ = br.render_heads(self.mean, self.qvec, self.svec_before_activation, self.alpha_before_activation,
+                                                        self.color_before_activation, cis, c2ws, bg_rgb=bg,
                                                         thresh=self.T_thresh, frustum_radius=fr, tile_radius=self.tile_culling_radius,
-                                                        detach_depth=self.depth_detach, stats=stats, z_var=True)
+                                                        detach_depth=self.depth_detach, stats=stats, z_var=True,
+                                                        activations=self._act_names)
         return {"rgb": rgb, "depth": depth, "opacity": opacity, "z_var": z_var}
 
     def render_one(self, c2w, camera_info, use_bg=True, rgb_only=False, overrides=None, return_T=False):

@@ -228,6 +228,15 @@ int gsgen_project_gaussians_backward_batch_heads_moments(uint32_t n_views, uint3
                                                          float *g_mean, float *g_qvec, float *g_svec, float *g_color,
                                                          float *stat_grad_accum /* or NULL, as above */, float *stat_cnt /* or NULL */,
                                                          gsgen_stream_t stream);
+/* The model's parameter activations (utils/activations.py:36-57; svec / alpha / color = act(raw), gs/gaussian_splatting.py:113-124) for
+ * all three fields in one launch, and their backward in one (g_* hold d L / d activated on entry, d L / d raw on return).  Codes:
+ * 0 nothing, 1 exp, 2 sigmoid, 3 abs, 4 relu, 5 softplus, 6 biased_relu, 7 biased_abs.  svec / color are [N,3], alpha [N].  The
+ * reference runs three torch kernels forward and three autograd nodes backward per step: host time, not device time. */
+int gsgen_activate_fields(uint32_t N, const float *svec_raw, const float *alpha_raw, const float *color_raw, int svec_act,
+                          int alpha_act, int color_act, float *svec, float *alpha, float *color, gsgen_stream_t stream);
+int gsgen_activate_fields_backward(uint32_t N, const float *svec_raw, const float *alpha_raw, const float *color_raw,
+                                   const float *svec, const float *alpha, const float *color, int svec_act, int alpha_act,
+                                   int color_act, float *g_svec, float *g_alpha, float *g_color, gsgen_stream_t stream);
 int gsgen_adam_step(uint64_t n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
                     uint32_t n_groups, const uint64_t *group_end, const float *group_lr, float beta1,
                     float beta2, float eps, uint32_t step, gsgen_stream_t stream);

@@ -1539,6 +1539,32 @@ def test_emulated_projection_backward_over_a_batch_of_views(emu, n_views):
                                              P(got[0]), P(got[1]), P(got[2]), None)
 
 
+def test_emulated_parameter_activations_match_torch(emu):
+    """gsgen_activate_fields / _backward (the model's svec / alpha / color = act(raw), utils/activations.py:36-57, as one launch each way
+    inside the camera batch's autograd node) against torch's own kernels and autograd, every activation of the reference's table"""
+    import torch
+    from gsgen_amd.batch import ACTIVATION_CODES, TORCH_ACTIVATIONS
+    rng = np.random.default_rng(2)
+    N = 1000
+    for names in (("exp", "sigmoid", "sigmoid"), ("softplus", "nothing", "abs"), ("biased_relu", "relu", "biased_abs")):
+        raw = [rng.normal(size=(N, 3)).astype(np.float32) * 2, rng.normal(size=N).astype(np.float32) * 3, rng.normal(size=(N, 3)).astype(np.float32)]
+        raw[0][0, 0] = 25.0  # (softplus beyond its threshold)
+        codes = [ACTIVATION_CODES[a] for a in names]
+        out = [np.zeros_like(r) for r in raw]
+        emu.activate_fields(N, P(raw[0]), P(raw[1]), P(raw[2]), *codes, P(out[0]), P(out[1]), P(out[2]), None)
+        g = [rng.normal(size=r.shape).astype(np.float32) for r in raw]
+        gin = [x.copy() for x in g]
+        emu.activate_fields_backward(N, P(raw[0]), P(raw[1]), P(raw[2]), P(out[0]), P(out[1]), P(out[2]), *codes, P(g[0]), P(g[1]), P(g[2]), None)
+        for a, r, o, gi, go in zip(names, raw, out, gin, g):
+            x = torch.tensor(r, requires_grad=True)
+            y = TORCH_ACTIVATIONS[a](x)
+            y.backward(torch.tensor(gi))
+            assert np.abs(o - y.detach().numpy()).max() <= 2e-6 * max(1.0, float(y.abs().max())), a
+            assert np.abs(go - x.grad.numpy()).max() <= 2e-6 * max(1.0, float(x.grad.abs().max())), a
+    with pytest.raises(Exception, match="unsupported|invalid"):
+        emu.activate_fields(N, P(raw[0]), P(raw[1]), P(raw[2]), 9, 0, 0, P(out[0]), P(out[1]), P(out[2]), None)
+
+
 def test_emulated_adam_step_matches_torch_cpu(emu):
     """gsgen_adam_step on the emulator vs torch.optim.Adam (CPU) with one param group per field and
     learning rates that change every step (gs/gaussian_splatting.py:398-419, conf/base.yaml:8-11)"""

@@ -1108,3 +1108,54 @@ def test_cpp_autograd_node_equals_the_python_functions(kind):
     for k in keys:
         assert rel_err(Pe[k].grad.cpu().numpy(), want[k].cpu().numpy()) < 1e-4, k
     del junk
+
+
+def test_raw_parameters_depth_variance_and_background_inside_the_launches():
+    """Round 6: BatchRenderer.render_heads(..., activations=(...), z_var=True, bg_rgb=...) -- the model's three parameter activations as
+    one launch each way inside the batch's autograd node (gsgen_activate_fields), z_var = depth2 - depth^2 and rgb + T bg formed by the
+    forward's epilogue, their chain rules by the backward's prologue -- against the same render with those operations in torch
+    (activated leaves, render_heads without the options, torch's z_var and background arithmetic): images within 2e-6, every raw
+    gradient and the background's within 2e-4 of its tensor's largest entry."""
+    from gsgen_amd import renderer as R
+    from gsgen_amd import batch as Bm
+    sc = scenes.random_scene(5000, seed=12, svec=0.03, C=1)
+    N, W, H, B = sc["mean"].shape[0], 160, 112, 3
+    cams = [scenes.Camera(W, H, fx=250.0 + 20 * i, c2w=scenes.orbit(2.4, 5 + 12 * i, 50.0 + 100 * i)) for i in range(B)]
+    cis, c2ws = [R.CameraInfo(*c.intr) for c in cams], [c.c2w for c in cams]
+    raw0 = {"mean": sc["mean"], "qvec": sc["qvec"], "svec": np.log(sc["svec"]),
+            "alpha": np.log(np.clip(sc["alpha"], 1e-3, 1 - 1e-3) / (1 - np.clip(sc["alpha"], 1e-3, 1 - 1e-3))),
+            "color": np.log(np.clip(sc["color"], 1e-3, 1 - 1e-3) / (1 - np.clip(sc["color"], 1e-3, 1 - 1e-3)))}
+    gen = torch.Generator(device=dev()).manual_seed(5)
+    gos = [torch.randn(B, H, W, c, device=dev(), generator=gen) for c in (3, 1, 1, 1)]
+    keys = ("mean", "qvec", "svec", "alpha", "color")
+
+    def run(inside, use_ext=True):
+        P_ = {k: T_(raw0[k].astype(np.float32)).requires_grad_(True) for k in keys}
+        bg = torch.tensor([0.2, 0.5, 0.7], device=dev(), requires_grad=True)
+        br = Bm.BatchRenderer(N, W, H, dev(), max_batch=B)
+        br.use_ext = use_ext
+        for _ in range(2):
+            for v in list(P_.values()) + [bg]:
+                v.grad = None
+            if inside:
+                rgb, dep, opa, zv, _T = br.render_heads(P_["mean"], P_["qvec"], P_["svec"], P_["alpha"], P_["color"], cis, c2ws, bg_rgb=bg,
+                                                        z_var=True, activations=("exp", "sigmoid", "sigmoid"))
+            else:
+                rgb0, dep, opa, z2, T = br.render_heads(P_["mean"], P_["qvec"], torch.exp(P_["svec"]), torch.sigmoid(P_["alpha"]),
+                                                        torch.sigmoid(P_["color"]), cis, c2ws)
+                rgb = rgb0 + T * bg
+                zv = z2 - dep * dep
+            outs = (rgb, dep, opa, zv)
+            sum((o * g_).sum() for o, g_ in zip(outs, gos)).backward()
+        torch.cuda.synchronize()
+        return [o.detach().cpu().numpy() for o in outs], {k: P_[k].grad.cpu().numpy() for k in keys}, bg.grad.cpu().numpy()
+
+    o_in, g_in, b_in = run(True)
+    o_py, g_py, b_py = run(True, use_ext=False)   # the Python Functions: torch's activations in front of the same launches
+    o_t, g_t, b_t = run(False)
+    for a, b, c in zip(o_in, o_t, o_py):
+        sc_ = max(1.0, float(np.abs(b).max()))
+        assert np.abs(a - b).max() <= 2e-6 * sc_ and np.abs(c - b).max() <= 2e-6 * sc_
+    for k in keys:
+        assert rel_err(g_in[k], g_t[k]) <= 2e-4 and rel_err(g_py[k], g_t[k]) <= 2e-4, k
+    assert rel_err(b_in, b_t) <= 2e-4 and rel_err(b_py, b_t) <= 2e-4

@@ -34,6 +34,7 @@ ap.add_argument("--warmup", type=int, default=20)
 ap.add_argument("--graph", action="store_true", help="replay the whole step from one hipGraph")
 ap.add_argument("--profile", action="store_true", help="torch.profiler CPU table of 20 eager steps on stderr (where the host time goes)")
 ap.add_argument("--pipeline", choices=["auto", "on", "off"], default="off", help="BatchRenderer(pipeline=...): two half-batches on two streams")
+ap.add_argument("--torch-ops", action="store_true", help="activations / z_var as torch operations around render_heads (rounds 1-5) instead of inside its node")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 sc = scenes.pointe_scene(a.n, seed=0, C=1)
@@ -56,9 +57,13 @@ bg = torch.tensor([0.5, 0.5, 0.5], device=dev)
 
 def step():
     opt.zero_grad()
-    rgb, dpt, opa, z2, _ = br.render_heads(P["mean"], P["qvec"], torch.exp(P["svec"]), torch.sigmoid(P["alpha"]),
-                                           torch.sigmoid(P["color"]), cis, c2ws, bg_rgb=bg, stats=stats)
-    z_var = z2 - dpt * dpt
+    if a.torch_ops:  # rounds 1-5: the activations, the background and z_var as torch kernels / autograd nodes around the launches
+        rgb, dpt, opa, z2, _ = br.render_heads(P["mean"], P["qvec"], torch.exp(P["svec"]), torch.sigmoid(P["alpha"]),
+                                               torch.sigmoid(P["color"]), cis, c2ws, bg_rgb=bg, stats=stats)
+        z_var = z2 - dpt * dpt
+    else:  # round 6 (what gsgen_amd.model.GaussianSplattingRenderer.forward does): raw parameters in, z_var out
+        rgb, dpt, opa, z_var, _ = br.render_heads(P["mean"], P["qvec"], P["svec"], P["alpha"], P["color"], cis, c2ws, bg_rgb=bg, stats=stats,
+                                                  z_var=True, activations=("exp", "sigmoid", "sigmoid"))
     loss = (rgb * g_sds).sum() + 1e-3 * (opa * opa + 0.01).sqrt().mean() + 1e-3 * z_var.mean()  # trainer.py:305-388
     loss.backward()
     opt.step()
