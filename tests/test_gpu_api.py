@@ -1113,9 +1113,9 @@ def test_cpp_autograd_node_equals_the_python_functions(kind):
 def test_raw_parameters_depth_variance_and_background_inside_the_launches():
     """Round 6: BatchRenderer.render_heads(..., activations=(...), z_var=True, bg_rgb=...) -- the model's three parameter activations as
     one launch each way inside the batch's autograd node (gsgen_activate_fields), z_var = depth2 - depth^2 and rgb + T bg formed by the
-    forward's epilogue, their chain rules by the backward's prologue -- against the same render with those operations in torch
-    (activated leaves, render_heads without the options, torch's z_var and background arithmetic): images within 2e-6, every raw
-    gradient and the background's within 2e-4 of its tensor's largest entry."""
+    forward's epilogue, their chain rules by the backward's prologue -- against the same render with the activations and z_var in torch
+    (activated leaves, torch's z_var arithmetic and autograd): images within 2e-6, every raw gradient and the background's within 2e-4
+    of its tensor's largest entry."""
     from gsgen_amd import renderer as R
     from gsgen_amd import batch as Bm
     sc = scenes.random_scene(5000, seed=12, svec=0.03, C=1)
@@ -1141,9 +1141,10 @@ def test_raw_parameters_depth_variance_and_background_inside_the_launches():
                 rgb, dep, opa, zv, _T = br.render_heads(P_["mean"], P_["qvec"], P_["svec"], P_["alpha"], P_["color"], cis, c2ws, bg_rgb=bg,
                                                         z_var=True, activations=("exp", "sigmoid", "sigmoid"))
             else:
-                rgb0, dep, opa, z2, T = br.render_heads(P_["mean"], P_["qvec"], torch.exp(P_["svec"]), torch.sigmoid(P_["alpha"]),
-                                                        torch.sigmoid(P_["color"]), cis, c2ws)
-                rgb = rgb0 + T * bg
+                # (the background stays an argument: T is not a differentiable output -- composited outside, the T bg term's
+                # dependence on the splats would be lost; its in-launch form against torch's arithmetic: tests/test_cpu_host.py)
+                rgb, dep, opa, z2, T = br.render_heads(P_["mean"], P_["qvec"], torch.exp(P_["svec"]), torch.sigmoid(P_["alpha"]),
+                                                       torch.sigmoid(P_["color"]), cis, c2ws, bg_rgb=bg)
                 zv = z2 - dep * dep
             outs = (rgb, dep, opa, zv)
             sum((o * g_).sum() for o, g_ in zip(outs, gos)).backward()
