@@ -616,6 +616,12 @@ __device__ __forceinline__ void composite_fwd_sh_vec_tile(const CompParams &p, u
   if constexpr (POLY) {  // (per-tile routing: this tile is the polynomial kernel's until a staged batch says otherwise)
     if (t == 0 && p.tile_flags != nullptr) p.tile_flags[tile] = 0;
   }
+  // the background colour in three registers, loaded before any store of this tile (round 6): read in the epilogue, behind the image
+  // stores of the lane's previous pixel, the compiler has to assume they alias and fetches them again -- twelve dependent round trips
+  // to memory at the end of every tile
+  const bool has_bg = p.bg != nullptr;
+  float bgv[3] = {0.0f, 0.0f, 0.0f};
+  if (has_bg) { bgv[0] = p.bg[0]; bgv[1] = p.bg[1]; bgv[2] = p.bg[2]; }
   if (st == kListOverflow) {  // the frame's pairs did not fit the list (GSGEN_LIST_OVERFLOW): never a finite blank tile
 #pragma unroll
     for (int j = 0; j < PPL; ++j)
@@ -630,7 +636,7 @@ __device__ __forceinline__ void composite_fwd_sh_vec_tile(const CompParams &p, u
           const size_t pix = (size_t)gy[j] * p.W + gx;
           float *o = p.out + 3 * pix;
 #pragma unroll
-          for (int c = 0; c < 3; ++c) o[c] = p.bg != nullptr ? p.bg[c] : 0.0f;
+          for (int c = 0; c < 3; ++c) o[c] = bgv[c];
           if (p.fill_empty && p.T != nullptr) p.T[pix] = 1.0f;  // batched launches write the whole image (CompParams::fill_empty)
         }
     }
@@ -868,7 +874,7 @@ __device__ __forceinline__ void composite_fwd_sh_vec_tile(const CompParams &p, u
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const float a = acc2[j >> 1][c][j & 1];
-      o[c] = (p.bg != nullptr) ? a + p.bg[c] * Tj : a;  // vol_render_bg.h:95-100
+      o[c] = has_bg ? a + bgv[c] * Tj : a;  // vol_render_bg.h:95-100
     }
     if (p.T != nullptr) p.T[pix] = Tj;
   }

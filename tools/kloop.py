@@ -1,6 +1,6 @@
 """The entry loop of one kernel of the built library: the smallest backward-branch loop that encloses the first occurrence of an
 anchor opcode (default v_exp_f32: the Gaussian of an entry), with an opcode histogram and issue-slot estimate.
-    python tools/kloop.py <kernel substring> [--anchor OPCODE] [--dump] [--lib path]"""
+    python tools/kloop.py <kernel substring> [--anchor OPCODE] [--nth K] [--dump] [--lib path]"""
 import collections, os, re, subprocess, sys, tempfile
 
 LLVM = "/opt/rocm/lib/llvm/bin"
@@ -31,6 +31,7 @@ def main():
             i = argv.index(name); v = argv[i + 1]; del argv[i:i + 2]; return v
         return default
     anchor = opt("--anchor", "v_exp_f32")
+    nth = int(opt("--nth", "0"))  # which occurrence of the anchor (kernels with several loops that hold one)
     lib = opt("--lib") or os.environ.get("GSGEN_HIP_LIB") or os.path.join(os.path.dirname(__file__), "..", "gsgen_amd", "lib", "libgsgen_hip.so")
     dump = "--dump" in argv
     if dump:
@@ -45,7 +46,7 @@ def main():
     anchors = [a for a, t in ins if t.split()[0].startswith(anchor)]
     if not anchors:
         raise SystemExit(f"{name}: no {anchor}")
-    first = anchors[0]
+    first = anchors[min(nth, len(anchors) - 1)]
     loops = []
     for a, t in ins:
         b = re.match(r"s_c?branch\S*\s+(\d+)", t)
