@@ -345,24 +345,34 @@ def model_surfaces(sc, cams, dev, B, K, H, W):
         model.train()
         batch = {"c2w": c2w, "camera_info": infos}
 
-        def step():
+        def step(given=False):
             out = model(batch)
-            sum((out[k] * go[k]).sum() for k in out).backward()
+            if given:  # the guidance hands over d L / d image (SDS: trainer.py:305-331 turns it into a loss of that gradient): no loss kernels
+                torch.autograd.backward([out[k] for k in out], [go[k] for k in out])
+            else:
+                sum((out[k] * go[k]).sum() for k in out).backward()
             model.post_backward()
             for q in model.parameters():
                 q.grad = None
 
-        for _ in range(3):
-            step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(K):
-            step()
-        host = time.perf_counter() - t0
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t0
-        return {"value": B * K / el, "unit": "views/s", "ms_per_step": el / K * 1e3, "host_ms_per_step": host / K * 1e3,
-                "cameras_per_step": B, "steps": K, "class": label, "path": path}
+        def timed(given):
+            for _ in range(3):
+                step(given)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(K):
+                step(given)
+            host = time.perf_counter() - t0
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            return {"value": B * K / el, "unit": "views/s", "ms_per_step": el / K * 1e3, "host_ms_per_step": host / K * 1e3}
+
+        res = timed(False)
+        res.update({"cameras_per_step": B, "steps": K, "class": label, "path": path,
+                    # the same step with the image gradients handed to autograd.backward directly: what the harness' own four-term
+                    # loss (4 products, 4 sums and their backward over 123 MB of images: torch kernels, not this library's) costs
+                    "image_gradients_given": timed(True)})
+        return res
 
     res = {"model_surface": measure(
         GaussianSplattingRenderer(cfg, dict(init_)), [R.CameraInfo(*c.intr) for c in cams[:B]], "gsgen_amd.model.GaussianSplattingRenderer",

@@ -256,8 +256,11 @@ scan_tiles_body(uint32_t T, const uint32_t *__restrict__ tile_count, uint32_t *_
 // the border, and a compositing launch does not fit the chip all at once -- started in spatial
 // order the long tiles begin late and the launch ends on a few stragglers.  Counting sort of
 // the tiles by (list length / 8) descending, one workgroup, LDS atomics only.
+// n_long (ctrl[2]) = the number of tiles at the front of the order whose list is kWaveSortMax entries or longer: the sort launch
+// gives those a workgroup each and packs the rest four to a workgroup (sort_tiles_packed_body).
+constexpr uint32_t kWaveSortMax = 512;  // a multiple of 8; lists SHORTER than this are sorted by one wavefront in registers
 __device__ __forceinline__ void
-order_tiles_body(uint32_t T, const uint32_t *__restrict__ tile_count, uint32_t *__restrict__ tile_order) {
+order_tiles_body(uint32_t T, const uint32_t *__restrict__ tile_count, uint32_t *__restrict__ tile_order, uint32_t *__restrict__ n_long) {
   __shared__ uint32_t s_hist[256];
   __shared__ uint32_t s_base[256];
   const uint32_t t = threadIdx.x;
@@ -267,7 +270,11 @@ order_tiles_body(uint32_t T, const uint32_t *__restrict__ tile_count, uint32_t *
   __syncthreads();
   if (t == 0) {
     uint32_t run = 0;
-    for (int b = 0; b < 256; ++b) { s_base[b] = run; run += s_hist[b]; }
+    for (int b = 0; b < 256; ++b) {
+      if (b == 256 - (int)(kWaveSortMax >> 3)) *n_long = run;  // bins 0 .. b-1: count >> 3 >= kWaveSortMax / 8
+      s_base[b] = run;
+      run += s_hist[b];
+    }
   }
   __syncthreads();
   for (uint32_t i = t; i < T; i += kScanThreads) {
@@ -531,13 +538,48 @@ sort_tiles_coop_body(uint32_t tile, const uint32_t *__restrict__ tile_off, const
   else if (n <= 1024u) sort_segment_coop<4>(keys + b, ids + b, n, s_keys);
   else sort_segment_coop<8>(keys + b, ids + b, n, s_keys);
 }
+// With a launch order (order_tiles_body: longest list first, ctrl[2] = how many lists reach kWaveSortMax): workgroup `slot` of a
+// view takes the slot-th tile while those last, and FOUR of the shorter ones after that, a wavefront each -- a list one
+// wavefront sorts in registers leaves the other three with nothing to do, and the workgroup's 16 KB of LDS (ten workgroups a
+// compute unit) then held the short half of a frame's tiles to ten wavefronts a compute unit on a launch that waits on
+// cross-lane round trips.  (The surplus workgroups at the end of the grid leave at once.)
+__device__ __forceinline__ void
+sort_tiles_packed_body(uint32_t slot, uint32_t T, const uint32_t *__restrict__ tile_order, const uint32_t *__restrict__ tile_off,
+                       const uint32_t *__restrict__ ctrl, unsigned long long *__restrict__ keys, int *__restrict__ ids,
+                       int *__restrict__ start, int *__restrict__ end, u64 *s_keys) {
+  const uint32_t n_long = min(ctrl[2], T);
+  if (slot < n_long) {
+    sort_tiles_coop_body(tile_order[slot], tile_off, ctrl, keys, ids, start, end, s_keys);
+    return;
+  }
+  const uint32_t at = n_long + (slot - n_long) * (uint32_t)kCoopWaves + (threadIdx.x >> 6);
+  if (at >= T) return;
+  const uint32_t tile = tile_order[at];
+  const bool first = lane_id() == 0;
+  if (ctrl[1] != 0u) {  // (see sort_tiles_coop_body)
+    if (first) { start[tile] = kListOverflow; end[tile] = kListOverflow; }
+    return;
+  }
+  const uint32_t b = tile_off[tile], e = tile_off[tile + 1];
+  const uint32_t n = e - b;
+  if (first) {
+    start[tile] = n ? (int)b : -1;
+    end[tile] = n ? (int)e : -1;
+  }
+  if (n == 0) return;
+  if (n <= 64u) sort_segment_regs<1>(keys + b, ids + b, n);
+  else if (n <= 128u) sort_segment_regs<2>(keys + b, ids + b, n);
+  else if (n <= 256u) sort_segment_regs<4>(keys + b, ids + b, n);
+  else sort_segment_regs<8>(keys + b, ids + b, n);  // (kWaveSortMax = 512)
+}
+static_assert(kWaveSortMax <= 512 && kWaveSortMax % 8 == 0 && kWaveSortMax <= 255 * 8, "sort_tiles_packed_body");
 __global__ void __launch_bounds__(64 * kCoopWaves)
 k_sort_tiles(uint32_t T, const uint32_t *__restrict__ tile_off, const uint32_t *__restrict__ ctrl,
                   unsigned long long *__restrict__ keys, int *__restrict__ ids, int *__restrict__ start,
                   int *__restrict__ end, const uint32_t *__restrict__ tile_order) {
   __shared__ u64 s_keys[kCoopMax];
-  // longest list first (order_tiles_body) where the caller has an order: the four-wavefront sorts start at once
-  sort_tiles_coop_body(tile_order != nullptr ? tile_order[blockIdx.x] : blockIdx.x, tile_off, ctrl, keys, ids, start, end, s_keys);
+  if (tile_order != nullptr) sort_tiles_packed_body(blockIdx.x, T, tile_order, tile_off, ctrl, keys, ids, start, end, s_keys);
+  else sort_tiles_coop_body(blockIdx.x, tile_off, ctrl, keys, ids, start, end, s_keys);  // (legacy.hip's segments: no order)
 }
 // 1-D grid of T x B workgroups, view = id % B, tiles in order_tiles_body order (longest list first): every view's long sorts
 // start at once and the launch ends on the short ones.  (View-major order measured 134 us for 8 cfg2 views with one wavefront
@@ -547,7 +589,7 @@ k_sort_tiles_views(uint32_t T, uint32_t B, const GeoView *__restrict__ views) {
   __shared__ u64 s_keys[kCoopMax];
   const uint32_t rank = blockIdx.x / B;
   const GeoView v = views[blockIdx.x - rank * B];
-  sort_tiles_coop_body(v.tile_order[rank], v.tile_off, v.ctrl, v.keys, v.ids, v.start, v.end, s_keys);
+  sort_tiles_packed_body(rank, T, v.tile_order, v.tile_off, v.ctrl, v.keys, v.ids, v.start, v.end, s_keys);
 }
 
 // ---- self test of the cross-lane primitives (tests/ only; exported for the parity suite) ----
@@ -583,13 +625,13 @@ k_scan_order_tiles(uint32_t T, const uint32_t *__restrict__ tile_count, uint32_t
                    uint32_t *__restrict__ ctrl, uint32_t cap, uint32_t *__restrict__ total_out,
                    uint32_t *__restrict__ tile_order, uint32_t *report) {
   scan_tiles_body(T, tile_count, tile_off, ctrl, cap, total_out, report);
-  order_tiles_body(T, tile_count, tile_order);
+  order_tiles_body(T, tile_count, tile_order, ctrl + 2);
 }
 __global__ void __launch_bounds__(kScanThreads)
 k_scan_order_tiles_views(uint32_t T, const GeoView *__restrict__ views) {
   const GeoView v = views[blockIdx.y];
   scan_tiles_body(T, v.tile_count, v.tile_off, v.ctrl, v.cap, v.total, v.report);
-  order_tiles_body(T, v.tile_count, v.tile_order);
+  order_tiles_body(T, v.tile_count, v.tile_order, v.ctrl + 2);
 }
 // ---- push binning of a camera batch (round 4) ------------------------------------------------------------------------------
 // The pull kernels above -- every 8 x 8-tile group scans every 2 048-Gaussian chunk -- issue 25 + 31 M vector instructions per

@@ -735,8 +735,9 @@ def test_emulated_reduce_scatter(emu, Pc):
 
 
 def test_emulated_sort_register_widths(emu):
-    """every path of the per-tile sort under emulation: one wavefront up to 256 entries, four up to 2048, block sort + merge passes beyond"""
-    sizes = (1, 64, 65, 130, 300, 600, 1100, 2048, 2049, 4097, 9000)   # > 2048: register blocks + global merge passes
+    """every path of the per-tile sort under emulation: one wavefront below 512 entries (four such lists to a workgroup, behind the
+    longer ones in the launch order), four wavefronts up to 2048, block sort + merge passes beyond; the boundaries on both sides"""
+    sizes = (1, 64, 65, 130, 255, 256, 257, 300, 504, 511, 512, 513, 600, 1100, 2048, 2049, 4097, 9000, 3, 0, 77)   # > 2048: register blocks + global merge passes
     ntw, nth = len(sizes), 1
     rng = np.random.default_rng(12)
     tl_l, dep_l = [], []

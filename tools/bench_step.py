@@ -33,6 +33,7 @@ ap.add_argument("--steps", type=int, default=100)
 ap.add_argument("--warmup", type=int, default=20)
 ap.add_argument("--graph", action="store_true", help="replay the whole step from one hipGraph")
 ap.add_argument("--profile", action="store_true", help="torch.profiler CPU table of 20 eager steps on stderr (where the host time goes)")
+ap.add_argument("--cprofile", action="store_true", help="cProfile of 200 eager steps on stderr (the Python side of the host time)")
 ap.add_argument("--pipeline", choices=["auto", "on", "off"], default="off", help="BatchRenderer(pipeline=...): two half-batches on two streams")
 ap.add_argument("--torch-ops", action="store_true", help="activations / z_var as torch operations around render_heads (rounds 1-5) instead of inside its node")
 a = ap.parse_args()
@@ -101,6 +102,19 @@ if a.profile:
             step()
         torch.cuda.synchronize()
     print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=40, max_name_column_width=60), file=sys.stderr)
+if a.cprofile:
+    import cProfile
+    import pstats
+    torch.cuda.synchronize()
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(200):
+        step()
+    pr.disable()
+    torch.cuda.synchronize()
+    st = pstats.Stats(pr, stream=sys.stderr)
+    st.sort_stats("tottime").print_stats(45)
+    st.sort_stats("cumulative").print_stats(45)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(a.steps):
