@@ -302,8 +302,15 @@ __device__ __forceinline__ void cross_step(u64 (&k)[K], int m, bool flip) {
   int top = m;  // highest set bit of m decides who is the lower index
   top |= top >> 1; top |= top >> 2; top |= top >> 4;
   top = (top + 1) >> 1;
-  const bool keep_min = (lane & top) == 0;
-  auto pick = [&](u64 mine, u64 theirs) { return (keep_min ? (theirs < mine) : (theirs > mine)) ? theirs : mine; };
+  // the lower index keeps the smaller key, the upper one the larger: ONE comparison, flipped in the upper lanes (equal keys -- the
+  // +inf padding -- may trade places: the same bits).  (As `keep_min ? theirs < mine : theirs > mine` this compiled to two
+  // exec-masked branches per key: twice as many scalar as vector instructions in the launch.)
+  const bool upper = (lane & top) != 0;
+  auto pick = [&](u64 mine, u64 theirs) {
+    const bool take = (theirs < mine) != upper;
+    const uint32_t lo = take ? (uint32_t)theirs : (uint32_t)mine, hi = take ? (uint32_t)(theirs >> 32) : (uint32_t)(mine >> 32);
+    return ((u64)hi << 32) | lo;
+  };
   if (flip) {
     // my register r meets the partner's register K-1-r: handle (r, K-1-r) together so that no
     // copy of the whole key array is needed (K = 32 would spill otherwise)
