@@ -171,7 +171,10 @@ class Lib:
                 import torch  # noqa: F401
             except ImportError:
                 pass
-        self.cdll = C.CDLL(path)
+        # an experiment build (GSGEN_HIP_LIB) is loaded with global symbols: the compiled extensions (_gs, _gsbatch) are linked to
+        # libgsgen_hip.so by name and would otherwise bind to the in-tree build they find through their rpath -- an A/B through
+        # BatchRenderer's C++ node or the model class then measured the in-tree kernels twice (round 6, sessions 14-20)
+        self.cdll = C.CDLL(path, mode=C.RTLD_GLOBAL) if os.environ.get("GSGEN_HIP_LIB") and path == DEFAULT_LIB else C.CDLL(path)
         self.cdll.gsgen_version.restype = C.c_char_p
         self.cdll.gsgen_error_string.restype = C.c_char_p
         self.cdll.gsgen_error_string.argtypes = [i32]

@@ -654,7 +654,7 @@ k_scan_order_tiles_views(uint32_t T, const GeoView *__restrict__ views) {
 // the pull kernels.
 constexpr int kPushOwn = 12;
 constexpr uint32_t kPushMaxTiles = 8192;  // 32 KB of LDS: 2 048 x 1 024 pixels and the like
-constexpr int kPushThreads = 256;
+constexpr int kPushThreads = 512;  // (round 6: 256 -> 512: the count launch 25 -> 18 us, the emit 72 -> 66 us per 8 cfg2 views alone; 1 024: 17 / 64, no better in flight: profiles/r06_s22_*)
 constexpr uint32_t kPushMinWorkgroups = 128;  // (chunks x views) below which the pull kernels are the faster launch
 // A camera batch is a throughput launch (other steps' kernels fill the chip around it): there the fewer instructions win from
 // a quarter of that on.
