@@ -32,7 +32,7 @@ class RgbdView(C.Structure):
                 ("T", vp), ("grad_out6", vp), ("grad_mean", vp), ("grad_cov", vp), ("grad_chan6", vp),
                 ("grad_rgb", vp), ("grad_depth", vp), ("grad_opacity", vp), ("grad_depth2", vp),
                 ("out_rgb", vp), ("out_depth", vp), ("out_opacity", vp), ("out_depth2", vp), ("bg_rgb", vp), ("grad_bg", vp),
-                ("depth_variance", u32), ("chol", vp)]
+                ("depth_variance", u32), ("chol", vp), ("pixel_size_dev", vp)]
 
 
 class GeometryView(C.Structure):
@@ -89,6 +89,8 @@ SIGNATURES = {
     "gsgen_upload_small": [vp, vp, sz, vp],
     "gsgen_pack_camera_blocks": [u32, vp, u32, vp, f32, f32, vp],
     "gsgen_adam_step": [C.c_uint64, vp, vp, vp, vp, u32, vp, vp, f32, f32, f32, u32, vp],
+    "gsgen_adam_step_scalars": [u32, vp, f32, f32, u32, vp],
+    "gsgen_adam_step_device_scalars": [C.c_uint64, vp, vp, vp, vp, u32, vp, f32, f32, f32, vp, vp],
     "gsgen_densify_update_batch": [u32, u32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp, vp, vp, vp],
     "gsgen_densify_update": [u32, vp, vp, vp, vp, vp, vp, vp],
     "gsgen_tile_culling_aabb_count": [u32, vp, vp, u32, f32, f32, f32, f32, u32, u32, f32, vp, vp, vp, vp],

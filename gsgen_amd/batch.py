@@ -316,7 +316,7 @@ class _render_batch_heads(torch.autograd.Function):
 class BatchRenderer:
     """Renders [B] cameras of one (W, H) shape for a fixed Gaussian count N."""
 
-    def __init__(self, N, W, H, device, max_batch, D_cap=None, segments=1, strict=False, pipeline=False):
+    def __init__(self, N, W, H, device, max_batch, D_cap=None, segments=1, strict=False, pipeline=False, device_cameras=False):
         """D_cap: capacity of every slot's (tile, Gaussian) pair list.  None (default): the FIRST batch is rendered
         synchronously (one host sync) and sizes all slots at 1.5 x the largest count it saw; later batches report their
         counts through the geometry launch itself (no sync, renderer.PairCountReport) and the lists are regrown before the
@@ -327,8 +327,15 @@ class BatchRenderer:
         pipeline: False (default) -- one launch per stage for the whole batch; True -- two half-batches on two streams (the
         caller's and the renderer's own, forked and joined inside the call); "auto" -- True from 4 cameras on.  Measured not to
         pay under the join a loss imposes (module docstring); kept for callers whose backward may start per half.
-        segments: backward workgroups per tile (FrameBuffers)."""
+        segments: backward workgroups per tile (FrameBuffers).
+        device_cameras: False (default) -- a batch's camera blocks travel in kernel arguments (gsgen_upload_small) and its pixel sizes
+        in the view tables, i.e. in kernel arguments too; True -- the compositing kernels read both from DEVICE memory (filled by one
+        enqueue, upload_cameras), and a render enqueued while the stream is being captured uploads nothing: a
+        captured hipGraph of a step (gsgen_amd.graph.CapturedStep) then replays for whatever cameras were uploaded before the
+        replay -- poses and intrinsics.  RGB + heads and RGB batches (render_heads, render with C = 0); SH batches keep their pixel
+        sizes in the view tables."""
         self.N, self.W, self.H, self.device = N, W, H, torch.device(device)
+        self.device_cameras = bool(device_cameras)
         self.segments = int(segments)
         self.strict = bool(strict)
         if pipeline not in ("auto", True, False):
@@ -366,7 +373,11 @@ class BatchRenderer:
         # (_check_generation), so one set is enough.  Memory per slot beyond the lists: (22 + 24 [+ 24]) B x N.
         lib = _capi.load()
         self._Np = (N + 3) // 4 * 4
-        self._cams = torch.empty(max_batch, 68, device=device, dtype=torch.float32)
+        # camera rows [max_batch, 68] | pixel sizes [max_batch, 2] (device_cameras: gsgen_rgbd_view::pixel_size_dev)
+        self._camblock = torch.empty(max_batch * 70, device=device, dtype=torch.float32)
+        self._cams = self._camblock[:max_batch * 68].view(max_batch, 68)
+        self._pix = self._camblock[max_batch * 68:].view(max_batch, 2)
+        self._hostblock = np.zeros(max_batch * 70, np.float32)
         nth_, ntw_ = R.n_tiles(H, W)
         self._nb_sh = lib.sh_batch_workspace_bytes_routed(max_batch, nth_ * ntw_)  # parameter tables + per-tile routing flags
         # one batch workspace per half (routing flags of its views) + the geometry launches' view tables
@@ -427,11 +438,34 @@ class BatchRenderer:
                     np.asarray(c2w, np.float32).reshape(-1)[:12]
         intr[:B] = [(ci.fx, ci.fy, ci.cx, ci.cy, ci.w, ci.h, ci.near_plane, ci.far_plane) for ci in cam_infos]  # (one assignment)
         lib = _capi.load()
+        if self.device_cameras:
+            # a render enqueued into a stream capture uploads nothing: the replay renders what upload_cameras put in place before it
+            if torch.cuda.is_current_stream_capturing():
+                return self._cams[:B]
+            nb = len(self.slots)
+            hp = self._hostblock
+            lib.pack_camera_blocks(B, poses.ctypes.data, 12, intr.ctypes.data, frustum_radius, tile_radius, hp.ctypes.data)
+            px = hp[nb * 68:].reshape(nb, 2)
+            px[:B, 0] = 1.0 / intr[:B, 0]  # (rounded to fp32 exactly as the view tables' floats are)
+            px[:B, 1] = 1.0 / intr[:B, 1]
+            # rows and pixel sizes in one enqueue, through kernel arguments like the default upload (outside a capture that is as good
+            # as anywhere; the source is reusable at once -- a DMA copy from pinned memory was measured first: 10 us of stream time each)
+            lib.upload_small(_p(self._camblock), hp.ctypes.data, nb * 280, torch.cuda.current_stream(self.device).cuda_stream)
+            return self._cams[:B]
         lib.pack_camera_blocks(B, poses.ctypes.data, 12, intr.ctypes.data, frustum_radius, tile_radius, h.ctypes.data)
         # the renderer's own device block: its rows are read by the batch's backward, and no other batch of this renderer
         # may come between a forward and its backward (_check_generation)
         lib.upload_small(_p(self._cams), h.ctypes.data, B * 272, torch.cuda.current_stream(self.device).cuda_stream)
         return self._cams[:B]
+
+    def upload_cameras(self, cam_infos, c2ws, frustum_radius=6.0, tile_radius=6.0):
+        """device_cameras renderers: put a batch's cameras (poses and intrinsics) in place on the current stream without rendering --
+        what a captured step's replay then renders (gsgen_amd.graph.CapturedStep does this for you)"""
+        if not self.device_cameras:
+            raise RuntimeError("upload_cameras: this BatchRenderer was built without device_cameras=True")
+        self._check_batch(cam_infos)
+        self._upload(cam_infos, c2ws, frustum_radius, tile_radius)
+        self._cis = list(cam_infos)
 
     def _mask_table(self, B):
         """void*[B] of the slots' visibility masks (they never move): built once per batch size"""
@@ -504,6 +538,8 @@ class BatchRenderer:
                 v.depth = _p(buf.depth)
                 if kind == "rgbd":
                     g.zero_grad_chan6 = v.grad_chan6 = c0 + st * i
+                if self.device_cameras:
+                    v.pixel_size_dev = self._pix.data_ptr() + 8 * i
         self._table_cache[kind] = (cap, geo, views)
         return geo, views
 

@@ -1775,7 +1775,7 @@ k_composite_fwd_chan_vec(CompParams p_arg, ViewPack<BATCH> pack) {
   const CompParams *plist = pack.table();  // (kernel-argument memory: scalar loads, no table in device memory)
   static_assert(MODE == MODE_RGB || MODE == MODE_SCALAR || MODE == MODE_RGBD, "post-activation channel modes");
   uint32_t bid = blockIdx.x;
-  const CompParams p = BATCH ? plist[batch_view(p_arg, bid)] : p_arg;
+  const CompParams p = BATCH ? view_params(plist[batch_view(p_arg, bid)]) : p_arg;
   using TR = Traits<MODE, 1>;
   constexpr int PPL = 4, NT = 64, ROWS = NT / 16, NP = PPL / 2;
   constexpr int NCH = TR::NCH;
@@ -1960,7 +1960,7 @@ k_composite_bwd_chan_vec(CompParams p_arg, ViewPack<BATCH> pack) {
   static_assert(MODE == MODE_RGB || MODE == MODE_SCALAR || MODE == MODE_RGBD, "post-activation channel modes");
   static_assert(!MOM || MODE == MODE_RGBD, "the moment form exists for RGB + heads");
   uint32_t bid = blockIdx.x, grid = gridDim.x;
-  const CompParams p = BATCH ? plist[batch_view(p_arg, bid, &grid)] : p_arg;
+  const CompParams p = BATCH ? view_params(plist[batch_view(p_arg, bid, &grid)]) : p_arg;
   (void)grid;
   using TR = Traits<MODE, 1>;
   constexpr int PPL = 4, NT = 64, ROWS = NT / 16, NP = PPL / 2;
@@ -2998,6 +2998,7 @@ static int fill_rgbd_params(uint32_t n_views, const gsgen_rgbd_view *views, cons
     p.start = v.start; p.end = v.end; p.ids = v.gaussian_ids; p.topleft = v.topleft;
     p.ntw = (int)ntw; p.nth = (int)nth; p.H = (int)H; p.W = (int)W;
     p.psx = v.pixel_size_x; p.psy = v.pixel_size_y; p.thresh = thresh;
+    p.ps_dev = v.pixel_size_dev;
     p.tile_order = v.tile_order;
     p.n_hi = 0x7fffffff;
     if (backward) {

@@ -68,7 +68,19 @@ struct CompParams {
   // and "no exact fallback is launched behind this kernel: keep every tile, take the per-entry exact tier"
   uint32_t *route_report;
   int no_fallback;
+  // RGB / RGB + heads, batched launches (gsgen_rgbd_view::pixel_size_dev): the view's {psx, psy} in device memory -- read at the top of
+  // the kernel in place of the two floats above, so that a captured step replays for other intrinsics (view_params below)
+  const float *ps_dev;
 };
+// a batched channel-mode kernel's parameter block: the view's entry of the kernel-argument table, pixel sizes from device memory if given
+__device__ __forceinline__ CompParams view_params(const CompParams &src) {
+  CompParams p = src;
+  if (p.ps_dev != nullptr) {
+    p.psx = p.ps_dev[0];
+    p.psy = p.ps_dev[1];
+  }
+  return p;
+}
 constexpr int kSegLen = 32;
 
 // workgroup -> tile: explicit order if given, else the XCD-balanced spatial map

@@ -150,6 +150,7 @@ struct AdamArgs {
   float step_size[kAdamMaxGroups];
   uint32_t n_groups;
   float bc2_sqrt, beta1, beta2, eps;
+  const float *dev;  // or NULL: step_size[0 .. 7] | bc2_sqrt from device memory (gsgen_adam_step_device_scalars)
 };
 
 __global__ void __launch_bounds__(kThreads)
@@ -158,6 +159,11 @@ k_adam_step(uint64_t n, float *__restrict__ param, const float *__restrict__ gra
   const uint64_t i0 = 4 * ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x);
   if (i0 >= n) return;
   const float w1 = 1.0f - a.beta1, w2 = 1.0f - a.beta2;
+  if (a.dev != nullptr) {  // (uniform: scalar loads)
+#pragma unroll
+    for (int k = 0; k < kAdamMaxGroups; ++k) a.step_size[k] = a.dev[k];
+    a.bc2_sqrt = a.dev[kAdamMaxGroups];
+  }
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const uint64_t i = i0 + e;
@@ -1071,6 +1077,37 @@ int gsgen_adam_step(uint64_t n, float *param, const float *grad, float *exp_avg,
   a.n_groups = n_groups;
   a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
   a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
+  const uint64_t n4 = (n + 3) / 4;
+  const uint32_t blocks = (uint32_t)((n4 + kThreads - 1) / kThreads);
+  hipLaunchKernelGGL(k_adam_step, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, n, param, grad,
+                     exp_avg, exp_avg_sq, a);
+  return (int)hipGetLastError();
+}
+
+int gsgen_adam_step_scalars(uint32_t n_groups, const float *group_lr, float beta1, float beta2, uint32_t step, float *out9) {
+  if (!group_lr || !out9 || n_groups == 0 || n_groups > kAdamMaxGroups || step == 0) return GSGEN_EINVAL;
+  for (int k = 0; k < kAdamMaxGroups; ++k)  // (gsgen_adam_step's arithmetic)
+    out9[k] = k < (int)n_groups ? (float)((double)group_lr[k] / (1.0 - pow((double)beta1, (double)step))) : 0.0f;
+  out9[kAdamMaxGroups] = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+  return 0;
+}
+
+int gsgen_adam_step_device_scalars(uint64_t n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
+                                   uint32_t n_groups, const uint64_t *group_end, float beta1, float beta2, float eps,
+                                   const float *scalars, gsgen_stream_t stream) {
+  if (n == 0) return 0;
+  if (!param || !grad || !exp_avg || !exp_avg_sq || !group_end || !scalars) return GSGEN_EINVAL;
+  if (n_groups == 0 || n_groups > kAdamMaxGroups) return GSGEN_EINVAL;
+  AdamArgs a{};
+  uint64_t prev = 0;
+  for (uint32_t k = 0; k < n_groups; ++k) {
+    if (group_end[k] < prev || group_end[k] > n) return GSGEN_EINVAL;
+    a.end[k] = prev = group_end[k];
+  }
+  if (prev != n) return GSGEN_EINVAL;
+  a.n_groups = n_groups;
+  a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
+  a.dev = scalars;
   const uint64_t n4 = (n + 3) / 4;
   const uint32_t blocks = (uint32_t)((n4 + kThreads - 1) / kThreads);
   hipLaunchKernelGGL(k_adam_step, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, n, param, grad,

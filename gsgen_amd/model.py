@@ -169,6 +169,7 @@ class GaussianSplattingRenderer(nn.Module):
         self.masks, self.mean_2ds = [], []  # (the reference's per-camera bookkeeping for update_densify_info: stays empty here --
         # the fused backward accumulates the statistics itself)
         self._strict, self._pipeline = bool(strict), pipeline
+        self.device_cameras = False  # True: camera blocks and pixel sizes from device memory (gsgen_amd.graph.CapturedStep)
         self._br = None
         self.to(self.device)
 
@@ -248,12 +249,18 @@ class GaussianSplattingRenderer(nn.Module):
         """the BatchRenderer of the current (N, W, H): rebuilt when the Gaussian set (densify / prune), the image size or the
         largest batch seen changes"""
         br = self._br
-        same = br is not None and (br.N, br.W, br.H) == (self.N, W, H) and br.device == self.mean.device
+        same = (br is not None and (br.N, br.W, br.H) == (self.N, W, H) and br.device == self.mean.device
+                and br.device_cameras == self.device_cameras)
         if not same or len(br.slots) < B:
             cap = max(B, len(br.slots)) if same else B
             br = self._br = BatchRenderer(self.N, W, H, self.mean.device, max_batch=cap, strict=self._strict,
-                                          pipeline=self._pipeline)
+                                          pipeline=self._pipeline, device_cameras=self.device_cameras)
         return br
+
+    def batch_renderer(self, batch):
+        """the BatchRenderer forward(batch) will use (gsgen_amd.graph.CapturedStep uploads a replay's cameras through it)"""
+        infos = batch["camera_info"]
+        return self._renderer(len(infos), int(infos[0].w), int(infos[0].h))
 
     def forward(self, batch, use_bg=True, rgb_only=False):
         """batch: {"c2w": [B, 3|4, 4] tensor (any device) or array, "camera_info": B CameraInfo-like objects (fx, fy, cx, cy, w, h,

@@ -21,8 +21,12 @@ from . import _capi
 
 
 class FusedAdam:
-    def __init__(self, fields, lrs, betas=(0.9, 0.999), eps=1e-15):
-        """fields: dict name -> initial tensor (same device, fp32); lrs: dict name -> float."""
+    def __init__(self, fields, lrs, betas=(0.9, 0.999), eps=1e-15, capturable=False):
+        """fields: dict name -> initial tensor (same device, fp32); lrs: dict name -> float.
+        capturable: the step's scalars (learning rate / (1 - beta1^t) per field, sqrt(1 - beta2^t)) are read from DEVICE memory
+        (gsgen_adam_step_device_scalars) instead of riding in kernel arguments: a step() enqueued into a stream capture uploads
+        nothing, and prepare_replay() -- which gsgen_amd.graph.CapturedStep calls before every replay -- counts the step, evaluates
+        the scalars on the host and copies them there, so a replayed step is the step torch's Adam would take at that count."""
         self.names = list(fields)
         dev = next(iter(fields.values())).device
         sizes = [int(fields[k].numel()) for k in self.names]
@@ -44,6 +48,10 @@ class FusedAdam:
         self._ends = np.array(ends, np.uint64)
         self.lrs = dict(lrs)
         self.betas, self.eps, self.step_count = betas, float(eps), 0
+        self.capturable = bool(capturable)
+        if self.capturable:
+            self._scal = torch.zeros(9, device=dev, dtype=torch.float32)
+            self._scal_host = np.zeros(9, np.float32)
 
     def zero_grad(self):
         self.grad.zero_()
@@ -73,6 +81,15 @@ class FusedAdam:
 
     def step(self, lrs=None):
         """lrs: this step's learning rates (the reference re-evaluates its schedulers every step)"""
+        if self.capturable:
+            if not torch.cuda.is_current_stream_capturing():
+                self.prepare_replay(lrs)  # (eager: count the step and upload its scalars, then the launch below)
+            with torch.cuda.device(self.flat.device):
+                _capi.load().adam_step_device_scalars(self.n, self.flat.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(),
+                                                      self.exp_avg_sq.data_ptr(), len(self.names), self._ends.ctypes.data_as(C.c_void_p),
+                                                      self.betas[0], self.betas[1], self.eps, self._scal.data_ptr(),
+                                                      torch.cuda.current_stream(self.flat.device).cuda_stream)
+            return
         if lrs is not None:
             self.lrs.update(lrs)
         self.step_count += 1
@@ -82,3 +99,17 @@ class FusedAdam:
                                    self.exp_avg_sq.data_ptr(), len(self.names), self._ends.ctypes.data_as(C.c_void_p),
                                    lr.ctypes.data_as(C.c_void_p), self.betas[0], self.betas[1], self.eps,
                                    self.step_count, torch.cuda.current_stream(self.flat.device).cuda_stream)
+
+    def prepare_replay(self, lrs=None):
+        """capturable optimisers: count one step and put its scalars in place on the current stream (36 bytes through kernel arguments) -- before the replay of a captured step that contains step()"""
+        if not self.capturable:
+            raise RuntimeError("FusedAdam.prepare_replay: built without capturable=True")
+        if lrs is not None:
+            self.lrs.update(lrs)
+        self.step_count += 1
+        lr = np.array([self.lrs[n_] for n_ in self.names], np.float32)
+        lib = _capi.load()
+        lib.adam_step_scalars(len(self.names), lr.ctypes.data_as(C.c_void_p), self.betas[0], self.betas[1], self.step_count,
+                              self._scal_host.ctypes.data_as(C.c_void_p))
+        with torch.cuda.device(self.flat.device):
+            lib.upload_small(self._scal.data_ptr(), self._scal_host.ctypes.data, 36, torch.cuda.current_stream(self.flat.device).cuda_stream)

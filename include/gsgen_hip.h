@@ -240,6 +240,15 @@ int gsgen_activate_fields_backward(uint32_t N, const float *svec_raw, const floa
 int gsgen_adam_step(uint64_t n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
                     uint32_t n_groups, const uint64_t *group_end, const float *group_lr, float beta1,
                     float beta2, float eps, uint32_t step, gsgen_stream_t stream);
+/* The same step with its per-step scalars read from DEVICE memory, so that a captured hipGraph of an optimisation step replays with
+ * the learning rates and bias corrections of the step it is replayed for (gsgen_amd.graph.CapturedStep; gsgen_adam_step bakes them
+ * into its kernel arguments).  scalars [9] (device): step_size of group 0 .. 7 (lr / (1 - beta1^step), unused groups ignored) and, at
+ * [8], sqrt(1 - beta2^step) -- the nine floats gsgen_adam_step_scalars computes on the HOST (same double arithmetic as
+ * gsgen_adam_step) into out9 for the caller to copy there. */
+int gsgen_adam_step_scalars(uint32_t n_groups, const float *group_lr, float beta1, float beta2, uint32_t step, float *out9);
+int gsgen_adam_step_device_scalars(uint64_t n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
+                                   uint32_t n_groups, const uint64_t *group_end, float beta1, float beta2, float eps,
+                                   const float *scalars, gsgen_stream_t stream);
 /* Densification statistics of one camera (gs/gaussian_splatting.py:1240-1245, :464-469), rows
  * aligned with mask [N] (NULL = all rows):
  *   max_radii2d[i] = max(max_radii2d[i], m + sqrt(max(m^2 - det(cov2d_i), 0))), m = tr/2
@@ -668,6 +677,11 @@ typedef struct gsgen_rgbd_view {
    * then reads 16 bytes per record instead of running the fp64 Cholesky preparation (kernels.h:195-224 evaluates the quadratic form in
    * fp64; here its factor is prepared in fp64) per staged (tile, Gaussian) record in the forward and again in the backward */
   const float *chol;
+  /* optional (batched launches): DEVICE address of {pixel_size_x, pixel_size_y} of this view.  When set the kernels take the two from
+   * there and ignore the floats above: nothing that changes from step to step then travels in kernel arguments, so a captured
+   * hipGraph of the step can be replayed for other cameras (poses AND intrinsics: the reference samples a focal length per step,
+   * data/__init__.py:194) once their camera blocks and these floats are in place (gsgen_amd.graph.CapturedStep). */
+  const float *pixel_size_dev;
 } gsgen_rgbd_view;
 /* The batched forwards (rgbd and rgb) write EVERY pixel of out6 / T, empty tiles included (channels 0, T = 1): the caller need
  * not pre-initialise the images (the per-camera entry points above keep the reference's contract: empty tiles are left alone). */

@@ -863,6 +863,23 @@ def test_emulated_batched_rgb_heads_match_per_view_launches(emu):
     emu.vol_render_rgbd_backward_batch(len(views), arr, Nall, P(col), P(al), P(ga), 16, nth, ntw, H, W, 1e-4, P(bws), None)
     for v in views:
         assert not v["gch"][:, 5].any() and np.abs(v["gch"][:, :5]).max() > 0
+    # the views' pixel sizes from DEVICE memory (gsgen_rgbd_view::pixel_size_dev: what lets a captured step replay for other
+    # intrinsics): the floats in the table are then ignored -- same bits as before with nonsense in them
+    for a, v in zip(arr, views):
+        v["ps"] = np.array([1 / v["cam"].fx, 1 / v["cam"].fy], np.float32)
+        a.pixel_size_x, a.pixel_size_y, a.pixel_size_dev = 123.0, -7.0, P(v["ps"])
+        a.grad_out6, a.grad_depth2 = P(v["go"]), None
+        v["out"][:] = 9.0; v["T"][:] = 9.0
+        for k in ("gm", "gc", "gch"):
+            v[k][:] = 0
+    ga[:] = 0
+    emu.vol_render_rgbd_batch(len(views), arr, Nall, P(col), P(al), 16, nth, ntw, H, W, 1e-4, P(bws), None)
+    emu.vol_render_rgbd_backward_batch(len(views), arr, Nall, P(col), P(al), P(ga), 16, nth, ntw, H, W, 1e-4, P(bws), None)
+    for v in views:
+        assert np.array_equal(v["out"], v["out_ref"]) and np.array_equal(v["T"], v["T_ref"])
+        for k in ("gm", "gc", "gch"):
+            assert np.array_equal(v[k], keep[id(v)][k]), k
+    assert np.array_equal(ga, ga_keep)
     arr[2].depth = None
     with pytest.raises(Exception, match="invalid"):
         emu.vol_render_rgbd_batch(len(views), arr, Nall, P(col), P(al), 16, nth, ntw, H, W, 1e-4, P(bws), None)
@@ -1575,6 +1592,7 @@ def test_emulated_adam_step_matches_torch_cpu(emu):
     opt = torch.optim.Adam([{"params": [v], "lr": 0.0, "name": k} for k, v in ref.items()], lr=0.0, eps=1e-15)
     flat = np.concatenate([v.detach().numpy().reshape(-1) for v in ref.values()]).astype(np.float32)
     m = np.zeros_like(flat); v2 = np.zeros_like(flat)
+    flat2, m2, v22 = flat.copy(), m.copy(), v2.copy()
     ends = np.cumsum([int(np.prod(sh)) for sh in shapes.values()]).astype(np.uint64)
     for step in range(1, 6):
         lrs = np.array([5e-3 / step, 1e-3, 5e-3, 1e-2 * step, 3e-2], np.float32)
@@ -1588,8 +1606,16 @@ def test_emulated_adam_step_matches_torch_cpu(emu):
                       1e-15, step, None)
         want = np.concatenate([v.detach().numpy().reshape(-1) for v in ref.values()])
         assert np.abs(flat - want).max() <= 2e-6 * np.abs(want).max(), step
+        # the same step with its scalars read from (device) memory -- what a captured step replays with: the same bits
+        sc9 = np.zeros(9, np.float32)
+        emu.adam_step_scalars(len(shapes), lrs.ctypes.data, 0.9, 0.999, step, sc9.ctypes.data)
+        emu.adam_step_device_scalars(flat2.size, P(flat2), P(g), P(m2), P(v22), len(shapes), ends.ctypes.data, 0.9, 0.999, 1e-15,
+                                     sc9.ctypes.data, None)
+        assert np.array_equal(flat2, flat) and np.array_equal(m2, m) and np.array_equal(v22, v2)
     with pytest.raises(Exception, match="invalid"):
         emu.adam_step(flat.size, P(flat), P(g), P(m), P(v2), 1, ends.ctypes.data, lrs.ctypes.data, 0.9, 0.999, 1e-15, 1, None)
+    with pytest.raises(Exception, match="invalid"):
+        emu.adam_step_scalars(len(shapes), lrs.ctypes.data, 0.9, 0.999, 0, sc9.ctypes.data)
 
 
 @pytest.mark.parametrize("C,nseg", [(4, 4), (2, 3)])

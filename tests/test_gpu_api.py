@@ -1160,3 +1160,80 @@ def test_raw_parameters_depth_variance_and_background_inside_the_launches():
     for k in keys:
         assert rel_err(g_in[k], g_t[k]) <= 2e-4 and rel_err(g_py[k], g_t[k]) <= 2e-4, k
     assert rel_err(b_in, b_t) <= 2e-4 and rel_err(b_py, b_t) <= 2e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_ext", [True, False])
+def test_captured_step_replays_other_poses_and_intrinsics(use_ext):
+    """gsgen_amd.graph.CapturedStep (opt-in hipGraph): a whole step -- render_heads with raw parameters, a loss, backward,
+    FusedAdam -- captured once with cameras A on a device_cameras renderer, replayed for cameras B (other poses AND other focal
+    lengths: the reference draws both per step, data/__init__.py:194) and again for A: images, gradients and parameters follow the eager trajectory on the same cameras (mean difference <= 2e-6, a few
+    threshold pixels apart), one capture for all replays."""
+    from gsgen_amd import renderer as R
+    from gsgen_amd import batch as Bm
+    from gsgen_amd.graph import CapturedStep
+    from gsgen_amd.optim import FusedAdam
+    sc = scenes.random_scene(6000, seed=31, svec=0.03, C=1)
+    N, W, H, B = sc["mean"].shape[0], 160, 112, 2
+    mk = lambda fx, el, az: scenes.Camera(W, H, fx=fx, c2w=scenes.orbit(2.4, el, az))  # noqa: E731
+    sets = {"A": [mk(250.0, 5, 50), mk(300.0, 20, 170)], "B": [mk(190.0, 35, -60), mk(340.0, -10, 260)], "C": [mk(275.0, 50, 10), mk(225.0, 0, 95)]}
+    cam = {k: ([R.CameraInfo(*c.intr) for c in v], np.stack([c.c2w for c in v])) for k, v in sets.items()}
+    logit = lambda x: np.log(np.clip(x, 1e-3, 1 - 1e-3) / (1 - np.clip(x, 1e-3, 1 - 1e-3)))  # noqa: E731
+    raw0 = {"mean": sc["mean"], "qvec": sc["qvec"], "svec": np.log(sc["svec"]), "alpha": logit(sc["alpha"]), "color": logit(sc["color"])}
+    keys = ("mean", "qvec", "svec", "alpha", "color")
+    gen = torch.Generator(device=dev()).manual_seed(9)
+    gos = [torch.randn(B, H, W, c, device=dev(), generator=gen) * 1e-3 for c in (3, 1, 1, 1)]
+    bg = torch.tensor([0.3, 0.4, 0.5], device=dev())
+    order = ["A", "B", "A", "C", "B"]
+
+    def make(device_cameras):
+        opt = FusedAdam({k: T_(raw0[k].astype(np.float32)) for k in keys}, {k: 1e-3 for k in keys}, eps=1e-15, capturable=device_cameras)
+        br = Bm.BatchRenderer(N, W, H, dev(), max_batch=B, device_cameras=device_cameras)
+        br.use_ext = use_ext
+        P_ = opt.params
+
+        def step(cis, c2ws):
+            opt.zero_grad()
+            outs = br.render_heads(P_["mean"], P_["qvec"], P_["svec"], P_["alpha"], P_["color"], cis, c2ws, bg_rgb=bg, z_var=True,
+                                   activations=("exp", "sigmoid", "sigmoid"))[:4]
+            sum((o * g_).sum() for o, g_ in zip(outs, gos)).backward()
+            grads = [P_[k].grad for k in keys]
+            opt.step()
+            return outs, grads
+        return opt, br, step
+
+    def snap(outs, grads, opt):
+        torch.cuda.synchronize()
+        return ([o.detach().cpu().numpy().copy() for o in outs], [g.detach().cpu().numpy().copy() for g in grads],
+                {k: opt.params[k].detach().cpu().numpy().copy() for k in keys})
+
+    # eager reference trajectory on a default renderer: the warm-up steps CapturedStep takes on A (2 + 1 on the capture stream; the
+    # capture itself records, it does not execute), then `order`
+    opt_e, br_e, step_e = make(False)
+    for _ in range(3):
+        step_e(*cam["A"])
+    eager = [snap(*step_e(*cam[k]), opt_e) for k in order]
+    opt_g, br_g, step_g = make(True)
+    cs = CapturedStep(br_g, step_g, *cam["A"], optimizers=[opt_g])
+    got = []
+    for k in order:
+        outs, grads = cs(*cam[k])
+        got.append(snap(outs, grads, opt_g))
+    assert cs.captures == 1 and cs.replays == len(order) and opt_g.step_count == opt_e.step_count == 3 + len(order)
+    for k, (eo, eg, ep), (go_, gg, gp) in zip(order, eager, got):
+        # (two trajectories: the order of the gradients' atomics differs from run to run, Adam turns a sign flip of a near-zero
+        # gradient into a step of its own, and a splat at an alpha / transmittance threshold flips a pixel -- hence mean and
+        # outlier-fraction bounds, not a maximum; a replay that rendered the wrong cameras is off by tenths everywhere, below)
+        for a, b in zip(eo, go_):
+            assert np.isfinite(b).all() and np.abs(b).max() > 0
+            d = np.abs(a - b) / max(1.0, float(np.abs(a).max()))
+            assert d.mean() <= 2e-6 and (d > 2e-4).mean() <= 5e-4, (k, float(d.mean()), float((d > 2e-4).mean()))
+        for name, a, b in zip(keys, eg, gg):
+            assert rel_err(b, a) <= 2e-3, (k, name)
+        for name in keys:
+            d = np.abs(ep[name] - gp[name])
+            assert d.mean() <= 2e-6 and d.max() <= 1e-2, (k, name)
+    # the two focal lengths of a set really differ from the captured ones: a replay that ignored the uploaded intrinsics would not match
+    assert np.abs(eager[0][0][0] - eager[1][0][0]).mean() > 0.02 and np.abs(eager[0][0][0] - eager[3][0][0]).mean() > 0.02
+    with pytest.raises(ValueError, match="device_cameras"):
+        CapturedStep(br_e, step_e, *cam["A"])

@@ -43,20 +43,29 @@ logit = lambda x: np.log(x / (1 - x))  # noqa: E731
 raw0 = {"mean": sc["mean"], "qvec": sc["qvec"], "svec": np.log(sc["svec"]), "color": logit(np.clip(sc["color"], 1e-3, 1 - 1e-3)),
         "alpha": logit(np.clip(sc["alpha"], 1e-3, 1 - 1e-3))}
 opt = FusedAdam({k: torch.from_numpy(np.ascontiguousarray(v, np.float32)).to(dev) for k, v in raw0.items()},
-                {"mean": 5e-3, "qvec": 3e-3, "svec": 3e-3, "color": 1e-2, "alpha": 3e-3}, eps=1e-15)  # conf/base.yaml:8-30
+                {"mean": 5e-3, "qvec": 3e-3, "svec": 3e-3, "color": 1e-2, "alpha": 3e-3}, eps=1e-15,  # conf/base.yaml:8-30
+                capturable=a.graph)
 P = opt.params
 rng = np.random.default_rng(0)
-cams = [scenes.Camera(a.res, a.res, fx=float(rng.uniform(0.7, 1.35) * a.res),
-                      c2w=scenes.orbit(float(rng.uniform(2, 2.5)), float(rng.uniform(-20, 60)), float(rng.uniform(-180, 180))))
-        for _ in range(a.batch)]
-cis, c2ws = [R.CameraInfo(*c.intr) for c in cams], [c.c2w for c in cams]
-br = BatchRenderer(a.n, a.res, a.res, dev, max_batch=a.batch, pipeline={'auto': 'auto', 'on': True, 'off': False}[a.pipeline])
+# a pool of camera batches, a fresh one per step: pose AND focal length drawn per step as the reference's loader draws them
+# (data/__init__.py:187-200; conf/base.yaml:71-85)
+pool = []
+for _ in range(64):
+    cams = [scenes.Camera(a.res, a.res, fx=float(rng.uniform(0.75, 1.35) * a.res),
+                          c2w=scenes.orbit(2.5, float(rng.uniform(-20, 90)), float(rng.uniform(-180, 180)))) for _ in range(a.batch)]
+    pool.append(([R.CameraInfo(*c.intr) for c in cams], np.stack([c.c2w for c in cams])))
+tick = [0]
+br = BatchRenderer(a.n, a.res, a.res, dev, max_batch=a.batch, pipeline={'auto': 'auto', 'on': True, 'off': False}[a.pipeline],
+                   device_cameras=a.graph)
 stats = R.DensifyStats(a.n, dev)
 g_sds = torch.randn(a.batch, a.res, a.res, 3, device=dev) * 1e-4  # the guidance's gradient on the rendered batch
 bg = torch.tensor([0.5, 0.5, 0.5], device=dev)
 
 
-def step():
+def step(cis=None, c2ws=None):
+    if cis is None:
+        cis, c2ws = pool[tick[0] % len(pool)]
+        tick[0] += 1
     opt.zero_grad()
     if a.torch_ops:  # rounds 1-5: the activations, the background and z_var as torch kernels / autograd nodes around the launches
         rgb, dpt, opa, z2, _ = br.render_heads(P["mean"], P["qvec"], torch.exp(P["svec"]), torch.sigmoid(P["alpha"]),
@@ -77,21 +86,18 @@ for _ in range(a.warmup):
     step()
 run, graph_error = step, None
 if a.graph:
-    # (the captured optimiser step carries its step count -- the bias correction -- as a constant: fine for a timing run)
+    # gsgen_amd.graph.CapturedStep: the whole step as one hipGraph, replayed for a FRESH camera batch every time (camera blocks and pixel
+    # sizes from device memory, the optimiser's per-step scalars likewise: round 6)
     try:
-        torch.cuda.synchronize()
-        assert br.ensure_capacity(a.batch)  # also drops the pending pair-count event: nothing is queried during capture
-        s = torch.cuda.Stream(dev)
-        s.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(s):
-            step()
-            gr = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gr, stream=s):
-                step()
-            for _ in range(5):
-                gr.replay()
-        torch.cuda.current_stream(dev).wait_stream(s)
-        run = gr.replay
+        from gsgen_amd.graph import CapturedStep
+        cs = CapturedStep(br, step, *pool[0], optimizers=[opt])
+
+        def run():
+            cis, c2ws = pool[tick[0] % len(pool)]
+            tick[0] += 1
+            cs(cis, c2ws)
+        for _ in range(5):
+            run()
     except Exception as e:  # report, and time the eager step instead
         graph_error = f"{type(e).__name__}: {str(e)[:300]}"
 if a.profile:
@@ -124,7 +130,8 @@ torch.cuda.synchronize()
 t1 = time.perf_counter() - t0
 print(json.dumps({"metric": "optimisation-step iters/sec, renderer + optimiser share (guidance stubbed)", "value": a.steps / t1,
                   "unit": "iters/s", "ms_per_iter": 1e3 * t1 / a.steps, "host_ms_per_iter": 1e3 * t_host / a.steps,
-                  "views_per_s": a.batch * a.steps / t1, "hipgraph": bool(a.graph) and graph_error is None, "pipeline": a.pipeline, "hipgraph_error": graph_error,
+                  "views_per_s": a.batch * a.steps / t1, "hipgraph": bool(a.graph) and graph_error is None,
+                  "cameras": "a fresh batch per step (pose and focal length)", "graph_captures": (cs.captures if a.graph and graph_error is None else None), "pipeline": a.pipeline, "hipgraph_error": graph_error,
                   "config": {"workload": "BASELINE configs[4] without the diffusion model: 100k Gaussians, "
                                          f"{a.batch} views at {a.res}x{a.res}, rgb + depth + opacity + z_var, "
                                          "densify statistics, Adam on the five raw fields", "gaussians": a.n}}))
