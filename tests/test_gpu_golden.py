@@ -20,6 +20,11 @@ def dev():
 _KEEP = []
 
 
+def rel_err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
 def T_(a):
     t = torch.from_numpy(np.ascontiguousarray(a)).to(dev())
     _KEEP.append(t)
@@ -218,3 +223,70 @@ def test_fused_model_path_matches_the_reference_model_golden(through):
     assert np.abs(stats.cnt.cpu().numpy() - g["cnt"]).sum() <= mask_diff
     assert rel(stats.max_radii2d.cpu().numpy(), g["max_radii2d"]) < 1e-5 or mask_diff
     assert rel(stats.grad_accum.cpu().numpy(), g["grad_accum"]) < 1e-3
+
+
+@pytest.mark.gpu
+def test_model_class_forward_backward_captured_and_replayed_for_other_cameras():
+    """gsgen_amd.graph.CapturedStep around gsgen_amd.model.GaussianSplattingRenderer (model.device_cameras = True): forward(batch) ->
+    the four-term loss -> backward, captured with the fixture's two cameras and replayed for two others (other poses, other focal
+    lengths) and for the fixture's again: the images of every replay are those of an eager model on the same cameras (every pixel
+    within 1e-5), the raw-parameter gradients within 1e-3 of their tensor's largest entry, with one capture; the replay of the
+    fixture's own cameras still reproduces tests/golden/model/model_batch.npz's images."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import make_golden_model as MG
+    from gsgen_amd import renderer as R
+    from gsgen_amd.model import GaussianSplattingRenderer
+    from gsgen_amd.graph import CapturedStep
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "model", "model_batch.npz"))
+    names = ("mean", "qvec", "svec", "color", "alpha")
+    B = g["c2w"].shape[0]
+    ci = lambda row, f=1.0: R.CameraInfo(float(row[0]) * f, float(row[1]) * f, float(row[2]), float(row[3]), int(row[4]), int(row[5]),  # noqa: E731
+                                         float(row[6]), float(row[7]))
+    sets = {"fixture": ([ci(g["cam_intr"][b]) for b in range(B)], np.ascontiguousarray(g["c2w"], np.float32)),
+            "other": ([ci(g["cam_intr"][0], 0.8), ci(g["cam_intr"][1], 1.25)],
+                      np.stack([scenes.orbit(2.2, 35, -70), scenes.orbit(2.0, 5, 120)]).astype(np.float32))}
+    gos = {k: T_(g["go_" + k]) for k in ("rgb", "depth", "opacity", "z_var")}
+
+    def make(device_cameras):
+        cfg = MG.model_cfg()
+        cfg["device"] = "cuda:0"
+        model = GaussianSplattingRenderer(cfg, {"raw": True, **{k: torch.tensor(g["raw_" + k]) for k in names}})
+        model.train()
+        model.device_cameras = device_cameras
+        params = [model.mean, model.qvec, model.svec_before_activation, model.color_before_activation, model.alpha_before_activation]
+
+        def step(cis, c2ws):
+            for q in params:
+                q.grad = None
+            out = model({"c2w": c2ws, "camera_info": cis})
+            sum((out[k] * gos[k]).sum() for k in out).backward()
+            model.post_backward()
+            return out, [q.grad for q in params]
+        return model, step
+
+    def snap(res):
+        out, grads = res
+        torch.cuda.synchronize()
+        return {k: v.detach().cpu().numpy().copy() for k, v in out.items()}, [x.detach().cpu().numpy().copy() for x in grads]
+
+    _, step_e = make(False)
+    order = ["fixture", "other", "fixture"]
+    eager = {k: snap(step_e(*sets[k])) for k in sets}
+    model_g, step_g = make(True)
+    cs = CapturedStep(model_g, step_g, *sets["fixture"])
+    for k in order:
+        got_o, got_g = snap(cs(*sets[k]))
+        want_o, want_g = eager[k]
+        for name in want_o:
+            scale = max(1.0, float(np.abs(want_o[name]).max()))
+            assert np.abs(got_o[name] - want_o[name]).max() <= 1e-5 * scale, (k, name)
+        for name, a, b in zip(names, want_g, got_g):
+            assert rel_err(b, a) <= 1e-3, (k, name)
+    assert cs.captures == 1 and cs.replays == 3
+    assert np.abs(eager["fixture"][0]["rgb"] - eager["other"][0]["rgb"]).mean() > 0.02  # (the two sets really differ)
+    for name in ("rgb", "depth", "opacity", "z_var"):  # the fixture, through the replay (threshold pixels as in the test above)
+        d = np.abs(got_o[name] - g["out_" + name]) / max(1.0, float(np.abs(g["out_" + name]).max()))
+        assert (d > 1e-4).sum() <= 8 and d.max() <= 6e-3, name
+    with pytest.raises(ValueError, match="device_cameras"):
+        CapturedStep(make(False)[0], step_e, *sets["fixture"])
