@@ -320,6 +320,29 @@ def other_configs(steps=10, warmup=3):
     return out
 
 
+def trainer_step():
+    """BASELINE configs[4] without the diffusion model (tools/bench_step.py: 100 k Gaussians, 4 views at 512^2 drawn afresh per step,
+    rgb + depth + opacity + z_var, densify statistics, Adam on the five raw fields) -- eager, and as ONE hipGraph replayed for each
+    step's fresh cameras (gsgen_amd.graph.CapturedStep) -- each in a process of its own: iterations/s and host time per iteration."""
+    import subprocess
+    out = {}
+    tool = os.path.join(ROOT, "tools", "bench_step.py")
+    for name, extra in (("eager", []), ("captured_hipgraph", ["--graph"])):
+        try:
+            r = subprocess.run([sys.executable, tool, "--steps", "200", "--warmup", "20", *extra], capture_output=True, text=True, timeout=180)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not line:
+                out[name] = {"error": (r.stderr or r.stdout)[-300:]}
+                continue
+            j = json.loads(line[-1])
+            out[name] = {"value": j["value"], "unit": j["unit"], "ms_per_iter": j["ms_per_iter"], "host_ms_per_iter": j["host_ms_per_iter"],
+                         "hipgraph": j["hipgraph"], "hipgraph_error": j.get("hipgraph_error"), "graph_captures": j.get("graph_captures")}
+            out["workload"] = j["config"]["workload"] + "; " + j.get("cameras", "")
+        except Exception as e:
+            out[name] = {"error": repr(e)[:300]}
+    return out
+
+
 def model_surfaces(sc, cams, dev, B, K, H, W):
     """views/s of the model-level training call on the bench workload (B cameras per step, one step in flight, dense random
     gradients into all four outputs, gradients to the five raw parameter fields, densify statistics updated):
@@ -432,7 +455,7 @@ def main():
     What follows are secondary views, one function each, none of which touches `value`: exact_basis_view (the same region, exact SH
     basis), the no-gather region (multi-GPU), one_in_flight (one step at a time), heads_report (the RGB + heads step measured like
     `value`), alone_pass (one launch in flight), latency_view (one camera at a time), autograd_surface_view (BatchRenderer + autograd),
-    model_surfaces (the model-level call; module level), other_configs (cfg3 / cfg4 / stress lines; module level), cpu_baseline
+    model_surfaces (the model-level call; module level), other_configs (cfg3 / cfg4 / stress lines; module level), trainer_step (the 4 x 512^2 optimisation step, eager and captured; module level), cpu_baseline
     (the oracle; module level).  `--only-timed` runs warm-up + timed regions and none of them."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -504,7 +527,7 @@ def main():
                     help="experiment: after every J steps all slot streams wait for each other -- with --batch B/2 --slots 2 "
                          "--join-every 2 a strictly sequential optimiser whose step is two half-batches on two streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-other-configs", action="store_true", help="skip the cfg3 / cfg4 / routing-stress lines (`other_configs`)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the cfg3 / cfg4 / routing-stress lines (`other_configs`) and the trainer-shaped step (`trainer_step`)")
     ap.add_argument("--no-latency", action="store_true", help="skip the one-render-in-flight and hipGraph passes")
     args = ap.parse_args()
     dry = args.dry_run_lib is not None
@@ -1455,6 +1478,7 @@ def main():
             res["cpu_baseline"] = cpu_baseline(sc, cams, C)
         if world == 1 and args.config == "cfg2" and not args.no_other_configs and args.focal_scale == 1.0 and args.outlier_fraction == 0.0:
             res["other_configs"] = other_configs()
+            res["trainer_step"] = trainer_step()
         print(json.dumps(res), file=json_out, flush=True)
     if dist is not None:
         dist.barrier()
