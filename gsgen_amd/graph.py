@@ -37,8 +37,8 @@ from .batch import BatchRenderer
 class CapturedStep:
     def __init__(self, renderer, step, cam_infos, c2ws, warmup=2, frustum_radius=6.0, tile_radius=6.0, optimizers=()):
         """renderer: a BatchRenderer built with device_cameras=True (or a gsgen_amd.model.GaussianSplattingRenderer whose
-        `device_cameras` attribute is True: its current BatchRenderer is used, fixed / learned_const backgrounds only -- a random
-        background is drawn on the host per call).  step(cam_infos, c2ws): enqueues the whole step on the current stream and returns
+        `device_cameras` attribute is True: its current BatchRenderer is used; a random background's colours are drawn on the host before
+        every replay exactly as an eager forward draws them, random_aug backgrounds are not supported inside a capture).  step(cam_infos, c2ws): enqueues the whole step on the current stream and returns
         tensors (or None); it is called `warmup` + 1 times eagerly with the given cameras (real steps), then once more under capture
         (recorded, not executed).
         optimizers: the FusedAdam(capturable=True) objects whose step() the step contains -- before every replay their
@@ -105,6 +105,8 @@ class CapturedStep:
             self._capture(list(cam_infos), c2ws)
             br = self._renderer_used
         br.upload_cameras(cam_infos, c2ws, *self._radii)
+        if self._model is not None and hasattr(self._model, "prepare_replay"):
+            self._model.prepare_replay({"camera_info": cam_infos, "c2w": c2ws})  # (a random background's colours for this replay)
         for o in self._optimizers:
             o.prepare_replay()
         self._graph.replay()

@@ -110,6 +110,10 @@ class _Background(nn.Module):
         elif self.type != "random":
             raise NotImplementedError(f"gsgen_amd.model: background type {self.type!r} (MLPBackground needs tinycudann; pass the "
                                       "colours yourself through BatchRenderer.render_heads(bg_rgb=...))")
+        # a captured step (gsgen_amd.graph.CapturedStep, model.device_cameras): the colours drawn on the host live in ONE device tensor
+        # that the captured launches read; a forward enqueued into a capture draws nothing, refresh() draws for the next replay
+        self.static = False
+        self._static = None
 
     def forward(self, B, device=None):
         """B cameras -> [B, 1, 1, 3] (what the batched forward composites); or, called as the reference calls it -- bg(rays_d) with
@@ -117,7 +121,19 @@ class _Background(nn.Module):
         if isinstance(B, torch.Tensor):
             rays = B
             return self.forward(1, rays.device).view(1, 1, 3).expand(rays.shape[0], rays.shape[1], 3).to(rays.dtype)
+        if self.static and self.type == "random" and not self.random_aug:
+            if torch.cuda.is_current_stream_capturing():
+                if self._static is None or self._static.shape[0] < B:
+                    raise RuntimeError("gsgen_amd.model: a random background inside a capture needs one eager forward of this batch size first")
+                return self._static[:B]
+            cols = self._colours(B, device)
+            if self._static is None or self._static.shape[0] < B or self._static.device != cols.device:
+                self._static = torch.empty(B, 1, 1, 3, device=cols.device, dtype=cols.dtype)
+            self._static[:B].copy_(cols)
+            return self._static[:B]
         if self.random_aug and self.training and self.type != "fixed":
+            if self.static and torch.cuda.is_current_stream_capturing():
+                raise NotImplementedError("gsgen_amd.model: random_aug backgrounds pick per camera on the host: not inside a captured step")
             # gs/backgrounds.py:24-36: with probability 1 - random_aug_prob a camera's background is one random colour
             import random
             cols = self._colours(B, device)
@@ -257,6 +273,14 @@ class GaussianSplattingRenderer(nn.Module):
                                           pipeline=self._pipeline, device_cameras=self.device_cameras)
         return br
 
+    def prepare_replay(self, batch):
+        """before the replay of a captured step (gsgen_amd.graph.CapturedStep calls it): what an eager forward does on the HOST for this
+        batch and a capture cannot -- a random background's colours, drawn as the reference draws them (gs/backgrounds.py:58) and put
+        where the captured launches read them"""
+        self.bg.static = self.device_cameras
+        if self.bg.type == "random" and self.bg.static:
+            self.bg(len(batch["camera_info"]), self.mean.device)
+
     def batch_renderer(self, batch):
         """the BatchRenderer forward(batch) will use (gsgen_amd.graph.CapturedStep uploads a replay's cameras through it)"""
         infos = batch["camera_info"]
@@ -283,6 +307,7 @@ class GaussianSplattingRenderer(nn.Module):
                 self.reset_densify_info()
             stats = _Stats(self.max_radii2d, self.mean_2d_grad_accum if self.densify_enabled else None,
                            self.cnt if self.densify_enabled else None)
+        self.bg.static = self.device_cameras
         bg = self.bg(B, self.mean.device)
         fr = 0.0 if self.skip_frustum_culling else self.frustum_culling_radius
         if rgb_only:
