@@ -11,7 +11,7 @@
         opt.step()
         return loss
 
-    cs = CapturedStep(br, step, cam_infos, c2ws)       # two eager steps (they size the pair lists), then the capture
+    cs = CapturedStep(br, step, cam_infos, c2ws)       # warmup + 1 = 3 REAL eager steps with these cameras (they size the pair lists), then the capture
     for it in range(steps):
         cam_infos, c2ws = sample_cameras()             # a pose AND a focal length per step, as the reference's loader draws them
         image_gradient.copy_(guidance(...))            # inputs of the step other than the cameras: update them IN PLACE
@@ -24,8 +24,8 @@ is being captured; `CapturedStep.__call__` uploads the new cameras (one small en
 What a replay does NOT do is the host side of an eager call: the pair-list bookkeeping.  After every replay the renderer's report
 words are read (no sync, as every eager render does): a camera that did not fit its list raises PairListOverflow exactly as in eager
 mode (its image was NaN and it contributed no gradients: the captured step has been applied without it), and whenever the lists were
-regrown -- quietly, with 25 % headroom left, or after an overflow -- the graph is captured again before the next replay (the lists'
-addresses are baked into it).  Densify / prune change N: build a new renderer and a new CapturedStep.
+regrown -- quietly, with 25 % headroom left, or after an overflow -- the next call runs its step eagerly and records the graph again behind
+it (the lists' addresses are baked into a graph): one step per call either way.  Densify / prune change N: build a new renderer and a new CapturedStep.
 
 RGB + heads and RGB batches (render_heads; render with C = 0).  Reference: the loop this replaces is trainer.py:291-421 around
 gs/gaussian_splatting.py:1423-1466."""
@@ -62,7 +62,7 @@ class CapturedStep:
             if not getattr(o, "capturable", False):
                 raise ValueError("CapturedStep: optimizers must be FusedAdam(capturable=True)")
         self.replays = self.captures = 0
-        self._capture(list(cam_infos), c2ws)
+        self._capture(list(cam_infos), c2ws, self._warmup + 1)
 
     # ------------------------------------------------------------------------------------------------------------------------
     def _renderer(self, cam_infos, c2ws):
@@ -70,27 +70,29 @@ class CapturedStep:
             return self._model.batch_renderer({"camera_info": cam_infos, "c2w": c2ws})
         return self._br
 
-    def _capture(self, cam_infos, c2ws):
-        for _ in range(self._warmup):  # eager: sizes the pair lists (one host sync the first time), builds every table and buffer
-            self._step(cam_infos, c2ws)
+    def _capture(self, cam_infos, c2ws, eager_steps):
+        """`eager_steps` REAL steps with these cameras on the capture stream (they size the pair lists, build every table and buffer,
+        fill the allocator's pools), then the capture, which records the step and does not run it -> the last eager step's outputs"""
         br = self._renderer(cam_infos, c2ws)
         dev = br.device
-        torch.cuda.synchronize(dev)
-        if not br.ensure_capacity(self._B):  # (also settles the report words: nothing is pending when the capture starts)
-            self._step(cam_infos, c2ws)
-            torch.cuda.synchronize(dev)
-            br.ensure_capacity(self._B)
-        self._key = self._lists_key(br)
         side = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
-            self._step(cam_infos, c2ws)  # (once more on the capture stream: allocator pools, lazily built tables)
+            for _ in range(max(1, eager_steps)):
+                out_e = self._step(cam_infos, c2ws)
+            br = self._renderer(cam_infos, c2ws)
+            side.synchronize()
+            while not br.ensure_capacity(self._B):  # (one host sync; settles the report words: nothing is pending when the capture starts)
+                out_e = self._step(cam_infos, c2ws)  # that step's images were NaN for a camera that did not fit: once more, as eager callers do
+                side.synchronize()
+            self._key = self._lists_key(br)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=side):
                 out = self._step(cam_infos, c2ws)
         torch.cuda.current_stream(dev).wait_stream(side)
         self._graph, self.outputs, self._renderer_used = graph, out, br
         self.captures += 1
+        return out_e
 
     @staticmethod
     def _lists_key(br):
@@ -101,9 +103,10 @@ class CapturedStep:
         if len(cam_infos) != self._B:
             raise ValueError(f"CapturedStep: captured for {self._B} cameras, got {len(cam_infos)}")
         br = self._renderer(cam_infos, c2ws)
-        if br is not self._renderer_used or self._lists_key(br) != self._key:  # the lists moved (regrown) or the model rebuilt its renderer
-            self._capture(list(cam_infos), c2ws)
-            br = self._renderer_used
+        if br is not self._renderer_used or self._lists_key(br) != self._key:
+            # the lists moved (regrown) or the model rebuilt its renderer: THIS call's step runs eagerly -- one step per call, as ever --
+            # and the graph is recorded again behind it (-> that eager step's outputs, valid until the next call like the captured ones)
+            return self._capture(list(cam_infos), c2ws, 1)
         br.upload_cameras(cam_infos, c2ws, *self._radii)
         if self._model is not None and hasattr(self._model, "prepare_replay"):
             self._model.prepare_replay({"camera_info": cam_infos, "c2w": c2ws})  # (a random background's colours for this replay)

@@ -1237,3 +1237,27 @@ def test_captured_step_replays_other_poses_and_intrinsics(use_ext):
     assert np.abs(eager[0][0][0] - eager[1][0][0]).mean() > 0.02 and np.abs(eager[0][0][0] - eager[3][0][0]).mean() > 0.02
     with pytest.raises(ValueError, match="device_cameras"):
         CapturedStep(br_e, step_e, *cam["A"])
+    # cameras that need far more (tile, Gaussian) pairs than the lists hold: the replay renders them as NaN and the report words say so
+    # (PairListOverflow, lists regrown -- exactly the eager behaviour); the next call runs its step eagerly and records the graph again;
+    # the one after replays the new graph.  One optimiser step per call throughout.
+    import gsgen_amd
+    near = [scenes.Camera(W, H, fx=520.0, c2w=scenes.orbit(1.15, 10, 30)), scenes.Camera(W, H, fx=480.0, c2w=scenes.orbit(1.2, 25, 200))]
+    near = ([R.CameraInfo(*c.intr) for c in near], np.stack([c.c2w for c in near]))
+    cap0, calls = br_g.slots[0].D_cap, 0
+    try:
+        cs(*near); calls += 1
+        torch.cuda.synchronize()
+        cs(*near); calls += 1   # (the report of the first replay is certainly in by now)
+        overflowed = False
+    except gsgen_amd.PairListOverflow:
+        calls += 1
+        overflowed = True
+    assert overflowed or br_g.slots[0].D_cap > cap0, "the near cameras were meant to outgrow the lists"
+    outs, _ = cs(*near); calls += 1
+    assert cs.captures == 2
+    outs2, _ = cs(*near); calls += 1
+    torch.cuda.synchronize()
+    assert cs.captures == 2 and opt_g.step_count == 3 + len(order) + calls
+    for o in list(outs) + list(outs2):
+        assert torch.isfinite(o).all()
+    assert float((outs2[2] > 0.5).float().mean()) > 0.2  # (opacity: the near views are mostly covered)
