@@ -23,7 +23,8 @@ is being captured; `CapturedStep.__call__` uploads the new cameras (one small en
 
 What a replay does NOT do is the host side of an eager call: the pair-list bookkeeping.  After every replay the renderer's report
 words are read (no sync, as every eager render does): a camera that did not fit its list raises PairListOverflow exactly as in eager
-mode (its image was NaN and it contributed no gradients: the captured step has been applied without it), and whenever the lists were
+mode (its image was NaN and it contributed no gradients: the captured step has been applied without it; the replay in flight at that
+moment ran on the old lists too and is settled with it), and whenever the lists were
 regrown -- quietly, with 25 % headroom left, or after an overflow -- the next call runs its step eagerly and records the graph again behind
 it (the lists' addresses are baked into a graph): one step per call either way.  Densify / prune change N: build a new renderer and a new CapturedStep.
 
@@ -114,5 +115,12 @@ class CapturedStep:
             o.prepare_replay()
         self._graph.replay()
         self.replays += 1
-        br.check_overflow()  # (no sync; raises PairListOverflow for a camera of an earlier replay, regrows quietly near capacity)
+        try:
+            br.check_overflow()  # (no sync; raises PairListOverflow for a camera of an earlier replay, regrows quietly near capacity)
+        except Exception:
+            # the lists have been regrown; the replay just enqueued still ran on the old ones and is lost with the reported one (its
+            # report would otherwise raise once more, from the eager step of the next call): settle it here, once per episode
+            torch.cuda.synchronize(br.device)
+            br._report.clear()
+            raise
         return self.outputs

@@ -1173,7 +1173,7 @@ def test_captured_step_replays_other_poses_and_intrinsics(use_ext):
     from gsgen_amd import batch as Bm
     from gsgen_amd.graph import CapturedStep
     from gsgen_amd.optim import FusedAdam
-    sc = scenes.random_scene(6000, seed=31, svec=0.03, C=1)
+    sc = scenes.random_scene(6000, seed=31, svec=0.1, C=1)
     N, W, H, B = sc["mean"].shape[0], 160, 112, 2
     mk = lambda fx, el, az: scenes.Camera(W, H, fx=fx, c2w=scenes.orbit(2.4, el, az))  # noqa: E731
     sets = {"A": [mk(250.0, 5, 50), mk(300.0, 20, 170)], "B": [mk(190.0, 35, -60), mk(340.0, -10, 260)], "C": [mk(275.0, 50, 10), mk(225.0, 0, 95)]}
@@ -1186,9 +1186,16 @@ def test_captured_step_replays_other_poses_and_intrinsics(use_ext):
     bg = torch.tensor([0.3, 0.4, 0.5], device=dev())
     order = ["A", "B", "A", "C", "B"]
 
+    # pair lists sized for the three camera sets with 35 % to spare (an explicit D_cap: the default minimum of 65 536 pairs would
+    # hold anything this scene can produce) -- the near cameras further down do not fit
+    near = [scenes.Camera(W, H, fx=520.0, c2w=scenes.orbit(1.15, 10, 30)), scenes.Camera(W, H, fx=480.0, c2w=scenes.orbit(1.2, 25, 200))]
+    need = {k: max(scenes.oracle_geometry(sc, c)["D"] for c in v) for k, v in {**sets, "near": near}.items()}
+    D_cap = int(1.35 * max(need[k] for k in sets))
+    assert need["near"] > D_cap, need
+
     def make(device_cameras):
         opt = FusedAdam({k: T_(raw0[k].astype(np.float32)) for k in keys}, {k: 1e-3 for k in keys}, eps=1e-15, capturable=device_cameras)
-        br = Bm.BatchRenderer(N, W, H, dev(), max_batch=B, device_cameras=device_cameras)
+        br = Bm.BatchRenderer(N, W, H, dev(), max_batch=B, device_cameras=device_cameras, D_cap=D_cap)
         br.use_ext = use_ext
         P_ = opt.params
 
@@ -1241,7 +1248,6 @@ def test_captured_step_replays_other_poses_and_intrinsics(use_ext):
     # (PairListOverflow, lists regrown -- exactly the eager behaviour); the next call runs its step eagerly and records the graph again;
     # the one after replays the new graph.  One optimiser step per call throughout.
     import gsgen_amd
-    near = [scenes.Camera(W, H, fx=520.0, c2w=scenes.orbit(1.15, 10, 30)), scenes.Camera(W, H, fx=480.0, c2w=scenes.orbit(1.2, 25, 200))]
     near = ([R.CameraInfo(*c.intr) for c in near], np.stack([c.c2w for c in near]))
     cap0, calls = br_g.slots[0].D_cap, 0
     try:
