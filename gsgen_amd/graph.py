@@ -44,7 +44,7 @@ class CapturedStep:
         (recorded, not executed).
         optimizers: the FusedAdam(capturable=True) objects whose step() the step contains -- before every replay their
         prepare_replay() counts the step and uploads its learning rates / bias corrections (an optimiser that bakes them into kernel
-        arguments would repeat the captured step's)."""
+        arguments would repeat the captured step's).  A learning-rate schedule: set `opt.lrs[name]` before the call."""
         self._model = None
         if not isinstance(renderer, BatchRenderer):
             self._model, model = renderer, renderer
