@@ -8,9 +8,11 @@ import scenes
 from oracle import oracle as O
 
 
-FUZZ_ATOL = 1e-5
-# (ts, C, W, H, n, seed, svec, opaque): examples a 1 500-example hunt on the MI355X found beyond rtol 1e-3 + 1e-6 (round 5)
-KNOWN_WORST = [(8, 1, 10, 35, 1258, 2, 0.2, True)]
+FUZZ_ATOL = 2e-5
+# (ts, C, W, H, n, seed, svec, opaque): examples 1 500-example hunts on the MI355X found beyond rtol 1e-3 + 1e-6 (round 5: 8.7e-6) and
+# beyond rtol 1e-3 + 1e-5 (round 6: a 194 x 1 image of 2 002 opaque image-sized splats, SH degree 3 -- d cov2d 1.12e-5 beyond the
+# relative part, every run alike; 2.3e-6 on the emulator, whose exp and reciprocal are exact where the GPU's are 1 ulp off)
+KNOWN_WORST = [(8, 1, 10, 35, 1258, 2, 0.2, True), (8, 4, 194, 1, 2002, 4518, 0.2, True)]
 
 
 def other_tile_size_chain(L, ts, C, W, H, sync=lambda: None, rtol=1e-4, n=300, seed=None, svec=0.07, opaque=False, atol=0.0, ftol=1e-5):
@@ -19,9 +21,9 @@ def other_tile_size_chain(L, ts, C, W, H, sync=lambda: None, rtol=1e-4, n=300, s
     scene; opaque: every opacity at 0.999 (above the 0.99 clamp: lists end early, T crosses the stop threshold).
     Gradients: |got - want| <= rtol * max|want| + atol (atol for the fuzz: a one-pixel image of opaque, image-sized
     splats has gradients of 1e-5 behind (final - prefix) / (1 - 0.99), i.e. rounding noise of 1e-7 amplified 100 x.
-    FUZZ_ATOL = 1e-5 is that floor: fp32 epsilon 6e-8 x an O(1) colour x 1 / (1 - 0.99); long random hunts -- 1 500
-    examples per fuzz, round 5 -- found tiny-gradient scenes where 1e-6 was exceeded by exactly this term, 8.7e-6 at
-    most: KNOWN_WORST below, rerun by every suite).
+    FUZZ_ATOL = 2e-5 is that floor: fp32 epsilon 6e-8 x an O(1) colour (up to ~3 behind a degree-3 SH sum) x 1 / (1 - 0.99); long
+    random hunts -- 1 500 examples per fuzz, rounds 5 and 6 -- found tiny-gradient scenes where 1e-6 was exceeded by exactly this term,
+    8.7e-6 and 1.12e-5 at most: KNOWN_WORST above, rerun by every suite).
     ftol: forward tolerance (1e-5 on the fixed scenes; the fuzz takes north_star's 1e-4: a transmittance within rounding
     of the stop threshold lets one side composite one splat more, which weighs up to 1e-4).  When the ORACLE's own
     decision margins say that an SH pixel sits within a few ulps of a threshold (oracle.sh_decision_margin), the SH
