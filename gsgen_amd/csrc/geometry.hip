@@ -463,13 +463,14 @@ __device__ __forceinline__ void moments_to_grads_sh(const float *__restrict__ co
 // Gaussians, the four partial sums meet in LDS and wavefront 0 writes.  One thread per Gaussian looping over all views (rounds
 // 1-5) left a 100 k-Gaussian launch at 1.5 wavefronts per SIMD, each running eight dependent fp64 chains back to back: 43 us per
 // 8 views on MI355X once the chain went to fp64 -- four times the wavefronts, a quarter of the serial work each.
-constexpr int kPbvGauss = 64, kPbvLanes = kThreads / kPbvGauss;
-__global__ void __launch_bounds__(kThreads)
+constexpr int kPbvThreads = 128;  // (round 6, in flight: 64 / 128 / 256 threads measured -- profiles/r06_notes.md section 20)
+constexpr int kPbvGauss = 64, kPbvLanes = kPbvThreads / kPbvGauss;
+__global__ void __launch_bounds__(kPbvThreads)
 k_project_bwd_views(uint32_t N, const float *__restrict__ mean, const float *__restrict__ qvec,
                     const float *__restrict__ svec, ProjBwdViews pv, int n_views, int detach_depth, int accumulate,
                     int moments, float *__restrict__ g_mean, float *__restrict__ g_qvec, float *__restrict__ g_svec,
                     float *__restrict__ g_color, float *__restrict__ stat_accum, float *__restrict__ stat_cnt) {
-  __shared__ float part[kPbvLanes - 1][15][kPbvGauss];  // the other view lanes' partial sums, [component][Gaussian]: conflict-free
+  __shared__ float part[kPbvLanes > 1 ? kPbvLanes - 1 : 1][15][kPbvGauss];  // the other view lanes' partial sums, [component][Gaussian]: conflict-free
   const int gl = (int)(threadIdx.x & (kPbvGauss - 1)), vq = (int)(threadIdx.x / kPbvGauss);
   const uint32_t n = blockIdx.x * kPbvGauss + gl;
   const bool live = n < N;
@@ -688,7 +689,8 @@ struct GeoViewPack { GeoView v[kViewPack]; };
 // zero-filled by ALL workgroups of the launch together (grid-stride over the launch's threads) -- with the per-view targets of
 // GeoView this replaces the caller's fill kernel between forward and backward (38.8 MB per 8-view step at cfg2: a launch of its
 // own in every step's chain).
-__global__ void __launch_bounds__(kThreads)
+constexpr int kFrameThreads = 256;  // (workgroup of the batched projection: 64 / 128 / 256 measured in flight, profiles/r06_notes.md section 20)
+__global__ void __launch_bounds__(kFrameThreads)
 k_frame_project_views(uint32_t N, const float *__restrict__ mean, const float *__restrict__ qvec,
                       const float *__restrict__ svec, int w, int h, int ntw, GeoViewPack pack, GeoView *__restrict__ dst,
                       float4 *__restrict__ z_shared, uint32_t z_quads) {
@@ -906,7 +908,7 @@ static int project_bwd_batch(uint32_t n_views, uint32_t N, const float *mean, co
       pv.cov2d[i] = cov2d ? cov2d[v0 + i] : nullptr;
       pv.chol[i] = chol ? chol[v0 + i] : nullptr;
     }
-    hipLaunchKernelGGL(k_project_bwd_views, dim3((N + kPbvGauss - 1) / kPbvGauss), dim3(kThreads), 0, (hipStream_t)stream, N, mean, qvec,
+    hipLaunchKernelGGL(k_project_bwd_views, dim3((N + kPbvGauss - 1) / kPbvGauss), dim3(kPbvThreads), 0, (hipStream_t)stream, N, mean, qvec,
                        svec, pv, (int)nv, detach_depth, v0 ? 1 : 0, cov2d ? moments_form : 0, g_mean, g_qvec, g_svec, g_color,
                        stat_accum, stat_cnt);
     v0 += nv;
@@ -1157,13 +1159,13 @@ int gsgen_internal_frame_project_views(uint32_t N, const float *mean, const floa
                                        int w, int h, int ntw, const GeoView *host_views, GeoView *dev_views,
                                        uint32_t B, float *zero_shared, size_t zero_shared_floats, gsgen_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
-  const uint32_t gx = N ? grid_for(N).x : 1u;  // (N == 0: one workgroup per view, for the table alone)
+  const uint32_t gx = N ? (N + (uint32_t)kFrameThreads - 1u) / (uint32_t)kFrameThreads : 1u;  // (N == 0: one workgroup per view, for the table alone)
   for (uint32_t b0 = 0; b0 < B; b0 += kViewPack) {
     GeoViewPack pack{};
     const uint32_t n = (B - b0) < (uint32_t)kViewPack ? (B - b0) : (uint32_t)kViewPack;
     for (uint32_t i = 0; i < n; ++i) pack.v[i] = host_views[b0 + i];
     // (the shared block is zeroed by the first launch of the batch; zero_shared_floats is a multiple of 4, checked by the caller)
-    hipLaunchKernelGGL(k_frame_project_views, dim3(gx, n), dim3(kThreads), 0, s, N, mean, qvec, svec, w, h, ntw, pack,
+    hipLaunchKernelGGL(k_frame_project_views, dim3(gx, n), dim3(kFrameThreads), 0, s, N, mean, qvec, svec, w, h, ntw, pack,
                        dev_views + b0, b0 == 0 ? reinterpret_cast<float4 *>(zero_shared) : (float4 *)nullptr,
                        (uint32_t)(zero_shared_floats / 4));
   }
