@@ -1267,3 +1267,50 @@ def test_captured_step_replays_other_poses_and_intrinsics(use_ext):
     for o in list(outs) + list(outs2):
         assert torch.isfinite(o).all()
     assert float((outs2[2] > 0.5).float().mean()) > 0.2  # (opacity: the near views are mostly covered)
+
+
+@pytest.mark.gpu
+def test_device_cameras_renderer_renders_what_the_default_one_does():
+    """BatchRenderer(device_cameras=True) outside any capture: camera rows and pixel sizes reach the kernels through device memory
+    instead of kernel arguments -- SH degree 3 (pixel sizes still in the view tables), post-activation RGB and RGB + heads batches give the
+    default renderer's images bit for bit and its gradients to atomics' order, also when a second batch with other intrinsics follows
+    on the same renderer (the device block is rewritten, nothing stale is read)."""
+    from gsgen_amd import renderer as R
+    from gsgen_amd import batch as Bm
+    sc = scenes.random_scene(4000, seed=77, svec=0.04, C=4)
+    N, W, H, B = sc["mean"].shape[0], 144, 96, 3
+    batches = [[scenes.Camera(W, H, fx=f, c2w=scenes.orbit(r_, el, az)) for f, r_, el, az in row] for row in (
+        ((200.0, 2.4, 10, 30), (260.0, 2.2, 35, 150), (180.0, 2.6, -5, 260)), ((320.0, 2.0, 50, -40), (150.0, 2.8, 0, 90), (240.0, 2.3, 20, 200)))]
+    col = np.ascontiguousarray(1 / (1 + np.exp(-sc["sh"][:, :, 0])), np.float32)  # some post-activation colour
+    gen = torch.Generator(device=dev()).manual_seed(3)
+    go3, go1 = torch.randn(B, H, W, 3, device=dev(), generator=gen), torch.randn(B, H, W, 1, device=dev(), generator=gen)
+
+    def run(device_cameras):
+        res = []
+        br = Bm.BatchRenderer(N, W, H, dev(), max_batch=B, device_cameras=device_cameras)
+        for cams in batches:
+            cis, c2ws = [R.CameraInfo(*c.intr) for c in cams], [c.c2w for c in cams]
+            P_ = {k: T_(sc[k]).requires_grad_(True) for k in ("mean", "qvec", "svec", "alpha", "sh")}
+            c_ = T_(col).requires_grad_(True)
+            for kind in ("sh", "rgb", "heads"):
+                for q in list(P_.values()) + [c_]:
+                    q.grad = None
+                if kind == "sh":
+                    outs = br.render(P_["mean"], P_["qvec"], P_["svec"], P_["alpha"], P_["sh"], cis, c2ws, C=4)[:1]
+                    gos = [go3]
+                elif kind == "rgb":
+                    outs = br.render(P_["mean"], P_["qvec"], P_["svec"], P_["alpha"], c_, cis, c2ws, C=0)[:1]
+                    gos = [go3]
+                else:
+                    outs = br.render_heads(P_["mean"], P_["qvec"], P_["svec"], P_["alpha"], c_, cis, c2ws)[:4]
+                    gos = [go3, go1, go1, go1]
+                torch.autograd.backward(list(outs), gos)
+                torch.cuda.synchronize()
+                res.append(([o.detach().cpu().numpy() for o in outs], P_["mean"].grad.cpu().numpy().copy(), P_["svec"].grad.cpu().numpy().copy()))
+        return res
+
+    want, got = run(False), run(True)
+    for (wo, wm, ws), (go_, gm, gs) in zip(want, got):
+        for a, b in zip(wo, go_):
+            assert np.array_equal(a, b) and np.abs(a).max() > 0
+        assert rel_err(gm, wm) <= 1e-4 and rel_err(gs, ws) <= 1e-4
