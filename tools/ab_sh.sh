@@ -2,7 +2,8 @@
 tag=$1; rounds=$2; shift 2
 mkdir -p gpurun_out; out=gpurun_out/${tag}_ab_sh.txt; : > $out
 for r in $(seq 1 $rounds); do
-  for v in "$@"; do
+  order=("$@"); if [ $((r % 2)) -eq 0 ]; then order=(); for ((i=$#; i>=1; i--)); do order+=("${!i}"); done; fi  # (even rounds in reverse: on some boxes the later run of a pair is the slower one)
+  for v in "${order[@]}"; do
     if [ "$v" = "-" ]; then envs=""; else envs="GSGEN_HIP_LIB=$v"; fi
     env $envs timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-surface --no-latency --no-heads --no-other-configs $AB_ARGS 2>/dev/null | python -c "
 import sys,json
